@@ -1,0 +1,80 @@
+"""Synthetic read sets for the SdBG-construction benchmarks.
+
+Genome = i.i.d. uniform ACGT; PE fragments: start ~ U[0, G-frag), read 1 = forward `read_len`
+bases at start, read 2 = reverse complement of the `read_len` bases ending at start+frag;
+substitution errors i.i.d. with probability `err`, replaced by a uniformly different base.
+Reads are written straight into the reference's read-library format
+(`<prefix>.lib_info` + `<prefix>.bin`, reference src/sequence/io/sequence_lib.cpp:84-90 and
+src/sequence/sequence_package.h:224-240): per read `uint32 len` + ceil(len/16) uint32 words,
+base j in bits 31-2j..30-2j of word j/16, forward orientation.
+"""
+import numpy as np
+
+
+def pack_reads(bases):
+    """bases: uint8 [n, L] in 0..3 -> uint32 [n, ceil(L/16)] MSB-first."""
+    n, L = bases.shape
+    nw = (L + 15) // 16
+    pad = np.zeros((n, nw * 16), dtype=np.uint32)
+    pad[:, :L] = bases
+    pad = pad.reshape(n, nw, 16)
+    shifts = (30 - 2 * np.arange(16, dtype=np.uint32)).astype(np.uint32)
+    return (pad << shifts).sum(axis=2, dtype=np.uint64).astype(np.uint32)
+
+
+def gen_pe_reads(n_pairs, genome_len, read_len=150, frag=400, err=0.005, seed=1, genome=None):
+    """-> uint8 [2*n_pairs, read_len] (reads interleaved r1,r2,r1,r2...)."""
+    rng = np.random.default_rng(seed)
+    if genome is None:
+        genome = rng.integers(0, 4, size=genome_len, dtype=np.uint8)
+    start = rng.integers(0, genome_len - frag, size=n_pairs)
+    idx = np.arange(read_len)
+    r1 = genome[start[:, None] + idx[None, :]]
+    r2 = 3 - genome[(start + frag - 1)[:, None] - idx[None, :]]
+    reads = np.empty((2 * n_pairs, read_len), dtype=np.uint8)
+    reads[0::2] = r1
+    reads[1::2] = r2
+    if err > 0:
+        mask = rng.random(reads.shape) < err
+        delta = rng.integers(1, 4, size=int(mask.sum()), dtype=np.uint8)
+        reads[mask] = (reads[mask] + delta) & 3
+    return reads
+
+
+def write_read_lib(prefix, reads_list, description="synthetic", paired=True):
+    """reads_list: list of uint8 arrays [n_i, L_i] (one block per fixed length) or list of 1-D arrays."""
+    total_bases = 0
+    total_reads = 0
+    max_len = 0
+    with open(prefix + ".bin", "wb") as f:
+        for block in reads_list:
+            if isinstance(block, np.ndarray) and block.ndim == 2:
+                n, L = block.shape
+                packed = pack_reads(block)
+                rec = np.empty((n, 1 + packed.shape[1]), dtype=np.uint32)
+                rec[:, 0] = L
+                rec[:, 1:] = packed
+                rec.tofile(f)
+                total_bases += n * L
+                total_reads += n
+                max_len = max(max_len, L)
+            else:
+                for r in block:
+                    r = np.asarray(r, dtype=np.uint8)
+                    L = len(r)
+                    np.array([L], dtype=np.uint32).tofile(f)
+                    if L:
+                        pack_reads(r[None, :])[0].tofile(f)
+                    total_bases += L
+                    total_reads += 1
+                    max_len = max(max_len, L)
+    with open(prefix + ".lib_info", "w") as f:
+        f.write("%d %d\n%s\n0 %d %d %d\n" % (total_bases, total_reads, description, total_reads, max_len, int(paired)))
+    return total_reads, total_bases
+
+
+def write_fasta(path, reads):
+    lut = np.frombuffer(b"ACGT", dtype=np.uint8)
+    with open(path, "w") as f:
+        for i, r in enumerate(reads):
+            f.write(">r%d\n%s\n" % (i, lut[np.asarray(r)].tobytes().decode()))
