@@ -1,0 +1,172 @@
+/*
+ * mhx.h — C ABI of libmhx.so: MI355X-native SdBG construction (MEGAHIT's `count`,
+ * `read2sdbg`, `seq2sdbg` hot path) as hand-written HIP kernels for gfx950.
+ *
+ * The reference (voutcn/megahit v1.2.9) has no FFI for this path; its seams are
+ *   B1  the CLI  `megahit_core count|read2sdbg|seq2sdbg`  (src/main_sdbg_build.cpp:35-224),
+ *   B2  the engine template method BaseSequenceSortingEngine::Run + six virtuals
+ *       (src/sorting/base_engine.h:221-233,256),
+ *   B3  the sort functor SelectSortingFunc (src/sorting/kmsort_selector.h:7).
+ * Each entry point below names the reference interface it replaces.  The product CLI
+ * (megahit_amd/csrc/host/mhx_core.cpp) sits on exactly these symbols and keeps B1's flags
+ * and on-disk formats, so `megahit` (the Python orchestrator) and `megahit_core assemble`
+ * consume the output unchanged.
+ *
+ * Conventions: plain C, opaque handle, int status (0 = ok, <0 = error, text via
+ * mhx_last_error()), no exceptions cross the boundary, the caller owns every host buffer,
+ * the library owns device memory.  One handle drives one GPU and one HIP stream; it is not
+ * thread-safe (use one handle per thread).  All integers little-endian native.
+ *
+ * Packed sequences: uint32 words, base i of the concatenation of all sequences lives in word
+ * i/16 at bits 31-2(i%16)..30-2(i%16) (A,C,G,T = 0..3), no padding between sequences — the
+ * layout of SequencePackage (reference src/sequence/sequence_package.h:38-320).
+ */
+#ifndef MHX_H
+#define MHX_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MHX_NUM_BUCKETS 65536 /* reference src/sorting/base_engine.h:21 */
+#define MHX_MAX_MUL 65535     /* reference src/sdbg/sdbg_def.h:12 */
+#define MHX_MAX_K 255         /* reference src/sdbg/sdbg_def.h:20 */
+
+typedef struct mhx_ctx mhx_ctx;
+
+/* ---- lifetime / errors ---- */
+const char *mhx_last_error(void);
+const char *mhx_version(void);
+/* number of visible HIP devices, <0 on error */
+int mhx_device_count(void);
+/* device: HIP ordinal.  Fails (returns NULL, message in mhx_last_error) when no GPU / no
+ * gfx950 code object is usable — there is no CPU fallback. */
+mhx_ctx *mhx_create(int device);
+void mhx_destroy(mhx_ctx *);
+/* release cached device workspaces (they are otherwise kept between calls) */
+int mhx_trim(mhx_ctx *);
+int mhx_synchronize(mhx_ctx *);
+
+/* ---- sequence store (replaces SeqPackage held by each engine:
+ *      kmer_counter.h:76, read_to_sdbg.h:47-51, seq_to_sdbg.h:79) ---- */
+/* Upload a packed sequence set.  start_pos has n_seqs+1 entries (base offsets; start_pos[0]=0)
+ * or is NULL when every sequence has fixed_len bases.  For `count`/`read2sdbg` the reads must
+ * already be REVERSED as the reference does at load time (binary_reader.h:41-45). */
+int mhx_load_sequences(mhx_ctx *, const uint32_t *packed, uint64_t n_words, uint64_t n_seqs,
+                       uint32_t fixed_len, const uint64_t *start_pos);
+/* Same, but from the forward-orientation `.bin` record stream of a read library
+ * (uint32 len + ceil(len/16) words per read, sequence_package.h:224-240): reversal and
+ * concatenation happen on the GPU (replaces BinaryReader::Read + AppendReversedCompactSequence). */
+int mhx_load_bin_records(mhx_ctx *, const uint32_t *records, uint64_t n_words, uint64_t n_seqs,
+                         int reverse);
+/* per-sequence multiplicities for seq2sdbg (seq_to_sdbg.h:80) */
+int mhx_load_multiplicity(mhx_ctx *, const uint16_t *mult, uint64_t n_seqs);
+uint64_t mhx_num_sequences(const mhx_ctx *);
+uint64_t mhx_num_bases(const mhx_ctx *);
+
+/* ---- result buffers (device resident until fetched) ---- */
+enum mhx_buffer {
+  MHX_BUF_EDGES = 1,        /* uint32[n_edges][words_per_edge], bucket order (edge_writer.h:69-80) */
+  MHX_BUF_BUCKET_COUNT = 2, /* uint64[65536]: edges (count) or SdBG items (s2/seq2sdbg) per bucket */
+  MHX_BUF_FIRST_0_OUT = 3,  /* uint32[n_reads]   (kmer_counter.h:78) */
+  MHX_BUF_LAST_0_IN = 4,    /* uint32[n_reads]   (kmer_counter.h:79) */
+  MHX_BUF_MUL_HIST = 5,     /* int64[65536]      (edge_counter.h:14-56) */
+  MHX_BUF_IS_SOLID = 6,     /* uint64[ceil(n_bases/64)] (AtomicBitVector, kmbitvector.h:67-88) */
+  MHX_BUF_MERCY_CAND = 7,   /* int64[n_mercy_cand], sorted ascending (read_to_sdbg_s1.cpp:466-551) */
+  MHX_BUF_SDBG_BYTES = 8,   /* uint8[sdbg_bytes]: bucket byte streams, bucket-id order (sdbg_writer.cpp:38-57) */
+  MHX_BUF_BUCKET_OFFSET = 9,/* uint64[65536] starting byte of each bucket in MHX_BUF_SDBG_BYTES */
+  MHX_BUF_BUCKET_TIPS = 10, /* uint64[65536] */
+  MHX_BUF_BUCKET_LARGE = 11,/* uint64[65536] */
+  MHX_BUF_SORTED_ITEMS = 12,/* uint32[n_items][item_words]: the sorted lv2 items of the last engine (tests) */
+  MHX_BUF_W_COUNT = 13      /* uint64[9] + ones_in_last: uint64[10] (sdbg_meta.h:41-48) */
+};
+/* bytes currently held in a result buffer (0 if absent) */
+uint64_t mhx_buffer_bytes(const mhx_ctx *, int which);
+/* copy [offset, offset+bytes) of a result buffer to host memory */
+int mhx_fetch(mhx_ctx *, int which, void *dst, uint64_t offset, uint64_t bytes);
+
+/* ---- engines ---- */
+typedef struct {
+  uint64_t n_items;        /* items sorted = sum max(0, len-k) */
+  uint64_t n_distinct;     /* distinct (k+1)-mers */
+  uint64_t n_edges;        /* solid edges emitted */
+  uint32_t words_per_edge; /* ceil((2(k+1)+16)/32), edge_writer.h:37-40 */
+  uint32_t item_words;     /* stride of MHX_BUF_SORTED_ITEMS */
+} mhx_count_result;
+/* KmerCounter::Run (kmer_counter.cpp:60-414 under base_engine.cpp:143-211).
+ * Fills EDGES, BUCKET_COUNT, FIRST_0_OUT, LAST_0_IN, MUL_HIST. */
+int mhx_count(mhx_ctx *, uint32_t k, uint32_t min_count, mhx_count_result *out);
+
+typedef struct {
+  uint64_t n_items;      /* (k-1)-mer items sorted */
+  uint64_t n_solid;      /* solid (k+1)-mer occurrences marked */
+  uint64_t n_mercy_cand; /* 0 unless want_mercy */
+  uint32_t item_words;
+} mhx_s1_result;
+/* Read2SdbgS1::Run (read_to_sdbg_s1.cpp:88-566).  Fills IS_SOLID, MUL_HIST and, when
+ * want_mercy != 0, MERCY_CAND.  Tie order between equal keys is the stable one
+ * (first item = first in read order); see DESIGN.md "H1". */
+int mhx_read2sdbg_s1(mhx_ctx *, uint32_t k, uint32_t min_count, int want_mercy, mhx_s1_result *out);
+
+/* mercy block of Read2SdbgS2::Initialize (read_to_sdbg_s2.cpp:122-266): consumes MERCY_CAND,
+ * sets extra IS_SOLID bits on the device copy; *num_mercy receives "Number mercy". */
+int mhx_read2sdbg_add_mercy(mhx_ctx *, uint32_t k, uint64_t *num_mercy);
+/* replace the device IS_SOLID bitmap (e.g. one produced elsewhere); n_words = ceil(n_bases/64) */
+int mhx_set_is_solid(mhx_ctx *, const uint64_t *bits, uint64_t n_words);
+
+typedef struct {
+  uint64_t n_items;    /* lv2 items sorted */
+  uint64_t n_sdbg;     /* SdBG records emitted */
+  uint64_t n_tips;     /* $-tips */
+  uint64_t n_large;    /* records with multiplicity > 254 */
+  uint64_t sdbg_bytes; /* size of MHX_BUF_SDBG_BYTES */
+  uint32_t words_per_tip_label;
+  uint32_t item_words;
+} mhx_sdbg_result;
+/* Read2SdbgS2::Run minus the mercy block (read_to_sdbg_s2.cpp:271-630).  Uses IS_SOLID unless
+ * min_count == 1 (for_sure_solid, read_to_sdbg_s2.cpp:295).  Fills SDBG_BYTES, BUCKET_*. */
+int mhx_read2sdbg_s2(mhx_ctx *, uint32_t k, uint32_t min_count, mhx_sdbg_result *out);
+/* SeqToSdbg::Run minus input parsing (seq_to_sdbg.cpp:530-807) on the loaded sequences +
+ * multiplicities.  Fills SDBG_BYTES, BUCKET_*. */
+int mhx_seq2sdbg(mhx_ctx *, uint32_t k, mhx_sdbg_result *out);
+
+/* SeqToSdbg::GenMercyEdges (seq_to_sdbg.cpp:171-357): the loaded sequences must be the sorted
+ * (k+1)-mer edges; cand = candidate reads (packed, start_pos as in mhx_load_sequences).  Appends
+ * the mercy edges (multiplicity 1) to the loaded set; *n_mercy receives their number. */
+int mhx_gen_mercy_edges(mhx_ctx *, uint32_t k, const uint32_t *cand_packed, uint64_t cand_words,
+                        uint64_t n_cand, const uint64_t *cand_start, uint64_t *n_mercy);
+
+/* B3: sort n fixed-width records in place on the GPU, ascending by the first key_words words
+ * (lexicographic on uint32, as Substr::operator<, kmsort_selector.cpp:18-27); aux words ride
+ * along.  Replaces SelectSortingFunc(key_words, aux_words) (kmsort_selector.cpp:61-63).  Stable. */
+int mhx_sort_records(mhx_ctx *, uint32_t *host_items, uint64_t n, uint32_t key_words, uint32_t aux_words);
+
+/* ---- multi-GPU: the lv1 buckets are partitioned over `n_parts` owners.
+ * With a partition set, engines keep only items whose bucket belongs to `my_part`
+ * (the reference's OffsetFiller::IsHandling filter, base_engine.h:106-108) unless an item
+ * exchange is installed with mhx_set_exchange. ---- */
+int mhx_set_partition(mhx_ctx *, int my_part, int n_parts, const uint32_t *bucket_begin /* n_parts+1 */);
+/* all-to-all of device buffers: send_counts/recv_counts in bytes per peer; implemented by the
+ * caller on its communication backend (RCCL through torch.distributed in megahit_amd/dist.py). */
+typedef int (*mhx_exchange_fn)(void *user, const void *d_send, const uint64_t *send_bytes,
+                               void *d_recv, const uint64_t *recv_bytes, int n_parts);
+int mhx_set_exchange(mhx_ctx *, mhx_exchange_fn fn, void *user);
+
+/* ---- measurement ---- */
+typedef struct {
+  char name[48];
+  uint32_t launches;
+  double total_ms;     /* HIP-event time on the engine's stream */
+  double algo_bytes;   /* algorithmic bytes moved by those launches */
+} mhx_kernel_stat;
+int mhx_profile_enable(mhx_ctx *, int on);
+int mhx_profile_reset(mhx_ctx *);
+/* returns number of distinct kernels; fills up to cap entries */
+int mhx_profile_get(mhx_ctx *, mhx_kernel_stat *out, int cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

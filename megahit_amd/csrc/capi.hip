@@ -1,0 +1,456 @@
+// C-ABI entry points of libmhx.so (declared in include/mhx.h) and context plumbing.
+#include <cstdarg>
+
+#include "dev_prims.h"
+#include "mhx_internal.h"
+
+namespace mhx {
+
+static thread_local char g_err[1024] = "";
+
+void set_error(const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof g_err, fmt, ap);
+  va_end(ap);
+}
+
+void DevBuf::reserve(size_t bytes) {
+  if (bytes == 0) bytes = 16;
+  if (cap >= bytes && p) return;
+  if (p && cap) (void)hipFree(p);
+  p = nullptr;
+  cap = 0;
+  // grow with a little headroom so that repeated calls with slightly different sizes do not re-allocate
+  size_t want = bytes + bytes / 16 + 256;
+  hipError_t e = hipMalloc(&p, want);
+  if (e != hipSuccess) {
+    want = bytes;
+    e = hipMalloc(&p, want);
+  }
+  if (e != hipSuccess) {
+    p = nullptr;
+    char b[256];
+    snprintf(b, sizeof b, "hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
+    throw Error(b);
+  }
+  cap = want;
+}
+void DevBuf::release() {
+  if (p && cap) (void)hipFree(p);
+  p = nullptr;
+  cap = used = 0;
+}
+
+}  // namespace mhx
+
+void mhx_ctx::prof_begin(const char *name, double bytes) {
+  if (!profiling) return;
+  hipEvent_t a, b;
+  if (event_pool.size() >= 2) {
+    a = event_pool.back(); event_pool.pop_back();
+    b = event_pool.back(); event_pool.pop_back();
+  } else {
+    MHX_HIP(hipEventCreate(&a));
+    MHX_HIP(hipEventCreate(&b));
+  }
+  MHX_HIP(hipEventRecord(a, stream));
+  pending.push_back({name, a, b, bytes});
+}
+void mhx_ctx::prof_end() {
+  if (!profiling) return;
+  MHX_HIP(hipEventRecord(pending.back().b, stream));
+  if (pending.size() > 4096) prof_collect();
+}
+void mhx_ctx::prof_collect() {
+  if (pending.empty()) return;
+  MHX_HIP(hipStreamSynchronize(stream));
+  for (auto &pe : pending) {
+    float ms = 0;
+    MHX_HIP(hipEventElapsedTime(&ms, pe.a, pe.b));
+    mhx::KernelStat &ks = stats[pe.name];
+    ks.launches++;
+    ks.ms += ms;
+    ks.bytes += pe.bytes;
+    event_pool.push_back(pe.a);
+    event_pool.push_back(pe.b);
+  }
+  pending.clear();
+}
+
+namespace mhx {
+
+// ---- sequence upload -------------------------------------------------------
+__global__ void k_fixed_starts(uint64_t *start, uint64_t n_seqs, uint32_t fixed_len) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i <= n_seqs) start[i] = i * fixed_len;
+}
+
+constexpr size_t kSeqPadWords = 64;
+
+void upload_sequences(mhx_ctx *c, const uint32_t *packed, uint64_t n_words, uint64_t n_seqs, uint32_t fixed_len,
+                      const uint64_t *start_pos) {
+  SeqSet &s = c->seqs;
+  hipStream_t st = c->stream;
+  s.n_seqs = n_seqs;
+  s.fixed_len = start_pos ? 0 : fixed_len;
+  s.n_words = n_words;
+  s.words.reserve((n_words + kSeqPadWords) * 4);
+  s.start.reserve((n_seqs + 2) * 8);
+  if (n_words) MHX_HIP(hipMemcpyAsync(s.words.p, packed, n_words * 4, hipMemcpyHostToDevice, st));
+  MHX_HIP(hipMemsetAsync(s.words.as<uint32_t>() + n_words, 0, kSeqPadWords * 4, st));
+  if (start_pos) {
+    MHX_HIP(hipMemcpyAsync(s.start.p, start_pos, (n_seqs + 1) * 8, hipMemcpyHostToDevice, st));
+    s.n_bases = start_pos[n_seqs];
+    uint32_t mx = 0;
+    for (uint64_t i = 0; i < n_seqs; ++i) {
+      uint64_t L = start_pos[i + 1] - start_pos[i];
+      if (L > mx) mx = (uint32_t)L;
+    }
+    s.max_len = mx;
+  } else {
+    hipLaunchKernelGGL(k_fixed_starts, dim3((unsigned)div_ceil(n_seqs + 1, 256)), dim3(256), 0, st, s.start.as<uint64_t>(), n_seqs,
+                       fixed_len);
+    MHX_HIP(hipGetLastError());
+    s.n_bases = n_seqs * (uint64_t)fixed_len;
+    s.max_len = fixed_len;
+  }
+  if (s.n_bases > n_words * 16) throw Error("load_sequences: start_pos/n_seqs exceed the packed buffer");
+  s.mult.used = 0;
+  MHX_HIP(hipStreamSynchronize(st));
+}
+
+// .bin record stream -> (reversed) concatenated store, on the GPU.
+// Host walks the record headers (one uint32 per read) to get lengths; bases are moved by a kernel.
+__global__ void k_unpack_records(const uint32_t *__restrict__ rec, const uint64_t *__restrict__ rec_off, const uint64_t *__restrict__ start,
+                                 uint64_t n_seqs, int reverse, uint32_t *__restrict__ out_words, uint64_t n_out_words) {
+  // one thread per OUTPUT word: gathers its 16 bases (no atomics, coalesced stores)
+  const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= n_out_words) return;
+  const uint64_t b0 = w * 16;
+  // sequence containing base b0
+  uint64_t lo = 0, hi = n_seqs;
+  while (hi - lo > 1) {
+    uint64_t mid = (lo + hi) >> 1;
+    if (start[mid] <= b0) lo = mid;
+    else hi = mid;
+  }
+  uint64_t sid = lo;
+  uint32_t word = 0;
+  const uint64_t total = start[n_seqs];
+  for (int j = 0; j < 16; ++j) {
+    const uint64_t b = b0 + j;
+    if (b >= total) break;
+    while (b >= start[sid + 1]) ++sid;
+    const uint64_t L = start[sid + 1] - start[sid];
+    uint64_t off = b - start[sid];
+    if (reverse) off = L - 1 - off;
+    const uint32_t *r = rec + rec_off[sid] + 1;  // skip the length word
+    const unsigned ch = (r[off >> 4] >> (30 - 2 * (unsigned)(off & 15))) & 3u;
+    word |= ch << (30 - 2 * j);
+  }
+  out_words[w] = word;
+}
+
+void upload_bin_records(mhx_ctx *c, const uint32_t *records, uint64_t n_words, uint64_t n_seqs, int reverse) {
+  // lengths (host): an empty read becomes a 1-base 'A' (sequence_package.h:275-281)
+  std::vector<uint64_t> rec_off(n_seqs + 1), start(n_seqs + 1);
+  uint64_t pos = 0, bases = 0;
+  uint32_t mx = 0;
+  static const uint32_t kFake[2] = {1u, 0u};
+  bool has_empty = false;
+  for (uint64_t i = 0; i < n_seqs; ++i) {
+    if (pos >= n_words) throw Error("load_bin_records: truncated record stream");
+    uint32_t L = records[pos];
+    rec_off[i] = pos;
+    start[i] = bases;
+    pos += 1 + (L + 15) / 16;
+    if (L == 0) { has_empty = true; L = 1; }
+    bases += L;
+    if (L > mx) mx = L;
+  }
+  if (pos > n_words) throw Error("load_bin_records: truncated record stream");
+  start[n_seqs] = bases;
+  (void)kFake;
+  hipStream_t st = c->stream;
+  SeqSet &s = c->seqs;
+  // an empty read's record has no payload word: give it one zero word by copying records with a pad
+  std::vector<uint32_t> patched;
+  const uint32_t *src = records;
+  uint64_t src_words = n_words;
+  if (has_empty) {
+    patched.reserve(n_words + 1024);
+    uint64_t p2 = 0;
+    for (uint64_t i = 0; i < n_seqs; ++i) {
+      uint32_t L = records[rec_off[i]];
+      uint64_t nw = (L + 15) / 16;
+      uint64_t new_off = patched.size();
+      patched.push_back(L ? L : 1u);
+      if (L == 0) patched.push_back(0u);
+      else patched.insert(patched.end(), records + rec_off[i] + 1, records + rec_off[i] + 1 + nw);
+      rec_off[i] = new_off;
+      (void)p2;
+    }
+    src = patched.data();
+    src_words = patched.size();
+  }
+  DevBuf &d_rec = c->ws("bin_records", (src_words + 4) * 4);
+  DevBuf &d_off = c->ws("bin_rec_off", (n_seqs + 1) * 8);
+  const uint64_t n_out_words = div_ceil(bases, 16);
+  s.words.reserve((n_out_words + kSeqPadWords) * 4);
+  s.start.reserve((n_seqs + 2) * 8);
+  MHX_HIP(hipMemcpyAsync(d_rec.p, src, src_words * 4, hipMemcpyHostToDevice, st));
+  MHX_HIP(hipMemcpyAsync(d_off.p, rec_off.data(), (n_seqs + 1) * 8, hipMemcpyHostToDevice, st));
+  MHX_HIP(hipMemcpyAsync(s.start.p, start.data(), (n_seqs + 1) * 8, hipMemcpyHostToDevice, st));
+  MHX_HIP(hipMemsetAsync(s.words.as<uint32_t>() + n_out_words, 0, kSeqPadWords * 4, st));
+  if (n_out_words) {
+    MHX_LAUNCH(c, "unpack_records", (double)src_words * 4 + (double)n_out_words * 4,
+               hipLaunchKernelGGL(k_unpack_records, dim3((unsigned)div_ceil(n_out_words, 256)), dim3(256), 0, st, d_rec.as<uint32_t>(),
+                                  d_off.as<uint64_t>(), s.start.as<uint64_t>(), n_seqs, reverse, s.words.as<uint32_t>(), n_out_words));
+  }
+  MHX_HIP(hipStreamSynchronize(st));
+  s.n_seqs = n_seqs;
+  s.n_bases = bases;
+  s.n_words = n_out_words;
+  s.max_len = mx;
+  s.fixed_len = 0;
+  // fixed-length fast path when every read has the same length
+  if (n_seqs && bases == (uint64_t)mx * n_seqs) s.fixed_len = mx;
+  s.mult.used = 0;
+}
+
+}  // namespace mhx
+
+// ---------------------------------------------------------------------------
+#define MHX_TRY(...)                          \
+  try {                                       \
+    __VA_ARGS__;                              \
+    return 0;                                 \
+  } catch (const std::exception &e) {         \
+    mhx::set_error("%s", e.what());           \
+    return -1;                                \
+  }
+
+extern "C" {
+
+const char *mhx_last_error(void) { return mhx::g_err; }
+const char *mhx_version(void) { return "mhx 0.1 (gfx950)"; }
+
+int mhx_device_count(void) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) {
+    mhx::set_error("hipGetDeviceCount: %s", hipGetErrorString(e));
+    return -1;
+  }
+  return n;
+}
+
+mhx_ctx *mhx_create(int device) {
+  try {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) throw mhx::Error("no HIP device available (libmhx has no CPU fallback)");
+    if (device < 0 || device >= n) throw mhx::Error("invalid device ordinal");
+    MHX_HIP(hipSetDevice(device));
+    mhx_ctx *c = new mhx_ctx();
+    c->device = device;
+    MHX_HIP(hipStreamCreate(&c->stream));
+    return c;
+  } catch (const std::exception &e) {
+    mhx::set_error("%s", e.what());
+    return nullptr;
+  }
+}
+
+int mhx_trim(mhx_ctx *c) {
+  MHX_TRY({
+    MHX_HIP(hipStreamSynchronize(c->stream));
+    for (auto &kv : c->work) kv.second.release();
+    c->work.clear();
+    // the sorted-items view aliases a workspace
+    auto it = c->results.find(MHX_BUF_SORTED_ITEMS);
+    if (it != c->results.end()) c->results.erase(it);
+  })
+}
+
+void mhx_destroy(mhx_ctx *c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  for (auto &kv : c->work) kv.second.release();
+  for (auto &kv : c->results) kv.second.release();
+  c->seqs.words.release();
+  c->seqs.start.release();
+  c->seqs.mult.release();
+  for (auto &pe : c->pending) {
+    (void)hipEventDestroy(pe.a);
+    (void)hipEventDestroy(pe.b);
+  }
+  for (auto ev : c->event_pool) (void)hipEventDestroy(ev);
+  (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+int mhx_synchronize(mhx_ctx *c) { MHX_TRY(MHX_HIP(hipStreamSynchronize(c->stream))) }
+
+int mhx_load_sequences(mhx_ctx *c, const uint32_t *packed, uint64_t n_words, uint64_t n_seqs, uint32_t fixed_len,
+                       const uint64_t *start_pos) {
+  MHX_TRY({
+    MHX_HIP(hipSetDevice(c->device));
+    mhx::upload_sequences(c, packed, n_words, n_seqs, fixed_len, start_pos);
+  })
+}
+int mhx_load_bin_records(mhx_ctx *c, const uint32_t *records, uint64_t n_words, uint64_t n_seqs, int reverse) {
+  MHX_TRY({
+    MHX_HIP(hipSetDevice(c->device));
+    mhx::upload_bin_records(c, records, n_words, n_seqs, reverse);
+  })
+}
+int mhx_load_multiplicity(mhx_ctx *c, const uint16_t *mult, uint64_t n_seqs) {
+  MHX_TRY({
+    if (n_seqs != c->seqs.n_seqs) throw mhx::Error("load_multiplicity: n_seqs differs from the loaded sequence set");
+    c->seqs.mult.reserve((n_seqs + 1) * 2);
+    c->seqs.mult.used = n_seqs * 2;
+    if (n_seqs) MHX_HIP(hipMemcpyAsync(c->seqs.mult.p, mult, n_seqs * 2, hipMemcpyHostToDevice, c->stream));
+    MHX_HIP(hipStreamSynchronize(c->stream));
+  })
+}
+uint64_t mhx_num_sequences(const mhx_ctx *c) { return c->seqs.n_seqs; }
+uint64_t mhx_num_bases(const mhx_ctx *c) { return c->seqs.n_bases; }
+
+uint64_t mhx_buffer_bytes(const mhx_ctx *c, int which) {
+  auto it = c->results.find(which);
+  return it == c->results.end() ? 0 : it->second.used;
+}
+int mhx_fetch(mhx_ctx *c, int which, void *dst, uint64_t offset, uint64_t bytes) {
+  MHX_TRY({
+    auto it = c->results.find(which);
+    if (it == c->results.end() || !it->second.p) throw mhx::Error("fetch: buffer not present");
+    if (offset + bytes > it->second.used) throw mhx::Error("fetch: range exceeds buffer");
+    if (bytes) {
+      MHX_HIP(hipMemcpyAsync(dst, (const char *)it->second.p + offset, bytes, hipMemcpyDeviceToHost, c->stream));
+      MHX_HIP(hipStreamSynchronize(c->stream));
+    }
+  })
+}
+
+int mhx_count(mhx_ctx *c, uint32_t k, uint32_t min_count, mhx_count_result *out) {
+  MHX_TRY({
+    MHX_HIP(hipSetDevice(c->device));
+    mhx::run_count(c, k, min_count, out);
+  })
+}
+int mhx_read2sdbg_s1(mhx_ctx *c, uint32_t k, uint32_t min_count, int want_mercy, mhx_s1_result *out) {
+  MHX_TRY({
+    MHX_HIP(hipSetDevice(c->device));
+    mhx::run_s1(c, k, min_count, want_mercy, out);
+  })
+}
+int mhx_read2sdbg_add_mercy(mhx_ctx *c, uint32_t k, uint64_t *num_mercy) {
+  MHX_TRY({
+    MHX_HIP(hipSetDevice(c->device));
+    mhx::run_s1_mercy(c, k, num_mercy);
+  })
+}
+int mhx_set_is_solid(mhx_ctx *c, const uint64_t *bits, uint64_t n_words) {
+  MHX_TRY({
+    uint64_t need = mhx::div_ceil(c->seqs.n_bases, 64);
+    if (n_words < need) throw mhx::Error("set_is_solid: bitmap too short");
+    mhx::DevBuf &b = c->result(MHX_BUF_IS_SOLID, (need + 1) * 8);
+    b.used = need * 8;
+    if (need) MHX_HIP(hipMemcpyAsync(b.p, bits, need * 8, hipMemcpyHostToDevice, c->stream));
+    MHX_HIP(hipStreamSynchronize(c->stream));
+  })
+}
+int mhx_read2sdbg_s2(mhx_ctx *c, uint32_t k, uint32_t min_count, mhx_sdbg_result *out) {
+  MHX_TRY({
+    MHX_HIP(hipSetDevice(c->device));
+    mhx::run_s2(c, k, min_count, out);
+  })
+}
+int mhx_seq2sdbg(mhx_ctx *c, uint32_t k, mhx_sdbg_result *out) {
+  MHX_TRY({
+    MHX_HIP(hipSetDevice(c->device));
+    mhx::run_seq2sdbg(c, k, out);
+  })
+}
+int mhx_gen_mercy_edges(mhx_ctx *c, uint32_t k, const uint32_t *cand_packed, uint64_t cand_words, uint64_t n_cand,
+                        const uint64_t *cand_start, uint64_t *n_mercy) {
+  MHX_TRY({
+    MHX_HIP(hipSetDevice(c->device));
+    mhx::run_gen_mercy(c, k, cand_packed, cand_words, n_cand, cand_start, n_mercy);
+  })
+}
+
+int mhx_sort_records(mhx_ctx *c, uint32_t *host_items, uint64_t n, uint32_t key_words, uint32_t aux_words) {
+  MHX_TRY({
+    MHX_HIP(hipSetDevice(c->device));
+    const int w = (int)(key_words + aux_words), S = mhx::round_up2(w);
+    if (key_words == 0 || S > 20) throw mhx::Error("sort_records: unsupported record width");
+    if (n == 0) return 0;
+    uint32_t *a = c->ws("items_a", n * S * 4 + 64).as<uint32_t>();
+    uint32_t *b = c->ws("items_b", n * S * 4 + 64).as<uint32_t>();
+    if (S == w) {
+      MHX_HIP(hipMemcpyAsync(a, host_items, n * w * 4, hipMemcpyHostToDevice, c->stream));
+    } else {
+      MHX_HIP(hipMemsetAsync(a, 0, n * S * 4, c->stream));
+      MHX_HIP(hipMemcpy2DAsync(a, S * 4, host_items, w * 4, w * 4, n, hipMemcpyHostToDevice, c->stream));
+    }
+    uint32_t *r = mhx::radix_sort(c, a, b, n, S, (int)key_words, mhx::make_passes((int)key_words, 0, (int)key_words * 32));
+    if (S == w) MHX_HIP(hipMemcpyAsync(host_items, r, n * w * 4, hipMemcpyDeviceToHost, c->stream));
+    else MHX_HIP(hipMemcpy2DAsync(host_items, w * 4, r, S * 4, w * 4, n, hipMemcpyDeviceToHost, c->stream));
+    MHX_HIP(hipStreamSynchronize(c->stream));
+  })
+}
+
+int mhx_set_partition(mhx_ctx *c, int my_part, int n_parts, const uint32_t *bucket_begin) {
+  MHX_TRY({
+    if (n_parts < 1 || my_part < 0 || my_part >= n_parts) throw mhx::Error("set_partition: bad arguments");
+    c->my_part = my_part;
+    c->n_parts = n_parts;
+    c->part_begin.assign(bucket_begin, bucket_begin + n_parts + 1);
+    if (c->part_begin.front() != 0 || c->part_begin.back() != MHX_NUM_BUCKETS)
+      throw mhx::Error("set_partition: bucket_begin must start at 0 and end at 65536");
+  })
+}
+int mhx_set_exchange(mhx_ctx *c, mhx_exchange_fn fn, void *user) {
+  c->exchange = fn;
+  c->exchange_user = user;
+  return 0;
+}
+
+int mhx_profile_enable(mhx_ctx *c, int on) {
+  MHX_TRY({
+    if (!on) c->prof_collect();
+    c->profiling = on != 0;
+  })
+}
+int mhx_profile_reset(mhx_ctx *c) {
+  MHX_TRY({
+    c->prof_collect();
+    c->stats.clear();
+  })
+}
+int mhx_profile_get(mhx_ctx *c, mhx_kernel_stat *out, int cap) {
+  try {
+    c->prof_collect();
+    int i = 0;
+    for (auto &kv : c->stats) {
+      if (i < cap) {
+        memset(&out[i], 0, sizeof(out[i]));
+        strncpy(out[i].name, kv.first.c_str(), sizeof(out[i].name) - 1);
+        out[i].launches = kv.second.launches;
+        out[i].total_ms = kv.second.ms;
+        out[i].algo_bytes = kv.second.bytes;
+      }
+      ++i;
+    }
+    return i;
+  } catch (const std::exception &e) {
+    mhx::set_error("%s", e.what());
+    return -1;
+  }
+}
+
+}  // extern "C"

@@ -1,0 +1,257 @@
+// `count` engine: replaces KmerCounter (reference src/sorting/kmer_counter.cpp) on the GPU.
+//
+//   extract     one lv2 item per (k+1)-mer occurrence, straight from the packed reads
+//               (Lv1FillOffsets :158-206 + Lv2ExtractSubString :208-252 fused; no lv1 offsets)
+//   radix sort  by the 2(k+1) key bits (sort.hip)  -> bucket order falls out of the key order
+//   runs        heads of equal-key runs (scan.hip)
+//   reduce      per run: multiplicity, prev/next counts, first_0_out / last_0_in atomics,
+//               multiplicity histogram  (Lv2Postprocess :254-381)
+//   emit        packed solid edges + per-bucket counts (PackEdge :32-52, EdgeWriter::Write)
+#include "dev_prims.h"
+#include "mhx_internal.h"
+
+namespace mhx {
+
+// ---------------------------------------------------------------------------
+__global__ void k_seq_item_counts(const uint64_t *__restrict__ start, uint64_t n_seqs, uint32_t sub, uint32_t min_len,
+                                  uint32_t *__restrict__ cnt) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_seqs) {
+    uint64_t L = start[i + 1] - start[i];
+    cnt[i] = L >= min_len ? (uint32_t)(L - sub) : 0u;
+  }
+}
+
+template <int KW, int S>
+__global__ __launch_bounds__(256) void k_count_extract(const uint32_t *__restrict__ seq, const uint64_t *__restrict__ start,
+                                                       const uint64_t *__restrict__ item_start, uint64_t n_seqs, int k,
+                                                       uint32_t *__restrict__ items) {
+  const int lane = lane_id();
+  const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / kWave;
+  const uint64_t n_waves = (uint64_t)gridDim.x * blockDim.x / kWave;
+  for (uint64_t r = wave; r < n_seqs; r += n_waves) {
+    const uint64_t st = start[r];
+    const uint32_t L = (uint32_t)(start[r + 1] - st);
+    if (L < (uint32_t)k + 1) continue;
+    const uint64_t ibase = item_start[r];
+    for (uint32_t p = lane; p + k < L; p += kWave) {
+      uint32_t e[KW], rc[KW];
+      load_chars<KW>(seq, st + p, k + 1, e);
+      rc_chars<KW>(e, k + 1, rc);
+      const int strand = cmp_words<KW>(rc, e) < 0;  // rev_edge.cmp(edge) < 0, kmer_counter.cpp:179
+      unsigned prev = p > 0 ? base_at(seq, st + p - 1) : kSentinel;
+      unsigned next = p + k + 1 < L ? base_at(seq, st + p + k + 1) : kSentinel;
+      const uint64_t full = ((st + p) << 1) | (uint64_t)strand;
+      uint64_t info;
+      uint32_t out[S];
+      if (!strand) {
+#pragma unroll
+        for (int i = 0; i < KW; ++i) out[i] = e[i];
+        info = (full << 6) | (prev << 3) | next;
+      } else {
+#pragma unroll
+        for (int i = 0; i < KW; ++i) out[i] = rc[i];
+        info = (full << 6) | (comp_or_sentinel(next) << 3) | comp_or_sentinel(prev);
+      }
+      out[KW] = (uint32_t)(info >> 32);
+      out[KW + 1] = (uint32_t)info;
+      if constexpr (S > KW + 2) out[KW + 2] = 0;
+      uint32_t *dst = items + (ibase + p) * S;
+      if constexpr (S % 4 == 0) {
+#pragma unroll
+        for (int i = 0; i < S / 4; ++i)
+          reinterpret_cast<uint4 *>(dst)[i] = make_uint4(out[4 * i], out[4 * i + 1], out[4 * i + 2], out[4 * i + 3]);
+      } else {
+#pragma unroll
+        for (int i = 0; i < S / 2; ++i) reinterpret_cast<uint2 *>(dst)[i] = make_uint2(out[2 * i], out[2 * i + 1]);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+constexpr int kLocalHist = 1024;
+
+__global__ __launch_bounds__(256) void k_count_runs(const uint32_t *__restrict__ items, uint64_t n, int stride, int kw,
+                                                    const uint64_t *__restrict__ heads, uint64_t n_runs, uint32_t m,
+                                                    const uint64_t *__restrict__ start, uint64_t n_seqs, uint32_t fixed_len,
+                                                    uint32_t *__restrict__ run_count, uint32_t *__restrict__ solid_flag,
+                                                    uint32_t *__restrict__ first_0_out, uint32_t *__restrict__ last_0_in_p1,
+                                                    unsigned long long *__restrict__ hist) {
+  __shared__ uint32_t lh[kLocalHist];
+  for (int i = threadIdx.x; i < kLocalHist; i += blockDim.x) lh[i] = 0;
+  __syncthreads();
+  const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < n_runs) {
+    const uint64_t b = heads[r], e = (r + 1 < n_runs) ? heads[r + 1] : n;
+    const uint64_t count = e - b;
+    uint32_t cp[4] = {0, 0, 0, 0}, cn[4] = {0, 0, 0, 0};
+    for (uint64_t j = b; j < e; ++j) {
+      const unsigned pn = items[j * stride + kw + 1] & 63u;
+      const unsigned pv = pn >> 3, nx = pn & 7;
+#pragma unroll
+      for (int x = 0; x < 4; ++x) {
+        cp[x] += (pv == (unsigned)x);
+        cn[x] += (nx == (unsigned)x);
+      }
+    }
+    bool has_in = false, has_out = false;
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+      has_in |= cp[x] >= m;
+      has_out |= cn[x] >= m;
+    }
+    const bool solid = count >= m;
+    if (solid && (!has_in || !has_out)) {
+      for (uint64_t j = b; j < e; ++j) {
+        const uint64_t info = (((uint64_t)items[j * stride + kw] << 32) | items[j * stride + kw + 1]) >> 6;
+        const uint64_t abs = info >> 1;
+        const unsigned strand = (unsigned)(info & 1);
+        const uint64_t rid = seq_of_offset(start, n_seqs, fixed_len, abs);
+        const uint32_t off = (uint32_t)(abs - start[rid]);
+        // !has_in: strand 0 -> last_0_in = max(off), strand 1 -> first_0_out = min(off+1)   (:307-337)
+        // !has_out: the roles swap                                                             (:339-368)
+        if (!has_in) {
+          if (strand == 0) atomicMax(&last_0_in_p1[rid], off + 1);
+          else atomicMin(&first_0_out[rid], off + 1);
+        }
+        if (!has_out) {
+          if (strand == 0) atomicMin(&first_0_out[rid], off + 1);
+          else atomicMax(&last_0_in_p1[rid], off + 1);
+        }
+      }
+    }
+    run_count[r] = count > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)count;
+    solid_flag[r] = solid ? 1u : 0u;
+    const uint64_t hb = count > MHX_MAX_MUL ? MHX_MAX_MUL : count;
+    if (hb < kLocalHist) atomicAdd(&lh[hb], 1u);
+    else atomicAdd(&hist[hb], 1ull);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < kLocalHist; i += blockDim.x)
+    if (lh[i]) atomicAdd(&hist[i], (unsigned long long)lh[i]);
+}
+
+__global__ void k_count_emit(const uint32_t *__restrict__ items, int stride, int kw, const uint64_t *__restrict__ heads, uint64_t n_runs,
+                             const uint32_t *__restrict__ run_count, const uint32_t *__restrict__ solid_flag,
+                             const uint64_t *__restrict__ pos, int wpe, uint32_t *__restrict__ edges,
+                             unsigned long long *__restrict__ bucket_count) {
+  const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n_runs || !solid_flag[r]) return;
+  const uint32_t *it = items + heads[r] * stride;
+  uint32_t *ed = edges + pos[r] * wpe;
+  for (int x = 0; x < wpe; ++x) ed[x] = x < kw ? it[x] : 0u;
+  const uint32_t c = run_count[r];
+  ed[wpe - 1] |= c > MHX_MAX_MUL ? (uint32_t)MHX_MAX_MUL : c;
+  atomicAdd(&bucket_count[it[0] >> 16], 1ull);
+}
+
+__global__ void k_fix_last(uint32_t *__restrict__ last_p1, uint64_t n) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) last_p1[i] = last_p1[i] - 1u;  // 0 (unset) -> 0xFFFFFFFF sentinel, v+1 -> v
+}
+
+// ---------------------------------------------------------------------------
+int run_count(mhx_ctx *c, uint32_t k, uint32_t m, mhx_count_result *out) {
+  SeqSet &s = c->seqs;
+  if (k < 9 || k > MHX_MAX_K) throw Error("count: k out of range [9,255]");
+  const int KWv = (int)div_ceil((k + 1) * 2, 32);
+  const int S = round_up2(KWv + 2);
+  const int wpe = (int)div_ceil((k + 1) * 2 + 16, 32);
+  const uint64_t ns = s.n_seqs;
+  hipStream_t st = c->stream;
+
+  // per-read item counts -> item_start
+  uint32_t *cnt = c->ws("seq_item_cnt", (ns + 1) * 4).as<uint32_t>();
+  uint64_t *item_start = c->ws("seq_item_start", (ns + 2) * 8).as<uint64_t>();
+  uint64_t *d_total = item_start + ns + 1;
+  uint64_t n_items = 0;
+  if (ns) {
+    MHX_LAUNCH(c, "item_counts", (double)ns * 12,
+               hipLaunchKernelGGL(k_seq_item_counts, dim3((unsigned)div_ceil(ns, 256)), dim3(256), 0, st, s.start.as<uint64_t>(), ns, k,
+                                  k + 1, cnt));
+    exclusive_scan_u32_u64(c, cnt, item_start, ns, d_total);
+    MHX_HIP(hipMemcpyAsync(&n_items, d_total, 8, hipMemcpyDeviceToHost, st));
+    MHX_HIP(hipStreamSynchronize(st));
+  }
+
+  const size_t item_bytes = (size_t)S * 4;
+  uint32_t *buf_a = c->ws("items_a", n_items * item_bytes + 64).as<uint32_t>();
+  uint32_t *buf_b = c->ws("items_b", n_items * item_bytes + 64).as<uint32_t>();
+  if (n_items) {
+    const unsigned grid = 256 * 8;
+    MHX_DISPATCH_KW(KWv, {
+      if (S == KW + 2)
+        MHX_LAUNCH(c, "count_extract", (double)n_items * item_bytes + (double)s.n_bases / 4,
+                   hipLaunchKernelGGL((k_count_extract<KW, KW + 2>), dim3(grid), dim3(256), 0, st, s.words.as<uint32_t>(),
+                                      s.start.as<uint64_t>(), item_start, ns, (int)k, buf_a));
+      else
+        MHX_LAUNCH(c, "count_extract", (double)n_items * item_bytes + (double)s.n_bases / 4,
+                   hipLaunchKernelGGL((k_count_extract<KW, KW + 3>), dim3(grid), dim3(256), 0, st, s.words.as<uint32_t>(),
+                                      s.start.as<uint64_t>(), item_start, ns, (int)k, buf_a));
+    });
+  }
+  const int key_bits = (int)(k + 1) * 2;
+  uint32_t *sorted = radix_sort(c, buf_a, buf_b, n_items, S, KWv, make_passes(KWv, KWv * 32 - key_bits, KWv * 32));
+
+  // results
+  uint32_t *first = c->result(MHX_BUF_FIRST_0_OUT, (ns ? ns : 1) * 4).as<uint32_t>();
+  uint32_t *last = c->result(MHX_BUF_LAST_0_IN, (ns ? ns : 1) * 4).as<uint32_t>();
+  c->results[MHX_BUF_FIRST_0_OUT].used = ns * 4;
+  c->results[MHX_BUF_LAST_0_IN].used = ns * 4;
+  unsigned long long *hist = c->result(MHX_BUF_MUL_HIST, (MHX_MAX_MUL + 1) * 8).as<unsigned long long>();
+  unsigned long long *bcount = c->result(MHX_BUF_BUCKET_COUNT, MHX_NUM_BUCKETS * 8).as<unsigned long long>();
+  MHX_HIP(hipMemsetAsync(first, 0xFF, (ns ? ns : 1) * 4, st));
+  MHX_HIP(hipMemsetAsync(last, 0x00, (ns ? ns : 1) * 4, st));
+  MHX_HIP(hipMemsetAsync(hist, 0, (MHX_MAX_MUL + 1) * 8, st));
+  MHX_HIP(hipMemsetAsync(bcount, 0, MHX_NUM_BUCKETS * 8, st));
+
+  const uint64_t n_runs = count_group_heads(c, sorted, n_items, S, key_bits);
+  uint64_t n_edges = 0;
+  if (n_runs) {
+    uint64_t *heads = c->ws("heads", n_runs * 8).as<uint64_t>();
+    find_group_heads(c, sorted, n_items, S, key_bits, heads, nullptr);
+    uint32_t *run_count_d = c->ws("run_count", n_runs * 4).as<uint32_t>();
+    uint32_t *solid = c->ws("run_solid", n_runs * 4).as<uint32_t>();
+    uint64_t *pos = c->ws("run_pos", (n_runs + 1) * 8).as<uint64_t>();
+    const unsigned grid = (unsigned)div_ceil(n_runs, 256);
+    MHX_LAUNCH(c, "count_runs", (double)n_items * item_bytes + (double)n_runs * 16,
+               hipLaunchKernelGGL(k_count_runs, dim3(grid), dim3(256), 0, st, sorted, n_items, S, KWv, heads, n_runs, m,
+                                  s.start.as<uint64_t>(), ns, s.fixed_len, run_count_d, solid, first, last, hist));
+    exclusive_scan_u32_u64(c, solid, pos, n_runs, pos + n_runs);
+    MHX_HIP(hipMemcpyAsync(&n_edges, pos + n_runs, 8, hipMemcpyDeviceToHost, st));
+    MHX_HIP(hipStreamSynchronize(st));
+    uint32_t *edges = c->result(MHX_BUF_EDGES, (n_edges ? n_edges : 1) * wpe * 4).as<uint32_t>();
+    c->results[MHX_BUF_EDGES].used = n_edges * wpe * 4;
+    MHX_LAUNCH(c, "count_emit", (double)n_runs * 24 + (double)n_edges * (wpe * 4 + item_bytes),
+               hipLaunchKernelGGL(k_count_emit, dim3(grid), dim3(256), 0, st, sorted, S, KWv, heads, n_runs, run_count_d, solid, pos, wpe,
+                                  edges, bcount));
+  } else {
+    c->result(MHX_BUF_EDGES, 4);
+    c->results[MHX_BUF_EDGES].used = 0;
+  }
+  if (ns)
+    MHX_LAUNCH(c, "fix_last", (double)ns * 8,
+               hipLaunchKernelGGL(k_fix_last, dim3((unsigned)div_ceil(ns, 256)), dim3(256), 0, st, last, ns));
+
+  // expose the sorted items for tests (no copy: alias the workspace)
+  mhx::DevBuf &si = c->results[MHX_BUF_SORTED_ITEMS];
+  si.release();
+  c->sorted_item_words = S;
+  c->work["sorted_alias"].p = nullptr;  // marker only
+  c->results[MHX_BUF_SORTED_ITEMS].p = sorted;
+  c->results[MHX_BUF_SORTED_ITEMS].cap = 0;  // cap 0 = not owned
+  c->results[MHX_BUF_SORTED_ITEMS].used = n_items * item_bytes;
+
+  MHX_HIP(hipStreamSynchronize(st));
+  if (out) {
+    out->n_items = n_items;
+    out->n_distinct = n_runs;
+    out->n_edges = n_edges;
+    out->words_per_edge = wpe;
+    out->item_words = S;
+  }
+  return 0;
+}
+
+}  // namespace mhx

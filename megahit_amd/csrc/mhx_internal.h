@@ -1,0 +1,149 @@
+// Internal host-side declarations of libmhx (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/mhx.h"
+
+namespace mhx {
+
+void set_error(const char *fmt, ...);
+
+struct Error : std::runtime_error {
+  explicit Error(const std::string &s) : std::runtime_error(s) {}
+};
+
+#define MHX_HIP(expr)                                                                          \
+  do {                                                                                         \
+    hipError_t e_ = (expr);                                                                    \
+    if (e_ != hipSuccess) {                                                                    \
+      char buf_[512];                                                                          \
+      snprintf(buf_, sizeof buf_, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, \
+               __LINE__);                                                                      \
+      throw mhx::Error(buf_);                                                                  \
+    }                                                                                          \
+  } while (0)
+
+// A grow-only device allocation that is kept between engine calls.
+struct DevBuf {
+  void *p = nullptr;
+  size_t cap = 0;   // bytes allocated
+  size_t used = 0;  // bytes holding valid data (for result buffers)
+  void reserve(size_t bytes);
+  void release();
+  template <class T>
+  T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+struct KernelStat {
+  uint32_t launches = 0;
+  double ms = 0, bytes = 0;
+};
+
+struct PendingEvent {
+  const char *name;
+  hipEvent_t a, b;
+  double bytes;
+};
+
+// device-resident packed sequence set
+struct SeqSet {
+  DevBuf words;      // uint32, padded with >= 32 zero words
+  DevBuf start;      // uint64[n_seqs+1] (always materialised on device)
+  DevBuf mult;       // uint16[n_seqs]
+  uint64_t n_seqs = 0, n_bases = 0, n_words = 0;
+  uint32_t fixed_len = 0, max_len = 0;
+  std::vector<uint64_t> h_start;  // host copy when variable length (small path helpers)
+};
+
+}  // namespace mhx
+
+struct mhx_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  mhx::SeqSet seqs;
+  std::map<int, mhx::DevBuf> results;      // keyed by enum mhx_buffer
+  std::map<std::string, mhx::DevBuf> work; // named scratch workspaces
+  uint32_t sorted_item_words = 0;
+  // partition
+  int my_part = 0, n_parts = 1;
+  std::vector<uint32_t> part_begin;
+  mhx_exchange_fn exchange = nullptr;
+  void *exchange_user = nullptr;
+  // profiling
+  bool profiling = false;
+  std::vector<mhx::PendingEvent> pending;
+  std::vector<hipEvent_t> event_pool;
+  std::map<std::string, mhx::KernelStat> stats;
+
+  mhx::DevBuf &ws(const char *name, size_t bytes) {
+    mhx::DevBuf &b = work[name];
+    b.reserve(bytes);
+    return b;
+  }
+  mhx::DevBuf &result(int which, size_t bytes) {
+    mhx::DevBuf &b = results[which];
+    b.reserve(bytes);
+    b.used = bytes;
+    return b;
+  }
+  void prof_begin(const char *name, double bytes);
+  void prof_end();
+  void prof_collect();
+};
+
+// Launch wrapper: records a HIP-event pair around the launch when profiling is on.
+#define MHX_LAUNCH(ctx, name, bytes, ...) \
+  do {                                    \
+    (ctx)->prof_begin(name, bytes);       \
+    __VA_ARGS__;                          \
+    MHX_HIP(hipGetLastError());           \
+    (ctx)->prof_end();                    \
+  } while (0)
+
+namespace mhx {
+
+// ---- sort.hip ----
+struct SortPass {
+  int shift;  // bit offset from the LSB of the big-endian key (key_words*32 bits)
+  int bits;   // <= 8
+};
+// Sorts n items of `stride` uint32 words held in buf_a (ping-pong with buf_b) by the digit passes
+// (least-significant pass first).  Returns the buffer holding the result.
+uint32_t *radix_sort(mhx_ctx *c, uint32_t *buf_a, uint32_t *buf_b, uint64_t n, int stride, int key_words,
+                     const std::vector<SortPass> &passes);
+std::vector<SortPass> make_passes(int key_words, int lo_bit, int hi_bit);
+
+// ---- scan.hip ----
+// exclusive scan of n uint32 values into uint64 (in != out); returns total via d_total (device, uint64[1])
+void exclusive_scan_u32_u64(mhx_ctx *c, const uint32_t *in, uint64_t *out, uint64_t n, uint64_t *d_total);
+void exclusive_scan_u64(mhx_ctx *c, const uint64_t *in, uint64_t *out, uint64_t n, uint64_t *d_total);
+// positions i in [0,n) where item i differs from item i-1 in the first `cmp_bits` bits of the key
+// (big-endian words), written ascending to heads[]; *d_count receives their number.
+void find_group_heads(mhx_ctx *c, const uint32_t *items, uint64_t n, int stride, int cmp_bits,
+                      uint64_t *heads, uint64_t *d_count);
+uint64_t count_group_heads(mhx_ctx *c, const uint32_t *items, uint64_t n, int stride, int cmp_bits);
+
+// ---- engines ----
+int run_count(mhx_ctx *c, uint32_t k, uint32_t m, mhx_count_result *out);
+int run_s1(mhx_ctx *c, uint32_t k, uint32_t m, int want_mercy, mhx_s1_result *out);
+int run_s1_mercy(mhx_ctx *c, uint32_t k, uint64_t *num_mercy);
+int run_s2(mhx_ctx *c, uint32_t k, uint32_t m, mhx_sdbg_result *out);
+int run_seq2sdbg(mhx_ctx *c, uint32_t k, mhx_sdbg_result *out);
+int run_gen_mercy(mhx_ctx *c, uint32_t k, const uint32_t *cand_packed, uint64_t cand_words, uint64_t n_cand,
+                  const uint64_t *cand_start, uint64_t *n_mercy);
+void upload_sequences(mhx_ctx *c, const uint32_t *packed, uint64_t n_words, uint64_t n_seqs, uint32_t fixed_len,
+                      const uint64_t *start_pos);
+void upload_bin_records(mhx_ctx *c, const uint32_t *records, uint64_t n_words, uint64_t n_seqs, int reverse);
+
+inline int round_up2(int x) { return (x + 1) & ~1; }
+inline uint64_t div_ceil(uint64_t a, uint64_t b) { return (a + b - 1) / b; }
+
+}  // namespace mhx

@@ -1,0 +1,241 @@
+// LSD radix sort of fixed-width multi-word records (replaces kmlib::kmsort behind
+// SelectSortingFunc, reference src/sorting/kmsort_selector.cpp:39-63 / src/kmlib/kmsort.h:45-122).
+//
+// Device-wide, stable, 8-bit digits.  Per pass:
+//   radix_hist     per-chunk digit histogram (LDS per-wavefront histograms)      reads  n*S*4 B
+//   scan           exclusive scan of the digit-major chunk histograms            (small)
+//   radix_scatter  per tile: wavefront match-any ranking (ballot) -> LDS-staged
+//                  reorder by digit -> coalesced run writes                      reads+writes n*S*4 B
+// Records are AoS with a stride of S uint32 words (S even): a record is moved with
+// uint4/uint2 accesses, never word by word.  HBM-bound; no MFMA.
+#include "dev_prims.h"
+#include "mhx_internal.h"
+
+namespace mhx {
+
+constexpr int kSortThreads = 256;
+constexpr int kSortWaves = kSortThreads / kWave;
+constexpr int kTilesPerChunk = 4;
+
+template <int S>
+struct SortCfg {
+  // items per thread per tile, chosen so the LDS stage stays <= 64 KiB
+  static constexpr int kItems = (S <= 4) ? 16 : (S <= 8 ? 8 : (S <= 12 ? 5 : (S <= 16 ? 4 : 3)));
+  static constexpr int kTile = kSortThreads * kItems;
+  static constexpr int kChunk = kTile * kTilesPerChunk;
+};
+
+template <int S>
+struct Rec {
+  uint32_t w[S];
+};
+
+template <int S>
+__device__ __forceinline__ void load_rec(const uint32_t *__restrict__ p, Rec<S> &r) {
+  if constexpr (S % 4 == 0) {
+#pragma unroll
+    for (int i = 0; i < S / 4; ++i) {
+      uint4 v = reinterpret_cast<const uint4 *>(p)[i];
+      r.w[4 * i] = v.x; r.w[4 * i + 1] = v.y; r.w[4 * i + 2] = v.z; r.w[4 * i + 3] = v.w;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < S / 2; ++i) {
+      uint2 v = reinterpret_cast<const uint2 *>(p)[i];
+      r.w[2 * i] = v.x; r.w[2 * i + 1] = v.y;
+    }
+  }
+}
+template <int S>
+__device__ __forceinline__ void store_rec(uint32_t *__restrict__ p, const Rec<S> &r) {
+  if constexpr (S % 4 == 0) {
+#pragma unroll
+    for (int i = 0; i < S / 4; ++i)
+      reinterpret_cast<uint4 *>(p)[i] = make_uint4(r.w[4 * i], r.w[4 * i + 1], r.w[4 * i + 2], r.w[4 * i + 3]);
+  } else {
+#pragma unroll
+    for (int i = 0; i < S / 2; ++i) reinterpret_cast<uint2 *>(p)[i] = make_uint2(r.w[2 * i], r.w[2 * i + 1]);
+  }
+}
+
+// digit of a record held in registers: bits [bit, bit+nbits) of word wi (and wi-1 when straddling)
+template <int S>
+__device__ __forceinline__ unsigned rec_digit(const Rec<S> &r, int wi, unsigned bit, unsigned mask) {
+  uint32_t lo = 0, hi = 0;
+#pragma unroll
+  for (int i = 0; i < S; ++i) {
+    if (i == wi) lo = r.w[i];
+    if (i == wi - 1) hi = r.w[i];
+  }
+  uint64_t v = ((uint64_t)hi << 32) | lo;
+  return (unsigned)(v >> bit) & mask;
+}
+
+template <int S>
+__global__ __launch_bounds__(kSortThreads) void k_radix_hist(const uint32_t *__restrict__ items, uint64_t n, int wi, unsigned bit,
+                                                             unsigned mask, uint32_t *__restrict__ hist, uint64_t n_chunks) {
+  __shared__ uint32_t h[kSortWaves][256];
+  for (int i = threadIdx.x; i < kSortWaves * 256; i += kSortThreads) (&h[0][0])[i] = 0;
+  __syncthreads();
+  const int w = threadIdx.x / kWave;
+  const uint64_t base = (uint64_t)blockIdx.x * SortCfg<S>::kChunk;
+  const bool straddle = bit + (32 - __builtin_clz(mask)) > 32 && wi > 0;
+  for (int j = 0; j < SortCfg<S>::kChunk / kSortThreads; ++j) {
+    uint64_t idx = base + (uint64_t)j * kSortThreads + threadIdx.x;
+    if (idx < n) {
+      const uint32_t *p = items + idx * S;
+      uint64_t v = p[wi];
+      if (straddle) v |= (uint64_t)p[wi - 1] << 32;
+      atomicAdd(&h[w][(unsigned)(v >> bit) & mask], 1u);
+    }
+  }
+  __syncthreads();
+  {
+    const int d = threadIdx.x;  // kSortThreads == 256 digits
+    uint32_t s = 0;
+#pragma unroll
+    for (int i = 0; i < kSortWaves; ++i) s += h[i][d];
+    hist[(uint64_t)d * n_chunks + blockIdx.x] = s;
+  }
+}
+
+template <int S>
+__global__ __launch_bounds__(kSortThreads) void k_radix_scatter(const uint32_t *__restrict__ in, uint32_t *__restrict__ out, uint64_t n,
+                                                                int wi, unsigned bit, unsigned mask, int nbits,
+                                                                const uint64_t *__restrict__ offs, uint64_t n_chunks) {
+  using Cfg = SortCfg<S>;
+  constexpr int ITEMS = Cfg::kItems;
+  __shared__ __attribute__((aligned(16))) uint32_t stage[Cfg::kTile * S];
+  __shared__ uint32_t wave_cnt[kSortWaves][256];   // per-wave running digit counters, then wave bases
+  __shared__ long long g_off[256];                 // global position minus position in tile, per digit
+  __shared__ uint64_t g_base[256];                 // running global base per digit for this chunk
+  __shared__ uint32_t sm_scan[kSortThreads / kWave + 1];
+
+  const int tid = threadIdx.x, w = tid / kWave, lane = tid & (kWave - 1);
+  g_base[tid] = offs[(uint64_t)tid * n_chunks + blockIdx.x];
+  const uint64_t chunk_base = (uint64_t)blockIdx.x * Cfg::kChunk;
+  const uint64_t lanemask_lt = (1ull << lane) - 1;
+
+  for (int t = 0; t < kTilesPerChunk; ++t) {
+    const uint64_t tile_base = chunk_base + (uint64_t)t * Cfg::kTile;
+    if (tile_base >= n) break;
+    const uint64_t rem = n - tile_base;
+    const int tile_n = rem < (uint64_t)Cfg::kTile ? (int)rem : Cfg::kTile;
+#pragma unroll
+    for (int i = 0; i < kSortWaves; ++i) wave_cnt[i][tid] = 0;
+    __syncthreads();
+
+    Rec<S> rec[ITEMS];
+    uint32_t rank[ITEMS];
+    unsigned dig[ITEMS];
+    // wave-blocked striped arrangement: wave w owns [w*64*ITEMS, (w+1)*64*ITEMS) of the tile
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+      const int li = w * (kWave * ITEMS) + j * kWave + lane;
+      const bool valid = li < tile_n;
+      if (valid) load_rec<S>(in + (tile_base + li) * S, rec[j]);
+      unsigned d = valid ? rec_digit<S>(rec[j], wi, bit, mask) : 0u;
+      dig[j] = d;
+      // match-any over the digit bits
+      uint64_t peers = __ballot(valid);
+      for (int b = 0; b < nbits; ++b) {
+        const bool bitset = (d >> b) & 1u;
+        const uint64_t m = __ballot(bitset);
+        peers &= bitset ? m : ~m;
+      }
+      // every lane reads the running counter of its digit, then the lowest peer lane bumps it:
+      // LDS operations of one wavefront execute in program order, so the read precedes the write.
+      const uint32_t before = wave_cnt[w][d];
+      rank[j] = before + __builtin_popcountll(peers & lanemask_lt);
+      __builtin_amdgcn_wave_barrier();
+      if (valid && (peers & lanemask_lt) == 0) wave_cnt[w][d] = before + __builtin_popcountll(peers);
+      __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+    // thread d: turn per-wave totals into bases inside the tile
+    {
+      uint32_t c[kSortWaves], tot = 0;
+#pragma unroll
+      for (int i = 0; i < kSortWaves; ++i) {
+        c[i] = wave_cnt[i][tid];
+        tot += c[i];
+      }
+      uint32_t start = block_exclusive_sum<uint32_t, kSortThreads>(tot, sm_scan, nullptr);
+      uint32_t run = start;
+#pragma unroll
+      for (int i = 0; i < kSortWaves; ++i) {
+        wave_cnt[i][tid] = run;
+        run += c[i];
+      }
+      g_off[tid] = (long long)g_base[tid] - (long long)start;
+      g_base[tid] += tot;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+      const int li = w * (kWave * ITEMS) + j * kWave + lane;
+      if (li < tile_n) store_rec<S>(stage + (size_t)(wave_cnt[w][dig[j]] + rank[j]) * S, rec[j]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+      const int li = j * kSortThreads + tid;
+      if (li < tile_n) {
+        Rec<S> r;
+        load_rec<S>(stage + (size_t)li * S, r);
+        const unsigned d = rec_digit<S>(r, wi, bit, mask);
+        store_rec<S>(out + (uint64_t)(g_off[d] + li) * S, r);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+std::vector<SortPass> make_passes(int key_words, int lo_bit, int hi_bit) {
+  (void)key_words;
+  std::vector<SortPass> p;
+  for (int s = lo_bit; s < hi_bit; s += 8) p.push_back({s, std::min(8, hi_bit - s)});
+  return p;
+}
+
+template <int S>
+static uint32_t *radix_sort_impl(mhx_ctx *c, uint32_t *a, uint32_t *b, uint64_t n, int key_words,
+                                 const std::vector<SortPass> &passes) {
+  if (n == 0) return a;
+  const uint64_t n_chunks = div_ceil(n, SortCfg<S>::kChunk);
+  uint32_t *hist = c->ws("sort_hist", n_chunks * 256 * 4).as<uint32_t>();
+  uint64_t *offs = c->ws("sort_offs", n_chunks * 256 * 8).as<uint64_t>();
+  const double bytes = (double)n * S * 4;
+  for (const SortPass &ps : passes) {
+    const int wi = key_words - 1 - ps.shift / 32;
+    const unsigned bit = ps.shift % 32, mask = (1u << ps.bits) - 1;
+    MHX_LAUNCH(c, "radix_hist", bytes,
+               hipLaunchKernelGGL(k_radix_hist<S>, dim3((unsigned)n_chunks), dim3(kSortThreads), 0, c->stream, a, n, wi, bit, mask,
+                                  hist, n_chunks));
+    exclusive_scan_u32_u64(c, hist, offs, n_chunks * 256, nullptr);
+    MHX_LAUNCH(c, "radix_scatter", 2 * bytes,
+               hipLaunchKernelGGL(k_radix_scatter<S>, dim3((unsigned)n_chunks), dim3(kSortThreads), 0, c->stream, a, b, n, wi, bit,
+                                  mask, ps.bits, offs, n_chunks));
+    std::swap(a, b);
+  }
+  return a;
+}
+
+uint32_t *radix_sort(mhx_ctx *c, uint32_t *a, uint32_t *b, uint64_t n, int stride, int key_words,
+                     const std::vector<SortPass> &passes) {
+  switch (stride) {
+    case 2: return radix_sort_impl<2>(c, a, b, n, key_words, passes);
+    case 4: return radix_sort_impl<4>(c, a, b, n, key_words, passes);
+    case 6: return radix_sort_impl<6>(c, a, b, n, key_words, passes);
+    case 8: return radix_sort_impl<8>(c, a, b, n, key_words, passes);
+    case 10: return radix_sort_impl<10>(c, a, b, n, key_words, passes);
+    case 12: return radix_sort_impl<12>(c, a, b, n, key_words, passes);
+    case 14: return radix_sort_impl<14>(c, a, b, n, key_words, passes);
+    case 16: return radix_sort_impl<16>(c, a, b, n, key_words, passes);
+    case 18: return radix_sort_impl<18>(c, a, b, n, key_words, passes);
+    case 20: return radix_sort_impl<20>(c, a, b, n, key_words, passes);
+    default: throw Error("radix_sort: unsupported record stride");
+  }
+}
+
+}  // namespace mhx

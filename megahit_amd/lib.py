@@ -1,0 +1,234 @@
+"""ctypes binding of libmhx.so (C ABI in include/mhx.h).
+
+There is deliberately no fallback: if the HIP library is missing or no GPU is usable every
+call raises.  The oracle under oracle/ is test infrastructure and is never imported here.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmhx.so")
+
+NUM_BUCKETS = 65536
+MAX_MUL = 65535
+
+BUF_EDGES = 1
+BUF_BUCKET_COUNT = 2
+BUF_FIRST_0_OUT = 3
+BUF_LAST_0_IN = 4
+BUF_MUL_HIST = 5
+BUF_IS_SOLID = 6
+BUF_MERCY_CAND = 7
+BUF_SDBG_BYTES = 8
+BUF_BUCKET_OFFSET = 9
+BUF_BUCKET_TIPS = 10
+BUF_BUCKET_LARGE = 11
+BUF_SORTED_ITEMS = 12
+BUF_W_COUNT = 13
+
+
+class MhxError(RuntimeError):
+    pass
+
+
+class CountResult(C.Structure):
+    _fields_ = [("n_items", C.c_uint64), ("n_distinct", C.c_uint64), ("n_edges", C.c_uint64),
+                ("words_per_edge", C.c_uint32), ("item_words", C.c_uint32)]
+
+
+class S1Result(C.Structure):
+    _fields_ = [("n_items", C.c_uint64), ("n_solid", C.c_uint64), ("n_mercy_cand", C.c_uint64),
+                ("item_words", C.c_uint32)]
+
+
+class SdbgResult(C.Structure):
+    _fields_ = [("n_items", C.c_uint64), ("n_sdbg", C.c_uint64), ("n_tips", C.c_uint64), ("n_large", C.c_uint64),
+                ("sdbg_bytes", C.c_uint64), ("words_per_tip_label", C.c_uint32), ("item_words", C.c_uint32)]
+
+
+class KernelStat(C.Structure):
+    _fields_ = [("name", C.c_char * 48), ("launches", C.c_uint32), ("total_ms", C.c_double),
+                ("algo_bytes", C.c_double)]
+
+
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64), C.c_void_p,
+                          C.POINTER(C.c_uint64), C.c_int)
+
+# every symbol include/mhx.h declares: (restype, argtypes)
+_P = C.c_void_p
+SYMBOLS = {
+    "mhx_last_error": (C.c_char_p, []),
+    "mhx_version": (C.c_char_p, []),
+    "mhx_device_count": (C.c_int, []),
+    "mhx_create": (_P, [C.c_int]),
+    "mhx_destroy": (None, [_P]),
+    "mhx_trim": (C.c_int, [_P]),
+    "mhx_synchronize": (C.c_int, [_P]),
+    "mhx_load_sequences": (C.c_int, [_P, _P, C.c_uint64, C.c_uint64, C.c_uint32, _P]),
+    "mhx_load_bin_records": (C.c_int, [_P, _P, C.c_uint64, C.c_uint64, C.c_int]),
+    "mhx_load_multiplicity": (C.c_int, [_P, _P, C.c_uint64]),
+    "mhx_num_sequences": (C.c_uint64, [_P]),
+    "mhx_num_bases": (C.c_uint64, [_P]),
+    "mhx_buffer_bytes": (C.c_uint64, [_P, C.c_int]),
+    "mhx_fetch": (C.c_int, [_P, C.c_int, _P, C.c_uint64, C.c_uint64]),
+    "mhx_count": (C.c_int, [_P, C.c_uint32, C.c_uint32, C.POINTER(CountResult)]),
+    "mhx_read2sdbg_s1": (C.c_int, [_P, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(S1Result)]),
+    "mhx_read2sdbg_add_mercy": (C.c_int, [_P, C.c_uint32, C.POINTER(C.c_uint64)]),
+    "mhx_set_is_solid": (C.c_int, [_P, _P, C.c_uint64]),
+    "mhx_read2sdbg_s2": (C.c_int, [_P, C.c_uint32, C.c_uint32, C.POINTER(SdbgResult)]),
+    "mhx_seq2sdbg": (C.c_int, [_P, C.c_uint32, C.POINTER(SdbgResult)]),
+    "mhx_gen_mercy_edges": (C.c_int, [_P, C.c_uint32, _P, C.c_uint64, C.c_uint64, _P, C.POINTER(C.c_uint64)]),
+    "mhx_sort_records": (C.c_int, [_P, _P, C.c_uint64, C.c_uint32, C.c_uint32]),
+    "mhx_set_partition": (C.c_int, [_P, C.c_int, C.c_int, _P]),
+    "mhx_set_exchange": (C.c_int, [_P, EXCHANGE_FN, _P]),
+    "mhx_profile_enable": (C.c_int, [_P, C.c_int]),
+    "mhx_profile_reset": (C.c_int, [_P]),
+    "mhx_profile_get": (C.c_int, [_P, C.POINTER(KernelStat), C.c_int]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libmhx.so (no compute).  Raises MhxError if the HIP extension was not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise MhxError("%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(there is no CPU fallback)" % LIB_PATH)
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class Engine:
+    """One GPU, one HIP stream: mirrors the reference's engine objects (KmerCounter, Read2SdbgS1/S2,
+    SeqToSdbg — reference src/sorting/*.h) on top of the C ABI."""
+
+    def __init__(self, device=0):
+        self.lib = load()
+        self.h = self.lib.mhx_create(device)
+        if not self.h:
+            raise MhxError(self.lib.mhx_last_error().decode())
+
+    def close(self):
+        if self.h:
+            self.lib.mhx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise MhxError(self.lib.mhx_last_error().decode())
+
+    # ---- inputs
+    def load_sequences(self, packed, n_seqs, fixed_len=0, start_pos=None):
+        packed = np.ascontiguousarray(packed, dtype=np.uint32)
+        if start_pos is not None:
+            start_pos = np.ascontiguousarray(start_pos, dtype=np.uint64)
+        self._keep = (packed, start_pos)
+        self._chk(self.lib.mhx_load_sequences(self.h, _ptr(packed), packed.size, n_seqs, fixed_len, _ptr(start_pos)))
+
+    def load_bin_records(self, records, n_seqs, reverse=True):
+        records = np.ascontiguousarray(records, dtype=np.uint32)
+        self._chk(self.lib.mhx_load_bin_records(self.h, _ptr(records), records.size, n_seqs, int(reverse)))
+
+    def load_multiplicity(self, mult):
+        mult = np.ascontiguousarray(mult, dtype=np.uint16)
+        self._chk(self.lib.mhx_load_multiplicity(self.h, _ptr(mult), mult.size))
+
+    def set_is_solid(self, bits):
+        bits = np.ascontiguousarray(bits, dtype=np.uint64)
+        self._chk(self.lib.mhx_set_is_solid(self.h, _ptr(bits), bits.size))
+
+    @property
+    def n_seqs(self):
+        return self.lib.mhx_num_sequences(self.h)
+
+    @property
+    def n_bases(self):
+        return self.lib.mhx_num_bases(self.h)
+
+    # ---- engines
+    def count(self, k, m):
+        r = CountResult()
+        self._chk(self.lib.mhx_count(self.h, k, m, C.byref(r)))
+        return r
+
+    def read2sdbg_s1(self, k, m, want_mercy=False):
+        r = S1Result()
+        self._chk(self.lib.mhx_read2sdbg_s1(self.h, k, m, int(want_mercy), C.byref(r)))
+        return r
+
+    def read2sdbg_add_mercy(self, k):
+        n = C.c_uint64(0)
+        self._chk(self.lib.mhx_read2sdbg_add_mercy(self.h, k, C.byref(n)))
+        return n.value
+
+    def read2sdbg_s2(self, k, m):
+        r = SdbgResult()
+        self._chk(self.lib.mhx_read2sdbg_s2(self.h, k, m, C.byref(r)))
+        return r
+
+    def seq2sdbg(self, k):
+        r = SdbgResult()
+        self._chk(self.lib.mhx_seq2sdbg(self.h, k, C.byref(r)))
+        return r
+
+    def gen_mercy_edges(self, k, cand_packed, n_cand, cand_start):
+        cand_packed = np.ascontiguousarray(cand_packed, dtype=np.uint32)
+        cand_start = np.ascontiguousarray(cand_start, dtype=np.uint64)
+        n = C.c_uint64(0)
+        self._chk(self.lib.mhx_gen_mercy_edges(self.h, k, _ptr(cand_packed), cand_packed.size, n_cand, _ptr(cand_start),
+                                               C.byref(n)))
+        return n.value
+
+    def sort_records(self, items, key_words):
+        """items: uint32 [n, w]; sorted in place by the first key_words words."""
+        assert items.dtype == np.uint32 and items.flags.c_contiguous and items.ndim == 2
+        self._chk(self.lib.mhx_sort_records(self.h, _ptr(items), items.shape[0], key_words, items.shape[1] - key_words))
+        return items
+
+    # ---- outputs
+    def fetch(self, which, dtype):
+        nbytes = self.lib.mhx_buffer_bytes(self.h, which)
+        out = np.empty(nbytes // np.dtype(dtype).itemsize, dtype=dtype)
+        if nbytes:
+            self._chk(self.lib.mhx_fetch(self.h, which, _ptr(out), 0, nbytes))
+        return out
+
+    def synchronize(self):
+        self._chk(self.lib.mhx_synchronize(self.h))
+
+    def trim(self):
+        self._chk(self.lib.mhx_trim(self.h))
+
+    # ---- profiling
+    def profile(self, on=True):
+        self._chk(self.lib.mhx_profile_enable(self.h, int(on)))
+
+    def profile_reset(self):
+        self._chk(self.lib.mhx_profile_reset(self.h))
+
+    def profile_get(self):
+        arr = (KernelStat * 128)()
+        n = self.lib.mhx_profile_get(self.h, arr, 128)
+        if n < 0:
+            raise MhxError(self.lib.mhx_last_error().decode())
+        return {arr[i].name.decode(): dict(launches=arr[i].launches, ms=arr[i].total_ms, bytes=arr[i].algo_bytes)
+                for i in range(min(n, 128))}
