@@ -88,6 +88,14 @@ __global__ void k_fixed_starts(uint64_t *start, uint64_t n_seqs, uint32_t fixed_
 
 constexpr size_t kSeqPadWords = 64;
 
+void upload_fixed_starts(mhx_ctx *c) {
+  SeqSet &s = c->seqs;
+  hipLaunchKernelGGL(k_fixed_starts, dim3((unsigned)div_ceil(s.n_seqs + 1, 256)), dim3(256), 0, c->stream, s.start.as<uint64_t>(), s.n_seqs,
+                     s.fixed_len);
+  MHX_HIP(hipGetLastError());
+  MHX_HIP(hipStreamSynchronize(c->stream));
+}
+
 void upload_sequences(mhx_ctx *c, const uint32_t *packed, uint64_t n_words, uint64_t n_seqs, uint32_t fixed_len,
                       const uint64_t *start_pos) {
   SeqSet &s = c->seqs;

@@ -1,0 +1,304 @@
+#include "formats.h"
+
+#include <zlib.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+
+namespace mhxio {
+
+void fatal(const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  fprintf(stderr, "FATAL ");
+  vfprintf(stderr, fmt, ap);
+  fprintf(stderr, "\n");
+  va_end(ap);
+  exit(1);
+}
+void info(const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  fprintf(stderr, "INFO  ");
+  vfprintf(stderr, fmt, ap);
+  fprintf(stderr, "\n");
+  va_end(ap);
+}
+
+void PackedSeqs::append_packed(const uint32_t *src, uint32_t len, bool rev) {
+  if (len == 0) {  // fake 1-base sequence, sequence_package.h:276-281
+    uint32_t fake = 0;
+    append_packed(&fake, 1, false);
+    return;
+  }
+  uint64_t pos = start.back();
+  words.resize((pos + len + 15) / 16, 0);
+  if (!rev && (pos & 15) == 0) {
+    memcpy(&words[pos >> 4], src, ((len + 15) / 16) * 4);
+    if (len & 15) words[(pos + len) >> 4] &= 0xFFFFFFFFu << (32 - 2 * (len & 15));
+  } else {
+    for (uint32_t i = 0; i < len; ++i) {
+      uint32_t j = rev ? len - 1 - i : i;
+      uint32_t c = (src[j >> 4] >> (30 - 2 * (j & 15))) & 3u;
+      words[(pos + i) >> 4] |= c << (30 - 2 * ((pos + i) & 15));
+    }
+  }
+  start.push_back(pos + len);
+}
+
+void PackedSeqs::append_string(const char *s, uint32_t len, bool rev) {
+  if (len == 0) {  // sequence_package.h:262-267
+    append_string("A", 1, false);
+    return;
+  }
+  uint64_t pos = start.back();
+  words.resize((pos + len + 15) / 16, 0);
+  for (uint32_t i = 0; i < len; ++i) {
+    char ch = s[rev ? len - 1 - i : i];
+    uint32_t c;  // "ACGTNacgtn" -> 0123201232 (sequence_package.h:80-82)
+    switch (ch) {
+      case 'C': case 'c': c = 1; break;
+      case 'G': case 'g': case 'N': case 'n': c = 2; break;
+      case 'T': case 't': c = 3; break;
+      default: c = 0;
+    }
+    words[(pos + i) >> 4] |= c << (30 - 2 * ((pos + i) & 15));
+  }
+  start.push_back(pos + len);
+}
+
+void read_lib_info(const std::string &prefix, int64_t *total_bases, int64_t *total_reads) {
+  std::ifstream f(prefix + ".lib_info");
+  if (!f || !(f >> *total_bases >> *total_reads)) fatal("cannot read %s.lib_info", prefix.c_str());
+}
+
+std::vector<uint32_t> read_bin_file(const std::string &path) {
+  FILE *f = fopen(path.c_str(), "rb");
+  if (!f) fatal("Cannot open %s", path.c_str());
+  fseek(f, 0, SEEK_END);
+  long sz = ftell(f);
+  fseek(f, 0, SEEK_SET);
+  std::vector<uint32_t> v((size_t)sz / 4);
+  if (sz && fread(v.data(), 4, v.size(), f) != v.size()) fatal("short read on %s", path.c_str());
+  fclose(f);
+  return v;
+}
+
+std::vector<uint64_t> index_bin_records(const std::vector<uint32_t> &rec) {
+  std::vector<uint64_t> off;
+  uint64_t pos = 0;
+  while (pos < rec.size()) {
+    off.push_back(pos);
+    pos += 1 + (rec[pos] + 15) / 16;
+  }
+  if (pos != rec.size()) fatal("truncated .bin record stream");
+  return off;
+}
+
+// buckets -> files: contiguous bucket ranges with roughly equal payload
+static std::vector<int> split_buckets(const uint64_t *weight, int n_buckets, int n_files) {
+  std::vector<int> file_of(n_buckets, 0);
+  long double total = 0;
+  for (int b = 0; b < n_buckets; ++b) total += weight[b];
+  long double acc = 0;
+  for (int b = 0; b < n_buckets; ++b) {
+    int f = total > 0 ? (int)(acc * n_files / total) : 0;
+    file_of[b] = std::min(f, n_files - 1);
+    acc += weight[b];
+  }
+  return file_of;
+}
+
+void write_edges(const std::string &prefix, uint32_t k, uint32_t wpe, const uint32_t *edges, uint64_t n_edges,
+                 const uint64_t *bucket_count, int n_files) {
+  const int NB = 65536;
+  if (n_files < 1) n_files = 1;
+  std::vector<int> file_of = split_buckets(bucket_count, NB, n_files);
+  std::vector<FILE *> fs(n_files);
+  for (int i = 0; i < n_files; ++i) {
+    std::string p = prefix + ".edges." + std::to_string(i);
+    fs[i] = fopen(p.c_str(), "wb");
+    if (!fs[i]) fatal("Cannot open %s", p.c_str());
+  }
+  std::vector<int64_t> in_file(n_files, 0);
+  std::ofstream meta(prefix + ".edges.info");
+  meta << "kmer_size " << k << '\n' << "words_per_edge " << wpe << '\n' << "num_files " << n_files << '\n'
+       << "num_buckets " << NB << '\n' << "num_edges " << n_edges << '\n' << "is_sorted " << 1 << '\n';
+  uint64_t pos = 0;
+  for (int b = 0; b < NB; ++b) {
+    if (bucket_count[b] == 0) {
+      meta << b << " -1 0 0\n";  // EdgeIoBucketInfo defaults, edge_io_meta.h:11-15
+      continue;
+    }
+    int f = file_of[b];
+    fwrite(edges + pos * wpe, 4, bucket_count[b] * wpe, fs[f]);
+    meta << b << ' ' << f << ' ' << in_file[f] << ' ' << bucket_count[b] << '\n';
+    in_file[f] += (int64_t)bucket_count[b];
+    pos += bucket_count[b];
+  }
+  if (pos != n_edges) fatal("write_edges: bucket counts do not add up");
+  for (FILE *f : fs) fclose(f);
+}
+
+void write_cand(const std::string &prefix, const std::vector<uint32_t> &rec, const std::vector<uint64_t> &rec_off,
+                const uint32_t *first_0_out, const uint32_t *last_0_in, int64_t *n_cand, int64_t *n_has_tips) {
+  FILE *f = fopen((prefix + ".cand").c_str(), "wb");
+  if (!f) fatal("Cannot open %s.cand", prefix.c_str());
+  *n_cand = *n_has_tips = 0;
+  PackedSeqs one;
+  for (size_t i = 0; i < rec_off.size(); ++i) {
+    uint32_t first = first_0_out[i], last = last_0_in[i];
+    if (first != 0xFFFFFFFFu && last != 0xFFFFFFFFu) {
+      ++*n_has_tips;
+      if (last > first) {
+        ++*n_cand;
+        uint32_t len = rec[rec_off[i]];
+        one.words.clear();
+        one.start.assign(1, 0);
+        one.append_packed(&rec[rec_off[i] + 1], len, true);  // the engine's package holds reversed reads
+        uint32_t out_len = (uint32_t)one.n_bases();
+        fwrite(&out_len, 4, 1, f);
+        fwrite(one.words.data(), 4, (out_len + 15) / 16, f);
+      }
+    }
+  }
+  fclose(f);
+}
+
+void write_counting(const std::string &prefix, const int64_t *hist) {
+  FILE *f = fopen((prefix + ".counting").c_str(), "w");
+  if (!f) fatal("Cannot open %s.counting", prefix.c_str());
+  for (int i = 1; i <= 65535; ++i) fprintf(f, "%d %lld\n", i, (long long)hist[i]);
+  fclose(f);
+}
+
+void write_sdbg(const std::string &prefix, uint32_t k, uint32_t wpt, const uint8_t *bytes, uint64_t n_bytes, const uint64_t *bucket_off,
+                const uint64_t *b_items, const uint64_t *b_tips, const uint64_t *b_large, int n_files) {
+  const int NB = 65536;
+  if (n_files < 1) n_files = 1;
+  std::vector<uint64_t> weight(NB);
+  for (int b = 0; b < NB; ++b) weight[b] = 2 * (b_items[b] + b_large[b]) + 4ull * wpt * b_tips[b];
+  std::vector<int> file_of = split_buckets(weight.data(), NB, n_files);
+  std::vector<FILE *> fs(n_files);
+  for (int i = 0; i < n_files; ++i) {
+    std::string p = prefix + ".sdbg." + std::to_string(i);
+    fs[i] = fopen(p.c_str(), "wb");
+    if (!fs[i]) fatal("Cannot open %s", p.c_str());
+  }
+  std::vector<uint64_t> in_file(n_files, 0);
+  // bucket records sorted by (file_id, starting_offset), null buckets last (sdbg_meta.cpp:44-61)
+  std::ostringstream lines;
+  int used_files = 0, n_null = 0;
+  uint64_t total = 0;
+  for (int b = 0; b < NB; ++b) {
+    if (b_items[b] == 0) {
+      ++n_null;
+      continue;
+    }
+    int f = file_of[b];
+    if (weight[b]) fwrite(bytes + bucket_off[b], 1, weight[b], fs[f]);
+    lines << b << ' ' << f << ' ' << in_file[f] << ' ' << b_items[b] << ' ' << b_tips[b] << ' ' << b_large[b] << '\n';
+    in_file[f] += weight[b];
+    total += weight[b];
+    used_files = std::max(used_files, f + 1);
+  }
+  if (total != n_bytes) fatal("write_sdbg: bucket sizes do not add up (%llu vs %llu)", (unsigned long long)total, (unsigned long long)n_bytes);
+  for (FILE *f : fs) fclose(f);
+  std::ofstream meta(prefix + ".sdbg_info");
+  meta << "k " << k << "\n" << "words_per_tip_label " << wpt << "\n" << "num_buckets " << NB << "\n" << "num_files " << used_files << "\n";
+  meta << lines.str();
+  for (int i = 0; i < n_null; ++i) meta << "18446744073709551615 18446744073709551615 0 0 0 0\n";
+}
+
+static bool scan_field(std::istream &is, const char *name, long long *v) {
+  std::string s;
+  return static_cast<bool>(is >> s >> *v) && s == name;
+}
+
+EdgeSet read_edges(const std::string &prefix) {
+  std::ifstream meta(prefix + ".edges.info");
+  if (!meta) fatal("Cannot open %s.edges.info", prefix.c_str());
+  long long k, wpe, nfiles, nb, nedges, sorted;
+  if (!scan_field(meta, "kmer_size", &k) || !scan_field(meta, "words_per_edge", &wpe) || !scan_field(meta, "num_files", &nfiles) ||
+      !scan_field(meta, "num_buckets", &nb) || !scan_field(meta, "num_edges", &nedges) || !scan_field(meta, "is_sorted", &sorted))
+    fatal("Invalid format: %s.edges.info", prefix.c_str());
+  EdgeSet es;
+  es.k = (uint32_t)k;
+  es.words_per_edge = (uint32_t)wpe;
+  es.sorted = sorted != 0;
+  es.raw.resize((size_t)nedges * wpe);
+  std::vector<FILE *> fs((size_t)nfiles);
+  for (long long i = 0; i < nfiles; ++i) {
+    std::string p = prefix + ".edges." + std::to_string(i);
+    fs[i] = fopen(p.c_str(), "rb");
+    if (!fs[i]) fatal("Cannot open %s", p.c_str());
+  }
+  uint64_t pos = 0;
+  if (es.sorted) {
+    for (long long b = 0; b < nb; ++b) {
+      long long id, fid, off, cnt;
+      if (!(meta >> id >> fid >> off >> cnt) || id != b) fatal("Invalid format: bucket id not matched!");
+      if (fid >= nfiles) fatal("Record ID %lld is greater than number of files %lld", fid, nfiles);
+      if (fid < 0) continue;
+      fseek(fs[fid], off * wpe * 4, SEEK_SET);
+      if (fread(&es.raw[pos * wpe], 4, (size_t)(cnt * wpe), fs[fid]) != (size_t)(cnt * wpe)) fatal("short read on edges file");
+      pos += (uint64_t)cnt;
+    }
+  } else if (nedges) {
+    if (fread(es.raw.data(), 4, (size_t)(nedges * wpe), fs[0]) != (size_t)(nedges * wpe)) fatal("short read on edges file");
+    pos = (uint64_t)nedges;
+  }
+  if (pos != (uint64_t)nedges) fatal("edge count mismatch in %s", prefix.c_str());
+  for (FILE *f : fs) fclose(f);
+  return es;
+}
+
+int64_t read_contigs(const std::string &fasta, PackedSeqs *pkg, std::vector<uint16_t> *mult, unsigned min_len, unsigned k_from,
+                     unsigned k_to, bool reverse) {
+  gzFile f = gzopen(fasta.c_str(), "r");
+  if (!f) fatal("Cannot open %s", fasta.c_str());
+  const bool extend_loop = k_from < k_to;
+  std::string seq, comment;
+  std::vector<char> line(1 << 20);
+  bool have = false, eof = false;
+  int64_t n_read = 0;
+  auto flush = [&]() {
+    if (!have || seq.size() < min_len) return;
+    unsigned flag = comment.size() > 5 ? (unsigned)(comment[5] - '0') : 0;  // "flag=x multi=..." (contig_reader.h:66)
+    if (extend_loop && (flag & 2u)) {                                       // contig_flag::kLoop
+      if (seq.size() < k_to + 1u) return;
+      for (unsigned i = k_from; i < k_to; ++i) seq.push_back(seq[i]);
+    }
+    pkg->append_string(seq.data(), (uint32_t)seq.size(), reverse);
+    double m = comment.size() > 13 ? atof(comment.c_str() + 13) : 0;
+    mult->push_back((uint16_t)(m + .5));  // GetMultiplicity<mul_t>, contig_reader.h:111-119
+    ++n_read;
+  };
+  while (!eof) {
+    char *r = gzgets(f, line.data(), (int)line.size());
+    if (!r) eof = true;
+    if (eof || line[0] == '>') {
+      flush();
+      if (eof) break;
+      have = true;
+      seq.clear();
+      std::string hdr(line.data() + 1);
+      while (!hdr.empty() && (hdr.back() == '\n' || hdr.back() == '\r')) hdr.pop_back();
+      size_t sp = hdr.find_first_of(" \t");
+      comment = sp == std::string::npos ? "" : hdr.substr(hdr.find_first_not_of(" \t", sp));
+    } else if (have) {
+      size_t n = strlen(line.data());
+      while (n && (line[n - 1] == '\n' || line[n - 1] == '\r')) --n;
+      seq.append(line.data(), n);
+    }
+  }
+  gzclose(f);
+  return n_read;
+}
+
+}  // namespace mhxio

@@ -1,0 +1,59 @@
+// Host-side readers/writers of the on-disk formats around the SdBG-construction path.
+// Byte-for-byte the reference's formats; each function cites the reference code
+// whose output/input it must match.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace mhxio {
+
+[[noreturn]] void fatal(const char *fmt, ...);
+void info(const char *fmt, ...);
+
+// 2-bit packed, gap-free sequence set on the host (SequencePackage layout).
+struct PackedSeqs {
+  std::vector<uint32_t> words;
+  std::vector<uint64_t> start{0};
+  uint64_t n_seqs() const { return start.size() - 1; }
+  uint64_t n_bases() const { return start.back(); }
+  void append_packed(const uint32_t *src, uint32_t len, bool rev);  // sequence_package.h:275-306
+  void append_string(const char *s, uint32_t len, bool rev);        // sequence_package.h:261-273
+  unsigned base(uint64_t i) const { return (words[i >> 4] >> (30 - 2 * (i & 15))) & 3u; }
+};
+
+// <prefix>.lib_info: total_bases total_reads (sequence_lib.cpp:84-90,93-99)
+void read_lib_info(const std::string &prefix, int64_t *total_bases, int64_t *total_reads);
+// whole <prefix>.bin record stream: per read uint32 len + ceil(len/16) words (sequence_package.h:224-240)
+std::vector<uint32_t> read_bin_file(const std::string &path);
+// offsets (in words) of each record in a .bin stream
+std::vector<uint64_t> index_bin_records(const std::vector<uint32_t> &rec);
+
+// EdgeWriter + EdgeIoMetadata::Serialize (edge_writer.h:17-111, edge_io_meta.h:25-44); edges are in
+// bucket order; they are split over n_files files at bucket boundaries.
+void write_edges(const std::string &prefix, uint32_t k, uint32_t words_per_edge, const uint32_t *edges, uint64_t n_edges,
+                 const uint64_t *bucket_count, int n_files);
+// KmerCounter::Lv0Postprocess (kmer_counter.cpp:383-403): reversed reads with first_0_out < last_0_in
+void write_cand(const std::string &prefix, const std::vector<uint32_t> &bin_records, const std::vector<uint64_t> &rec_off,
+                const uint32_t *first_0_out, const uint32_t *last_0_in, int64_t *n_cand, int64_t *n_has_tips);
+// EdgeMultiplicityRecorder::DumpStat (edge_counter.h:44-52)
+void write_counting(const std::string &prefix, const int64_t *hist);
+// SdbgWriter::Finalize + SdbgMeta::Serialize (sdbg_writer.cpp:68-79, sdbg_meta.cpp:12-61)
+void write_sdbg(const std::string &prefix, uint32_t k, uint32_t words_per_tip_label, const uint8_t *bytes, uint64_t n_bytes,
+                const uint64_t *bucket_off, const uint64_t *bucket_items, const uint64_t *bucket_tips, const uint64_t *bucket_large,
+                int n_files);
+
+// EdgeReader (edge_reader.h:13-158): sorted (bucket-id order over any number of files) or unsorted
+struct EdgeSet {
+  uint32_t k = 0, words_per_edge = 0;
+  bool sorted = true;
+  std::vector<uint32_t> raw;  // n_edges * words_per_edge, in reading order
+  uint64_t n_edges() const { return words_per_edge ? raw.size() / words_per_edge : 0; }
+};
+EdgeSet read_edges(const std::string &prefix);
+
+// ContigReader::ReadAllWithMultiplicity (contig_reader.h:52-119) on a FASTA file
+int64_t read_contigs(const std::string &fasta, PackedSeqs *pkg, std::vector<uint16_t> *mult, unsigned min_len, unsigned k_from,
+                     unsigned k_to, bool reverse);
+
+}  // namespace mhxio

@@ -131,6 +131,10 @@ void find_group_heads(mhx_ctx *c, const uint32_t *items, uint64_t n, int stride,
                       uint64_t *heads, uint64_t *d_count);
 uint64_t count_group_heads(mhx_ctx *c, const uint32_t *items, uint64_t n, int stride, int cmp_bits);
 
+std::vector<SortPass> make_passes_ranges(int key_words, const std::vector<std::pair<int, int>> &ranges);
+// s2.hip: SdBG records from sorted lv2 items (shared by read2sdbg S2 and seq2sdbg)
+void emit_sdbg(mhx_ctx *c, const uint32_t *sorted, uint64_t n_items, int S, int kw, uint32_t k, int is_seq, mhx_sdbg_result *out);
+
 // ---- engines ----
 int run_count(mhx_ctx *c, uint32_t k, uint32_t m, mhx_count_result *out);
 int run_s1(mhx_ctx *c, uint32_t k, uint32_t m, int want_mercy, mhx_s1_result *out);
@@ -141,6 +145,7 @@ int run_gen_mercy(mhx_ctx *c, uint32_t k, const uint32_t *cand_packed, uint64_t 
                   const uint64_t *cand_start, uint64_t *n_mercy);
 void upload_sequences(mhx_ctx *c, const uint32_t *packed, uint64_t n_words, uint64_t n_seqs, uint32_t fixed_len,
                       const uint64_t *start_pos);
+void upload_fixed_starts(mhx_ctx *c);
 void upload_bin_records(mhx_ctx *c, const uint32_t *records, uint64_t n_words, uint64_t n_seqs, int reverse);
 
 inline int round_up2(int x) { return (x + 1) & ~1; }

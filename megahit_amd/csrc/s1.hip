@@ -1,4 +1,307 @@
+// read2sdbg stage 1: replaces Read2SdbgS1 (reference src/sorting/read_to_sdbg_s1.cpp) on the GPU.
+//
+//   extract   one item per canonical (k-1)-mer occurrence (+ both strands at the read ends) with
+//             (head,tail) in the low 6 key bits and (prev,next,position) as aux
+//             (Lv1FillOffsets :208-296 + Lv2ExtractSubString :298-366 fused)
+//   sort      by (k-1)-mer then (head,tail)                                   (sort.hip)
+//   groups    heads of equal-(k-1)-mer groups                                 (scan.hip)
+//   reduce    per group: (head,tail) run lengths -> is_solid bits (atomicOr), multiplicity histogram,
+//             optional mercy candidates                                       (Lv2Postprocess :368-555)
+//
+// Tie order: the sort is stable and items are emitted in the reference's global order, so the
+// "first item" of a group (whose prev/next the reference re-uses for the whole group, :399) is the
+// first in read order.  kmlib::kmsort is unstable for buckets > 64 items, so mercy candidates can
+// differ from the reference there; is_solid and the histogram never depend on it.
+#include "dev_prims.h"
 #include "mhx_internal.h"
+
 namespace mhx {
-int run_s1(mhx_ctx *, uint32_t, uint32_t, int, mhx_s1_result *) { throw Error("read2sdbg_s1: not implemented"); }
+
+__global__ void k_s1_item_counts(const uint64_t *__restrict__ start, uint64_t n_seqs, uint32_t k, uint32_t *__restrict__ cnt) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_seqs) {
+    uint64_t L = start[i + 1] - start[i];
+    cnt[i] = L >= k + 1 ? (uint32_t)(L - k + 4) : 0u;  // read_to_sdbg_s1.cpp:228-292
+  }
 }
+
+template <int KW, int S>
+__global__ __launch_bounds__(256) void k_s1_extract(const uint32_t *__restrict__ seq, const uint64_t *__restrict__ start,
+                                                    const uint64_t *__restrict__ item_start, uint64_t n_seqs, int k,
+                                                    uint32_t *__restrict__ items) {
+  const int lane = lane_id();
+  const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / kWave;
+  const uint64_t n_waves = (uint64_t)gridDim.x * blockDim.x / kWave;
+  for (uint64_t r = wave; r < n_seqs; r += n_waves) {
+    const uint64_t st = start[r];
+    const uint32_t L = (uint32_t)(start[r + 1] - st);
+    if (L < (uint32_t)k + 1) continue;
+    const uint64_t ibase = item_start[r];
+    const uint32_t n_slots = L - k + 4;
+    for (uint32_t j = lane; j < n_slots; j += kWave) {
+      // slot -> ((k-1)-mer offset q, forced strand or -1)
+      uint32_t q;
+      int forced = -1;
+      if (j < 2) { q = 0; forced = (int)j; }
+      else if (j >= L - k + 2) { q = L - k + 1; forced = (int)(j - (L - k + 2)); }
+      else q = j - 1;
+      uint32_t f[KW], rc[KW];
+      load_chars<KW>(seq, st + q, k - 1, f);
+      rc_chars<KW>(f, k - 1, rc);
+      const unsigned head = q >= 1 ? base_at(seq, st + q - 1) : kSentinel;
+      const unsigned prev = q >= 2 ? base_at(seq, st + q - 2) : kSentinel;
+      const unsigned tail = q + k - 1 < L ? base_at(seq, st + q + k - 1) : kSentinel;
+      const unsigned next = q + k < L ? base_at(seq, st + q + k) : kSentinel;
+      int strand;
+      if (forced >= 0) strand = forced;
+      else {
+        const int c = cmp_words<KW>(f, rc);
+        if (c > 0) strand = 1;
+        else if (c < 0) strand = 0;
+        else strand = head <= 3 - tail ? 0 : 1;  // palindrome rule, :264-279 (head/tail are bases here)
+      }
+      const uint64_t full = ((st + q) << 1) | (uint64_t)strand;
+      uint64_t info;
+      uint32_t out[S];
+      if (!strand) {
+#pragma unroll
+        for (int i = 0; i < KW; ++i) out[i] = f[i];
+        out[KW - 1] |= (head << 3) | tail;
+        info = (full << 6) | (prev << 3) | next;
+      } else {
+#pragma unroll
+        for (int i = 0; i < KW; ++i) out[i] = rc[i];
+        out[KW - 1] |= (comp_or_sentinel(tail) << 3) | comp_or_sentinel(head);
+        info = (full << 6) | (comp_or_sentinel(next) << 3) | comp_or_sentinel(prev);
+      }
+      out[KW] = (uint32_t)(info >> 32);
+      out[KW + 1] = (uint32_t)info;
+      if constexpr (S > KW + 2) out[KW + 2] = 0;
+      uint32_t *dst = items + (ibase + j) * S;
+      if constexpr (S % 4 == 0) {
+#pragma unroll
+        for (int i = 0; i < S / 4; ++i)
+          reinterpret_cast<uint4 *>(dst)[i] = make_uint4(out[4 * i], out[4 * i + 1], out[4 * i + 2], out[4 * i + 3]);
+      } else {
+#pragma unroll
+        for (int i = 0; i < S / 2; ++i) reinterpret_cast<uint2 *>(dst)[i] = make_uint2(out[2 * i], out[2 * i + 1]);
+      }
+    }
+  }
+}
+
+constexpr int kS1LocalHist = 1024;
+
+// One thread per (k-1)-mer group.
+__global__ __launch_bounds__(256) void k_s1_groups(const uint32_t *__restrict__ items, uint64_t n, int stride, int kw,
+                                                   const uint64_t *__restrict__ heads, uint64_t n_groups, uint32_t m,
+                                                   const uint64_t *__restrict__ start, uint64_t n_seqs, uint32_t fixed_len,
+                                                   unsigned long long *__restrict__ is_solid, unsigned long long *__restrict__ hist,
+                                                   unsigned long long *__restrict__ n_solid_out, int want_mercy,
+                                                   long long *__restrict__ mercy, unsigned long long *__restrict__ mercy_n) {
+  __shared__ uint32_t lh[kS1LocalHist];
+  __shared__ unsigned long long blk_solid;
+  for (int i = threadIdx.x; i < kS1LocalHist; i += blockDim.x) lh[i] = 0;
+  if (threadIdx.x == 0) blk_solid = 0;
+  __syncthreads();
+  const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned long long my_solid = 0;
+  if (g < n_groups) {
+    const uint64_t b = heads[g], e = (g + 1 < n_groups) ? heads[g + 1] : n;
+    const unsigned pn_first = items[b * stride + kw + 1] & 63u;
+    uint64_t cnt_head[4] = {0, 0, 0, 0}, cnt_tail[4] = {0, 0, 0, 0};
+    unsigned l_has_out = 0, r_has_in = 0;
+    // walk 1: (head,tail) run lengths
+    for (uint64_t j = b; j < e;) {
+      const unsigned ht = items[j * stride + kw - 1] & 63u;
+      uint64_t j0 = j;
+      do ++j;
+      while (j < e && (items[j * stride + kw - 1] & 63u) == ht);
+      const uint64_t c = j - j0;
+      const unsigned h = ht >> 3, t = ht & 7;
+#pragma unroll
+      for (int x = 0; x < 4; ++x) {
+        if (h == (unsigned)x) cnt_head[x] += c;
+        if (t == (unsigned)x) cnt_tail[x] += c;
+      }
+      if (h < 4 && t < 4 && c >= m) {
+        l_has_out |= 1u << h;
+        r_has_in |= 1u << t;
+      }
+    }
+    unsigned has_in = 0, has_out = 0;
+    if ((pn_first >> 3) < 4) {
+#pragma unroll
+      for (int x = 0; x < 4; ++x)
+        if (cnt_head[x] >= m) has_in |= 1u << x;
+    }
+    if ((pn_first & 7) < 4) {
+#pragma unroll
+      for (int x = 0; x < 4; ++x)
+        if (cnt_tail[x] >= m) has_out |= 1u << x;
+    }
+    // walk 2
+    for (uint64_t j = b; j < e;) {
+      const unsigned ht = items[j * stride + kw - 1] & 63u;
+      uint64_t j0 = j;
+      do ++j;
+      while (j < e && (items[j * stride + kw - 1] & 63u) == ht);
+      const uint64_t c = j - j0;
+      const unsigned h = ht >> 3, t = ht & 7;
+      const bool both = h < 4 && t < 4;
+      if (both) {
+        const uint64_t hb = c > MHX_MAX_MUL ? MHX_MAX_MUL : c;
+        if (hb < kS1LocalHist) atomicAdd(&lh[hb], 1u);
+        else atomicAdd(&hist[hb], 1ull);
+      }
+      const bool solid = both && c >= m;
+      if (!solid && !want_mercy) continue;
+      for (uint64_t x = j0; x < j; ++x) {
+        const uint64_t info = (((uint64_t)items[x * stride + kw] << 32) | items[x * stride + kw + 1]) >> 6;
+        const uint64_t abs = info >> 1;
+        const int strand = (int)(info & 1);
+        if (solid) {
+          atomicOr(&is_solid[(abs - 1) >> 6], 1ull << ((abs - 1) & 63));  // :464
+          ++my_solid;
+        }
+        if (want_mercy) {
+          const uint64_t rid = seq_of_offset(start, n_seqs, fixed_len, abs);
+          const long long base = (long long)start[rid];
+          const long long off = (long long)abs - base - 1;
+          const long long l_off = strand == 0 ? off : off + 1, r_off = strand == 0 ? off + 1 : off;
+          long long c0 = -1, c1 = -1;
+          if (solid) {  // :466-483
+            if (!(has_in & (1u << h))) c0 = ((base + l_off) << 2) | (1 + strand);
+            if (!(has_out & (1u << t))) c1 = ((base + r_off) << 2) | (2 - strand);
+          } else {      // :485-551 (head/tail may be '$' here: the masks only hold bits 0..3)
+            if (l_has_out & (1u << h)) c0 = ((base + l_off) << 2) | ((has_in & (1u << h)) ? 0 : (1 + strand));
+            else if (has_in & (1u << h)) c0 = ((base + l_off) << 2) | (2 - strand);
+            if (r_has_in & (1u << t)) c1 = ((base + r_off) << 2) | ((has_out & (1u << t)) ? 0 : (2 - strand));
+            else if (has_out & (1u << t)) c1 = ((base + r_off) << 2) | (1 + strand);
+          }
+          if (c0 >= 0) mercy[atomicAdd(mercy_n, 1ull)] = c0;
+          if (c1 >= 0) mercy[atomicAdd(mercy_n, 1ull)] = c1;
+        }
+      }
+    }
+  }
+  if (my_solid) atomicAdd(&blk_solid, my_solid);
+  __syncthreads();
+  for (int i = threadIdx.x; i < kS1LocalHist; i += blockDim.x)
+    if (lh[i]) atomicAdd(&hist[i], (unsigned long long)lh[i]);
+  if (threadIdx.x == 0 && blk_solid) atomicAdd(n_solid_out, blk_solid);
+}
+
+// int64 <-> (hi,lo) word pairs so that the big-endian record sort orders them numerically
+__global__ void k_swap_words(uint32_t *__restrict__ v, uint64_t n) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    uint2 x = reinterpret_cast<uint2 *>(v)[i];
+    reinterpret_cast<uint2 *>(v)[i] = make_uint2(x.y, x.x);
+  }
+}
+
+int run_s1(mhx_ctx *c, uint32_t k, uint32_t m, int want_mercy, mhx_s1_result *out) {
+  SeqSet &s = c->seqs;
+  if (k < 9 || k > MHX_MAX_K) throw Error("read2sdbg: k out of range [9,255]");
+  const int KWv = (int)div_ceil((k - 1) * 2 + 6, 32);  // read_to_sdbg_s1.cpp:107-108
+  const int S = round_up2(KWv + 2);
+  const uint64_t ns = s.n_seqs;
+  hipStream_t st = c->stream;
+
+  uint32_t *cnt = c->ws("seq_item_cnt", (ns + 1) * 4).as<uint32_t>();
+  uint64_t *item_start = c->ws("seq_item_start", (ns + 2) * 8).as<uint64_t>();
+  uint64_t n_items = 0;
+  if (ns) {
+    MHX_LAUNCH(c, "item_counts", (double)ns * 12,
+               hipLaunchKernelGGL(k_s1_item_counts, dim3((unsigned)div_ceil(ns, 256)), dim3(256), 0, st, s.start.as<uint64_t>(), ns, k, cnt));
+    exclusive_scan_u32_u64(c, cnt, item_start, ns, item_start + ns + 1);
+    MHX_HIP(hipMemcpyAsync(&n_items, item_start + ns + 1, 8, hipMemcpyDeviceToHost, st));
+    MHX_HIP(hipStreamSynchronize(st));
+  }
+  const size_t item_bytes = (size_t)S * 4;
+  uint32_t *buf_a = c->ws("items_a", n_items * item_bytes + 64).as<uint32_t>();
+  uint32_t *buf_b = c->ws("items_b", n_items * item_bytes + 64).as<uint32_t>();
+  if (n_items) {
+    const unsigned grid = 256 * 8;
+    MHX_DISPATCH_KW(KWv, {
+      if (S == KW + 2)
+        MHX_LAUNCH(c, "s1_extract", (double)n_items * item_bytes + (double)s.n_bases / 4,
+                   hipLaunchKernelGGL((k_s1_extract<KW, KW + 2>), dim3(grid), dim3(256), 0, st, s.words.as<uint32_t>(),
+                                      s.start.as<uint64_t>(), item_start, ns, (int)k, buf_a));
+      else
+        MHX_LAUNCH(c, "s1_extract", (double)n_items * item_bytes + (double)s.n_bases / 4,
+                   hipLaunchKernelGGL((k_s1_extract<KW, KW + 3>), dim3(grid), dim3(256), 0, st, s.words.as<uint32_t>(),
+                                      s.start.as<uint64_t>(), item_start, ns, (int)k, buf_a));
+    });
+  }
+  const int kmer_bits = (int)(k - 1) * 2;
+  std::vector<SortPass> passes = make_passes(KWv, 0, 6);
+  {
+    std::vector<SortPass> hi = make_passes(KWv, KWv * 32 - kmer_bits, KWv * 32);
+    // the (head,tail) bits may overlap the last k-mer digit range only if they share a word with
+    // k-mer bits; they never overlap bit-wise (6 + 2(k-1) <= 32*KW)
+    passes.insert(passes.end(), hi.begin(), hi.end());
+  }
+  uint32_t *sorted = radix_sort(c, buf_a, buf_b, n_items, S, KWv, passes);
+  uint32_t *spare = sorted == buf_a ? buf_b : buf_a;
+
+  const uint64_t n_words64 = div_ceil(s.n_bases, 64);
+  unsigned long long *is_solid = c->result(MHX_BUF_IS_SOLID, (n_words64 + 1) * 8).as<unsigned long long>();
+  c->results[MHX_BUF_IS_SOLID].used = n_words64 * 8;
+  unsigned long long *hist = c->result(MHX_BUF_MUL_HIST, (MHX_MAX_MUL + 1) * 8).as<unsigned long long>();
+  MHX_HIP(hipMemsetAsync(is_solid, 0, (n_words64 + 1) * 8, st));
+  MHX_HIP(hipMemsetAsync(hist, 0, (MHX_MAX_MUL + 1) * 8, st));
+  unsigned long long *ctr = c->ws("s1_counters", 64).as<unsigned long long>();
+  MHX_HIP(hipMemsetAsync(ctr, 0, 64, st));
+
+  const uint64_t n_groups = count_group_heads(c, sorted, n_items, S, kmer_bits);
+  uint64_t n_solid = 0, n_mercy = 0;
+  if (n_groups) {
+    uint64_t *heads = c->ws("heads", n_groups * 8).as<uint64_t>();
+    find_group_heads(c, sorted, n_items, S, kmer_bits, heads, nullptr);
+    // mercy candidates (<= 2 per item, 8 B each) go to the spare sort buffer: S*4 >= 16 bytes per item
+    long long *mercy = reinterpret_cast<long long *>(spare);
+    MHX_LAUNCH(c, "s1_groups", (double)n_items * item_bytes + (double)n_groups * 8,
+               hipLaunchKernelGGL(k_s1_groups, dim3((unsigned)div_ceil(n_groups, 256)), dim3(256), 0, st, sorted, n_items, S, KWv, heads,
+                                  n_groups, m, s.start.as<uint64_t>(), ns, s.fixed_len, is_solid, hist, ctr, want_mercy, mercy, ctr + 1));
+    unsigned long long h[2];
+    MHX_HIP(hipMemcpyAsync(h, ctr, 16, hipMemcpyDeviceToHost, st));
+    MHX_HIP(hipStreamSynchronize(st));
+    n_solid = h[0];
+    n_mercy = h[1];
+    if (want_mercy && n_mercy) {
+      // sort the candidates numerically: swap to (hi,lo), record sort with 2 key words, swap back
+      uint32_t *ma = c->ws("mercy_a", n_mercy * 8 + 64).as<uint32_t>();
+      uint32_t *mb = c->ws("mercy_b", n_mercy * 8 + 64).as<uint32_t>();
+      MHX_HIP(hipMemcpyAsync(ma, mercy, n_mercy * 8, hipMemcpyDeviceToDevice, st));
+      const unsigned g2 = (unsigned)div_ceil(n_mercy, 256);
+      hipLaunchKernelGGL(k_swap_words, dim3(g2), dim3(256), 0, st, ma, n_mercy);
+      int hi_bit = 3;
+      while (hi_bit < 64 && ((s.n_bases << 2) >> hi_bit)) ++hi_bit;
+      uint32_t *ms = radix_sort(c, ma, mb, n_mercy, 2, 2, make_passes(2, 0, hi_bit));
+      hipLaunchKernelGGL(k_swap_words, dim3(g2), dim3(256), 0, st, ms, n_mercy);
+      DevBuf &res = c->result(MHX_BUF_MERCY_CAND, n_mercy * 8);
+      MHX_HIP(hipMemcpyAsync(res.p, ms, n_mercy * 8, hipMemcpyDeviceToDevice, st));
+    }
+  }
+  if (!want_mercy || !n_mercy) {
+    c->result(MHX_BUF_MERCY_CAND, 8);
+    c->results[MHX_BUF_MERCY_CAND].used = 0;
+  }
+  c->results[MHX_BUF_SORTED_ITEMS].release();
+  c->results[MHX_BUF_SORTED_ITEMS].p = sorted;
+  c->results[MHX_BUF_SORTED_ITEMS].cap = 0;
+  c->results[MHX_BUF_SORTED_ITEMS].used = n_items * item_bytes;
+  c->sorted_item_words = S;
+  MHX_HIP(hipStreamSynchronize(st));
+  if (out) {
+    out->n_items = n_items;
+    out->n_solid = n_solid;
+    out->n_mercy_cand = want_mercy ? n_mercy : 0;
+    out->item_words = S;
+  }
+  return 0;
+}
+
+}  // namespace mhx

@@ -1,4 +1,423 @@
+// read2sdbg stage 2 and the SdBG emission shared with seq2sdbg.
+// Replaces Read2SdbgS2 (reference src/sorting/read_to_sdbg_s2.cpp:271-630) and the
+// Lv2Postprocess of SeqToSdbg (src/sorting/seq_to_sdbg.cpp:702-789) + SdbgWriter
+// (src/sdbg/sdbg_writer.cpp:25-58) on the GPU.
+//
+//   s2_count / s2_extract   <= 6 items per solid (k+1)-mer occurrence (Lv1FillOffsets :347-440 +
+//                            Lv2ExtractSubString :442-519), item slots from a per-read scan
+//   sort                    by k-mer chars, then the "full" flag, then W           (sort.hip)
+//   groups                  heads of equal-(k-1)-mer groups                         (scan.hip)
+//   sdbg_count / sdbg_emit  per group: W, last, tip, multiplicity -> byte-exact records at offsets
+//                           from exclusive scans of (records, tips, large multiplicities)
+//   bucket_stats            per-bucket starting offset / item / tip / large counts (sdbg_meta.h:22-34)
+#include "dev_prims.h"
 #include "mhx_internal.h"
+
 namespace mhx {
-int run_s2(mhx_ctx *, uint32_t, uint32_t, mhx_sdbg_result *) { throw Error("read2sdbg_s2: not implemented"); }
+
+// ---------------------------------------------------------------------------
+// S2 item generation
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ bool bit_at(const unsigned long long *__restrict__ bits, uint64_t i) {
+  return (bits[i >> 6] >> (i & 63)) & 1ull;
 }
+
+// number of items the (k+1)-mer occurrence at read offset p emits (0 if not solid); *mask gets
+// bit0 = left-$ pair, bit1 = right-$ pair, bit2 = palindrome
+template <int KW>
+__device__ __forceinline__ unsigned s2_items_at(const uint32_t *__restrict__ seq, const unsigned long long *__restrict__ solid, bool sure,
+                                                uint64_t st, uint32_t L, uint32_t p, int k, unsigned *mask) {
+  const uint64_t fo = st + p;
+  if (!(sure || bit_at(solid, fo))) return 0;
+  uint32_t e[KW], rc[KW];
+  load_chars<KW>(seq, fo, k + 1, e);
+  rc_chars<KW>(e, k + 1, rc);
+  const bool pal = cmp_words<KW>(e, rc) == 0;
+  const bool left = p == 0 || !(sure || bit_at(solid, fo - 1));          // :385-386
+  const bool right = p + k + 1 == L || !(sure || bit_at(solid, fo + 1)); // :411-412
+  *mask = (left ? 1u : 0u) | (right ? 2u : 0u) | (pal ? 4u : 0u);
+  return (1u + left + right) * (pal ? 1u : 2u);
+}
+
+template <int KW>
+__global__ __launch_bounds__(256) void k_s2_count(const uint32_t *__restrict__ seq, const uint64_t *__restrict__ start, uint64_t n_seqs,
+                                                  int k, const unsigned long long *__restrict__ solid, int sure,
+                                                  uint32_t *__restrict__ cnt) {
+  const int lane = lane_id();
+  const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / kWave;
+  const uint64_t n_waves = (uint64_t)gridDim.x * blockDim.x / kWave;
+  for (uint64_t r = wave; r < n_seqs; r += n_waves) {
+    const uint64_t st = start[r];
+    const uint32_t L = (uint32_t)(start[r + 1] - st);
+    uint32_t total = 0;
+    if (L >= (uint32_t)k + 1) {
+      for (uint32_t p0 = 0; p0 < L - k; p0 += kWave) {
+        const uint32_t p = p0 + lane;
+        unsigned mask, c = 0;
+        if (p < L - k) c = s2_items_at<KW>(seq, solid, sure != 0, st, L, p, k, &mask);
+        total += wave_sum<uint32_t>(c);
+      }
+    }
+    if (lane == 0) cnt[r] = total;
+  }
+}
+
+// type: 0 left-$, 1 solid, 2 right-$  (EncodeOffset, read_to_sdbg_s2.cpp:36-41)
+template <int KW, int S>
+__device__ __forceinline__ void s2_write_item(const uint32_t *__restrict__ seq, uint64_t fo, int k, int strand, int type,
+                                              uint32_t *__restrict__ dst) {
+  int n = k;
+  unsigned prev = kSentinel;
+  uint64_t off = fo;
+  if (!strand) {  // :457-485
+    if (type == 1) { prev = base_at(seq, fo); off = fo + 1; }
+    else if (type == 2) { prev = base_at(seq, fo + 1); off = fo + 2; n = k - 1; }
+  } else {        // :487-512
+    if (type == 0) { n = k - 1; prev = 3 - base_at(seq, fo + k - 1); }
+    else if (type == 1) prev = 3 - base_at(seq, fo + k);
+    else off = fo + 1;
+  }
+  uint32_t f[KW], out[S];
+  load_chars<KW>(seq, off, n, f);
+  if (strand) {
+    uint32_t rc[KW];
+    rc_chars<KW>(f, n, rc);
+#pragma unroll
+    for (int i = 0; i < KW; ++i) out[i] = rc[i];
+  } else {
+#pragma unroll
+    for (int i = 0; i < KW; ++i) out[i] = f[i];
+  }
+  out[KW - 1] |= ((n == k) ? 8u : 0u) | prev;
+  if constexpr (S > KW) out[KW] = 0;
+  if constexpr (S % 4 == 0) {
+#pragma unroll
+    for (int i = 0; i < S / 4; ++i)
+      reinterpret_cast<uint4 *>(dst)[i] = make_uint4(out[4 * i], out[4 * i + 1], out[4 * i + 2], out[4 * i + 3]);
+  } else {
+#pragma unroll
+    for (int i = 0; i < S / 2; ++i) reinterpret_cast<uint2 *>(dst)[i] = make_uint2(out[2 * i], out[2 * i + 1]);
+  }
+}
+
+template <int KW, int S>
+__global__ __launch_bounds__(256) void k_s2_extract(const uint32_t *__restrict__ seq, const uint64_t *__restrict__ start,
+                                                    const uint64_t *__restrict__ item_start, uint64_t n_seqs, int k,
+                                                    const unsigned long long *__restrict__ solid, int sure,
+                                                    uint32_t *__restrict__ items) {
+  const int lane = lane_id();
+  const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / kWave;
+  const uint64_t n_waves = (uint64_t)gridDim.x * blockDim.x / kWave;
+  for (uint64_t r = wave; r < n_seqs; r += n_waves) {
+    const uint64_t st = start[r];
+    const uint32_t L = (uint32_t)(start[r + 1] - st);
+    if (L < (uint32_t)k + 1) continue;
+    uint64_t carry = item_start[r];
+    for (uint32_t p0 = 0; p0 < L - k; p0 += kWave) {
+      const uint32_t p = p0 + lane;
+      unsigned mask = 0, c = 0;
+      if (p < L - k) c = s2_items_at<KW>(seq, solid, sure != 0, st, L, p, k, &mask);
+      const uint32_t inc = wave_inclusive_sum<uint32_t>(c);
+      const uint32_t tot = __shfl(inc, kWave - 1, kWave);
+      if (c) {
+        uint32_t *dst = items + (carry + inc - c) * S;
+        const bool pal = mask & 4u;
+        const uint64_t fo = st + p;
+        if (mask & 1u) {
+          s2_write_item<KW, S>(seq, fo, k, 0, 0, dst); dst += S;
+          if (!pal) { s2_write_item<KW, S>(seq, fo, k, 1, 0, dst); dst += S; }
+        }
+        s2_write_item<KW, S>(seq, fo, k, 0, 1, dst); dst += S;
+        if (!pal) { s2_write_item<KW, S>(seq, fo, k, 1, 1, dst); dst += S; }
+        if (mask & 2u) {
+          s2_write_item<KW, S>(seq, fo, k, 0, 2, dst); dst += S;
+          if (!pal) { s2_write_item<KW, S>(seq, fo, k, 1, 2, dst); dst += S; }
+        }
+      }
+      carry += tot;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// SdBG emission (shared)
+// ---------------------------------------------------------------------------
+struct SdbgParams {
+  int stride, kw, k;
+  int bshift, fshift;  // W char / "full k chars" flag position in the last key word
+  int aw, ashift;      // word and shift of the k-th char
+  int wpt;             // words per tip label
+  int is_seq;          // multiplicity comes from the key (seq2sdbg) instead of the run length (S2)
+};
+
+__device__ __forceinline__ int ex_a(const uint32_t *__restrict__ it, const SdbgParams &P) {
+  return ((it[P.kw - 1] >> P.fshift) & 1u) ? (int)((it[P.aw] >> P.ashift) & 3u) : 4;
+}
+__device__ __forceinline__ int ex_b(const uint32_t *__restrict__ it, const SdbgParams &P) { return (int)((it[P.kw - 1] >> P.bshift) & 7u); }
+
+// Walks one (k-1)-mer group exactly as Lv2Postprocess does (read_to_sdbg_s2.cpp:537-611 /
+// seq_to_sdbg.cpp:718-786).  EMIT=false counts records; EMIT=true writes them.
+template <bool EMIT>
+__device__ __forceinline__ void sdbg_walk_group(const uint32_t *__restrict__ items, uint64_t b, uint64_t e, const SdbgParams &P,
+                                                uint32_t &n_out, uint32_t &n_tips, uint32_t &n_large, uint16_t *__restrict__ out16,
+                                                uint64_t o16, uint32_t *wcnt /* [10] when EMIT */) {
+  int has_a = 0, has_b = 0;
+  uint64_t la0 = ~0ull, la1 = ~0ull, la2 = ~0ull, la3 = ~0ull;
+  for (uint64_t i = b; i < e; ++i) {
+    const uint32_t *it = items + i * P.stride;
+    const int a = ex_a(it, P), bb = ex_b(it, P);
+    if (a != 4 && bb != 4) {
+      has_a |= 1 << a;
+      has_b |= 1 << bb;
+    }
+    if (a != 4 && (bb != 4 || !(has_a & (1 << a)))) {
+      if (a == 0) la0 = i;
+      else if (a == 1) la1 = i;
+      else if (a == 2) la2 = i;
+      else la3 = i;
+    }
+  }
+  int outputed_b = 0;
+  for (uint64_t i = b, j; i < e; i = j) {
+    const uint32_t *cur = items + i * P.stride;
+    const int a = ex_a(cur, P), bb = ex_b(cur, P);
+    j = i + 1;
+    while (j < e) {
+      const uint32_t *nx = items + j * P.stride;
+      if (ex_a(nx, P) != a || ex_b(nx, P) != bb) break;
+      ++j;
+    }
+    int is_dollar = 0;
+    if (a == 4) {
+      if (has_b & (1 << bb)) continue;
+      is_dollar = 1;
+    }
+    if (bb == 4) {
+      if (has_a & (1 << a)) continue;
+    }
+    const int w = bb == 4 ? 0 : ((outputed_b & (1 << bb)) ? bb + 5 : bb + 1);
+    const uint64_t la = a == 0 ? la0 : (a == 1 ? la1 : (a == 2 ? la2 : la3));
+    const int last = a == 4 ? 0 : (la == j - 1 ? 1 : 0);
+    outputed_b |= 1 << bb;
+    uint32_t mul;
+    if (P.is_seq) mul = MHX_MAX_MUL - (cur[P.kw - 1] & 0xFFFFu);
+    else mul = (j - i) > (uint64_t)MHX_MAX_MUL ? (uint32_t)MHX_MAX_MUL : (uint32_t)(j - i);
+    ++n_out;
+    n_tips += is_dollar;
+    n_large += mul > 254;
+    if constexpr (EMIT) {
+      // SdbgItem (sdbg_item.h:14-24): byte0 = w | last<<4 | tip<<5, byte1 = min(mul,255)
+      out16[o16++] = (uint16_t)(w | (last << 4) | (is_dollar << 5) | ((mul > 255 ? 255u : mul) << 8));
+      if (mul > 254) out16[o16++] = (uint16_t)mul;
+      if (is_dollar) {
+        for (int x = 0; x < P.wpt; ++x) {
+          const uint32_t v = cur[x];
+          out16[o16++] = (uint16_t)(v & 0xFFFFu);
+          out16[o16++] = (uint16_t)(v >> 16);
+        }
+      }
+      atomicAdd(&wcnt[w], 1u);
+      if (last) atomicAdd(&wcnt[9], 1u);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_sdbg_count(const uint32_t *__restrict__ items, uint64_t n, const uint64_t *__restrict__ heads,
+                                                    uint64_t n_groups, SdbgParams P, uint32_t *__restrict__ g_out,
+                                                    uint32_t *__restrict__ g_tips, uint32_t *__restrict__ g_large) {
+  const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= n_groups) return;
+  const uint64_t b = heads[g], e = (g + 1 < n_groups) ? heads[g + 1] : n;
+  uint32_t no = 0, nt = 0, nl = 0;
+  sdbg_walk_group<false>(items, b, e, P, no, nt, nl, nullptr, 0, nullptr);
+  g_out[g] = no;
+  g_tips[g] = nt;
+  g_large[g] = nl;
+}
+
+__global__ __launch_bounds__(256) void k_sdbg_emit(const uint32_t *__restrict__ items, uint64_t n, const uint64_t *__restrict__ heads,
+                                                   uint64_t n_groups, SdbgParams P, const uint64_t *__restrict__ s_out,
+                                                   const uint64_t *__restrict__ s_tips, const uint64_t *__restrict__ s_large,
+                                                   uint16_t *__restrict__ out16, unsigned long long *__restrict__ w_count) {
+  __shared__ uint32_t wcnt[10];
+  if (threadIdx.x < 10) wcnt[threadIdx.x] = 0;
+  __syncthreads();
+  const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g < n_groups) {
+    const uint64_t b = heads[g], e = (g + 1 < n_groups) ? heads[g + 1] : n;
+    uint32_t no = 0, nt = 0, nl = 0;
+    const uint64_t o16 = s_out[g] + s_large[g] + 2ull * P.wpt * s_tips[g];
+    sdbg_walk_group<true>(items, b, e, P, no, nt, nl, out16, o16, wcnt);
+  }
+  __syncthreads();
+  if (threadIdx.x < 10 && wcnt[threadIdx.x]) atomicAdd(&w_count[threadIdx.x], (unsigned long long)wcnt[threadIdx.x]);
+}
+
+__global__ void k_bucket_stats(const uint32_t *__restrict__ items, int stride, const uint64_t *__restrict__ heads, uint64_t n_groups,
+                               const uint64_t *__restrict__ s_out, const uint64_t *__restrict__ s_tips,
+                               const uint64_t *__restrict__ s_large, int wpt, unsigned long long *__restrict__ b_items,
+                               unsigned long long *__restrict__ b_tips, unsigned long long *__restrict__ b_large,
+                               unsigned long long *__restrict__ b_off) {
+  const uint32_t bk = blockIdx.x * blockDim.x + threadIdx.x;
+  if (bk >= MHX_NUM_BUCKETS) return;
+  uint64_t bound[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const uint32_t target = bk + t;  // first group whose bucket >= target
+    uint64_t lo = 0, hi = n_groups;
+    while (lo < hi) {
+      uint64_t mid = (lo + hi) >> 1;
+      if ((items[heads[mid] * stride] >> 16) < target) lo = mid + 1;
+      else hi = mid;
+    }
+    bound[t] = lo;
+  }
+  const uint64_t g0 = bound[0], g1 = bound[1];
+  b_items[bk] = s_out[g1] - s_out[g0];
+  b_tips[bk] = s_tips[g1] - s_tips[g0];
+  b_large[bk] = s_large[g1] - s_large[g0];
+  b_off[bk] = 2ull * (s_out[g0] + s_large[g0]) + 4ull * wpt * s_tips[g0];
+}
+
+// sorted: n_items records of stride S with kw key words, sorted; fills the SdBG result buffers.
+void emit_sdbg(mhx_ctx *c, const uint32_t *sorted, uint64_t n_items, int S, int kw, uint32_t k, int is_seq, mhx_sdbg_result *out) {
+  hipStream_t st = c->stream;
+  SdbgParams P;
+  P.stride = S;
+  P.kw = kw;
+  P.k = (int)k;
+  P.bshift = is_seq ? 16 : 0;
+  P.fshift = P.bshift + 3;
+  P.aw = (int)(k - 1) / 16;
+  P.ashift = (15 - (int)((k - 1) % 16)) * 2;
+  P.wpt = (int)div_ceil(k, 16);
+  P.is_seq = is_seq;
+
+  unsigned long long *b_items = c->result(MHX_BUF_BUCKET_COUNT, MHX_NUM_BUCKETS * 8).as<unsigned long long>();
+  unsigned long long *b_tips = c->result(MHX_BUF_BUCKET_TIPS, MHX_NUM_BUCKETS * 8).as<unsigned long long>();
+  unsigned long long *b_large = c->result(MHX_BUF_BUCKET_LARGE, MHX_NUM_BUCKETS * 8).as<unsigned long long>();
+  unsigned long long *b_off = c->result(MHX_BUF_BUCKET_OFFSET, MHX_NUM_BUCKETS * 8).as<unsigned long long>();
+  unsigned long long *w_count = c->result(MHX_BUF_W_COUNT, 10 * 8).as<unsigned long long>();
+  MHX_HIP(hipMemsetAsync(w_count, 0, 80, st));
+
+  const int kmer_bits = (int)(k - 1) * 2;
+  const uint64_t n_groups = count_group_heads(c, sorted, n_items, S, kmer_bits);
+  uint64_t tot[3] = {0, 0, 0};
+  if (n_groups) {
+    uint64_t *heads = c->ws("heads", n_groups * 8).as<uint64_t>();
+    find_group_heads(c, sorted, n_items, S, kmer_bits, heads, nullptr);
+    uint32_t *g3 = c->ws("sdbg_group_cnt", n_groups * 12).as<uint32_t>();
+    uint32_t *g_out = g3, *g_tips = g3 + n_groups, *g_large = g3 + 2 * n_groups;
+    uint64_t *s3 = c->ws("sdbg_group_scan", (n_groups + 1) * 24).as<uint64_t>();
+    uint64_t *s_out = s3, *s_tips = s3 + (n_groups + 1), *s_large = s3 + 2 * (n_groups + 1);
+    const unsigned grid = (unsigned)div_ceil(n_groups, 256);
+    const double item_bytes = (double)n_items * S * 4;
+    MHX_LAUNCH(c, "sdbg_count", 2 * item_bytes + (double)n_groups * 20,
+               hipLaunchKernelGGL(k_sdbg_count, dim3(grid), dim3(256), 0, st, sorted, n_items, heads, n_groups, P, g_out, g_tips, g_large));
+    exclusive_scan_u32_u64(c, g_out, s_out, n_groups, s_out + n_groups);
+    exclusive_scan_u32_u64(c, g_tips, s_tips, n_groups, s_tips + n_groups);
+    exclusive_scan_u32_u64(c, g_large, s_large, n_groups, s_large + n_groups);
+    MHX_HIP(hipMemcpyAsync(&tot[0], s_out + n_groups, 8, hipMemcpyDeviceToHost, st));
+    MHX_HIP(hipMemcpyAsync(&tot[1], s_tips + n_groups, 8, hipMemcpyDeviceToHost, st));
+    MHX_HIP(hipMemcpyAsync(&tot[2], s_large + n_groups, 8, hipMemcpyDeviceToHost, st));
+    MHX_HIP(hipStreamSynchronize(st));
+    const uint64_t bytes = 2 * (tot[0] + tot[2]) + 4ull * P.wpt * tot[1];
+    uint16_t *out16 = c->result(MHX_BUF_SDBG_BYTES, bytes ? bytes : 2).as<uint16_t>();
+    c->results[MHX_BUF_SDBG_BYTES].used = bytes;
+    MHX_LAUNCH(c, "sdbg_emit", 2 * item_bytes + (double)n_groups * 32 + (double)bytes,
+               hipLaunchKernelGGL(k_sdbg_emit, dim3(grid), dim3(256), 0, st, sorted, n_items, heads, n_groups, P, s_out, s_tips, s_large,
+                                  out16, w_count));
+    MHX_LAUNCH(c, "bucket_stats", (double)MHX_NUM_BUCKETS * 32,
+               hipLaunchKernelGGL(k_bucket_stats, dim3(MHX_NUM_BUCKETS / 256), dim3(256), 0, st, sorted, S, heads, n_groups, s_out, s_tips,
+                                  s_large, P.wpt, b_items, b_tips, b_large, b_off));
+  } else {
+    c->result(MHX_BUF_SDBG_BYTES, 2);
+    c->results[MHX_BUF_SDBG_BYTES].used = 0;
+    MHX_HIP(hipMemsetAsync(b_items, 0, MHX_NUM_BUCKETS * 8, st));
+    MHX_HIP(hipMemsetAsync(b_tips, 0, MHX_NUM_BUCKETS * 8, st));
+    MHX_HIP(hipMemsetAsync(b_large, 0, MHX_NUM_BUCKETS * 8, st));
+    MHX_HIP(hipMemsetAsync(b_off, 0, MHX_NUM_BUCKETS * 8, st));
+  }
+  c->results[MHX_BUF_SORTED_ITEMS].release();
+  c->results[MHX_BUF_SORTED_ITEMS].p = const_cast<uint32_t *>(sorted);
+  c->results[MHX_BUF_SORTED_ITEMS].cap = 0;
+  c->results[MHX_BUF_SORTED_ITEMS].used = n_items * (size_t)S * 4;
+  c->sorted_item_words = S;
+  MHX_HIP(hipStreamSynchronize(st));
+  if (out) {
+    out->n_items = n_items;
+    out->n_sdbg = tot[0];
+    out->n_tips = tot[1];
+    out->n_large = tot[2];
+    out->sdbg_bytes = 2 * (tot[0] + tot[2]) + 4ull * P.wpt * tot[1];
+    out->words_per_tip_label = P.wpt;
+    out->item_words = S;
+  }
+}
+
+// fewest 8-bit passes covering the given bit ranges (ascending, disjoint)
+std::vector<SortPass> make_passes_ranges(int key_words, const std::vector<std::pair<int, int>> &ranges) {
+  size_t sep = 0;
+  for (auto &r : ranges) sep += (size_t)div_ceil(r.second - r.first, 8);
+  const int lo = ranges.front().first, hi = ranges.back().second;
+  if ((size_t)div_ceil(hi - lo, 8) <= sep) return make_passes(key_words, lo, hi);
+  std::vector<SortPass> p;
+  for (auto &r : ranges) {
+    auto q = make_passes(key_words, r.first, r.second);
+    p.insert(p.end(), q.begin(), q.end());
+  }
+  return p;
+}
+
+int run_s2(mhx_ctx *c, uint32_t k, uint32_t m, mhx_sdbg_result *out) {
+  SeqSet &s = c->seqs;
+  if (k < 9 || k > MHX_MAX_K) throw Error("read2sdbg: k out of range [9,255]");
+  const int KWv = (int)div_ceil(k * 2 + 4, 32);  // read_to_sdbg_s2.cpp:98-99
+  const int S = round_up2(KWv);
+  const uint64_t ns = s.n_seqs;
+  hipStream_t st = c->stream;
+  const int sure = m == 1;  // for_sure_solid, :295
+  const unsigned long long *solid = nullptr;
+  if (!sure) {
+    auto it = c->results.find(MHX_BUF_IS_SOLID);
+    if (it == c->results.end() || it->second.used < div_ceil(s.n_bases, 64) * 8)
+      throw Error("read2sdbg_s2: no is_solid bitmap (run mhx_read2sdbg_s1 or mhx_set_is_solid first)");
+    solid = it->second.as<unsigned long long>();
+  }
+
+  uint32_t *cnt = c->ws("seq_item_cnt", (ns + 1) * 4).as<uint32_t>();
+  uint64_t *item_start = c->ws("seq_item_start", (ns + 2) * 8).as<uint64_t>();
+  uint64_t n_items = 0;
+  const unsigned grid = 256 * 8;
+  if (ns) {
+    MHX_DISPATCH_KW(KWv, {
+      MHX_LAUNCH(c, "s2_count", (double)s.n_bases * 3 / 8 + (double)ns * 20,
+                 hipLaunchKernelGGL((k_s2_count<KW>), dim3(grid), dim3(256), 0, st, s.words.as<uint32_t>(), s.start.as<uint64_t>(), ns,
+                                    (int)k, solid, sure, cnt));
+    });
+    exclusive_scan_u32_u64(c, cnt, item_start, ns, item_start + ns + 1);
+    MHX_HIP(hipMemcpyAsync(&n_items, item_start + ns + 1, 8, hipMemcpyDeviceToHost, st));
+    MHX_HIP(hipStreamSynchronize(st));
+  }
+  const size_t item_bytes = (size_t)S * 4;
+  uint32_t *buf_a = c->ws("items_a", n_items * item_bytes + 64).as<uint32_t>();
+  uint32_t *buf_b = c->ws("items_b", n_items * item_bytes + 64).as<uint32_t>();
+  if (n_items) {
+    MHX_DISPATCH_KW(KWv, {
+      if (S == KW)
+        MHX_LAUNCH(c, "s2_extract", (double)n_items * item_bytes + (double)s.n_bases * 3 / 8,
+                   hipLaunchKernelGGL((k_s2_extract<KW, KW>), dim3(grid), dim3(256), 0, st, s.words.as<uint32_t>(), s.start.as<uint64_t>(),
+                                      item_start, ns, (int)k, solid, sure, buf_a));
+      else
+        MHX_LAUNCH(c, "s2_extract", (double)n_items * item_bytes + (double)s.n_bases * 3 / 8,
+                   hipLaunchKernelGGL((k_s2_extract<KW, KW + 1>), dim3(grid), dim3(256), 0, st, s.words.as<uint32_t>(),
+                                      s.start.as<uint64_t>(), item_start, ns, (int)k, solid, sure, buf_a));
+    });
+  }
+  const int char_bits = (int)k * 2;
+  uint32_t *sorted = radix_sort(c, buf_a, buf_b, n_items, S, KWv, make_passes_ranges(KWv, {{0, 4}, {KWv * 32 - char_bits, KWv * 32}}));
+  emit_sdbg(c, sorted, n_items, S, KWv, k, 0, out);
+  return 0;
+}
+
+}  // namespace mhx

@@ -22,6 +22,19 @@ def pack_reads(bases):
     return (pad << shifts).sum(axis=2, dtype=np.uint64).astype(np.uint32)
 
 
+def pack_reads_concat(bases):
+    """bases: uint8 [n, L] -> uint32 words of the gap-free concatenation (SequencePackage layout)."""
+    flat = np.ascontiguousarray(bases).reshape(-1)
+    pad = (-flat.size) % 16
+    if pad:
+        flat = np.concatenate([flat, np.zeros(pad, dtype=np.uint8)])
+    out = np.zeros(flat.size // 16, dtype=np.uint32)
+    f = flat.reshape(-1, 16)
+    for j in range(16):
+        out |= f[:, j].astype(np.uint32) << np.uint32(30 - 2 * j)
+    return out
+
+
 def gen_pe_reads(n_pairs, genome_len, read_len=150, frag=400, err=0.005, seed=1, genome=None):
     """-> uint8 [2*n_pairs, read_len] (reads interleaved r1,r2,r1,r2...)."""
     rng = np.random.default_rng(seed)

@@ -64,6 +64,9 @@ def lib():
         L.orc_s2.argtypes = [C.POINTER(Pkg), C.c_int, C.c_int, C.c_void_p, C.POINTER(SdbgOut)]
         L.orc_seq2sdbg.argtypes = [C.POINTER(Pkg), C.c_void_p, C.c_int, C.POINTER(SdbgOut)]
         L.orc_sdbg_free.argtypes = [C.POINTER(SdbgOut)]
+        L.orc_gen_mercy_edges.argtypes = [C.POINTER(Pkg), C.POINTER(C.POINTER(C.c_uint16)), C.POINTER(C.c_uint64),
+                                          C.POINTER(Pkg), C.c_int]
+        L.orc_gen_mercy_edges.restype = C.c_int64
         L.orc_sort_items.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int]
         _lib = L
     return _lib
@@ -173,3 +176,21 @@ def sort_items(items, key_words, kmsort=False):
     items = np.ascontiguousarray(items, dtype=np.uint32).copy()
     lib().orc_sort_items(items.ctypes.data, items.shape[0], items.shape[1], key_words, 1 if kmsort else 0)
     return items
+
+
+def gen_mercy_edges(edge_pkg, mult, cand_pkg, k):
+    """Appends mercy edges to edge_pkg (in place); returns (n_mercy, new multiplicity array)."""
+    L = lib()
+    libc = C.CDLL(None)
+    libc.malloc.restype = C.c_void_p
+    libc.malloc.argtypes = [C.c_size_t]
+    mult = np.ascontiguousarray(mult, dtype=np.uint16)
+    raw = libc.malloc(max(2, mult.size * 2))
+    C.memmove(raw, mult.ctypes.data, mult.size * 2)
+    mp = C.cast(raw, C.POINTER(C.c_uint16))
+    nm = C.c_uint64(mult.size)
+    n = L.orc_gen_mercy_edges(C.byref(edge_pkg.p), C.byref(mp), C.byref(nm), C.byref(cand_pkg.p), k)
+    out = np.ctypeslib.as_array(mp, shape=(nm.value,)).copy() if nm.value else np.zeros(0, dtype=np.uint16)
+    libc.free.argtypes = [C.c_void_p]
+    libc.free(C.cast(mp, C.c_void_p))
+    return n, out

@@ -1,0 +1,123 @@
+"""GPU parity for read2sdbg (S1, mercy, S2) and seq2sdbg (+ mercy edges) vs the C oracle, through the C ABI."""
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+from megahit_amd import lib
+from test_gpu_count import load, make_reads
+
+pytestmark = pytest.mark.gpu
+
+CASES = [("fixed", 21, 2), ("var", 21, 2), ("var", 27, 3), ("lowcomplex", 21, 2), ("var", 32, 2), ("var", 47, 2), ("fixed", 63, 2)]
+
+
+def check_sdbg(engine, r, want):
+    assert r.n_items == want["n_sort_items"]
+    assert r.words_per_tip_label == want["wpt"]
+    got = engine.fetch(lib.BUF_SDBG_BYTES, np.uint8)
+    assert got.size == want["bytes"].size == r.sdbg_bytes
+    assert np.array_equal(got, want["bytes"])
+    assert np.array_equal(engine.fetch(lib.BUF_BUCKET_COUNT, np.uint64), want["bucket_items"])
+    assert np.array_equal(engine.fetch(lib.BUF_BUCKET_TIPS, np.uint64), want["bucket_tips"])
+    assert np.array_equal(engine.fetch(lib.BUF_BUCKET_LARGE, np.uint64), want["bucket_large"])
+    nz = want["bucket_items"] > 0
+    assert np.array_equal(engine.fetch(lib.BUF_BUCKET_OFFSET, np.uint64)[nz], want["bucket_off"][nz])
+    wc = engine.fetch(lib.BUF_W_COUNT, np.uint64)
+    assert np.array_equal(wc[:9], want["w_count"]) and wc[9] == want["ones_in_last"]
+    assert r.n_sdbg == int(want["bucket_items"].sum()) and r.n_tips == int(want["bucket_tips"].sum())
+
+
+@pytest.mark.parametrize("kind,k,m", CASES)
+def test_read2sdbg_matches_oracle(engine, kind, k, m):
+    reads = make_reads(kind, 5)
+    pkg = ob.Package(reads, reverse=True)
+    w1 = ob.s1(pkg, k, m, tie_stable=True)
+    load(engine, pkg)
+    r1 = engine.read2sdbg_s1(k, m, want_mercy=True)
+    assert r1.n_items == w1["n_items"]
+    solid = engine.fetch(lib.BUF_IS_SOLID, np.uint64)
+    assert np.array_equal(solid, w1["is_solid"][: solid.size])
+    assert np.array_equal(engine.fetch(lib.BUF_MUL_HIST, np.int64), w1["hist"])
+    assert r1.n_solid == int(sum(bin(int(x)).count("1") for x in w1["is_solid"]))
+    mercy = engine.fetch(lib.BUF_MERCY_CAND, np.int64)
+    assert np.array_equal(mercy, w1["mercy"])
+    # S2 without mercy
+    r2 = engine.read2sdbg_s2(k, m)
+    check_sdbg(engine, r2, ob.s2(pkg, k, m, w1["is_solid"]))
+    # mercy block, then S2 again
+    n_want, solid_want = ob.s2_add_mercy(pkg, k, w1["is_solid"], w1["mercy"])
+    n_got = engine.read2sdbg_add_mercy(k)
+    assert n_got == n_want
+    assert np.array_equal(engine.fetch(lib.BUF_IS_SOLID, np.uint64), solid_want[: solid.size])
+    r3 = engine.read2sdbg_s2(k, m)
+    check_sdbg(engine, r3, ob.s2(pkg, k, m, solid_want))
+
+
+@pytest.mark.parametrize("kind,k", [("var", 21), ("lowcomplex", 27), ("fixed", 31)])
+def test_read2sdbg_min_count_1(engine, kind, k):
+    reads = make_reads(kind, 9)
+    pkg = ob.Package(reads, reverse=True)
+    load(engine, pkg)
+    r = engine.read2sdbg_s2(k, 1)  # for_sure_solid: S1 is skipped (main_sdbg_build.cpp:142-146)
+    check_sdbg(engine, r, ob.s2(pkg, k, 1, None))
+
+
+def edges_package(edges, k):
+    """count output -> (package of (k+1)-mers, multiplicities) as EdgeReader does."""
+    seqs = []
+    wpe = edges.shape[1]
+    for e in edges:
+        bases = np.empty(k + 1, dtype=np.uint8)
+        for j in range(k + 1):
+            bases[j] = (int(e[j >> 4]) >> (30 - 2 * (j & 15))) & 3
+        seqs.append(bases)
+    mult = (edges[:, wpe - 1] & 0xFFFF).astype(np.uint16) if len(edges) else np.zeros(0, dtype=np.uint16)
+    return seqs, mult
+
+
+@pytest.mark.parametrize("kind,k,m", [("fixed", 21, 2), ("var", 27, 2), ("var", 47, 2)])
+def test_seq2sdbg_from_edges_with_mercy(engine, kind, k, m):
+    reads = make_reads(kind, 3)
+    pkg = ob.Package(reads, reverse=True)
+    cnt = ob.count(pkg, k, m)
+    seqs, mult = edges_package(cnt["edges"], k)
+    epkg = ob.Package(seqs, reverse=False)
+    engine.load_sequences(epkg.words(), epkg.n_seqs, k + 1, None)
+    engine.load_multiplicity(mult)
+    r = engine.seq2sdbg(k)
+    check_sdbg(engine, r, ob.seq2sdbg(epkg, mult, k))
+    # mercy: candidate reads as KmerCounter::Lv0Postprocess selects them (kmer_counter.cpp:390-403)
+    first, last = cnt["first_0_out"], cnt["last_0_in"]
+    sel = [i for i in range(len(reads)) if first[i] != 0xFFFFFFFF and last[i] != 0xFFFFFFFF and last[i] > first[i]]
+    cand = ob.Package([reads[i][::-1] for i in sel], reverse=False)  # .cand holds the reversed reads
+    n_want, mult2 = ob.gen_mercy_edges(epkg, mult, cand, k)
+    engine.load_sequences(ob.Package(seqs, reverse=False).words(), len(seqs), k + 1, None)
+    engine.load_multiplicity(mult)
+    n_got = engine.gen_mercy_edges(k, cand.words(), cand.n_seqs, cand.start())
+    assert n_got == n_want
+    r2 = engine.seq2sdbg(k)
+    check_sdbg(engine, r2, ob.seq2sdbg(epkg, mult2, k))
+
+
+@pytest.mark.parametrize("k", [21, 29, 39, 59, 79, 99, 119, 141, 255])
+def test_seq2sdbg_wide_keys(engine, k):
+    """contig-like inputs at the k-list of BASELINE config 4 (item widths 2..9 words) and kmax."""
+    rng = np.random.default_rng(k)
+    genome = rng.integers(0, 4, size=6000, dtype=np.uint8)
+    seqs = []
+    for _ in range(120):
+        a = rng.integers(0, 5000)
+        L = rng.integers(k - 3, 900)
+        s = genome[a:a + L].copy()
+        if rng.random() < 0.5:
+            s = (3 - s)[::-1]
+        seqs.append(s)
+    seqs.append(np.zeros(k + 1, dtype=np.uint8))
+    seqs.append(np.zeros(3, dtype=np.uint8))
+    mult = rng.integers(0, 70000, size=len(seqs)).clip(0, 65535).astype(np.uint16)
+    mult[:5] = [0, 1, 254, 255, 65535]
+    pkg = ob.Package(seqs, reverse=True)
+    engine.load_sequences(pkg.words(), pkg.n_seqs, 0, pkg.start())
+    engine.load_multiplicity(mult)
+    r = engine.seq2sdbg(k)
+    check_sdbg(engine, r, ob.seq2sdbg(pkg, mult, k))
