@@ -61,6 +61,10 @@ int mhx_load_sequences(mhx_ctx *, const uint32_t *packed, uint64_t n_words, uint
  * concatenation happen on the GPU (replaces BinaryReader::Read + AppendReversedCompactSequence). */
 int mhx_load_bin_records(mhx_ctx *, const uint32_t *records, uint64_t n_words, uint64_t n_seqs,
                          int reverse);
+/* Append more sequences (and their multiplicities, may be NULL -> 0) behind the loaded set, as
+ * SeqToSdbg::Initialize does for contigs after edges (seq_to_sdbg.cpp:449-503). */
+int mhx_append_sequences(mhx_ctx *, const uint32_t *packed, uint64_t n_words, uint64_t n_seqs,
+                         uint32_t fixed_len, const uint64_t *start_pos, const uint16_t *mult);
 /* per-sequence multiplicities for seq2sdbg (seq_to_sdbg.h:80) */
 int mhx_load_multiplicity(mhx_ctx *, const uint16_t *mult, uint64_t n_seqs);
 uint64_t mhx_num_sequences(const mhx_ctx *);

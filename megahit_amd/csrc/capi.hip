@@ -1,4 +1,5 @@
 // C-ABI entry points of libmhx.so (declared in include/mhx.h) and context plumbing.
+#include <algorithm>
 #include <cstdarg>
 
 #include "dev_prims.h"
@@ -128,6 +129,85 @@ void upload_sequences(mhx_ctx *c, const uint32_t *packed, uint64_t n_words, uint
   MHX_HIP(hipStreamSynchronize(st));
 }
 
+// append host sequences behind the device-resident set (bit-unaligned: one thread per output word)
+__global__ void k_append_words(uint32_t *__restrict__ dst, uint64_t old_bases, uint64_t new_bases, const uint32_t *__restrict__ src) {
+  const uint64_t w = old_bases / 16 + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (w * 16 >= new_bases) return;
+  uint32_t word = 0;
+  for (int j = 0; j < 16; ++j) {
+    const uint64_t b = w * 16 + j;
+    unsigned ch = 0;
+    if (b < old_bases) ch = (dst[w] >> (30 - 2 * j)) & 3u;
+    else if (b < new_bases) ch = base_at(src, b - old_bases);
+    word |= ch << (30 - 2 * j);
+  }
+  dst[w] = word;
+}
+__global__ void k_offset_starts(uint64_t *__restrict__ start, uint64_t from, uint64_t n_new, const uint64_t *__restrict__ rel, uint32_t fixed_len,
+                                uint64_t base) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i <= n_new) start[from + i] = base + (rel ? rel[i] : i * fixed_len);
+}
+
+static void grow_keep(mhx_ctx *c, DevBuf &b, size_t new_bytes, size_t keep_bytes) {
+  if (b.cap >= new_bytes) return;
+  DevBuf nb;
+  nb.reserve(new_bytes);
+  if (keep_bytes && b.p) MHX_HIP(hipMemcpyAsync(nb.p, b.p, keep_bytes, hipMemcpyDeviceToDevice, c->stream));
+  MHX_HIP(hipStreamSynchronize(c->stream));
+  nb.used = b.used;
+  b.release();
+  b = nb;
+}
+
+void append_sequences(mhx_ctx *c, const uint32_t *packed, uint64_t n_words, uint64_t n_new, uint32_t fixed_len, const uint64_t *start_pos,
+                      const uint16_t *mult) {
+  SeqSet &s = c->seqs;
+  hipStream_t st = c->stream;
+  if (n_new == 0) return;
+  const uint64_t add_bases = start_pos ? start_pos[n_new] : n_new * (uint64_t)fixed_len;
+  if (add_bases > n_words * 16) throw Error("append_sequences: start_pos/n_seqs exceed the packed buffer");
+  const uint64_t old_bases = s.n_bases, new_bases = old_bases + add_bases, new_words = div_ceil(new_bases, 16);
+  const uint64_t old_seqs = s.n_seqs, new_seqs = old_seqs + n_new;
+  const bool had_mult = s.mult.used >= old_seqs * 2 && (old_seqs > 0 || mult);
+  grow_keep(c, s.words, (new_words + kSeqPadWords) * 4, (s.n_words + 1) * 4);
+  grow_keep(c, s.start, (new_seqs + 2) * 8, (old_seqs + 1) * 8);
+  uint32_t *src = c->ws("append_words", (n_words + kSeqPadWords) * 4).as<uint32_t>();
+  MHX_HIP(hipMemcpyAsync(src, packed, n_words * 4, hipMemcpyHostToDevice, st));
+  const uint64_t first_w = old_bases / 16;
+  const uint64_t zero_from = (old_bases % 16 == 0) ? first_w : first_w + 1;
+  MHX_HIP(hipMemsetAsync(s.words.as<uint32_t>() + zero_from, 0, (new_words + kSeqPadWords - zero_from) * 4, st));
+  const uint64_t n_w = new_words - first_w;
+  MHX_LAUNCH(c, "append_words", (double)n_w * 8,
+             hipLaunchKernelGGL(k_append_words, dim3((unsigned)div_ceil(n_w, 256)), dim3(256), 0, st, s.words.as<uint32_t>(), old_bases,
+                                new_bases, src));
+  uint64_t *rel = nullptr;
+  if (start_pos) {
+    rel = c->ws("append_start", (n_new + 1) * 8).as<uint64_t>();
+    MHX_HIP(hipMemcpyAsync(rel, start_pos, (n_new + 1) * 8, hipMemcpyHostToDevice, st));
+  }
+  hipLaunchKernelGGL(k_offset_starts, dim3((unsigned)div_ceil(n_new + 1, 256)), dim3(256), 0, st, s.start.as<uint64_t>(), old_seqs, n_new, rel,
+                     fixed_len, old_bases);
+  MHX_HIP(hipGetLastError());
+  if (had_mult || mult) {
+    grow_keep(c, s.mult, (new_seqs + 1) * 2, old_seqs * 2);
+    if (mult) MHX_HIP(hipMemcpyAsync(s.mult.as<uint16_t>() + old_seqs, mult, n_new * 2, hipMemcpyHostToDevice, st));
+    else MHX_HIP(hipMemsetAsync(s.mult.as<uint16_t>() + old_seqs, 0, n_new * 2, st));
+    s.mult.used = new_seqs * 2;
+  }
+  uint32_t mx = s.max_len;
+  if (start_pos) {
+    for (uint64_t i = 0; i < n_new; ++i) mx = std::max<uint32_t>(mx, (uint32_t)(start_pos[i + 1] - start_pos[i]));
+  } else mx = std::max(mx, fixed_len);
+  const bool still_fixed = !start_pos && (old_seqs == 0 || s.fixed_len == fixed_len);
+  s.fixed_len = still_fixed ? fixed_len : 0;
+  s.max_len = mx;
+  s.n_seqs = new_seqs;
+  s.n_bases = new_bases;
+  s.n_words = new_words;
+  MHX_HIP(hipStreamSynchronize(st));
+}
+
 // .bin record stream -> (reversed) concatenated store, on the GPU.
 // Host walks the record headers (one uint32 per read) to get lengths; bases are moved by a kernel.
 __global__ void k_unpack_records(const uint32_t *__restrict__ rec, const uint64_t *__restrict__ rec_off, const uint64_t *__restrict__ start,
@@ -165,7 +245,6 @@ void upload_bin_records(mhx_ctx *c, const uint32_t *records, uint64_t n_words, u
   std::vector<uint64_t> rec_off(n_seqs + 1), start(n_seqs + 1);
   uint64_t pos = 0, bases = 0;
   uint32_t mx = 0;
-  static const uint32_t kFake[2] = {1u, 0u};
   bool has_empty = false;
   for (uint64_t i = 0; i < n_seqs; ++i) {
     if (pos >= n_words) throw Error("load_bin_records: truncated record stream");
@@ -179,7 +258,6 @@ void upload_bin_records(mhx_ctx *c, const uint32_t *records, uint64_t n_words, u
   }
   if (pos > n_words) throw Error("load_bin_records: truncated record stream");
   start[n_seqs] = bases;
-  (void)kFake;
   hipStream_t st = c->stream;
   SeqSet &s = c->seqs;
   // an empty read's record has no payload word: give it one zero word by copying records with a pad
@@ -188,7 +266,6 @@ void upload_bin_records(mhx_ctx *c, const uint32_t *records, uint64_t n_words, u
   uint64_t src_words = n_words;
   if (has_empty) {
     patched.reserve(n_words + 1024);
-    uint64_t p2 = 0;
     for (uint64_t i = 0; i < n_seqs; ++i) {
       uint32_t L = records[rec_off[i]];
       uint64_t nw = (L + 15) / 16;
@@ -197,7 +274,6 @@ void upload_bin_records(mhx_ctx *c, const uint32_t *records, uint64_t n_words, u
       if (L == 0) patched.push_back(0u);
       else patched.insert(patched.end(), records + rec_off[i] + 1, records + rec_off[i] + 1 + nw);
       rec_off[i] = new_off;
-      (void)p2;
     }
     src = patched.data();
     src_words = patched.size();
@@ -307,6 +383,13 @@ int mhx_load_sequences(mhx_ctx *c, const uint32_t *packed, uint64_t n_words, uin
   MHX_TRY({
     MHX_HIP(hipSetDevice(c->device));
     mhx::upload_sequences(c, packed, n_words, n_seqs, fixed_len, start_pos);
+  })
+}
+int mhx_append_sequences(mhx_ctx *c, const uint32_t *packed, uint64_t n_words, uint64_t n_seqs, uint32_t fixed_len,
+                         const uint64_t *start_pos, const uint16_t *mult) {
+  MHX_TRY({
+    MHX_HIP(hipSetDevice(c->device));
+    mhx::append_sequences(c, packed, n_words, n_seqs, fixed_len, start_pos, mult);
   })
 }
 int mhx_load_bin_records(mhx_ctx *c, const uint32_t *records, uint64_t n_words, uint64_t n_seqs, int reverse) {

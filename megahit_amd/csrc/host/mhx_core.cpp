@@ -1,0 +1,376 @@
+// mhx_core — drop-in for `megahit_core count | read2sdbg | seq2sdbg` (reference
+// src/main_sdbg_build.cpp:35-224, dispatched from src/main.cpp:68-110): same flags, same on-disk
+// inputs and outputs, the sorting engines replaced by libmhx (HIP, gfx950) through its C ABI.
+//
+// Sub-programs outside the SdBG-construction path (buildlib, assemble, iterate, local, ...) are not
+// implemented here; when MHX_REF_CORE names a reference `megahit_core` binary they are forwarded to
+// it unchanged, so the unmodified `megahit` orchestrator can run with this binary in place.
+#include <unistd.h>
+
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "formats.h"
+#include "mhx.h"
+
+using mhxio::fatal;
+using mhxio::info;
+
+namespace {
+
+struct Timer {
+  std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+  double lap() {
+    auto t1 = std::chrono::steady_clock::now();
+    double s = std::chrono::duration<double>(t1 - t0).count();
+    t0 = t1;
+    return s;
+  }
+};
+
+// OptionsDescription (reference src/utils/options_description.cpp:33-96): long options take their
+// value as the next argument (or --name=value), bool options take none, unknown options are errors.
+struct Options {
+  struct Opt {
+    std::string long_name, short_name;
+    bool is_flag;
+    std::string value;
+    bool seen = false;
+  };
+  std::vector<Opt> opts;
+  void add(const char *l, const char *s, bool flag, const char *def) { opts.push_back({l, s, flag, def}); }
+  void parse(int argc, char **argv) {
+    for (int i = 1; i < argc; ++i) {
+      std::string a = argv[i], name, val;
+      bool has_val = false;
+      Opt *o = nullptr;
+      if (a.rfind("--", 0) == 0) {
+        size_t eq = a.find('=');
+        name = a.substr(2, eq == std::string::npos ? std::string::npos : eq - 2);
+        if (eq != std::string::npos) { val = a.substr(eq + 1); has_val = true; }
+        for (auto &x : opts) if (x.long_name == name) o = &x;
+      } else if (a.size() >= 2 && a[0] == '-') {
+        name = a.substr(1, 1);
+        if (a.size() > 2) { val = a.substr(2); has_val = true; }
+        for (auto &x : opts) if (!x.short_name.empty() && x.short_name == name) o = &x;
+      } else {
+        continue;  // positional arguments are ignored, as getopt_long permutes them away
+      }
+      if (!o) throw std::string("Invalid option ") + a;
+      o->seen = true;
+      if (o->is_flag) { o->value = "1"; continue; }
+      if (!has_val) {
+        if (i + 1 >= argc) throw std::string("Option ") + a + " requires an argument";
+        val = argv[++i];
+      }
+      o->value = val;
+    }
+  }
+  const std::string &get(const char *l) const {
+    for (auto &x : opts) if (x.long_name == l) return x.value;
+    static std::string empty;
+    return empty;
+  }
+  void usage() const {
+    for (auto &x : opts)
+      fprintf(stderr, "  %s--%s %s\n", x.short_name.empty() ? "" : ("-" + x.short_name + ", ").c_str(), x.long_name.c_str(),
+              x.is_flag ? "" : "<arg>");
+  }
+};
+
+int num_threads_or_all(int n) {
+  if (n > 0) return n;
+  unsigned hc = std::thread::hardware_concurrency();
+  return hc ? (int)hc : 1;
+}
+
+mhx_ctx *open_gpu() {
+  int dev = 0;
+  if (const char *e = getenv("MHX_DEVICE")) dev = atoi(e);
+  mhx_ctx *c = mhx_create(dev);
+  if (!c) fatal("%s", mhx_last_error());
+  return c;
+}
+#define CK(call)                                  \
+  do {                                            \
+    if ((call) != 0) fatal("%s", mhx_last_error()); \
+  } while (0)
+
+template <class T>
+std::vector<T> fetch(mhx_ctx *c, int which) {
+  uint64_t bytes = mhx_buffer_bytes(c, which);
+  std::vector<T> v(bytes / sizeof(T));
+  if (bytes) CK(mhx_fetch(c, which, v.data(), 0, bytes));
+  return v;
+}
+
+int out_files(int n_threads) {
+  if (const char *e = getenv("MHX_NUM_OUT_FILES")) return std::max(1, std::min(atoi(e), n_threads));
+  return 1;
+}
+
+struct ReadLib {
+  std::vector<uint32_t> rec;
+  std::vector<uint64_t> off;
+};
+ReadLib load_read_lib(mhx_ctx *c, const std::string &prefix) {
+  int64_t bases, reads;
+  mhxio::read_lib_info(prefix, &bases, &reads);
+  ReadLib lib;
+  lib.rec = mhxio::read_bin_file(prefix + ".bin");
+  lib.off = mhxio::index_bin_records(lib.rec);
+  if ((int64_t)lib.off.size() != reads) info("lib_info says %lld reads, .bin holds %zu", (long long)reads, lib.off.size());
+  CK(mhx_load_bin_records(c, lib.rec.data(), lib.rec.size(), lib.off.size(), 1 /* reversed, kmer_counter.cpp:61 */));
+  return lib;
+}
+
+// ---------------------------------------------------------------------------
+int main_kmer_count(int argc, char **argv) {
+  Options o;
+  o.add("kmer_k", "k", false, "21");
+  o.add("min_kmer_frequency", "m", false, "2");
+  o.add("host_mem", "", false, "0");
+  o.add("num_cpu_threads", "", false, "0");
+  o.add("read_lib_file", "", false, "");
+  o.add("output_prefix", "", false, "out");
+  o.add("mem_flag", "", false, "1");
+  try {
+    o.parse(argc, argv);
+    if (o.get("read_lib_file").empty()) throw std::string("No read library configuration file!");
+    if (atof(o.get("host_mem").c_str()) == 0) throw std::string("Please specify the host memory!");
+  } catch (std::string &e) {
+    fprintf(stderr, "%s\nUsage: sdbg_builder count --input_file fastx_file -o out\nOptions:\n", e.c_str());
+    o.usage();
+    exit(1);
+  }
+  const uint32_t k = (uint32_t)atoi(o.get("kmer_k").c_str()), m = (uint32_t)atoi(o.get("min_kmer_frequency").c_str());
+  const int n_threads = num_threads_or_all(atoi(o.get("num_cpu_threads").c_str()));
+  const std::string out = o.get("output_prefix");
+  Timer t;
+  mhx_ctx *c = open_gpu();
+  info("Preparing data...");
+  ReadLib lib = load_read_lib(c, o.get("read_lib_file"));
+  info("%llu reads; Preparing data... Done. Time elapsed: %.4f", (unsigned long long)mhx_num_sequences(c), t.lap());
+  mhx_count_result r;
+  CK(mhx_count(c, k, m, &r));
+  info("GPU count: %llu items, %llu distinct, %llu solid. Time elapsed: %.4f", (unsigned long long)r.n_items,
+       (unsigned long long)r.n_distinct, (unsigned long long)r.n_edges, t.lap());
+  auto edges = fetch<uint32_t>(c, MHX_BUF_EDGES);
+  auto bcount = fetch<uint64_t>(c, MHX_BUF_BUCKET_COUNT);
+  auto first = fetch<uint32_t>(c, MHX_BUF_FIRST_0_OUT), last = fetch<uint32_t>(c, MHX_BUF_LAST_0_IN);
+  auto hist = fetch<int64_t>(c, MHX_BUF_MUL_HIST);
+  mhxio::write_edges(out, k, r.words_per_edge, edges.data(), r.n_edges, bcount.data(), out_files(n_threads));
+  int64_t n_cand = 0, n_tips = 0;
+  mhxio::write_cand(out, lib.rec, lib.off, first.data(), last.data(), &n_cand, &n_tips);
+  mhxio::write_counting(out, hist.data());
+  info("Total number of candidate reads: %lld (%lld)", (long long)n_cand, (long long)n_tips);
+  info("Total number of solid edges: %llu", (unsigned long long)r.n_edges);
+  info("Postprocess done. Time elapsed: %.4f", t.lap());
+  mhx_destroy(c);
+  return 0;
+}
+
+void report_sdbg(mhx_ctx *c, const mhx_sdbg_result &r) {
+  auto wc = fetch<uint64_t>(c, MHX_BUF_W_COUNT);
+  info("Number of $ A C G T A- C- G- T-:");
+  fprintf(stderr, "INFO  ");
+  for (int i = 0; i < 9; ++i) fprintf(stderr, "%llu ", (unsigned long long)wc[i]);
+  fprintf(stderr, "\n");
+  info("Total number of edges: %llu", (unsigned long long)r.n_sdbg);
+  info("Total number of ONEs: %llu", (unsigned long long)wc[9]);
+  info("Total number of $v edges: %llu", (unsigned long long)r.n_tips);
+}
+void write_sdbg_from_gpu(mhx_ctx *c, const std::string &out, uint32_t k, const mhx_sdbg_result &r, int n_files) {
+  auto bytes = fetch<uint8_t>(c, MHX_BUF_SDBG_BYTES);
+  auto off = fetch<uint64_t>(c, MHX_BUF_BUCKET_OFFSET), items = fetch<uint64_t>(c, MHX_BUF_BUCKET_COUNT);
+  auto tips = fetch<uint64_t>(c, MHX_BUF_BUCKET_TIPS), large = fetch<uint64_t>(c, MHX_BUF_BUCKET_LARGE);
+  mhxio::write_sdbg(out, k, r.words_per_tip_label, bytes.data(), bytes.size(), off.data(), items.data(), tips.data(), large.data(), n_files);
+}
+
+int main_read2sdbg(int argc, char **argv) {
+  Options o;
+  o.add("kmer_k", "k", false, "21");
+  o.add("min_kmer_frequency", "m", false, "2");
+  o.add("host_mem", "", false, "0");
+  o.add("num_cpu_threads", "", false, "0");
+  o.add("read_lib_file", "", false, "");
+  o.add("output_prefix", "", false, "out");
+  o.add("mem_flag", "", false, "1");
+  o.add("need_mercy", "", true, "");
+  try {
+    o.parse(argc, argv);
+    if (o.get("read_lib_file").empty()) throw std::string("No input file!");
+    if (atof(o.get("host_mem").c_str()) == 0) throw std::string("Please specify the host memory!");
+  } catch (std::string &e) {
+    fprintf(stderr, "%s\nUsage: sdbg_builder read2sdbg --read_lib_file fastx_file -o out\nOptions:\n", e.c_str());
+    o.usage();
+    exit(1);
+  }
+  const uint32_t k = (uint32_t)atoi(o.get("kmer_k").c_str()), m = (uint32_t)atoi(o.get("min_kmer_frequency").c_str());
+  const int n_threads = num_threads_or_all(atoi(o.get("num_cpu_threads").c_str()));
+  const bool need_mercy = !o.get("need_mercy").empty();
+  const std::string out = o.get("output_prefix");
+  Timer t;
+  mhx_ctx *c = open_gpu();
+  info("Preparing data...");
+  load_read_lib(c, o.get("read_lib_file"));
+  info("%llu reads, %llu total bases; Preparing data... Done. Time elapsed: %.4f", (unsigned long long)mhx_num_sequences(c),
+       (unsigned long long)mhx_num_bases(c), t.lap());
+  if (m > 1) {  // stage 1 is skipped when every edge is solid (main_sdbg_build.cpp:139-147)
+    mhx_s1_result r1;
+    CK(mhx_read2sdbg_s1(c, k, m, need_mercy ? 1 : 0, &r1));
+    auto hist = fetch<int64_t>(c, MHX_BUF_MUL_HIST);
+    int64_t n_solid_edges = 0;
+    for (uint32_t i = m; i <= 65535; ++i) n_solid_edges += hist[i];
+    info("Total number of solid edges: %lld", (long long)n_solid_edges);
+    mhxio::write_counting(out, hist.data());
+    info("Stage 1 done (%llu items, %llu solid occurrences). Time elapsed: %.4f", (unsigned long long)r1.n_items,
+         (unsigned long long)r1.n_solid, t.lap());
+    if (need_mercy) {
+      info("Adding mercy edges...");
+      uint64_t nm = 0;
+      CK(mhx_read2sdbg_add_mercy(c, k, &nm));
+      info("Adding mercy Done. Time elapsed: %.4f", t.lap());
+      info("Number mercy: %llu", (unsigned long long)nm);
+    }
+  }
+  mhx_sdbg_result r2;
+  CK(mhx_read2sdbg_s2(c, k, m, &r2));
+  info("Stage 2 done (%llu items). Time elapsed: %.4f", (unsigned long long)r2.n_items, t.lap());
+  write_sdbg_from_gpu(c, out, k, r2, out_files(n_threads));
+  report_sdbg(c, r2);
+  info("Postprocess done. Time elapsed: %.4f", t.lap());
+  mhx_destroy(c);
+  return 0;
+}
+
+int main_seq2sdbg(int argc, char **argv) {
+  Options o;
+  o.add("host_mem", "", false, "0");
+  o.add("kmer_size", "k", false, "0");
+  o.add("kmer_from", "", false, "0");
+  o.add("num_cpu_threads", "t", false, "0");
+  o.add("contig", "", false, "");
+  o.add("bubble", "", false, "");
+  o.add("addi_contig", "", false, "");
+  o.add("local_contig", "", false, "");
+  o.add("input_prefix", "", false, "");
+  o.add("output_prefix", "o", false, "");
+  o.add("need_mercy", "", true, "");
+  o.add("mem_flag", "", false, "1");
+  try {
+    o.parse(argc, argv);
+    if (o.get("input_prefix").empty() && o.get("contig").empty() && o.get("addi_contig").empty()) throw std::string("No input files!");
+    if (atoi(o.get("kmer_size").c_str()) < 9) throw std::string("kmer size must be >= 9!");
+    if (atof(o.get("host_mem").c_str()) == 0) throw std::string("Please specify the host memory!");
+  } catch (std::string &e) {
+    fprintf(stderr,
+            "%s\nUsage: sdbg_builder seq2sdbg -k kmer_size --contig contigs.fa [--addi_contig add.fa] [--input_prefix input] -o out\nOptions:\n",
+            e.c_str());
+    o.usage();
+    exit(1);
+  }
+  const uint32_t k = (uint32_t)atoi(o.get("kmer_size").c_str()), k_from = (uint32_t)atoi(o.get("kmer_from").c_str());
+  const int n_threads = num_threads_or_all(atoi(o.get("num_cpu_threads").c_str()));
+  const bool need_mercy = !o.get("need_mercy").empty();
+  const std::string in = o.get("input_prefix"), out = o.get("output_prefix");
+  Timer t;
+  mhx_ctx *c = open_gpu();
+  bool loaded = false;
+  if (!in.empty()) {
+    mhxio::EdgeSet es = mhxio::read_edges(in);
+    info("Number edges: %llu", (unsigned long long)es.n_edges());
+    // edges -> gap-free (k+1)-mer store + multiplicities (EdgeReader::ReadSorted/ReadUnsorted, edge_reader.h:24-52)
+    mhxio::PackedSeqs pk;
+    std::vector<uint16_t> mult(es.n_edges());
+    pk.words.reserve(es.n_edges() * (es.k + 1) / 16 + 2);
+    for (uint64_t i = 0; i < es.n_edges(); ++i) {
+      const uint32_t *e = &es.raw[i * es.words_per_edge];
+      pk.append_packed(e, es.k + 1, false);
+      mult[i] = (uint16_t)(e[es.words_per_edge - 1] & 0xFFFF);
+    }
+    CK(mhx_load_sequences(c, pk.words.data(), pk.words.size(), es.n_edges(), es.k + 1, nullptr));
+    CK(mhx_load_multiplicity(c, mult.data(), mult.size()));
+    loaded = true;
+    info("Read %llu edges. Time elapsed: %.4f", (unsigned long long)es.n_edges(), t.lap());
+    if (need_mercy) {
+      info("Adding mercy edges...");
+      std::vector<uint32_t> rec = mhxio::read_bin_file(in + ".cand");
+      std::vector<uint64_t> off = mhxio::index_bin_records(rec);
+      mhxio::PackedSeqs cand;
+      for (size_t i = 0; i < off.size(); ++i) cand.append_packed(&rec[off[i] + 1], rec[off[i]], false);
+      uint64_t nm = 0;
+      CK(mhx_gen_mercy_edges(c, k, cand.words.data(), cand.words.size(), cand.n_seqs(), cand.start.data(), &nm));
+      info("Number of reads: %llu, Number of mercy edges: %llu", (unsigned long long)cand.n_seqs(), (unsigned long long)nm);
+      info("Done. Time elapsed: %.4f", t.lap());
+    }
+  }
+  // contigs (reversed; loop contigs extended k_from -> k), bubble, addi, local: seq_to_sdbg.cpp:449-503
+  mhxio::PackedSeqs contigs;
+  std::vector<uint16_t> cmult;
+  auto read_one = [&](const std::string &f, unsigned kf, unsigned kt) {
+    if (f.empty()) return;
+    int64_t n = mhxio::read_contigs(f, &contigs, &cmult, k + 1, kf, kt, true);
+    info("Read %lld contigs from %s.", (long long)n, f.c_str());
+  };
+  if (!o.get("contig").empty()) {
+    read_one(o.get("contig"), k_from, k);
+    read_one(o.get("bubble"), 0, 0);
+  }
+  read_one(o.get("addi_contig"), 0, 0);
+  read_one(o.get("local_contig"), 0, 0);
+  if (contigs.n_seqs()) {
+    if (loaded)
+      CK(mhx_append_sequences(c, contigs.words.data(), contigs.words.size(), contigs.n_seqs(), 0, contigs.start.data(), cmult.data()));
+    else {
+      CK(mhx_load_sequences(c, contigs.words.data(), contigs.words.size(), contigs.n_seqs(), 0, contigs.start.data()));
+      CK(mhx_load_multiplicity(c, cmult.data(), cmult.size()));
+    }
+    loaded = true;
+  }
+  if (!loaded) {
+    uint64_t zero = 0;
+    uint32_t w = 0;
+    CK(mhx_load_sequences(c, &w, 0, 0, 0, &zero));
+    uint16_t mz = 0;
+    CK(mhx_load_multiplicity(c, &mz, 0));
+  }
+  info("Finally, %llu sequences, %llu bases. Time elapsed: %.4f", (unsigned long long)mhx_num_sequences(c),
+       (unsigned long long)mhx_num_bases(c), t.lap());
+  mhx_sdbg_result r;
+  CK(mhx_seq2sdbg(c, k, &r));
+  info("GPU seq2sdbg done (%llu items). Time elapsed: %.4f", (unsigned long long)r.n_items, t.lap());
+  write_sdbg_from_gpu(c, out, k, r, out_files(n_threads));
+  report_sdbg(c, r);
+  info("Postprocess done. Time elapsed: %.4f", t.lap());
+  mhx_destroy(c);
+  return 0;
+}
+
+}  // namespace
+
+int main(int argc, char **argv) {
+  if (argc < 2) {
+    fprintf(stderr, "Usage: %s <sub_program> [sub options]\n    sub-programs: count read2sdbg seq2sdbg (GPU); others via MHX_REF_CORE\n", argv[0]);
+    return 1;
+  }
+  const std::string sub = argv[1];
+  if (sub == "count") return main_kmer_count(argc - 1, argv + 1);
+  if (sub == "read2sdbg") return main_read2sdbg(argc - 1, argv + 1);
+  if (sub == "seq2sdbg") return main_seq2sdbg(argc - 1, argv + 1);
+  if (sub == "kmax") { printf("%d\n", MHX_MAX_K); return 0; }
+  if (const char *ref = getenv("MHX_REF_CORE")) {
+    execv(ref, argv);  // buildlib / assemble / iterate / local / ... : not on this path
+    perror("execv MHX_REF_CORE");
+    return 1;
+  }
+  fprintf(stderr, "sub-program '%s' is outside the SdBG-construction path; set MHX_REF_CORE to a reference megahit_core to forward it\n",
+          sub.c_str());
+  return 1;
+}

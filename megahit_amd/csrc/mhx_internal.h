@@ -146,6 +146,8 @@ int run_gen_mercy(mhx_ctx *c, uint32_t k, const uint32_t *cand_packed, uint64_t 
 void upload_sequences(mhx_ctx *c, const uint32_t *packed, uint64_t n_words, uint64_t n_seqs, uint32_t fixed_len,
                       const uint64_t *start_pos);
 void upload_fixed_starts(mhx_ctx *c);
+void append_sequences(mhx_ctx *c, const uint32_t *packed, uint64_t n_words, uint64_t n_new, uint32_t fixed_len, const uint64_t *start_pos,
+                      const uint16_t *mult);
 void upload_bin_records(mhx_ctx *c, const uint32_t *records, uint64_t n_words, uint64_t n_seqs, int reverse);
 
 inline int round_up2(int x) { return (x + 1) & ~1; }

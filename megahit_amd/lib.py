@@ -68,6 +68,7 @@ SYMBOLS = {
     "mhx_synchronize": (C.c_int, [_P]),
     "mhx_load_sequences": (C.c_int, [_P, _P, C.c_uint64, C.c_uint64, C.c_uint32, _P]),
     "mhx_load_bin_records": (C.c_int, [_P, _P, C.c_uint64, C.c_uint64, C.c_int]),
+    "mhx_append_sequences": (C.c_int, [_P, _P, C.c_uint64, C.c_uint64, C.c_uint32, _P, _P]),
     "mhx_load_multiplicity": (C.c_int, [_P, _P, C.c_uint64]),
     "mhx_num_sequences": (C.c_uint64, [_P]),
     "mhx_num_bases": (C.c_uint64, [_P]),
@@ -147,6 +148,14 @@ class Engine:
     def load_bin_records(self, records, n_seqs, reverse=True):
         records = np.ascontiguousarray(records, dtype=np.uint32)
         self._chk(self.lib.mhx_load_bin_records(self.h, _ptr(records), records.size, n_seqs, int(reverse)))
+
+    def append_sequences(self, packed, n_seqs, fixed_len=0, start_pos=None, mult=None):
+        packed = np.ascontiguousarray(packed, dtype=np.uint32)
+        if start_pos is not None:
+            start_pos = np.ascontiguousarray(start_pos, dtype=np.uint64)
+        if mult is not None:
+            mult = np.ascontiguousarray(mult, dtype=np.uint16)
+        self._chk(self.lib.mhx_append_sequences(self.h, _ptr(packed), packed.size, n_seqs, fixed_len, _ptr(start_pos), _ptr(mult)))
 
     def load_multiplicity(self, mult):
         mult = np.ascontiguousarray(mult, dtype=np.uint16)
