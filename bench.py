@@ -1,0 +1,195 @@
+#!/usr/bin/env python
+"""Benchmark of the SdBG-construction hot path on MI355X (contract: see the task's bench.py section).
+
+A "step" is one pass of `read2sdbg` (stage 1 + stage 2, k=21, min count 2, no mercy) over one batch of
+synthetic 150 bp paired-end reads that is already resident in HBM (BASELINE.json configs[1]: 10 M reads
+per GPU).  metric = M (k+1)-mer edge occurrences sorted+counted per second, E = sum(max(0, len-k)).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--reads R] [--no-cpu-baseline]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+K = 21
+MIN_COUNT = 2
+READ_LEN = 150
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E datasheet peak (MI355X_MICROARCH.md)
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def make_reads(n_reads, rank, world):
+    """Reads of this rank: PE fragments from ONE genome shared by all ranks (G = 2.5 bp per read in the
+    whole job, i.e. ~60x coverage as in SURVEY.md §8d), per-rank read seed.  Returned reversed+packed."""
+    import numpy as np
+    from megahit_amd import synth
+    total_reads = n_reads * world
+    G = max(5000, int(total_reads * 2.5))
+    genome = np.random.default_rng(1).integers(0, 4, size=G, dtype=np.uint8)
+    chunks = []
+    step = 1000000
+    for i, lo in enumerate(range(0, n_reads // 2, step)):
+        n = min(step, n_reads // 2 - lo)
+        r = synth.gen_pe_reads(n, G, read_len=READ_LEN, frag=400, err=0.005, seed=1000 * (rank + 1) + i, genome=genome)
+        chunks.append(synth.pack_reads_concat(r[:, ::-1]))  # stored reversed, as the reference loads them
+    # every chunk is a whole number of words only if n*2*150 % 16 == 0: true for n multiple of 8
+    return np.concatenate(chunks)
+
+
+def cpu_baseline(sample_reads):
+    """The reference's own CPU path (oracle/_ref/ref_core = reference sources compiled in place) on a
+    bounded sample of the same workload, all host cores.  Falls back to the C port (oracle_core)."""
+    import numpy as np
+    from megahit_amd import synth
+    ref = os.path.join(ROOT, "oracle", "_ref", "ref_core")
+    port = os.path.join(ROOT, "oracle", "oracle_core")
+    cores = os.cpu_count() or 1
+    G = max(5000, int(sample_reads * 2.5))
+    reads = synth.gen_pe_reads(sample_reads // 2, G, read_len=READ_LEN, frag=400, err=0.005, seed=77)
+    E = reads.shape[0] * (READ_LEN - K)
+    with tempfile.TemporaryDirectory(prefix="mhx_cpu_") as d:
+        synth.write_read_lib(os.path.join(d, "reads"), [reads])
+        if os.path.exists(ref):
+            kind, exe, used = "reference", ref, cores
+            cmd = [exe, "read2sdbg", "-k", str(K), "-m", str(MIN_COUNT), "--host_mem", "32e9", "--num_cpu_threads", str(cores),
+                   "--read_lib_file", os.path.join(d, "reads"), "--output_prefix", os.path.join(d, "out")]
+        else:
+            if not os.path.exists(port):
+                subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "oracle"])
+            kind, exe, used = "port", port, 1
+            cmd = [exe, "read2sdbg", "-k", str(K), "-m", str(MIN_COUNT), "--read_lib_file", os.path.join(d, "reads"),
+                   "--output_prefix", os.path.join(d, "out")]
+        t0 = time.perf_counter()
+        subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        dt = time.perf_counter() - t0
+    return {"value": round(E / dt / 1e6, 3), "unit": "M edges/s", "cores": used, "kind": kind,
+            "sample": "read2sdbg k=%d m=%d on %d synthetic %d bp reads (%.1f M edges), wall %.1f s incl. file I/O"
+                      % (K, MIN_COUNT, reads.shape[0], READ_LEN, E / 1e6, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--reads", type=float, default=10e6, help="reads per GPU (BASELINE configs[1]: 10 M)")
+    ap.add_argument("--cpu-sample-reads", type=float, default=400e3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+
+    import numpy as np
+    import torch
+    from megahit_amd import lib
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (libmhx has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    n_reads = int(args.reads) // 16 * 16
+    t0 = time.time()
+    packed = make_reads(n_reads, rank, world)
+    log("[rank %d] generated %d reads in %.1f s" % (rank, n_reads, time.time() - t0))
+
+    eng = lib.Engine(local_rank)
+    eng.load_sequences(packed, n_reads, READ_LEN, None)  # H2D happens here, outside the timed region
+    E = n_reads * (READ_LEN - K)
+
+    if world > 1:
+        import torch.distributed as dist
+        from megahit_amd import dist as mdist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        runner = mdist.DistRead2Sdbg(eng, K, MIN_COUNT, rank, world, device=torch.device("cuda", local_rank))
+        step = runner.step
+
+        def barrier():
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+    else:
+        def step():
+            r1 = eng.read2sdbg_s1(K, MIN_COUNT)
+            r2 = eng.read2sdbg_s2(K, MIN_COUNT)
+            return r1, r2
+
+        def barrier():
+            eng.synchronize()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        res = step()
+    barrier()
+    eng.profile(True)
+    eng.profile_reset()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    stats = eng.profile_get()
+    eng.profile(False)
+
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        ms_step = dt / args.steps * 1e3
+        value = E * world * args.steps / dt / 1e6
+        # dominant kernel by total time
+        name, ks = max(stats.items(), key=lambda kv: kv[1]["ms"])
+        per_launch_bytes = ks["bytes"] / ks["launches"]
+        per_launch_ms = ks["ms"] / ks["launches"]
+        achieved = per_launch_bytes / per_launch_ms / 1e6  # GB/s
+        roof = {"bound": "hbm", "kernel": name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "launches_per_step": ks["launches"] // max(1, args.steps), "avg_launch_ms": round(per_launch_ms, 4),
+                "algo_bytes_per_launch": per_launch_bytes,
+                "kernel_ms_per_step": {k2: round(v["ms"] / args.steps, 3) for k2, v in sorted(stats.items(), key=lambda kv: -kv[1]["ms"])}}
+        out = {"metric": "M (k+1)-mer edges sorted+counted/sec, sdbg_build k=21", "value": round(value, 2), "unit": "M edges/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 3),
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+               "config": {"workload": "read2sdbg (S1+S2) k=21 m=2 no mercy, %d synthetic 150 bp PE reads per GPU "
+                                      "(BASELINE configs[1]), inputs resident in HBM, outputs left in HBM" % n_reads,
+                          "reads_per_gpu": n_reads, "edges_per_gpu": E, "k": K, "min_count": MIN_COUNT,
+                          "parallelism": "1 GPU" if world == 1 else "lv1 buckets over %d GPUs, all-to-all" % world},
+               "roofline": roof}
+        if world == 1:
+            r1, r2 = res
+            out["config"]["s1_items"] = int(r1.n_items)
+            out["config"]["s2_items"] = int(r2.n_items)
+            out["config"]["sdbg_records"] = int(r2.n_sdbg)
+            if not args.no_cpu_baseline:
+                try:
+                    out["cpu_baseline"] = cpu_baseline(int(args.cpu_sample_reads) // 2 * 2)
+                except Exception as ex:  # the baseline is reporting only; never lose the GPU number
+                    out["cpu_baseline"] = {"value": None, "error": str(ex)}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+    eng.close()
+
+
+if __name__ == "__main__":
+    main()
