@@ -147,16 +147,35 @@ int mhx_gen_mercy_edges(mhx_ctx *, uint32_t k, const uint32_t *cand_packed, uint
  * along.  Replaces SelectSortingFunc(key_words, aux_words) (kmsort_selector.cpp:61-63).  Stable. */
 int mhx_sort_records(mhx_ctx *, uint32_t *host_items, uint64_t n, uint32_t key_words, uint32_t aux_words);
 
-/* ---- multi-GPU: the lv1 buckets are partitioned over `n_parts` owners.
- * With a partition set, engines keep only items whose bucket belongs to `my_part`
- * (the reference's OffsetFiller::IsHandling filter, base_engine.h:106-108) unless an item
- * exchange is installed with mhx_set_exchange. ---- */
+/* ---- multi-GPU: one handle per GPU/process.  The 65536 lv1 buckets are split into
+ * contiguous owner ranges; every rank extracts the items of ITS reads, partitions them by owner
+ * (one stable multisplit pass), the caller moves them with an all-to-all on its own communication
+ * backend (RCCL via torch.distributed in megahit_amd/dist.py), and every rank sorts + reduces the
+ * buckets it owns — the reference's OffsetFiller::IsHandling bucket filter (base_engine.h:106-108)
+ * turned into an exchange.  Supported for read2sdbg without mercy (BASELINE configs[2]). ---- */
 int mhx_set_partition(mhx_ctx *, int my_part, int n_parts, const uint32_t *bucket_begin /* n_parts+1 */);
-/* all-to-all of device buffers: send_counts/recv_counts in bytes per peer; implemented by the
- * caller on its communication backend (RCCL through torch.distributed in megahit_amd/dist.py). */
-typedef int (*mhx_exchange_fn)(void *user, const void *d_send, const uint64_t *send_bytes,
-                               void *d_recv, const uint64_t *recv_bytes, int n_parts);
-int mhx_set_exchange(mhx_ctx *, mhx_exchange_fn fn, void *user);
+/* This rank's reads sit at base offset pos_base of a global read set of global_bases bases
+ * (is_solid then spans the global set).  (0, 0) switches the global layout off. */
+int mhx_set_global_layout(mhx_ctx *, uint64_t pos_base, uint64_t global_bases);
+enum mhx_stage { MHX_STAGE_S1 = 1, MHX_STAGE_S2 = 2 };
+typedef struct {
+  void *d_items;       /* device pointer: items grouped by owner, owners ascending */
+  uint64_t n_items;
+  uint32_t item_bytes;
+} mhx_dist_items;
+/* extract + partition; counts[p] = items destined to owner p (n_parts entries) */
+int mhx_dist_extract(mhx_ctx *, int stage, uint32_t k, uint32_t min_count, mhx_dist_items *out, uint64_t *counts);
+/* library-owned device buffer to receive n_items items into */
+void *mhx_dist_recv_buffer(mhx_ctx *, uint64_t n_items, uint32_t item_bytes);
+/* sort + reduce the received items: S1 sets bits of the GLOBAL is_solid bitmap (MHX_BUF_IS_SOLID),
+ * S2 emits the SdBG records of the owned buckets */
+int mhx_dist_process_s1(mhx_ctx *, uint32_t k, uint32_t min_count, uint64_t n_items, mhx_s1_result *out);
+int mhx_dist_process_s2(mhx_ctx *, uint32_t k, uint64_t n_items, mhx_sdbg_result *out);
+/* raw device pointer of a result buffer (for collectives on it); NULL if absent */
+void *mhx_device_pointer(mhx_ctx *, int which);
+/* after the bitmap reduction: install this rank's slice (device pointer, n_words uint64) as the
+ * local is_solid used by stage 2 */
+int mhx_adopt_is_solid_slice(mhx_ctx *, const void *d_words, uint64_t n_words);
 
 /* ---- measurement ---- */
 typedef struct {

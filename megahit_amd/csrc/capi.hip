@@ -497,18 +497,90 @@ int mhx_sort_records(mhx_ctx *c, uint32_t *host_items, uint64_t n, uint32_t key_
 
 int mhx_set_partition(mhx_ctx *c, int my_part, int n_parts, const uint32_t *bucket_begin) {
   MHX_TRY({
-    if (n_parts < 1 || my_part < 0 || my_part >= n_parts) throw mhx::Error("set_partition: bad arguments");
+    if (n_parts < 1 || n_parts > 256 || my_part < 0 || my_part >= n_parts) throw mhx::Error("set_partition: bad arguments");
+    std::vector<uint32_t> pb(bucket_begin, bucket_begin + n_parts + 1);
+    if (pb.front() != 0 || pb.back() != MHX_NUM_BUCKETS) throw mhx::Error("set_partition: bucket_begin must start at 0 and end at 65536");
+    std::vector<uint8_t> lut(MHX_NUM_BUCKETS);
+    for (int p = 0; p < n_parts; ++p) {
+      if (pb[p] > pb[p + 1]) throw mhx::Error("set_partition: bucket_begin must be non-decreasing");
+      for (uint32_t b = pb[p]; b < pb[p + 1]; ++b) lut[b] = (uint8_t)p;
+    }
     c->my_part = my_part;
     c->n_parts = n_parts;
-    c->part_begin.assign(bucket_begin, bucket_begin + n_parts + 1);
-    if (c->part_begin.front() != 0 || c->part_begin.back() != MHX_NUM_BUCKETS)
-      throw mhx::Error("set_partition: bucket_begin must start at 0 and end at 65536");
+    c->part_begin = pb;
+    mhx::DevBuf &d = c->ws("owner_lut", MHX_NUM_BUCKETS);
+    MHX_HIP(hipMemcpyAsync(d.p, lut.data(), MHX_NUM_BUCKETS, hipMemcpyHostToDevice, c->stream));
+    MHX_HIP(hipStreamSynchronize(c->stream));
   })
 }
-int mhx_set_exchange(mhx_ctx *c, mhx_exchange_fn fn, void *user) {
-  c->exchange = fn;
-  c->exchange_user = user;
-  return 0;
+int mhx_set_global_layout(mhx_ctx *c, uint64_t pos_base, uint64_t global_bases) {
+  MHX_TRY({
+    if (global_bases && pos_base + c->seqs.n_bases > global_bases) throw mhx::Error("set_global_layout: local reads exceed the global set");
+    c->pos_base = pos_base;
+    c->global_bases = global_bases;
+  })
+}
+int mhx_dist_extract(mhx_ctx *c, int stage, uint32_t k, uint32_t min_count, mhx_dist_items *out, uint64_t *counts) {
+  MHX_TRY({
+    MHX_HIP(hipSetDevice(c->device));
+    if (c->work.find("owner_lut") == c->work.end()) throw mhx::Error("dist_extract: call mhx_set_partition first");
+    uint64_t n = 0;
+    int S = 0;
+    if (stage == MHX_STAGE_S1) {
+      n = mhx::s1_extract(c, k);
+      S = mhx::round_up2((int)mhx::div_ceil((k - 1) * 2 + 6, 32) + 2);
+    } else if (stage == MHX_STAGE_S2) {
+      n = mhx::s2_extract(c, k, min_count);
+      S = mhx::round_up2((int)mhx::div_ceil(k * 2 + 4, 32));
+    } else throw mhx::Error("dist_extract: unknown stage");
+    uint32_t *a = c->work["items_a"].as<uint32_t>();
+    uint32_t *send = c->ws("items_send", n * (size_t)S * 4 + 64).as<uint32_t>();
+    mhx::partition_by_owner(c, a, send, n, S, c->work["owner_lut"].as<uint8_t>(), c->n_parts, counts);
+    out->d_items = send;
+    out->n_items = n;
+    out->item_bytes = (uint32_t)S * 4;
+  })
+}
+void *mhx_dist_recv_buffer(mhx_ctx *c, uint64_t n_items, uint32_t item_bytes) {
+  try {
+    MHX_HIP(hipSetDevice(c->device));
+    return c->ws("items_recv", n_items * (size_t)item_bytes + 64).p;
+  } catch (const std::exception &e) {
+    mhx::set_error("%s", e.what());
+    return nullptr;
+  }
+}
+int mhx_dist_process_s1(mhx_ctx *c, uint32_t k, uint32_t min_count, uint64_t n_items, mhx_s1_result *out) {
+  MHX_TRY({
+    MHX_HIP(hipSetDevice(c->device));
+    const int S = mhx::round_up2((int)mhx::div_ceil((k - 1) * 2 + 6, 32) + 2);
+    uint32_t *a = c->ws("items_recv", n_items * (size_t)S * 4 + 64).as<uint32_t>();
+    uint32_t *b = c->ws("items_b", n_items * (size_t)S * 4 + 64).as<uint32_t>();
+    mhx::s1_process(c, k, min_count, 0, a, b, n_items, out);
+  })
+}
+int mhx_dist_process_s2(mhx_ctx *c, uint32_t k, uint64_t n_items, mhx_sdbg_result *out) {
+  MHX_TRY({
+    MHX_HIP(hipSetDevice(c->device));
+    const int S = mhx::round_up2((int)mhx::div_ceil(k * 2 + 4, 32));
+    uint32_t *a = c->ws("items_recv", n_items * (size_t)S * 4 + 64).as<uint32_t>();
+    uint32_t *b = c->ws("items_b", n_items * (size_t)S * 4 + 64).as<uint32_t>();
+    mhx::s2_process(c, k, a, b, n_items, out);
+  })
+}
+void *mhx_device_pointer(mhx_ctx *c, int which) {
+  auto it = c->results.find(which);
+  return it == c->results.end() ? nullptr : it->second.p;
+}
+int mhx_adopt_is_solid_slice(mhx_ctx *c, const void *d_words, uint64_t n_words) {
+  MHX_TRY({
+    const uint64_t need = mhx::div_ceil(c->seqs.n_bases, 64);
+    if (n_words < need) throw mhx::Error("adopt_is_solid_slice: slice shorter than the local reads");
+    mhx::DevBuf &b = c->result(mhx::MHX_BUF_IS_SOLID_LOCAL, (need + 1) * 8);
+    b.used = need * 8;
+    if (need) MHX_HIP(hipMemcpyAsync(b.p, d_words, need * 8, hipMemcpyDeviceToDevice, c->stream));
+    MHX_HIP(hipStreamSynchronize(c->stream));
+  })
 }
 
 int mhx_profile_enable(mhx_ctx *c, int on) {

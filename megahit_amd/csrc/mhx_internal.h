@@ -72,11 +72,10 @@ struct mhx_ctx {
   std::map<int, mhx::DevBuf> results;      // keyed by enum mhx_buffer
   std::map<std::string, mhx::DevBuf> work; // named scratch workspaces
   uint32_t sorted_item_words = 0;
-  // partition
+  // multi-GPU: lv1-bucket partition and this rank's place in the global read set
   int my_part = 0, n_parts = 1;
   std::vector<uint32_t> part_begin;
-  mhx_exchange_fn exchange = nullptr;
-  void *exchange_user = nullptr;
+  uint64_t pos_base = 0, global_bases = 0;
   // profiling
   bool profiling = false;
   std::vector<mhx::PendingEvent> pending;
@@ -134,6 +133,14 @@ uint64_t count_group_heads(mhx_ctx *c, const uint32_t *items, uint64_t n, int st
 std::vector<SortPass> make_passes_ranges(int key_words, const std::vector<std::pair<int, int>> &ranges);
 // s2.hip: SdBG records from sorted lv2 items (shared by read2sdbg S2 and seq2sdbg)
 void emit_sdbg(mhx_ctx *c, const uint32_t *sorted, uint64_t n_items, int S, int kw, uint32_t k, int is_seq, mhx_sdbg_result *out);
+
+void partition_by_owner(mhx_ctx *c, const uint32_t *a, uint32_t *b, uint64_t n, int stride, const uint8_t *lut, int n_parts,
+                        uint64_t *counts);
+uint64_t s1_extract(mhx_ctx *c, uint32_t k);
+int s1_process(mhx_ctx *c, uint32_t k, uint32_t m, int want_mercy, uint32_t *buf_a, uint32_t *buf_b, uint64_t n_items, mhx_s1_result *out);
+uint64_t s2_extract(mhx_ctx *c, uint32_t k, uint32_t m);
+int s2_process(mhx_ctx *c, uint32_t k, uint32_t *buf_a, uint32_t *buf_b, uint64_t n_items, mhx_sdbg_result *out);
+constexpr int MHX_BUF_IS_SOLID_LOCAL = 100;  // internal: this rank's slice of the global bitmap (multi-GPU)
 
 // ---- engines ----
 int run_count(mhx_ctx *c, uint32_t k, uint32_t m, mhx_count_result *out);

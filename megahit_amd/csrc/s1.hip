@@ -28,7 +28,7 @@ __global__ void k_s1_item_counts(const uint64_t *__restrict__ start, uint64_t n_
 template <int KW, int S>
 __global__ __launch_bounds__(256) void k_s1_extract(const uint32_t *__restrict__ seq, const uint64_t *__restrict__ start,
                                                     const uint64_t *__restrict__ item_start, uint64_t n_seqs, int k,
-                                                    uint32_t *__restrict__ items) {
+                                                    uint64_t pos_base, uint32_t *__restrict__ items) {
   const int lane = lane_id();
   const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / kWave;
   const uint64_t n_waves = (uint64_t)gridDim.x * blockDim.x / kWave;
@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void k_s1_extract(const uint32_t *__restrict__
         else if (c < 0) strand = 0;
         else strand = head <= 3 - tail ? 0 : 1;  // palindrome rule, :264-279 (head/tail are bases here)
       }
-      const uint64_t full = ((st + q) << 1) | (uint64_t)strand;
+      const uint64_t full = ((pos_base + st + q) << 1) | (uint64_t)strand;  // pos_base: this rank's offset in the global read set
       uint64_t info;
       uint32_t out[S];
       if (!strand) {
@@ -201,14 +201,16 @@ __global__ void k_swap_words(uint32_t *__restrict__ v, uint64_t n) {
   }
 }
 
-int run_s1(mhx_ctx *c, uint32_t k, uint32_t m, int want_mercy, mhx_s1_result *out) {
+// ---- host driver, in two halves so that the multi-GPU path can exchange items in between ----
+static int s1_kw(uint32_t k) { return (int)div_ceil((k - 1) * 2 + 6, 32); }  // read_to_sdbg_s1.cpp:107-108
+
+// items of the local reads -> c->ws("items_a"); returns their number
+uint64_t s1_extract(mhx_ctx *c, uint32_t k) {
   SeqSet &s = c->seqs;
   if (k < 9 || k > MHX_MAX_K) throw Error("read2sdbg: k out of range [9,255]");
-  const int KWv = (int)div_ceil((k - 1) * 2 + 6, 32);  // read_to_sdbg_s1.cpp:107-108
-  const int S = round_up2(KWv + 2);
+  const int KWv = s1_kw(k), S = round_up2(KWv + 2);
   const uint64_t ns = s.n_seqs;
   hipStream_t st = c->stream;
-
   uint32_t *cnt = c->ws("seq_item_cnt", (ns + 1) * 4).as<uint32_t>();
   uint64_t *item_start = c->ws("seq_item_start", (ns + 2) * 8).as<uint64_t>();
   uint64_t n_items = 0;
@@ -221,32 +223,38 @@ int run_s1(mhx_ctx *c, uint32_t k, uint32_t m, int want_mercy, mhx_s1_result *ou
   }
   const size_t item_bytes = (size_t)S * 4;
   uint32_t *buf_a = c->ws("items_a", n_items * item_bytes + 64).as<uint32_t>();
-  uint32_t *buf_b = c->ws("items_b", n_items * item_bytes + 64).as<uint32_t>();
   if (n_items) {
     const unsigned grid = 256 * 8;
     MHX_DISPATCH_KW(KWv, {
       if (S == KW + 2)
         MHX_LAUNCH(c, "s1_extract", (double)n_items * item_bytes + (double)s.n_bases / 4,
                    hipLaunchKernelGGL((k_s1_extract<KW, KW + 2>), dim3(grid), dim3(256), 0, st, s.words.as<uint32_t>(),
-                                      s.start.as<uint64_t>(), item_start, ns, (int)k, buf_a));
+                                      s.start.as<uint64_t>(), item_start, ns, (int)k, c->pos_base, buf_a));
       else
         MHX_LAUNCH(c, "s1_extract", (double)n_items * item_bytes + (double)s.n_bases / 4,
                    hipLaunchKernelGGL((k_s1_extract<KW, KW + 3>), dim3(grid), dim3(256), 0, st, s.words.as<uint32_t>(),
-                                      s.start.as<uint64_t>(), item_start, ns, (int)k, buf_a));
+                                      s.start.as<uint64_t>(), item_start, ns, (int)k, c->pos_base, buf_a));
     });
   }
+  return n_items;
+}
+
+// sort + group reduction of n_items items held in buf_a (buf_b = ping-pong space of the same size)
+int s1_process(mhx_ctx *c, uint32_t k, uint32_t m, int want_mercy, uint32_t *buf_a, uint32_t *buf_b, uint64_t n_items,
+               mhx_s1_result *out) {
+  SeqSet &s = c->seqs;
+  const int KWv = s1_kw(k), S = round_up2(KWv + 2);
+  const uint64_t ns = s.n_seqs;
+  const size_t item_bytes = (size_t)S * 4;
+  hipStream_t st = c->stream;
+  const bool global = c->global_bases != 0;  // multi-GPU: positions index the global read set
+  if (global && want_mercy) throw Error("read2sdbg_s1: mercy candidates are not supported in multi-GPU mode");
   const int kmer_bits = (int)(k - 1) * 2;
-  std::vector<SortPass> passes = make_passes(KWv, 0, 6);
-  {
-    std::vector<SortPass> hi = make_passes(KWv, KWv * 32 - kmer_bits, KWv * 32);
-    // the (head,tail) bits may overlap the last k-mer digit range only if they share a word with
-    // k-mer bits; they never overlap bit-wise (6 + 2(k-1) <= 32*KW)
-    passes.insert(passes.end(), hi.begin(), hi.end());
-  }
-  uint32_t *sorted = radix_sort(c, buf_a, buf_b, n_items, S, KWv, passes);
+  uint32_t *sorted = radix_sort(c, buf_a, buf_b, n_items, S, KWv, make_passes_ranges(KWv, {{0, 6}, {KWv * 32 - kmer_bits, KWv * 32}}));
   uint32_t *spare = sorted == buf_a ? buf_b : buf_a;
 
-  const uint64_t n_words64 = div_ceil(s.n_bases, 64);
+  const uint64_t n_bits = global ? c->global_bases : s.n_bases;
+  const uint64_t n_words64 = div_ceil(n_bits, 64);
   unsigned long long *is_solid = c->result(MHX_BUF_IS_SOLID, (n_words64 + 1) * 8).as<unsigned long long>();
   c->results[MHX_BUF_IS_SOLID].used = n_words64 * 8;
   unsigned long long *hist = c->result(MHX_BUF_MUL_HIST, (MHX_MAX_MUL + 1) * 8).as<unsigned long long>();
@@ -302,6 +310,15 @@ int run_s1(mhx_ctx *c, uint32_t k, uint32_t m, int want_mercy, mhx_s1_result *ou
     out->item_words = S;
   }
   return 0;
+}
+
+int run_s1(mhx_ctx *c, uint32_t k, uint32_t m, int want_mercy, mhx_s1_result *out) {
+  if (c->global_bases) throw Error("read2sdbg_s1: a global layout is set; use the mhx_dist_* entry points");
+  const uint64_t n_items = s1_extract(c, k);
+  const int S = round_up2(s1_kw(k) + 2);
+  uint32_t *buf_a = c->work["items_a"].as<uint32_t>();
+  uint32_t *buf_b = c->ws("items_b", n_items * (size_t)S * 4 + 64).as<uint32_t>();
+  return s1_process(c, k, m, want_mercy, buf_a, buf_b, n_items, out);
 }
 
 }  // namespace mhx

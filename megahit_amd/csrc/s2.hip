@@ -369,22 +369,23 @@ std::vector<SortPass> make_passes_ranges(int key_words, const std::vector<std::p
   return p;
 }
 
-int run_s2(mhx_ctx *c, uint32_t k, uint32_t m, mhx_sdbg_result *out) {
+static int s2_kw(uint32_t k) { return (int)div_ceil(k * 2 + 4, 32); }  // read_to_sdbg_s2.cpp:98-99
+
+// items of the local reads -> c->ws("items_a"); returns their number
+uint64_t s2_extract(mhx_ctx *c, uint32_t k, uint32_t m) {
   SeqSet &s = c->seqs;
   if (k < 9 || k > MHX_MAX_K) throw Error("read2sdbg: k out of range [9,255]");
-  const int KWv = (int)div_ceil(k * 2 + 4, 32);  // read_to_sdbg_s2.cpp:98-99
-  const int S = round_up2(KWv);
+  const int KWv = s2_kw(k), S = round_up2(KWv);
   const uint64_t ns = s.n_seqs;
   hipStream_t st = c->stream;
   const int sure = m == 1;  // for_sure_solid, :295
   const unsigned long long *solid = nullptr;
   if (!sure) {
-    auto it = c->results.find(MHX_BUF_IS_SOLID);
+    auto it = c->results.find(c->global_bases ? MHX_BUF_IS_SOLID_LOCAL : MHX_BUF_IS_SOLID);
     if (it == c->results.end() || it->second.used < div_ceil(s.n_bases, 64) * 8)
       throw Error("read2sdbg_s2: no is_solid bitmap (run mhx_read2sdbg_s1 or mhx_set_is_solid first)");
     solid = it->second.as<unsigned long long>();
   }
-
   uint32_t *cnt = c->ws("seq_item_cnt", (ns + 1) * 4).as<uint32_t>();
   uint64_t *item_start = c->ws("seq_item_start", (ns + 2) * 8).as<uint64_t>();
   uint64_t n_items = 0;
@@ -401,7 +402,6 @@ int run_s2(mhx_ctx *c, uint32_t k, uint32_t m, mhx_sdbg_result *out) {
   }
   const size_t item_bytes = (size_t)S * 4;
   uint32_t *buf_a = c->ws("items_a", n_items * item_bytes + 64).as<uint32_t>();
-  uint32_t *buf_b = c->ws("items_b", n_items * item_bytes + 64).as<uint32_t>();
   if (n_items) {
     MHX_DISPATCH_KW(KWv, {
       if (S == KW)
@@ -414,10 +414,24 @@ int run_s2(mhx_ctx *c, uint32_t k, uint32_t m, mhx_sdbg_result *out) {
                                       s.start.as<uint64_t>(), item_start, ns, (int)k, solid, sure, buf_a));
     });
   }
+  return n_items;
+}
+
+int s2_process(mhx_ctx *c, uint32_t k, uint32_t *buf_a, uint32_t *buf_b, uint64_t n_items, mhx_sdbg_result *out) {
+  const int KWv = s2_kw(k), S = round_up2(KWv);
   const int char_bits = (int)k * 2;
   uint32_t *sorted = radix_sort(c, buf_a, buf_b, n_items, S, KWv, make_passes_ranges(KWv, {{0, 4}, {KWv * 32 - char_bits, KWv * 32}}));
   emit_sdbg(c, sorted, n_items, S, KWv, k, 0, out);
   return 0;
+}
+
+int run_s2(mhx_ctx *c, uint32_t k, uint32_t m, mhx_sdbg_result *out) {
+  if (c->global_bases) throw Error("read2sdbg_s2: a global layout is set; use the mhx_dist_* entry points");
+  const uint64_t n_items = s2_extract(c, k, m);
+  const int S = round_up2(s2_kw(k));
+  uint32_t *buf_a = c->work["items_a"].as<uint32_t>();
+  uint32_t *buf_b = c->ws("items_b", n_items * (size_t)S * 4 + 64).as<uint32_t>();
+  return s2_process(c, k, buf_a, buf_b, n_items, out);
 }
 
 }  // namespace mhx

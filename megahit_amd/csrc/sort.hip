@@ -73,7 +73,8 @@ __device__ __forceinline__ unsigned rec_digit(const Rec<S> &r, int wi, unsigned 
 
 template <int S>
 __global__ __launch_bounds__(kSortThreads) void k_radix_hist(const uint32_t *__restrict__ items, uint64_t n, int wi, unsigned bit,
-                                                             unsigned mask, uint32_t *__restrict__ hist, uint64_t n_chunks) {
+                                                             unsigned mask, uint32_t *__restrict__ hist, uint64_t n_chunks,
+                                                             const uint8_t *__restrict__ lut) {
   __shared__ uint32_t h[kSortWaves][256];
   for (int i = threadIdx.x; i < kSortWaves * 256; i += kSortThreads) (&h[0][0])[i] = 0;
   __syncthreads();
@@ -84,9 +85,14 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_hist(const uint32_t *__r
     uint64_t idx = base + (uint64_t)j * kSortThreads + threadIdx.x;
     if (idx < n) {
       const uint32_t *p = items + idx * S;
-      uint64_t v = p[wi];
-      if (straddle) v |= (uint64_t)p[wi - 1] << 32;
-      atomicAdd(&h[w][(unsigned)(v >> bit) & mask], 1u);
+      unsigned d;
+      if (lut) d = lut[p[0] >> 16];  // digit = owner of the item's lv1 bucket
+      else {
+        uint64_t v = p[wi];
+        if (straddle) v |= (uint64_t)p[wi - 1] << 32;
+        d = (unsigned)(v >> bit) & mask;
+      }
+      atomicAdd(&h[w][d], 1u);
     }
   }
   __syncthreads();
@@ -102,7 +108,8 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_hist(const uint32_t *__r
 template <int S>
 __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(const uint32_t *__restrict__ in, uint32_t *__restrict__ out, uint64_t n,
                                                                 int wi, unsigned bit, unsigned mask, int nbits,
-                                                                const uint64_t *__restrict__ offs, uint64_t n_chunks) {
+                                                                const uint64_t *__restrict__ offs, uint64_t n_chunks,
+                                                                const uint8_t *__restrict__ lut) {
   using Cfg = SortCfg<S>;
   constexpr int ITEMS = Cfg::kItems;
   __shared__ __attribute__((aligned(16))) uint32_t stage[Cfg::kTile * S];
@@ -134,7 +141,7 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(const uint32_t *
       const int li = w * (kWave * ITEMS) + j * kWave + lane;
       const bool valid = li < tile_n;
       if (valid) load_rec<S>(in + (tile_base + li) * S, rec[j]);
-      unsigned d = valid ? rec_digit<S>(rec[j], wi, bit, mask) : 0u;
+      unsigned d = valid ? (lut ? (unsigned)lut[rec[j].w[0] >> 16] : rec_digit<S>(rec[j], wi, bit, mask)) : 0u;
       dig[j] = d;
       // match-any over the digit bits
       uint64_t peers = __ballot(valid);
@@ -183,7 +190,7 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(const uint32_t *
       if (li < tile_n) {
         Rec<S> r;
         load_rec<S>(stage + (size_t)li * S, r);
-        const unsigned d = rec_digit<S>(r, wi, bit, mask);
+        const unsigned d = lut ? (unsigned)lut[r.w[0] >> 16] : rec_digit<S>(r, wi, bit, mask);
         store_rec<S>(out + (uint64_t)(g_off[d] + li) * S, r);
       }
     }
@@ -211,14 +218,58 @@ static uint32_t *radix_sort_impl(mhx_ctx *c, uint32_t *a, uint32_t *b, uint64_t 
     const unsigned bit = ps.shift % 32, mask = (1u << ps.bits) - 1;
     MHX_LAUNCH(c, "radix_hist", bytes,
                hipLaunchKernelGGL(k_radix_hist<S>, dim3((unsigned)n_chunks), dim3(kSortThreads), 0, c->stream, a, n, wi, bit, mask,
-                                  hist, n_chunks));
+                                  hist, n_chunks, (const uint8_t *)nullptr));
     exclusive_scan_u32_u64(c, hist, offs, n_chunks * 256, nullptr);
     MHX_LAUNCH(c, "radix_scatter", 2 * bytes,
                hipLaunchKernelGGL(k_radix_scatter<S>, dim3((unsigned)n_chunks), dim3(kSortThreads), 0, c->stream, a, b, n, wi, bit,
-                                  mask, ps.bits, offs, n_chunks));
+                                  mask, ps.bits, offs, n_chunks, (const uint8_t *)nullptr));
     std::swap(a, b);
   }
   return a;
+}
+
+// One stable multisplit pass: digit = owner_lut[item.w[0] >> 16].  Items of owner p end up contiguous
+// in `b`, owners ascending; counts[p] receives their numbers.
+template <int S>
+static void partition_impl(mhx_ctx *c, const uint32_t *a, uint32_t *b, uint64_t n, const uint8_t *lut, int n_parts, uint64_t *counts) {
+  for (int p = 0; p < n_parts; ++p) counts[p] = 0;
+  if (n == 0) return;
+  const uint64_t n_chunks = div_ceil(n, SortCfg<S>::kChunk);
+  uint32_t *hist = c->ws("sort_hist", n_chunks * 256 * 4).as<uint32_t>();
+  uint64_t *offs = c->ws("sort_offs", (n_chunks * 256 + 1) * 8).as<uint64_t>();
+  const double bytes = (double)n * S * 4;
+  int nbits = 1;
+  while ((1 << nbits) < n_parts) ++nbits;
+  MHX_LAUNCH(c, "owner_hist", bytes,
+             hipLaunchKernelGGL(k_radix_hist<S>, dim3((unsigned)n_chunks), dim3(kSortThreads), 0, c->stream, a, n, 0, 0u, 0xFFu, hist,
+                                n_chunks, lut));
+  exclusive_scan_u32_u64(c, hist, offs, n_chunks * 256, offs + n_chunks * 256);
+  MHX_LAUNCH(c, "owner_scatter", 2 * bytes,
+             hipLaunchKernelGGL(k_radix_scatter<S>, dim3((unsigned)n_chunks), dim3(kSortThreads), 0, c->stream, a, b, n, 0, 0u, 0xFFu,
+                                nbits, offs, n_chunks, lut));
+  std::vector<uint64_t> starts(n_parts + 1);
+  for (int p = 0; p <= n_parts; ++p)
+    MHX_HIP(hipMemcpyAsync(&starts[p], offs + (uint64_t)p * n_chunks, 8, hipMemcpyDeviceToHost, c->stream));
+  MHX_HIP(hipStreamSynchronize(c->stream));
+  for (int p = 0; p < n_parts; ++p) counts[p] = starts[p + 1] - starts[p];
+}
+
+void partition_by_owner(mhx_ctx *c, const uint32_t *a, uint32_t *b, uint64_t n, int stride, const uint8_t *lut, int n_parts,
+                        uint64_t *counts) {
+  if (n_parts > 256) throw Error("partition_by_owner: at most 256 owners");
+  switch (stride) {
+    case 2: return partition_impl<2>(c, a, b, n, lut, n_parts, counts);
+    case 4: return partition_impl<4>(c, a, b, n, lut, n_parts, counts);
+    case 6: return partition_impl<6>(c, a, b, n, lut, n_parts, counts);
+    case 8: return partition_impl<8>(c, a, b, n, lut, n_parts, counts);
+    case 10: return partition_impl<10>(c, a, b, n, lut, n_parts, counts);
+    case 12: return partition_impl<12>(c, a, b, n, lut, n_parts, counts);
+    case 14: return partition_impl<14>(c, a, b, n, lut, n_parts, counts);
+    case 16: return partition_impl<16>(c, a, b, n, lut, n_parts, counts);
+    case 18: return partition_impl<18>(c, a, b, n, lut, n_parts, counts);
+    case 20: return partition_impl<20>(c, a, b, n, lut, n_parts, counts);
+    default: throw Error("partition_by_owner: unsupported record stride");
+  }
 }
 
 uint32_t *radix_sort(mhx_ctx *c, uint32_t *a, uint32_t *b, uint64_t n, int stride, int key_words,

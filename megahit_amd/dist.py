@@ -1,0 +1,143 @@
+"""Multi-GPU read2sdbg: one process per GPU, lv1 buckets sharded over ranks, items moved with an
+all-to-all (RCCL over xGMI through torch.distributed; `gloo` on CPU for tests).
+
+Per stage (S1, then S2) every rank
+  1. extracts the items of ITS reads and partitions them by bucket owner   (engine.dist_extract)
+  2. exchanges per-owner counts, then the items themselves                (all_to_all_single)
+  3. sorts and reduces the buckets it owns                                (engine.dist_process_*)
+After S1 the global is_solid bitmap (every bit is set by exactly one rank, because every (k+1)-mer
+occurrence lives in exactly one (k-1)-mer item: reference src/sorting/read_to_sdbg_s1.cpp:259-292,464)
+is summed over ranks and each rank keeps the slice covering its own reads for S2.
+
+The reference has no counterpart: it shards buckets over OpenMP threads inside one process
+(reference src/sorting/base_engine.cpp:213-223,318-327).  `engine` is anything with the phased
+interface of megahit_amd.lib.Engine; tests drive the same class on CPU tensors with an oracle-backed
+stand-in, so the communication logic is covered without GPUs.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+NUM_BUCKETS = 65536
+STAGE_S1 = 1
+STAGE_S2 = 2
+BUF_IS_SOLID = 6
+
+
+class _DevPtr:
+    """Expose a raw device pointer to torch through the CUDA array interface (works on ROCm builds)."""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
+
+
+def device_bytes(ptr, nbytes, device):
+    """uint8 tensor aliasing [ptr, ptr+nbytes) of device memory owned by libmhx."""
+    if nbytes == 0:
+        return torch.empty(0, dtype=torch.uint8, device=device)
+    return torch.as_tensor(_DevPtr(ptr, nbytes), device=device)
+
+
+def equal_partition(world):
+    """bucket_begin[world+1]: contiguous, equally wide bucket ranges."""
+    return np.array([(NUM_BUCKETS * r) // world for r in range(world + 1)], dtype=np.uint32)
+
+
+def balanced_partition(bucket_weight, world):
+    """Contiguous bucket ranges with ~equal total weight (e.g. the global lv1 bucket histogram)."""
+    w = np.asarray(bucket_weight, dtype=np.float64)
+    cum = np.concatenate([[0.0], np.cumsum(w)])
+    total = cum[-1]
+    begin = [0]
+    for r in range(1, world):
+        begin.append(int(np.searchsorted(cum, total * r / world, side="left")))
+    begin.append(NUM_BUCKETS)
+    begin = np.maximum.accumulate(np.minimum(np.array(begin), NUM_BUCKETS))
+    begin[0] = 0
+    return begin.astype(np.uint32)
+
+
+class Exchanger:
+    """The collectives of the distributed path, on whatever device the tensors live."""
+
+    def __init__(self, rank, world, device, group=None):
+        self.rank, self.world, self.device, self.group = rank, world, device, group
+
+    def exchange_counts(self, send_counts):
+        """send_counts[p] = items this rank sends to p  ->  recv_counts[p] = items p sends to this rank."""
+        s = torch.as_tensor(np.asarray(send_counts, dtype=np.int64), device=self.device)
+        r = torch.empty_like(s)
+        dist.all_to_all_single(r, s, group=self.group)
+        return r.cpu().numpy().astype(np.uint64)
+
+    def exchange_items(self, send, send_counts, recv, recv_counts, item_bytes):
+        """send/recv: uint8 tensors; counts in items."""
+        assert item_bytes % 8 == 0
+        q = item_bytes // 8
+        s64, r64 = send.view(torch.int64), recv.view(torch.int64)
+        dist.all_to_all_single(r64, s64, [int(c) * q for c in recv_counts], [int(c) * q for c in send_counts], group=self.group)
+
+    def sum_bitmap_and_take_slice(self, bitmap_i64, words_per_rank):
+        """bitmap_i64: int64 tensor of world*words_per_rank words.  Returns this rank's summed slice."""
+        if dist.get_backend(self.group) == "nccl":
+            out = torch.empty(words_per_rank, dtype=torch.int64, device=bitmap_i64.device)
+            dist.reduce_scatter_tensor(out, bitmap_i64, op=dist.ReduceOp.SUM, group=self.group)
+            return out
+        dist.all_reduce(bitmap_i64, op=dist.ReduceOp.SUM, group=self.group)  # gloo: no reduce_scatter
+        return bitmap_i64[self.rank * words_per_rank:(self.rank + 1) * words_per_rank].clone()
+
+    def max_int(self, v):
+        t = torch.tensor([int(v)], dtype=torch.int64, device=self.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        return int(t.item())
+
+
+class DistRead2Sdbg:
+    """read2sdbg (S1 + S2, no mercy) over `world` ranks.  After step(): engine holds this rank's SdBG
+    records (its bucket range) exactly as the single-GPU engine would for those buckets."""
+
+    def __init__(self, engine, k, min_count, rank, world, device, bucket_begin=None, staging=None):
+        self.e, self.k, self.m, self.rank, self.world, self.device = engine, k, min_count, rank, world, device
+        self.x = Exchanger(rank, world, device)
+        # engines that keep items in GPU memory while the process group is CPU-only (gloo) stage through host
+        self.staging = staging
+        self.bucket_begin = equal_partition(world) if bucket_begin is None else np.asarray(bucket_begin, dtype=np.uint32)
+        engine.set_partition(rank, world, self.bucket_begin)
+        # global read layout: rank r's bases start at r*stride, stride a multiple of 64 bits
+        stride = self.x.max_int(engine.n_bases)
+        self.stride_words = (stride + 63) // 64
+        self.stride = self.stride_words * 64
+        engine.set_global_layout(rank * self.stride, world * self.stride)
+
+    def _alltoall(self, stage):
+        ptr, n_items, item_bytes, counts = self.e.dist_extract(stage, self.k, self.m)
+        recv_counts = self.x.exchange_counts(counts)
+        n_recv = int(recv_counts.sum())
+        rptr = self.e.dist_recv_buffer(n_recv, item_bytes)
+        send = self.e.as_tensor(ptr, int(n_items) * item_bytes, self.device)
+        recv = self.e.as_tensor(rptr, n_recv * item_bytes, self.device)
+        if self.staging == "host":  # GPU engine + gloo group: bounce through pinned host memory
+            hs, hr = send.cpu(), torch.empty(n_recv * item_bytes, dtype=torch.uint8)
+            self.x.exchange_items(hs, counts, hr, recv_counts, item_bytes)
+            recv.copy_(hr)
+        else:
+            self.x.exchange_items(send, counts, recv, recv_counts, item_bytes)
+        return n_recv
+
+    def step(self):
+        r1 = None
+        if self.m > 1:  # stage 1 is skipped when every edge is solid (reference main_sdbg_build.cpp:139-147)
+            n1 = self._alltoall(STAGE_S1)
+            r1 = self.e.dist_process_s1(self.k, self.m, n1)
+            n_words = self.world * self.stride_words
+            bm = self.e.as_tensor(self.e.device_pointer(BUF_IS_SOLID), n_words * 8, self.device).view(torch.int64)
+            if self.staging == "host":
+                h = bm.cpu()
+                sl = self.x.sum_bitmap_and_take_slice(h, self.stride_words).to(bm.device)
+            else:
+                sl = self.x.sum_bitmap_and_take_slice(bm, self.stride_words)
+            self.e.adopt_is_solid_slice(sl.data_ptr(), self.stride_words)
+            self._keep = sl
+        n2 = self._alltoall(STAGE_S2)
+        r2 = self.e.dist_process_s2(self.k, n2)
+        return r1, r2

@@ -53,8 +53,12 @@ class KernelStat(C.Structure):
                 ("algo_bytes", C.c_double)]
 
 
-EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64), C.c_void_p,
-                          C.POINTER(C.c_uint64), C.c_int)
+class DistItems(C.Structure):
+    _fields_ = [("d_items", C.c_void_p), ("n_items", C.c_uint64), ("item_bytes", C.c_uint32)]
+
+
+STAGE_S1 = 1
+STAGE_S2 = 2
 
 # every symbol include/mhx.h declares: (restype, argtypes)
 _P = C.c_void_p
@@ -83,7 +87,13 @@ SYMBOLS = {
     "mhx_gen_mercy_edges": (C.c_int, [_P, C.c_uint32, _P, C.c_uint64, C.c_uint64, _P, C.POINTER(C.c_uint64)]),
     "mhx_sort_records": (C.c_int, [_P, _P, C.c_uint64, C.c_uint32, C.c_uint32]),
     "mhx_set_partition": (C.c_int, [_P, C.c_int, C.c_int, _P]),
-    "mhx_set_exchange": (C.c_int, [_P, EXCHANGE_FN, _P]),
+    "mhx_set_global_layout": (C.c_int, [_P, C.c_uint64, C.c_uint64]),
+    "mhx_dist_extract": (C.c_int, [_P, C.c_int, C.c_uint32, C.c_uint32, C.POINTER(DistItems), _P]),
+    "mhx_dist_recv_buffer": (_P, [_P, C.c_uint64, C.c_uint32]),
+    "mhx_dist_process_s1": (C.c_int, [_P, C.c_uint32, C.c_uint32, C.c_uint64, C.POINTER(S1Result)]),
+    "mhx_dist_process_s2": (C.c_int, [_P, C.c_uint32, C.c_uint64, C.POINTER(SdbgResult)]),
+    "mhx_device_pointer": (_P, [_P, C.c_int]),
+    "mhx_adopt_is_solid_slice": (C.c_int, [_P, _P, C.c_uint64]),
     "mhx_profile_enable": (C.c_int, [_P, C.c_int]),
     "mhx_profile_reset": (C.c_int, [_P]),
     "mhx_profile_get": (C.c_int, [_P, C.POINTER(KernelStat), C.c_int]),
@@ -212,6 +222,49 @@ class Engine:
         assert items.dtype == np.uint32 and items.flags.c_contiguous and items.ndim == 2
         self._chk(self.lib.mhx_sort_records(self.h, _ptr(items), items.shape[0], key_words, items.shape[1] - key_words))
         return items
+
+    # ---- multi-GPU phases (see megahit_amd/dist.py)
+    def set_partition(self, my_part, n_parts, bucket_begin):
+        bb = np.ascontiguousarray(bucket_begin, dtype=np.uint32)
+        self._chk(self.lib.mhx_set_partition(self.h, my_part, n_parts, _ptr(bb)))
+        self.n_parts = n_parts
+
+    def set_global_layout(self, pos_base, global_bases):
+        self._chk(self.lib.mhx_set_global_layout(self.h, pos_base, global_bases))
+
+    def dist_extract(self, stage, k, m):
+        """-> (device pointer, n_items, item_bytes, counts per owner)"""
+        out = DistItems()
+        counts = np.zeros(self.n_parts, dtype=np.uint64)
+        self._chk(self.lib.mhx_dist_extract(self.h, stage, k, m, C.byref(out), _ptr(counts)))
+        return out.d_items, out.n_items, out.item_bytes, counts
+
+    def dist_recv_buffer(self, n_items, item_bytes):
+        p = self.lib.mhx_dist_recv_buffer(self.h, n_items, item_bytes)
+        if not p:
+            raise MhxError(self.lib.mhx_last_error().decode())
+        return p
+
+    def dist_process_s1(self, k, m, n_items):
+        r = S1Result()
+        self._chk(self.lib.mhx_dist_process_s1(self.h, k, m, n_items, C.byref(r)))
+        return r
+
+    def dist_process_s2(self, k, n_items):
+        r = SdbgResult()
+        self._chk(self.lib.mhx_dist_process_s2(self.h, k, n_items, C.byref(r)))
+        return r
+
+    def as_tensor(self, ptr, nbytes, device):
+        """torch uint8 view of library-owned device memory (for the collectives in megahit_amd/dist.py)."""
+        from .dist import device_bytes
+        return device_bytes(ptr, nbytes, device)
+
+    def device_pointer(self, which):
+        return self.lib.mhx_device_pointer(self.h, which)
+
+    def adopt_is_solid_slice(self, ptr, n_words):
+        self._chk(self.lib.mhx_adopt_is_solid_slice(self.h, ptr, n_words))
 
     # ---- outputs
     def fetch(self, which, dtype):

@@ -428,23 +428,19 @@ static int diff_km1(const uint32_t *a, const uint32_t *b, int k) {
   return 0;
 }
 
-int orc_s1(const orc_pkg *reads, int k, int m, int tie_mode, orc_s1_out *out) {
-  memset(out, 0, sizeof(*out));
+/* item enumeration of stage 1 (Lv1FillOffsets, read_to_sdbg_s1.cpp:208-296); pos_base is added to
+ * every absolute position (0 for the single-process engines; a rank offset in the multi-GPU tests) */
+void orc_s1_items(const orc_pkg *reads, int k, uint64_t pos_base, orc_vec *items) {
   const int W = DIVCEIL((k - 1) * 2 + 6, 32); /* read_to_sdbg_s1.cpp:107-108 */
-  const int IW = W + 2;
-  out->n_bits = reads->start[reads->n_seqs];
-  out->is_solid = (uint64_t *)calloc(DIVCEIL(out->n_bits, 64) + 1, 8);
-
-  /* enumeration order: Lv1FillOffsets, read_to_sdbg_s1.cpp:208-296 */
-  orc_vec items;
-  vec_init(&items, IW);
+  vec_init(items, W + 2);
   uint32_t f[20], r[20];
   for (uint64_t rid = 0; rid < reads->n_seqs; ++rid) {
     uint64_t st = reads->start[rid];
     uint32_t L = (uint32_t)(reads->start[rid + 1] - st);
     if (L < (uint32_t)k + 1) continue;
-    s1_emit(reads, &items, W, k, st, L, 0, 0); /* first (k-1)-mer: both strands, :239-245 */
-    s1_emit(reads, &items, W, k, st, L, 0, 1);
+    uint64_t first = items->n;
+    s1_emit(reads, items, W, k, st, L, 0, 0); /* first (k-1)-mer: both strands, :239-245 */
+    s1_emit(reads, items, W, k, st, L, 0, 1);
     for (uint32_t q = 1; q + k - 1 < L; ++q) { /* middles: q = 1 .. L-k */
       get_chars(reads, st + q, k - 1, 0, f, W);
       get_chars(reads, st + q, k - 1, 1, r, W);
@@ -456,15 +452,29 @@ int orc_s1(const orc_pkg *reads, int k, int m, int tie_mode, orc_s1_out *out) {
         unsigned pv = orc_base(reads, st + q - 1), nx = orc_base(reads, st + q + k - 1);
         strand = pv <= 3 - nx ? 0 : 1;
       }
-      s1_emit(reads, &items, W, k, st, L, q, strand);
+      s1_emit(reads, items, W, k, st, L, q, strand);
     }
-    s1_emit(reads, &items, W, k, st, L, L - k + 1, 0); /* last one: both strands, :286-292 */
-    s1_emit(reads, &items, W, k, st, L, L - k + 1, 1);
+    s1_emit(reads, items, W, k, st, L, L - k + 1, 0); /* last one: both strands, :286-292 */
+    s1_emit(reads, items, W, k, st, L, L - k + 1, 1);
+    if (pos_base) /* shift the positions stored in the aux words */
+      for (uint64_t i = first; i < items->n; ++i) {
+        uint32_t *it = items->d + i * (W + 2);
+        uint64_t info = ((uint64_t)it[W] << 32) | it[W + 1];
+        info += pos_base << 7;
+        it[W] = (uint32_t)(info >> 32);
+        it[W + 1] = (uint32_t)info;
+      }
   }
-  out->n_items = (int64_t)items.n;
+}
+
+/* bucket sort + Lv2Postprocess (read_to_sdbg_s1.cpp:368-555) of arbitrary stage-1 items.  reads may be
+ * NULL (then no mercy candidates are produced: positions need not belong to a local package). */
+void orc_s1_reduce(const orc_pkg *reads, const orc_vec *items_in, int k, int m, int tie_mode, orc_s1_out *out) {
+  const int W = DIVCEIL((k - 1) * 2 + 6, 32);
+  const int IW = W + 2;
+  out->n_items = (int64_t)items_in->n;
   int64_t *starts = (int64_t *)malloc((ORC_NUM_BUCKETS + 1) * sizeof(int64_t));
-  uint32_t *sorted = bucketize(&items, starts);
-  free(items.d);
+  uint32_t *sorted = bucketize(items_in, starts);
 
   for (int b = 0; b < ORC_NUM_BUCKETS; ++b) {
     int64_t n = starts[b + 1] - starts[b];
@@ -510,12 +520,13 @@ int orc_s1(const orc_pkg *reads, int k, int m, int tie_mode, orc_s1_out *out) {
           uint64_t info = (((uint64_t)s[idx * IW + W] << 32) | s[idx * IW + W + 1]) >> 6;
           uint64_t abs = info >> 1;
           int strand = (int)(info & 1);
+          if (solid) out->is_solid[(abs - 1) >> 6] |= 1ull << ((abs - 1) & 63); /* :464 */
+          if (!reads) continue;
           uint64_t rid = seq_of_offset(reads, abs);
           int64_t base = (int64_t)reads->start[rid];
           int64_t off = (int64_t)abs - base - 1;
           int64_t l_off = strand == 0 ? off : off + 1, r_off = strand == 0 ? off + 1 : off;
           if (solid) {
-            out->is_solid[(abs - 1) >> 6] |= 1ull << ((abs - 1) & 63); /* :464 */
             if (!(has_in & (1 << head))) s1_push_mercy(out, ((base + l_off) << 2) | (1 + strand));
             if (!(has_out & (1 << tail))) s1_push_mercy(out, ((base + r_off) << 2) | (2 - strand));
           } else { /* :485-551 */
@@ -539,6 +550,16 @@ int orc_s1(const orc_pkg *reads, int k, int m, int tie_mode, orc_s1_out *out) {
   free(sorted);
   free(starts);
   orc_kmsort_u64((uint64_t *)out->mercy, (int64_t)out->n_mercy);
+}
+
+int orc_s1(const orc_pkg *reads, int k, int m, int tie_mode, orc_s1_out *out) {
+  memset(out, 0, sizeof(*out));
+  out->n_bits = reads->start[reads->n_seqs];
+  out->is_solid = (uint64_t *)calloc(DIVCEIL(out->n_bits, 64) + 1, 8);
+  orc_vec items;
+  orc_s1_items(reads, k, 0, &items);
+  orc_s1_reduce(reads, &items, k, m, tie_mode, out);
+  free(items.d);
   return 0;
 }
 void orc_s1_free(orc_s1_out *o) {
@@ -719,18 +740,14 @@ static void s2_emit(const orc_pkg *reads, orc_vec *items, int W, int k, uint64_t
   it[W - 1] |= (uint32_t)(n == (unsigned)k) << 3;
   it[W - 1] |= prev;
 }
-int orc_s2(const orc_pkg *reads, int k, int m, const uint64_t *is_solid, orc_sdbg_out *out) {
-  memset(out, 0, sizeof(*out));
-  out->k = k;
-  out->words_per_tip_label = DIVCEIL(k, 16);
+/* Lv1FillOffsets, read_to_sdbg_s2.cpp:347-440 */
+void orc_s2_items(const orc_pkg *reads, int k, int m, const uint64_t *is_solid, orc_vec *items) {
   const int W = DIVCEIL(k * 2 + 4, 32); /* read_to_sdbg_s2.cpp:98-99 */
   const int EW = DIVCEIL((k + 1) * 2, 32);
   const int sure = (m == 1);
-  orc_vec items;
-  vec_init(&items, W);
+  vec_init(items, W);
   uint32_t e[20], r[20];
 #define SOLID(x) (sure || ((is_solid[(x) >> 6] >> ((x)&63)) & 1))
-  /* Lv1FillOffsets, read_to_sdbg_s2.cpp:347-440 */
   for (uint64_t rid = 0; rid < reads->n_seqs; ++rid) {
     uint64_t st = reads->start[rid];
     uint32_t L = (uint32_t)(reads->start[rid + 1] - st);
@@ -742,19 +759,30 @@ int orc_s2(const orc_pkg *reads, int k, int m, const uint64_t *is_solid, orc_sdb
       get_chars(reads, fo, k + 1, 1, r, EW);
       int pal = cmp_words(r, e, EW) == 0;
       if (p == 0 || !SOLID(fo - 1)) {
-        s2_emit(reads, &items, W, k, st, p, 0, 0);
-        if (!pal) s2_emit(reads, &items, W, k, st, p, 1, 0);
+        s2_emit(reads, items, W, k, st, p, 0, 0);
+        if (!pal) s2_emit(reads, items, W, k, st, p, 1, 0);
       }
-      s2_emit(reads, &items, W, k, st, p, 0, 1);
-      if (!pal) s2_emit(reads, &items, W, k, st, p, 1, 1);
+      s2_emit(reads, items, W, k, st, p, 0, 1);
+      if (!pal) s2_emit(reads, items, W, k, st, p, 1, 1);
       if (p + k + 1 == L || !SOLID(fo + 1)) {
-        s2_emit(reads, &items, W, k, st, p, 0, 2);
-        if (!pal) s2_emit(reads, &items, W, k, st, p, 1, 2);
+        s2_emit(reads, items, W, k, st, p, 0, 2);
+        if (!pal) s2_emit(reads, items, W, k, st, p, 1, 2);
       }
     }
   }
 #undef SOLID
-  sdbg_run_buckets(out, &items, W, k, 0);
+}
+/* bucket sort + Lv2Postprocess + SdbgWriter of arbitrary lv2 items (consumes items->d) */
+void orc_sdbg_from_items(orc_vec *items, int k, int is_seq2sdbg, orc_sdbg_out *out) {
+  memset(out, 0, sizeof(*out));
+  out->k = k;
+  out->words_per_tip_label = DIVCEIL(k, 16);
+  sdbg_run_buckets(out, items, items->w, k, is_seq2sdbg);
+}
+int orc_s2(const orc_pkg *reads, int k, int m, const uint64_t *is_solid, orc_sdbg_out *out) {
+  orc_vec items;
+  orc_s2_items(reads, k, m, is_solid, &items);
+  orc_sdbg_from_items(&items, k, 0, out);
   return 0;
 }
 

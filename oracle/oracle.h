@@ -83,6 +83,11 @@ typedef struct {
 int orc_s1(const orc_pkg *reads, int k, int m, int tie_mode, orc_s1_out *out);
 void orc_s1_free(orc_s1_out *o);
 
+/* the two halves of orc_s1 / orc_s2, exposed so that tests can exchange items between ranks */
+void orc_s1_items(const orc_pkg *reads, int k, uint64_t pos_base, orc_vec *items);
+void orc_s1_reduce(const orc_pkg *reads /* may be NULL: no mercy */, const orc_vec *items, int k, int m, int tie_mode,
+                   orc_s1_out *out /* is_solid preallocated, zeroed */);
+
 /* mercy block of Read2SdbgS2::Initialize (read_to_sdbg_s2.cpp:122-266);
  * returns "Number mercy". cands must be sorted. */
 int64_t orc_s2_add_mercy(const orc_pkg *reads, int k, uint64_t *is_solid,
@@ -104,8 +109,12 @@ void orc_sdbg_free(orc_sdbg_out *o);
 /* read_to_sdbg_s2.cpp:271-614; is_solid may be NULL iff m==1 (for_sure_solid) */
 int orc_s2(const orc_pkg *reads, int k, int m, const uint64_t *is_solid, orc_sdbg_out *out);
 
+void orc_s2_items(const orc_pkg *reads, int k, int m, const uint64_t *is_solid, orc_vec *items);
 /* seq_to_sdbg.cpp:530-789; mult has one entry per sequence */
 int orc_seq2sdbg(const orc_pkg *seqs, const uint16_t *mult, int k, orc_sdbg_out *out);
+
+/* sort + postprocess + SdbgWriter of arbitrary lv2 items (frees items->d) */
+void orc_sdbg_from_items(orc_vec *items, int k, int is_seq2sdbg, orc_sdbg_out *out);
 
 /* seq_to_sdbg.cpp:100-357 (GenMercyEdges): edges = sorted (k+1)-mer package,
  * cand = candidate reads.  Appends mercy edges to `edges` (and mult 1 to *mult). */

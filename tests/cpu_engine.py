@@ -1,0 +1,90 @@
+"""TEST INFRASTRUCTURE: the phased multi-GPU interface of megahit_amd.lib.Engine, implemented on the
+CPU with the oracle, so that megahit_amd/dist.py (partition, all-to-all, bitmap reduction) can be
+exercised with world_size 2 on the gloo backend without GPUs.  Never used by the product."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+import oracle_binding as ob
+
+BUF_IS_SOLID = 6
+
+
+class Res:
+    pass
+
+
+class OracleEngine:
+    def __init__(self, reads):
+        self.pkg = ob.Package(reads, reverse=True)
+        self.n_bases = int(self.pkg.start()[-1])
+        self.bufs = {}
+        self.next_handle = 1
+        self.pos_base = 0
+        self.global_bases = 0
+        self.local_solid = None
+        self.sdbg = None
+
+    def _new(self, arr):
+        h = self.next_handle
+        self.next_handle += 1
+        self.bufs[h] = arr
+        return h
+
+    def set_partition(self, my_part, n_parts, bucket_begin):
+        self.my_part, self.n_parts = my_part, n_parts
+        self.lut = np.zeros(65536, dtype=np.int64)
+        for p in range(n_parts):
+            self.lut[int(bucket_begin[p]):int(bucket_begin[p + 1])] = p
+        self.bucket_begin = np.asarray(bucket_begin)
+
+    def set_global_layout(self, pos_base, global_bases):
+        self.pos_base, self.global_bases = pos_base, global_bases
+
+    def dist_extract(self, stage, k, m):
+        if stage == 1:
+            items = ob.s1_items(self.pkg, k, self.pos_base)
+        else:
+            items = ob.s2_items(self.pkg, k, m, self.local_solid if m > 1 else None)
+        owner = self.lut[items[:, 0] >> 16] if len(items) else np.zeros(0, dtype=np.int64)
+        order = np.argsort(owner, kind="stable")
+        items = np.ascontiguousarray(items[order])
+        counts = np.bincount(owner, minlength=self.n_parts).astype(np.uint64)
+        return self._new(items.view(np.uint8).reshape(-1)), items.shape[0], items.shape[1] * 4, counts
+
+    def dist_recv_buffer(self, n_items, item_bytes):
+        self.recv = np.zeros(n_items * item_bytes, dtype=np.uint8)
+        return self._new(self.recv)
+
+    def as_tensor(self, handle, nbytes, device):
+        return torch.from_numpy(self.bufs[handle][:nbytes])
+
+    def device_pointer(self, which):
+        assert which == BUF_IS_SOLID
+        return self._new(self.global_bits.view(np.uint8))
+
+    def dist_process_s1(self, k, m, n_items):
+        w = (2 * (k - 1) + 6 + 31) // 32 + 2
+        items = self.recv.view(np.uint32).reshape(-1, w)[:n_items]
+        assert (self.lut[items[:, 0] >> 16] == self.my_part).all()
+        bits, hist = ob.s1_reduce(items, k, m, self.global_bases)
+        self.global_bits = np.ascontiguousarray(bits)
+        self.hist = hist
+        r = Res()
+        r.n_items = n_items
+        return r
+
+    def adopt_is_solid_slice(self, ptr, n_words):
+        arr = np.ctypeslib.as_array((C.c_uint64 * n_words).from_address(ptr)).copy()
+        self.local_solid = arr[: (self.n_bases + 63) // 64]
+
+    def dist_process_s2(self, k, n_items):
+        w = (2 * k + 4 + 31) // 32
+        items = self.recv.view(np.uint32).reshape(-1, w)[:n_items]
+        assert (self.lut[items[:, 0] >> 16] == self.my_part).all()
+        self.sdbg = ob.sdbg_from_items(items, k, False)
+        r = Res()
+        r.n_items = n_items
+        r.n_sdbg = int(self.sdbg["bucket_items"].sum())
+        return r

@@ -64,6 +64,10 @@ def lib():
         L.orc_s2.argtypes = [C.POINTER(Pkg), C.c_int, C.c_int, C.c_void_p, C.POINTER(SdbgOut)]
         L.orc_seq2sdbg.argtypes = [C.POINTER(Pkg), C.c_void_p, C.c_int, C.POINTER(SdbgOut)]
         L.orc_sdbg_free.argtypes = [C.POINTER(SdbgOut)]
+        L.orc_s1_items.argtypes = [C.POINTER(Pkg), C.c_int, C.c_uint64, C.POINTER(Vec)]
+        L.orc_s1_reduce.argtypes = [C.c_void_p, C.POINTER(Vec), C.c_int, C.c_int, C.c_int, C.POINTER(S1Out)]
+        L.orc_s2_items.argtypes = [C.POINTER(Pkg), C.c_int, C.c_int, C.c_void_p, C.POINTER(Vec)]
+        L.orc_sdbg_from_items.argtypes = [C.POINTER(Vec), C.c_int, C.c_int, C.POINTER(SdbgOut)]
         L.orc_gen_mercy_edges.argtypes = [C.POINTER(Pkg), C.POINTER(C.POINTER(C.c_uint16)), C.POINTER(C.c_uint64),
                                           C.POINTER(Pkg), C.c_int]
         L.orc_gen_mercy_edges.restype = C.c_int64
@@ -194,3 +198,53 @@ def gen_mercy_edges(edge_pkg, mult, cand_pkg, k):
     libc.free.argtypes = [C.c_void_p]
     libc.free(C.cast(mp, C.c_void_p))
     return n, out
+
+
+def _take_vec(v):
+    out = _arr(v.d, v.n * v.w, np.uint32).reshape(-1, v.w) if v.n else np.zeros((0, v.w), dtype=np.uint32)
+    libc = C.CDLL(None)
+    libc.free.argtypes = [C.c_void_p]
+    libc.free(C.cast(v.d, C.c_void_p))
+    return out
+
+
+def s1_items(pkg, k, pos_base=0):
+    v = Vec()
+    lib().orc_s1_items(C.byref(pkg.p), k, pos_base, C.byref(v))
+    return _take_vec(v)
+
+
+def s2_items(pkg, k, m, is_solid):
+    v = Vec()
+    p = None
+    if is_solid is not None:
+        buf = np.concatenate([np.ascontiguousarray(is_solid, dtype=np.uint64), np.zeros(2, dtype=np.uint64)])
+        p = buf.ctypes.data
+    lib().orc_s2_items(C.byref(pkg.p), k, m, p, C.byref(v))
+    return _take_vec(v)
+
+
+def s1_reduce(items, k, m, n_bits, tie_stable=True):
+    """items: uint32 [n, W+2] (any order) -> (is_solid uint64[ceil(n_bits/64)], hist)."""
+    items = np.ascontiguousarray(items, dtype=np.uint32)
+    v = Vec(items.ctypes.data_as(C.POINTER(C.c_uint32)), items.shape[0], items.shape[0], items.shape[1])
+    o = S1Out()
+    nw = (n_bits + 63) // 64
+    bits = np.zeros(nw + 2, dtype=np.uint64)
+    o.is_solid = bits.ctypes.data_as(C.POINTER(C.c_uint64))
+    o.n_bits = n_bits
+    lib().orc_s1_reduce(None, C.byref(v), k, m, 0 if tie_stable else 1, C.byref(o))
+    return bits[:nw], np.array(o.hist, dtype=np.int64)
+
+
+def sdbg_from_items(items, k, is_seq2sdbg=False):
+    items = np.ascontiguousarray(items, dtype=np.uint32)
+    libc = C.CDLL(None)
+    libc.malloc.restype = C.c_void_p
+    libc.malloc.argtypes = [C.c_size_t]
+    raw = libc.malloc(max(8, items.nbytes))
+    C.memmove(raw, items.ctypes.data, items.nbytes)
+    v = Vec(C.cast(raw, C.POINTER(C.c_uint32)), items.shape[0], items.shape[0], items.shape[1])
+    o = SdbgOut()
+    lib().orc_sdbg_from_items(C.byref(v), k, int(is_seq2sdbg), C.byref(o))  # frees raw
+    return _sdbg(o)

@@ -1,0 +1,77 @@
+"""GPU: the multi-GPU path with real kernels.  A 1-GPU box cannot host two RCCL ranks (RCCL refuses
+duplicate devices), so two processes share cuda:0, the process group is gloo and item buffers are
+staged through host memory; extraction, owner partition, sort, reduction and SdBG emission are the
+same HIP kernels the N-GPU bench runs."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(HERE))
+
+pytestmark = pytest.mark.gpu
+
+
+def _reads(seed):
+    from test_dist_cpu import _reads as r
+    return r(seed, n_pairs=600)
+
+
+def _worker(rank, world, port, k, m, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import oracle_binding as ob
+    from megahit_amd import dist as mdist
+    from megahit_amd import lib
+    pkg = ob.Package(_reads(100 + rank), reverse=True)
+    eng = lib.Engine(0)
+    eng.load_sequences(pkg.words(), pkg.n_seqs, 0, pkg.start())
+    runner = mdist.DistRead2Sdbg(eng, k, m, rank, world, torch.device("cuda", 0), staging="host")
+    r1, r2 = runner.step()
+    r1, r2 = runner.step()  # a second step must give the same answer (buffers are reused)
+    lo, hi = int(runner.bucket_begin[rank]), int(runner.bucket_begin[rank + 1])
+    q.put((rank, lo, hi, eng.fetch(lib.BUF_SDBG_BYTES, np.uint8).tobytes(), eng.fetch(lib.BUF_BUCKET_COUNT, np.uint64),
+           eng.fetch(lib.BUF_BUCKET_TIPS, np.uint64), eng.fetch(lib.BUF_BUCKET_LARGE, np.uint64),
+           eng.fetch(lib.BUF_MUL_HIST, np.int64) if m > 1 else None))
+    dist.barrier()
+    dist.destroy_process_group()
+    eng.close()
+
+
+@pytest.mark.parametrize("world,k,m", [(2, 21, 2), (2, 21, 1), (1, 27, 2), (3, 31, 2)])
+def test_ranks_on_one_gpu_equal_single_process(world, k, m):
+    import oracle_binding as ob
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29600 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, world, port, k, m, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = sorted([q.get(timeout=600) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    allreads = []
+    for r in range(world):
+        allreads += _reads(100 + r)
+    pkg = ob.Package(allreads, reverse=True)
+    if m > 1:
+        s1 = ob.s1(pkg, k, m)
+        want = ob.s2(pkg, k, m, s1["is_solid"])
+        assert np.array_equal(sum(o[7] for o in outs), s1["hist"])
+    else:
+        want = ob.s2(pkg, k, 1, None)
+    off = np.concatenate([want["bucket_off"], [len(want["bytes"])]]).astype(np.int64)
+    for rank, lo, hi, byts, b_items, b_tips, b_large, _ in outs:
+        assert np.array_equal(b_items[lo:hi], want["bucket_items"][lo:hi])
+        assert np.array_equal(b_tips[lo:hi], want["bucket_tips"][lo:hi])
+        assert np.array_equal(b_large[lo:hi], want["bucket_large"][lo:hi])
+        assert b_items[:lo].sum() == 0 and b_items[hi:].sum() == 0
+        assert byts == want["bytes"][off[lo]:off[hi]].tobytes()
