@@ -9,6 +9,7 @@
 //   emit        packed solid edges + per-bucket counts (PackEdge :32-52, EdgeWriter::Write)
 #include "dev_prims.h"
 #include "mhx_internal.h"
+#include "tile_groups.h"
 
 namespace mhx {
 
@@ -72,22 +73,46 @@ __global__ __launch_bounds__(256) void k_count_extract(const uint32_t *__restric
 // ---------------------------------------------------------------------------
 constexpr int kLocalHist = 1024;
 
-__global__ __launch_bounds__(256) void k_count_runs(const uint32_t *__restrict__ items, uint64_t n, int stride, int kw,
-                                                    const uint64_t *__restrict__ heads, uint64_t n_runs, uint32_t m,
-                                                    const uint64_t *__restrict__ start, uint64_t n_seqs, uint32_t fixed_len,
-                                                    uint32_t *__restrict__ run_count, uint32_t *__restrict__ solid_flag,
-                                                    uint32_t *__restrict__ first_0_out, uint32_t *__restrict__ last_0_in_p1,
-                                                    unsigned long long *__restrict__ hist) {
+__device__ __forceinline__ uint32_t *count_local_hist() {
   __shared__ uint32_t lh[kLocalHist];
-  for (int i = threadIdx.x; i < kLocalHist; i += blockDim.x) lh[i] = 0;
-  __syncthreads();
-  const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (r < n_runs) {
-    const uint64_t b = heads[r], e = (r + 1 < n_runs) ? heads[r + 1] : n;
-    const uint64_t count = e - b;
+  return lh;
+}
+
+// Lv2Postprocess of KmerCounter (kmer_counter.cpp:254-381) as a tile-group operator (tile_groups.h).
+template <int S>
+struct CountOp {
+  int kw, wpe;
+  uint32_t m;
+  int side_effects;  // first launch: histogram + first_0_out/last_0_in atomics; second launch: emit only
+  const uint64_t *start;
+  uint64_t n_seqs;
+  uint32_t fixed_len;
+  uint32_t *first_0_out, *last_0_in_p1;
+  unsigned long long *hist, *bucket_count;
+  uint32_t *edges;
+
+  __device__ void begin_block() const {
+    if (!side_effects) return;
+    uint32_t *lh = count_local_hist();
+    for (int i = threadIdx.x; i < kLocalHist; i += blockDim.x) lh[i] = 0;
+    __syncthreads();
+  }
+  __device__ void end_block() const {
+    if (!side_effects) return;
+    uint32_t *lh = count_local_hist();
+    for (int i = threadIdx.x; i < kLocalHist; i += blockDim.x)
+      if (lh[i]) atomicAdd(&hist[i], (unsigned long long)lh[i]);
+  }
+  __device__ GroupCounts count(const TileAcc<S> &acc, uint32_t b, uint32_t e) const {
+    GroupCounts gc;
+    const uint32_t count = e - b;
+    const bool solid = count >= m;
+    gc.c0 = solid ? 1u : 0u;
+    gc.c1 = 1u;
+    if (!side_effects) return gc;
     uint32_t cp[4] = {0, 0, 0, 0}, cn[4] = {0, 0, 0, 0};
-    for (uint64_t j = b; j < e; ++j) {
-      const unsigned pn = items[j * stride + kw + 1] & 63u;
+    for (uint32_t j = b; j < e; ++j) {
+      const unsigned pn = acc.word(j, kw + 1) & 63u;
       const unsigned pv = pn >> 3, nx = pn & 7;
 #pragma unroll
       for (int x = 0; x < 4; ++x) {
@@ -101,10 +126,9 @@ __global__ __launch_bounds__(256) void k_count_runs(const uint32_t *__restrict__
       has_in |= cp[x] >= m;
       has_out |= cn[x] >= m;
     }
-    const bool solid = count >= m;
     if (solid && (!has_in || !has_out)) {
-      for (uint64_t j = b; j < e; ++j) {
-        const uint64_t info = (((uint64_t)items[j * stride + kw] << 32) | items[j * stride + kw + 1]) >> 6;
+      for (uint32_t j = b; j < e; ++j) {
+        const uint64_t info = (((uint64_t)acc.word(j, kw) << 32) | acc.word(j, kw + 1)) >> 6;
         const uint64_t abs = info >> 1;
         const unsigned strand = (unsigned)(info & 1);
         const uint64_t rid = seq_of_offset(start, n_seqs, fixed_len, abs);
@@ -121,34 +145,66 @@ __global__ __launch_bounds__(256) void k_count_runs(const uint32_t *__restrict__
         }
       }
     }
-    run_count[r] = count > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)count;
-    solid_flag[r] = solid ? 1u : 0u;
-    const uint64_t hb = count > MHX_MAX_MUL ? MHX_MAX_MUL : count;
-    if (hb < kLocalHist) atomicAdd(&lh[hb], 1u);
+    const uint32_t hb = count > MHX_MAX_MUL ? (uint32_t)MHX_MAX_MUL : count;
+    if (hb < kLocalHist) atomicAdd(&count_local_hist()[hb], 1u);
     else atomicAdd(&hist[hb], 1ull);
+    return gc;
   }
-  __syncthreads();
-  for (int i = threadIdx.x; i < kLocalHist; i += blockDim.x)
-    if (lh[i]) atomicAdd(&hist[i], (unsigned long long)lh[i]);
-}
-
-__global__ void k_count_emit(const uint32_t *__restrict__ items, int stride, int kw, const uint64_t *__restrict__ heads, uint64_t n_runs,
-                             const uint32_t *__restrict__ run_count, const uint32_t *__restrict__ solid_flag,
-                             const uint64_t *__restrict__ pos, int wpe, uint32_t *__restrict__ edges,
-                             unsigned long long *__restrict__ bucket_count) {
-  const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= n_runs || !solid_flag[r]) return;
-  const uint32_t *it = items + heads[r] * stride;
-  uint32_t *ed = edges + pos[r] * wpe;
-  for (int x = 0; x < wpe; ++x) ed[x] = x < kw ? it[x] : 0u;
-  const uint32_t c = run_count[r];
-  ed[wpe - 1] |= c > MHX_MAX_MUL ? (uint32_t)MHX_MAX_MUL : c;
-  atomicAdd(&bucket_count[it[0] >> 16], 1ull);
-}
+  // PackEdge (kmer_counter.cpp:32-52) + EdgeWriter::Write bucket accounting
+  __device__ void emit(const TileAcc<S> &acc, uint32_t b, uint32_t e, uint64_t o0, uint64_t, uint64_t) const {
+    const uint32_t count = e - b;
+    if (count < m) return;
+    uint32_t *ed = edges + o0 * wpe;
+    for (int x = 0; x < wpe; ++x) ed[x] = x < kw ? acc.word(b, x) : 0u;
+    ed[wpe - 1] |= count > MHX_MAX_MUL ? (uint32_t)MHX_MAX_MUL : count;
+    atomicAdd(&bucket_count[acc.word(b, 0) >> 16], 1ull);
+  }
+};
 
 __global__ void k_fix_last(uint32_t *__restrict__ last_p1, uint64_t n) {
   uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) last_p1[i] = last_p1[i] - 1u;  // 0 (unset) -> 0xFFFFFFFF sentinel, v+1 -> v
+}
+
+template <int S>
+static void count_postprocess(mhx_ctx *c, const uint32_t *sorted, uint64_t n_items, int KWv, int key_bits, uint32_t m, int wpe,
+                              uint32_t *first, uint32_t *last, unsigned long long *hist, unsigned long long *bcount, uint64_t *n_runs,
+                              uint64_t *n_edges) {
+  SeqSet &s = c->seqs;
+  hipStream_t st = c->stream;
+  *n_runs = *n_edges = 0;
+  if (n_items == 0) {
+    c->result(MHX_BUF_EDGES, 4);
+    c->results[MHX_BUF_EDGES].used = 0;
+    return;
+  }
+  constexpr int T = TileCfg<S>::kT;
+  const uint64_t n_tiles = div_ceil(n_items, T);
+  uint64_t *tot = c->ws("tile_tot", (3 * n_tiles + 4) * 8).as<uint64_t>();
+  uint64_t *tb = c->ws("tile_base", (3 * n_tiles + 4) * 8).as<uint64_t>();
+  const int full_words = key_bits / 32, rem = key_bits % 32;
+  const uint32_t last_mask = rem ? 0xFFFFFFFFu << (32 - rem) : 0;
+  CountOp<S> op{KWv, wpe, m, 1, s.start.as<uint64_t>(), s.n_seqs, s.fixed_len, first, last, hist, bcount, nullptr};
+  const double bytes = (double)n_items * S * 4;
+  MHX_LAUNCH(c, "count_runs", bytes,
+             hipLaunchKernelGGL((k_tile_groups<S, CountOp<S>, false>), dim3((unsigned)n_tiles), dim3(kTileThreads), 0, st, sorted, n_items,
+                                full_words, last_mask, op, tot, (const uint64_t *)nullptr, n_tiles));
+  uint64_t *d_tot = c->ws("tile_totals", 64).as<uint64_t>();
+  exclusive_scan_u64(c, tot, tb, n_tiles, d_tot);
+  exclusive_scan_u64(c, tot + n_tiles, tb + n_tiles, n_tiles, d_tot + 1);
+  MHX_HIP(hipMemsetAsync(tb + 2 * n_tiles, 0, n_tiles * 8, st));
+  uint64_t h[2];
+  MHX_HIP(hipMemcpyAsync(h, d_tot, 16, hipMemcpyDeviceToHost, st));
+  MHX_HIP(hipStreamSynchronize(st));
+  *n_edges = h[0];
+  *n_runs = h[1];
+  uint32_t *edges = c->result(MHX_BUF_EDGES, (h[0] ? h[0] : 1) * wpe * 4).as<uint32_t>();
+  c->results[MHX_BUF_EDGES].used = h[0] * wpe * 4;
+  op.side_effects = 0;
+  op.edges = edges;
+  MHX_LAUNCH(c, "count_emit", bytes + (double)h[0] * wpe * 4,
+             hipLaunchKernelGGL((k_tile_groups<S, CountOp<S>, true>), dim3((unsigned)n_tiles), dim3(kTileThreads), 0, st, sorted, n_items,
+                                full_words, last_mask, op, (uint64_t *)nullptr, (const uint64_t *)tb, n_tiles));
 }
 
 // ---------------------------------------------------------------------------
@@ -206,29 +262,13 @@ int run_count(mhx_ctx *c, uint32_t k, uint32_t m, mhx_count_result *out) {
   MHX_HIP(hipMemsetAsync(hist, 0, (MHX_MAX_MUL + 1) * 8, st));
   MHX_HIP(hipMemsetAsync(bcount, 0, MHX_NUM_BUCKETS * 8, st));
 
-  const uint64_t n_runs = count_group_heads(c, sorted, n_items, S, key_bits);
-  uint64_t n_edges = 0;
-  if (n_runs) {
-    uint64_t *heads = c->ws("heads", n_runs * 8).as<uint64_t>();
-    find_group_heads(c, sorted, n_items, S, key_bits, heads, nullptr);
-    uint32_t *run_count_d = c->ws("run_count", n_runs * 4).as<uint32_t>();
-    uint32_t *solid = c->ws("run_solid", n_runs * 4).as<uint32_t>();
-    uint64_t *pos = c->ws("run_pos", (n_runs + 1) * 8).as<uint64_t>();
-    const unsigned grid = (unsigned)div_ceil(n_runs, 256);
-    MHX_LAUNCH(c, "count_runs", (double)n_items * item_bytes + (double)n_runs * 16,
-               hipLaunchKernelGGL(k_count_runs, dim3(grid), dim3(256), 0, st, sorted, n_items, S, KWv, heads, n_runs, m,
-                                  s.start.as<uint64_t>(), ns, s.fixed_len, run_count_d, solid, first, last, hist));
-    exclusive_scan_u32_u64(c, solid, pos, n_runs, pos + n_runs);
-    MHX_HIP(hipMemcpyAsync(&n_edges, pos + n_runs, 8, hipMemcpyDeviceToHost, st));
-    MHX_HIP(hipStreamSynchronize(st));
-    uint32_t *edges = c->result(MHX_BUF_EDGES, (n_edges ? n_edges : 1) * wpe * 4).as<uint32_t>();
-    c->results[MHX_BUF_EDGES].used = n_edges * wpe * 4;
-    MHX_LAUNCH(c, "count_emit", (double)n_runs * 24 + (double)n_edges * (wpe * 4 + item_bytes),
-               hipLaunchKernelGGL(k_count_emit, dim3(grid), dim3(256), 0, st, sorted, S, KWv, heads, n_runs, run_count_d, solid, pos, wpe,
-                                  edges, bcount));
-  } else {
-    c->result(MHX_BUF_EDGES, 4);
-    c->results[MHX_BUF_EDGES].used = 0;
+  uint64_t n_runs = 0, n_edges = 0;
+  switch (S) {
+#define MHX_CASE(SV) \
+  case SV: count_postprocess<SV>(c, sorted, n_items, KWv, key_bits, m, wpe, first, last, hist, bcount, &n_runs, &n_edges); break;
+    MHX_CASE(4) MHX_CASE(6) MHX_CASE(8) MHX_CASE(10) MHX_CASE(12) MHX_CASE(14) MHX_CASE(16) MHX_CASE(18) MHX_CASE(20)
+#undef MHX_CASE
+    default: throw Error("count: unsupported record stride");
   }
   if (ns)
     MHX_LAUNCH(c, "fix_last", (double)ns * 8,

@@ -14,6 +14,7 @@
 // differ from the reference there; is_solid and the histogram never depend on it.
 #include "dev_prims.h"
 #include "mhx_internal.h"
+#include "tile_groups.h"
 
 namespace mhx {
 
@@ -92,32 +93,54 @@ __global__ __launch_bounds__(256) void k_s1_extract(const uint32_t *__restrict__
 
 constexpr int kS1LocalHist = 1024;
 
-// One thread per (k-1)-mer group.
-__global__ __launch_bounds__(256) void k_s1_groups(const uint32_t *__restrict__ items, uint64_t n, int stride, int kw,
-                                                   const uint64_t *__restrict__ heads, uint64_t n_groups, uint32_t m,
-                                                   const uint64_t *__restrict__ start, uint64_t n_seqs, uint32_t fixed_len,
-                                                   unsigned long long *__restrict__ is_solid, unsigned long long *__restrict__ hist,
-                                                   unsigned long long *__restrict__ n_solid_out, int want_mercy,
-                                                   long long *__restrict__ mercy, unsigned long long *__restrict__ mercy_n) {
+__device__ __forceinline__ uint32_t *s1_local_hist() {
   __shared__ uint32_t lh[kS1LocalHist];
-  __shared__ unsigned long long blk_solid;
-  for (int i = threadIdx.x; i < kS1LocalHist; i += blockDim.x) lh[i] = 0;
-  if (threadIdx.x == 0) blk_solid = 0;
-  __syncthreads();
-  const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  unsigned long long my_solid = 0;
-  if (g < n_groups) {
-    const uint64_t b = heads[g], e = (g + 1 < n_groups) ? heads[g + 1] : n;
-    const unsigned pn_first = items[b * stride + kw + 1] & 63u;
-    uint64_t cnt_head[4] = {0, 0, 0, 0}, cnt_tail[4] = {0, 0, 0, 0};
+  return lh;
+}
+__device__ __forceinline__ unsigned long long *s1_block_solid() {
+  __shared__ unsigned long long v;
+  return &v;
+}
+
+// Lv2Postprocess of Read2SdbgS1 (read_to_sdbg_s1.cpp:368-555) as a tile-group operator: one thread per
+// (k-1)-mer group, records read out of the LDS tile (tile_groups.h).  No ordered output: a single launch.
+template <int S>
+struct S1Op {
+  int kw;
+  uint32_t m;
+  const uint64_t *start;
+  uint64_t n_seqs;
+  uint32_t fixed_len;
+  unsigned long long *is_solid, *hist, *n_solid_out;
+  int want_mercy;
+  long long *mercy;
+  unsigned long long *mercy_n;
+
+  __device__ void begin_block() const {
+    uint32_t *lh = s1_local_hist();
+    for (int i = threadIdx.x; i < kS1LocalHist; i += blockDim.x) lh[i] = 0;
+    if (threadIdx.x == 0) *s1_block_solid() = 0;
+    __syncthreads();
+  }
+  __device__ void end_block() const {
+    uint32_t *lh = s1_local_hist();
+    for (int i = threadIdx.x; i < kS1LocalHist; i += blockDim.x)
+      if (lh[i]) atomicAdd(&hist[i], (unsigned long long)lh[i]);
+    if (threadIdx.x == 0 && *s1_block_solid()) atomicAdd(n_solid_out, *s1_block_solid());
+  }
+  __device__ void emit(const TileAcc<S> &, uint32_t, uint32_t, uint64_t, uint64_t, uint64_t) const {}
+  __device__ GroupCounts count(const TileAcc<S> &acc, uint32_t b, uint32_t e) const {
+    unsigned long long my_solid = 0;
+    const unsigned pn_first = acc.word(b, kw + 1) & 63u;  // H1: prev/next of the group's FIRST item, :399
+    uint32_t cnt_head[4] = {0, 0, 0, 0}, cnt_tail[4] = {0, 0, 0, 0};
     unsigned l_has_out = 0, r_has_in = 0;
     // walk 1: (head,tail) run lengths
-    for (uint64_t j = b; j < e;) {
-      const unsigned ht = items[j * stride + kw - 1] & 63u;
-      uint64_t j0 = j;
+    for (uint32_t j = b; j < e;) {
+      const unsigned ht = acc.word(j, kw - 1) & 63u;
+      const uint32_t j0 = j;
       do ++j;
-      while (j < e && (items[j * stride + kw - 1] & 63u) == ht);
-      const uint64_t c = j - j0;
+      while (j < e && (acc.word(j, kw - 1) & 63u) == ht);
+      const uint32_t c = j - j0;
       const unsigned h = ht >> 3, t = ht & 7;
 #pragma unroll
       for (int x = 0; x < 4; ++x) {
@@ -141,23 +164,23 @@ __global__ __launch_bounds__(256) void k_s1_groups(const uint32_t *__restrict__ 
         if (cnt_tail[x] >= m) has_out |= 1u << x;
     }
     // walk 2
-    for (uint64_t j = b; j < e;) {
-      const unsigned ht = items[j * stride + kw - 1] & 63u;
-      uint64_t j0 = j;
+    for (uint32_t j = b; j < e;) {
+      const unsigned ht = acc.word(j, kw - 1) & 63u;
+      const uint32_t j0 = j;
       do ++j;
-      while (j < e && (items[j * stride + kw - 1] & 63u) == ht);
-      const uint64_t c = j - j0;
+      while (j < e && (acc.word(j, kw - 1) & 63u) == ht);
+      const uint32_t c = j - j0;
       const unsigned h = ht >> 3, t = ht & 7;
       const bool both = h < 4 && t < 4;
       if (both) {
-        const uint64_t hb = c > MHX_MAX_MUL ? MHX_MAX_MUL : c;
-        if (hb < kS1LocalHist) atomicAdd(&lh[hb], 1u);
+        const uint32_t hb = c > MHX_MAX_MUL ? (uint32_t)MHX_MAX_MUL : c;
+        if (hb < kS1LocalHist) atomicAdd(&s1_local_hist()[hb], 1u);
         else atomicAdd(&hist[hb], 1ull);
       }
       const bool solid = both && c >= m;
       if (!solid && !want_mercy) continue;
-      for (uint64_t x = j0; x < j; ++x) {
-        const uint64_t info = (((uint64_t)items[x * stride + kw] << 32) | items[x * stride + kw + 1]) >> 6;
+      for (uint32_t x = j0; x < j; ++x) {
+        const uint64_t info = (((uint64_t)acc.word(x, kw) << 32) | acc.word(x, kw + 1)) >> 6;
         const uint64_t abs = info >> 1;
         const int strand = (int)(info & 1);
         if (solid) {
@@ -184,12 +207,24 @@ __global__ __launch_bounds__(256) void k_s1_groups(const uint32_t *__restrict__ 
         }
       }
     }
+    if (my_solid) atomicAdd(s1_block_solid(), my_solid);
+    return GroupCounts();
   }
-  if (my_solid) atomicAdd(&blk_solid, my_solid);
-  __syncthreads();
-  for (int i = threadIdx.x; i < kS1LocalHist; i += blockDim.x)
-    if (lh[i]) atomicAdd(&hist[i], (unsigned long long)lh[i]);
-  if (threadIdx.x == 0 && blk_solid) atomicAdd(n_solid_out, blk_solid);
+};
+
+template <int S>
+static void s1_groups_launch(mhx_ctx *c, const uint32_t *sorted, uint64_t n_items, int KWv, int kmer_bits, uint32_t m,
+                             unsigned long long *is_solid, unsigned long long *hist, unsigned long long *ctr, int want_mercy,
+                             long long *mercy) {
+  SeqSet &s = c->seqs;
+  constexpr int T = TileCfg<S>::kT;
+  const uint64_t n_tiles = div_ceil(n_items, T);
+  const int full_words = kmer_bits / 32, rem = kmer_bits % 32;
+  const uint32_t last_mask = rem ? 0xFFFFFFFFu << (32 - rem) : 0;
+  S1Op<S> op{KWv, m, s.start.as<uint64_t>(), s.n_seqs, s.fixed_len, is_solid, hist, ctr, want_mercy, mercy, ctr + 1};
+  MHX_LAUNCH(c, "s1_groups", (double)n_items * S * 4,
+             hipLaunchKernelGGL((k_tile_groups<S, S1Op<S>, false>), dim3((unsigned)n_tiles), dim3(kTileThreads), 0, c->stream, sorted,
+                                n_items, full_words, last_mask, op, (uint64_t *)nullptr, (const uint64_t *)nullptr, n_tiles));
 }
 
 // int64 <-> (hi,lo) word pairs so that the big-endian record sort orders them numerically
@@ -244,7 +279,6 @@ int s1_process(mhx_ctx *c, uint32_t k, uint32_t m, int want_mercy, uint32_t *buf
                mhx_s1_result *out) {
   SeqSet &s = c->seqs;
   const int KWv = s1_kw(k), S = round_up2(KWv + 2);
-  const uint64_t ns = s.n_seqs;
   const size_t item_bytes = (size_t)S * 4;
   hipStream_t st = c->stream;
   const bool global = c->global_bases != 0;  // multi-GPU: positions index the global read set
@@ -263,16 +297,17 @@ int s1_process(mhx_ctx *c, uint32_t k, uint32_t m, int want_mercy, uint32_t *buf
   unsigned long long *ctr = c->ws("s1_counters", 64).as<unsigned long long>();
   MHX_HIP(hipMemsetAsync(ctr, 0, 64, st));
 
-  const uint64_t n_groups = count_group_heads(c, sorted, n_items, S, kmer_bits);
   uint64_t n_solid = 0, n_mercy = 0;
-  if (n_groups) {
-    uint64_t *heads = c->ws("heads", n_groups * 8).as<uint64_t>();
-    find_group_heads(c, sorted, n_items, S, kmer_bits, heads, nullptr);
+  if (n_items) {
     // mercy candidates (<= 2 per item, 8 B each) go to the spare sort buffer: S*4 >= 16 bytes per item
     long long *mercy = reinterpret_cast<long long *>(spare);
-    MHX_LAUNCH(c, "s1_groups", (double)n_items * item_bytes + (double)n_groups * 8,
-               hipLaunchKernelGGL(k_s1_groups, dim3((unsigned)div_ceil(n_groups, 256)), dim3(256), 0, st, sorted, n_items, S, KWv, heads,
-                                  n_groups, m, s.start.as<uint64_t>(), ns, s.fixed_len, is_solid, hist, ctr, want_mercy, mercy, ctr + 1));
+    switch (S) {
+#define MHX_CASE(SV) \
+  case SV: s1_groups_launch<SV>(c, sorted, n_items, KWv, kmer_bits, m, is_solid, hist, ctr, want_mercy, mercy); break;
+      MHX_CASE(4) MHX_CASE(6) MHX_CASE(8) MHX_CASE(10) MHX_CASE(12) MHX_CASE(14) MHX_CASE(16) MHX_CASE(18) MHX_CASE(20)
+#undef MHX_CASE
+      default: throw Error("read2sdbg_s1: unsupported record stride");
+    }
     unsigned long long h[2];
     MHX_HIP(hipMemcpyAsync(h, ctr, 16, hipMemcpyDeviceToHost, st));
     MHX_HIP(hipStreamSynchronize(st));

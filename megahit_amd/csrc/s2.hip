@@ -12,6 +12,7 @@
 //   bucket_stats            per-bucket starting offset / item / tip / large counts (sdbg_meta.h:22-34)
 #include "dev_prims.h"
 #include "mhx_internal.h"
+#include "tile_groups.h"
 
 namespace mhx {
 
@@ -150,22 +151,21 @@ struct SdbgParams {
   int is_seq;          // multiplicity comes from the key (seq2sdbg) instead of the run length (S2)
 };
 
-__device__ __forceinline__ int ex_a(const uint32_t *__restrict__ it, const SdbgParams &P) {
-  return ((it[P.kw - 1] >> P.fshift) & 1u) ? (int)((it[P.aw] >> P.ashift) & 3u) : 4;
-}
-__device__ __forceinline__ int ex_b(const uint32_t *__restrict__ it, const SdbgParams &P) { return (int)((it[P.kw - 1] >> P.bshift) & 7u); }
-
 // Walks one (k-1)-mer group exactly as Lv2Postprocess does (read_to_sdbg_s2.cpp:537-611 /
-// seq_to_sdbg.cpp:718-786).  EMIT=false counts records; EMIT=true writes them.
-template <bool EMIT>
-__device__ __forceinline__ void sdbg_walk_group(const uint32_t *__restrict__ items, uint64_t b, uint64_t e, const SdbgParams &P,
-                                                uint32_t &n_out, uint32_t &n_tips, uint32_t &n_large, uint16_t *__restrict__ out16,
-                                                uint64_t o16, uint32_t *wcnt /* [10] when EMIT */) {
+// seq_to_sdbg.cpp:718-786), records coming from the LDS tile.  EMIT=false counts records;
+// EMIT=true writes them.
+template <int S, bool EMIT>
+__device__ __forceinline__ void sdbg_walk_group(const TileAcc<S> &acc, uint32_t b, uint32_t e, const SdbgParams &P, uint32_t &n_out,
+                                                uint32_t &n_tips, uint32_t &n_large, uint16_t *__restrict__ out16, uint64_t o16,
+                                                uint32_t *wcnt /* [10] when EMIT */) {
+  auto ex_a = [&](uint32_t i) -> int {
+    return ((acc.word(i, P.kw - 1) >> P.fshift) & 1u) ? (int)((acc.word(i, P.aw) >> P.ashift) & 3u) : 4;
+  };
+  auto ex_b = [&](uint32_t i) -> int { return (int)((acc.word(i, P.kw - 1) >> P.bshift) & 7u); };
   int has_a = 0, has_b = 0;
-  uint64_t la0 = ~0ull, la1 = ~0ull, la2 = ~0ull, la3 = ~0ull;
-  for (uint64_t i = b; i < e; ++i) {
-    const uint32_t *it = items + i * P.stride;
-    const int a = ex_a(it, P), bb = ex_b(it, P);
+  uint32_t la0 = ~0u, la1 = ~0u, la2 = ~0u, la3 = ~0u;
+  for (uint32_t i = b; i < e; ++i) {
+    const int a = ex_a(i), bb = ex_b(i);
     if (a != 4 && bb != 4) {
       has_a |= 1 << a;
       has_b |= 1 << bb;
@@ -178,15 +178,10 @@ __device__ __forceinline__ void sdbg_walk_group(const uint32_t *__restrict__ ite
     }
   }
   int outputed_b = 0;
-  for (uint64_t i = b, j; i < e; i = j) {
-    const uint32_t *cur = items + i * P.stride;
-    const int a = ex_a(cur, P), bb = ex_b(cur, P);
+  for (uint32_t i = b, j; i < e; i = j) {
+    const int a = ex_a(i), bb = ex_b(i);
     j = i + 1;
-    while (j < e) {
-      const uint32_t *nx = items + j * P.stride;
-      if (ex_a(nx, P) != a || ex_b(nx, P) != bb) break;
-      ++j;
-    }
+    while (j < e && ex_a(j) == a && ex_b(j) == bb) ++j;
     int is_dollar = 0;
     if (a == 4) {
       if (has_b & (1 << bb)) continue;
@@ -196,12 +191,12 @@ __device__ __forceinline__ void sdbg_walk_group(const uint32_t *__restrict__ ite
       if (has_a & (1 << a)) continue;
     }
     const int w = bb == 4 ? 0 : ((outputed_b & (1 << bb)) ? bb + 5 : bb + 1);
-    const uint64_t la = a == 0 ? la0 : (a == 1 ? la1 : (a == 2 ? la2 : la3));
+    const uint32_t la = a == 0 ? la0 : (a == 1 ? la1 : (a == 2 ? la2 : la3));
     const int last = a == 4 ? 0 : (la == j - 1 ? 1 : 0);
     outputed_b |= 1 << bb;
     uint32_t mul;
-    if (P.is_seq) mul = MHX_MAX_MUL - (cur[P.kw - 1] & 0xFFFFu);
-    else mul = (j - i) > (uint64_t)MHX_MAX_MUL ? (uint32_t)MHX_MAX_MUL : (uint32_t)(j - i);
+    if (P.is_seq) mul = MHX_MAX_MUL - (acc.word(i, P.kw - 1) & 0xFFFFu);
+    else mul = (j - i) > (uint32_t)MHX_MAX_MUL ? (uint32_t)MHX_MAX_MUL : (j - i);
     ++n_out;
     n_tips += is_dollar;
     n_large += mul > 254;
@@ -211,7 +206,7 @@ __device__ __forceinline__ void sdbg_walk_group(const uint32_t *__restrict__ ite
       if (mul > 254) out16[o16++] = (uint16_t)mul;
       if (is_dollar) {
         for (int x = 0; x < P.wpt; ++x) {
-          const uint32_t v = cur[x];
+          const uint32_t v = acc.word(i, x);
           out16[o16++] = (uint16_t)(v & 0xFFFFu);
           out16[o16++] = (uint16_t)(v >> 16);
         }
@@ -222,61 +217,140 @@ __device__ __forceinline__ void sdbg_walk_group(const uint32_t *__restrict__ ite
   }
 }
 
-__global__ __launch_bounds__(256) void k_sdbg_count(const uint32_t *__restrict__ items, uint64_t n, const uint64_t *__restrict__ heads,
-                                                    uint64_t n_groups, SdbgParams P, uint32_t *__restrict__ g_out,
-                                                    uint32_t *__restrict__ g_tips, uint32_t *__restrict__ g_large) {
-  const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= n_groups) return;
-  const uint64_t b = heads[g], e = (g + 1 < n_groups) ? heads[g + 1] : n;
-  uint32_t no = 0, nt = 0, nl = 0;
-  sdbg_walk_group<false>(items, b, e, P, no, nt, nl, nullptr, 0, nullptr);
-  g_out[g] = no;
-  g_tips[g] = nt;
-  g_large[g] = nl;
+__device__ __forceinline__ uint32_t *sdbg_wcnt() {
+  __shared__ uint32_t w[10];
+  return w;
 }
 
-__global__ __launch_bounds__(256) void k_sdbg_emit(const uint32_t *__restrict__ items, uint64_t n, const uint64_t *__restrict__ heads,
-                                                   uint64_t n_groups, SdbgParams P, const uint64_t *__restrict__ s_out,
-                                                   const uint64_t *__restrict__ s_tips, const uint64_t *__restrict__ s_large,
-                                                   uint16_t *__restrict__ out16, unsigned long long *__restrict__ w_count) {
-  __shared__ uint32_t wcnt[10];
-  if (threadIdx.x < 10) wcnt[threadIdx.x] = 0;
-  __syncthreads();
-  const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (g < n_groups) {
-    const uint64_t b = heads[g], e = (g + 1 < n_groups) ? heads[g + 1] : n;
-    uint32_t no = 0, nt = 0, nl = 0;
-    const uint64_t o16 = s_out[g] + s_large[g] + 2ull * P.wpt * s_tips[g];
-    sdbg_walk_group<true>(items, b, e, P, no, nt, nl, out16, o16, wcnt);
+constexpr unsigned long long kNoStart = ~0ull;
+
+template <int S>
+struct SdbgOp {
+  SdbgParams P;
+  uint16_t *out16;
+  unsigned long long *w_count;
+  unsigned long long *bstart;  // [3][65536]: running (records, tips, large) at the first group of each bucket
+
+  __device__ void begin_block() const {
+    if (threadIdx.x < 10) sdbg_wcnt()[threadIdx.x] = 0;
+    __syncthreads();
   }
-  __syncthreads();
-  if (threadIdx.x < 10 && wcnt[threadIdx.x]) atomicAdd(&w_count[threadIdx.x], (unsigned long long)wcnt[threadIdx.x]);
-}
-
-__global__ void k_bucket_stats(const uint32_t *__restrict__ items, int stride, const uint64_t *__restrict__ heads, uint64_t n_groups,
-                               const uint64_t *__restrict__ s_out, const uint64_t *__restrict__ s_tips,
-                               const uint64_t *__restrict__ s_large, int wpt, unsigned long long *__restrict__ b_items,
-                               unsigned long long *__restrict__ b_tips, unsigned long long *__restrict__ b_large,
-                               unsigned long long *__restrict__ b_off) {
-  const uint32_t bk = blockIdx.x * blockDim.x + threadIdx.x;
-  if (bk >= MHX_NUM_BUCKETS) return;
-  uint64_t bound[2];
-#pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    const uint32_t target = bk + t;  // first group whose bucket >= target
-    uint64_t lo = 0, hi = n_groups;
-    while (lo < hi) {
-      uint64_t mid = (lo + hi) >> 1;
-      if ((items[heads[mid] * stride] >> 16) < target) lo = mid + 1;
-      else hi = mid;
+  __device__ void end_block() const {
+    if (out16 && threadIdx.x < 10 && sdbg_wcnt()[threadIdx.x]) atomicAdd(&w_count[threadIdx.x], (unsigned long long)sdbg_wcnt()[threadIdx.x]);
+  }
+  __device__ GroupCounts count(const TileAcc<S> &acc, uint32_t b, uint32_t e) const {
+    GroupCounts gc;
+    sdbg_walk_group<S, false>(acc, b, e, P, gc.c0, gc.c1, gc.c2, nullptr, 0, nullptr);
+    return gc;
+  }
+  __device__ void emit(const TileAcc<S> &acc, uint32_t b, uint32_t e, uint64_t o0, uint64_t o1, uint64_t o2) const {
+    // first group of its lv1 bucket?  (the previous record has another bucket prefix)
+    const uint32_t bk = acc.word(b, 0) >> 16;
+    bool first = acc.base + b == 0;
+    if (!first) {
+      const uint32_t prev = b > 0 ? acc.word(b - 1, 0) : acc.glob[(acc.base - 1) * S];
+      first = (prev >> 16) != bk;
     }
-    bound[t] = lo;
+    if (first) {
+      bstart[bk] = o0;
+      bstart[MHX_NUM_BUCKETS + bk] = o1;
+      bstart[2 * MHX_NUM_BUCKETS + bk] = o2;
+    }
+    uint32_t no = 0, nt = 0, nl = 0;
+    sdbg_walk_group<S, true>(acc, b, e, P, no, nt, nl, out16, o0 + o2 + 2ull * P.wpt * o1, sdbg_wcnt());
   }
-  const uint64_t g0 = bound[0], g1 = bound[1];
-  b_items[bk] = s_out[g1] - s_out[g0];
-  b_tips[bk] = s_tips[g1] - s_tips[g0];
-  b_large[bk] = s_large[g1] - s_large[g0];
-  b_off[bk] = 2ull * (s_out[g0] + s_large[g0]) + 4ull * wpt * s_tips[g0];
+};
+
+// bstart[3][65536] (kNoStart = empty bucket) + totals -> per-bucket counts and byte offsets.
+// One workgroup; thread t owns buckets [256t, 256t+256).
+__global__ __launch_bounds__(256) void k_bucket_fix(const unsigned long long *__restrict__ bstart, const uint64_t *__restrict__ totals,
+                                                    int wpt, unsigned long long *__restrict__ b_items, unsigned long long *__restrict__ b_tips,
+                                                    unsigned long long *__restrict__ b_large, unsigned long long *__restrict__ b_off) {
+  __shared__ unsigned long long first[3][256];
+  const int t = threadIdx.x, lo = t * 256, hi = lo + 256;
+  unsigned long long f0 = kNoStart, f1 = kNoStart, f2 = kNoStart;
+  for (int bk = lo; bk < hi; ++bk)
+    if (bstart[bk] != kNoStart) {
+      f0 = bstart[bk];
+      f1 = bstart[MHX_NUM_BUCKETS + bk];
+      f2 = bstart[2 * MHX_NUM_BUCKETS + bk];
+      break;
+    }
+  first[0][t] = f0;
+  first[1][t] = f1;
+  first[2][t] = f2;
+  __syncthreads();
+  unsigned long long n0 = totals[0], n1 = totals[1], n2 = totals[2];  // start of the next non-empty bucket
+  for (int u = t + 1; u < 256; ++u)
+    if (first[0][u] != kNoStart) {
+      n0 = first[0][u];
+      n1 = first[1][u];
+      n2 = first[2][u];
+      break;
+    }
+  for (int bk = hi - 1; bk >= lo; --bk) {
+    const unsigned long long s0 = bstart[bk];
+    if (s0 != kNoStart) {
+      const unsigned long long s1 = bstart[MHX_NUM_BUCKETS + bk], s2 = bstart[2 * MHX_NUM_BUCKETS + bk];
+      b_items[bk] = n0 - s0;
+      b_tips[bk] = n1 - s1;
+      b_large[bk] = n2 - s2;
+      b_off[bk] = 2ull * (s0 + s2) + 4ull * wpt * s1;
+      n0 = s0;
+      n1 = s1;
+      n2 = s2;
+    } else {
+      b_items[bk] = b_tips[bk] = b_large[bk] = 0;
+      b_off[bk] = 2ull * (n0 + n2) + 4ull * wpt * n1;
+    }
+  }
+}
+
+template <int S>
+static void emit_sdbg_impl(mhx_ctx *c, const uint32_t *sorted, uint64_t n_items, const SdbgParams &P, int kmer_bits, uint64_t tot[3]) {
+  hipStream_t st = c->stream;
+  unsigned long long *b_items = c->result(MHX_BUF_BUCKET_COUNT, MHX_NUM_BUCKETS * 8).as<unsigned long long>();
+  unsigned long long *b_tips = c->result(MHX_BUF_BUCKET_TIPS, MHX_NUM_BUCKETS * 8).as<unsigned long long>();
+  unsigned long long *b_large = c->result(MHX_BUF_BUCKET_LARGE, MHX_NUM_BUCKETS * 8).as<unsigned long long>();
+  unsigned long long *b_off = c->result(MHX_BUF_BUCKET_OFFSET, MHX_NUM_BUCKETS * 8).as<unsigned long long>();
+  unsigned long long *w_count = c->result(MHX_BUF_W_COUNT, 10 * 8).as<unsigned long long>();
+  MHX_HIP(hipMemsetAsync(w_count, 0, 80, st));
+  tot[0] = tot[1] = tot[2] = 0;
+  if (n_items == 0) {
+    c->result(MHX_BUF_SDBG_BYTES, 2);
+    c->results[MHX_BUF_SDBG_BYTES].used = 0;
+    MHX_HIP(hipMemsetAsync(b_items, 0, MHX_NUM_BUCKETS * 8, st));
+    MHX_HIP(hipMemsetAsync(b_tips, 0, MHX_NUM_BUCKETS * 8, st));
+    MHX_HIP(hipMemsetAsync(b_large, 0, MHX_NUM_BUCKETS * 8, st));
+    MHX_HIP(hipMemsetAsync(b_off, 0, MHX_NUM_BUCKETS * 8, st));
+    return;
+  }
+  constexpr int T = TileCfg<S>::kT;
+  const uint64_t n_tiles = div_ceil(n_items, T);
+  uint64_t *tt = c->ws("tile_tot", (3 * n_tiles + 4) * 8).as<uint64_t>();
+  uint64_t *tb = c->ws("tile_base", (3 * n_tiles + 4) * 8).as<uint64_t>();
+  uint64_t *d_tot = c->ws("tile_totals", 64).as<uint64_t>();
+  unsigned long long *bstart = c->ws("bucket_start", 3 * MHX_NUM_BUCKETS * 8).as<unsigned long long>();
+  const int full_words = kmer_bits / 32, rem = kmer_bits % 32;
+  const uint32_t last_mask = rem ? 0xFFFFFFFFu << (32 - rem) : 0;
+  SdbgOp<S> op{P, nullptr, w_count, bstart};
+  const double bytes = (double)n_items * S * 4;
+  MHX_LAUNCH(c, "sdbg_count", bytes,
+             hipLaunchKernelGGL((k_tile_groups<S, SdbgOp<S>, false>), dim3((unsigned)n_tiles), dim3(kTileThreads), 0, st, sorted, n_items,
+                                full_words, last_mask, op, tt, (const uint64_t *)nullptr, n_tiles));
+  for (int r = 0; r < 3; ++r) exclusive_scan_u64(c, tt + r * n_tiles, tb + r * n_tiles, n_tiles, d_tot + r);
+  MHX_HIP(hipMemcpyAsync(tot, d_tot, 24, hipMemcpyDeviceToHost, st));
+  MHX_HIP(hipStreamSynchronize(st));
+  const uint64_t out_bytes = 2 * (tot[0] + tot[2]) + 4ull * P.wpt * tot[1];
+  uint16_t *out16 = c->result(MHX_BUF_SDBG_BYTES, out_bytes ? out_bytes : 2).as<uint16_t>();
+  c->results[MHX_BUF_SDBG_BYTES].used = out_bytes;
+  MHX_HIP(hipMemsetAsync(bstart, 0xFF, 3 * MHX_NUM_BUCKETS * 8, st));
+  op.out16 = out16;
+  MHX_LAUNCH(c, "sdbg_emit", bytes + (double)out_bytes,
+             hipLaunchKernelGGL((k_tile_groups<S, SdbgOp<S>, true>), dim3((unsigned)n_tiles), dim3(kTileThreads), 0, st, sorted, n_items,
+                                full_words, last_mask, op, (uint64_t *)nullptr, (const uint64_t *)tb, n_tiles));
+  MHX_LAUNCH(c, "bucket_stats", (double)MHX_NUM_BUCKETS * 56,
+             hipLaunchKernelGGL(k_bucket_fix, dim3(1), dim3(256), 0, st, bstart, d_tot, P.wpt, b_items, b_tips, b_large, b_off));
 }
 
 // sorted: n_items records of stride S with kw key words, sorted; fills the SdBG result buffers.
@@ -292,51 +366,14 @@ void emit_sdbg(mhx_ctx *c, const uint32_t *sorted, uint64_t n_items, int S, int 
   P.ashift = (15 - (int)((k - 1) % 16)) * 2;
   P.wpt = (int)div_ceil(k, 16);
   P.is_seq = is_seq;
-
-  unsigned long long *b_items = c->result(MHX_BUF_BUCKET_COUNT, MHX_NUM_BUCKETS * 8).as<unsigned long long>();
-  unsigned long long *b_tips = c->result(MHX_BUF_BUCKET_TIPS, MHX_NUM_BUCKETS * 8).as<unsigned long long>();
-  unsigned long long *b_large = c->result(MHX_BUF_BUCKET_LARGE, MHX_NUM_BUCKETS * 8).as<unsigned long long>();
-  unsigned long long *b_off = c->result(MHX_BUF_BUCKET_OFFSET, MHX_NUM_BUCKETS * 8).as<unsigned long long>();
-  unsigned long long *w_count = c->result(MHX_BUF_W_COUNT, 10 * 8).as<unsigned long long>();
-  MHX_HIP(hipMemsetAsync(w_count, 0, 80, st));
-
   const int kmer_bits = (int)(k - 1) * 2;
-  const uint64_t n_groups = count_group_heads(c, sorted, n_items, S, kmer_bits);
   uint64_t tot[3] = {0, 0, 0};
-  if (n_groups) {
-    uint64_t *heads = c->ws("heads", n_groups * 8).as<uint64_t>();
-    find_group_heads(c, sorted, n_items, S, kmer_bits, heads, nullptr);
-    uint32_t *g3 = c->ws("sdbg_group_cnt", n_groups * 12).as<uint32_t>();
-    uint32_t *g_out = g3, *g_tips = g3 + n_groups, *g_large = g3 + 2 * n_groups;
-    uint64_t *s3 = c->ws("sdbg_group_scan", (n_groups + 1) * 24).as<uint64_t>();
-    uint64_t *s_out = s3, *s_tips = s3 + (n_groups + 1), *s_large = s3 + 2 * (n_groups + 1);
-    const unsigned grid = (unsigned)div_ceil(n_groups, 256);
-    const double item_bytes = (double)n_items * S * 4;
-    MHX_LAUNCH(c, "sdbg_count", 2 * item_bytes + (double)n_groups * 20,
-               hipLaunchKernelGGL(k_sdbg_count, dim3(grid), dim3(256), 0, st, sorted, n_items, heads, n_groups, P, g_out, g_tips, g_large));
-    exclusive_scan_u32_u64(c, g_out, s_out, n_groups, s_out + n_groups);
-    exclusive_scan_u32_u64(c, g_tips, s_tips, n_groups, s_tips + n_groups);
-    exclusive_scan_u32_u64(c, g_large, s_large, n_groups, s_large + n_groups);
-    MHX_HIP(hipMemcpyAsync(&tot[0], s_out + n_groups, 8, hipMemcpyDeviceToHost, st));
-    MHX_HIP(hipMemcpyAsync(&tot[1], s_tips + n_groups, 8, hipMemcpyDeviceToHost, st));
-    MHX_HIP(hipMemcpyAsync(&tot[2], s_large + n_groups, 8, hipMemcpyDeviceToHost, st));
-    MHX_HIP(hipStreamSynchronize(st));
-    const uint64_t bytes = 2 * (tot[0] + tot[2]) + 4ull * P.wpt * tot[1];
-    uint16_t *out16 = c->result(MHX_BUF_SDBG_BYTES, bytes ? bytes : 2).as<uint16_t>();
-    c->results[MHX_BUF_SDBG_BYTES].used = bytes;
-    MHX_LAUNCH(c, "sdbg_emit", 2 * item_bytes + (double)n_groups * 32 + (double)bytes,
-               hipLaunchKernelGGL(k_sdbg_emit, dim3(grid), dim3(256), 0, st, sorted, n_items, heads, n_groups, P, s_out, s_tips, s_large,
-                                  out16, w_count));
-    MHX_LAUNCH(c, "bucket_stats", (double)MHX_NUM_BUCKETS * 32,
-               hipLaunchKernelGGL(k_bucket_stats, dim3(MHX_NUM_BUCKETS / 256), dim3(256), 0, st, sorted, S, heads, n_groups, s_out, s_tips,
-                                  s_large, P.wpt, b_items, b_tips, b_large, b_off));
-  } else {
-    c->result(MHX_BUF_SDBG_BYTES, 2);
-    c->results[MHX_BUF_SDBG_BYTES].used = 0;
-    MHX_HIP(hipMemsetAsync(b_items, 0, MHX_NUM_BUCKETS * 8, st));
-    MHX_HIP(hipMemsetAsync(b_tips, 0, MHX_NUM_BUCKETS * 8, st));
-    MHX_HIP(hipMemsetAsync(b_large, 0, MHX_NUM_BUCKETS * 8, st));
-    MHX_HIP(hipMemsetAsync(b_off, 0, MHX_NUM_BUCKETS * 8, st));
+  switch (S) {
+#define MHX_CASE(SV) \
+  case SV: emit_sdbg_impl<SV>(c, sorted, n_items, P, kmer_bits, tot); break;
+    MHX_CASE(2) MHX_CASE(4) MHX_CASE(6) MHX_CASE(8) MHX_CASE(10) MHX_CASE(12) MHX_CASE(14) MHX_CASE(16) MHX_CASE(18) MHX_CASE(20)
+#undef MHX_CASE
+    default: throw Error("emit_sdbg: unsupported record stride");
   }
   c->results[MHX_BUF_SORTED_ITEMS].release();
   c->results[MHX_BUF_SORTED_ITEMS].p = const_cast<uint32_t *>(sorted);

@@ -213,14 +213,15 @@ static uint32_t *radix_sort_impl(mhx_ctx *c, uint32_t *a, uint32_t *b, uint64_t 
   uint32_t *hist = c->ws("sort_hist", n_chunks * 256 * 4).as<uint32_t>();
   uint64_t *offs = c->ws("sort_offs", n_chunks * 256 * 8).as<uint64_t>();
   const double bytes = (double)n * S * 4;
+  static const std::string nm_hist = "radix_hist_" + std::to_string(S * 4) + "B", nm_scat = "radix_scatter_" + std::to_string(S * 4) + "B";
   for (const SortPass &ps : passes) {
     const int wi = key_words - 1 - ps.shift / 32;
     const unsigned bit = ps.shift % 32, mask = (1u << ps.bits) - 1;
-    MHX_LAUNCH(c, "radix_hist", bytes,
+    MHX_LAUNCH(c, nm_hist.c_str(), bytes,
                hipLaunchKernelGGL(k_radix_hist<S>, dim3((unsigned)n_chunks), dim3(kSortThreads), 0, c->stream, a, n, wi, bit, mask,
                                   hist, n_chunks, (const uint8_t *)nullptr));
     exclusive_scan_u32_u64(c, hist, offs, n_chunks * 256, nullptr);
-    MHX_LAUNCH(c, "radix_scatter", 2 * bytes,
+    MHX_LAUNCH(c, nm_scat.c_str(), 2 * bytes,
                hipLaunchKernelGGL(k_radix_scatter<S>, dim3((unsigned)n_chunks), dim3(kSortThreads), 0, c->stream, a, b, n, wi, bit,
                                   mask, ps.bits, offs, n_chunks, (const uint8_t *)nullptr));
     std::swap(a, b);
