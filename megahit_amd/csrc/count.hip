@@ -73,14 +73,34 @@ __global__ __launch_bounds__(256) void k_count_extract(const uint32_t *__restric
 // ---------------------------------------------------------------------------
 constexpr int kLocalHist = 1024;
 
+template <int S>
+struct CountTile {
+  static constexpr int kRaw = 16384 / (S * 4);
+  static constexpr int kT = kRaw >= 1024 ? 1024 : (kRaw >= 256 ? (kRaw / 256) * 256 : 256);
+  static constexpr int kRuns = kT + kMaxTailRuns;
+};
+
 __device__ __forceinline__ uint32_t *count_local_hist() {
   __shared__ uint32_t lh[kLocalHist];
   return lh;
 }
+template <int S>
+__device__ __forceinline__ uint32_t *count_run_ctr() {  // [run][8]: prev A,C,G,T / next A,C,G,T
+  __shared__ uint32_t rc[CountTile<S>::kRuns * 8];
+  return rc;
+}
+template <int S>
+__device__ __forceinline__ uint8_t *count_run_mark() {
+  __shared__ uint8_t mk[CountTile<S>::kRuns];
+  return mk;
+}
 
-// Lv2Postprocess of KmerCounter (kmer_counter.cpp:254-381) as a tile-group operator (tile_groups.h).
+// Lv2Postprocess of KmerCounter (kmer_counter.cpp:254-381) as a tile operator (tile_groups.h).
+// A run is a whole group here (all records of a (k+1)-mer).
 template <int S>
 struct CountOp {
+  static constexpr bool kItemPhase = true, kItemFinal = true, kRunPhase = false, kUnitIsRun = false;
+  __device__ void run_phase(const TileCtx<S> &, uint32_t, uint32_t) const {}
   int kw, wpe;
   uint32_t m;
   int side_effects;  // first launch: histogram + first_0_out/last_0_in atomics; second launch: emit only
@@ -91,10 +111,15 @@ struct CountOp {
   unsigned long long *hist, *bucket_count;
   uint32_t *edges;
 
+  __device__ bool same_run(const uint32_t *, const uint32_t *) const { return true; }
+  __device__ bool item_phase_enabled() const { return side_effects != 0; }
+  __device__ bool item_final_enabled() const { return side_effects != 0; }
   __device__ void begin_block() const {
     if (!side_effects) return;
     uint32_t *lh = count_local_hist();
     for (int i = threadIdx.x; i < kLocalHist; i += blockDim.x) lh[i] = 0;
+    uint32_t *rc = count_run_ctr<S>();
+    for (int i = threadIdx.x; i < CountTile<S>::kRuns * 8; i += blockDim.x) rc[i] = 0;
     __syncthreads();
   }
   __device__ void end_block() const {
@@ -103,61 +128,61 @@ struct CountOp {
     for (int i = threadIdx.x; i < kLocalHist; i += blockDim.x)
       if (lh[i]) atomicAdd(&hist[i], (unsigned long long)lh[i]);
   }
-  __device__ GroupCounts count(const TileAcc<S> &acc, uint32_t b, uint32_t e) const {
+  // per record: count_prev / count_next of its run (:283-292)
+  __device__ void item_phase(const TileCtx<S> &c, uint32_t rel, uint32_t run) const {
+    const unsigned pn = c.acc.word(rel, kw + 1) & 63u, pv = pn >> 3, nx = pn & 7;
+    uint32_t *rc = count_run_ctr<S>() + run * 8;
+    if (pv < 4) atomicAdd(&rc[pv], 1u);
+    if (nx < 4) atomicAdd(&rc[4 + nx], 1u);
+  }
+  __device__ GroupCounts unit_count(const TileCtx<S> &c, uint32_t g) const {
     GroupCounts gc;
-    const uint32_t count = e - b;
+    const uint32_t r = c.gpos[g];
+    const uint32_t count = c.run_len(r);
     const bool solid = count >= m;
     gc.c0 = solid ? 1u : 0u;
     gc.c1 = 1u;
     if (!side_effects) return gc;
-    uint32_t cp[4] = {0, 0, 0, 0}, cn[4] = {0, 0, 0, 0};
-    for (uint32_t j = b; j < e; ++j) {
-      const unsigned pn = acc.word(j, kw + 1) & 63u;
-      const unsigned pv = pn >> 3, nx = pn & 7;
-#pragma unroll
-      for (int x = 0; x < 4; ++x) {
-        cp[x] += (pv == (unsigned)x);
-        cn[x] += (nx == (unsigned)x);
-      }
-    }
+    const uint32_t *rc = count_run_ctr<S>() + r * 8;
     bool has_in = false, has_out = false;
 #pragma unroll
     for (int x = 0; x < 4; ++x) {
-      has_in |= cp[x] >= m;
-      has_out |= cn[x] >= m;
+      has_in |= rc[x] >= m;
+      has_out |= rc[4 + x] >= m;
     }
-    if (solid && (!has_in || !has_out)) {
-      for (uint32_t j = b; j < e; ++j) {
-        const uint64_t info = (((uint64_t)acc.word(j, kw) << 32) | acc.word(j, kw + 1)) >> 6;
-        const uint64_t abs = info >> 1;
-        const unsigned strand = (unsigned)(info & 1);
-        const uint64_t rid = seq_of_offset(start, n_seqs, fixed_len, abs);
-        const uint32_t off = (uint32_t)(abs - start[rid]);
-        // !has_in: strand 0 -> last_0_in = max(off), strand 1 -> first_0_out = min(off+1)   (:307-337)
-        // !has_out: the roles swap                                                             (:339-368)
-        if (!has_in) {
-          if (strand == 0) atomicMax(&last_0_in_p1[rid], off + 1);
-          else atomicMin(&first_0_out[rid], off + 1);
-        }
-        if (!has_out) {
-          if (strand == 0) atomicMin(&first_0_out[rid], off + 1);
-          else atomicMax(&last_0_in_p1[rid], off + 1);
-        }
-      }
-    }
+    count_run_mark<S>()[r] = (uint8_t)((solid && !has_in ? 1 : 0) | (solid && !has_out ? 2 : 0));
     const uint32_t hb = count > MHX_MAX_MUL ? (uint32_t)MHX_MAX_MUL : count;
     if (hb < kLocalHist) atomicAdd(&count_local_hist()[hb], 1u);
     else atomicAdd(&hist[hb], 1ull);
     return gc;
   }
+  // per record of a solid run without in/out: first_0_out / last_0_in (:307-368)
+  __device__ void item_final(const TileCtx<S> &c, uint32_t rel, uint32_t run) const {
+    const unsigned f = count_run_mark<S>()[run];
+    if (!f) return;
+    const uint64_t info = (((uint64_t)c.acc.word(rel, kw) << 32) | c.acc.word(rel, kw + 1)) >> 6;
+    const uint64_t abs = info >> 1;
+    const unsigned strand = (unsigned)(info & 1);
+    const uint64_t rid = seq_of_offset(start, n_seqs, fixed_len, abs);
+    const uint32_t off = (uint32_t)(abs - start[rid]);
+    if (f & 1u) {  // !has_in: strand 0 -> last_0_in = max(off), strand 1 -> first_0_out = min(off+1)
+      if (strand == 0) atomicMax(&last_0_in_p1[rid], off + 1);
+      else atomicMin(&first_0_out[rid], off + 1);
+    }
+    if (f & 2u) {  // !has_out: the roles swap
+      if (strand == 0) atomicMin(&first_0_out[rid], off + 1);
+      else atomicMax(&last_0_in_p1[rid], off + 1);
+    }
+  }
   // PackEdge (kmer_counter.cpp:32-52) + EdgeWriter::Write bucket accounting
-  __device__ void emit(const TileAcc<S> &acc, uint32_t b, uint32_t e, uint64_t o0, uint64_t, uint64_t) const {
-    const uint32_t count = e - b;
+  __device__ void unit_emit(const TileCtx<S> &c, uint32_t g, uint64_t o0, uint64_t, uint64_t) const {
+    const uint32_t r = c.gpos[g];
+    const uint32_t count = c.run_len(r), b = c.run_start(r);
     if (count < m) return;
     uint32_t *ed = edges + o0 * wpe;
-    for (int x = 0; x < wpe; ++x) ed[x] = x < kw ? acc.word(b, x) : 0u;
+    for (int x = 0; x < wpe; ++x) ed[x] = x < kw ? c.acc.word(b, x) : 0u;
     ed[wpe - 1] |= count > MHX_MAX_MUL ? (uint32_t)MHX_MAX_MUL : count;
-    atomicAdd(&bucket_count[acc.word(b, 0) >> 16], 1ull);
+    atomicAdd(&bucket_count[c.acc.word(b, 0) >> 16], 1ull);
   }
 };
 
@@ -178,7 +203,7 @@ static void count_postprocess(mhx_ctx *c, const uint32_t *sorted, uint64_t n_ite
     c->results[MHX_BUF_EDGES].used = 0;
     return;
   }
-  constexpr int T = TileCfg<S>::kT;
+  constexpr int T = CountTile<S>::kT;
   const uint64_t n_tiles = div_ceil(n_items, T);
   uint64_t *tot = c->ws("tile_tot", (3 * n_tiles + 4) * 8).as<uint64_t>();
   uint64_t *tb = c->ws("tile_base", (3 * n_tiles + 4) * 8).as<uint64_t>();
@@ -187,7 +212,7 @@ static void count_postprocess(mhx_ctx *c, const uint32_t *sorted, uint64_t n_ite
   CountOp<S> op{KWv, wpe, m, 1, s.start.as<uint64_t>(), s.n_seqs, s.fixed_len, first, last, hist, bcount, nullptr};
   const double bytes = (double)n_items * S * 4;
   MHX_LAUNCH(c, "count_runs", bytes,
-             hipLaunchKernelGGL((k_tile_groups<S, CountOp<S>, false>), dim3((unsigned)n_tiles), dim3(kTileThreads), 0, st, sorted, n_items,
+             hipLaunchKernelGGL((k_tile_groups<S, T, CountOp<S>, false>), dim3((unsigned)n_tiles), dim3(kTileThreads), 0, st, sorted, n_items,
                                 full_words, last_mask, op, tot, (const uint64_t *)nullptr, n_tiles));
   uint64_t *d_tot = c->ws("tile_totals", 64).as<uint64_t>();
   exclusive_scan_u64(c, tot, tb, n_tiles, d_tot);
@@ -203,7 +228,7 @@ static void count_postprocess(mhx_ctx *c, const uint32_t *sorted, uint64_t n_ite
   op.side_effects = 0;
   op.edges = edges;
   MHX_LAUNCH(c, "count_emit", bytes + (double)h[0] * wpe * 4,
-             hipLaunchKernelGGL((k_tile_groups<S, CountOp<S>, true>), dim3((unsigned)n_tiles), dim3(kTileThreads), 0, st, sorted, n_items,
+             hipLaunchKernelGGL((k_tile_groups<S, T, CountOp<S>, true>), dim3((unsigned)n_tiles), dim3(kTileThreads), 0, st, sorted, n_items,
                                 full_words, last_mask, op, (uint64_t *)nullptr, (const uint64_t *)tb, n_tiles));
 }
 

@@ -93,6 +93,13 @@ __global__ __launch_bounds__(256) void k_s1_extract(const uint32_t *__restrict__
 
 constexpr int kS1LocalHist = 1024;
 
+template <int S>
+struct S1Tile {
+  static constexpr int kRaw = 32768 / (S * 4);
+  static constexpr int kT = kRaw >= 2048 ? 2048 : (kRaw >= 256 ? (kRaw / 256) * 256 : 256);
+  static constexpr int kRuns = kT + kMaxTailRuns;
+};
+
 __device__ __forceinline__ uint32_t *s1_local_hist() {
   __shared__ uint32_t lh[kS1LocalHist];
   return lh;
@@ -101,21 +108,34 @@ __device__ __forceinline__ unsigned long long *s1_block_solid() {
   __shared__ unsigned long long v;
   return &v;
 }
+template <int S>
+__device__ __forceinline__ uint32_t *s1_run_info() {  // bit0 solid | has_in<<1 | has_out<<5 | l_has_out<<9 | r_has_in<<13
+  __shared__ uint32_t ri[S1Tile<S>::kRuns];
+  return ri;
+}
 
-// Lv2Postprocess of Read2SdbgS1 (read_to_sdbg_s1.cpp:368-555) as a tile-group operator: one thread per
-// (k-1)-mer group, records read out of the LDS tile (tile_groups.h).  No ordered output: a single launch.
+// Lv2Postprocess of Read2SdbgS1 (read_to_sdbg_s1.cpp:368-555) as a tile operator (tile_groups.h):
+// run = records of one (k-1)-mer with the same (head,tail); the per-group logic iterates runs, the
+// per-record actions (is_solid bits, mercy candidates) are item-parallel.  No ordered output.
 template <int S>
 struct S1Op {
+  static constexpr bool kItemPhase = false, kItemFinal = true, kRunPhase = false, kUnitIsRun = false;
+  __device__ void run_phase(const TileCtx<S> &, uint32_t, uint32_t) const {}
   int kw;
   uint32_t m;
   const uint64_t *start;
   uint64_t n_seqs;
   uint32_t fixed_len;
-  unsigned long long *is_solid, *hist, *n_solid_out;
+  uint8_t *solid_bytes;  // one byte per base position (plain stores, packed to the bitmap afterwards)
+  unsigned long long *hist, *n_solid_out;
   int want_mercy;
   long long *mercy;
   unsigned long long *mercy_n;
 
+  __device__ bool same_run(const uint32_t *cur, const uint32_t *prev) const { return ((cur[kw - 1] ^ prev[kw - 1]) & 63u) == 0; }
+  __device__ bool item_phase_enabled() const { return false; }
+  __device__ bool item_final_enabled() const { return true; }
+  __device__ void item_phase(const TileCtx<S> &, uint32_t, uint32_t) const {}
   __device__ void begin_block() const {
     uint32_t *lh = s1_local_hist();
     for (int i = threadIdx.x; i < kS1LocalHist; i += blockDim.x) lh[i] = 0;
@@ -126,28 +146,23 @@ struct S1Op {
     uint32_t *lh = s1_local_hist();
     for (int i = threadIdx.x; i < kS1LocalHist; i += blockDim.x)
       if (lh[i]) atomicAdd(&hist[i], (unsigned long long)lh[i]);
-    if (threadIdx.x == 0 && *s1_block_solid()) atomicAdd(n_solid_out, *s1_block_solid());
+    (void)n_solid_out;  // counted by k_pack_solid
   }
-  __device__ void emit(const TileAcc<S> &, uint32_t, uint32_t, uint64_t, uint64_t, uint64_t) const {}
-  __device__ GroupCounts count(const TileAcc<S> &acc, uint32_t b, uint32_t e) const {
-    unsigned long long my_solid = 0;
-    const unsigned pn_first = acc.word(b, kw + 1) & 63u;  // H1: prev/next of the group's FIRST item, :399
-    uint32_t cnt_head[4] = {0, 0, 0, 0}, cnt_tail[4] = {0, 0, 0, 0};
+  __device__ void unit_emit(const TileCtx<S> &, uint32_t, uint64_t, uint64_t, uint64_t) const {}
+  __device__ GroupCounts unit_count(const TileCtx<S> &c, uint32_t g) const {
+    const uint32_t r0 = c.gpos[g], r1 = c.gpos[g + 1];
+    const unsigned pn_first = c.acc.word(c.run_start(r0), kw + 1) & 63u;  // H1: prev/next of the group's FIRST item, :399
+    uint64_t cnt_head[4] = {0, 0, 0, 0}, cnt_tail[4] = {0, 0, 0, 0};
     unsigned l_has_out = 0, r_has_in = 0;
-    // walk 1: (head,tail) run lengths
-    for (uint32_t j = b; j < e;) {
-      const unsigned ht = acc.word(j, kw - 1) & 63u;
-      const uint32_t j0 = j;
-      do ++j;
-      while (j < e && (acc.word(j, kw - 1) & 63u) == ht);
-      const uint32_t c = j - j0;
-      const unsigned h = ht >> 3, t = ht & 7;
+    for (uint32_t r = r0; r < r1; ++r) {
+      const unsigned ht = c.acc.word(c.run_start(r), kw - 1) & 63u, h = ht >> 3, t = ht & 7;
+      const uint32_t n = c.run_len(r);
 #pragma unroll
       for (int x = 0; x < 4; ++x) {
-        if (h == (unsigned)x) cnt_head[x] += c;
-        if (t == (unsigned)x) cnt_tail[x] += c;
+        if (h == (unsigned)x) cnt_head[x] += n;
+        if (t == (unsigned)x) cnt_tail[x] += n;
       }
-      if (h < 4 && t < 4 && c >= m) {
+      if (h < 4 && t < 4 && n >= m) {
         l_has_out |= 1u << h;
         r_has_in |= 1u << t;
       }
@@ -163,67 +178,95 @@ struct S1Op {
       for (int x = 0; x < 4; ++x)
         if (cnt_tail[x] >= m) has_out |= 1u << x;
     }
-    // walk 2
-    for (uint32_t j = b; j < e;) {
-      const unsigned ht = acc.word(j, kw - 1) & 63u;
-      const uint32_t j0 = j;
-      do ++j;
-      while (j < e && (acc.word(j, kw - 1) & 63u) == ht);
-      const uint32_t c = j - j0;
-      const unsigned h = ht >> 3, t = ht & 7;
+    const uint32_t masks = (has_in << 1) | (has_out << 5) | (l_has_out << 9) | (r_has_in << 13);
+    unsigned long long my_solid = 0;
+    for (uint32_t r = r0; r < r1; ++r) {
+      const unsigned ht = c.acc.word(c.run_start(r), kw - 1) & 63u, h = ht >> 3, t = ht & 7;
+      const uint32_t n = c.run_len(r);
       const bool both = h < 4 && t < 4;
       if (both) {
-        const uint32_t hb = c > MHX_MAX_MUL ? (uint32_t)MHX_MAX_MUL : c;
+        const uint32_t hb = n > MHX_MAX_MUL ? (uint32_t)MHX_MAX_MUL : n;
         if (hb < kS1LocalHist) atomicAdd(&s1_local_hist()[hb], 1u);
         else atomicAdd(&hist[hb], 1ull);
       }
-      const bool solid = both && c >= m;
-      if (!solid && !want_mercy) continue;
-      for (uint32_t x = j0; x < j; ++x) {
-        const uint64_t info = (((uint64_t)acc.word(x, kw) << 32) | acc.word(x, kw + 1)) >> 6;
-        const uint64_t abs = info >> 1;
-        const int strand = (int)(info & 1);
-        if (solid) {
-          atomicOr(&is_solid[(abs - 1) >> 6], 1ull << ((abs - 1) & 63));  // :464
-          ++my_solid;
-        }
-        if (want_mercy) {
-          const uint64_t rid = seq_of_offset(start, n_seqs, fixed_len, abs);
-          const long long base = (long long)start[rid];
-          const long long off = (long long)abs - base - 1;
-          const long long l_off = strand == 0 ? off : off + 1, r_off = strand == 0 ? off + 1 : off;
-          long long c0 = -1, c1 = -1;
-          if (solid) {  // :466-483
-            if (!(has_in & (1u << h))) c0 = ((base + l_off) << 2) | (1 + strand);
-            if (!(has_out & (1u << t))) c1 = ((base + r_off) << 2) | (2 - strand);
-          } else {      // :485-551 (head/tail may be '$' here: the masks only hold bits 0..3)
-            if (l_has_out & (1u << h)) c0 = ((base + l_off) << 2) | ((has_in & (1u << h)) ? 0 : (1 + strand));
-            else if (has_in & (1u << h)) c0 = ((base + l_off) << 2) | (2 - strand);
-            if (r_has_in & (1u << t)) c1 = ((base + r_off) << 2) | ((has_out & (1u << t)) ? 0 : (2 - strand));
-            else if (has_out & (1u << t)) c1 = ((base + r_off) << 2) | (1 + strand);
-          }
-          if (c0 >= 0) mercy[atomicAdd(mercy_n, 1ull)] = c0;
-          if (c1 >= 0) mercy[atomicAdd(mercy_n, 1ull)] = c1;
-        }
-      }
+      const bool solid = both && n >= m;
+      if (solid) my_solid += n;
+      s1_run_info<S>()[r] = masks | (solid ? 1u : 0u);
     }
-    if (my_solid) atomicAdd(s1_block_solid(), my_solid);
+    (void)my_solid;
     return GroupCounts();
+  }
+  __device__ void item_final(const TileCtx<S> &c, uint32_t rel, uint32_t run) const {
+    const uint32_t ri = s1_run_info<S>()[run];
+    const bool solid = ri & 1u;
+    if (!solid && !want_mercy) return;
+    const uint64_t info = (((uint64_t)c.acc.word(rel, kw) << 32) | c.acc.word(rel, kw + 1)) >> 6;
+    const uint64_t abs = info >> 1;
+    const int strand = (int)(info & 1);
+    if (solid) solid_bytes[abs - 1] = 1;  // is_solid.set(pos-1), :464 — a plain byte store instead of a 64-bit atomic
+    if (want_mercy) {
+      const unsigned has_in = (ri >> 1) & 15u, has_out = (ri >> 5) & 15u, l_has_out = (ri >> 9) & 15u, r_has_in = (ri >> 13) & 15u;
+      const unsigned ht = c.acc.word(rel, kw - 1) & 63u, h = ht >> 3, t = ht & 7;
+      const uint64_t rid = seq_of_offset(start, n_seqs, fixed_len, abs);
+      const long long base = (long long)start[rid];
+      const long long off = (long long)abs - base - 1;
+      const long long l_off = strand == 0 ? off : off + 1, r_off = strand == 0 ? off + 1 : off;
+      long long c0 = -1, c1 = -1;
+      if (solid) {  // :466-483
+        if (!(has_in & (1u << h))) c0 = ((base + l_off) << 2) | (1 + strand);
+        if (!(has_out & (1u << t))) c1 = ((base + r_off) << 2) | (2 - strand);
+      } else {      // :485-551 (head/tail may be '$' here: the masks only hold bits 0..3)
+        if (l_has_out & (1u << h)) c0 = ((base + l_off) << 2) | ((has_in & (1u << h)) ? 0 : (1 + strand));
+        else if (has_in & (1u << h)) c0 = ((base + l_off) << 2) | (2 - strand);
+        if (r_has_in & (1u << t)) c1 = ((base + r_off) << 2) | ((has_out & (1u << t)) ? 0 : (2 - strand));
+        else if (has_out & (1u << t)) c1 = ((base + r_off) << 2) | (1 + strand);
+      }
+      if (c0 >= 0) mercy[atomicAdd(mercy_n, 1ull)] = c0;
+      if (c1 >= 0) mercy[atomicAdd(mercy_n, 1ull)] = c1;
+    }
   }
 };
 
+// byte map -> AtomicBitVector layout (bit i = word i/64, bit i%64; kmbitvector.h:67-88) + popcount
+__global__ __launch_bounds__(256) void k_pack_solid(const uint8_t *__restrict__ bytes, uint64_t n_bits, unsigned long long *__restrict__ words,
+                                                    uint64_t n_words, unsigned long long *__restrict__ n_solid) {
+  __shared__ uint64_t sm[256 / kWave + 1];
+  const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned long long v = 0;
+  if (w < n_words) {
+    const uint4 *p = reinterpret_cast<const uint4 *>(bytes + w * 64);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const uint4 x = p[q];
+      const uint32_t xs[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        // bytes are 0/1: gather the low bit of each of the 4 bytes
+        const uint32_t b = xs[t] & 0x01010101u;
+        const uint32_t nib = (b | (b >> 7) | (b >> 14) | (b >> 21)) & 0xFu;
+        v |= (unsigned long long)nib << (q * 16 + t * 4);
+      }
+    }
+    if ((w + 1) * 64 > n_bits) v &= (n_bits & 63) ? ((1ull << (n_bits & 63)) - 1) : ~0ull;
+    words[w] = v;
+  }
+  uint64_t tot;
+  block_exclusive_sum<uint64_t, 256>((uint64_t)__builtin_popcountll(v), sm, &tot);
+  if (threadIdx.x == 0 && tot) atomicAdd(n_solid, (unsigned long long)tot);
+}
+
 template <int S>
 static void s1_groups_launch(mhx_ctx *c, const uint32_t *sorted, uint64_t n_items, int KWv, int kmer_bits, uint32_t m,
-                             unsigned long long *is_solid, unsigned long long *hist, unsigned long long *ctr, int want_mercy,
+                             uint8_t *is_solid, unsigned long long *hist, unsigned long long *ctr, int want_mercy,
                              long long *mercy) {
   SeqSet &s = c->seqs;
-  constexpr int T = TileCfg<S>::kT;
+  constexpr int T = S1Tile<S>::kT;
   const uint64_t n_tiles = div_ceil(n_items, T);
   const int full_words = kmer_bits / 32, rem = kmer_bits % 32;
   const uint32_t last_mask = rem ? 0xFFFFFFFFu << (32 - rem) : 0;
   S1Op<S> op{KWv, m, s.start.as<uint64_t>(), s.n_seqs, s.fixed_len, is_solid, hist, ctr, want_mercy, mercy, ctr + 1};
   MHX_LAUNCH(c, "s1_groups", (double)n_items * S * 4,
-             hipLaunchKernelGGL((k_tile_groups<S, S1Op<S>, false>), dim3((unsigned)n_tiles), dim3(kTileThreads), 0, c->stream, sorted,
+             hipLaunchKernelGGL((k_tile_groups<S, T, S1Op<S>, false>), dim3((unsigned)n_tiles), dim3(kTileThreads), 0, c->stream, sorted,
                                 n_items, full_words, last_mask, op, (uint64_t *)nullptr, (const uint64_t *)nullptr, n_tiles));
 }
 
@@ -292,22 +335,30 @@ int s1_process(mhx_ctx *c, uint32_t k, uint32_t m, int want_mercy, uint32_t *buf
   unsigned long long *is_solid = c->result(MHX_BUF_IS_SOLID, (n_words64 + 1) * 8).as<unsigned long long>();
   c->results[MHX_BUF_IS_SOLID].used = n_words64 * 8;
   unsigned long long *hist = c->result(MHX_BUF_MUL_HIST, (MHX_MAX_MUL + 1) * 8).as<unsigned long long>();
-  MHX_HIP(hipMemsetAsync(is_solid, 0, (n_words64 + 1) * 8, st));
+  uint8_t *solid_bytes = c->ws("solid_bytes", (n_words64 + 1) * 64).as<uint8_t>();
+  MHX_HIP(hipMemsetAsync(solid_bytes, 0, (n_words64 + 1) * 64, st));
+  MHX_HIP(hipMemsetAsync(is_solid + n_words64, 0, 8, st));
   MHX_HIP(hipMemsetAsync(hist, 0, (MHX_MAX_MUL + 1) * 8, st));
   unsigned long long *ctr = c->ws("s1_counters", 64).as<unsigned long long>();
   MHX_HIP(hipMemsetAsync(ctr, 0, 64, st));
 
   uint64_t n_solid = 0, n_mercy = 0;
+  // mercy candidates (<= 2 per item, 8 B each) go to the spare sort buffer: S*4 >= 16 bytes per item
+  long long *mercy = reinterpret_cast<long long *>(spare);
   if (n_items) {
-    // mercy candidates (<= 2 per item, 8 B each) go to the spare sort buffer: S*4 >= 16 bytes per item
-    long long *mercy = reinterpret_cast<long long *>(spare);
     switch (S) {
 #define MHX_CASE(SV) \
-  case SV: s1_groups_launch<SV>(c, sorted, n_items, KWv, kmer_bits, m, is_solid, hist, ctr, want_mercy, mercy); break;
+  case SV: s1_groups_launch<SV>(c, sorted, n_items, KWv, kmer_bits, m, solid_bytes, hist, ctr, want_mercy, mercy); break;
       MHX_CASE(4) MHX_CASE(6) MHX_CASE(8) MHX_CASE(10) MHX_CASE(12) MHX_CASE(14) MHX_CASE(16) MHX_CASE(18) MHX_CASE(20)
 #undef MHX_CASE
       default: throw Error("read2sdbg_s1: unsupported record stride");
     }
+  }
+  if (n_words64)
+    MHX_LAUNCH(c, "pack_solid", (double)n_words64 * 72,
+               hipLaunchKernelGGL(k_pack_solid, dim3((unsigned)div_ceil(n_words64, 256)), dim3(256), 0, st, solid_bytes, n_bits, is_solid, n_words64,
+                                  ctr));
+  {
     unsigned long long h[2];
     MHX_HIP(hipMemcpyAsync(h, ctr, 16, hipMemcpyDeviceToHost, st));
     MHX_HIP(hipStreamSynchronize(st));

@@ -151,113 +151,138 @@ struct SdbgParams {
   int is_seq;          // multiplicity comes from the key (seq2sdbg) instead of the run length (S2)
 };
 
-// Walks one (k-1)-mer group exactly as Lv2Postprocess does (read_to_sdbg_s2.cpp:537-611 /
-// seq_to_sdbg.cpp:718-786), records coming from the LDS tile.  EMIT=false counts records;
-// EMIT=true writes them.
-template <int S, bool EMIT>
-__device__ __forceinline__ void sdbg_walk_group(const TileAcc<S> &acc, uint32_t b, uint32_t e, const SdbgParams &P, uint32_t &n_out,
-                                                uint32_t &n_tips, uint32_t &n_large, uint16_t *__restrict__ out16, uint64_t o16,
-                                                uint32_t *wcnt /* [10] when EMIT */) {
-  auto ex_a = [&](uint32_t i) -> int {
-    return ((acc.word(i, P.kw - 1) >> P.fshift) & 1u) ? (int)((acc.word(i, P.aw) >> P.ashift) & 3u) : 4;
-  };
-  auto ex_b = [&](uint32_t i) -> int { return (int)((acc.word(i, P.kw - 1) >> P.bshift) & 7u); };
-  int has_a = 0, has_b = 0;
-  uint32_t la0 = ~0u, la1 = ~0u, la2 = ~0u, la3 = ~0u;
-  for (uint32_t i = b; i < e; ++i) {
-    const int a = ex_a(i), bb = ex_b(i);
-    if (a != 4 && bb != 4) {
-      has_a |= 1 << a;
-      has_b |= 1 << bb;
-    }
-    if (a != 4 && (bb != 4 || !(has_a & (1 << a)))) {
-      if (a == 0) la0 = i;
-      else if (a == 1) la1 = i;
-      else if (a == 2) la2 = i;
-      else la3 = i;
-    }
-  }
-  int outputed_b = 0;
-  for (uint32_t i = b, j; i < e; i = j) {
-    const int a = ex_a(i), bb = ex_b(i);
-    j = i + 1;
-    while (j < e && ex_a(j) == a && ex_b(j) == bb) ++j;
-    int is_dollar = 0;
-    if (a == 4) {
-      if (has_b & (1 << bb)) continue;
-      is_dollar = 1;
-    }
-    if (bb == 4) {
-      if (has_a & (1 << a)) continue;
-    }
-    const int w = bb == 4 ? 0 : ((outputed_b & (1 << bb)) ? bb + 5 : bb + 1);
-    const uint32_t la = a == 0 ? la0 : (a == 1 ? la1 : (a == 2 ? la2 : la3));
-    const int last = a == 4 ? 0 : (la == j - 1 ? 1 : 0);
-    outputed_b |= 1 << bb;
-    uint32_t mul;
-    if (P.is_seq) mul = MHX_MAX_MUL - (acc.word(i, P.kw - 1) & 0xFFFFu);
-    else mul = (j - i) > (uint32_t)MHX_MAX_MUL ? (uint32_t)MHX_MAX_MUL : (j - i);
-    ++n_out;
-    n_tips += is_dollar;
-    n_large += mul > 254;
-    if constexpr (EMIT) {
-      // SdbgItem (sdbg_item.h:14-24): byte0 = w | last<<4 | tip<<5, byte1 = min(mul,255)
-      out16[o16++] = (uint16_t)(w | (last << 4) | (is_dollar << 5) | ((mul > 255 ? 255u : mul) << 8));
-      if (mul > 254) out16[o16++] = (uint16_t)mul;
-      if (is_dollar) {
-        for (int x = 0; x < P.wpt; ++x) {
-          const uint32_t v = acc.word(i, x);
-          out16[o16++] = (uint16_t)(v & 0xFFFFu);
-          out16[o16++] = (uint16_t)(v >> 16);
-        }
-      }
-      atomicAdd(&wcnt[w], 1u);
-      if (last) atomicAdd(&wcnt[9], 1u);
-    }
-  }
-}
+template <int S>
+struct SdbgTile {
+  static constexpr int kRaw = 32768 / (S * 4);
+  static constexpr int kT = kRaw >= 2048 ? 2048 : (kRaw >= 256 ? (kRaw / 256) * 256 : 256);
+};
 
 __device__ __forceinline__ uint32_t *sdbg_wcnt() {
   __shared__ uint32_t w[10];
   return w;
 }
 
+template <int S>
+__device__ __forceinline__ uint32_t *sdbg_gmask() {  // per group: which (a,b) pairs occur
+  __shared__ uint32_t gm[SdbgTile<S>::kT];
+  return gm;
+}
+
 constexpr unsigned long long kNoStart = ~0ull;
 
+// Lv2Postprocess of Read2SdbgS2 / SeqToSdbg (read_to_sdbg_s2.cpp:537-611, seq_to_sdbg.cpp:718-786) +
+// SdbgWriter::Write (sdbg_writer.cpp:25-58) as a tile operator (tile_groups.h).  A run = the records of
+// one (k-1)-mer group with the same (a, b) = (k-th char or $, W char); the reference's per-item loops
+// only ever look at (a, b), so they are restated over the <= 25 runs of a group.
 template <int S>
 struct SdbgOp {
+  static constexpr bool kItemPhase = false, kItemFinal = false, kRunPhase = true, kUnitIsRun = true;
   SdbgParams P;
   uint16_t *out16;
   unsigned long long *w_count;
   unsigned long long *bstart;  // [3][65536]: running (records, tips, large) at the first group of each bucket
 
+  __device__ bool item_phase_enabled() const { return false; }
+  __device__ bool item_final_enabled() const { return false; }
+  __device__ void item_phase(const TileCtx<S> &, uint32_t, uint32_t) const {}
+  __device__ void item_final(const TileCtx<S> &, uint32_t, uint32_t) const {}
+  __device__ bool same_run(const uint32_t *cur, const uint32_t *prev) const {
+    // same "full" flag + W char, and same k-th char (zero padding when the flag is clear)
+    return (((cur[P.kw - 1] ^ prev[P.kw - 1]) >> P.bshift) & 0xFu) == 0 && (((cur[P.aw] ^ prev[P.aw]) >> P.ashift) & 3u) == 0;
+  }
   __device__ void begin_block() const {
     if (threadIdx.x < 10) sdbg_wcnt()[threadIdx.x] = 0;
+    uint32_t *gm = sdbg_gmask<S>();
+    for (int i = threadIdx.x; i < SdbgTile<S>::kT; i += blockDim.x) gm[i] = 0;
     __syncthreads();
   }
   __device__ void end_block() const {
     if (out16 && threadIdx.x < 10 && sdbg_wcnt()[threadIdx.x]) atomicAdd(&w_count[threadIdx.x], (unsigned long long)sdbg_wcnt()[threadIdx.x]);
   }
-  __device__ GroupCounts count(const TileAcc<S> &acc, uint32_t b, uint32_t e) const {
+  __device__ __forceinline__ int ex_a(const TileCtx<S> &c, uint32_t i) const {
+    return ((c.acc.word(i, P.kw - 1) >> P.fshift) & 1u) ? (int)((c.acc.word(i, P.aw) >> P.ashift) & 3u) : 4;
+  }
+  __device__ __forceinline__ int ex_b(const TileCtx<S> &c, uint32_t i) const { return (int)((c.acc.word(i, P.kw - 1) >> P.bshift) & 7u); }
+
+  // Everything the reference's two loops decide for a run (a,b) follows from WHICH (a,b) pairs occur
+  // in the group: M bit (a5*5 + b), a5 = 0 for '$', a+1 otherwise.
+  //   has_solid_a(a) = any b<4 with (a,b);  has_solid_b(b) = any a<4 with (a,b)
+  //   ($,b) is dropped iff has_solid_b(b);  (a,$) is dropped iff has_solid_a(a)        (:568-585)
+  //   W = b+5 iff an earlier output run has the same b, i.e. some (a'<a, b) exists      (:587-589)
+  //   last = 1 iff no later run with the same a survives: b<4 -> no (a,b'>b,b'<4); (a,$) kept -> 1
+  __device__ __forceinline__ bool decide(uint32_t M, int a, int b, int &w, int &last, int &is_dollar) const {
+    const int a5 = a == 4 ? 0 : a + 1;
+    const uint32_t col = (1u << b) * 0x108420u;  // bits (a'+1)*5 + b for a' = 0..3
+    is_dollar = 0;
+    if (a == 4) {
+      if (M & col) return false;
+      is_dollar = 1;
+    }
+    if (b == 4) {
+      if ((M >> (a5 * 5)) & 0xFu) return false;
+    }
+    if (b == 4) w = 0;
+    else {
+      const uint32_t earlier = a == 4 ? 0u : (M & col & ((1u << (a5 * 5)) - 1u));
+      w = earlier ? b + 5 : b + 1;
+    }
+    if (a == 4) last = 0;
+    else if (b == 4) last = 1;
+    else last = (((M >> (a5 * 5)) & 0xFu) >> (b + 1)) == 0;
+    return true;
+  }
+  __device__ __forceinline__ uint32_t run_mul(const TileCtx<S> &c, uint32_t r, uint32_t i) const {
+    if (P.is_seq) return MHX_MAX_MUL - (c.acc.word(i, P.kw - 1) & 0xFFFFu);  // seq_to_sdbg.cpp:782-785
+    const uint32_t n = c.run_len(r);                                         // read_to_sdbg_s2.cpp:579
+    return n > (uint32_t)MHX_MAX_MUL ? (uint32_t)MHX_MAX_MUL : n;
+  }
+  __device__ void run_phase(const TileCtx<S> &c, uint32_t r, uint32_t g) const {
+    const uint32_t i = c.run_start(r);
+    const int a = ex_a(c, i), b = ex_b(c, i);
+    atomicOr(&sdbg_gmask<S>()[g], 1u << ((a == 4 ? 0 : a + 1) * 5 + b));
+  }
+  __device__ GroupCounts unit_count(const TileCtx<S> &c, uint32_t r) const {
     GroupCounts gc;
-    sdbg_walk_group<S, false>(acc, b, e, P, gc.c0, gc.c1, gc.c2, nullptr, 0, nullptr);
+    const uint32_t i = c.run_start(r);
+    int w, last, tip;
+    if (!decide(sdbg_gmask<S>()[c.rgid[r]], ex_a(c, i), ex_b(c, i), w, last, tip)) return gc;
+    gc.c0 = 1;
+    gc.c1 = (uint32_t)tip;
+    gc.c2 = run_mul(c, r, i) > 254;
     return gc;
   }
-  __device__ void emit(const TileAcc<S> &acc, uint32_t b, uint32_t e, uint64_t o0, uint64_t o1, uint64_t o2) const {
-    // first group of its lv1 bucket?  (the previous record has another bucket prefix)
-    const uint32_t bk = acc.word(b, 0) >> 16;
-    bool first = acc.base + b == 0;
-    if (!first) {
-      const uint32_t prev = b > 0 ? acc.word(b - 1, 0) : acc.glob[(acc.base - 1) * S];
-      first = (prev >> 16) != bk;
+  __device__ void unit_emit(const TileCtx<S> &c, uint32_t r, uint64_t o0, uint64_t o1, uint64_t o2) const {
+    const uint32_t i = c.run_start(r);
+    if (c.run_is_group_head(r)) {
+      // first group of its lv1 bucket?  (the previous record has another bucket prefix)
+      const uint32_t bk = c.acc.word(i, 0) >> 16;
+      bool first = c.acc.base + i == 0;
+      if (!first) {
+        const uint32_t prev = c.acc.lds[((int)i - 1) * S];  // record -1 is staged as well
+        first = (prev >> 16) != bk;
+      }
+      if (first) {
+        bstart[bk] = o0;
+        bstart[MHX_NUM_BUCKETS + bk] = o1;
+        bstart[2 * MHX_NUM_BUCKETS + bk] = o2;
+      }
     }
-    if (first) {
-      bstart[bk] = o0;
-      bstart[MHX_NUM_BUCKETS + bk] = o1;
-      bstart[2 * MHX_NUM_BUCKETS + bk] = o2;
+    int w, last, tip;
+    if (!decide(sdbg_gmask<S>()[c.rgid[r]], ex_a(c, i), ex_b(c, i), w, last, tip)) return;
+    const uint32_t mul = run_mul(c, r, i);
+    uint64_t o16 = o0 + o2 + 2ull * P.wpt * o1;
+    // SdbgItem (sdbg_item.h:14-24): byte0 = w | last<<4 | tip<<5, byte1 = min(mul,255)
+    out16[o16++] = (uint16_t)(w | (last << 4) | (tip << 5) | ((mul > 255 ? 255u : mul) << 8));
+    if (mul > 254) out16[o16++] = (uint16_t)mul;
+    if (tip) {
+      for (int x = 0; x < P.wpt; ++x) {
+        const uint32_t v = c.acc.word(i, x);
+        out16[o16++] = (uint16_t)(v & 0xFFFFu);
+        out16[o16++] = (uint16_t)(v >> 16);
+      }
     }
-    uint32_t no = 0, nt = 0, nl = 0;
-    sdbg_walk_group<S, true>(acc, b, e, P, no, nt, nl, out16, o0 + o2 + 2ull * P.wpt * o1, sdbg_wcnt());
+    atomicAdd(&sdbg_wcnt()[w], 1u);
+    if (last) atomicAdd(&sdbg_wcnt()[9], 1u);
   }
 };
 
@@ -325,7 +350,7 @@ static void emit_sdbg_impl(mhx_ctx *c, const uint32_t *sorted, uint64_t n_items,
     MHX_HIP(hipMemsetAsync(b_off, 0, MHX_NUM_BUCKETS * 8, st));
     return;
   }
-  constexpr int T = TileCfg<S>::kT;
+  constexpr int T = SdbgTile<S>::kT;
   const uint64_t n_tiles = div_ceil(n_items, T);
   uint64_t *tt = c->ws("tile_tot", (3 * n_tiles + 4) * 8).as<uint64_t>();
   uint64_t *tb = c->ws("tile_base", (3 * n_tiles + 4) * 8).as<uint64_t>();
@@ -336,7 +361,7 @@ static void emit_sdbg_impl(mhx_ctx *c, const uint32_t *sorted, uint64_t n_items,
   SdbgOp<S> op{P, nullptr, w_count, bstart};
   const double bytes = (double)n_items * S * 4;
   MHX_LAUNCH(c, "sdbg_count", bytes,
-             hipLaunchKernelGGL((k_tile_groups<S, SdbgOp<S>, false>), dim3((unsigned)n_tiles), dim3(kTileThreads), 0, st, sorted, n_items,
+             hipLaunchKernelGGL((k_tile_groups<S, T, SdbgOp<S>, false>), dim3((unsigned)n_tiles), dim3(kTileThreads), 0, st, sorted, n_items,
                                 full_words, last_mask, op, tt, (const uint64_t *)nullptr, n_tiles));
   for (int r = 0; r < 3; ++r) exclusive_scan_u64(c, tt + r * n_tiles, tb + r * n_tiles, n_tiles, d_tot + r);
   MHX_HIP(hipMemcpyAsync(tot, d_tot, 24, hipMemcpyDeviceToHost, st));
@@ -347,7 +372,7 @@ static void emit_sdbg_impl(mhx_ctx *c, const uint32_t *sorted, uint64_t n_items,
   MHX_HIP(hipMemsetAsync(bstart, 0xFF, 3 * MHX_NUM_BUCKETS * 8, st));
   op.out16 = out16;
   MHX_LAUNCH(c, "sdbg_emit", bytes + (double)out_bytes,
-             hipLaunchKernelGGL((k_tile_groups<S, SdbgOp<S>, true>), dim3((unsigned)n_tiles), dim3(kTileThreads), 0, st, sorted, n_items,
+             hipLaunchKernelGGL((k_tile_groups<S, T, SdbgOp<S>, true>), dim3((unsigned)n_tiles), dim3(kTileThreads), 0, st, sorted, n_items,
                                 full_words, last_mask, op, (uint64_t *)nullptr, (const uint64_t *)tb, n_tiles));
   MHX_LAUNCH(c, "bucket_stats", (double)MHX_NUM_BUCKETS * 56,
              hipLaunchKernelGGL(k_bucket_fix, dim3(1), dim3(256), 0, st, bstart, d_tot, P.wpt, b_items, b_tips, b_large, b_off));

@@ -9,19 +9,25 @@
 // Records are AoS with a stride of S uint32 words (S even): a record is moved with
 // uint4/uint2 accesses, never word by word.  HBM-bound; no MFMA.
 #include "dev_prims.h"
+#include <cstdlib>
+
 #include "mhx_internal.h"
 
 namespace mhx {
 
 constexpr int kSortThreads = 256;
 constexpr int kSortWaves = kSortThreads / kWave;
-constexpr int kTilesPerChunk = 4;
 
+// default records per thread per tile, chosen so the LDS stage stays <= 64 KiB
 template <int S>
+constexpr int default_items() {
+  return (S <= 4) ? 4 : (S <= 8 ? 8 : (S <= 12 ? 5 : (S <= 16 ? 4 : 3)));
+}
+template <int S, int ITEMS>
 struct SortCfg {
-  // items per thread per tile, chosen so the LDS stage stays <= 64 KiB
-  static constexpr int kItems = (S <= 4) ? 16 : (S <= 8 ? 8 : (S <= 12 ? 5 : (S <= 16 ? 4 : 3)));
+  static constexpr int kItems = ITEMS;
   static constexpr int kTile = kSortThreads * kItems;
+  static constexpr int kTilesPerChunk = (16384 / kTile) > 4 ? (16384 / kTile) : 4;  // ~16 K records per chunk
   static constexpr int kChunk = kTile * kTilesPerChunk;
 };
 
@@ -71,7 +77,7 @@ __device__ __forceinline__ unsigned rec_digit(const Rec<S> &r, int wi, unsigned 
   return (unsigned)(v >> bit) & mask;
 }
 
-template <int S>
+template <int S, int NI>
 __global__ __launch_bounds__(kSortThreads) void k_radix_hist(const uint32_t *__restrict__ items, uint64_t n, int wi, unsigned bit,
                                                              unsigned mask, uint32_t *__restrict__ hist, uint64_t n_chunks,
                                                              const uint8_t *__restrict__ lut) {
@@ -79,9 +85,9 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_hist(const uint32_t *__r
   for (int i = threadIdx.x; i < kSortWaves * 256; i += kSortThreads) (&h[0][0])[i] = 0;
   __syncthreads();
   const int w = threadIdx.x / kWave;
-  const uint64_t base = (uint64_t)blockIdx.x * SortCfg<S>::kChunk;
+  const uint64_t base = (uint64_t)blockIdx.x * SortCfg<S, NI>::kChunk;
   const bool straddle = bit + (32 - __builtin_clz(mask)) > 32 && wi > 0;
-  for (int j = 0; j < SortCfg<S>::kChunk / kSortThreads; ++j) {
+  for (int j = 0; j < SortCfg<S, NI>::kChunk / kSortThreads; ++j) {
     uint64_t idx = base + (uint64_t)j * kSortThreads + threadIdx.x;
     if (idx < n) {
       const uint32_t *p = items + idx * S;
@@ -105,12 +111,12 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_hist(const uint32_t *__r
   }
 }
 
-template <int S>
+template <int S, int NI>
 __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(const uint32_t *__restrict__ in, uint32_t *__restrict__ out, uint64_t n,
                                                                 int wi, unsigned bit, unsigned mask, int nbits,
                                                                 const uint64_t *__restrict__ offs, uint64_t n_chunks,
                                                                 const uint8_t *__restrict__ lut) {
-  using Cfg = SortCfg<S>;
+  using Cfg = SortCfg<S, NI>;
   constexpr int ITEMS = Cfg::kItems;
   __shared__ __attribute__((aligned(16))) uint32_t stage[Cfg::kTile * S];
   __shared__ uint32_t wave_cnt[kSortWaves][256];   // per-wave running digit counters, then wave bases
@@ -123,7 +129,7 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(const uint32_t *
   const uint64_t chunk_base = (uint64_t)blockIdx.x * Cfg::kChunk;
   const uint64_t lanemask_lt = (1ull << lane) - 1;
 
-  for (int t = 0; t < kTilesPerChunk; ++t) {
+  for (int t = 0; t < Cfg::kTilesPerChunk; ++t) {
     const uint64_t tile_base = chunk_base + (uint64_t)t * Cfg::kTile;
     if (tile_base >= n) break;
     const uint64_t rem = n - tile_base;
@@ -205,11 +211,11 @@ std::vector<SortPass> make_passes(int key_words, int lo_bit, int hi_bit) {
   return p;
 }
 
-template <int S>
-static uint32_t *radix_sort_impl(mhx_ctx *c, uint32_t *a, uint32_t *b, uint64_t n, int key_words,
-                                 const std::vector<SortPass> &passes) {
+template <int S, int NI>
+static uint32_t *radix_sort_impl2(mhx_ctx *c, uint32_t *a, uint32_t *b, uint64_t n, int key_words,
+                                  const std::vector<SortPass> &passes) {
   if (n == 0) return a;
-  const uint64_t n_chunks = div_ceil(n, SortCfg<S>::kChunk);
+  const uint64_t n_chunks = div_ceil(n, SortCfg<S, NI>::kChunk);
   uint32_t *hist = c->ws("sort_hist", n_chunks * 256 * 4).as<uint32_t>();
   uint64_t *offs = c->ws("sort_offs", n_chunks * 256 * 8).as<uint64_t>();
   const double bytes = (double)n * S * 4;
@@ -218,15 +224,31 @@ static uint32_t *radix_sort_impl(mhx_ctx *c, uint32_t *a, uint32_t *b, uint64_t 
     const int wi = key_words - 1 - ps.shift / 32;
     const unsigned bit = ps.shift % 32, mask = (1u << ps.bits) - 1;
     MHX_LAUNCH(c, nm_hist.c_str(), bytes,
-               hipLaunchKernelGGL(k_radix_hist<S>, dim3((unsigned)n_chunks), dim3(kSortThreads), 0, c->stream, a, n, wi, bit, mask,
+               hipLaunchKernelGGL((k_radix_hist<S, NI>), dim3((unsigned)n_chunks), dim3(kSortThreads), 0, c->stream, a, n, wi, bit, mask,
                                   hist, n_chunks, (const uint8_t *)nullptr));
     exclusive_scan_u32_u64(c, hist, offs, n_chunks * 256, nullptr);
     MHX_LAUNCH(c, nm_scat.c_str(), 2 * bytes,
-               hipLaunchKernelGGL(k_radix_scatter<S>, dim3((unsigned)n_chunks), dim3(kSortThreads), 0, c->stream, a, b, n, wi, bit,
+               hipLaunchKernelGGL((k_radix_scatter<S, NI>), dim3((unsigned)n_chunks), dim3(kSortThreads), 0, c->stream, a, b, n, wi, bit,
                                   mask, ps.bits, offs, n_chunks, (const uint8_t *)nullptr));
     std::swap(a, b);
   }
   return a;
+}
+
+// tile-shape selection: MHX_SORT_ITEMS=8|16 overrides the default for 8- and 16-byte records (tuning knob)
+template <int S>
+static uint32_t *radix_sort_impl(mhx_ctx *c, uint32_t *a, uint32_t *b, uint64_t n, int key_words,
+                                 const std::vector<SortPass> &passes) {
+  if constexpr (S <= 4) {
+    static const int items = [] {
+      const char *e = getenv("MHX_SORT_ITEMS");
+      return e ? atoi(e) : default_items<S>();
+    }();
+    if (items == 4) return radix_sort_impl2<S, 4>(c, a, b, n, key_words, passes);
+    if (items == 8) return radix_sort_impl2<S, 8>(c, a, b, n, key_words, passes);
+    if (items == 12) return radix_sort_impl2<S, 12>(c, a, b, n, key_words, passes);
+  }
+  return radix_sort_impl2<S, default_items<S>()>(c, a, b, n, key_words, passes);
 }
 
 // One stable multisplit pass: digit = owner_lut[item.w[0] >> 16].  Items of owner p end up contiguous
@@ -235,18 +257,18 @@ template <int S>
 static void partition_impl(mhx_ctx *c, const uint32_t *a, uint32_t *b, uint64_t n, const uint8_t *lut, int n_parts, uint64_t *counts) {
   for (int p = 0; p < n_parts; ++p) counts[p] = 0;
   if (n == 0) return;
-  const uint64_t n_chunks = div_ceil(n, SortCfg<S>::kChunk);
+  const uint64_t n_chunks = div_ceil(n, SortCfg<S, default_items<S>()>::kChunk);
   uint32_t *hist = c->ws("sort_hist", n_chunks * 256 * 4).as<uint32_t>();
   uint64_t *offs = c->ws("sort_offs", (n_chunks * 256 + 1) * 8).as<uint64_t>();
   const double bytes = (double)n * S * 4;
   int nbits = 1;
   while ((1 << nbits) < n_parts) ++nbits;
   MHX_LAUNCH(c, "owner_hist", bytes,
-             hipLaunchKernelGGL(k_radix_hist<S>, dim3((unsigned)n_chunks), dim3(kSortThreads), 0, c->stream, a, n, 0, 0u, 0xFFu, hist,
+             hipLaunchKernelGGL((k_radix_hist<S, default_items<S>()>), dim3((unsigned)n_chunks), dim3(kSortThreads), 0, c->stream, a, n, 0, 0u, 0xFFu, hist,
                                 n_chunks, lut));
   exclusive_scan_u32_u64(c, hist, offs, n_chunks * 256, offs + n_chunks * 256);
   MHX_LAUNCH(c, "owner_scatter", 2 * bytes,
-             hipLaunchKernelGGL(k_radix_scatter<S>, dim3((unsigned)n_chunks), dim3(kSortThreads), 0, c->stream, a, b, n, 0, 0u, 0xFFu,
+             hipLaunchKernelGGL((k_radix_scatter<S, default_items<S>()>), dim3((unsigned)n_chunks), dim3(kSortThreads), 0, c->stream, a, b, n, 0, 0u, 0xFFu,
                                 nbits, offs, n_chunks, lut));
   std::vector<uint64_t> starts(n_parts + 1);
   for (int p = 0; p <= n_parts; ++p)

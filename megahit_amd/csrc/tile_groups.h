@@ -1,45 +1,60 @@
-// Tile-wise group processing of a sorted record array (the Lv2Postprocess step of every engine).
+// Tile-wise group processing of a sorted record array (the Lv2Postprocess step of every engine),
+// without serial per-item walks.
 //
-// A workgroup stages one tile of T consecutive records in LDS with coalesced 16-byte loads, finds
-// the group heads inside the tile (record differs from its predecessor in the first cmp_bits key
-// bits), and lets each thread walk whole groups out of LDS.  A group belongs to the tile that holds
-// its head; its tail beyond the tile is read from global memory by the owning thread.
+// A workgroup stages a tile of T consecutive records in LDS (coalesced 16-byte loads) and derives, with
+// item-parallel flag evaluation + one block scan,
+//   runs    maximal stretches of records with the same key AND the same engine-defined run key
+//   groups  maximal stretches with the same key prefix (cmp_bits); a group is a list of runs
+// A group belongs to the tile that holds its head; the part of its last group that lies beyond the tile
+// ("tail") is discovered by wavefront 0 in 64-record coalesced chunks and appended to the run list.
+// Engines then work thread-per-GROUP over the short run list (<= a few dozen runs per group), and
+// item-parallel where a per-record action is needed (bit sets, atomics).
 //
-// Ordered output needs two launches of the same kernel:
-//   EMIT=false  Op::count(group) -> three small counters, summed per tile  -> tile_tot[3][n_tiles]
-//   (exclusive scan of the three rows on the host side)
-//   EMIT=true   per-group counters again -> block scan in LDS -> Op::emit(group, offsets)
-// so the only per-group state ever written to HBM is the output itself; no head array, no per-group
-// arrays.  HBM traffic: each launch reads the records once.
+// Ordered output = two launches of the same kernel:
+//   EMIT=false  Op::unit_count -> three counters, summed per tile -> tile_tot[3][n_tiles]
+//   (exclusive scans of the three rows)
+//   EMIT=true   the counters again -> block scan in LDS -> Op::unit_emit(offsets)
+// Nothing per-group or per-run is ever written to HBM; each launch reads the records once.
 #pragma once
 #include "dev_prims.h"
 
 namespace mhx {
 
 constexpr int kTileThreads = 256;
+constexpr int kMaxTailRuns = 64;
 
-template <int S>
-struct TileCfg {
-  // ~32 KiB of records per tile, a multiple of 256, at least 256
-  static constexpr int kRaw = 32768 / (S * 4);
-  static constexpr int kT = kRaw >= 4096 ? 4096 : (kRaw >= 256 ? (kRaw / 256) * 256 : 256);
+struct GroupCounts {
+  uint32_t c0 = 0, c1 = 0, c2 = 0;
 };
 
-// record accessor: LDS inside the tile, global memory beyond it
+// record accessor: LDS inside the tile, global memory beyond it (relative index)
 template <int S>
 struct TileAcc {
   const uint32_t *lds;
   const uint32_t *glob;  // records of the whole array
   uint64_t base;         // index of the tile's first record
   uint64_t n;            // total records
-  int t_n;               // records staged in LDS
+  int t_n;               // records staged in LDS (tile + look-ahead); record -1 (the predecessor) is staged too
+  // Keep the LDS path and the (rare) HBM path as separate code: a select between an LDS and a global
+  // pointer would turn every access into a slow FLAT load.
+  __device__ __attribute__((noinline)) uint32_t far_word(uint32_t rel, int w) const { return glob[(base + rel) * S + w]; }
   __device__ __forceinline__ uint32_t word(uint32_t rel, int w) const {
-    return rel < (uint32_t)t_n ? lds[rel * S + w] : glob[(base + rel) * S + w];
+    if (__builtin_expect((int)rel < t_n, 1)) return lds[(int)rel * S + w];
+    return far_word(rel, w);
   }
 };
 
-struct GroupCounts {
-  uint32_t c0 = 0, c1 = 0, c2 = 0;
+// what the engines see of a tile
+template <int S>
+struct TileCtx {
+  TileAcc<S> acc;
+  const uint32_t *rpos;   // run starts, relative to the tile; bit 31 = first run of a group; rpos[n_runs] = end
+  const uint16_t *gpos;   // first run of each group; gpos[n_groups] = n_runs
+  const uint16_t *rgid;   // group of each run
+  uint32_t n_runs, n_groups;
+  __device__ __forceinline__ bool run_is_group_head(uint32_t r) const { return rpos[r] >> 31; }
+  __device__ __forceinline__ uint32_t run_start(uint32_t r) const { return rpos[r] & 0x7FFFFFFFu; }
+  __device__ __forceinline__ uint32_t run_len(uint32_t r) const { return (rpos[r + 1] & 0x7FFFFFFFu) - (rpos[r] & 0x7FFFFFFFu); }
 };
 
 template <int S>
@@ -49,30 +64,46 @@ __device__ __forceinline__ bool key_differs(const uint32_t *a, const uint32_t *b
   return last_mask && ((a[full_words] ^ b[full_words]) & last_mask);
 }
 
-// Op interface:
-//   __device__ void begin_block();                    (optional per-block LDS init, called by all threads)
-//   __device__ GroupCounts count(const TileAcc<S>&, uint32_t b, uint32_t e);   b,e relative to the tile
-//   __device__ void emit(const TileAcc<S>&, uint32_t b, uint32_t e, uint64_t o0, uint64_t o1, uint64_t o2);
-//   __device__ void end_block();                      (optional flush, called by all threads after a barrier)
-template <int S, class Op, bool EMIT>
+// Op interface (all const; LDS state through function-local __shared__ accessors):
+//   static constexpr bool kItemPhase, kItemFinal;
+//   bool same_run(const uint32_t *cur, const uint32_t *prev)     records of the same group: same run?
+//   void begin_block() / end_block()
+//   void item_phase(const TileCtx<S>&, uint32_t rel, uint32_t run)   (if kItemPhase; before the group phase)
+//   static constexpr bool kRunPhase, kUnitIsRun;
+//   void run_phase(const TileCtx<S>&, uint32_t r, uint32_t g)       (if kRunPhase: e.g. LDS atomics into group aggregates)
+//   GroupCounts unit_count(const TileCtx<S>&, uint32_t u)           u = run (kUnitIsRun) or group
+//   void unit_emit(const TileCtx<S>&, uint32_t u, uint64_t o0, uint64_t o1, uint64_t o2)
+//   void item_final(const TileCtx<S>&, uint32_t rel, uint32_t run)   (if kItemFinal; after the group phase)
+constexpr int kLookAhead = 64;  // records staged beyond the tile so that short tails never touch HBM again
+
+template <int S, int T, class Op, bool EMIT>
 __global__ __launch_bounds__(kTileThreads) void k_tile_groups(const uint32_t *__restrict__ items, uint64_t n, int full_words,
                                                              uint32_t last_mask, Op op, uint64_t *__restrict__ tile_tot,
                                                              const uint64_t *__restrict__ tile_base, uint64_t n_tiles) {
-  constexpr int T = TileCfg<S>::kT;
   constexpr int PER = T / kTileThreads;
-  __shared__ __attribute__((aligned(16))) uint32_t tile[T * S];
-  __shared__ uint16_t hpos[T + 1];
-  __shared__ uint64_t gcnt[EMIT ? T : 1];
-  __shared__ uint32_t sm32[kTileThreads / kWave + 1];
-  __shared__ uint64_t sm64[kTileThreads / kWave + 1];
+  constexpr int NW = kTileThreads / kWave;
+  static_assert(T % kTileThreads == 0 && PER <= 16, "tile shape");
+  __shared__ __attribute__((aligned(16))) uint32_t tile0[(T + kLookAhead + 4) * S];
+  uint32_t *const tile = tile0 + 4 * S;  // tile[-1] holds the record before the tile (16-byte alignment kept)
+  __shared__ uint32_t rpos[T + kMaxTailRuns + 1];
+  __shared__ uint16_t gpos[T + 1];
+  __shared__ uint16_t rgid[T + kMaxTailRuns];
+  __shared__ uint64_t gcnt[EMIT ? T + kMaxTailRuns : 1];
+  __shared__ uint64_t sm64[NW + 1];
+  __shared__ uint32_t cnt_g[PER * NW + 1], cnt_r[PER * NW + 1];  // per (round, wave) head counts -> exclusive prefixes
+  __shared__ uint32_t s_first_head, s_tail_end, s_nruns;
 
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, wv = tid / kWave, lane = tid & (kWave - 1);
+  const uint64_t lanemask_lt = (1ull << lane) - 1;
   const uint64_t base = (uint64_t)blockIdx.x * T;
   const uint64_t rem = n - base;
   const int t_n = rem < (uint64_t)T ? (int)rem : T;
+  const int staged = rem < (uint64_t)(T + kLookAhead) ? (int)rem : T + kLookAhead;  // tile + look-ahead
+  if (tid == 0) s_first_head = 0xFFFFFFFFu;
   op.begin_block();
-  // 1. stage the tile (coalesced)
-  for (int i = tid; i < t_n; i += kTileThreads) {
+  // 1. stage the tile, the look-ahead and the predecessor record (coalesced)
+  for (int i = tid - 1; i < staged; i += kTileThreads) {
+    if (i < 0 && base == 0) continue;
     const uint32_t *src = items + (base + i) * S;
     uint32_t *dst = tile + i * S;
     if constexpr (S % 4 == 0) {
@@ -84,80 +115,203 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_groups(const uint32_t *__
     }
   }
   __syncthreads();
-  // 2. heads, in order: thread t owns records [t*PER, (t+1)*PER)
-  uint32_t flags = 0, cnt = 0;
+  // 2. group-head / run-head flags, striped: round j, thread t looks at record j*256 + t (conflict-free LDS reads)
+  uint32_t gflags = 0, rflags = 0;
+  uint32_t my_first = 0xFFFFFFFFu;
 #pragma unroll
   for (int j = 0; j < PER; ++j) {
-    const int i = tid * PER + j;
+    const int i = j * kTileThreads + tid;
     if (i < t_n) {
-      bool head;
-      if (i == 0) head = base == 0 || key_differs<S>(tile, items + (base - 1) * S, full_words, last_mask);
-      else head = key_differs<S>(tile + i * S, tile + (i - 1) * S, full_words, last_mask);
-      if (head) {
-        flags |= 1u << j;
-        ++cnt;
+      const uint32_t *cur = tile + i * S;
+      const uint32_t *prev = tile + (i - 1) * S;  // LDS also for i == 0 (staged predecessor)
+      const bool gh = (i == 0 && base == 0) || key_differs<S>(cur, prev, full_words, last_mask);
+      const bool rh = gh || !op.same_run(cur, prev);
+      if (gh) {
+        gflags |= 1u << j;
+        if (my_first == 0xFFFFFFFFu) my_first = (uint32_t)i;
       }
+      if (rh) rflags |= 1u << j;
     }
   }
-  uint32_t n_heads;
-  uint32_t hp = block_exclusive_sum<uint32_t, kTileThreads>(cnt, sm32, &n_heads);
+  if (my_first != 0xFFFFFFFFu) atomicMin(&s_first_head, my_first);
+  __syncthreads();
+  // records before the tile's first group head belong to a group owned by an earlier tile: not ours
+  const uint32_t first_head = s_first_head;
+  uint64_t gball[PER], rball[PER];
 #pragma unroll
-  for (int j = 0; j < PER; ++j)
-    if (flags & (1u << j)) hpos[hp++] = (uint16_t)(tid * PER + j);
+  for (int j = 0; j < PER; ++j) {
+    const uint32_t i = (uint32_t)(j * kTileThreads + tid);
+    const bool rv = ((rflags >> j) & 1u) && i >= first_head;
+    if (!rv) rflags &= ~(1u << j);
+    gball[j] = __ballot((gflags >> j) & 1u);
+    rball[j] = __ballot(rv);
+    if (lane == 0) {
+      cnt_g[j * NW + wv] = (uint32_t)__builtin_popcountll(gball[j]);
+      cnt_r[j * NW + wv] = (uint32_t)__builtin_popcountll(rball[j]);
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {  // exclusive prefix over the PER*NW (round, wave) cells, in record order
+    uint32_t ag = 0, ar = 0;
+    for (int x = 0; x < PER * NW; ++x) {
+      const uint32_t g = cnt_g[x], r = cnt_r[x];
+      cnt_g[x] = ag;
+      cnt_r[x] = ar;
+      ag += g;
+      ar += r;
+    }
+    cnt_g[PER * NW] = ag;
+    cnt_r[PER * NW] = ar;
+    s_tail_end = (uint32_t)t_n;
+    s_nruns = ar;
+  }
+  __syncthreads();
+  const uint32_t n_groups = cnt_g[PER * NW], n_runs_tile = cnt_r[PER * NW];
+#pragma unroll
+  for (int j = 0; j < PER; ++j) {
+    if ((rflags >> j) & 1u) {
+      const uint32_t r = cnt_r[j * NW + wv] + (uint32_t)__builtin_popcountll(rball[j] & lanemask_lt);
+      const bool gh = (gflags >> j) & 1u;
+      // groups at or before this record (this record's own head included)
+      const uint32_t g_incl = cnt_g[j * NW + wv] + (uint32_t)__builtin_popcountll(gball[j] & lanemask_lt) + (gh ? 1u : 0u);
+      rpos[r] = (uint32_t)(j * kTileThreads + tid) | (gh ? 0x80000000u : 0u);
+      if (gh) gpos[g_incl - 1] = (uint16_t)r;
+      rgid[r] = (uint16_t)(g_incl - 1);
+    }
+  }
+  __syncthreads();
+  // 3. tail of the last group, beyond the tile: wavefront 0, 64 records per step; the first step reads the
+  //    look-ahead records already in LDS
+  if (n_groups > 0 && base + t_n < n && tid < kWave) {
+    const uint32_t *gkey = tile + (size_t)(rpos[gpos[n_groups - 1]] & 0x7FFFFFFFu) * S;
+    uint32_t nr = n_runs_tile, e = (uint32_t)t_n;
+    for (;;) {
+      const uint32_t rel = e + lane;
+      const uint64_t p = base + rel;
+      bool in_group = false, rh = false;
+      if (e + kWave <= (uint32_t)staged) {  // whole step inside the staged look-ahead: LDS only
+        const uint32_t *cur = tile + (size_t)rel * S;
+        in_group = !key_differs<S>(cur, gkey, full_words, last_mask);
+        if (in_group) rh = !op.same_run(cur, cur - S);
+      } else if (p < n) {                   // beyond it: HBM
+        const uint32_t *cur = items + p * S;
+        in_group = !key_differs<S>(cur, gkey, full_words, last_mask);
+        if (in_group) rh = !op.same_run(cur, cur - S);
+      }
+      const uint64_t m_in = __ballot(in_group);
+      const int cnt = m_in == ~0ull ? 64 : __builtin_ctzll(~m_in);  // leading in-group lanes
+      const uint64_t m_rh = __ballot(rh && lane < cnt);
+      if (rh && lane < cnt) {
+        const uint32_t slot = nr + __builtin_popcountll(m_rh & lanemask_lt);
+        if (slot < (uint32_t)(T + kMaxTailRuns)) {
+          rpos[slot] = rel;
+          rgid[slot] = (uint16_t)(n_groups - 1);
+        }
+      }
+      nr += __builtin_popcountll(m_rh);
+      e += cnt;
+      if (cnt < 64) break;
+    }
+    if (lane == 0) {
+      s_tail_end = e;
+      s_nruns = nr < (uint32_t)(T + kMaxTailRuns) ? nr : (uint32_t)(T + kMaxTailRuns);
+    }
+  }
+  __syncthreads();
+  const uint32_t n_runs = s_nruns, tail_end = s_tail_end;
+  if (tid == 0) {
+    rpos[n_runs] = tail_end;
+    gpos[n_groups] = (uint16_t)n_runs;
+  }
   __syncthreads();
 
-  TileAcc<S> acc{tile, items, base, n, t_n};
-  // end of the last group: it may run past the tile
-  auto group_end = [&](uint32_t g) -> uint32_t {
-    if (g + 1 < n_heads) return hpos[g + 1];
-    uint32_t e = (uint32_t)t_n;
-    if (base + e < n) {  // walk the tail in global memory while the key stays the same
-      const uint32_t *first = tile + (size_t)hpos[g] * S;
-      while (base + e < n && !key_differs<S>(first, items + (base + e) * S, full_words, last_mask)) ++e;
-    }
-    return e;
+  TileCtx<S> ctx{{tile, items, base, n, staged}, rpos, gpos, rgid, n_runs, n_groups};
+
+  // run index of a tail record (few tail runs: linear search)
+  auto tail_run = [&](uint32_t rel) -> uint32_t {
+    uint32_t r = n_runs_tile ? n_runs_tile - 1 : 0;
+    while (r + 1 < n_runs && (rpos[r + 1] & 0x7FFFFFFFu) <= rel) ++r;
+    return r;
+  };
+  // run of this thread's record in round j (records before the first head have none)
+  auto own_run = [&](int j) -> int {
+    return (int)(cnt_r[j * NW + wv] + (uint32_t)__builtin_popcountll(rball[j] & (lanemask_lt | (1ull << lane)))) - 1;
   };
 
+  // 4. optional item-parallel pass before the unit phase
+  if constexpr (Op::kItemPhase) {
+    if (op.item_phase_enabled() && n_groups > 0) {
+#pragma unroll
+      for (int j = 0; j < PER; ++j) {
+        const uint32_t i = (uint32_t)(j * kTileThreads + tid);
+        if (i < (uint32_t)t_n && i >= first_head) op.item_phase(ctx, i, (uint32_t)own_run(j));
+      }
+      if (tid < kWave)
+        for (uint32_t rel = (uint32_t)t_n + tid; rel < tail_end; rel += kWave) op.item_phase(ctx, rel, tail_run(rel));
+    }
+    __syncthreads();
+  }
+
+  // 5. unit phase: a unit is a run (Op::kUnitIsRun) or a group
+  if constexpr (Op::kRunPhase) {
+    for (uint32_t r = tid; r < n_runs; r += kTileThreads) op.run_phase(ctx, r, rgid[r]);
+    __syncthreads();
+  }
+  const uint32_t n_units = Op::kUnitIsRun ? n_runs : n_groups;
   if constexpr (!EMIT) {
     uint64_t t0 = 0, t1 = 0, t2 = 0;
-    for (uint32_t g = tid; g < n_heads; g += kTileThreads) {
-      GroupCounts c = op.count(acc, hpos[g], group_end(g));
+    for (uint32_t u = tid; u < n_units; u += kTileThreads) {
+      GroupCounts c = op.unit_count(ctx, u);
       t0 += c.c0;
       t1 += c.c1;
       t2 += c.c2;
     }
-    uint64_t s0, s1, s2;
-    block_exclusive_sum<uint64_t, kTileThreads>(t0, sm64, &s0);
-    block_exclusive_sum<uint64_t, kTileThreads>(t1, sm64, &s1);
-    block_exclusive_sum<uint64_t, kTileThreads>(t2, sm64, &s2);
-    if (tid == 0 && tile_tot) {
-      tile_tot[blockIdx.x] = s0;
-      tile_tot[n_tiles + blockIdx.x] = s1;
-      tile_tot[2 * n_tiles + blockIdx.x] = s2;
+    if (tile_tot) {
+      uint64_t s0, s1, s2;
+      block_exclusive_sum<uint64_t, kTileThreads>(t0, sm64, &s0);
+      block_exclusive_sum<uint64_t, kTileThreads>(t1, sm64, &s1);
+      block_exclusive_sum<uint64_t, kTileThreads>(t2, sm64, &s2);
+      if (tid == 0) {
+        tile_tot[blockIdx.x] = s0;
+        tile_tot[n_tiles + blockIdx.x] = s1;
+        tile_tot[2 * n_tiles + blockIdx.x] = s2;
+      }
     }
   } else {
-    // per-group counters, packed 21 bits each (a tile never yields 2^21 outputs)
-    for (uint32_t g = tid; g < n_heads; g += kTileThreads) {
-      GroupCounts c = op.count(acc, hpos[g], group_end(g));
-      gcnt[g] = (uint64_t)c.c0 | ((uint64_t)c.c1 << 21) | ((uint64_t)c.c2 << 42);
+    // per-unit counters, packed 21 bits each (a tile never yields 2^21 outputs)
+    for (uint32_t u = tid; u < n_units; u += kTileThreads) {
+      GroupCounts c = op.unit_count(ctx, u);
+      gcnt[u] = (uint64_t)c.c0 | ((uint64_t)c.c1 << 21) | ((uint64_t)c.c2 << 42);
     }
     __syncthreads();
-    // exclusive scan of gcnt[0..n_heads) in place: contiguous chunks per thread
-    const uint32_t chunk = (n_heads + kTileThreads - 1) / kTileThreads;
-    const uint32_t lo = min(n_heads, tid * chunk), hi = min(n_heads, lo + chunk);
+    const uint32_t chunk = (n_units + kTileThreads - 1) / kTileThreads;
+    const uint32_t lo = min(n_units, tid * chunk), hi = min(n_units, lo + chunk);
     uint64_t s = 0;
-    for (uint32_t g = lo; g < hi; ++g) s += gcnt[g];
+    for (uint32_t u = lo; u < hi; ++u) s += gcnt[u];
     uint64_t run = block_exclusive_sum<uint64_t, kTileThreads>(s, sm64, nullptr);
-    for (uint32_t g = lo; g < hi; ++g) {
-      const uint64_t v = gcnt[g];
-      gcnt[g] = run;
+    for (uint32_t u = lo; u < hi; ++u) {
+      const uint64_t v = gcnt[u];
+      gcnt[u] = run;
       run += v;
     }
     __syncthreads();
     const uint64_t b0 = tile_base[blockIdx.x], b1 = tile_base[n_tiles + blockIdx.x], b2 = tile_base[2 * n_tiles + blockIdx.x];
-    for (uint32_t g = tid; g < n_heads; g += kTileThreads) {
-      const uint64_t p = gcnt[g];
-      op.emit(acc, hpos[g], group_end(g), b0 + (p & 0x1FFFFF), b1 + ((p >> 21) & 0x1FFFFF), b2 + (p >> 42));
+    for (uint32_t u = tid; u < n_units; u += kTileThreads) {
+      const uint64_t p = gcnt[u];
+      op.unit_emit(ctx, u, b0 + (p & 0x1FFFFF), b1 + ((p >> 21) & 0x1FFFFF), b2 + (p >> 42));
+    }
+  }
+  // 6. optional item-parallel pass after the unit phase
+  if constexpr (Op::kItemFinal) {
+    __syncthreads();
+    if (op.item_final_enabled() && n_groups > 0) {
+#pragma unroll
+      for (int j = 0; j < PER; ++j) {
+        const uint32_t i = (uint32_t)(j * kTileThreads + tid);
+        if (i < (uint32_t)t_n && i >= first_head) op.item_final(ctx, i, (uint32_t)own_run(j));
+      }
+      if (tid < kWave)
+        for (uint32_t rel = (uint32_t)t_n + tid; rel < tail_end; rel += kWave) op.item_final(ctx, rel, tail_run(rel));
     }
   }
   __syncthreads();
