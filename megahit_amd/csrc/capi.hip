@@ -1,6 +1,7 @@
 // C-ABI entry points of libmhx.so (declared in include/mhx.h) and context plumbing.
 #include <algorithm>
 #include <cstdarg>
+#include <cstdlib>
 
 #include "dev_prims.h"
 #include "mhx_internal.h"
@@ -340,6 +341,13 @@ mhx_ctx *mhx_create(int device) {
     mhx_ctx *c = new mhx_ctx();
     c->device = device;
     MHX_HIP(hipStreamCreate(&c->stream));
+    // ranking inside the radix scatter: ballot match-any (default, order-independent by construction);
+    // MHX_SORT_RANK=atomic opts into one returning LDS atomic per record, used only if the device passes
+    // the lane-order probe (measured on MI355X: probe passes, gain < 2 %, so it is not the default)
+    const char *rk = getenv("MHX_SORT_RANK");
+    if (rk && !strcmp(rk, "atomic")) c->lds_atomic_ordered = mhx::probe_lds_atomic_order(c);
+    if (getenv("MHX_VERBOSE")) fprintf(stderr, "[mhx] device %d: LDS atomic lane order %s -> %s ranking\n", device,
+                                       c->lds_atomic_ordered ? "verified" : "not used", c->lds_atomic_ordered ? "atomic" : "ballot");
     return c;
   } catch (const std::exception &e) {
     mhx::set_error("%s", e.what());

@@ -76,6 +76,9 @@ struct mhx_ctx {
   int my_part = 0, n_parts = 1;
   std::vector<uint32_t> part_begin;
   uint64_t pos_base = 0, global_bases = 0;
+  // the LDS applies same-address lanes of one returning atomic in lane order (probed at mhx_create):
+  // lets the radix scatter rank records with one ds_add_rtn instead of an 8-ballot match-any
+  bool lds_atomic_ordered = false;
   // profiling
   bool profiling = false;
   std::vector<mhx::PendingEvent> pending;
@@ -111,14 +114,17 @@ namespace mhx {
 
 // ---- sort.hip ----
 struct SortPass {
-  int shift;  // bit offset from the LSB of the big-endian key (key_words*32 bits)
-  int bits;   // <= 8
+  int shift;       // bit offset from the LSB of the big-endian key (key_words*32 bits)
+  int bits;        // digit = bits [shift, shift+bits) ...
+  int shift2 = 0;  // ... optionally continued by bits [shift2, shift2+bits2) as its upper part
+  int bits2 = 0;   // bits + bits2 <= 8
 };
 // Sorts n items of `stride` uint32 words held in buf_a (ping-pong with buf_b) by the digit passes
 // (least-significant pass first).  Returns the buffer holding the result.
 uint32_t *radix_sort(mhx_ctx *c, uint32_t *buf_a, uint32_t *buf_b, uint64_t n, int stride, int key_words,
                      const std::vector<SortPass> &passes);
 std::vector<SortPass> make_passes(int key_words, int lo_bit, int hi_bit);
+bool probe_lds_atomic_order(mhx_ctx *c);
 
 // ---- scan.hip ----
 // exclusive scan of n uint32 values into uint64 (in != out); returns total via d_total (device, uint64[1])

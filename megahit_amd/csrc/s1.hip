@@ -13,6 +13,8 @@
 // first in read order.  kmlib::kmsort is unstable for buckets > 64 items, so mercy candidates can
 // differ from the reference there; is_solid and the histogram never depend on it.
 #include "dev_prims.h"
+#include <cstdlib>
+
 #include "mhx_internal.h"
 #include "tile_groups.h"
 
@@ -127,6 +129,8 @@ struct S1Op {
   uint64_t n_seqs;
   uint32_t fixed_len;
   uint8_t *solid_bytes;  // one byte per base position (plain stores, packed to the bitmap afterwards)
+  unsigned long long *solid_bits;  // or: the bitmap itself, set with atomics (mark_atomic)
+  int mark_atomic;
   unsigned long long *hist, *n_solid_out;
   int want_mercy;
   long long *mercy;
@@ -203,7 +207,10 @@ struct S1Op {
     const uint64_t info = (((uint64_t)c.acc.word(rel, kw) << 32) | c.acc.word(rel, kw + 1)) >> 6;
     const uint64_t abs = info >> 1;
     const int strand = (int)(info & 1);
-    if (solid) solid_bytes[abs - 1] = 1;  // is_solid.set(pos-1), :464 — a plain byte store instead of a 64-bit atomic
+    if (solid) {  // is_solid.set(pos-1), :464
+      if (mark_atomic) atomicOr(reinterpret_cast<unsigned int *>(solid_bits) + ((abs - 1) >> 5), 1u << ((abs - 1) & 31));
+      else solid_bytes[abs - 1] = 1;
+    }
     if (want_mercy) {
       const unsigned has_in = (ri >> 1) & 15u, has_out = (ri >> 5) & 15u, l_has_out = (ri >> 9) & 15u, r_has_in = (ri >> 13) & 15u;
       const unsigned ht = c.acc.word(rel, kw - 1) & 63u, h = ht >> 3, t = ht & 7;
@@ -255,16 +262,25 @@ __global__ __launch_bounds__(256) void k_pack_solid(const uint8_t *__restrict__ 
   if (threadIdx.x == 0 && tot) atomicAdd(n_solid, (unsigned long long)tot);
 }
 
+__global__ __launch_bounds__(256) void k_count_solid(const unsigned long long *__restrict__ words, uint64_t n_words,
+                                                     unsigned long long *__restrict__ n_solid) {
+  __shared__ uint64_t sm[256 / kWave + 1];
+  const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  uint64_t tot;
+  block_exclusive_sum<uint64_t, 256>(w < n_words ? (uint64_t)__builtin_popcountll(words[w]) : 0, sm, &tot);
+  if (threadIdx.x == 0 && tot) atomicAdd(n_solid, (unsigned long long)tot);
+}
+
 template <int S>
 static void s1_groups_launch(mhx_ctx *c, const uint32_t *sorted, uint64_t n_items, int KWv, int kmer_bits, uint32_t m,
-                             uint8_t *is_solid, unsigned long long *hist, unsigned long long *ctr, int want_mercy,
+                             uint8_t *is_solid, unsigned long long *solid_bits, int mark_atomic, unsigned long long *hist, unsigned long long *ctr, int want_mercy,
                              long long *mercy) {
   SeqSet &s = c->seqs;
   constexpr int T = S1Tile<S>::kT;
   const uint64_t n_tiles = div_ceil(n_items, T);
   const int full_words = kmer_bits / 32, rem = kmer_bits % 32;
   const uint32_t last_mask = rem ? 0xFFFFFFFFu << (32 - rem) : 0;
-  S1Op<S> op{KWv, m, s.start.as<uint64_t>(), s.n_seqs, s.fixed_len, is_solid, hist, ctr, want_mercy, mercy, ctr + 1};
+  S1Op<S> op{KWv, m, s.start.as<uint64_t>(), s.n_seqs, s.fixed_len, is_solid, solid_bits, mark_atomic, hist, ctr, want_mercy, mercy, ctr + 1};
   MHX_LAUNCH(c, "s1_groups", (double)n_items * S * 4,
              hipLaunchKernelGGL((k_tile_groups<S, T, S1Op<S>, false>), dim3((unsigned)n_tiles), dim3(kTileThreads), 0, c->stream, sorted,
                                 n_items, full_words, last_mask, op, (uint64_t *)nullptr, (const uint64_t *)nullptr, n_tiles));
@@ -335,9 +351,17 @@ int s1_process(mhx_ctx *c, uint32_t k, uint32_t m, int want_mercy, uint32_t *buf
   unsigned long long *is_solid = c->result(MHX_BUF_IS_SOLID, (n_words64 + 1) * 8).as<unsigned long long>();
   c->results[MHX_BUF_IS_SOLID].used = n_words64 * 8;
   unsigned long long *hist = c->result(MHX_BUF_MUL_HIST, (MHX_MAX_MUL + 1) * 8).as<unsigned long long>();
-  uint8_t *solid_bytes = c->ws("solid_bytes", (n_words64 + 1) * 64).as<uint8_t>();
-  MHX_HIP(hipMemsetAsync(solid_bytes, 0, (n_words64 + 1) * 64, st));
-  MHX_HIP(hipMemsetAsync(is_solid + n_words64, 0, 8, st));
+  static const int mark_atomic = [] {
+    const char *e = getenv("MHX_S1_MARK");
+    return e && !strcmp(e, "atomic") ? 1 : 0;
+  }();
+  uint8_t *solid_bytes = nullptr;
+  if (mark_atomic) MHX_HIP(hipMemsetAsync(is_solid, 0, (n_words64 + 1) * 8, st));
+  else {
+    solid_bytes = c->ws("solid_bytes", (n_words64 + 1) * 64).as<uint8_t>();
+    MHX_HIP(hipMemsetAsync(solid_bytes, 0, (n_words64 + 1) * 64, st));
+    MHX_HIP(hipMemsetAsync(is_solid + n_words64, 0, 8, st));
+  }
   MHX_HIP(hipMemsetAsync(hist, 0, (MHX_MAX_MUL + 1) * 8, st));
   unsigned long long *ctr = c->ws("s1_counters", 64).as<unsigned long long>();
   MHX_HIP(hipMemsetAsync(ctr, 0, 64, st));
@@ -348,13 +372,16 @@ int s1_process(mhx_ctx *c, uint32_t k, uint32_t m, int want_mercy, uint32_t *buf
   if (n_items) {
     switch (S) {
 #define MHX_CASE(SV) \
-  case SV: s1_groups_launch<SV>(c, sorted, n_items, KWv, kmer_bits, m, solid_bytes, hist, ctr, want_mercy, mercy); break;
+  case SV: s1_groups_launch<SV>(c, sorted, n_items, KWv, kmer_bits, m, solid_bytes, is_solid, mark_atomic, hist, ctr, want_mercy, mercy); break;
       MHX_CASE(4) MHX_CASE(6) MHX_CASE(8) MHX_CASE(10) MHX_CASE(12) MHX_CASE(14) MHX_CASE(16) MHX_CASE(18) MHX_CASE(20)
 #undef MHX_CASE
       default: throw Error("read2sdbg_s1: unsupported record stride");
     }
   }
-  if (n_words64)
+  if (n_words64 && mark_atomic)
+    MHX_LAUNCH(c, "count_solid", (double)n_words64 * 8,
+               hipLaunchKernelGGL(k_count_solid, dim3((unsigned)div_ceil(n_words64, 256)), dim3(256), 0, st, is_solid, n_words64, ctr));
+  if (n_words64 && !mark_atomic)
     MHX_LAUNCH(c, "pack_solid", (double)n_words64 * 72,
                hipLaunchKernelGGL(k_pack_solid, dim3((unsigned)div_ceil(n_words64, 256)), dim3(256), 0, st, solid_bytes, n_bits, is_solid, n_words64,
                                   ctr));

@@ -63,33 +63,28 @@ __global__ __launch_bounds__(256) void k_s2_count(const uint32_t *__restrict__ s
   }
 }
 
-// type: 0 left-$, 1 solid, 2 right-$  (EncodeOffset, read_to_sdbg_s2.cpp:36-41)
+// in << c chars (c = 1 or 2), then keep n chars
+template <int KW>
+__device__ __forceinline__ void shl_mask_chars(const uint32_t (&in)[KW], int c, int n, uint32_t (&out)[KW]) {
+  const unsigned sh = 2u * c;
+#pragma unroll
+  for (int i = 0; i < KW; ++i) {
+    const uint32_t nxt = i + 1 < KW ? in[i + 1] : 0u;
+    out[i] = c ? ((in[i] << sh) | (nxt >> (32 - sh))) : in[i];
+  }
+  const int full = n >> 4, rem = n & 15;
+#pragma unroll
+  for (int i = 0; i < KW; ++i) {
+    if (i > full) out[i] = 0;
+    else if (i == full) out[i] = rem ? (out[i] & (0xFFFFFFFFu << (32 - 2 * rem))) : 0u;
+  }
+}
 template <int KW, int S>
-__device__ __forceinline__ void s2_write_item(const uint32_t *__restrict__ seq, uint64_t fo, int k, int strand, int type,
-                                              uint32_t *__restrict__ dst) {
-  int n = k;
-  unsigned prev = kSentinel;
-  uint64_t off = fo;
-  if (!strand) {  // :457-485
-    if (type == 1) { prev = base_at(seq, fo); off = fo + 1; }
-    else if (type == 2) { prev = base_at(seq, fo + 1); off = fo + 2; n = k - 1; }
-  } else {        // :487-512
-    if (type == 0) { n = k - 1; prev = 3 - base_at(seq, fo + k - 1); }
-    else if (type == 1) prev = 3 - base_at(seq, fo + k);
-    else off = fo + 1;
-  }
-  uint32_t f[KW], out[S];
-  load_chars<KW>(seq, off, n, f);
-  if (strand) {
-    uint32_t rc[KW];
-    rc_chars<KW>(f, n, rc);
+__device__ __forceinline__ void s2_store(const uint32_t (&key)[KW], uint32_t low, uint32_t *__restrict__ dst) {
+  uint32_t out[S];
 #pragma unroll
-    for (int i = 0; i < KW; ++i) out[i] = rc[i];
-  } else {
-#pragma unroll
-    for (int i = 0; i < KW; ++i) out[i] = f[i];
-  }
-  out[KW - 1] |= ((n == k) ? 8u : 0u) | prev;
+  for (int i = 0; i < KW; ++i) out[i] = key[i];
+  out[KW - 1] |= low;
   if constexpr (S > KW) out[KW] = 0;
   if constexpr (S % 4 == 0) {
 #pragma unroll
@@ -98,6 +93,42 @@ __device__ __forceinline__ void s2_write_item(const uint32_t *__restrict__ seq, 
   } else {
 #pragma unroll
     for (int i = 0; i < S / 2; ++i) reinterpret_cast<uint2 *>(dst)[i] = make_uint2(out[2 * i], out[2 * i + 1]);
+  }
+}
+
+// All (<= 6) items of the solid (k+1)-mer occurrence e = r[p..p+k] (Lv2ExtractSubString,
+// read_to_sdbg_s2.cpp:442-519; edge types of EncodeOffset :36-41) derived from e and its reverse
+// complement rc held in registers: every item is a 1- or 2-char shift of one of the two.
+//   left-$  fwd: e[0..k-1] W=$        rc: rc[2..k] (k-1 chars) W=rc[1]
+//   solid   fwd: e[1..k]   W=e[0]     rc: rc[1..k]             W=rc[0]
+//   right-$ fwd: e[2..k] (k-1) W=e[1] rc: rc[0..k-1]           W=$
+template <int KW, int S>
+__device__ __forceinline__ void s2_write_items(const uint32_t (&e)[KW], const uint32_t (&rc)[KW], int k, unsigned mask,
+                                               uint32_t *__restrict__ dst) {
+  const bool pal = mask & 4u;
+  const uint32_t e0 = e[0] >> 30, e1 = (e[0] >> 28) & 3u, r0 = rc[0] >> 30, r1 = (rc[0] >> 28) & 3u;
+  uint32_t t[KW];
+  if (mask & 1u) {
+    shl_mask_chars<KW>(e, 0, k, t);
+    s2_store<KW, S>(t, 8u | kSentinel, dst); dst += S;
+    if (!pal) {
+      shl_mask_chars<KW>(rc, 2, k - 1, t);
+      s2_store<KW, S>(t, r1, dst); dst += S;
+    }
+  }
+  shl_mask_chars<KW>(e, 1, k, t);
+  s2_store<KW, S>(t, 8u | e0, dst); dst += S;
+  if (!pal) {
+    shl_mask_chars<KW>(rc, 1, k, t);
+    s2_store<KW, S>(t, 8u | r0, dst); dst += S;
+  }
+  if (mask & 2u) {
+    shl_mask_chars<KW>(e, 2, k - 1, t);
+    s2_store<KW, S>(t, e1, dst); dst += S;
+    if (!pal) {
+      shl_mask_chars<KW>(rc, 0, k, t);
+      s2_store<KW, S>(t, 8u | kSentinel, dst); dst += S;
+    }
   }
 }
 
@@ -117,24 +148,22 @@ __global__ __launch_bounds__(256) void k_s2_extract(const uint32_t *__restrict__
     for (uint32_t p0 = 0; p0 < L - k; p0 += kWave) {
       const uint32_t p = p0 + lane;
       unsigned mask = 0, c = 0;
-      if (p < L - k) c = s2_items_at<KW>(seq, solid, sure != 0, st, L, p, k, &mask);
-      const uint32_t inc = wave_inclusive_sum<uint32_t>(c);
-      const uint32_t tot = __shfl(inc, kWave - 1, kWave);
-      if (c) {
-        uint32_t *dst = items + (carry + inc - c) * S;
-        const bool pal = mask & 4u;
+      uint32_t e[KW], rc[KW];
+      if (p < L - k) {
         const uint64_t fo = st + p;
-        if (mask & 1u) {
-          s2_write_item<KW, S>(seq, fo, k, 0, 0, dst); dst += S;
-          if (!pal) { s2_write_item<KW, S>(seq, fo, k, 1, 0, dst); dst += S; }
-        }
-        s2_write_item<KW, S>(seq, fo, k, 0, 1, dst); dst += S;
-        if (!pal) { s2_write_item<KW, S>(seq, fo, k, 1, 1, dst); dst += S; }
-        if (mask & 2u) {
-          s2_write_item<KW, S>(seq, fo, k, 0, 2, dst); dst += S;
-          if (!pal) { s2_write_item<KW, S>(seq, fo, k, 1, 2, dst); dst += S; }
+        if (sure || bit_at(solid, fo)) {
+          load_chars<KW>(seq, fo, k + 1, e);
+          rc_chars<KW>(e, k + 1, rc);
+          const bool pal = cmp_words<KW>(e, rc) == 0;
+          const bool left = p == 0 || !(sure || bit_at(solid, fo - 1));          // :385-386
+          const bool right = p + k + 1 == L || !(sure || bit_at(solid, fo + 1)); // :411-412
+          mask = (left ? 1u : 0u) | (right ? 2u : 0u) | (pal ? 4u : 0u);
+          c = (1u + left + right) * (pal ? 1u : 2u);
         }
       }
+      const uint32_t inc = wave_inclusive_sum<uint32_t>(c);
+      const uint32_t tot = __shfl(inc, kWave - 1, kWave);
+      if (c) s2_write_items<KW, S>(e, rc, k, mask, items + (carry + inc - c) * S);
       carry += tot;
     }
   }
@@ -417,16 +446,24 @@ void emit_sdbg(mhx_ctx *c, const uint32_t *sorted, uint64_t n_items, int S, int 
   }
 }
 
-// fewest 8-bit passes covering the given bit ranges (ascending, disjoint)
+// fewest 8-bit passes covering the given bit ranges (ascending, disjoint; at most two): the bits of the
+// ranges are concatenated into one virtual key, so a digit may consist of the top of one range and the
+// bottom of the next (two-field digit) instead of wasting a pass on a partial digit per range.
 std::vector<SortPass> make_passes_ranges(int key_words, const std::vector<std::pair<int, int>> &ranges) {
-  size_t sep = 0;
-  for (auto &r : ranges) sep += (size_t)div_ceil(r.second - r.first, 8);
-  const int lo = ranges.front().first, hi = ranges.back().second;
-  if ((size_t)div_ceil(hi - lo, 8) <= sep) return make_passes(key_words, lo, hi);
+  if (ranges.size() == 1) return make_passes(key_words, ranges[0].first, ranges[0].second);
+  if (ranges.size() != 2) throw Error("make_passes_ranges: at most two ranges");
+  const int lo0 = ranges[0].first, len0 = ranges[0].second - ranges[0].first;
+  const int lo1 = ranges[1].first, len1 = ranges[1].second - ranges[1].first;
+  // covering the gap as well costs no extra pass? then a plain contiguous plan is simplest
+  if ((int)div_ceil(ranges[1].second - lo0, 8) <= (int)div_ceil(len0 + len1, 8)) return make_passes(key_words, lo0, ranges[1].second);
   std::vector<SortPass> p;
-  for (auto &r : ranges) {
-    auto q = make_passes(key_words, r.first, r.second);
-    p.insert(p.end(), q.begin(), q.end());
+  for (int v = 0; v < len0 + len1; v += 8) {
+    const int n = std::min(8, len0 + len1 - v);
+    SortPass ps{0, 0, 0, 0};
+    if (v + n <= len0) ps = {lo0 + v, n, 0, 0};
+    else if (v >= len0) ps = {lo1 + (v - len0), n, 0, 0};
+    else ps = {lo0 + v, len0 - v, lo1, n - (len0 - v)};
+    p.push_back(ps);
   }
   return p;
 }

@@ -64,6 +64,14 @@ __device__ __forceinline__ void store_rec(uint32_t *__restrict__ p, const Rec<S>
   }
 }
 
+// where a pass's digit lives: up to two bit fields (word index, bit offset, mask); field 2 is the upper part
+struct DigitSpec {
+  int wi1;
+  unsigned bit1, mask1;
+  int wi2;
+  unsigned bit2, mask2, sh2;  // mask2 == 0: single field
+};
+
 // digit of a record held in registers: bits [bit, bit+nbits) of word wi (and wi-1 when straddling)
 template <int S>
 __device__ __forceinline__ unsigned rec_digit(const Rec<S> &r, int wi, unsigned bit, unsigned mask) {
@@ -76,17 +84,27 @@ __device__ __forceinline__ unsigned rec_digit(const Rec<S> &r, int wi, unsigned 
   uint64_t v = ((uint64_t)hi << 32) | lo;
   return (unsigned)(v >> bit) & mask;
 }
+template <int S>
+__device__ __forceinline__ unsigned rec_digit2(const Rec<S> &r, const DigitSpec &ds) {
+  unsigned d = rec_digit<S>(r, ds.wi1, ds.bit1, ds.mask1);
+  if (ds.mask2) d |= rec_digit<S>(r, ds.wi2, ds.bit2, ds.mask2) << ds.sh2;
+  return d;
+}
+__device__ __forceinline__ unsigned mem_digit(const uint32_t *p, int wi, unsigned bit, unsigned mask) {
+  uint64_t v = p[wi];
+  if (bit + (32 - __builtin_clz(mask)) > 32 && wi > 0) v |= (uint64_t)p[wi - 1] << 32;
+  return (unsigned)(v >> bit) & mask;
+}
 
 template <int S, int NI>
-__global__ __launch_bounds__(kSortThreads) void k_radix_hist(const uint32_t *__restrict__ items, uint64_t n, int wi, unsigned bit,
-                                                             unsigned mask, uint32_t *__restrict__ hist, uint64_t n_chunks,
+__global__ __launch_bounds__(kSortThreads) void k_radix_hist(const uint32_t *__restrict__ items, uint64_t n, DigitSpec ds,
+                                                             uint32_t *__restrict__ hist, uint64_t n_chunks,
                                                              const uint8_t *__restrict__ lut) {
   __shared__ uint32_t h[kSortWaves][256];
   for (int i = threadIdx.x; i < kSortWaves * 256; i += kSortThreads) (&h[0][0])[i] = 0;
   __syncthreads();
   const int w = threadIdx.x / kWave;
   const uint64_t base = (uint64_t)blockIdx.x * SortCfg<S, NI>::kChunk;
-  const bool straddle = bit + (32 - __builtin_clz(mask)) > 32 && wi > 0;
   for (int j = 0; j < SortCfg<S, NI>::kChunk / kSortThreads; ++j) {
     uint64_t idx = base + (uint64_t)j * kSortThreads + threadIdx.x;
     if (idx < n) {
@@ -94,9 +112,8 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_hist(const uint32_t *__r
       unsigned d;
       if (lut) d = lut[p[0] >> 16];  // digit = owner of the item's lv1 bucket
       else {
-        uint64_t v = p[wi];
-        if (straddle) v |= (uint64_t)p[wi - 1] << 32;
-        d = (unsigned)(v >> bit) & mask;
+        d = mem_digit(p, ds.wi1, ds.bit1, ds.mask1);
+        if (ds.mask2) d |= mem_digit(p, ds.wi2, ds.bit2, ds.mask2) << ds.sh2;
       }
       atomicAdd(&h[w][d], 1u);
     }
@@ -111,9 +128,12 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_hist(const uint32_t *__r
   }
 }
 
-template <int S, int NI>
+// RANK_ATOMIC: rank inside a wavefront with one returning LDS atomic per record instead of the 8-ballot
+// match-any.  Stable only if the LDS serialises same-address lanes of one instruction in lane order;
+// libmhx verifies that on the device at start-up (probe_lds_atomic_order) before selecting it.
+template <int S, int NI, bool RANK_ATOMIC>
 __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(const uint32_t *__restrict__ in, uint32_t *__restrict__ out, uint64_t n,
-                                                                int wi, unsigned bit, unsigned mask, int nbits,
+                                                                DigitSpec ds, int nbits,
                                                                 const uint64_t *__restrict__ offs, uint64_t n_chunks,
                                                                 const uint8_t *__restrict__ lut) {
   using Cfg = SortCfg<S, NI>;
@@ -147,22 +167,26 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(const uint32_t *
       const int li = w * (kWave * ITEMS) + j * kWave + lane;
       const bool valid = li < tile_n;
       if (valid) load_rec<S>(in + (tile_base + li) * S, rec[j]);
-      unsigned d = valid ? (lut ? (unsigned)lut[rec[j].w[0] >> 16] : rec_digit<S>(rec[j], wi, bit, mask)) : 0u;
+      unsigned d = valid ? (lut ? (unsigned)lut[rec[j].w[0] >> 16] : rec_digit2<S>(rec[j], ds)) : 0u;
       dig[j] = d;
-      // match-any over the digit bits
-      uint64_t peers = __ballot(valid);
-      for (int b = 0; b < nbits; ++b) {
-        const bool bitset = (d >> b) & 1u;
-        const uint64_t m = __ballot(bitset);
-        peers &= bitset ? m : ~m;
+      if constexpr (RANK_ATOMIC) {
+        rank[j] = valid ? atomicAdd(&wave_cnt[w][d], 1u) : 0u;
+      } else {
+        // match-any over the digit bits
+        uint64_t peers = __ballot(valid);
+        for (int b = 0; b < nbits; ++b) {
+          const bool bitset = (d >> b) & 1u;
+          const uint64_t m = __ballot(bitset);
+          peers &= bitset ? m : ~m;
+        }
+        // every lane reads the running counter of its digit, then the lowest peer lane bumps it:
+        // LDS operations of one wavefront execute in program order, so the read precedes the write.
+        const uint32_t before = wave_cnt[w][d];
+        rank[j] = before + __builtin_popcountll(peers & lanemask_lt);
+        __builtin_amdgcn_wave_barrier();
+        if (valid && (peers & lanemask_lt) == 0) wave_cnt[w][d] = before + __builtin_popcountll(peers);
+        __builtin_amdgcn_wave_barrier();
       }
-      // every lane reads the running counter of its digit, then the lowest peer lane bumps it:
-      // LDS operations of one wavefront execute in program order, so the read precedes the write.
-      const uint32_t before = wave_cnt[w][d];
-      rank[j] = before + __builtin_popcountll(peers & lanemask_lt);
-      __builtin_amdgcn_wave_barrier();
-      if (valid && (peers & lanemask_lt) == 0) wave_cnt[w][d] = before + __builtin_popcountll(peers);
-      __builtin_amdgcn_wave_barrier();
     }
     __syncthreads();
     // thread d: turn per-wave totals into bases inside the tile
@@ -196,7 +220,7 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(const uint32_t *
       if (li < tile_n) {
         Rec<S> r;
         load_rec<S>(stage + (size_t)li * S, r);
-        const unsigned d = lut ? (unsigned)lut[r.w[0] >> 16] : rec_digit<S>(r, wi, bit, mask);
+        const unsigned d = lut ? (unsigned)lut[r.w[0] >> 16] : rec_digit2<S>(r, ds);
         store_rec<S>(out + (uint64_t)(g_off[d] + li) * S, r);
       }
     }
@@ -204,10 +228,56 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(const uint32_t *
   }
 }
 
+// Does the LDS apply the lanes of ONE returning atomic instruction that hit the same address in lane order?
+// Each wave does ds_add_rtn on a few shared counters with adversarial lane->address patterns; a lane's
+// returned value must equal the number of lower lanes of its wave that used the same address.
+__global__ __launch_bounds__(kSortThreads) void k_probe_lds_atomic(uint32_t *bad, uint32_t seed) {
+  __shared__ uint32_t cnt[kSortWaves][256];
+  const int tid = threadIdx.x, w = tid / kWave, lane = tid & (kWave - 1);
+  uint32_t x = seed * 2654435761u + blockIdx.x * 40503u + 12345u;
+  for (int it = 0; it < 64; ++it) {
+    for (int i = tid; i < kSortWaves * 256; i += kSortThreads) (&cnt[0][0])[i] = 0;
+    __syncthreads();
+    x = x * 1664525u + 1013904223u;
+    const uint32_t mode = (x >> 28) & 3u;
+    uint32_t lx = (x ^ (uint32_t)lane * 2246822519u) * 3266489917u;
+    lx ^= lx >> 15;
+    uint32_t d;
+    if (mode == 0) d = lx & 255u;           // random digits
+    else if (mode == 1) d = lx & 3u;        // 4 hot addresses
+    else if (mode == 2) d = 7u;             // all lanes one address
+    else d = (uint32_t)(lane & 1) * 128u + ((lx >> 8) & 1u);
+    const bool active = ((lx >> 20) & 7u) != 0;  // some lanes sit out
+    uint32_t got = 0;
+    if (active) got = atomicAdd(&cnt[w][d], 1u);
+    // expected: lower active lanes of this wave with the same d
+    uint32_t expect = 0;
+    for (int l = 0; l < kWave; ++l) {
+      const uint32_t od = __shfl(d, l, kWave);
+      const int oa = __shfl((int)active, l, kWave);
+      if (l < lane && oa && od == d) ++expect;
+    }
+    if (active && got != expect) atomicAdd(bad, 1u);
+    __syncthreads();
+  }
+}
+
+bool probe_lds_atomic_order(mhx_ctx *c) {
+  uint32_t *d_bad = c->ws("probe_bad", 64).as<uint32_t>();
+  MHX_HIP(hipMemsetAsync(d_bad, 0, 4, c->stream));
+  for (uint32_t seed = 1; seed <= 4; ++seed)
+    hipLaunchKernelGGL(k_probe_lds_atomic, dim3(1024), dim3(kSortThreads), 0, c->stream, d_bad, seed);
+  MHX_HIP(hipGetLastError());
+  uint32_t bad = 1;
+  MHX_HIP(hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, c->stream));
+  MHX_HIP(hipStreamSynchronize(c->stream));
+  return bad == 0;
+}
+
 std::vector<SortPass> make_passes(int key_words, int lo_bit, int hi_bit) {
   (void)key_words;
   std::vector<SortPass> p;
-  for (int s = lo_bit; s < hi_bit; s += 8) p.push_back({s, std::min(8, hi_bit - s)});
+  for (int s = lo_bit; s < hi_bit; s += 8) p.push_back({s, std::min(8, hi_bit - s), 0, 0});
   return p;
 }
 
@@ -221,15 +291,26 @@ static uint32_t *radix_sort_impl2(mhx_ctx *c, uint32_t *a, uint32_t *b, uint64_t
   const double bytes = (double)n * S * 4;
   static const std::string nm_hist = "radix_hist_" + std::to_string(S * 4) + "B", nm_scat = "radix_scatter_" + std::to_string(S * 4) + "B";
   for (const SortPass &ps : passes) {
-    const int wi = key_words - 1 - ps.shift / 32;
-    const unsigned bit = ps.shift % 32, mask = (1u << ps.bits) - 1;
+    DigitSpec ds{key_words - 1 - ps.shift / 32, (unsigned)(ps.shift % 32), (1u << ps.bits) - 1, 0, 0u, 0u, 0u};
+    if (ps.bits2) {
+      ds.wi2 = key_words - 1 - ps.shift2 / 32;
+      ds.bit2 = (unsigned)(ps.shift2 % 32);
+      ds.mask2 = (1u << ps.bits2) - 1;
+      ds.sh2 = (unsigned)ps.bits;
+    }
+    const int nbits = ps.bits + ps.bits2;
     MHX_LAUNCH(c, nm_hist.c_str(), bytes,
-               hipLaunchKernelGGL((k_radix_hist<S, NI>), dim3((unsigned)n_chunks), dim3(kSortThreads), 0, c->stream, a, n, wi, bit, mask,
+               hipLaunchKernelGGL((k_radix_hist<S, NI>), dim3((unsigned)n_chunks), dim3(kSortThreads), 0, c->stream, a, n, ds,
                                   hist, n_chunks, (const uint8_t *)nullptr));
     exclusive_scan_u32_u64(c, hist, offs, n_chunks * 256, nullptr);
-    MHX_LAUNCH(c, nm_scat.c_str(), 2 * bytes,
-               hipLaunchKernelGGL((k_radix_scatter<S, NI>), dim3((unsigned)n_chunks), dim3(kSortThreads), 0, c->stream, a, b, n, wi, bit,
-                                  mask, ps.bits, offs, n_chunks, (const uint8_t *)nullptr));
+    if (c->lds_atomic_ordered)
+      MHX_LAUNCH(c, nm_scat.c_str(), 2 * bytes,
+                 hipLaunchKernelGGL((k_radix_scatter<S, NI, true>), dim3((unsigned)n_chunks), dim3(kSortThreads), 0, c->stream, a, b, n, ds,
+                                    nbits, offs, n_chunks, (const uint8_t *)nullptr));
+    else
+      MHX_LAUNCH(c, nm_scat.c_str(), 2 * bytes,
+                 hipLaunchKernelGGL((k_radix_scatter<S, NI, false>), dim3((unsigned)n_chunks), dim3(kSortThreads), 0, c->stream, a, b, n, ds,
+                                    nbits, offs, n_chunks, (const uint8_t *)nullptr));
     std::swap(a, b);
   }
   return a;
@@ -244,7 +325,10 @@ static uint32_t *radix_sort_impl(mhx_ctx *c, uint32_t *a, uint32_t *b, uint64_t 
       const char *e = getenv("MHX_SORT_ITEMS");
       return e ? atoi(e) : default_items<S>();
     }();
-    if (items == 4) return radix_sort_impl2<S, 4>(c, a, b, n, key_words, passes);
+    if (items == 2) return radix_sort_impl2<S, 2>(c, a, b, n, key_words, passes);
+    if (items == 3) return radix_sort_impl2<S, 3>(c, a, b, n, key_words, passes);
+    if (items == 6) return radix_sort_impl2<S, 6>(c, a, b, n, key_words, passes);
+    if (items == 16) return radix_sort_impl2<S, 16>(c, a, b, n, key_words, passes);
     if (items == 8) return radix_sort_impl2<S, 8>(c, a, b, n, key_words, passes);
     if (items == 12) return radix_sort_impl2<S, 12>(c, a, b, n, key_words, passes);
   }
@@ -264,11 +348,11 @@ static void partition_impl(mhx_ctx *c, const uint32_t *a, uint32_t *b, uint64_t 
   int nbits = 1;
   while ((1 << nbits) < n_parts) ++nbits;
   MHX_LAUNCH(c, "owner_hist", bytes,
-             hipLaunchKernelGGL((k_radix_hist<S, default_items<S>()>), dim3((unsigned)n_chunks), dim3(kSortThreads), 0, c->stream, a, n, 0, 0u, 0xFFu, hist,
+             hipLaunchKernelGGL((k_radix_hist<S, default_items<S>()>), dim3((unsigned)n_chunks), dim3(kSortThreads), 0, c->stream, a, n, DigitSpec{0, 0u, 0xFFu, 0, 0u, 0u, 0u}, hist,
                                 n_chunks, lut));
   exclusive_scan_u32_u64(c, hist, offs, n_chunks * 256, offs + n_chunks * 256);
   MHX_LAUNCH(c, "owner_scatter", 2 * bytes,
-             hipLaunchKernelGGL((k_radix_scatter<S, default_items<S>()>), dim3((unsigned)n_chunks), dim3(kSortThreads), 0, c->stream, a, b, n, 0, 0u, 0xFFu,
+             hipLaunchKernelGGL((k_radix_scatter<S, default_items<S>(), false>), dim3((unsigned)n_chunks), dim3(kSortThreads), 0, c->stream, a, b, n, DigitSpec{0, 0u, 0xFFu, 0, 0u, 0u, 0u},
                                 nbits, offs, n_chunks, lut));
   std::vector<uint64_t> starts(n_parts + 1);
   for (int p = 0; p <= n_parts; ++p)
