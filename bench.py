@@ -48,6 +48,28 @@ def make_reads(n_reads, rank, world):
     return np.concatenate(chunks)
 
 
+def pmc_traffic(kernel_name):
+    """HBM bytes per launch of `kernel_name` measured with rocprofv3 PMC passes on THIS workload
+    (profiles/r01_pmc_traffic.json, produced by tools/pmc_to_json.py with the gfx950 FETCH_SIZE x2 correction);
+    counters cannot be collected from inside the timed run, so the committed measurement is reported."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    try:
+        with open(path) as f:
+            kernels = json.load(f)["kernels"]
+    except Exception:
+        return None, None
+    prefix = None
+    for stem in ("radix_scatter_", "radix_hist_"):
+        if kernel_name.startswith(stem) and kernel_name.endswith("B"):
+            prefix = "k_%s<%d," % (stem[:-1], int(kernel_name[len(stem):-1]) // 4)
+    if prefix is None:
+        return None, None
+    for k, v in kernels.items():
+        if k.startswith(prefix):
+            return v["hbm_bytes"], "profiles/r01_pmc_traffic.json:" + k
+    return None, None
+
+
 def cpu_baseline(sample_reads):
     """The reference's own CPU path (oracle/_ref/ref_core = reference sources compiled in place) on a
     bounded sample of the same workload, all host cores.  Falls back to the C port (oracle_core)."""
@@ -161,8 +183,9 @@ def main():
         per_launch_bytes = ks["bytes"] / ks["launches"]
         per_launch_ms = ks["ms"] / ks["launches"]
         achieved = per_launch_bytes / per_launch_ms / 1e6  # GB/s
+        traffic, traffic_src = pmc_traffic(name) if n_reads == 10000000 else (None, None)
         roof = {"bound": "hbm", "kernel": name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "launches_per_step": ks["launches"] // max(1, args.steps), "avg_launch_ms": round(per_launch_ms, 4),
                 "algo_bytes_per_launch": per_launch_bytes,
                 "kernel_ms_per_step": {k2: round(v["ms"] / args.steps, 3) for k2, v in sorted(stats.items(), key=lambda kv: -kv[1]["ms"])}}

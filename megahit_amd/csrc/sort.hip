@@ -149,6 +149,19 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(const uint32_t *
   const uint64_t chunk_base = (uint64_t)blockIdx.x * Cfg::kChunk;
   const uint64_t lanemask_lt = (1ull << lane) - 1;
 
+  // records of the next tile are fetched while the current one is ranked, staged and written
+  // (wave-blocked striped arrangement: wave w owns [w*64*ITEMS, (w+1)*64*ITEMS) of a tile)
+  Rec<S> nxt[ITEMS];
+  auto fetch_tile = [&](int t) {
+    const uint64_t tb = chunk_base + (uint64_t)t * Cfg::kTile;
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+      const uint64_t gi = tb + (uint64_t)(w * (kWave * ITEMS) + j * kWave + lane);
+      if (t < Cfg::kTilesPerChunk && gi < n) load_rec<S>(in + gi * S, nxt[j]);
+    }
+  };
+  fetch_tile(0);
+
   for (int t = 0; t < Cfg::kTilesPerChunk; ++t) {
     const uint64_t tile_base = chunk_base + (uint64_t)t * Cfg::kTile;
     if (tile_base >= n) break;
@@ -161,12 +174,13 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(const uint32_t *
     Rec<S> rec[ITEMS];
     uint32_t rank[ITEMS];
     unsigned dig[ITEMS];
-    // wave-blocked striped arrangement: wave w owns [w*64*ITEMS, (w+1)*64*ITEMS) of the tile
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) rec[j] = nxt[j];
+    fetch_tile(t + 1);
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
       const int li = w * (kWave * ITEMS) + j * kWave + lane;
       const bool valid = li < tile_n;
-      if (valid) load_rec<S>(in + (tile_base + li) * S, rec[j]);
       unsigned d = valid ? (lut ? (unsigned)lut[rec[j].w[0] >> 16] : rec_digit2<S>(rec[j], ds)) : 0u;
       dig[j] = d;
       if constexpr (RANK_ATOMIC) {
@@ -174,7 +188,7 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(const uint32_t *
       } else {
         // match-any over the digit bits
         uint64_t peers = __ballot(valid);
-        for (int b = 0; b < nbits; ++b) {
+        for (int b = 0; b < (nbits < 0 ? -nbits : nbits); ++b) {
           const bool bitset = (d >> b) & 1u;
           const uint64_t m = __ballot(bitset);
           peers &= bitset ? m : ~m;
@@ -221,7 +235,9 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(const uint32_t *
         Rec<S> r;
         load_rec<S>(stage + (size_t)li * S, r);
         const unsigned d = lut ? (unsigned)lut[r.w[0] >> 16] : rec_digit2<S>(r, ds);
-        store_rec<S>(out + (uint64_t)(g_off[d] + li) * S, r);
+        // nbits < 0: timing experiment only (identity placement: same LDS work, perfectly coalesced stores)
+        const uint64_t dst = nbits < 0 ? tile_base + li : (uint64_t)(g_off[d] + li);
+        store_rec<S>(out + dst * S, r);
       }
     }
     __syncthreads();
@@ -298,7 +314,8 @@ static uint32_t *radix_sort_impl2(mhx_ctx *c, uint32_t *a, uint32_t *b, uint64_t
       ds.mask2 = (1u << ps.bits2) - 1;
       ds.sh2 = (unsigned)ps.bits;
     }
-    const int nbits = ps.bits + ps.bits2;
+    static const bool dbg_identity = getenv("MHX_DEBUG_IDENTITY_SCATTER") != nullptr;  // WRONG RESULTS: timing experiment
+    const int nbits = dbg_identity ? -(ps.bits + ps.bits2) : ps.bits + ps.bits2;
     MHX_LAUNCH(c, nm_hist.c_str(), bytes,
                hipLaunchKernelGGL((k_radix_hist<S, NI>), dim3((unsigned)n_chunks), dim3(kSortThreads), 0, c->stream, a, n, ds,
                                   hist, n_chunks, (const uint8_t *)nullptr));
