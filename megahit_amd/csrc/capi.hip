@@ -535,8 +535,8 @@ int mhx_dist_extract(mhx_ctx *c, int stage, uint32_t k, uint32_t min_count, mhx_
     uint64_t n = 0;
     int S = 0;
     if (stage == MHX_STAGE_S1) {
-      n = mhx::s1_extract(c, k);
-      S = mhx::round_up2((int)mhx::div_ceil((k - 1) * 2 + 6, 32) + 2);
+      n = mhx::s1_extract(c, k, mhx::s1_compact(c, 0));
+      S = mhx::s1_stride(k, mhx::s1_compact(c, 0));
     } else if (stage == MHX_STAGE_S2) {
       n = mhx::s2_extract(c, k, min_count);
       S = mhx::round_up2((int)mhx::div_ceil(k * 2 + 4, 32));
@@ -561,7 +561,7 @@ void *mhx_dist_recv_buffer(mhx_ctx *c, uint64_t n_items, uint32_t item_bytes) {
 int mhx_dist_process_s1(mhx_ctx *c, uint32_t k, uint32_t min_count, uint64_t n_items, mhx_s1_result *out) {
   MHX_TRY({
     MHX_HIP(hipSetDevice(c->device));
-    const int S = mhx::round_up2((int)mhx::div_ceil((k - 1) * 2 + 6, 32) + 2);
+    const int S = mhx::s1_stride(k, mhx::s1_compact(c, 0));
     uint32_t *a = c->ws("items_recv", n_items * (size_t)S * 4 + 64).as<uint32_t>();
     uint32_t *b = c->ws("items_b", n_items * (size_t)S * 4 + 64).as<uint32_t>();
     mhx::s1_process(c, k, min_count, 0, a, b, n_items, out);

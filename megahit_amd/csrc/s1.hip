@@ -28,7 +28,9 @@ __global__ void k_s1_item_counts(const uint64_t *__restrict__ start, uint64_t n_
   }
 }
 
-template <int KW, int S>
+// COMPACT (no mercy requested): the aux part is one word, the absolute position of the (k-1)-mer; that is
+// all the group reduction needs to set is_solid, and it makes the record 12 instead of 16 bytes at k <= 29.
+template <int KW, int S, bool COMPACT>
 __global__ __launch_bounds__(256) void k_s1_extract(const uint32_t *__restrict__ seq, const uint64_t *__restrict__ start,
                                                     const uint64_t *__restrict__ item_start, uint64_t n_seqs, int k,
                                                     uint64_t pos_base, uint32_t *__restrict__ items) {
@@ -77,11 +79,19 @@ __global__ __launch_bounds__(256) void k_s1_extract(const uint32_t *__restrict__
         out[KW - 1] |= (comp_or_sentinel(tail) << 3) | comp_or_sentinel(head);
         info = (full << 6) | (comp_or_sentinel(next) << 3) | comp_or_sentinel(prev);
       }
-      out[KW] = (uint32_t)(info >> 32);
-      out[KW + 1] = (uint32_t)info;
-      if constexpr (S > KW + 2) out[KW + 2] = 0;
+      if constexpr (COMPACT) {
+        out[KW] = (uint32_t)(pos_base + st + q);
+        if constexpr (S > KW + 1) out[KW + 1] = 0;
+      } else {
+        out[KW] = (uint32_t)(info >> 32);
+        out[KW + 1] = (uint32_t)info;
+        if constexpr (S > KW + 2) out[KW + 2] = 0;
+      }
       uint32_t *dst = items + (ibase + j) * S;
-      if constexpr (S % 4 == 0) {
+      if constexpr (S % 2 == 1) {
+#pragma unroll
+        for (int i = 0; i < S; ++i) dst[i] = out[i];
+      } else if constexpr (S % 4 == 0) {
 #pragma unroll
         for (int i = 0; i < S / 4; ++i)
           reinterpret_cast<uint4 *>(dst)[i] = make_uint4(out[4 * i], out[4 * i + 1], out[4 * i + 2], out[4 * i + 3]);
@@ -119,7 +129,7 @@ __device__ __forceinline__ uint32_t *s1_run_info() {  // bit0 solid | has_in<<1 
 // Lv2Postprocess of Read2SdbgS1 (read_to_sdbg_s1.cpp:368-555) as a tile operator (tile_groups.h):
 // run = records of one (k-1)-mer with the same (head,tail); the per-group logic iterates runs, the
 // per-record actions (is_solid bits, mercy candidates) are item-parallel.  No ordered output.
-template <int S>
+template <int S, bool COMPACT>
 struct S1Op {
   static constexpr bool kItemPhase = false, kItemFinal = true, kRunPhase = false, kUnitIsRun = false;
   __device__ void run_phase(const TileCtx<S> &, uint32_t, uint32_t) const {}
@@ -155,7 +165,8 @@ struct S1Op {
   __device__ void unit_emit(const TileCtx<S> &, uint32_t, uint64_t, uint64_t, uint64_t) const {}
   __device__ GroupCounts unit_count(const TileCtx<S> &c, uint32_t g) const {
     const uint32_t r0 = c.gpos[g], r1 = c.gpos[g + 1];
-    const unsigned pn_first = c.acc.word(c.run_start(r0), kw + 1) & 63u;  // H1: prev/next of the group's FIRST item, :399
+    // H1: prev/next of the group's FIRST item, :399 (compact records carry none: only mercy needs has_in/has_out)
+    const unsigned pn_first = COMPACT ? 0u : (c.acc.word(c.run_start(r0), kw + 1) & 63u);
     uint64_t cnt_head[4] = {0, 0, 0, 0}, cnt_tail[4] = {0, 0, 0, 0};
     unsigned l_has_out = 0, r_has_in = 0;
     for (uint32_t r = r0; r < r1; ++r) {
@@ -204,14 +215,19 @@ struct S1Op {
     const uint32_t ri = s1_run_info<S>()[run];
     const bool solid = ri & 1u;
     if (!solid && !want_mercy) return;
-    const uint64_t info = (((uint64_t)c.acc.word(rel, kw) << 32) | c.acc.word(rel, kw + 1)) >> 6;
-    const uint64_t abs = info >> 1;
-    const int strand = (int)(info & 1);
+    uint64_t abs;
+    int strand = 0;
+    if constexpr (COMPACT) abs = c.acc.word(rel, kw);
+    else {
+      const uint64_t info = (((uint64_t)c.acc.word(rel, kw) << 32) | c.acc.word(rel, kw + 1)) >> 6;
+      abs = info >> 1;
+      strand = (int)(info & 1);
+    }
     if (solid) {  // is_solid.set(pos-1), :464
       if (mark_atomic) atomicOr(reinterpret_cast<unsigned int *>(solid_bits) + ((abs - 1) >> 5), 1u << ((abs - 1) & 31));
       else solid_bytes[abs - 1] = 1;
     }
-    if (want_mercy) {
+    if (!COMPACT && want_mercy) {
       const unsigned has_in = (ri >> 1) & 15u, has_out = (ri >> 5) & 15u, l_has_out = (ri >> 9) & 15u, r_has_in = (ri >> 13) & 15u;
       const unsigned ht = c.acc.word(rel, kw - 1) & 63u, h = ht >> 3, t = ht & 7;
       const uint64_t rid = seq_of_offset(start, n_seqs, fixed_len, abs);
@@ -271,7 +287,7 @@ __global__ __launch_bounds__(256) void k_count_solid(const unsigned long long *_
   if (threadIdx.x == 0 && tot) atomicAdd(n_solid, (unsigned long long)tot);
 }
 
-template <int S>
+template <int S, bool COMPACT>
 static void s1_groups_launch(mhx_ctx *c, const uint32_t *sorted, uint64_t n_items, int KWv, int kmer_bits, uint32_t m,
                              uint8_t *is_solid, unsigned long long *solid_bits, int mark_atomic, unsigned long long *hist, unsigned long long *ctr, int want_mercy,
                              long long *mercy) {
@@ -280,9 +296,9 @@ static void s1_groups_launch(mhx_ctx *c, const uint32_t *sorted, uint64_t n_item
   const uint64_t n_tiles = div_ceil(n_items, T);
   const int full_words = kmer_bits / 32, rem = kmer_bits % 32;
   const uint32_t last_mask = rem ? 0xFFFFFFFFu << (32 - rem) : 0;
-  S1Op<S> op{KWv, m, s.start.as<uint64_t>(), s.n_seqs, s.fixed_len, is_solid, solid_bits, mark_atomic, hist, ctr, want_mercy, mercy, ctr + 1};
+  S1Op<S, COMPACT> op{KWv, m, s.start.as<uint64_t>(), s.n_seqs, s.fixed_len, is_solid, solid_bits, mark_atomic, hist, ctr, want_mercy, mercy, ctr + 1};
   MHX_LAUNCH(c, "s1_groups", (double)n_items * S * 4,
-             hipLaunchKernelGGL((k_tile_groups<S, T, S1Op<S>, false>), dim3((unsigned)n_tiles), dim3(kTileThreads), 0, c->stream, sorted,
+             hipLaunchKernelGGL((k_tile_groups<S, T, S1Op<S, COMPACT>, false>), dim3((unsigned)n_tiles), dim3(kTileThreads), 0, c->stream, sorted,
                                 n_items, full_words, last_mask, op, (uint64_t *)nullptr, (const uint64_t *)nullptr, n_tiles));
 }
 
@@ -297,12 +313,22 @@ __global__ void k_swap_words(uint32_t *__restrict__ v, uint64_t n) {
 
 // ---- host driver, in two halves so that the multi-GPU path can exchange items in between ----
 static int s1_kw(uint32_t k) { return (int)div_ceil((k - 1) * 2 + 6, 32); }  // read_to_sdbg_s1.cpp:107-108
+// compact 1-word aux when no mercy candidates are wanted and positions fit 32 bits
+bool s1_compact(const mhx_ctx *c, int want_mercy) {
+  const uint64_t n_bits = c->global_bases ? c->global_bases : c->seqs.n_bases;
+  return !want_mercy && n_bits < (1ull << 32);
+}
+int s1_stride(uint32_t k, bool compact) {
+  const int kw = s1_kw(k);
+  if (!compact) return round_up2(kw + 2);
+  return kw + 1 == 3 ? 3 : round_up2(kw + 1);  // 12-byte records are supported natively, other odd widths are padded
+}
 
 // items of the local reads -> c->ws("items_a"); returns their number
-uint64_t s1_extract(mhx_ctx *c, uint32_t k) {
+uint64_t s1_extract(mhx_ctx *c, uint32_t k, bool compact) {
   SeqSet &s = c->seqs;
   if (k < 9 || k > MHX_MAX_K) throw Error("read2sdbg: k out of range [9,255]");
-  const int KWv = s1_kw(k), S = round_up2(KWv + 2);
+  const int KWv = s1_kw(k), S = s1_stride(k, compact);
   const uint64_t ns = s.n_seqs;
   hipStream_t st = c->stream;
   uint32_t *cnt = c->ws("seq_item_cnt", (ns + 1) * 4).as<uint32_t>();
@@ -319,16 +345,20 @@ uint64_t s1_extract(mhx_ctx *c, uint32_t k) {
   uint32_t *buf_a = c->ws("items_a", n_items * item_bytes + 64).as<uint32_t>();
   if (n_items) {
     const unsigned grid = 256 * 8;
+#define MHX_S1X(SV, CP)                                                                                                      \
+  MHX_LAUNCH(c, "s1_extract", (double)n_items * item_bytes + (double)s.n_bases / 4,                                          \
+             hipLaunchKernelGGL((k_s1_extract<KW, SV, CP>), dim3(grid), dim3(256), 0, st, s.words.as<uint32_t>(),            \
+                                s.start.as<uint64_t>(), item_start, ns, (int)k, c->pos_base, buf_a))
     MHX_DISPATCH_KW(KWv, {
-      if (S == KW + 2)
-        MHX_LAUNCH(c, "s1_extract", (double)n_items * item_bytes + (double)s.n_bases / 4,
-                   hipLaunchKernelGGL((k_s1_extract<KW, KW + 2>), dim3(grid), dim3(256), 0, st, s.words.as<uint32_t>(),
-                                      s.start.as<uint64_t>(), item_start, ns, (int)k, c->pos_base, buf_a));
-      else
-        MHX_LAUNCH(c, "s1_extract", (double)n_items * item_bytes + (double)s.n_bases / 4,
-                   hipLaunchKernelGGL((k_s1_extract<KW, KW + 3>), dim3(grid), dim3(256), 0, st, s.words.as<uint32_t>(),
-                                      s.start.as<uint64_t>(), item_start, ns, (int)k, c->pos_base, buf_a));
+      if (compact) {
+        if (S == KW + 1) MHX_S1X(KW + 1, true);
+        else MHX_S1X(KW + 2, true);
+      } else {
+        if (S == KW + 2) MHX_S1X(KW + 2, false);
+        else MHX_S1X(KW + 3, false);
+      }
     });
+#undef MHX_S1X
   }
   return n_items;
 }
@@ -337,7 +367,8 @@ uint64_t s1_extract(mhx_ctx *c, uint32_t k) {
 int s1_process(mhx_ctx *c, uint32_t k, uint32_t m, int want_mercy, uint32_t *buf_a, uint32_t *buf_b, uint64_t n_items,
                mhx_s1_result *out) {
   SeqSet &s = c->seqs;
-  const int KWv = s1_kw(k), S = round_up2(KWv + 2);
+  const bool compact = s1_compact(c, want_mercy);
+  const int KWv = s1_kw(k), S = s1_stride(k, compact);
   const size_t item_bytes = (size_t)S * 4;
   hipStream_t st = c->stream;
   const bool global = c->global_bases != 0;  // multi-GPU: positions index the global read set
@@ -370,13 +401,16 @@ int s1_process(mhx_ctx *c, uint32_t k, uint32_t m, int want_mercy, uint32_t *buf
   // mercy candidates (<= 2 per item, 8 B each) go to the spare sort buffer: S*4 >= 16 bytes per item
   long long *mercy = reinterpret_cast<long long *>(spare);
   if (n_items) {
+#define MHX_CASE(SV)                                                                                                            \
+  case SV:                                                                                                                      \
+    if (compact) s1_groups_launch<SV, true>(c, sorted, n_items, KWv, kmer_bits, m, solid_bytes, is_solid, mark_atomic, hist, ctr, 0, mercy); \
+    else s1_groups_launch<SV, false>(c, sorted, n_items, KWv, kmer_bits, m, solid_bytes, is_solid, mark_atomic, hist, ctr, want_mercy, mercy); \
+    break;
     switch (S) {
-#define MHX_CASE(SV) \
-  case SV: s1_groups_launch<SV>(c, sorted, n_items, KWv, kmer_bits, m, solid_bytes, is_solid, mark_atomic, hist, ctr, want_mercy, mercy); break;
-      MHX_CASE(4) MHX_CASE(6) MHX_CASE(8) MHX_CASE(10) MHX_CASE(12) MHX_CASE(14) MHX_CASE(16) MHX_CASE(18) MHX_CASE(20)
-#undef MHX_CASE
+      MHX_CASE(3) MHX_CASE(4) MHX_CASE(6) MHX_CASE(8) MHX_CASE(10) MHX_CASE(12) MHX_CASE(14) MHX_CASE(16) MHX_CASE(18) MHX_CASE(20)
       default: throw Error("read2sdbg_s1: unsupported record stride");
     }
+#undef MHX_CASE
   }
   if (n_words64 && mark_atomic)
     MHX_LAUNCH(c, "count_solid", (double)n_words64 * 8,
@@ -427,8 +461,9 @@ int s1_process(mhx_ctx *c, uint32_t k, uint32_t m, int want_mercy, uint32_t *buf
 
 int run_s1(mhx_ctx *c, uint32_t k, uint32_t m, int want_mercy, mhx_s1_result *out) {
   if (c->global_bases) throw Error("read2sdbg_s1: a global layout is set; use the mhx_dist_* entry points");
-  const uint64_t n_items = s1_extract(c, k);
-  const int S = round_up2(s1_kw(k) + 2);
+  const bool compact = s1_compact(c, want_mercy);
+  const uint64_t n_items = s1_extract(c, k, compact);
+  const int S = s1_stride(k, compact);
   uint32_t *buf_a = c->work["items_a"].as<uint32_t>();
   uint32_t *buf_b = c->ws("items_b", n_items * (size_t)S * 4 + 64).as<uint32_t>();
   return s1_process(c, k, m, want_mercy, buf_a, buf_b, n_items, out);

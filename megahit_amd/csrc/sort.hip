@@ -44,12 +44,15 @@ __device__ __forceinline__ void load_rec(const uint32_t *__restrict__ p, Rec<S> 
       uint4 v = reinterpret_cast<const uint4 *>(p)[i];
       r.w[4 * i] = v.x; r.w[4 * i + 1] = v.y; r.w[4 * i + 2] = v.z; r.w[4 * i + 3] = v.w;
     }
-  } else {
+  } else if constexpr (S % 2 == 0) {
 #pragma unroll
     for (int i = 0; i < S / 2; ++i) {
       uint2 v = reinterpret_cast<const uint2 *>(p)[i];
       r.w[2 * i] = v.x; r.w[2 * i + 1] = v.y;
     }
+  } else {  // odd strides (12-byte records): dword accesses, merged by the compiler where alignment allows
+#pragma unroll
+    for (int i = 0; i < S; ++i) r.w[i] = p[i];
   }
 }
 template <int S>
@@ -58,9 +61,12 @@ __device__ __forceinline__ void store_rec(uint32_t *__restrict__ p, const Rec<S>
 #pragma unroll
     for (int i = 0; i < S / 4; ++i)
       reinterpret_cast<uint4 *>(p)[i] = make_uint4(r.w[4 * i], r.w[4 * i + 1], r.w[4 * i + 2], r.w[4 * i + 3]);
-  } else {
+  } else if constexpr (S % 2 == 0) {
 #pragma unroll
     for (int i = 0; i < S / 2; ++i) reinterpret_cast<uint2 *>(p)[i] = make_uint2(r.w[2 * i], r.w[2 * i + 1]);
+  } else {
+#pragma unroll
+    for (int i = 0; i < S; ++i) p[i] = r.w[i];
   }
 }
 
@@ -128,6 +134,43 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_hist(const uint32_t *__r
   }
 }
 
+// Histogram of a pass from the 1-byte-per-record digit side array that the previous pass's scatter wrote
+// (same chunking and output layout as k_radix_hist, 1/8 .. 1/16 of its HBM traffic).
+template <int CHUNK>
+__global__ __launch_bounds__(kSortThreads) void k_radix_hist_bytes(const uint8_t *__restrict__ dig, uint64_t n, uint32_t *__restrict__ hist,
+                                                                   uint64_t n_chunks) {
+  __shared__ uint32_t h[kSortWaves][256];
+  for (int i = threadIdx.x; i < kSortWaves * 256; i += kSortThreads) (&h[0][0])[i] = 0;
+  __syncthreads();
+  const int w = threadIdx.x / kWave;
+  const uint64_t base = (uint64_t)blockIdx.x * CHUNK;
+  static_assert(CHUNK % 16 == 0, "chunk shape");
+  const uint64_t end = base + CHUNK < n ? base + CHUNK : n;
+  for (uint64_t idx = base + (uint64_t)threadIdx.x * 16; idx < end; idx += (uint64_t)kSortThreads * 16) {
+    if (idx + 16 <= end) {
+      const uint4 v = *reinterpret_cast<const uint4 *>(dig + idx);
+      const uint32_t x[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        atomicAdd(&h[w][x[q] & 255u], 1u);
+        atomicAdd(&h[w][(x[q] >> 8) & 255u], 1u);
+        atomicAdd(&h[w][(x[q] >> 16) & 255u], 1u);
+        atomicAdd(&h[w][x[q] >> 24], 1u);
+      }
+    } else {
+      for (uint64_t i = idx; i < end; ++i) atomicAdd(&h[w][dig[i]], 1u);
+    }
+  }
+  __syncthreads();
+  {
+    const int d = threadIdx.x;
+    uint32_t s = 0;
+#pragma unroll
+    for (int i = 0; i < kSortWaves; ++i) s += h[i][d];
+    hist[(uint64_t)d * n_chunks + blockIdx.x] = s;
+  }
+}
+
 // RANK_ATOMIC: rank inside a wavefront with one returning LDS atomic per record instead of the 8-ballot
 // match-any.  Stable only if the LDS serialises same-address lanes of one instruction in lane order;
 // libmhx verifies that on the device at start-up (probe_lds_atomic_order) before selecting it.
@@ -135,7 +178,8 @@ template <int S, int NI, bool RANK_ATOMIC>
 __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(const uint32_t *__restrict__ in, uint32_t *__restrict__ out, uint64_t n,
                                                                 DigitSpec ds, int nbits,
                                                                 const uint64_t *__restrict__ offs, uint64_t n_chunks,
-                                                                const uint8_t *__restrict__ lut) {
+                                                                const uint8_t *__restrict__ lut, DigitSpec ds_next,
+                                                                uint8_t *__restrict__ dnext) {
   using Cfg = SortCfg<S, NI>;
   constexpr int ITEMS = Cfg::kItems;
   __shared__ __attribute__((aligned(16))) uint32_t stage[Cfg::kTile * S];
@@ -238,6 +282,7 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(const uint32_t *
         // nbits < 0: timing experiment only (identity placement: same LDS work, perfectly coalesced stores)
         const uint64_t dst = nbits < 0 ? tile_base + li : (uint64_t)(g_off[d] + li);
         store_rec<S>(out + dst * S, r);
+        if (dnext) dnext[dst] = (uint8_t)rec_digit2<S>(r, ds_next);  // next pass's digit, read by k_radix_hist_bytes
       }
     }
     __syncthreads();
@@ -306,7 +351,7 @@ static uint32_t *radix_sort_impl2(mhx_ctx *c, uint32_t *a, uint32_t *b, uint64_t
   uint64_t *offs = c->ws("sort_offs", n_chunks * 256 * 8).as<uint64_t>();
   const double bytes = (double)n * S * 4;
   static const std::string nm_hist = "radix_hist_" + std::to_string(S * 4) + "B", nm_scat = "radix_scatter_" + std::to_string(S * 4) + "B";
-  for (const SortPass &ps : passes) {
+  auto spec_of = [&](const SortPass &ps) {
     DigitSpec ds{key_words - 1 - ps.shift / 32, (unsigned)(ps.shift % 32), (1u << ps.bits) - 1, 0, 0u, 0u, 0u};
     if (ps.bits2) {
       ds.wi2 = key_words - 1 - ps.shift2 / 32;
@@ -314,20 +359,36 @@ static uint32_t *radix_sort_impl2(mhx_ctx *c, uint32_t *a, uint32_t *b, uint64_t
       ds.mask2 = (1u << ps.bits2) - 1;
       ds.sh2 = (unsigned)ps.bits;
     }
+    return ds;
+  };
+  static const bool use_side = getenv("MHX_SORT_NO_SIDE_DIGITS") == nullptr;
+  uint8_t *dnext = use_side && passes.size() > 1 ? c->ws("sort_digits", n + 64).as<uint8_t>() : nullptr;
+  static const std::string nm_histb = "radix_hist_bytes";
+  for (size_t pi = 0; pi < passes.size(); ++pi) {
+    const SortPass &ps = passes[pi];
+    const DigitSpec ds = spec_of(ps);
+    const bool last = pi + 1 == passes.size();
+    const DigitSpec ds_next = last ? ds : spec_of(passes[pi + 1]);
     static const bool dbg_identity = getenv("MHX_DEBUG_IDENTITY_SCATTER") != nullptr;  // WRONG RESULTS: timing experiment
     const int nbits = dbg_identity ? -(ps.bits + ps.bits2) : ps.bits + ps.bits2;
-    MHX_LAUNCH(c, nm_hist.c_str(), bytes,
-               hipLaunchKernelGGL((k_radix_hist<S, NI>), dim3((unsigned)n_chunks), dim3(kSortThreads), 0, c->stream, a, n, ds,
-                                  hist, n_chunks, (const uint8_t *)nullptr));
-    exclusive_scan_u32_u64(c, hist, offs, n_chunks * 256, nullptr);
-    if (c->lds_atomic_ordered)
-      MHX_LAUNCH(c, nm_scat.c_str(), 2 * bytes,
-                 hipLaunchKernelGGL((k_radix_scatter<S, NI, true>), dim3((unsigned)n_chunks), dim3(kSortThreads), 0, c->stream, a, b, n, ds,
-                                    nbits, offs, n_chunks, (const uint8_t *)nullptr));
+    if (pi == 0 || !dnext)
+      MHX_LAUNCH(c, nm_hist.c_str(), bytes,
+                 hipLaunchKernelGGL((k_radix_hist<S, NI>), dim3((unsigned)n_chunks), dim3(kSortThreads), 0, c->stream, a, n, ds, hist,
+                                    n_chunks, (const uint8_t *)nullptr));
     else
-      MHX_LAUNCH(c, nm_scat.c_str(), 2 * bytes,
+      MHX_LAUNCH(c, nm_histb.c_str(), (double)n,
+                 hipLaunchKernelGGL((k_radix_hist_bytes<SortCfg<S, NI>::kChunk>), dim3((unsigned)n_chunks), dim3(kSortThreads), 0,
+                                    c->stream, dnext, n, hist, n_chunks));
+    exclusive_scan_u32_u64(c, hist, offs, n_chunks * 256, nullptr);
+    uint8_t *dn = last ? nullptr : dnext;
+    if (c->lds_atomic_ordered)
+      MHX_LAUNCH(c, nm_scat.c_str(), 2 * bytes + (dn ? (double)n : 0.0),
+                 hipLaunchKernelGGL((k_radix_scatter<S, NI, true>), dim3((unsigned)n_chunks), dim3(kSortThreads), 0, c->stream, a, b, n, ds,
+                                    nbits, offs, n_chunks, (const uint8_t *)nullptr, ds_next, dn));
+    else
+      MHX_LAUNCH(c, nm_scat.c_str(), 2 * bytes + (dn ? (double)n : 0.0),
                  hipLaunchKernelGGL((k_radix_scatter<S, NI, false>), dim3((unsigned)n_chunks), dim3(kSortThreads), 0, c->stream, a, b, n, ds,
-                                    nbits, offs, n_chunks, (const uint8_t *)nullptr));
+                                    nbits, offs, n_chunks, (const uint8_t *)nullptr, ds_next, dn));
     std::swap(a, b);
   }
   return a;
@@ -370,7 +431,7 @@ static void partition_impl(mhx_ctx *c, const uint32_t *a, uint32_t *b, uint64_t 
   exclusive_scan_u32_u64(c, hist, offs, n_chunks * 256, offs + n_chunks * 256);
   MHX_LAUNCH(c, "owner_scatter", 2 * bytes,
              hipLaunchKernelGGL((k_radix_scatter<S, default_items<S>(), false>), dim3((unsigned)n_chunks), dim3(kSortThreads), 0, c->stream, a, b, n, DigitSpec{0, 0u, 0xFFu, 0, 0u, 0u, 0u},
-                                nbits, offs, n_chunks, lut));
+                                nbits, offs, n_chunks, lut, DigitSpec{0, 0u, 0xFFu, 0, 0u, 0u, 0u}, (uint8_t *)nullptr));
   std::vector<uint64_t> starts(n_parts + 1);
   for (int p = 0; p <= n_parts; ++p)
     MHX_HIP(hipMemcpyAsync(&starts[p], offs + (uint64_t)p * n_chunks, 8, hipMemcpyDeviceToHost, c->stream));
@@ -383,6 +444,7 @@ void partition_by_owner(mhx_ctx *c, const uint32_t *a, uint32_t *b, uint64_t n, 
   if (n_parts > 256) throw Error("partition_by_owner: at most 256 owners");
   switch (stride) {
     case 2: return partition_impl<2>(c, a, b, n, lut, n_parts, counts);
+    case 3: return partition_impl<3>(c, a, b, n, lut, n_parts, counts);
     case 4: return partition_impl<4>(c, a, b, n, lut, n_parts, counts);
     case 6: return partition_impl<6>(c, a, b, n, lut, n_parts, counts);
     case 8: return partition_impl<8>(c, a, b, n, lut, n_parts, counts);
@@ -400,6 +462,7 @@ uint32_t *radix_sort(mhx_ctx *c, uint32_t *a, uint32_t *b, uint64_t n, int strid
                      const std::vector<SortPass> &passes) {
   switch (stride) {
     case 2: return radix_sort_impl<2>(c, a, b, n, key_words, passes);
+    case 3: return radix_sort_impl<3>(c, a, b, n, key_words, passes);
     case 4: return radix_sort_impl<4>(c, a, b, n, key_words, passes);
     case 6: return radix_sort_impl<6>(c, a, b, n, key_words, passes);
     case 8: return radix_sort_impl<8>(c, a, b, n, key_words, passes);

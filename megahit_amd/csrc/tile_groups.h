@@ -109,9 +109,12 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_groups(const uint32_t *__
     if constexpr (S % 4 == 0) {
 #pragma unroll
       for (int q = 0; q < S / 4; ++q) reinterpret_cast<uint4 *>(dst)[q] = reinterpret_cast<const uint4 *>(src)[q];
-    } else {
+    } else if constexpr (S % 2 == 0) {
 #pragma unroll
       for (int q = 0; q < S / 2; ++q) reinterpret_cast<uint2 *>(dst)[q] = reinterpret_cast<const uint2 *>(src)[q];
+    } else {
+#pragma unroll
+      for (int q = 0; q < S; ++q) dst[q] = src[q];
     }
   }
   __syncthreads();

@@ -72,10 +72,13 @@ class Exchanger:
 
     def exchange_items(self, send, send_counts, recv, recv_counts, item_bytes):
         """send/recv: uint8 tensors; counts in items."""
-        assert item_bytes % 8 == 0
-        q = item_bytes // 8
-        s64, r64 = send.view(torch.int64), recv.view(torch.int64)
-        dist.all_to_all_single(r64, s64, [int(c) * q for c in recv_counts], [int(c) * q for c in send_counts], group=self.group)
+        if item_bytes % 8 == 0:
+            q, dt = item_bytes // 8, torch.int64
+        else:  # 12-byte records (compact stage-1 items)
+            assert item_bytes % 4 == 0
+            q, dt = item_bytes // 4, torch.int32
+        dist.all_to_all_single(recv.view(dt), send.view(dt), [int(c) * q for c in recv_counts], [int(c) * q for c in send_counts],
+                               group=self.group)
 
     def sum_bitmap_and_take_slice(self, bitmap_i64, words_per_rank):
         """bitmap_i64: int64 tensor of world*words_per_rank words.  Returns this rank's summed slice."""

@@ -53,6 +53,22 @@ def test_read2sdbg_matches_oracle(engine, kind, k, m):
     check_sdbg(engine, r3, ob.s2(pkg, k, m, solid_want))
 
 
+@pytest.mark.parametrize("kind,k,m", CASES)
+def test_read2sdbg_s1_without_mercy_compact_records(engine, kind, k, m):
+    """want_mercy=False takes the compact-record path (12-byte stage-1 items at k <= 29)."""
+    reads = make_reads(kind, 6)
+    pkg = ob.Package(reads, reverse=True)
+    w1 = ob.s1(pkg, k, m, tie_stable=True)
+    load(engine, pkg)
+    r1 = engine.read2sdbg_s1(k, m, want_mercy=False)
+    assert r1.n_items == w1["n_items"] and r1.n_mercy_cand == 0
+    solid = engine.fetch(lib.BUF_IS_SOLID, np.uint64)
+    assert np.array_equal(solid, w1["is_solid"][: solid.size])
+    assert np.array_equal(engine.fetch(lib.BUF_MUL_HIST, np.int64), w1["hist"])
+    assert r1.n_solid == int(sum(bin(int(x)).count("1") for x in w1["is_solid"]))
+    check_sdbg(engine, engine.read2sdbg_s2(k, m), ob.s2(pkg, k, m, w1["is_solid"]))
+
+
 @pytest.mark.parametrize("kind,k", [("var", 21), ("lowcomplex", 27), ("fixed", 31)])
 def test_read2sdbg_min_count_1(engine, kind, k):
     reads = make_reads(kind, 9)
