@@ -361,7 +361,9 @@ static uint32_t *radix_sort_impl2(mhx_ctx *c, uint32_t *a, uint32_t *b, uint64_t
     }
     return ds;
   };
-  static const bool use_side = getenv("MHX_SORT_NO_SIDE_DIGITS") == nullptr;
+  // MHX_SORT_SIDE_DIGITS=1: scatter also writes the next pass's digit per record (1 B) so that the next histogram reads
+  // bytes instead of records.  Measured on MI355X: histograms 52 -> 17 ms/step but scatter +33 ms/step: off by default.
+  static const bool use_side = getenv("MHX_SORT_SIDE_DIGITS") != nullptr;
   uint8_t *dnext = use_side && passes.size() > 1 ? c->ws("sort_digits", n + 64).as<uint8_t>() : nullptr;
   static const std::string nm_histb = "radix_hist_bytes";
   for (size_t pi = 0; pi < passes.size(); ++pi) {
@@ -381,13 +383,14 @@ static uint32_t *radix_sort_impl2(mhx_ctx *c, uint32_t *a, uint32_t *b, uint64_t
                                     c->stream, dnext, n, hist, n_chunks));
     exclusive_scan_u32_u64(c, hist, offs, n_chunks * 256, nullptr);
     uint8_t *dn = last ? nullptr : dnext;
+    static const unsigned lds_pad = getenv("MHX_SORT_LDS_PAD") ? (unsigned)atoi(getenv("MHX_SORT_LDS_PAD")) : 0u;  // occupancy experiment
     if (c->lds_atomic_ordered)
       MHX_LAUNCH(c, nm_scat.c_str(), 2 * bytes + (dn ? (double)n : 0.0),
-                 hipLaunchKernelGGL((k_radix_scatter<S, NI, true>), dim3((unsigned)n_chunks), dim3(kSortThreads), 0, c->stream, a, b, n, ds,
+                 hipLaunchKernelGGL((k_radix_scatter<S, NI, true>), dim3((unsigned)n_chunks), dim3(kSortThreads), lds_pad, c->stream, a, b, n, ds,
                                     nbits, offs, n_chunks, (const uint8_t *)nullptr, ds_next, dn));
     else
       MHX_LAUNCH(c, nm_scat.c_str(), 2 * bytes + (dn ? (double)n : 0.0),
-                 hipLaunchKernelGGL((k_radix_scatter<S, NI, false>), dim3((unsigned)n_chunks), dim3(kSortThreads), 0, c->stream, a, b, n, ds,
+                 hipLaunchKernelGGL((k_radix_scatter<S, NI, false>), dim3((unsigned)n_chunks), dim3(kSortThreads), lds_pad, c->stream, a, b, n, ds,
                                     nbits, offs, n_chunks, (const uint8_t *)nullptr, ds_next, dn));
     std::swap(a, b);
   }
