@@ -110,8 +110,9 @@ typedef struct {
   uint32_t item_words;
 } mhx_s1_result;
 /* Read2SdbgS1::Run (read_to_sdbg_s1.cpp:88-566).  Fills IS_SOLID, MUL_HIST and, when
- * want_mercy != 0, MERCY_CAND.  Tie order between equal keys is the stable one
- * (first item = first in read order); see DESIGN.md "H1". */
+ * want_mercy != 0, MERCY_CAND.  want_mercy: 0 = no candidates; 1 = candidates with the stable tie order
+ * (a group's first item = first in read order); 2 = candidates with the reference's exact tie order
+ * (kmlib::kmsort's unstable permutation replayed per lv1 bucket; slower) — see DESIGN.md "H1". */
 int mhx_read2sdbg_s1(mhx_ctx *, uint32_t k, uint32_t min_count, int want_mercy, mhx_s1_result *out);
 
 /* mercy block of Read2SdbgS2::Initialize (read_to_sdbg_s2.cpp:122-266): consumes MERCY_CAND,

@@ -224,7 +224,10 @@ int main_read2sdbg(int argc, char **argv) {
        (unsigned long long)mhx_num_bases(c), t.lap());
   if (m > 1) {  // stage 1 is skipped when every edge is solid (main_sdbg_build.cpp:139-147)
     mhx_s1_result r1;
-    CK(mhx_read2sdbg_s1(c, k, m, need_mercy ? 1 : 0, &r1));
+    // --need_mercy: reproduce the reference's kmsort tie order (bit-identical mercy edges); MHX_STABLE_TIES=1
+    // selects the faster stable order instead (DESIGN.md "H1")
+    const int mercy_mode = !need_mercy ? 0 : (getenv("MHX_STABLE_TIES") ? 1 : 2);
+    CK(mhx_read2sdbg_s1(c, k, m, mercy_mode, &r1));
     auto hist = fetch<int64_t>(c, MHX_BUF_MUL_HIST);
     int64_t n_solid_edges = 0;
     for (uint32_t i = m; i <= 65535; ++i) n_solid_edges += hist[i];

@@ -125,6 +125,8 @@ uint32_t *radix_sort(mhx_ctx *c, uint32_t *buf_a, uint32_t *buf_b, uint64_t n, i
                      const std::vector<SortPass> &passes);
 std::vector<SortPass> make_passes(int key_words, int lo_bit, int hi_bit);
 bool probe_lds_atomic_order(mhx_ctx *c);
+// kmsort_emu.hip: sort with the reference's exact (unstable) tie order, one GPU thread per lv1 bucket
+uint32_t *kmsort_exact(mhx_ctx *c, uint32_t *buf_a, uint32_t *buf_b, uint64_t n, int S, int key_words);
 
 // ---- scan.hip ----
 // exclusive scan of n uint32 values into uint64 (in != out); returns total via d_total (device, uint64[1])

@@ -374,7 +374,10 @@ int s1_process(mhx_ctx *c, uint32_t k, uint32_t m, int want_mercy, uint32_t *buf
   const bool global = c->global_bases != 0;  // multi-GPU: positions index the global read set
   if (global && want_mercy) throw Error("read2sdbg_s1: mercy candidates are not supported in multi-GPU mode");
   const int kmer_bits = (int)(k - 1) * 2;
-  uint32_t *sorted = radix_sort(c, buf_a, buf_b, n_items, S, KWv, make_passes_ranges(KWv, {{0, 6}, {KWv * 32 - kmer_bits, KWv * 32}}));
+  // want_mercy == 2: records with equal keys in exactly the order the reference's kmsort leaves them (H1)
+  uint32_t *sorted = want_mercy == 2
+                         ? kmsort_exact(c, buf_a, buf_b, n_items, S, KWv)
+                         : radix_sort(c, buf_a, buf_b, n_items, S, KWv, make_passes_ranges(KWv, {{0, 6}, {KWv * 32 - kmer_bits, KWv * 32}}));
   uint32_t *spare = sorted == buf_a ? buf_b : buf_a;
 
   const uint64_t n_bits = global ? c->global_bases : s.n_bases;

@@ -190,6 +190,7 @@ class Engine:
         return r
 
     def read2sdbg_s1(self, k, m, want_mercy=False):
+        """want_mercy: False/0 none, True/1 stable tie order, 2 reference-exact (kmsort) tie order."""
         r = S1Result()
         self._chk(self.lib.mhx_read2sdbg_s1(self.h, k, m, int(want_mercy), C.byref(r)))
         return r

@@ -9,19 +9,23 @@ import golden_util as gu
 pytestmark = pytest.mark.gpu
 
 
+@pytest.mark.parametrize("ent", [e for e in gu.cases() if e["case"]["prog"] == "read2sdbg" and e["case"].get("mercy")][:3], ids=gu.case_id)
+def test_cli_stable_tie_mode_matches_oracle_stable(ent, tmp_path, monkeypatch):
+    """MHX_STABLE_TIES=1 (the fast mode): equality with the oracle in stable-tie mode."""
+    monkeypatch.setenv("MHX_STABLE_TIES", "1")
+    got = gu.run_case(gu.MHX_CORE, ent, str(tmp_path))
+    gu.ensure_oracle()
+    os.makedirs(str(tmp_path / "o"), exist_ok=True)
+    want = gu.run_case(gu.ORACLE_CORE, ent, str(tmp_path / "o"), extra=["--tie", "stable"])
+    assert got["sdbg"] == want["sdbg"] and got["n_sdbg"] == want["n_sdbg"]
+
+
 @pytest.mark.parametrize("ent", gu.cases(), ids=gu.case_id)
 def test_cli_reproduces_reference(ent, tmp_path):
     assert os.path.exists(gu.MHX_CORE), "mhx_core not built"
     c = ent["case"]
     got = gu.run_case(gu.MHX_CORE, ent, str(tmp_path))
-    if c["prog"] == "read2sdbg" and c.get("mercy"):
-        # H1: with --need_mercy the reference's result depends on kmsort's unstable tie order; the GPU
-        # sort is stable, so the contract is equality with the oracle in stable-tie mode.
-        gu.ensure_oracle()
-        os.makedirs(str(tmp_path / "o"), exist_ok=True)
-        want = gu.run_case(gu.ORACLE_CORE, ent, str(tmp_path / "o"), extra=["--tie", "stable"])
-        assert got["sdbg"] == want["sdbg"] and got["n_sdbg"] == want["n_sdbg"]
-        return
+    # read2sdbg --need_mercy included: the CLI replays kmsort's tie order (H1), so it matches the reference too
     for key, want in ent.items():
         if key in ("case", "mercy_cand_kmsort"):
             continue

@@ -53,6 +53,24 @@ def test_read2sdbg_matches_oracle(engine, kind, k, m):
     check_sdbg(engine, r3, ob.s2(pkg, k, m, solid_want))
 
 
+@pytest.mark.parametrize("kind,k,m", [("fixed", 21, 2), ("var", 21, 2), ("lowcomplex", 21, 2), ("var", 27, 3), ("var", 47, 2)])
+def test_read2sdbg_reference_exact_tie_order(engine, kind, k, m):
+    """want_mercy=2 replays kmlib::kmsort per bucket: mercy candidates equal the oracle's kmsort mode, which is
+    pinned to the reference (H1).  'fixed' and 'lowcomplex' have buckets far larger than 64 records."""
+    reads = make_reads(kind, 5)
+    pkg = ob.Package(reads, reverse=True)
+    w1 = ob.s1(pkg, k, m, tie_stable=False)
+    load(engine, pkg)
+    r1 = engine.read2sdbg_s1(k, m, want_mercy=2)
+    assert r1.n_items == w1["n_items"]
+    assert np.array_equal(engine.fetch(lib.BUF_MERCY_CAND, np.int64), w1["mercy"])
+    solid = engine.fetch(lib.BUF_IS_SOLID, np.uint64)
+    assert np.array_equal(solid, w1["is_solid"][: solid.size])
+    n_want, solid_want = ob.s2_add_mercy(pkg, k, w1["is_solid"], w1["mercy"])
+    assert engine.read2sdbg_add_mercy(k) == n_want
+    check_sdbg(engine, engine.read2sdbg_s2(k, m), ob.s2(pkg, k, m, solid_want))
+
+
 @pytest.mark.parametrize("kind,k,m", CASES)
 def test_read2sdbg_s1_without_mercy_compact_records(engine, kind, k, m):
     """want_mercy=False takes the compact-record path (12-byte stage-1 items at k <= 29)."""
