@@ -102,6 +102,7 @@ void upload_sequences(mhx_ctx *c, const uint32_t *packed, uint64_t n_words, uint
                       const uint64_t *start_pos) {
   SeqSet &s = c->seqs;
   hipStream_t st = c->stream;
+  c->agg_valid = false;
   s.n_seqs = n_seqs;
   s.fixed_len = start_pos ? 0 : fixed_len;
   s.n_words = n_words;
@@ -165,6 +166,7 @@ void append_sequences(mhx_ctx *c, const uint32_t *packed, uint64_t n_words, uint
                       const uint16_t *mult) {
   SeqSet &s = c->seqs;
   hipStream_t st = c->stream;
+  c->agg_valid = false;
   if (n_new == 0) return;
   const uint64_t add_bases = start_pos ? start_pos[n_new] : n_new * (uint64_t)fixed_len;
   if (add_bases > n_words * 16) throw Error("append_sequences: start_pos/n_seqs exceed the packed buffer");
@@ -242,6 +244,7 @@ __global__ void k_unpack_records(const uint32_t *__restrict__ rec, const uint64_
 }
 
 void upload_bin_records(mhx_ctx *c, const uint32_t *records, uint64_t n_words, uint64_t n_seqs, int reverse) {
+  c->agg_valid = false;
   // lengths (host): an empty read becomes a 1-base 'A' (sequence_package.h:275-281)
   std::vector<uint64_t> rec_off(n_seqs + 1), start(n_seqs + 1);
   uint64_t pos = 0, bases = 0;
@@ -456,6 +459,7 @@ int mhx_set_is_solid(mhx_ctx *c, const uint64_t *bits, uint64_t n_words) {
   MHX_TRY({
     uint64_t need = mhx::div_ceil(c->seqs.n_bases, 64);
     if (n_words < need) throw mhx::Error("set_is_solid: bitmap too short");
+    c->agg_valid = false;
     mhx::DevBuf &b = c->result(MHX_BUF_IS_SOLID, (need + 1) * 8);
     b.used = need * 8;
     if (need) MHX_HIP(hipMemcpyAsync(b.p, bits, need * 8, hipMemcpyHostToDevice, c->stream));

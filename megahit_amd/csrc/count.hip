@@ -99,7 +99,7 @@ __device__ __forceinline__ uint8_t *count_run_mark() {
 // A run is a whole group here (all records of a (k+1)-mer).
 template <int S>
 struct CountOp {
-  static constexpr bool kItemPhase = true, kItemFinal = true, kRunPhase = false, kUnitIsRun = false;
+  static constexpr bool kItemPhase = true, kItemFinal = true, kRunPhase = false, kUnitIsRun = false, kAtomicBase = false;
   __device__ void run_phase(const TileCtx<S> &, uint32_t, uint32_t) const {}
   int kw, wpe;
   uint32_t m;

@@ -58,6 +58,7 @@ __global__ __launch_bounds__(256) void k_s1_mercy(const long long *__restrict__ 
 
 int run_s1_mercy(mhx_ctx *c, uint32_t k, uint64_t *num_mercy) {
   SeqSet &s = c->seqs;
+  c->agg_valid = false;  // mercy turns non-solid occurrences solid: stage 2 must look at every occurrence again
   hipStream_t st = c->stream;
   auto itc = c->results.find(MHX_BUF_MERCY_CAND);
   auto its = c->results.find(MHX_BUF_IS_SOLID);

@@ -79,6 +79,11 @@ struct mhx_ctx {
   // the LDS applies same-address lanes of one returning atomic in lane order (probed at mhx_create):
   // lets the radix scatter rank records with one ds_add_rtn instead of an 8-ballot match-any
   bool lds_atomic_ordered = false;
+  // stage-2 items aggregated by stage 1 (ws "s2_agg_items"): valid for one (k, m) until the reads or the
+  // is_solid bitmap change
+  bool agg_valid = false;
+  uint32_t agg_k = 0, agg_m = 0;
+  uint64_t agg_n = 0;
   // profiling
   bool profiling = false;
   std::vector<mhx::PendingEvent> pending;

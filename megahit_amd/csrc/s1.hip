@@ -129,10 +129,23 @@ __device__ __forceinline__ uint32_t *s1_run_info() {  // bit0 solid | has_in<<1 
 // Lv2Postprocess of Read2SdbgS1 (read_to_sdbg_s1.cpp:368-555) as a tile operator (tile_groups.h):
 // run = records of one (k-1)-mer with the same (head,tail); the per-group logic iterates runs, the
 // per-record actions (is_solid bits, mercy candidates) are item-parallel.  No ordered output.
-template <int S, bool COMPACT>
+// 64-bit helpers for the aggregated stage-2 items (k <= 22: a (k+1)-mer and the 20 flag/W/count bits fit 64 bits)
+__device__ __forceinline__ uint64_t rc64(uint64_t x, int n) {  // reverse complement of the n chars in the top 2n bits
+  uint64_t r = __builtin_bitreverse64(x);
+  r = ((r >> 1) & 0x5555555555555555ull) | ((r & 0x5555555555555555ull) << 1);
+  return (~r) << (64 - 2 * n);
+}
+
+// AGG: besides marking, every solid (head,S,tail) run emits the stage-2 items of its (k+1)-mer ONCE, with the
+// run length as multiplicity, instead of stage 2 emitting them once per occurrence (read_to_sdbg_s2.cpp:398-409
+// emits "solid" items per occurrence and Lv2Postprocess :579 counts them again): same records, ~8x fewer items
+// to sort.  Item = seq2sdbg layout (k chars | full<<19 | W<<16 | count).
+template <int S, bool COMPACT, bool AGG>
 struct S1Op {
-  static constexpr bool kItemPhase = false, kItemFinal = true, kRunPhase = false, kUnitIsRun = false;
+  static constexpr bool kItemPhase = false, kItemFinal = true, kRunPhase = false, kUnitIsRun = false, kAtomicBase = AGG;
   __device__ void run_phase(const TileCtx<S> &, uint32_t, uint32_t) const {}
+  int k;
+  uint2 *agg_items;
   int kw;
   uint32_t m;
   const uint64_t *start;
@@ -162,7 +175,32 @@ struct S1Op {
       if (lh[i]) atomicAdd(&hist[i], (unsigned long long)lh[i]);
     (void)n_solid_out;  // counted by k_pack_solid
   }
-  __device__ void unit_emit(const TileCtx<S> &, uint32_t, uint64_t, uint64_t, uint64_t) const {}
+  // the (k+1)-mer head.S.tail of a run, chars MSB-first in 64 bits
+  __device__ __forceinline__ uint64_t edge_of(const TileCtx<S> &c, uint32_t i, unsigned h, unsigned t) const {
+    const uint64_t key = ((uint64_t)c.acc.word(i, 0) << 32) | c.acc.word(i, 1);
+    const uint64_t smer = key & (~0ull << (64 - 2 * (k - 1)));  // the (k-1)-mer, head/tail bits dropped
+    return ((uint64_t)h << 62) | (smer >> 2) | ((uint64_t)t << (62 - 2 * k));
+  }
+  __device__ void unit_emit(const TileCtx<S> &c, uint32_t g, uint64_t o0, uint64_t, uint64_t) const {
+    if constexpr (AGG) {
+      const uint32_t r0 = c.gpos[g], r1 = c.gpos[g + 1];
+      const uint64_t mask_k = ~0ull << (64 - 2 * k);
+      for (uint32_t r = r0; r < r1; ++r) {
+        if (!(s1_run_info<S>()[r] & 1u)) continue;
+        const uint32_t i = c.run_start(r);
+        const unsigned ht = c.acc.word(i, kw - 1) & 63u, h = ht >> 3, t = ht & 7;
+        const uint32_t n = c.run_len(r);
+        const uint64_t cnt = n > MHX_MAX_MUL ? (uint64_t)MHX_MAX_MUL : n;
+        const uint64_t x = edge_of(c, i, h, t), xr = rc64(x, k + 1);
+        const uint64_t f = ((x << 2) & mask_k) | (1ull << 19) | ((x >> 62) << 16) | cnt;   // k-mer x[1..k], W = x[0]
+        agg_items[o0++] = make_uint2((uint32_t)(f >> 32), (uint32_t)f);
+        if (x != xr) {  // palindromic (k+1)-mers emit the forward item only (:385-423)
+          const uint64_t b = ((xr << 2) & mask_k) | (1ull << 19) | ((xr >> 62) << 16) | cnt;
+          agg_items[o0++] = make_uint2((uint32_t)(b >> 32), (uint32_t)b);
+        }
+      }
+    }
+  }
   __device__ GroupCounts unit_count(const TileCtx<S> &c, uint32_t g) const {
     const uint32_t r0 = c.gpos[g], r1 = c.gpos[g + 1];
     // H1: prev/next of the group's FIRST item, :399 (compact records carry none: only mercy needs has_in/has_out)
@@ -195,6 +233,7 @@ struct S1Op {
     }
     const uint32_t masks = (has_in << 1) | (has_out << 5) | (l_has_out << 9) | (r_has_in << 13);
     unsigned long long my_solid = 0;
+    uint32_t n_agg = 0;
     for (uint32_t r = r0; r < r1; ++r) {
       const unsigned ht = c.acc.word(c.run_start(r), kw - 1) & 63u, h = ht >> 3, t = ht & 7;
       const uint32_t n = c.run_len(r);
@@ -207,9 +246,17 @@ struct S1Op {
       const bool solid = both && n >= m;
       if (solid) my_solid += n;
       s1_run_info<S>()[r] = masks | (solid ? 1u : 0u);
+      if constexpr (AGG) {
+        if (solid) {
+          const uint64_t x = edge_of(c, c.run_start(r), h, t);
+          n_agg += x == rc64(x, k + 1) ? 1u : 2u;
+        }
+      }
     }
     (void)my_solid;
-    return GroupCounts();
+    GroupCounts gc;
+    gc.c0 = n_agg;
+    return gc;
   }
   __device__ void item_final(const TileCtx<S> &c, uint32_t rel, uint32_t run) const {
     const uint32_t ri = s1_run_info<S>()[run];
@@ -287,19 +334,24 @@ __global__ __launch_bounds__(256) void k_count_solid(const unsigned long long *_
   if (threadIdx.x == 0 && tot) atomicAdd(n_solid, (unsigned long long)tot);
 }
 
-template <int S, bool COMPACT>
+template <int S, bool COMPACT, bool AGG>
 static void s1_groups_launch(mhx_ctx *c, const uint32_t *sorted, uint64_t n_items, int KWv, int kmer_bits, uint32_t m,
                              uint8_t *is_solid, unsigned long long *solid_bits, int mark_atomic, unsigned long long *hist, unsigned long long *ctr, int want_mercy,
-                             long long *mercy) {
+                             long long *mercy, int k, uint2 *agg_items, uint64_t *agg_cursor) {
   SeqSet &s = c->seqs;
   constexpr int T = S1Tile<S>::kT;
   const uint64_t n_tiles = div_ceil(n_items, T);
   const int full_words = kmer_bits / 32, rem = kmer_bits % 32;
   const uint32_t last_mask = rem ? 0xFFFFFFFFu << (32 - rem) : 0;
-  S1Op<S, COMPACT> op{KWv, m, s.start.as<uint64_t>(), s.n_seqs, s.fixed_len, is_solid, solid_bits, mark_atomic, hist, ctr, want_mercy, mercy, ctr + 1};
-  MHX_LAUNCH(c, "s1_groups", (double)n_items * S * 4,
-             hipLaunchKernelGGL((k_tile_groups<S, T, S1Op<S, COMPACT>, false>), dim3((unsigned)n_tiles), dim3(kTileThreads), 0, c->stream, sorted,
-                                n_items, full_words, last_mask, op, (uint64_t *)nullptr, (const uint64_t *)nullptr, n_tiles));
+  S1Op<S, COMPACT, AGG> op{k, agg_items, KWv, m, s.start.as<uint64_t>(), s.n_seqs, s.fixed_len, is_solid, solid_bits, mark_atomic, hist, ctr, want_mercy, mercy, ctr + 1};
+  if constexpr (AGG)
+    MHX_LAUNCH(c, "s1_groups", (double)n_items * S * 4,
+               hipLaunchKernelGGL((k_tile_groups<S, T, S1Op<S, COMPACT, true>, true>), dim3((unsigned)n_tiles), dim3(kTileThreads), 0, c->stream,
+                                  sorted, n_items, full_words, last_mask, op, agg_cursor, (const uint64_t *)nullptr, n_tiles));
+  else
+    MHX_LAUNCH(c, "s1_groups", (double)n_items * S * 4,
+               hipLaunchKernelGGL((k_tile_groups<S, T, S1Op<S, COMPACT, false>, false>), dim3((unsigned)n_tiles), dim3(kTileThreads), 0, c->stream,
+                                  sorted, n_items, full_words, last_mask, op, (uint64_t *)nullptr, (const uint64_t *)nullptr, n_tiles));
 }
 
 // int64 <-> (hi,lo) word pairs so that the big-endian record sort orders them numerically
@@ -403,17 +455,37 @@ int s1_process(mhx_ctx *c, uint32_t k, uint32_t m, int want_mercy, uint32_t *buf
   uint64_t n_solid = 0, n_mercy = 0;
   // mercy candidates (<= 2 per item, 8 B each) go to the spare sort buffer: S*4 >= 16 bytes per item
   long long *mercy = reinterpret_cast<long long *>(spare);
+  // aggregated stage-2 items (k <= 22, m >= 2): at most 2 per solid run, a solid run has >= m records
+  static const bool agg_off = getenv("MHX_S2_PER_OCCURRENCE") != nullptr;
+  const bool agg = !agg_off && !global && k <= 22 && m >= 2 && KWv == 2;
+  c->agg_valid = false;
+  uint2 *agg_items = nullptr;
+  uint64_t *agg_cursor = c->ws("s2_agg_cursor", 64).as<uint64_t>();
+  if (agg) {
+    agg_items = c->ws("s2_agg_items", (n_items / m + 16) * 2 * 8).as<uint2>();
+    MHX_HIP(hipMemsetAsync(agg_cursor, 0, 24, st));
+  }
   if (n_items) {
-#define MHX_CASE(SV)                                                                                                            \
-  case SV:                                                                                                                      \
-    if (compact) s1_groups_launch<SV, true>(c, sorted, n_items, KWv, kmer_bits, m, solid_bytes, is_solid, mark_atomic, hist, ctr, 0, mercy); \
-    else s1_groups_launch<SV, false>(c, sorted, n_items, KWv, kmer_bits, m, solid_bytes, is_solid, mark_atomic, hist, ctr, want_mercy, mercy); \
+#define MHX_ARGS(WM) c, sorted, n_items, KWv, kmer_bits, m, solid_bytes, is_solid, mark_atomic, hist, ctr, WM, mercy, (int)k, agg_items, agg_cursor
+#define MHX_CASE(SV)                                                          \
+  case SV:                                                                    \
+    if (compact) s1_groups_launch<SV, true, false>(MHX_ARGS(0));              \
+    else s1_groups_launch<SV, false, false>(MHX_ARGS(want_mercy));            \
     break;
-    switch (S) {
+    if (agg && S == 3) s1_groups_launch<3, true, true>(MHX_ARGS(0));
+    else if (agg && S == 4 && !compact) s1_groups_launch<4, false, true>(MHX_ARGS(want_mercy));
+    else switch (S) {
       MHX_CASE(3) MHX_CASE(4) MHX_CASE(6) MHX_CASE(8) MHX_CASE(10) MHX_CASE(12) MHX_CASE(14) MHX_CASE(16) MHX_CASE(18) MHX_CASE(20)
       default: throw Error("read2sdbg_s1: unsupported record stride");
     }
 #undef MHX_CASE
+#undef MHX_ARGS
+    if (agg && (S == 3 || (S == 4 && !compact))) {
+      MHX_HIP(hipMemcpyAsync(&c->agg_n, agg_cursor, 8, hipMemcpyDeviceToHost, st));
+      c->agg_valid = true;
+      c->agg_k = k;
+      c->agg_m = m;
+    }
   }
   if (n_words64 && mark_atomic)
     MHX_LAUNCH(c, "count_solid", (double)n_words64 * 8,

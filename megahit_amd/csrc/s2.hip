@@ -170,6 +170,96 @@ __global__ __launch_bounds__(256) void k_s2_extract(const uint32_t *__restrict__
 }
 
 // ---------------------------------------------------------------------------
+// Aggregated stage 2 (k <= 22, m >= 2): the "solid" items come from stage 1 with their multiplicity
+// (s1.hip, S1Op<AGG>); only the $-dummy items (types 0 and 2 of EncodeOffset) still have to be produced per
+// occurrence.  Same seq2sdbg-style layout, count field = 1.  64-bit arithmetic: k+1 <= 23 chars.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t rc64_s2(uint64_t x, int n) {
+  uint64_t r = __builtin_bitreverse64(x);
+  r = ((r >> 1) & 0x5555555555555555ull) | ((r & 0x5555555555555555ull) << 1);
+  return (~r) << (64 - 2 * n);
+}
+// dummies of the occurrence at read offset p: bit0 left pair, bit1 right pair, bit2 palindrome; returns their number
+__device__ __forceinline__ unsigned s2d_items_at(const uint32_t *__restrict__ seq, const unsigned long long *__restrict__ solid, uint64_t st,
+                                                 uint32_t L, uint32_t p, int k, unsigned *mask, uint64_t *e_out) {
+  const uint64_t fo = st + p;
+  if (!bit_at(solid, fo)) return 0;
+  const bool left = p == 0 || !bit_at(solid, fo - 1);
+  const bool right = p + k + 1 == L || !bit_at(solid, fo + 1);
+  if (!left && !right) return 0;
+  uint32_t w[2];
+  load_chars<2>(seq, fo, k + 1, w);
+  const uint64_t e = ((uint64_t)w[0] << 32) | w[1];
+  const bool pal = e == rc64_s2(e, k + 1);
+  *e_out = e;
+  *mask = (left ? 1u : 0u) | (right ? 2u : 0u) | (pal ? 4u : 0u);
+  return ((left ? 1u : 0u) + (right ? 1u : 0u)) * (pal ? 1u : 2u);
+}
+
+__global__ __launch_bounds__(256) void k_s2d_count(const uint32_t *__restrict__ seq, const uint64_t *__restrict__ start, uint64_t n_seqs, int k,
+                                                   const unsigned long long *__restrict__ solid, uint32_t *__restrict__ cnt) {
+  const int lane = lane_id();
+  const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / kWave;
+  const uint64_t n_waves = (uint64_t)gridDim.x * blockDim.x / kWave;
+  for (uint64_t r = wave; r < n_seqs; r += n_waves) {
+    const uint64_t st = start[r];
+    const uint32_t L = (uint32_t)(start[r + 1] - st);
+    uint32_t total = 0;
+    if (L >= (uint32_t)k + 1) {
+      for (uint32_t p0 = 0; p0 < L - k; p0 += kWave) {
+        const uint32_t p = p0 + lane;
+        unsigned mask, c = 0;
+        uint64_t e;
+        if (p < L - k) c = s2d_items_at(seq, solid, st, L, p, k, &mask, &e);
+        total += wave_sum<uint32_t>(c);
+      }
+    }
+    if (lane == 0) cnt[r] = total;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_s2d_extract(const uint32_t *__restrict__ seq, const uint64_t *__restrict__ start,
+                                                     const uint64_t *__restrict__ item_start, uint64_t n_seqs, int k,
+                                                     const unsigned long long *__restrict__ solid, uint2 *__restrict__ items) {
+  const int lane = lane_id();
+  const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / kWave;
+  const uint64_t n_waves = (uint64_t)gridDim.x * blockDim.x / kWave;
+  const uint64_t mask_k = ~0ull << (64 - 2 * k), mask_k1 = ~0ull << (64 - 2 * (k - 1));
+  for (uint64_t r = wave; r < n_seqs; r += n_waves) {
+    const uint64_t st = start[r];
+    const uint32_t L = (uint32_t)(start[r + 1] - st);
+    if (L < (uint32_t)k + 1) continue;
+    uint64_t carry = item_start[r];
+    for (uint32_t p0 = 0; p0 < L - k; p0 += kWave) {
+      const uint32_t p = p0 + lane;
+      unsigned mask = 0, c = 0;
+      uint64_t e = 0;
+      if (p < L - k) c = s2d_items_at(seq, solid, st, L, p, k, &mask, &e);
+      const uint32_t inc = wave_inclusive_sum<uint32_t>(c);
+      const uint32_t tot = __shfl(inc, kWave - 1, kWave);
+      if (c) {
+        uint2 *dst = items + (carry + inc - c);
+        const bool pal = mask & 4u;
+        const uint64_t er = rc64_s2(e, k + 1);
+        auto put = [&](uint64_t key, uint64_t full, uint64_t w) {
+          const uint64_t v = key | (full << 19) | (w << 16) | 1ull;
+          *dst++ = make_uint2((uint32_t)(v >> 32), (uint32_t)v);
+        };
+        if (mask & 1u) {                                                     // left-$ (read_to_sdbg_s2.cpp:387-396, :457-512)
+          put(e & mask_k, 1, kSentinel);                                     //   fwd: e[0..k-1], W = $
+          if (!pal) put((er << 4) & mask_k1, 0, (er >> 60) & 3u);            //   rc : e'[2..k],  W = e'[1]
+        }
+        if (mask & 2u) {                                                     // right-$ (:411-425)
+          put((e << 4) & mask_k1, 0, (e >> 60) & 3u);                        //   fwd: e[2..k],   W = e[1]
+          if (!pal) put(er & mask_k, 1, kSentinel);                          //   rc : e'[0..k-1], W = $
+        }
+      }
+      carry += tot;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
 // SdBG emission (shared)
 // ---------------------------------------------------------------------------
 struct SdbgParams {
@@ -177,7 +267,8 @@ struct SdbgParams {
   int bshift, fshift;  // W char / "full k chars" flag position in the last key word
   int aw, ashift;      // word and shift of the k-th char
   int wpt;             // words per tip label
-  int is_seq;          // multiplicity comes from the key (seq2sdbg) instead of the run length (S2)
+  int is_seq;          // 0: S2 (multiplicity = run length); 1: seq2sdbg (65535 - key field); 2: aggregated S2 (sum of counts)
+  int ref_kw;          // key words of the reference's stage-2 item, ceil((2k+4)/32) (tip-label reconstruction)
 };
 
 template <int S>
@@ -205,7 +296,7 @@ constexpr unsigned long long kNoStart = ~0ull;
 // only ever look at (a, b), so they are restated over the <= 25 runs of a group.
 template <int S>
 struct SdbgOp {
-  static constexpr bool kItemPhase = false, kItemFinal = false, kRunPhase = true, kUnitIsRun = true;
+  static constexpr bool kItemPhase = false, kItemFinal = false, kRunPhase = true, kUnitIsRun = true, kAtomicBase = false;
   SdbgParams P;
   uint16_t *out16;
   unsigned long long *w_count;
@@ -261,6 +352,12 @@ struct SdbgOp {
     return true;
   }
   __device__ __forceinline__ uint32_t run_mul(const TileCtx<S> &c, uint32_t r, uint32_t i) const {
+    if (P.is_seq == 2) {  // pre-aggregated stage-2 items: multiplicity = sum of the items' counts
+      const uint32_t e = i + c.run_len(r);
+      uint64_t sum = 0;
+      for (uint32_t j = i; j < e && sum < MHX_MAX_MUL; ++j) sum += c.acc.word(j, P.kw - 1) & 0xFFFFu;
+      return sum > MHX_MAX_MUL ? (uint32_t)MHX_MAX_MUL : (uint32_t)sum;
+    }
     if (P.is_seq) return MHX_MAX_MUL - (c.acc.word(i, P.kw - 1) & 0xFFFFu);  // seq_to_sdbg.cpp:782-785
     const uint32_t n = c.run_len(r);                                         // read_to_sdbg_s2.cpp:579
     return n > (uint32_t)MHX_MAX_MUL ? (uint32_t)MHX_MAX_MUL : n;
@@ -305,7 +402,15 @@ struct SdbgOp {
     if (mul > 254) out16[o16++] = (uint16_t)mul;
     if (tip) {
       for (int x = 0; x < P.wpt; ++x) {
-        const uint32_t v = c.acc.word(i, x);
+        uint32_t v = c.acc.word(i, x);
+        if (P.is_seq == 2 && x == P.wpt - 1) {
+          // the reference's stage-2 item carries only (full<<3 | W) below the chars (read_to_sdbg_s2.cpp:480-514) and
+          // writes its raw words as the tip label (:603-607): rebuild that word from the aggregated layout
+          const int tip_chars = P.k - 1, in_word = tip_chars - 16 * x;  // chars of the (k-1)-char tip in this word
+          const uint32_t cm = in_word >= 16 ? 0xFFFFFFFFu : (in_word <= 0 ? 0u : 0xFFFFFFFFu << (32 - 2 * in_word));
+          v &= cm;
+          if (x == P.ref_kw - 1) v |= (uint32_t)ex_b(c, i);  // full flag is 0 for a tip
+        }
         out16[o16++] = (uint16_t)(v & 0xFFFFu);
         out16[o16++] = (uint16_t)(v >> 16);
       }
@@ -414,6 +519,7 @@ void emit_sdbg(mhx_ctx *c, const uint32_t *sorted, uint64_t n_items, int S, int 
   P.stride = S;
   P.kw = kw;
   P.k = (int)k;
+  P.ref_kw = (int)div_ceil(k * 2 + 4, 32);
   P.bshift = is_seq ? 16 : 0;
   P.fshift = P.bshift + 3;
   P.aw = (int)(k - 1) / 16;
@@ -524,8 +630,40 @@ int s2_process(mhx_ctx *c, uint32_t k, uint32_t *buf_a, uint32_t *buf_b, uint64_
   return 0;
 }
 
+// aggregated stage 2: solid items from stage 1 + dummy items from the reads; k <= 22
+static int run_s2_aggregated(mhx_ctx *c, uint32_t k, mhx_sdbg_result *out) {
+  SeqSet &s = c->seqs;
+  hipStream_t st = c->stream;
+  const uint64_t ns = s.n_seqs, n_agg = c->agg_n;
+  const unsigned long long *solid = c->results[MHX_BUF_IS_SOLID].as<unsigned long long>();
+  uint32_t *cnt = c->ws("seq_item_cnt", (ns + 1) * 4).as<uint32_t>();
+  uint64_t *item_start = c->ws("seq_item_start", (ns + 2) * 8).as<uint64_t>();
+  uint64_t n_dummy = 0;
+  const unsigned grid = 256 * 8;
+  if (ns) {
+    MHX_LAUNCH(c, "s2_count", (double)s.n_bases * 3 / 8 + (double)ns * 20,
+               hipLaunchKernelGGL(k_s2d_count, dim3(grid), dim3(256), 0, st, s.words.as<uint32_t>(), s.start.as<uint64_t>(), ns, (int)k, solid, cnt));
+    exclusive_scan_u32_u64(c, cnt, item_start, ns, item_start + ns + 1);
+    MHX_HIP(hipMemcpyAsync(&n_dummy, item_start + ns + 1, 8, hipMemcpyDeviceToHost, st));
+    MHX_HIP(hipStreamSynchronize(st));
+  }
+  const uint64_t n_items = n_agg + n_dummy;
+  uint32_t *buf_a = c->ws("items_a", n_items * 8 + 64).as<uint32_t>();
+  uint32_t *buf_b = c->ws("items_b", n_items * 8 + 64).as<uint32_t>();
+  if (n_agg) MHX_HIP(hipMemcpyAsync(buf_a, c->work["s2_agg_items"].p, n_agg * 8, hipMemcpyDeviceToDevice, st));
+  if (n_dummy)
+    MHX_LAUNCH(c, "s2_extract", (double)n_dummy * 8 + (double)s.n_bases * 3 / 8,
+               hipLaunchKernelGGL(k_s2d_extract, dim3(grid), dim3(256), 0, st, s.words.as<uint32_t>(), s.start.as<uint64_t>(), item_start, ns,
+                                  (int)k, solid, reinterpret_cast<uint2 *>(buf_a) + n_agg));
+  // sort by k-mer chars, "full" flag and W; the count bits [0,16) ride along
+  uint32_t *sorted = radix_sort(c, buf_a, buf_b, n_items, 2, 2, make_passes_ranges(2, {{16, 20}, {64 - 2 * (int)k, 64}}));
+  emit_sdbg(c, sorted, n_items, 2, 2, k, 2, out);
+  return 0;
+}
+
 int run_s2(mhx_ctx *c, uint32_t k, uint32_t m, mhx_sdbg_result *out) {
   if (c->global_bases) throw Error("read2sdbg_s2: a global layout is set; use the mhx_dist_* entry points");
+  if (c->agg_valid && c->agg_k == k && c->agg_m == m && m > 1) return run_s2_aggregated(c, k, out);
   const uint64_t n_items = s2_extract(c, k, m);
   const int S = round_up2(s2_kw(k));
   uint32_t *buf_a = c->work["items_a"].as<uint32_t>();

@@ -69,7 +69,7 @@ __device__ __forceinline__ bool key_differs(const uint32_t *a, const uint32_t *b
 //   bool same_run(const uint32_t *cur, const uint32_t *prev)     records of the same group: same run?
 //   void begin_block() / end_block()
 //   void item_phase(const TileCtx<S>&, uint32_t rel, uint32_t run)   (if kItemPhase; before the group phase)
-//   static constexpr bool kRunPhase, kUnitIsRun;
+//   static constexpr bool kRunPhase, kUnitIsRun, kAtomicBase (EMIT only: unordered output, single launch);
 //   void run_phase(const TileCtx<S>&, uint32_t r, uint32_t g)       (if kRunPhase: e.g. LDS atomics into group aggregates)
 //   GroupCounts unit_count(const TileCtx<S>&, uint32_t u)           u = run (kUnitIsRun) or group
 //   void unit_emit(const TileCtx<S>&, uint32_t u, uint64_t o0, uint64_t o1, uint64_t o2)
@@ -298,7 +298,28 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_groups(const uint32_t *__
       run += v;
     }
     __syncthreads();
-    const uint64_t b0 = tile_base[blockIdx.x], b1 = tile_base[n_tiles + blockIdx.x], b2 = tile_base[2 * n_tiles + blockIdx.x];
+    uint64_t b0, b1, b2;
+    if constexpr (Op::kAtomicBase) {
+      // output order across tiles does not matter: reserve this tile's slice with one atomic per counter
+      // (tile_tot = the three global cursors) instead of a scan over per-tile totals in a previous launch
+      __shared__ uint64_t s_base[3];
+      uint64_t tot;
+      block_exclusive_sum<uint64_t, kTileThreads>(s, sm64, &tot);
+      if (tid == 0) {
+        const uint64_t t0 = tot & 0x1FFFFF, t1 = (tot >> 21) & 0x1FFFFF, t2 = tot >> 42;
+        s_base[0] = t0 ? atomicAdd(reinterpret_cast<unsigned long long *>(tile_tot), (unsigned long long)t0) : 0;
+        s_base[1] = t1 ? atomicAdd(reinterpret_cast<unsigned long long *>(tile_tot) + 1, (unsigned long long)t1) : 0;
+        s_base[2] = t2 ? atomicAdd(reinterpret_cast<unsigned long long *>(tile_tot) + 2, (unsigned long long)t2) : 0;
+      }
+      __syncthreads();
+      b0 = s_base[0];
+      b1 = s_base[1];
+      b2 = s_base[2];
+    } else {
+      b0 = tile_base[blockIdx.x];
+      b1 = tile_base[n_tiles + blockIdx.x];
+      b2 = tile_base[2 * n_tiles + blockIdx.x];
+    }
     for (uint32_t u = tid; u < n_units; u += kTileThreads) {
       const uint64_t p = gcnt[u];
       op.unit_emit(ctx, u, b0 + (p & 0x1FFFFF), b1 + ((p >> 21) & 0x1FFFFF), b2 + (p >> 42));

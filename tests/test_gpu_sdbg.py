@@ -11,8 +11,11 @@ pytestmark = pytest.mark.gpu
 CASES = [("fixed", 21, 2), ("var", 21, 2), ("var", 27, 3), ("lowcomplex", 21, 2), ("var", 32, 2), ("var", 47, 2), ("fixed", 63, 2)]
 
 
-def check_sdbg(engine, r, want):
-    assert r.n_items == want["n_sort_items"]
+def check_sdbg(engine, r, want, per_occurrence=False):
+    # stage 2 after stage 1 sorts pre-aggregated items (one per solid (k+1)-mer and strand, k <= 22), so its item
+    # count only equals the reference's per-occurrence count on the legacy path
+    if per_occurrence:
+        assert r.n_items == want["n_sort_items"]
     assert r.words_per_tip_label == want["wpt"]
     got = engine.fetch(lib.BUF_SDBG_BYTES, np.uint8)
     assert got.size == want["bytes"].size == r.sdbg_bytes
@@ -50,7 +53,7 @@ def test_read2sdbg_matches_oracle(engine, kind, k, m):
     assert n_got == n_want
     assert np.array_equal(engine.fetch(lib.BUF_IS_SOLID, np.uint64), solid_want[: solid.size])
     r3 = engine.read2sdbg_s2(k, m)
-    check_sdbg(engine, r3, ob.s2(pkg, k, m, solid_want))
+    check_sdbg(engine, r3, ob.s2(pkg, k, m, solid_want), per_occurrence=True)  # after mercy: per-occurrence path
 
 
 @pytest.mark.parametrize("kind,k,m", [("fixed", 21, 2), ("var", 21, 2), ("lowcomplex", 21, 2), ("var", 27, 3), ("var", 47, 2)])
@@ -93,7 +96,7 @@ def test_read2sdbg_min_count_1(engine, kind, k):
     pkg = ob.Package(reads, reverse=True)
     load(engine, pkg)
     r = engine.read2sdbg_s2(k, 1)  # for_sure_solid: S1 is skipped (main_sdbg_build.cpp:142-146)
-    check_sdbg(engine, r, ob.s2(pkg, k, 1, None))
+    check_sdbg(engine, r, ob.s2(pkg, k, 1, None), per_occurrence=True)
 
 
 def edges_package(edges, k):
@@ -119,7 +122,7 @@ def test_seq2sdbg_from_edges_with_mercy(engine, kind, k, m):
     engine.load_sequences(epkg.words(), epkg.n_seqs, k + 1, None)
     engine.load_multiplicity(mult)
     r = engine.seq2sdbg(k)
-    check_sdbg(engine, r, ob.seq2sdbg(epkg, mult, k))
+    check_sdbg(engine, r, ob.seq2sdbg(epkg, mult, k), per_occurrence=True)
     # mercy: candidate reads as KmerCounter::Lv0Postprocess selects them (kmer_counter.cpp:390-403)
     first, last = cnt["first_0_out"], cnt["last_0_in"]
     sel = [i for i in range(len(reads)) if first[i] != 0xFFFFFFFF and last[i] != 0xFFFFFFFF and last[i] > first[i]]
@@ -130,7 +133,7 @@ def test_seq2sdbg_from_edges_with_mercy(engine, kind, k, m):
     n_got = engine.gen_mercy_edges(k, cand.words(), cand.n_seqs, cand.start())
     assert n_got == n_want
     r2 = engine.seq2sdbg(k)
-    check_sdbg(engine, r2, ob.seq2sdbg(epkg, mult2, k))
+    check_sdbg(engine, r2, ob.seq2sdbg(epkg, mult2, k), per_occurrence=True)
 
 
 @pytest.mark.parametrize("k", [21, 29, 39, 59, 79, 99, 119, 141, 255])
@@ -154,4 +157,23 @@ def test_seq2sdbg_wide_keys(engine, k):
     engine.load_sequences(pkg.words(), pkg.n_seqs, 0, pkg.start())
     engine.load_multiplicity(mult)
     r = engine.seq2sdbg(k)
-    check_sdbg(engine, r, ob.seq2sdbg(pkg, mult, k))
+    check_sdbg(engine, r, ob.seq2sdbg(pkg, mult, k), per_occurrence=True)
+
+
+@pytest.mark.parametrize("kind,k,m", [("fixed", 21, 2), ("var", 21, 3), ("lowcomplex", 21, 2), ("var", 15, 2), ("fixed", 22, 2), ("lowcomplex", 16, 2)])
+def test_s2_aggregated_equals_per_occurrence(engine, kind, k, m, monkeypatch):
+    """k <= 22: stage 2 fed by stage 1's aggregated items must give the reference's records (incl. tips labels,
+    multiplicities > 254 in the poly-A reads) and must sort far fewer items."""
+    reads = make_reads(kind, 8)
+    pkg = ob.Package(reads, reverse=True)
+    w1 = ob.s1(pkg, k, m)
+    want = ob.s2(pkg, k, m, w1["is_solid"])
+    load(engine, pkg)
+    engine.read2sdbg_s1(k, m)
+    r = engine.read2sdbg_s2(k, m)
+    check_sdbg(engine, r, want)
+    assert r.n_items < want["n_sort_items"] or want["n_sort_items"] == 0
+    # replacing the bitmap invalidates the aggregated items -> per-occurrence path, same answer
+    engine.set_is_solid(w1["is_solid"])
+    r = engine.read2sdbg_s2(k, m)
+    check_sdbg(engine, r, want, per_occurrence=True)
