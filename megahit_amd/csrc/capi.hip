@@ -542,8 +542,16 @@ int mhx_dist_extract(mhx_ctx *c, int stage, uint32_t k, uint32_t min_count, mhx_
       n = mhx::s1_extract(c, k, mhx::s1_compact(c, 0));
       S = mhx::s1_stride(k, mhx::s1_compact(c, 0));
     } else if (stage == MHX_STAGE_S2) {
-      n = mhx::s2_extract(c, k, min_count);
-      S = mhx::round_up2((int)mhx::div_ceil(k * 2 + 4, 32));
+      // every rank must take the same path: the aggregated one needs stage 1 to have run with this (k, m) on
+      // all ranks, which the (k <= 22, m >= 2) rule makes a pure function of the arguments
+      c->dist_s2_agg = mhx::s2_use_aggregated(c, k, min_count);
+      if (c->dist_s2_agg) {
+        n = mhx::s2_agg_extract(c, k);
+        S = 2;
+      } else {
+        n = mhx::s2_extract(c, k, min_count);
+        S = mhx::round_up2((int)mhx::div_ceil(k * 2 + 4, 32));
+      }
     } else throw mhx::Error("dist_extract: unknown stage");
     uint32_t *a = c->work["items_a"].as<uint32_t>();
     uint32_t *send = c->ws("items_send", n * (size_t)S * 4 + 64).as<uint32_t>();
@@ -574,10 +582,11 @@ int mhx_dist_process_s1(mhx_ctx *c, uint32_t k, uint32_t min_count, uint64_t n_i
 int mhx_dist_process_s2(mhx_ctx *c, uint32_t k, uint64_t n_items, mhx_sdbg_result *out) {
   MHX_TRY({
     MHX_HIP(hipSetDevice(c->device));
-    const int S = mhx::round_up2((int)mhx::div_ceil(k * 2 + 4, 32));
+    const int S = c->dist_s2_agg ? 2 : mhx::round_up2((int)mhx::div_ceil(k * 2 + 4, 32));
     uint32_t *a = c->ws("items_recv", n_items * (size_t)S * 4 + 64).as<uint32_t>();
     uint32_t *b = c->ws("items_b", n_items * (size_t)S * 4 + 64).as<uint32_t>();
-    mhx::s2_process(c, k, a, b, n_items, out);
+    if (c->dist_s2_agg) mhx::s2_agg_process(c, k, a, b, n_items, out);
+    else mhx::s2_process(c, k, a, b, n_items, out);
   })
 }
 void *mhx_device_pointer(mhx_ctx *c, int which) {

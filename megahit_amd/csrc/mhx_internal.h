@@ -84,6 +84,7 @@ struct mhx_ctx {
   bool agg_valid = false;
   uint32_t agg_k = 0, agg_m = 0;
   uint64_t agg_n = 0;
+  bool dist_s2_agg = false;  // the items of the current multi-GPU stage-2 exchange are aggregated ones
   // profiling
   bool profiling = false;
   std::vector<mhx::PendingEvent> pending;
@@ -155,6 +156,9 @@ int s1_stride(uint32_t k, bool compact);
 int s1_process(mhx_ctx *c, uint32_t k, uint32_t m, int want_mercy, uint32_t *buf_a, uint32_t *buf_b, uint64_t n_items, mhx_s1_result *out);
 uint64_t s2_extract(mhx_ctx *c, uint32_t k, uint32_t m);
 int s2_process(mhx_ctx *c, uint32_t k, uint32_t *buf_a, uint32_t *buf_b, uint64_t n_items, mhx_sdbg_result *out);
+bool s2_use_aggregated(const mhx_ctx *c, uint32_t k, uint32_t m);
+uint64_t s2_agg_extract(mhx_ctx *c, uint32_t k);
+int s2_agg_process(mhx_ctx *c, uint32_t k, uint32_t *buf_a, uint32_t *buf_b, uint64_t n_items, mhx_sdbg_result *out);
 constexpr int MHX_BUF_IS_SOLID_LOCAL = 100;  // internal: this rank's slice of the global bitmap (multi-GPU)
 
 // ---- engines ----

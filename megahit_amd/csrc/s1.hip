@@ -154,6 +154,9 @@ struct S1Op {
   uint8_t *solid_bytes;  // one byte per base position (plain stores, packed to the bitmap afterwards)
   unsigned long long *solid_bits;  // or: the bitmap itself, set with atomics (mark_atomic)
   int mark_atomic;
+  // mark_mode 0: mark solid occurrences; 1: mark the NON-solid ones (fewer scattered stores when most are solid;
+  // k_pack_solid_inv turns "valid position and not marked" into is_solid); 2: statistics only (sampled tiles)
+  int mark_mode;
   unsigned long long *hist, *n_solid_out;
   int want_mercy;
   long long *mercy;
@@ -161,7 +164,7 @@ struct S1Op {
 
   __device__ bool same_run(const uint32_t *cur, const uint32_t *prev) const { return ((cur[kw - 1] ^ prev[kw - 1]) & 63u) == 0; }
   __device__ bool item_phase_enabled() const { return false; }
-  __device__ bool item_final_enabled() const { return true; }
+  __device__ bool item_final_enabled() const { return mark_mode != 2; }
   __device__ void item_phase(const TileCtx<S> &, uint32_t, uint32_t) const {}
   __device__ void begin_block() const {
     uint32_t *lh = s1_local_hist();
@@ -170,10 +173,13 @@ struct S1Op {
     __syncthreads();
   }
   __device__ void end_block() const {
+    if (mark_mode == 2) {  // sampled statistics: [0] solid occurrences, [2] occurrences with head and tail
+      if (threadIdx.x == 0 && *s1_block_solid()) atomicAdd(n_solid_out, *s1_block_solid());
+      return;
+    }
     uint32_t *lh = s1_local_hist();
     for (int i = threadIdx.x; i < kS1LocalHist; i += blockDim.x)
       if (lh[i]) atomicAdd(&hist[i], (unsigned long long)lh[i]);
-    (void)n_solid_out;  // counted by k_pack_solid
   }
   // the (k+1)-mer head.S.tail of a run, chars MSB-first in 64 bits
   __device__ __forceinline__ uint64_t edge_of(const TileCtx<S> &c, uint32_t i, unsigned h, unsigned t) const {
@@ -232,28 +238,36 @@ struct S1Op {
         if (cnt_tail[x] >= m) has_out |= 1u << x;
     }
     const uint32_t masks = (has_in << 1) | (has_out << 5) | (l_has_out << 9) | (r_has_in << 13);
-    unsigned long long my_solid = 0;
+    unsigned long long my_solid = 0, my_both = 0;
     uint32_t n_agg = 0;
     for (uint32_t r = r0; r < r1; ++r) {
       const unsigned ht = c.acc.word(c.run_start(r), kw - 1) & 63u, h = ht >> 3, t = ht & 7;
       const uint32_t n = c.run_len(r);
       const bool both = h < 4 && t < 4;
+      const bool solid = both && n >= m;
+      if (mark_mode == 2) {
+        if (solid) my_solid += n;
+        if (both) my_both += n;
+        continue;
+      }
       if (both) {
         const uint32_t hb = n > MHX_MAX_MUL ? (uint32_t)MHX_MAX_MUL : n;
         if (hb < kS1LocalHist) atomicAdd(&s1_local_hist()[hb], 1u);
         else atomicAdd(&hist[hb], 1ull);
       }
-      const bool solid = both && n >= m;
       if (solid) my_solid += n;
-      s1_run_info<S>()[r] = masks | (solid ? 1u : 0u);
+      s1_run_info<S>()[r] = masks | (solid ? 1u : 0u) | (both ? 1u << 17 : 0u);
       if constexpr (AGG) {
-        if (solid) {
+        if (solid && mark_mode != 2) {
           const uint64_t x = edge_of(c, c.run_start(r), h, t);
           n_agg += x == rc64(x, k + 1) ? 1u : 2u;
         }
       }
     }
-    (void)my_solid;
+    if (mark_mode == 2) {
+      if (my_solid) atomicAdd(s1_block_solid(), my_solid);
+      if (my_both) atomicAdd(n_solid_out + 2, my_both);
+    }
     GroupCounts gc;
     gc.c0 = n_agg;
     return gc;
@@ -261,7 +275,8 @@ struct S1Op {
   __device__ void item_final(const TileCtx<S> &c, uint32_t rel, uint32_t run) const {
     const uint32_t ri = s1_run_info<S>()[run];
     const bool solid = ri & 1u;
-    if (!solid && !want_mercy) return;
+    const bool mark = mark_mode == 1 ? (!solid && (ri >> 17 & 1u)) : solid;
+    if (!mark && !want_mercy) return;
     uint64_t abs;
     int strand = 0;
     if constexpr (COMPACT) abs = c.acc.word(rel, kw);
@@ -270,7 +285,7 @@ struct S1Op {
       abs = info >> 1;
       strand = (int)(info & 1);
     }
-    if (solid) {  // is_solid.set(pos-1), :464
+    if (mark) {  // is_solid.set(pos-1), :464 (or its complement, see mark_mode)
       if (mark_atomic) atomicOr(reinterpret_cast<unsigned int *>(solid_bits) + ((abs - 1) >> 5), 1u << ((abs - 1) & 31));
       else solid_bytes[abs - 1] = 1;
     }
@@ -334,16 +349,63 @@ __global__ __launch_bounds__(256) void k_count_solid(const unsigned long long *_
   if (threadIdx.x == 0 && tot) atomicAdd(n_solid, (unsigned long long)tot);
 }
 
+// mark_mode 1: bytes mark the NON-solid occurrences; a position is solid iff a (k+1)-mer starts there
+// (offset + k + 1 <= read length) and it is not marked.  One thread per 64 positions.
+__global__ __launch_bounds__(256) void k_pack_solid_inv(const uint8_t *__restrict__ bytes, uint64_t n_bits, const uint64_t *__restrict__ start,
+                                                        uint64_t n_seqs, uint32_t fixed_len, int k, unsigned long long *__restrict__ words,
+                                                        uint64_t n_words, unsigned long long *__restrict__ n_solid) {
+  __shared__ uint64_t sm[256 / kWave + 1];
+  const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned long long v = 0;
+  if (w < n_words) {
+    const uint64_t p0 = w * 64;
+    uint64_t rid = p0 < n_bits ? seq_of_offset(start, n_seqs, fixed_len, p0) : 0;
+    uint64_t rs = start[rid], re = start[rid + 1];
+    const uint4 *pb = reinterpret_cast<const uint4 *>(bytes + p0);
+    for (int q = 0; q < 4; ++q) {
+      const uint4 x = pb[q];
+      const uint32_t xs[4] = {x.x, x.y, x.z, x.w};
+      for (int t = 0; t < 16; ++t) {
+        const uint64_t p = p0 + q * 16 + t;
+        if (p >= n_bits) break;
+        while (p >= re) {
+          ++rid;
+          rs = re;
+          re = start[rid + 1];
+        }
+        const bool valid = p + (uint64_t)k + 1 <= re;  // a (k+1)-mer of this read starts at p
+        const bool marked = (xs[t >> 2] >> ((t & 3) * 8)) & 1u;
+        if (valid && !marked) v |= 1ull << (q * 16 + t);
+      }
+    }
+    (void)rs;
+    words[w] = v;
+  }
+  uint64_t tot;
+  block_exclusive_sum<uint64_t, 256>((uint64_t)__builtin_popcountll(v), sm, &tot);
+  if (threadIdx.x == 0 && tot) atomicAdd(n_solid, (unsigned long long)tot);
+}
+
 template <int S, bool COMPACT, bool AGG>
 static void s1_groups_launch(mhx_ctx *c, const uint32_t *sorted, uint64_t n_items, int KWv, int kmer_bits, uint32_t m,
                              uint8_t *is_solid, unsigned long long *solid_bits, int mark_atomic, unsigned long long *hist, unsigned long long *ctr, int want_mercy,
-                             long long *mercy, int k, uint2 *agg_items, uint64_t *agg_cursor) {
+                             long long *mercy, int k, uint2 *agg_items, uint64_t *agg_cursor, int mark_mode) {
   SeqSet &s = c->seqs;
   constexpr int T = S1Tile<S>::kT;
   const uint64_t n_tiles = div_ceil(n_items, T);
   const int full_words = kmer_bits / 32, rem = kmer_bits % 32;
   const uint32_t last_mask = rem ? 0xFFFFFFFFu << (32 - rem) : 0;
-  S1Op<S, COMPACT, AGG> op{k, agg_items, KWv, m, s.start.as<uint64_t>(), s.n_seqs, s.fixed_len, is_solid, solid_bits, mark_atomic, hist, ctr, want_mercy, mercy, ctr + 1};
+  S1Op<S, COMPACT, AGG> op{k, agg_items, KWv, m, s.start.as<uint64_t>(), s.n_seqs, s.fixed_len, is_solid, solid_bits, mark_atomic, mark_mode, hist, ctr, want_mercy, mercy, ctr + 1};
+  if (mark_mode == 2) {  // statistics on every 64th tile (no output): solid fraction -> marking polarity
+    const uint32_t stride = 64;
+    const uint64_t nt = div_ceil(n_tiles, stride);
+    MHX_LAUNCH(c, "s1_sample", (double)nt * T * S * 4,
+               hipLaunchKernelGGL((k_tile_groups<S, T, S1Op<S, COMPACT, false>, false>), dim3((unsigned)nt), dim3(kTileThreads), 0, c->stream, sorted,
+                                  n_items, full_words, last_mask, S1Op<S, COMPACT, false>{k, nullptr, KWv, m, s.start.as<uint64_t>(), s.n_seqs,
+                                  s.fixed_len, is_solid, solid_bits, mark_atomic, 2, hist, ctr, 0, mercy, ctr + 1},
+                                  (uint64_t *)nullptr, (const uint64_t *)nullptr, n_tiles, stride));
+    return;
+  }
   if constexpr (AGG)
     MHX_LAUNCH(c, "s1_groups", (double)n_items * S * 4,
                hipLaunchKernelGGL((k_tile_groups<S, T, S1Op<S, COMPACT, true>, true>), dim3((unsigned)n_tiles), dim3(kTileThreads), 0, c->stream,
@@ -437,10 +499,9 @@ int s1_process(mhx_ctx *c, uint32_t k, uint32_t m, int want_mercy, uint32_t *buf
   unsigned long long *is_solid = c->result(MHX_BUF_IS_SOLID, (n_words64 + 1) * 8).as<unsigned long long>();
   c->results[MHX_BUF_IS_SOLID].used = n_words64 * 8;
   unsigned long long *hist = c->result(MHX_BUF_MUL_HIST, (MHX_MAX_MUL + 1) * 8).as<unsigned long long>();
-  static const int mark_atomic = [] {
-    const char *e = getenv("MHX_S1_MARK");
-    return e && !strcmp(e, "atomic") ? 1 : 0;
-  }();
+  // MHX_S1_MARK: atomic (atomicOr into the bitmap) | solid | nonsolid (force the byte-map polarity) | unset = auto
+  const char *mark_env = getenv("MHX_S1_MARK");
+  const int mark_atomic = mark_env && !strcmp(mark_env, "atomic") ? 1 : 0;
   uint8_t *solid_bytes = nullptr;
   if (mark_atomic) MHX_HIP(hipMemsetAsync(is_solid, 0, (n_words64 + 1) * 8, st));
   else {
@@ -453,11 +514,12 @@ int s1_process(mhx_ctx *c, uint32_t k, uint32_t m, int want_mercy, uint32_t *buf
   MHX_HIP(hipMemsetAsync(ctr, 0, 64, st));
 
   uint64_t n_solid = 0, n_mercy = 0;
+  int s1_mark_mode_used = 0;
   // mercy candidates (<= 2 per item, 8 B each) go to the spare sort buffer: S*4 >= 16 bytes per item
   long long *mercy = reinterpret_cast<long long *>(spare);
   // aggregated stage-2 items (k <= 22, m >= 2): at most 2 per solid run, a solid run has >= m records
   static const bool agg_off = getenv("MHX_S2_PER_OCCURRENCE") != nullptr;
-  const bool agg = !agg_off && !global && k <= 22 && m >= 2 && KWv == 2;
+  const bool agg = !agg_off && k <= 22 && m >= 2 && KWv == 2;
   c->agg_valid = false;
   uint2 *agg_items = nullptr;
   uint64_t *agg_cursor = c->ws("s2_agg_cursor", 64).as<uint64_t>();
@@ -466,31 +528,55 @@ int s1_process(mhx_ctx *c, uint32_t k, uint32_t m, int want_mercy, uint32_t *buf
     MHX_HIP(hipMemsetAsync(agg_cursor, 0, 24, st));
   }
   if (n_items) {
-#define MHX_ARGS(WM) c, sorted, n_items, KWv, kmer_bits, m, solid_bytes, is_solid, mark_atomic, hist, ctr, WM, mercy, (int)k, agg_items, agg_cursor
+    // marking polarity from a 1/64 sample of the tiles: when most occurrences are solid it is cheaper to mark the
+    // non-solid ones (each mark is a 32-byte partial HBM write).  Single GPU only: ranks must agree on the meaning.
+    int mark_mode = 0;
+    const bool can_invert = !global && !mark_atomic;
+#define MHX_ARGS(WM) c, sorted, n_items, KWv, kmer_bits, m, solid_bytes, is_solid, mark_atomic, hist, ctr, WM, mercy, (int)k, agg_items, agg_cursor, mark_mode
 #define MHX_CASE(SV)                                                          \
   case SV:                                                                    \
     if (compact) s1_groups_launch<SV, true, false>(MHX_ARGS(0));              \
     else s1_groups_launch<SV, false, false>(MHX_ARGS(want_mercy));            \
     break;
+#define MHX_ALL_CASES                                                                                                            \
+  switch (S) {                                                                                                                   \
+    MHX_CASE(3) MHX_CASE(4) MHX_CASE(6) MHX_CASE(8) MHX_CASE(10) MHX_CASE(12) MHX_CASE(14) MHX_CASE(16) MHX_CASE(18) MHX_CASE(20) \
+    default: throw Error("read2sdbg_s1: unsupported record stride");                                                             \
+  }
+    if (can_invert && mark_env && !strcmp(mark_env, "nonsolid")) mark_mode = 1;
+    else if (can_invert && !mark_env && n_items > (1u << 16)) {
+      mark_mode = 2;
+      MHX_ALL_CASES
+      unsigned long long hs[3] = {0, 0, 0};
+      MHX_HIP(hipMemcpyAsync(hs, ctr, 24, hipMemcpyDeviceToHost, st));
+      MHX_HIP(hipStreamSynchronize(st));
+      mark_mode = hs[2] > 0 && hs[0] * 2 > hs[2] ? 1 : 0;
+      MHX_HIP(hipMemsetAsync(ctr, 0, 64, st));
+    }
     if (agg && S == 3) s1_groups_launch<3, true, true>(MHX_ARGS(0));
     else if (agg && S == 4 && !compact) s1_groups_launch<4, false, true>(MHX_ARGS(want_mercy));
-    else switch (S) {
-      MHX_CASE(3) MHX_CASE(4) MHX_CASE(6) MHX_CASE(8) MHX_CASE(10) MHX_CASE(12) MHX_CASE(14) MHX_CASE(16) MHX_CASE(18) MHX_CASE(20)
-      default: throw Error("read2sdbg_s1: unsupported record stride");
-    }
+    else MHX_ALL_CASES
+#undef MHX_ALL_CASES
 #undef MHX_CASE
 #undef MHX_ARGS
-    if (agg && (S == 3 || (S == 4 && !compact))) {
-      MHX_HIP(hipMemcpyAsync(&c->agg_n, agg_cursor, 8, hipMemcpyDeviceToHost, st));
-      c->agg_valid = true;
-      c->agg_k = k;
-      c->agg_m = m;
-    }
+    s1_mark_mode_used = mark_mode;
+
+  }
+  if (agg && (S == 3 || (S == 4 && !compact))) {  // also with zero local items: every rank takes the same stage-2 path
+    c->agg_n = 0;
+    MHX_HIP(hipMemcpyAsync(&c->agg_n, agg_cursor, 8, hipMemcpyDeviceToHost, st));
+    c->agg_valid = true;
+    c->agg_k = k;
+    c->agg_m = m;
   }
   if (n_words64 && mark_atomic)
     MHX_LAUNCH(c, "count_solid", (double)n_words64 * 8,
                hipLaunchKernelGGL(k_count_solid, dim3((unsigned)div_ceil(n_words64, 256)), dim3(256), 0, st, is_solid, n_words64, ctr));
-  if (n_words64 && !mark_atomic)
+  if (n_words64 && !mark_atomic && s1_mark_mode_used == 1)
+    MHX_LAUNCH(c, "pack_solid", (double)n_words64 * 72,
+               hipLaunchKernelGGL(k_pack_solid_inv, dim3((unsigned)div_ceil(n_words64, 256)), dim3(256), 0, st, solid_bytes, n_bits,
+                                  s.start.as<uint64_t>(), s.n_seqs, s.fixed_len, (int)k, is_solid, n_words64, ctr));
+  if (n_words64 && !mark_atomic && s1_mark_mode_used != 1)
     MHX_LAUNCH(c, "pack_solid", (double)n_words64 * 72,
                hipLaunchKernelGGL(k_pack_solid, dim3((unsigned)div_ceil(n_words64, 256)), dim3(256), 0, st, solid_bytes, n_bits, is_solid, n_words64,
                                   ctr));

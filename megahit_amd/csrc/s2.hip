@@ -630,12 +630,14 @@ int s2_process(mhx_ctx *c, uint32_t k, uint32_t *buf_a, uint32_t *buf_b, uint64_
   return 0;
 }
 
-// aggregated stage 2: solid items from stage 1 + dummy items from the reads; k <= 22
-static int run_s2_aggregated(mhx_ctx *c, uint32_t k, mhx_sdbg_result *out) {
+// aggregated stage 2 (k <= 22): solid items from stage 1 + dummy items from the local reads -> ws "items_a"
+uint64_t s2_agg_extract(mhx_ctx *c, uint32_t k) {
   SeqSet &s = c->seqs;
   hipStream_t st = c->stream;
   const uint64_t ns = s.n_seqs, n_agg = c->agg_n;
-  const unsigned long long *solid = c->results[MHX_BUF_IS_SOLID].as<unsigned long long>();
+  auto it = c->results.find(c->global_bases ? MHX_BUF_IS_SOLID_LOCAL : MHX_BUF_IS_SOLID);
+  if (it == c->results.end() || it->second.used < div_ceil(s.n_bases, 64) * 8) throw Error("read2sdbg_s2: no is_solid bitmap");
+  const unsigned long long *solid = it->second.as<unsigned long long>();
   uint32_t *cnt = c->ws("seq_item_cnt", (ns + 1) * 4).as<uint32_t>();
   uint64_t *item_start = c->ws("seq_item_start", (ns + 2) * 8).as<uint64_t>();
   uint64_t n_dummy = 0;
@@ -649,21 +651,27 @@ static int run_s2_aggregated(mhx_ctx *c, uint32_t k, mhx_sdbg_result *out) {
   }
   const uint64_t n_items = n_agg + n_dummy;
   uint32_t *buf_a = c->ws("items_a", n_items * 8 + 64).as<uint32_t>();
-  uint32_t *buf_b = c->ws("items_b", n_items * 8 + 64).as<uint32_t>();
   if (n_agg) MHX_HIP(hipMemcpyAsync(buf_a, c->work["s2_agg_items"].p, n_agg * 8, hipMemcpyDeviceToDevice, st));
   if (n_dummy)
     MHX_LAUNCH(c, "s2_extract", (double)n_dummy * 8 + (double)s.n_bases * 3 / 8,
                hipLaunchKernelGGL(k_s2d_extract, dim3(grid), dim3(256), 0, st, s.words.as<uint32_t>(), s.start.as<uint64_t>(), item_start, ns,
                                   (int)k, solid, reinterpret_cast<uint2 *>(buf_a) + n_agg));
-  // sort by k-mer chars, "full" flag and W; the count bits [0,16) ride along
+  return n_items;
+}
+// sort by k-mer chars, "full" flag and W (the count bits [0,16) ride along), then emit
+int s2_agg_process(mhx_ctx *c, uint32_t k, uint32_t *buf_a, uint32_t *buf_b, uint64_t n_items, mhx_sdbg_result *out) {
   uint32_t *sorted = radix_sort(c, buf_a, buf_b, n_items, 2, 2, make_passes_ranges(2, {{16, 20}, {64 - 2 * (int)k, 64}}));
   emit_sdbg(c, sorted, n_items, 2, 2, k, 2, out);
   return 0;
 }
+bool s2_use_aggregated(const mhx_ctx *c, uint32_t k, uint32_t m) { return c->agg_valid && c->agg_k == k && c->agg_m == m && m > 1; }
 
 int run_s2(mhx_ctx *c, uint32_t k, uint32_t m, mhx_sdbg_result *out) {
   if (c->global_bases) throw Error("read2sdbg_s2: a global layout is set; use the mhx_dist_* entry points");
-  if (c->agg_valid && c->agg_k == k && c->agg_m == m && m > 1) return run_s2_aggregated(c, k, out);
+  if (s2_use_aggregated(c, k, m)) {
+    const uint64_t n_items = s2_agg_extract(c, k);
+    return s2_agg_process(c, k, c->work["items_a"].as<uint32_t>(), c->ws("items_b", n_items * 8 + 64).as<uint32_t>(), n_items, out);
+  }
   const uint64_t n_items = s2_extract(c, k, m);
   const int S = round_up2(s2_kw(k));
   uint32_t *buf_a = c->work["items_a"].as<uint32_t>();

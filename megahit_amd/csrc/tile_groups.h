@@ -79,7 +79,8 @@ constexpr int kLookAhead = 64;  // records staged beyond the tile so that short 
 template <int S, int T, class Op, bool EMIT>
 __global__ __launch_bounds__(kTileThreads) void k_tile_groups(const uint32_t *__restrict__ items, uint64_t n, int full_words,
                                                              uint32_t last_mask, Op op, uint64_t *__restrict__ tile_tot,
-                                                             const uint64_t *__restrict__ tile_base, uint64_t n_tiles) {
+                                                             const uint64_t *__restrict__ tile_base, uint64_t n_tiles,
+                                                             uint32_t tile_stride = 1) {
   constexpr int PER = T / kTileThreads;
   constexpr int NW = kTileThreads / kWave;
   static_assert(T % kTileThreads == 0 && PER <= 16, "tile shape");
@@ -95,7 +96,7 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_groups(const uint32_t *__
 
   const int tid = threadIdx.x, wv = tid / kWave, lane = tid & (kWave - 1);
   const uint64_t lanemask_lt = (1ull << lane) - 1;
-  const uint64_t base = (uint64_t)blockIdx.x * T;
+  const uint64_t base = (uint64_t)blockIdx.x * tile_stride * T;  // tile_stride > 1: a sample of the tiles (statistics only)
   const uint64_t rem = n - base;
   const int t_n = rem < (uint64_t)T ? (int)rem : T;
   const int staged = rem < (uint64_t)(T + kLookAhead) ? (int)rem : T + kLookAhead;  // tile + look-ahead

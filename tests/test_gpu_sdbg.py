@@ -177,3 +177,37 @@ def test_s2_aggregated_equals_per_occurrence(engine, kind, k, m, monkeypatch):
     engine.set_is_solid(w1["is_solid"])
     r = engine.read2sdbg_s2(k, m)
     check_sdbg(engine, r, want, per_occurrence=True)
+
+
+@pytest.mark.parametrize("polarity", ["solid", "nonsolid", None])
+@pytest.mark.parametrize("kind,k,m,mercy", [("fixed", 21, 2, 0), ("var", 21, 2, 1), ("lowcomplex", 21, 2, 0), ("var", 27, 3, 0),
+                                           ("var", 47, 2, 1), ("short", 21, 2, 0)])
+def test_s1_marking_polarity(engine, kind, k, m, mercy, polarity, monkeypatch):
+    """is_solid is built from a byte map that marks either the solid occurrences or (when a sample says most are
+    solid) the non-solid ones; both polarities and the sampled choice give the reference's bitmap."""
+    if polarity is None:
+        monkeypatch.delenv("MHX_S1_MARK", raising=False)
+    else:
+        monkeypatch.setenv("MHX_S1_MARK", polarity)
+    if kind == "short":  # reads shorter than k+1 and of exactly k+1 among longer ones: no edge may be marked there
+        rng = np.random.default_rng(11)
+        g = rng.integers(0, 4, size=3000, dtype=np.uint8)
+        reads = []
+        for _ in range(4000):
+            L = int(rng.choice([5, k - 1, k, k + 1, k + 2, 60, 100]))
+            o = int(rng.integers(0, g.size - L))
+            reads.append(g[o:o + L].copy())
+    else:
+        reads = make_reads(kind, 9)
+    pkg = ob.Package(reads, reverse=True)
+    w1 = ob.s1(pkg, k, m, tie_stable=True)
+    load(engine, pkg)
+    r1 = engine.read2sdbg_s1(k, m, want_mercy=mercy)
+    assert r1.n_items == w1["n_items"]
+    solid = engine.fetch(lib.BUF_IS_SOLID, np.uint64)
+    assert np.array_equal(solid, w1["is_solid"][: solid.size])
+    assert r1.n_solid == int(sum(bin(int(x)).count("1") for x in w1["is_solid"]))
+    assert np.array_equal(engine.fetch(lib.BUF_MUL_HIST, np.int64), w1["hist"])
+    if mercy:
+        assert np.array_equal(engine.fetch(lib.BUF_MERCY_CAND, np.int64), w1["mercy"])
+    check_sdbg(engine, engine.read2sdbg_s2(k, m), ob.s2(pkg, k, m, w1["is_solid"]))
