@@ -153,12 +153,18 @@ int mhx_sort_records(mhx_ctx *, uint32_t *host_items, uint64_t n, uint32_t key_w
  * (one stable multisplit pass), the caller moves them with an all-to-all on its own communication
  * backend (RCCL via torch.distributed in megahit_amd/dist.py), and every rank sorts + reduces the
  * buckets it owns — the reference's OffsetFiller::IsHandling bucket filter (base_engine.h:106-108)
- * turned into an exchange.  Supported for read2sdbg without mercy (BASELINE configs[2]). ---- */
+ * turned into an exchange.  All three sub-programs are supported (BASELINE configs[2..4]). ---- */
 int mhx_set_partition(mhx_ctx *, int my_part, int n_parts, const uint32_t *bucket_begin /* n_parts+1 */);
 /* This rank's reads sit at base offset pos_base of a global read set of global_bases bases
  * (is_solid then spans the global set).  (0, 0) switches the global layout off. */
 int mhx_set_global_layout(mhx_ctx *, uint64_t pos_base, uint64_t global_bases);
-enum mhx_stage { MHX_STAGE_S1 = 1, MHX_STAGE_S2 = 2 };
+enum mhx_stage {
+  MHX_STAGE_S1 = 1,        /* read2sdbg stage 1, no mercy: compact items */
+  MHX_STAGE_S2 = 2,        /* read2sdbg stage 2 */
+  MHX_STAGE_COUNT = 3,     /* count */
+  MHX_STAGE_SEQ2SDBG = 4,  /* seq2sdbg */
+  MHX_STAGE_S1_MERCY = 5   /* read2sdbg stage 1 with mercy candidates: full items (prev/next, 64-bit position) */
+};
 typedef struct {
   void *d_items;       /* device pointer: items grouped by owner, owners ascending */
   uint64_t n_items;
@@ -170,8 +176,23 @@ int mhx_dist_extract(mhx_ctx *, int stage, uint32_t k, uint32_t min_count, mhx_d
 void *mhx_dist_recv_buffer(mhx_ctx *, uint64_t n_items, uint32_t item_bytes);
 /* sort + reduce the received items: S1 sets bits of the GLOBAL is_solid bitmap (MHX_BUF_IS_SOLID),
  * S2 emits the SdBG records of the owned buckets */
-int mhx_dist_process_s1(mhx_ctx *, uint32_t k, uint32_t min_count, uint64_t n_items, mhx_s1_result *out);
+int mhx_dist_process_s1(mhx_ctx *, uint32_t k, uint32_t min_count, int want_mercy, uint64_t n_items, mhx_s1_result *out);
 int mhx_dist_process_s2(mhx_ctx *, uint32_t k, uint64_t n_items, mhx_sdbg_result *out);
+/* count: solid edges + bucket counts + histogram of the owned buckets; first_0_out / last_0_in of the LOCAL reads are
+ * complete only after the read events have been routed (below).  seq2sdbg: SdBG records of the owned buckets (items
+ * carry no positions, so the sequences may be spread over the ranks in any way; no mercy edges in this mode). */
+int mhx_dist_process_count(mhx_ctx *, uint32_t k, uint32_t min_count, uint64_t n_items, mhx_count_result *out);
+int mhx_dist_process_seq2sdbg(mhx_ctx *, uint32_t k, uint64_t n_items, mhx_sdbg_result *out);
+/* Records keyed by a position in the GLOBAL read set, produced by the bucket owners and consumed by the rank that
+ * holds the read (SURVEY §8e "secondary reductions"): the first_0_out/last_0_in updates of count
+ * (kmer_counter.cpp:307-368) and the mercy candidates of read2sdbg stage 1 (read_to_sdbg_s1.cpp:466-551).
+ * route: 8-byte records sorted by position + counts[p] = records for rank p, where rank p holds positions
+ * [p*stride_bases, (p+1)*stride_bases); the caller moves them with an all-to-all into mhx_dist_recv_buffer;
+ * apply: count -> finishes MHX_BUF_FIRST_0_OUT / MHX_BUF_LAST_0_IN; mercy -> installs the local candidate list used by
+ * mhx_read2sdbg_add_mercy (which, with a global layout set, updates the adopted is_solid slice). */
+enum mhx_route { MHX_ROUTE_COUNT_EVENTS = 1, MHX_ROUTE_MERCY_CAND = 2 };
+int mhx_dist_route_records(mhx_ctx *, int which, uint64_t stride_bases, mhx_dist_items *out, uint64_t *counts);
+int mhx_dist_apply_routed(mhx_ctx *, int which, uint64_t n_records);
 /* raw device pointer of a result buffer (for collectives on it); NULL if absent */
 void *mhx_device_pointer(mhx_ctx *, int which);
 /* after the bitmap reduction: install this rank's slice (device pointer, n_words uint64) as the

@@ -538,9 +538,16 @@ int mhx_dist_extract(mhx_ctx *c, int stage, uint32_t k, uint32_t min_count, mhx_
     if (c->work.find("owner_lut") == c->work.end()) throw mhx::Error("dist_extract: call mhx_set_partition first");
     uint64_t n = 0;
     int S = 0;
-    if (stage == MHX_STAGE_S1) {
-      n = mhx::s1_extract(c, k, mhx::s1_compact(c, 0));
-      S = mhx::s1_stride(k, mhx::s1_compact(c, 0));
+    if (stage == MHX_STAGE_S1 || stage == MHX_STAGE_S1_MERCY) {
+      const bool compact = mhx::s1_compact(c, stage == MHX_STAGE_S1_MERCY ? 1 : 0);
+      n = mhx::s1_extract(c, k, compact);
+      S = mhx::s1_stride(k, compact);
+    } else if (stage == MHX_STAGE_COUNT) {
+      n = mhx::count_extract(c, k);
+      S = mhx::count_stride(k);
+    } else if (stage == MHX_STAGE_SEQ2SDBG) {
+      n = mhx::seq2sdbg_extract(c, k);
+      S = mhx::seq2sdbg_stride(k);
     } else if (stage == MHX_STAGE_S2) {
       // every rank must take the same path: the aggregated one needs stage 1 to have run with this (k, m) on
       // all ranks, which the (k <= 22, m >= 2) rule makes a pure function of the arguments
@@ -570,13 +577,85 @@ void *mhx_dist_recv_buffer(mhx_ctx *c, uint64_t n_items, uint32_t item_bytes) {
     return nullptr;
   }
 }
-int mhx_dist_process_s1(mhx_ctx *c, uint32_t k, uint32_t min_count, uint64_t n_items, mhx_s1_result *out) {
+int mhx_dist_process_s1(mhx_ctx *c, uint32_t k, uint32_t min_count, int want_mercy, uint64_t n_items, mhx_s1_result *out) {
   MHX_TRY({
     MHX_HIP(hipSetDevice(c->device));
-    const int S = mhx::s1_stride(k, mhx::s1_compact(c, 0));
+    const int S = mhx::s1_stride(k, mhx::s1_compact(c, want_mercy));
     uint32_t *a = c->ws("items_recv", n_items * (size_t)S * 4 + 64).as<uint32_t>();
     uint32_t *b = c->ws("items_b", n_items * (size_t)S * 4 + 64).as<uint32_t>();
-    mhx::s1_process(c, k, min_count, 0, a, b, n_items, out);
+    mhx::s1_process(c, k, min_count, want_mercy, a, b, n_items, out);
+  })
+}
+int mhx_dist_process_count(mhx_ctx *c, uint32_t k, uint32_t min_count, uint64_t n_items, mhx_count_result *out) {
+  MHX_TRY({
+    MHX_HIP(hipSetDevice(c->device));
+    if (!c->global_bases) throw mhx::Error("dist_process_count: call mhx_set_global_layout first");
+    const int S = mhx::count_stride(k);
+    uint32_t *a = c->ws("items_recv", n_items * (size_t)S * 4 + 64).as<uint32_t>();
+    uint32_t *b = c->ws("items_b", n_items * (size_t)S * 4 + 64).as<uint32_t>();
+    mhx::count_process(c, k, min_count, a, b, n_items, out);
+  })
+}
+int mhx_dist_process_seq2sdbg(mhx_ctx *c, uint32_t k, uint64_t n_items, mhx_sdbg_result *out) {
+  MHX_TRY({
+    MHX_HIP(hipSetDevice(c->device));
+    const int S = mhx::seq2sdbg_stride(k);
+    uint32_t *a = c->ws("items_recv", n_items * (size_t)S * 4 + 64).as<uint32_t>();
+    uint32_t *b = c->ws("items_b", n_items * (size_t)S * 4 + 64).as<uint32_t>();
+    mhx::seq2sdbg_process(c, k, a, b, n_items, out);
+  })
+}
+// first record whose position (value >> shift) is >= r * stride, r = 0..n_parts
+__global__ void k_route_bounds(const unsigned long long *__restrict__ v, uint64_t n, int shift, uint64_t stride, int n_parts,
+                               uint64_t *__restrict__ bounds) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r > n_parts) return;
+  const uint64_t key = (uint64_t)r * stride;
+  uint64_t lo = 0, hi = n;
+  while (lo < hi) {
+    const uint64_t mid = (lo + hi) >> 1;
+    if ((v[mid] >> shift) < key) lo = mid + 1;
+    else hi = mid;
+  }
+  bounds[r] = r == n_parts ? n : lo;
+}
+int mhx_dist_route_records(mhx_ctx *c, int which, uint64_t stride_bases, mhx_dist_items *out, uint64_t *counts) {
+  MHX_TRY({
+    MHX_HIP(hipSetDevice(c->device));
+    if (!stride_bases || c->n_parts < 1) throw mhx::Error("dist_route_records: bad stride or no partition");
+    void *p = nullptr;
+    uint64_t n = 0;
+    int shift = 0;
+    if (which == MHX_ROUTE_COUNT_EVENTS) {
+      p = c->ws("route_records", 64).p;
+      n = c->n_route;
+      shift = 1;
+    } else if (which == MHX_ROUTE_MERCY_CAND) {
+      auto it = c->results.find(MHX_BUF_MERCY_CAND);
+      if (it == c->results.end()) throw mhx::Error("dist_route_records: no mercy candidates");
+      p = it->second.p;
+      n = it->second.used / 8;
+      shift = 2;
+    } else throw mhx::Error("dist_route_records: unknown record kind");
+    uint64_t *bounds = c->ws("route_bounds", (c->n_parts + 2) * 8).as<uint64_t>();
+    hipLaunchKernelGGL(k_route_bounds, dim3((c->n_parts + 1 + 63) / 64), dim3(64), 0, c->stream, (const unsigned long long *)p, n, shift,
+                       stride_bases, c->n_parts, bounds);
+    std::vector<uint64_t> h(c->n_parts + 1);
+    MHX_HIP(hipMemcpyAsync(h.data(), bounds, (c->n_parts + 1) * 8, hipMemcpyDeviceToHost, c->stream));
+    MHX_HIP(hipStreamSynchronize(c->stream));
+    for (int r = 0; r < c->n_parts; ++r) counts[r] = h[r + 1] - h[r];
+    out->d_items = p;
+    out->n_items = n;
+    out->item_bytes = 8;
+  })
+}
+int mhx_dist_apply_routed(mhx_ctx *c, int which, uint64_t n_records) {
+  MHX_TRY({
+    MHX_HIP(hipSetDevice(c->device));
+    void *recv = c->ws("items_recv", n_records * 8 + 64).p;
+    if (which == MHX_ROUTE_COUNT_EVENTS) mhx::count_apply_events(c, (const unsigned long long *)recv, n_records);
+    else if (which == MHX_ROUTE_MERCY_CAND) mhx::mercy_adopt_routed(c, (const long long *)recv, n_records);
+    else throw mhx::Error("dist_apply_routed: unknown record kind");
   })
 }
 int mhx_dist_process_s2(mhx_ctx *c, uint32_t k, uint64_t n_items, mhx_sdbg_result *out) {

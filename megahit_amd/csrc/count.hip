@@ -26,7 +26,7 @@ __global__ void k_seq_item_counts(const uint64_t *__restrict__ start, uint64_t n
 template <int KW, int S>
 __global__ __launch_bounds__(256) void k_count_extract(const uint32_t *__restrict__ seq, const uint64_t *__restrict__ start,
                                                        const uint64_t *__restrict__ item_start, uint64_t n_seqs, int k,
-                                                       uint32_t *__restrict__ items) {
+                                                       uint64_t pos_base, uint32_t *__restrict__ items) {
   const int lane = lane_id();
   const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / kWave;
   const uint64_t n_waves = (uint64_t)gridDim.x * blockDim.x / kWave;
@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void k_count_extract(const uint32_t *__restric
       const int strand = cmp_words<KW>(rc, e) < 0;  // rev_edge.cmp(edge) < 0, kmer_counter.cpp:179
       unsigned prev = p > 0 ? base_at(seq, st + p - 1) : kSentinel;
       unsigned next = p + k + 1 < L ? base_at(seq, st + p + k + 1) : kSentinel;
-      const uint64_t full = ((st + p) << 1) | (uint64_t)strand;
+      const uint64_t full = ((pos_base + st + p) << 1) | (uint64_t)strand;
       uint64_t info;
       uint32_t out[S];
       if (!strand) {
@@ -110,6 +110,10 @@ struct CountOp {
   uint32_t *first_0_out, *last_0_in_p1;
   unsigned long long *hist, *bucket_count;
   uint32_t *edges;
+  // multi-GPU: the reads of an item may live on another rank, so the first_0_out / last_0_in updates are recorded as
+  // events ((global position << 1) | which; 0: last_0_in = max(offset), 1: first_0_out = min(offset + 1)) and
+  // routed to the rank holding the read (mhx_dist_route_records / mhx_dist_apply_routed)
+  unsigned long long *events, *n_events;
 
   __device__ bool same_run(const uint32_t *, const uint32_t *) const { return true; }
   __device__ bool item_phase_enabled() const { return side_effects != 0; }
@@ -163,6 +167,11 @@ struct CountOp {
     const uint64_t info = (((uint64_t)c.acc.word(rel, kw) << 32) | c.acc.word(rel, kw + 1)) >> 6;
     const uint64_t abs = info >> 1;
     const unsigned strand = (unsigned)(info & 1);
+    if (events) {
+      if (f & 1u) events[atomicAdd(n_events, 1ull)] = (abs << 1) | (strand == 0 ? 0u : 1u);
+      if (f & 2u) events[atomicAdd(n_events, 1ull)] = (abs << 1) | (strand == 0 ? 1u : 0u);
+      return;
+    }
     const uint64_t rid = seq_of_offset(start, n_seqs, fixed_len, abs);
     const uint32_t off = (uint32_t)(abs - start[rid]);
     if (f & 1u) {  // !has_in: strand 0 -> last_0_in = max(off), strand 1 -> first_0_out = min(off+1)
@@ -186,6 +195,19 @@ struct CountOp {
   }
 };
 
+// routed events -> first_0_out / last_0_in of the local reads
+__global__ void k_apply_count_events(const unsigned long long *__restrict__ ev, uint64_t n, uint64_t pos_base,
+                                     const uint64_t *__restrict__ start, uint64_t n_seqs, uint32_t fixed_len,
+                                     uint32_t *__restrict__ first_0_out, uint32_t *__restrict__ last_0_in_p1) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t abs = (ev[i] >> 1) - pos_base;
+  const uint64_t rid = seq_of_offset(start, n_seqs, fixed_len, abs);
+  const uint32_t off = (uint32_t)(abs - start[rid]);
+  if (ev[i] & 1ull) atomicMin(&first_0_out[rid], off + 1);
+  else atomicMax(&last_0_in_p1[rid], off + 1);
+}
+
 __global__ void k_fix_last(uint32_t *__restrict__ last_p1, uint64_t n) {
   uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) last_p1[i] = last_p1[i] - 1u;  // 0 (unset) -> 0xFFFFFFFF sentinel, v+1 -> v
@@ -194,7 +216,7 @@ __global__ void k_fix_last(uint32_t *__restrict__ last_p1, uint64_t n) {
 template <int S>
 static void count_postprocess(mhx_ctx *c, const uint32_t *sorted, uint64_t n_items, int KWv, int key_bits, uint32_t m, int wpe,
                               uint32_t *first, uint32_t *last, unsigned long long *hist, unsigned long long *bcount, uint64_t *n_runs,
-                              uint64_t *n_edges) {
+                              uint64_t *n_edges, unsigned long long *events, unsigned long long *n_events) {
   SeqSet &s = c->seqs;
   hipStream_t st = c->stream;
   *n_runs = *n_edges = 0;
@@ -209,7 +231,7 @@ static void count_postprocess(mhx_ctx *c, const uint32_t *sorted, uint64_t n_ite
   uint64_t *tb = c->ws("tile_base", (3 * n_tiles + 4) * 8).as<uint64_t>();
   const int full_words = key_bits / 32, rem = key_bits % 32;
   const uint32_t last_mask = rem ? 0xFFFFFFFFu << (32 - rem) : 0;
-  CountOp<S> op{KWv, wpe, m, 1, s.start.as<uint64_t>(), s.n_seqs, s.fixed_len, first, last, hist, bcount, nullptr};
+  CountOp<S> op{KWv, wpe, m, 1, s.start.as<uint64_t>(), s.n_seqs, s.fixed_len, first, last, hist, bcount, nullptr, events, n_events};
   const double bytes = (double)n_items * S * 4;
   MHX_LAUNCH(c, "count_runs", bytes,
              hipLaunchKernelGGL((k_tile_groups<S, T, CountOp<S>, false>), dim3((unsigned)n_tiles), dim3(kTileThreads), 0, st, sorted, n_items,
@@ -233,15 +255,16 @@ static void count_postprocess(mhx_ctx *c, const uint32_t *sorted, uint64_t n_ite
 }
 
 // ---------------------------------------------------------------------------
-int run_count(mhx_ctx *c, uint32_t k, uint32_t m, mhx_count_result *out) {
+static int count_kw(uint32_t k) { return (int)div_ceil((k + 1) * 2, 32); }
+int count_stride(uint32_t k) { return round_up2(count_kw(k) + 2); }
+
+// items of the local reads -> c->ws("items_a"); returns their number
+uint64_t count_extract(mhx_ctx *c, uint32_t k) {
   SeqSet &s = c->seqs;
   if (k < 9 || k > MHX_MAX_K) throw Error("count: k out of range [9,255]");
-  const int KWv = (int)div_ceil((k + 1) * 2, 32);
-  const int S = round_up2(KWv + 2);
-  const int wpe = (int)div_ceil((k + 1) * 2 + 16, 32);
+  const int KWv = count_kw(k), S = count_stride(k);
   const uint64_t ns = s.n_seqs;
   hipStream_t st = c->stream;
-
   // per-read item counts -> item_start
   uint32_t *cnt = c->ws("seq_item_cnt", (ns + 1) * 4).as<uint32_t>();
   uint64_t *item_start = c->ws("seq_item_start", (ns + 2) * 8).as<uint64_t>();
@@ -255,25 +278,36 @@ int run_count(mhx_ctx *c, uint32_t k, uint32_t m, mhx_count_result *out) {
     MHX_HIP(hipMemcpyAsync(&n_items, d_total, 8, hipMemcpyDeviceToHost, st));
     MHX_HIP(hipStreamSynchronize(st));
   }
-
   const size_t item_bytes = (size_t)S * 4;
   uint32_t *buf_a = c->ws("items_a", n_items * item_bytes + 64).as<uint32_t>();
-  uint32_t *buf_b = c->ws("items_b", n_items * item_bytes + 64).as<uint32_t>();
   if (n_items) {
     const unsigned grid = 256 * 8;
     MHX_DISPATCH_KW(KWv, {
       if (S == KW + 2)
         MHX_LAUNCH(c, "count_extract", (double)n_items * item_bytes + (double)s.n_bases / 4,
                    hipLaunchKernelGGL((k_count_extract<KW, KW + 2>), dim3(grid), dim3(256), 0, st, s.words.as<uint32_t>(),
-                                      s.start.as<uint64_t>(), item_start, ns, (int)k, buf_a));
+                                      s.start.as<uint64_t>(), item_start, ns, (int)k, c->pos_base, buf_a));
       else
         MHX_LAUNCH(c, "count_extract", (double)n_items * item_bytes + (double)s.n_bases / 4,
                    hipLaunchKernelGGL((k_count_extract<KW, KW + 3>), dim3(grid), dim3(256), 0, st, s.words.as<uint32_t>(),
-                                      s.start.as<uint64_t>(), item_start, ns, (int)k, buf_a));
+                                      s.start.as<uint64_t>(), item_start, ns, (int)k, c->pos_base, buf_a));
     });
   }
+  return n_items;
+}
+
+// sort + run reduction of n_items items held in buf_a (buf_b = ping-pong space of the same size)
+int count_process(mhx_ctx *c, uint32_t k, uint32_t m, uint32_t *buf_a, uint32_t *buf_b, uint64_t n_items, mhx_count_result *out) {
+  SeqSet &s = c->seqs;
+  const int KWv = count_kw(k), S = count_stride(k);
+  const int wpe = (int)div_ceil((k + 1) * 2 + 16, 32);
+  const uint64_t ns = s.n_seqs;
+  const size_t item_bytes = (size_t)S * 4;
+  hipStream_t st = c->stream;
+  const bool global = c->global_bases != 0;
   const int key_bits = (int)(k + 1) * 2;
   uint32_t *sorted = radix_sort(c, buf_a, buf_b, n_items, S, KWv, make_passes(KWv, KWv * 32 - key_bits, KWv * 32));
+  uint32_t *spare = sorted == buf_a ? buf_b : buf_a;
 
   // results
   uint32_t *first = c->result(MHX_BUF_FIRST_0_OUT, (ns ? ns : 1) * 4).as<uint32_t>();
@@ -286,24 +320,35 @@ int run_count(mhx_ctx *c, uint32_t k, uint32_t m, mhx_count_result *out) {
   MHX_HIP(hipMemsetAsync(last, 0x00, (ns ? ns : 1) * 4, st));
   MHX_HIP(hipMemsetAsync(hist, 0, (MHX_MAX_MUL + 1) * 8, st));
   MHX_HIP(hipMemsetAsync(bcount, 0, MHX_NUM_BUCKETS * 8, st));
+  // multi-GPU: at most 2 events of 8 bytes per item fit the spare sort buffer (records are >= 16 bytes)
+  unsigned long long *events = global ? reinterpret_cast<unsigned long long *>(spare) : nullptr;
+  unsigned long long *ev_n = c->ws("count_ev_n", 64).as<unsigned long long>();
+  MHX_HIP(hipMemsetAsync(ev_n, 0, 8, st));
 
   uint64_t n_runs = 0, n_edges = 0;
   switch (S) {
 #define MHX_CASE(SV) \
-  case SV: count_postprocess<SV>(c, sorted, n_items, KWv, key_bits, m, wpe, first, last, hist, bcount, &n_runs, &n_edges); break;
+  case SV: count_postprocess<SV>(c, sorted, n_items, KWv, key_bits, m, wpe, first, last, hist, bcount, &n_runs, &n_edges, events, ev_n); break;
     MHX_CASE(4) MHX_CASE(6) MHX_CASE(8) MHX_CASE(10) MHX_CASE(12) MHX_CASE(14) MHX_CASE(16) MHX_CASE(18) MHX_CASE(20)
 #undef MHX_CASE
     default: throw Error("count: unsupported record stride");
   }
-  if (ns)
+  if (global) {  // events -> sorted by position in ws("route_records"); first/last are finished by mhx_dist_apply_routed
+    unsigned long long h = 0;
+    MHX_HIP(hipMemcpyAsync(&h, ev_n, 8, hipMemcpyDeviceToHost, st));
+    MHX_HIP(hipStreamSynchronize(st));
+    int hi_bit = 2;
+    while (hi_bit < 64 && ((c->global_bases << 1) >> hi_bit)) ++hi_bit;
+    stash_route_records(c, events, h, hi_bit);
+  } else if (ns) {
     MHX_LAUNCH(c, "fix_last", (double)ns * 8,
                hipLaunchKernelGGL(k_fix_last, dim3((unsigned)div_ceil(ns, 256)), dim3(256), 0, st, last, ns));
+  }
 
   // expose the sorted items for tests (no copy: alias the workspace)
   mhx::DevBuf &si = c->results[MHX_BUF_SORTED_ITEMS];
   si.release();
   c->sorted_item_words = S;
-  c->work["sorted_alias"].p = nullptr;  // marker only
   c->results[MHX_BUF_SORTED_ITEMS].p = sorted;
   c->results[MHX_BUF_SORTED_ITEMS].cap = 0;  // cap 0 = not owned
   c->results[MHX_BUF_SORTED_ITEMS].used = n_items * item_bytes;
@@ -317,6 +362,32 @@ int run_count(mhx_ctx *c, uint32_t k, uint32_t m, mhx_count_result *out) {
     out->item_words = S;
   }
   return 0;
+}
+
+// received events (device, n of them) -> first_0_out / last_0_in of the local reads
+void count_apply_events(mhx_ctx *c, const unsigned long long *ev, uint64_t n) {
+  SeqSet &s = c->seqs;
+  hipStream_t st = c->stream;
+  auto itf = c->results.find(MHX_BUF_FIRST_0_OUT), itl = c->results.find(MHX_BUF_LAST_0_IN);
+  if (itf == c->results.end() || itl == c->results.end() || itf->second.used != s.n_seqs * 4)
+    throw Error("dist_apply_routed: run mhx_dist_process_count first");
+  if (n)
+    MHX_LAUNCH(c, "count_apply_events", (double)n * 24,
+               hipLaunchKernelGGL(k_apply_count_events, dim3((unsigned)div_ceil(n, 256)), dim3(256), 0, st, ev, n, c->pos_base,
+                                  s.start.as<uint64_t>(), s.n_seqs, s.fixed_len, itf->second.as<uint32_t>(), itl->second.as<uint32_t>()));
+  if (s.n_seqs)
+    MHX_LAUNCH(c, "fix_last", (double)s.n_seqs * 8,
+               hipLaunchKernelGGL(k_fix_last, dim3((unsigned)div_ceil(s.n_seqs, 256)), dim3(256), 0, st, itl->second.as<uint32_t>(), s.n_seqs));
+  MHX_HIP(hipStreamSynchronize(st));
+}
+
+int run_count(mhx_ctx *c, uint32_t k, uint32_t m, mhx_count_result *out) {
+  if (c->global_bases) throw Error("count: the global layout is set; use the mhx_dist_* entry points (or mhx_set_global_layout(0, 0))");
+  const uint64_t n_items = count_extract(c, k);
+  const size_t item_bytes = (size_t)count_stride(k) * 4;
+  uint32_t *buf_a = c->work["items_a"].as<uint32_t>();
+  uint32_t *buf_b = c->ws("items_b", n_items * item_bytes + 64).as<uint32_t>();
+  return count_process(c, k, m, buf_a, buf_b, n_items, out);
 }
 
 }  // namespace mhx

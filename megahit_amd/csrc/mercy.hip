@@ -56,12 +56,33 @@ __global__ __launch_bounds__(256) void k_s1_mercy(const long long *__restrict__ 
   if (added) atomicAdd(num_mercy, added);
 }
 
+__global__ void k_rebase_cands(long long *__restrict__ v, uint64_t n, long long delta) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) v[i] -= delta;
+}
+
+// multi-GPU: candidates routed to this rank (global positions, one sorted run per source rank) -> sorted, local positions
+void mercy_adopt_routed(mhx_ctx *c, const long long *recv, uint64_t n) {
+  hipStream_t st = c->stream;
+  DevBuf &res = c->result(MHX_BUF_MERCY_CAND_LOCAL, n * 8 + 8);
+  res.used = n * 8;
+  if (n) {
+    int hi_bit = 3;
+    while (hi_bit < 64 && ((c->global_bases << 2) >> hi_bit)) ++hi_bit;
+    const uint64_t *sorted = sort_u64(c, recv, n, hi_bit);
+    MHX_HIP(hipMemcpyAsync(res.p, sorted, n * 8, hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL(k_rebase_cands, dim3((unsigned)div_ceil(n, 256)), dim3(256), 0, st, res.as<long long>(), n, (long long)(c->pos_base << 2));
+  }
+  MHX_HIP(hipStreamSynchronize(st));
+}
+
 int run_s1_mercy(mhx_ctx *c, uint32_t k, uint64_t *num_mercy) {
   SeqSet &s = c->seqs;
   c->agg_valid = false;  // mercy turns non-solid occurrences solid: stage 2 must look at every occurrence again
   hipStream_t st = c->stream;
-  auto itc = c->results.find(MHX_BUF_MERCY_CAND);
-  auto its = c->results.find(MHX_BUF_IS_SOLID);
+  // multi-GPU: the local slice of the bitmap and the candidates routed to this rank
+  auto itc = c->results.find(c->global_bases ? MHX_BUF_MERCY_CAND_LOCAL : MHX_BUF_MERCY_CAND);
+  auto its = c->results.find(c->global_bases ? MHX_BUF_IS_SOLID_LOCAL : MHX_BUF_IS_SOLID);
   if (its == c->results.end() || its->second.used < div_ceil(s.n_bases, 64) * 8) throw Error("add_mercy: no is_solid bitmap");
   if (itc == c->results.end()) throw Error("add_mercy: no mercy candidates (run mhx_read2sdbg_s1 with want_mercy)");
   const uint64_t n = itc->second.used / 8;

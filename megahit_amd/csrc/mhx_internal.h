@@ -84,6 +84,7 @@ struct mhx_ctx {
   bool agg_valid = false;
   uint32_t agg_k = 0, agg_m = 0;
   uint64_t agg_n = 0;
+  uint64_t n_route = 0;      // multi-GPU: records in ws("route_records") (count events)
   bool dist_s2_agg = false;  // the items of the current multi-GPU stage-2 exchange are aggregated ones
   // profiling
   bool profiling = false;
@@ -160,6 +161,17 @@ bool s2_use_aggregated(const mhx_ctx *c, uint32_t k, uint32_t m);
 uint64_t s2_agg_extract(mhx_ctx *c, uint32_t k);
 int s2_agg_process(mhx_ctx *c, uint32_t k, uint32_t *buf_a, uint32_t *buf_b, uint64_t n_items, mhx_sdbg_result *out);
 constexpr int MHX_BUF_IS_SOLID_LOCAL = 100;  // internal: this rank's slice of the global bitmap (multi-GPU)
+constexpr int MHX_BUF_MERCY_CAND_LOCAL = 101;  // internal: routed mercy candidates of the local reads, local positions
+uint64_t count_extract(mhx_ctx *c, uint32_t k);
+int count_stride(uint32_t k);
+int count_process(mhx_ctx *c, uint32_t k, uint32_t m, uint32_t *buf_a, uint32_t *buf_b, uint64_t n_items, mhx_count_result *out);
+void count_apply_events(mhx_ctx *c, const unsigned long long *ev, uint64_t n);
+uint64_t seq2sdbg_extract(mhx_ctx *c, uint32_t k);
+int seq2sdbg_stride(uint32_t k);
+int seq2sdbg_process(mhx_ctx *c, uint32_t k, uint32_t *buf_a, uint32_t *buf_b, uint64_t n_items, mhx_sdbg_result *out);
+const uint64_t *sort_u64(mhx_ctx *c, const void *src, uint64_t n, int hi_bit);
+void stash_route_records(mhx_ctx *c, const void *src, uint64_t n, int hi_bit);
+void mercy_adopt_routed(mhx_ctx *c, const long long *recv, uint64_t n);
 
 // ---- engines ----
 int run_count(mhx_ctx *c, uint32_t k, uint32_t m, mhx_count_result *out);

@@ -292,9 +292,9 @@ struct S1Op {
     if (!COMPACT && want_mercy) {
       const unsigned has_in = (ri >> 1) & 15u, has_out = (ri >> 5) & 15u, l_has_out = (ri >> 9) & 15u, r_has_in = (ri >> 13) & 15u;
       const unsigned ht = c.acc.word(rel, kw - 1) & 63u, h = ht >> 3, t = ht & 7;
-      const uint64_t rid = seq_of_offset(start, n_seqs, fixed_len, abs);
-      const long long base = (long long)start[rid];
-      const long long off = (long long)abs - base - 1;
+      // ((pkg_offset + l_offset) << 2 | flag, :466-551) with l_offset/r_offset = the item's offset in its read (+1 on
+      // the far side): pkg_offset + offset = abs - 1, so the read itself is never looked up
+      const long long base = 0, off = (long long)abs - 1;
       const long long l_off = strand == 0 ? off : off + 1, r_off = strand == 0 ? off + 1 : off;
       long long c0 = -1, c1 = -1;
       if (solid) {  // :466-483
@@ -425,6 +425,28 @@ __global__ void k_swap_words(uint32_t *__restrict__ v, uint64_t n) {
   }
 }
 
+// numeric sort of n 64-bit records on the device: swap to (hi,lo) words, record sort with 2 key words, swap back.
+// Returns a pointer into the workspace ("u64_sort_a" / "u64_sort_b") holding the sorted copy.
+const uint64_t *sort_u64(mhx_ctx *c, const void *src, uint64_t n, int hi_bit) {
+  hipStream_t st = c->stream;
+  uint32_t *ma = c->ws("u64_sort_a", n * 8 + 64).as<uint32_t>();
+  uint32_t *mb = c->ws("u64_sort_b", n * 8 + 64).as<uint32_t>();
+  if (!n) return reinterpret_cast<const uint64_t *>(ma);
+  MHX_HIP(hipMemcpyAsync(ma, src, n * 8, hipMemcpyDeviceToDevice, st));
+  const unsigned g2 = (unsigned)div_ceil(n, 256);
+  hipLaunchKernelGGL(k_swap_words, dim3(g2), dim3(256), 0, st, ma, n);
+  uint32_t *ms = radix_sort(c, ma, mb, n, 2, 2, make_passes(2, 0, hi_bit));
+  hipLaunchKernelGGL(k_swap_words, dim3(g2), dim3(256), 0, st, ms, n);
+  return reinterpret_cast<const uint64_t *>(ms);
+}
+// multi-GPU: position-keyed records (count events, mercy candidates) waiting to be routed to the ranks that hold the reads
+void stash_route_records(mhx_ctx *c, const void *src, uint64_t n, int hi_bit) {
+  const uint64_t *sorted = sort_u64(c, src, n, hi_bit);
+  DevBuf &r = c->ws("route_records", n * 8 + 64);
+  if (n) MHX_HIP(hipMemcpyAsync(r.p, sorted, n * 8, hipMemcpyDeviceToDevice, c->stream));
+  c->n_route = n;
+}
+
 // ---- host driver, in two halves so that the multi-GPU path can exchange items in between ----
 static int s1_kw(uint32_t k) { return (int)div_ceil((k - 1) * 2 + 6, 32); }  // read_to_sdbg_s1.cpp:107-108
 // compact 1-word aux when no mercy candidates are wanted and positions fit 32 bits
@@ -486,7 +508,6 @@ int s1_process(mhx_ctx *c, uint32_t k, uint32_t m, int want_mercy, uint32_t *buf
   const size_t item_bytes = (size_t)S * 4;
   hipStream_t st = c->stream;
   const bool global = c->global_bases != 0;  // multi-GPU: positions index the global read set
-  if (global && want_mercy) throw Error("read2sdbg_s1: mercy candidates are not supported in multi-GPU mode");
   const int kmer_bits = (int)(k - 1) * 2;
   // want_mercy == 2: records with equal keys in exactly the order the reference's kmsort leaves them (H1)
   uint32_t *sorted = want_mercy == 2
@@ -587,16 +608,9 @@ int s1_process(mhx_ctx *c, uint32_t k, uint32_t m, int want_mercy, uint32_t *buf
     n_solid = h[0];
     n_mercy = h[1];
     if (want_mercy && n_mercy) {
-      // sort the candidates numerically: swap to (hi,lo), record sort with 2 key words, swap back
-      uint32_t *ma = c->ws("mercy_a", n_mercy * 8 + 64).as<uint32_t>();
-      uint32_t *mb = c->ws("mercy_b", n_mercy * 8 + 64).as<uint32_t>();
-      MHX_HIP(hipMemcpyAsync(ma, mercy, n_mercy * 8, hipMemcpyDeviceToDevice, st));
-      const unsigned g2 = (unsigned)div_ceil(n_mercy, 256);
-      hipLaunchKernelGGL(k_swap_words, dim3(g2), dim3(256), 0, st, ma, n_mercy);
       int hi_bit = 3;
-      while (hi_bit < 64 && ((s.n_bases << 2) >> hi_bit)) ++hi_bit;
-      uint32_t *ms = radix_sort(c, ma, mb, n_mercy, 2, 2, make_passes(2, 0, hi_bit));
-      hipLaunchKernelGGL(k_swap_words, dim3(g2), dim3(256), 0, st, ms, n_mercy);
+      while (hi_bit < 64 && ((n_bits << 2) >> hi_bit)) ++hi_bit;
+      const uint64_t *ms = sort_u64(c, mercy, n_mercy, hi_bit);
       DevBuf &res = c->result(MHX_BUF_MERCY_CAND, n_mercy * 8);
       MHX_HIP(hipMemcpyAsync(res.p, ms, n_mercy * 8, hipMemcpyDeviceToDevice, st));
     }

@@ -196,67 +196,82 @@ __device__ __forceinline__ unsigned s2d_items_at(const uint32_t *__restrict__ se
   return ((left ? 1u : 0u) + (right ? 1u : 0u)) * (pal ? 1u : 2u);
 }
 
-__global__ __launch_bounds__(256) void k_s2d_count(const uint32_t *__restrict__ seq, const uint64_t *__restrict__ start, uint64_t n_seqs, int k,
-                                                   const unsigned long long *__restrict__ solid, uint32_t *__restrict__ cnt) {
-  const int lane = lane_id();
-  const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / kWave;
-  const uint64_t n_waves = (uint64_t)gridDim.x * blockDim.x / kWave;
-  for (uint64_t r = wave; r < n_seqs; r += n_waves) {
-    const uint64_t st = start[r];
-    const uint32_t L = (uint32_t)(start[r + 1] - st);
-    uint32_t total = 0;
-    if (L >= (uint32_t)k + 1) {
-      for (uint32_t p0 = 0; p0 < L - k; p0 += kWave) {
-        const uint32_t p = p0 + lane;
-        unsigned mask, c = 0;
-        uint64_t e;
-        if (p < L - k) c = s2d_items_at(seq, solid, st, L, p, k, &mask, &e);
-        total += wave_sum<uint32_t>(c);
-      }
-    }
-    if (lane == 0) cnt[r] = total;
-  }
+// The dummies sit at the ends of the runs of solid positions.  Stage 1 only sets bits where a (k+1)-mer starts, so the
+// bit before a read's first position and the bit after its last (k+1)-mer are 0 and the read-boundary cases of
+// :385-386 / :411-412 are run ends as well: one thread per 64-bit bitmap word finds them with shifts.
+__device__ __forceinline__ void s2d_run_ends(const unsigned long long *__restrict__ solid, uint64_t i, uint64_t n_words,
+                                             unsigned long long *l, unsigned long long *r) {
+  const unsigned long long w = solid[i];
+  const unsigned long long prev = i ? solid[i - 1] >> 63 : 0ull, next = i + 1 < n_words ? solid[i + 1] & 1ull : 0ull;
+  *l = w & ~((w << 1) | prev);
+  *r = w & ~((w >> 1) | (next << 63));
 }
-
-__global__ __launch_bounds__(256) void k_s2d_extract(const uint32_t *__restrict__ seq, const uint64_t *__restrict__ start,
-                                                     const uint64_t *__restrict__ item_start, uint64_t n_seqs, int k,
-                                                     const unsigned long long *__restrict__ solid, uint2 *__restrict__ items) {
-  const int lane = lane_id();
-  const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / kWave;
-  const uint64_t n_waves = (uint64_t)gridDim.x * blockDim.x / kWave;
+// upper bound of the number of dummy items (exact unless palindromes occur)
+__global__ __launch_bounds__(256) void k_s2d_bound(const unsigned long long *__restrict__ solid, uint64_t n_words,
+                                                   unsigned long long *__restrict__ total) {
+  __shared__ uint64_t sm[256 / kWave + 1];
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  uint64_t c = 0;
+  if (i < n_words) {
+    unsigned long long l, r;
+    s2d_run_ends(solid, i, n_words, &l, &r);
+    c = 2ull * (__builtin_popcountll(l) + __builtin_popcountll(r));
+  }
+  uint64_t tot;
+  block_exclusive_sum<uint64_t, 256>(c, sm, &tot);
+  if (threadIdx.x == 0 && tot) atomicAdd(total, (unsigned long long)tot);
+}
+// emission in arbitrary order (the items are sorted next): per block one atomicAdd on the output cursor
+__global__ __launch_bounds__(256) void k_s2d_emit(const uint32_t *__restrict__ seq, const uint64_t *__restrict__ start, uint64_t n_seqs,
+                                                  uint32_t fixed_len, int k, const unsigned long long *__restrict__ solid, uint64_t n_words,
+                                                  uint2 *__restrict__ items, unsigned long long *__restrict__ cursor) {
+  __shared__ uint64_t sm[256 / kWave + 1];
+  __shared__ unsigned long long s_base;
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const uint64_t mask_k = ~0ull << (64 - 2 * k), mask_k1 = ~0ull << (64 - 2 * (k - 1));
-  for (uint64_t r = wave; r < n_seqs; r += n_waves) {
-    const uint64_t st = start[r];
-    const uint32_t L = (uint32_t)(start[r + 1] - st);
-    if (L < (uint32_t)k + 1) continue;
-    uint64_t carry = item_start[r];
-    for (uint32_t p0 = 0; p0 < L - k; p0 += kWave) {
-      const uint32_t p = p0 + lane;
-      unsigned mask = 0, c = 0;
-      uint64_t e = 0;
-      if (p < L - k) c = s2d_items_at(seq, solid, st, L, p, k, &mask, &e);
-      const uint32_t inc = wave_inclusive_sum<uint32_t>(c);
-      const uint32_t tot = __shfl(inc, kWave - 1, kWave);
-      if (c) {
-        uint2 *dst = items + (carry + inc - c);
-        const bool pal = mask & 4u;
-        const uint64_t er = rc64_s2(e, k + 1);
-        auto put = [&](uint64_t key, uint64_t full, uint64_t w) {
-          const uint64_t v = key | (full << 19) | (w << 16) | 1ull;
-          *dst++ = make_uint2((uint32_t)(v >> 32), (uint32_t)v);
-        };
-        if (mask & 1u) {                                                     // left-$ (read_to_sdbg_s2.cpp:387-396, :457-512)
-          put(e & mask_k, 1, kSentinel);                                     //   fwd: e[0..k-1], W = $
-          if (!pal) put((er << 4) & mask_k1, 0, (er >> 60) & 3u);            //   rc : e'[2..k],  W = e'[1]
-        }
-        if (mask & 2u) {                                                     // right-$ (:411-425)
-          put((e << 4) & mask_k1, 0, (e >> 60) & 3u);                        //   fwd: e[2..k],   W = e[1]
-          if (!pal) put(er & mask_k, 1, kSentinel);                          //   rc : e'[0..k-1], W = $
-        }
-      }
-      carry += tot;
+  unsigned long long l = 0, r = 0;
+  if (i < n_words) s2d_run_ends(solid, i, n_words, &l, &r);
+  // pass 1: number of items of this word (palindromes emit the forward item only)
+  uint32_t c = 0;
+  for (unsigned long long cand = l | r; cand; cand &= cand - 1) {
+    const int b = __builtin_ctzll(cand);
+    const uint64_t fo = i * 64 + b;
+    uint32_t w[2];
+    load_chars<2>(seq, fo, k + 1, w);
+    const uint64_t e = ((uint64_t)w[0] << 32) | w[1];
+    const unsigned ends = (unsigned)((l >> b) & 1ull) + (unsigned)((r >> b) & 1ull);
+    c += ends * (e == rc64_s2(e, k + 1) ? 1u : 2u);
+  }
+  uint64_t tot;
+  const uint64_t excl = block_exclusive_sum<uint64_t, 256>((uint64_t)c, sm, &tot);
+  if (threadIdx.x == 0) s_base = tot ? atomicAdd(cursor, (unsigned long long)tot) : 0ull;
+  __syncthreads();
+  if (!c) return;
+  uint2 *dst = items + s_base + excl;
+  for (unsigned long long cand = l | r; cand; cand &= cand - 1) {
+    const int b = __builtin_ctzll(cand);
+    const uint64_t fo = i * 64 + b;
+    uint32_t w[2];
+    load_chars<2>(seq, fo, k + 1, w);
+    const uint64_t e = ((uint64_t)w[0] << 32) | w[1];
+    const uint64_t er = rc64_s2(e, k + 1);
+    const bool pal = e == er;
+    auto put = [&](uint64_t key, uint64_t full, uint64_t wc) {
+      const uint64_t v = key | (full << 19) | (wc << 16) | 1ull;
+      *dst++ = make_uint2((uint32_t)(v >> 32), (uint32_t)v);
+    };
+    if ((l >> b) & 1ull) {                                               // left-$ (read_to_sdbg_s2.cpp:387-396, :457-512)
+      put(e & mask_k, 1, kSentinel);                                     //   fwd: e[0..k-1], W = $
+      if (!pal) put((er << 4) & mask_k1, 0, (er >> 60) & 3u);            //   rc : e'[2..k],  W = e'[1]
+    }
+    if ((r >> b) & 1ull) {                                               // right-$ (:411-425)
+      put((e << 4) & mask_k1, 0, (e >> 60) & 3u);                        //   fwd: e[2..k],   W = e[1]
+      if (!pal) put(er & mask_k, 1, kSentinel);                          //   rc : e'[0..k-1], W = $
     }
   }
+  (void)start;
+  (void)n_seqs;
+  (void)fixed_len;
 }
 
 // ---------------------------------------------------------------------------
@@ -638,24 +653,27 @@ uint64_t s2_agg_extract(mhx_ctx *c, uint32_t k) {
   auto it = c->results.find(c->global_bases ? MHX_BUF_IS_SOLID_LOCAL : MHX_BUF_IS_SOLID);
   if (it == c->results.end() || it->second.used < div_ceil(s.n_bases, 64) * 8) throw Error("read2sdbg_s2: no is_solid bitmap");
   const unsigned long long *solid = it->second.as<unsigned long long>();
-  uint32_t *cnt = c->ws("seq_item_cnt", (ns + 1) * 4).as<uint32_t>();
-  uint64_t *item_start = c->ws("seq_item_start", (ns + 2) * 8).as<uint64_t>();
+  const uint64_t n_words = div_ceil(s.n_bases, 64);
+  unsigned long long *cur = c->ws("s2d_cursor", 64).as<unsigned long long>();
+  MHX_HIP(hipMemsetAsync(cur, 0, 16, st));
+  uint64_t bound = 0;
+  if (n_words) {
+    MHX_LAUNCH(c, "s2_bound", (double)n_words * 8,
+               hipLaunchKernelGGL(k_s2d_bound, dim3((unsigned)div_ceil(n_words, 256)), dim3(256), 0, st, solid, n_words, cur + 1));
+    MHX_HIP(hipMemcpyAsync(&bound, cur + 1, 8, hipMemcpyDeviceToHost, st));
+    MHX_HIP(hipStreamSynchronize(st));
+  }
+  uint32_t *buf_a = c->ws("items_a", (n_agg + bound) * 8 + 64).as<uint32_t>();
+  if (n_agg) MHX_HIP(hipMemcpyAsync(buf_a, c->work["s2_agg_items"].p, n_agg * 8, hipMemcpyDeviceToDevice, st));
   uint64_t n_dummy = 0;
-  const unsigned grid = 256 * 8;
-  if (ns) {
-    MHX_LAUNCH(c, "s2_count", (double)s.n_bases * 3 / 8 + (double)ns * 20,
-               hipLaunchKernelGGL(k_s2d_count, dim3(grid), dim3(256), 0, st, s.words.as<uint32_t>(), s.start.as<uint64_t>(), ns, (int)k, solid, cnt));
-    exclusive_scan_u32_u64(c, cnt, item_start, ns, item_start + ns + 1);
-    MHX_HIP(hipMemcpyAsync(&n_dummy, item_start + ns + 1, 8, hipMemcpyDeviceToHost, st));
+  if (bound) {
+    MHX_LAUNCH(c, "s2_extract", (double)bound * 8 + (double)n_words * 8,
+               hipLaunchKernelGGL(k_s2d_emit, dim3((unsigned)div_ceil(n_words, 256)), dim3(256), 0, st, s.words.as<uint32_t>(),
+                                  s.start.as<uint64_t>(), ns, s.fixed_len, (int)k, solid, n_words, reinterpret_cast<uint2 *>(buf_a) + n_agg, cur));
+    MHX_HIP(hipMemcpyAsync(&n_dummy, cur, 8, hipMemcpyDeviceToHost, st));
     MHX_HIP(hipStreamSynchronize(st));
   }
   const uint64_t n_items = n_agg + n_dummy;
-  uint32_t *buf_a = c->ws("items_a", n_items * 8 + 64).as<uint32_t>();
-  if (n_agg) MHX_HIP(hipMemcpyAsync(buf_a, c->work["s2_agg_items"].p, n_agg * 8, hipMemcpyDeviceToDevice, st));
-  if (n_dummy)
-    MHX_LAUNCH(c, "s2_extract", (double)n_dummy * 8 + (double)s.n_bases * 3 / 8,
-               hipLaunchKernelGGL(k_s2d_extract, dim3(grid), dim3(256), 0, st, s.words.as<uint32_t>(), s.start.as<uint64_t>(), item_start, ns,
-                                  (int)k, solid, reinterpret_cast<uint2 *>(buf_a) + n_agg));
   return n_items;
 }
 // sort by k-mer chars, "full" flag and W (the count bits [0,16) ride along), then emit

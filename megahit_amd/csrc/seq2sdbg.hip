@@ -72,12 +72,15 @@ __global__ __launch_bounds__(256) void k_seq_extract(const uint32_t *__restrict_
   }
 }
 
-int run_seq2sdbg(mhx_ctx *c, uint32_t k, mhx_sdbg_result *out) {
+static int seq2sdbg_kw(uint32_t k) { return (int)div_ceil(k * 2 + 3 + 1 + 16, 32); }  // seq_to_sdbg.cpp:511-513
+int seq2sdbg_stride(uint32_t k) { return round_up2(seq2sdbg_kw(k)); }
+
+// items of the local sequences -> c->ws("items_a"); returns their number
+uint64_t seq2sdbg_extract(mhx_ctx *c, uint32_t k) {
   SeqSet &s = c->seqs;
   if (k < 9 || k > MHX_MAX_K) throw Error("seq2sdbg: kmer size must be >= 9 and <= 255");  // main_sdbg_build.cpp:205-207
   if (s.mult.used < s.n_seqs * 2) throw Error("seq2sdbg: multiplicities not loaded (mhx_load_multiplicity)");
-  const int KWv = (int)div_ceil(k * 2 + 3 + 1 + 16, 32);  // seq_to_sdbg.cpp:511-513
-  const int S = round_up2(KWv);
+  const int KWv = seq2sdbg_kw(k), S = seq2sdbg_stride(k);
   const uint64_t ns = s.n_seqs;
   hipStream_t st = c->stream;
 
@@ -94,7 +97,6 @@ int run_seq2sdbg(mhx_ctx *c, uint32_t k, mhx_sdbg_result *out) {
   const uint32_t fixed_items = (s.fixed_len >= k + 1) ? 2 * (s.fixed_len - k + 2) : 0;
   const size_t item_bytes = (size_t)S * 4;
   uint32_t *buf_a = c->ws("items_a", n_items * item_bytes + 64).as<uint32_t>();
-  uint32_t *buf_b = c->ws("items_b", n_items * item_bytes + 64).as<uint32_t>();
   if (n_items) {
     const unsigned grid = (unsigned)div_ceil(n_items, 256);
     MHX_DISPATCH_KW(KWv, {
@@ -108,10 +110,24 @@ int run_seq2sdbg(mhx_ctx *c, uint32_t k, mhx_sdbg_result *out) {
                                       s.start.as<uint64_t>(), item_start, ns, fixed_items, s.mult.as<uint16_t>(), (int)k, n_items, buf_a));
     });
   }
+  return n_items;
+}
+
+// sort + SdBG emission of n_items items held in buf_a (items carry no positions: any rank can process any bucket)
+int seq2sdbg_process(mhx_ctx *c, uint32_t k, uint32_t *buf_a, uint32_t *buf_b, uint64_t n_items, mhx_sdbg_result *out) {
+  const int KWv = seq2sdbg_kw(k), S = seq2sdbg_stride(k);
   const int char_bits = (int)k * 2;
   uint32_t *sorted = radix_sort(c, buf_a, buf_b, n_items, S, KWv, make_passes_ranges(KWv, {{0, 20}, {KWv * 32 - char_bits, KWv * 32}}));
   emit_sdbg(c, sorted, n_items, S, KWv, k, 1, out);
   return 0;
+}
+
+int run_seq2sdbg(mhx_ctx *c, uint32_t k, mhx_sdbg_result *out) {
+  const uint64_t n_items = seq2sdbg_extract(c, k);
+  const size_t item_bytes = (size_t)seq2sdbg_stride(k) * 4;
+  uint32_t *buf_a = c->work["items_a"].as<uint32_t>();
+  uint32_t *buf_b = c->ws("items_b", n_items * item_bytes + 64).as<uint32_t>();
+  return seq2sdbg_process(c, k, buf_a, buf_b, n_items, out);
 }
 
 }  // namespace mhx

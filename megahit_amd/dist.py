@@ -21,6 +21,11 @@ import torch.distributed as dist
 NUM_BUCKETS = 65536
 STAGE_S1 = 1
 STAGE_S2 = 2
+STAGE_COUNT = 3
+STAGE_SEQ2SDBG = 4
+STAGE_S1_MERCY = 5
+ROUTE_COUNT_EVENTS = 1
+ROUTE_MERCY_CAND = 2
 BUF_IS_SOLID = 6
 
 
@@ -95,31 +100,30 @@ class Exchanger:
         return int(t.item())
 
 
-class DistRead2Sdbg:
-    """read2sdbg (S1 + S2, no mercy) over `world` ranks.  After step(): engine holds this rank's SdBG
-    records (its bucket range) exactly as the single-GPU engine would for those buckets."""
+class _DistBase:
+    """Shared plumbing: bucket partition, global read layout (rank r's bases start at r*stride, stride a multiple of
+    64 bits) and the two kinds of all-to-all (items to bucket owners, position-keyed records back to read owners)."""
 
-    def __init__(self, engine, k, min_count, rank, world, device, bucket_begin=None, staging=None):
-        self.e, self.k, self.m, self.rank, self.world, self.device = engine, k, min_count, rank, world, device
+    def __init__(self, engine, rank, world, device, bucket_begin=None, staging=None, global_layout=True):
+        self.e, self.rank, self.world, self.device = engine, rank, world, device
         self.x = Exchanger(rank, world, device)
         # engines that keep items in GPU memory while the process group is CPU-only (gloo) stage through host
         self.staging = staging
         self.bucket_begin = equal_partition(world) if bucket_begin is None else np.asarray(bucket_begin, dtype=np.uint32)
         engine.set_partition(rank, world, self.bucket_begin)
-        # global read layout: rank r's bases start at r*stride, stride a multiple of 64 bits
-        stride = self.x.max_int(engine.n_bases)
-        self.stride_words = (stride + 63) // 64
-        self.stride = self.stride_words * 64
-        engine.set_global_layout(rank * self.stride, world * self.stride)
+        if global_layout:
+            stride = self.x.max_int(engine.n_bases)
+            self.stride_words = (stride + 63) // 64
+            self.stride = self.stride_words * 64
+            engine.set_global_layout(rank * self.stride, world * self.stride)
 
-    def _alltoall(self, stage):
-        ptr, n_items, item_bytes, counts = self.e.dist_extract(stage, self.k, self.m)
+    def _move(self, ptr, n_items, item_bytes, counts):
         recv_counts = self.x.exchange_counts(counts)
         n_recv = int(recv_counts.sum())
         rptr = self.e.dist_recv_buffer(n_recv, item_bytes)
         send = self.e.as_tensor(ptr, int(n_items) * item_bytes, self.device)
         recv = self.e.as_tensor(rptr, n_recv * item_bytes, self.device)
-        if self.staging == "host":  # GPU engine + gloo group: bounce through pinned host memory
+        if self.staging == "host":  # GPU engine + gloo group: bounce through host memory
             hs, hr = send.cpu(), torch.empty(n_recv * item_bytes, dtype=torch.uint8)
             self.x.exchange_items(hs, counts, hr, recv_counts, item_bytes)
             recv.copy_(hr)
@@ -127,11 +131,61 @@ class DistRead2Sdbg:
             self.x.exchange_items(send, counts, recv, recv_counts, item_bytes)
         return n_recv
 
+    def _alltoall(self, stage, k, m):
+        """items of the local sequences -> their bucket owners"""
+        return self._move(*self.e.dist_extract(stage, k, m))
+
+    def _route(self, which):
+        """position-keyed records of the owned buckets -> the ranks holding those reads"""
+        n = self._move(*self.e.dist_route_records(which, self.stride))
+        self.e.dist_apply_routed(which, n)
+        return n
+
+
+class DistCount(_DistBase):
+    """count over `world` ranks (reference KmerCounter, src/sorting/kmer_counter.cpp).  After step(): the engine holds
+    the solid edges / bucket counts / multiplicity histogram of this rank's bucket range (the histogram is summed over
+    ranks by the caller) and first_0_out / last_0_in of this rank's reads."""
+
+    def __init__(self, engine, k, min_count, rank, world, device, bucket_begin=None, staging=None):
+        super().__init__(engine, rank, world, device, bucket_begin, staging)
+        self.k, self.m = k, min_count
+
+    def step(self):
+        n = self._alltoall(STAGE_COUNT, self.k, self.m)
+        r = self.e.dist_process_count(self.k, self.m, n)
+        self._route(ROUTE_COUNT_EVENTS)
+        return r
+
+
+class DistSeq2Sdbg(_DistBase):
+    """seq2sdbg over `world` ranks (reference SeqToSdbg, src/sorting/seq_to_sdbg.cpp): every rank loads any share of
+    the edges/contigs (+ multiplicities); items carry no positions, so one all-to-all is the whole exchange."""
+
+    def __init__(self, engine, k, rank, world, device, bucket_begin=None, staging=None):
+        super().__init__(engine, rank, world, device, bucket_begin, staging, global_layout=False)
+        self.k = k
+
+    def step(self):
+        n = self._alltoall(STAGE_SEQ2SDBG, self.k, 0)
+        return self.e.dist_process_seq2sdbg(self.k, n)
+
+
+class DistRead2Sdbg(_DistBase):
+    """read2sdbg (S1 [+ mercy] + S2) over `world` ranks.  After step(): engine holds this rank's SdBG
+    records (its bucket range) exactly as the single-GPU engine would for those buckets.
+    need_mercy: 0 none, 1 stable tie order, 2 reference-exact tie order (as mhx_read2sdbg_s1)."""
+
+    def __init__(self, engine, k, min_count, rank, world, device, bucket_begin=None, staging=None, need_mercy=0):
+        super().__init__(engine, rank, world, device, bucket_begin, staging)
+        self.k, self.m, self.need_mercy = k, min_count, int(need_mercy)
+        self.n_mercy = 0
+
     def step(self):
         r1 = None
         if self.m > 1:  # stage 1 is skipped when every edge is solid (reference main_sdbg_build.cpp:139-147)
-            n1 = self._alltoall(STAGE_S1)
-            r1 = self.e.dist_process_s1(self.k, self.m, n1)
+            n1 = self._alltoall(STAGE_S1_MERCY if self.need_mercy else STAGE_S1, self.k, self.m)
+            r1 = self.e.dist_process_s1(self.k, self.m, n1, self.need_mercy)
             n_words = self.world * self.stride_words
             bm = self.e.as_tensor(self.e.device_pointer(BUF_IS_SOLID), n_words * 8, self.device).view(torch.int64)
             if self.staging == "host":
@@ -141,6 +195,9 @@ class DistRead2Sdbg:
                 sl = self.x.sum_bitmap_and_take_slice(bm, self.stride_words)
             self.e.adopt_is_solid_slice(sl.data_ptr(), self.stride_words)
             self._keep = sl
-        n2 = self._alltoall(STAGE_S2)
+            if self.need_mercy:  # candidates -> read owners; the mercy block of Read2SdbgS2::Initialize runs there
+                self._route(ROUTE_MERCY_CAND)
+                self.n_mercy = self.e.read2sdbg_add_mercy(self.k)
+        n2 = self._alltoall(STAGE_S2, self.k, self.m)
         r2 = self.e.dist_process_s2(self.k, n2)
         return r1, r2

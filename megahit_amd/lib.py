@@ -90,8 +90,12 @@ SYMBOLS = {
     "mhx_set_global_layout": (C.c_int, [_P, C.c_uint64, C.c_uint64]),
     "mhx_dist_extract": (C.c_int, [_P, C.c_int, C.c_uint32, C.c_uint32, C.POINTER(DistItems), _P]),
     "mhx_dist_recv_buffer": (_P, [_P, C.c_uint64, C.c_uint32]),
-    "mhx_dist_process_s1": (C.c_int, [_P, C.c_uint32, C.c_uint32, C.c_uint64, C.POINTER(S1Result)]),
+    "mhx_dist_process_s1": (C.c_int, [_P, C.c_uint32, C.c_uint32, C.c_int, C.c_uint64, C.POINTER(S1Result)]),
     "mhx_dist_process_s2": (C.c_int, [_P, C.c_uint32, C.c_uint64, C.POINTER(SdbgResult)]),
+    "mhx_dist_process_count": (C.c_int, [_P, C.c_uint32, C.c_uint32, C.c_uint64, C.POINTER(CountResult)]),
+    "mhx_dist_process_seq2sdbg": (C.c_int, [_P, C.c_uint32, C.c_uint64, C.POINTER(SdbgResult)]),
+    "mhx_dist_route_records": (C.c_int, [_P, C.c_int, C.c_uint64, C.POINTER(DistItems), _P]),
+    "mhx_dist_apply_routed": (C.c_int, [_P, C.c_int, C.c_uint64]),
     "mhx_device_pointer": (_P, [_P, C.c_int]),
     "mhx_adopt_is_solid_slice": (C.c_int, [_P, _P, C.c_uint64]),
     "mhx_profile_enable": (C.c_int, [_P, C.c_int]),
@@ -246,10 +250,30 @@ class Engine:
             raise MhxError(self.lib.mhx_last_error().decode())
         return p
 
-    def dist_process_s1(self, k, m, n_items):
+    def dist_process_s1(self, k, m, n_items, want_mercy=0):
         r = S1Result()
-        self._chk(self.lib.mhx_dist_process_s1(self.h, k, m, n_items, C.byref(r)))
+        self._chk(self.lib.mhx_dist_process_s1(self.h, k, m, int(want_mercy), n_items, C.byref(r)))
         return r
+
+    def dist_process_count(self, k, m, n_items):
+        r = CountResult()
+        self._chk(self.lib.mhx_dist_process_count(self.h, k, m, n_items, C.byref(r)))
+        return r
+
+    def dist_process_seq2sdbg(self, k, n_items):
+        r = SdbgResult()
+        self._chk(self.lib.mhx_dist_process_seq2sdbg(self.h, k, n_items, C.byref(r)))
+        return r
+
+    def dist_route_records(self, which, stride_bases):
+        """-> (device pointer, n_records, 8, counts per read-owning rank)"""
+        out = DistItems()
+        counts = np.zeros(self.n_parts, dtype=np.uint64)
+        self._chk(self.lib.mhx_dist_route_records(self.h, which, stride_bases, C.byref(out), _ptr(counts)))
+        return out.d_items, out.n_items, out.item_bytes, counts
+
+    def dist_apply_routed(self, which, n_records):
+        self._chk(self.lib.mhx_dist_apply_routed(self.h, which, n_records))
 
     def dist_process_s2(self, k, n_items):
         r = SdbgResult()

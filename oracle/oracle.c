@@ -286,23 +286,13 @@ static uint32_t *bucketize(const orc_vec *v, int64_t *starts) {
 /* ------------------------------------------------------------------ */
 /* count  (sorting/kmer_counter.cpp)                                   */
 /* ------------------------------------------------------------------ */
-int orc_count(const orc_pkg *reads, int k, int m, orc_count_out *out) {
-  memset(out, 0, sizeof(*out));
-  const int W = DIVCEIL((k + 1) * 2, 32);               /* kmer_counter.cpp:78-79 */
-  out->words_per_edge = DIVCEIL((k + 1) * 2 + 16, 32);  /* kmer_counter.cpp:80-81 */
-  const int IW = W + 2;
-  uint64_t nr = reads->n_seqs;
-  out->first_0_out = (uint32_t *)malloc((nr ? nr : 1) * 4);
-  out->last_0_in = (uint32_t *)malloc((nr ? nr : 1) * 4);
-  memset(out->first_0_out, 0xFF, (nr ? nr : 1) * 4); /* kmer_counter.cpp:86-89 */
-  memset(out->last_0_in, 0xFF, (nr ? nr : 1) * 4);
-  vec_init(&out->edges, out->words_per_edge);
-
-  /* item enumeration: Lv1FillOffsets (kmer_counter.cpp:158-206) + Lv2ExtractSubString (:208-252) */
-  orc_vec items;
-  vec_init(&items, IW);
+/* item enumeration: Lv1FillOffsets (kmer_counter.cpp:158-206) + Lv2ExtractSubString (:208-252).
+ * pos_base shifts the recorded positions (multi-rank tests: position in the global read set). */
+void orc_count_items(const orc_pkg *reads, int k, uint64_t pos_base, orc_vec *items) {
+  const int W = DIVCEIL((k + 1) * 2, 32); /* kmer_counter.cpp:78-79 */
+  vec_init(items, W + 2);
   uint32_t e[20], r[20];
-  for (uint64_t rid = 0; rid < nr; ++rid) {
+  for (uint64_t rid = 0; rid < reads->n_seqs; ++rid) {
     uint64_t st = reads->start[rid];
     uint32_t L = (uint32_t)(reads->start[rid + 1] - st);
     if (L < (uint32_t)k + 1) continue;
@@ -312,9 +302,9 @@ int orc_count(const orc_pkg *reads, int k, int m, orc_count_out *out) {
       int strand = cmp_words(r, e, W) < 0; /* rev_edge.cmp(edge) < 0 -> strand 1, :179 */
       unsigned prev = p > 0 ? orc_base(reads, st + p - 1) : ORC_SENTINEL;
       unsigned next = p + k + 1 < L ? orc_base(reads, st + p + k + 1) : ORC_SENTINEL;
-      uint64_t full = ((st + p) << 1) | (uint64_t)strand;
+      uint64_t full = ((pos_base + st + p) << 1) | (uint64_t)strand;
       uint64_t info;
-      uint32_t *it = vec_push(&items);
+      uint32_t *it = vec_push(items);
       if (!strand) {
         memcpy(it, e, W * 4);
         info = (full << 6) | (prev << 3) | next;
@@ -326,13 +316,25 @@ int orc_count(const orc_pkg *reads, int k, int m, orc_count_out *out) {
       it[W + 1] = (uint32_t)info;
     }
   }
-  out->n_items = (int64_t)items.n;
+}
 
+/* per bucket: sort + Lv2Postprocess (kmer_counter.cpp:254-381) of the given items (consumed).  The
+ * first_0_out / last_0_in updates are returned as events ((position << 1) | which; which 0: last_0_in =
+ * max(offset), 1: first_0_out = min(offset + 1)) so that a multi-rank test can route them to the rank that
+ * holds the read; orc_count applies them directly. */
+void orc_count_reduce(orc_vec *items, int k, int m, orc_count_out *out, uint64_t **events, uint64_t *n_events) {
+  const int W = DIVCEIL((k + 1) * 2, 32);
+  const int IW = W + 2;
+  out->words_per_edge = DIVCEIL((k + 1) * 2 + 16, 32); /* kmer_counter.cpp:80-81 */
+  vec_init(&out->edges, out->words_per_edge);
+  out->n_items = (int64_t)items->n;
+  uint64_t ev_cap = 1024, ev_n = 0;
+  uint64_t *ev = (uint64_t *)malloc(ev_cap * 8);
   int64_t *starts = (int64_t *)malloc((ORC_NUM_BUCKETS + 1) * sizeof(int64_t));
-  uint32_t *sorted = bucketize(&items, starts);
-  free(items.d);
-
-  /* per bucket: sort + Lv2Postprocess (kmer_counter.cpp:254-381) */
+  uint32_t *sorted = bucketize(items, starts);
+  free(items->d);
+  items->d = NULL;
+  items->n = 0;
   for (int b = 0; b < ORC_NUM_BUCKETS; ++b) {
     int64_t n = starts[b + 1] - starts[b];
     if (!n) continue;
@@ -357,16 +359,10 @@ int orc_count(const orc_pkg *reads, int k, int m, orc_count_out *out) {
         if (count < m || (pass == 0 ? has_in : has_out)) continue;
         for (int64_t j = i; j < to; ++j) {
           uint64_t info = (((uint64_t)s[j * IW + W] << 32) | s[j * IW + W + 1]) >> 6;
-          uint64_t rid = seq_of_offset(reads, info >> 1);
           int strand = (int)(info & 1);
-          uint32_t off = (uint32_t)((info >> 1) - reads->start[rid]);
           int update_last = (pass == 0) ? (strand == 0) : (strand == 1);
-          if (update_last) {
-            uint32_t old = out->last_0_in[rid];
-            if (old == 0xFFFFFFFFu || old < off) out->last_0_in[rid] = off;
-          } else {
-            if (out->first_0_out[rid] > off + 1) out->first_0_out[rid] = off + 1;
-          }
+          if (ev_n == ev_cap) ev = (uint64_t *)realloc(ev, (ev_cap *= 2) * 8);
+          ev[ev_n++] = ((info >> 1) << 1) | (update_last ? 0u : 1u);
         }
       }
       out->hist[count > ORC_MAX_MUL ? ORC_MAX_MUL : count]++; /* edge_counter.h:30-32 */
@@ -380,6 +376,39 @@ int orc_count(const orc_pkg *reads, int k, int m, orc_count_out *out) {
   }
   free(sorted);
   free(starts);
+  *events = ev;
+  *n_events = ev_n;
+}
+
+/* first_0_out / last_0_in of the local reads from events whose positions are relative to pos_base */
+void orc_count_apply_events(const orc_pkg *reads, uint64_t pos_base, const uint64_t *ev, uint64_t n_ev, uint32_t *first_0_out,
+                            uint32_t *last_0_in) {
+  for (uint64_t i = 0; i < n_ev; ++i) {
+    uint64_t abs = (ev[i] >> 1) - pos_base;
+    uint64_t rid = seq_of_offset(reads, abs);
+    uint32_t off = (uint32_t)(abs - reads->start[rid]);
+    if (!(ev[i] & 1)) {
+      uint32_t old = last_0_in[rid];
+      if (old == 0xFFFFFFFFu || old < off) last_0_in[rid] = off;
+    } else {
+      if (first_0_out[rid] > off + 1) first_0_out[rid] = off + 1;
+    }
+  }
+}
+
+int orc_count(const orc_pkg *reads, int k, int m, orc_count_out *out) {
+  memset(out, 0, sizeof(*out));
+  uint64_t nr = reads->n_seqs;
+  out->first_0_out = (uint32_t *)malloc((nr ? nr : 1) * 4);
+  out->last_0_in = (uint32_t *)malloc((nr ? nr : 1) * 4);
+  memset(out->first_0_out, 0xFF, (nr ? nr : 1) * 4); /* kmer_counter.cpp:86-89 */
+  memset(out->last_0_in, 0xFF, (nr ? nr : 1) * 4);
+  orc_vec items;
+  orc_count_items(reads, k, 0, &items);
+  uint64_t *ev, n_ev;
+  orc_count_reduce(&items, k, m, out, &ev, &n_ev);
+  orc_count_apply_events(reads, 0, ev, n_ev, out->first_0_out, out->last_0_in);
+  free(ev);
   return 0;
 }
 void orc_count_free(orc_count_out *o) {
@@ -470,6 +499,12 @@ void orc_s1_items(const orc_pkg *reads, int k, uint64_t pos_base, orc_vec *items
 /* bucket sort + Lv2Postprocess (read_to_sdbg_s1.cpp:368-555) of arbitrary stage-1 items.  reads may be
  * NULL (then no mercy candidates are produced: positions need not belong to a local package). */
 void orc_s1_reduce(const orc_pkg *reads, const orc_vec *items_in, int k, int m, int tie_mode, orc_s1_out *out) {
+  orc_s1_reduce_ex(reads, items_in, k, m, tie_mode, 0, out);
+}
+/* mercy_without_reads: multi-rank tests reduce items whose reads live on another rank; a candidate is
+ * ((pkg_offset + offset) << 2) | flag and pkg_offset + offset = position - 1, so the read need not be known. */
+void orc_s1_reduce_ex(const orc_pkg *reads, const orc_vec *items_in, int k, int m, int tie_mode, int mercy_without_reads,
+                      orc_s1_out *out) {
   const int W = DIVCEIL((k - 1) * 2 + 6, 32);
   const int IW = W + 2;
   out->n_items = (int64_t)items_in->n;
@@ -521,9 +556,9 @@ void orc_s1_reduce(const orc_pkg *reads, const orc_vec *items_in, int k, int m, 
           uint64_t abs = info >> 1;
           int strand = (int)(info & 1);
           if (solid) out->is_solid[(abs - 1) >> 6] |= 1ull << ((abs - 1) & 63); /* :464 */
-          if (!reads) continue;
-          uint64_t rid = seq_of_offset(reads, abs);
-          int64_t base = (int64_t)reads->start[rid];
+          if (!reads && !mercy_without_reads) continue;
+          int64_t base = 0;
+          if (reads) base = (int64_t)reads->start[seq_of_offset(reads, abs)];
           int64_t off = (int64_t)abs - base - 1;
           int64_t l_off = strand == 0 ? off : off + 1, r_off = strand == 0 ? off + 1 : off;
           if (solid) {
@@ -789,10 +824,7 @@ int orc_s2(const orc_pkg *reads, int k, int m, const uint64_t *is_solid, orc_sdb
 /* ------------------------------------------------------------------ */
 /* seq2sdbg  (sorting/seq_to_sdbg.cpp)                                 */
 /* ------------------------------------------------------------------ */
-int orc_seq2sdbg(const orc_pkg *seqs, const uint16_t *mult, int k, orc_sdbg_out *out) {
-  memset(out, 0, sizeof(*out));
-  out->k = k;
-  out->words_per_tip_label = DIVCEIL(k, 16);
+void orc_seq2sdbg_items(const orc_pkg *seqs, const uint16_t *mult, int k, orc_vec *items_out) {
   const int W = DIVCEIL(k * 2 + 3 + 1 + 16, 32); /* seq_to_sdbg.cpp:511-513 */
   orc_vec items;
   vec_init(&items, W);
@@ -822,6 +854,16 @@ int orc_seq2sdbg(const orc_pkg *seqs, const uint16_t *mult, int k, orc_sdbg_out 
       }
     }
   }
+  *items_out = items;
+}
+
+int orc_seq2sdbg(const orc_pkg *seqs, const uint16_t *mult, int k, orc_sdbg_out *out) {
+  memset(out, 0, sizeof(*out));
+  out->k = k;
+  out->words_per_tip_label = DIVCEIL(k, 16);
+  const int W = DIVCEIL(k * 2 + 3 + 1 + 16, 32);
+  orc_vec items;
+  orc_seq2sdbg_items(seqs, mult, k, &items);
   sdbg_run_buckets(out, &items, W, k, 1);
   return 0;
 }

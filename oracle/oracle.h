@@ -70,6 +70,12 @@ typedef struct {
 } orc_count_out;
 int orc_count(const orc_pkg *reads, int k, int m, orc_count_out *out);
 void orc_count_free(orc_count_out *o);
+/* the halves of orc_count, exposed so that tests can exchange items and read events between ranks */
+void orc_count_items(const orc_pkg *reads, int k, uint64_t pos_base, orc_vec *items);
+void orc_count_reduce(orc_vec *items /* consumed */, int k, int m, orc_count_out *out /* zeroed; first/last untouched */,
+                      uint64_t **events, uint64_t *n_events);
+void orc_count_apply_events(const orc_pkg *reads, uint64_t pos_base, const uint64_t *ev, uint64_t n_ev, uint32_t *first_0_out,
+                            uint32_t *last_0_in);
 
 /* ---- read2sdbg stage 1 (sorting/read_to_sdbg_s1.cpp) ---- */
 typedef struct {
@@ -83,6 +89,8 @@ typedef struct {
 int orc_s1(const orc_pkg *reads, int k, int m, int tie_mode, orc_s1_out *out);
 void orc_s1_free(orc_s1_out *o);
 
+void orc_s1_reduce_ex(const orc_pkg *reads, const orc_vec *items, int k, int m, int tie_mode, int mercy_without_reads,
+                      orc_s1_out *out);
 /* the two halves of orc_s1 / orc_s2, exposed so that tests can exchange items between ranks */
 void orc_s1_items(const orc_pkg *reads, int k, uint64_t pos_base, orc_vec *items);
 void orc_s1_reduce(const orc_pkg *reads /* may be NULL: no mercy */, const orc_vec *items, int k, int m, int tie_mode,
@@ -112,6 +120,7 @@ int orc_s2(const orc_pkg *reads, int k, int m, const uint64_t *is_solid, orc_sdb
 void orc_s2_items(const orc_pkg *reads, int k, int m, const uint64_t *is_solid, orc_vec *items);
 /* seq_to_sdbg.cpp:530-789; mult has one entry per sequence */
 int orc_seq2sdbg(const orc_pkg *seqs, const uint16_t *mult, int k, orc_sdbg_out *out);
+void orc_seq2sdbg_items(const orc_pkg *seqs, const uint16_t *mult, int k, orc_vec *items);
 
 /* sort + postprocess + SdbgWriter of arbitrary lv2 items (frees items->d) */
 void orc_sdbg_from_items(orc_vec *items, int k, int is_seq2sdbg, orc_sdbg_out *out);

@@ -16,8 +16,9 @@ class Res:
 
 
 class OracleEngine:
-    def __init__(self, reads):
-        self.pkg = ob.Package(reads, reverse=True)
+    def __init__(self, reads, reverse=True, mult=None):
+        self.pkg = ob.Package(reads, reverse=reverse)
+        self.mult = mult
         self.n_bases = int(self.pkg.start()[-1])
         self.bufs = {}
         self.next_handle = 1
@@ -43,8 +44,12 @@ class OracleEngine:
         self.pos_base, self.global_bases = pos_base, global_bases
 
     def dist_extract(self, stage, k, m):
-        if stage == 1:
+        if stage in (1, 5):
             items = ob.s1_items(self.pkg, k, self.pos_base)
+        elif stage == 3:
+            items = ob.count_items(self.pkg, k, self.pos_base)
+        elif stage == 4:
+            items = ob.seq2sdbg_items(self.pkg, self.mult, k)
         else:
             items = ob.s2_items(self.pkg, k, m, self.local_solid if m > 1 else None)
         owner = self.lut[items[:, 0] >> 16] if len(items) else np.zeros(0, dtype=np.int64)
@@ -64,11 +69,14 @@ class OracleEngine:
         assert which == BUF_IS_SOLID
         return self._new(self.global_bits.view(np.uint8))
 
-    def dist_process_s1(self, k, m, n_items):
+    def dist_process_s1(self, k, m, n_items, want_mercy=0):
         w = (2 * (k - 1) + 6 + 31) // 32 + 2
         items = self.recv.view(np.uint32).reshape(-1, w)[:n_items]
         assert (self.lut[items[:, 0] >> 16] == self.my_part).all()
-        bits, hist = ob.s1_reduce(items, k, m, self.global_bases)
+        if want_mercy:
+            bits, hist, self.mercy_global = ob.s1_reduce_mercy(items, k, m, self.global_bases, tie_stable=want_mercy != 2)
+        else:
+            bits, hist = ob.s1_reduce(items, k, m, self.global_bases)
         self.global_bits = np.ascontiguousarray(bits)
         self.hist = hist
         r = Res()
@@ -88,3 +96,41 @@ class OracleEngine:
         r.n_items = n_items
         r.n_sdbg = int(self.sdbg["bucket_items"].sum())
         return r
+
+    def dist_process_count(self, k, m, n_items):
+        w = (2 * (k + 1) + 31) // 32 + 2
+        items = self.recv.view(np.uint32).reshape(-1, w)[:n_items]
+        assert (self.lut[items[:, 0] >> 16] == self.my_part).all()
+        self.count = ob.count_reduce(items, k, m)
+        r = Res()
+        r.n_items = n_items
+        r.n_edges = len(self.count["edges"])
+        return r
+
+    def dist_process_seq2sdbg(self, k, n_items):
+        w = (2 * k + 20 + 31) // 32
+        items = self.recv.view(np.uint32).reshape(-1, w)[:n_items]
+        assert (self.lut[items[:, 0] >> 16] == self.my_part).all()
+        self.sdbg = ob.sdbg_from_items(items, k, True)
+        r = Res()
+        r.n_items = n_items
+        return r
+
+    def dist_route_records(self, which, stride):
+        rec = np.sort(self.count["events"]) if which == 1 else np.sort(self.mercy_global.astype(np.uint64))
+        shift = 1 if which == 1 else 2
+        owner = ((rec >> np.uint64(shift)) // np.uint64(stride)).astype(np.int64)
+        counts = np.bincount(owner, minlength=self.n_parts).astype(np.uint64)
+        assert len(counts) == self.n_parts
+        return self._new(np.ascontiguousarray(rec).view(np.uint8).reshape(-1)), len(rec), 8, counts
+
+    def dist_apply_routed(self, which, n):
+        rec = self.recv.view(np.uint64)[:n]
+        if which == 1:
+            self.first_0_out, self.last_0_in = ob.count_apply_events(self.pkg, self.pos_base, rec)
+        else:
+            self.mercy_local = np.sort(rec.astype(np.int64) - (self.pos_base << 2))
+
+    def read2sdbg_add_mercy(self, k):
+        n, self.local_solid = ob.s2_add_mercy(self.pkg, k, self.local_solid, self.mercy_local)
+        return n

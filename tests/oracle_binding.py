@@ -72,6 +72,12 @@ def lib():
                                           C.POINTER(Pkg), C.c_int]
         L.orc_gen_mercy_edges.restype = C.c_int64
         L.orc_sort_items.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int]
+        L.orc_s1_reduce_ex.argtypes = [C.c_void_p, C.POINTER(Vec), C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(S1Out)]
+        L.orc_count_items.argtypes = [C.POINTER(Pkg), C.c_int, C.c_uint64, C.POINTER(Vec)]
+        L.orc_count_reduce.argtypes = [C.POINTER(Vec), C.c_int, C.c_int, C.POINTER(CountOut), C.POINTER(C.POINTER(C.c_uint64)),
+                                       C.POINTER(C.c_uint64)]
+        L.orc_count_apply_events.argtypes = [C.POINTER(Pkg), C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
+        L.orc_seq2sdbg_items.argtypes = [C.POINTER(Pkg), C.c_void_p, C.c_int, C.POINTER(Vec)]
         _lib = L
     return _lib
 
@@ -222,6 +228,74 @@ def s2_items(pkg, k, m, is_solid):
         p = buf.ctypes.data
     lib().orc_s2_items(C.byref(pkg.p), k, m, p, C.byref(v))
     return _take_vec(v)
+
+
+def _malloc_copy(arr):
+    libc = C.CDLL(None)
+    libc.malloc.restype = C.c_void_p
+    libc.malloc.argtypes = [C.c_size_t]
+    raw = libc.malloc(max(8, arr.nbytes))
+    C.memmove(raw, arr.ctypes.data, arr.nbytes)
+    return raw
+
+
+def count_items(pkg, k, pos_base=0):
+    v = Vec()
+    lib().orc_count_items(C.byref(pkg.p), k, pos_base, C.byref(v))
+    return _take_vec(v)
+
+
+def count_reduce(items, k, m):
+    """items: uint32 [n, W+2] -> dict(edges, bucket_count, hist, events uint64[(pos << 1) | which])."""
+    items = np.ascontiguousarray(items, dtype=np.uint32)
+    raw = _malloc_copy(items)
+    v = Vec(C.cast(raw, C.POINTER(C.c_uint32)), items.shape[0], items.shape[0], items.shape[1])
+    o = CountOut()
+    ev = C.POINTER(C.c_uint64)()
+    n_ev = C.c_uint64(0)
+    lib().orc_count_reduce(C.byref(v), k, m, C.byref(o), C.byref(ev), C.byref(n_ev))  # frees raw
+    res = dict(wpe=o.words_per_edge, n_items=o.n_items,
+               edges=_arr(o.edges.d, o.edges.n * o.words_per_edge, np.uint32).reshape(-1, o.words_per_edge),
+               bucket_count=np.array(o.bucket_count, dtype=np.uint64), hist=np.array(o.hist, dtype=np.int64),
+               events=_arr(ev, n_ev.value, np.uint64))
+    libc = C.CDLL(None)
+    libc.free.argtypes = [C.c_void_p]
+    libc.free(C.cast(ev, C.c_void_p))
+    libc.free(C.cast(o.edges.d, C.c_void_p))
+    return res
+
+
+def count_apply_events(pkg, pos_base, events):
+    n = pkg.n_seqs
+    first = np.full(max(n, 1), 0xFFFFFFFF, dtype=np.uint32)
+    last = np.full(max(n, 1), 0xFFFFFFFF, dtype=np.uint32)
+    events = np.ascontiguousarray(events, dtype=np.uint64)
+    lib().orc_count_apply_events(C.byref(pkg.p), pos_base, events.ctypes.data, events.size, first.ctypes.data, last.ctypes.data)
+    return first[:n], last[:n]
+
+
+def seq2sdbg_items(pkg, mult, k):
+    v = Vec()
+    mult = np.ascontiguousarray(mult, dtype=np.uint16)
+    lib().orc_seq2sdbg_items(C.byref(pkg.p), mult.ctypes.data, k, C.byref(v))
+    return _take_vec(v)
+
+
+def s1_reduce_mercy(items, k, m, n_bits, tie_stable=True):
+    """As s1_reduce, plus the mercy candidates (global positions) computed without the reads."""
+    items = np.ascontiguousarray(items, dtype=np.uint32)
+    v = Vec(items.ctypes.data_as(C.POINTER(C.c_uint32)), items.shape[0], items.shape[0], items.shape[1])
+    o = S1Out()
+    nw = (n_bits + 63) // 64
+    bits = np.zeros(nw + 2, dtype=np.uint64)
+    o.is_solid = bits.ctypes.data_as(C.POINTER(C.c_uint64))
+    o.n_bits = n_bits
+    lib().orc_s1_reduce_ex(None, C.byref(v), k, m, 0 if tie_stable else 1, 1, C.byref(o))
+    mercy = _arr(o.mercy, o.n_mercy, np.int64)
+    libc = C.CDLL(None)
+    libc.free.argtypes = [C.c_void_p]
+    libc.free(C.cast(o.mercy, C.c_void_p))
+    return bits[:nw], np.array(o.hist, dtype=np.int64), mercy
 
 
 def s1_reduce(items, k, m, n_bits, tie_stable=True):

@@ -78,6 +78,112 @@ def test_two_ranks_equal_single_process(k, m, balanced):
     assert covered == 65536
 
 
+def _seqs_with_mult(rank_seed):
+    """seq2sdbg input: (k+1)-mer-or-longer sequences with multiplicities, as edges/contigs would be"""
+    rng = np.random.default_rng(rank_seed)
+    genome = np.random.default_rng(7).integers(0, 4, size=4000, dtype=np.uint8)
+    seqs, mult = [], []
+    for _ in range(300):
+        L = int(rng.integers(5, 90))
+        o = int(rng.integers(0, genome.size - L))
+        seqs.append(genome[o:o + L].copy())
+        mult.append(int(rng.integers(1, 400)))
+    return seqs, np.array(mult, dtype=np.uint16)
+
+
+def _worker2(rank, world, port, mode, k, m, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from cpu_engine import OracleEngine
+    from megahit_amd import dist as mdist
+    dev = torch.device("cpu")
+    if mode == "count":
+        eng = OracleEngine(_reads(100 + rank))
+        runner = mdist.DistCount(eng, k, m, rank, world, dev)
+        runner.step()
+        q.put((rank, eng.count["edges"], eng.count["bucket_count"], eng.count["hist"], eng.first_0_out, eng.last_0_in))
+    elif mode == "seq2sdbg":
+        seqs, mult = _seqs_with_mult(50 + rank)
+        eng = OracleEngine(seqs, reverse=False, mult=mult)
+        runner = mdist.DistSeq2Sdbg(eng, k, rank, world, dev)
+        runner.step()
+        lo, hi = int(runner.bucket_begin[rank]), int(runner.bucket_begin[rank + 1])
+        q.put((rank, lo, hi, eng.sdbg["bytes"].tobytes(), eng.sdbg["bucket_items"], eng.sdbg["bucket_tips"], eng.sdbg["bucket_large"]))
+    else:  # read2sdbg with mercy
+        eng = OracleEngine(_reads(100 + rank))
+        runner = mdist.DistRead2Sdbg(eng, k, m, rank, world, dev, need_mercy=1)
+        runner.step()
+        lo, hi = int(runner.bucket_begin[rank]), int(runner.bucket_begin[rank + 1])
+        q.put((rank, lo, hi, eng.sdbg["bytes"].tobytes(), eng.sdbg["bucket_items"], eng.sdbg["bucket_tips"], eng.sdbg["bucket_large"],
+               runner.n_mercy))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run2(mode, k, m, world=2):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker2, args=(r, world, port, mode, k, m, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = sorted([q.get(timeout=300) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return outs
+
+
+def _check_sdbg_ranges(outs, want):
+    off = np.concatenate([want["bucket_off"], [len(want["bytes"])]]).astype(np.int64)
+    for o in outs:
+        rank, lo, hi, byts, b_items, b_tips, b_large = o[:7]
+        assert np.array_equal(b_items[lo:hi], want["bucket_items"][lo:hi])
+        assert np.array_equal(b_tips[lo:hi], want["bucket_tips"][lo:hi])
+        assert np.array_equal(b_large[lo:hi], want["bucket_large"][lo:hi])
+        assert b_items[:lo].sum() == 0 and b_items[hi:].sum() == 0
+        assert byts == want["bytes"][off[lo]:off[hi]].tobytes()
+
+
+@pytest.mark.parametrize("k,m", [(21, 2), (31, 3)])
+def test_two_ranks_count(k, m):
+    """count: items to bucket owners, first_0_out/last_0_in events routed back to the read owners"""
+    import oracle_binding as ob
+    outs = _run2("count", k, m)
+    r0, r1 = _reads(100), _reads(101)
+    want = ob.count(ob.Package(r0 + r1, reverse=True), k, m)
+    assert np.array_equal(np.concatenate([o[1] for o in outs]), want["edges"])  # rank order = bucket order = sorted order
+    assert np.array_equal(sum(o[2] for o in outs), want["bucket_count"])
+    assert np.array_equal(sum(o[3] for o in outs), want["hist"])
+    assert np.array_equal(np.concatenate([o[4] for o in outs]), want["first_0_out"])
+    assert np.array_equal(np.concatenate([o[5] for o in outs]), want["last_0_in"])
+    assert (want["first_0_out"] != 0xFFFFFFFF).any() and (want["last_0_in"] != 0xFFFFFFFF).any()
+
+
+@pytest.mark.parametrize("k", [21, 39])
+def test_two_ranks_seq2sdbg(k):
+    import oracle_binding as ob
+    outs = _run2("seq2sdbg", k, 0)
+    s0, m0 = _seqs_with_mult(50)
+    s1, m1 = _seqs_with_mult(51)
+    want = ob.seq2sdbg(ob.Package(s0 + s1, reverse=False), np.concatenate([m0, m1]), k)
+    assert want["bucket_items"].sum() > 0
+    _check_sdbg_ranges(outs, want)
+
+
+@pytest.mark.parametrize("k,m", [(21, 2), (27, 3)])
+def test_two_ranks_read2sdbg_with_mercy(k, m):
+    """mercy candidates are produced by the bucket owners and routed to the ranks holding the reads"""
+    import oracle_binding as ob
+    outs = _run2("mercy", k, m)
+    pkg = ob.Package(_reads(100) + _reads(101), reverse=True)
+    s1 = ob.s1(pkg, k, m, tie_stable=True)
+    n_want, solid = ob.s2_add_mercy(pkg, k, s1["is_solid"], s1["mercy"])
+    assert sum(o[7] for o in outs) == n_want and n_want > 0
+    _check_sdbg_ranges(outs, ob.s2(pkg, k, m, solid))
+
+
 def test_partitions():
     from megahit_amd import dist as mdist
     assert list(mdist.equal_partition(4)) == [0, 16384, 32768, 49152, 65536]

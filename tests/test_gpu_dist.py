@@ -75,3 +75,101 @@ def test_ranks_on_one_gpu_equal_single_process(world, k, m):
         assert np.array_equal(b_large[lo:hi], want["bucket_large"][lo:hi])
         assert b_items[:lo].sum() == 0 and b_items[hi:].sum() == 0
         assert byts == want["bytes"][off[lo]:off[hi]].tobytes()
+
+
+def _worker2(rank, world, port, mode, k, m, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import oracle_binding as ob
+    from megahit_amd import dist as mdist
+    from megahit_amd import lib
+    from test_dist_cpu import _seqs_with_mult
+    dev = torch.device("cuda", 0)
+    eng = lib.Engine(0)
+    if mode == "seq2sdbg":
+        seqs, mult = _seqs_with_mult(50 + rank)
+        pkg = ob.Package(seqs, reverse=False)
+        eng.load_sequences(pkg.words(), pkg.n_seqs, 0, pkg.start())
+        eng.load_multiplicity(mult)
+        runner = mdist.DistSeq2Sdbg(eng, k, rank, world, dev, staging="host")
+    else:
+        pkg = ob.Package(_reads(100 + rank), reverse=True)
+        eng.load_sequences(pkg.words(), pkg.n_seqs, 0, pkg.start())
+        if mode == "count":
+            runner = mdist.DistCount(eng, k, m, rank, world, dev, staging="host")
+        else:
+            runner = mdist.DistRead2Sdbg(eng, k, m, rank, world, dev, staging="host", need_mercy=2 if mode == "mercy_exact" else 1)
+    runner.step()
+    runner.step()  # buffers are reused: same answer the second time
+    lo, hi = int(runner.bucket_begin[rank]), int(runner.bucket_begin[rank + 1])
+    if mode == "count":
+        r = eng.fetch(lib.BUF_EDGES, np.uint32)
+        q.put((rank, r, eng.fetch(lib.BUF_BUCKET_COUNT, np.uint64), eng.fetch(lib.BUF_MUL_HIST, np.int64),
+               eng.fetch(lib.BUF_FIRST_0_OUT, np.uint32), eng.fetch(lib.BUF_LAST_0_IN, np.uint32)))
+    else:
+        q.put((rank, lo, hi, eng.fetch(lib.BUF_SDBG_BYTES, np.uint8).tobytes(), eng.fetch(lib.BUF_BUCKET_COUNT, np.uint64),
+               eng.fetch(lib.BUF_BUCKET_TIPS, np.uint64), eng.fetch(lib.BUF_BUCKET_LARGE, np.uint64),
+               getattr(runner, "n_mercy", 0)))
+    dist.barrier()
+    dist.destroy_process_group()
+    eng.close()
+
+
+def _run2(mode, k, m, world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33600 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker2, args=(r, world, port, mode, k, m, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = sorted([q.get(timeout=600) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    return outs
+
+
+@pytest.mark.parametrize("world,k,m", [(2, 21, 2), (3, 31, 3)])
+def test_count_ranks_on_one_gpu(world, k, m):
+    import oracle_binding as ob
+    outs = _run2("count", k, m, world)
+    allreads = []
+    for r in range(world):
+        allreads += _reads(100 + r)
+    want = ob.count(ob.Package(allreads, reverse=True), k, m)
+    wpe = want["wpe"]
+    assert np.array_equal(np.concatenate([o[1] for o in outs]).reshape(-1, wpe), want["edges"])
+    assert np.array_equal(sum(o[2] for o in outs), want["bucket_count"])
+    assert np.array_equal(sum(o[3] for o in outs), want["hist"])
+    assert np.array_equal(np.concatenate([o[4] for o in outs]), want["first_0_out"])
+    assert np.array_equal(np.concatenate([o[5] for o in outs]), want["last_0_in"])
+
+
+@pytest.mark.parametrize("world,k", [(2, 21), (2, 39), (3, 29)])
+def test_seq2sdbg_ranks_on_one_gpu(world, k):
+    import oracle_binding as ob
+    from test_dist_cpu import _check_sdbg_ranges, _seqs_with_mult
+    outs = _run2("seq2sdbg", k, 0, world)
+    seqs, mult = [], []
+    for r in range(world):
+        s, m_ = _seqs_with_mult(50 + r)
+        seqs += s
+        mult.append(m_)
+    want = ob.seq2sdbg(ob.Package(seqs, reverse=False), np.concatenate(mult), k)
+    _check_sdbg_ranges(outs, want)
+
+
+@pytest.mark.parametrize("world,k,m,mode", [(2, 21, 2, "mercy"), (3, 27, 3, "mercy"), (2, 21, 2, "mercy_exact")])
+def test_read2sdbg_mercy_ranks_on_one_gpu(world, k, m, mode):
+    import oracle_binding as ob
+    from test_dist_cpu import _check_sdbg_ranges
+    outs = _run2(mode, k, m, world)
+    allreads = []
+    for r in range(world):
+        allreads += _reads(100 + r)
+    pkg = ob.Package(allreads, reverse=True)
+    s1 = ob.s1(pkg, k, m, tie_stable=mode == "mercy")
+    n_want, solid = ob.s2_add_mercy(pkg, k, s1["is_solid"], s1["mercy"])
+    assert sum(o[7] for o in outs) == n_want and n_want > 0
+    _check_sdbg_ranges(outs, ob.s2(pkg, k, m, solid))
