@@ -234,8 +234,8 @@ static void count_postprocess(mhx_ctx *c, const uint32_t *sorted, uint64_t n_ite
   CountOp<S> op{KWv, wpe, m, 1, s.start.as<uint64_t>(), s.n_seqs, s.fixed_len, first, last, hist, bcount, nullptr, events, n_events};
   const double bytes = (double)n_items * S * 4;
   MHX_LAUNCH(c, "count_runs", bytes,
-             hipLaunchKernelGGL((k_tile_groups<S, T, CountOp<S>, false>), dim3((unsigned)n_tiles), dim3(kTileThreads), 0, st, sorted, n_items,
-                                full_words, last_mask, op, tot, (const uint64_t *)nullptr, n_tiles));
+             hipLaunchKernelGGL((k_tile_groups<S, T, CountOp<S>, false>), dim3(tile_grid(n_tiles)), dim3(kTileThreads), 0, st, sorted, n_items,
+                                full_words, last_mask, op, tot, (const uint64_t *)nullptr, n_tiles, n_tiles));
   uint64_t *d_tot = c->ws("tile_totals", 64).as<uint64_t>();
   exclusive_scan_u64(c, tot, tb, n_tiles, d_tot);
   exclusive_scan_u64(c, tot + n_tiles, tb + n_tiles, n_tiles, d_tot + 1);
@@ -250,8 +250,8 @@ static void count_postprocess(mhx_ctx *c, const uint32_t *sorted, uint64_t n_ite
   op.side_effects = 0;
   op.edges = edges;
   MHX_LAUNCH(c, "count_emit", bytes + (double)h[0] * wpe * 4,
-             hipLaunchKernelGGL((k_tile_groups<S, T, CountOp<S>, true>), dim3((unsigned)n_tiles), dim3(kTileThreads), 0, st, sorted, n_items,
-                                full_words, last_mask, op, (uint64_t *)nullptr, (const uint64_t *)tb, n_tiles));
+             hipLaunchKernelGGL((k_tile_groups<S, T, CountOp<S>, true>), dim3(tile_grid(n_tiles)), dim3(kTileThreads), 0, st, sorted, n_items,
+                                full_words, last_mask, op, (uint64_t *)nullptr, (const uint64_t *)tb, n_tiles, n_tiles));
 }
 
 // ---------------------------------------------------------------------------

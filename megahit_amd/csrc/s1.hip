@@ -30,6 +30,54 @@ __global__ void k_s1_item_counts(const uint64_t *__restrict__ start, uint64_t n_
 
 // COMPACT (no mercy requested): the aux part is one word, the absolute position of the (k-1)-mer; that is
 // all the group reduction needs to set is_solid, and it makes the record 12 instead of 16 bytes at k <= 29.
+// item of slot j (0 .. L-k+3) of the read at base offset st, length L (read_to_sdbg_s1.cpp:228-292, :344-363)
+template <int KW, int S, bool COMPACT>
+__device__ __forceinline__ void s1_make_item(const uint32_t *__restrict__ seq, uint64_t st, uint32_t L, int k, uint32_t j, uint64_t pos_base,
+                                             uint32_t (&out)[S]) {
+  // slot -> ((k-1)-mer offset q, forced strand or -1)
+  uint32_t q;
+  int forced = -1;
+  if (j < 2) { q = 0; forced = (int)j; }
+  else if (j >= L - k + 2) { q = L - k + 1; forced = (int)(j - (L - k + 2)); }
+  else q = j - 1;
+  uint32_t f[KW], rc[KW];
+  load_chars<KW>(seq, st + q, k - 1, f);
+  rc_chars<KW>(f, k - 1, rc);
+  const unsigned head = q >= 1 ? base_at(seq, st + q - 1) : kSentinel;
+  const unsigned prev = q >= 2 ? base_at(seq, st + q - 2) : kSentinel;
+  const unsigned tail = q + k - 1 < L ? base_at(seq, st + q + k - 1) : kSentinel;
+  const unsigned next = q + k < L ? base_at(seq, st + q + k) : kSentinel;
+  int strand;
+  if (forced >= 0) strand = forced;
+  else {
+    const int c = cmp_words<KW>(f, rc);
+    if (c > 0) strand = 1;
+    else if (c < 0) strand = 0;
+    else strand = head <= 3 - tail ? 0 : 1;  // palindrome rule, :264-279 (head/tail are bases here)
+  }
+  const uint64_t full = ((pos_base + st + q) << 1) | (uint64_t)strand;  // pos_base: this rank's offset in the global read set
+  uint64_t info;
+  if (!strand) {
+#pragma unroll
+    for (int i = 0; i < KW; ++i) out[i] = f[i];
+    out[KW - 1] |= (head << 3) | tail;
+    info = (full << 6) | (prev << 3) | next;
+  } else {
+#pragma unroll
+    for (int i = 0; i < KW; ++i) out[i] = rc[i];
+    out[KW - 1] |= (comp_or_sentinel(tail) << 3) | comp_or_sentinel(head);
+    info = (full << 6) | (comp_or_sentinel(next) << 3) | comp_or_sentinel(prev);
+  }
+  if constexpr (COMPACT) {
+    out[KW] = (uint32_t)(pos_base + st + q);
+    if constexpr (S > KW + 1) out[KW + 1] = 0;
+  } else {
+    out[KW] = (uint32_t)(info >> 32);
+    out[KW + 1] = (uint32_t)info;
+    if constexpr (S > KW + 2) out[KW + 2] = 0;
+  }
+}
+
 template <int KW, int S, bool COMPACT>
 __global__ __launch_bounds__(256) void k_s1_extract(const uint32_t *__restrict__ seq, const uint64_t *__restrict__ start,
                                                     const uint64_t *__restrict__ item_start, uint64_t n_seqs, int k,
@@ -44,49 +92,8 @@ __global__ __launch_bounds__(256) void k_s1_extract(const uint32_t *__restrict__
     const uint64_t ibase = item_start[r];
     const uint32_t n_slots = L - k + 4;
     for (uint32_t j = lane; j < n_slots; j += kWave) {
-      // slot -> ((k-1)-mer offset q, forced strand or -1)
-      uint32_t q;
-      int forced = -1;
-      if (j < 2) { q = 0; forced = (int)j; }
-      else if (j >= L - k + 2) { q = L - k + 1; forced = (int)(j - (L - k + 2)); }
-      else q = j - 1;
-      uint32_t f[KW], rc[KW];
-      load_chars<KW>(seq, st + q, k - 1, f);
-      rc_chars<KW>(f, k - 1, rc);
-      const unsigned head = q >= 1 ? base_at(seq, st + q - 1) : kSentinel;
-      const unsigned prev = q >= 2 ? base_at(seq, st + q - 2) : kSentinel;
-      const unsigned tail = q + k - 1 < L ? base_at(seq, st + q + k - 1) : kSentinel;
-      const unsigned next = q + k < L ? base_at(seq, st + q + k) : kSentinel;
-      int strand;
-      if (forced >= 0) strand = forced;
-      else {
-        const int c = cmp_words<KW>(f, rc);
-        if (c > 0) strand = 1;
-        else if (c < 0) strand = 0;
-        else strand = head <= 3 - tail ? 0 : 1;  // palindrome rule, :264-279 (head/tail are bases here)
-      }
-      const uint64_t full = ((pos_base + st + q) << 1) | (uint64_t)strand;  // pos_base: this rank's offset in the global read set
-      uint64_t info;
       uint32_t out[S];
-      if (!strand) {
-#pragma unroll
-        for (int i = 0; i < KW; ++i) out[i] = f[i];
-        out[KW - 1] |= (head << 3) | tail;
-        info = (full << 6) | (prev << 3) | next;
-      } else {
-#pragma unroll
-        for (int i = 0; i < KW; ++i) out[i] = rc[i];
-        out[KW - 1] |= (comp_or_sentinel(tail) << 3) | comp_or_sentinel(head);
-        info = (full << 6) | (comp_or_sentinel(next) << 3) | comp_or_sentinel(prev);
-      }
-      if constexpr (COMPACT) {
-        out[KW] = (uint32_t)(pos_base + st + q);
-        if constexpr (S > KW + 1) out[KW + 1] = 0;
-      } else {
-        out[KW] = (uint32_t)(info >> 32);
-        out[KW + 1] = (uint32_t)info;
-        if constexpr (S > KW + 2) out[KW + 2] = 0;
-      }
+      s1_make_item<KW, S, COMPACT>(seq, st, L, k, j, pos_base, out);
       uint32_t *dst = items + (ibase + j) * S;
       if constexpr (S % 2 == 1) {
 #pragma unroll
@@ -103,12 +110,51 @@ __global__ __launch_bounds__(256) void k_s1_extract(const uint32_t *__restrict__
   }
 }
 
+// Reads of one length (the usual case): item g belongs to read g / per, slot g % per, so every lane of every wave has
+// work (a wave per read leaves the last of ceil(per/64) rounds nearly empty), and odd-stride records are transposed
+// through LDS so that each store instruction writes 256 contiguous bytes.
+template <int KW, int S, bool COMPACT>
+__global__ __launch_bounds__(256) void k_s1_extract_fixed(const uint32_t *__restrict__ seq, uint32_t L, uint32_t per, uint64_t n_items, int k,
+                                                          uint64_t pos_base, uint32_t *__restrict__ items) {
+  __shared__ uint32_t xpose[S % 2 == 1 ? 256 * S : 1];
+  const uint64_t g = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  uint32_t out[S];
+  if (g < n_items) {
+    const uint64_t r = g / per;
+    s1_make_item<KW, S, COMPACT>(seq, r * L, L, k, (uint32_t)(g - r * per), pos_base, out);
+  }
+  if constexpr (S % 2 == 1) {
+#pragma unroll
+    for (int i = 0; i < S; ++i) xpose[threadIdx.x * S + i] = out[i];
+    __syncthreads();
+    const uint64_t w0 = (uint64_t)blockIdx.x * 256 * S, n_words = n_items * S;
+#pragma unroll
+    for (int i = 0; i < S; ++i) {
+      const uint64_t w = w0 + (uint64_t)i * 256 + threadIdx.x;
+      if (w < n_words) items[w] = xpose[i * 256 + threadIdx.x];
+    }
+  } else if (g < n_items) {
+    uint32_t *dst = items + g * S;
+    if constexpr (S % 4 == 0) {
+#pragma unroll
+      for (int i = 0; i < S / 4; ++i)
+        reinterpret_cast<uint4 *>(dst)[i] = make_uint4(out[4 * i], out[4 * i + 1], out[4 * i + 2], out[4 * i + 3]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < S / 2; ++i) reinterpret_cast<uint2 *>(dst)[i] = make_uint2(out[2 * i], out[2 * i + 1]);
+    }
+  }
+}
+
 constexpr int kS1LocalHist = 1024;
 
 template <int S>
 struct S1Tile {
+#ifndef MHX_S1_TILE
+#define MHX_S1_TILE 2048
+#endif
   static constexpr int kRaw = 32768 / (S * 4);
-  static constexpr int kT = kRaw >= 2048 ? 2048 : (kRaw >= 256 ? (kRaw / 256) * 256 : 256);
+  static constexpr int kT = kRaw >= MHX_S1_TILE ? MHX_S1_TILE : (kRaw >= 256 ? (kRaw / 256) * 256 : 256);
   static constexpr int kRuns = kT + kMaxTailRuns;
 };
 
@@ -400,20 +446,20 @@ static void s1_groups_launch(mhx_ctx *c, const uint32_t *sorted, uint64_t n_item
     const uint32_t stride = 64;
     const uint64_t nt = div_ceil(n_tiles, stride);
     MHX_LAUNCH(c, "s1_sample", (double)nt * T * S * 4,
-               hipLaunchKernelGGL((k_tile_groups<S, T, S1Op<S, COMPACT, false>, false>), dim3((unsigned)nt), dim3(kTileThreads), 0, c->stream, sorted,
+               hipLaunchKernelGGL((k_tile_groups<S, T, S1Op<S, COMPACT, false>, false>), dim3(tile_grid(nt)), dim3(kTileThreads), 0, c->stream, sorted,
                                   n_items, full_words, last_mask, S1Op<S, COMPACT, false>{k, nullptr, KWv, m, s.start.as<uint64_t>(), s.n_seqs,
                                   s.fixed_len, is_solid, solid_bits, mark_atomic, 2, hist, ctr, 0, mercy, ctr + 1},
-                                  (uint64_t *)nullptr, (const uint64_t *)nullptr, n_tiles, stride));
+                                  (uint64_t *)nullptr, (const uint64_t *)nullptr, n_tiles, nt, stride));
     return;
   }
   if constexpr (AGG)
     MHX_LAUNCH(c, "s1_groups", (double)n_items * S * 4,
-               hipLaunchKernelGGL((k_tile_groups<S, T, S1Op<S, COMPACT, true>, true>), dim3((unsigned)n_tiles), dim3(kTileThreads), 0, c->stream,
-                                  sorted, n_items, full_words, last_mask, op, agg_cursor, (const uint64_t *)nullptr, n_tiles));
+               hipLaunchKernelGGL((k_tile_groups<S, T, S1Op<S, COMPACT, true>, true>), dim3(tile_grid(n_tiles)), dim3(kTileThreads), 0, c->stream,
+                                  sorted, n_items, full_words, last_mask, op, agg_cursor, (const uint64_t *)nullptr, n_tiles, n_tiles));
   else
     MHX_LAUNCH(c, "s1_groups", (double)n_items * S * 4,
-               hipLaunchKernelGGL((k_tile_groups<S, T, S1Op<S, COMPACT, false>, false>), dim3((unsigned)n_tiles), dim3(kTileThreads), 0, c->stream,
-                                  sorted, n_items, full_words, last_mask, op, (uint64_t *)nullptr, (const uint64_t *)nullptr, n_tiles));
+               hipLaunchKernelGGL((k_tile_groups<S, T, S1Op<S, COMPACT, false>, false>), dim3(tile_grid(n_tiles)), dim3(kTileThreads), 0, c->stream,
+                                  sorted, n_items, full_words, last_mask, op, (uint64_t *)nullptr, (const uint64_t *)nullptr, n_tiles, n_tiles));
 }
 
 // int64 <-> (hi,lo) word pairs so that the big-endian record sort orders them numerically
@@ -481,10 +527,18 @@ uint64_t s1_extract(mhx_ctx *c, uint32_t k, bool compact) {
   uint32_t *buf_a = c->ws("items_a", n_items * item_bytes + 64).as<uint32_t>();
   if (n_items) {
     const unsigned grid = 256 * 8;
+    const bool fixed = s.fixed_len >= k + 1 && n_items == (uint64_t)ns * (s.fixed_len - k + 4) && div_ceil(n_items, 256) < (1ull << 31);
 #define MHX_S1X(SV, CP)                                                                                                      \
-  MHX_LAUNCH(c, "s1_extract", (double)n_items * item_bytes + (double)s.n_bases / 4,                                          \
-             hipLaunchKernelGGL((k_s1_extract<KW, SV, CP>), dim3(grid), dim3(256), 0, st, s.words.as<uint32_t>(),            \
-                                s.start.as<uint64_t>(), item_start, ns, (int)k, c->pos_base, buf_a))
+  do {                                                                                                                       \
+    if (fixed)                                                                                                               \
+      MHX_LAUNCH(c, "s1_extract", (double)n_items * item_bytes + (double)s.n_bases / 4,                                      \
+                 hipLaunchKernelGGL((k_s1_extract_fixed<KW, SV, CP>), dim3((unsigned)div_ceil(n_items, 256)), dim3(256), 0, st, \
+                                    s.words.as<uint32_t>(), s.fixed_len, s.fixed_len - k + 4, n_items, (int)k, c->pos_base, buf_a)); \
+    else                                                                                                                     \
+      MHX_LAUNCH(c, "s1_extract", (double)n_items * item_bytes + (double)s.n_bases / 4,                                      \
+                 hipLaunchKernelGGL((k_s1_extract<KW, SV, CP>), dim3(grid), dim3(256), 0, st, s.words.as<uint32_t>(),        \
+                                    s.start.as<uint64_t>(), item_start, ns, (int)k, c->pos_base, buf_a));                    \
+  } while (0)
     MHX_DISPATCH_KW(KWv, {
       if (compact) {
         if (S == KW + 1) MHX_S1X(KW + 1, true);
@@ -645,3 +699,15 @@ int run_s1(mhx_ctx *c, uint32_t k, uint32_t m, int want_mercy, mhx_s1_result *ou
 }
 
 }  // namespace mhx
+
+#ifdef MHX_TILE_TIMING
+// debug build only: phase clocks of the stage-1 tile kernels (this translation unit's copy of g_tile_phase)
+extern "C" int mhx_debug_tile_phases(unsigned long long *out16, int reset) {
+  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(mhx::g_tile_phase), 16 * 8) != hipSuccess) return -1;
+  if (reset) {
+    unsigned long long z[16] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(mhx::g_tile_phase), z, 16 * 8) != hipSuccess) return -1;
+  }
+  return 0;
+}
+#endif

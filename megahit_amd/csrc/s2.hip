@@ -510,8 +510,8 @@ static void emit_sdbg_impl(mhx_ctx *c, const uint32_t *sorted, uint64_t n_items,
   SdbgOp<S> op{P, nullptr, w_count, bstart};
   const double bytes = (double)n_items * S * 4;
   MHX_LAUNCH(c, "sdbg_count", bytes,
-             hipLaunchKernelGGL((k_tile_groups<S, T, SdbgOp<S>, false>), dim3((unsigned)n_tiles), dim3(kTileThreads), 0, st, sorted, n_items,
-                                full_words, last_mask, op, tt, (const uint64_t *)nullptr, n_tiles));
+             hipLaunchKernelGGL((k_tile_groups<S, T, SdbgOp<S>, false>), dim3(tile_grid(n_tiles)), dim3(kTileThreads), 0, st, sorted, n_items,
+                                full_words, last_mask, op, tt, (const uint64_t *)nullptr, n_tiles, n_tiles));
   for (int r = 0; r < 3; ++r) exclusive_scan_u64(c, tt + r * n_tiles, tb + r * n_tiles, n_tiles, d_tot + r);
   MHX_HIP(hipMemcpyAsync(tot, d_tot, 24, hipMemcpyDeviceToHost, st));
   MHX_HIP(hipStreamSynchronize(st));
@@ -521,8 +521,8 @@ static void emit_sdbg_impl(mhx_ctx *c, const uint32_t *sorted, uint64_t n_items,
   MHX_HIP(hipMemsetAsync(bstart, 0xFF, 3 * MHX_NUM_BUCKETS * 8, st));
   op.out16 = out16;
   MHX_LAUNCH(c, "sdbg_emit", bytes + (double)out_bytes,
-             hipLaunchKernelGGL((k_tile_groups<S, T, SdbgOp<S>, true>), dim3((unsigned)n_tiles), dim3(kTileThreads), 0, st, sorted, n_items,
-                                full_words, last_mask, op, (uint64_t *)nullptr, (const uint64_t *)tb, n_tiles));
+             hipLaunchKernelGGL((k_tile_groups<S, T, SdbgOp<S>, true>), dim3(tile_grid(n_tiles)), dim3(kTileThreads), 0, st, sorted, n_items,
+                                full_words, last_mask, op, (uint64_t *)nullptr, (const uint64_t *)tb, n_tiles, n_tiles));
   MHX_LAUNCH(c, "bucket_stats", (double)MHX_NUM_BUCKETS * 56,
              hipLaunchKernelGGL(k_bucket_fix, dim3(1), dim3(256), 0, st, bstart, d_tot, P.wpt, b_items, b_tips, b_large, b_off));
 }

@@ -76,11 +76,27 @@ __device__ __forceinline__ bool key_differs(const uint32_t *a, const uint32_t *b
 //   void item_final(const TileCtx<S>&, uint32_t rel, uint32_t run)   (if kItemFinal; after the group phase)
 constexpr int kLookAhead = 64;  // records staged beyond the tile so that short tails never touch HBM again
 
+// Debug build only (make timing -> libmhx_timing.so, tools/probe_phases.py): shader-clock ticks per phase of the
+// tile kernel, summed over workgroups.
+#ifdef MHX_TILE_TIMING
+static __device__ unsigned long long g_tile_phase[16];
+#define MHX_TT(i)                                      \
+  if (threadIdx.x == 0) {                              \
+    const unsigned long long now_ = clock64();         \
+    atomicAdd(&g_tile_phase[i], now_ - tt_prev_);      \
+    tt_prev_ = now_;                                   \
+  }
+#define MHX_TT_BEGIN unsigned long long tt_prev_ = clock64();
+#else
+#define MHX_TT(i)
+#define MHX_TT_BEGIN
+#endif
+
 template <int S, int T, class Op, bool EMIT>
 __global__ __launch_bounds__(kTileThreads) void k_tile_groups(const uint32_t *__restrict__ items, uint64_t n, int full_words,
                                                              uint32_t last_mask, Op op, uint64_t *__restrict__ tile_tot,
                                                              const uint64_t *__restrict__ tile_base, uint64_t n_tiles,
-                                                             uint32_t tile_stride = 1) {
+                                                             uint64_t n_work, uint32_t tile_stride = 1) {
   constexpr int PER = T / kTileThreads;
   constexpr int NW = kTileThreads / kWave;
   static_assert(T % kTileThreads == 0 && PER <= 16, "tile shape");
@@ -96,29 +112,58 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_groups(const uint32_t *__
 
   const int tid = threadIdx.x, wv = tid / kWave, lane = tid & (kWave - 1);
   const uint64_t lanemask_lt = (1ull << lane) - 1;
-  const uint64_t base = (uint64_t)blockIdx.x * tile_stride * T;  // tile_stride > 1: a sample of the tiles (statistics only)
+  // Persistent workgroups: tile indices blockIdx.x, blockIdx.x + gridDim.x, ... < n_work.  The records of the NEXT tile
+  // are fetched into registers (16-byte loads of the flat word array) while the current tile is processed, so the HBM
+  // latency of staging overlaps with the LDS-only phases instead of stalling every tile.
+  constexpr int kStageVec = (T + kLookAhead) * S / 4;  // T is a multiple of 256: whole 16-byte vectors, 16-byte aligned
+  constexpr int NV = (kStageVec + kTileThreads - 1) / kTileThreads;
+  static_assert(NV <= 9, "prefetch registers");
+  uint4 pf0, pf1, pf2, pf3, pf4, pf5, pf6, pf7, pf8;  // named (not an array) so that they stay in VGPRs
+  uint32_t pf_prev = 0;
+  bool pf_valid = false;  // workgroup-uniform: the next tile is a full one (tile + look-ahead inside the array)
+#define MHX_PF_EACH(X) X(0, pf0) X(1, pf1) X(2, pf2) X(3, pf3) X(4, pf4) X(5, pf5) X(6, pf6) X(7, pf7) X(8, pf8)
+#define MHX_PF_LOAD(I, R)                                                          \
+  if constexpr (I < NV) {                                                          \
+    if (I + 1 < NV || I * kTileThreads + tid < kStageVec) R = src_[I * kTileThreads + tid]; \
+  }
+#define MHX_PF_STORE(I, R)                                                         \
+  if constexpr (I < NV) {                                                          \
+    if (I + 1 < NV || I * kTileThreads + tid < kStageVec) reinterpret_cast<uint4 *>(tile)[I * kTileThreads + tid] = R; \
+  }
+#define MHX_TILE_PREFETCH(TILE_IDX)                                                     \
+  {                                                                                     \
+    const uint64_t b_ = (TILE_IDX) * tile_stride * T;                                   \
+    pf_valid = n - b_ >= (uint64_t)(T + kLookAhead);                                    \
+    if (pf_valid) {                                                                     \
+      const uint4 *src_ = reinterpret_cast<const uint4 *>(items + b_ * S);              \
+      MHX_PF_EACH(MHX_PF_LOAD)                                                          \
+      if (tid < S && b_ != 0) pf_prev = items[b_ * S - S + tid];                        \
+    }                                                                                   \
+  }
+  if (blockIdx.x < n_work) MHX_TILE_PREFETCH((uint64_t)blockIdx.x)
+  for (uint64_t tile_idx = blockIdx.x; tile_idx < n_work; tile_idx += gridDim.x) {
+  const uint64_t base = tile_idx * tile_stride * T;  // tile_stride > 1: a sample of the tiles (statistics only)
   const uint64_t rem = n - base;
   const int t_n = rem < (uint64_t)T ? (int)rem : T;
   const int staged = rem < (uint64_t)(T + kLookAhead) ? (int)rem : T + kLookAhead;  // tile + look-ahead
   if (tid == 0) s_first_head = 0xFFFFFFFFu;
+  MHX_TT_BEGIN
   op.begin_block();
-  // 1. stage the tile, the look-ahead and the predecessor record (coalesced)
-  for (int i = tid - 1; i < staged; i += kTileThreads) {
-    if (i < 0 && base == 0) continue;
-    const uint32_t *src = items + (base + i) * S;
-    uint32_t *dst = tile + i * S;
-    if constexpr (S % 4 == 0) {
-#pragma unroll
-      for (int q = 0; q < S / 4; ++q) reinterpret_cast<uint4 *>(dst)[q] = reinterpret_cast<const uint4 *>(src)[q];
-    } else if constexpr (S % 2 == 0) {
-#pragma unroll
-      for (int q = 0; q < S / 2; ++q) reinterpret_cast<uint2 *>(dst)[q] = reinterpret_cast<const uint2 *>(src)[q];
-    } else {
-#pragma unroll
-      for (int q = 0; q < S; ++q) dst[q] = src[q];
-    }
+  MHX_TT(0)
+  // 1. stage the tile, the look-ahead and the predecessor record
+  if (pf_valid) {
+    MHX_PF_EACH(MHX_PF_STORE)
+    if (tid < S && base != 0) tile[-S + tid] = pf_prev;
+  } else {  // the last, partial tile
+    const uint32_t *src = items + base * S;
+    const int n_words = staged * S, n_vec = n_words / 4;
+    for (int v = tid; v < n_vec; v += kTileThreads) reinterpret_cast<uint4 *>(tile)[v] = reinterpret_cast<const uint4 *>(src)[v];
+    for (int w = n_vec * 4 + tid; w < n_words; w += kTileThreads) tile[w] = src[w];
+    if (tid < S && base != 0) tile[-S + tid] = src[-S + tid];
   }
   __syncthreads();
+  if (tile_idx + gridDim.x < n_work) MHX_TILE_PREFETCH(tile_idx + gridDim.x)
+  MHX_TT(1)
   // 2. group-head / run-head flags, striped: round j, thread t looks at record j*256 + t (conflict-free LDS reads)
   uint32_t gflags = 0, rflags = 0;
   uint32_t my_first = 0xFFFFFFFFu;
@@ -184,6 +229,7 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_groups(const uint32_t *__
     }
   }
   __syncthreads();
+  MHX_TT(2)
   // 3. tail of the last group, beyond the tile: wavefront 0, 64 records per step; the first step reads the
   //    look-ahead records already in LDS
   if (n_groups > 0 && base + t_n < n && tid < kWave) {
@@ -230,6 +276,7 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_groups(const uint32_t *__
   __syncthreads();
 
   TileCtx<S> ctx{{tile, items, base, n, staged}, rpos, gpos, rgid, n_runs, n_groups};
+  MHX_TT(3)
 
   // run index of a tail record (few tail runs: linear search)
   auto tail_run = [&](uint32_t rel) -> uint32_t {
@@ -256,6 +303,7 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_groups(const uint32_t *__
     __syncthreads();
   }
 
+  MHX_TT(4)
   // 5. unit phase: a unit is a run (Op::kUnitIsRun) or a group
   if constexpr (Op::kRunPhase) {
     for (uint32_t r = tid; r < n_runs; r += kTileThreads) op.run_phase(ctx, r, rgid[r]);
@@ -276,9 +324,9 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_groups(const uint32_t *__
       block_exclusive_sum<uint64_t, kTileThreads>(t1, sm64, &s1);
       block_exclusive_sum<uint64_t, kTileThreads>(t2, sm64, &s2);
       if (tid == 0) {
-        tile_tot[blockIdx.x] = s0;
-        tile_tot[n_tiles + blockIdx.x] = s1;
-        tile_tot[2 * n_tiles + blockIdx.x] = s2;
+        tile_tot[tile_idx] = s0;
+        tile_tot[n_tiles + tile_idx] = s1;
+        tile_tot[2 * n_tiles + tile_idx] = s2;
       }
     }
   } else {
@@ -288,11 +336,13 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_groups(const uint32_t *__
       gcnt[u] = (uint64_t)c.c0 | ((uint64_t)c.c1 << 21) | ((uint64_t)c.c2 << 42);
     }
     __syncthreads();
+    MHX_TT(5)
     const uint32_t chunk = (n_units + kTileThreads - 1) / kTileThreads;
     const uint32_t lo = min(n_units, tid * chunk), hi = min(n_units, lo + chunk);
     uint64_t s = 0;
     for (uint32_t u = lo; u < hi; ++u) s += gcnt[u];
-    uint64_t run = block_exclusive_sum<uint64_t, kTileThreads>(s, sm64, nullptr);
+    uint64_t tot;
+    uint64_t run = block_exclusive_sum<uint64_t, kTileThreads>(s, sm64, &tot);
     for (uint32_t u = lo; u < hi; ++u) {
       const uint64_t v = gcnt[u];
       gcnt[u] = run;
@@ -304,8 +354,6 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_groups(const uint32_t *__
       // output order across tiles does not matter: reserve this tile's slice with one atomic per counter
       // (tile_tot = the three global cursors) instead of a scan over per-tile totals in a previous launch
       __shared__ uint64_t s_base[3];
-      uint64_t tot;
-      block_exclusive_sum<uint64_t, kTileThreads>(s, sm64, &tot);
       if (tid == 0) {
         const uint64_t t0 = tot & 0x1FFFFF, t1 = (tot >> 21) & 0x1FFFFF, t2 = tot >> 42;
         s_base[0] = t0 ? atomicAdd(reinterpret_cast<unsigned long long *>(tile_tot), (unsigned long long)t0) : 0;
@@ -317,10 +365,11 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_groups(const uint32_t *__
       b1 = s_base[1];
       b2 = s_base[2];
     } else {
-      b0 = tile_base[blockIdx.x];
-      b1 = tile_base[n_tiles + blockIdx.x];
-      b2 = tile_base[2 * n_tiles + blockIdx.x];
+      b0 = tile_base[tile_idx];
+      b1 = tile_base[n_tiles + tile_idx];
+      b2 = tile_base[2 * n_tiles + tile_idx];
     }
+    MHX_TT(6)
     for (uint32_t u = tid; u < n_units; u += kTileThreads) {
       const uint64_t p = gcnt[u];
       op.unit_emit(ctx, u, b0 + (p & 0x1FFFFF), b1 + ((p >> 21) & 0x1FFFFF), b2 + (p >> 42));
@@ -329,6 +378,7 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_groups(const uint32_t *__
   // 6. optional item-parallel pass after the unit phase
   if constexpr (Op::kItemFinal) {
     __syncthreads();
+    MHX_TT(7)
     if (op.item_final_enabled() && n_groups > 0) {
 #pragma unroll
       for (int j = 0; j < PER; ++j) {
@@ -340,7 +390,18 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_groups(const uint32_t *__
     }
   }
   __syncthreads();
+  MHX_TT(8)
   op.end_block();
+  MHX_TT(9)
+  __syncthreads();
+  }  // tiles of this workgroup
+#undef MHX_TILE_PREFETCH
+#undef MHX_PF_EACH
+#undef MHX_PF_LOAD
+#undef MHX_PF_STORE
 }
+
+// grid of the persistent launch: a few workgroups per CU (LDS allows 2-4), each looping over its tiles
+inline unsigned tile_grid(uint64_t n_work) { return (unsigned)(n_work < 2048 ? (n_work ? n_work : 1) : 2048); }
 
 }  // namespace mhx

@@ -9,7 +9,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmhx.so")
+# MHX_LIBRARY: load another build of the same library (the phase-timing debug build of tools/probe_phases.py)
+LIB_PATH = os.environ.get("MHX_LIBRARY") or os.path.join(_HERE, "libmhx.so")
 
 NUM_BUCKETS = 65536
 MAX_MUL = 65535

@@ -211,3 +211,25 @@ def test_s1_marking_polarity(engine, kind, k, m, mercy, polarity, monkeypatch):
     if mercy:
         assert np.array_equal(engine.fetch(lib.BUF_MERCY_CAND, np.int64), w1["mercy"])
     check_sdbg(engine, engine.read2sdbg_s2(k, m), ob.s2(pkg, k, m, w1["is_solid"]))
+
+
+@pytest.mark.parametrize("k,m,mercy", [(21, 2, 0), (21, 2, 1), (27, 2, 0), (32, 3, 0), (47, 2, 1)])
+def test_read2sdbg_fixed_length_reads(engine, k, m, mercy):
+    """Reads of one length loaded without a start array (fixed_len): the flattened extraction path."""
+    reads = make_reads("fixed", 21)
+    assert len({len(r) for r in reads}) == 1
+    pkg = ob.Package(reads, reverse=True)
+    w1 = ob.s1(pkg, k, m, tie_stable=True)
+    engine.load_sequences(pkg.words(), pkg.n_seqs, len(reads[0]), None)
+    r1 = engine.read2sdbg_s1(k, m, want_mercy=mercy)
+    assert r1.n_items == w1["n_items"]
+    solid = engine.fetch(lib.BUF_IS_SOLID, np.uint64)
+    assert np.array_equal(solid, w1["is_solid"][: solid.size])
+    if mercy:
+        assert np.array_equal(engine.fetch(lib.BUF_MERCY_CAND, np.int64), w1["mercy"])
+    check_sdbg(engine, engine.read2sdbg_s2(k, m), ob.s2(pkg, k, m, w1["is_solid"]))
+    want = ob.count(pkg, k, m)
+    r = engine.count(k, m)
+    assert np.array_equal(engine.fetch(lib.BUF_EDGES, np.uint32).reshape(-1, r.words_per_edge), want["edges"])
+    assert np.array_equal(engine.fetch(lib.BUF_FIRST_0_OUT, np.uint32), want["first_0_out"])
+    assert np.array_equal(engine.fetch(lib.BUF_LAST_0_IN, np.uint32), want["last_0_in"])
