@@ -70,6 +70,29 @@ def pmc_traffic(kernel_name):
     return None, None
 
 
+def copy_bandwidth(torch):
+    """GB/s (read + write) of a plain device-to-device copy of 2 GiB in this run: what a streaming kernel reaches on
+    this part, quoted beside the datasheet peak."""
+    try:
+        n = 1 << 31
+        a = torch.empty(n, dtype=torch.uint8, device="cuda")
+        b = torch.empty(n, dtype=torch.uint8, device="cuda")
+        a.zero_()
+        b.copy_(a)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(5):
+            b.copy_(a)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 5
+        del a, b
+        return round(2 * n / ms / 1e6, 1)
+    except Exception:
+        return None
+
+
 def cpu_baseline(sample_reads):
     """The reference's own CPU path (oracle/_ref/ref_core = reference sources compiled in place) on a
     bounded sample of the same workload, all host cores.  Falls back to the C port (oracle_core)."""
@@ -109,6 +132,8 @@ def main():
     ap.add_argument("--reads", type=float, default=10e6, help="reads per GPU (BASELINE configs[1]: 10 M)")
     ap.add_argument("--cpu-sample-reads", type=float, default=400e3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--engine", choices=["read2sdbg", "count", "seq2sdbg"], default="read2sdbg",
+                    help="sub-program to time; read2sdbg is BASELINE.json's metric, the others are reported beside it (1 GPU)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -135,6 +160,8 @@ def main():
     eng.load_sequences(packed, n_reads, READ_LEN, None)  # H2D happens here, outside the timed region
     E = n_reads * (READ_LEN - K)
 
+    if args.engine != "read2sdbg" and world > 1:
+        raise SystemExit("--engine %s is a single-GPU report" % args.engine)
     if world > 1:
         import torch.distributed as dist
         from megahit_amd import dist as mdist
@@ -146,12 +173,32 @@ def main():
             torch.cuda.synchronize()
             dist.barrier()
             torch.cuda.synchronize()
+    elif args.engine == "count":
+        def step():
+            return eng.count(K, MIN_COUNT), None
+    elif args.engine == "seq2sdbg":
+        # the reference's 2-pass route: count, then seq2sdbg over the solid (k+1)-mer edges (untimed: count + reload)
+        rc = eng.count(K, MIN_COUNT)
+        edges = eng.fetch(lib.BUF_EDGES, np.uint32).reshape(-1, rc.words_per_edge)
+        mult = (edges[:, -1] & 0xFFFF).astype(np.uint16)
+        n_edges = edges.shape[0]
+        from megahit_amd import synth
+        chars = np.zeros((n_edges, K + 1), dtype=np.uint8)
+        for i in range(K + 1):
+            chars[:, i] = (edges[:, i // 16] >> (30 - 2 * (i % 16))) & 3
+        eng.load_sequences(synth.pack_reads_concat(chars[: n_edges // 16 * 16]), n_edges // 16 * 16, K + 1, None)
+        eng.load_multiplicity(mult[: n_edges // 16 * 16])
+        E = n_edges // 16 * 16  # units: input edges
+
+        def step():
+            return None, eng.seq2sdbg(K)
     else:
         def step():
             r1 = eng.read2sdbg_s1(K, MIN_COUNT)
             r2 = eng.read2sdbg_s2(K, MIN_COUNT)
             return r1, r2
 
+    if world == 1:
         def barrier():
             eng.synchronize()
             torch.cuda.synchronize()
@@ -183,26 +230,38 @@ def main():
         per_launch_bytes = ks["bytes"] / ks["launches"]
         per_launch_ms = ks["ms"] / ks["launches"]
         achieved = per_launch_bytes / per_launch_ms / 1e6  # GB/s
-        traffic, traffic_src = pmc_traffic(name) if n_reads == 10000000 else (None, None)
+        traffic, traffic_src = pmc_traffic(name) if n_reads == 10000000 and args.engine == "read2sdbg" else (None, None)
+        copy_gbs = copy_bandwidth(torch)
         roof = {"bound": "hbm", "kernel": name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                "copy_kernel_GBs": copy_gbs, "frac_of_copy_kernel": round(achieved / copy_gbs, 4) if copy_gbs else None,
                 "launches_per_step": ks["launches"] // max(1, args.steps), "avg_launch_ms": round(per_launch_ms, 4),
                 "algo_bytes_per_launch": per_launch_bytes,
                 "kernel_ms_per_step": {k2: round(v["ms"] / args.steps, 3) for k2, v in sorted(stats.items(), key=lambda kv: -kv[1]["ms"])}}
-        out = {"metric": "M (k+1)-mer edges sorted+counted/sec, sdbg_build k=21", "value": round(value, 2), "unit": "M edges/s",
+        metric = {"read2sdbg": "M (k+1)-mer edges sorted+counted/sec, sdbg_build k=21",
+                  "count": "M (k+1)-mer edges sorted+counted/sec, count k=21 (beside the headline metric)",
+                  "seq2sdbg": "M input (k+1)-mer edges/sec, seq2sdbg k=21 (beside the headline metric)"}[args.engine]
+        workload = {"read2sdbg": "read2sdbg (S1+S2) k=21 m=2 no mercy", "count": "count k=21 m=2",
+                    "seq2sdbg": "seq2sdbg k=21 over the solid edges of count"}[args.engine]
+        out = {"metric": metric, "value": round(value, 2), "unit": "M edges/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
-               "config": {"workload": "read2sdbg (S1+S2) k=21 m=2 no mercy, %d synthetic 150 bp PE reads per GPU "
+               "config": {"workload": workload + ", %d synthetic 150 bp PE reads per GPU "
                                       "(BASELINE configs[1]), inputs resident in HBM, outputs left in HBM" % n_reads,
                           "reads_per_gpu": n_reads, "edges_per_gpu": E, "k": K, "min_count": MIN_COUNT,
                           "parallelism": "1 GPU" if world == 1 else "lv1 buckets over %d GPUs, all-to-all" % world},
                "roofline": roof}
         if world == 1:
             r1, r2 = res
-            out["config"]["s1_items"] = int(r1.n_items)
-            out["config"]["s2_items"] = int(r2.n_items)
-            out["config"]["sdbg_records"] = int(r2.n_sdbg)
-            if not args.no_cpu_baseline:
+            if args.engine == "read2sdbg":
+                out["config"]["s1_items"] = int(r1.n_items)
+            if args.engine == "count":
+                out["config"]["items"] = int(r1.n_items)
+                out["config"]["solid_edges"] = int(r1.n_edges)
+            if r2 is not None:
+                out["config"]["s2_items" if args.engine == "read2sdbg" else "items"] = int(r2.n_items)
+                out["config"]["sdbg_records"] = int(r2.n_sdbg)
+            if not args.no_cpu_baseline and args.engine == "read2sdbg":
                 try:
                     out["cpu_baseline"] = cpu_baseline(int(args.cpu_sample_reads) // 2 * 2)
                 except Exception as ex:  # the baseline is reporting only; never lose the GPU number

@@ -13,6 +13,9 @@ if [ -z "$2" ]; then
 fi
 timeout 600 python bench.py > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err
 cat $O/${TAG}_bench.json
+timeout 600 python bench.py --engine count --steps 3 > $O/${TAG}_bench_count.json 2>> $O/${TAG}_bench.err
+timeout 600 python bench.py --engine seq2sdbg --steps 3 > $O/${TAG}_bench_seq2sdbg.json 2>> $O/${TAG}_bench.err
+cat $O/${TAG}_bench_count.json $O/${TAG}_bench_seq2sdbg.json
 cd /tmp
 BENCH="python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_trace -- $BENCH > $O/${TAG}_trace.log 2>&1
