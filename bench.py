@@ -58,15 +58,16 @@ def pmc_traffic(kernel_name):
             kernels = json.load(f)["kernels"]
     except Exception:
         return None, None
-    prefix = None
-    for stem in ("radix_scatter_", "radix_hist_"):
-        if kernel_name.startswith(stem) and kernel_name.endswith("B"):
-            prefix = "k_%s<%d," % (stem[:-1], int(kernel_name[len(stem):-1]) // 4)
-    if prefix is None:
-        return None, None
-    for k, v in kernels.items():
-        if k.startswith(prefix):
-            return v["hbm_bytes"], "profiles/r01_pmc_traffic.json:" + k
+    prefixes = []
+    for stem, names in (("radix_scatter_", ("k_radix_onesweep", "k_radix_scatter")), ("radix_hist_all_", ("k_radix_hist_all",)),
+                        ("radix_hist_", ("k_radix_hist",))):
+        if kernel_name.startswith(stem) and kernel_name.endswith("B") and kernel_name[len(stem):-1].isdigit():
+            prefixes = ["%s<%d" % (nm, int(kernel_name[len(stem):-1]) // 4) for nm in names]
+            break
+    for prefix in prefixes:
+        for k, v in kernels.items():
+            if k.startswith(prefix + ",") or k.startswith(prefix + ">"):
+                return v["hbm_bytes"], "profiles/r01_pmc_traffic.json:" + k
     return None, None
 
 

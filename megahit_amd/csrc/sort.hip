@@ -10,6 +10,8 @@
 // uint4/uint2 accesses, never word by word.  HBM-bound; no MFMA.
 #include "dev_prims.h"
 #include <cstdlib>
+#include <cstring>
+#include <string>
 
 #include "mhx_internal.h"
 
@@ -289,6 +291,190 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(const uint32_t *
   }
 }
 
+// ---------------------------------------------------------------------------
+// Chained-scan ("onesweep") scatter: no per-pass histogram read.  The global digit histograms of ALL passes come
+// from one read of the input (k_radix_hist_all; a digit histogram does not depend on the record order), and the
+// scatter resolves "how many records with my digit precede my unit" with a decoupled look-back over per-unit
+// status words instead of a scanned per-chunk table.  A unit = UT tiles held in registers, so a workgroup can
+// publish its digit counts before it knows its own offsets and predecessors never wait for successors.
+//   status[unit][digit] = tag<<58 | flag<<56 | value      flag 1: count of this unit, 2: inclusive prefix
+// (tag = pass number, so one memset per sort).  Units are handed out by an atomic ticket, which guarantees that every
+// predecessor of a running unit is running too.  Stable: units in input order, tiles of a unit in order.
+// ---------------------------------------------------------------------------
+constexpr int kMaxFusedPasses = 8;
+struct DigitSpecs {
+  DigitSpec d[kMaxFusedPasses];
+  int n;
+};
+
+template <int S>
+__global__ __launch_bounds__(kSortThreads) void k_radix_hist_all(const uint32_t *__restrict__ items, uint64_t n, DigitSpecs specs,
+                                                                 unsigned long long *__restrict__ ghist) {
+  __shared__ uint32_t h[kMaxFusedPasses][256];
+  for (int i = threadIdx.x; i < kMaxFusedPasses * 256; i += kSortThreads) (&h[0][0])[i] = 0;
+  __syncthreads();
+  const uint64_t stride = (uint64_t)gridDim.x * kSortThreads;
+  for (uint64_t idx = (uint64_t)blockIdx.x * kSortThreads + threadIdx.x; idx < n; idx += stride) {
+    Rec<S> r;
+    load_rec<S>(items + idx * S, r);
+    for (int p = 0; p < specs.n; ++p) atomicAdd(&h[p][rec_digit2<S>(r, specs.d[p])], 1u);
+  }
+  __syncthreads();
+  for (int p = 0; p < specs.n; ++p) {
+    const uint32_t v = h[p][threadIdx.x];
+    if (v) atomicAdd(&ghist[p * 256 + threadIdx.x], (unsigned long long)v);
+  }
+}
+// per pass: exclusive scan over the 256 digits -> first output index of each digit
+__global__ __launch_bounds__(256) void k_bin_starts(const unsigned long long *__restrict__ ghist, unsigned long long *__restrict__ starts) {
+  __shared__ uint64_t sm[256 / kWave + 1];
+  const unsigned long long v = ghist[blockIdx.x * 256 + threadIdx.x];
+  starts[blockIdx.x * 256 + threadIdx.x] = block_exclusive_sum<uint64_t, 256>((uint64_t)v, sm, nullptr);
+}
+
+constexpr unsigned long long kStValMask = (1ull << 56) - 1;
+
+template <int S, int NI, int UT>
+__global__ __launch_bounds__(kSortThreads) void k_radix_onesweep(const uint32_t *__restrict__ in, uint32_t *__restrict__ out, uint64_t n,
+                                                                 DigitSpec ds, int nbits, const unsigned long long *__restrict__ bin_start,
+                                                                 unsigned long long *__restrict__ status, uint32_t *__restrict__ ticket,
+                                                                 uint32_t *__restrict__ err, unsigned long long tag) {
+  constexpr int kTile = kSortThreads * NI;
+  __shared__ __attribute__((aligned(16))) uint32_t stage[kTile * S];
+  __shared__ uint32_t wave_cnt[kSortWaves][256];
+  __shared__ long long g_off[256];
+  __shared__ uint64_t g_base[256];
+  __shared__ uint32_t sm_scan[kSortThreads / kWave + 1];
+  __shared__ uint32_t s_unit;
+
+  const int tid = threadIdx.x, w = tid / kWave, lane = tid & (kWave - 1);
+  const uint64_t lanemask_lt = (1ull << lane) - 1;
+  if (tid == 0) s_unit = atomicAdd(ticket, 1u);
+#pragma unroll
+  for (int i = 0; i < kSortWaves; ++i) wave_cnt[i][tid] = 0;
+  __syncthreads();
+  const uint64_t unit = s_unit;
+  const uint64_t unit_base = unit * (uint64_t)(kTile * UT);
+
+  // 1. the unit's records -> registers (wave-blocked striped arrangement inside each tile, as in k_radix_scatter)
+  Rec<S> rec[UT][NI];
+#pragma unroll
+  for (int t = 0; t < UT; ++t)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const uint64_t gi = unit_base + (uint64_t)t * kTile + (uint64_t)(w * (kWave * NI) + j * kWave + lane);
+      if (gi < n) load_rec<S>(in + gi * S, rec[t][j]);
+    }
+  // 2. digit counts of the unit (per-wave LDS histograms), published before anything depends on other units
+#pragma unroll
+  for (int t = 0; t < UT; ++t)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const uint64_t gi = unit_base + (uint64_t)t * kTile + (uint64_t)(w * (kWave * NI) + j * kWave + lane);
+      if (gi < n) atomicAdd(&wave_cnt[w][rec_digit2<S>(rec[t][j], ds)], 1u);
+    }
+  __syncthreads();
+  {
+    unsigned long long tot = 0;
+#pragma unroll
+    for (int i = 0; i < kSortWaves; ++i) tot += wave_cnt[i][tid];
+    unsigned long long *st = status + unit * 256 + tid;
+    const unsigned long long tagbits = tag << 58;
+    __hip_atomic_store(st, tagbits | ((unit == 0 ? 2ull : 1ull) << 56) | tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // 3. decoupled look-back: sum the counts of the predecessors until one of them knows its inclusive prefix
+    unsigned long long excl = 0;
+    if (unit > 0) {
+      uint32_t polls = 0;
+      for (uint64_t p = unit; p-- > 0;) {
+        unsigned long long v;
+        for (;;) {
+          v = __hip_atomic_load(status + p * 256 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if ((v >> 58) == tag && ((v >> 56) & 3ull)) break;
+          if (++polls > (1u << 22)) {  // never observed; guarantees termination (the host raises on *err)
+            atomicOr(err, 1u);
+            v = 2ull << 56;
+            break;
+          }
+          __builtin_amdgcn_s_sleep(1);
+        }
+        excl += v & kStValMask;
+        if (((v >> 56) & 3ull) == 2ull) break;
+      }
+      __hip_atomic_store(st, tagbits | (2ull << 56) | (excl + tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    g_base[tid] = bin_start[tid] + excl;
+  }
+  __syncthreads();
+
+  // 4. tile by tile: rank, stage in LDS by digit, write the per-digit runs (same as k_radix_scatter)
+#pragma unroll
+  for (int t = 0; t < UT; ++t) {
+    const uint64_t tile_base = unit_base + (uint64_t)t * kTile;
+    if (tile_base >= n) break;
+    const uint64_t rem = n - tile_base;
+    const int tile_n = rem < (uint64_t)kTile ? (int)rem : kTile;
+#pragma unroll
+    for (int i = 0; i < kSortWaves; ++i) wave_cnt[i][tid] = 0;
+    __syncthreads();
+    uint32_t rank[NI];
+    unsigned dig[NI];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int li = w * (kWave * NI) + j * kWave + lane;
+      const bool valid = li < tile_n;
+      const unsigned d = valid ? rec_digit2<S>(rec[t][j], ds) : 0u;
+      dig[j] = d;
+      uint64_t peers = __ballot(valid);
+      for (int b = 0; b < nbits; ++b) {
+        const bool bitset = (d >> b) & 1u;
+        const uint64_t m = __ballot(bitset);
+        peers &= bitset ? m : ~m;
+      }
+      const uint32_t before = wave_cnt[w][d];
+      rank[j] = before + __builtin_popcountll(peers & lanemask_lt);
+      __builtin_amdgcn_wave_barrier();
+      if (valid && (peers & lanemask_lt) == 0) wave_cnt[w][d] = before + __builtin_popcountll(peers);
+      __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+    {
+      uint32_t c[kSortWaves], tot = 0;
+#pragma unroll
+      for (int i = 0; i < kSortWaves; ++i) {
+        c[i] = wave_cnt[i][tid];
+        tot += c[i];
+      }
+      const uint32_t start = block_exclusive_sum<uint32_t, kSortThreads>(tot, sm_scan, nullptr);
+      uint32_t run = start;
+#pragma unroll
+      for (int i = 0; i < kSortWaves; ++i) {
+        wave_cnt[i][tid] = run;
+        run += c[i];
+      }
+      g_off[tid] = (long long)g_base[tid] - (long long)start;
+      g_base[tid] += tot;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int li = w * (kWave * NI) + j * kWave + lane;
+      if (li < tile_n) store_rec<S>(stage + (size_t)(wave_cnt[w][dig[j]] + rank[j]) * S, rec[t][j]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int li = j * kSortThreads + tid;
+      if (li < tile_n) {
+        Rec<S> r;
+        load_rec<S>(stage + (size_t)li * S, r);
+        const unsigned d = rec_digit2<S>(r, ds);
+        store_rec<S>(out + (uint64_t)(g_off[d] + li) * S, r);
+      }
+    }
+    __syncthreads();
+  }
+}
+
 // Does the LDS apply the lanes of ONE returning atomic instruction that hit the same address in lane order?
 // Each wave does ds_add_rtn on a few shared counters with adversarial lane->address patterns; a lane's
 // returned value must equal the number of lower lanes of its wave that used the same address.
@@ -342,10 +528,64 @@ std::vector<SortPass> make_passes(int key_words, int lo_bit, int hi_bit) {
   return p;
 }
 
+static DigitSpec spec_of_pass(const SortPass &ps, int key_words) {
+  DigitSpec ds{key_words - 1 - ps.shift / 32, (unsigned)(ps.shift % 32), (1u << ps.bits) - 1, 0, 0u, 0u, 0u};
+  if (ps.bits2) {
+    ds.wi2 = key_words - 1 - ps.shift2 / 32;
+    ds.bit2 = (unsigned)(ps.shift2 % 32);
+    ds.mask2 = (1u << ps.bits2) - 1;
+    ds.sh2 = (unsigned)ps.bits;
+  }
+  return ds;
+}
+
+// chained-scan sort (8/12/16-byte records, <= 8 passes); MHX_SORT=classic selects the histogram + scan + scatter passes
+template <int S, int NI, int UT>
+static uint32_t *radix_sort_onesweep(mhx_ctx *c, uint32_t *a, uint32_t *b, uint64_t n, int key_words, const std::vector<SortPass> &passes) {
+  const int P = (int)passes.size();
+  const uint64_t unit = (uint64_t)kSortThreads * NI * UT, n_units = div_ceil(n, unit);
+  hipStream_t st = c->stream;
+  unsigned long long *status = c->ws("sort_status", n_units * 256 * 8).as<unsigned long long>();
+  unsigned long long *gh = c->ws("sort_ghist", (size_t)2 * kMaxFusedPasses * 256 * 8).as<unsigned long long>();
+  unsigned long long *starts = gh + kMaxFusedPasses * 256;
+  uint32_t *tickets = c->ws("sort_tickets", 64 * 4).as<uint32_t>();  // [0..P) tickets, [63] error flag
+  MHX_HIP(hipMemsetAsync(status, 0, n_units * 256 * 8, st));
+  MHX_HIP(hipMemsetAsync(gh, 0, (size_t)kMaxFusedPasses * 256 * 8, st));
+  MHX_HIP(hipMemsetAsync(tickets, 0, 64 * 4, st));
+  DigitSpecs specs;
+  specs.n = P;
+  for (int p = 0; p < P; ++p) specs.d[p] = spec_of_pass(passes[p], key_words);
+  const double bytes = (double)n * S * 4;
+  static const std::string nm_hist = "radix_hist_all_" + std::to_string(S * 4) + "B", nm_scat = "radix_scatter_" + std::to_string(S * 4) + "B";
+  const unsigned hgrid = (unsigned)std::min<uint64_t>(div_ceil(n, kSortThreads), 4096);
+  MHX_LAUNCH(c, nm_hist.c_str(), bytes, hipLaunchKernelGGL((k_radix_hist_all<S>), dim3(hgrid), dim3(kSortThreads), 0, st, a, n, specs, gh));
+  hipLaunchKernelGGL(k_bin_starts, dim3(P), dim3(256), 0, st, gh, starts);
+  for (int p = 0; p < P; ++p) {
+    MHX_LAUNCH(c, nm_scat.c_str(), 2 * bytes,
+               hipLaunchKernelGGL((k_radix_onesweep<S, NI, UT>), dim3((unsigned)n_units), dim3(kSortThreads), 0, st, a, b, n, specs.d[p],
+                                  passes[p].bits + passes[p].bits2, starts + p * 256, status, tickets + p, tickets + 63,
+                                  (unsigned long long)(p + 1)));
+    std::swap(a, b);
+  }
+  uint32_t e = 0;
+  MHX_HIP(hipMemcpyAsync(&e, tickets + 63, 4, hipMemcpyDeviceToHost, st));
+  MHX_HIP(hipStreamSynchronize(st));
+  if (e) throw Error("radix sort: chained scan timed out waiting for a predecessor unit (set MHX_SORT=classic)");
+  return a;
+}
+
 template <int S, int NI>
 static uint32_t *radix_sort_impl2(mhx_ctx *c, uint32_t *a, uint32_t *b, uint64_t n, int key_words,
                                   const std::vector<SortPass> &passes) {
   if (n == 0) return a;
+  if constexpr (S <= 4 && NI == 4) {
+    static const bool classic = [] {
+      const char *e = getenv("MHX_SORT");
+      return e && !strcmp(e, "classic");
+    }();
+    if (!classic && passes.size() <= (size_t)kMaxFusedPasses && div_ceil(n, (uint64_t)kSortThreads * NI * 4) < (1ull << 31))
+      return radix_sort_onesweep<S, NI, 4>(c, a, b, n, key_words, passes);
+  }
   const uint64_t n_chunks = div_ceil(n, SortCfg<S, NI>::kChunk);
   uint32_t *hist = c->ws("sort_hist", n_chunks * 256 * 4).as<uint32_t>();
   uint64_t *offs = c->ws("sort_offs", n_chunks * 256 * 8).as<uint64_t>();
