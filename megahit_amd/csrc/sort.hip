@@ -374,36 +374,12 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_onesweep(const uint32_t 
       if (gi < n) atomicAdd(&wave_cnt[w][rec_digit2<S>(rec[t][j], ds)], 1u);
     }
   __syncthreads();
-  {
-    unsigned long long tot = 0;
+  unsigned long long unit_tot = 0;
 #pragma unroll
-    for (int i = 0; i < kSortWaves; ++i) tot += wave_cnt[i][tid];
-    unsigned long long *st = status + unit * 256 + tid;
-    const unsigned long long tagbits = tag << 58;
-    __hip_atomic_store(st, tagbits | ((unit == 0 ? 2ull : 1ull) << 56) | tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    // 3. decoupled look-back: sum the counts of the predecessors until one of them knows its inclusive prefix
-    unsigned long long excl = 0;
-    if (unit > 0) {
-      uint32_t polls = 0;
-      for (uint64_t p = unit; p-- > 0;) {
-        unsigned long long v;
-        for (;;) {
-          v = __hip_atomic_load(status + p * 256 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if ((v >> 58) == tag && ((v >> 56) & 3ull)) break;
-          if (++polls > (1u << 22)) {  // never observed; guarantees termination (the host raises on *err)
-            atomicOr(err, 1u);
-            v = 2ull << 56;
-            break;
-          }
-          __builtin_amdgcn_s_sleep(1);
-        }
-        excl += v & kStValMask;
-        if (((v >> 56) & 3ull) == 2ull) break;
-      }
-      __hip_atomic_store(st, tagbits | (2ull << 56) | (excl + tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    g_base[tid] = bin_start[tid] + excl;
-  }
+  for (int i = 0; i < kSortWaves; ++i) unit_tot += wave_cnt[i][tid];
+  unsigned long long *const st = status + unit * 256 + tid;
+  const unsigned long long tagbits = tag << 58;
+  __hip_atomic_store(st, tagbits | ((unit == 0 ? 2ull : 1ull) << 56) | unit_tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __syncthreads();
 
   // 4. tile by tile: rank, stage in LDS by digit, write the per-digit runs (same as k_radix_scatter)
@@ -450,6 +426,31 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_onesweep(const uint32_t 
       for (int i = 0; i < kSortWaves; ++i) {
         wave_cnt[i][tid] = run;
         run += c[i];
+      }
+      if (t == 0) {
+        // 3. decoupled look-back (after the first tile's ranking, so that the predecessors had time to publish): sum the
+        //    counts of the predecessors until one of them knows its inclusive prefix
+        unsigned long long excl = 0;
+        if (unit > 0) {
+          uint32_t polls = 0;
+          for (uint64_t p = unit; p-- > 0;) {
+            unsigned long long v;
+            for (;;) {
+              v = __hip_atomic_load(status + p * 256 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              if ((v >> 58) == tag && ((v >> 56) & 3ull)) break;
+              if (++polls > (1u << 22)) {  // never observed; guarantees termination (the host raises on *err)
+                atomicOr(err, 1u);
+                v = 2ull << 56;
+                break;
+              }
+              __builtin_amdgcn_s_sleep(1);
+            }
+            excl += v & kStValMask;
+            if (((v >> 56) & 3ull) == 2ull) break;
+          }
+          __hip_atomic_store(st, tagbits | (2ull << 56) | (excl + unit_tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        g_base[tid] = bin_start[tid] + excl;
       }
       g_off[tid] = (long long)g_base[tid] - (long long)start;
       g_base[tid] += tot;
@@ -583,8 +584,12 @@ static uint32_t *radix_sort_impl2(mhx_ctx *c, uint32_t *a, uint32_t *b, uint64_t
       const char *e = getenv("MHX_SORT");
       return e && !strcmp(e, "classic");
     }();
-    if (!classic && passes.size() <= (size_t)kMaxFusedPasses && div_ceil(n, (uint64_t)kSortThreads * NI * 4) < (1ull << 31))
+    static const int ut = getenv("MHX_SORT_UT") ? atoi(getenv("MHX_SORT_UT")) : 4;  // tiles per unit (measured at 12 B: 2 -> 89, 4 -> 67, 8 -> 80 ms)
+    if (!classic && passes.size() <= (size_t)kMaxFusedPasses && div_ceil(n, (uint64_t)kSortThreads * NI * 2) < (1ull << 31)) {
+      if (ut == 2) return radix_sort_onesweep<S, NI, 2>(c, a, b, n, key_words, passes);
+      if (ut == 8 && S <= 3) return radix_sort_onesweep<S, NI, 8>(c, a, b, n, key_words, passes);
       return radix_sort_onesweep<S, NI, 4>(c, a, b, n, key_words, passes);
+    }
   }
   const uint64_t n_chunks = div_ceil(n, SortCfg<S, NI>::kChunk);
   uint32_t *hist = c->ws("sort_hist", n_chunks * 256 * 4).as<uint32_t>();
