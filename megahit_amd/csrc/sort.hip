@@ -579,16 +579,28 @@ template <int S, int NI>
 static uint32_t *radix_sort_impl2(mhx_ctx *c, uint32_t *a, uint32_t *b, uint64_t n, int key_words,
                                   const std::vector<SortPass> &passes) {
   if (n == 0) return a;
-  if constexpr (S <= 4 && NI == 4) {
+  if constexpr (S <= 4 && NI == default_items<S>()) {
     static const bool classic = [] {
       const char *e = getenv("MHX_SORT");
       return e && !strcmp(e, "classic");
     }();
-    static const int ut = getenv("MHX_SORT_UT") ? atoi(getenv("MHX_SORT_UT")) : 4;  // tiles per unit (measured at 12 B: 2 -> 89, 4 -> 67, 8 -> 80 ms)
-    if (!classic && passes.size() <= (size_t)kMaxFusedPasses && div_ceil(n, (uint64_t)kSortThreads * NI * 2) < (1ull << 31)) {
-      if (ut == 2) return radix_sort_onesweep<S, NI, 2>(c, a, b, n, key_words, passes);
-      if (ut == 8 && S <= 3) return radix_sort_onesweep<S, NI, 8>(c, a, b, n, key_words, passes);
-      return radix_sort_onesweep<S, NI, 4>(c, a, b, n, key_words, passes);
+    // unit shape: records per thread per tile x tiles per unit (MHX_SORT_SHAPE overrides).  Measured at 12 B, 1.33 G
+    // records, ms per 6 passes on one box: 4x2 89, 4x4 66, 4x8 80, 8x1 88, 6x2 72, 12x1 75, 16x1 78, 8x2 59, 8x3 57, 8x4 70
+    // (classic 3-kernel passes: 63 + 20 histogram): 2048-record tiles halve the number of scattered runs, units of
+    // 4-6 K records amortise the look-back, more registers cost occupancy.
+    static const std::string shape = getenv("MHX_SORT_SHAPE") ? getenv("MHX_SORT_SHAPE") : (S <= 3 ? "8x3" : "8x2");
+    if (!classic && passes.size() <= (size_t)kMaxFusedPasses && div_ceil(n, (uint64_t)kSortThreads * 8) < (1ull << 31)) {
+      if (shape == "8x2") return radix_sort_onesweep<S, 8, 2>(c, a, b, n, key_words, passes);
+      if (shape == "8x1") return radix_sort_onesweep<S, 8, 1>(c, a, b, n, key_words, passes);
+      if (shape == "8x3" && S <= 3) return radix_sort_onesweep<S, 8, 3>(c, a, b, n, key_words, passes);
+      if (shape == "8x4" && S <= 3) return radix_sort_onesweep<S, 8, 4>(c, a, b, n, key_words, passes);
+      if (shape == "12x1") return radix_sort_onesweep<S, 12, 1>(c, a, b, n, key_words, passes);
+      if (shape == "6x2") return radix_sort_onesweep<S, 6, 2>(c, a, b, n, key_words, passes);
+      if (shape == "16x1") return radix_sort_onesweep<S, 16, 1>(c, a, b, n, key_words, passes);
+      if (shape == "4x2") return radix_sort_onesweep<S, 4, 2>(c, a, b, n, key_words, passes);
+      if (shape == "4x8" && S <= 3) return radix_sort_onesweep<S, 4, 8>(c, a, b, n, key_words, passes);
+      if (shape == "4x4") return radix_sort_onesweep<S, 4, 4>(c, a, b, n, key_words, passes);
+      return radix_sort_onesweep<S, 8, 2>(c, a, b, n, key_words, passes);
     }
   }
   const uint64_t n_chunks = div_ceil(n, SortCfg<S, NI>::kChunk);
