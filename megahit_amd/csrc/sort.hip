@@ -301,7 +301,8 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(const uint32_t *
 // (tag = pass number, so one memset per sort).  Units are handed out by an atomic ticket, which guarantees that every
 // predecessor of a running unit is running too.  Stable: units in input order, tiles of a unit in order.
 // ---------------------------------------------------------------------------
-constexpr int kMaxFusedPasses = 8;
+constexpr int kMaxFusedPasses = 16;  // digit histograms taken in one read of the input
+constexpr int kMaxChainedPasses = 60;  // status tag = pass number + 1 in 6 bits
 struct DigitSpecs {
   DigitSpec d[kMaxFusedPasses];
   int n;
@@ -547,23 +548,28 @@ static uint32_t *radix_sort_onesweep(mhx_ctx *c, uint32_t *a, uint32_t *b, uint6
   const uint64_t unit = (uint64_t)kSortThreads * NI * UT, n_units = div_ceil(n, unit);
   hipStream_t st = c->stream;
   unsigned long long *status = c->ws("sort_status", n_units * 256 * 8).as<unsigned long long>();
-  unsigned long long *gh = c->ws("sort_ghist", (size_t)2 * kMaxFusedPasses * 256 * 8).as<unsigned long long>();
-  unsigned long long *starts = gh + kMaxFusedPasses * 256;
+  unsigned long long *gh = c->ws("sort_ghist", (size_t)2 * kMaxChainedPasses * 256 * 8).as<unsigned long long>();
+  unsigned long long *starts = gh + kMaxChainedPasses * 256;
   uint32_t *tickets = c->ws("sort_tickets", 64 * 4).as<uint32_t>();  // [0..P) tickets, [63] error flag
   MHX_HIP(hipMemsetAsync(status, 0, n_units * 256 * 8, st));
-  MHX_HIP(hipMemsetAsync(gh, 0, (size_t)kMaxFusedPasses * 256 * 8, st));
+  MHX_HIP(hipMemsetAsync(gh, 0, (size_t)kMaxChainedPasses * 256 * 8, st));
   MHX_HIP(hipMemsetAsync(tickets, 0, 64 * 4, st));
-  DigitSpecs specs;
-  specs.n = P;
-  for (int p = 0; p < P; ++p) specs.d[p] = spec_of_pass(passes[p], key_words);
   const double bytes = (double)n * S * 4;
   static const std::string nm_hist = "radix_hist_all_" + std::to_string(S * 4) + "B", nm_scat = "radix_scatter_" + std::to_string(S * 4) + "B";
   const unsigned hgrid = (unsigned)std::min<uint64_t>(div_ceil(n, kSortThreads), 4096);
-  MHX_LAUNCH(c, nm_hist.c_str(), bytes, hipLaunchKernelGGL((k_radix_hist_all<S>), dim3(hgrid), dim3(kSortThreads), 0, st, a, n, specs, gh));
+  std::vector<DigitSpec> all(P);
+  for (int p = 0; p < P; ++p) all[p] = spec_of_pass(passes[p], key_words);
+  for (int p0 = 0; p0 < P; p0 += kMaxFusedPasses) {  // one read of the input per 16 passes
+    DigitSpecs specs;
+    specs.n = std::min(kMaxFusedPasses, P - p0);
+    for (int p = 0; p < specs.n; ++p) specs.d[p] = all[p0 + p];
+    MHX_LAUNCH(c, nm_hist.c_str(), bytes,
+               hipLaunchKernelGGL((k_radix_hist_all<S>), dim3(hgrid), dim3(kSortThreads), 0, st, a, n, specs, gh + (size_t)p0 * 256));
+  }
   hipLaunchKernelGGL(k_bin_starts, dim3(P), dim3(256), 0, st, gh, starts);
   for (int p = 0; p < P; ++p) {
     MHX_LAUNCH(c, nm_scat.c_str(), 2 * bytes,
-               hipLaunchKernelGGL((k_radix_onesweep<S, NI, UT>), dim3((unsigned)n_units), dim3(kSortThreads), 0, st, a, b, n, specs.d[p],
+               hipLaunchKernelGGL((k_radix_onesweep<S, NI, UT>), dim3((unsigned)n_units), dim3(kSortThreads), 0, st, a, b, n, all[p],
                                   passes[p].bits + passes[p].bits2, starts + p * 256, status, tickets + p, tickets + 63,
                                   (unsigned long long)(p + 1)));
     std::swap(a, b);
@@ -579,28 +585,27 @@ template <int S, int NI>
 static uint32_t *radix_sort_impl2(mhx_ctx *c, uint32_t *a, uint32_t *b, uint64_t n, int key_words,
                                   const std::vector<SortPass> &passes) {
   if (n == 0) return a;
-  if constexpr (S <= 4 && NI == default_items<S>()) {
+  if constexpr (S <= 8 && NI == default_items<S>()) {
     static const bool classic = [] {
       const char *e = getenv("MHX_SORT");
       return e && !strcmp(e, "classic");
     }();
-    // unit shape: records per thread per tile x tiles per unit (MHX_SORT_SHAPE overrides).  Measured at 12 B, 1.33 G
-    // records, ms per 6 passes on one box: 4x2 89, 4x4 66, 4x8 80, 8x1 88, 6x2 72, 12x1 75, 16x1 78, 8x2 59, 8x3 57, 8x4 70
-    // (classic 3-kernel passes: 63 + 20 histogram): 2048-record tiles halve the number of scattered runs, units of
-    // 4-6 K records amortise the look-back, more registers cost occupancy.
-    static const std::string shape = getenv("MHX_SORT_SHAPE") ? getenv("MHX_SORT_SHAPE") : (S <= 3 ? "8x3" : "8x2");
-    if (!classic && passes.size() <= (size_t)kMaxFusedPasses && div_ceil(n, (uint64_t)kSortThreads * 8) < (1ull << 31)) {
-      if (shape == "8x2") return radix_sort_onesweep<S, 8, 2>(c, a, b, n, key_words, passes);
-      if (shape == "8x1") return radix_sort_onesweep<S, 8, 1>(c, a, b, n, key_words, passes);
-      if (shape == "8x3" && S <= 3) return radix_sort_onesweep<S, 8, 3>(c, a, b, n, key_words, passes);
-      if (shape == "8x4" && S <= 3) return radix_sort_onesweep<S, 8, 4>(c, a, b, n, key_words, passes);
-      if (shape == "12x1") return radix_sort_onesweep<S, 12, 1>(c, a, b, n, key_words, passes);
-      if (shape == "6x2") return radix_sort_onesweep<S, 6, 2>(c, a, b, n, key_words, passes);
-      if (shape == "16x1") return radix_sort_onesweep<S, 16, 1>(c, a, b, n, key_words, passes);
-      if (shape == "4x2") return radix_sort_onesweep<S, 4, 2>(c, a, b, n, key_words, passes);
-      if (shape == "4x8" && S <= 3) return radix_sort_onesweep<S, 4, 8>(c, a, b, n, key_words, passes);
-      if (shape == "4x4") return radix_sort_onesweep<S, 4, 4>(c, a, b, n, key_words, passes);
-      return radix_sort_onesweep<S, 8, 2>(c, a, b, n, key_words, passes);
+    if (!classic && passes.size() <= (size_t)kMaxChainedPasses && div_ceil(n, (uint64_t)kSortThreads * 8) < (1ull << 31)) {
+      if constexpr (S <= 4) {
+        // unit shape: records per thread per tile x tiles per unit (MHX_SORT_SHAPE overrides).  Measured at 12 B, 1.33 G
+        // records, ms per 6 passes on one box: 4x2 89, 4x4 66, 4x8 80, 8x1 88, 6x2 72, 12x1 75, 16x1 78, 8x2 59, 8x3 57, 8x4 70
+        // (classic 3-kernel passes: 63 + 20 histogram): 2048-record tiles halve the number of scattered runs, units of
+        // 4-6 K records amortise the look-back, more registers cost occupancy.
+        static const std::string shape = getenv("MHX_SORT_SHAPE") ? getenv("MHX_SORT_SHAPE") : (S <= 3 ? "8x3" : "8x2");
+        if (shape == "8x2") return radix_sort_onesweep<S, 8, 2>(c, a, b, n, key_words, passes);
+        if (shape == "4x4") return radix_sort_onesweep<S, 4, 4>(c, a, b, n, key_words, passes);
+        if (shape == "16x1") return radix_sort_onesweep<S, 16, 1>(c, a, b, n, key_words, passes);
+        if (shape == "8x4" && S <= 3) return radix_sort_onesweep<S, 8, 4>(c, a, b, n, key_words, passes);
+        if (S <= 3) return radix_sort_onesweep<S, 8, 3>(c, a, b, n, key_words, passes);
+        return radix_sort_onesweep<S, 8, 2>(c, a, b, n, key_words, passes);
+      } else {
+        return radix_sort_onesweep<S, 4, 2>(c, a, b, n, key_words, passes);  // 24/32-byte records: 8 per thread in registers
+      }
     }
   }
   const uint64_t n_chunks = div_ceil(n, SortCfg<S, NI>::kChunk);
