@@ -12,6 +12,8 @@
 // "first item" of a group (whose prev/next the reference re-uses for the whole group, :399) is the
 // first in read order.  kmlib::kmsort is unstable for buckets > 64 items, so mercy candidates can
 // differ from the reference there; is_solid and the histogram never depend on it.
+#include <algorithm>
+
 #include "dev_prims.h"
 #include <cstdlib>
 
@@ -115,9 +117,10 @@ __global__ __launch_bounds__(256) void k_s1_extract(const uint32_t *__restrict__
 // through LDS so that each store instruction writes 256 contiguous bytes.
 template <int KW, int S, bool COMPACT>
 __global__ __launch_bounds__(256) void k_s1_extract_fixed(const uint32_t *__restrict__ seq, uint32_t L, uint32_t per, uint64_t n_items, int k,
-                                                          uint64_t pos_base, uint32_t *__restrict__ items) {
+                                                          uint64_t pos_base, uint32_t *__restrict__ items, uint64_t first_block) {
   __shared__ uint32_t xpose[S % 2 == 1 ? 256 * S : 1];
-  const uint64_t g = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  const uint64_t blk = first_block + blockIdx.x;  // a launch covers < 2^31 items (a grid holds fewer than 2^32 threads)
+  const uint64_t g = blk * 256 + threadIdx.x;
   uint32_t out[S];
   if (g < n_items) {
     const uint64_t r = g / per;
@@ -127,7 +130,7 @@ __global__ __launch_bounds__(256) void k_s1_extract_fixed(const uint32_t *__rest
 #pragma unroll
     for (int i = 0; i < S; ++i) xpose[threadIdx.x * S + i] = out[i];
     __syncthreads();
-    const uint64_t w0 = (uint64_t)blockIdx.x * 256 * S, n_words = n_items * S;
+    const uint64_t w0 = blk * 256 * S, n_words = n_items * S;
 #pragma unroll
     for (int i = 0; i < S; ++i) {
       const uint64_t w = w0 + (uint64_t)i * 256 + threadIdx.x;
@@ -527,14 +530,16 @@ uint64_t s1_extract(mhx_ctx *c, uint32_t k, bool compact) {
   uint32_t *buf_a = c->ws("items_a", n_items * item_bytes + 64).as<uint32_t>();
   if (n_items) {
     const unsigned grid = 256 * 8;
-    const bool fixed = s.fixed_len >= k + 1 && n_items == (uint64_t)ns * (s.fixed_len - k + 4) && div_ceil(n_items, 256) < (1ull << 31);
+    const bool fixed = s.fixed_len >= k + 1 && n_items == (uint64_t)ns * (s.fixed_len - k + 4);
 #define MHX_S1X(SV, CP)                                                                                                      \
   do {                                                                                                                       \
-    if (fixed)                                                                                                               \
-      MHX_LAUNCH(c, "s1_extract", (double)n_items * item_bytes + (double)s.n_bases / 4,                                      \
-                 hipLaunchKernelGGL((k_s1_extract_fixed<KW, SV, CP>), dim3((unsigned)div_ceil(n_items, 256)), dim3(256), 0, st, \
-                                    s.words.as<uint32_t>(), s.fixed_len, s.fixed_len - k + 4, n_items, (int)k, c->pos_base, buf_a)); \
-    else                                                                                                                     \
+    if (fixed) {                                                                                                             \
+      const uint64_t n_blocks = div_ceil(n_items, 256), per_launch = 1ull << 23;                                             \
+      for (uint64_t b0 = 0; b0 < n_blocks; b0 += per_launch)                                                                 \
+        MHX_LAUNCH(c, "s1_extract", ((double)n_items * item_bytes + (double)s.n_bases / 4) * std::min(per_launch, n_blocks - b0) / n_blocks, \
+                   hipLaunchKernelGGL((k_s1_extract_fixed<KW, SV, CP>), dim3((unsigned)std::min(per_launch, n_blocks - b0)), dim3(256), 0, st, \
+                                      s.words.as<uint32_t>(), s.fixed_len, s.fixed_len - k + 4, n_items, (int)k, c->pos_base, buf_a, b0)); \
+    } else                                                                                                                   \
       MHX_LAUNCH(c, "s1_extract", (double)n_items * item_bytes + (double)s.n_bases / 4,                                      \
                  hipLaunchKernelGGL((k_s1_extract<KW, SV, CP>), dim3(grid), dim3(256), 0, st, s.words.as<uint32_t>(),        \
                                     s.start.as<uint64_t>(), item_start, ns, (int)k, c->pos_base, buf_a));                    \

@@ -4,6 +4,8 @@
 //            on both strands, with the W char and 65535-multiplicity in the low 20 key bits
 //            (Lv1FillOffsets :579-628 + Lv2ExtractSubString :630-700 fused)
 //   sort / groups / emit: shared with read2sdbg S2 (s2.hip)
+#include <algorithm>
+
 #include "dev_prims.h"
 #include "mhx_internal.h"
 
@@ -21,8 +23,8 @@ template <int KW, int S>
 __global__ __launch_bounds__(256) void k_seq_extract(const uint32_t *__restrict__ seq, const uint64_t *__restrict__ start,
                                                      const uint64_t *__restrict__ item_start, uint64_t n_seqs, uint32_t fixed_items,
                                                      const uint16_t *__restrict__ mult, int k, uint64_t n_items,
-                                                     uint32_t *__restrict__ items) {
-  const uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+                                                     uint32_t *__restrict__ items, uint64_t first_item) {
+  const uint64_t idx = first_item + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;  // a launch covers < 2^31 items
   if (idx >= n_items) return;
   uint64_t sid;
   if (fixed_items) sid = idx / fixed_items;
@@ -97,17 +99,21 @@ uint64_t seq2sdbg_extract(mhx_ctx *c, uint32_t k) {
   const uint32_t fixed_items = (s.fixed_len >= k + 1) ? 2 * (s.fixed_len - k + 2) : 0;
   const size_t item_bytes = (size_t)S * 4;
   uint32_t *buf_a = c->ws("items_a", n_items * item_bytes + 64).as<uint32_t>();
-  if (n_items) {
-    const unsigned grid = (unsigned)div_ceil(n_items, 256);
+  // one thread per item; a grid holds fewer than 2^32 threads, so large inputs take several launches
+  const uint64_t per_launch = 1ull << 31;
+  for (uint64_t first = 0; first < n_items; first += per_launch) {
+    const uint64_t n_now = std::min(per_launch, n_items - first);
+    const unsigned grid = (unsigned)div_ceil(n_now, 256);
+    const double bytes_now = ((double)n_items * item_bytes + (double)s.n_bases / 4) * (double)n_now / (double)n_items;
     MHX_DISPATCH_KW(KWv, {
       if (S == KW)
-        MHX_LAUNCH(c, "seq_extract", (double)n_items * item_bytes + (double)s.n_bases / 4,
+        MHX_LAUNCH(c, "seq_extract", bytes_now,
                    hipLaunchKernelGGL((k_seq_extract<KW, KW>), dim3(grid), dim3(256), 0, st, s.words.as<uint32_t>(), s.start.as<uint64_t>(),
-                                      item_start, ns, fixed_items, s.mult.as<uint16_t>(), (int)k, n_items, buf_a));
+                                      item_start, ns, fixed_items, s.mult.as<uint16_t>(), (int)k, n_items, buf_a, first));
       else
-        MHX_LAUNCH(c, "seq_extract", (double)n_items * item_bytes + (double)s.n_bases / 4,
+        MHX_LAUNCH(c, "seq_extract", bytes_now,
                    hipLaunchKernelGGL((k_seq_extract<KW, KW + 1>), dim3(grid), dim3(256), 0, st, s.words.as<uint32_t>(),
-                                      s.start.as<uint64_t>(), item_start, ns, fixed_items, s.mult.as<uint16_t>(), (int)k, n_items, buf_a));
+                                      s.start.as<uint64_t>(), item_start, ns, fixed_items, s.mult.as<uint16_t>(), (int)k, n_items, buf_a, first));
     });
   }
   return n_items;
