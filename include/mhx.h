@@ -199,6 +199,19 @@ void *mhx_device_pointer(mhx_ctx *, int which);
  * local is_solid used by stage 2 */
 int mhx_adopt_is_solid_slice(mhx_ctx *, const void *d_words, uint64_t n_words);
 
+/* ---- memory-bounded operation: the reference's lv1 passes (base_engine.cpp:54-141,213-281) ----
+ * By default an engine call materialises all its items at once.  For inputs whose items exceed HBM, run the call
+ * once per set of lv1 buckets: with a filter set, items are extracted over batches of reads (batch_bytes of staging,
+ * 0 = 1 GiB) and only those of the kept buckets are stored, so the working set is 2 x expected_items x item size.
+ * keep: 65536 flags (NULL switches the filter off); expected_items: an upper bound of the items in the kept buckets
+ * (sum of mhx_bucket_histogram over them).  The outputs of a filtered call cover the kept buckets only (edges / SdBG
+ * records and the per-bucket tables); with accumulate != 0 the state that spans buckets continues from the previous
+ * call instead of being reset: is_solid marks, multiplicity histogram, mercy candidates and aggregated stage-2 items
+ * of read2sdbg stage 1; first_0_out / last_0_in and the histogram of count.  Like the reference, every pass rescans
+ * all reads.  Works with the single-GPU calls and with mhx_dist_extract. */
+int mhx_bucket_histogram(mhx_ctx *, int stage /* enum mhx_stage */, uint32_t k, uint32_t min_count, uint64_t *hist /* 65536 */);
+int mhx_set_bucket_filter(mhx_ctx *, const uint8_t *keep, uint64_t expected_items, uint64_t batch_bytes, int accumulate);
+
 /* ---- measurement ---- */
 typedef struct {
   char name[48];

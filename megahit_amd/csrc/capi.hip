@@ -536,30 +536,10 @@ int mhx_dist_extract(mhx_ctx *c, int stage, uint32_t k, uint32_t min_count, mhx_
   MHX_TRY({
     MHX_HIP(hipSetDevice(c->device));
     if (c->work.find("owner_lut") == c->work.end()) throw mhx::Error("dist_extract: call mhx_set_partition first");
-    uint64_t n = 0;
-    int S = 0;
-    if (stage == MHX_STAGE_S1 || stage == MHX_STAGE_S1_MERCY) {
-      const bool compact = mhx::s1_compact(c, stage == MHX_STAGE_S1_MERCY ? 1 : 0);
-      n = mhx::s1_extract(c, k, compact);
-      S = mhx::s1_stride(k, compact);
-    } else if (stage == MHX_STAGE_COUNT) {
-      n = mhx::count_extract(c, k);
-      S = mhx::count_stride(k);
-    } else if (stage == MHX_STAGE_SEQ2SDBG) {
-      n = mhx::seq2sdbg_extract(c, k);
-      S = mhx::seq2sdbg_stride(k);
-    } else if (stage == MHX_STAGE_S2) {
-      // every rank must take the same path: the aggregated one needs stage 1 to have run with this (k, m) on
-      // all ranks, which the (k <= 22, m >= 2) rule makes a pure function of the arguments
-      c->dist_s2_agg = mhx::s2_use_aggregated(c, k, min_count);
-      if (c->dist_s2_agg) {
-        n = mhx::s2_agg_extract(c, k);
-        S = 2;
-      } else {
-        n = mhx::s2_extract(c, k, min_count);
-        S = mhx::round_up2((int)mhx::div_ceil(k * 2 + 4, 32));
-      }
-    } else throw mhx::Error("dist_extract: unknown stage");
+    const mhx::StageItems it = mhx::extract_stage(c, stage, k, min_count);
+    if (stage == MHX_STAGE_S2) c->dist_s2_agg = it.agg;
+    const uint64_t n = it.n;
+    const int S = it.S;
     uint32_t *a = c->work["items_a"].as<uint32_t>();
     uint32_t *send = c->ws("items_send", n * (size_t)S * 4 + 64).as<uint32_t>();
     mhx::partition_by_owner(c, a, send, n, S, c->work["owner_lut"].as<uint8_t>(), c->n_parts, counts);
@@ -680,6 +660,39 @@ int mhx_adopt_is_solid_slice(mhx_ctx *c, const void *d_words, uint64_t n_words) 
     b.used = need * 8;
     if (need) MHX_HIP(hipMemcpyAsync(b.p, d_words, need * 8, hipMemcpyDeviceToDevice, c->stream));
     MHX_HIP(hipStreamSynchronize(c->stream));
+  })
+}
+
+int mhx_bucket_histogram(mhx_ctx *c, int stage, uint32_t k, uint32_t min_count, uint64_t *hist) {
+  MHX_TRY({
+    MHX_HIP(hipSetDevice(c->device));
+    const bool was = c->filter_on;
+    c->filter_on = false;
+    try {
+      mhx::bucket_histogram(c, stage, k, min_count, hist);
+    } catch (...) {
+      c->filter_on = was;
+      throw;
+    }
+    c->filter_on = was;
+  })
+}
+int mhx_set_bucket_filter(mhx_ctx *c, const uint8_t *keep, uint64_t expected_items, uint64_t batch_bytes, int accumulate) {
+  MHX_TRY({
+    MHX_HIP(hipSetDevice(c->device));
+    c->accumulate = accumulate != 0;
+    c->filter_batch_bytes = batch_bytes;
+    if (!keep) {
+      c->filter_on = false;
+      return 0;
+    }
+    std::vector<uint8_t> lut(MHX_NUM_BUCKETS);
+    for (int b = 0; b < MHX_NUM_BUCKETS; ++b) lut[b] = keep[b] ? 0 : 1;  // owner 0 = keep, 1 = drop (partition_by_owner)
+    mhx::DevBuf &d = c->ws("filter_lut", MHX_NUM_BUCKETS);
+    MHX_HIP(hipMemcpyAsync(d.p, lut.data(), MHX_NUM_BUCKETS, hipMemcpyHostToDevice, c->stream));
+    MHX_HIP(hipStreamSynchronize(c->stream));
+    c->filter_on = true;
+    c->filter_expected = expected_items;
   })
 }
 

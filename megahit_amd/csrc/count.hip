@@ -208,9 +208,9 @@ __global__ void k_apply_count_events(const unsigned long long *__restrict__ ev, 
   else atomicMax(&last_0_in_p1[rid], off + 1);
 }
 
-__global__ void k_fix_last(uint32_t *__restrict__ last_p1, uint64_t n) {
+__global__ void k_fix_last(const uint32_t *__restrict__ last_p1, uint32_t *__restrict__ last_out, uint64_t n) {
   uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) last_p1[i] = last_p1[i] - 1u;  // 0 (unset) -> 0xFFFFFFFF sentinel, v+1 -> v
+  if (i < n) last_out[i] = last_p1[i] - 1u;  // 0 (unset) -> 0xFFFFFFFF sentinel, v+1 -> v
 }
 
 template <int S>
@@ -310,15 +310,22 @@ int count_process(mhx_ctx *c, uint32_t k, uint32_t m, uint32_t *buf_a, uint32_t 
   uint32_t *spare = sorted == buf_a ? buf_b : buf_a;
 
   // results
+  // accumulate (bucket-range passes after the first): first_0_out, the raw last_0_in (+1) values and the histogram of
+  // the earlier passes are kept; the published last_0_in is re-derived from the raw values after every pass
+  const bool acc = c->accumulate && c->results.count(MHX_BUF_FIRST_0_OUT) && c->results[MHX_BUF_FIRST_0_OUT].used == ns * 4 &&
+                   c->work.count("last_p1") && c->results.count(MHX_BUF_MUL_HIST);
   uint32_t *first = c->result(MHX_BUF_FIRST_0_OUT, (ns ? ns : 1) * 4).as<uint32_t>();
-  uint32_t *last = c->result(MHX_BUF_LAST_0_IN, (ns ? ns : 1) * 4).as<uint32_t>();
+  uint32_t *last_out = c->result(MHX_BUF_LAST_0_IN, (ns ? ns : 1) * 4).as<uint32_t>();
+  uint32_t *last = c->ws("last_p1", (ns ? ns : 1) * 4).as<uint32_t>();
   c->results[MHX_BUF_FIRST_0_OUT].used = ns * 4;
   c->results[MHX_BUF_LAST_0_IN].used = ns * 4;
   unsigned long long *hist = c->result(MHX_BUF_MUL_HIST, (MHX_MAX_MUL + 1) * 8).as<unsigned long long>();
   unsigned long long *bcount = c->result(MHX_BUF_BUCKET_COUNT, MHX_NUM_BUCKETS * 8).as<unsigned long long>();
-  MHX_HIP(hipMemsetAsync(first, 0xFF, (ns ? ns : 1) * 4, st));
-  MHX_HIP(hipMemsetAsync(last, 0x00, (ns ? ns : 1) * 4, st));
-  MHX_HIP(hipMemsetAsync(hist, 0, (MHX_MAX_MUL + 1) * 8, st));
+  if (!acc) {
+    MHX_HIP(hipMemsetAsync(first, 0xFF, (ns ? ns : 1) * 4, st));
+    MHX_HIP(hipMemsetAsync(last, 0x00, (ns ? ns : 1) * 4, st));
+    MHX_HIP(hipMemsetAsync(hist, 0, (MHX_MAX_MUL + 1) * 8, st));
+  }
   MHX_HIP(hipMemsetAsync(bcount, 0, MHX_NUM_BUCKETS * 8, st));
   // multi-GPU: at most 2 events of 8 bytes per item fit the spare sort buffer (records are >= 16 bytes)
   unsigned long long *events = global ? reinterpret_cast<unsigned long long *>(spare) : nullptr;
@@ -342,7 +349,7 @@ int count_process(mhx_ctx *c, uint32_t k, uint32_t m, uint32_t *buf_a, uint32_t 
     stash_route_records(c, events, h, hi_bit);
   } else if (ns) {
     MHX_LAUNCH(c, "fix_last", (double)ns * 8,
-               hipLaunchKernelGGL(k_fix_last, dim3((unsigned)div_ceil(ns, 256)), dim3(256), 0, st, last, ns));
+               hipLaunchKernelGGL(k_fix_last, dim3((unsigned)div_ceil(ns, 256)), dim3(256), 0, st, last, last_out, ns));
   }
 
   // expose the sorted items for tests (no copy: alias the workspace)
@@ -369,25 +376,25 @@ void count_apply_events(mhx_ctx *c, const unsigned long long *ev, uint64_t n) {
   SeqSet &s = c->seqs;
   hipStream_t st = c->stream;
   auto itf = c->results.find(MHX_BUF_FIRST_0_OUT), itl = c->results.find(MHX_BUF_LAST_0_IN);
-  if (itf == c->results.end() || itl == c->results.end() || itf->second.used != s.n_seqs * 4)
+  if (itf == c->results.end() || itl == c->results.end() || itf->second.used != s.n_seqs * 4 || !c->work.count("last_p1"))
     throw Error("dist_apply_routed: run mhx_dist_process_count first");
+  uint32_t *last_p1 = c->work["last_p1"].as<uint32_t>();
   if (n)
     MHX_LAUNCH(c, "count_apply_events", (double)n * 24,
                hipLaunchKernelGGL(k_apply_count_events, dim3((unsigned)div_ceil(n, 256)), dim3(256), 0, st, ev, n, c->pos_base,
-                                  s.start.as<uint64_t>(), s.n_seqs, s.fixed_len, itf->second.as<uint32_t>(), itl->second.as<uint32_t>()));
+                                  s.start.as<uint64_t>(), s.n_seqs, s.fixed_len, itf->second.as<uint32_t>(), last_p1));
   if (s.n_seqs)
     MHX_LAUNCH(c, "fix_last", (double)s.n_seqs * 8,
-               hipLaunchKernelGGL(k_fix_last, dim3((unsigned)div_ceil(s.n_seqs, 256)), dim3(256), 0, st, itl->second.as<uint32_t>(), s.n_seqs));
+               hipLaunchKernelGGL(k_fix_last, dim3((unsigned)div_ceil(s.n_seqs, 256)), dim3(256), 0, st, last_p1, itl->second.as<uint32_t>(), s.n_seqs));
   MHX_HIP(hipStreamSynchronize(st));
 }
 
 int run_count(mhx_ctx *c, uint32_t k, uint32_t m, mhx_count_result *out) {
   if (c->global_bases) throw Error("count: the global layout is set; use the mhx_dist_* entry points (or mhx_set_global_layout(0, 0))");
-  const uint64_t n_items = count_extract(c, k);
-  const size_t item_bytes = (size_t)count_stride(k) * 4;
+  const StageItems it = extract_stage(c, MHX_STAGE_COUNT, k, m);
   uint32_t *buf_a = c->work["items_a"].as<uint32_t>();
-  uint32_t *buf_b = c->ws("items_b", n_items * item_bytes + 64).as<uint32_t>();
-  return count_process(c, k, m, buf_a, buf_b, n_items, out);
+  uint32_t *buf_b = c->ws("items_b", it.n * (size_t)it.S * 4 + 64).as<uint32_t>();
+  return count_process(c, k, m, buf_a, buf_b, it.n, out);
 }
 
 }  // namespace mhx

@@ -85,6 +85,11 @@ struct mhx_ctx {
   uint32_t agg_k = 0, agg_m = 0;
   uint64_t agg_n = 0;
   uint64_t n_route = 0;      // multi-GPU: records in ws("route_records") (count events)
+  // memory-bounded passes (passes.hip): only items of the kept lv1 buckets are materialised
+  bool filter_on = false, accumulate = false;
+  uint64_t filter_expected = 0, filter_batch_bytes = 0;
+  uint64_t s1_acc_bits = 0, mercy_acc_n = 0;  // stage-1 state that accumulate continues
+  uint32_t s1_acc_k = 0, s1_acc_m = 0;
   bool dist_s2_agg = false;  // the items of the current multi-GPU stage-2 exchange are aggregated ones
   // profiling
   bool profiling = false;
@@ -160,6 +165,15 @@ int s2_process(mhx_ctx *c, uint32_t k, uint32_t *buf_a, uint32_t *buf_b, uint64_
 bool s2_use_aggregated(const mhx_ctx *c, uint32_t k, uint32_t m);
 uint64_t s2_agg_extract(mhx_ctx *c, uint32_t k);
 int s2_agg_process(mhx_ctx *c, uint32_t k, uint32_t *buf_a, uint32_t *buf_b, uint64_t n_items, mhx_sdbg_result *out);
+struct StageItems {
+  uint64_t n;      // items in ws("items_a")
+  int S;           // words per item
+  bool agg;        // stage 2: aggregated items (s2.hip)
+  bool batchable;  // produced by a scan over reads
+};
+StageItems extract_stage(mhx_ctx *c, int stage, uint32_t k, uint32_t m);
+void bucket_histogram(mhx_ctx *c, int stage, uint32_t k, uint32_t m, uint64_t *h_out);
+int s2_stride(uint32_t k);
 constexpr int MHX_BUF_IS_SOLID_LOCAL = 100;  // internal: this rank's slice of the global bitmap (multi-GPU)
 constexpr int MHX_BUF_MERCY_CAND_LOCAL = 101;  // internal: routed mercy candidates of the local reads, local positions
 uint64_t count_extract(mhx_ctx *c, uint32_t k);
@@ -170,6 +184,7 @@ uint64_t seq2sdbg_extract(mhx_ctx *c, uint32_t k);
 int seq2sdbg_stride(uint32_t k);
 int seq2sdbg_process(mhx_ctx *c, uint32_t k, uint32_t *buf_a, uint32_t *buf_b, uint64_t n_items, mhx_sdbg_result *out);
 const uint64_t *sort_u64(mhx_ctx *c, const void *src, uint64_t n, int hi_bit);
+DevBuf &grow_preserving(mhx_ctx *c, DevBuf &b, size_t bytes, size_t keep);
 void stash_route_records(mhx_ctx *c, const void *src, uint64_t n, int hi_bit);
 void mercy_adopt_routed(mhx_ctx *c, const long long *recv, uint64_t n);
 

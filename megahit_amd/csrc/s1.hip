@@ -474,6 +474,18 @@ __global__ void k_swap_words(uint32_t *__restrict__ v, uint64_t n) {
   }
 }
 
+// make `b` at least `bytes` large, preserving its first `keep` bytes
+DevBuf &grow_preserving(mhx_ctx *c, DevBuf &b, size_t bytes, size_t keep) {
+  if (b.cap >= bytes) return b;
+  DevBuf nb;
+  nb.reserve(bytes + bytes / 4);
+  if (keep && b.p) MHX_HIP(hipMemcpyAsync(nb.p, b.p, keep, hipMemcpyDeviceToDevice, c->stream));
+  MHX_HIP(hipStreamSynchronize(c->stream));
+  b.release();
+  b = nb;
+  return b;
+}
+
 // numeric sort of n 64-bit records on the device: swap to (hi,lo) words, record sort with 2 key words, swap back.
 // Returns a pointer into the workspace ("u64_sort_a" / "u64_sort_b") holding the sorted copy.
 const uint64_t *sort_u64(mhx_ctx *c, const void *src, uint64_t n, int hi_bit) {
@@ -582,14 +594,21 @@ int s1_process(mhx_ctx *c, uint32_t k, uint32_t m, int want_mercy, uint32_t *buf
   // MHX_S1_MARK: atomic (atomicOr into the bitmap) | solid | nonsolid (force the byte-map polarity) | unset = auto
   const char *mark_env = getenv("MHX_S1_MARK");
   const int mark_atomic = mark_env && !strcmp(mark_env, "atomic") ? 1 : 0;
+  // accumulate (bucket-range passes after the first, passes.hip): marks, histogram, aggregated stage-2 items and
+  // mercy candidates of the earlier passes are kept and the published results are cumulative
+  const bool acc = c->accumulate && c->s1_acc_bits == n_bits && c->s1_acc_k == k && c->s1_acc_m == m;
   uint8_t *solid_bytes = nullptr;
-  if (mark_atomic) MHX_HIP(hipMemsetAsync(is_solid, 0, (n_words64 + 1) * 8, st));
-  else {
+  if (mark_atomic) {
+    if (!acc) MHX_HIP(hipMemsetAsync(is_solid, 0, (n_words64 + 1) * 8, st));
+  } else {
     solid_bytes = c->ws("solid_bytes", (n_words64 + 1) * 64).as<uint8_t>();
-    MHX_HIP(hipMemsetAsync(solid_bytes, 0, (n_words64 + 1) * 64, st));
+    if (!acc) MHX_HIP(hipMemsetAsync(solid_bytes, 0, (n_words64 + 1) * 64, st));
     MHX_HIP(hipMemsetAsync(is_solid + n_words64, 0, 8, st));
   }
-  MHX_HIP(hipMemsetAsync(hist, 0, (MHX_MAX_MUL + 1) * 8, st));
+  if (!acc) MHX_HIP(hipMemsetAsync(hist, 0, (MHX_MAX_MUL + 1) * 8, st));
+  c->s1_acc_bits = n_bits;
+  c->s1_acc_k = k;
+  c->s1_acc_m = m;
   unsigned long long *ctr = c->ws("s1_counters", 64).as<unsigned long long>();
   MHX_HIP(hipMemsetAsync(ctr, 0, 64, st));
 
@@ -600,18 +619,21 @@ int s1_process(mhx_ctx *c, uint32_t k, uint32_t m, int want_mercy, uint32_t *buf
   // aggregated stage-2 items (k <= 22, m >= 2): at most 2 per solid run, a solid run has >= m records
   static const bool agg_off = getenv("MHX_S2_PER_OCCURRENCE") != nullptr;
   const bool agg = !agg_off && k <= 22 && m >= 2 && KWv == 2;
+  const bool agg_continues = acc && c->agg_valid && c->agg_k == k && c->agg_m == m;
   c->agg_valid = false;
   uint2 *agg_items = nullptr;
   uint64_t *agg_cursor = c->ws("s2_agg_cursor", 64).as<uint64_t>();
   if (agg) {
-    agg_items = c->ws("s2_agg_items", (n_items / m + 16) * 2 * 8).as<uint2>();
+    const uint64_t prev = agg_continues ? c->agg_n : 0;  // items of the earlier passes stay in front
+    agg_items = grow_preserving(c, c->work["s2_agg_items"], (prev + (n_items / m + 16) * 2) * 8, prev * 8).as<uint2>();
     MHX_HIP(hipMemsetAsync(agg_cursor, 0, 24, st));
+    if (prev) MHX_HIP(hipMemcpyAsync(agg_cursor, &c->agg_n, 8, hipMemcpyHostToDevice, st));
   }
   if (n_items) {
     // marking polarity from a 1/64 sample of the tiles: when most occurrences are solid it is cheaper to mark the
     // non-solid ones (each mark is a 32-byte partial HBM write).  Single GPU only: ranks must agree on the meaning.
     int mark_mode = 0;
-    const bool can_invert = !global && !mark_atomic;
+    const bool can_invert = !global && !mark_atomic && !c->filter_on && !c->accumulate;  // passes must agree on the meaning
 #define MHX_ARGS(WM) c, sorted, n_items, KWv, kmer_bits, m, solid_bytes, is_solid, mark_atomic, hist, ctr, WM, mercy, (int)k, agg_items, agg_cursor, mark_mode
 #define MHX_CASE(SV)                                                          \
   case SV:                                                                    \
@@ -666,6 +688,13 @@ int s1_process(mhx_ctx *c, uint32_t k, uint32_t m, int want_mercy, uint32_t *buf
     MHX_HIP(hipStreamSynchronize(st));
     n_solid = h[0];
     n_mercy = h[1];
+    if (want_mercy && (c->accumulate || c->filter_on)) {  // keep the candidates of every pass; publish their sorted union
+      const uint64_t prev = acc ? c->mercy_acc_n : 0;
+      DevBuf &ma = grow_preserving(c, c->work["mercy_acc"], (prev + n_mercy) * 8 + 8, prev * 8);
+      if (n_mercy) MHX_HIP(hipMemcpyAsync(reinterpret_cast<char *>(ma.p) + prev * 8, mercy, n_mercy * 8, hipMemcpyDeviceToDevice, st));
+      c->mercy_acc_n = n_mercy = prev + n_mercy;
+      mercy = ma.as<long long>();
+    }
     if (want_mercy && n_mercy) {
       int hi_bit = 3;
       while (hi_bit < 64 && ((n_bits << 2) >> hi_bit)) ++hi_bit;
@@ -695,12 +724,10 @@ int s1_process(mhx_ctx *c, uint32_t k, uint32_t m, int want_mercy, uint32_t *buf
 
 int run_s1(mhx_ctx *c, uint32_t k, uint32_t m, int want_mercy, mhx_s1_result *out) {
   if (c->global_bases) throw Error("read2sdbg_s1: a global layout is set; use the mhx_dist_* entry points");
-  const bool compact = s1_compact(c, want_mercy);
-  const uint64_t n_items = s1_extract(c, k, compact);
-  const int S = s1_stride(k, compact);
+  const StageItems it = extract_stage(c, want_mercy ? MHX_STAGE_S1_MERCY : MHX_STAGE_S1, k, m);
   uint32_t *buf_a = c->work["items_a"].as<uint32_t>();
-  uint32_t *buf_b = c->ws("items_b", n_items * (size_t)S * 4 + 64).as<uint32_t>();
-  return s1_process(c, k, m, want_mercy, buf_a, buf_b, n_items, out);
+  uint32_t *buf_b = c->ws("items_b", it.n * (size_t)it.S * 4 + 64).as<uint32_t>();
+  return s1_process(c, k, m, want_mercy, buf_a, buf_b, it.n, out);
 }
 
 }  // namespace mhx

@@ -590,6 +590,7 @@ std::vector<SortPass> make_passes_ranges(int key_words, const std::vector<std::p
 }
 
 static int s2_kw(uint32_t k) { return (int)div_ceil(k * 2 + 4, 32); }  // read_to_sdbg_s2.cpp:98-99
+int s2_stride(uint32_t k) { return round_up2(s2_kw(k)); }
 
 // items of the local reads -> c->ws("items_a"); returns their number
 uint64_t s2_extract(mhx_ctx *c, uint32_t k, uint32_t m) {
@@ -686,15 +687,11 @@ bool s2_use_aggregated(const mhx_ctx *c, uint32_t k, uint32_t m) { return c->agg
 
 int run_s2(mhx_ctx *c, uint32_t k, uint32_t m, mhx_sdbg_result *out) {
   if (c->global_bases) throw Error("read2sdbg_s2: a global layout is set; use the mhx_dist_* entry points");
-  if (s2_use_aggregated(c, k, m)) {
-    const uint64_t n_items = s2_agg_extract(c, k);
-    return s2_agg_process(c, k, c->work["items_a"].as<uint32_t>(), c->ws("items_b", n_items * 8 + 64).as<uint32_t>(), n_items, out);
-  }
-  const uint64_t n_items = s2_extract(c, k, m);
-  const int S = round_up2(s2_kw(k));
+  const StageItems it = extract_stage(c, MHX_STAGE_S2, k, m);
   uint32_t *buf_a = c->work["items_a"].as<uint32_t>();
-  uint32_t *buf_b = c->ws("items_b", n_items * (size_t)S * 4 + 64).as<uint32_t>();
-  return s2_process(c, k, buf_a, buf_b, n_items, out);
+  uint32_t *buf_b = c->ws("items_b", it.n * (size_t)it.S * 4 + 64).as<uint32_t>();
+  if (it.agg) return s2_agg_process(c, k, buf_a, buf_b, it.n, out);
+  return s2_process(c, k, buf_a, buf_b, it.n, out);
 }
 
 }  // namespace mhx

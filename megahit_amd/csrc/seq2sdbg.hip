@@ -129,11 +129,10 @@ int seq2sdbg_process(mhx_ctx *c, uint32_t k, uint32_t *buf_a, uint32_t *buf_b, u
 }
 
 int run_seq2sdbg(mhx_ctx *c, uint32_t k, mhx_sdbg_result *out) {
-  const uint64_t n_items = seq2sdbg_extract(c, k);
-  const size_t item_bytes = (size_t)seq2sdbg_stride(k) * 4;
+  const StageItems it = extract_stage(c, MHX_STAGE_SEQ2SDBG, k, 0);
   uint32_t *buf_a = c->work["items_a"].as<uint32_t>();
-  uint32_t *buf_b = c->ws("items_b", n_items * item_bytes + 64).as<uint32_t>();
-  return seq2sdbg_process(c, k, buf_a, buf_b, n_items, out);
+  uint32_t *buf_b = c->ws("items_b", it.n * (size_t)it.S * 4 + 64).as<uint32_t>();
+  return seq2sdbg_process(c, k, buf_a, buf_b, it.n, out);
 }
 
 }  // namespace mhx

@@ -60,6 +60,9 @@ class DistItems(C.Structure):
 
 STAGE_S1 = 1
 STAGE_S2 = 2
+STAGE_COUNT = 3
+STAGE_SEQ2SDBG = 4
+STAGE_S1_MERCY = 5
 
 # every symbol include/mhx.h declares: (restype, argtypes)
 _P = C.c_void_p
@@ -99,6 +102,8 @@ SYMBOLS = {
     "mhx_dist_apply_routed": (C.c_int, [_P, C.c_int, C.c_uint64]),
     "mhx_device_pointer": (_P, [_P, C.c_int]),
     "mhx_adopt_is_solid_slice": (C.c_int, [_P, _P, C.c_uint64]),
+    "mhx_bucket_histogram": (C.c_int, [_P, C.c_int, C.c_uint32, C.c_uint32, _P]),
+    "mhx_set_bucket_filter": (C.c_int, [_P, _P, C.c_uint64, C.c_uint64, C.c_int]),
     "mhx_profile_enable": (C.c_int, [_P, C.c_int]),
     "mhx_profile_reset": (C.c_int, [_P]),
     "mhx_profile_get": (C.c_int, [_P, C.POINTER(KernelStat), C.c_int]),
@@ -291,6 +296,20 @@ class Engine:
 
     def adopt_is_solid_slice(self, ptr, n_words):
         self._chk(self.lib.mhx_adopt_is_solid_slice(self.h, ptr, n_words))
+
+    # ---- memory-bounded passes (see megahit_amd/passes.py)
+    def bucket_histogram(self, stage, k, m):
+        h = np.zeros(NUM_BUCKETS, dtype=np.uint64)
+        self._chk(self.lib.mhx_bucket_histogram(self.h, stage, k, m, _ptr(h)))
+        return h
+
+    def set_bucket_filter(self, keep, expected_items=0, batch_bytes=0, accumulate=False):
+        if keep is None:
+            self._chk(self.lib.mhx_set_bucket_filter(self.h, None, 0, batch_bytes, int(accumulate)))
+            return
+        keep = np.ascontiguousarray(keep, dtype=np.uint8)
+        assert keep.size == NUM_BUCKETS
+        self._chk(self.lib.mhx_set_bucket_filter(self.h, _ptr(keep), int(expected_items), int(batch_bytes), int(accumulate)))
 
     # ---- outputs
     def fetch(self, which, dtype):

@@ -1,0 +1,81 @@
+"""GPU: memory-bounded bucket-range passes (the reference's lv1 passes) give the single-pass result."""
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+from megahit_amd import lib, passes
+from test_gpu_count import load, make_reads
+from test_gpu_sdbg import edges_package
+
+pytestmark = pytest.mark.gpu
+
+BATCH = 8 << 20  # small staging so that every pass runs over many read batches
+
+
+def _check_sdbg(got, want):
+    assert got["n_passes"] >= 3
+    assert got["wpt"] == want["wpt"]
+    assert np.array_equal(got["bytes"], want["bytes"])
+    assert np.array_equal(got["bucket_items"], want["bucket_items"])
+    assert np.array_equal(got["bucket_tips"], want["bucket_tips"])
+    assert np.array_equal(got["bucket_large"], want["bucket_large"])
+    nz = want["bucket_items"] > 0
+    assert np.array_equal(got["bucket_off"][nz], want["bucket_off"][nz])
+    assert np.array_equal(got["w_count"][:9], want["w_count"]) and got["w_count"][9] == want["ones_in_last"]
+
+
+@pytest.mark.parametrize("kind,k,m", [("fixed", 21, 2), ("var", 31, 3), ("lowcomplex", 21, 2)])
+def test_count_in_passes(engine, kind, k, m):
+    reads = make_reads(kind, 31)
+    pkg = ob.Package(reads, reverse=True)
+    want = ob.count(pkg, k, m)
+    load(engine, pkg)
+    got = passes.count_in_passes(engine, k, m, max_items=-4, batch_bytes=BATCH)
+    assert got["n_passes"] >= 3
+    assert np.array_equal(got["edges"], want["edges"])
+    assert np.array_equal(got["bucket_count"], want["bucket_count"])
+    assert np.array_equal(got["hist"], want["hist"])
+    assert np.array_equal(got["first_0_out"], want["first_0_out"])
+    assert np.array_equal(got["last_0_in"], want["last_0_in"])
+    # the filter is off again: a plain call gives the full result
+    r = engine.count(k, m)
+    assert r.n_items == want["n_items"] and r.n_edges == len(want["edges"])
+
+
+@pytest.mark.parametrize("kind,k,m,mercy", [("fixed", 21, 2, 0), ("var", 21, 2, 1), ("var", 27, 3, 0), ("var", 27, 2, 2),
+                                           ("lowcomplex", 21, 2, 0), ("var", 31, 1, 0)])
+def test_read2sdbg_in_passes(engine, kind, k, m, mercy):
+    reads = make_reads(kind, 32)
+    pkg = ob.Package(reads, reverse=True)
+    load(engine, pkg)
+    if m > 1:
+        w1 = ob.s1(pkg, k, m, tie_stable=mercy != 2)
+        solid = w1["is_solid"]
+        if mercy:
+            n_want, solid = ob.s2_add_mercy(pkg, k, w1["is_solid"], w1["mercy"])
+        want = ob.s2(pkg, k, m, solid)
+    else:
+        want = ob.s2(pkg, k, 1, None)
+    s1, got = passes.read2sdbg_in_passes(engine, k, m, max_items_s1=-3, max_items_s2=-4, need_mercy=mercy, batch_bytes=BATCH)
+    if m > 1:
+        assert s1["n_passes"] >= 3 and s1["n_items"] == w1["n_items"]
+        assert np.array_equal(engine.fetch(lib.BUF_MUL_HIST, np.int64), w1["hist"])
+        bits = engine.fetch(lib.BUF_IS_SOLID, np.uint64)
+        assert np.array_equal(bits, solid[: bits.size])
+        if mercy:
+            assert s1["n_mercy"] == n_want
+            assert np.array_equal(engine.fetch(lib.BUF_MERCY_CAND, np.int64), w1["mercy"])
+    _check_sdbg(got, want)
+
+
+@pytest.mark.parametrize("k", [21, 39, 79])
+def test_seq2sdbg_in_passes(engine, k):
+    reads = make_reads("var", 33)
+    cnt = ob.count(ob.Package(reads, reverse=True), k, 2)
+    seqs, mult = edges_package(cnt["edges"], k)
+    pkg = ob.Package(seqs, reverse=False)
+    want = ob.seq2sdbg(pkg, mult, k)
+    engine.load_sequences(pkg.words(), pkg.n_seqs, 0, pkg.start())
+    engine.load_multiplicity(mult)
+    got = passes.seq2sdbg_in_passes(engine, k, max_items=-5, batch_bytes=BATCH)
+    _check_sdbg(got, want)
