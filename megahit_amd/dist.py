@@ -1,4 +1,4 @@
-"""Multi-GPU read2sdbg: one process per GPU, lv1 buckets sharded over ranks, items moved with an
+"""Multi-GPU count / read2sdbg / seq2sdbg: one process per GPU, lv1 buckets sharded over ranks, items moved with an
 all-to-all (RCCL over xGMI through torch.distributed; `gloo` on CPU for tests).
 
 Per stage (S1, then S2) every rank
@@ -117,6 +117,26 @@ class _DistBase:
             self.stride = self.stride_words * 64
             engine.set_global_layout(rank * self.stride, world * self.stride)
 
+    def plan_passes(self, stage, k, m, n_passes):
+        """Split every owner's bucket range into n_passes contiguous sub-ranges of about equal GLOBAL weight; pass p
+        handles sub-range p of every owner, so each pass keeps all ranks busy with 1/n_passes of the items.
+        -> [(keep mask uint8[65536], items of the LOCAL reads in it)]"""
+        local = np.asarray(self.e.bucket_histogram(stage, k, m), dtype=np.int64)
+        t = torch.as_tensor(local.copy(), device=self.device)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.x.group)
+        glob = t.cpu().numpy().astype(np.float64)
+        masks = [np.zeros(NUM_BUCKETS, dtype=np.uint8) for _ in range(n_passes)]
+        for r in range(self.world):
+            lo, hi = int(self.bucket_begin[r]), int(self.bucket_begin[r + 1])
+            if hi <= lo:
+                continue
+            cum = np.concatenate([[0.0], np.cumsum(glob[lo:hi])])
+            cuts = [lo + int(np.searchsorted(cum, cum[-1] * p / n_passes, side="left")) for p in range(1, n_passes)]
+            cuts = np.maximum.accumulate(np.clip(np.array([lo] + cuts + [hi]), lo, hi))
+            for p in range(n_passes):
+                masks[p][cuts[p]:cuts[p + 1]] = 1
+        return [(mk, int(local[mk.astype(bool)].sum())) for mk in masks]
+
     def _move(self, ptr, n_items, item_bytes, counts):
         recv_counts = self.x.exchange_counts(counts)
         n_recv = int(recv_counts.sum())
@@ -174,30 +194,55 @@ class DistSeq2Sdbg(_DistBase):
 class DistRead2Sdbg(_DistBase):
     """read2sdbg (S1 [+ mercy] + S2) over `world` ranks.  After step(): engine holds this rank's SdBG
     records (its bucket range) exactly as the single-GPU engine would for those buckets.
-    need_mercy: 0 none, 1 stable tie order, 2 reference-exact tie order (as mhx_read2sdbg_s1)."""
+    need_mercy: 0 none, 1 stable tie order, 2 reference-exact tie order (as mhx_read2sdbg_s1).
+    n_passes > 1: memory-bounded operation (megahit_amd/passes.py): every stage runs once per sub-range of the owned
+    buckets; stage-1 state accumulates, the stage-2 output of pass p is handed to on_s2_pass(p, result) (the
+    engine's result buffers then hold that sub-range) before the next pass overwrites it."""
 
-    def __init__(self, engine, k, min_count, rank, world, device, bucket_begin=None, staging=None, need_mercy=0):
+    def __init__(self, engine, k, min_count, rank, world, device, bucket_begin=None, staging=None, need_mercy=0, n_passes=1,
+                 batch_bytes=0, on_s2_pass=None):
         super().__init__(engine, rank, world, device, bucket_begin, staging)
         self.k, self.m, self.need_mercy = k, min_count, int(need_mercy)
+        self.n_passes, self.batch_bytes, self.on_s2_pass = int(n_passes), batch_bytes, on_s2_pass
         self.n_mercy = 0
+
+    def _passes(self, stage):
+        if self.n_passes <= 1:
+            return [(None, 0)]
+        return self.plan_passes(stage, self.k, self.m, self.n_passes)
 
     def step(self):
         r1 = None
-        if self.m > 1:  # stage 1 is skipped when every edge is solid (reference main_sdbg_build.cpp:139-147)
-            n1 = self._alltoall(STAGE_S1_MERCY if self.need_mercy else STAGE_S1, self.k, self.m)
-            r1 = self.e.dist_process_s1(self.k, self.m, n1, self.need_mercy)
-            n_words = self.world * self.stride_words
-            bm = self.e.as_tensor(self.e.device_pointer(BUF_IS_SOLID), n_words * 8, self.device).view(torch.int64)
-            if self.staging == "host":
-                h = bm.cpu()
-                sl = self.x.sum_bitmap_and_take_slice(h, self.stride_words).to(bm.device)
-            else:
-                sl = self.x.sum_bitmap_and_take_slice(bm, self.stride_words)
-            self.e.adopt_is_solid_slice(sl.data_ptr(), self.stride_words)
-            self._keep = sl
-            if self.need_mercy:  # candidates -> read owners; the mercy block of Read2SdbgS2::Initialize runs there
-                self._route(ROUTE_MERCY_CAND)
-                self.n_mercy = self.e.read2sdbg_add_mercy(self.k)
-        n2 = self._alltoall(STAGE_S2, self.k, self.m)
-        r2 = self.e.dist_process_s2(self.k, n2)
+        try:
+            if self.m > 1:  # stage 1 is skipped when every edge is solid (reference main_sdbg_build.cpp:139-147)
+                stage = STAGE_S1_MERCY if self.need_mercy else STAGE_S1
+                for p, (mask, expected) in enumerate(self._passes(stage)):
+                    if mask is not None:
+                        self.e.set_bucket_filter(mask, expected, self.batch_bytes, accumulate=p > 0)
+                    n1 = self._alltoall(stage, self.k, self.m)
+                    r1 = self.e.dist_process_s1(self.k, self.m, n1, self.need_mercy)
+                self.e.set_bucket_filter(None)
+                n_words = self.world * self.stride_words
+                bm = self.e.as_tensor(self.e.device_pointer(BUF_IS_SOLID), n_words * 8, self.device).view(torch.int64)
+                if self.staging == "host":
+                    h = bm.cpu()
+                    sl = self.x.sum_bitmap_and_take_slice(h, self.stride_words).to(bm.device)
+                else:
+                    sl = self.x.sum_bitmap_and_take_slice(bm, self.stride_words)
+                self.e.adopt_is_solid_slice(sl.data_ptr(), self.stride_words)
+                self._keep = sl
+                if self.need_mercy:  # candidates -> read owners; the mercy block of Read2SdbgS2::Initialize runs there
+                    self._route(ROUTE_MERCY_CAND)
+                    self.n_mercy = self.e.read2sdbg_add_mercy(self.k)
+            r2 = None
+            for p, (mask, expected) in enumerate(self._passes(STAGE_S2)):
+                if mask is not None:
+                    self.e.set_bucket_filter(mask, expected, self.batch_bytes)
+                n2 = self._alltoall(STAGE_S2, self.k, self.m)
+                r2 = self.e.dist_process_s2(self.k, n2)
+                if self.on_s2_pass is not None:
+                    self.on_s2_pass(p, r2)
+        finally:
+            if self.n_passes > 1:
+                self.e.set_bucket_filter(None)
         return r1, r2

@@ -26,6 +26,9 @@ class OracleEngine:
         self.global_bases = 0
         self.local_solid = None
         self.sdbg = None
+        self.keep = None
+        self.accumulate = False
+        self.mercy_global = np.zeros(0, dtype=np.int64)
 
     def _new(self, arr):
         h = self.next_handle
@@ -43,8 +46,30 @@ class OracleEngine:
     def set_global_layout(self, pos_base, global_bases):
         self.pos_base, self.global_bases = pos_base, global_bases
 
-    def dist_extract(self, stage, k, m):
+    def _items(self, stage, k, m):
         if stage in (1, 5):
+            return ob.s1_items(self.pkg, k, self.pos_base)
+        if stage == 3:
+            return ob.count_items(self.pkg, k, self.pos_base)
+        if stage == 4:
+            return ob.seq2sdbg_items(self.pkg, self.mult, k)
+        return ob.s2_items(self.pkg, k, m, self.local_solid if m > 1 else None)
+
+    def bucket_histogram(self, stage, k, m):
+        it = self._items(stage, k, m)
+        return np.bincount(it[:, 0] >> 16, minlength=65536).astype(np.uint64)
+
+    def set_bucket_filter(self, keep, expected_items=0, batch_bytes=0, accumulate=False):
+        self.keep = None if keep is None else np.asarray(keep).astype(bool)
+        self.expected = expected_items
+        self.accumulate = bool(accumulate)
+
+    def dist_extract(self, stage, k, m):
+        if self.keep is not None:
+            items = self._items(stage, k, m)
+            items = items[self.keep[items[:, 0] >> 16]]
+            assert len(items) <= self.expected
+        elif stage in (1, 5):
             items = ob.s1_items(self.pkg, k, self.pos_base)
         elif stage == 3:
             items = ob.count_items(self.pkg, k, self.pos_base)
@@ -73,12 +98,18 @@ class OracleEngine:
         w = (2 * (k - 1) + 6 + 31) // 32 + 2
         items = self.recv.view(np.uint32).reshape(-1, w)[:n_items]
         assert (self.lut[items[:, 0] >> 16] == self.my_part).all()
+        mercy = np.zeros(0, dtype=np.int64)
         if want_mercy:
-            bits, hist, self.mercy_global = ob.s1_reduce_mercy(items, k, m, self.global_bases, tie_stable=want_mercy != 2)
+            bits, hist, mercy = ob.s1_reduce_mercy(items, k, m, self.global_bases, tie_stable=want_mercy != 2)
         else:
             bits, hist = ob.s1_reduce(items, k, m, self.global_bases)
+        if self.accumulate:  # later bucket-range pass: continue from the earlier ones
+            bits = bits | self.global_bits
+            hist = hist + self.hist
+            mercy = np.concatenate([self.mercy_global, mercy])
         self.global_bits = np.ascontiguousarray(bits)
         self.hist = hist
+        self.mercy_global = mercy
         r = Res()
         r.n_items = n_items
         return r

@@ -98,6 +98,8 @@ def _worker2(rank, world, port, mode, k, m, q):
     from cpu_engine import OracleEngine
     from megahit_amd import dist as mdist
     dev = torch.device("cpu")
+    if mode.startswith("passes"):
+        pass
     if mode == "count":
         eng = OracleEngine(_reads(100 + rank))
         runner = mdist.DistCount(eng, k, m, rank, world, dev)
@@ -110,6 +112,21 @@ def _worker2(rank, world, port, mode, k, m, q):
         runner.step()
         lo, hi = int(runner.bucket_begin[rank]), int(runner.bucket_begin[rank + 1])
         q.put((rank, lo, hi, eng.sdbg["bytes"].tobytes(), eng.sdbg["bucket_items"], eng.sdbg["bucket_tips"], eng.sdbg["bucket_large"]))
+    elif mode in ("passes", "passes_mercy"):  # memory-bounded: every stage in 3 bucket sub-range passes
+        eng = OracleEngine(_reads(100 + rank))
+        got = dict(bytes=[], items=0, tips=0, large=0)
+
+        def collect(p, r2):
+            got["bytes"].append(eng.sdbg["bytes"].tobytes())
+            got["items"] = got["items"] + eng.sdbg["bucket_items"]
+            got["tips"] = got["tips"] + eng.sdbg["bucket_tips"]
+            got["large"] = got["large"] + eng.sdbg["bucket_large"]
+
+        runner = mdist.DistRead2Sdbg(eng, k, m, rank, world, dev, need_mercy=1 if mode == "passes_mercy" else 0, n_passes=3,
+                                     on_s2_pass=collect)
+        runner.step()
+        lo, hi = int(runner.bucket_begin[rank]), int(runner.bucket_begin[rank + 1])
+        q.put((rank, lo, hi, b"".join(got["bytes"]), got["items"], got["tips"], got["large"], runner.n_mercy))
     else:  # read2sdbg with mercy
         eng = OracleEngine(_reads(100 + rank))
         runner = mdist.DistRead2Sdbg(eng, k, m, rank, world, dev, need_mercy=1)
@@ -182,6 +199,24 @@ def test_two_ranks_read2sdbg_with_mercy(k, m):
     n_want, solid = ob.s2_add_mercy(pkg, k, s1["is_solid"], s1["mercy"])
     assert sum(o[7] for o in outs) == n_want and n_want > 0
     _check_sdbg_ranges(outs, ob.s2(pkg, k, m, solid))
+
+
+@pytest.mark.parametrize("mode,k,m", [("passes", 21, 2), ("passes_mercy", 27, 2), ("passes", 21, 1)])
+def test_two_ranks_read2sdbg_in_passes(mode, k, m):
+    """bucket sub-range passes on every rank (filtered extraction, accumulating stage 1) = the single-pass result"""
+    import oracle_binding as ob
+    outs = _run2(mode, k, m)
+    pkg = ob.Package(_reads(100) + _reads(101), reverse=True)
+    if m > 1:
+        s1 = ob.s1(pkg, k, m, tie_stable=True)
+        solid = s1["is_solid"]
+        if mode == "passes_mercy":
+            n_want, solid = ob.s2_add_mercy(pkg, k, s1["is_solid"], s1["mercy"])
+            assert sum(o[7] for o in outs) == n_want and n_want > 0
+        want = ob.s2(pkg, k, m, solid)
+    else:
+        want = ob.s2(pkg, k, 1, None)
+    _check_sdbg_ranges(outs, want)
 
 
 def test_partitions():

@@ -96,8 +96,26 @@ def _worker2(rank, world, port, mode, k, m, q):
     else:
         pkg = ob.Package(_reads(100 + rank), reverse=True)
         eng.load_sequences(pkg.words(), pkg.n_seqs, 0, pkg.start())
+        got = dict(bytes=[], items=0, tips=0, large=0)
+
+        def collect(p, r2):
+            got["bytes"].append(eng.fetch(lib.BUF_SDBG_BYTES, np.uint8).tobytes())
+            got["items"] = got["items"] + eng.fetch(lib.BUF_BUCKET_COUNT, np.uint64)
+            got["tips"] = got["tips"] + eng.fetch(lib.BUF_BUCKET_TIPS, np.uint64)
+            got["large"] = got["large"] + eng.fetch(lib.BUF_BUCKET_LARGE, np.uint64)
+
         if mode == "count":
             runner = mdist.DistCount(eng, k, m, rank, world, dev, staging="host")
+        elif mode.startswith("passes"):
+            runner = mdist.DistRead2Sdbg(eng, k, m, rank, world, dev, staging="host", need_mercy=1 if mode == "passes_mercy" else 0,
+                                         n_passes=3, batch_bytes=8 << 20, on_s2_pass=collect)
+            runner.step()
+            lo, hi = int(runner.bucket_begin[rank]), int(runner.bucket_begin[rank + 1])
+            q.put((rank, lo, hi, b"".join(got["bytes"]), got["items"], got["tips"], got["large"], runner.n_mercy))
+            dist.barrier()
+            dist.destroy_process_group()
+            eng.close()
+            return
         else:
             runner = mdist.DistRead2Sdbg(eng, k, m, rank, world, dev, staging="host", need_mercy=2 if mode == "mercy_exact" else 1)
     runner.step()
@@ -173,3 +191,25 @@ def test_read2sdbg_mercy_ranks_on_one_gpu(world, k, m, mode):
     n_want, solid = ob.s2_add_mercy(pkg, k, s1["is_solid"], s1["mercy"])
     assert sum(o[7] for o in outs) == n_want and n_want > 0
     _check_sdbg_ranges(outs, ob.s2(pkg, k, m, solid))
+
+
+@pytest.mark.parametrize("world,k,m,mode", [(2, 21, 2, "passes"), (2, 27, 2, "passes_mercy"), (2, 31, 1, "passes")])
+def test_read2sdbg_passes_ranks_on_one_gpu(world, k, m, mode):
+    """memory-bounded operation on every rank: 3 bucket sub-range passes per stage"""
+    import oracle_binding as ob
+    from test_dist_cpu import _check_sdbg_ranges
+    outs = _run2(mode, k, m, world)
+    allreads = []
+    for r in range(world):
+        allreads += _reads(100 + r)
+    pkg = ob.Package(allreads, reverse=True)
+    if m > 1:
+        s1 = ob.s1(pkg, k, m, tie_stable=True)
+        solid = s1["is_solid"]
+        if mode == "passes_mercy":
+            n_want, solid = ob.s2_add_mercy(pkg, k, s1["is_solid"], s1["mercy"])
+            assert sum(o[7] for o in outs) == n_want and n_want > 0
+        want = ob.s2(pkg, k, m, solid)
+    else:
+        want = ob.s2(pkg, k, 1, None)
+    _check_sdbg_ranges(outs, want)
