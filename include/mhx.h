@@ -209,6 +209,7 @@ int mhx_adopt_is_solid_slice(mhx_ctx *, const void *d_words, uint64_t n_words);
  * call instead of being reset: is_solid marks, multiplicity histogram, mercy candidates and aggregated stage-2 items
  * of read2sdbg stage 1; first_0_out / last_0_in and the histogram of count.  Like the reference, every pass rescans
  * all reads.  Works with the single-GPU calls and with mhx_dist_extract. */
+uint64_t mhx_device_free_bytes(mhx_ctx *);  /* free HBM on the handle's device right now (workspaces of this handle included in "used") */
 int mhx_bucket_histogram(mhx_ctx *, int stage /* enum mhx_stage */, uint32_t k, uint32_t min_count, uint64_t *hist /* 65536 */);
 int mhx_set_bucket_filter(mhx_ctx *, const uint8_t *keep, uint64_t expected_items, uint64_t batch_bytes, int accumulate);
 

@@ -663,6 +663,11 @@ int mhx_adopt_is_solid_slice(mhx_ctx *c, const void *d_words, uint64_t n_words) 
   })
 }
 
+uint64_t mhx_device_free_bytes(mhx_ctx *c) {
+  size_t free_b = 0, total_b = 0;
+  if (hipSetDevice(c->device) != hipSuccess || hipMemGetInfo(&free_b, &total_b) != hipSuccess) return 0;
+  return (uint64_t)free_b;
+}
 int mhx_bucket_histogram(mhx_ctx *c, int stage, uint32_t k, uint32_t min_count, uint64_t *hist) {
   MHX_TRY({
     MHX_HIP(hipSetDevice(c->device));

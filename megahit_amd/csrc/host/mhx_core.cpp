@@ -115,6 +115,87 @@ int out_files(int n_threads) {
   return 1;
 }
 
+// ---- memory plan (the reference's --host_mem / lv1 passes, base_engine.cpp:54-141): when the items of a stage do not
+// fit the free HBM (or MHX_MAX_ITEMS caps them), the stage runs once per contiguous range of lv1 buckets.
+struct BucketRange {
+  uint32_t lo, hi;
+  uint64_t n_items;
+};
+std::vector<BucketRange> plan_ranges(mhx_ctx *c, int stage, uint32_t k, uint32_t m, size_t item_bytes, double items_upper_bound) {
+  uint64_t max_items = 0;
+  if (const char *e = getenv("MHX_MAX_ITEMS")) max_items = strtoull(e, nullptr, 10);
+  else {
+    const double fit = (double)mhx_device_free_bytes(c) * 0.8 / (3.0 * (double)item_bytes);  // 2 sort buffers + filtered copy
+    if (items_upper_bound <= fit) return {{0, MHX_NUM_BUCKETS, 0}};
+    max_items = (uint64_t)fit;
+  }
+  if (!max_items) return {{0, MHX_NUM_BUCKETS, 0}};
+  std::vector<uint64_t> hist(MHX_NUM_BUCKETS);
+  CK(mhx_bucket_histogram(c, stage, k, m, hist.data()));
+  std::vector<BucketRange> out;
+  uint32_t lo = 0;
+  uint64_t acc = 0;
+  for (uint32_t b = 0; b < MHX_NUM_BUCKETS; ++b) {
+    if (acc && acc + hist[b] > max_items) {
+      out.push_back({lo, b, acc});
+      lo = b;
+      acc = 0;
+    }
+    acc += hist[b];
+  }
+  out.push_back({lo, MHX_NUM_BUCKETS, acc});
+  if (out.size() > 1) info("Memory plan: %zu passes over lv1 bucket ranges (at most %llu items each)", out.size(), (unsigned long long)max_items);
+  return out;
+}
+void set_range(mhx_ctx *c, const std::vector<BucketRange> &ranges, size_t i, bool accumulate) {
+  if (ranges.size() == 1) return;  // everything at once: no filter
+  std::vector<uint8_t> keep(MHX_NUM_BUCKETS, 0);
+  for (uint32_t b = ranges[i].lo; b < ranges[i].hi; ++b) keep[b] = 1;
+  CK(mhx_set_bucket_filter(c, keep.data(), ranges[i].n_items, 0, accumulate && i > 0 ? 1 : 0));
+}
+void clear_range(mhx_ctx *c, const std::vector<BucketRange> &ranges) {
+  if (ranges.size() > 1) CK(mhx_set_bucket_filter(c, nullptr, 0, 0, 0));
+}
+
+// SdBG output collected over the passes (bucket order = pass order)
+struct SdbgAcc {
+  std::vector<uint8_t> bytes;
+  std::vector<uint64_t> off = std::vector<uint64_t>(MHX_NUM_BUCKETS, 0), items = off, tips = off, large = off;
+  uint64_t wc[10] = {0};
+  mhx_sdbg_result r{};
+  void add(mhx_ctx *c, const mhx_sdbg_result &pr) {
+    auto b = fetch<uint8_t>(c, MHX_BUF_SDBG_BYTES);
+    auto o = fetch<uint64_t>(c, MHX_BUF_BUCKET_OFFSET), it = fetch<uint64_t>(c, MHX_BUF_BUCKET_COUNT);
+    auto tp = fetch<uint64_t>(c, MHX_BUF_BUCKET_TIPS), lg = fetch<uint64_t>(c, MHX_BUF_BUCKET_LARGE);
+    auto w = fetch<uint64_t>(c, MHX_BUF_W_COUNT);
+    for (int i = 0; i < MHX_NUM_BUCKETS; ++i) {
+      if (it[i]) off[i] = o[i] + bytes.size();
+      items[i] += it[i];
+      tips[i] += tp[i];
+      large[i] += lg[i];
+    }
+    for (int i = 0; i < 10; ++i) wc[i] += w[i];
+    bytes.insert(bytes.end(), b.begin(), b.end());
+    r.n_items += pr.n_items;
+    r.n_sdbg += pr.n_sdbg;
+    r.n_tips += pr.n_tips;
+    r.n_large += pr.n_large;
+    r.sdbg_bytes += pr.sdbg_bytes;
+    r.words_per_tip_label = pr.words_per_tip_label;
+    r.item_words = pr.item_words;
+  }
+  void write(const std::string &out, uint32_t k, int n_files) const {
+    mhxio::write_sdbg(out, k, r.words_per_tip_label, bytes.data(), bytes.size(), off.data(), items.data(), tips.data(), large.data(), n_files);
+    info("Number of $ A C G T A- C- G- T-:");
+    fprintf(stderr, "INFO  ");
+    for (int i = 0; i < 9; ++i) fprintf(stderr, "%llu ", (unsigned long long)wc[i]);
+    fprintf(stderr, "\n");
+    info("Total number of edges: %llu", (unsigned long long)r.n_sdbg);
+    info("Total number of ONEs: %llu", (unsigned long long)wc[9]);
+    info("Total number of $v edges: %llu", (unsigned long long)r.n_tips);
+  }
+};
+
 struct ReadLib {
   std::vector<uint32_t> rec;
   std::vector<uint64_t> off;
@@ -157,12 +238,27 @@ int main_kmer_count(int argc, char **argv) {
   info("Preparing data...");
   ReadLib lib = load_read_lib(c, o.get("read_lib_file"));
   info("%llu reads; Preparing data... Done. Time elapsed: %.4f", (unsigned long long)mhx_num_sequences(c), t.lap());
-  mhx_count_result r;
-  CK(mhx_count(c, k, m, &r));
+  const size_t count_item_bytes = (size_t)(((2 * (k + 1) + 31) / 32 + 2 + 1) / 2 * 2) * 4;
+  const auto ranges = plan_ranges(c, MHX_STAGE_COUNT, k, m, count_item_bytes, (double)mhx_num_bases(c));
+  mhx_count_result r{};
+  std::vector<uint32_t> edges;
+  std::vector<uint64_t> bcount(MHX_NUM_BUCKETS, 0);
+  for (size_t i = 0; i < ranges.size(); ++i) {
+    set_range(c, ranges, i, true);
+    mhx_count_result pr;
+    CK(mhx_count(c, k, m, &pr));
+    auto e = fetch<uint32_t>(c, MHX_BUF_EDGES);
+    auto bc = fetch<uint64_t>(c, MHX_BUF_BUCKET_COUNT);
+    edges.insert(edges.end(), e.begin(), e.end());
+    for (int b = 0; b < MHX_NUM_BUCKETS; ++b) bcount[b] += bc[b];
+    r.n_items += pr.n_items;
+    r.n_distinct += pr.n_distinct;
+    r.n_edges += pr.n_edges;
+    r.words_per_edge = pr.words_per_edge;
+  }
+  clear_range(c, ranges);
   info("GPU count: %llu items, %llu distinct, %llu solid. Time elapsed: %.4f", (unsigned long long)r.n_items,
        (unsigned long long)r.n_distinct, (unsigned long long)r.n_edges, t.lap());
-  auto edges = fetch<uint32_t>(c, MHX_BUF_EDGES);
-  auto bcount = fetch<uint64_t>(c, MHX_BUF_BUCKET_COUNT);
   auto first = fetch<uint32_t>(c, MHX_BUF_FIRST_0_OUT), last = fetch<uint32_t>(c, MHX_BUF_LAST_0_IN);
   auto hist = fetch<int64_t>(c, MHX_BUF_MUL_HIST);
   mhxio::write_edges(out, k, r.words_per_edge, edges.data(), r.n_edges, bcount.data(), out_files(n_threads));
@@ -174,23 +270,6 @@ int main_kmer_count(int argc, char **argv) {
   info("Postprocess done. Time elapsed: %.4f", t.lap());
   mhx_destroy(c);
   return 0;
-}
-
-void report_sdbg(mhx_ctx *c, const mhx_sdbg_result &r) {
-  auto wc = fetch<uint64_t>(c, MHX_BUF_W_COUNT);
-  info("Number of $ A C G T A- C- G- T-:");
-  fprintf(stderr, "INFO  ");
-  for (int i = 0; i < 9; ++i) fprintf(stderr, "%llu ", (unsigned long long)wc[i]);
-  fprintf(stderr, "\n");
-  info("Total number of edges: %llu", (unsigned long long)r.n_sdbg);
-  info("Total number of ONEs: %llu", (unsigned long long)wc[9]);
-  info("Total number of $v edges: %llu", (unsigned long long)r.n_tips);
-}
-void write_sdbg_from_gpu(mhx_ctx *c, const std::string &out, uint32_t k, const mhx_sdbg_result &r, int n_files) {
-  auto bytes = fetch<uint8_t>(c, MHX_BUF_SDBG_BYTES);
-  auto off = fetch<uint64_t>(c, MHX_BUF_BUCKET_OFFSET), items = fetch<uint64_t>(c, MHX_BUF_BUCKET_COUNT);
-  auto tips = fetch<uint64_t>(c, MHX_BUF_BUCKET_TIPS), large = fetch<uint64_t>(c, MHX_BUF_BUCKET_LARGE);
-  mhxio::write_sdbg(out, k, r.words_per_tip_label, bytes.data(), bytes.size(), off.data(), items.data(), tips.data(), large.data(), n_files);
 }
 
 int main_read2sdbg(int argc, char **argv) {
@@ -227,7 +306,17 @@ int main_read2sdbg(int argc, char **argv) {
     // --need_mercy: reproduce the reference's kmsort tie order (bit-identical mercy edges); MHX_STABLE_TIES=1
     // selects the faster stable order instead (DESIGN.md "H1")
     const int mercy_mode = !need_mercy ? 0 : (getenv("MHX_STABLE_TIES") ? 1 : 2);
-    CK(mhx_read2sdbg_s1(c, k, m, mercy_mode, &r1));
+    const size_t s1_item_bytes = 16 + (k > 30 ? (size_t)((2 * (k - 1) + 6 + 31) / 32 - 2 + 1) / 2 * 8 : 0);
+    const auto ranges = plan_ranges(c, mercy_mode ? MHX_STAGE_S1_MERCY : MHX_STAGE_S1, k, m, s1_item_bytes,
+                                    (double)mhx_num_bases(c) + 4.0 * (double)mhx_num_sequences(c));
+    uint64_t n1 = 0;
+    for (size_t i = 0; i < ranges.size(); ++i) {
+      set_range(c, ranges, i, true);
+      CK(mhx_read2sdbg_s1(c, k, m, mercy_mode, &r1));
+      n1 += r1.n_items;
+    }
+    clear_range(c, ranges);
+    r1.n_items = n1;
     auto hist = fetch<int64_t>(c, MHX_BUF_MUL_HIST);
     int64_t n_solid_edges = 0;
     for (uint32_t i = m; i <= 65535; ++i) n_solid_edges += hist[i];
@@ -243,11 +332,19 @@ int main_read2sdbg(int argc, char **argv) {
       info("Number mercy: %llu", (unsigned long long)nm);
     }
   }
-  mhx_sdbg_result r2;
-  CK(mhx_read2sdbg_s2(c, k, m, &r2));
-  info("Stage 2 done (%llu items). Time elapsed: %.4f", (unsigned long long)r2.n_items, t.lap());
-  write_sdbg_from_gpu(c, out, k, r2, out_files(n_threads));
-  report_sdbg(c, r2);
+  const size_t s2_item_bytes = (size_t)(((2 * k + 4 + 31) / 32 + 1) / 2 * 2) * 4;
+  // per-occurrence path: up to 2 + 4/(solid run) items per base position; the aggregated path (k <= 22) is far smaller
+  const auto ranges2 = plan_ranges(c, MHX_STAGE_S2, k, m, s2_item_bytes, (m > 1 && k <= 22 ? 0.5 : 2.2) * (double)mhx_num_bases(c));
+  SdbgAcc acc;
+  for (size_t i = 0; i < ranges2.size(); ++i) {
+    set_range(c, ranges2, i, false);
+    mhx_sdbg_result pr;
+    CK(mhx_read2sdbg_s2(c, k, m, &pr));
+    acc.add(c, pr);
+  }
+  clear_range(c, ranges2);
+  info("Stage 2 done (%llu items). Time elapsed: %.4f", (unsigned long long)acc.r.n_items, t.lap());
+  acc.write(out, k, out_files(n_threads));
   info("Postprocess done. Time elapsed: %.4f", t.lap());
   mhx_destroy(c);
   return 0;
@@ -346,11 +443,18 @@ int main_seq2sdbg(int argc, char **argv) {
   }
   info("Finally, %llu sequences, %llu bases. Time elapsed: %.4f", (unsigned long long)mhx_num_sequences(c),
        (unsigned long long)mhx_num_bases(c), t.lap());
-  mhx_sdbg_result r;
-  CK(mhx_seq2sdbg(c, k, &r));
-  info("GPU seq2sdbg done (%llu items). Time elapsed: %.4f", (unsigned long long)r.n_items, t.lap());
-  write_sdbg_from_gpu(c, out, k, r, out_files(n_threads));
-  report_sdbg(c, r);
+  const size_t seq_item_bytes = (size_t)(((2 * k + 20 + 31) / 32 + 1) / 2 * 2) * 4;
+  const auto ranges = plan_ranges(c, MHX_STAGE_SEQ2SDBG, k, 0, seq_item_bytes, 2.0 * (double)mhx_num_bases(c) + 4.0 * (double)mhx_num_sequences(c));
+  SdbgAcc acc;
+  for (size_t i = 0; i < ranges.size(); ++i) {
+    set_range(c, ranges, i, false);
+    mhx_sdbg_result pr;
+    CK(mhx_seq2sdbg(c, k, &pr));
+    acc.add(c, pr);
+  }
+  clear_range(c, ranges);
+  info("GPU seq2sdbg done (%llu items). Time elapsed: %.4f", (unsigned long long)acc.r.n_items, t.lap());
+  acc.write(out, k, out_files(n_threads));
   info("Postprocess done. Time elapsed: %.4f", t.lap());
   mhx_destroy(c);
   return 0;

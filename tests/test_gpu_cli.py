@@ -30,3 +30,15 @@ def test_cli_reproduces_reference(ent, tmp_path):
         if key in ("case", "mercy_cand_kmsort"):
             continue
         assert got.get(key) == want, key
+
+
+@pytest.mark.parametrize("ent", gu.cases(), ids=gu.case_id)
+def test_cli_memory_bounded_passes(ent, tmp_path, monkeypatch):
+    """MHX_MAX_ITEMS caps the items per pass: every stage then runs over several lv1 bucket ranges (the reference's
+    lv1 passes) and must write the same files."""
+    monkeypatch.setenv("MHX_MAX_ITEMS", "20000")
+    got = gu.run_case(gu.MHX_CORE, ent, str(tmp_path))
+    for key, want in ent.items():
+        if key in ("case", "mercy_cand_kmsort"):
+            continue
+        assert got.get(key) == want, key
