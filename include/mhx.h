@@ -174,7 +174,9 @@ typedef struct {
 int mhx_dist_extract(mhx_ctx *, int stage, uint32_t k, uint32_t min_count, mhx_dist_items *out, uint64_t *counts);
 /* library-owned device buffer to receive n_items items into */
 void *mhx_dist_recv_buffer(mhx_ctx *, uint64_t n_items, uint32_t item_bytes);
-/* sort + reduce the received items: S1 sets bits of the GLOBAL is_solid bitmap (MHX_BUF_IS_SOLID),
+/* sort + reduce the received items: S1 sets bits of the GLOBAL bitmap MHX_BUF_IS_SOLID — by convention the bits of the
+ * NON-solid (k+1)-mer occurrences of the owned buckets (fewer marks on typical inputs; summing over ranks still means
+ * OR); mhx_adopt_is_solid_slice derives is_solid = "a (k+1)-mer starts here and it is not marked" for the local reads.
  * S2 emits the SdBG records of the owned buckets */
 int mhx_dist_process_s1(mhx_ctx *, uint32_t k, uint32_t min_count, int want_mercy, uint64_t n_items, mhx_s1_result *out);
 int mhx_dist_process_s2(mhx_ctx *, uint32_t k, uint64_t n_items, mhx_sdbg_result *out);

@@ -659,6 +659,7 @@ int mhx_adopt_is_solid_slice(mhx_ctx *c, const void *d_words, uint64_t n_words) 
     mhx::DevBuf &b = c->result(mhx::MHX_BUF_IS_SOLID_LOCAL, (need + 1) * 8);
     b.used = need * 8;
     if (need) MHX_HIP(hipMemcpyAsync(b.p, d_words, need * 8, hipMemcpyDeviceToDevice, c->stream));
+    if (c->global_marks_inverted) mhx::invert_local_marks(c, b.as<unsigned long long>(), need);
     MHX_HIP(hipStreamSynchronize(c->stream));
   })
 }

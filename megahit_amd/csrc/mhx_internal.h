@@ -88,6 +88,7 @@ struct mhx_ctx {
   // memory-bounded passes (passes.hip): only items of the kept lv1 buckets are materialised
   bool filter_on = false, accumulate = false;
   uint64_t filter_expected = 0, filter_batch_bytes = 0;
+  bool global_marks_inverted = false;  // multi-GPU stage 1 marked the non-solid occurrences (s1.hip)
   uint64_t s1_acc_bits = 0, mercy_acc_n = 0;  // stage-1 state that accumulate continues
   uint32_t s1_acc_k = 0, s1_acc_m = 0;
   bool dist_s2_agg = false;  // the items of the current multi-GPU stage-2 exchange are aggregated ones
@@ -184,6 +185,7 @@ uint64_t seq2sdbg_extract(mhx_ctx *c, uint32_t k);
 int seq2sdbg_stride(uint32_t k);
 int seq2sdbg_process(mhx_ctx *c, uint32_t k, uint32_t *buf_a, uint32_t *buf_b, uint64_t n_items, mhx_sdbg_result *out);
 const uint64_t *sort_u64(mhx_ctx *c, const void *src, uint64_t n, int hi_bit);
+void invert_local_marks(mhx_ctx *c, unsigned long long *words, uint64_t n_words);
 DevBuf &grow_preserving(mhx_ctx *c, DevBuf &b, size_t bytes, size_t keep);
 void stash_route_records(mhx_ctx *c, const void *src, uint64_t n, int hi_bit);
 void mercy_adopt_routed(mhx_ctx *c, const long long *recv, uint64_t n);

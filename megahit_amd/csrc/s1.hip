@@ -435,6 +435,33 @@ __global__ __launch_bounds__(256) void k_pack_solid_inv(const uint8_t *__restric
   if (threadIdx.x == 0 && tot) atomicAdd(n_solid, (unsigned long long)tot);
 }
 
+// multi-GPU: the adopted slice holds the summed NON-solid marks of the local reads -> is_solid = valid & ~marked
+__global__ __launch_bounds__(256) void k_invert_marks(unsigned long long *__restrict__ words, uint64_t n_words, uint64_t n_bits,
+                                                      const uint64_t *__restrict__ start, uint64_t n_seqs, uint32_t fixed_len, int k) {
+  const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= n_words) return;
+  const uint64_t p0 = w * 64;
+  unsigned long long valid = 0;
+  if (p0 < n_bits) {
+    uint64_t rid = seq_of_offset(start, n_seqs, fixed_len, p0);
+    uint64_t re = start[rid + 1];
+    for (int t = 0; t < 64; ++t) {
+      const uint64_t p = p0 + t;
+      if (p >= n_bits) break;
+      while (p >= re) re = start[++rid + 1];
+      if (p + (uint64_t)k + 1 <= re) valid |= 1ull << t;
+    }
+  }
+  words[w] = valid & ~words[w];
+}
+void invert_local_marks(mhx_ctx *c, unsigned long long *words, uint64_t n_words) {
+  SeqSet &s = c->seqs;
+  if (n_words)
+    MHX_LAUNCH(c, "invert_marks", (double)n_words * 16,
+               hipLaunchKernelGGL(k_invert_marks, dim3((unsigned)div_ceil(n_words, 256)), dim3(256), 0, c->stream, words, n_words, s.n_bases,
+                                  s.start.as<uint64_t>(), s.n_seqs, s.fixed_len, (int)c->s1_acc_k));
+}
+
 template <int S, bool COMPACT, bool AGG>
 static void s1_groups_launch(mhx_ctx *c, const uint32_t *sorted, uint64_t n_items, int KWv, int kmer_bits, uint32_t m,
                              uint8_t *is_solid, unsigned long long *solid_bits, int mark_atomic, unsigned long long *hist, unsigned long long *ctr, int want_mercy,
@@ -645,7 +672,11 @@ int s1_process(mhx_ctx *c, uint32_t k, uint32_t m, int want_mercy, uint32_t *buf
     MHX_CASE(3) MHX_CASE(4) MHX_CASE(6) MHX_CASE(8) MHX_CASE(10) MHX_CASE(12) MHX_CASE(14) MHX_CASE(16) MHX_CASE(18) MHX_CASE(20) \
     default: throw Error("read2sdbg_s1: unsupported record stride");                                                             \
   }
-    if (can_invert && mark_env && !strcmp(mark_env, "nonsolid")) mark_mode = 1;
+    // multi-GPU: every rank marks the NON-solid occurrences of the buckets it owns (a fixed convention, so that the
+    // summed bitmaps mean the same on all ranks; typical inputs are mostly solid, see the polarity note above);
+    // mhx_adopt_is_solid_slice turns "valid position and not marked" into the local is_solid
+    if (global && !mark_atomic) mark_mode = 1;
+    else if (can_invert && mark_env && !strcmp(mark_env, "nonsolid")) mark_mode = 1;
     else if (can_invert && !mark_env && n_items > (1u << 16)) {
       mark_mode = 2;
       MHX_ALL_CASES
@@ -674,11 +705,12 @@ int s1_process(mhx_ctx *c, uint32_t k, uint32_t m, int want_mercy, uint32_t *buf
   if (n_words64 && mark_atomic)
     MHX_LAUNCH(c, "count_solid", (double)n_words64 * 8,
                hipLaunchKernelGGL(k_count_solid, dim3((unsigned)div_ceil(n_words64, 256)), dim3(256), 0, st, is_solid, n_words64, ctr));
-  if (n_words64 && !mark_atomic && s1_mark_mode_used == 1)
+  c->global_marks_inverted = global && !mark_atomic;
+  if (n_words64 && !mark_atomic && s1_mark_mode_used == 1 && !global)
     MHX_LAUNCH(c, "pack_solid", (double)n_words64 * 72,
                hipLaunchKernelGGL(k_pack_solid_inv, dim3((unsigned)div_ceil(n_words64, 256)), dim3(256), 0, st, solid_bytes, n_bits,
                                   s.start.as<uint64_t>(), s.n_seqs, s.fixed_len, (int)k, is_solid, n_words64, ctr));
-  if (n_words64 && !mark_atomic && s1_mark_mode_used != 1)
+  if (n_words64 && !mark_atomic && (s1_mark_mode_used != 1 || global))  // global: the marks themselves (see above)
     MHX_LAUNCH(c, "pack_solid", (double)n_words64 * 72,
                hipLaunchKernelGGL(k_pack_solid, dim3((unsigned)div_ceil(n_words64, 256)), dim3(256), 0, st, solid_bytes, n_bits, is_solid, n_words64,
                                   ctr));
