@@ -601,7 +601,7 @@ static uint32_t *radix_sort_impl2(mhx_ctx *c, uint32_t *a, uint32_t *b, uint64_t
         if (shape == "4x4") return radix_sort_onesweep<S, 4, 4>(c, a, b, n, key_words, passes);
         if (shape == "16x1") return radix_sort_onesweep<S, 16, 1>(c, a, b, n, key_words, passes);
         if (shape == "8x4" && S <= 3) return radix_sort_onesweep<S, 8, 4>(c, a, b, n, key_words, passes);
-        if (S <= 3) return radix_sort_onesweep<S, 8, 3>(c, a, b, n, key_words, passes);
+        if (shape == "8x3" || S <= 3) return radix_sort_onesweep<S, 8, 3>(c, a, b, n, key_words, passes);
         return radix_sort_onesweep<S, 8, 2>(c, a, b, n, key_words, passes);
       } else {
         return radix_sort_onesweep<S, 4, 2>(c, a, b, n, key_words, passes);  // 24/32-byte records: 8 per thread in registers
