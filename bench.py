@@ -133,6 +133,7 @@ def main():
     ap.add_argument("--reads", type=float, default=10e6, help="reads per GPU (BASELINE configs[1]: 10 M)")
     ap.add_argument("--cpu-sample-reads", type=float, default=400e3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true", help="run the multi-GPU code path (RCCL collectives) even with one rank")
     ap.add_argument("--engine", choices=["read2sdbg", "count", "seq2sdbg"], default="read2sdbg",
                     help="sub-program to time; read2sdbg is BASELINE.json's metric, the others are reported beside it (1 GPU)")
     args = ap.parse_args()
@@ -163,10 +164,15 @@ def main():
 
     if args.engine != "read2sdbg" and world > 1:
         raise SystemExit("--engine %s is a single-GPU report" % args.engine)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         import torch.distributed as dist
         from megahit_amd import dist as mdist
+        if "MASTER_ADDR" not in os.environ:  # --force-dist without a launcher
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
+        log("[rank %d] init_process_group nccl, world %d" % (rank, world))
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        log("[rank %d] process group up" % rank)
         runner = mdist.DistRead2Sdbg(eng, K, MIN_COUNT, rank, world, device=torch.device("cuda", local_rank))
         step = runner.step
 
@@ -199,7 +205,7 @@ def main():
             r2 = eng.read2sdbg_s2(K, MIN_COUNT)
             return r1, r2
 
-    if world == 1:
+    if not use_dist:
         def barrier():
             eng.synchronize()
             torch.cuda.synchronize()
@@ -217,7 +223,7 @@ def main():
     stats = eng.profile_get()
     eng.profile(False)
 
-    if world > 1:
+    if use_dist:
         import torch.distributed as dist
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -250,9 +256,9 @@ def main():
                "config": {"workload": workload + ", %d synthetic 150 bp PE reads per GPU "
                                       "(BASELINE configs[1]), inputs resident in HBM, outputs left in HBM" % n_reads,
                           "reads_per_gpu": n_reads, "edges_per_gpu": E, "k": K, "min_count": MIN_COUNT,
-                          "parallelism": "1 GPU" if world == 1 else "lv1 buckets over %d GPUs, all-to-all" % world},
+                          "parallelism": "1 GPU" if not use_dist else "lv1 buckets over %d GPUs, all-to-all" % world},
                "roofline": roof}
-        if world == 1:
+        if not use_dist:
             r1, r2 = res
             if args.engine == "read2sdbg":
                 out["config"]["s1_items"] = int(r1.n_items)
@@ -268,7 +274,7 @@ def main():
                 except Exception as ex:  # the baseline is reporting only; never lose the GPU number
                     out["cpu_baseline"] = {"value": None, "error": str(ex)}
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         import torch.distributed as dist
         dist.destroy_process_group()
     eng.close()

@@ -14,9 +14,26 @@ The reference has no counterpart: it shards buckets over OpenMP threads inside o
 interface of megahit_amd.lib.Engine; tests drive the same class on CPU tensors with an oracle-backed
 stand-in, so the communication logic is covered without GPUs.
 """
+import os
+import sys
+import time
+
 import numpy as np
 import torch
 import torch.distributed as dist
+
+_T0 = time.time()
+
+
+def _dbg(msg):
+    if os.environ.get("MHX_DIST_DEBUG"):
+        print("[dist %.2f s rank %s] %s" % (time.time() - _T0, os.environ.get("RANK", "?"), msg), file=sys.stderr, flush=True)
+
+
+def _sync(t):
+    """Collectives run on torch's streams, the library on its own: finish the collective before libmhx touches the data."""
+    if t.is_cuda:
+        torch.cuda.synchronize(t.device)
 
 NUM_BUCKETS = 65536
 STAGE_S1 = 1
@@ -72,26 +89,67 @@ class Exchanger:
         """send_counts[p] = items this rank sends to p  ->  recv_counts[p] = items p sends to this rank."""
         s = torch.as_tensor(np.asarray(send_counts, dtype=np.int64), device=self.device)
         r = torch.empty_like(s)
+        _dbg("exchange_counts %s" % list(np.asarray(send_counts)))
         dist.all_to_all_single(r, s, group=self.group)
         return r.cpu().numpy().astype(np.uint64)
 
+    MAX_MSG_BYTES = 1 << 30
+
     def exchange_items(self, send, send_counts, recv, recv_counts, item_bytes):
-        """send/recv: uint8 tensors; counts in items."""
-        if item_bytes % 8 == 0:
-            q, dt = item_bytes // 8, torch.int64
-        else:  # 12-byte records (compact stage-1 items)
-            assert item_bytes % 4 == 0
-            q, dt = item_bytes // 4, torch.int32
-        dist.all_to_all_single(recv.view(dt), send.view(dt), [int(c) * q for c in recv_counts], [int(c) * q for c in send_counts],
-                               group=self.group)
+        """send/recv: uint8 tensors holding the per-peer segments back to back (peers ascending); counts in items."""
+        _dbg("exchange_items %d B/item, send %s recv %s" % (item_bytes, [int(c) for c in send_counts], [int(c) for c in recv_counts]))
+        if dist.get_backend(self.group) != "nccl":
+            if item_bytes % 8 == 0:
+                q, dt = item_bytes // 8, torch.int64
+            else:  # 12-byte records (compact stage-1 items)
+                assert item_bytes % 4 == 0
+                q, dt = item_bytes // 4, torch.int32
+            dist.all_to_all_single(recv.view(dt), send.view(dt), [int(c) * q for c in recv_counts], [int(c) * q for c in send_counts],
+                                   group=self.group)
+            _sync(recv)
+            return
+        # RCCL: the rank's own segment is a device copy; every other segment goes as point-to-point messages of at most
+        # 1 GiB (one 16 GB message hung RCCL 2.26 on MI355X), all pairs of a round grouped in one batch.  Sender and
+        # receiver derive the same chunking from the exchanged counts, so no further agreement is needed.
+        sb = np.concatenate([[0], np.cumsum(np.asarray(send_counts, dtype=np.int64))]) * item_bytes
+        rb = np.concatenate([[0], np.cumsum(np.asarray(recv_counts, dtype=np.int64))]) * item_bytes
+        me = self.rank
+        n_self = int(sb[me + 1] - sb[me])
+        assert n_self == int(rb[me + 1] - rb[me])
+        if n_self:
+            recv[int(rb[me]):int(rb[me]) + n_self].copy_(send[int(sb[me]):int(sb[me]) + n_self])
+        chunk = self.MAX_MSG_BYTES // item_bytes * item_bytes
+        n_rounds = 0
+        for p in range(self.world):
+            if p != me:
+                n_rounds = max(n_rounds, -(-int(sb[p + 1] - sb[p]) // chunk), -(-int(rb[p + 1] - rb[p]) // chunk))
+        for c in range(n_rounds):
+            ops = []
+            for d in range(1, self.world):  # pair order: send to me+d, receive from me-d (same ring offset on every rank)
+                to, frm = (me + d) % self.world, (me - d) % self.world
+                lo, hi = int(sb[to]) + c * chunk, min(int(sb[to + 1]), int(sb[to]) + (c + 1) * chunk)
+                if lo < hi:
+                    ops.append(dist.P2POp(dist.isend, send[lo:hi], to, group=self.group))
+                lo, hi = int(rb[frm]) + c * chunk, min(int(rb[frm + 1]), int(rb[frm]) + (c + 1) * chunk)
+                if lo < hi:
+                    ops.append(dist.P2POp(dist.irecv, recv[lo:hi], frm, group=self.group))
+            if ops:
+                for w in dist.batch_isend_irecv(ops):
+                    w.wait()
+        _sync(recv)
+        _dbg("exchange_items done (%d rounds)" % n_rounds)
 
     def sum_bitmap_and_take_slice(self, bitmap_i64, words_per_rank):
         """bitmap_i64: int64 tensor of world*words_per_rank words.  Returns this rank's summed slice."""
         if dist.get_backend(self.group) == "nccl":
             out = torch.empty(words_per_rank, dtype=torch.int64, device=bitmap_i64.device)
+            _dbg("reduce_scatter of %d words" % bitmap_i64.numel())
             dist.reduce_scatter_tensor(out, bitmap_i64, op=dist.ReduceOp.SUM, group=self.group)
+            _sync(out)
+            _dbg("reduce_scatter done")
             return out
         dist.all_reduce(bitmap_i64, op=dist.ReduceOp.SUM, group=self.group)  # gloo: no reduce_scatter
+        _sync(bitmap_i64)
         return bitmap_i64[self.rank * words_per_rank:(self.rank + 1) * words_per_rank].clone()
 
     def max_int(self, v):
