@@ -79,6 +79,38 @@ def balanced_partition(bucket_weight, world):
     return begin.astype(np.uint32)
 
 
+def p2p_plan(send_counts, recv_counts, item_bytes, rank, world, max_msg_bytes):
+    """Chunked point-to-point schedule of one all-to-all of byte buffers whose per-peer segments lie back to back.
+    -> (self_copy (send_offset, recv_offset, n_bytes) or None, rounds); a round is a list of
+    ("send" | "recv", peer, lo, hi) byte ranges.  Chunk c of the segment for/from a peer goes in round c, pairs in ring
+    order (send to rank+d, receive from rank-d), so every message a rank sends in round c is received by its peer in
+    the same round with the same size."""
+    sb = np.concatenate([[0], np.cumsum(np.asarray(send_counts, dtype=np.int64))]) * item_bytes
+    rb = np.concatenate([[0], np.cumsum(np.asarray(recv_counts, dtype=np.int64))]) * item_bytes
+    n_self = int(sb[rank + 1] - sb[rank])
+    assert n_self == int(rb[rank + 1] - rb[rank])
+    self_copy = (int(sb[rank]), int(rb[rank]), n_self) if n_self else None
+    chunk = max(item_bytes, max_msg_bytes // item_bytes * item_bytes)
+    n_rounds = 0
+    for p in range(world):
+        if p != rank:
+            n_rounds = max(n_rounds, -(-int(sb[p + 1] - sb[p]) // chunk), -(-int(rb[p + 1] - rb[p]) // chunk))
+    rounds = []
+    for c in range(n_rounds):
+        plan = []
+        for d in range(1, world):
+            to, frm = (rank + d) % world, (rank - d) % world
+            lo, hi = int(sb[to]) + c * chunk, min(int(sb[to + 1]), int(sb[to]) + (c + 1) * chunk)
+            if lo < hi:
+                plan.append(("send", to, lo, hi))
+            lo, hi = int(rb[frm]) + c * chunk, min(int(rb[frm + 1]), int(rb[frm]) + (c + 1) * chunk)
+            if lo < hi:
+                plan.append(("recv", frm, lo, hi))
+        if plan:
+            rounds.append(plan)
+    return self_copy, rounds
+
+
 class Exchanger:
     """The collectives of the distributed path, on whatever device the tensors live."""
 
@@ -111,31 +143,16 @@ class Exchanger:
         # RCCL: the rank's own segment is a device copy; every other segment goes as point-to-point messages of at most
         # 1 GiB (one 16 GB message hung RCCL 2.26 on MI355X), all pairs of a round grouped in one batch.  Sender and
         # receiver derive the same chunking from the exchanged counts, so no further agreement is needed.
-        sb = np.concatenate([[0], np.cumsum(np.asarray(send_counts, dtype=np.int64))]) * item_bytes
-        rb = np.concatenate([[0], np.cumsum(np.asarray(recv_counts, dtype=np.int64))]) * item_bytes
-        me = self.rank
-        n_self = int(sb[me + 1] - sb[me])
-        assert n_self == int(rb[me + 1] - rb[me])
-        if n_self:
-            recv[int(rb[me]):int(rb[me]) + n_self].copy_(send[int(sb[me]):int(sb[me]) + n_self])
-        chunk = self.MAX_MSG_BYTES // item_bytes * item_bytes
-        n_rounds = 0
-        for p in range(self.world):
-            if p != me:
-                n_rounds = max(n_rounds, -(-int(sb[p + 1] - sb[p]) // chunk), -(-int(rb[p + 1] - rb[p]) // chunk))
-        for c in range(n_rounds):
-            ops = []
-            for d in range(1, self.world):  # pair order: send to me+d, receive from me-d (same ring offset on every rank)
-                to, frm = (me + d) % self.world, (me - d) % self.world
-                lo, hi = int(sb[to]) + c * chunk, min(int(sb[to + 1]), int(sb[to]) + (c + 1) * chunk)
-                if lo < hi:
-                    ops.append(dist.P2POp(dist.isend, send[lo:hi], to, group=self.group))
-                lo, hi = int(rb[frm]) + c * chunk, min(int(rb[frm + 1]), int(rb[frm]) + (c + 1) * chunk)
-                if lo < hi:
-                    ops.append(dist.P2POp(dist.irecv, recv[lo:hi], frm, group=self.group))
-            if ops:
-                for w in dist.batch_isend_irecv(ops):
-                    w.wait()
+        self_copy, rounds = p2p_plan(send_counts, recv_counts, item_bytes, self.rank, self.world, self.MAX_MSG_BYTES)
+        if self_copy is not None:
+            s_lo, r_lo, nb = self_copy
+            recv[r_lo:r_lo + nb].copy_(send[s_lo:s_lo + nb])
+        n_rounds = len(rounds)
+        for plan in rounds:
+            ops = [dist.P2POp(dist.isend if kind == "send" else dist.irecv, (send if kind == "send" else recv)[lo:hi], peer, group=self.group)
+                   for kind, peer, lo, hi in plan]
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
         _sync(recv)
         _dbg("exchange_items done (%d rounds)" % n_rounds)
 

@@ -228,3 +228,40 @@ def test_partitions():
     bb = mdist.balanced_partition(w, 4)
     assert bb[0] == 0 and bb[-1] == 65536 and (np.diff(bb.astype(np.int64)) >= 0).all()
     assert bb[1] <= 30 and bb[2] <= 60
+
+
+@pytest.mark.parametrize("world,item_bytes,max_msg", [(2, 12, 1000), (4, 16, 4096), (8, 8, 64), (3, 12, 1 << 30)])
+def test_p2p_plan_is_consistent_across_ranks(world, item_bytes, max_msg):
+    """The RCCL item exchange is chunked point-to-point traffic: simulate every rank's schedule and check that each
+    round's sends are matched by receives of the same size on the peer, that all bytes are covered exactly once and
+    that no message exceeds the limit."""
+    from megahit_amd import dist as mdist
+    rng = np.random.default_rng(world * 100 + item_bytes)
+    counts = rng.integers(0, 400, size=(world, world))  # counts[s][d]: items s sends to d
+    counts[rng.integers(0, world)][rng.integers(0, world)] = 0
+    plans = [mdist.p2p_plan(counts[r], counts[:, r], item_bytes, r, world, max_msg) for r in range(world)]
+    n_rounds = max(len(p[1]) for p in plans)
+    sent = [np.zeros(int(counts[r].sum()) * item_bytes, dtype=np.int32) for r in range(world)]
+    got = [np.zeros(int(counts[:, r].sum()) * item_bytes, dtype=np.int32) for r in range(world)]
+    for r, (self_copy, _) in enumerate(plans):
+        if self_copy:
+            s_lo, r_lo, nb = self_copy
+            assert nb == counts[r][r] * item_bytes
+            sent[r][s_lo:s_lo + nb] += 1
+            got[r][r_lo:r_lo + nb] += 1
+    for c in range(n_rounds):
+        sends, recvs = {}, {}
+        for r, (_, rounds) in enumerate(plans):
+            for kind, peer, lo, hi in (rounds[c] if c < len(rounds) else []):
+                assert 0 < hi - lo <= max(item_bytes, max_msg) and (hi - lo) % item_bytes == 0
+                if kind == "send":
+                    assert (r, peer) not in sends
+                    sends[(r, peer)] = hi - lo
+                    sent[r][lo:hi] += 1
+                else:
+                    assert (peer, r) not in recvs
+                    recvs[(peer, r)] = hi - lo
+                    got[r][lo:hi] += 1
+        assert sends == recvs  # same pairs, same sizes, same round
+    for r in range(world):
+        assert (sent[r] == 1).all() and (got[r] == 1).all()
