@@ -538,6 +538,7 @@ int mhx_dist_extract(mhx_ctx *c, int stage, uint32_t k, uint32_t min_count, mhx_
     if (c->work.find("owner_lut") == c->work.end()) throw mhx::Error("dist_extract: call mhx_set_partition first");
     const mhx::StageItems it = mhx::extract_stage(c, stage, k, min_count);
     if (stage == MHX_STAGE_S2) c->dist_s2_agg = it.agg;
+    c->pre_hist_buf = nullptr;  // the items are about to be partitioned and exchanged
     const uint64_t n = it.n;
     const int S = it.S;
     uint32_t *a = c->work["items_a"].as<uint32_t>();

@@ -85,6 +85,10 @@ struct mhx_ctx {
   uint32_t agg_k = 0, agg_m = 0;
   uint64_t agg_n = 0;
   uint64_t n_route = 0;      // multi-GPU: records in ws("route_records") (count events)
+  // digit histograms of the next sort, taken by the extraction kernel (ws "sort_pre_hist"): valid for exactly this buffer
+  const void *pre_hist_buf = nullptr;
+  uint64_t pre_hist_n = 0;
+  int pre_hist_passes = 0;
   // memory-bounded passes (passes.hip): only items of the kept lv1 buckets are materialised
   bool filter_on = false, accumulate = false;
   uint64_t filter_expected = 0, filter_batch_bytes = 0;
@@ -151,6 +155,8 @@ void find_group_heads(mhx_ctx *c, const uint32_t *items, uint64_t n, int stride,
                       uint64_t *heads, uint64_t *d_count);
 uint64_t count_group_heads(mhx_ctx *c, const uint32_t *items, uint64_t n, int stride, int cmp_bits);
 
+struct DigitSpec;
+DigitSpec spec_of_pass(const SortPass &ps, int key_words);
 std::vector<SortPass> make_passes_ranges(int key_words, const std::vector<std::pair<int, int>> &ranges);
 // s2.hip: SdBG records from sorted lv2 items (shared by read2sdbg S2 and seq2sdbg)
 void emit_sdbg(mhx_ctx *c, const uint32_t *sorted, uint64_t n_items, int S, int kw, uint32_t k, int is_seq, mhx_sdbg_result *out);

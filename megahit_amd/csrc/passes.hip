@@ -137,6 +137,7 @@ StageItems extract_stage(mhx_ctx *c, int stage, uint32_t k, uint32_t m) {
   });
   MHX_HIP(hipStreamSynchronize(st));
   if (keep) std::swap(c->work["items_a"], *keep);  // the engines take their input from "items_a"
+  c->pre_hist_buf = nullptr;
   res.n = kept;
   return res;
 }

@@ -18,6 +18,7 @@
 #include <cstdlib>
 
 #include "mhx_internal.h"
+#include "sort_digits.h"
 #include "tile_groups.h"
 
 namespace mhx {
@@ -117,35 +118,48 @@ __global__ __launch_bounds__(256) void k_s1_extract(const uint32_t *__restrict__
 // through LDS so that each store instruction writes 256 contiguous bytes.
 template <int KW, int S, bool COMPACT>
 __global__ __launch_bounds__(256) void k_s1_extract_fixed(const uint32_t *__restrict__ seq, uint32_t L, uint32_t per, uint64_t n_items, int k,
-                                                          uint64_t pos_base, uint32_t *__restrict__ items, uint64_t first_block) {
+                                                          uint64_t pos_base, uint32_t *__restrict__ items, DigitSpecs specs,
+                                                          unsigned long long *__restrict__ ghist) {
   __shared__ uint32_t xpose[S % 2 == 1 ? 256 * S : 1];
-  const uint64_t blk = first_block + blockIdx.x;  // a launch covers < 2^31 items (a grid holds fewer than 2^32 threads)
-  const uint64_t g = blk * 256 + threadIdx.x;
-  uint32_t out[S];
-  if (g < n_items) {
-    const uint64_t r = g / per;
-    s1_make_item<KW, S, COMPACT>(seq, r * L, L, k, (uint32_t)(g - r * per), pos_base, out);
+  __shared__ uint32_t h[kMaxFusedPasses][256];  // digit histograms of the coming sort passes (specs.n == 0: none)
+  for (int i = threadIdx.x; i < specs.n * 256; i += 256) (&h[0][0])[i] = 0;
+  __syncthreads();
+  const uint64_t n_blocks = (n_items + 255) / 256;
+  for (uint64_t blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {  // persistent: one histogram flush per workgroup
+    const uint64_t g = blk * 256 + threadIdx.x;
+    uint32_t out[S];
+    if (g < n_items) {
+      const uint64_t r = g / per;
+      s1_make_item<KW, S, COMPACT>(seq, r * L, L, k, (uint32_t)(g - r * per), pos_base, out);
+      for (int p = 0; p < specs.n; ++p) atomicAdd(&h[p][words_digit2<S>(out, specs.d[p])], 1u);
+    }
+    if constexpr (S % 2 == 1) {
+#pragma unroll
+      for (int i = 0; i < S; ++i) xpose[threadIdx.x * S + i] = out[i];
+      __syncthreads();
+      const uint64_t w0 = blk * 256 * S, n_words = n_items * S;
+#pragma unroll
+      for (int i = 0; i < S; ++i) {
+        const uint64_t w = w0 + (uint64_t)i * 256 + threadIdx.x;
+        if (w < n_words) items[w] = xpose[i * 256 + threadIdx.x];
+      }
+      __syncthreads();
+    } else if (g < n_items) {
+      uint32_t *dst = items + g * S;
+      if constexpr (S % 4 == 0) {
+#pragma unroll
+        for (int i = 0; i < S / 4; ++i)
+          reinterpret_cast<uint4 *>(dst)[i] = make_uint4(out[4 * i], out[4 * i + 1], out[4 * i + 2], out[4 * i + 3]);
+      } else {
+#pragma unroll
+        for (int i = 0; i < S / 2; ++i) reinterpret_cast<uint2 *>(dst)[i] = make_uint2(out[2 * i], out[2 * i + 1]);
+      }
+    }
   }
-  if constexpr (S % 2 == 1) {
-#pragma unroll
-    for (int i = 0; i < S; ++i) xpose[threadIdx.x * S + i] = out[i];
-    __syncthreads();
-    const uint64_t w0 = blk * 256 * S, n_words = n_items * S;
-#pragma unroll
-    for (int i = 0; i < S; ++i) {
-      const uint64_t w = w0 + (uint64_t)i * 256 + threadIdx.x;
-      if (w < n_words) items[w] = xpose[i * 256 + threadIdx.x];
-    }
-  } else if (g < n_items) {
-    uint32_t *dst = items + g * S;
-    if constexpr (S % 4 == 0) {
-#pragma unroll
-      for (int i = 0; i < S / 4; ++i)
-        reinterpret_cast<uint4 *>(dst)[i] = make_uint4(out[4 * i], out[4 * i + 1], out[4 * i + 2], out[4 * i + 3]);
-    } else {
-#pragma unroll
-      for (int i = 0; i < S / 2; ++i) reinterpret_cast<uint2 *>(dst)[i] = make_uint2(out[2 * i], out[2 * i + 1]);
-    }
+  __syncthreads();
+  for (int p = 0; p < specs.n; ++p) {
+    const uint32_t v = h[p][threadIdx.x];
+    if (v) atomicAdd(&ghist[p * 256 + threadIdx.x], (unsigned long long)v);
   }
 }
 
@@ -537,6 +551,11 @@ void stash_route_records(mhx_ctx *c, const void *src, uint64_t n, int hi_bit) {
 
 // ---- host driver, in two halves so that the multi-GPU path can exchange items in between ----
 static int s1_kw(uint32_t k) { return (int)div_ceil((k - 1) * 2 + 6, 32); }  // read_to_sdbg_s1.cpp:107-108
+// LSD passes of the stage-1 sort: the 6 head/tail bits, then the (k-1)-mer
+static std::vector<SortPass> s1_sort_passes(uint32_t k) {
+  const int KWv = s1_kw(k), kmer_bits = (int)(k - 1) * 2;
+  return make_passes_ranges(KWv, {{0, 6}, {KWv * 32 - kmer_bits, KWv * 32}});
+}
 // compact 1-word aux when no mercy candidates are wanted and positions fit 32 bits
 bool s1_compact(const mhx_ctx *c, int want_mercy) {
   const uint64_t n_bits = c->global_bases ? c->global_bases : c->seqs.n_bases;
@@ -570,14 +589,30 @@ uint64_t s1_extract(mhx_ctx *c, uint32_t k, bool compact) {
   if (n_items) {
     const unsigned grid = 256 * 8;
     const bool fixed = s.fixed_len >= k + 1 && n_items == (uint64_t)ns * (s.fixed_len - k + 4);
+    // the stage-1 sort's digit histograms come for free while the records are still in registers (fixed-length path)
+    DigitSpecs specs;
+    specs.n = 0;
+    unsigned long long *pre_hist = nullptr;
+    c->pre_hist_buf = nullptr;
+    if (fixed && S <= 4) {
+      const std::vector<SortPass> passes = s1_sort_passes(k);
+      if ((int)passes.size() <= kMaxFusedPasses) {
+        specs.n = (int)passes.size();
+        for (int p = 0; p < specs.n; ++p) specs.d[p] = spec_of_pass(passes[p], KWv);
+        pre_hist = c->ws("sort_pre_hist", (size_t)kMaxFusedPasses * 256 * 8).as<unsigned long long>();
+        MHX_HIP(hipMemsetAsync(pre_hist, 0, (size_t)specs.n * 256 * 8, st));
+        c->pre_hist_buf = buf_a;
+        c->pre_hist_n = n_items;
+        c->pre_hist_passes = specs.n;
+      }
+    }
 #define MHX_S1X(SV, CP)                                                                                                      \
   do {                                                                                                                       \
     if (fixed) {                                                                                                             \
-      const uint64_t n_blocks = div_ceil(n_items, 256), per_launch = 1ull << 23;                                             \
-      for (uint64_t b0 = 0; b0 < n_blocks; b0 += per_launch)                                                                 \
-        MHX_LAUNCH(c, "s1_extract", ((double)n_items * item_bytes + (double)s.n_bases / 4) * std::min(per_launch, n_blocks - b0) / n_blocks, \
-                   hipLaunchKernelGGL((k_s1_extract_fixed<KW, SV, CP>), dim3((unsigned)std::min(per_launch, n_blocks - b0)), dim3(256), 0, st, \
-                                      s.words.as<uint32_t>(), s.fixed_len, s.fixed_len - k + 4, n_items, (int)k, c->pos_base, buf_a, b0)); \
+      MHX_LAUNCH(c, "s1_extract", (double)n_items * item_bytes + (double)s.n_bases / 4,                                      \
+                 hipLaunchKernelGGL((k_s1_extract_fixed<KW, SV, CP>), dim3((unsigned)std::min<uint64_t>(div_ceil(n_items, 256), 256 * 16)), \
+                                    dim3(256), 0, st, s.words.as<uint32_t>(), s.fixed_len, s.fixed_len - k + 4, n_items, (int)k, \
+                                    c->pos_base, buf_a, specs, pre_hist));                                                     \
     } else                                                                                                                   \
       MHX_LAUNCH(c, "s1_extract", (double)n_items * item_bytes + (double)s.n_bases / 4,                                      \
                  hipLaunchKernelGGL((k_s1_extract<KW, SV, CP>), dim3(grid), dim3(256), 0, st, s.words.as<uint32_t>(),        \
@@ -610,7 +645,8 @@ int s1_process(mhx_ctx *c, uint32_t k, uint32_t m, int want_mercy, uint32_t *buf
   // want_mercy == 2: records with equal keys in exactly the order the reference's kmsort leaves them (H1)
   uint32_t *sorted = want_mercy == 2
                          ? kmsort_exact(c, buf_a, buf_b, n_items, S, KWv)
-                         : radix_sort(c, buf_a, buf_b, n_items, S, KWv, make_passes_ranges(KWv, {{0, 6}, {KWv * 32 - kmer_bits, KWv * 32}}));
+                         : radix_sort(c, buf_a, buf_b, n_items, S, KWv, s1_sort_passes(k));
+  c->pre_hist_buf = nullptr;
   uint32_t *spare = sorted == buf_a ? buf_b : buf_a;
 
   const uint64_t n_bits = global ? c->global_bases : s.n_bases;

@@ -14,6 +14,7 @@
 #include <string>
 
 #include "mhx_internal.h"
+#include "sort_digits.h"
 
 namespace mhx {
 
@@ -71,14 +72,6 @@ __device__ __forceinline__ void store_rec(uint32_t *__restrict__ p, const Rec<S>
     for (int i = 0; i < S; ++i) p[i] = r.w[i];
   }
 }
-
-// where a pass's digit lives: up to two bit fields (word index, bit offset, mask); field 2 is the upper part
-struct DigitSpec {
-  int wi1;
-  unsigned bit1, mask1;
-  int wi2;
-  unsigned bit2, mask2, sh2;  // mask2 == 0: single field
-};
 
 // digit of a record held in registers: bits [bit, bit+nbits) of word wi (and wi-1 when straddling)
 template <int S>
@@ -301,12 +294,7 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(const uint32_t *
 // (tag = pass number, so one memset per sort).  Units are handed out by an atomic ticket, which guarantees that every
 // predecessor of a running unit is running too.  Stable: units in input order, tiles of a unit in order.
 // ---------------------------------------------------------------------------
-constexpr int kMaxFusedPasses = 16;  // digit histograms taken in one read of the input
 constexpr int kMaxChainedPasses = 60;  // status tag = pass number + 1 in 6 bits
-struct DigitSpecs {
-  DigitSpec d[kMaxFusedPasses];
-  int n;
-};
 
 template <int S>
 __global__ __launch_bounds__(kSortThreads) void k_radix_hist_all(const uint32_t *__restrict__ items, uint64_t n, DigitSpecs specs,
@@ -530,7 +518,7 @@ std::vector<SortPass> make_passes(int key_words, int lo_bit, int hi_bit) {
   return p;
 }
 
-static DigitSpec spec_of_pass(const SortPass &ps, int key_words) {
+DigitSpec spec_of_pass(const SortPass &ps, int key_words) {
   DigitSpec ds{key_words - 1 - ps.shift / 32, (unsigned)(ps.shift % 32), (1u << ps.bits) - 1, 0, 0u, 0u, 0u};
   if (ps.bits2) {
     ds.wi2 = key_words - 1 - ps.shift2 / 32;
@@ -559,7 +547,11 @@ static uint32_t *radix_sort_onesweep(mhx_ctx *c, uint32_t *a, uint32_t *b, uint6
   const unsigned hgrid = (unsigned)std::min<uint64_t>(div_ceil(n, kSortThreads), 4096);
   std::vector<DigitSpec> all(P);
   for (int p = 0; p < P; ++p) all[p] = spec_of_pass(passes[p], key_words);
-  for (int p0 = 0; p0 < P; p0 += kMaxFusedPasses) {  // one read of the input per 16 passes
+  // extraction may have taken the digit histograms while it produced the records (s1.hip): then no read at all
+  const bool pre = c->pre_hist_buf == (const void *)a && c->pre_hist_n == n && c->pre_hist_passes == P && P <= kMaxFusedPasses;
+  c->pre_hist_buf = nullptr;
+  if (pre) MHX_HIP(hipMemcpyAsync(gh, c->work["sort_pre_hist"].p, (size_t)P * 256 * 8, hipMemcpyDeviceToDevice, st));
+  for (int p0 = 0; p0 < P && !pre; p0 += kMaxFusedPasses) {  // one read of the input per 16 passes
     DigitSpecs specs;
     specs.n = std::min(kMaxFusedPasses, P - p0);
     for (int p = 0; p < specs.n; ++p) specs.d[p] = all[p0 + p];
