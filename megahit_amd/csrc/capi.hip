@@ -561,7 +561,7 @@ void *mhx_dist_recv_buffer(mhx_ctx *c, uint64_t n_items, uint32_t item_bytes) {
 int mhx_dist_process_s1(mhx_ctx *c, uint32_t k, uint32_t min_count, int want_mercy, uint64_t n_items, mhx_s1_result *out) {
   MHX_TRY({
     MHX_HIP(hipSetDevice(c->device));
-    const int S = mhx::s1_stride(k, mhx::s1_compact(c, want_mercy));
+    const int S = mhx::s1_stride(k, mhx::s1_compact(c, k, want_mercy));
     uint32_t *a = c->ws("items_recv", n_items * (size_t)S * 4 + 64).as<uint32_t>();
     uint32_t *b = c->ws("items_b", n_items * (size_t)S * 4 + 64).as<uint32_t>();
     mhx::s1_process(c, k, min_count, want_mercy, a, b, n_items, out);

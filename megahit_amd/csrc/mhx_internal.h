@@ -164,7 +164,8 @@ void emit_sdbg(mhx_ctx *c, const uint32_t *sorted, uint64_t n_items, int S, int 
 void partition_by_owner(mhx_ctx *c, const uint32_t *a, uint32_t *b, uint64_t n, int stride, const uint8_t *lut, int n_parts,
                         uint64_t *counts);
 uint64_t s1_extract(mhx_ctx *c, uint32_t k, bool compact);
-bool s1_compact(const mhx_ctx *c, int want_mercy);
+bool s1_compact(const mhx_ctx *c, uint32_t k, int want_mercy);
+bool s1_rank_tagged(const mhx_ctx *c, uint32_t k);
 int s1_stride(uint32_t k, bool compact);
 int s1_process(mhx_ctx *c, uint32_t k, uint32_t m, int want_mercy, uint32_t *buf_a, uint32_t *buf_b, uint64_t n_items, mhx_s1_result *out);
 uint64_t s2_extract(mhx_ctx *c, uint32_t k, uint32_t m);

@@ -51,7 +51,7 @@ __global__ void k_bucket_hist(const uint32_t *__restrict__ items, uint64_t n, in
 static StageItems extract_all(mhx_ctx *c, int stage, uint32_t k, uint32_t m) {
   StageItems r{0, 0, false, true};
   if (stage == MHX_STAGE_S1 || stage == MHX_STAGE_S1_MERCY) {
-    const bool compact = s1_compact(c, stage == MHX_STAGE_S1_MERCY ? 1 : 0);
+    const bool compact = s1_compact(c, k, stage == MHX_STAGE_S1_MERCY ? 1 : 0);
     r.n = s1_extract(c, k, compact);
     r.S = s1_stride(k, compact);
   } else if (stage == MHX_STAGE_COUNT) {

@@ -36,7 +36,7 @@ __global__ void k_s1_item_counts(const uint64_t *__restrict__ start, uint64_t n_
 // item of slot j (0 .. L-k+3) of the read at base offset st, length L (read_to_sdbg_s1.cpp:228-292, :344-363)
 template <int KW, int S, bool COMPACT>
 __device__ __forceinline__ void s1_make_item(const uint32_t *__restrict__ seq, uint64_t st, uint32_t L, int k, uint32_t j, uint64_t pos_base,
-                                             uint32_t (&out)[S]) {
+                                             uint32_t rank_tag, uint32_t (&out)[S]) {
   // slot -> ((k-1)-mer offset q, forced strand or -1)
   uint32_t q;
   int forced = -1;
@@ -72,6 +72,9 @@ __device__ __forceinline__ void s1_make_item(const uint32_t *__restrict__ seq, u
     info = (full << 6) | (comp_or_sentinel(next) << 3) | comp_or_sentinel(prev);
   }
   if constexpr (COMPACT) {
+    // multi-GPU beyond 2^32 global positions: the position stays rank-local (pos_base = 0) and the source rank rides in
+    // key bits that no comparison looks at (between the head/tail bits and the (k-1)-mer): rank_tag = rank << 6
+    out[KW - 1] |= rank_tag;
     out[KW] = (uint32_t)(pos_base + st + q);
     if constexpr (S > KW + 1) out[KW + 1] = 0;
   } else {
@@ -84,7 +87,7 @@ __device__ __forceinline__ void s1_make_item(const uint32_t *__restrict__ seq, u
 template <int KW, int S, bool COMPACT>
 __global__ __launch_bounds__(256) void k_s1_extract(const uint32_t *__restrict__ seq, const uint64_t *__restrict__ start,
                                                     const uint64_t *__restrict__ item_start, uint64_t n_seqs, int k,
-                                                    uint64_t pos_base, uint32_t *__restrict__ items) {
+                                                    uint64_t pos_base, uint32_t rank_tag, uint32_t *__restrict__ items) {
   const int lane = lane_id();
   const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / kWave;
   const uint64_t n_waves = (uint64_t)gridDim.x * blockDim.x / kWave;
@@ -96,7 +99,7 @@ __global__ __launch_bounds__(256) void k_s1_extract(const uint32_t *__restrict__
     const uint32_t n_slots = L - k + 4;
     for (uint32_t j = lane; j < n_slots; j += kWave) {
       uint32_t out[S];
-      s1_make_item<KW, S, COMPACT>(seq, st, L, k, j, pos_base, out);
+      s1_make_item<KW, S, COMPACT>(seq, st, L, k, j, pos_base, rank_tag, out);
       uint32_t *dst = items + (ibase + j) * S;
       if constexpr (S % 2 == 1) {
 #pragma unroll
@@ -118,7 +121,7 @@ __global__ __launch_bounds__(256) void k_s1_extract(const uint32_t *__restrict__
 // through LDS so that each store instruction writes 256 contiguous bytes.
 template <int KW, int S, bool COMPACT>
 __global__ __launch_bounds__(256) void k_s1_extract_fixed(const uint32_t *__restrict__ seq, uint32_t L, uint32_t per, uint64_t n_items, int k,
-                                                          uint64_t pos_base, uint32_t *__restrict__ items, DigitSpecs specs,
+                                                          uint64_t pos_base, uint32_t rank_tag, uint32_t *__restrict__ items, DigitSpecs specs,
                                                           unsigned long long *__restrict__ ghist) {
   __shared__ uint32_t xpose[S % 2 == 1 ? 256 * S : 1];
   __shared__ uint32_t h[kMaxFusedPasses][256];  // digit histograms of the coming sort passes (specs.n == 0: none)
@@ -130,7 +133,7 @@ __global__ __launch_bounds__(256) void k_s1_extract_fixed(const uint32_t *__rest
     uint32_t out[S];
     if (g < n_items) {
       const uint64_t r = g / per;
-      s1_make_item<KW, S, COMPACT>(seq, r * L, L, k, (uint32_t)(g - r * per), pos_base, out);
+      s1_make_item<KW, S, COMPACT>(seq, r * L, L, k, (uint32_t)(g - r * per), pos_base, rank_tag, out);
       for (int p = 0; p < specs.n; ++p) atomicAdd(&h[p][words_digit2<S>(out, specs.d[p])], 1u);
     }
     if constexpr (S % 2 == 1) {
@@ -224,6 +227,7 @@ struct S1Op {
   int want_mercy;
   long long *mercy;
   unsigned long long *mercy_n;
+  uint64_t pos_stride;  // compact records tagged with their source rank: global position = local + rank * pos_stride (else 0)
 
   __device__ bool same_run(const uint32_t *cur, const uint32_t *prev) const { return ((cur[kw - 1] ^ prev[kw - 1]) & 63u) == 0; }
   __device__ bool item_phase_enabled() const { return false; }
@@ -342,7 +346,7 @@ struct S1Op {
     if (!mark && !want_mercy) return;
     uint64_t abs;
     int strand = 0;
-    if constexpr (COMPACT) abs = c.acc.word(rel, kw);
+    if constexpr (COMPACT) abs = c.acc.word(rel, kw) + (uint64_t)((c.acc.word(rel, kw - 1) >> 6) & 0xFFu) * pos_stride;
     else {
       const uint64_t info = (((uint64_t)c.acc.word(rel, kw) << 32) | c.acc.word(rel, kw + 1)) >> 6;
       abs = info >> 1;
@@ -485,14 +489,15 @@ static void s1_groups_launch(mhx_ctx *c, const uint32_t *sorted, uint64_t n_item
   const uint64_t n_tiles = div_ceil(n_items, T);
   const int full_words = kmer_bits / 32, rem = kmer_bits % 32;
   const uint32_t last_mask = rem ? 0xFFFFFFFFu << (32 - rem) : 0;
-  S1Op<S, COMPACT, AGG> op{k, agg_items, KWv, m, s.start.as<uint64_t>(), s.n_seqs, s.fixed_len, is_solid, solid_bits, mark_atomic, mark_mode, hist, ctr, want_mercy, mercy, ctr + 1};
+  const uint64_t pos_stride = COMPACT && s1_rank_tagged(c, (uint32_t)k) ? c->global_bases / (uint64_t)c->n_parts : 0;
+  S1Op<S, COMPACT, AGG> op{k, agg_items, KWv, m, s.start.as<uint64_t>(), s.n_seqs, s.fixed_len, is_solid, solid_bits, mark_atomic, mark_mode, hist, ctr, want_mercy, mercy, ctr + 1, pos_stride};
   if (mark_mode == 2) {  // statistics on every 64th tile (no output): solid fraction -> marking polarity
     const uint32_t stride = 64;
     const uint64_t nt = div_ceil(n_tiles, stride);
     MHX_LAUNCH(c, "s1_sample", (double)nt * T * S * 4,
                hipLaunchKernelGGL((k_tile_groups<S, T, S1Op<S, COMPACT, false>, false>), dim3(tile_grid(nt)), dim3(kTileThreads), 0, c->stream, sorted,
                                   n_items, full_words, last_mask, S1Op<S, COMPACT, false>{k, nullptr, KWv, m, s.start.as<uint64_t>(), s.n_seqs,
-                                  s.fixed_len, is_solid, solid_bits, mark_atomic, 2, hist, ctr, 0, mercy, ctr + 1},
+                                  s.fixed_len, is_solid, solid_bits, mark_atomic, 2, hist, ctr, 0, mercy, ctr + 1, pos_stride},
                                   (uint64_t *)nullptr, (const uint64_t *)nullptr, n_tiles, nt, stride));
     return;
   }
@@ -557,9 +562,21 @@ static std::vector<SortPass> s1_sort_passes(uint32_t k) {
   return make_passes_ranges(KWv, {{0, 6}, {KWv * 32 - kmer_bits, KWv * 32}});
 }
 // compact 1-word aux when no mercy candidates are wanted and positions fit 32 bits
-bool s1_compact(const mhx_ctx *c, int want_mercy) {
+// Multi-GPU with more than 2^32 global base positions: compact records keep a rank-local 32-bit position and carry the
+// source rank in the unused key bits between head/tail and the (k-1)-mer (needs 8 spare bits and the rank-stride layout
+// of megahit_amd/dist.py: rank r's reads start at r * stride, stride = global_bases / n_parts < 2^32).
+bool s1_rank_tagged(const mhx_ctx *c, uint32_t k) {
+  static const bool force = getenv("MHX_S1_FORCE_TAGGED") != nullptr;  // tests: take this path at small sizes too
+  if (!c->global_bases || (c->global_bases < (1ull << 32) && !force) || c->n_parts < 1 || c->n_parts > 256) return false;
+  if (c->global_bases % (uint64_t)c->n_parts) return false;
+  const uint64_t stride = c->global_bases / (uint64_t)c->n_parts;
+  const int spare = 32 * s1_kw(k) - (int)(k - 1) * 2 - 6;
+  return stride < (1ull << 32) && c->pos_base == stride * (uint64_t)c->my_part && c->seqs.n_bases <= stride && spare >= 8;
+}
+bool s1_compact(const mhx_ctx *c, uint32_t k, int want_mercy) {
+  if (want_mercy) return false;
   const uint64_t n_bits = c->global_bases ? c->global_bases : c->seqs.n_bases;
-  return !want_mercy && n_bits < (1ull << 32);
+  return n_bits < (1ull << 32) || s1_rank_tagged(c, k);
 }
 int s1_stride(uint32_t k, bool compact) {
   const int kw = s1_kw(k);
@@ -589,6 +606,9 @@ uint64_t s1_extract(mhx_ctx *c, uint32_t k, bool compact) {
   if (n_items) {
     const unsigned grid = 256 * 8;
     const bool fixed = s.fixed_len >= k + 1 && n_items == (uint64_t)ns * (s.fixed_len - k + 4);
+    const bool tagged = compact && s1_rank_tagged(c, k);
+    const uint64_t pos_base = tagged ? 0 : c->pos_base;
+    const uint32_t rank_tag = tagged ? (uint32_t)c->my_part << 6 : 0u;
     // the stage-1 sort's digit histograms come for free while the records are still in registers (fixed-length path)
     DigitSpecs specs;
     specs.n = 0;
@@ -612,11 +632,11 @@ uint64_t s1_extract(mhx_ctx *c, uint32_t k, bool compact) {
       MHX_LAUNCH(c, "s1_extract", (double)n_items * item_bytes + (double)s.n_bases / 4,                                      \
                  hipLaunchKernelGGL((k_s1_extract_fixed<KW, SV, CP>), dim3((unsigned)std::min<uint64_t>(div_ceil(n_items, 256), 256 * 16)), \
                                     dim3(256), 0, st, s.words.as<uint32_t>(), s.fixed_len, s.fixed_len - k + 4, n_items, (int)k, \
-                                    c->pos_base, buf_a, specs, pre_hist));                                                     \
+                                    pos_base, rank_tag, buf_a, specs, pre_hist));                                               \
     } else                                                                                                                   \
       MHX_LAUNCH(c, "s1_extract", (double)n_items * item_bytes + (double)s.n_bases / 4,                                      \
                  hipLaunchKernelGGL((k_s1_extract<KW, SV, CP>), dim3(grid), dim3(256), 0, st, s.words.as<uint32_t>(),        \
-                                    s.start.as<uint64_t>(), item_start, ns, (int)k, c->pos_base, buf_a));                    \
+                                    s.start.as<uint64_t>(), item_start, ns, (int)k, pos_base, rank_tag, buf_a));              \
   } while (0)
     MHX_DISPATCH_KW(KWv, {
       if (compact) {
@@ -636,7 +656,7 @@ uint64_t s1_extract(mhx_ctx *c, uint32_t k, bool compact) {
 int s1_process(mhx_ctx *c, uint32_t k, uint32_t m, int want_mercy, uint32_t *buf_a, uint32_t *buf_b, uint64_t n_items,
                mhx_s1_result *out) {
   SeqSet &s = c->seqs;
-  const bool compact = s1_compact(c, want_mercy);
+  const bool compact = s1_compact(c, k, want_mercy);
   const int KWv = s1_kw(k), S = s1_stride(k, compact);
   const size_t item_bytes = (size_t)S * 4;
   hipStream_t st = c->stream;

@@ -213,3 +213,32 @@ def test_read2sdbg_passes_ranks_on_one_gpu(world, k, m, mode):
     else:
         want = ob.s2(pkg, k, 1, None)
     _check_sdbg_ranges(outs, want)
+
+
+@pytest.mark.parametrize("world,k,m", [(2, 21, 2), (3, 21, 3), (3, 27, 2)])
+def test_rank_tagged_compact_items(world, k, m, monkeypatch):
+    """Past 2^32 global positions the compact stage-1 records keep rank-local positions and carry the source rank in
+    spare key bits; MHX_S1_FORCE_TAGGED takes that path at test sizes (k=27 has the spare bits too: 64-52-6)."""
+    import oracle_binding as ob
+    monkeypatch.setenv("MHX_S1_FORCE_TAGGED", "1")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29600 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, world, port, k, m, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = sorted([q.get(timeout=600) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    allreads = []
+    for r in range(world):
+        allreads += _reads(100 + r)
+    pkg = ob.Package(allreads, reverse=True)
+    s1 = ob.s1(pkg, k, m)
+    want = ob.s2(pkg, k, m, s1["is_solid"])
+    assert np.array_equal(sum(o[7] for o in outs), s1["hist"])
+    off = np.concatenate([want["bucket_off"], [len(want["bytes"])]]).astype(np.int64)
+    for rank, lo, hi, byts, b_items, b_tips, b_large, _ in outs:
+        assert np.array_equal(b_items[lo:hi], want["bucket_items"][lo:hi])
+        assert byts == want["bytes"][off[lo]:off[hi]].tobytes()
