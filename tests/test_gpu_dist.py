@@ -215,10 +215,11 @@ def test_read2sdbg_passes_ranks_on_one_gpu(world, k, m, mode):
     _check_sdbg_ranges(outs, want)
 
 
-@pytest.mark.parametrize("world,k,m", [(2, 21, 2), (3, 21, 3), (3, 27, 2)])
+@pytest.mark.parametrize("world,k,m", [(2, 21, 2), (3, 21, 3), (3, 26, 2), (3, 27, 2)])
 def test_rank_tagged_compact_items(world, k, m, monkeypatch):
     """Past 2^32 global positions the compact stage-1 records keep rank-local positions and carry the source rank in
-    spare key bits; MHX_S1_FORCE_TAGGED takes that path at test sizes (k=27 has the spare bits too: 64-52-6)."""
+    spare key bits; MHX_S1_FORCE_TAGGED takes that path at test sizes (k=26 is the last k with 8 spare bits; k=27
+    must fall back to plain global positions)."""
     import oracle_binding as ob
     monkeypatch.setenv("MHX_S1_FORCE_TAGGED", "1")
     ctx = mp.get_context("spawn")
