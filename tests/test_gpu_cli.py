@@ -42,3 +42,28 @@ def test_cli_memory_bounded_passes(ent, tmp_path, monkeypatch):
         if key in ("case", "mercy_cand_kmsort"):
             continue
         assert got.get(key) == want, key
+
+
+def _pick_multi_file_cases():
+    seen, out = set(), []
+    for e in gu.cases():
+        c = e["case"]
+        key = (c["prog"], c.get("input"))
+        if key not in seen:
+            seen.add(key)
+            out.append(e)
+    return out
+
+
+@pytest.mark.parametrize("ent", _pick_multi_file_cases(), ids=gu.case_id)
+def test_cli_multi_file_outputs(ent, tmp_path, monkeypatch):
+    """MHX_NUM_OUT_FILES=3: .edges.<i> / .sdbg.<i> split at bucket boundaries as the reference does per thread
+    (--num_cpu_threads 3 in these runs); the canonical streams stay the same, and seq2sdbg reads the split edges back."""
+    monkeypatch.setenv("MHX_NUM_OUT_FILES", "3")
+    got = gu.run_case(gu.MHX_CORE, ent, str(tmp_path))
+    for key, want in ent.items():
+        if key in ("case", "mercy_cand_kmsort"):
+            continue
+        assert got.get(key) == want, key
+    produced = [f for f in os.listdir(str(tmp_path)) if ".sdbg." in f or ".edges." in f]
+    assert any(f.endswith(".2") for f in produced), produced
