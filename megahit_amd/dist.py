@@ -116,6 +116,7 @@ class Exchanger:
 
     def __init__(self, rank, world, device, group=None):
         self.rank, self.world, self.device, self.group = rank, world, device, group
+        self.force_p2p = bool(os.environ.get("MHX_DIST_FORCE_P2P"))  # tests: the RCCL code path on gloo
 
     def exchange_counts(self, send_counts):
         """send_counts[p] = items this rank sends to p  ->  recv_counts[p] = items p sends to this rank."""
@@ -130,7 +131,7 @@ class Exchanger:
     def exchange_items(self, send, send_counts, recv, recv_counts, item_bytes):
         """send/recv: uint8 tensors holding the per-peer segments back to back (peers ascending); counts in items."""
         _dbg("exchange_items %d B/item, send %s recv %s" % (item_bytes, [int(c) for c in send_counts], [int(c) for c in recv_counts]))
-        if dist.get_backend(self.group) != "nccl":
+        if dist.get_backend(self.group) != "nccl" and not self.force_p2p:
             if item_bytes % 8 == 0:
                 q, dt = item_bytes // 8, torch.int64
             else:  # 12-byte records (compact stage-1 items)

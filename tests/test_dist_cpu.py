@@ -265,3 +265,54 @@ def test_p2p_plan_is_consistent_across_ranks(world, item_bytes, max_msg):
         assert sends == recvs  # same pairs, same sizes, same round
     for r in range(world):
         assert (sent[r] == 1).all() and (got[r] == 1).all()
+
+
+def _p2p_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["MHX_DIST_FORCE_P2P"] = "1"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from megahit_amd import dist as mdist
+    x = mdist.Exchanger(rank, world, torch.device("cpu"))
+    x.MAX_MSG_BYTES = 100  # several rounds per pair
+    item_bytes = 12
+    counts = np.random.default_rng(7).integers(0, 40, size=(world, world))  # same matrix on every rank
+    counts[0][1] = 0
+    send = np.concatenate([np.full(int(counts[rank][d]) * item_bytes, 16 * rank + d, dtype=np.uint8) for d in range(world)])
+    send[::7] ^= 0x80  # not constant inside a segment
+    recv_counts = x.exchange_counts(counts[rank])
+    assert list(recv_counts) == [int(counts[s][rank]) for s in range(world)]
+    recv = torch.zeros(int(recv_counts.sum()) * item_bytes, dtype=torch.uint8)
+    x.exchange_items(torch.from_numpy(send), counts[rank], recv, recv_counts, item_bytes)
+    q.put((rank, send.tobytes(), recv.numpy().tobytes()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_chunked_p2p_exchange_three_ranks():
+    """The code path RCCL runs (self copy + batched isend/irecv in rounds of bounded messages), executed for real on
+    gloo with 3 processes: every rank receives exactly the bytes its peers addressed to it."""
+    world = 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 32500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_p2p_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    counts = np.random.default_rng(7).integers(0, 40, size=(world, world))
+    counts[0][1] = 0
+    sb = [np.concatenate([[0], np.cumsum(counts[r])]) * 12 for r in range(world)]
+    for r in range(world):
+        want = b"".join(outs[s][1][int(sb[s][r]):int(sb[s][r + 1])] for s in range(world))
+        assert outs[r][2] == want
+
+
+def test_two_ranks_with_p2p_exchange(monkeypatch):
+    """the whole read2sdbg + mercy orchestration over the point-to-point exchange path (as on RCCL)"""
+    monkeypatch.setenv("MHX_DIST_FORCE_P2P", "1")
+    test_two_ranks_read2sdbg_with_mercy(21, 2)
+    test_two_ranks_count(21, 2)
