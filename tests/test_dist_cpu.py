@@ -316,3 +316,20 @@ def test_two_ranks_with_p2p_exchange(monkeypatch):
     monkeypatch.setenv("MHX_DIST_FORCE_P2P", "1")
     test_two_ranks_read2sdbg_with_mercy(21, 2)
     test_two_ranks_count(21, 2)
+
+
+def test_three_ranks_read2sdbg_and_count():
+    """odd world size: uneven bucket ranges (65536 / 3), three-way exchange and routing"""
+    import oracle_binding as ob
+    world, k, m = 3, 21, 2
+    pkg = ob.Package(_reads(100) + _reads(101) + _reads(102), reverse=True)
+    outs = _run2("mercy", k, m, world=world)
+    s1 = ob.s1(pkg, k, m, tie_stable=True)
+    n_want, solid = ob.s2_add_mercy(pkg, k, s1["is_solid"], s1["mercy"])
+    assert sum(o[7] for o in outs) == n_want
+    _check_sdbg_ranges(outs, ob.s2(pkg, k, m, solid))
+    outs = _run2("count", k, m, world=world)
+    want = ob.count(pkg, k, m)
+    assert np.array_equal(np.concatenate([o[1] for o in outs]), want["edges"])
+    assert np.array_equal(np.concatenate([o[4] for o in outs]), want["first_0_out"])
+    assert np.array_equal(np.concatenate([o[5] for o in outs]), want["last_0_in"])
