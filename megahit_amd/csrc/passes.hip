@@ -88,9 +88,15 @@ static StageItems for_each_batch(mhx_ctx *c, int stage, uint32_t k, uint32_t m, 
     return first;
   }
   const uint64_t batch_bytes = c->filter_batch_bytes ? c->filter_batch_bytes : (1ull << 30);
-  const uint64_t per_read = 6ull * (s.max_len ? s.max_len : 1) + 8;  // upper bound of items per read in any engine
-  const uint64_t item_bytes_max = 80;
-  uint64_t batch_reads = std::max<uint64_t>(1, batch_bytes / (per_read * item_bytes_max));
+  // upper bound of the staged bytes per read: items per read (count/S1: one per position + 4; stage 2: up to 6 per
+  // position; seq2sdbg: 2 per position + 4) x item size
+  const uint64_t L = s.max_len ? s.max_len : 1;
+  uint64_t per_read_bytes;
+  if (stage == MHX_STAGE_COUNT) per_read_bytes = (L + 4) * (uint64_t)count_stride(k) * 4;
+  else if (stage == MHX_STAGE_S1 || stage == MHX_STAGE_S1_MERCY) per_read_bytes = (L + 4) * (uint64_t)s1_stride(k, false) * 4;
+  else if (stage == MHX_STAGE_SEQ2SDBG) per_read_bytes = (2 * L + 4) * (uint64_t)seq2sdbg_stride(k) * 4;
+  else per_read_bytes = 6 * L * (uint64_t)s2_stride(k) * 4;
+  uint64_t batch_reads = std::max<uint64_t>(1, batch_bytes / per_read_bytes);
   bool have = false;
   for (uint64_t r0 = 0; r0 < ns || !have; r0 += batch_reads) {
     const uint64_t r1 = std::min(ns, r0 + batch_reads);
