@@ -126,7 +126,7 @@ class Exchanger:
         dist.all_to_all_single(r, s, group=self.group)
         return r.cpu().numpy().astype(np.uint64)
 
-    MAX_MSG_BYTES = 1 << 30
+    MAX_MSG_BYTES = 1 << 28  # 256 MiB per message (a 0.5 GB all-to-all ran fine on RCCL 2.26, a 16 GB one hung)
 
     def exchange_items(self, send, send_counts, recv, recv_counts, item_bytes):
         """send/recv: uint8 tensors holding the per-peer segments back to back (peers ascending); counts in items."""
@@ -142,7 +142,7 @@ class Exchanger:
             _sync(recv)
             return
         # RCCL: the rank's own segment is a device copy; every other segment goes as point-to-point messages of at most
-        # 1 GiB (one 16 GB message hung RCCL 2.26 on MI355X), all pairs of a round grouped in one batch.  Sender and
+        # 256 MiB (one 16 GB message hung RCCL 2.26 on MI355X), all pairs of a round grouped in one batch.  Sender and
         # receiver derive the same chunking from the exchanged counts, so no further agreement is needed.
         self_copy, rounds = p2p_plan(send_counts, recv_counts, item_bytes, self.rank, self.world, self.MAX_MSG_BYTES)
         if self_copy is not None:
