@@ -125,6 +125,44 @@ def cpu_baseline(sample_reads):
                       % (K, MIN_COUNT, reads.shape[0], READ_LEN, E / 1e6, dt)}
 
 
+def output_parity(eng, engine, n_reads, world, res):
+    """After the timed region: digest the outputs the LAST step left in HBM and compare them with the reference's
+    known answer for this exact workload (tests/golden/fullsize.json: oracle/_ref/ref_core on the same 10 M reads,
+    tools/make_fullsize_golden.py).  None when no known answer exists for the configuration."""
+    import numpy as np
+    from megahit_amd import canon, lib
+    try:
+        with open(os.path.join(ROOT, "tests", "golden", "fullsize.json")) as f:
+            full = json.load(f)
+    except Exception:
+        return None
+    if world != 1 or n_reads != full["reads"] or K != full["k"] or MIN_COUNT != full["m"]:
+        return None
+    if engine == "read2sdbg":
+        want = full["cases"]["read2sdbg"]
+        got = canon.digest_sdbg_buffers(K, eng.fetch(lib.BUF_SDBG_BYTES, np.uint8), eng.fetch(lib.BUF_BUCKET_COUNT, np.uint64),
+                                        eng.fetch(lib.BUF_BUCKET_TIPS, np.uint64), eng.fetch(lib.BUF_BUCKET_LARGE, np.uint64),
+                                        eng.fetch(lib.BUF_BUCKET_OFFSET, np.uint64))
+        n_got, n_want = int(res[1].n_sdbg), want["n_sdbg"]
+    elif engine == "count":
+        import hashlib
+        want = full["cases"]["count"]
+        edges = eng.fetch(lib.BUF_EDGES, np.uint32)
+        counts = eng.fetch(lib.BUF_BUCKET_COUNT, np.uint64).astype(np.int64)
+        wpe = int(res[0].words_per_edge)
+        h = hashlib.md5()
+        h.update(("k%d w%d n%d|" % (K, wpe, edges.size // wpe)).encode())
+        h.update(counts.tobytes())
+        h.update(edges.tobytes())
+        got = h.hexdigest()
+        n_got, n_want = int(res[0].n_edges), want["n_edges"]
+    else:
+        return None
+    return {"checked": got == want["digest"] and n_got == n_want, "digest": got, "reference_digest": want["digest"],
+            "records": n_got, "reference_records": n_want,
+            "reference": "oracle/_ref/ref_core (reference sources) on the same reads: tests/golden/fullsize.json"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -223,6 +261,8 @@ def main():
     stats = eng.profile_get()
     eng.profile(False)
 
+    parity = output_parity(eng, args.engine, n_reads, world, res) if rank == 0 and not use_dist else None
+
     if use_dist:
         import torch.distributed as dist
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
@@ -257,7 +297,8 @@ def main():
                                       "(BASELINE configs[1]), inputs resident in HBM, outputs left in HBM" % n_reads,
                           "reads_per_gpu": n_reads, "edges_per_gpu": E, "k": K, "min_count": MIN_COUNT,
                           "parallelism": "1 GPU" if not use_dist else "lv1 buckets over %d GPUs, all-to-all" % world},
-               "roofline": roof}
+               "roofline": roof,
+               "parity_checked": bool(parity["checked"]) if parity else None, "parity": parity}
         if not use_dist:
             r1, r2 = res
             if args.engine == "read2sdbg":

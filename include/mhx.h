@@ -48,6 +48,14 @@ void mhx_destroy(mhx_ctx *);
 /* release cached device workspaces (they are otherwise kept between calls) */
 int mhx_trim(mhx_ctx *);
 int mhx_synchronize(mhx_ctx *);
+/* Tuning / diagnostic knobs of one handle (never needed for correct results).  A knob that was not set falls back to
+ * the environment variable MHX_<NAME IN UPPER CASE>, then to its built-in default.  Known names:
+ *   s1_seg (1)        0: stage 1 always sorts fully and reduces with the tile kernel (no segment group-by)
+ *   s1_seg_bits (0)   force the prefix width of the partial stage-1 sort (0 = chosen from the item count)
+ *   s1_seg_la (3)     look-ahead chunks of the segment group-by before a tile gives up (-> classic path)
+ *   s1_seg_per (8)    records per thread and tile of the segment group-by (4 or 8)
+ * Returns <0 for a NULL handle/name. */
+int mhx_set_option(mhx_ctx *, const char *name, long long value);
 
 /* ---- sequence store (replaces SeqPackage held by each engine:
  *      kmer_counter.h:76, read_to_sdbg.h:47-51, seq_to_sdbg.h:79) ---- */

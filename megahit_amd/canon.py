@@ -92,6 +92,25 @@ def digest_sdbg(prefix):
     return h.hexdigest()
 
 
+def digest_sdbg_buffers(k, sdbg_bytes, bucket_items, bucket_tips, bucket_large, bucket_offset):
+    """The digest of digest_sdbg() computed from the library's result buffers (MHX_BUF_SDBG_BYTES + the per-bucket
+    tables) instead of from files: lets a resident-in-HBM run be compared with a reference run's files."""
+    wpt = (k + 15) // 16
+    h = hashlib.md5()
+    h.update(("k%d w%d|" % (k, wpt)).encode())
+    items = np.asarray(bucket_items, dtype=np.uint64)
+    tips = np.asarray(bucket_tips, dtype=np.uint64)
+    large = np.asarray(bucket_large, dtype=np.uint64)
+    off = np.asarray(bucket_offset, dtype=np.uint64)
+    buf = memoryview(np.ascontiguousarray(sdbg_bytes, dtype=np.uint8))
+    for bid in np.nonzero(items)[0]:
+        ni, nt, nl = int(items[bid]), int(tips[bid]), int(large[bid])
+        h.update(np.array([bid, ni, nt, nl], dtype=np.uint64).tobytes())
+        o = int(off[bid])
+        h.update(buf[o:o + sdbg_bucket_nbytes(ni, nt, nl, wpt)])
+    return h.hexdigest()
+
+
 def digest_file(path):
     h = hashlib.md5()
     with open(path, "rb") as f:

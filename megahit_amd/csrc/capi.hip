@@ -389,6 +389,20 @@ void mhx_destroy(mhx_ctx *c) {
 
 int mhx_synchronize(mhx_ctx *c) { MHX_TRY(MHX_HIP(hipStreamSynchronize(c->stream))) }
 
+long long mhx_ctx::opt(const char *name, long long dflt) const {
+  auto it = options.find(name);
+  if (it != options.end()) return it->second;
+  std::string env = "MHX_";
+  for (const char *p = name; *p; ++p) env += (char)toupper((unsigned char)*p);
+  const char *e = getenv(env.c_str());
+  return e && *e ? atoll(e) : dflt;
+}
+int mhx_set_option(mhx_ctx *c, const char *name, long long value) {
+  if (!c || !name) return -1;
+  c->options[name] = value;
+  return 0;
+}
+
 int mhx_load_sequences(mhx_ctx *c, const uint32_t *packed, uint64_t n_words, uint64_t n_seqs, uint32_t fixed_len,
                        const uint64_t *start_pos) {
   MHX_TRY({

@@ -89,6 +89,7 @@ struct mhx_ctx {
   const void *pre_hist_buf = nullptr;
   uint64_t pre_hist_n = 0;
   int pre_hist_passes = 0;
+  uint64_t pre_hist_sig = 0;  // passes_signature() of the plan the histograms were taken for
   // memory-bounded passes (passes.hip): only items of the kept lv1 buckets are materialised
   bool filter_on = false, accumulate = false;
   uint64_t filter_expected = 0, filter_batch_bytes = 0;
@@ -96,6 +97,9 @@ struct mhx_ctx {
   uint64_t s1_acc_bits = 0, mercy_acc_n = 0;  // stage-1 state that accumulate continues
   uint32_t s1_acc_k = 0, s1_acc_m = 0;
   bool dist_s2_agg = false;  // the items of the current multi-GPU stage-2 exchange are aggregated ones
+  // tuning knobs (mhx_set_option): explicit value, else environment MHX_<NAME>, else the default
+  std::map<std::string, long long> options;
+  long long opt(const char *name, long long dflt) const;
   // profiling
   bool profiling = false;
   std::vector<mhx::PendingEvent> pending;
@@ -141,6 +145,7 @@ struct SortPass {
 uint32_t *radix_sort(mhx_ctx *c, uint32_t *buf_a, uint32_t *buf_b, uint64_t n, int stride, int key_words,
                      const std::vector<SortPass> &passes);
 std::vector<SortPass> make_passes(int key_words, int lo_bit, int hi_bit);
+uint64_t passes_signature(const std::vector<SortPass> &ps);
 bool probe_lds_atomic_order(mhx_ctx *c);
 // kmsort_emu.hip: sort with the reference's exact (unstable) tie order, one GPU thread per lv1 bucket
 uint32_t *kmsort_exact(mhx_ctx *c, uint32_t *buf_a, uint32_t *buf_b, uint64_t n, int S, int key_words);

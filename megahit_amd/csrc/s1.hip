@@ -379,6 +379,262 @@ struct S1Op {
   }
 };
 
+// ---------------------------------------------------------------------------------------------------------------
+// Segment group-by: the no-mercy reduction of Read2SdbgS1::Lv2Postprocess (read_to_sdbg_s1.cpp:368-555) WITHOUT a
+// full sort.  Without mercy candidates the reduction only needs, per distinct key (k-1)-mer|head|tail, the number of
+// records carrying it (:430-464: histogram, count >= m -> is_solid.set per occurrence) — not their order.  So the
+// records are radix-sorted on the top `prefix` bits of the (k-1)-mer only (half the LSD passes at k=21), which
+// leaves every key inside one contiguous SEGMENT of equal prefix (~100 records on average), and one workgroup
+// counts the equal keys of the segments of its tile in an LDS hash table (64-bit compare-and-swap + counter):
+//   insert   every record of the tile (and of the look-ahead that completes its last segment) -> slot, count++
+//   marks    per record: count of its slot -> solid? -> byte-map store                          (item-parallel)
+//   slots    per occupied slot = per distinct key: histogram, aggregated stage-2 items           (key-parallel)
+// A segment belongs to the tile that holds its first record: records of the tile that continue the previous tile's
+// last segment (prefix == that of the record before the tile) are inserted but neither marked nor emitted, records
+// behind the tile with the prefix of its last record are fetched until the prefix changes.  No head flags, no scans,
+// three barriers per tile.  A tile whose last segment outgrows the look-ahead or whose keys overflow the table sets
+// *err and does nothing; the host then falls back to the full sort + k_tile_groups (same results).
+// ---------------------------------------------------------------------------------------------------------------
+struct S1SegArgs {
+  int k;
+  uint32_t m;
+  uint32_t pfx_mask;  // bits of key word 0 that form the segment prefix
+  uint32_t eq_mask1;  // bits of key word 1 that take part in key equality: (k-1)-mer bits + head/tail (not the rank tag)
+  uint8_t *solid_bytes;
+  int mark_mode;      // 0: mark solid occurrences, 1: mark the non-solid ones, 2: statistics only
+  unsigned long long *hist, *ctr;  // ctr[0] / ctr[2]: solid / head-and-tail occurrences (mark_mode 2)
+  uint2 *agg_items;
+  unsigned long long *agg_cursor;
+  uint64_t pos_stride;
+  uint32_t *err;
+  int la_chunks;      // look-ahead limit, in chunks of 256 records
+};
+
+constexpr unsigned long long kSegEmpty = ~0ull;  // never a key: head/tail bits 63 do not occur (max (4<<3)|4)
+
+template <int PER, bool AGG>
+__global__ __launch_bounds__(256) void k_s1_seg(const uint32_t *__restrict__ items, uint64_t n, S1SegArgs a, uint64_t n_work,
+                                                uint32_t tile_stride) {
+  constexpr int T = 256 * PER;
+  constexpr int NSLOT = 2 * T;
+  constexpr int LOGS = PER == 8 ? 12 : (PER == 4 ? 11 : (PER == 16 ? 13 : 10));
+  static_assert((1 << LOGS) == NSLOT, "table size");
+  constexpr int NR = PER + 1;  // tile records + the first look-ahead chunk, per thread
+  __shared__ unsigned long long keys[NSLOT];
+  __shared__ uint32_t cnts[NSLOT];
+  __shared__ uint32_t lhist[kS1LocalHist];
+  __shared__ uint32_t s_bad;
+  const int tid = threadIdx.x, lane = tid & (kWave - 1);
+  for (int i = tid; i < NSLOT; i += 256) {
+    keys[i] = kSegEmpty;
+    cnts[i] = 0;
+  }
+  for (int i = tid; i < kS1LocalHist; i += 256) lhist[i] = 0;
+  if (tid == 0) s_bad = 0;
+  __syncthreads();
+
+  const uint32_t pfx = a.pfx_mask, eqm = a.eq_mask1, m = a.m;
+  auto insert = [&](uint32_t w0, uint32_t w1) -> uint32_t {
+    const unsigned long long key = ((unsigned long long)w0 << 32) | (w1 & eqm);
+    uint32_t h = (w0 * 0x9E3779B1u + (w1 & eqm) * 0x85EBCA6Bu) >> (32 - LOGS);
+    for (int probes = 0; probes < 512; ++probes) {
+      const unsigned long long old = atomicCAS(&keys[h], kSegEmpty, key);
+      if (old == kSegEmpty || old == key) {
+        atomicAdd(&cnts[h], 1u);
+        return h;
+      }
+      h = (h + 1) & (NSLOT - 1);
+    }
+    s_bad = 1;  // table (nearly) full
+    return 0;
+  };
+  auto lookup = [&](uint32_t w0, uint32_t w1) -> uint32_t {
+    const unsigned long long key = ((unsigned long long)w0 << 32) | (w1 & eqm);
+    uint32_t h = (w0 * 0x9E3779B1u + (w1 & eqm) * 0x85EBCA6Bu) >> (32 - LOGS);
+    for (int probes = 0; probes < 512 && keys[h] != key; ++probes) h = (h + 1) & (NSLOT - 1);
+    return h;
+  };
+  auto mark = [&](uint32_t w1, uint32_t w2, uint32_t cnt) {
+    const bool both = (w1 & 0x24u) == 0;  // head < 4 and tail < 4
+    const bool solid = both && cnt >= m;
+    if (a.mark_mode == 1 ? (both && !solid) : solid) {
+      const uint64_t abs = w2 + (uint64_t)((w1 >> 6) & 0xFFu) * a.pos_stride;
+      a.solid_bytes[abs - 1] = 1;  // is_solid.set(pos - 1), :464 (or its complement)
+    }
+  };
+
+  // records of a tile in registers (striped: thread t holds records j*256 + t), prefetched one tile ahead together
+  // with the three uniform words that decide segment ownership
+  uint32_t nw0[NR], nw1[NR], nw2[NR];
+  uint32_t n_prev = 0, n_last = 0, n_lalast = 0;
+  auto prefetch = [&](uint64_t tile_idx) {
+    const uint64_t base = tile_idx * tile_stride * T;
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+      const uint64_t gi = base + (uint64_t)j * 256 + tid;
+      if (gi < n) {
+        const uint32_t *p = items + gi * 3;
+        nw0[j] = p[0];
+        nw1[j] = p[1];
+        nw2[j] = p[2];
+      }
+    }
+    const uint64_t tile_end = n - base < (uint64_t)T ? n : base + T;
+    if (base) n_prev = items[(base - 1) * 3];
+    n_last = items[(tile_end - 1) * 3];
+    if (tile_end + 256 < n) n_lalast = items[(tile_end + 255) * 3];
+  };
+  if (blockIdx.x < n_work) prefetch(blockIdx.x);
+
+  unsigned long long st_solid = 0, st_both = 0;
+  for (uint64_t tile_idx = blockIdx.x; tile_idx < n_work; tile_idx += gridDim.x) {
+    const uint64_t base = tile_idx * tile_stride * T;
+    const uint64_t tile_end = n - base < (uint64_t)T ? n : base + T;
+    uint32_t w0[NR], w1[NR], w2[NR];
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+      w0[j] = nw0[j];
+      w1[j] = nw1[j];
+      w2[j] = nw2[j];
+    }
+    const bool has_prev = base != 0;
+    const uint32_t p_prev = n_prev & pfx, p_last = n_last & pfx;
+    // the last segment starts in this tile (else the whole tile continues a segment of an earlier tile)
+    const bool la_own = tile_end < n && !(has_prev && p_last == p_prev);
+    bool more = la_own && tile_end + 256 < n && (n_lalast & pfx) == p_last;  // it even outgrows the first look-ahead chunk
+    if (tile_idx + gridDim.x < n_work) prefetch(tile_idx + gridDim.x);
+
+    uint32_t slot[NR];
+    bool own[NR];
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+      const uint64_t gi = base + (uint64_t)j * 256 + tid;
+      if (j < PER) own[j] = gi < tile_end && !(has_prev && (w0[j] & pfx) == p_prev);
+      else own[j] = la_own && gi < n && (w0[j] & pfx) == p_last;
+      // records of the tile that are not ours are inserted as well (their prefix occurs nowhere else, so they change
+      // no count of ours): no divergence on the common path
+      const bool ins = j < PER ? gi < tile_end : own[j];
+      slot[j] = ins ? insert(w0[j], w1[j]) : 0u;
+    }
+    if (more) {  // rare: further look-ahead chunks straight from HBM
+      for (int c = 1;; ++c) {
+        const uint64_t cb = tile_end + (uint64_t)c * 256;
+        if (c > a.la_chunks) {
+          s_bad = 1;
+          break;
+        }
+        const uint64_t gi = cb + tid;
+        if (gi < n) {
+          const uint32_t *p = items + gi * 3;
+          const uint32_t x0 = p[0], x1 = p[1];
+          if ((x0 & pfx) == p_last) insert(x0, x1);
+        }
+        if (!(cb + 256 < n && (items[(cb + 255) * 3] & pfx) == p_last)) break;
+      }
+    }
+    __syncthreads();
+    const bool bad = s_bad != 0;  // workgroup-uniform
+    uint32_t my_agg = 0;
+    if (!bad) {
+      if (a.mark_mode != 2) {
+#pragma unroll
+        for (int j = 0; j < NR; ++j)
+          if (own[j]) mark(w1[j], w2[j], cnts[slot[j]]);
+        if (more) {
+          for (int c = 1; c <= a.la_chunks; ++c) {
+            const uint64_t cb = tile_end + (uint64_t)c * 256;
+            const uint64_t gi = cb + tid;
+            if (gi < n) {
+              const uint32_t *p = items + gi * 3;
+              const uint32_t x0 = p[0], x1 = p[1], x2 = p[2];
+              if ((x0 & pfx) == p_last) mark(x1, x2, cnts[lookup(x0, x1)]);
+            }
+            if (!(cb + 256 < n && (items[(cb + 255) * 3] & pfx) == p_last)) break;
+          }
+        }
+      }
+      // per distinct key (= occupied slot that is ours)
+      for (int s = tid; s < NSLOT; s += 256) {
+        const unsigned long long key = keys[s];
+        if (key == kSegEmpty) continue;
+        if (has_prev && ((uint32_t)(key >> 32) & pfx) == p_prev) continue;
+        const uint32_t cnt = cnts[s];
+        const bool both = ((uint32_t)key & 0x24u) == 0;
+        if (!both) continue;
+        const bool solid = cnt >= m;
+        if (a.mark_mode == 2) {
+          st_both += cnt;
+          if (solid) st_solid += cnt;
+          continue;
+        }
+        const uint32_t hb = cnt > MHX_MAX_MUL ? (uint32_t)MHX_MAX_MUL : cnt;  // :430-436
+        if (hb < kS1LocalHist) atomicAdd(&lhist[hb], 1u);
+        else atomicAdd(&a.hist[hb], 1ull);
+        if constexpr (AGG) {
+          if (solid) {
+            const unsigned ht = (uint32_t)key & 63u;
+            const uint64_t smer = key & (~0ull << (64 - 2 * (a.k - 1)));
+            const uint64_t x = ((uint64_t)(ht >> 3) << 62) | (smer >> 2) | ((uint64_t)(ht & 7) << (62 - 2 * a.k));
+            my_agg += x == rc64(x, a.k + 1) ? 1u : 2u;
+          }
+        }
+      }
+    }
+    uint64_t agg_at = 0;
+    if constexpr (AGG) {
+      // output order is irrelevant (stage 2 sorts): one cursor bump per wavefront
+      const uint32_t incl = wave_inclusive_sum(my_agg);
+      const uint32_t tot = __shfl(incl, kWave - 1, kWave);
+      unsigned long long wbase = 0;
+      if (lane == 0 && tot) wbase = atomicAdd(a.agg_cursor, (unsigned long long)tot);
+      wbase = __shfl(wbase, 0, kWave);
+      agg_at = wbase + incl - my_agg;
+    }
+    __syncthreads();  // every count has been read: slots may be recycled
+    for (int s = tid; s < NSLOT; s += 256) {
+      const unsigned long long key = keys[s];
+      if (key == kSegEmpty) continue;
+      if constexpr (AGG) {
+        const uint32_t cnt = cnts[s];
+        const bool mine = !(has_prev && ((uint32_t)(key >> 32) & pfx) == p_prev);
+        if (!bad && a.mark_mode != 2 && mine && ((uint32_t)key & 0x24u) == 0 && cnt >= m) {
+          const unsigned ht = (uint32_t)key & 63u;
+          const int k = a.k;
+          const uint64_t mask_k = ~0ull << (64 - 2 * k);
+          const uint64_t smer = key & (~0ull << (64 - 2 * (k - 1)));
+          const uint64_t x = ((uint64_t)(ht >> 3) << 62) | (smer >> 2) | ((uint64_t)(ht & 7) << (62 - 2 * k));
+          const uint64_t xr = rc64(x, k + 1);
+          const uint64_t mul = cnt > MHX_MAX_MUL ? (uint64_t)MHX_MAX_MUL : cnt;
+          const uint64_t f = ((x << 2) & mask_k) | (1ull << 19) | ((x >> 62) << 16) | mul;  // k-mer x[1..k], W = x[0]
+          a.agg_items[agg_at++] = make_uint2((uint32_t)(f >> 32), (uint32_t)f);
+          if (x != xr) {  // palindromic (k+1)-mers emit the forward item only (read_to_sdbg_s2.cpp:385-423)
+            const uint64_t b = ((xr << 2) & mask_k) | (1ull << 19) | ((xr >> 62) << 16) | mul;
+            a.agg_items[agg_at++] = make_uint2((uint32_t)(b >> 32), (uint32_t)b);
+          }
+        }
+      }
+      keys[s] = kSegEmpty;
+      cnts[s] = 0;
+    }
+    if (bad && tid == 0) {
+      atomicOr(a.err, 1u);
+      s_bad = 0;
+    }
+    __syncthreads();
+  }
+  if (a.mark_mode == 2) {
+    st_solid = wave_sum(st_solid);
+    st_both = wave_sum(st_both);
+    if (lane == 0 && st_both) {
+      atomicAdd(a.ctr, st_solid);
+      atomicAdd(a.ctr + 2, st_both);
+    }
+  } else {
+    for (int i = tid; i < kS1LocalHist; i += 256)
+      if (lhist[i]) atomicAdd(&a.hist[i], (unsigned long long)lhist[i]);
+  }
+}
+
 // byte map -> AtomicBitVector layout (bit i = word i/64, bit i%64; kmbitvector.h:67-88) + popcount
 __global__ __launch_bounds__(256) void k_pack_solid(const uint8_t *__restrict__ bytes, uint64_t n_bits, unsigned long long *__restrict__ words,
                                                     uint64_t n_words, unsigned long long *__restrict__ n_solid) {
@@ -561,6 +817,27 @@ static std::vector<SortPass> s1_sort_passes(uint32_t k) {
   const int KWv = s1_kw(k), kmer_bits = (int)(k - 1) * 2;
   return make_passes_ranges(KWv, {{0, 6}, {KWv * 32 - kmer_bits, KWv * 32}});
 }
+// Stage-1 sort plan.  seg_bits > 0: only the top seg_bits of the (k-1)-mer are sorted and k_s1_seg groups the equal keys
+// of each segment (no-mercy 12-byte records); the width is chosen so that a segment holds ~100 records on average
+// (n_eff = items of the whole job: a rank of a multi-GPU run owns 1/n_parts of the key space).
+struct S1Plan {
+  std::vector<SortPass> passes;
+  int seg_bits;
+};
+static S1Plan s1_plan(const mhx_ctx *c, uint32_t k, uint64_t n_items, bool compact, int want_mercy) {
+  const int force_bits = (int)c->opt("s1_seg_bits", 0);
+  const int kmer_bits = (int)(k - 1) * 2;
+  S1Plan p{s1_sort_passes(k), 0};
+  if (!c->opt("s1_seg", 1) || !compact || want_mercy || s1_kw(k) != 2 || s1_stride(k, compact) != 3 || !n_items) return p;
+  const double n_eff = (double)n_items * (double)(c->n_parts > 1 ? c->n_parts : 1);
+  int bits = 8;
+  while (bits < 32 && n_eff / 96.0 > (double)(1ull << bits)) bits += 8;
+  if (force_bits) bits = force_bits;
+  bits = std::max(1, std::min(bits, std::min(32, kmer_bits)));
+  p.seg_bits = bits;
+  p.passes = make_passes(2, 64 - bits, 64);
+  return p;
+}
 // compact 1-word aux when no mercy candidates are wanted and positions fit 32 bits
 // Multi-GPU with more than 2^32 global base positions: compact records keep a rank-local 32-bit position and carry the
 // source rank in the unused key bits between head/tail and the (k-1)-mer (needs 8 spare bits and the rank-stride layout
@@ -615,8 +892,9 @@ uint64_t s1_extract(mhx_ctx *c, uint32_t k, bool compact) {
     unsigned long long *pre_hist = nullptr;
     c->pre_hist_buf = nullptr;
     if (fixed && S <= 4) {
-      const std::vector<SortPass> passes = s1_sort_passes(k);
+      const std::vector<SortPass> passes = s1_plan(c, k, n_items, compact, compact ? 0 : 1).passes;
       if ((int)passes.size() <= kMaxFusedPasses) {
+        c->pre_hist_sig = passes_signature(passes);
         specs.n = (int)passes.size();
         for (int p = 0; p < specs.n; ++p) specs.d[p] = spec_of_pass(passes[p], KWv);
         pre_hist = c->ws("sort_pre_hist", (size_t)kMaxFusedPasses * 256 * 8).as<unsigned long long>();
@@ -663,9 +941,10 @@ int s1_process(mhx_ctx *c, uint32_t k, uint32_t m, int want_mercy, uint32_t *buf
   const bool global = c->global_bases != 0;  // multi-GPU: positions index the global read set
   const int kmer_bits = (int)(k - 1) * 2;
   // want_mercy == 2: records with equal keys in exactly the order the reference's kmsort leaves them (H1)
+  const S1Plan plan = s1_plan(c, k, n_items, compact, want_mercy);
   uint32_t *sorted = want_mercy == 2
                          ? kmsort_exact(c, buf_a, buf_b, n_items, S, KWv)
-                         : radix_sort(c, buf_a, buf_b, n_items, S, KWv, s1_sort_passes(k));
+                         : radix_sort(c, buf_a, buf_b, n_items, S, KWv, plan.passes);
   c->pre_hist_buf = nullptr;
   uint32_t *spare = sorted == buf_a ? buf_b : buf_a;
 
@@ -712,6 +991,37 @@ int s1_process(mhx_ctx *c, uint32_t k, uint32_t m, int want_mercy, uint32_t *buf
     MHX_HIP(hipMemsetAsync(agg_cursor, 0, 24, st));
     if (prev) MHX_HIP(hipMemcpyAsync(agg_cursor, &c->agg_n, 8, hipMemcpyHostToDevice, st));
   }
+  // segment group-by (k_s1_seg) on the partially sorted records
+  uint32_t *seg_err = c->ws("s1_seg_err", 64).as<uint32_t>();
+  auto seg_launch = [&](int mode) {
+    const int per = (int)c->opt("s1_seg_per", 8);
+    const int la = (int)c->opt("s1_seg_la", 3);
+    const int T = 256 * (per == 4 ? 4 : 8);
+    const uint64_t n_tiles = div_ceil(n_items, (uint64_t)T);
+    const uint32_t stride = mode == 2 ? 64u : 1u;
+    const uint64_t n_work = div_ceil(n_tiles, stride);
+    const uint64_t pos_stride = s1_rank_tagged(c, k) ? c->global_bases / (uint64_t)c->n_parts : 0;
+    const uint32_t pfx_mask = plan.seg_bits >= 32 ? 0xFFFFFFFFu : ~(0xFFFFFFFFu >> plan.seg_bits);
+    const uint32_t eq_mask1 = (kmer_bits > 32 ? ~(0xFFFFFFFFu >> (kmer_bits - 32)) : 0u) | 63u;
+    const bool agg_on = agg && mode != 2;
+    S1SegArgs a{(int)k, m, pfx_mask, eq_mask1, solid_bytes, mode, hist, ctr, agg_items,
+                reinterpret_cast<unsigned long long *>(agg_cursor), pos_stride, seg_err, la};
+    MHX_HIP(hipMemsetAsync(seg_err, 0, 4, st));
+    const unsigned grid = (unsigned)std::min<uint64_t>(n_work, per == 4 ? 256 * 6 : 256 * 3);
+    const char *nm = mode == 2 ? "s1_sample" : "s1_groups";
+    const double bytes = (double)n_work * T * 12;
+#define MHX_SEG(PERV, AGGV) \
+  MHX_LAUNCH(c, nm, bytes, hipLaunchKernelGGL((k_s1_seg<PERV, AGGV>), dim3(grid), dim3(256), 0, st, sorted, n_items, a, n_work, stride))
+    if (per == 4) {
+      if (agg_on) MHX_SEG(4, true);
+      else MHX_SEG(4, false);
+    } else {
+      if (agg_on) MHX_SEG(8, true);
+      else MHX_SEG(8, false);
+    }
+#undef MHX_SEG
+  };
+  bool seg_failed = false;
   if (n_items) {
     // marking polarity from a 1/64 sample of the tiles: when most occurrences are solid it is cheaper to mark the
     // non-solid ones (each mark is a 32-byte partial HBM write).  Single GPU only: ranks must agree on the meaning.
@@ -735,14 +1045,39 @@ int s1_process(mhx_ctx *c, uint32_t k, uint32_t m, int want_mercy, uint32_t *buf
     else if (can_invert && mark_env && !strcmp(mark_env, "nonsolid")) mark_mode = 1;
     else if (can_invert && !mark_env && n_items > (1u << 16)) {
       mark_mode = 2;
-      MHX_ALL_CASES
+      if (plan.seg_bits) seg_launch(2);
+      else MHX_ALL_CASES
       unsigned long long hs[3] = {0, 0, 0};
       MHX_HIP(hipMemcpyAsync(hs, ctr, 24, hipMemcpyDeviceToHost, st));
       MHX_HIP(hipStreamSynchronize(st));
       mark_mode = hs[2] > 0 && hs[0] * 2 > hs[2] ? 1 : 0;
       MHX_HIP(hipMemsetAsync(ctr, 0, 64, st));
     }
-    if (agg && S == 3) s1_groups_launch<3, true, true>(MHX_ARGS(0));
+    if (plan.seg_bits) {
+      // histogram / aggregate cursor as they are now, in case a tile gives up and the classic path has to redo the job
+      unsigned long long *hist_save = c->ws("s1_hist_save", (MHX_MAX_MUL + 1) * 8).as<unsigned long long>();
+      MHX_HIP(hipMemcpyAsync(hist_save, hist, (MHX_MAX_MUL + 1) * 8, hipMemcpyDeviceToDevice, st));
+      seg_launch(mark_mode);
+      uint32_t e = 0;
+      MHX_HIP(hipMemcpyAsync(&e, seg_err, 4, hipMemcpyDeviceToHost, st));
+      MHX_HIP(hipStreamSynchronize(st));
+      if (e) {  // a segment beyond the look-ahead or a full table: full sort + the classic tile kernel (marks are idempotent)
+        seg_failed = true;
+        MHX_HIP(hipMemcpyAsync(hist, hist_save, (MHX_MAX_MUL + 1) * 8, hipMemcpyDeviceToDevice, st));
+        if (agg) {
+          const uint64_t prev = agg_continues ? c->agg_n : 0;
+          MHX_HIP(hipMemsetAsync(agg_cursor, 0, 24, st));
+          if (prev) MHX_HIP(hipMemcpyAsync(agg_cursor, &c->agg_n, 8, hipMemcpyHostToDevice, st));
+        }
+        MHX_HIP(hipMemsetAsync(ctr, 0, 64, st));
+        uint32_t *other = sorted == buf_a ? buf_b : buf_a;
+        sorted = radix_sort(c, sorted, other, n_items, S, KWv, s1_sort_passes(k));
+        spare = sorted == buf_a ? buf_b : buf_a;
+        mercy = reinterpret_cast<long long *>(spare);
+      }
+    }
+    if (plan.seg_bits && !seg_failed) {
+    } else if (agg && S == 3) s1_groups_launch<3, true, true>(MHX_ARGS(0));
     else if (agg && S == 4 && !compact) s1_groups_launch<4, false, true>(MHX_ARGS(want_mercy));
     else MHX_ALL_CASES
 #undef MHX_ALL_CASES

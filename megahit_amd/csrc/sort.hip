@@ -518,6 +518,13 @@ std::vector<SortPass> make_passes(int key_words, int lo_bit, int hi_bit) {
   return p;
 }
 
+uint64_t passes_signature(const std::vector<SortPass> &ps) {
+  uint64_t h = 1469598103934665603ull;
+  for (const SortPass &q : ps)
+    for (int v : {q.shift, q.bits, q.shift2, q.bits2}) h = (h ^ (uint64_t)(v + 1)) * 1099511628211ull;
+  return h;
+}
+
 DigitSpec spec_of_pass(const SortPass &ps, int key_words) {
   DigitSpec ds{key_words - 1 - ps.shift / 32, (unsigned)(ps.shift % 32), (1u << ps.bits) - 1, 0, 0u, 0u, 0u};
   if (ps.bits2) {
@@ -548,7 +555,8 @@ static uint32_t *radix_sort_onesweep(mhx_ctx *c, uint32_t *a, uint32_t *b, uint6
   std::vector<DigitSpec> all(P);
   for (int p = 0; p < P; ++p) all[p] = spec_of_pass(passes[p], key_words);
   // extraction may have taken the digit histograms while it produced the records (s1.hip): then no read at all
-  const bool pre = c->pre_hist_buf == (const void *)a && c->pre_hist_n == n && c->pre_hist_passes == P && P <= kMaxFusedPasses;
+  const bool pre = c->pre_hist_buf == (const void *)a && c->pre_hist_n == n && c->pre_hist_passes == P && P <= kMaxFusedPasses &&
+                   c->pre_hist_sig == passes_signature(passes);
   c->pre_hist_buf = nullptr;
   if (pre) MHX_HIP(hipMemcpyAsync(gh, c->work["sort_pre_hist"].p, (size_t)P * 256 * 8, hipMemcpyDeviceToDevice, st));
   for (int p0 = 0; p0 < P && !pre; p0 += kMaxFusedPasses) {  // one read of the input per 16 passes

@@ -1,0 +1,96 @@
+"""GPU, BASELINE configs[1] size: the drop-in CLI on 10 M synthetic 150 bp PE reads (k=21, m=2) reproduces the
+REFERENCE's canonical streams.  The known answers in tests/golden/fullsize.json were produced by oracle/_ref/ref_core
+(= the reference's own sources) on the same deterministic read library (tools/make_fullsize_golden.py); the library is
+regenerated here, only digests are committed.  Reference: src/sorting/read_to_sdbg_s2.cpp:521-614,
+src/sdbg/sdbg_writer.cpp:25-79, src/sorting/kmer_counter.cpp:254-414."""
+import json
+import os
+import subprocess
+import sys
+import time
+
+import pytest
+
+import golden_util as gu
+from megahit_amd import canon
+
+pytestmark = pytest.mark.gpu
+
+sys.path.insert(0, os.path.join(gu.ROOT, "tools"))
+with open(os.path.join(gu.GOLD, "fullsize.json")) as f:
+    FULL = json.load(f)
+
+
+@pytest.fixture(scope="module")
+def full(tmp_path_factory):
+    import make_fullsize_golden as mfg
+    d = str(tmp_path_factory.mktemp("full"))
+    mfg.gen_library(os.path.join(d, "reads"), FULL["reads"])
+    assert canon.digest_file(os.path.join(d, "reads.bin")) == FULL["lib_bin_md5"], "the generator is not deterministic across boxes"
+    return d
+
+
+def run(args, env=None):
+    t0 = time.perf_counter()
+    e = dict(os.environ)
+    e.update(env or {})
+    p = subprocess.run([gu.MHX_CORE] + args, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, env=e)
+    assert p.returncode == 0, p.stderr[-2000:]
+    return time.perf_counter() - t0, p.stderr
+
+
+def common(d):
+    return ["-k", str(FULL["k"]), "-m", str(FULL["m"]), "--host_mem", "64e9", "--num_cpu_threads", "8", "--read_lib_file", os.path.join(d, "reads")]
+
+
+def sdbg_counts(prefix):
+    _hdr, rows = canon.read_sdbg_info(prefix)
+    live = [r for r in rows if r[0] != canon.NULL_ID]
+    return sum(r[3] for r in live), sum(r[4] for r in live), sum(r[5] for r in live)
+
+
+def check_sdbg(prefix, want):
+    assert sdbg_counts(prefix) == (want["n_sdbg"], want["n_tips"], want["n_large"])
+    assert canon.digest_sdbg(prefix) == want["digest"]
+
+
+def test_fullsize_read2sdbg(full):
+    out = os.path.join(full, "r2s")
+    run(["read2sdbg"] + common(full) + ["--output_prefix", out])
+    want = FULL["cases"]["read2sdbg"]
+    assert canon.digest_file(out + ".counting") == want["counting_md5"]
+    check_sdbg(out, want)
+
+
+def test_fullsize_read2sdbg_classic_stage1(full):
+    """the same with the segment group-by switched off: full sort + tile kernel"""
+    out = os.path.join(full, "r2c")
+    run(["read2sdbg"] + common(full) + ["--output_prefix", out], env={"MHX_S1_SEG": "0"})
+    check_sdbg(out, FULL["cases"]["read2sdbg"])
+
+
+def test_fullsize_count_then_seq2sdbg(full):
+    cnt = os.path.join(full, "cnt")
+    run(["count"] + common(full) + ["--output_prefix", cnt])
+    want = FULL["cases"]["count"]
+    hdr, _rows = canon.read_edges_info(cnt)
+    assert hdr["num_edges"] == want["n_edges"]
+    assert canon.digest_file(cnt + ".counting") == want["counting_md5"]
+    assert canon.digest_file(cnt + ".cand") == want["cand_md5"]
+    assert canon.digest_edges(cnt) == want["digest"]
+    s2s = ["seq2sdbg", "-k", str(FULL["k"]), "--kmer_from", "0", "--host_mem", "64e9", "--num_cpu_threads", "8", "--input_prefix", cnt]
+    run(s2s + ["--output_prefix", os.path.join(full, "s2s")])
+    check_sdbg(os.path.join(full, "s2s"), FULL["cases"]["seq2sdbg"])
+    # the orchestrator's default route (src/megahit:939-966): seq2sdbg --need_mercy over count's edges + .cand
+    run(s2s + ["--need_mercy", "--output_prefix", os.path.join(full, "s2m")])
+    check_sdbg(os.path.join(full, "s2m"), FULL["cases"]["seq2sdbg_need_mercy"])
+
+
+def test_fullsize_read2sdbg_need_mercy(full):
+    """--need_mercy replays kmlib::kmsort's tie order: the reference's mercy candidates and SdBG"""
+    out = os.path.join(full, "r2m")
+    _dt, log = run(["read2sdbg"] + common(full) + ["--need_mercy", "--output_prefix", out])
+    want = FULL["cases"]["read2sdbg_need_mercy"]
+    nm = [int(l.split(":")[-1].split()[0]) for l in log.splitlines() if "Number mercy" in l]
+    assert nm and nm[-1] == want["number_mercy"]
+    check_sdbg(out, want)

@@ -90,6 +90,40 @@ def test_read2sdbg_s1_without_mercy_compact_records(engine, kind, k, m):
     check_sdbg(engine, engine.read2sdbg_s2(k, m), ob.s2(pkg, k, m, w1["is_solid"]))
 
 
+SEG_DEFAULTS = dict(s1_seg=1, s1_seg_bits=0, s1_seg_la=3, s1_seg_per=8)
+SEG_VARIANTS = [dict(s1_seg=0),                      # classic: full sort + tile kernel
+                dict(s1_seg_bits=8, s1_seg_la=0),   # segments of ~1000 records with no look-ahead: tiles give up -> fallback
+                dict(s1_seg_bits=8),                # long segments, several look-ahead chunks
+                dict(s1_seg_bits=16, s1_seg_la=1),
+                dict(s1_seg_bits=32),               # prefix = the whole first key word
+                dict(s1_seg_per=4),
+                dict(s1_seg_per=4, s1_seg_bits=8)]
+
+
+@pytest.mark.parametrize("opts", SEG_VARIANTS, ids=lambda o: ",".join("%s=%d" % kv for kv in o.items()))
+@pytest.mark.parametrize("kind,k,m", [("fixed", 21, 2), ("var", 21, 2), ("lowcomplex", 21, 2), ("var", 27, 3), ("fixed", 25, 2)])
+def test_s1_segment_groupby_variants(engine, kind, k, m, opts):
+    """The no-mercy stage 1 = partial sort + segment group-by (k_s1_seg); every knob setting, the give-up -> classic
+    fallback and the classic path itself must produce the oracle's is_solid / histogram / SdBG."""
+    reads = make_reads(kind, 8)
+    pkg = ob.Package(reads, reverse=True)
+    w1 = ob.s1(pkg, k, m, tie_stable=True)
+    load(engine, pkg)
+    try:
+        for name, v in opts.items():
+            engine.set_option(name, v)
+        r1 = engine.read2sdbg_s1(k, m, want_mercy=False)
+        assert r1.n_items == w1["n_items"]
+        solid = engine.fetch(lib.BUF_IS_SOLID, np.uint64)
+        assert np.array_equal(solid, w1["is_solid"][: solid.size])
+        assert np.array_equal(engine.fetch(lib.BUF_MUL_HIST, np.int64), w1["hist"])
+        assert r1.n_solid == int(sum(bin(int(x)).count("1") for x in w1["is_solid"]))
+        check_sdbg(engine, engine.read2sdbg_s2(k, m), ob.s2(pkg, k, m, w1["is_solid"]))
+    finally:
+        for name, v in SEG_DEFAULTS.items():
+            engine.set_option(name, v)
+
+
 @pytest.mark.parametrize("kind,k", [("var", 21), ("lowcomplex", 27), ("fixed", 31)])
 def test_read2sdbg_min_count_1(engine, kind, k):
     reads = make_reads(kind, 9)

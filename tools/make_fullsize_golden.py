@@ -1,0 +1,116 @@
+"""Known answers of the REFERENCE at BASELINE configs[1] size (10 M synthetic 150 bp PE reads, k=21, m=2).
+
+Runs oracle/_ref/ref_core (= the reference's own sources compiled in place) on the deterministic read library of
+tools/e2e_cli.py / bench.py rank 0 (genome seed 1, read seeds 1001+i) and stores the digests of the canonical streams
+in tests/golden/fullsize.json.  The library itself is regenerated on the GPU box (numpy is deterministic), only the
+digests travel.  Needs /root/reference to have been compiled (make -C oracle ref); ~25 min of 8-thread CPU time.
+
+    python tools/make_fullsize_golden.py [--reads 1e7] [--threads 8] [--keep DIR]
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from megahit_amd import canon, synth  # noqa: E402
+
+
+def gen_library(prefix, n_reads):
+    """The bench.py / e2e_cli.py workload: one genome (seed 1, 2.5 bp per read), PE blocks of 1 M pairs (seed 1001+i)."""
+    import numpy as np
+    G = int(n_reads * 2.5)
+    genome = np.random.default_rng(1).integers(0, 4, size=G, dtype=np.uint8)
+    blocks = []
+    for i, lo in enumerate(range(0, n_reads // 2, 1000000)):
+        c = min(1000000, n_reads // 2 - lo)
+        blocks.append(synth.gen_pe_reads(c, G, read_len=150, frag=400, err=0.005, seed=1001 + i, genome=genome))
+    synth.write_read_lib(prefix, blocks)
+
+
+def run(cmd):
+    t0 = time.perf_counter()
+    p = subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True)
+    dt = time.perf_counter() - t0
+    if p.returncode != 0:
+        sys.stderr.write(p.stderr[-3000:])
+        raise SystemExit("command failed: " + " ".join(cmd))
+    return dt, p.stderr
+
+
+def sdbg_summary(prefix):
+    hdr, rows = canon.read_sdbg_info(prefix)
+    items = sum(r[3] for r in rows if r[0] != canon.NULL_ID)
+    tips = sum(r[4] for r in rows if r[0] != canon.NULL_ID)
+    large = sum(r[5] for r in rows if r[0] != canon.NULL_ID)
+    return {"digest": canon.digest_sdbg(prefix), "n_sdbg": items, "n_tips": tips, "n_large": large}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reads", type=float, default=1e7)
+    ap.add_argument("--threads", type=int, default=8)
+    ap.add_argument("--keep", default=None, help="work directory to keep (default: a temp dir)")
+    ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden", "fullsize.json"))
+    args = ap.parse_args()
+    n = int(args.reads) // 2 * 2
+    k, m = 21, 2
+    ref = os.path.join(ROOT, "oracle", "_ref", "ref_core")
+    d = args.keep or tempfile.mkdtemp(prefix="mhx_full_")
+    os.makedirs(d, exist_ok=True)
+    lib = os.path.join(d, "reads")
+    if not os.path.exists(lib + ".bin"):
+        gen_library(lib, n)
+    out = {"reads": n, "k": k, "m": m, "edges": n * (150 - k), "generator": "tools/make_fullsize_golden.py",
+           "reference_threads": args.threads, "lib_bin_md5": canon.digest_file(lib + ".bin"), "cases": {}}
+    common = ["-k", str(k), "-m", str(m), "--host_mem", "48e9", "--num_cpu_threads", str(args.threads), "--read_lib_file", lib]
+
+    dt, _ = run([ref, "read2sdbg"] + common + ["--output_prefix", os.path.join(d, "r2s")])
+    c = sdbg_summary(os.path.join(d, "r2s"))
+    c.update(wall_s=round(dt, 1), counting_md5=canon.digest_file(os.path.join(d, "r2s.counting")))
+    out["cases"]["read2sdbg"] = c
+    print("read2sdbg", c, flush=True)
+
+    dt, _ = run([ref, "count"] + common + ["--output_prefix", os.path.join(d, "cnt")])
+    hdr, _rows = canon.read_edges_info(os.path.join(d, "cnt"))
+    c = {"digest": canon.digest_edges(os.path.join(d, "cnt")), "n_edges": hdr["num_edges"], "wall_s": round(dt, 1),
+         "counting_md5": canon.digest_file(os.path.join(d, "cnt.counting")),
+         "cand_md5": canon.digest_file(os.path.join(d, "cnt.cand"))}
+    out["cases"]["count"] = c
+    print("count", c, flush=True)
+
+    s2s = ["-k", str(k), "--kmer_from", "0", "--host_mem", "48e9", "--num_cpu_threads", str(args.threads),
+           "--input_prefix", os.path.join(d, "cnt")]
+    dt, _ = run([ref, "seq2sdbg"] + s2s + ["--output_prefix", os.path.join(d, "s2s")])
+    c = sdbg_summary(os.path.join(d, "s2s"))
+    c["wall_s"] = round(dt, 1)
+    out["cases"]["seq2sdbg"] = c
+    print("seq2sdbg", c, flush=True)
+
+    # the orchestrator's default route: count, then seq2sdbg --need_mercy on the same prefix (reads .cand + the read lib)
+    dt, _ = run([ref, "seq2sdbg"] + s2s + ["--need_mercy", "--output_prefix", os.path.join(d, "s2m")])
+    c = sdbg_summary(os.path.join(d, "s2m"))
+    c["wall_s"] = round(dt, 1)
+    out["cases"]["seq2sdbg_need_mercy"] = c
+    print("seq2sdbg_need_mercy", c, flush=True)
+
+    dt, log = run([ref, "read2sdbg"] + common + ["--need_mercy", "--output_prefix", os.path.join(d, "r2m")])
+    c = sdbg_summary(os.path.join(d, "r2m"))
+    c["wall_s"] = round(dt, 1)
+    for line in log.splitlines():
+        if "Number mercy" in line:
+            c["number_mercy"] = int(line.split(":")[-1].strip().split()[0])
+    out["cases"]["read2sdbg_need_mercy"] = c
+    print("read2sdbg_need_mercy", c, flush=True)
+
+    with open(args.out, "w") as f:
+        json.dump(out, f, indent=1)
+    print("wrote", args.out)
+
+
+if __name__ == "__main__":
+    main()
