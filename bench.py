@@ -32,7 +32,9 @@ def log(*a):
 
 def make_reads(n_reads, rank, world):
     """Reads of this rank: PE fragments from ONE genome shared by all ranks (G = 2.5 bp per read in the
-    whole job, i.e. ~60x coverage as in SURVEY.md §8d), per-rank read seed.  Returned reversed+packed."""
+    whole job, i.e. ~60x coverage as in SURVEY.md §8d), per-rank read seed.  Returned reversed+packed.
+    Rank 0 of a 1-GPU run holds exactly the library of tools/make_fullsize_golden.py (read seeds 1001+i), for which
+    tests/golden/fullsize.json holds the reference's answers."""
     import numpy as np
     from megahit_amd import synth
     total_reads = n_reads * world
@@ -42,7 +44,7 @@ def make_reads(n_reads, rank, world):
     step = 1000000
     for i, lo in enumerate(range(0, n_reads // 2, step)):
         n = min(step, n_reads // 2 - lo)
-        r = synth.gen_pe_reads(n, G, read_len=READ_LEN, frag=400, err=0.005, seed=1000 * (rank + 1) + i, genome=genome)
+        r = synth.gen_pe_reads(n, G, read_len=READ_LEN, frag=400, err=0.005, seed=1000 * (rank + 1) + 1 + i, genome=genome)
         chunks.append(synth.pack_reads_concat(r[:, ::-1]))  # stored reversed, as the reference loads them
     # every chunk is a whole number of words only if n*2*150 % 16 == 0: true for n multiple of 8
     return np.concatenate(chunks)

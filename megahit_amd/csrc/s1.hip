@@ -403,14 +403,22 @@ struct S1SegArgs {
   uint8_t *solid_bytes;
   int mark_mode;      // 0: mark solid occurrences, 1: mark the non-solid ones, 2: statistics only
   unsigned long long *hist, *ctr;  // ctr[0] / ctr[2]: solid / head-and-tail occurrences (mark_mode 2)
-  uint2 *agg_items;
-  unsigned long long *agg_cursor;
+  // aggregated stage-2 items: every (persistent) workgroup fills a region of its own, agg_raw[blockIdx.x * agg_cap ...],
+  // and leaves its item count in agg_counts[blockIdx.x]; k_agg_compact packs the regions afterwards.  (A shared
+  // cursor costs one same-address global atomic per wavefront and tile: ~10 ns each, 2.6 M of them at 10 M reads.)
+  uint2 *agg_raw;
+  uint32_t agg_cap;
+  uint32_t *agg_counts;
   uint64_t pos_stride;
   uint32_t *err;
   int la_chunks;      // look-ahead limit, in chunks of 256 records
 };
 
 constexpr unsigned long long kSegEmpty = ~0ull;  // never a key: head/tail bits 63 do not occur (max (4<<3)|4)
+
+constexpr int kSegExtra = 256;  // distinct keys a tile may meet beyond its first look-ahead chunk
+constexpr int kSegHist = 512;    // multiplicities counted in LDS
+//  // distinct keys a tile may meet beyond its first look-ahead chunk
 
 template <int PER, bool AGG>
 __global__ __launch_bounds__(256) void k_s1_seg(const uint32_t *__restrict__ items, uint64_t n, S1SegArgs a, uint64_t n_work,
@@ -420,37 +428,68 @@ __global__ __launch_bounds__(256) void k_s1_seg(const uint32_t *__restrict__ ite
   constexpr int LOGS = PER == 8 ? 12 : (PER == 4 ? 11 : (PER == 16 ? 13 : 10));
   static_assert((1 << LOGS) == NSLOT, "table size");
   constexpr int NR = PER + 1;  // tile records + the first look-ahead chunk, per thread
+  constexpr uint32_t kCreated = 0x80000000u;
   __shared__ unsigned long long keys[NSLOT];
   __shared__ uint32_t cnts[NSLOT];
-  __shared__ uint32_t lhist[kS1LocalHist];
-  __shared__ uint32_t s_bad;
+  __shared__ uint32_t lhist[kSegHist];
+  __shared__ uint32_t xl_slot[kSegExtra];  // slots created by the rare further look-ahead chunks
+  __shared__ uint32_t s_bad, xl_n, s_agg_cur;
   const int tid = threadIdx.x, lane = tid & (kWave - 1);
+  uint2 *const agg_out = AGG ? a.agg_raw + (size_t)blockIdx.x * a.agg_cap : nullptr;
   for (int i = tid; i < NSLOT; i += 256) {
     keys[i] = kSegEmpty;
     cnts[i] = 0;
   }
-  for (int i = tid; i < kS1LocalHist; i += 256) lhist[i] = 0;
-  if (tid == 0) s_bad = 0;
+  for (int i = tid; i < kSegHist; i += 256) lhist[i] = 0;
+  if (tid == 0) {
+    s_bad = 0;
+    xl_n = 0;
+    s_agg_cur = 0;
+  }
   __syncthreads();
 
   const uint32_t pfx = a.pfx_mask, eqm = a.eq_mask1, m = a.m;
-  auto insert = [&](uint32_t w0, uint32_t w1) -> uint32_t {
-    const unsigned long long key = ((unsigned long long)w0 << 32) | (w1 & eqm);
-    uint32_t h = (w0 * 0x9E3779B1u + (w1 & eqm) * 0x85EBCA6Bu) >> (32 - LOGS);
+  // -> slot | kCreated if this call created the slot (exactly one caller per distinct key does)
+  auto insert = [&](uint32_t w0, uint32_t w1m, uint32_t mult) -> uint32_t {
+    const unsigned long long key = ((unsigned long long)w0 << 32) | w1m;
+    uint32_t h = (w0 * 0x9E3779B1u + w1m * 0x85EBCA6Bu) >> (32 - LOGS);
     for (int probes = 0; probes < 512; ++probes) {
       const unsigned long long old = atomicCAS(&keys[h], kSegEmpty, key);
       if (old == kSegEmpty || old == key) {
-        atomicAdd(&cnts[h], 1u);
-        return h;
+        atomicAdd(&cnts[h], mult);
+        return h | (old == kSegEmpty ? kCreated : 0u);
       }
       h = (h + 1) & (NSLOT - 1);
     }
     s_bad = 1;  // table (nearly) full
     return 0;
   };
-  auto lookup = [&](uint32_t w0, uint32_t w1) -> uint32_t {
-    const unsigned long long key = ((unsigned long long)w0 << 32) | (w1 & eqm);
-    uint32_t h = (w0 * 0x9E3779B1u + (w1 & eqm) * 0x85EBCA6Bu) >> (32 - LOGS);
+  // Equal keys sit next to each other (a segment holds a handful of distinct keys, the frequent ones dozens of times),
+  // and the LDS serialises the lanes of one atomic that hit the same address.  So the lanes of a wavefront first find
+  // their equals with a match-any over 8 hash bits (ballots), confirm against the group's first lane, and only that
+  // lane inserts, adding the whole group's size; hash-equal lanes with a different key insert on their own.
+  // Must be called by all lanes of the wavefront (ins = this lane has a record to insert).
+  auto insert_wave = [&](bool ins, uint32_t w0, uint32_t w1m) -> uint32_t {
+    const uint32_t h8 = (w0 * 0x9E3779B1u + w1m * 0x85EBCA6Bu) >> 24;
+    uint64_t peers = __ballot(ins);
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      const bool bit = (h8 >> b) & 1u;
+      const uint64_t mb = __ballot(bit);
+      peers &= bit ? mb : ~mb;
+    }
+    const int leader = ins ? __builtin_ctzll(peers) : lane;
+    const bool eq = ins && __shfl(w0, leader, kWave) == w0 && __shfl(w1m, leader, kWave) == w1m;
+    const uint64_t grp = __ballot(eq) & peers;
+    uint32_t slot = 0;
+    if (ins && lane == leader) slot = insert(w0, w1m, (uint32_t)__builtin_popcountll(grp));
+    else if (ins && !eq) slot = insert(w0, w1m, 1u);
+    const uint32_t lslot = __shfl(slot, leader, kWave) & ~kCreated;
+    return eq && lane != leader ? lslot : slot;
+  };
+  auto lookup = [&](uint32_t w0, uint32_t w1m) -> uint32_t {
+    const unsigned long long key = ((unsigned long long)w0 << 32) | w1m;
+    uint32_t h = (w0 * 0x9E3779B1u + w1m * 0x85EBCA6Bu) >> (32 - LOGS);
     for (int probes = 0; probes < 512 && keys[h] != key; ++probes) h = (h + 1) & (NSLOT - 1);
     return h;
   };
@@ -460,6 +499,42 @@ __global__ __launch_bounds__(256) void k_s1_seg(const uint32_t *__restrict__ ite
     if (a.mark_mode == 1 ? (both && !solid) : solid) {
       const uint64_t abs = w2 + (uint64_t)((w1 >> 6) & 0xFFu) * a.pos_stride;
       a.solid_bytes[abs - 1] = 1;  // is_solid.set(pos - 1), :464 (or its complement)
+    }
+  };
+  // the (k+1)-mer head.S.tail of a key, chars MSB-first in 64 bits
+  auto edge_of = [&](unsigned long long key) -> uint64_t {
+    const unsigned ht = (uint32_t)key & 63u;
+    const uint64_t smer = key & (~0ull << (64 - 2 * (a.k - 1)));
+    return ((uint64_t)(ht >> 3) << 62) | (smer >> 2) | ((uint64_t)(ht & 7) << (62 - 2 * a.k));
+  };
+  unsigned long long st_solid = 0, st_both = 0;
+  // per distinct key (called once, by the slot's creator): histogram, statistics; -> aggregated items it will emit
+  auto key_work = [&](unsigned long long key, uint32_t cnt) -> uint32_t {
+    if (((uint32_t)key & 0x24u) != 0) return 0;
+    const bool solid = cnt >= m;
+    if (a.mark_mode == 2) {
+      st_both += cnt;
+      if (solid) st_solid += cnt;
+      return 0;
+    }
+    const uint32_t hb = cnt > MHX_MAX_MUL ? (uint32_t)MHX_MAX_MUL : cnt;  // :430-436
+    if (hb < kSegHist) atomicAdd(&lhist[hb], 1u);
+    else atomicAdd(&a.hist[hb], 1ull);
+    if (!AGG || !solid) return 0;
+    const uint64_t x = edge_of(key);
+    return x == rc64(x, a.k + 1) ? 1u : 2u;
+  };
+  auto key_emit = [&](unsigned long long key, uint32_t cnt, uint32_t &at) {
+    if (((uint32_t)key & 0x24u) != 0 || cnt < m) return;
+    const int k = a.k;
+    const uint64_t mask_k = ~0ull << (64 - 2 * k);
+    const uint64_t x = edge_of(key), xr = rc64(x, k + 1);
+    const uint64_t mul = cnt > MHX_MAX_MUL ? (uint64_t)MHX_MAX_MUL : cnt;
+    const uint64_t f = ((x << 2) & mask_k) | (1ull << 19) | ((x >> 62) << 16) | mul;  // k-mer x[1..k], W = x[0]
+    agg_out[at++] = make_uint2((uint32_t)(f >> 32), (uint32_t)f);
+    if (x != xr) {  // palindromic (k+1)-mers emit the forward item only (read_to_sdbg_s2.cpp:385-423)
+      const uint64_t b = ((xr << 2) & mask_k) | (1ull << 19) | ((xr >> 62) << 16) | mul;
+      agg_out[at++] = make_uint2((uint32_t)(b >> 32), (uint32_t)b);
     }
   };
 
@@ -486,7 +561,6 @@ __global__ __launch_bounds__(256) void k_s1_seg(const uint32_t *__restrict__ ite
   };
   if (blockIdx.x < n_work) prefetch(blockIdx.x);
 
-  unsigned long long st_solid = 0, st_both = 0;
   for (uint64_t tile_idx = blockIdx.x; tile_idx < n_work; tile_idx += gridDim.x) {
     const uint64_t base = tile_idx * tile_stride * T;
     const uint64_t tile_end = n - base < (uint64_t)T ? n : base + T;
@@ -501,10 +575,10 @@ __global__ __launch_bounds__(256) void k_s1_seg(const uint32_t *__restrict__ ite
     const uint32_t p_prev = n_prev & pfx, p_last = n_last & pfx;
     // the last segment starts in this tile (else the whole tile continues a segment of an earlier tile)
     const bool la_own = tile_end < n && !(has_prev && p_last == p_prev);
-    bool more = la_own && tile_end + 256 < n && (n_lalast & pfx) == p_last;  // it even outgrows the first look-ahead chunk
+    const bool more = la_own && tile_end + 256 < n && (n_lalast & pfx) == p_last;  // it even outgrows the first look-ahead chunk
     if (tile_idx + gridDim.x < n_work) prefetch(tile_idx + gridDim.x);
 
-    uint32_t slot[NR];
+    uint32_t slot[NR];  // | kCreated: this lane created the slot and does the per-key work
     bool own[NR];
 #pragma unroll
     for (int j = 0; j < NR; ++j) {
@@ -514,7 +588,8 @@ __global__ __launch_bounds__(256) void k_s1_seg(const uint32_t *__restrict__ ite
       // records of the tile that are not ours are inserted as well (their prefix occurs nowhere else, so they change
       // no count of ours): no divergence on the common path
       const bool ins = j < PER ? gi < tile_end : own[j];
-      slot[j] = ins ? insert(w0[j], w1[j]) : 0u;
+      slot[j] = insert_wave(ins, w0[j], w1[j] & eqm);
+      if (!ins) slot[j] = 0;
     }
     if (more) {  // rare: further look-ahead chunks straight from HBM
       for (int c = 1;; ++c) {
@@ -527,98 +602,87 @@ __global__ __launch_bounds__(256) void k_s1_seg(const uint32_t *__restrict__ ite
         if (gi < n) {
           const uint32_t *p = items + gi * 3;
           const uint32_t x0 = p[0], x1 = p[1];
-          if ((x0 & pfx) == p_last) insert(x0, x1);
+          if ((x0 & pfx) == p_last) {
+            const uint32_t sl = insert(x0, x1 & eqm, 1u);
+            if (sl & kCreated) {
+              const uint32_t at = atomicAdd(&xl_n, 1u);
+              if (at < (uint32_t)kSegExtra) xl_slot[at] = sl & ~kCreated;
+              else s_bad = 1;
+            }
+          }
         }
         if (!(cb + 256 < n && (items[(cb + 255) * 3] & pfx) == p_last)) break;
       }
     }
     __syncthreads();
     const bool bad = s_bad != 0;  // workgroup-uniform
+    const uint32_t n_extra = more ? (xl_n < (uint32_t)kSegExtra ? xl_n : (uint32_t)kSegExtra) : 0u;
     uint32_t my_agg = 0;
     if (!bad) {
-      if (a.mark_mode != 2) {
 #pragma unroll
-        for (int j = 0; j < NR; ++j)
-          if (own[j]) mark(w1[j], w2[j], cnts[slot[j]]);
-        if (more) {
+      for (int j = 0; j < NR; ++j) {
+        if (!own[j]) continue;
+        const uint32_t cnt = cnts[slot[j] & ~kCreated];
+        if (a.mark_mode != 2) mark(w1[j], w2[j], cnt);
+        if (slot[j] & kCreated) my_agg += key_work(((unsigned long long)w0[j] << 32) | (w1[j] & eqm), cnt);
+      }
+      if (more) {
+        if (a.mark_mode != 2) {
           for (int c = 1; c <= a.la_chunks; ++c) {
             const uint64_t cb = tile_end + (uint64_t)c * 256;
             const uint64_t gi = cb + tid;
             if (gi < n) {
               const uint32_t *p = items + gi * 3;
               const uint32_t x0 = p[0], x1 = p[1], x2 = p[2];
-              if ((x0 & pfx) == p_last) mark(x1, x2, cnts[lookup(x0, x1)]);
+              if ((x0 & pfx) == p_last) mark(x1, x2, cnts[lookup(x0, x1 & eqm)]);
             }
             if (!(cb + 256 < n && (items[(cb + 255) * 3] & pfx) == p_last)) break;
           }
         }
-      }
-      // per distinct key (= occupied slot that is ours)
-      for (int s = tid; s < NSLOT; s += 256) {
-        const unsigned long long key = keys[s];
-        if (key == kSegEmpty) continue;
-        if (has_prev && ((uint32_t)(key >> 32) & pfx) == p_prev) continue;
-        const uint32_t cnt = cnts[s];
-        const bool both = ((uint32_t)key & 0x24u) == 0;
-        if (!both) continue;
-        const bool solid = cnt >= m;
-        if (a.mark_mode == 2) {
-          st_both += cnt;
-          if (solid) st_solid += cnt;
-          continue;
-        }
-        const uint32_t hb = cnt > MHX_MAX_MUL ? (uint32_t)MHX_MAX_MUL : cnt;  // :430-436
-        if (hb < kS1LocalHist) atomicAdd(&lhist[hb], 1u);
-        else atomicAdd(&a.hist[hb], 1ull);
-        if constexpr (AGG) {
-          if (solid) {
-            const unsigned ht = (uint32_t)key & 63u;
-            const uint64_t smer = key & (~0ull << (64 - 2 * (a.k - 1)));
-            const uint64_t x = ((uint64_t)(ht >> 3) << 62) | (smer >> 2) | ((uint64_t)(ht & 7) << (62 - 2 * a.k));
-            my_agg += x == rc64(x, a.k + 1) ? 1u : 2u;
-          }
-        }
+        for (uint32_t i = tid; i < n_extra; i += 256) my_agg += key_work(keys[xl_slot[i]], cnts[xl_slot[i]]);
       }
     }
-    uint64_t agg_at = 0;
+    uint32_t agg_at = 0;
+    bool agg_ok = true;  // wavefront-uniform
     if constexpr (AGG) {
-      // output order is irrelevant (stage 2 sorts): one cursor bump per wavefront
+      // output order is irrelevant (stage 2 sorts): one bump of the workgroup's LDS cursor per wavefront
       const uint32_t incl = wave_inclusive_sum(my_agg);
       const uint32_t tot = __shfl(incl, kWave - 1, kWave);
-      unsigned long long wbase = 0;
-      if (lane == 0 && tot) wbase = atomicAdd(a.agg_cursor, (unsigned long long)tot);
+      uint32_t wbase = 0;
+      if (lane == 0 && tot) wbase = atomicAdd(&s_agg_cur, tot);
       wbase = __shfl(wbase, 0, kWave);
+      agg_ok = wbase + tot <= a.agg_cap;  // a region overflow (absurdly skewed input) sends the host to the classic path
+      if (!agg_ok && lane == 0) atomicOr(a.err, 1u);
       agg_at = wbase + incl - my_agg;
     }
-    __syncthreads();  // every count has been read: slots may be recycled
-    for (int s = tid; s < NSLOT; s += 256) {
-      const unsigned long long key = keys[s];
-      if (key == kSegEmpty) continue;
-      if constexpr (AGG) {
-        const uint32_t cnt = cnts[s];
-        const bool mine = !(has_prev && ((uint32_t)(key >> 32) & pfx) == p_prev);
-        if (!bad && a.mark_mode != 2 && mine && ((uint32_t)key & 0x24u) == 0 && cnt >= m) {
-          const unsigned ht = (uint32_t)key & 63u;
-          const int k = a.k;
-          const uint64_t mask_k = ~0ull << (64 - 2 * k);
-          const uint64_t smer = key & (~0ull << (64 - 2 * (k - 1)));
-          const uint64_t x = ((uint64_t)(ht >> 3) << 62) | (smer >> 2) | ((uint64_t)(ht & 7) << (62 - 2 * k));
-          const uint64_t xr = rc64(x, k + 1);
-          const uint64_t mul = cnt > MHX_MAX_MUL ? (uint64_t)MHX_MAX_MUL : cnt;
-          const uint64_t f = ((x << 2) & mask_k) | (1ull << 19) | ((x >> 62) << 16) | mul;  // k-mer x[1..k], W = x[0]
-          a.agg_items[agg_at++] = make_uint2((uint32_t)(f >> 32), (uint32_t)f);
-          if (x != xr) {  // palindromic (k+1)-mers emit the forward item only (read_to_sdbg_s2.cpp:385-423)
-            const uint64_t b = ((xr << 2) & mask_k) | (1ull << 19) | ((xr >> 62) << 16) | mul;
-            a.agg_items[agg_at++] = make_uint2((uint32_t)(b >> 32), (uint32_t)b);
-          }
-        }
-      }
-      keys[s] = kSegEmpty;
-      cnts[s] = 0;
-    }
-    if (bad && tid == 0) {
-      atomicOr(a.err, 1u);
+    __syncthreads();  // every count has been read: the creators emit and recycle their slots
+    if (tid == 0) {     // (everyone has read these; the barrier below orders the reset before the next tile's inserts)
       s_bad = 0;
+      xl_n = 0;
+    }
+    if (!bad) {
+#pragma unroll
+      for (int j = 0; j < NR; ++j) {
+        if (!(slot[j] & kCreated)) continue;
+        const uint32_t sl = slot[j] & ~kCreated;
+        if constexpr (AGG)
+          if (own[j] && agg_ok && a.mark_mode != 2) key_emit(((unsigned long long)w0[j] << 32) | (w1[j] & eqm), cnts[sl], agg_at);
+        keys[sl] = kSegEmpty;
+        cnts[sl] = 0;
+      }
+      for (uint32_t i = tid; i < n_extra; i += 256) {
+        const uint32_t sl = xl_slot[i];
+        if constexpr (AGG)
+          if (agg_ok && a.mark_mode != 2) key_emit(keys[sl], cnts[sl], agg_at);
+        keys[sl] = kSegEmpty;
+        cnts[sl] = 0;
+      }
+    } else {  // the tile gave up: wipe the table, tell the host
+      for (int i = tid; i < NSLOT; i += 256) {
+        keys[i] = kSegEmpty;
+        cnts[i] = 0;
+      }
+      if (tid == 0) atomicOr(a.err, 1u);
     }
     __syncthreads();
   }
@@ -630,9 +694,25 @@ __global__ __launch_bounds__(256) void k_s1_seg(const uint32_t *__restrict__ ite
       atomicAdd(a.ctr + 2, st_both);
     }
   } else {
-    for (int i = tid; i < kS1LocalHist; i += 256)
+    __syncthreads();
+    for (int i = tid; i < kSegHist; i += 256)
       if (lhist[i]) atomicAdd(&a.hist[i], (unsigned long long)lhist[i]);
+    if (AGG && tid == 0) a.agg_counts[blockIdx.x] = s_agg_cur < a.agg_cap ? s_agg_cur : a.agg_cap;
   }
+}
+
+// regions of k_s1_seg -> one dense array: block (r, j) copies slice j of region r behind the items of the regions before it
+__global__ __launch_bounds__(256) void k_agg_compact(const uint2 *__restrict__ raw, uint32_t cap, const uint32_t *__restrict__ counts,
+                                                    uint2 *__restrict__ dense) {
+  __shared__ uint64_t sm[256 / kWave + 1];
+  const uint32_t r = blockIdx.x;
+  uint64_t part = 0;
+  for (uint32_t i = threadIdx.x; i < r; i += 256) part += counts[i];
+  uint64_t off;
+  block_exclusive_sum<uint64_t, 256>(part, sm, &off);
+  const uint32_t n = counts[r];
+  const uint2 *src = raw + (size_t)r * cap;
+  for (uint32_t i = blockIdx.y * 256 + threadIdx.x; i < n; i += gridDim.y * 256) dense[off + i] = src[i];
 }
 
 // byte map -> AtomicBitVector layout (bit i = word i/64, bit i%64; kmbitvector.h:67-88) + popcount
@@ -985,12 +1065,15 @@ int s1_process(mhx_ctx *c, uint32_t k, uint32_t m, int want_mercy, uint32_t *buf
   c->agg_valid = false;
   uint2 *agg_items = nullptr;
   uint64_t *agg_cursor = c->ws("s2_agg_cursor", 64).as<uint64_t>();
-  if (agg) {
-    const uint64_t prev = agg_continues ? c->agg_n : 0;  // items of the earlier passes stay in front
-    agg_items = grow_preserving(c, c->work["s2_agg_items"], (prev + (n_items / m + 16) * 2) * 8, prev * 8).as<uint2>();
+  const uint64_t agg_prev = agg_continues ? c->agg_n : 0;  // items of the earlier passes stay in front
+  const uint64_t agg_bound = (n_items / m + 16) * 2;
+  auto agg_prepare_classic = [&]() {  // k_tile_groups appends to the dense array through a global cursor
+    if (!agg) return;
+    agg_items = grow_preserving(c, c->work["s2_agg_items"], (agg_prev + agg_bound) * 8, agg_prev * 8).as<uint2>();
     MHX_HIP(hipMemsetAsync(agg_cursor, 0, 24, st));
-    if (prev) MHX_HIP(hipMemcpyAsync(agg_cursor, &c->agg_n, 8, hipMemcpyHostToDevice, st));
-  }
+    if (agg_prev) MHX_HIP(hipMemcpyAsync(agg_cursor, &agg_prev, 8, hipMemcpyHostToDevice, st));
+  };
+  uint32_t seg_grid = 0, seg_cap = 0;
   // segment group-by (k_s1_seg) on the partially sorted records
   uint32_t *seg_err = c->ws("s1_seg_err", 64).as<uint32_t>();
   auto seg_launch = [&](int mode) {
@@ -1004,10 +1087,17 @@ int s1_process(mhx_ctx *c, uint32_t k, uint32_t m, int want_mercy, uint32_t *buf
     const uint32_t pfx_mask = plan.seg_bits >= 32 ? 0xFFFFFFFFu : ~(0xFFFFFFFFu >> plan.seg_bits);
     const uint32_t eq_mask1 = (kmer_bits > 32 ? ~(0xFFFFFFFFu >> (kmer_bits - 32)) : 0u) | 63u;
     const bool agg_on = agg && mode != 2;
-    S1SegArgs a{(int)k, m, pfx_mask, eq_mask1, solid_bytes, mode, hist, ctr, agg_items,
-                reinterpret_cast<unsigned long long *>(agg_cursor), pos_stride, seg_err, la};
-    MHX_HIP(hipMemsetAsync(seg_err, 0, 4, st));
     const unsigned grid = (unsigned)std::min<uint64_t>(n_work, per == 4 ? 256 * 6 : 256 * 3);
+    uint2 *raw = nullptr;
+    uint32_t *counts = nullptr;
+    if (agg_on) {
+      seg_grid = grid;
+      seg_cap = (uint32_t)std::min<uint64_t>(agg_bound / grid + 4096, 0xFFFFFFF0u);
+      raw = c->ws("s2_agg_raw", (size_t)grid * seg_cap * 8).as<uint2>();
+      counts = c->ws("s2_agg_counts", (size_t)grid * 4).as<uint32_t>();
+    }
+    S1SegArgs a{(int)k, m, pfx_mask, eq_mask1, solid_bytes, mode, hist, ctr, raw, seg_cap, counts, pos_stride, seg_err, la};
+    MHX_HIP(hipMemsetAsync(seg_err, 0, 4, st));
     const char *nm = mode == 2 ? "s1_sample" : "s1_groups";
     const double bytes = (double)n_work * T * 12;
 #define MHX_SEG(PERV, AGGV) \
@@ -1059,16 +1149,25 @@ int s1_process(mhx_ctx *c, uint32_t k, uint32_t m, int want_mercy, uint32_t *buf
       MHX_HIP(hipMemcpyAsync(hist_save, hist, (MHX_MAX_MUL + 1) * 8, hipMemcpyDeviceToDevice, st));
       seg_launch(mark_mode);
       uint32_t e = 0;
+      std::vector<uint32_t> h_counts(agg ? seg_grid : 0);
       MHX_HIP(hipMemcpyAsync(&e, seg_err, 4, hipMemcpyDeviceToHost, st));
+      if (agg) MHX_HIP(hipMemcpyAsync(h_counts.data(), c->work["s2_agg_counts"].p, (size_t)seg_grid * 4, hipMemcpyDeviceToHost, st));
       MHX_HIP(hipStreamSynchronize(st));
+      if (!e && agg) {  // pack the workgroups' regions behind the items of the earlier passes
+        uint64_t total = 0;
+        for (uint32_t v : h_counts) total += v;
+        uint2 *dense = grow_preserving(c, c->work["s2_agg_items"], (agg_prev + total) * 8 + 64, agg_prev * 8).as<uint2>();
+        if (total)
+          MHX_LAUNCH(c, "agg_compact", (double)total * 16,
+                     hipLaunchKernelGGL(k_agg_compact, dim3(seg_grid, 8), dim3(256), 0, st, c->work["s2_agg_raw"].as<uint2>(), seg_cap,
+                                        c->work["s2_agg_counts"].as<uint32_t>(), dense + agg_prev));
+        const uint64_t agg_n = agg_prev + total;
+        MHX_HIP(hipMemcpyAsync(agg_cursor, &agg_n, 8, hipMemcpyHostToDevice, st));
+        MHX_HIP(hipStreamSynchronize(st));  // agg_n is a stack variable
+      }
       if (e) {  // a segment beyond the look-ahead or a full table: full sort + the classic tile kernel (marks are idempotent)
         seg_failed = true;
         MHX_HIP(hipMemcpyAsync(hist, hist_save, (MHX_MAX_MUL + 1) * 8, hipMemcpyDeviceToDevice, st));
-        if (agg) {
-          const uint64_t prev = agg_continues ? c->agg_n : 0;
-          MHX_HIP(hipMemsetAsync(agg_cursor, 0, 24, st));
-          if (prev) MHX_HIP(hipMemcpyAsync(agg_cursor, &c->agg_n, 8, hipMemcpyHostToDevice, st));
-        }
         MHX_HIP(hipMemsetAsync(ctr, 0, 64, st));
         uint32_t *other = sorted == buf_a ? buf_b : buf_a;
         sorted = radix_sort(c, sorted, other, n_items, S, KWv, s1_sort_passes(k));
@@ -1076,6 +1175,7 @@ int s1_process(mhx_ctx *c, uint32_t k, uint32_t m, int want_mercy, uint32_t *buf
         mercy = reinterpret_cast<long long *>(spare);
       }
     }
+    if (!(plan.seg_bits && !seg_failed)) agg_prepare_classic();
     if (plan.seg_bits && !seg_failed) {
     } else if (agg && S == 3) s1_groups_launch<3, true, true>(MHX_ARGS(0));
     else if (agg && S == 4 && !compact) s1_groups_launch<4, false, true>(MHX_ARGS(want_mercy));
@@ -1086,6 +1186,7 @@ int s1_process(mhx_ctx *c, uint32_t k, uint32_t m, int want_mercy, uint32_t *buf
     s1_mark_mode_used = mark_mode;
 
   }
+  if (!n_items) agg_prepare_classic();  // no launch at all: the cursor still has to hold the earlier passes' count
   if (agg && (S == 3 || (S == 4 && !compact))) {  // also with zero local items: every rank takes the same stage-2 path
     c->agg_n = 0;
     MHX_HIP(hipMemcpyAsync(&c->agg_n, agg_cursor, 8, hipMemcpyDeviceToHost, st));
