@@ -416,9 +416,7 @@ struct S1SegArgs {
 
 constexpr unsigned long long kSegEmpty = ~0ull;  // never a key: head/tail bits 63 do not occur (max (4<<3)|4)
 
-constexpr int kSegExtra = 256;  // distinct keys a tile may meet beyond its first look-ahead chunk
-constexpr int kSegHist = 512;    // multiplicities counted in LDS
-//  // distinct keys a tile may meet beyond its first look-ahead chunk
+constexpr int kSegHist = 512;  // multiplicities counted in LDS
 
 template <int PER, bool AGG>
 __global__ __launch_bounds__(256) void k_s1_seg(const uint32_t *__restrict__ items, uint64_t n, S1SegArgs a, uint64_t n_work,
@@ -430,62 +428,39 @@ __global__ __launch_bounds__(256) void k_s1_seg(const uint32_t *__restrict__ ite
   constexpr int NR = PER + 1;  // tile records + the first look-ahead chunk, per thread
   constexpr uint32_t kCreated = 0x80000000u;
   __shared__ unsigned long long keys[NSLOT];
-  __shared__ uint32_t cnts[NSLOT];
+  __shared__ uint32_t cnts[NSLOT / 2];   // two 16-bit counters per word (a tile inserts < 65536 records)
+  __shared__ uint16_t created[NSLOT];    // slots created by this tile = its distinct keys, in any order
   __shared__ uint32_t lhist[kSegHist];
-  __shared__ uint32_t xl_slot[kSegExtra];  // slots created by the rare further look-ahead chunks
-  __shared__ uint32_t s_bad, xl_n, s_agg_cur;
+  __shared__ uint32_t s_bad, s_ncreated, s_agg_cur;
   const int tid = threadIdx.x, lane = tid & (kWave - 1);
+  const uint64_t lanemask_lt = (1ull << lane) - 1;
   uint2 *const agg_out = AGG ? a.agg_raw + (size_t)blockIdx.x * a.agg_cap : nullptr;
-  for (int i = tid; i < NSLOT; i += 256) {
-    keys[i] = kSegEmpty;
-    cnts[i] = 0;
-  }
+  for (int i = tid; i < NSLOT; i += 256) keys[i] = kSegEmpty;
+  for (int i = tid; i < NSLOT / 2; i += 256) cnts[i] = 0;
   for (int i = tid; i < kSegHist; i += 256) lhist[i] = 0;
   if (tid == 0) {
     s_bad = 0;
-    xl_n = 0;
+    s_ncreated = 0;
     s_agg_cur = 0;
   }
   __syncthreads();
 
   const uint32_t pfx = a.pfx_mask, eqm = a.eq_mask1, m = a.m;
-  // -> slot | kCreated if this call created the slot (exactly one caller per distinct key does)
-  auto insert = [&](uint32_t w0, uint32_t w1m, uint32_t mult) -> uint32_t {
+  auto count_of = [&](uint32_t slot) -> uint32_t { return (cnts[slot >> 1] >> ((slot & 1u) * 16)) & 0xFFFFu; };
+  auto count_add = [&](uint32_t slot, uint32_t mult) { atomicAdd(&cnts[slot >> 1], mult << ((slot & 1u) * 16)); };
+  // probing insert -> slot | kCreated if this call created the slot (exactly one caller per distinct key does)
+  auto insert = [&](uint32_t w0, uint32_t w1m, uint32_t mult, uint32_t h) -> uint32_t {
     const unsigned long long key = ((unsigned long long)w0 << 32) | w1m;
-    uint32_t h = (w0 * 0x9E3779B1u + w1m * 0x85EBCA6Bu) >> (32 - LOGS);
     for (int probes = 0; probes < 512; ++probes) {
       const unsigned long long old = atomicCAS(&keys[h], kSegEmpty, key);
       if (old == kSegEmpty || old == key) {
-        atomicAdd(&cnts[h], mult);
+        count_add(h, mult);
         return h | (old == kSegEmpty ? kCreated : 0u);
       }
       h = (h + 1) & (NSLOT - 1);
     }
     s_bad = 1;  // table (nearly) full
     return 0;
-  };
-  // Equal keys sit next to each other (a segment holds a handful of distinct keys, the frequent ones dozens of times),
-  // and the LDS serialises the lanes of one atomic that hit the same address.  So the lanes of a wavefront first find
-  // their equals with a match-any over 8 hash bits (ballots), confirm against the group's first lane, and only that
-  // lane inserts, adding the whole group's size; hash-equal lanes with a different key insert on their own.
-  // Must be called by all lanes of the wavefront (ins = this lane has a record to insert).
-  auto insert_wave = [&](bool ins, uint32_t w0, uint32_t w1m) -> uint32_t {
-    const uint32_t h8 = (w0 * 0x9E3779B1u + w1m * 0x85EBCA6Bu) >> 24;
-    uint64_t peers = __ballot(ins);
-#pragma unroll
-    for (int b = 0; b < 8; ++b) {
-      const bool bit = (h8 >> b) & 1u;
-      const uint64_t mb = __ballot(bit);
-      peers &= bit ? mb : ~mb;
-    }
-    const int leader = ins ? __builtin_ctzll(peers) : lane;
-    const bool eq = ins && __shfl(w0, leader, kWave) == w0 && __shfl(w1m, leader, kWave) == w1m;
-    const uint64_t grp = __ballot(eq) & peers;
-    uint32_t slot = 0;
-    if (ins && lane == leader) slot = insert(w0, w1m, (uint32_t)__builtin_popcountll(grp));
-    else if (ins && !eq) slot = insert(w0, w1m, 1u);
-    const uint32_t lslot = __shfl(slot, leader, kWave) & ~kCreated;
-    return eq && lane != leader ? lslot : slot;
   };
   auto lookup = [&](uint32_t w0, uint32_t w1m) -> uint32_t {
     const unsigned long long key = ((unsigned long long)w0 << 32) | w1m;
@@ -508,35 +483,6 @@ __global__ __launch_bounds__(256) void k_s1_seg(const uint32_t *__restrict__ ite
     return ((uint64_t)(ht >> 3) << 62) | (smer >> 2) | ((uint64_t)(ht & 7) << (62 - 2 * a.k));
   };
   unsigned long long st_solid = 0, st_both = 0;
-  // per distinct key (called once, by the slot's creator): histogram, statistics; -> aggregated items it will emit
-  auto key_work = [&](unsigned long long key, uint32_t cnt) -> uint32_t {
-    if (((uint32_t)key & 0x24u) != 0) return 0;
-    const bool solid = cnt >= m;
-    if (a.mark_mode == 2) {
-      st_both += cnt;
-      if (solid) st_solid += cnt;
-      return 0;
-    }
-    const uint32_t hb = cnt > MHX_MAX_MUL ? (uint32_t)MHX_MAX_MUL : cnt;  // :430-436
-    if (hb < kSegHist) atomicAdd(&lhist[hb], 1u);
-    else atomicAdd(&a.hist[hb], 1ull);
-    if (!AGG || !solid) return 0;
-    const uint64_t x = edge_of(key);
-    return x == rc64(x, a.k + 1) ? 1u : 2u;
-  };
-  auto key_emit = [&](unsigned long long key, uint32_t cnt, uint32_t &at) {
-    if (((uint32_t)key & 0x24u) != 0 || cnt < m) return;
-    const int k = a.k;
-    const uint64_t mask_k = ~0ull << (64 - 2 * k);
-    const uint64_t x = edge_of(key), xr = rc64(x, k + 1);
-    const uint64_t mul = cnt > MHX_MAX_MUL ? (uint64_t)MHX_MAX_MUL : cnt;
-    const uint64_t f = ((x << 2) & mask_k) | (1ull << 19) | ((x >> 62) << 16) | mul;  // k-mer x[1..k], W = x[0]
-    agg_out[at++] = make_uint2((uint32_t)(f >> 32), (uint32_t)f);
-    if (x != xr) {  // palindromic (k+1)-mers emit the forward item only (read_to_sdbg_s2.cpp:385-423)
-      const uint64_t b = ((xr << 2) & mask_k) | (1ull << 19) | ((xr >> 62) << 16) | mul;
-      agg_out[at++] = make_uint2((uint32_t)(b >> 32), (uint32_t)b);
-    }
-  };
 
   // records of a tile in registers (striped: thread t holds records j*256 + t), prefetched one tile ahead together
   // with the three uniform words that decide segment ownership
@@ -578,18 +524,90 @@ __global__ __launch_bounds__(256) void k_s1_seg(const uint32_t *__restrict__ ite
     const bool more = la_own && tile_end + 256 < n && (n_lalast & pfx) == p_last;  // it even outgrows the first look-ahead chunk
     if (tile_idx + gridDim.x < n_work) prefetch(tile_idx + gridDim.x);
 
-    uint32_t slot[NR];  // | kCreated: this lane created the slot and does the per-key work
+    uint32_t slot[NR];
     bool own[NR];
+    {
+      // Equal keys sit next to each other (a segment holds a handful of distinct keys, the frequent ones dozens of
+      // times), and the LDS serialises the lanes of one atomic that hit the same address.  So the lanes of a wavefront
+      // first find their equals with a match-any over some hash bits (ballots), confirm against the group's first
+      // lane, and only that lane inserts, adding the whole group's size; hash-equal lanes with a different key insert
+      // on their own.  NB rounds at a time, phase by phase, so that the LDS round trips of a phase overlap.
+      constexpr int NB = NR % 3 == 0 ? 3 : (NR % 5 == 0 ? 5 : 1);
+      constexpr int MB = 7;  // match bits
 #pragma unroll
-    for (int j = 0; j < NR; ++j) {
-      const uint64_t gi = base + (uint64_t)j * 256 + tid;
-      if (j < PER) own[j] = gi < tile_end && !(has_prev && (w0[j] & pfx) == p_prev);
-      else own[j] = la_own && gi < n && (w0[j] & pfx) == p_last;
-      // records of the tile that are not ours are inserted as well (their prefix occurs nowhere else, so they change
-      // no count of ours): no divergence on the common path
-      const bool ins = j < PER ? gi < tile_end : own[j];
-      slot[j] = insert_wave(ins, w0[j], w1[j] & eqm);
-      if (!ins) slot[j] = 0;
+      for (int j0 = 0; j0 < NR; j0 += NB) {
+        bool ins[NB], eq[NB], doer[NB];
+        int leader[NB];
+        uint32_t hs[NB], mult[NB], km[NB];
+        uint64_t peers[NB];
+#pragma unroll
+        for (int q = 0; q < NB; ++q) {
+          const int j = j0 + q;
+          const uint64_t gi = base + (uint64_t)j * 256 + tid;
+          if (j < PER) own[j] = gi < tile_end && !(has_prev && (w0[j] & pfx) == p_prev);
+          else own[j] = la_own && gi < n && (w0[j] & pfx) == p_last;
+          // records of the tile that are not ours are inserted as well (their prefix occurs nowhere else, so they
+          // change no count of ours): no divergence on the common path
+          ins[q] = j < PER ? gi < tile_end : own[j];
+          km[q] = w1[j] & eqm;
+          const uint32_t hf = w0[j] * 0x9E3779B1u + km[q] * 0x85EBCA6Bu;
+          hs[q] = hf >> (32 - LOGS);
+          const uint32_t hm = hf >> (32 - MB);
+          uint64_t pm = __ballot(ins[q]);
+#pragma unroll
+          for (int b = 0; b < MB; ++b) {
+            const bool bit = (hm >> b) & 1u;
+            const uint64_t mb = __ballot(bit);
+            pm &= bit ? mb : ~mb;
+          }
+          peers[q] = pm;
+          leader[q] = ins[q] ? __builtin_ctzll(pm) : lane;
+        }
+        uint32_t l0[NB], l1[NB];
+#pragma unroll
+        for (int q = 0; q < NB; ++q) {
+          l0[q] = __shfl(w0[j0 + q], leader[q], kWave);
+          l1[q] = __shfl(km[q], leader[q], kWave);
+        }
+        unsigned long long old[NB];
+#pragma unroll
+        for (int q = 0; q < NB; ++q) {
+          eq[q] = ins[q] && l0[q] == w0[j0 + q] && l1[q] == km[q];
+          const uint64_t grp = __ballot(eq[q]) & peers[q];
+          doer[q] = ins[q] && (lane == leader[q] || !eq[q]);  // group leaders, and hash-equal lanes with another key
+          mult[q] = lane == leader[q] ? (uint32_t)__builtin_popcountll(grp) : 1u;
+          old[q] = 0;
+          if (doer[q]) old[q] = atomicCAS(&keys[hs[q]], kSegEmpty, ((unsigned long long)w0[j0 + q] << 32) | km[q]);
+        }
+#pragma unroll
+        for (int q = 0; q < NB; ++q) {
+          const int j = j0 + q;
+          slot[j] = 0;
+          if (doer[q]) {
+            const unsigned long long key = ((unsigned long long)w0[j] << 32) | km[q];
+            if (old[q] == kSegEmpty || old[q] == key) {
+              count_add(hs[q], mult[q]);
+              slot[j] = hs[q] | (old[q] == kSegEmpty ? kCreated : 0u);
+            } else {  // first probe taken by another key: the probing loop
+              slot[j] = insert(w0[j], km[q], mult[q], (hs[q] + 1) & (NSLOT - 1));
+            }
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < NB; ++q) {
+          const int j = j0 + q;
+          // the slots this round created go to the tile's list of distinct keys (one LDS cursor bump per wavefront)
+          const bool cr = (slot[j] & kCreated) != 0;
+          const uint64_t crm = __ballot(cr);
+          uint32_t cbase = 0;
+          if (lane == 0 && crm) cbase = atomicAdd(&s_ncreated, (uint32_t)__builtin_popcountll(crm));
+          cbase = __shfl(cbase, 0, kWave);
+          slot[j] &= ~kCreated;
+          if (cr) created[cbase + __builtin_popcountll(crm & lanemask_lt)] = (uint16_t)slot[j];
+          const uint32_t lslot = __shfl(slot[j], leader[q], kWave);
+          if (eq[q] && lane != leader[q]) slot[j] = lslot;
+        }
+      }
     }
     if (more) {  // rare: further look-ahead chunks straight from HBM
       for (int c = 1;; ++c) {
@@ -601,14 +619,10 @@ __global__ __launch_bounds__(256) void k_s1_seg(const uint32_t *__restrict__ ite
         const uint64_t gi = cb + tid;
         if (gi < n) {
           const uint32_t *p = items + gi * 3;
-          const uint32_t x0 = p[0], x1 = p[1];
+          const uint32_t x0 = p[0], x1 = p[1] & eqm;
           if ((x0 & pfx) == p_last) {
-            const uint32_t sl = insert(x0, x1 & eqm, 1u);
-            if (sl & kCreated) {
-              const uint32_t at = atomicAdd(&xl_n, 1u);
-              if (at < (uint32_t)kSegExtra) xl_slot[at] = sl & ~kCreated;
-              else s_bad = 1;
-            }
+            const uint32_t sl = insert(x0, x1, 1u, (x0 * 0x9E3779B1u + x1 * 0x85EBCA6Bu) >> (32 - LOGS));
+            if (sl & kCreated) created[atomicAdd(&s_ncreated, 1u)] = (uint16_t)(sl & ~kCreated);
           }
         }
         if (!(cb + 256 < n && (items[(cb + 255) * 3] & pfx) == p_last)) break;
@@ -616,30 +630,46 @@ __global__ __launch_bounds__(256) void k_s1_seg(const uint32_t *__restrict__ ite
     }
     __syncthreads();
     const bool bad = s_bad != 0;  // workgroup-uniform
-    const uint32_t n_extra = more ? (xl_n < (uint32_t)kSegExtra ? xl_n : (uint32_t)kSegExtra) : 0u;
+    const uint32_t n_created = s_ncreated;
     uint32_t my_agg = 0;
     if (!bad) {
+      if (a.mark_mode != 2) {
 #pragma unroll
-      for (int j = 0; j < NR; ++j) {
-        if (!own[j]) continue;
-        const uint32_t cnt = cnts[slot[j] & ~kCreated];
-        if (a.mark_mode != 2) mark(w1[j], w2[j], cnt);
-        if (slot[j] & kCreated) my_agg += key_work(((unsigned long long)w0[j] << 32) | (w1[j] & eqm), cnt);
-      }
-      if (more) {
-        if (a.mark_mode != 2) {
+        for (int j = 0; j < NR; ++j)
+          if (own[j]) mark(w1[j], w2[j], count_of(slot[j]));
+        if (more) {
           for (int c = 1; c <= a.la_chunks; ++c) {
             const uint64_t cb = tile_end + (uint64_t)c * 256;
             const uint64_t gi = cb + tid;
             if (gi < n) {
               const uint32_t *p = items + gi * 3;
               const uint32_t x0 = p[0], x1 = p[1], x2 = p[2];
-              if ((x0 & pfx) == p_last) mark(x1, x2, cnts[lookup(x0, x1 & eqm)]);
+              if ((x0 & pfx) == p_last) mark(x1, x2, count_of(lookup(x0, x1 & eqm)));
             }
             if (!(cb + 256 < n && (items[(cb + 255) * 3] & pfx) == p_last)) break;
           }
         }
-        for (uint32_t i = tid; i < n_extra; i += 256) my_agg += key_work(keys[xl_slot[i]], cnts[xl_slot[i]]);
+      }
+      // per distinct key of ours (dense over the list of created slots): histogram, statistics, aggregated-item count
+      for (uint32_t i = tid; i < n_created; i += 256) {
+        const uint32_t sl = created[i];
+        const unsigned long long key = keys[sl];
+        if (has_prev && ((uint32_t)(key >> 32) & pfx) == p_prev) continue;  // a key of the previous tile's last segment
+        if (((uint32_t)key & 0x24u) != 0) continue;                         // head or tail is '$'
+        const uint32_t cnt = count_of(sl);
+        const bool solid = cnt >= m;
+        if (a.mark_mode == 2) {
+          st_both += cnt;
+          if (solid) st_solid += cnt;
+          continue;
+        }
+        const uint32_t hb = cnt > MHX_MAX_MUL ? (uint32_t)MHX_MAX_MUL : cnt;  // :430-436
+        if (hb < kSegHist) atomicAdd(&lhist[hb], 1u);
+        else atomicAdd(&a.hist[hb], 1ull);
+        if (AGG && solid) {
+          const uint64_t x = edge_of(key);
+          my_agg += x == rc64(x, a.k + 1) ? 1u : 2u;
+        }
       }
     }
     uint32_t agg_at = 0;
@@ -655,33 +685,37 @@ __global__ __launch_bounds__(256) void k_s1_seg(const uint32_t *__restrict__ ite
       if (!agg_ok && lane == 0) atomicOr(a.err, 1u);
       agg_at = wbase + incl - my_agg;
     }
-    __syncthreads();  // every count has been read: the creators emit and recycle their slots
+    __syncthreads();  // every count has been read: emit, then recycle the slots
     if (tid == 0) {     // (everyone has read these; the barrier below orders the reset before the next tile's inserts)
       s_bad = 0;
-      xl_n = 0;
+      s_ncreated = 0;
     }
     if (!bad) {
-#pragma unroll
-      for (int j = 0; j < NR; ++j) {
-        if (!(slot[j] & kCreated)) continue;
-        const uint32_t sl = slot[j] & ~kCreated;
-        if constexpr (AGG)
-          if (own[j] && agg_ok && a.mark_mode != 2) key_emit(((unsigned long long)w0[j] << 32) | (w1[j] & eqm), cnts[sl], agg_at);
+      for (uint32_t i = tid; i < n_created; i += 256) {
+        const uint32_t sl = created[i];
+        if constexpr (AGG) {
+          const unsigned long long key = keys[sl];
+          const uint32_t cnt = count_of(sl);
+          const bool mine = !(has_prev && ((uint32_t)(key >> 32) & pfx) == p_prev);
+          if (agg_ok && a.mark_mode != 2 && mine && ((uint32_t)key & 0x24u) == 0 && cnt >= m) {
+            const int k = a.k;
+            const uint64_t mask_k = ~0ull << (64 - 2 * k);
+            const uint64_t x = edge_of(key), xr = rc64(x, k + 1);
+            const uint64_t mul = cnt > MHX_MAX_MUL ? (uint64_t)MHX_MAX_MUL : cnt;
+            const uint64_t f = ((x << 2) & mask_k) | (1ull << 19) | ((x >> 62) << 16) | mul;  // k-mer x[1..k], W = x[0]
+            agg_out[agg_at++] = make_uint2((uint32_t)(f >> 32), (uint32_t)f);
+            if (x != xr) {  // palindromic (k+1)-mers emit the forward item only (read_to_sdbg_s2.cpp:385-423)
+              const uint64_t b = ((xr << 2) & mask_k) | (1ull << 19) | ((xr >> 62) << 16) | mul;
+              agg_out[agg_at++] = make_uint2((uint32_t)(b >> 32), (uint32_t)b);
+            }
+          }
+        }
         keys[sl] = kSegEmpty;
-        cnts[sl] = 0;
-      }
-      for (uint32_t i = tid; i < n_extra; i += 256) {
-        const uint32_t sl = xl_slot[i];
-        if constexpr (AGG)
-          if (agg_ok && a.mark_mode != 2) key_emit(keys[sl], cnts[sl], agg_at);
-        keys[sl] = kSegEmpty;
-        cnts[sl] = 0;
+        atomicAnd(&cnts[sl >> 1], (sl & 1u) ? 0x0000FFFFu : 0xFFFF0000u);  // its half of the shared counter word
       }
     } else {  // the tile gave up: wipe the table, tell the host
-      for (int i = tid; i < NSLOT; i += 256) {
-        keys[i] = kSegEmpty;
-        cnts[i] = 0;
-      }
+      for (int i = tid; i < NSLOT; i += 256) keys[i] = kSegEmpty;
+      for (int i = tid; i < NSLOT / 2; i += 256) cnts[i] = 0;
       if (tid == 0) atomicOr(a.err, 1u);
     }
     __syncthreads();
@@ -1078,7 +1112,7 @@ int s1_process(mhx_ctx *c, uint32_t k, uint32_t m, int want_mercy, uint32_t *buf
   uint32_t *seg_err = c->ws("s1_seg_err", 64).as<uint32_t>();
   auto seg_launch = [&](int mode) {
     const int per = (int)c->opt("s1_seg_per", 8);
-    const int la = (int)c->opt("s1_seg_la", 3);
+    const int la = (int)std::min<long long>(std::max<long long>(c->opt("s1_seg_la", 3), 0), 200);  // 16-bit tile counters
     const int T = 256 * (per == 4 ? 4 : 8);
     const uint64_t n_tiles = div_ceil(n_items, (uint64_t)T);
     const uint32_t stride = mode == 2 ? 64u : 1u;
