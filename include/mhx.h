@@ -54,6 +54,9 @@ int mhx_synchronize(mhx_ctx *);
  *   s1_seg_bits (0)   force the prefix width of the partial stage-1 sort (0 = chosen from the item count)
  *   s1_seg_la (3)     look-ahead chunks of the segment group-by before a tile gives up (-> classic path)
  *   s1_seg_per (8)    records per thread and tile of the segment group-by (4 or 8)
+ *   dist_sparse_marks (0)  multi-GPU stage 1 emits MHX_ROUTE_S1_MARKS records instead of marking a bitmap of the
+ *                     global read set (set by mhx_dist_setup; the torch.distributed path of megahit_amd/dist.py
+ *                     still reduces the bitmap)
  * Returns <0 for a NULL handle/name. */
 int mhx_set_option(mhx_ctx *, const char *name, long long value);
 
@@ -200,7 +203,14 @@ int mhx_dist_process_seq2sdbg(mhx_ctx *, uint32_t k, uint64_t n_items, mhx_sdbg_
  * [p*stride_bases, (p+1)*stride_bases); the caller moves them with an all-to-all into mhx_dist_recv_buffer;
  * apply: count -> finishes MHX_BUF_FIRST_0_OUT / MHX_BUF_LAST_0_IN; mercy -> installs the local candidate list used by
  * mhx_read2sdbg_add_mercy (which, with a global layout set, updates the adopted is_solid slice). */
-enum mhx_route { MHX_ROUTE_COUNT_EVENTS = 1, MHX_ROUTE_MERCY_CAND = 2 };
+enum mhx_route {
+  MHX_ROUTE_COUNT_EVENTS = 1,
+  MHX_ROUTE_MERCY_CAND = 2,
+  /* stage 1 with the knob dist_sparse_marks set (mhx_dist_setup sets it): the global positions of the NON-solid
+   * (k+1)-mer occurrences of the owned buckets; apply: the read owner derives its local is_solid from them — nothing of
+   * the size of the global read set is allocated or reduced */
+  MHX_ROUTE_S1_MARKS = 3
+};
 int mhx_dist_route_records(mhx_ctx *, int which, uint64_t stride_bases, mhx_dist_items *out, uint64_t *counts);
 int mhx_dist_apply_routed(mhx_ctx *, int which, uint64_t n_records);
 /* raw device pointer of a result buffer (for collectives on it); NULL if absent */
@@ -208,6 +218,39 @@ void *mhx_device_pointer(mhx_ctx *, int which);
 /* after the bitmap reduction: install this rank's slice (device pointer, n_words uint64) as the
  * local is_solid used by stage 2 */
 int mhx_adopt_is_solid_slice(mhx_ctx *, const void *d_words, uint64_t n_words);
+
+/* ---- multi-GPU behind the C ABI: communicator + collective drivers (megahit_amd/csrc/comm.hip).  One rank per GPU;
+ * ranks are threads of one process (mhx_core --gpus N) or separate processes (bench.py --gpus N).  The drivers are
+ * COLLECTIVE: every rank calls them with the same arguments.  They replace, for N GPUs, what BaseSequenceSortingEngine::Run
+ * does for N OpenMP threads (base_engine.cpp:143-211,318-363): lv1 buckets -> owners, one item all-to-all per stage
+ * (RCCL ncclSend/ncclRecv over xGMI, <= 256 MiB per message), position-keyed records routed back to the read owners. ---- */
+typedef struct mhx_comm mhx_comm;
+#define MHX_COMM_ID_BYTES 128
+/* RCCL transport: one rank creates the id and ships its 128 bytes to the others by any means (the launcher's store,
+ * a file, a broadcast), then every rank calls mhx_comm_init_rank with the handle of ITS GPU.  n_ranks == 1 with
+ * id == NULL gives a trivial communicator without RCCL.  Returns NULL on error. */
+int mhx_comm_unique_id(void *id /* MHX_COMM_ID_BYTES */);
+mhx_comm *mhx_comm_init_rank(mhx_ctx *, const void *id, int rank, int n_ranks);
+/* in-process transport without RCCL: the n ranks are threads of this process and may share GPUs (tests); exchanges are
+ * device-to-device copies between the ranks' buffers.  out receives n handles, out[r] bound to ctxs[r]. */
+int mhx_comm_local_group(int n_ranks, mhx_ctx *const *ctxs, mhx_comm **out);
+void mhx_comm_destroy(mhx_comm *);
+int mhx_comm_rank(const mhx_comm *);
+int mhx_comm_size(const mhx_comm *);
+int mhx_comm_barrier(mhx_comm *);
+int mhx_comm_all_reduce_u64(mhx_comm *, uint64_t *values, uint64_t n, int is_max /* else sum */);
+/* agree on the bucket partition (balance_stage = 0: equal ranges; else an enum mhx_stage whose all-reduced lv1 bucket
+ * histogram balances the ranges) and on the global read layout (rank r's bases at r * stride); sets dist_sparse_marks */
+int mhx_dist_setup(mhx_ctx *, mhx_comm *, int balance_stage, uint32_t k, uint32_t min_count);
+/* read2sdbg over all ranks: afterwards every handle holds the SdBG records of ITS bucket range (MHX_BUF_SDBG_BYTES,
+ * MHX_BUF_BUCKET_*: one file of the reference's multi-file .sdbg.<i> format) and MHX_BUF_MUL_HIST of its buckets.
+ * need_mercy as want_mercy of mhx_read2sdbg_s1. */
+int mhx_dist_read2sdbg(mhx_ctx *, mhx_comm *, uint32_t k, uint32_t min_count, int need_mercy, mhx_s1_result *out1,
+                       mhx_sdbg_result *out2, uint64_t *num_mercy);
+/* count: edges / bucket counts / histogram of the owned buckets, first_0_out / last_0_in of the local reads */
+int mhx_dist_count(mhx_ctx *, mhx_comm *, uint32_t k, uint32_t min_count, mhx_count_result *out);
+/* seq2sdbg: the loaded sequences (+ multiplicities) may be spread over the ranks in any way */
+int mhx_dist_seq2sdbg(mhx_ctx *, mhx_comm *, uint32_t k, mhx_sdbg_result *out);
 
 /* ---- memory-bounded operation: the reference's lv1 passes (base_engine.cpp:54-141,213-281) ----
  * By default an engine call materialises all its items at once.  For inputs whose items exceed HBM, run the call

@@ -631,6 +631,12 @@ int mhx_dist_route_records(mhx_ctx *c, int which, uint64_t stride_bases, mhx_dis
       p = it->second.p;
       n = it->second.used / 8;
       shift = 2;
+    } else if (which == MHX_ROUTE_S1_MARKS) {
+      n = c->n_marks;
+      int hi_bit = 1;
+      while (hi_bit < 64 && (c->global_bases >> hi_bit)) ++hi_bit;
+      p = const_cast<uint64_t *>(mhx::sort_u64(c, c->ws("s1_marks", 64).p, n, hi_bit));
+      shift = 0;
     } else throw mhx::Error("dist_route_records: unknown record kind");
     uint64_t *bounds = c->ws("route_bounds", (c->n_parts + 2) * 8).as<uint64_t>();
     hipLaunchKernelGGL(k_route_bounds, dim3((c->n_parts + 1 + 63) / 64), dim3(64), 0, c->stream, (const unsigned long long *)p, n, shift,
@@ -650,6 +656,7 @@ int mhx_dist_apply_routed(mhx_ctx *c, int which, uint64_t n_records) {
     void *recv = c->ws("items_recv", n_records * 8 + 64).p;
     if (which == MHX_ROUTE_COUNT_EVENTS) mhx::count_apply_events(c, (const unsigned long long *)recv, n_records);
     else if (which == MHX_ROUTE_MERCY_CAND) mhx::mercy_adopt_routed(c, (const long long *)recv, n_records);
+    else if (which == MHX_ROUTE_S1_MARKS) mhx::s1_apply_marks(c, (const unsigned long long *)recv, n_records);
     else throw mhx::Error("dist_apply_routed: unknown record kind");
   })
 }

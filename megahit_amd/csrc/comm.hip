@@ -1,0 +1,460 @@
+// Multi-GPU SdBG construction behind the C ABI: communicator + the distributed drivers of the three sub-programs.
+//
+// One rank per GPU; ranks are threads of one process (mhx_core --gpus N) or separate processes (bench.py under
+// torch.distributed.run).  The 65536 lv1 buckets are split into contiguous owner ranges; per stage every rank extracts
+// the items of ITS reads, partitions them by owner, the items cross the node in one all-to-all, and every rank sorts
+// and reduces the buckets it owns (the reference shards buckets over OpenMP threads instead:
+// src/sorting/base_engine.cpp:213-223,318-327).  Records keyed by a read position — non-solid marks of stage 1, mercy
+// candidates, first_0_out/last_0_in events of count — travel back to the rank that holds the read with a second
+// all-to-all; nothing of the size of the global read set is ever allocated or reduced.
+//
+// Transports (function table mhx_transport):
+//   rccl   RCCL called directly (dlopen of librccl; grouped ncclSend/ncclRecv in <= 256 MiB messages per pair and round
+//          for the all-to-all, ncclAllGather / ncclAllReduce for counts and plans), on the engine's own HIP stream
+//   local  ranks = threads of this process, any devices (also several ranks on ONE GPU: the tests): exchanges are
+//          device-to-device copies out of the peers' send buffers between two barriers
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <condition_variable>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "mhx_internal.h"
+
+namespace mhx {
+
+// ---- RCCL through dlopen: libmhx has no link-time dependency on it, and a process that already maps a librccl
+// (PyTorch bundles one) keeps using that instance ----
+struct RcclApi {
+  void *h = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+
+static RcclApi &rccl() {
+  static RcclApi api;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    std::vector<std::string> cand;
+    if (const char *e = getenv("MHX_RCCL_LIB")) cand.push_back(e);
+    {  // an instance that is already mapped into this process
+      std::ifstream maps("/proc/self/maps");
+      std::string line;
+      while (std::getline(maps, line)) {
+        const size_t p = line.find('/');
+        if (p != std::string::npos && line.find("librccl.so", p) != std::string::npos) {
+          cand.push_back(line.substr(p));
+          break;
+        }
+      }
+    }
+    cand.push_back("librccl.so.1");
+    cand.push_back("/opt/rocm/lib/librccl.so.1");
+    cand.push_back("librccl.so");
+    for (const std::string &c : cand) {
+      api.h = dlopen(c.c_str(), RTLD_NOW | RTLD_LOCAL);
+      if (api.h) break;
+    }
+    if (!api.h) return;
+#define MHX_SYM(name) api.name = reinterpret_cast<decltype(api.name)>(dlsym(api.h, "nccl" #name))
+    MHX_SYM(GetUniqueId);
+    MHX_SYM(CommInitRank);
+    MHX_SYM(CommDestroy);
+    MHX_SYM(AllReduce);
+    MHX_SYM(AllGather);
+    MHX_SYM(Send);
+    MHX_SYM(Recv);
+    MHX_SYM(GroupStart);
+    MHX_SYM(GroupEnd);
+    MHX_SYM(GetErrorString);
+#undef MHX_SYM
+    if (!api.GetUniqueId || !api.CommInitRank || !api.AllReduce || !api.AllGather || !api.Send || !api.Recv || !api.GroupStart ||
+        !api.GroupEnd)
+      api.h = nullptr;
+  });
+  if (!api.h) throw Error("RCCL is not available (librccl.so could not be loaded; set MHX_RCCL_LIB)");
+  return api;
+}
+#define MHX_NCCL(expr)                                                                                  \
+  do {                                                                                                  \
+    ncclResult_t r_ = (expr);                                                                           \
+    if (r_ != ncclSuccess) {                                                                            \
+      char buf_[512];                                                                                   \
+      snprintf(buf_, sizeof buf_, "%s failed: %s (%s:%d)", #expr,                                       \
+               mhx::rccl().GetErrorString ? mhx::rccl().GetErrorString(r_) : "rccl error", __FILE__, __LINE__); \
+      throw mhx::Error(buf_);                                                                           \
+    }                                                                                                   \
+  } while (0)
+
+// in-process group: the ranks are threads
+struct LocalGroup {
+  int n = 0;
+  std::mutex mu;
+  std::condition_variable cv;
+  int arrived = 0;
+  uint64_t generation = 0;
+  int refs = 0;
+  std::vector<std::vector<uint64_t>> vals;      // per rank: a host vector being reduced / gathered
+  std::vector<const char *> send_ptr;            // per rank: device send buffer of the running all-to-all
+  std::vector<std::vector<uint64_t>> send_off;   // per rank: byte offsets of the per-peer segments (n + 1)
+  void barrier() {
+    std::unique_lock<std::mutex> lk(mu);
+    const uint64_t gen = generation;
+    if (++arrived == n) {
+      arrived = 0;
+      ++generation;
+      cv.notify_all();
+    } else {
+      cv.wait(lk, [&] { return generation != gen; });
+    }
+  }
+};
+
+}  // namespace mhx
+
+struct mhx_comm {
+  int rank = 0, n = 1;
+  mhx_ctx *ctx = nullptr;
+  // rccl transport
+  ncclComm_t nccl = nullptr;
+  // local transport
+  mhx::LocalGroup *grp = nullptr;
+  uint64_t max_msg_bytes = 1ull << 28;  // 256 MiB per message (one 16 GB message hung RCCL 2.26 on MI355X)
+  // agreed layout
+  uint64_t stride_bases = 0;
+
+  // ---- collectives on small host vectors ----
+  void all_reduce(std::vector<uint64_t> &v, bool is_max) {
+    if (n == 1) return;
+    hipStream_t st = ctx->stream;
+    if (nccl) {
+      unsigned long long *d = ctx->ws("comm_small", v.size() * 8 + 64).as<unsigned long long>();
+      MHX_HIP(hipMemcpyAsync(d, v.data(), v.size() * 8, hipMemcpyHostToDevice, st));
+      MHX_NCCL(mhx::rccl().AllReduce(d, d, v.size(), ncclUint64, is_max ? ncclMax : ncclSum, nccl, st));
+      MHX_HIP(hipMemcpyAsync(v.data(), d, v.size() * 8, hipMemcpyDeviceToHost, st));
+      MHX_HIP(hipStreamSynchronize(st));
+      return;
+    }
+    grp->vals[rank] = v;
+    grp->barrier();
+    for (size_t i = 0; i < v.size(); ++i) {
+      uint64_t acc = is_max ? 0 : 0;
+      for (int r = 0; r < n; ++r) acc = is_max ? std::max(acc, grp->vals[r][i]) : acc + grp->vals[r][i];
+      v[i] = acc;
+    }
+    grp->barrier();
+  }
+  // send[p] = what this rank has for p  ->  recv[p] = what p has for this rank
+  void all_to_all_counts(const std::vector<uint64_t> &send, std::vector<uint64_t> &recv) {
+    recv.assign(n, 0);
+    if (n == 1) {
+      recv[0] = send[0];
+      return;
+    }
+    hipStream_t st = ctx->stream;
+    if (nccl) {
+      unsigned long long *d = ctx->ws("comm_small", (size_t)(n + 1) * n * 8 + 64).as<unsigned long long>();
+      MHX_HIP(hipMemcpyAsync(d, send.data(), (size_t)n * 8, hipMemcpyHostToDevice, st));
+      MHX_NCCL(mhx::rccl().AllGather(d, d + n, (size_t)n, ncclUint64, nccl, st));  // row r = counts of rank r
+      std::vector<uint64_t> m((size_t)n * n);
+      MHX_HIP(hipMemcpyAsync(m.data(), d + n, (size_t)n * n * 8, hipMemcpyDeviceToHost, st));
+      MHX_HIP(hipStreamSynchronize(st));
+      for (int p = 0; p < n; ++p) recv[p] = m[(size_t)p * n + rank];
+      return;
+    }
+    grp->vals[rank] = send;
+    grp->barrier();
+    for (int p = 0; p < n; ++p) recv[p] = grp->vals[p][rank];
+    grp->barrier();
+  }
+  // device buffers with the per-peer segments back to back (peers ascending); counts in items
+  void all_to_all_v(const void *d_send, const std::vector<uint64_t> &send_counts, void *d_recv, const std::vector<uint64_t> &recv_counts,
+                    uint32_t item_bytes) {
+    hipStream_t st = ctx->stream;
+    std::vector<uint64_t> so(n + 1, 0), ro(n + 1, 0);
+    for (int p = 0; p < n; ++p) {
+      so[p + 1] = so[p] + send_counts[p] * item_bytes;
+      ro[p + 1] = ro[p] + recv_counts[p] * item_bytes;
+    }
+    const char *s = static_cast<const char *>(d_send);
+    char *r = static_cast<char *>(d_recv);
+    if (nccl || n == 1) {
+      // own segment: a device copy; every other segment: point-to-point messages of at most max_msg_bytes, all pairs of a
+      // round in one group (direct xGMI sends, not a ring).  Sender and receiver derive the same chunking from the counts.
+      if (so[rank + 1] > so[rank])
+        MHX_HIP(hipMemcpyAsync(r + ro[rank], s + so[rank], so[rank + 1] - so[rank], hipMemcpyDeviceToDevice, st));
+      const uint64_t chunk = std::max<uint64_t>(item_bytes, max_msg_bytes / item_bytes * item_bytes);
+      uint64_t rounds = 0;
+      for (int p = 0; p < n; ++p)
+        if (p != rank) rounds = std::max({rounds, mhx::div_ceil(so[p + 1] - so[p], chunk), mhx::div_ceil(ro[p + 1] - ro[p], chunk)});
+      for (uint64_t c = 0; c < rounds; ++c) {
+        MHX_NCCL(mhx::rccl().GroupStart());
+        for (int d = 1; d < n; ++d) {
+          const int to = (rank + d) % n, from = (rank - d + n) % n;
+          uint64_t lo = so[to] + c * chunk, hi = std::min(so[to + 1], so[to] + (c + 1) * chunk);
+          if (lo < hi) MHX_NCCL(mhx::rccl().Send(s + lo, hi - lo, ncclChar, to, nccl, st));
+          lo = ro[from] + c * chunk;
+          hi = std::min(ro[from + 1], ro[from] + (c + 1) * chunk);
+          if (lo < hi) MHX_NCCL(mhx::rccl().Recv(r + lo, hi - lo, ncclChar, from, nccl, st));
+        }
+        MHX_NCCL(mhx::rccl().GroupEnd());
+      }
+      MHX_HIP(hipStreamSynchronize(st));
+      return;
+    }
+    // local: publish the send buffer (complete: the stream is drained first), pull the segments addressed to this rank
+    MHX_HIP(hipStreamSynchronize(st));
+    grp->send_ptr[rank] = s;
+    grp->send_off[rank] = so;
+    grp->barrier();
+    for (int p = 0; p < n; ++p) {
+      const uint64_t bytes = ro[p + 1] - ro[p];
+      if (bytes) MHX_HIP(hipMemcpyAsync(r + ro[p], grp->send_ptr[p] + grp->send_off[p][rank], bytes, hipMemcpyDeviceToDevice, st));
+    }
+    MHX_HIP(hipStreamSynchronize(st));
+    grp->barrier();  // nobody reuses a send buffer before every peer has read it
+  }
+  void barrier() {
+    if (n == 1) return;
+    if (nccl) {
+      std::vector<uint64_t> one(1, 1);
+      all_reduce(one, false);
+    } else {
+      grp->barrier();
+    }
+  }
+};
+
+namespace mhx {
+
+// ---- the distributed drivers ----
+static void move_items(mhx_ctx *c, mhx_comm *cm, const mhx_dist_items &it, const std::vector<uint64_t> &counts, uint64_t *n_recv) {
+  std::vector<uint64_t> rc;
+  cm->all_to_all_counts(counts, rc);
+  uint64_t n = 0;
+  for (uint64_t v : rc) n += v;
+  void *recv = mhx_dist_recv_buffer(c, n, it.item_bytes);
+  if (!recv) throw Error(mhx_last_error());
+  cm->all_to_all_v(it.d_items, counts, recv, rc, it.item_bytes);
+  *n_recv = n;
+}
+#define MHX_CK(call)                                  \
+  do {                                                \
+    if ((call) != 0) throw mhx::Error(mhx_last_error()); \
+  } while (0)
+
+static uint64_t exchange_stage(mhx_ctx *c, mhx_comm *cm, int stage, uint32_t k, uint32_t m) {
+  mhx_dist_items it{};
+  std::vector<uint64_t> counts(cm->n, 0);
+  MHX_CK(mhx_dist_extract(c, stage, k, m, &it, counts.data()));
+  uint64_t n = 0;
+  move_items(c, cm, it, counts, &n);
+  return n;
+}
+static uint64_t route(mhx_ctx *c, mhx_comm *cm, int which) {
+  mhx_dist_items it{};
+  std::vector<uint64_t> counts(cm->n, 0);
+  MHX_CK(mhx_dist_route_records(c, which, cm->stride_bases, &it, counts.data()));
+  uint64_t n = 0;
+  move_items(c, cm, it, counts, &n);
+  MHX_CK(mhx_dist_apply_routed(c, which, n));
+  return n;
+}
+
+}  // namespace mhx
+
+extern "C" {
+
+#define MHX_TRYC(body)                 \
+  try {                                \
+    body;                              \
+    return 0;                          \
+  } catch (const std::exception &e) {  \
+    mhx::set_error("%s", e.what());    \
+    return -1;                         \
+  }
+
+int mhx_comm_unique_id(void *id) {
+  MHX_TRYC({
+    static_assert(sizeof(ncclUniqueId) <= MHX_COMM_ID_BYTES, "id size");
+    ncclUniqueId u;
+    MHX_NCCL(mhx::rccl().GetUniqueId(&u));
+    memset(id, 0, MHX_COMM_ID_BYTES);
+    memcpy(id, &u, sizeof u);
+  })
+}
+
+mhx_comm *mhx_comm_init_rank(mhx_ctx *c, const void *id, int rank, int n_ranks) {
+  try {
+    if (!c || n_ranks < 1 || n_ranks > 256 || rank < 0 || rank >= n_ranks) throw mhx::Error("comm_init_rank: bad arguments");
+    MHX_HIP(hipSetDevice(c->device));
+    mhx_comm *cm = new mhx_comm;
+    cm->rank = rank;
+    cm->n = n_ranks;
+    cm->ctx = c;
+    if (const char *e = getenv("MHX_COMM_MAX_MSG")) cm->max_msg_bytes = std::max<uint64_t>(4096, strtoull(e, nullptr, 10));
+    if (n_ranks > 1 || id) {
+      if (!id) {
+        delete cm;
+        throw mhx::Error("comm_init_rank: a unique id is needed for more than one rank");
+      }
+      ncclUniqueId u;
+      memcpy(&u, id, sizeof u);
+      MHX_NCCL(mhx::rccl().CommInitRank(&cm->nccl, n_ranks, u, rank));
+    }
+    return cm;
+  } catch (const std::exception &e) {
+    mhx::set_error("%s", e.what());
+    return nullptr;
+  }
+}
+
+int mhx_comm_local_group(int n_ranks, mhx_ctx *const *ctxs, mhx_comm **out) {
+  MHX_TRYC({
+    if (n_ranks < 1 || n_ranks > 256 || !ctxs || !out) throw mhx::Error("comm_local_group: bad arguments");
+    mhx::LocalGroup *g = new mhx::LocalGroup;
+    g->n = n_ranks;
+    g->refs = n_ranks;
+    g->vals.resize(n_ranks);
+    g->send_ptr.assign(n_ranks, nullptr);
+    g->send_off.resize(n_ranks);
+    for (int r = 0; r < n_ranks; ++r) {
+      mhx_comm *cm = new mhx_comm;
+      cm->rank = r;
+      cm->n = n_ranks;
+      cm->ctx = ctxs[r];
+      cm->grp = g;
+      out[r] = cm;
+    }
+  })
+}
+
+void mhx_comm_destroy(mhx_comm *cm) {
+  if (!cm) return;
+  if (cm->nccl && mhx::rccl().CommDestroy) mhx::rccl().CommDestroy(cm->nccl);
+  if (cm->grp) {
+    bool last;
+    {
+      std::lock_guard<std::mutex> lk(cm->grp->mu);
+      last = --cm->grp->refs == 0;
+    }
+    if (last) delete cm->grp;
+  }
+  delete cm;
+}
+int mhx_comm_rank(const mhx_comm *cm) { return cm ? cm->rank : -1; }
+int mhx_comm_size(const mhx_comm *cm) { return cm ? cm->n : -1; }
+int mhx_comm_barrier(mhx_comm *cm) { MHX_TRYC(cm->barrier()) }
+int mhx_comm_all_reduce_u64(mhx_comm *cm, uint64_t *values, uint64_t n, int is_max) {
+  MHX_TRYC({
+    std::vector<uint64_t> v(values, values + n);
+    cm->all_reduce(v, is_max != 0);
+    memcpy(values, v.data(), n * 8);
+  })
+}
+
+int mhx_dist_setup(mhx_ctx *c, mhx_comm *cm, int balance_stage, uint32_t k, uint32_t min_count) {
+  MHX_TRYC({
+    MHX_HIP(hipSetDevice(c->device));
+    const int n = cm->n;
+    std::vector<uint32_t> begin(n + 1, 0);
+    for (int r = 0; r <= n; ++r) begin[r] = (uint32_t)(((uint64_t)MHX_NUM_BUCKETS * r) / n);
+    if (balance_stage && n > 1) {
+      // contiguous bucket ranges of ~equal weight from the all-reduced lv1 bucket histogram (the reference balances its
+      // size-sorted bucket list the same way: base_engine.cpp:231-252)
+      std::vector<uint64_t> hist(MHX_NUM_BUCKETS, 0);
+      c->global_bases = 0;  // the histogram is a local scan
+      MHX_CK(mhx_bucket_histogram(c, balance_stage, k, min_count, hist.data()));
+      cm->all_reduce(hist, false);
+      long double total = 0;
+      for (uint64_t v : hist) total += v;
+      long double acc = 0;
+      int r = 1;
+      for (uint32_t b = 0; b < MHX_NUM_BUCKETS && r < n; ++b) {
+        while (r < n && acc >= total * r / n) begin[r++] = b;
+        acc += hist[b];
+      }
+      while (r < n) begin[r++] = MHX_NUM_BUCKETS;
+      begin[n] = MHX_NUM_BUCKETS;
+      for (int i = 1; i <= n; ++i) begin[i] = std::max(begin[i], begin[i - 1]);
+    }
+    MHX_CK(mhx_set_partition(c, cm->rank, n, begin.data()));
+    // global read layout: rank r's bases start at r * stride, stride = the largest local read set rounded up to 64
+    std::vector<uint64_t> nb(1, c->seqs.n_bases);
+    cm->all_reduce(nb, true);
+    cm->stride_bases = (nb[0] + 63) / 64 * 64;
+    if (!cm->stride_bases) cm->stride_bases = 64;
+    MHX_CK(mhx_set_global_layout(c, (uint64_t)cm->rank * cm->stride_bases, (uint64_t)n * cm->stride_bases));
+    c->options["dist_sparse_marks"] = 1;
+  })
+}
+
+int mhx_dist_read2sdbg(mhx_ctx *c, mhx_comm *cm, uint32_t k, uint32_t min_count, int need_mercy, mhx_s1_result *out1,
+                       mhx_sdbg_result *out2, uint64_t *num_mercy) {
+  MHX_TRYC({
+    MHX_HIP(hipSetDevice(c->device));
+    if (!c->global_bases || !cm->stride_bases) throw mhx::Error("dist_read2sdbg: call mhx_dist_setup first");
+    mhx_s1_result r1{};
+    if (num_mercy) *num_mercy = 0;
+    if (min_count > 1) {  // stage 1 is skipped when every edge is solid (main_sdbg_build.cpp:139-147)
+      const uint64_t n1 = mhx::exchange_stage(c, cm, need_mercy ? MHX_STAGE_S1_MERCY : MHX_STAGE_S1, k, min_count);
+      MHX_CK(mhx_dist_process_s1(c, k, min_count, need_mercy, n1, &r1));
+      // the marks of the NON-solid (k+1)-mer occurrences of the owned buckets -> the ranks that hold those reads, which
+      // derive is_solid = "a (k+1)-mer starts here and it is not marked" for their reads
+      mhx::route(c, cm, MHX_ROUTE_S1_MARKS);
+      r1.n_solid = c->dist_local_solid;
+      if (need_mercy) {  // candidates -> read owners; the mercy block of Read2SdbgS2::Initialize runs there
+        mhx::route(c, cm, MHX_ROUTE_MERCY_CAND);
+        uint64_t nm = 0;
+        MHX_CK(mhx_read2sdbg_add_mercy(c, k, &nm));
+        if (num_mercy) *num_mercy = nm;
+      }
+    }
+    const uint64_t n2 = mhx::exchange_stage(c, cm, MHX_STAGE_S2, k, min_count);
+    mhx_sdbg_result r2{};
+    MHX_CK(mhx_dist_process_s2(c, k, n2, &r2));
+    if (out1) *out1 = r1;
+    if (out2) *out2 = r2;
+  })
+}
+
+int mhx_dist_count(mhx_ctx *c, mhx_comm *cm, uint32_t k, uint32_t min_count, mhx_count_result *out) {
+  MHX_TRYC({
+    MHX_HIP(hipSetDevice(c->device));
+    if (!c->global_bases || !cm->stride_bases) throw mhx::Error("dist_count: call mhx_dist_setup first");
+    const uint64_t n = mhx::exchange_stage(c, cm, MHX_STAGE_COUNT, k, min_count);
+    mhx_count_result r{};
+    MHX_CK(mhx_dist_process_count(c, k, min_count, n, &r));
+    mhx::route(c, cm, MHX_ROUTE_COUNT_EVENTS);
+    if (out) *out = r;
+  })
+}
+
+int mhx_dist_seq2sdbg(mhx_ctx *c, mhx_comm *cm, uint32_t k, mhx_sdbg_result *out) {
+  MHX_TRYC({
+    MHX_HIP(hipSetDevice(c->device));
+    if (c->part_begin.empty()) throw mhx::Error("dist_seq2sdbg: call mhx_dist_setup first");
+    const uint64_t saved = c->global_bases;  // items carry no positions
+    const uint64_t n = mhx::exchange_stage(c, cm, MHX_STAGE_SEQ2SDBG, k, 0);
+    mhx_sdbg_result r{};
+    MHX_CK(mhx_dist_process_seq2sdbg(c, k, n, &r));
+    c->global_bases = saved;
+    if (out) *out = r;
+  })
+}
+
+}  // extern "C"

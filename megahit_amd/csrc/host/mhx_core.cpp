@@ -7,6 +7,8 @@
 // it unchanged, so the unmodified `megahit` orchestrator can run with this binary in place.
 #include <unistd.h>
 
+#include <algorithm>
+
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -102,6 +104,96 @@ mhx_ctx *open_gpu() {
     if ((call) != 0) fatal("%s", mhx_last_error()); \
   } while (0)
 
+// ---- multi-GPU: `mhx_core --gpus N <sub-program> ...` or MHX_NUM_GPUS=N.  One host thread per GPU in this process (no
+// launcher): reads are sharded contiguously over the ranks, lv1 buckets over their owners, the items cross the node
+// through the communicator of include/mhx.h (RCCL over xGMI; the in-process transport when ranks share a device, i.e.
+// MHX_GPU_MAP="0,0" on a 1-GPU box) — what base_engine.cpp:213-223,318-327 does with OpenMP threads.
+int g_num_gpus = 1;
+struct RankSet {
+  int n = 1;
+  std::vector<int> dev;
+  bool local = false;
+};
+RankSet rank_set() {
+  RankSet rs;
+  rs.n = g_num_gpus;
+  if (const char *e = getenv("MHX_GPU_MAP")) {
+    for (const char *p = e; *p;) {
+      rs.dev.push_back(atoi(p));
+      while (*p && *p != ',') ++p;
+      if (*p == ',') ++p;
+    }
+  }
+  for (int r = (int)rs.dev.size(); r < rs.n; ++r) rs.dev.push_back(r);
+  rs.dev.resize(rs.n);
+  for (int a = 0; a < rs.n; ++a)
+    for (int b = a + 1; b < rs.n; ++b)
+      if (rs.dev[a] == rs.dev[b]) rs.local = true;  // RCCL refuses two ranks on one device
+  if (const char *e = getenv("MHX_COMM")) rs.local = !strcmp(e, "local");
+  return rs;
+}
+// body(rank, ctx, comm) on one thread per rank; any failure ends the process with the rank's message
+template <class Body>
+void run_ranks(const RankSet &rs, Body body) {
+  std::vector<mhx_ctx *> ctx(rs.n, nullptr);
+  for (int r = 0; r < rs.n; ++r) {
+    ctx[r] = mhx_create(rs.dev[r]);
+    if (!ctx[r]) fatal("rank %d (device %d): %s", r, rs.dev[r], mhx_last_error());
+  }
+  std::vector<mhx_comm *> comm(rs.n, nullptr);
+  unsigned char id[MHX_COMM_ID_BYTES];
+  if (rs.local) {
+    if (mhx_comm_local_group(rs.n, ctx.data(), comm.data()) != 0) fatal("%s", mhx_last_error());
+  } else if (mhx_comm_unique_id(id) != 0) {
+    fatal("%s", mhx_last_error());
+  }
+  info("%d ranks on devices %s over %s", rs.n, [&] { std::string d; for (int v : rs.dev) d += std::to_string(v) + " "; return d; }().c_str(),
+       rs.local ? "the in-process transport" : "RCCL");
+  std::vector<std::string> err(rs.n);
+  std::vector<std::thread> th;
+  for (int r = 0; r < rs.n; ++r)
+    th.emplace_back([&, r] {
+      try {
+        if (!rs.local) {
+          comm[r] = mhx_comm_init_rank(ctx[r], id, r, rs.n);  // collective: returns when every rank has joined
+          if (!comm[r]) throw std::string(mhx_last_error());
+        }
+        body(r, ctx[r], comm[r]);
+      } catch (const std::string &e) {
+        err[r] = e.empty() ? "failed" : e;
+      }
+    });
+  for (auto &t : th) t.join();
+  for (int r = 0; r < rs.n; ++r)
+    if (!err[r].empty()) fatal("rank %d: %s", r, err[r].c_str());
+  for (int r = 0; r < rs.n; ++r) {
+    mhx_comm_destroy(comm[r]);
+    mhx_destroy(ctx[r]);
+  }
+}
+#define CKT(call)                                             \
+  do {                                                        \
+    if ((call) != 0) throw std::string(mhx_last_error());     \
+  } while (0)
+// contiguous shards of the reads with about equal numbers of record words
+std::vector<uint64_t> shard_reads(const std::vector<uint64_t> &rec_off, uint64_t total_words, int n) {
+  std::vector<uint64_t> first(n + 1, rec_off.size());
+  first[0] = 0;
+  for (int r = 1; r < n; ++r) {
+    const uint64_t target = total_words / n * r;
+    first[r] = std::lower_bound(rec_off.begin(), rec_off.end(), target) - rec_off.begin();
+  }
+  return first;
+}
+
+template <class T>
+std::vector<T> fetch_t(mhx_ctx *c, int which) {  // the throwing flavour for rank threads
+  uint64_t bytes = mhx_buffer_bytes(c, which);
+  std::vector<T> v(bytes / sizeof(T));
+  if (bytes) CKT(mhx_fetch(c, which, v.data(), 0, bytes));
+  return v;
+}
+
 template <class T>
 std::vector<T> fetch(mhx_ctx *c, int which) {
   uint64_t bytes = mhx_buffer_bytes(c, which);
@@ -164,10 +256,12 @@ struct SdbgAcc {
   uint64_t wc[10] = {0};
   mhx_sdbg_result r{};
   void add(mhx_ctx *c, const mhx_sdbg_result &pr) {
-    auto b = fetch<uint8_t>(c, MHX_BUF_SDBG_BYTES);
-    auto o = fetch<uint64_t>(c, MHX_BUF_BUCKET_OFFSET), it = fetch<uint64_t>(c, MHX_BUF_BUCKET_COUNT);
-    auto tp = fetch<uint64_t>(c, MHX_BUF_BUCKET_TIPS), lg = fetch<uint64_t>(c, MHX_BUF_BUCKET_LARGE);
-    auto w = fetch<uint64_t>(c, MHX_BUF_W_COUNT);
+    add(fetch<uint8_t>(c, MHX_BUF_SDBG_BYTES), fetch<uint64_t>(c, MHX_BUF_BUCKET_OFFSET), fetch<uint64_t>(c, MHX_BUF_BUCKET_COUNT),
+        fetch<uint64_t>(c, MHX_BUF_BUCKET_TIPS), fetch<uint64_t>(c, MHX_BUF_BUCKET_LARGE), fetch<uint64_t>(c, MHX_BUF_W_COUNT), pr);
+  }
+  void add(const SdbgAcc &o) { add(o.bytes, o.off, o.items, o.tips, o.large, std::vector<uint64_t>(o.wc, o.wc + 10), o.r); }
+  void add(const std::vector<uint8_t> &b, const std::vector<uint64_t> &o, const std::vector<uint64_t> &it, const std::vector<uint64_t> &tp,
+           const std::vector<uint64_t> &lg, const std::vector<uint64_t> &w, const mhx_sdbg_result &pr) {
     for (int i = 0; i < MHX_NUM_BUCKETS; ++i) {
       if (it[i]) off[i] = o[i] + bytes.size();
       items[i] += it[i];
@@ -234,6 +328,56 @@ int main_kmer_count(int argc, char **argv) {
   const int n_threads = num_threads_or_all(atoi(o.get("num_cpu_threads").c_str()));
   const std::string out = o.get("output_prefix");
   Timer t;
+  if (g_num_gpus > 1) {
+    const RankSet rs = rank_set();
+    info("Preparing data...");
+    ReadLib lib;
+    lib.rec = mhxio::read_bin_file(o.get("read_lib_file") + ".bin");
+    lib.off = mhxio::index_bin_records(lib.rec);
+    const std::vector<uint64_t> first = shard_reads(lib.off, lib.rec.size(), rs.n);
+    info("%zu reads; Preparing data... Done. Time elapsed: %.4f", lib.off.size(), t.lap());
+    std::vector<std::vector<uint32_t>> edges(rs.n), f0(rs.n), l0(rs.n);
+    std::vector<std::vector<uint64_t>> bc(rs.n);
+    std::vector<std::vector<int64_t>> hist(rs.n);
+    std::vector<mhx_count_result> res(rs.n);
+    run_ranks(rs, [&](int r, mhx_ctx *c, mhx_comm *cm) {
+      const uint64_t lo = first[r], hi = first[r + 1];
+      const uint64_t w0 = lo < lib.off.size() ? lib.off[lo] : lib.rec.size(), w1 = hi < lib.off.size() ? lib.off[hi] : lib.rec.size();
+      CKT(mhx_load_bin_records(c, lib.rec.data() + w0, w1 - w0, hi - lo, 1));
+      CKT(mhx_dist_setup(c, cm, MHX_STAGE_COUNT, k, m));
+      CKT(mhx_dist_count(c, cm, k, m, &res[r]));
+      edges[r] = fetch_t<uint32_t>(c, MHX_BUF_EDGES);
+      bc[r] = fetch_t<uint64_t>(c, MHX_BUF_BUCKET_COUNT);
+      hist[r] = fetch_t<int64_t>(c, MHX_BUF_MUL_HIST);
+      f0[r] = fetch_t<uint32_t>(c, MHX_BUF_FIRST_0_OUT);
+      l0[r] = fetch_t<uint32_t>(c, MHX_BUF_LAST_0_IN);
+    });
+    mhx_count_result r{};
+    std::vector<uint32_t> all_edges, first_out, last_in;
+    std::vector<uint64_t> bcount(MHX_NUM_BUCKETS, 0);
+    std::vector<int64_t> h(MHX_MAX_MUL + 1, 0);
+    for (int q = 0; q < rs.n; ++q) {  // ranks own ascending bucket ranges and hold ascending read ranges
+      all_edges.insert(all_edges.end(), edges[q].begin(), edges[q].end());
+      first_out.insert(first_out.end(), f0[q].begin(), f0[q].end());
+      last_in.insert(last_in.end(), l0[q].begin(), l0[q].end());
+      for (int b = 0; b < MHX_NUM_BUCKETS; ++b) bcount[b] += bc[q][b];
+      for (int i = 0; i <= MHX_MAX_MUL; ++i) h[i] += hist[q][i];
+      r.n_items += res[q].n_items;
+      r.n_distinct += res[q].n_distinct;
+      r.n_edges += res[q].n_edges;
+      r.words_per_edge = res[q].words_per_edge;
+    }
+    info("GPU count: %llu items, %llu distinct, %llu solid. Time elapsed: %.4f", (unsigned long long)r.n_items,
+         (unsigned long long)r.n_distinct, (unsigned long long)r.n_edges, t.lap());
+    mhxio::write_edges(out, k, r.words_per_edge, all_edges.data(), r.n_edges, bcount.data(), std::max(out_files(n_threads), std::min(rs.n, n_threads)));
+    int64_t n_cand = 0, n_tips = 0;
+    mhxio::write_cand(out, lib.rec, lib.off, first_out.data(), last_in.data(), &n_cand, &n_tips);
+    mhxio::write_counting(out, h.data());
+    info("Total number of candidate reads: %lld (%lld)", (long long)n_cand, (long long)n_tips);
+    info("Total number of solid edges: %llu", (unsigned long long)r.n_edges);
+    info("Postprocess done. Time elapsed: %.4f", t.lap());
+    return 0;
+  }
   mhx_ctx *c = open_gpu();
   info("Preparing data...");
   ReadLib lib = load_read_lib(c, o.get("read_lib_file"));
@@ -296,6 +440,52 @@ int main_read2sdbg(int argc, char **argv) {
   const bool need_mercy = !o.get("need_mercy").empty();
   const std::string out = o.get("output_prefix");
   Timer t;
+  if (g_num_gpus > 1) {
+    const RankSet rs = rank_set();
+    info("Preparing data...");
+    std::vector<uint32_t> rec = mhxio::read_bin_file(o.get("read_lib_file") + ".bin");
+    std::vector<uint64_t> off = mhxio::index_bin_records(rec);
+    const std::vector<uint64_t> first = shard_reads(off, rec.size(), rs.n);
+    info("%zu reads; Preparing data... Done. Time elapsed: %.4f", off.size(), t.lap());
+    const int mercy_mode = !need_mercy ? 0 : (getenv("MHX_STABLE_TIES") ? 1 : 2);
+    std::vector<SdbgAcc> part(rs.n);
+    std::vector<std::vector<int64_t>> hist(rs.n);
+    std::vector<mhx_s1_result> r1(rs.n);
+    std::vector<uint64_t> nm(rs.n, 0);
+    run_ranks(rs, [&](int r, mhx_ctx *c, mhx_comm *cm) {
+      const uint64_t lo = first[r], hi = first[r + 1];
+      const uint64_t w0 = lo < off.size() ? off[lo] : rec.size(), w1 = hi < off.size() ? off[hi] : rec.size();
+      CKT(mhx_load_bin_records(c, rec.data() + w0, w1 - w0, hi - lo, 1));
+      CKT(mhx_dist_setup(c, cm, m > 1 ? (mercy_mode ? MHX_STAGE_S1_MERCY : MHX_STAGE_S1) : MHX_STAGE_S2, k, m));
+      mhx_sdbg_result r2{};
+      CKT(mhx_dist_read2sdbg(c, cm, k, m, mercy_mode, &r1[r], &r2, &nm[r]));
+      if (m > 1) hist[r] = fetch_t<int64_t>(c, MHX_BUF_MUL_HIST);
+      part[r].add(fetch_t<uint8_t>(c, MHX_BUF_SDBG_BYTES), fetch_t<uint64_t>(c, MHX_BUF_BUCKET_OFFSET), fetch_t<uint64_t>(c, MHX_BUF_BUCKET_COUNT),
+                  fetch_t<uint64_t>(c, MHX_BUF_BUCKET_TIPS), fetch_t<uint64_t>(c, MHX_BUF_BUCKET_LARGE), fetch_t<uint64_t>(c, MHX_BUF_W_COUNT), r2);
+    });
+    if (m > 1) {
+      std::vector<int64_t> h(MHX_MAX_MUL + 1, 0);
+      uint64_t n1 = 0, ns = 0, mercy_total = 0;
+      for (int q = 0; q < rs.n; ++q) {
+        for (int i = 0; i <= MHX_MAX_MUL; ++i) h[i] += hist[q][i];
+        n1 += r1[q].n_items;
+        ns += r1[q].n_solid;
+        mercy_total += nm[q];
+      }
+      int64_t n_solid_edges = 0;
+      for (uint32_t i = m; i <= 65535; ++i) n_solid_edges += h[i];
+      info("Total number of solid edges: %lld", (long long)n_solid_edges);
+      mhxio::write_counting(out, h.data());
+      info("Stage 1 done (%llu items, %llu solid occurrences).", (unsigned long long)n1, (unsigned long long)ns);
+      if (need_mercy) info("Number mercy: %llu", (unsigned long long)mercy_total);
+    }
+    SdbgAcc acc;
+    for (int q = 0; q < rs.n; ++q) acc.add(part[q]);  // ranks own ascending bucket ranges: concatenation = bucket order
+    info("Stage 2 done (%llu items). Time elapsed: %.4f", (unsigned long long)acc.r.n_items, t.lap());
+    acc.write(out, k, std::max(out_files(n_threads), std::min(rs.n, n_threads)));
+    info("Postprocess done. Time elapsed: %.4f", t.lap());
+    return 0;
+  }
   mhx_ctx *c = open_gpu();
   info("Preparing data...");
   load_read_lib(c, o.get("read_lib_file"));
@@ -381,6 +571,75 @@ int main_seq2sdbg(int argc, char **argv) {
   const bool need_mercy = !o.get("need_mercy").empty();
   const std::string in = o.get("input_prefix"), out = o.get("output_prefix");
   Timer t;
+  if (g_num_gpus > 1 && need_mercy) info("seq2sdbg --need_mercy searches the whole sorted edge list (seq_to_sdbg.cpp:171-357): running on one GPU");
+  if (g_num_gpus > 1 && !need_mercy) {
+    // edges are sharded contiguously over the ranks (their items carry no positions, so any split works); the contigs,
+    // a small share of the input, are loaded by rank 0; sorting and emission are balanced by the bucket partition
+    const RankSet rs = rank_set();
+    mhxio::EdgeSet es;
+    if (!in.empty()) {
+      es = mhxio::read_edges(in);
+      info("Number edges: %llu", (unsigned long long)es.n_edges());
+    }
+    mhxio::PackedSeqs contigs;
+    std::vector<uint16_t> cmult;
+    auto read_one = [&](const std::string &f, unsigned kf, unsigned kt) {
+      if (f.empty()) return;
+      int64_t n = mhxio::read_contigs(f, &contigs, &cmult, k + 1, kf, kt, true);
+      info("Read %lld contigs from %s.", (long long)n, f.c_str());
+    };
+    if (!o.get("contig").empty()) {
+      read_one(o.get("contig"), k_from, k);
+      read_one(o.get("bubble"), 0, 0);
+    }
+    read_one(o.get("addi_contig"), 0, 0);
+    read_one(o.get("local_contig"), 0, 0);
+    std::vector<SdbgAcc> part(rs.n);
+    run_ranks(rs, [&](int r, mhx_ctx *c, mhx_comm *cm) {
+      const uint64_t ne = es.n_edges(), lo = ne * r / rs.n, hi = ne * (r + 1) / rs.n;
+      bool loaded = false;
+      if (hi > lo) {
+        mhxio::PackedSeqs pk;
+        std::vector<uint16_t> mult(hi - lo);
+        pk.words.reserve((hi - lo) * (es.k + 1) / 16 + 2);
+        for (uint64_t i = lo; i < hi; ++i) {
+          const uint32_t *e = &es.raw[i * es.words_per_edge];
+          pk.append_packed(e, es.k + 1, false);
+          mult[i - lo] = (uint16_t)(e[es.words_per_edge - 1] & 0xFFFF);
+        }
+        CKT(mhx_load_sequences(c, pk.words.data(), pk.words.size(), hi - lo, es.k + 1, nullptr));
+        CKT(mhx_load_multiplicity(c, mult.data(), mult.size()));
+        loaded = true;
+      }
+      if (r == 0 && contigs.n_seqs()) {
+        if (loaded)
+          CKT(mhx_append_sequences(c, contigs.words.data(), contigs.words.size(), contigs.n_seqs(), 0, contigs.start.data(), cmult.data()));
+        else {
+          CKT(mhx_load_sequences(c, contigs.words.data(), contigs.words.size(), contigs.n_seqs(), 0, contigs.start.data()));
+          CKT(mhx_load_multiplicity(c, cmult.data(), cmult.size()));
+        }
+        loaded = true;
+      }
+      if (!loaded) {
+        uint64_t zero = 0;
+        uint32_t w = 0;
+        uint16_t mz = 0;
+        CKT(mhx_load_sequences(c, &w, 0, 0, 0, &zero));
+        CKT(mhx_load_multiplicity(c, &mz, 0));
+      }
+      CKT(mhx_dist_setup(c, cm, MHX_STAGE_SEQ2SDBG, k, 0));
+      mhx_sdbg_result r2{};
+      CKT(mhx_dist_seq2sdbg(c, cm, k, &r2));
+      part[r].add(fetch_t<uint8_t>(c, MHX_BUF_SDBG_BYTES), fetch_t<uint64_t>(c, MHX_BUF_BUCKET_OFFSET), fetch_t<uint64_t>(c, MHX_BUF_BUCKET_COUNT),
+                  fetch_t<uint64_t>(c, MHX_BUF_BUCKET_TIPS), fetch_t<uint64_t>(c, MHX_BUF_BUCKET_LARGE), fetch_t<uint64_t>(c, MHX_BUF_W_COUNT), r2);
+    });
+    SdbgAcc acc;
+    for (int q = 0; q < rs.n; ++q) acc.add(part[q]);
+    info("GPU seq2sdbg done (%llu items). Time elapsed: %.4f", (unsigned long long)acc.r.n_items, t.lap());
+    acc.write(out, k, std::max(out_files(n_threads), std::min(rs.n, n_threads)));
+    info("Postprocess done. Time elapsed: %.4f", t.lap());
+    return 0;
+  }
   mhx_ctx *c = open_gpu();
   bool loaded = false;
   if (!in.empty()) {
@@ -466,6 +725,22 @@ int main(int argc, char **argv) {
   if (argc < 2) {
     fprintf(stderr, "Usage: %s <sub_program> [sub options]\n    sub-programs: count read2sdbg seq2sdbg (GPU); others via MHX_REF_CORE\n", argv[0]);
     return 1;
+  }
+  // `mhx_core --gpus N <sub-program> ...` (or MHX_NUM_GPUS): our only addition to the reference's command line; it sits
+  // before the sub-program so that the sub-programs' own option sets stay the reference's
+  if (const char *e = getenv("MHX_NUM_GPUS")) g_num_gpus = std::max(1, atoi(e));
+  if (!strcmp(argv[1], "--gpus") && argc >= 4) {
+    g_num_gpus = std::max(1, atoi(argv[2]));
+    argv[2] = argv[0];
+    argv += 2;
+    argc -= 2;
+  }
+  if (g_num_gpus > 1) {
+    const int have = mhx_device_count();
+    if (!getenv("MHX_GPU_MAP") && have > 0 && g_num_gpus > have) {
+      info("--gpus %d but only %d device(s) visible: using %d", g_num_gpus, have, have);
+      g_num_gpus = have;
+    }
   }
   const std::string sub = argv[1];
   if (sub == "count") return main_kmer_count(argc - 1, argv + 1);

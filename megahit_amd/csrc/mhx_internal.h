@@ -96,6 +96,8 @@ struct mhx_ctx {
   bool global_marks_inverted = false;  // multi-GPU stage 1 marked the non-solid occurrences (s1.hip)
   uint64_t s1_acc_bits = 0, mercy_acc_n = 0;  // stage-1 state that accumulate continues
   uint32_t s1_acc_k = 0, s1_acc_m = 0;
+  uint64_t n_marks = 0;          // multi-GPU, sparse marks: positions in ws("s1_marks") waiting to be routed
+  uint64_t dist_local_solid = 0; // multi-GPU, sparse marks: solid occurrences in the local reads after the marks arrived
   bool dist_s2_agg = false;  // the items of the current multi-GPU stage-2 exchange are aggregated ones
   // tuning knobs (mhx_set_option): explicit value, else environment MHX_<NAME>, else the default
   std::map<std::string, long long> options;
@@ -201,6 +203,7 @@ void invert_local_marks(mhx_ctx *c, unsigned long long *words, uint64_t n_words)
 DevBuf &grow_preserving(mhx_ctx *c, DevBuf &b, size_t bytes, size_t keep);
 void stash_route_records(mhx_ctx *c, const void *src, uint64_t n, int hi_bit);
 void mercy_adopt_routed(mhx_ctx *c, const long long *recv, uint64_t n);
+void s1_apply_marks(mhx_ctx *c, const unsigned long long *recv, uint64_t n);
 
 // ---- engines ----
 int run_count(mhx_ctx *c, uint32_t k, uint32_t m, mhx_count_result *out);

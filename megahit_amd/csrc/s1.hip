@@ -409,6 +409,12 @@ struct S1SegArgs {
   uint2 *agg_raw;
   uint32_t agg_cap;
   uint32_t *agg_counts;
+  // multi-GPU, sparse marks: instead of a store into a byte map of the GLOBAL read set, a mark is the position itself,
+  // appended to the workgroup's region marks_raw[blockIdx.x * marks_cap ...] (count in marks_counts[blockIdx.x]); the
+  // host packs the regions and routes the positions to the ranks that hold those reads (comm.hip)
+  unsigned long long *marks_raw;
+  uint32_t marks_cap;
+  uint32_t *marks_counts;
   uint64_t pos_stride;
   uint32_t *err;
   int la_chunks;      // look-ahead limit, in chunks of 256 records
@@ -431,7 +437,7 @@ __global__ __launch_bounds__(256) void k_s1_seg(const uint32_t *__restrict__ ite
   __shared__ uint32_t cnts[NSLOT / 2];   // two 16-bit counters per word (a tile inserts < 65536 records)
   __shared__ uint16_t created[NSLOT];    // slots created by this tile = its distinct keys, in any order
   __shared__ uint32_t lhist[kSegHist];
-  __shared__ uint32_t s_bad, s_ncreated, s_agg_cur;
+  __shared__ uint32_t s_bad, s_ncreated, s_agg_cur, s_mark_cur;
   const int tid = threadIdx.x, lane = tid & (kWave - 1);
   const uint64_t lanemask_lt = (1ull << lane) - 1;
   uint2 *const agg_out = AGG ? a.agg_raw + (size_t)blockIdx.x * a.agg_cap : nullptr;
@@ -442,8 +448,10 @@ __global__ __launch_bounds__(256) void k_s1_seg(const uint32_t *__restrict__ ite
     s_bad = 0;
     s_ncreated = 0;
     s_agg_cur = 0;
+    s_mark_cur = 0;
   }
   __syncthreads();
+  unsigned long long *const marks_out = a.marks_raw ? a.marks_raw + (size_t)blockIdx.x * a.marks_cap : nullptr;
 
   const uint32_t pfx = a.pfx_mask, eqm = a.eq_mask1, m = a.m;
   auto count_of = [&](uint32_t slot) -> uint32_t { return (cnts[slot >> 1] >> ((slot & 1u) * 16)) & 0xFFFFu; };
@@ -468,12 +476,24 @@ __global__ __launch_bounds__(256) void k_s1_seg(const uint32_t *__restrict__ ite
     for (int probes = 0; probes < 512 && keys[h] != key; ++probes) h = (h + 1) & (NSLOT - 1);
     return h;
   };
-  auto mark = [&](uint32_t w1, uint32_t w2, uint32_t cnt) {
+  // convergent (every lane of the wavefront calls it; `mine` = this lane has a record of ours)
+  auto mark = [&](bool mine, uint32_t w1, uint32_t w2, uint32_t cnt) {
     const bool both = (w1 & 0x24u) == 0;  // head < 4 and tail < 4
     const bool solid = both && cnt >= m;
-    if (a.mark_mode == 1 ? (both && !solid) : solid) {
-      const uint64_t abs = w2 + (uint64_t)((w1 >> 6) & 0xFFu) * a.pos_stride;
-      a.solid_bytes[abs - 1] = 1;  // is_solid.set(pos - 1), :464 (or its complement)
+    const bool mk = mine && (a.mark_mode == 1 ? (both && !solid) : solid);
+    const uint64_t abs = w2 + (uint64_t)((w1 >> 6) & 0xFFu) * a.pos_stride;
+    if (!marks_out) {
+      if (mk) a.solid_bytes[abs - 1] = 1;  // is_solid.set(pos - 1), :464 (or its complement)
+      return;
+    }
+    const uint64_t mm = __ballot(mk);
+    if (!mm) return;
+    uint32_t mbase = 0;
+    if (lane == 0) mbase = atomicAdd(&s_mark_cur, (uint32_t)__builtin_popcountll(mm));
+    mbase = __shfl(mbase, 0, kWave);
+    if (mk) {
+      const uint32_t at = mbase + (uint32_t)__builtin_popcountll(mm & lanemask_lt);
+      if (at < a.marks_cap) marks_out[at] = abs - 1;
     }
   };
   // the (k+1)-mer head.S.tail of a key, chars MSB-first in 64 bits
@@ -635,17 +655,20 @@ __global__ __launch_bounds__(256) void k_s1_seg(const uint32_t *__restrict__ ite
     if (!bad) {
       if (a.mark_mode != 2) {
 #pragma unroll
-        for (int j = 0; j < NR; ++j)
-          if (own[j]) mark(w1[j], w2[j], count_of(slot[j]));
+        for (int j = 0; j < NR; ++j) mark(own[j], w1[j], w2[j], count_of(own[j] ? slot[j] : 0u));
         if (more) {
           for (int c = 1; c <= a.la_chunks; ++c) {
             const uint64_t cb = tile_end + (uint64_t)c * 256;
             const uint64_t gi = cb + tid;
+            uint32_t x0 = 0, x1 = 0, x2 = 0;
             if (gi < n) {
               const uint32_t *p = items + gi * 3;
-              const uint32_t x0 = p[0], x1 = p[1], x2 = p[2];
-              if ((x0 & pfx) == p_last) mark(x1, x2, count_of(lookup(x0, x1 & eqm)));
+              x0 = p[0];
+              x1 = p[1];
+              x2 = p[2];
             }
+            const bool mine = gi < n && (x0 & pfx) == p_last;
+            mark(mine, x1, x2, mine ? count_of(lookup(x0, x1 & eqm)) : 0u);
             if (!(cb + 256 < n && (items[(cb + 255) * 3] & pfx) == p_last)) break;
           }
         }
@@ -732,6 +755,10 @@ __global__ __launch_bounds__(256) void k_s1_seg(const uint32_t *__restrict__ ite
     for (int i = tid; i < kSegHist; i += 256)
       if (lhist[i]) atomicAdd(&a.hist[i], (unsigned long long)lhist[i]);
     if (AGG && tid == 0) a.agg_counts[blockIdx.x] = s_agg_cur < a.agg_cap ? s_agg_cur : a.agg_cap;
+    if (marks_out && tid == 0) {
+      if (s_mark_cur > a.marks_cap) atomicOr(a.err, 2u);  // cannot happen: the region holds every record of the workgroup
+      a.marks_counts[blockIdx.x] = s_mark_cur < a.marks_cap ? s_mark_cur : a.marks_cap;
+    }
   }
 }
 
@@ -747,6 +774,39 @@ __global__ __launch_bounds__(256) void k_agg_compact(const uint2 *__restrict__ r
   const uint32_t n = counts[r];
   const uint2 *src = raw + (size_t)r * cap;
   for (uint32_t i = blockIdx.y * 256 + threadIdx.x; i < n; i += gridDim.y * 256) dense[off + i] = src[i];
+}
+
+// multi-GPU, sparse marks, classic path: positions of the set bytes of the (global) byte map, appended in any order
+__global__ __launch_bounds__(256) void k_collect_marks(const uint8_t *__restrict__ bytes, uint64_t n_bytes, unsigned long long *__restrict__ out,
+                                                      unsigned long long *__restrict__ cursor) {
+  __shared__ uint32_t s_n;
+  __shared__ unsigned long long s_base;
+  const uint64_t p0 = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 16;
+  uint32_t mask = 0;
+  if (p0 < n_bytes) {
+    const uint4 v = *reinterpret_cast<const uint4 *>(bytes + p0);  // the map is padded to a multiple of 64 bytes
+    const uint32_t xs[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int t = 0; t < 16; ++t)
+      if (p0 + t < n_bytes && ((xs[t >> 2] >> ((t & 3) * 8)) & 1u)) mask |= 1u << t;
+  }
+  if (threadIdx.x == 0) s_n = 0;
+  __syncthreads();
+  const uint32_t cnt = __builtin_popcount(mask);
+  uint32_t at = cnt ? atomicAdd(&s_n, cnt) : 0u;
+  __syncthreads();
+  if (threadIdx.x == 0 && s_n) s_base = atomicAdd(cursor, (unsigned long long)s_n);
+  __syncthreads();
+  for (uint32_t mm = mask; mm; mm &= mm - 1) out[s_base + at++] = p0 + (uint64_t)__builtin_ctz(mm);
+}
+// routed marks (global positions of non-solid occurrences in the local reads) -> local byte map
+__global__ void k_apply_marks(const unsigned long long *__restrict__ pos, uint64_t n, uint64_t pos_base, uint64_t n_local, uint8_t *__restrict__ bytes,
+                              uint32_t *__restrict__ bad) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t p = pos[i] - pos_base;
+  if (p < n_local) bytes[p] = 1;
+  else atomicOr(bad, 1u);
 }
 
 // byte map -> AtomicBitVector layout (bit i = word i/64, bit i%64; kmbitvector.h:67-88) + popcount
@@ -1063,24 +1123,37 @@ int s1_process(mhx_ctx *c, uint32_t k, uint32_t m, int want_mercy, uint32_t *buf
   uint32_t *spare = sorted == buf_a ? buf_b : buf_a;
 
   const uint64_t n_bits = global ? c->global_bases : s.n_bases;
-  const uint64_t n_words64 = div_ceil(n_bits, 64);
-  unsigned long long *is_solid = c->result(MHX_BUF_IS_SOLID, (n_words64 + 1) * 8).as<unsigned long long>();
-  c->results[MHX_BUF_IS_SOLID].used = n_words64 * 8;
-  unsigned long long *hist = c->result(MHX_BUF_MUL_HIST, (MHX_MAX_MUL + 1) * 8).as<unsigned long long>();
   // MHX_S1_MARK: atomic (atomicOr into the bitmap) | solid | nonsolid (force the byte-map polarity) | unset = auto
   const char *mark_env = getenv("MHX_S1_MARK");
   const int mark_atomic = mark_env && !strcmp(mark_env, "atomic") ? 1 : 0;
+  // multi-GPU with sparse marks (comm.hip): the marks of the non-solid occurrences leave this function as a list of
+  // global positions (ws "s1_marks", c->n_marks) to be routed to the read owners; no bitmap / byte map of the GLOBAL read
+  // set exists unless the classic tile kernel has to run (then its byte map is converted to the list)
+  const bool sparse = global && !mark_atomic && c->opt("dist_sparse_marks", 0) != 0;
+  const uint64_t n_words64 = sparse ? 0 : div_ceil(n_bits, 64);
+  unsigned long long *is_solid = c->result(MHX_BUF_IS_SOLID, (n_words64 + 1) * 8).as<unsigned long long>();
+  c->results[MHX_BUF_IS_SOLID].used = n_words64 * 8;
+  unsigned long long *hist = c->result(MHX_BUF_MUL_HIST, (MHX_MAX_MUL + 1) * 8).as<unsigned long long>();
   // accumulate (bucket-range passes after the first, passes.hip): marks, histogram, aggregated stage-2 items and
   // mercy candidates of the earlier passes are kept and the published results are cumulative
   const bool acc = c->accumulate && c->s1_acc_bits == n_bits && c->s1_acc_k == k && c->s1_acc_m == m;
   uint8_t *solid_bytes = nullptr;
+  const uint64_t marks_prev = sparse && acc ? c->n_marks : 0;  // marks of the earlier bucket-range passes stay in front
+  if (!sparse || !acc) c->n_marks = 0;
+  auto ensure_byte_map = [&]() {  // (sparse: only when the classic kernel runs; always zeroed, its marks are collected below)
+    if (solid_bytes) return;
+    const uint64_t nw = div_ceil(n_bits, 64);
+    solid_bytes = c->ws("solid_bytes", (nw + 1) * 64).as<uint8_t>();
+    if (!acc || sparse) MHX_HIP(hipMemsetAsync(solid_bytes, 0, (nw + 1) * 64, st));
+  };
   if (mark_atomic) {
     if (!acc) MHX_HIP(hipMemsetAsync(is_solid, 0, (n_words64 + 1) * 8, st));
   } else {
-    solid_bytes = c->ws("solid_bytes", (n_words64 + 1) * 64).as<uint8_t>();
-    if (!acc) MHX_HIP(hipMemsetAsync(solid_bytes, 0, (n_words64 + 1) * 64, st));
+    if (!sparse) ensure_byte_map();
     MHX_HIP(hipMemsetAsync(is_solid + n_words64, 0, 8, st));
   }
+  bool classic_ran = false;
+  uint64_t seg_marks = 0;  // sparse: marks the segment kernel left in ws "s1_marks_seg"
   if (!acc) MHX_HIP(hipMemsetAsync(hist, 0, (MHX_MAX_MUL + 1) * 8, st));
   c->s1_acc_bits = n_bits;
   c->s1_acc_k = k;
@@ -1107,7 +1180,7 @@ int s1_process(mhx_ctx *c, uint32_t k, uint32_t m, int want_mercy, uint32_t *buf
     MHX_HIP(hipMemsetAsync(agg_cursor, 0, 24, st));
     if (agg_prev) MHX_HIP(hipMemcpyAsync(agg_cursor, &agg_prev, 8, hipMemcpyHostToDevice, st));
   };
-  uint32_t seg_grid = 0, seg_cap = 0;
+  uint32_t seg_grid = 0, seg_cap = 0, seg_mcap = 0;
   // segment group-by (k_s1_seg) on the partially sorted records
   uint32_t *seg_err = c->ws("s1_seg_err", 64).as<uint32_t>();
   auto seg_launch = [&](int mode) {
@@ -1130,7 +1203,19 @@ int s1_process(mhx_ctx *c, uint32_t k, uint32_t m, int want_mercy, uint32_t *buf
       raw = c->ws("s2_agg_raw", (size_t)grid * seg_cap * 8).as<uint2>();
       counts = c->ws("s2_agg_counts", (size_t)grid * 4).as<uint32_t>();
     }
-    S1SegArgs a{(int)k, m, pfx_mask, eq_mask1, solid_bytes, mode, hist, ctr, raw, seg_cap, counts, pos_stride, seg_err, la};
+    // sparse marks go to the spare sort buffer (>= 12 bytes per record, a record yields at most one 8-byte mark): a
+    // workgroup's region holds every record it can meet
+    unsigned long long *mraw = nullptr;
+    uint32_t *mcounts = nullptr;
+    uint32_t mcap = 0;
+    if (sparse && mode != 2) {
+      mraw = reinterpret_cast<unsigned long long *>(spare);
+      mcap = (uint32_t)std::min<uint64_t>(n_items * (uint64_t)S * 4 / 8 / grid, 0xFFFFFFF0u);
+      mcounts = c->ws("s1_mark_counts", (size_t)grid * 4).as<uint32_t>();
+      seg_grid = grid;
+      seg_mcap = mcap;
+    }
+    S1SegArgs a{(int)k, m, pfx_mask, eq_mask1, solid_bytes, mode, hist, ctr, raw, seg_cap, counts, mraw, mcap, mcounts, pos_stride, seg_err, la};
     MHX_HIP(hipMemsetAsync(seg_err, 0, 4, st));
     const char *nm = mode == 2 ? "s1_sample" : "s1_groups";
     const double bytes = (double)n_work * T * 12;
@@ -1183,10 +1268,20 @@ int s1_process(mhx_ctx *c, uint32_t k, uint32_t m, int want_mercy, uint32_t *buf
       MHX_HIP(hipMemcpyAsync(hist_save, hist, (MHX_MAX_MUL + 1) * 8, hipMemcpyDeviceToDevice, st));
       seg_launch(mark_mode);
       uint32_t e = 0;
-      std::vector<uint32_t> h_counts(agg ? seg_grid : 0);
+      std::vector<uint32_t> h_counts(agg ? seg_grid : 0), h_mcounts(sparse ? seg_grid : 0);
       MHX_HIP(hipMemcpyAsync(&e, seg_err, 4, hipMemcpyDeviceToHost, st));
       if (agg) MHX_HIP(hipMemcpyAsync(h_counts.data(), c->work["s2_agg_counts"].p, (size_t)seg_grid * 4, hipMemcpyDeviceToHost, st));
+      if (sparse) MHX_HIP(hipMemcpyAsync(h_mcounts.data(), c->work["s1_mark_counts"].p, (size_t)seg_grid * 4, hipMemcpyDeviceToHost, st));
       MHX_HIP(hipStreamSynchronize(st));
+      if (!e && sparse) {  // pack the workgroups' mark regions (they live in the spare sort buffer) behind the earlier passes' marks
+        for (uint32_t v : h_mcounts) seg_marks += v;
+        unsigned long long *dense = grow_preserving(c, c->work["s1_marks"], (marks_prev + seg_marks) * 8 + 64, marks_prev * 8).as<unsigned long long>();
+        if (seg_marks)
+          MHX_LAUNCH(c, "marks_compact", (double)seg_marks * 16,
+                     hipLaunchKernelGGL(k_agg_compact, dim3(seg_grid, 8), dim3(256), 0, st, reinterpret_cast<const uint2 *>(spare), seg_mcap,
+                                        c->work["s1_mark_counts"].as<uint32_t>(), reinterpret_cast<uint2 *>(dense + marks_prev)));
+        c->n_marks = marks_prev + seg_marks;
+      }
       if (!e && agg) {  // pack the workgroups' regions behind the items of the earlier passes
         uint64_t total = 0;
         for (uint32_t v : h_counts) total += v;
@@ -1209,7 +1304,11 @@ int s1_process(mhx_ctx *c, uint32_t k, uint32_t m, int want_mercy, uint32_t *buf
         mercy = reinterpret_cast<long long *>(spare);
       }
     }
-    if (!(plan.seg_bits && !seg_failed)) agg_prepare_classic();
+    if (!(plan.seg_bits && !seg_failed)) {
+      agg_prepare_classic();
+      ensure_byte_map();
+      classic_ran = true;
+    }
     if (plan.seg_bits && !seg_failed) {
     } else if (agg && S == 3) s1_groups_launch<3, true, true>(MHX_ARGS(0));
     else if (agg && S == 4 && !compact) s1_groups_launch<4, false, true>(MHX_ARGS(want_mercy));
@@ -1227,6 +1326,20 @@ int s1_process(mhx_ctx *c, uint32_t k, uint32_t m, int want_mercy, uint32_t *buf
     c->agg_valid = true;
     c->agg_k = k;
     c->agg_m = m;
+  }
+  if (sparse && classic_ran) {  // the classic kernel marked a byte map of the global read set: turn it into the list
+    const uint64_t n_bytes = div_ceil(n_bits, 64) * 64;
+    unsigned long long *cur = c->ws("s1_mark_cursor", 64).as<unsigned long long>();
+    MHX_HIP(hipMemsetAsync(cur, 0, 8, st));
+    // upper bound of the marks: every record
+    unsigned long long *dense = grow_preserving(c, c->work["s1_marks"], (marks_prev + n_items) * 8 + 64, marks_prev * 8).as<unsigned long long>();
+    MHX_LAUNCH(c, "collect_marks", (double)n_bytes,
+               hipLaunchKernelGGL(k_collect_marks, dim3((unsigned)div_ceil(n_bytes, 256 * 16)), dim3(256), 0, st, solid_bytes, n_bytes,
+                                  dense + marks_prev, cur));
+    uint64_t got = 0;
+    MHX_HIP(hipMemcpyAsync(&got, cur, 8, hipMemcpyDeviceToHost, st));
+    MHX_HIP(hipStreamSynchronize(st));
+    c->n_marks = marks_prev + got;
   }
   if (n_words64 && mark_atomic)
     MHX_LAUNCH(c, "count_solid", (double)n_words64 * 8,
@@ -1278,6 +1391,34 @@ int s1_process(mhx_ctx *c, uint32_t k, uint32_t m, int want_mercy, uint32_t *buf
     out->item_words = S;
   }
   return 0;
+}
+
+// multi-GPU, sparse marks: the routed marks of the local reads (global positions of their non-solid (k+1)-mer occurrences)
+// -> local is_solid = "a (k+1)-mer starts here and it is not marked" (MHX_BUF_IS_SOLID_LOCAL, read by stage 2)
+void s1_apply_marks(mhx_ctx *c, const unsigned long long *recv, uint64_t n) {
+  SeqSet &s = c->seqs;
+  hipStream_t st = c->stream;
+  const uint64_t need = div_ceil(s.n_bases, 64);
+  uint8_t *bytes = c->ws("solid_bytes_local", (need + 1) * 64).as<uint8_t>();
+  MHX_HIP(hipMemsetAsync(bytes, 0, (need + 1) * 64, st));
+  unsigned long long *ctr = c->ws("s1_counters", 64).as<unsigned long long>();
+  MHX_HIP(hipMemsetAsync(ctr, 0, 64, st));
+  uint32_t *bad = reinterpret_cast<uint32_t *>(ctr + 4);
+  if (n)
+    MHX_LAUNCH(c, "apply_marks", (double)n * 40,
+               hipLaunchKernelGGL(k_apply_marks, dim3((unsigned)div_ceil(n, 256)), dim3(256), 0, st, recv, n, c->pos_base, s.n_bases, bytes, bad));
+  DevBuf &b = c->result(MHX_BUF_IS_SOLID_LOCAL, (need + 1) * 8);
+  b.used = need * 8;
+  if (need)
+    MHX_LAUNCH(c, "pack_solid", (double)need * 72,
+               hipLaunchKernelGGL(k_pack_solid_inv, dim3((unsigned)div_ceil(need, 256)), dim3(256), 0, st, bytes, s.n_bases, s.start.as<uint64_t>(),
+                                  s.n_seqs, s.fixed_len, (int)c->s1_acc_k, b.as<unsigned long long>(), need, ctr));
+  unsigned long long h[5] = {0, 0, 0, 0, 0};
+  MHX_HIP(hipMemcpyAsync(h, ctr, 40, hipMemcpyDeviceToHost, st));
+  MHX_HIP(hipStreamSynchronize(st));
+  if (h[4] & 0xFFFFFFFFull) throw Error("dist_apply_routed: a mark outside this rank's reads (ranks disagree on the global layout)");
+  c->dist_local_solid = h[0];
+  c->global_marks_inverted = false;
 }
 
 int run_s1(mhx_ctx *c, uint32_t k, uint32_t m, int want_mercy, mhx_s1_result *out) {

@@ -103,6 +103,18 @@ SYMBOLS = {
     "mhx_dist_apply_routed": (C.c_int, [_P, C.c_int, C.c_uint64]),
     "mhx_device_pointer": (_P, [_P, C.c_int]),
     "mhx_adopt_is_solid_slice": (C.c_int, [_P, _P, C.c_uint64]),
+    "mhx_comm_unique_id": (C.c_int, [_P]),
+    "mhx_comm_init_rank": (_P, [_P, _P, C.c_int, C.c_int]),
+    "mhx_comm_local_group": (C.c_int, [C.c_int, _P, _P]),
+    "mhx_comm_destroy": (None, [_P]),
+    "mhx_comm_rank": (C.c_int, [_P]),
+    "mhx_comm_size": (C.c_int, [_P]),
+    "mhx_comm_barrier": (C.c_int, [_P]),
+    "mhx_comm_all_reduce_u64": (C.c_int, [_P, _P, C.c_uint64, C.c_int]),
+    "mhx_dist_setup": (C.c_int, [_P, _P, C.c_int, C.c_uint32, C.c_uint32]),
+    "mhx_dist_read2sdbg": (C.c_int, [_P, _P, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(S1Result), C.POINTER(SdbgResult), _P]),
+    "mhx_dist_count": (C.c_int, [_P, _P, C.c_uint32, C.c_uint32, C.POINTER(CountResult)]),
+    "mhx_dist_seq2sdbg": (C.c_int, [_P, _P, C.c_uint32, C.POINTER(SdbgResult)]),
     "mhx_device_free_bytes": (C.c_uint64, [_P]),
     "mhx_bucket_histogram": (C.c_int, [_P, C.c_int, C.c_uint32, C.c_uint32, _P]),
     "mhx_set_bucket_filter": (C.c_int, [_P, _P, C.c_uint64, C.c_uint64, C.c_int]),
@@ -345,3 +357,73 @@ class Engine:
             raise MhxError(self.lib.mhx_last_error().decode())
         return {arr[i].name.decode(): dict(launches=arr[i].launches, ms=arr[i].total_ms, bytes=arr[i].algo_bytes)
                 for i in range(min(n, 128))}
+
+
+COMM_ID_BYTES = 128
+
+
+def comm_unique_id():
+    """RCCL unique id (bytes) created by one rank and shipped to the others (mhx_comm_unique_id)."""
+    buf = C.create_string_buffer(COMM_ID_BYTES)
+    if load().mhx_comm_unique_id(buf) != 0:
+        raise MhxError(load().mhx_last_error().decode())
+    return buf.raw
+
+
+class Comm:
+    """Communicator of the C++ multi-GPU drivers (include/mhx.h: mhx_comm_*).  One per rank, bound to the rank's Engine."""
+
+    def __init__(self, engine, handle):
+        self.lib, self.e, self.h = engine.lib, engine, handle
+
+    @classmethod
+    def rccl(cls, engine, unique_id, rank, n_ranks):
+        h = engine.lib.mhx_comm_init_rank(engine.h, unique_id, rank, n_ranks)
+        if not h:
+            raise MhxError(engine.lib.mhx_last_error().decode())
+        return cls(engine, h)
+
+    @classmethod
+    def local_group(cls, engines):
+        """In-process group (no RCCL): the ranks are threads of this process and may share GPUs."""
+        n = len(engines)
+        ctxs = (C.c_void_p * n)(*[e.h for e in engines])
+        out = (C.c_void_p * n)()
+        if engines[0].lib.mhx_comm_local_group(n, ctxs, out) != 0:
+            raise MhxError(engines[0].lib.mhx_last_error().decode())
+        return [cls(e, out[i]) for i, e in enumerate(engines)]
+
+    def close(self):
+        if self.h:
+            self.lib.mhx_comm_destroy(self.h)
+            self.h = None
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise MhxError(self.lib.mhx_last_error().decode())
+
+    def barrier(self):
+        self._chk(self.lib.mhx_comm_barrier(self.h))
+
+    def all_reduce(self, values, is_max=False):
+        v = np.ascontiguousarray(values, dtype=np.uint64).copy()
+        self._chk(self.lib.mhx_comm_all_reduce_u64(self.h, _ptr(v), v.size, int(is_max)))
+        return v
+
+    def setup(self, balance_stage=0, k=21, m=2):
+        self._chk(self.lib.mhx_dist_setup(self.e.h, self.h, balance_stage, k, m))
+
+    def read2sdbg(self, k, m, need_mercy=0):
+        r1, r2, nm = S1Result(), SdbgResult(), C.c_uint64(0)
+        self._chk(self.lib.mhx_dist_read2sdbg(self.e.h, self.h, k, m, int(need_mercy), C.byref(r1), C.byref(r2), C.byref(nm)))
+        return r1, r2, int(nm.value)
+
+    def count(self, k, m):
+        r = CountResult()
+        self._chk(self.lib.mhx_dist_count(self.e.h, self.h, k, m, C.byref(r)))
+        return r
+
+    def seq2sdbg(self, k):
+        r = SdbgResult()
+        self._chk(self.lib.mhx_dist_seq2sdbg(self.e.h, self.h, k, C.byref(r)))
+        return r

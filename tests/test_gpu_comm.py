@@ -1,0 +1,208 @@
+"""GPU: the C++ multi-GPU drivers (include/mhx.h mhx_comm_* / mhx_dist_*, megahit_amd/csrc/comm.hip).
+
+A 1-GPU box cannot host two RCCL ranks, so the ranks are threads of this process sharing cuda:0 behind the in-process
+transport (mhx_comm_local_group): extraction, owner partition, exchange bookkeeping, sparse mark routing, sort,
+reduction and emission are exactly what `mhx_core --gpus N` and `bench.py --gpus N` run; only the byte mover differs
+(device copies instead of ncclSend/ncclRecv).  The RCCL transport itself is exercised with one rank."""
+import os
+import subprocess
+import threading
+
+import numpy as np
+import pytest
+
+import golden_util as gu
+import oracle_binding as ob
+from megahit_amd import canon, lib
+from test_dist_cpu import _reads as reads_of
+from test_dist_cpu import _seqs_with_mult
+
+pytestmark = pytest.mark.gpu
+
+STAGE_S1, STAGE_COUNT = 1, 3
+
+
+def run_ranks(world, load, body, options=None):
+    """world threads, one Engine each on cuda:0, one local group; returns [body(rank, engine, comm)]."""
+    engines = [lib.Engine(0) for _ in range(world)]
+    for e in engines:
+        for kname, v in (options or {}).items():
+            e.set_option(kname, v)
+    for r, e in enumerate(engines):
+        load(r, e)
+    comms = lib.Comm.local_group(engines)
+    out, err = [None] * world, [None] * world
+
+    def work(r):
+        try:
+            out[r] = body(r, engines[r], comms[r])
+        except BaseException as ex:  # noqa: BLE001 - re-raised in the main thread
+            err[r] = ex
+
+    ts = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=600)
+    for cm in comms:
+        cm.close()
+    for e in engines:
+        e.close()
+    for ex in err:
+        if ex is not None:
+            raise ex
+    return out
+
+
+def load_reads(r, e):
+    pkg = ob.Package(reads_of(100 + r, n_pairs=600), reverse=True)
+    e.load_sequences(pkg.words(), pkg.n_seqs, 0, pkg.start())
+
+
+def all_reads(world):
+    out = []
+    for r in range(world):
+        out += reads_of(100 + r, n_pairs=600)
+    return ob.Package(out, reverse=True)
+
+
+def sdbg_of(e):
+    return (e.fetch(lib.BUF_SDBG_BYTES, np.uint8).tobytes(), e.fetch(lib.BUF_BUCKET_COUNT, np.uint64), e.fetch(lib.BUF_BUCKET_TIPS, np.uint64),
+            e.fetch(lib.BUF_BUCKET_LARGE, np.uint64))
+
+
+def check_sdbg(outs, want):
+    """ranks own contiguous ascending bucket ranges: their byte streams concatenate to the single-GPU stream"""
+    assert b"".join(o[0] for o in outs) == want["bytes"].tobytes()
+    assert np.array_equal(sum(o[1] for o in outs), want["bucket_items"])
+    assert np.array_equal(sum(o[2] for o in outs), want["bucket_tips"])
+    assert np.array_equal(sum(o[3] for o in outs), want["bucket_large"])
+    for a in range(len(outs)):  # every bucket has exactly one owner
+        for b in range(a + 1, len(outs)):
+            assert not np.any((outs[a][1] > 0) & (outs[b][1] > 0))
+
+
+@pytest.mark.parametrize("world,k,m,balance,opts", [
+    (2, 21, 2, 0, None), (3, 21, 2, STAGE_S1, None), (2, 21, 1, 0, None), (3, 31, 2, STAGE_S1, None), (1, 27, 2, 0, None),
+    (2, 21, 2, STAGE_S1, {"s1_seg": 0}),                      # classic stage 1: global byte map -> collected marks
+    (3, 21, 2, 0, {"s1_seg_bits": 8, "s1_seg_la": 0}),       # tiles give up -> classic fallback inside the dist path
+])
+def test_read2sdbg_ranks_as_threads(world, k, m, balance, opts):
+    def body(r, e, cm):
+        cm.setup(balance, k, m)
+        cm.read2sdbg(k, m)
+        r1, r2, _ = cm.read2sdbg(k, m)  # buffers are reused: same answer the second time
+        return sdbg_of(e) + (e.fetch(lib.BUF_MUL_HIST, np.int64) if m > 1 else None, int(r1.n_solid))
+
+    outs = run_ranks(world, load_reads, body, opts)
+    pkg = all_reads(world)
+    if m > 1:
+        s1 = ob.s1(pkg, k, m)
+        want = ob.s2(pkg, k, m, s1["is_solid"])
+        assert np.array_equal(sum(o[4] for o in outs), s1["hist"])
+        assert sum(o[5] for o in outs) == int(sum(bin(int(x)).count("1") for x in s1["is_solid"]))
+    else:
+        want = ob.s2(pkg, k, 1, None)
+    check_sdbg(outs, want)
+
+
+@pytest.mark.parametrize("world,k,m,mercy", [(2, 21, 2, 1), (3, 27, 3, 1), (2, 21, 2, 2)])
+def test_read2sdbg_mercy_ranks_as_threads(world, k, m, mercy):
+    def body(r, e, cm):
+        cm.setup(0, k, m)
+        _r1, _r2, nm = cm.read2sdbg(k, m, need_mercy=mercy)
+        return sdbg_of(e) + (nm,)
+
+    outs = run_ranks(world, load_reads, body)
+    pkg = all_reads(world)
+    s1 = ob.s1(pkg, k, m, tie_stable=mercy == 1)
+    n_want, solid = ob.s2_add_mercy(pkg, k, s1["is_solid"], s1["mercy"])
+    assert sum(o[4] for o in outs) == n_want and n_want > 0
+    check_sdbg(outs, ob.s2(pkg, k, m, solid))
+
+
+def test_rank_tagged_records_with_sparse_marks(monkeypatch):
+    """compact records that carry the source rank in spare key bits (the layout past 2^32 global positions)"""
+    monkeypatch.setenv("MHX_S1_FORCE_TAGGED", "1")
+    world, k, m = 3, 21, 2
+
+    def body(r, e, cm):
+        cm.setup(0, k, m)
+        cm.read2sdbg(k, m)
+        return sdbg_of(e)
+
+    outs = run_ranks(world, load_reads, body)
+    pkg = all_reads(world)
+    s1 = ob.s1(pkg, k, m)
+    check_sdbg(outs, ob.s2(pkg, k, m, s1["is_solid"]))
+
+
+@pytest.mark.parametrize("world,k,m", [(2, 21, 2), (3, 31, 3)])
+def test_count_ranks_as_threads(world, k, m):
+    def body(r, e, cm):
+        cm.setup(STAGE_COUNT, k, m)
+        cm.count(k, m)
+        return (e.fetch(lib.BUF_EDGES, np.uint32), e.fetch(lib.BUF_BUCKET_COUNT, np.uint64), e.fetch(lib.BUF_MUL_HIST, np.int64),
+                e.fetch(lib.BUF_FIRST_0_OUT, np.uint32), e.fetch(lib.BUF_LAST_0_IN, np.uint32))
+
+    outs = run_ranks(world, load_reads, body)
+    want = ob.count(all_reads(world), k, m)
+    assert np.array_equal(np.concatenate([o[0] for o in outs]).reshape(-1, want["wpe"]), want["edges"])
+    assert np.array_equal(sum(o[1] for o in outs), want["bucket_count"])
+    assert np.array_equal(sum(o[2] for o in outs), want["hist"])
+    assert np.array_equal(np.concatenate([o[3] for o in outs]), want["first_0_out"])
+    assert np.array_equal(np.concatenate([o[4] for o in outs]), want["last_0_in"])
+
+
+@pytest.mark.parametrize("world,k", [(2, 21), (3, 39)])
+def test_seq2sdbg_ranks_as_threads(world, k):
+    def load(r, e):
+        seqs, mult = _seqs_with_mult(50 + r)
+        pkg = ob.Package(seqs, reverse=False)
+        e.load_sequences(pkg.words(), pkg.n_seqs, 0, pkg.start())
+        e.load_multiplicity(mult)
+
+    def body(r, e, cm):
+        cm.setup(0, k, 0)
+        cm.seq2sdbg(k)
+        return sdbg_of(e)
+
+    outs = run_ranks(world, load, body)
+    seqs, mult = [], []
+    for r in range(world):
+        s, m_ = _seqs_with_mult(50 + r)
+        seqs += s
+        mult.append(m_)
+    check_sdbg(outs, ob.seq2sdbg(ob.Package(seqs, reverse=False), np.concatenate(mult), k))
+
+
+def test_rccl_transport_single_rank():
+    """dlopen(librccl) + ncclGetUniqueId + ncclCommInitRank + the RCCL code path of every collective, with one rank"""
+    k, m = 21, 2
+    e = lib.Engine(0)
+    load_reads(0, e)
+    cm = lib.Comm.rccl(e, lib.comm_unique_id(), 0, 1)
+    assert np.array_equal(cm.all_reduce([3, 5]), [3, 5])
+    cm.setup(STAGE_S1, k, m)
+    cm.read2sdbg(k, m)
+    got = sdbg_of(e)
+    cm.close()
+    e.close()
+    pkg = all_reads(1)
+    s1 = ob.s1(pkg, k, m)
+    check_sdbg([got], ob.s2(pkg, k, m, s1["is_solid"]))
+
+
+@pytest.mark.parametrize("ent", [e for e in gu.cases() if e["case"]["prog"] in ("count", "read2sdbg")][:6] +
+                         [e for e in gu.cases() if e["case"]["prog"] == "seq2sdbg" and e["case"].get("input") == "count" and not e["case"].get("mercy")][:2],
+                         ids=gu.case_id)
+@pytest.mark.parametrize("gpus", [2, 3])
+def test_cli_gpus_flag_reproduces_reference(ent, gpus, tmp_path, monkeypatch):
+    """`mhx_core --gpus N` (MHX_NUM_GPUS): one host thread per rank; here all ranks on device 0 (MHX_GPU_MAP)"""
+    monkeypatch.setenv("MHX_NUM_GPUS", str(gpus))
+    monkeypatch.setenv("MHX_GPU_MAP", ",".join("0" for _ in range(gpus)))
+    got = gu.run_case(gu.MHX_CORE, ent, str(tmp_path))
+    for key, want in ent.items():
+        if key in ("case", "mercy_cand_kmsort"):
+            continue
+        assert got.get(key) == want, key
