@@ -79,6 +79,9 @@ int mhx_append_sequences(mhx_ctx *, const uint32_t *packed, uint64_t n_words, ui
 /* per-sequence multiplicities for seq2sdbg (seq_to_sdbg.h:80) */
 int mhx_load_multiplicity(mhx_ctx *, const uint16_t *mult, uint64_t n_seqs);
 uint64_t mhx_num_sequences(const mhx_ctx *);
+/* common length of the loaded sequences, 0 when they differ (SequencePackage's fixed-length fast path,
+ * sequence_package.h:131-137) */
+uint32_t mhx_fixed_length(const mhx_ctx *);
 uint64_t mhx_num_bases(const mhx_ctx *);
 
 /* ---- result buffers (device resident until fetched) ---- */

@@ -1,5 +1,6 @@
 // C-ABI entry points of libmhx.so (declared in include/mhx.h) and context plumbing.
 #include <algorithm>
+#include <thread>
 #include <cstdarg>
 #include <cstdlib>
 
@@ -108,7 +109,7 @@ void upload_sequences(mhx_ctx *c, const uint32_t *packed, uint64_t n_words, uint
   s.n_words = n_words;
   s.words.reserve((n_words + kSeqPadWords) * 4);
   s.start.reserve((n_seqs + 2) * 8);
-  if (n_words) MHX_HIP(hipMemcpyAsync(s.words.p, packed, n_words * 4, hipMemcpyHostToDevice, st));
+  if (n_words) upload_pinned(c, s.words.p, packed, n_words * 4);
   MHX_HIP(hipMemsetAsync(s.words.as<uint32_t>() + n_words, 0, kSeqPadWords * 4, st));
   if (start_pos) {
     MHX_HIP(hipMemcpyAsync(s.start.p, start_pos, (n_seqs + 1) * 8, hipMemcpyHostToDevice, st));
@@ -243,8 +244,110 @@ __global__ void k_unpack_records(const uint32_t *__restrict__ rec, const uint64_
   out_words[w] = word;
 }
 
+// Host -> device copy of a large pageable (e.g. mmap'ed) buffer through two pinned staging buffers: a few host threads
+// fill one buffer from the page cache while the DMA engine drains the other.  A plain hipMemcpy of pageable memory
+// staged 400 MB of reads in ~0.3 s; this takes what the slower of (page-cache memcpy, PCIe) takes.
+void upload_pinned(mhx_ctx *c, void *d_dst, const void *h_src, size_t bytes) {
+  hipStream_t st = c->stream;
+  if (bytes < (8u << 20)) {
+    MHX_HIP(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, st));
+    MHX_HIP(hipStreamSynchronize(st));
+    return;
+  }
+  constexpr size_t kChunk = 32u << 20;
+  constexpr int kThreads = 4;
+  if (!c->pinned[0]) {
+    for (int i = 0; i < 2; ++i) {
+      MHX_HIP(hipHostMalloc(&c->pinned[i], kChunk, hipHostMallocDefault));
+      MHX_HIP(hipEventCreateWithFlags(&c->pinned_free[i], hipEventDisableTiming));
+    }
+  }
+  const char *src = static_cast<const char *>(h_src);
+  char *dst = static_cast<char *>(d_dst);
+  int b = 0;
+  bool used[2] = {false, false};
+  for (size_t off = 0; off < bytes; off += kChunk, b ^= 1) {
+    const size_t len = std::min(kChunk, bytes - off);
+    if (used[b]) MHX_HIP(hipEventSynchronize(c->pinned_free[b]));
+    char *stage = static_cast<char *>(c->pinned[b]);
+    std::thread th[kThreads - 1];
+    const size_t part = (len / kThreads + 63) & ~(size_t)63;
+    for (int t = 1; t < kThreads; ++t) {
+      const size_t lo = std::min(len, part * t), hi = std::min(len, part * (t + 1));
+      th[t - 1] = std::thread([=] { if (hi > lo) memcpy(stage + lo, src + off + lo, hi - lo); });
+    }
+    memcpy(stage, src + off, std::min(len, part));
+    for (auto &t : th) t.join();
+    MHX_HIP(hipMemcpyAsync(dst + off, stage, len, hipMemcpyHostToDevice, st));
+    MHX_HIP(hipEventRecord(c->pinned_free[b], st));
+    used[b] = true;
+  }
+  MHX_HIP(hipStreamSynchronize(st));
+}
+
+// every record holds exactly L bases (rw = 1 + ceil(L/16) words per record): one thread per OUTPUT word
+__global__ void k_unpack_fixed(const uint32_t *__restrict__ rec, uint64_t n_seqs, uint32_t L, uint32_t rw, int reverse,
+                               uint32_t *__restrict__ out_words, uint64_t n_out_words) {
+  const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= n_out_words) return;
+  const uint64_t b0 = w * 16, total = n_seqs * (uint64_t)L;
+  uint64_t sid = b0 / L;
+  uint32_t off = (uint32_t)(b0 - sid * L);
+  const uint32_t *r = rec + sid * rw + 1;
+  uint32_t word = 0;
+  for (int j = 0; j < 16; ++j) {
+    if (b0 + j >= total) break;
+    const uint32_t o = reverse ? L - 1 - off : off;
+    word |= ((r[o >> 4] >> (30 - 2 * (o & 15))) & 3u) << (30 - 2 * j);
+    if (++off == L) {
+      off = 0;
+      r += rw;
+    }
+  }
+  out_words[w] = word;
+}
+__global__ void k_check_fixed(const uint32_t *__restrict__ rec, uint64_t n_seqs, uint32_t L, uint32_t rw, uint32_t *__restrict__ bad) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_seqs && rec[i * rw] != L) atomicOr(bad, 1u);
+}
+
+// the common library: every read has the same length (checked on the device) -> no per-record tables at all
+static bool upload_bin_records_fixed(mhx_ctx *c, const uint32_t *records, uint64_t n_words, uint64_t n_seqs, int reverse) {
+  if (!n_seqs || !n_words) return false;
+  const uint32_t L = records[0], rw = 1 + (L + 15) / 16;
+  if (L == 0 || n_words != n_seqs * (uint64_t)rw) return false;
+  hipStream_t st = c->stream;
+  SeqSet &s = c->seqs;
+  DevBuf &d_rec = c->ws("bin_records", (n_words + 4) * 4);
+  upload_pinned(c, d_rec.p, records, n_words * 4);
+  uint32_t *bad = c->ws("bin_bad", 64).as<uint32_t>();
+  MHX_HIP(hipMemsetAsync(bad, 0, 4, st));
+  hipLaunchKernelGGL(k_check_fixed, dim3((unsigned)div_ceil(n_seqs, 256)), dim3(256), 0, st, d_rec.as<uint32_t>(), n_seqs, L, rw, bad);
+  const uint64_t bases = n_seqs * (uint64_t)L, n_out_words = div_ceil(bases, 16);
+  s.words.reserve((n_out_words + kSeqPadWords) * 4);
+  MHX_HIP(hipMemsetAsync(s.words.as<uint32_t>() + n_out_words, 0, kSeqPadWords * 4, st));
+  MHX_LAUNCH(c, "unpack_records", (double)n_words * 4 + (double)n_out_words * 4,
+             hipLaunchKernelGGL(k_unpack_fixed, dim3((unsigned)div_ceil(n_out_words, 256)), dim3(256), 0, st, d_rec.as<uint32_t>(), n_seqs, L, rw,
+                                reverse, s.words.as<uint32_t>(), n_out_words));
+  uint32_t h_bad = 1;
+  MHX_HIP(hipMemcpyAsync(&h_bad, bad, 4, hipMemcpyDeviceToHost, st));
+  MHX_HIP(hipStreamSynchronize(st));
+  if (h_bad) return false;  // some record has another length: the general path
+  s.n_seqs = n_seqs;
+  s.n_bases = bases;
+  s.n_words = n_out_words;
+  s.max_len = L;
+  s.fixed_len = L;
+  s.mult.used = 0;
+  s.h_start.clear();
+  s.start.reserve((n_seqs + 2) * 8);
+  upload_fixed_starts(c);
+  return true;
+}
+
 void upload_bin_records(mhx_ctx *c, const uint32_t *records, uint64_t n_words, uint64_t n_seqs, int reverse) {
   c->agg_valid = false;
+  if (upload_bin_records_fixed(c, records, n_words, n_seqs, reverse)) return;
   // lengths (host): an empty read becomes a 1-base 'A' (sequence_package.h:275-281)
   std::vector<uint64_t> rec_off(n_seqs + 1), start(n_seqs + 1);
   uint64_t pos = 0, bases = 0;
@@ -287,7 +390,7 @@ void upload_bin_records(mhx_ctx *c, const uint32_t *records, uint64_t n_words, u
   const uint64_t n_out_words = div_ceil(bases, 16);
   s.words.reserve((n_out_words + kSeqPadWords) * 4);
   s.start.reserve((n_seqs + 2) * 8);
-  MHX_HIP(hipMemcpyAsync(d_rec.p, src, src_words * 4, hipMemcpyHostToDevice, st));
+  upload_pinned(c, d_rec.p, src, src_words * 4);
   MHX_HIP(hipMemcpyAsync(d_off.p, rec_off.data(), (n_seqs + 1) * 8, hipMemcpyHostToDevice, st));
   MHX_HIP(hipMemcpyAsync(s.start.p, start.data(), (n_seqs + 1) * 8, hipMemcpyHostToDevice, st));
   MHX_HIP(hipMemsetAsync(s.words.as<uint32_t>() + n_out_words, 0, kSeqPadWords * 4, st));
@@ -383,6 +486,10 @@ void mhx_destroy(mhx_ctx *c) {
     (void)hipEventDestroy(pe.b);
   }
   for (auto ev : c->event_pool) (void)hipEventDestroy(ev);
+  for (int i = 0; i < 2; ++i) {
+    if (c->pinned[i]) (void)hipHostFree(c->pinned[i]);
+    if (c->pinned_free[i]) (void)hipEventDestroy(c->pinned_free[i]);
+  }
   (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -432,6 +539,7 @@ int mhx_load_multiplicity(mhx_ctx *c, const uint16_t *mult, uint64_t n_seqs) {
     MHX_HIP(hipStreamSynchronize(c->stream));
   })
 }
+uint32_t mhx_fixed_length(const mhx_ctx *c) { return c ? c->seqs.fixed_len : 0; }
 uint64_t mhx_num_sequences(const mhx_ctx *c) { return c->seqs.n_seqs; }
 uint64_t mhx_num_bases(const mhx_ctx *c) { return c->seqs.n_bases; }
 

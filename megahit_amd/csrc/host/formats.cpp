@@ -1,5 +1,9 @@
 #include "formats.h"
 
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <zlib.h>
 
 #include <algorithm>
@@ -89,15 +93,67 @@ std::vector<uint32_t> read_bin_file(const std::string &path) {
   return v;
 }
 
-std::vector<uint64_t> index_bin_records(const std::vector<uint32_t> &rec) {
+std::vector<uint64_t> index_bin_records(const uint32_t *rec, uint64_t n_words) {
   std::vector<uint64_t> off;
   uint64_t pos = 0;
-  while (pos < rec.size()) {
+  while (pos < n_words) {
     off.push_back(pos);
     pos += 1 + (rec[pos] + 15) / 16;
   }
-  if (pos != rec.size()) fatal("truncated .bin record stream");
+  if (pos != n_words) fatal("truncated .bin record stream");
   return off;
+}
+std::vector<uint64_t> index_bin_records(const std::vector<uint32_t> &rec) { return index_bin_records(rec.data(), rec.size()); }
+
+BinFile open_bin_file(const std::string &path) {
+  BinFile b;
+  int fd = open(path.c_str(), O_RDONLY);
+  if (fd < 0) fatal("Cannot open %s", path.c_str());
+  struct stat st;
+  if (fstat(fd, &st) != 0) fatal("Cannot stat %s", path.c_str());
+  b.n_words = (uint64_t)st.st_size / 4;
+  if (st.st_size > 0) {
+    void *m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+    if (m != MAP_FAILED) {
+      (void)madvise(m, (size_t)st.st_size, MADV_SEQUENTIAL);
+      (void)madvise(m, (size_t)st.st_size, MADV_WILLNEED);
+      b.map_ = m;
+      b.map_bytes_ = (uint64_t)st.st_size;
+      b.data = static_cast<const uint32_t *>(m);
+    } else {  // no mmap on this file system: read it
+      b.owned_.resize(b.n_words);
+      size_t got = 0;
+      while (got < b.n_words * 4) {
+        ssize_t r = pread(fd, reinterpret_cast<char *>(b.owned_.data()) + got, b.n_words * 4 - got, (off_t)got);
+        if (r <= 0) fatal("short read on %s", path.c_str());
+        got += (size_t)r;
+      }
+      b.data = b.owned_.data();
+    }
+  }
+  ::close(fd);
+  // candidate for the arithmetic index: the first record's size divides the stream (the caller confirms that every
+  // record really has that length before relying on it)
+  if (b.n_words) {
+    const uint32_t rw = 1 + (b.data[0] + 15) / 16;
+    if (b.data[0] && b.n_words % rw == 0) {
+      b.fixed_rw = rw;
+      b.n_reads = b.n_words / rw;
+    }
+  }
+  if (!b.fixed_rw) b.build_index();
+  return b;
+}
+void BinFile::build_index() {
+  fixed_rw = 0;
+  off = index_bin_records(data, n_words);
+  n_reads = off.size();
+}
+void BinFile::close() {
+  if (map_) munmap(map_, map_bytes_);
+  map_ = nullptr;
+  data = nullptr;
+  owned_.clear();
 }
 
 // buckets -> files: contiguous bucket ranges with roughly equal payload
@@ -136,45 +192,48 @@ void write_edges(const std::string &prefix, uint32_t k, uint32_t wpe, const uint
       continue;
     }
     int f = file_of[b];
-    fwrite(edges + pos * wpe, 4, bucket_count[b] * wpe, fs[f]);
+    if (fwrite(edges + pos * wpe, 4, bucket_count[b] * wpe, fs[f]) != bucket_count[b] * wpe) fatal("write error on %s.edges.%d", prefix.c_str(), f);
     meta << b << ' ' << f << ' ' << in_file[f] << ' ' << bucket_count[b] << '\n';
     in_file[f] += (int64_t)bucket_count[b];
     pos += bucket_count[b];
   }
   if (pos != n_edges) fatal("write_edges: bucket counts do not add up");
-  for (FILE *f : fs) fclose(f);
+  for (FILE *f : fs)
+    if (fclose(f) != 0) fatal("write error on %s.edges.*", prefix.c_str());
 }
 
-void write_cand(const std::string &prefix, const std::vector<uint32_t> &rec, const std::vector<uint64_t> &rec_off,
-                const uint32_t *first_0_out, const uint32_t *last_0_in, int64_t *n_cand, int64_t *n_has_tips) {
+void write_cand(const std::string &prefix, const BinFile &bin, const uint32_t *first_0_out, const uint32_t *last_0_in, int64_t *n_cand,
+                int64_t *n_has_tips) {
   FILE *f = fopen((prefix + ".cand").c_str(), "wb");
   if (!f) fatal("Cannot open %s.cand", prefix.c_str());
   *n_cand = *n_has_tips = 0;
   PackedSeqs one;
-  for (size_t i = 0; i < rec_off.size(); ++i) {
+  const uint32_t *rec = bin.data;
+  for (uint64_t i = 0; i < bin.n_reads; ++i) {
     uint32_t first = first_0_out[i], last = last_0_in[i];
     if (first != 0xFFFFFFFFu && last != 0xFFFFFFFFu) {
       ++*n_has_tips;
       if (last > first) {
         ++*n_cand;
-        uint32_t len = rec[rec_off[i]];
+        const uint64_t ro = bin.offset_of(i);
+        uint32_t len = rec[ro];
         one.words.clear();
         one.start.assign(1, 0);
-        one.append_packed(&rec[rec_off[i] + 1], len, true);  // the engine's package holds reversed reads
+        one.append_packed(&rec[ro + 1], len, true);  // the engine's package holds reversed reads
         uint32_t out_len = (uint32_t)one.n_bases();
-        fwrite(&out_len, 4, 1, f);
-        fwrite(one.words.data(), 4, (out_len + 15) / 16, f);
+        if (fwrite(&out_len, 4, 1, f) != 1 || fwrite(one.words.data(), 4, (out_len + 15) / 16, f) != (out_len + 15) / 16)
+          fatal("write error on %s.cand", prefix.c_str());
       }
     }
   }
-  fclose(f);
+  if (fclose(f) != 0) fatal("write error on %s.cand", prefix.c_str());
 }
 
 void write_counting(const std::string &prefix, const int64_t *hist) {
   FILE *f = fopen((prefix + ".counting").c_str(), "w");
   if (!f) fatal("Cannot open %s.counting", prefix.c_str());
   for (int i = 1; i <= 65535; ++i) fprintf(f, "%d %lld\n", i, (long long)hist[i]);
-  fclose(f);
+  if (fclose(f) != 0) fatal("write error on %s.counting", prefix.c_str());
 }
 
 void write_sdbg(const std::string &prefix, uint32_t k, uint32_t wpt, const uint8_t *bytes, uint64_t n_bytes, const uint64_t *bucket_off,
@@ -201,18 +260,21 @@ void write_sdbg(const std::string &prefix, uint32_t k, uint32_t wpt, const uint8
       continue;
     }
     int f = file_of[b];
-    if (weight[b]) fwrite(bytes + bucket_off[b], 1, weight[b], fs[f]);
+    if (weight[b] && fwrite(bytes + bucket_off[b], 1, weight[b], fs[f]) != weight[b]) fatal("write error on %s.sdbg.%d", prefix.c_str(), f);
     lines << b << ' ' << f << ' ' << in_file[f] << ' ' << b_items[b] << ' ' << b_tips[b] << ' ' << b_large[b] << '\n';
     in_file[f] += weight[b];
     total += weight[b];
     used_files = std::max(used_files, f + 1);
   }
   if (total != n_bytes) fatal("write_sdbg: bucket sizes do not add up (%llu vs %llu)", (unsigned long long)total, (unsigned long long)n_bytes);
-  for (FILE *f : fs) fclose(f);
+  for (FILE *f : fs)
+    if (fclose(f) != 0) fatal("write error on %s.sdbg.*", prefix.c_str());
   std::ofstream meta(prefix + ".sdbg_info");
   meta << "k " << k << "\n" << "words_per_tip_label " << wpt << "\n" << "num_buckets " << NB << "\n" << "num_files " << used_files << "\n";
   meta << lines.str();
   for (int i = 0; i < n_null; ++i) meta << "18446744073709551615 18446744073709551615 0 0 0 0\n";
+  meta.close();
+  if (!meta) fatal("write error on %s.sdbg_info", prefix.c_str());
 }
 
 static bool scan_field(std::istream &is, const char *name, long long *v) {

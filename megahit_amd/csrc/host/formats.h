@@ -28,14 +28,35 @@ void read_lib_info(const std::string &prefix, int64_t *total_bases, int64_t *tot
 std::vector<uint32_t> read_bin_file(const std::string &path);
 // offsets (in words) of each record in a .bin stream
 std::vector<uint64_t> index_bin_records(const std::vector<uint32_t> &rec);
+std::vector<uint64_t> index_bin_records(const uint32_t *rec, uint64_t n_words);
+// The record stream of a read library mapped read-only (no copy: the pages come straight from the page cache), with
+// the record offsets either arithmetic (every read has the same length: `fixed_rw` words per record, confirmed by the
+// caller) or indexed on demand.
+struct BinFile {
+  const uint32_t *data = nullptr;
+  uint64_t n_words = 0;
+  uint32_t fixed_rw = 0;          // != 0: record i starts at word i * fixed_rw
+  std::vector<uint64_t> off;      // else: offsets of all records
+  uint64_t n_reads = 0;
+  uint64_t offset_of(uint64_t i) const { return fixed_rw ? i * fixed_rw : off[i]; }
+  uint64_t end_offset(uint64_t i) const { return i >= n_reads ? n_words : offset_of(i); }
+  void build_index();             // variable lengths: scan the record headers
+  void close();
+ private:
+  void *map_ = nullptr;
+  uint64_t map_bytes_ = 0;
+  std::vector<uint32_t> owned_;
+  friend BinFile open_bin_file(const std::string &path);
+};
+BinFile open_bin_file(const std::string &path);
 
 // EdgeWriter + EdgeIoMetadata::Serialize (edge_writer.h:17-111, edge_io_meta.h:25-44); edges are in
 // bucket order; they are split over n_files files at bucket boundaries.
 void write_edges(const std::string &prefix, uint32_t k, uint32_t words_per_edge, const uint32_t *edges, uint64_t n_edges,
                  const uint64_t *bucket_count, int n_files);
 // KmerCounter::Lv0Postprocess (kmer_counter.cpp:383-403): reversed reads with first_0_out < last_0_in
-void write_cand(const std::string &prefix, const std::vector<uint32_t> &bin_records, const std::vector<uint64_t> &rec_off,
-                const uint32_t *first_0_out, const uint32_t *last_0_in, int64_t *n_cand, int64_t *n_has_tips);
+void write_cand(const std::string &prefix, const BinFile &bin, const uint32_t *first_0_out, const uint32_t *last_0_in, int64_t *n_cand,
+                int64_t *n_has_tips);
 // EdgeMultiplicityRecorder::DumpStat (edge_counter.h:44-52)
 void write_counting(const std::string &prefix, const int64_t *hist);
 // SdbgWriter::Finalize + SdbgMeta::Serialize (sdbg_writer.cpp:68-79, sdbg_meta.cpp:12-61)

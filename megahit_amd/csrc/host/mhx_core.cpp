@@ -176,12 +176,13 @@ void run_ranks(const RankSet &rs, Body body) {
     if ((call) != 0) throw std::string(mhx_last_error());     \
   } while (0)
 // contiguous shards of the reads with about equal numbers of record words
-std::vector<uint64_t> shard_reads(const std::vector<uint64_t> &rec_off, uint64_t total_words, int n) {
-  std::vector<uint64_t> first(n + 1, rec_off.size());
+std::vector<uint64_t> shard_reads(const mhxio::BinFile &bin, int n) {
+  std::vector<uint64_t> first(n + 1, bin.n_reads);
   first[0] = 0;
   for (int r = 1; r < n; ++r) {
-    const uint64_t target = total_words / n * r;
-    first[r] = std::lower_bound(rec_off.begin(), rec_off.end(), target) - rec_off.begin();
+    const uint64_t target = bin.n_words / n * r;
+    if (bin.fixed_rw) first[r] = std::min<uint64_t>(bin.n_reads, (target + bin.fixed_rw - 1) / bin.fixed_rw);
+    else first[r] = std::lower_bound(bin.off.begin(), bin.off.end(), target) - bin.off.begin();
   }
   return first;
 }
@@ -260,7 +261,7 @@ struct SdbgAcc {
         fetch<uint64_t>(c, MHX_BUF_BUCKET_TIPS), fetch<uint64_t>(c, MHX_BUF_BUCKET_LARGE), fetch<uint64_t>(c, MHX_BUF_W_COUNT), pr);
   }
   void add(const SdbgAcc &o) { add(o.bytes, o.off, o.items, o.tips, o.large, std::vector<uint64_t>(o.wc, o.wc + 10), o.r); }
-  void add(const std::vector<uint8_t> &b, const std::vector<uint64_t> &o, const std::vector<uint64_t> &it, const std::vector<uint64_t> &tp,
+  void add(std::vector<uint8_t> b, const std::vector<uint64_t> &o, const std::vector<uint64_t> &it, const std::vector<uint64_t> &tp,
            const std::vector<uint64_t> &lg, const std::vector<uint64_t> &w, const mhx_sdbg_result &pr) {
     for (int i = 0; i < MHX_NUM_BUCKETS; ++i) {
       if (it[i]) off[i] = o[i] + bytes.size();
@@ -269,7 +270,8 @@ struct SdbgAcc {
       large[i] += lg[i];
     }
     for (int i = 0; i < 10; ++i) wc[i] += w[i];
-    bytes.insert(bytes.end(), b.begin(), b.end());
+    if (bytes.empty()) bytes = std::move(b);  // the usual single pass: no second copy of the byte stream
+    else bytes.insert(bytes.end(), b.begin(), b.end());
     r.n_items += pr.n_items;
     r.n_sdbg += pr.n_sdbg;
     r.n_tips += pr.n_tips;
@@ -290,19 +292,35 @@ struct SdbgAcc {
   }
 };
 
-struct ReadLib {
-  std::vector<uint32_t> rec;
-  std::vector<uint64_t> off;
-};
-ReadLib load_read_lib(mhx_ctx *c, const std::string &prefix) {
+// The read library's record stream, mapped (no host copy), loaded into the GPU store reversed (kmer_counter.cpp:61).
+// When every read has the same length — the first record's size divides the stream and the device finds that length in
+// every record header — no per-read table is ever built on the host.
+mhxio::BinFile load_read_lib(mhx_ctx *c, const std::string &prefix) {
   int64_t bases, reads;
   mhxio::read_lib_info(prefix, &bases, &reads);
-  ReadLib lib;
-  lib.rec = mhxio::read_bin_file(prefix + ".bin");
-  lib.off = mhxio::index_bin_records(lib.rec);
-  if ((int64_t)lib.off.size() != reads) info("lib_info says %lld reads, .bin holds %zu", (long long)reads, lib.off.size());
-  CK(mhx_load_bin_records(c, lib.rec.data(), lib.rec.size(), lib.off.size(), 1 /* reversed, kmer_counter.cpp:61 */));
-  return lib;
+  mhxio::BinFile bin = mhxio::open_bin_file(prefix + ".bin");
+  if (bin.fixed_rw) {
+    CK(mhx_load_bin_records(c, bin.data, bin.n_words, bin.n_reads, 1));
+    if (bin.n_reads && mhx_fixed_length(c) != bin.data[0]) {  // lengths differ after all: index the records and load again
+      bin.build_index();
+      CK(mhx_load_bin_records(c, bin.data, bin.n_words, bin.n_reads, 1));
+    }
+  } else {
+    CK(mhx_load_bin_records(c, bin.data, bin.n_words, bin.n_reads, 1));
+  }
+  if ((int64_t)bin.n_reads != reads) info("lib_info says %lld reads, .bin holds %llu", (long long)reads, (unsigned long long)bin.n_reads);
+  return bin;
+}
+// the multi-GPU paths shard the records on the host: they need the true record offsets
+mhxio::BinFile open_indexed(const std::string &prefix) {
+  mhxio::BinFile bin = mhxio::open_bin_file(prefix + ".bin");
+  if (bin.fixed_rw) {  // confirm the arithmetic index on the host (one header word per record)
+    const uint32_t L = bin.data[0];
+    bool ok = true;
+    for (uint64_t i = 0; i < bin.n_reads && ok; ++i) ok = bin.data[i * bin.fixed_rw] == L;
+    if (!ok) bin.build_index();
+  }
+  return bin;
 }
 
 // ---------------------------------------------------------------------------
@@ -331,19 +349,17 @@ int main_kmer_count(int argc, char **argv) {
   if (g_num_gpus > 1) {
     const RankSet rs = rank_set();
     info("Preparing data...");
-    ReadLib lib;
-    lib.rec = mhxio::read_bin_file(o.get("read_lib_file") + ".bin");
-    lib.off = mhxio::index_bin_records(lib.rec);
-    const std::vector<uint64_t> first = shard_reads(lib.off, lib.rec.size(), rs.n);
-    info("%zu reads; Preparing data... Done. Time elapsed: %.4f", lib.off.size(), t.lap());
+    mhxio::BinFile lib = open_indexed(o.get("read_lib_file"));
+    const std::vector<uint64_t> first = shard_reads(lib, rs.n);
+    info("%llu reads; Preparing data... Done. Time elapsed: %.4f", (unsigned long long)lib.n_reads, t.lap());
     std::vector<std::vector<uint32_t>> edges(rs.n), f0(rs.n), l0(rs.n);
     std::vector<std::vector<uint64_t>> bc(rs.n);
     std::vector<std::vector<int64_t>> hist(rs.n);
     std::vector<mhx_count_result> res(rs.n);
     run_ranks(rs, [&](int r, mhx_ctx *c, mhx_comm *cm) {
       const uint64_t lo = first[r], hi = first[r + 1];
-      const uint64_t w0 = lo < lib.off.size() ? lib.off[lo] : lib.rec.size(), w1 = hi < lib.off.size() ? lib.off[hi] : lib.rec.size();
-      CKT(mhx_load_bin_records(c, lib.rec.data() + w0, w1 - w0, hi - lo, 1));
+      const uint64_t w0 = lib.end_offset(lo), w1 = lib.end_offset(hi);
+      CKT(mhx_load_bin_records(c, lib.data + w0, w1 - w0, hi - lo, 1));
       CKT(mhx_dist_setup(c, cm, MHX_STAGE_COUNT, k, m));
       CKT(mhx_dist_count(c, cm, k, m, &res[r]));
       edges[r] = fetch_t<uint32_t>(c, MHX_BUF_EDGES);
@@ -371,7 +387,7 @@ int main_kmer_count(int argc, char **argv) {
          (unsigned long long)r.n_distinct, (unsigned long long)r.n_edges, t.lap());
     mhxio::write_edges(out, k, r.words_per_edge, all_edges.data(), r.n_edges, bcount.data(), std::max(out_files(n_threads), std::min(rs.n, n_threads)));
     int64_t n_cand = 0, n_tips = 0;
-    mhxio::write_cand(out, lib.rec, lib.off, first_out.data(), last_in.data(), &n_cand, &n_tips);
+    mhxio::write_cand(out, lib, first_out.data(), last_in.data(), &n_cand, &n_tips);
     mhxio::write_counting(out, h.data());
     info("Total number of candidate reads: %lld (%lld)", (long long)n_cand, (long long)n_tips);
     info("Total number of solid edges: %llu", (unsigned long long)r.n_edges);
@@ -379,8 +395,9 @@ int main_kmer_count(int argc, char **argv) {
     return 0;
   }
   mhx_ctx *c = open_gpu();
+  info("Device ready. Time elapsed: %.4f", t.lap());
   info("Preparing data...");
-  ReadLib lib = load_read_lib(c, o.get("read_lib_file"));
+  mhxio::BinFile lib = load_read_lib(c, o.get("read_lib_file"));
   info("%llu reads; Preparing data... Done. Time elapsed: %.4f", (unsigned long long)mhx_num_sequences(c), t.lap());
   const size_t count_item_bytes = (size_t)(((2 * (k + 1) + 31) / 32 + 2 + 1) / 2 * 2) * 4;
   const auto ranges = plan_ranges(c, MHX_STAGE_COUNT, k, m, count_item_bytes, (double)mhx_num_bases(c));
@@ -407,7 +424,7 @@ int main_kmer_count(int argc, char **argv) {
   auto hist = fetch<int64_t>(c, MHX_BUF_MUL_HIST);
   mhxio::write_edges(out, k, r.words_per_edge, edges.data(), r.n_edges, bcount.data(), out_files(n_threads));
   int64_t n_cand = 0, n_tips = 0;
-  mhxio::write_cand(out, lib.rec, lib.off, first.data(), last.data(), &n_cand, &n_tips);
+  mhxio::write_cand(out, lib, first.data(), last.data(), &n_cand, &n_tips);
   mhxio::write_counting(out, hist.data());
   info("Total number of candidate reads: %lld (%lld)", (long long)n_cand, (long long)n_tips);
   info("Total number of solid edges: %llu", (unsigned long long)r.n_edges);
@@ -443,10 +460,9 @@ int main_read2sdbg(int argc, char **argv) {
   if (g_num_gpus > 1) {
     const RankSet rs = rank_set();
     info("Preparing data...");
-    std::vector<uint32_t> rec = mhxio::read_bin_file(o.get("read_lib_file") + ".bin");
-    std::vector<uint64_t> off = mhxio::index_bin_records(rec);
-    const std::vector<uint64_t> first = shard_reads(off, rec.size(), rs.n);
-    info("%zu reads; Preparing data... Done. Time elapsed: %.4f", off.size(), t.lap());
+    mhxio::BinFile lib = open_indexed(o.get("read_lib_file"));
+    const std::vector<uint64_t> first = shard_reads(lib, rs.n);
+    info("%llu reads; Preparing data... Done. Time elapsed: %.4f", (unsigned long long)lib.n_reads, t.lap());
     const int mercy_mode = !need_mercy ? 0 : (getenv("MHX_STABLE_TIES") ? 1 : 2);
     std::vector<SdbgAcc> part(rs.n);
     std::vector<std::vector<int64_t>> hist(rs.n);
@@ -454,8 +470,8 @@ int main_read2sdbg(int argc, char **argv) {
     std::vector<uint64_t> nm(rs.n, 0);
     run_ranks(rs, [&](int r, mhx_ctx *c, mhx_comm *cm) {
       const uint64_t lo = first[r], hi = first[r + 1];
-      const uint64_t w0 = lo < off.size() ? off[lo] : rec.size(), w1 = hi < off.size() ? off[hi] : rec.size();
-      CKT(mhx_load_bin_records(c, rec.data() + w0, w1 - w0, hi - lo, 1));
+      const uint64_t w0 = lib.end_offset(lo), w1 = lib.end_offset(hi);
+      CKT(mhx_load_bin_records(c, lib.data + w0, w1 - w0, hi - lo, 1));
       CKT(mhx_dist_setup(c, cm, m > 1 ? (mercy_mode ? MHX_STAGE_S1_MERCY : MHX_STAGE_S1) : MHX_STAGE_S2, k, m));
       mhx_sdbg_result r2{};
       CKT(mhx_dist_read2sdbg(c, cm, k, m, mercy_mode, &r1[r], &r2, &nm[r]));
@@ -487,6 +503,7 @@ int main_read2sdbg(int argc, char **argv) {
     return 0;
   }
   mhx_ctx *c = open_gpu();
+  info("Device ready. Time elapsed: %.4f", t.lap());
   info("Preparing data...");
   load_read_lib(c, o.get("read_lib_file"));
   info("%llu reads, %llu total bases; Preparing data... Done. Time elapsed: %.4f", (unsigned long long)mhx_num_sequences(c),

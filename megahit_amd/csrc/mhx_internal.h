@@ -102,6 +102,9 @@ struct mhx_ctx {
   // tuning knobs (mhx_set_option): explicit value, else environment MHX_<NAME>, else the default
   std::map<std::string, long long> options;
   long long opt(const char *name, long long dflt) const;
+  // pinned staging buffers of upload_pinned (capi.hip)
+  void *pinned[2] = {nullptr, nullptr};
+  hipEvent_t pinned_free[2] = {nullptr, nullptr};
   // profiling
   bool profiling = false;
   std::vector<mhx::PendingEvent> pending;
@@ -216,6 +219,7 @@ int run_gen_mercy(mhx_ctx *c, uint32_t k, const uint32_t *cand_packed, uint64_t 
 void upload_sequences(mhx_ctx *c, const uint32_t *packed, uint64_t n_words, uint64_t n_seqs, uint32_t fixed_len,
                       const uint64_t *start_pos);
 void upload_fixed_starts(mhx_ctx *c);
+void upload_pinned(mhx_ctx *c, void *d_dst, const void *h_src, size_t bytes);
 void append_sequences(mhx_ctx *c, const uint32_t *packed, uint64_t n_words, uint64_t n_new, uint32_t fixed_len, const uint64_t *start_pos,
                       const uint16_t *mult);
 void upload_bin_records(mhx_ctx *c, const uint32_t *records, uint64_t n_words, uint64_t n_seqs, int reverse);

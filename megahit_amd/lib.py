@@ -80,6 +80,7 @@ SYMBOLS = {
     "mhx_append_sequences": (C.c_int, [_P, _P, C.c_uint64, C.c_uint64, C.c_uint32, _P, _P]),
     "mhx_load_multiplicity": (C.c_int, [_P, _P, C.c_uint64]),
     "mhx_num_sequences": (C.c_uint64, [_P]),
+    "mhx_fixed_length": (C.c_uint32, [_P]),
     "mhx_num_bases": (C.c_uint64, [_P]),
     "mhx_buffer_bytes": (C.c_uint64, [_P, C.c_int]),
     "mhx_fetch": (C.c_int, [_P, C.c_int, _P, C.c_uint64, C.c_uint64]),
