@@ -440,7 +440,8 @@ __global__ __launch_bounds__(256) void k_s1_seg(const uint32_t *__restrict__ ite
   __shared__ uint32_t s_bad, s_ncreated, s_agg_cur, s_mark_cur;
   const int tid = threadIdx.x, lane = tid & (kWave - 1);
   const uint64_t lanemask_lt = (1ull << lane) - 1;
-  uint2 *const agg_out = AGG ? a.agg_raw + (size_t)blockIdx.x * a.agg_cap : nullptr;
+  // the workgroup's output region (in the spare sort buffer): marks grow from its front, aggregated items from its back
+  uint2 *const agg_end = AGG ? a.agg_raw + (size_t)(blockIdx.x + 1) * a.agg_cap : nullptr;
   for (int i = tid; i < NSLOT; i += 256) keys[i] = kSegEmpty;
   for (int i = tid; i < NSLOT / 2; i += 256) cnts[i] = 0;
   for (int i = tid; i < kSegHist; i += 256) lhist[i] = 0;
@@ -493,7 +494,8 @@ __global__ __launch_bounds__(256) void k_s1_seg(const uint32_t *__restrict__ ite
     mbase = __shfl(mbase, 0, kWave);
     if (mk) {
       const uint32_t at = mbase + (uint32_t)__builtin_popcountll(mm & lanemask_lt);
-      if (at < a.marks_cap) marks_out[at] = abs - 1;
+      if (at + s_agg_cur < a.marks_cap) marks_out[at] = abs - 1;
+      else atomicOr(a.err, 2u);
     }
   };
   // the (k+1)-mer head.S.tail of a key, chars MSB-first in 64 bits
@@ -704,7 +706,9 @@ __global__ __launch_bounds__(256) void k_s1_seg(const uint32_t *__restrict__ ite
       uint32_t wbase = 0;
       if (lane == 0 && tot) wbase = atomicAdd(&s_agg_cur, tot);
       wbase = __shfl(wbase, 0, kWave);
-      agg_ok = wbase + tot <= a.agg_cap;  // a region overflow (absurdly skewed input) sends the host to the classic path
+      // (marks in front, items at the back: a record yields a mark or a share of an item, never both, so the region —
+      // 12 bytes per record of the workgroup — only overflows when the tiles are spread very unevenly; then: classic path)
+      agg_ok = wbase + tot + (marks_out ? s_mark_cur : 0u) <= a.agg_cap;
       if (!agg_ok && lane == 0) atomicOr(a.err, 1u);
       agg_at = wbase + incl - my_agg;
     }
@@ -726,10 +730,10 @@ __global__ __launch_bounds__(256) void k_s1_seg(const uint32_t *__restrict__ ite
             const uint64_t x = edge_of(key), xr = rc64(x, k + 1);
             const uint64_t mul = cnt > MHX_MAX_MUL ? (uint64_t)MHX_MAX_MUL : cnt;
             const uint64_t f = ((x << 2) & mask_k) | (1ull << 19) | ((x >> 62) << 16) | mul;  // k-mer x[1..k], W = x[0]
-            agg_out[agg_at++] = make_uint2((uint32_t)(f >> 32), (uint32_t)f);
+            agg_end[-1 - (long)agg_at++] = make_uint2((uint32_t)(f >> 32), (uint32_t)f);
             if (x != xr) {  // palindromic (k+1)-mers emit the forward item only (read_to_sdbg_s2.cpp:385-423)
               const uint64_t b = ((xr << 2) & mask_k) | (1ull << 19) | ((xr >> 62) << 16) | mul;
-              agg_out[agg_at++] = make_uint2((uint32_t)(b >> 32), (uint32_t)b);
+              agg_end[-1 - (long)agg_at++] = make_uint2((uint32_t)(b >> 32), (uint32_t)b);
             }
           }
         }
@@ -755,16 +759,13 @@ __global__ __launch_bounds__(256) void k_s1_seg(const uint32_t *__restrict__ ite
     for (int i = tid; i < kSegHist; i += 256)
       if (lhist[i]) atomicAdd(&a.hist[i], (unsigned long long)lhist[i]);
     if (AGG && tid == 0) a.agg_counts[blockIdx.x] = s_agg_cur < a.agg_cap ? s_agg_cur : a.agg_cap;
-    if (marks_out && tid == 0) {
-      if (s_mark_cur > a.marks_cap) atomicOr(a.err, 2u);  // cannot happen: the region holds every record of the workgroup
-      a.marks_counts[blockIdx.x] = s_mark_cur < a.marks_cap ? s_mark_cur : a.marks_cap;
-    }
+    if (marks_out && tid == 0) a.marks_counts[blockIdx.x] = s_mark_cur < a.marks_cap ? s_mark_cur : a.marks_cap;
   }
 }
 
 // regions of k_s1_seg -> one dense array: block (r, j) copies slice j of region r behind the items of the regions before it
 __global__ __launch_bounds__(256) void k_agg_compact(const uint2 *__restrict__ raw, uint32_t cap, const uint32_t *__restrict__ counts,
-                                                    uint2 *__restrict__ dense) {
+                                                    uint2 *__restrict__ dense, int from_back) {
   __shared__ uint64_t sm[256 / kWave + 1];
   const uint32_t r = blockIdx.x;
   uint64_t part = 0;
@@ -773,7 +774,7 @@ __global__ __launch_bounds__(256) void k_agg_compact(const uint2 *__restrict__ r
   block_exclusive_sum<uint64_t, 256>(part, sm, &off);
   const uint32_t n = counts[r];
   const uint2 *src = raw + (size_t)r * cap;
-  for (uint32_t i = blockIdx.y * 256 + threadIdx.x; i < n; i += gridDim.y * 256) dense[off + i] = src[i];
+  for (uint32_t i = blockIdx.y * 256 + threadIdx.x; i < n; i += gridDim.y * 256) dense[off + i] = from_back ? src[cap - 1 - i] : src[i];
 }
 
 // multi-GPU, sparse marks, classic path: positions of the set bytes of the (global) byte map, appended in any order
@@ -1195,12 +1196,14 @@ int s1_process(mhx_ctx *c, uint32_t k, uint32_t m, int want_mercy, uint32_t *buf
     const uint32_t eq_mask1 = (kmer_bits > 32 ? ~(0xFFFFFFFFu >> (kmer_bits - 32)) : 0u) | 63u;
     const bool agg_on = agg && mode != 2;
     const unsigned grid = (unsigned)std::min<uint64_t>(n_work, per == 4 ? 256 * 6 : 256 * 3);
+    // per-workgroup output regions in the spare sort buffer (S*4 >= 12 bytes per record, outputs are 8-byte entries)
+    const uint32_t region = (uint32_t)std::min<uint64_t>(n_items * (uint64_t)S * 4 / 8 / grid, 0xFFFFFFF0u);
     uint2 *raw = nullptr;
     uint32_t *counts = nullptr;
     if (agg_on) {
       seg_grid = grid;
-      seg_cap = (uint32_t)std::min<uint64_t>(agg_bound / grid + 4096, 0xFFFFFFF0u);
-      raw = c->ws("s2_agg_raw", (size_t)grid * seg_cap * 8).as<uint2>();
+      seg_cap = region;
+      raw = reinterpret_cast<uint2 *>(spare);
       counts = c->ws("s2_agg_counts", (size_t)grid * 4).as<uint32_t>();
     }
     // sparse marks go to the spare sort buffer (>= 12 bytes per record, a record yields at most one 8-byte mark): a
@@ -1210,7 +1213,7 @@ int s1_process(mhx_ctx *c, uint32_t k, uint32_t m, int want_mercy, uint32_t *buf
     uint32_t mcap = 0;
     if (sparse && mode != 2) {
       mraw = reinterpret_cast<unsigned long long *>(spare);
-      mcap = (uint32_t)std::min<uint64_t>(n_items * (uint64_t)S * 4 / 8 / grid, 0xFFFFFFF0u);
+      mcap = region;
       mcounts = c->ws("s1_mark_counts", (size_t)grid * 4).as<uint32_t>();
       seg_grid = grid;
       seg_mcap = mcap;
@@ -1279,7 +1282,7 @@ int s1_process(mhx_ctx *c, uint32_t k, uint32_t m, int want_mercy, uint32_t *buf
         if (seg_marks)
           MHX_LAUNCH(c, "marks_compact", (double)seg_marks * 16,
                      hipLaunchKernelGGL(k_agg_compact, dim3(seg_grid, 8), dim3(256), 0, st, reinterpret_cast<const uint2 *>(spare), seg_mcap,
-                                        c->work["s1_mark_counts"].as<uint32_t>(), reinterpret_cast<uint2 *>(dense + marks_prev)));
+                                        c->work["s1_mark_counts"].as<uint32_t>(), reinterpret_cast<uint2 *>(dense + marks_prev), 0));
         c->n_marks = marks_prev + seg_marks;
       }
       if (!e && agg) {  // pack the workgroups' regions behind the items of the earlier passes
@@ -1288,8 +1291,8 @@ int s1_process(mhx_ctx *c, uint32_t k, uint32_t m, int want_mercy, uint32_t *buf
         uint2 *dense = grow_preserving(c, c->work["s2_agg_items"], (agg_prev + total) * 8 + 64, agg_prev * 8).as<uint2>();
         if (total)
           MHX_LAUNCH(c, "agg_compact", (double)total * 16,
-                     hipLaunchKernelGGL(k_agg_compact, dim3(seg_grid, 8), dim3(256), 0, st, c->work["s2_agg_raw"].as<uint2>(), seg_cap,
-                                        c->work["s2_agg_counts"].as<uint32_t>(), dense + agg_prev));
+                     hipLaunchKernelGGL(k_agg_compact, dim3(seg_grid, 8), dim3(256), 0, st, reinterpret_cast<const uint2 *>(spare), seg_cap,
+                                        c->work["s2_agg_counts"].as<uint32_t>(), dense + agg_prev, 1));
         const uint64_t agg_n = agg_prev + total;
         MHX_HIP(hipMemcpyAsync(agg_cursor, &agg_n, 8, hipMemcpyHostToDevice, st));
         MHX_HIP(hipStreamSynchronize(st));  // agg_n is a stack variable

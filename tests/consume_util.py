@@ -30,14 +30,21 @@ def read_fasta(path):
     return recs
 
 
-def canonical_contigs(path):
-    """Order- and strand-independent view of a contig file: sorted (min(seq, rc(seq)), flag, multi) tuples."""
-    out = []
+def canonical_contigs(path, kk=31):
+    """Order-, strand- and rotation-independent view of a contig file: (sorted (length, flag, multi) of the contigs, the
+    set of canonical kk-mers of all of them).  The reference prints a circular contig as the cycle plus an overlap,
+    starting wherever its traversal happened to start (thread timing), so whole sequences are not comparable; the
+    k-mer set, the lengths and the multiplicities are."""
+    meta, kmers = [], set()
     for name, seq in read_fasta(path):
-        rc = seq.translate(_COMP)[::-1]
         m = re.search(r"flag=(\d+) multi=([0-9.]+)", name)
-        out.append((min(seq, rc), m.group(1) if m else "", m.group(2) if m else ""))
-    return sorted(out)
+        meta.append((len(seq), m.group(1) if m else "", m.group(2) if m else ""))
+        rc = seq.translate(_COMP)[::-1]
+        n = len(seq)
+        for i in range(n - kk + 1):
+            a, b = seq[i:i + kk], rc[n - kk - i:n - i]
+            kmers.add(a if a < b else b)
+    return sorted(meta), kmers
 
 
 def run_orchestrator(bin_dir, out_dir, extra=(), env=None):
