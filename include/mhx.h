@@ -98,7 +98,24 @@ enum mhx_buffer {
   MHX_BUF_BUCKET_TIPS = 10, /* uint64[65536] */
   MHX_BUF_BUCKET_LARGE = 11,/* uint64[65536] */
   MHX_BUF_SORTED_ITEMS = 12,/* uint32[n_items][item_words]: the sorted lv2 items of the last engine (tests) */
-  MHX_BUF_W_COUNT = 13      /* uint64[9] + ones_in_last: uint64[10] (sdbg_meta.h:41-48) */
+  MHX_BUF_W_COUNT = 13,     /* uint64[9] + ones_in_last: uint64[10] (sdbg_meta.h:41-48) */
+  /* device-resident SdBG hand-over, filled by mhx_sdbg_build_index (below); layouts = the reference's in-memory ones */
+  MHX_BUF_SDBG_W = 20,          /* uint64[ceil(n/16)]: 4 bits per item, item i at bits 4*(i%16) (sdbg_raw_content.h:22) */
+  MHX_BUF_SDBG_LAST = 21,       /* uint64[ceil(n/64)]: bit i%64 of word i/64 */
+  MHX_BUF_SDBG_TIP = 22,        /* same */
+  MHX_BUF_SDBG_INVALID = 23,    /* tip | (W == 0): SDBG::invalid_ after LoadFromFile (sdbg.h:33-60) */
+  MHX_BUF_SDBG_SMALL_MUL = 24,  /* uint8[n], 255 = look in MUL (sdbg_raw_content.cpp:72-83) */
+  MHX_BUF_SDBG_MUL = 25,        /* uint16[n]: SDBG::EdgeMultiplicity */
+  MHX_BUF_SDBG_TIP_LABELS = 26, /* uint32[n_tips][words_per_tip_label], chars reversed inside each word (:85-91) */
+  MHX_BUF_SDBG_PREFIX_LKT = 27, /* int64[65536][2]: first / last item of every bucket (sdbg.h:38-49) */
+  MHX_BUF_SDBG_RS_W_L2 = 28,    /* int64[9][num_l2_w]   kmlib::RankAndSelect<4,9> over W (kmrns.h:118-175) */
+  MHX_BUF_SDBG_RS_W_L1 = 29,    /* uint16[9][num_l1_w] */
+  MHX_BUF_SDBG_RS_W_SEL = 30,   /* uint32[]: select samples of character c at [w_sel_offset[c], w_sel_offset[c+1]) */
+  MHX_BUF_SDBG_RS_LAST_L2 = 31, /* int64[num_l2_bits]   RankAndSelect<1,2> over last */
+  MHX_BUF_SDBG_RS_LAST_L1 = 32, /* uint16[num_l1_bits] */
+  MHX_BUF_SDBG_RS_LAST_SEL = 33,/* uint32[last_sel_count] */
+  MHX_BUF_SDBG_RS_TIP_L2 = 34,  /* rank-only structure over tip */
+  MHX_BUF_SDBG_RS_TIP_L1 = 35
 };
 /* bytes currently held in a result buffer (0 if absent) */
 uint64_t mhx_buffer_bytes(const mhx_ctx *, int which);
@@ -156,6 +173,29 @@ int mhx_seq2sdbg(mhx_ctx *, uint32_t k, mhx_sdbg_result *out);
  * the mercy edges (multiplicity 1) to the loaded set; *n_mercy receives their number. */
 int mhx_gen_mercy_edges(mhx_ctx *, uint32_t k, const uint32_t *cand_packed, uint64_t cand_words,
                         uint64_t n_cand, const uint64_t *cand_start, uint64_t *n_mercy);
+
+/* ---- device-resident SdBG hand-over.  Builds, on the GPU and from the SdBG the handle holds
+ * (MHX_BUF_SDBG_BYTES + MHX_BUF_BUCKET_* of the last stage-2 / seq2sdbg call, or a stream installed with
+ * mhx_sdbg_load_bytes), everything SDBG::LoadFromFile builds on one CPU thread: the W / last / tip / multiplicity /
+ * tip-label arrays of LoadSdbgRawContent (sdbg_raw_content.cpp:18-96) and the rank/select tables, prefix table, f and
+ * rank_f of sdbg.h:26-61 over kmlib/kmrns.h:118-175 — in the reference's own layouts (MHX_BUF_SDBG_*), so a
+ * downstream stage can adopt them without reading .sdbg files back. ---- */
+typedef struct {
+  uint64_t n_items, n_tips, n_large;
+  uint32_t k, words_per_tip_label;
+  int use_full_mul;          /* what the reference would choose: n_large >= 0.08 n (sdbg_raw_content.cpp:29-30) */
+  uint64_t num_l1_w, num_l2_w;       /* table lengths per character of the W structure */
+  uint64_t num_l1_bits, num_l2_bits; /* ... of the last / tip structures */
+  uint64_t w_char_count[9];          /* kmrns char_count_ (character 0 includes the zero padding of the last word) */
+  uint64_t w_sel_offset[10];
+  uint64_t ones_in_last, ones_in_tip, last_sel_count;
+  long long f[6], rank_f[6];         /* sdbg.h:482-483 */
+} mhx_sdbg_index_info;
+int mhx_sdbg_build_index(mhx_ctx *, uint32_t k, mhx_sdbg_index_info *out);
+/* install an SdBG produced elsewhere (e.g. read back from .sdbg.* files: bucket byte ranges back to back) as the handle's
+ * current SdBG; the four tables have 65536 entries (starting byte, items, tips, large multiplicities per bucket) */
+int mhx_sdbg_load_bytes(mhx_ctx *, const uint8_t *bytes, uint64_t n_bytes, const uint64_t *bucket_offset, const uint64_t *bucket_items,
+                        const uint64_t *bucket_tips, const uint64_t *bucket_large);
 
 /* B3: sort n fixed-width records in place on the GPU, ascending by the first key_words words
  * (lexicographic on uint32, as Substr::operator<, kmsort_selector.cpp:18-27); aux words ride

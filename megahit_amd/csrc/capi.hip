@@ -608,6 +608,19 @@ int mhx_gen_mercy_edges(mhx_ctx *c, uint32_t k, const uint32_t *cand_packed, uin
   })
 }
 
+int mhx_sdbg_build_index(mhx_ctx *c, uint32_t k, mhx_sdbg_index_info *out) {
+  MHX_TRY({
+    MHX_HIP(hipSetDevice(c->device));
+    mhx::sdbg_build_index(c, k, out);
+  })
+}
+int mhx_sdbg_load_bytes(mhx_ctx *c, const uint8_t *bytes, uint64_t n_bytes, const uint64_t *bucket_offset, const uint64_t *bucket_items,
+                        const uint64_t *bucket_tips, const uint64_t *bucket_large) {
+  MHX_TRY({
+    MHX_HIP(hipSetDevice(c->device));
+    mhx::sdbg_load_bytes(c, bytes, n_bytes, bucket_offset, bucket_items, bucket_tips, bucket_large);
+  })
+}
 int mhx_sort_records(mhx_ctx *c, uint32_t *host_items, uint64_t n, uint32_t key_words, uint32_t aux_words) {
   MHX_TRY({
     MHX_HIP(hipSetDevice(c->device));

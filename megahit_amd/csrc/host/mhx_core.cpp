@@ -187,6 +187,14 @@ std::vector<uint64_t> shard_reads(const mhxio::BinFile &bin, int n) {
   return first;
 }
 
+// The outputs are on disk and closed: leave without tearing the HIP runtime down (freeing tens of GB of device memory
+// page by page costs more than the GPU stages of a small job).  MHX_CLEAN_EXIT=1 destroys the handle first.
+[[noreturn]] void finish(mhx_ctx *c) {
+  if (getenv("MHX_CLEAN_EXIT")) mhx_destroy(c);
+  fflush(nullptr);
+  _exit(0);
+}
+
 template <class T>
 std::vector<T> fetch_t(mhx_ctx *c, int which) {  // the throwing flavour for rank threads
   uint64_t bytes = mhx_buffer_bytes(c, which);
@@ -429,8 +437,7 @@ int main_kmer_count(int argc, char **argv) {
   info("Total number of candidate reads: %lld (%lld)", (long long)n_cand, (long long)n_tips);
   info("Total number of solid edges: %llu", (unsigned long long)r.n_edges);
   info("Postprocess done. Time elapsed: %.4f", t.lap());
-  mhx_destroy(c);
-  return 0;
+  finish(c);
 }
 
 int main_read2sdbg(int argc, char **argv) {
@@ -553,8 +560,7 @@ int main_read2sdbg(int argc, char **argv) {
   info("Stage 2 done (%llu items). Time elapsed: %.4f", (unsigned long long)acc.r.n_items, t.lap());
   acc.write(out, k, out_files(n_threads));
   info("Postprocess done. Time elapsed: %.4f", t.lap());
-  mhx_destroy(c);
-  return 0;
+  finish(c);
 }
 
 int main_seq2sdbg(int argc, char **argv) {
@@ -732,8 +738,7 @@ int main_seq2sdbg(int argc, char **argv) {
   info("GPU seq2sdbg done (%llu items). Time elapsed: %.4f", (unsigned long long)acc.r.n_items, t.lap());
   acc.write(out, k, out_files(n_threads));
   info("Postprocess done. Time elapsed: %.4f", t.lap());
-  mhx_destroy(c);
-  return 0;
+  finish(c);
 }
 
 }  // namespace

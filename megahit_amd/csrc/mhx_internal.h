@@ -207,6 +207,9 @@ DevBuf &grow_preserving(mhx_ctx *c, DevBuf &b, size_t bytes, size_t keep);
 void stash_route_records(mhx_ctx *c, const void *src, uint64_t n, int hi_bit);
 void mercy_adopt_routed(mhx_ctx *c, const long long *recv, uint64_t n);
 void s1_apply_marks(mhx_ctx *c, const unsigned long long *recv, uint64_t n);
+int sdbg_build_index(mhx_ctx *c, uint32_t k, mhx_sdbg_index_info *out);
+int sdbg_load_bytes(mhx_ctx *c, const uint8_t *bytes, uint64_t n_bytes, const uint64_t *off, const uint64_t *items, const uint64_t *tips,
+                    const uint64_t *large);
 
 // ---- engines ----
 int run_count(mhx_ctx *c, uint32_t k, uint32_t m, mhx_count_result *out);

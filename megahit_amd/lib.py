@@ -27,6 +27,9 @@ BUF_BUCKET_OFFSET = 9
 BUF_BUCKET_TIPS = 10
 BUF_BUCKET_LARGE = 11
 BUF_SORTED_ITEMS = 12
+(BUF_SDBG_W, BUF_SDBG_LAST, BUF_SDBG_TIP, BUF_SDBG_INVALID, BUF_SDBG_SMALL_MUL, BUF_SDBG_MUL, BUF_SDBG_TIP_LABELS, BUF_SDBG_PREFIX_LKT,
+ BUF_SDBG_RS_W_L2, BUF_SDBG_RS_W_L1, BUF_SDBG_RS_W_SEL, BUF_SDBG_RS_LAST_L2, BUF_SDBG_RS_LAST_L1, BUF_SDBG_RS_LAST_SEL, BUF_SDBG_RS_TIP_L2,
+ BUF_SDBG_RS_TIP_L1) = range(20, 36)
 BUF_W_COUNT = 13
 
 
@@ -52,6 +55,14 @@ class SdbgResult(C.Structure):
 class KernelStat(C.Structure):
     _fields_ = [("name", C.c_char * 48), ("launches", C.c_uint32), ("total_ms", C.c_double),
                 ("algo_bytes", C.c_double)]
+
+
+class SdbgIndexInfo(C.Structure):
+    _fields_ = [("n_items", C.c_uint64), ("n_tips", C.c_uint64), ("n_large", C.c_uint64), ("k", C.c_uint32),
+                ("words_per_tip_label", C.c_uint32), ("use_full_mul", C.c_int), ("num_l1_w", C.c_uint64), ("num_l2_w", C.c_uint64),
+                ("num_l1_bits", C.c_uint64), ("num_l2_bits", C.c_uint64), ("w_char_count", C.c_uint64 * 9),
+                ("w_sel_offset", C.c_uint64 * 10), ("ones_in_last", C.c_uint64), ("ones_in_tip", C.c_uint64),
+                ("last_sel_count", C.c_uint64), ("f", C.c_longlong * 6), ("rank_f", C.c_longlong * 6)]
 
 
 class DistItems(C.Structure):
@@ -104,6 +115,8 @@ SYMBOLS = {
     "mhx_dist_apply_routed": (C.c_int, [_P, C.c_int, C.c_uint64]),
     "mhx_device_pointer": (_P, [_P, C.c_int]),
     "mhx_adopt_is_solid_slice": (C.c_int, [_P, _P, C.c_uint64]),
+    "mhx_sdbg_build_index": (C.c_int, [_P, C.c_uint32, C.POINTER(SdbgIndexInfo)]),
+    "mhx_sdbg_load_bytes": (C.c_int, [_P, _P, C.c_uint64, _P, _P, _P, _P]),
     "mhx_comm_unique_id": (C.c_int, [_P]),
     "mhx_comm_init_rank": (_P, [_P, _P, C.c_int, C.c_int]),
     "mhx_comm_local_group": (C.c_int, [C.c_int, _P, _P]),
@@ -339,6 +352,17 @@ class Engine:
 
     def trim(self):
         self._chk(self.lib.mhx_trim(self.h))
+
+    def sdbg_build_index(self, k):
+        """W/last/tip/mul arrays + rank/select tables on the device (include/mhx.h: mhx_sdbg_build_index)."""
+        info = SdbgIndexInfo()
+        self._chk(self.lib.mhx_sdbg_build_index(self.h, k, C.byref(info)))
+        return info
+
+    def sdbg_load_bytes(self, data, offset, items, tips, large):
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        tabs = [np.ascontiguousarray(t, dtype=np.uint64) for t in (offset, items, tips, large)]
+        self._chk(self.lib.mhx_sdbg_load_bytes(self.h, _ptr(data), data.size, *[_ptr(t) for t in tabs]))
 
     def set_option(self, name, value):
         """Tuning / diagnostic knob of this handle (include/mhx.h: mhx_set_option)."""

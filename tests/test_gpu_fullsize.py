@@ -94,3 +94,21 @@ def test_fullsize_read2sdbg_need_mercy(full):
     nm = [int(l.split(":")[-1].split()[0]) for l in log.splitlines() if "Number mercy" in l]
     assert nm and nm[-1] == want["number_mercy"]
     check_sdbg(out, want)
+
+
+def test_fullsize_sdbg_index_equals_reference_loader(full, engine):
+    """SURVEY section 8f N1 at BASELINE configs[1] size: the device-built W/last/tip/multiplicity arrays and rank/select
+    tables of the 59.9 M-record SdBG equal what the reference's SDBG::LoadFromFile builds from the same files."""
+    import test_gpu_sdbg_index as tsi
+    if not os.path.exists(tsi.REF_DUMP):
+        pytest.skip("oracle/_ref/ref_sdbg_dump not built")
+    out = os.path.join(full, "r2s")
+    if not os.path.exists(out + ".sdbg_info"):
+        run(["read2sdbg"] + common(full) + ["--output_prefix", out])
+    dump = os.path.join(full, "r2s.dump")
+    subprocess.run([tsi.REF_DUMP, out, dump], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    k = tsi.load_files_into(engine, out)
+    t0 = time.perf_counter()
+    info = tsi.check_index(engine, k, tsi.read_dump(dump))
+    assert info.n_items == FULL["cases"]["read2sdbg"]["n_sdbg"]
+    engine.trim()
