@@ -213,6 +213,368 @@ __global__ void k_fix_last(const uint32_t *__restrict__ last_p1, uint32_t *__res
   if (i < n) last_out[i] = last_p1[i] - 1u;  // 0 (unset) -> 0xFFFFFFFF sentinel, v+1 -> v
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Segment group-by for count (k <= 23: 16-byte records, one-word-pair keys, 2-word edges) — the counterpart of k_s1_seg
+// (s1.hip).  KmerCounter::Lv2Postprocess (kmer_counter.cpp:254-381) needs, per distinct (k+1)-mer, its count and the
+// counts of the bases before / after its occurrences; none of it depends on the order of the records.  So the records
+// are sorted on the top `prefix` bits of the key only (half the LSD passes at k=21), every key then lies inside one
+// SEGMENT of equal prefix, and a workgroup counts the keys of its tile's segments in an LDS hash table:
+//   A  insert   per record (match-any over hash bits per wavefront: the first lane of a group of equal keys inserts
+//               for the group): slot.next5 += counts of the 5 possible next chars of the group (their sum is the
+//               multiplicity), slot.prev5 likewise
+//   B  per key  (dense over the slots this tile created) has_in / has_out, histogram, solid edge -> the workgroup's
+//               output region (unordered; the ~2 % of the records that are solid edges are sorted afterwards); the
+//               "no in-edge / no out-edge" flags go into the zero low bits of the key
+//   C  per record of a flagged key: first_0_out / last_0_in atomics (or routed events)          (:307-368)
+// Ownership of segments across tiles, look-ahead, give-up -> classic fallback: exactly as k_s1_seg.
+// ---------------------------------------------------------------------------------------------------------------
+struct CountSegArgs {
+  uint32_t m;
+  uint32_t pfx_mask;   // bits of key word 0 that form the segment prefix
+  const uint64_t *start;
+  uint64_t n_seqs;
+  uint32_t fixed_len;
+  uint32_t *first_0_out, *last_0_in_p1;
+  unsigned long long *hist;
+  unsigned long long *edges_raw;  // per-workgroup regions of edges_cap 8-byte edges (in the spare sort buffer)
+  uint32_t edges_cap;
+  uint32_t *edge_counts;          // per workgroup
+  unsigned long long *n_distinct;
+  unsigned long long *events, *n_events;
+  uint32_t *err;
+  int la_chunks;
+};
+constexpr int kCountSegMaxDistinct = 1024;  // distinct keys a tile may hold (NSLOT = 2 x this); more -> the tile gives up
+
+static_assert(kCountSegMaxDistinct == 4 * 256, "dense pass: 4 keys per thread");
+template <int PER>
+__global__ __launch_bounds__(256) void k_count_seg(const uint32_t *__restrict__ items, uint64_t n, CountSegArgs a, uint64_t n_work) {
+  constexpr int T = 256 * PER;
+  constexpr int NSLOT = 2 * kCountSegMaxDistinct;
+  constexpr int LOGS = 11;
+  static_assert((1 << LOGS) == NSLOT, "table size");
+  constexpr int NR = PER + 1;
+  constexpr uint32_t kCreated = 0x80000000u;
+  constexpr unsigned long long kEmpty = ~0ull;  // not a key: its low (zero-padding) bits are all ones
+  __shared__ unsigned long long keys[NSLOT];
+  __shared__ unsigned long long prev5[NSLOT], next5[NSLOT];  // 5 x 12-bit counters each ('$' = 4 included)
+  __shared__ uint16_t created[kCountSegMaxDistinct];
+  __shared__ uint32_t lhist[512];
+  __shared__ uint32_t s_bad, s_ncreated, s_edge_cur;
+  const int tid = threadIdx.x, lane = tid & (kWave - 1);
+  const uint64_t lanemask_lt = (1ull << lane) - 1;
+  unsigned long long *const edges_out = a.edges_raw + (size_t)blockIdx.x * a.edges_cap;
+  for (int i = tid; i < NSLOT; i += 256) {
+    keys[i] = kEmpty;
+    prev5[i] = 0;
+    next5[i] = 0;
+  }
+  for (int i = tid; i < 512; i += 256) lhist[i] = 0;
+  if (tid == 0) {
+    s_bad = 0;
+    s_ncreated = 0;
+    s_edge_cur = 0;
+  }
+  __syncthreads();
+  const uint32_t pfx = a.pfx_mask, m = a.m;
+  unsigned long long my_distinct = 0;
+  auto hash_of = [&](uint32_t w0, uint32_t w1) -> uint32_t { return w0 * 0x9E3779B1u + w1 * 0x85EBCA6Bu; };
+  auto probe_insert = [&](unsigned long long key, uint32_t h) -> uint32_t {
+    for (int probes = 0; probes < 256; ++probes) {
+      const unsigned long long old = atomicCAS(&keys[h], kEmpty, key);
+      if (old == kEmpty || old == key) return h | (old == kEmpty ? kCreated : 0u);
+      h = (h + 1) & (NSLOT - 1);
+    }
+    s_bad = 1;
+    return 0;
+  };
+  auto lookup = [&](unsigned long long key) -> uint32_t {
+    uint32_t h = hash_of((uint32_t)(key >> 32), (uint32_t)key) >> (32 - LOGS);
+    for (int probes = 0; probes < 256 && (keys[h] & ~7ull) != key; ++probes) h = (h + 1) & (NSLOT - 1);
+    return h;
+  };
+  // per record of a key that lacks an in- or an out-edge (flags f): kmer_counter.cpp:307-368
+  auto record_final = [&](unsigned f, uint32_t w2, uint32_t w3) {
+    const uint64_t info = (((uint64_t)w2 << 32) | w3) >> 6;
+    const uint64_t abs = info >> 1;
+    const unsigned strand = (unsigned)(info & 1);
+    if (a.events) {
+      if (f & 1u) a.events[atomicAdd(a.n_events, 1ull)] = (abs << 1) | (strand == 0 ? 0u : 1u);
+      if (f & 2u) a.events[atomicAdd(a.n_events, 1ull)] = (abs << 1) | (strand == 0 ? 1u : 0u);
+      return;
+    }
+    const uint64_t rid = seq_of_offset(a.start, a.n_seqs, a.fixed_len, abs);
+    const uint32_t off = (uint32_t)(abs - a.start[rid]);
+    if (f & 1u) {
+      if (strand == 0) atomicMax(&a.last_0_in_p1[rid], off + 1);
+      else atomicMin(&a.first_0_out[rid], off + 1);
+    }
+    if (f & 2u) {
+      if (strand == 0) atomicMin(&a.first_0_out[rid], off + 1);
+      else atomicMax(&a.last_0_in_p1[rid], off + 1);
+    }
+  };
+
+  for (uint64_t tile_idx = blockIdx.x; tile_idx < n_work; tile_idx += gridDim.x) {
+    const uint64_t base = tile_idx * T;
+    const uint64_t tile_end = n - base < (uint64_t)T ? n : base + T;
+    uint32_t w0[NR], w1[NR], w2[NR], w3[NR];
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+      const uint64_t gi = base + (uint64_t)j * 256 + tid;
+      if (gi < n) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(items + gi * 4);
+        w0[j] = v.x;
+        w1[j] = v.y;
+        w2[j] = v.z;
+        w3[j] = v.w;
+      }
+    }
+    const bool has_prev = base != 0;
+    const uint32_t p_prev = has_prev ? items[(base - 1) * 4] & pfx : 0u, p_last = items[(tile_end - 1) * 4] & pfx;
+    const bool la_own = tile_end < n && !(has_prev && p_last == p_prev);
+    const bool more = la_own && tile_end + 256 < n && (items[(tile_end + 255) * 4] & pfx) == p_last;
+
+    uint32_t slot[NR];
+    bool own[NR];
+    constexpr int NB = NR % 3 == 0 ? 3 : (NR % 5 == 0 ? 5 : 1);
+    constexpr int MB = 7;
+#pragma unroll
+    for (int j0 = 0; j0 < NR; j0 += NB) {
+      bool ins[NB], eq[NB], doer[NB];
+      int leader[NB];
+      uint32_t hs[NB];
+      uint64_t peers[NB];
+#pragma unroll
+      for (int q = 0; q < NB; ++q) {
+        const int j = j0 + q;
+        const uint64_t gi = base + (uint64_t)j * 256 + tid;
+        if (j < PER) own[j] = gi < tile_end && !(has_prev && (w0[j] & pfx) == p_prev);
+        else own[j] = la_own && gi < n && (w0[j] & pfx) == p_last;
+        ins[q] = j < PER ? gi < tile_end : own[j];
+        const uint32_t hf = hash_of(w0[j], w1[j]);
+        hs[q] = hf >> (32 - LOGS);
+        const uint32_t hm = hf >> (32 - MB);
+        uint64_t pm = __ballot(ins[q]);
+#pragma unroll
+        for (int b = 0; b < MB; ++b) {
+          const bool bit = (hm >> b) & 1u;
+          const uint64_t mb = __ballot(bit);
+          pm &= bit ? mb : ~mb;
+        }
+        peers[q] = pm;
+        leader[q] = ins[q] ? __builtin_ctzll(pm) : lane;
+      }
+      uint32_t l0[NB], l1[NB];
+#pragma unroll
+      for (int q = 0; q < NB; ++q) {
+        l0[q] = __shfl(w0[j0 + q], leader[q], kWave);
+        l1[q] = __shfl(w1[j0 + q], leader[q], kWave);
+      }
+      unsigned long long addp[NB], addn[NB];
+#pragma unroll
+      for (int q = 0; q < NB; ++q) {
+        const int j = j0 + q;
+        eq[q] = ins[q] && l0[q] == w0[j] && l1[q] == w1[j];
+        const uint64_t grp = __ballot(eq[q]) & peers[q];
+        doer[q] = ins[q] && (lane == leader[q] || !eq[q]);
+        // what this lane's insert adds to the slot's five prev / next counters: the whole group's chars for a leader,
+        // its own for a hash-equal lane with another key
+        const unsigned pv = (w3[j] >> 3) & 7u, nx = w3[j] & 7u;
+        const uint64_t mine = lane == leader[q] ? grp : (1ull << lane);
+        unsigned long long ap = 0, an = 0;
+#pragma unroll
+        for (unsigned x = 0; x < 5; ++x) {
+          ap |= (unsigned long long)__builtin_popcountll(__ballot(ins[q] && pv == x) & mine) << (12 * x);
+          an |= (unsigned long long)__builtin_popcountll(__ballot(ins[q] && nx == x) & mine) << (12 * x);
+        }
+        addp[q] = ap;
+        addn[q] = an;
+      }
+#pragma unroll
+      for (int q = 0; q < NB; ++q) {
+        const int j = j0 + q;
+        slot[j] = 0;
+        if (doer[q]) {
+          const uint32_t sl = probe_insert(((unsigned long long)w0[j] << 32) | w1[j], hs[q]);
+          atomicAdd(&prev5[sl & ~kCreated], addp[q]);
+          atomicAdd(&next5[sl & ~kCreated], addn[q]);
+          slot[j] = sl;
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < NB; ++q) {
+        const int j = j0 + q;
+        const bool cr = (slot[j] & kCreated) != 0;
+        const uint64_t crm = __ballot(cr);
+        uint32_t cbase = 0;
+        if (lane == 0 && crm) cbase = atomicAdd(&s_ncreated, (uint32_t)__builtin_popcountll(crm));
+        cbase = __shfl(cbase, 0, kWave);
+        slot[j] &= ~kCreated;
+        if (cr) {
+          const uint32_t at = cbase + (uint32_t)__builtin_popcountll(crm & lanemask_lt);
+          if (at < (uint32_t)kCountSegMaxDistinct) created[at] = (uint16_t)slot[j];
+          else s_bad = 1;
+        }
+        const uint32_t lslot = __shfl(slot[j], leader[q], kWave);
+        if (eq[q] && lane != leader[q]) slot[j] = lslot;
+      }
+    }
+    if (more) {  // rare: further look-ahead chunks straight from HBM
+      for (int c = 1;; ++c) {
+        const uint64_t cb = tile_end + (uint64_t)c * 256;
+        if (c > a.la_chunks) {
+          s_bad = 1;
+          break;
+        }
+        const uint64_t gi = cb + tid;
+        if (gi < n) {
+          const uint4 v = *reinterpret_cast<const uint4 *>(items + gi * 4);
+          if ((v.x & pfx) == p_last) {
+            const uint32_t sl = probe_insert(((unsigned long long)v.x << 32) | v.y, hash_of(v.x, v.y) >> (32 - LOGS));
+            atomicAdd(&prev5[sl & ~kCreated], 1ull << (12 * ((v.w >> 3) & 7u)));
+            atomicAdd(&next5[sl & ~kCreated], 1ull << (12 * (v.w & 7u)));
+            if (sl & kCreated) {
+              const uint32_t at = atomicAdd(&s_ncreated, 1u);
+              if (at < (uint32_t)kCountSegMaxDistinct) created[at] = (uint16_t)(sl & ~kCreated);
+              else s_bad = 1;
+            }
+          }
+        }
+        if (!(cb + 256 < n && (items[(cb + 255) * 4] & pfx) == p_last)) break;
+      }
+    }
+    __syncthreads();
+    const bool bad = s_bad != 0;
+    const uint32_t n_created = s_ncreated < (uint32_t)kCountSegMaxDistinct ? s_ncreated : (uint32_t)kCountSegMaxDistinct;
+    // B: per distinct key of ours
+    uint32_t my_edges = 0;
+    unsigned long long ebuf[4];  // (n_created <= 1024 = 4 per thread: the thread's edges stay in registers)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) ebuf[q] = 0;
+    if (!bad) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const uint32_t i = tid + 256 * q;
+        if (i >= n_created) continue;
+        const uint32_t sl = created[i];
+        const unsigned long long key = keys[sl];
+        if (has_prev && ((uint32_t)(key >> 32) & pfx) == p_prev) continue;
+        const unsigned long long pp = prev5[sl], nn = next5[sl];
+        uint32_t count = 0;
+        bool has_in = false, has_out = false;
+#pragma unroll
+        for (unsigned x = 0; x < 5; ++x) {
+          const uint32_t cn = (uint32_t)(nn >> (12 * x)) & 0xFFFu, cp = (uint32_t)(pp >> (12 * x)) & 0xFFFu;
+          count += cn;
+          if (x < 4) {
+            has_in |= cp >= m;
+            has_out |= cn >= m;
+          }
+        }
+        ++my_distinct;
+        const bool solid = count >= m;
+        const uint32_t hb = count > MHX_MAX_MUL ? (uint32_t)MHX_MAX_MUL : count;
+        if (hb < 512) atomicAdd(&lhist[hb], 1u);
+        else atomicAdd(&a.hist[hb], 1ull);
+        if (solid) {
+          keys[sl] = key | (has_in ? 0u : 1u) | (has_out ? 0u : 2u);  // flags ride in the key's zero padding
+          ebuf[q] = key | hb;  // PackEdge (kmer_counter.cpp:32-52): multiplicity in the low 16 bits of the last word
+          ++my_edges;
+        }
+      }
+    }
+    const uint32_t incl = wave_inclusive_sum(my_edges);
+    const uint32_t tot = __shfl(incl, kWave - 1, kWave);
+    uint32_t wbase = 0;
+    if (lane == 0 && tot) wbase = atomicAdd(&s_edge_cur, tot);
+    wbase = __shfl(wbase, 0, kWave);
+    if (wbase + tot > a.edges_cap) {
+      if (lane == 0) atomicOr(a.err, 1u);
+    } else if (!bad) {
+      uint32_t at = wbase + incl - my_edges;
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (ebuf[q]) edges_out[at++] = ebuf[q];
+    }
+    __syncthreads();
+    // C: per record of a key without an in- or out-edge
+    if (!bad) {
+#pragma unroll
+      for (int j = 0; j < NR; ++j) {
+        if (!own[j]) continue;
+        const unsigned f = (unsigned)keys[slot[j]] & 3u;
+        if (f) record_final(f, w2[j], w3[j]);
+      }
+      if (more) {
+        for (int c = 1; c <= a.la_chunks; ++c) {
+          const uint64_t cb = tile_end + (uint64_t)c * 256;
+          const uint64_t gi = cb + tid;
+          if (gi < n) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(items + gi * 4);
+            if ((v.x & pfx) == p_last) {
+              const unsigned f = (unsigned)keys[lookup(((unsigned long long)v.x << 32) | v.y)] & 3u;
+              if (f) record_final(f, v.z, v.w);
+            }
+          }
+          if (!(cb + 256 < n && (items[(cb + 255) * 4] & pfx) == p_last)) break;
+        }
+      }
+    }
+    __syncthreads();
+    if (tid == 0) {
+      s_bad = 0;
+      s_ncreated = 0;
+    }
+    if (!bad) {
+      for (uint32_t i = tid; i < n_created; i += 256) {
+        const uint32_t sl = created[i];
+        keys[sl] = kEmpty;
+        prev5[sl] = 0;
+        next5[sl] = 0;
+      }
+    } else {
+      for (int i = tid; i < NSLOT; i += 256) {
+        keys[i] = kEmpty;
+        prev5[i] = 0;
+        next5[i] = 0;
+      }
+      if (tid == 0) atomicOr(a.err, 1u);
+    }
+    __syncthreads();
+  }
+  for (int i = tid; i < 512; i += 256)
+    if (lhist[i]) atomicAdd(&a.hist[i], (unsigned long long)lhist[i]);
+  my_distinct = wave_sum(my_distinct);
+  if (lane == 0 && my_distinct) atomicAdd(a.n_distinct, my_distinct);
+  if (tid == 0) a.edge_counts[blockIdx.x] = s_edge_cur < a.edges_cap ? s_edge_cur : a.edges_cap;
+}
+// regions -> dense (the same job as k_agg_compact in s1.hip, for 8-byte edges)
+__global__ __launch_bounds__(256) void k_edges_compact(const unsigned long long *__restrict__ raw, uint32_t cap, const uint32_t *__restrict__ counts,
+                                                      unsigned long long *__restrict__ dense) {
+  __shared__ uint64_t sm[256 / kWave + 1];
+  const uint32_t r = blockIdx.x;
+  uint64_t part = 0;
+  for (uint32_t i = threadIdx.x; i < r; i += 256) part += counts[i];
+  uint64_t off;
+  block_exclusive_sum<uint64_t, 256>(part, sm, &off);
+  const uint32_t nn = counts[r];
+  const unsigned long long *src = raw + (size_t)r * cap;
+  for (uint32_t i = blockIdx.y * 256 + threadIdx.x; i < nn; i += gridDim.y * 256) dense[off + i] = src[i];
+}
+// sorted 8-byte edges (hi word first in memory after the sort) -> bucket counts
+__global__ void k_edge_buckets(const uint32_t *__restrict__ edges, uint64_t n, unsigned long long *__restrict__ bcount) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) atomicAdd(&bcount[edges[2 * i] >> 16], 1ull);
+}
+__global__ void k_swap_pairs(uint32_t *__restrict__ v, uint64_t n) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    const uint2 x = reinterpret_cast<uint2 *>(v)[i];
+    reinterpret_cast<uint2 *>(v)[i] = make_uint2(x.y, x.x);
+  }
+}
+
 template <int S>
 static void count_postprocess(mhx_ctx *c, const uint32_t *sorted, uint64_t n_items, int KWv, int key_bits, uint32_t m, int wpe,
                               uint32_t *first, uint32_t *last, unsigned long long *hist, unsigned long long *bcount, uint64_t *n_runs,
@@ -306,7 +668,18 @@ int count_process(mhx_ctx *c, uint32_t k, uint32_t m, uint32_t *buf_a, uint32_t 
   hipStream_t st = c->stream;
   const bool global = c->global_bases != 0;
   const int key_bits = (int)(k + 1) * 2;
-  uint32_t *sorted = radix_sort(c, buf_a, buf_b, n_items, S, KWv, make_passes(KWv, KWv * 32 - key_bits, KWv * 32));
+  // Segment group-by (k_count_seg): sort only the top seg_bits of the key (a segment then holds ~100 records), count the
+  // equal keys of every segment in LDS, sort the few solid edges afterwards.  16-byte records / 2-word edges (k <= 23).
+  int seg_bits = 0;
+  if (c->opt("count_seg", 1) && S == 4 && KWv == 2 && wpe == 2 && m < 4096 && n_items) {
+    const double n_eff = (double)n_items * (double)(c->n_parts > 1 ? c->n_parts : 1);
+    seg_bits = 8;
+    while (seg_bits < 32 && n_eff / 96.0 > (double)(1ull << seg_bits)) seg_bits += 8;
+    if (c->opt("count_seg_bits", 0)) seg_bits = (int)c->opt("count_seg_bits", 0);
+    seg_bits = std::max(1, std::min(seg_bits, 32));
+  }
+  uint32_t *sorted = radix_sort(c, buf_a, buf_b, n_items, S, KWv,
+                                seg_bits ? make_passes(KWv, 64 - seg_bits, 64) : make_passes(KWv, KWv * 32 - key_bits, KWv * 32));
   uint32_t *spare = sorted == buf_a ? buf_b : buf_a;
 
   // results
@@ -333,7 +706,66 @@ int count_process(mhx_ctx *c, uint32_t k, uint32_t m, uint32_t *buf_a, uint32_t 
   MHX_HIP(hipMemsetAsync(ev_n, 0, 8, st));
 
   uint64_t n_runs = 0, n_edges = 0;
-  switch (S) {
+  bool seg_done = false;
+  if (seg_bits) {
+    // state as it is now, in case a tile gives up and the classic path has to redo the job (the atomics of the tiles
+    // that did finish cannot be taken back otherwise)
+    uint32_t *sv_first = c->ws("cs_save_first", (ns ? ns : 1) * 4).as<uint32_t>(), *sv_last = c->ws("cs_save_last", (ns ? ns : 1) * 4).as<uint32_t>();
+    unsigned long long *sv_hist = c->ws("cs_save_hist", (MHX_MAX_MUL + 1) * 8).as<unsigned long long>();
+    MHX_HIP(hipMemcpyAsync(sv_first, first, (ns ? ns : 1) * 4, hipMemcpyDeviceToDevice, st));
+    MHX_HIP(hipMemcpyAsync(sv_last, last, (ns ? ns : 1) * 4, hipMemcpyDeviceToDevice, st));
+    MHX_HIP(hipMemcpyAsync(sv_hist, hist, (MHX_MAX_MUL + 1) * 8, hipMemcpyDeviceToDevice, st));
+    constexpr int PER = 8, T = 256 * PER;
+    const uint64_t n_work = div_ceil(n_items, (uint64_t)T);
+    const unsigned grid = (unsigned)std::min<uint64_t>(n_work, 256 * 3);
+    const uint32_t cap = (uint32_t)std::min<uint64_t>(n_items * (uint64_t)S * 4 / 8 / grid, 0xFFFFFFF0u);
+    uint32_t *counts = c->ws("cs_edge_counts", (size_t)grid * 4).as<uint32_t>();
+    unsigned long long *ctrs = c->ws("cs_counters", 64).as<unsigned long long>();  // [0] distinct, [1] err
+    MHX_HIP(hipMemsetAsync(ctrs, 0, 64, st));
+    const uint32_t pfx_mask = seg_bits >= 32 ? 0xFFFFFFFFu : ~(0xFFFFFFFFu >> seg_bits);
+    const int la = (int)std::min<long long>(std::max<long long>(c->opt("count_seg_la", 3), 0), 6);  // 12-bit tile counters
+    CountSegArgs a{m, pfx_mask, s.start.as<uint64_t>(), s.n_seqs, s.fixed_len, first, last, hist, reinterpret_cast<unsigned long long *>(spare),
+                   cap, counts, ctrs, events, ev_n, reinterpret_cast<uint32_t *>(ctrs + 1), la};
+    // (multi-GPU: the events go to a buffer of their own — the spare sort buffer holds the edge regions here)
+    if (global) a.events = c->ws("cs_events", n_items * 2 * 8 + 64).as<unsigned long long>();
+    MHX_LAUNCH(c, "count_groups", (double)n_items * S * 4,
+               hipLaunchKernelGGL((k_count_seg<PER>), dim3(grid), dim3(256), 0, st, sorted, n_items, a, n_work));
+    std::vector<uint32_t> h_counts(grid);
+    unsigned long long h_ctr[2] = {0, 0};
+    MHX_HIP(hipMemcpyAsync(h_counts.data(), counts, (size_t)grid * 4, hipMemcpyDeviceToHost, st));
+    MHX_HIP(hipMemcpyAsync(h_ctr, ctrs, 16, hipMemcpyDeviceToHost, st));
+    MHX_HIP(hipStreamSynchronize(st));
+    if (!(h_ctr[1] & 0xFFFFFFFFull)) {
+      for (uint32_t v : h_counts) n_edges += v;
+      n_runs = h_ctr[0];
+      uint32_t *ea = c->ws("cs_edges_a", (n_edges + 1) * 8).as<uint32_t>(), *eb = c->ws("cs_edges_b", (n_edges + 1) * 8).as<uint32_t>();
+      uint32_t *edges = c->result(MHX_BUF_EDGES, (n_edges ? n_edges : 1) * wpe * 4).as<uint32_t>();
+      c->results[MHX_BUF_EDGES].used = n_edges * wpe * 4;
+      if (n_edges) {
+        MHX_LAUNCH(c, "edges_compact", (double)n_edges * 16,
+                   hipLaunchKernelGGL(k_edges_compact, dim3(grid, 4), dim3(256), 0, st, reinterpret_cast<const unsigned long long *>(spare), cap, counts,
+                                      reinterpret_cast<unsigned long long *>(ea)));
+        // uint64 (lo word first in memory) -> (hi, lo) word pairs = the edge's word order; sort by the (k+1)-mer bits
+        hipLaunchKernelGGL(k_swap_pairs, dim3((unsigned)div_ceil(n_edges, 256)), dim3(256), 0, st, ea, n_edges);
+        uint32_t *es = radix_sort(c, ea, eb, n_edges, 2, 2, make_passes(2, 64 - key_bits, 64));
+        MHX_HIP(hipMemcpyAsync(edges, es, n_edges * 8, hipMemcpyDeviceToDevice, st));
+        hipLaunchKernelGGL(k_edge_buckets, dim3((unsigned)div_ceil(n_edges, 256)), dim3(256), 0, st, edges, n_edges, bcount);
+        MHX_HIP(hipGetLastError());
+      }
+      if (global) events = a.events;
+      seg_done = true;
+    } else {  // a tile gave up: restore, sort fully, run the classic tile kernel
+      MHX_HIP(hipMemcpyAsync(first, sv_first, (ns ? ns : 1) * 4, hipMemcpyDeviceToDevice, st));
+      MHX_HIP(hipMemcpyAsync(last, sv_last, (ns ? ns : 1) * 4, hipMemcpyDeviceToDevice, st));
+      MHX_HIP(hipMemcpyAsync(hist, sv_hist, (MHX_MAX_MUL + 1) * 8, hipMemcpyDeviceToDevice, st));
+      MHX_HIP(hipMemsetAsync(ev_n, 0, 8, st));
+      uint32_t *other = sorted == buf_a ? buf_b : buf_a;
+      sorted = radix_sort(c, sorted, other, n_items, S, KWv, make_passes(KWv, KWv * 32 - key_bits, KWv * 32));
+      spare = sorted == buf_a ? buf_b : buf_a;
+      events = global ? reinterpret_cast<unsigned long long *>(spare) : nullptr;
+    }
+  }
+  if (!seg_done) switch (S) {
 #define MHX_CASE(SV) \
   case SV: count_postprocess<SV>(c, sorted, n_items, KWv, key_bits, m, wpe, first, last, hist, bcount, &n_runs, &n_edges, events, ev_n); break;
     MHX_CASE(4) MHX_CASE(6) MHX_CASE(8) MHX_CASE(10) MHX_CASE(12) MHX_CASE(14) MHX_CASE(16) MHX_CASE(18) MHX_CASE(20)

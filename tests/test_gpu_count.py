@@ -50,6 +50,36 @@ def test_count_matches_oracle(engine, kind, k, m):
     assert np.array_equal(engine.fetch(lib.BUF_LAST_0_IN, np.uint32), want["last_0_in"])
 
 
+COUNT_SEG_DEFAULTS = dict(count_seg=1, count_seg_bits=0, count_seg_la=3)
+
+
+@pytest.mark.parametrize("opts", [dict(count_seg=0), dict(count_seg_bits=8, count_seg_la=0), dict(count_seg_bits=8), dict(count_seg_bits=16, count_seg_la=1),
+                                  dict(count_seg_bits=32)], ids=lambda o: ",".join("%s=%d" % kv for kv in o.items()))
+@pytest.mark.parametrize("kind,k,m", [("fixed", 21, 2), ("var", 21, 2), ("lowcomplex", 21, 2), ("var", 23, 3), ("fixed", 17, 1)])
+def test_count_segment_groupby_variants(engine, kind, k, m, opts):
+    """count at k <= 23 = partial sort + segment group-by (k_count_seg) + sort of the solid edges; every knob setting, the
+    give-up -> classic fallback and the classic path itself must produce the oracle's outputs."""
+    from megahit_amd import lib
+    reads = make_reads(kind, 12)
+    pkg = ob.Package(reads, reverse=True)
+    want = ob.count(pkg, k, m)
+    load(engine, pkg)
+    try:
+        for name, v in opts.items():
+            engine.set_option(name, v)
+        r = engine.count(k, m)
+        assert r.n_items == want["n_items"] and r.n_edges == want["edges"].shape[0]
+        edges = engine.fetch(lib.BUF_EDGES, np.uint32).reshape(-1, r.words_per_edge)
+        assert np.array_equal(edges, want["edges"])
+        assert np.array_equal(engine.fetch(lib.BUF_BUCKET_COUNT, np.uint64), want["bucket_count"])
+        assert np.array_equal(engine.fetch(lib.BUF_MUL_HIST, np.int64), want["hist"])
+        assert np.array_equal(engine.fetch(lib.BUF_FIRST_0_OUT, np.uint32), want["first_0_out"])
+        assert np.array_equal(engine.fetch(lib.BUF_LAST_0_IN, np.uint32), want["last_0_in"])
+    finally:
+        for name, v in COUNT_SEG_DEFAULTS.items():
+            engine.set_option(name, v)
+
+
 def test_count_empty_and_short(engine):
     from megahit_amd import lib
     pkg = ob.Package([np.zeros(5, dtype=np.uint8), np.zeros(0, dtype=np.uint8), np.ones(21, dtype=np.uint8)], reverse=True)
