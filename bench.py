@@ -50,26 +50,35 @@ def make_reads(n_reads, rank, world):
     return np.concatenate(chunks)
 
 
-def pmc_traffic(kernel_name):
-    """HBM bytes per launch of `kernel_name` measured with rocprofv3 PMC passes on THIS workload
-    (profiles/r01_pmc_traffic.json, produced by tools/pmc_to_json.py with the gfx950 FETCH_SIZE x2 correction);
-    counters cannot be collected from inside the timed run, so the committed measurement is reported."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+def pmc_traffic(kernel_name, path=None):
+    """HBM bytes per launch of `kernel_name` measured with rocprofv3 PMC passes on THIS workload and THIS tree
+    (profiles/r02_pmc_traffic.json, produced by tools/gpu_evidence.sh -> tools/pmc_to_json.py with the gfx950
+    FETCH_SIZE x2 correction).  Counters cannot be collected from inside the timed run, so the committed measurement is
+    reported — but only when it was taken on the same kernel sources (megahit_amd/buildid.py): otherwise null."""
+    path = path or os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
     try:
+        from megahit_amd.buildid import build_id
         with open(path) as f:
-            kernels = json.load(f)["kernels"]
+            doc = json.load(f)
+        if doc.get("build_id") != build_id():
+            return None, "profiles/r02_pmc_traffic.json was measured on other kernel sources (build_id %s, running %s)" % (doc.get("build_id"), build_id())
+        kernels = doc["kernels"]
     except Exception:
         return None, None
-    prefixes = []
+    # profile name -> kernel symbol prefix
+    table = {"s1_groups": ("k_s1_seg<", "k_tile_groups<3"), "count_groups": ("k_count_seg<",), "s1_extract": ("k_s1_extract_fixed<", "k_s1_extract<"),
+             "count_extract": ("k_count_extract<",)}
+    prefixes = list(table.get(kernel_name, ()))
     for stem, names in (("radix_scatter_", ("k_radix_onesweep", "k_radix_scatter")), ("radix_hist_all_", ("k_radix_hist_all",)),
                         ("radix_hist_", ("k_radix_hist",))):
         if kernel_name.startswith(stem) and kernel_name.endswith("B") and kernel_name[len(stem):-1].isdigit():
-            prefixes = ["%s<%d" % (nm, int(kernel_name[len(stem):-1]) // 4) for nm in names]
+            prefixes = ["%s<%d," % (nm, int(kernel_name[len(stem):-1]) // 4) for nm in names] + \
+                       ["%s<%d>" % (nm, int(kernel_name[len(stem):-1]) // 4) for nm in names]
             break
     for prefix in prefixes:
         for k, v in kernels.items():
-            if k.startswith(prefix + ",") or k.startswith(prefix + ">"):
-                return v["hbm_bytes"], "profiles/r01_pmc_traffic.json:" + k
+            if k.startswith(prefix):
+                return v["hbm_bytes"], "profiles/r02_pmc_traffic.json:" + k
     return None, None
 
 
@@ -343,7 +352,7 @@ def main():
         per_launch_bytes = ks["bytes"] / ks["launches"]
         per_launch_ms = ks["ms"] / ks["launches"]
         achieved = per_launch_bytes / per_launch_ms / 1e6  # GB/s
-        traffic, traffic_src = pmc_traffic(name) if n_reads == 10000000 and args.engine == "read2sdbg" else (None, None)
+        traffic, traffic_src = pmc_traffic(name) if n_reads == 10000000 and args.engine == "read2sdbg" and not use_dist else (None, None)
         copy_gbs = copy_bandwidth(torch)
         roof = {"bound": "hbm", "kernel": name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,

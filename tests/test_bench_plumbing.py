@@ -7,13 +7,26 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def test_pmc_traffic_lookup_matches_committed_profile():
+def test_pmc_traffic_lookup_is_tied_to_the_kernel_sources(tmp_path):
+    """roofline.traffic comes from a committed PMC measurement only if that measurement was taken on the very kernel
+    sources that are running (megahit_amd/buildid.py)"""
     import bench
-    traffic, src = bench.pmc_traffic("radix_scatter_12B")
-    assert traffic and traffic > 3.0e10 and "k_radix_onesweep<3" in src
-    t8, _ = bench.pmc_traffic("radix_scatter_8B")
-    assert t8 and t8 < traffic
-    assert bench.pmc_traffic("s1_groups") == (None, None)
+    from megahit_amd.buildid import build_id
+    doc = {"build_id": build_id(), "kernels": {"k_radix_onesweep<3, 8, 3>": {"hbm_bytes": 40000000000},
+                                               "k_radix_onesweep<2, 8, 2>": {"hbm_bytes": 2000000000},
+                                               "k_s1_seg<8, true>": {"hbm_bytes": 21000000000}}}
+    p = str(tmp_path / "pmc.json")
+    with open(p, "w") as f:
+        json.dump(doc, f)
+    traffic, src = bench.pmc_traffic("radix_scatter_12B", p)
+    assert traffic == 40000000000 and "k_radix_onesweep<3" in src
+    assert bench.pmc_traffic("radix_scatter_8B", p)[0] == 2000000000
+    assert bench.pmc_traffic("s1_groups", p)[0] == 21000000000
+    doc["build_id"] = "0" * 16
+    with open(p, "w") as f:
+        json.dump(doc, f)
+    traffic, why = bench.pmc_traffic("radix_scatter_12B", p)
+    assert traffic is None and "other kernel sources" in why
 
 
 def test_committed_bench_line_has_the_contract_fields():
