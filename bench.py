@@ -241,6 +241,12 @@ def main():
                     help="sub-program to time; read2sdbg is BASELINE.json's metric, the others are reported beside it (1 GPU)")
     args = ap.parse_args()
 
+    # stdout carries exactly ONE line, the JSON result of rank 0: libraries that chat on stdout (RCCL's version banner,
+    # gloo's connection notes) are sent to stderr by pointing fd 1 there for the whole run
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -400,7 +406,8 @@ def main():
                     out["e2e"] = end_to_end(n_reads)
                 except Exception as ex:
                     out["e2e"] = {"error": str(ex)}
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if use_dist:
         import torch.distributed as dist
         comm.close()

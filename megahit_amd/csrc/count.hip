@@ -686,7 +686,9 @@ int count_process(mhx_ctx *c, uint32_t k, uint32_t m, uint32_t *buf_a, uint32_t 
   // accumulate (bucket-range passes after the first): first_0_out, the raw last_0_in (+1) values and the histogram of
   // the earlier passes are kept; the published last_0_in is re-derived from the raw values after every pass
   const bool acc = c->accumulate && c->results.count(MHX_BUF_FIRST_0_OUT) && c->results[MHX_BUF_FIRST_0_OUT].used == ns * 4 &&
-                   c->work.count("last_p1") && c->results.count(MHX_BUF_MUL_HIST);
+                   c->work.count("last_p1") && c->results.count(MHX_BUF_MUL_HIST) && c->count_acc_k == k && c->count_acc_m == m;
+  c->count_acc_k = k;  // a pass with another (k, m) starts from scratch instead of merging into stale state
+  c->count_acc_m = m;
   uint32_t *first = c->result(MHX_BUF_FIRST_0_OUT, (ns ? ns : 1) * 4).as<uint32_t>();
   uint32_t *last_out = c->result(MHX_BUF_LAST_0_IN, (ns ? ns : 1) * 4).as<uint32_t>();
   uint32_t *last = c->ws("last_p1", (ns ? ns : 1) * 4).as<uint32_t>();

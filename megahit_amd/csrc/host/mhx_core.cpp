@@ -222,11 +222,19 @@ struct BucketRange {
   uint32_t lo, hi;
   uint64_t n_items;
 };
-std::vector<BucketRange> plan_ranges(mhx_ctx *c, int stage, uint32_t k, uint32_t m, size_t item_bytes, double items_upper_bound) {
+// fixed_bytes: device state of the stage that does not shrink with the bucket range (stage 1: the 1 B/base mark map, the
+// bitmap and the aggregated stage-2 items; count: first_0_out / last_0_in; all: sort status words ~ items / 3)
+std::vector<BucketRange> plan_ranges(mhx_ctx *c, int stage, uint32_t k, uint32_t m, size_t item_bytes, double items_upper_bound,
+                                     double fixed_bytes = 0) {
   uint64_t max_items = 0;
   if (const char *e = getenv("MHX_MAX_ITEMS")) max_items = strtoull(e, nullptr, 10);
   else {
-    const double fit = (double)mhx_device_free_bytes(c) * 0.8 / (3.0 * (double)item_bytes);  // 2 sort buffers + filtered copy
+    double free_bytes = (double)mhx_device_free_bytes(c);
+    if (const char *e = getenv("MHX_FREE_BYTES")) free_bytes = atof(e);  // tests: make the automatic plan fire on a small input
+    const double avail = free_bytes * 0.8 - fixed_bytes;
+    if (avail <= 0) fatal("not enough free device memory for the fixed state of this stage (%.1f GB free, %.1f GB needed)", free_bytes / 1e9,
+                          fixed_bytes / 1e9);
+    const double fit = avail / (3.0 * (double)item_bytes + 1.0);  // 2 sort buffers + filtered copy (+ status words)
     if (items_upper_bound <= fit) return {{0, MHX_NUM_BUCKETS, 0}};
     max_items = (uint64_t)fit;
   }
@@ -245,6 +253,10 @@ std::vector<BucketRange> plan_ranges(mhx_ctx *c, int stage, uint32_t k, uint32_t
     acc += hist[b];
   }
   out.push_back({lo, MHX_NUM_BUCKETS, acc});
+  for (const BucketRange &r : out)
+    if (r.hi - r.lo == 1 && r.n_items > max_items)  // the reference gives up here (base_engine.cpp:96-99); we try, the allocation may fail
+      info("WARNING: lv1 bucket %u alone holds %llu items, more than the %llu that fit: trying it as a pass of its own", r.lo,
+           (unsigned long long)r.n_items, (unsigned long long)max_items);
   if (out.size() > 1) info("Memory plan: %zu passes over lv1 bucket ranges (at most %llu items each)", out.size(), (unsigned long long)max_items);
   return out;
 }
@@ -408,7 +420,7 @@ int main_kmer_count(int argc, char **argv) {
   mhxio::BinFile lib = load_read_lib(c, o.get("read_lib_file"));
   info("%llu reads; Preparing data... Done. Time elapsed: %.4f", (unsigned long long)mhx_num_sequences(c), t.lap());
   const size_t count_item_bytes = (size_t)(((2 * (k + 1) + 31) / 32 + 2 + 1) / 2 * 2) * 4;
-  const auto ranges = plan_ranges(c, MHX_STAGE_COUNT, k, m, count_item_bytes, (double)mhx_num_bases(c));
+  const auto ranges = plan_ranges(c, MHX_STAGE_COUNT, k, m, count_item_bytes, (double)mhx_num_bases(c), 12.0 * (double)mhx_num_sequences(c));
   mhx_count_result r{};
   std::vector<uint32_t> edges;
   std::vector<uint64_t> bcount(MHX_NUM_BUCKETS, 0);
@@ -521,8 +533,10 @@ int main_read2sdbg(int argc, char **argv) {
     // selects the faster stable order instead (DESIGN.md "H1")
     const int mercy_mode = !need_mercy ? 0 : (getenv("MHX_STABLE_TIES") ? 1 : 2);
     const size_t s1_item_bytes = 16 + (k > 30 ? (size_t)((2 * (k - 1) + 6 + 31) / 32 - 2 + 1) / 2 * 8 : 0);
+    // fixed: 1 B/base mark map + bitmap + the aggregated stage-2 items kept for stage 2 (k <= 22: <= 8 B per base, typically 1)
     const auto ranges = plan_ranges(c, mercy_mode ? MHX_STAGE_S1_MERCY : MHX_STAGE_S1, k, m, s1_item_bytes,
-                                    (double)mhx_num_bases(c) + 4.0 * (double)mhx_num_sequences(c));
+                                    (double)mhx_num_bases(c) + 4.0 * (double)mhx_num_sequences(c),
+                                    (double)mhx_num_bases(c) * (1.0 + 0.125 + (k <= 22 ? 1.0 : 0.0)));
     uint64_t n1 = 0;
     for (size_t i = 0; i < ranges.size(); ++i) {
       set_range(c, ranges, i, true);
@@ -593,6 +607,8 @@ int main_seq2sdbg(int argc, char **argv) {
   const int n_threads = num_threads_or_all(atoi(o.get("num_cpu_threads").c_str()));
   const bool need_mercy = !o.get("need_mercy").empty();
   const std::string in = o.get("input_prefix"), out = o.get("output_prefix");
+  if (need_mercy && in.empty())  // GenMercyEdges reads <input_prefix>.cand and the sorted edges (seq_to_sdbg.cpp:171-189,435)
+    fatal("--need_mercy needs --input_prefix (its .cand file and the sorted edges to search)");
   Timer t;
   if (g_num_gpus > 1 && need_mercy) info("seq2sdbg --need_mercy searches the whole sorted edge list (seq_to_sdbg.cpp:171-357): running on one GPU");
   if (g_num_gpus > 1 && !need_mercy) {

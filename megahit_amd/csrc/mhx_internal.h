@@ -96,6 +96,7 @@ struct mhx_ctx {
   bool global_marks_inverted = false;  // multi-GPU stage 1 marked the non-solid occurrences (s1.hip)
   uint64_t s1_acc_bits = 0, mercy_acc_n = 0;  // stage-1 state that accumulate continues
   uint32_t s1_acc_k = 0, s1_acc_m = 0;
+  uint32_t count_acc_k = 0, count_acc_m = 0;  // (k, m) of the count state that accumulate continues
   uint64_t n_marks = 0;          // multi-GPU, sparse marks: positions in ws("s1_marks") waiting to be routed
   uint64_t dist_local_solid = 0; // multi-GPU, sparse marks: solid occurrences in the local reads after the marks arrived
   bool dist_s2_agg = false;  // the items of the current multi-GPU stage-2 exchange are aggregated ones

@@ -421,18 +421,19 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_onesweep(const uint32_t 
         //    counts of the predecessors until one of them knows its inclusive prefix
         unsigned long long excl = 0;
         if (unit > 0) {
-          uint32_t polls = 0;
           for (uint64_t p = unit; p-- > 0;) {
             unsigned long long v;
+            uint32_t polls = 0;  // per predecessor: a unit only ever waits for units that already run (ticket order)
             for (;;) {
               v = __hip_atomic_load(status + p * 256 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
               if ((v >> 58) == tag && ((v >> 56) & 3ull)) break;
-              if (++polls > (1u << 22)) {  // never observed; guarantees termination (the host raises on *err)
+              if (++polls > (1u << 27)) {  // seconds of polling one predecessor (a wedged GPU): terminate, the host raises on *err
                 atomicOr(err, 1u);
                 v = 2ull << 56;
                 break;
               }
-              __builtin_amdgcn_s_sleep(1);
+              if (polls < 64) __builtin_amdgcn_s_sleep(1);
+              else __builtin_amdgcn_s_sleep(8);
             }
             excl += v & kStValMask;
             if (((v >> 56) & 3ull) == 2ull) break;

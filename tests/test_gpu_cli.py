@@ -67,3 +67,20 @@ def test_cli_multi_file_outputs(ent, tmp_path, monkeypatch):
         assert got.get(key) == want, key
     produced = [f for f in os.listdir(str(tmp_path)) if ".sdbg." in f or ".edges." in f]
     assert any(f.endswith(".2") for f in produced), produced
+
+
+@pytest.mark.parametrize("ent", [e for e in gu.cases() if e["case"]["prog"] in ("count", "read2sdbg")][:4], ids=gu.case_id)
+def test_cli_automatic_memory_plan(ent, tmp_path, monkeypatch):
+    """the planner itself (plan_ranges: free HBM minus the stage's fixed state, / 3 item buffers) decides on several lv1
+    passes when the free memory is small — here a faked 6 MB (MHX_FREE_BYTES) — and the outputs stay the reference's"""
+    import subprocess
+    monkeypatch.setenv("MHX_FREE_BYTES", "6e6")
+    got = gu.run_case(gu.MHX_CORE, ent, str(tmp_path))
+    for key, want in ent.items():
+        if key in ("case", "mercy_cand_kmsort"):
+            continue
+        assert got.get(key) == want, key
+    c = ent["case"]
+    p = subprocess.run([gu.MHX_CORE, c["prog"], "-k", str(c["k"]), "-m", str(c["m"]), "--read_lib_file", os.path.join(gu.GOLD, c["lib"]),
+                        "--output_prefix", str(tmp_path / "again"), "--host_mem", "2e9", "--num_cpu_threads", "3"], stderr=subprocess.PIPE, text=True)
+    assert p.returncode == 0 and "Memory plan:" in p.stderr, p.stderr[-800:]

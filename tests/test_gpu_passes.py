@@ -79,3 +79,33 @@ def test_seq2sdbg_in_passes(engine, k):
     engine.load_multiplicity(mult)
     got = passes.seq2sdbg_in_passes(engine, k, max_items=-5, batch_bytes=BATCH)
     _check_sdbg(got, want)
+
+
+@pytest.mark.parametrize("stage,k,m", [("count", 21, 2), ("s1", 21, 2), ("s1_mercy", 27, 2), ("s2", 21, 2), ("seq2sdbg", 29, 0)])
+def test_bucket_histogram_equals_oracle_items(engine, stage, k, m):
+    """mhx_bucket_histogram (the reference's Lv0CalcBucketSize: kmer_counter.cpp:114-156, read_to_sdbg_s1.cpp:145-206,
+    read_to_sdbg_s2.cpp:271-345, seq_to_sdbg.cpp:530-577) = the histogram of the top 16 bits of the oracle's lv2 items"""
+    import oracle_binding as ob
+    from test_gpu_count import load, make_reads
+    if stage == "seq2sdbg":
+        from test_dist_cpu import _seqs_with_mult
+        seqs, mult = _seqs_with_mult(9)
+        pkg = ob.Package(seqs, reverse=False)
+        engine.load_sequences(pkg.words(), pkg.n_seqs, 0, pkg.start())
+        engine.load_multiplicity(mult)
+        items = ob.seq2sdbg_items(pkg, mult, k)
+        sid = 4
+    else:
+        pkg = ob.Package(make_reads("var", 13), reverse=True)
+        load(engine, pkg)
+        if stage == "count":
+            items, sid = ob.count_items(pkg, k), 3
+        elif stage in ("s1", "s1_mercy"):
+            items, sid = ob.s1_items(pkg, k), (1 if stage == "s1" else 5)
+        else:
+            s1 = ob.s1(pkg, k, m)
+            engine.set_is_solid(s1["is_solid"][: (pkg.start()[-1] + 63) // 64])  # per-occurrence stage 2 (no aggregates)
+            items, sid = ob.s2_items(pkg, k, m, s1["is_solid"]), 2
+    want = np.bincount(np.asarray(items)[:, 0] >> 16, minlength=65536).astype(np.uint64)
+    got = engine.bucket_histogram(sid, k, m)
+    assert np.array_equal(np.asarray(got, dtype=np.uint64), want)
