@@ -54,6 +54,8 @@ int mhx_synchronize(mhx_ctx *);
  *   s1_seg_bits (0)   force the prefix width of the partial stage-1 sort (0 = chosen from the item count)
  *   s1_seg_la (3)     look-ahead chunks of the segment group-by before a tile gives up (-> classic path)
  *   s1_seg_per (8)    records per thread and tile of the segment group-by (4 or 8)
+ *   s1_stream (1)     0: never the two-pass bucket-streaming variant (k_s1_stream); s1_stream_max (40000): largest
+ *                     average lv1 bucket (records) it is chosen for
  *   count_seg (1), count_seg_bits (0), count_seg_la (3)  the same for count (k_count_seg)
  *   dist_sparse_marks (0)  multi-GPU stage 1 emits MHX_ROUTE_S1_MARKS records instead of marking a bitmap of the
  *                     global read set (set by mhx_dist_setup; the torch.distributed path of megahit_amd/dist.py

@@ -763,6 +763,220 @@ __global__ __launch_bounds__(256) void k_s1_seg(const uint32_t *__restrict__ ite
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Bucket-streaming variant of the segment group-by: sort only the top 16 bits of the (k-1)-mer — the reference's lv1
+// bucket, two LSD passes — and let one workgroup take one whole bucket (~20 K records at 10 M reads): it streams the
+// bucket twice (the second time out of L2 / Infinity Cache: a bucket is a few hundred KB), first inserting the keys
+// into an LDS table, then marking every record with its key's count.  Inside a bucket the prefix is constant, so the
+// table key is the remaining 2(k-1)-16 (k-1)-mer bits + head/tail = 32 bits at k <= 22 (4-byte compare-and-swap), and
+// nothing of k_s1_seg's segment ownership / look-ahead is needed: "two-level bucketed sort" with the second level in LDS.
+// A bucket with more distinct keys than the table holds sets *err -> the host falls back to k_s1_seg (three passes).
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kStreamThreads = 512;
+constexpr int kStreamSlots = 8192;
+constexpr uint32_t kStreamEmpty = 0xFFFFFFFFu;  // never a key: head/tail bits 63 do not occur
+
+__global__ void k_bucket_bounds(const uint32_t *__restrict__ items, uint64_t n, int stride, uint64_t *__restrict__ bstart);  // kmsort_emu.hip
+
+template <bool AGG>
+__global__ __launch_bounds__(kStreamThreads) void k_s1_stream(const uint32_t *__restrict__ items, const uint64_t *__restrict__ bounds, S1SegArgs a,
+                                                             uint32_t bucket_stride, uint32_t *__restrict__ ticket) {
+  constexpr int NT = kStreamThreads, NSLOT = kStreamSlots, LOGS = 13;
+  static_assert((1 << LOGS) == NSLOT, "table size");
+  __shared__ uint32_t keys[NSLOT];
+  __shared__ uint32_t cnts[NSLOT];
+  __shared__ uint32_t lhist[kSegHist];
+  __shared__ uint32_t s_bad, s_agg_cur, s_mark_cur, s_bucket;
+  const int tid = threadIdx.x, lane = tid & (kWave - 1);
+  const uint64_t lanemask_lt = (1ull << lane) - 1;
+  uint2 *const agg_end = AGG ? a.agg_raw + (size_t)(blockIdx.x + 1) * a.agg_cap : nullptr;
+  unsigned long long *const marks_out = a.marks_raw ? a.marks_raw + (size_t)blockIdx.x * a.marks_cap : nullptr;
+  for (int i = tid; i < NSLOT; i += NT) {
+    keys[i] = kStreamEmpty;
+    cnts[i] = 0;
+  }
+  for (int i = tid; i < kSegHist; i += NT) lhist[i] = 0;
+  if (tid == 0) {
+    s_bad = 0;
+    s_agg_cur = 0;
+    s_mark_cur = 0;
+  }
+  __syncthreads();
+  const uint32_t m = a.m;
+  const int k = a.k;
+  // local key: the (k-1)-mer bits below the 16-bit bucket prefix, then head/tail (the rank tag bits in between dropped)
+  const int rem = 2 * (k - 1) - 16;  // 2..26 bits at k = 10..22
+  auto local_key = [&](uint32_t w0, uint32_t w1) -> uint32_t {
+    const uint64_t key = ((uint64_t)w0 << 32) | w1;
+    return (uint32_t)((key << 16) >> (64 - rem)) << 6 | (w1 & 63u);
+  };
+  unsigned long long st_solid = 0, st_both = 0;
+
+  for (;;) {
+    if (tid == 0) s_bucket = atomicAdd(ticket, 1u);
+    __syncthreads();
+    const uint32_t bi = s_bucket * bucket_stride;
+    if (bi >= MHX_NUM_BUCKETS) break;
+    const uint64_t lo = bounds[bi], hi = bounds[bi + 1];
+    if (lo == hi) {
+      __syncthreads();
+      continue;
+    }
+    // A: insert (wave-aggregated: one compare-and-swap + add per group of equal keys in a wavefront)
+    for (uint64_t base = lo; base < hi; base += NT) {
+      const uint64_t gi = base + tid;
+      const bool ins = gi < hi;
+      uint32_t lk = 0;
+      if (ins) {
+        const uint32_t *p = items + gi * 3;
+        lk = local_key(p[0], p[1]);
+      }
+      const uint32_t hf = lk * 0x9E3779B1u;
+      const uint32_t hm = hf >> 25;
+      uint64_t pm = __ballot(ins);
+#pragma unroll
+      for (int b = 0; b < 7; ++b) {
+        const bool bit = (hm >> b) & 1u;
+        const uint64_t mb = __ballot(bit);
+        pm &= bit ? mb : ~mb;
+      }
+      const int leader = ins ? __builtin_ctzll(pm) : lane;
+      const bool eq = ins && __shfl(lk, leader, kWave) == lk;
+      const uint64_t grp = __ballot(eq) & pm;
+      if (ins && (lane == leader || !eq)) {
+        const uint32_t mult = lane == leader ? (uint32_t)__builtin_popcountll(grp) : 1u;
+        uint32_t h = hf >> (32 - LOGS);
+        int probes = 0;
+        const int probe_limit = a.la_chunks;  // (stream mode: the host passes the probe limit here; tests set it to 0)
+        for (; probes < probe_limit; ++probes) {
+          const uint32_t old = atomicCAS(&keys[h], kStreamEmpty, lk);
+          if (old == kStreamEmpty || old == lk) {
+            atomicAdd(&cnts[h], mult);
+            break;
+          }
+          h = (h + 1) & (NSLOT - 1);
+        }
+        if (probes == probe_limit) s_bad = 1;
+      }
+    }
+    __syncthreads();
+    const bool bad = s_bad != 0;
+    uint32_t my_agg = 0;
+    if (!bad) {
+      // B: marks, streaming the bucket again (cache-resident)
+      if (a.mark_mode != 2) {
+        for (uint64_t base = lo; base < hi; base += NT) {
+          const uint64_t gi = base + tid;
+          const bool in = gi < hi;
+          uint32_t w1 = 0, w2 = 0, cnt = 0;
+          if (in) {
+            const uint32_t *p = items + gi * 3;
+            const uint32_t w0 = p[0];
+            w1 = p[1];
+            w2 = p[2];
+            const uint32_t lk = local_key(w0, w1);
+            uint32_t h = (lk * 0x9E3779B1u) >> (32 - LOGS);
+            while (keys[h] != lk) h = (h + 1) & (NSLOT - 1);
+            cnt = cnts[h];
+          }
+          const bool both = (w1 & 0x24u) == 0;
+          const bool solid = both && cnt >= m;
+          const bool mk = in && (a.mark_mode == 1 ? (both && !solid) : solid);
+          const uint64_t abs = w2 + (uint64_t)((w1 >> 6) & 0xFFu) * a.pos_stride;
+          if (!marks_out) {
+            if (mk) a.solid_bytes[abs - 1] = 1;  // is_solid.set(pos - 1), :464 (or its complement)
+          } else {
+            const uint64_t mm = __ballot(mk);
+            if (mm) {
+              uint32_t mbase = 0;
+              if (lane == 0) mbase = atomicAdd(&s_mark_cur, (uint32_t)__builtin_popcountll(mm));
+              mbase = __shfl(mbase, 0, kWave);
+              if (mk) {
+                const uint32_t at = mbase + (uint32_t)__builtin_popcountll(mm & lanemask_lt);
+                if (at + s_agg_cur < a.marks_cap) marks_out[at] = abs - 1;
+                else atomicOr(a.err, 2u);
+              }
+            }
+          }
+        }
+      }
+      // C: per distinct key (every occupied slot)
+      for (int sl = tid; sl < NSLOT; sl += NT) {
+        const uint32_t lk = keys[sl];
+        if (lk == kStreamEmpty || (lk & 0x24u) != 0) continue;
+        const uint32_t cnt = cnts[sl];
+        const bool solid = cnt >= m;
+        if (a.mark_mode == 2) {
+          st_both += cnt;
+          if (solid) st_solid += cnt;
+          continue;
+        }
+        const uint32_t hb = cnt > MHX_MAX_MUL ? (uint32_t)MHX_MAX_MUL : cnt;  // :430-436
+        if (hb < kSegHist) atomicAdd(&lhist[hb], 1u);
+        else atomicAdd(&a.hist[hb], 1ull);
+        if (AGG && solid) {
+          const uint64_t smer = ((uint64_t)bi << 48) | ((uint64_t)(lk >> 6) << (48 - rem));  // the (k-1)-mer, MSB-first
+          const uint64_t x = ((uint64_t)((lk >> 3) & 7u) << 62) | (smer >> 2) | ((uint64_t)(lk & 7u) << (62 - 2 * k));
+          my_agg += x == rc64(x, k + 1) ? 1u : 2u;
+        }
+      }
+    }
+    uint32_t agg_at = 0;
+    bool agg_ok = true;
+    if constexpr (AGG) {
+      const uint32_t incl = wave_inclusive_sum(my_agg);
+      const uint32_t tot = __shfl(incl, kWave - 1, kWave);
+      uint32_t wbase = 0;
+      if (lane == 0 && tot) wbase = atomicAdd(&s_agg_cur, tot);
+      wbase = __shfl(wbase, 0, kWave);
+      agg_ok = wbase + tot + (marks_out ? s_mark_cur : 0u) <= a.agg_cap;
+      if (!agg_ok && lane == 0) atomicOr(a.err, 1u);
+      agg_at = wbase + incl - my_agg;
+    }
+    __syncthreads();  // every count has been read: emit, then recycle the slots
+    for (int sl = tid; sl < NSLOT; sl += NT) {
+      const uint32_t lk = keys[sl];
+      if (lk == kStreamEmpty) continue;
+      if constexpr (AGG) {
+        const uint32_t cnt = cnts[sl];
+        if (!bad && agg_ok && a.mark_mode != 2 && (lk & 0x24u) == 0 && cnt >= m) {
+          const uint64_t mask_k = ~0ull << (64 - 2 * k);
+          const uint64_t smer = ((uint64_t)bi << 48) | ((uint64_t)(lk >> 6) << (48 - rem));
+          const uint64_t x = ((uint64_t)((lk >> 3) & 7u) << 62) | (smer >> 2) | ((uint64_t)(lk & 7u) << (62 - 2 * k));
+          const uint64_t xr = rc64(x, k + 1);
+          const uint64_t mul = cnt > MHX_MAX_MUL ? (uint64_t)MHX_MAX_MUL : cnt;
+          const uint64_t f = ((x << 2) & mask_k) | (1ull << 19) | ((x >> 62) << 16) | mul;
+          agg_end[-1 - (long)agg_at++] = make_uint2((uint32_t)(f >> 32), (uint32_t)f);
+          if (x != xr) {
+            const uint64_t b = ((xr << 2) & mask_k) | (1ull << 19) | ((xr >> 62) << 16) | mul;
+            agg_end[-1 - (long)agg_at++] = make_uint2((uint32_t)(b >> 32), (uint32_t)b);
+          }
+        }
+      }
+      keys[sl] = kStreamEmpty;
+      cnts[sl] = 0;
+    }
+    if (bad && tid == 0) {
+      atomicOr(a.err, 1u);
+      s_bad = 0;
+    }
+    __syncthreads();
+  }
+  if (a.mark_mode == 2) {
+    st_solid = wave_sum(st_solid);
+    st_both = wave_sum(st_both);
+    if (lane == 0 && st_both) {
+      atomicAdd(a.ctr, st_solid);
+      atomicAdd(a.ctr + 2, st_both);
+    }
+  } else {
+    for (int i = tid; i < kSegHist; i += NT)
+      if (lhist[i]) atomicAdd(&a.hist[i], (unsigned long long)lhist[i]);
+    if (AGG && tid == 0) a.agg_counts[blockIdx.x] = s_agg_cur < a.agg_cap ? s_agg_cur : a.agg_cap;
+    if (marks_out && tid == 0) a.marks_counts[blockIdx.x] = s_mark_cur < a.marks_cap ? s_mark_cur : a.marks_cap;
+  }
+}
+
 // regions of k_s1_seg -> one dense array: block (r, j) copies slice j of region r behind the items of the regions before it
 __global__ __launch_bounds__(256) void k_agg_compact(const uint2 *__restrict__ raw, uint32_t cap, const uint32_t *__restrict__ counts,
                                                     uint2 *__restrict__ dense, int from_back) {
@@ -998,13 +1212,22 @@ static std::vector<SortPass> s1_sort_passes(uint32_t k) {
 struct S1Plan {
   std::vector<SortPass> passes;
   int seg_bits;
+  bool stream;  // seg_bits == 16 and one workgroup streams one lv1 bucket (k_s1_stream) instead of tiles (k_s1_seg)
 };
-static S1Plan s1_plan(const mhx_ctx *c, uint32_t k, uint64_t n_items, bool compact, int want_mercy) {
+static S1Plan s1_plan(const mhx_ctx *c, uint32_t k, uint64_t n_items, bool compact, int want_mercy, bool allow_stream = true) {
   const int force_bits = (int)c->opt("s1_seg_bits", 0);
   const int kmer_bits = (int)(k - 1) * 2;
-  S1Plan p{s1_sort_passes(k), 0};
+  S1Plan p{s1_sort_passes(k), 0, false};
   if (!c->opt("s1_seg", 1) || !compact || want_mercy || s1_kw(k) != 2 || s1_stride(k, compact) != 3 || !n_items) return p;
   const double n_eff = (double)n_items * (double)(c->n_parts > 1 ? c->n_parts : 1);
+  // two passes + bucket streaming while a bucket's distinct keys fit the LDS table (~1/8 of its records are distinct at
+  // 60x coverage; a fuller table sends the host to the tile kernel below)
+  if (allow_stream && c->opt("s1_stream", 1) && !force_bits && k >= 10 && k <= 22 && n_eff / 65536.0 <= (double)c->opt("s1_stream_max", 40000)) {
+    p.seg_bits = 16;
+    p.stream = true;
+    p.passes = make_passes(2, 48, 64);
+    return p;
+  }
   int bits = 8;
   while (bits < 32 && n_eff / 96.0 > (double)(1ull << bits)) bits += 8;
   if (force_bits) bits = force_bits;
@@ -1116,7 +1339,7 @@ int s1_process(mhx_ctx *c, uint32_t k, uint32_t m, int want_mercy, uint32_t *buf
   const bool global = c->global_bases != 0;  // multi-GPU: positions index the global read set
   const int kmer_bits = (int)(k - 1) * 2;
   // want_mercy == 2: records with equal keys in exactly the order the reference's kmsort leaves them (H1)
-  const S1Plan plan = s1_plan(c, k, n_items, compact, want_mercy);
+  S1Plan plan = s1_plan(c, k, n_items, compact, want_mercy);
   uint32_t *sorted = want_mercy == 2
                          ? kmsort_exact(c, buf_a, buf_b, n_items, S, KWv)
                          : radix_sort(c, buf_a, buf_b, n_items, S, KWv, plan.passes);
@@ -1190,12 +1413,12 @@ int s1_process(mhx_ctx *c, uint32_t k, uint32_t m, int want_mercy, uint32_t *buf
     const int T = 256 * (per == 4 ? 4 : 8);
     const uint64_t n_tiles = div_ceil(n_items, (uint64_t)T);
     const uint32_t stride = mode == 2 ? 64u : 1u;
-    const uint64_t n_work = div_ceil(n_tiles, stride);
+    const uint64_t n_work = plan.stream ? MHX_NUM_BUCKETS / stride : div_ceil(n_tiles, stride);
     const uint64_t pos_stride = s1_rank_tagged(c, k) ? c->global_bases / (uint64_t)c->n_parts : 0;
     const uint32_t pfx_mask = plan.seg_bits >= 32 ? 0xFFFFFFFFu : ~(0xFFFFFFFFu >> plan.seg_bits);
     const uint32_t eq_mask1 = (kmer_bits > 32 ? ~(0xFFFFFFFFu >> (kmer_bits - 32)) : 0u) | 63u;
     const bool agg_on = agg && mode != 2;
-    const unsigned grid = (unsigned)std::min<uint64_t>(n_work, per == 4 ? 256 * 6 : 256 * 3);
+    const unsigned grid = (unsigned)std::min<uint64_t>(n_work, plan.stream ? 256 * 2 : (per == 4 ? 256 * 6 : 256 * 3));
     // per-workgroup output regions in the spare sort buffer (S*4 >= 12 bytes per record, outputs are 8-byte entries)
     const uint32_t region = (uint32_t)std::min<uint64_t>(n_items * (uint64_t)S * 4 / 8 / grid, 0xFFFFFFF0u);
     uint2 *raw = nullptr;
@@ -1218,10 +1441,22 @@ int s1_process(mhx_ctx *c, uint32_t k, uint32_t m, int want_mercy, uint32_t *buf
       seg_grid = grid;
       seg_mcap = mcap;
     }
-    S1SegArgs a{(int)k, m, pfx_mask, eq_mask1, solid_bytes, mode, hist, ctr, raw, seg_cap, counts, mraw, mcap, mcounts, pos_stride, seg_err, la};
+    S1SegArgs a{(int)k, m, pfx_mask, eq_mask1, solid_bytes, mode, hist, ctr, raw, seg_cap, counts, mraw, mcap, mcounts, pos_stride, seg_err,
+                plan.stream ? (int)c->opt("s1_stream_probes", 1024) : la};
     MHX_HIP(hipMemsetAsync(seg_err, 0, 4, st));
     const char *nm = mode == 2 ? "s1_sample" : "s1_groups";
-    const double bytes = (double)n_work * T * 12;
+    const double bytes = plan.stream ? (double)n_items * 12 / stride : (double)n_work * T * 12;
+    if (plan.stream) {
+      uint64_t *bounds = c->ws("s1_bucket_bounds", (MHX_NUM_BUCKETS + 2) * 8).as<uint64_t>();
+      uint32_t *ticket = c->ws("s1_stream_ticket", 64).as<uint32_t>();
+      MHX_HIP(hipMemsetAsync(ticket, 0, 4, st));
+      hipLaunchKernelGGL(k_bucket_bounds, dim3(MHX_NUM_BUCKETS / 256 + 1), dim3(256), 0, st, sorted, n_items, 3, bounds);
+      if (agg_on)
+        MHX_LAUNCH(c, nm, bytes, hipLaunchKernelGGL((k_s1_stream<true>), dim3(grid), dim3(kStreamThreads), 0, st, sorted, bounds, a, stride, ticket));
+      else
+        MHX_LAUNCH(c, nm, bytes, hipLaunchKernelGGL((k_s1_stream<false>), dim3(grid), dim3(kStreamThreads), 0, st, sorted, bounds, a, stride, ticket));
+      return;
+    }
 #define MHX_SEG(PERV, AGGV) \
   MHX_LAUNCH(c, nm, bytes, hipLaunchKernelGGL((k_s1_seg<PERV, AGGV>), dim3(grid), dim3(256), 0, st, sorted, n_items, a, n_work, stride))
     if (per == 4) {
@@ -1269,6 +1504,7 @@ int s1_process(mhx_ctx *c, uint32_t k, uint32_t m, int want_mercy, uint32_t *buf
       // histogram / aggregate cursor as they are now, in case a tile gives up and the classic path has to redo the job
       unsigned long long *hist_save = c->ws("s1_hist_save", (MHX_MAX_MUL + 1) * 8).as<unsigned long long>();
       MHX_HIP(hipMemcpyAsync(hist_save, hist, (MHX_MAX_MUL + 1) * 8, hipMemcpyDeviceToDevice, st));
+    seg_again:
       seg_launch(mark_mode);
       uint32_t e = 0;
       std::vector<uint32_t> h_counts(agg ? seg_grid : 0), h_mcounts(sparse ? seg_grid : 0);
@@ -1296,6 +1532,17 @@ int s1_process(mhx_ctx *c, uint32_t k, uint32_t m, int want_mercy, uint32_t *buf
         const uint64_t agg_n = agg_prev + total;
         MHX_HIP(hipMemcpyAsync(agg_cursor, &agg_n, 8, hipMemcpyHostToDevice, st));
         MHX_HIP(hipStreamSynchronize(st));  // agg_n is a stack variable
+      }
+      if (e && plan.stream) {  // a bucket with too many distinct keys for the LDS table: three passes + the tile kernel
+        MHX_HIP(hipMemcpyAsync(hist, hist_save, (MHX_MAX_MUL + 1) * 8, hipMemcpyDeviceToDevice, st));
+        MHX_HIP(hipMemsetAsync(ctr, 0, 64, st));
+        plan = s1_plan(c, k, n_items, compact, want_mercy, false);
+        uint32_t *other = sorted == buf_a ? buf_b : buf_a;
+        sorted = radix_sort(c, sorted, other, n_items, S, KWv, plan.passes);
+        spare = sorted == buf_a ? buf_b : buf_a;
+        mercy = reinterpret_cast<long long *>(spare);
+        seg_marks = 0;
+        goto seg_again;
       }
       if (e) {  // a segment beyond the look-ahead or a full table: full sort + the classic tile kernel (marks are idempotent)
         seg_failed = true;
