@@ -74,7 +74,9 @@ def test_cli_automatic_memory_plan(ent, tmp_path, monkeypatch):
     """the planner itself (plan_ranges: free HBM minus the stage's fixed state, / 3 item buffers) decides on several lv1
     passes when the free memory is small — here a faked 6 MB (MHX_FREE_BYTES) — and the outputs stay the reference's"""
     import subprocess
-    monkeypatch.setenv("MHX_FREE_BYTES", "6e6")
+    with open(os.path.join(gu.GOLD, ent["case"]["lib"] + ".lib_info")) as f:
+        total_bases = int(f.read().split()[0])
+    monkeypatch.setenv("MHX_FREE_BYTES", str(40 * total_bases))  # room for ~0.6 items per base: two or three passes
     got = gu.run_case(gu.MHX_CORE, ent, str(tmp_path))
     for key, want in ent.items():
         if key in ("case", "mercy_cand_kmsort"):
