@@ -118,7 +118,8 @@ enum mhx_buffer {
   MHX_BUF_SDBG_RS_LAST_L1 = 32, /* uint16[num_l1_bits] */
   MHX_BUF_SDBG_RS_LAST_SEL = 33,/* uint32[last_sel_count] */
   MHX_BUF_SDBG_RS_TIP_L2 = 34,  /* rank-only structure over tip */
-  MHX_BUF_SDBG_RS_TIP_L1 = 35
+  MHX_BUF_SDBG_RS_TIP_L1 = 35,
+  MHX_BUF_LIB_RECORDS = 40      /* uint32[]: read-library records (len + packed words per read) of mhx_fastx_to_records */
 };
 /* bytes currently held in a result buffer (0 if absent) */
 uint64_t mhx_buffer_bytes(const mhx_ctx *, int which);
@@ -199,6 +200,20 @@ int mhx_sdbg_build_index(mhx_ctx *, uint32_t k, mhx_sdbg_index_info *out);
  * current SdBG; the four tables have 65536 entries (starting byte, items, tips, large multiplicities per bucket) */
 int mhx_sdbg_load_bytes(mhx_ctx *, const uint8_t *bytes, uint64_t n_bytes, const uint64_t *bucket_offset, const uint64_t *bucket_items,
                         const uint64_t *bucket_tips, const uint64_t *bucket_large);
+
+/* ---- buildlib on the GPU.  FASTA / FASTQ text (already inflated) -> the record stream of a read
+ * library (`<lib>.bin`: per read uint32 length + ceil(len/16) words, 2 bits per base MSB first, forward orientation;
+ * sequence_package.h:224-240) in MHX_BUF_LIB_RECORDS, with the reference's N-trimming (fastx_reader.cpp:56-71) and
+ * character mapping (sequence_package.h:78-83).  text2 != NULL: a paired library, records interleaved r1, r2, r1, ...
+ * (paired_fastx_reader.cpp:7-43).  Replaces SequenceLibCollection::Build's parse + pack (sequence_lib.cpp:8-91).
+ * out->status 1 = the text is not plain FASTA / four-line FASTQ (carriage returns, multi-line FASTQ, junk before the
+ * first header, mates of different counts): nothing was produced, run a sequential kseq-compatible parser instead. ---- */
+typedef struct {
+  uint64_t n_reads, n_bases, n_words; /* n_bases counts an all-N / empty read as 1 (it is stored as one 'A') */
+  uint32_t max_len;
+  int status;
+} mhx_fastx_result;
+int mhx_fastx_to_records(mhx_ctx *, const char *text1, uint64_t n1, const char *text2, uint64_t n2, mhx_fastx_result *out);
 
 /* B3: sort n fixed-width records in place on the GPU, ascending by the first key_words words
  * (lexicographic on uint32, as Substr::operator<, kmsort_selector.cpp:18-27); aux words ride

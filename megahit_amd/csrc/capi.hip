@@ -608,6 +608,13 @@ int mhx_gen_mercy_edges(mhx_ctx *c, uint32_t k, const uint32_t *cand_packed, uin
   })
 }
 
+int mhx_fastx_to_records(mhx_ctx *c, const char *text1, uint64_t n1, const char *text2, uint64_t n2, mhx_fastx_result *out) {
+  MHX_TRY({
+    MHX_HIP(hipSetDevice(c->device));
+    if (!out || !text1) throw mhx::Error("fastx_to_records: bad arguments");
+    mhx::fastx_to_records(c, text1, n1, text2, n2, out);
+  })
+}
 int mhx_sdbg_build_index(mhx_ctx *c, uint32_t k, mhx_sdbg_index_info *out) {
   MHX_TRY({
     MHX_HIP(hipSetDevice(c->device));

@@ -7,6 +7,7 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <cctype>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -91,6 +92,126 @@ std::vector<uint32_t> read_bin_file(const std::string &path) {
   if (sz && fread(v.data(), 4, v.size(), f) != v.size()) fatal("short read on %s", path.c_str());
   fclose(f);
   return v;
+}
+
+std::vector<char> read_text_file(const std::string &path) {
+  gzFile f = path == "-" ? gzdopen(fileno(stdin), "r") : gzopen(path.c_str(), "r");
+  if (!f) fatal("Cannot open file %s", path.c_str());
+  gzbuffer(f, 1 << 20);
+  std::vector<char> v;
+  size_t cap = 1 << 24, len = 0;
+  v.resize(cap);
+  for (;;) {
+    if (cap - len < (1u << 22)) {
+      cap *= 2;
+      v.resize(cap);
+    }
+    const int got = gzread(f, v.data() + len, (unsigned)std::min<size_t>(cap - len, 1u << 30));
+    if (got < 0) fatal("read error on %s", path.c_str());
+    if (got == 0) break;
+    len += (size_t)got;
+  }
+  gzclose(f);
+  v.resize(len);
+  return v;
+}
+
+void parse_fastx_sequential(const std::vector<char> &text, const std::function<void(const char *, size_t)> &on_seq) {
+  const char *t = text.data();
+  const size_t n = text.size();
+  size_t i = 0;
+  int last_char = 0;
+  std::string seq, line;
+  // one line starting at i (without its '\n'); advances i past the newline
+  auto take_line = [&](std::string *dst, bool append) {
+    size_t e = i;
+    while (e < n && t[e] != '\n') ++e;
+    if (!append) dst->clear();
+    dst->append(t + i, e - i);
+    i = e < n ? e + 1 : n;
+    if (dst->size() > 1 && dst->back() == '\r') dst->pop_back();  // ks_getuntil2: on the accumulated string
+  };
+  for (;;) {
+    if (last_char == 0) {  // jump to the next header char, anywhere
+      while (i < n && t[i] != '>' && t[i] != '@') ++i;
+      if (i >= n) return;
+      last_char = t[i++];
+    }
+    if (i >= n) return;  // a header char at the very end: ks_getuntil finds nothing -> EOF
+    // name = up to the first whitespace, then the rest of the header line is the comment
+    {
+      size_t e = i;
+      while (e < n && !isspace((unsigned char)t[e])) ++e;
+      const bool at_newline = e < n && t[e] == '\n';
+      i = e < n ? e + 1 : n;
+      if (!at_newline && e < n) take_line(&line, false);
+    }
+    seq.clear();
+    int c = -1;
+    while (i < n) {
+      c = (unsigned char)t[i++];
+      if (c == '>' || c == '+' || c == '@') break;
+      if (c == '\n') {
+        c = -1;
+        continue;
+      }
+      seq.push_back((char)c);
+      take_line(&seq, true);
+      c = -1;
+    }
+    if (c == '>' || c == '@') last_char = c;
+    else last_char = 0;
+    if (c != '+') {  // FASTA record (or the last record of the stream)
+      on_seq(seq.data(), seq.size());
+      if (c == -1) return;  // end of text
+      continue;
+    }
+    // FASTQ: skip the rest of the '+' line, then read quality lines until they cover the sequence
+    while (i < n && t[i] != '\n') ++i;
+    if (i >= n) return;  // no quality string: error -> the reader stops
+    ++i;
+    std::string qual;
+    do take_line(&qual, true);  // (kseq reads at least one quality line, even for an empty sequence)
+    while (qual.size() < seq.size() && i < n);
+    last_char = 0;
+    if (qual.size() != seq.size()) return;  // malformed: the reader stops here
+    on_seq(seq.data(), seq.size());
+  }
+}
+
+uint32_t append_bin_record(std::vector<uint32_t> *out, const char *s, size_t len) {
+  size_t b = len, e = len, i = 0;
+  for (; i < len; ++i) {
+    if (s[i] == 'N' || s[i] == 'n') {
+      if (b < len) break;
+    } else if (b == len) {
+      b = i;
+    }
+  }
+  e = i;
+  const char *p = s + b;
+  size_t L = e - b;
+  static const char fake[] = "A";
+  if (L == 0) {
+    p = fake;
+    L = 1;
+  }
+  out->push_back((uint32_t)L);
+  for (size_t w = 0; w * 16 < L; ++w) {
+    uint32_t v = 0;
+    for (size_t j = 0; j < 16 && w * 16 + j < L; ++j) {
+      unsigned code = 0;
+      switch (p[w * 16 + j]) {
+        case 'C': case 'c': code = 1; break;
+        case 'G': case 'g': case 'N': case 'n': code = 2; break;
+        case 'T': case 't': code = 3; break;
+        default: code = 0;
+      }
+      v |= code << (30 - 2 * j);
+    }
+    out->push_back(v);
+  }
+  return (uint32_t)L;
 }
 
 std::vector<uint64_t> index_bin_records(const uint32_t *rec, uint64_t n_words) {

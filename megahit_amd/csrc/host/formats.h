@@ -3,6 +3,7 @@
 // whose output/input it must match.
 #pragma once
 #include <cstdint>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -49,6 +50,16 @@ struct BinFile {
   friend BinFile open_bin_file(const std::string &path);
 };
 BinFile open_bin_file(const std::string &path);
+
+// whole (possibly gzip'ed) file -> memory; "-" = stdin (FastxReader opens its files through zlib the same way)
+std::vector<char> read_text_file(const std::string &path);
+// Sequential FASTA/FASTQ parser with kseq's semantics (kseq.h:193-247): multi-line records, junk before the first header,
+// '\r' stripped at line ends as ks_getuntil2 does, the stream ends at the first malformed FASTQ record.  calls
+// on_seq(ptr, len) per record.  The fallback of `buildlib` for texts the GPU parser declines.
+void parse_fastx_sequential(const std::vector<char> &text, const std::function<void(const char *, size_t)> &on_seq);
+// TrimN + character map + 2-bit packing of one sequence, appended as a .bin record (fastx_reader.cpp:56-71,
+// sequence_package.h:78-83,224-240,262-267); returns the stored length
+uint32_t append_bin_record(std::vector<uint32_t> *out, const char *s, size_t len);
 
 // EdgeWriter + EdgeIoMetadata::Serialize (edge_writer.h:17-111, edge_io_meta.h:25-44); edges are in
 // bucket order; they are split over n_files files at bucket boundaries.

@@ -757,11 +757,119 @@ int main_seq2sdbg(int argc, char **argv) {
   finish(c);
 }
 
+// ---------------------------------------------------------------------------
+// buildlib (reference src/main_buildlib.cpp + SequenceLibCollection::Build, sequence_lib.cpp:8-91): read-library
+// description -> <out>.bin + <out>.lib_info.  The texts are parsed and packed on the GPU (mhx_fastx_to_records);
+// a text the GPU parser declines goes through the sequential kseq-compatible parser.  MHX_BUILDLIB_HOST=1 forces that.
+int main_buildlib(int argc, char **argv) {
+  if (argc < 3) {
+    fprintf(stderr, "Usage %s <read_lib_file> <out_prefix>\n", argv[0]);
+    exit(1);
+  }
+  const std::string lib_file = argv[1], out = argv[2];
+  Timer t;
+  FILE *cfg = fopen(lib_file.c_str(), "r");
+  if (!cfg) fatal("File to open read_lib file: %s", lib_file.c_str());
+  std::vector<char> cfg_text;
+  for (int ch; (ch = fgetc(cfg)) != EOF;) cfg_text.push_back((char)ch);
+  fclose(cfg);
+  FILE *bin = fopen((out + ".bin").c_str(), "wb");
+  if (!bin) fatal("Cannot open %s.bin", out.c_str());
+  const bool host_only = getenv("MHX_BUILDLIB_HOST") != nullptr;
+  mhx_ctx *c = nullptr;
+  struct Lib {
+    std::string meta;
+    int64_t begin, end;
+    unsigned max_len;
+    bool paired;
+  };
+  std::vector<Lib> libs;
+  int64_t total_reads = 0, total_bases = 0;
+  // the description: per library one free-text line, then "<type> <file> [<file2>]" (sequence_lib.cpp:29-44)
+  size_t pos = 0;
+  auto next_line = [&](std::string *dst) -> bool {
+    if (pos >= cfg_text.size()) return false;
+    size_t e = pos;
+    while (e < cfg_text.size() && cfg_text[e] != '\n') ++e;
+    dst->assign(cfg_text.data() + pos, e - pos);
+    pos = e < cfg_text.size() ? e + 1 : e;
+    return true;
+  };
+  std::string meta, spec;
+  while (next_line(&meta)) {
+    if (!next_line(&spec)) break;
+    char type[64] = {0}, f1[4096] = {0}, f2[4096] = {0};
+    const int got = sscanf(spec.c_str(), "%63s %4095s %4095s", type, f1, f2);
+    const std::string ty = type;
+    if (got < 2 || (ty != "pe" && ty != "se" && ty != "interleaved") || (ty == "pe" && got < 3)) {
+      fprintf(stderr, "Cannot identify read library type %s\n", type);
+      fatal("Valid types: pe, se, interleaved");
+    }
+    std::vector<char> t1 = mhxio::read_text_file(f1), t2;
+    if (ty == "pe") t2 = mhxio::read_text_file(f2);
+    const int64_t begin = total_reads;
+    unsigned max_len = 0;
+    bool done = false;
+    if (!host_only) {
+      if (!c) c = open_gpu();
+      mhx_fastx_result r{};
+      CK(mhx_fastx_to_records(c, t1.data(), t1.size(), ty == "pe" ? t2.data() : nullptr, t2.size(), &r));
+      if (r.status == 0) {
+        std::vector<uint32_t> rec(r.n_words);
+        if (r.n_words) CK(mhx_fetch(c, MHX_BUF_LIB_RECORDS, rec.data(), 0, r.n_words * 4));
+        if (r.n_words && fwrite(rec.data(), 4, rec.size(), bin) != rec.size()) fatal("write error on %s.bin", out.c_str());
+        total_reads += (int64_t)r.n_reads;
+        total_bases += (int64_t)r.n_bases;
+        max_len = r.max_len;
+        done = true;
+      } else {
+        info("%s: not plain FASTA / four-line FASTQ, using the sequential parser", f1);
+      }
+    }
+    if (!done) {
+      std::vector<uint32_t> rec;
+      auto add = [&](const char *s, size_t len) {
+        const uint32_t L = mhxio::append_bin_record(&rec, s, len);
+        total_bases += L;
+        ++total_reads;
+        max_len = std::max(max_len, L);
+      };
+      if (ty == "pe") {  // alternate the two files, stop when either ends (paired_fastx_reader.cpp:7-43)
+        std::vector<std::string> a, b;
+        mhxio::parse_fastx_sequential(t1, [&](const char *s, size_t len) { a.emplace_back(s, len); });
+        mhxio::parse_fastx_sequential(t2, [&](const char *s, size_t len) { b.emplace_back(s, len); });
+        for (size_t i = 0; i < std::min(a.size(), b.size()); ++i) {
+          add(a[i].data(), a[i].size());
+          add(b[i].data(), b[i].size());
+        }
+      } else {
+        mhxio::parse_fastx_sequential(t1, add);
+      }
+      if (!rec.empty() && fwrite(rec.data(), 4, rec.size(), bin) != rec.size()) fatal("write error on %s.bin", out.c_str());
+    }
+    if (ty != "se" && (total_reads - begin) % 2 != 0) {
+      fprintf(stderr, "PE library number of reads is odd: %lld!\n", (long long)(total_reads - begin));
+      fatal("File(s): %s", meta.c_str());
+    }
+    info("Lib %zu (%s): %s, %lld reads, %u max length", libs.size(), meta.c_str(), type, (long long)(total_reads - begin), max_len);
+    libs.push_back({meta, begin, total_reads, max_len, ty != "se"});
+  }
+  if (fclose(bin) != 0) fatal("write error on %s.bin", out.c_str());
+  FILE *li = fopen((out + ".lib_info").c_str(), "w");
+  if (!li) fatal("Cannot open %s.lib_info", out.c_str());
+  fprintf(li, "%lld %lld\n", (long long)total_bases, (long long)total_reads);
+  for (const Lib &l : libs) fprintf(li, "%s\n%lld %lld %u %d\n", l.meta.c_str(), (long long)l.begin, (long long)l.end, l.max_len, l.paired ? 1 : 0);
+  if (fclose(li) != 0) fatal("write error on %s.lib_info", out.c_str());
+  info("buildlib done: %lld reads, %lld bases. Time elapsed: %.4f", (long long)total_reads, (long long)total_bases, t.lap());
+  if (c) finish(c);
+  return 0;
+}
+
 }  // namespace
 
 int main(int argc, char **argv) {
   if (argc < 2) {
-    fprintf(stderr, "Usage: %s <sub_program> [sub options]\n    sub-programs: count read2sdbg seq2sdbg (GPU); others via MHX_REF_CORE\n", argv[0]);
+    fprintf(stderr, "Usage: %s <sub_program> [sub options]\n    sub-programs: buildlib count read2sdbg seq2sdbg (GPU); others via MHX_REF_CORE\n", argv[0]);
     return 1;
   }
   // `mhx_core --gpus N <sub-program> ...` (or MHX_NUM_GPUS): our only addition to the reference's command line; it sits
@@ -785,6 +893,7 @@ int main(int argc, char **argv) {
   if (sub == "read2sdbg") return main_read2sdbg(argc - 1, argv + 1);
   if (sub == "seq2sdbg") return main_seq2sdbg(argc - 1, argv + 1);
   if (sub == "kmax") { printf("%d\n", MHX_MAX_K); return 0; }
+  if (sub == "buildlib" && !getenv("MHX_BUILDLIB_REF")) return main_buildlib(argc - 1, argv + 1);
   if (const char *ref = getenv("MHX_REF_CORE")) {
     execv(ref, argv);  // buildlib / assemble / iterate / local / ... : not on this path
     perror("execv MHX_REF_CORE");

@@ -31,6 +31,7 @@ BUF_SORTED_ITEMS = 12
  BUF_SDBG_RS_W_L2, BUF_SDBG_RS_W_L1, BUF_SDBG_RS_W_SEL, BUF_SDBG_RS_LAST_L2, BUF_SDBG_RS_LAST_L1, BUF_SDBG_RS_LAST_SEL, BUF_SDBG_RS_TIP_L2,
  BUF_SDBG_RS_TIP_L1) = range(20, 36)
 BUF_W_COUNT = 13
+BUF_LIB_RECORDS = 40
 
 
 class MhxError(RuntimeError):
@@ -55,6 +56,10 @@ class SdbgResult(C.Structure):
 class KernelStat(C.Structure):
     _fields_ = [("name", C.c_char * 48), ("launches", C.c_uint32), ("total_ms", C.c_double),
                 ("algo_bytes", C.c_double)]
+
+
+class FastxResult(C.Structure):
+    _fields_ = [("n_reads", C.c_uint64), ("n_bases", C.c_uint64), ("n_words", C.c_uint64), ("max_len", C.c_uint32), ("status", C.c_int)]
 
 
 class SdbgIndexInfo(C.Structure):
@@ -115,6 +120,7 @@ SYMBOLS = {
     "mhx_dist_apply_routed": (C.c_int, [_P, C.c_int, C.c_uint64]),
     "mhx_device_pointer": (_P, [_P, C.c_int]),
     "mhx_adopt_is_solid_slice": (C.c_int, [_P, _P, C.c_uint64]),
+    "mhx_fastx_to_records": (C.c_int, [_P, C.c_char_p, C.c_uint64, C.c_char_p, C.c_uint64, C.POINTER(FastxResult)]),
     "mhx_sdbg_build_index": (C.c_int, [_P, C.c_uint32, C.POINTER(SdbgIndexInfo)]),
     "mhx_sdbg_load_bytes": (C.c_int, [_P, _P, C.c_uint64, _P, _P, _P, _P]),
     "mhx_comm_unique_id": (C.c_int, [_P]),
@@ -352,6 +358,12 @@ class Engine:
 
     def trim(self):
         self._chk(self.lib.mhx_trim(self.h))
+
+    def fastx_to_records(self, text1, text2=None):
+        """FASTA/FASTQ text -> read-library records on the GPU; returns (FastxResult, uint32 records or None)."""
+        r = FastxResult()
+        self._chk(self.lib.mhx_fastx_to_records(self.h, text1, len(text1), text2, len(text2) if text2 is not None else 0, C.byref(r)))
+        return r, (self.fetch(BUF_LIB_RECORDS, np.uint32) if r.status == 0 else None)
 
     def sdbg_build_index(self, k):
         """W/last/tip/mul arrays + rank/select tables on the device (include/mhx.h: mhx_sdbg_build_index)."""
