@@ -116,9 +116,41 @@ std::vector<char> read_text_file(const std::string &path) {
   return v;
 }
 
-void parse_fastx_sequential(const std::vector<char> &text, const std::function<void(const char *, size_t)> &on_seq) {
-  const char *t = text.data();
-  const size_t n = text.size();
+TextFile open_text_file(const std::string &path) {
+  TextFile tf;
+  if (path != "-") {
+    int fd = open(path.c_str(), O_RDONLY);
+    if (fd < 0) fatal("Cannot open file %s", path.c_str());
+    struct stat st;
+    unsigned char magic[2] = {0, 0};
+    if (fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0 && pread(fd, magic, 2, 0) == 2 && !(magic[0] == 0x1f && magic[1] == 0x8b)) {
+      void *m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+      if (m != MAP_FAILED) {
+        (void)madvise(m, (size_t)st.st_size, MADV_SEQUENTIAL);
+        (void)madvise(m, (size_t)st.st_size, MADV_WILLNEED);
+        tf.map = m;
+        tf.data = static_cast<const char *>(m);
+        tf.size = (size_t)st.st_size;
+        ::close(fd);
+        return tf;
+      }
+    }
+    ::close(fd);
+  }
+  tf.owned = read_text_file(path);  // gzip, pipes, stdin: through zlib
+  tf.data = tf.owned.data();
+  tf.size = tf.owned.size();
+  return tf;
+}
+void TextFile::close() {
+  if (map) munmap(map, size);
+  map = nullptr;
+  data = nullptr;
+  owned.clear();
+  owned.shrink_to_fit();
+}
+
+void parse_fastx_sequential(const char *t, size_t n, const std::function<void(const char *, size_t)> &on_seq) {
   size_t i = 0;
   int last_char = 0;
   std::string seq, line;

@@ -53,10 +53,19 @@ BinFile open_bin_file(const std::string &path);
 
 // whole (possibly gzip'ed) file -> memory; "-" = stdin (FastxReader opens its files through zlib the same way)
 std::vector<char> read_text_file(const std::string &path);
+// the same without a copy when the file is a plain (not gzip'ed) regular file: mapped read-only
+struct TextFile {
+  const char *data = nullptr;
+  size_t size = 0;
+  std::vector<char> owned;
+  void *map = nullptr;
+  void close();
+};
+TextFile open_text_file(const std::string &path);
 // Sequential FASTA/FASTQ parser with kseq's semantics (kseq.h:193-247): multi-line records, junk before the first header,
 // '\r' stripped at line ends as ks_getuntil2 does, the stream ends at the first malformed FASTQ record.  calls
 // on_seq(ptr, len) per record.  The fallback of `buildlib` for texts the GPU parser declines.
-void parse_fastx_sequential(const std::vector<char> &text, const std::function<void(const char *, size_t)> &on_seq);
+void parse_fastx_sequential(const char *text, size_t n, const std::function<void(const char *, size_t)> &on_seq);
 // TrimN + character map + 2-bit packing of one sequence, appended as a .bin record (fastx_reader.cpp:56-71,
 // sequence_package.h:78-83,224-240,262-267); returns the stored length
 uint32_t append_bin_record(std::vector<uint32_t> *out, const char *s, size_t len);

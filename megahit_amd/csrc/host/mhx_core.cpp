@@ -805,15 +805,15 @@ int main_buildlib(int argc, char **argv) {
       fprintf(stderr, "Cannot identify read library type %s\n", type);
       fatal("Valid types: pe, se, interleaved");
     }
-    std::vector<char> t1 = mhxio::read_text_file(f1), t2;
-    if (ty == "pe") t2 = mhxio::read_text_file(f2);
+    mhxio::TextFile t1 = mhxio::open_text_file(f1), t2;
+    if (ty == "pe") t2 = mhxio::open_text_file(f2);
     const int64_t begin = total_reads;
     unsigned max_len = 0;
     bool done = false;
     if (!host_only) {
       if (!c) c = open_gpu();
       mhx_fastx_result r{};
-      CK(mhx_fastx_to_records(c, t1.data(), t1.size(), ty == "pe" ? t2.data() : nullptr, t2.size(), &r));
+      CK(mhx_fastx_to_records(c, t1.data, t1.size, ty == "pe" ? t2.data : nullptr, t2.size, &r));
       if (r.status == 0) {
         std::vector<uint32_t> rec(r.n_words);
         if (r.n_words) CK(mhx_fetch(c, MHX_BUF_LIB_RECORDS, rec.data(), 0, r.n_words * 4));
@@ -836,17 +836,19 @@ int main_buildlib(int argc, char **argv) {
       };
       if (ty == "pe") {  // alternate the two files, stop when either ends (paired_fastx_reader.cpp:7-43)
         std::vector<std::string> a, b;
-        mhxio::parse_fastx_sequential(t1, [&](const char *s, size_t len) { a.emplace_back(s, len); });
-        mhxio::parse_fastx_sequential(t2, [&](const char *s, size_t len) { b.emplace_back(s, len); });
+        mhxio::parse_fastx_sequential(t1.data, t1.size, [&](const char *s, size_t len) { a.emplace_back(s, len); });
+        mhxio::parse_fastx_sequential(t2.data, t2.size, [&](const char *s, size_t len) { b.emplace_back(s, len); });
         for (size_t i = 0; i < std::min(a.size(), b.size()); ++i) {
           add(a[i].data(), a[i].size());
           add(b[i].data(), b[i].size());
         }
       } else {
-        mhxio::parse_fastx_sequential(t1, add);
+        mhxio::parse_fastx_sequential(t1.data, t1.size, add);
       }
       if (!rec.empty() && fwrite(rec.data(), 4, rec.size(), bin) != rec.size()) fatal("write error on %s.bin", out.c_str());
     }
+    t1.close();
+    t2.close();
     if (ty != "se" && (total_reads - begin) % 2 != 0) {
       fprintf(stderr, "PE library number of reads is odd: %lld!\n", (long long)(total_reads - begin));
       fatal("File(s): %s", meta.c_str());
