@@ -79,6 +79,10 @@ int mhx_load_bin_records(mhx_ctx *, const uint32_t *records, uint64_t n_words, u
  * SeqToSdbg::Initialize does for contigs after edges (seq_to_sdbg.cpp:449-503). */
 int mhx_append_sequences(mhx_ctx *, const uint32_t *packed, uint64_t n_words, uint64_t n_seqs,
                          uint32_t fixed_len, const uint64_t *start_pos, const uint16_t *mult);
+/* Load packed (k+1)-mer edges exactly as `.edges.<i>` files hold them (words_per_edge words per edge, the multiplicity in
+ * the low 16 bits of the last word): sequences and multiplicities are unpacked on the GPU (replaces the per-edge
+ * AppendCompactSequence loop of EdgeReader::ReadSorted/ReadUnsorted, edge_reader.h:24-52, seq_to_sdbg.cpp:388-420). */
+int mhx_load_edges(mhx_ctx *, const uint32_t *edges, uint64_t n_edges, uint32_t k, uint32_t words_per_edge);
 /* per-sequence multiplicities for seq2sdbg (seq_to_sdbg.h:80) */
 int mhx_load_multiplicity(mhx_ctx *, const uint16_t *mult, uint64_t n_seqs);
 uint64_t mhx_num_sequences(const mhx_ctx *);
@@ -196,6 +200,12 @@ typedef struct {
   long long f[6], rank_f[6];         /* sdbg.h:482-483 */
 } mhx_sdbg_index_info;
 int mhx_sdbg_build_index(mhx_ctx *, uint32_t k, mhx_sdbg_index_info *out);
+/* SdBG-level tip trimming on the device-resident graph — sdbg_pruning::RemoveTips
+ * (assembly/sdbg_pruning.cpp:61-179: rounds of Trim with len = 2, 4, ... < max_tip_len, then max_tip_len) over the
+ * succinct graph's Forward/Backward navigation (sdbg.h:106-121,240-330), one thread per edge, on the buffers that
+ * mhx_sdbg_build_index left in HBM.  Updates MHX_BUF_SDBG_INVALID in place; *n_removed = tips removed (the number the
+ * reference logs).  `assemble` calls it with max_tip_len = 2k by default (main_assemble.cpp:143-156). */
+int mhx_sdbg_remove_tips(mhx_ctx *, const mhx_sdbg_index_info *info, int max_tip_len, uint64_t *n_removed);
 /* install an SdBG produced elsewhere (e.g. read back from .sdbg.* files: bucket byte ranges back to back) as the handle's
  * current SdBG; the four tables have 65536 entries (starting byte, items, tips, large multiplicities per bucket) */
 int mhx_sdbg_load_bytes(mhx_ctx *, const uint8_t *bytes, uint64_t n_bytes, const uint64_t *bucket_offset, const uint64_t *bucket_items,

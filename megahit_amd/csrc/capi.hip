@@ -244,6 +244,56 @@ __global__ void k_unpack_records(const uint32_t *__restrict__ rec, const uint64_
   out_words[w] = word;
 }
 
+// packed (k+1)-mer edges as EdgeWriter lays them out (words_per_edge words per edge: chars MSB-first, the multiplicity in
+// the low 16 bits of the last word; kmer_counter.cpp:32-52, edge_reader.h:24-52) -> gap-free sequence store + multiplicities
+__global__ void k_unpack_edges(const uint32_t *__restrict__ raw, uint64_t n_edges, uint32_t len, uint32_t wpe, uint32_t *__restrict__ out_words,
+                               uint64_t n_out_words, uint16_t *__restrict__ mult) {
+  const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (w < n_edges) mult[w] = (uint16_t)(raw[w * wpe + wpe - 1] & 0xFFFFu);
+  if (w >= n_out_words) return;
+  const uint64_t b0 = w * 16, total = n_edges * (uint64_t)len;
+  uint64_t e = b0 / len;
+  uint32_t off = (uint32_t)(b0 - e * len);
+  const uint32_t *r = raw + e * wpe;
+  uint32_t word = 0;
+  for (int j = 0; j < 16; ++j) {
+    if (b0 + j >= total) break;
+    word |= ((r[off >> 4] >> (30 - 2 * (off & 15))) & 3u) << (30 - 2 * j);
+    if (++off == len) {
+      off = 0;
+      r += wpe;
+    }
+  }
+  out_words[w] = word;
+}
+void upload_edges(mhx_ctx *c, const uint32_t *raw, uint64_t n_edges, uint32_t k, uint32_t wpe) {
+  hipStream_t st = c->stream;
+  SeqSet &s = c->seqs;
+  c->agg_valid = false;
+  const uint32_t len = k + 1;
+  if (wpe != (len * 2 + 16 + 31) / 32) throw Error("load_edges: words_per_edge does not match k");
+  uint32_t *d_raw = c->ws("edges_raw", (n_edges * wpe + 4) * 4).as<uint32_t>();
+  if (n_edges) upload_pinned(c, d_raw, raw, n_edges * wpe * 4);
+  const uint64_t bases = n_edges * (uint64_t)len, n_out = div_ceil(bases, 16);
+  s.words.reserve((n_out + kSeqPadWords) * 4);
+  s.start.reserve((n_edges + 2) * 8);
+  s.mult.reserve((n_edges + 1) * 2);
+  s.mult.used = n_edges * 2;
+  MHX_HIP(hipMemsetAsync(s.words.as<uint32_t>() + n_out, 0, kSeqPadWords * 4, st));
+  const uint64_t n_thr = std::max(n_out, n_edges);
+  if (n_thr)
+    MHX_LAUNCH(c, "unpack_edges", (double)n_edges * wpe * 4 + (double)n_out * 4,
+               hipLaunchKernelGGL(k_unpack_edges, dim3((unsigned)div_ceil(n_thr, 256)), dim3(256), 0, st, d_raw, n_edges, len, wpe, s.words.as<uint32_t>(),
+                                  n_out, s.mult.as<uint16_t>()));
+  s.n_seqs = n_edges;
+  s.n_bases = bases;
+  s.n_words = n_out;
+  s.max_len = n_edges ? len : 0;
+  s.fixed_len = len;
+  s.h_start.clear();
+  upload_fixed_starts(c);
+}
+
 // Host -> device copy of a large pageable (e.g. mmap'ed) buffer through two pinned staging buffers: a few host threads
 // fill one buffer from the page cache while the DMA engine drains the other.  A plain hipMemcpy of pageable memory
 // staged 400 MB of reads in ~0.3 s; this takes what the slower of (page-cache memcpy, PCIe) takes.
@@ -530,6 +580,12 @@ int mhx_load_bin_records(mhx_ctx *c, const uint32_t *records, uint64_t n_words, 
     mhx::upload_bin_records(c, records, n_words, n_seqs, reverse);
   })
 }
+int mhx_load_edges(mhx_ctx *c, const uint32_t *edges, uint64_t n_edges, uint32_t k, uint32_t words_per_edge) {
+  MHX_TRY({
+    MHX_HIP(hipSetDevice(c->device));
+    mhx::upload_edges(c, edges, n_edges, k, words_per_edge);
+  })
+}
 int mhx_load_multiplicity(mhx_ctx *c, const uint16_t *mult, uint64_t n_seqs) {
   MHX_TRY({
     if (n_seqs != c->seqs.n_seqs) throw mhx::Error("load_multiplicity: n_seqs differs from the loaded sequence set");
@@ -619,6 +675,13 @@ int mhx_sdbg_build_index(mhx_ctx *c, uint32_t k, mhx_sdbg_index_info *out) {
   MHX_TRY({
     MHX_HIP(hipSetDevice(c->device));
     mhx::sdbg_build_index(c, k, out);
+  })
+}
+int mhx_sdbg_remove_tips(mhx_ctx *c, const mhx_sdbg_index_info *info, int max_tip_len, uint64_t *n_removed) {
+  MHX_TRY({
+    MHX_HIP(hipSetDevice(c->device));
+    if (!info) throw mhx::Error("sdbg_remove_tips: no index info");
+    mhx::sdbg_remove_tips(c, info, max_tip_len, n_removed);
   })
 }
 int mhx_sdbg_load_bytes(mhx_ctx *c, const uint8_t *bytes, uint64_t n_bytes, const uint64_t *bucket_offset, const uint64_t *bucket_items,

@@ -638,16 +638,7 @@ int main_seq2sdbg(int argc, char **argv) {
       const uint64_t ne = es.n_edges(), lo = ne * r / rs.n, hi = ne * (r + 1) / rs.n;
       bool loaded = false;
       if (hi > lo) {
-        mhxio::PackedSeqs pk;
-        std::vector<uint16_t> mult(hi - lo);
-        pk.words.reserve((hi - lo) * (es.k + 1) / 16 + 2);
-        for (uint64_t i = lo; i < hi; ++i) {
-          const uint32_t *e = &es.raw[i * es.words_per_edge];
-          pk.append_packed(e, es.k + 1, false);
-          mult[i - lo] = (uint16_t)(e[es.words_per_edge - 1] & 0xFFFF);
-        }
-        CKT(mhx_load_sequences(c, pk.words.data(), pk.words.size(), hi - lo, es.k + 1, nullptr));
-        CKT(mhx_load_multiplicity(c, mult.data(), mult.size()));
+        CKT(mhx_load_edges(c, &es.raw[lo * es.words_per_edge], hi - lo, es.k, es.words_per_edge));
         loaded = true;
       }
       if (r == 0 && contigs.n_seqs()) {
@@ -684,17 +675,8 @@ int main_seq2sdbg(int argc, char **argv) {
   if (!in.empty()) {
     mhxio::EdgeSet es = mhxio::read_edges(in);
     info("Number edges: %llu", (unsigned long long)es.n_edges());
-    // edges -> gap-free (k+1)-mer store + multiplicities (EdgeReader::ReadSorted/ReadUnsorted, edge_reader.h:24-52)
-    mhxio::PackedSeqs pk;
-    std::vector<uint16_t> mult(es.n_edges());
-    pk.words.reserve(es.n_edges() * (es.k + 1) / 16 + 2);
-    for (uint64_t i = 0; i < es.n_edges(); ++i) {
-      const uint32_t *e = &es.raw[i * es.words_per_edge];
-      pk.append_packed(e, es.k + 1, false);
-      mult[i] = (uint16_t)(e[es.words_per_edge - 1] & 0xFFFF);
-    }
-    CK(mhx_load_sequences(c, pk.words.data(), pk.words.size(), es.n_edges(), es.k + 1, nullptr));
-    CK(mhx_load_multiplicity(c, mult.data(), mult.size()));
+    // edges -> gap-free (k+1)-mer store + multiplicities (EdgeReader::ReadSorted/ReadUnsorted, edge_reader.h:24-52): on the GPU
+    CK(mhx_load_edges(c, es.raw.data(), es.n_edges(), es.k, es.words_per_edge));
     loaded = true;
     info("Read %llu edges. Time elapsed: %.4f", (unsigned long long)es.n_edges(), t.lap());
     if (need_mercy) {

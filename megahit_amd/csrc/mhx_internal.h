@@ -209,6 +209,7 @@ void stash_route_records(mhx_ctx *c, const void *src, uint64_t n, int hi_bit);
 void mercy_adopt_routed(mhx_ctx *c, const long long *recv, uint64_t n);
 void s1_apply_marks(mhx_ctx *c, const unsigned long long *recv, uint64_t n);
 int sdbg_build_index(mhx_ctx *c, uint32_t k, mhx_sdbg_index_info *out);
+int sdbg_remove_tips(mhx_ctx *c, const mhx_sdbg_index_info *info, int max_tip_len, uint64_t *n_removed);
 int fastx_to_records(mhx_ctx *c, const char *text1, uint64_t n1, const char *text2, uint64_t n2, mhx_fastx_result *out);
 int sdbg_load_bytes(mhx_ctx *c, const uint8_t *bytes, uint64_t n_bytes, const uint64_t *off, const uint64_t *items, const uint64_t *tips,
                     const uint64_t *large);
@@ -224,6 +225,7 @@ int run_gen_mercy(mhx_ctx *c, uint32_t k, const uint32_t *cand_packed, uint64_t 
 void upload_sequences(mhx_ctx *c, const uint32_t *packed, uint64_t n_words, uint64_t n_seqs, uint32_t fixed_len,
                       const uint64_t *start_pos);
 void upload_fixed_starts(mhx_ctx *c);
+void upload_edges(mhx_ctx *c, const uint32_t *raw, uint64_t n_edges, uint32_t k, uint32_t wpe);
 void upload_pinned(mhx_ctx *c, void *d_dst, const void *h_src, size_t bytes);
 void append_sequences(mhx_ctx *c, const uint32_t *packed, uint64_t n_words, uint64_t n_new, uint32_t fixed_len, const uint64_t *start_pos,
                       const uint16_t *mult);

@@ -95,6 +95,7 @@ SYMBOLS = {
     "mhx_load_bin_records": (C.c_int, [_P, _P, C.c_uint64, C.c_uint64, C.c_int]),
     "mhx_append_sequences": (C.c_int, [_P, _P, C.c_uint64, C.c_uint64, C.c_uint32, _P, _P]),
     "mhx_load_multiplicity": (C.c_int, [_P, _P, C.c_uint64]),
+    "mhx_load_edges": (C.c_int, [_P, _P, C.c_uint64, C.c_uint32, C.c_uint32]),
     "mhx_num_sequences": (C.c_uint64, [_P]),
     "mhx_fixed_length": (C.c_uint32, [_P]),
     "mhx_num_bases": (C.c_uint64, [_P]),
@@ -123,6 +124,7 @@ SYMBOLS = {
     "mhx_fastx_to_records": (C.c_int, [_P, C.c_char_p, C.c_uint64, C.c_char_p, C.c_uint64, C.POINTER(FastxResult)]),
     "mhx_sdbg_build_index": (C.c_int, [_P, C.c_uint32, C.POINTER(SdbgIndexInfo)]),
     "mhx_sdbg_load_bytes": (C.c_int, [_P, _P, C.c_uint64, _P, _P, _P, _P]),
+    "mhx_sdbg_remove_tips": (C.c_int, [_P, C.POINTER(SdbgIndexInfo), C.c_int, _P]),
     "mhx_comm_unique_id": (C.c_int, [_P]),
     "mhx_comm_init_rank": (_P, [_P, _P, C.c_int, C.c_int]),
     "mhx_comm_local_group": (C.c_int, [C.c_int, _P, _P]),
@@ -370,6 +372,12 @@ class Engine:
         info = SdbgIndexInfo()
         self._chk(self.lib.mhx_sdbg_build_index(self.h, k, C.byref(info)))
         return info
+
+    def sdbg_remove_tips(self, info, max_tip_len):
+        """SURVEY N4: sdbg_pruning::RemoveTips on the device-resident graph; returns the number of tips removed."""
+        n = C.c_uint64(0)
+        self._chk(self.lib.mhx_sdbg_remove_tips(self.h, C.byref(info), int(max_tip_len), C.byref(n)))
+        return int(n.value)
 
     def sdbg_load_bytes(self, data, offset, items, tips, large):
         data = np.ascontiguousarray(data, dtype=np.uint8)

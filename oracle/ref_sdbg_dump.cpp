@@ -7,6 +7,7 @@
 #define private public
 #define protected public
 #include "sdbg/sdbg.h"
+#include "assembly/sdbg_pruning.h"
 #undef private
 #undef protected
 
@@ -44,8 +45,8 @@ static void dump_rs(const char *prefix, const RS &rs, unsigned c_lo, unsigned c_
 }
 
 int main(int argc, char **argv) {
-  if (argc != 3) {
-    fprintf(stderr, "usage: %s <sdbg prefix> <dump file>\n", argv[0]);
+  if (argc != 3 && argc != 4) {
+    fprintf(stderr, "usage: %s <sdbg prefix> <dump file> [max_tip_len: also run RemoveTips]\n", argv[0]);
     return 1;
   }
   SDBG g;
@@ -88,6 +89,12 @@ int main(int argc, char **argv) {
     fb.push_back((int64_t)g.Backward(i));
   }
   section("fwd_bwd", fb.data(), 8, fb.size());
+  if (argc >= 4) {  // the reference's SdBG-level tip trimming (assembly/sdbg_pruning.cpp:147-179)
+    const int max_tip_len = atoi(argv[3]);
+    uint64_t n_tips = sdbg_pruning::RemoveTips(g, max_tip_len);
+    section("tips_removed", &n_tips, 8, 1);
+    section("invalid_after_tips", g.invalid_.data_array_.data(), 8, g.invalid_.data_array_.size());
+  }
   fclose(g_out);
   return 0;
 }

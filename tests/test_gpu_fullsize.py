@@ -106,9 +106,14 @@ def test_fullsize_sdbg_index_equals_reference_loader(full, engine):
     if not os.path.exists(out + ".sdbg_info"):
         run(["read2sdbg"] + common(full) + ["--output_prefix", out])
     dump = os.path.join(full, "r2s.dump")
-    subprocess.run([tsi.REF_DUMP, out, dump], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    subprocess.run([tsi.REF_DUMP, out, dump, "42"], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     k = tsi.load_files_into(engine, out)
-    t0 = time.perf_counter()
-    info = tsi.check_index(engine, k, tsi.read_dump(dump))
+    want = tsi.read_dump(dump)
+    info = tsi.check_index(engine, k, want)
     assert info.n_items == FULL["cases"]["read2sdbg"]["n_sdbg"]
+    # N4: tip trimming on the 59.9 M-edge graph (398 923 tips in the reference)
+    import numpy as np
+    from megahit_amd import lib
+    assert engine.sdbg_remove_tips(info, 42) == int(want["tips_removed"][0])
+    assert np.array_equal(engine.fetch(lib.BUF_SDBG_INVALID, np.uint64), want["invalid_after_tips"])
     engine.trim()

@@ -118,3 +118,28 @@ def test_index_straight_from_stage2_buffers(engine, tmp_path):
     engine.read2sdbg_s1(21, 2)
     engine.read2sdbg_s2(21, 2)
     check_index(engine, 21, read_dump(dump))
+
+
+def _tip_cases():
+    out = [e for e in _cases() if e["case"]["prog"] == "read2sdbg"][:6]
+    out += [e for e in _cases() if e["case"]["prog"] == "seq2sdbg"][:4]
+    return out
+
+
+@pytest.mark.parametrize("ent", _tip_cases(), ids=gu.case_id)
+def test_tip_trimming_equals_reference(engine, ent, tmp_path):
+    """SURVEY section 8f N4: mhx_sdbg_remove_tips on the device-resident graph = sdbg_pruning::RemoveTips
+    (assembly/sdbg_pruning.cpp:61-179) of the reference, run by the dumper on the same files with max_tip_len = 2k
+    (main_assemble.cpp:143-156) — same number of tips, same invalid bit vector."""
+    gu.run_case(gu.MHX_CORE, ent, str(tmp_path))
+    prefix = os.path.join(str(tmp_path), "out")
+    dump = os.path.join(str(tmp_path), "ref.dump")
+    k = ent["case"]["k"]
+    subprocess.run([REF_DUMP, prefix, dump, str(2 * k)], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    want = read_dump(dump)
+    load_files_into(engine, prefix)
+    info = engine.sdbg_build_index(k)
+    assert np.array_equal(engine.fetch(lib.BUF_SDBG_INVALID, np.uint64), want["invalid"])
+    n = engine.sdbg_remove_tips(info, 2 * k)
+    assert n == int(want["tips_removed"][0])
+    assert np.array_equal(engine.fetch(lib.BUF_SDBG_INVALID, np.uint64), want["invalid_after_tips"])
