@@ -225,6 +225,20 @@ typedef struct {
 } mhx_fastx_result;
 int mhx_fastx_to_records(mhx_ctx *, const char *text1, uint64_t n1, const char *text2, uint64_t n2, mhx_fastx_result *out);
 
+/* ---- `iterate` — the (k+step+1)-mer edges that the loaded reads (FORWARD orientation:
+ * mhx_load_bin_records(..., reverse = 0)) support next to the contigs of round k.  Replaces ContigFlankIndex +
+ * KmerCollector (iterate/contig_flank_index.h:16-219, iterate/kmer_collector.h:49-69, main_iterate.cpp:117-145): flank
+ * records sorted and searched, one thread per read, the k-mer set = sort + unique.  contigs: packed as
+ * mhx_load_sequences takes them, forward, loop / standalone contigs already dropped by the caller
+ * (async_sequence_reader.h:80).  Fills MHX_BUF_EDGES with n_edges records of words_per_edge words, multiplicity 0 as
+ * the reference writes them, in sorted order (the reference's order is its hash set's). ---- */
+typedef struct {
+  uint64_t n_flanks, n_kmers, n_edges;
+  uint32_t words_per_edge;
+} mhx_iterate_result;
+int mhx_iterate(mhx_ctx *, uint32_t k, uint32_t step, const uint32_t *contig_packed, uint64_t contig_words, uint64_t n_contigs,
+                const uint64_t *contig_start, mhx_iterate_result *out);
+
 /* B3: sort n fixed-width records in place on the GPU, ascending by the first key_words words
  * (lexicographic on uint32, as Substr::operator<, kmsort_selector.cpp:18-27); aux words ride
  * along.  Replaces SelectSortingFunc(key_words, aux_words) (kmsort_selector.cpp:61-63).  Stable. */

@@ -664,6 +664,15 @@ int mhx_gen_mercy_edges(mhx_ctx *c, uint32_t k, const uint32_t *cand_packed, uin
   })
 }
 
+int mhx_iterate(mhx_ctx *c, uint32_t k, uint32_t step, const uint32_t *contig_packed, uint64_t contig_words, uint64_t n_contigs,
+                const uint64_t *contig_start, mhx_iterate_result *out) {
+  MHX_TRY({
+    MHX_HIP(hipSetDevice(c->device));
+    if (!out || (!contig_start && n_contigs)) throw mhx::Error("iterate: bad arguments");
+    static const uint64_t zero = 0;
+    mhx::iterate_edges(c, k, step, contig_packed, contig_words, n_contigs, n_contigs ? contig_start : &zero, out);
+  })
+}
 int mhx_fastx_to_records(mhx_ctx *c, const char *text1, uint64_t n1, const char *text2, uint64_t n2, mhx_fastx_result *out) {
   MHX_TRY({
     MHX_HIP(hipSetDevice(c->device));

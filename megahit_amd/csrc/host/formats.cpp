@@ -473,8 +473,20 @@ EdgeSet read_edges(const std::string &prefix) {
   return es;
 }
 
+void write_edges_unsorted(const std::string &prefix, uint32_t k, uint32_t wpe, const uint32_t *edges, uint64_t n_edges) {
+  FILE *f = fopen((prefix + ".edges.0").c_str(), "wb");
+  if (!f) fatal("Cannot open %s.edges.0", prefix.c_str());
+  if (n_edges && fwrite(edges, 4, (size_t)n_edges * wpe, f) != (size_t)n_edges * wpe) fatal("write error on %s.edges.0", prefix.c_str());
+  if (fclose(f) != 0) fatal("write error on %s.edges.0", prefix.c_str());
+  std::ofstream meta(prefix + ".edges.info");
+  meta << "kmer_size " << k << '\n' << "words_per_edge " << wpe << '\n' << "num_files " << 1 << '\n'
+       << "num_buckets " << 0 << '\n' << "num_edges " << n_edges << '\n' << "is_sorted " << 0 << '\n';
+  meta.close();
+  if (!meta) fatal("write error on %s.edges.info", prefix.c_str());
+}
+
 int64_t read_contigs(const std::string &fasta, PackedSeqs *pkg, std::vector<uint16_t> *mult, unsigned min_len, unsigned k_from,
-                     unsigned k_to, bool reverse) {
+                     unsigned k_to, bool reverse, unsigned discard_flags) {
   gzFile f = gzopen(fasta.c_str(), "r");
   if (!f) fatal("Cannot open %s", fasta.c_str());
   const bool extend_loop = k_from < k_to;
@@ -485,6 +497,7 @@ int64_t read_contigs(const std::string &fasta, PackedSeqs *pkg, std::vector<uint
   auto flush = [&]() {
     if (!have || seq.size() < min_len) return;
     unsigned flag = comment.size() > 5 ? (unsigned)(comment[5] - '0') : 0;  // "flag=x multi=..." (contig_reader.h:66)
+    if (discard_flags & flag) return;                                       // contig_reader.h:67-70
     if (extend_loop && (flag & 2u)) {                                       // contig_flag::kLoop
       if (seq.size() < k_to + 1u) return;
       for (unsigned i = k_from; i < k_to; ++i) seq.push_back(seq[i]);

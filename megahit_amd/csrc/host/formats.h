@@ -95,6 +95,9 @@ EdgeSet read_edges(const std::string &prefix);
 
 // ContigReader::ReadAllWithMultiplicity (contig_reader.h:52-119) on a FASTA file
 int64_t read_contigs(const std::string &fasta, PackedSeqs *pkg, std::vector<uint16_t> *mult, unsigned min_len, unsigned k_from,
-                     unsigned k_to, bool reverse);
+                     unsigned k_to, bool reverse, unsigned discard_flags = 0);
+// unsorted edge file as KmerCollector / EdgeWriter::WriteUnordered leave it (edge_writer.h:48-53,94-110): one file, no
+// bucket lines, is_sorted 0
+void write_edges_unsorted(const std::string &prefix, uint32_t k, uint32_t words_per_edge, const uint32_t *edges, uint64_t n_edges);
 
 }  // namespace mhxio

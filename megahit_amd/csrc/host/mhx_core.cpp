@@ -849,11 +849,69 @@ int main_buildlib(int argc, char **argv) {
   return 0;
 }
 
+// ---------------------------------------------------------------------------
+// iterate (reference src/main_iterate.cpp): contigs + bubbles of round k and the reads -> <o>.edges.0 / .edges.info, the
+// unsorted (k+step+1)-mer edges that feed seq2sdbg of round k+step.  SURVEY section 8f N2.
+int main_iterate(int argc, char **argv) {
+  Options o;
+  o.add("contig_file", "c", false, "");
+  o.add("bubble_file", "b", false, "");
+  o.add("read_file", "r", false, "");
+  o.add("num_cpu_threads", "t", false, "0");
+  o.add("kmer_k", "k", false, "0");
+  o.add("step", "s", false, "0");
+  o.add("output_prefix", "o", false, "");
+  int k = 0, step = 0;
+  try {
+    o.parse(argc, argv);
+    k = atoi(o.get("kmer_k").c_str());
+    step = atoi(o.get("step").c_str());
+    if (k + step >= MHX_MAX_K + 1) throw std::string("kmer_k + step must less than ") + std::to_string(MHX_MAX_K + 1);
+    if (o.get("contig_file").empty()) throw std::string("No contig file!");
+    if (o.get("bubble_file").empty()) throw std::string("No bubble file!");
+    if (o.get("read_file").empty()) throw std::string("No reads file!");
+    if (k <= 0) throw std::string("Invalid kmer size!");
+    if (step <= 0 || step > 28 || step % 2 == 1) throw std::string("Invalid step size!");
+    if (o.get("output_prefix").empty()) throw std::string("No output prefix!");
+  } catch (std::string &e) {
+    fprintf(stderr, "%s\nUsage: %s [opt]\nopt with (*) are must\nopt:\n", e.c_str(), argv[0]);
+    o.usage();
+    exit(1);
+  }
+  Timer t;
+  mhx_ctx *c = open_gpu();
+  // contigs and bubbles, forward, loop and standalone contigs dropped (async_sequence_reader.h:80)
+  mhxio::PackedSeqs ctg;
+  std::vector<uint16_t> unused_mult;
+  for (const std::string &f : {o.get("contig_file"), o.get("bubble_file")}) {
+    const int64_t n = mhxio::read_contigs(f, &ctg, &unused_mult, 0, 0, 0, false, 1u | 2u);
+    info("Read %lld contigs", (long long)n);
+  }
+  mhxio::BinFile bin = mhxio::open_bin_file(o.get("read_file"));
+  if (bin.fixed_rw) {
+    CK(mhx_load_bin_records(c, bin.data, bin.n_words, bin.n_reads, 0));
+    if (bin.n_reads && mhx_fixed_length(c) != bin.data[0]) {
+      bin.build_index();
+      CK(mhx_load_bin_records(c, bin.data, bin.n_words, bin.n_reads, 0));
+    }
+  } else {
+    CK(mhx_load_bin_records(c, bin.data, bin.n_words, bin.n_reads, 0));
+  }
+  mhx_iterate_result r{};
+  CK(mhx_iterate(c, (uint32_t)k, (uint32_t)step, ctg.words.data(), ctg.words.size(), ctg.n_seqs(), ctg.start.data(), &r));
+  info("Number of flank kmers: %llu", (unsigned long long)r.n_flanks);
+  std::vector<uint32_t> edges((size_t)r.n_edges * r.words_per_edge);
+  if (!edges.empty()) CK(mhx_fetch(c, MHX_BUF_EDGES, edges.data(), 0, edges.size() * 4));
+  mhxio::write_edges_unsorted(o.get("output_prefix"), (uint32_t)(k + step), r.words_per_edge, edges.data(), r.n_edges);
+  info("Total: %llu. Iterative edges: %llu. Time elapsed: %.4f", (unsigned long long)bin.n_reads, (unsigned long long)r.n_edges, t.lap());
+  finish(c);
+}
+
 }  // namespace
 
 int main(int argc, char **argv) {
   if (argc < 2) {
-    fprintf(stderr, "Usage: %s <sub_program> [sub options]\n    sub-programs: buildlib count read2sdbg seq2sdbg (GPU); others via MHX_REF_CORE\n", argv[0]);
+    fprintf(stderr, "Usage: %s <sub_program> [sub options]\n    sub-programs: buildlib count read2sdbg seq2sdbg iterate (GPU); others via MHX_REF_CORE\n", argv[0]);
     return 1;
   }
   // `mhx_core --gpus N <sub-program> ...` (or MHX_NUM_GPUS): our only addition to the reference's command line; it sits
@@ -878,6 +936,7 @@ int main(int argc, char **argv) {
   if (sub == "seq2sdbg") return main_seq2sdbg(argc - 1, argv + 1);
   if (sub == "kmax") { printf("%d\n", MHX_MAX_K); return 0; }
   if (sub == "buildlib" && !getenv("MHX_BUILDLIB_REF")) return main_buildlib(argc - 1, argv + 1);
+  if (sub == "iterate" && !getenv("MHX_ITERATE_REF")) return main_iterate(argc - 1, argv + 1);
   if (const char *ref = getenv("MHX_REF_CORE")) {
     execv(ref, argv);  // buildlib / assemble / iterate / local / ... : not on this path
     perror("execv MHX_REF_CORE");

@@ -210,6 +210,8 @@ void mercy_adopt_routed(mhx_ctx *c, const long long *recv, uint64_t n);
 void s1_apply_marks(mhx_ctx *c, const unsigned long long *recv, uint64_t n);
 int sdbg_build_index(mhx_ctx *c, uint32_t k, mhx_sdbg_index_info *out);
 int sdbg_remove_tips(mhx_ctx *c, const mhx_sdbg_index_info *info, int max_tip_len, uint64_t *n_removed);
+int iterate_edges(mhx_ctx *c, uint32_t k, uint32_t step, const uint32_t *ctg_words, uint64_t ctg_n_words, uint64_t n_ctg, const uint64_t *ctg_start,
+                  mhx_iterate_result *out);
 int fastx_to_records(mhx_ctx *c, const char *text1, uint64_t n1, const char *text2, uint64_t n2, mhx_fastx_result *out);
 int sdbg_load_bytes(mhx_ctx *c, const uint8_t *bytes, uint64_t n_bytes, const uint64_t *off, const uint64_t *items, const uint64_t *tips,
                     const uint64_t *large);

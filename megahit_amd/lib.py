@@ -62,6 +62,10 @@ class FastxResult(C.Structure):
     _fields_ = [("n_reads", C.c_uint64), ("n_bases", C.c_uint64), ("n_words", C.c_uint64), ("max_len", C.c_uint32), ("status", C.c_int)]
 
 
+class IterateResult(C.Structure):
+    _fields_ = [("n_flanks", C.c_uint64), ("n_kmers", C.c_uint64), ("n_edges", C.c_uint64), ("words_per_edge", C.c_uint32)]
+
+
 class SdbgIndexInfo(C.Structure):
     _fields_ = [("n_items", C.c_uint64), ("n_tips", C.c_uint64), ("n_large", C.c_uint64), ("k", C.c_uint32),
                 ("words_per_tip_label", C.c_uint32), ("use_full_mul", C.c_int), ("num_l1_w", C.c_uint64), ("num_l2_w", C.c_uint64),
@@ -121,6 +125,7 @@ SYMBOLS = {
     "mhx_dist_apply_routed": (C.c_int, [_P, C.c_int, C.c_uint64]),
     "mhx_device_pointer": (_P, [_P, C.c_int]),
     "mhx_adopt_is_solid_slice": (C.c_int, [_P, _P, C.c_uint64]),
+    "mhx_iterate": (C.c_int, [_P, C.c_uint32, C.c_uint32, _P, C.c_uint64, C.c_uint64, _P, C.POINTER(IterateResult)]),
     "mhx_fastx_to_records": (C.c_int, [_P, C.c_char_p, C.c_uint64, C.c_char_p, C.c_uint64, C.POINTER(FastxResult)]),
     "mhx_sdbg_build_index": (C.c_int, [_P, C.c_uint32, C.POINTER(SdbgIndexInfo)]),
     "mhx_sdbg_load_bytes": (C.c_int, [_P, _P, C.c_uint64, _P, _P, _P, _P]),
