@@ -74,6 +74,43 @@ def test_read2sdbg_reference_exact_tie_order(engine, kind, k, m):
     check_sdbg(engine, engine.read2sdbg_s2(k, m), ob.s2(pkg, k, m, solid_want))
 
 
+def repetitive_reads(seed):
+    """buckets of every size class of the kmsort replay: a 300-base genome at ~1000x (buckets of thousands of records, runs of
+    equal keys far longer than 64), 2500 poly-A reads (one bucket of ~2 x 10^5 records), random reads with errors"""
+    rng = np.random.default_rng(seed)
+    g = rng.integers(0, 4, size=300, dtype=np.uint8)
+    reads = []
+    for _ in range(3000):
+        a = int(rng.integers(0, 200))
+        r = g[a:a + 100].copy()
+        e = rng.random(100) < 0.01
+        r[e] = rng.integers(0, 4, size=int(e.sum()), dtype=np.uint8)
+        reads.append(r if rng.random() < 0.5 else (3 - r[::-1]).astype(np.uint8))
+    reads += [np.zeros(100, dtype=np.uint8) for _ in range(2500)]
+    reads += [rng.integers(0, 4, size=int(rng.integers(30, 120)), dtype=np.uint8) for _ in range(1000)]
+    order = rng.permutation(len(reads))
+    return [reads[i] for i in order]
+
+
+@pytest.mark.parametrize("k,m,legacy", [(21, 2, 0), (21, 2, 1), (31, 3, 0), (31, 3, 1), (61, 2, 0)])
+def test_kmsort_replay_on_repetitive_reads(engine, k, m, legacy):
+    """the wave-per-bucket replay (tags in LDS / in global memory for the poly-A bucket) and the one-thread-per-bucket
+    replay on whole records both leave the oracle's kmsort order"""
+    reads = repetitive_reads(77)
+    pkg = ob.Package(reads, reverse=True)
+    w1 = ob.s1(pkg, k, m, tie_stable=False)
+    load(engine, pkg)
+    engine.set_option("kmsort_emu_legacy", legacy)
+    try:
+        r1 = engine.read2sdbg_s1(k, m, want_mercy=2)
+    finally:
+        engine.set_option("kmsort_emu_legacy", 0)
+    assert r1.n_items == w1["n_items"]
+    assert np.array_equal(engine.fetch(lib.BUF_MERCY_CAND, np.int64), w1["mercy"])
+    solid = engine.fetch(lib.BUF_IS_SOLID, np.uint64)
+    assert np.array_equal(solid, w1["is_solid"][: solid.size])
+
+
 @pytest.mark.parametrize("kind,k,m", CASES)
 def test_read2sdbg_s1_without_mercy_compact_records(engine, kind, k, m):
     """want_mercy=False takes the compact-record path (12-byte stage-1 items at k <= 29)."""
