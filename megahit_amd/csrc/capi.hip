@@ -540,6 +540,8 @@ void mhx_destroy(mhx_ctx *c) {
     if (c->pinned[i]) (void)hipHostFree(c->pinned[i]);
     if (c->pinned_free[i]) (void)hipEventDestroy(c->pinned_free[i]);
   }
+  for (hipStream_t ss : c->side_streams) (void)hipStreamDestroy(ss);
+  for (hipEvent_t ev : c->side_events) (void)hipEventDestroy(ev);
   (void)hipStreamDestroy(c->stream);
   delete c;
 }

@@ -110,6 +110,9 @@ struct mhx_ctx {
   bool profiling = false;
   std::vector<mhx::PendingEvent> pending;
   std::vector<hipEvent_t> event_pool;
+  // side streams for kernels that run next to each other (kmsort_emu.hip) and the events that fork / join them
+  std::vector<hipStream_t> side_streams;
+  std::vector<hipEvent_t> side_events;
   std::map<std::string, mhx::KernelStat> stats;
 
   mhx::DevBuf &ws(const char *name, size_t bytes) {

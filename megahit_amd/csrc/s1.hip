@@ -373,8 +373,18 @@ struct S1Op {
         if (r_has_in & (1u << t)) c1 = ((base + r_off) << 2) | ((has_out & (1u << t)) ? 0 : (2 - strand));
         else if (has_out & (1u << t)) c1 = ((base + r_off) << 2) | (1 + strand);
       }
-      if (c0 >= 0) mercy[atomicAdd(mercy_n, 1ull)] = c0;
-      if (c1 >= 0) mercy[atomicAdd(mercy_n, 1ull)] = c1;
+      // one cursor atomic per wave, not per candidate (same-address global atomics cost ~10 ns each; the list is unordered)
+      const unsigned long long m0 = __ballot(c0 >= 0), m1 = __ballot(c1 >= 0);
+      if (m0 | m1) {
+        const int lane = lane_id(), leader = __builtin_ctzll(m0 | m1);
+        const unsigned n0 = (unsigned)__builtin_popcountll(m0);
+        unsigned long long at = 0;
+        if (lane == leader) at = atomicAdd(mercy_n, (unsigned long long)(n0 + __builtin_popcountll(m1)));
+        at = __shfl(at, leader, kWave);
+        const unsigned long long below = (1ull << lane) - 1;
+        if (c0 >= 0) mercy[at + __builtin_popcountll(m0 & below)] = c0;
+        if (c1 >= 0) mercy[at + n0 + __builtin_popcountll(m1 & below)] = c1;
+      }
     }
   }
 };
