@@ -446,13 +446,10 @@ EdgeSet read_edges(const std::string &prefix) {
   es.k = (uint32_t)k;
   es.words_per_edge = (uint32_t)wpe;
   es.sorted = sorted != 0;
-  es.raw.resize((size_t)nedges * wpe);
-  std::vector<FILE *> fs((size_t)nfiles);
-  for (long long i = 0; i < nfiles; ++i) {
-    std::string p = prefix + ".edges." + std::to_string(i);
-    fs[i] = fopen(p.c_str(), "rb");
-    if (!fs[i]) fatal("Cannot open %s", p.c_str());
-  }
+  // one file whose buckets lie one after the other (what EdgeWriter leaves with one thread, and every file of ours): map it,
+  // the upload reads the page cache directly; anything else is gathered into a copy
+  std::vector<long long> b_fid, b_off, b_cnt;
+  bool in_order = nfiles == 1;
   uint64_t pos = 0;
   if (es.sorted) {
     for (long long b = 0; b < nb; ++b) {
@@ -460,15 +457,52 @@ EdgeSet read_edges(const std::string &prefix) {
       if (!(meta >> id >> fid >> off >> cnt) || id != b) fatal("Invalid format: bucket id not matched!");
       if (fid >= nfiles) fatal("Record ID %lld is greater than number of files %lld", fid, nfiles);
       if (fid < 0) continue;
-      fseek(fs[fid], off * wpe * 4, SEEK_SET);
-      if (fread(&es.raw[pos * wpe], 4, (size_t)(cnt * wpe), fs[fid]) != (size_t)(cnt * wpe)) fatal("short read on edges file");
+      if (off != (long long)pos) in_order = false;
+      b_fid.push_back(fid);
+      b_off.push_back(off);
+      b_cnt.push_back(cnt);
       pos += (uint64_t)cnt;
     }
-  } else if (nedges) {
-    if (fread(es.raw.data(), 4, (size_t)(nedges * wpe), fs[0]) != (size_t)(nedges * wpe)) fatal("short read on edges file");
+  } else {
     pos = (uint64_t)nedges;
   }
   if (pos != (uint64_t)nedges) fatal("edge count mismatch in %s", prefix.c_str());
+  es.n_words = (uint64_t)nedges * wpe;
+  if (in_order && nedges) {
+    const std::string p = prefix + ".edges.0";
+    int fd = open(p.c_str(), O_RDONLY);
+    if (fd < 0) fatal("Cannot open %s", p.c_str());
+    struct stat st;
+    if (fstat(fd, &st) != 0 || (uint64_t)st.st_size < es.n_words * 4) fatal("short read on edges file");
+    const size_t bytes = (size_t)es.n_words * 4;
+    void *m = mmap(nullptr, bytes, PROT_READ, MAP_PRIVATE, fd, 0);
+    ::close(fd);
+    if (m != MAP_FAILED) {
+      (void)madvise(m, bytes, MADV_SEQUENTIAL);
+      (void)madvise(m, bytes, MADV_WILLNEED);
+      es.map = std::shared_ptr<void>(m, [bytes](void *q) { munmap(q, bytes); });
+      es.data = static_cast<const uint32_t *>(m);
+      return es;
+    }
+  }
+  es.raw.resize((size_t)nedges * wpe);
+  es.data = es.raw.data();
+  std::vector<FILE *> fs((size_t)nfiles);
+  for (long long i = 0; i < nfiles; ++i) {
+    std::string p = prefix + ".edges." + std::to_string(i);
+    fs[i] = fopen(p.c_str(), "rb");
+    if (!fs[i]) fatal("Cannot open %s", p.c_str());
+  }
+  pos = 0;
+  if (es.sorted) {
+    for (size_t b = 0; b < b_fid.size(); ++b) {
+      fseek(fs[b_fid[b]], b_off[b] * wpe * 4, SEEK_SET);
+      if (fread(&es.raw[pos * wpe], 4, (size_t)(b_cnt[b] * wpe), fs[b_fid[b]]) != (size_t)(b_cnt[b] * wpe)) fatal("short read on edges file");
+      pos += (uint64_t)b_cnt[b];
+    }
+  } else if (nedges) {
+    if (fread(es.raw.data(), 4, (size_t)(nedges * wpe), fs[0]) != (size_t)(nedges * wpe)) fatal("short read on edges file");
+  }
   for (FILE *f : fs) fclose(f);
   return es;
 }

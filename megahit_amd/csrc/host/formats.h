@@ -4,6 +4,7 @@
 #pragma once
 #include <cstdint>
 #include <functional>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -88,8 +89,11 @@ void write_sdbg(const std::string &prefix, uint32_t k, uint32_t words_per_tip_la
 struct EdgeSet {
   uint32_t k = 0, words_per_edge = 0;
   bool sorted = true;
-  std::vector<uint32_t> raw;  // n_edges * words_per_edge, in reading order
-  uint64_t n_edges() const { return words_per_edge ? raw.size() / words_per_edge : 0; }
+  const uint32_t *data = nullptr;  // n_edges * words_per_edge, in reading order: the mapped file when its buckets lie in order
+  uint64_t n_words = 0;
+  std::vector<uint32_t> raw;       // ... else a copy
+  std::shared_ptr<void> map;       // keeps the mapping alive
+  uint64_t n_edges() const { return words_per_edge ? n_words / words_per_edge : 0; }
 };
 EdgeSet read_edges(const std::string &prefix);
 

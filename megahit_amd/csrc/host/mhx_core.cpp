@@ -638,7 +638,7 @@ int main_seq2sdbg(int argc, char **argv) {
       const uint64_t ne = es.n_edges(), lo = ne * r / rs.n, hi = ne * (r + 1) / rs.n;
       bool loaded = false;
       if (hi > lo) {
-        CKT(mhx_load_edges(c, &es.raw[lo * es.words_per_edge], hi - lo, es.k, es.words_per_edge));
+        CKT(mhx_load_edges(c, es.data + lo * es.words_per_edge, hi - lo, es.k, es.words_per_edge));
         loaded = true;
       }
       if (r == 0 && contigs.n_seqs()) {
@@ -676,7 +676,7 @@ int main_seq2sdbg(int argc, char **argv) {
     mhxio::EdgeSet es = mhxio::read_edges(in);
     info("Number edges: %llu", (unsigned long long)es.n_edges());
     // edges -> gap-free (k+1)-mer store + multiplicities (EdgeReader::ReadSorted/ReadUnsorted, edge_reader.h:24-52): on the GPU
-    CK(mhx_load_edges(c, es.raw.data(), es.n_edges(), es.k, es.words_per_edge));
+    CK(mhx_load_edges(c, es.data, es.n_edges(), es.k, es.words_per_edge));
     loaded = true;
     info("Read %llu edges. Time elapsed: %.4f", (unsigned long long)es.n_edges(), t.lap());
     if (need_mercy) {

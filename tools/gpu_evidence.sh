@@ -29,4 +29,12 @@ timeout 600 python bench.py --engine count --steps 3 --no-e2e > $O/${TAG}_bench_
 timeout 600 python bench.py --engine seq2sdbg --steps 3 --no-e2e > $O/${TAG}_bench_seq2sdbg.json 2>> $O/${TAG}_bench.err
 timeout 600 python bench.py --force-dist --steps 3 --no-cpu-baseline --no-e2e > $O/${TAG}_bench_force_dist.json 2>> $O/${TAG}_bench.err
 cat $O/${TAG}_bench_count.json $O/${TAG}_bench_seq2sdbg.json
+# the three routes to the first graph through the CLI (files in -> files out), stage 1 with the reference-exact tie order,
+# buildlib, and the copy-invariance check at 20 M / 40 M reads on one GPU
+timeout 600 python tools/e2e_routes.py > $O/${TAG}_e2e_routes.json 2> $O/${TAG}_e2e_routes.err
+timeout 300 python tools/mercy_prof.py 10e6 > $O/${TAG}_mercy_stage1.json 2> $O/${TAG}_mercy_stage1.err
+timeout 300 python tools/buildlib_bench.py > $O/${TAG}_buildlib.json 2> $O/${TAG}_buildlib.err
+timeout 600 python tools/scale_check.py 10e6 2 > $O/${TAG}_scale_20M.json 2> $O/${TAG}_scale_20M.err
+timeout 900 python tools/scale_check.py 10e6 4 > $O/${TAG}_scale_40M.json 2> $O/${TAG}_scale_40M.err
+tail -c 600 $O/${TAG}_scale_40M.json
 ls -la $O | tail -20
