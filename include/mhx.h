@@ -60,6 +60,10 @@ int mhx_synchronize(mhx_ctx *);
  *   dist_sparse_marks (0)  multi-GPU stage 1 emits MHX_ROUTE_S1_MARKS records instead of marking a bitmap of the
  *                     global read set (set by mhx_dist_setup; the torch.distributed path of megahit_amd/dist.py
  *                     still reduces the bitmap)
+ *   kmsort_emu_legacy (0)  1: read2sdbg --need_mercy replays kmsort with one thread per lv1 bucket on whole records
+ *                     (round 1) instead of one wave per bucket on tags + indices (kmsort_emu.hip); same output
+ *   sort_xcd_units (1)  0: the chained-scan scatter hands its units out from one ticket counter instead of one per
+ *                     block-id class b % 8 (sort.hip); same output
  * Returns <0 for a NULL handle/name. */
 int mhx_set_option(mhx_ctx *, const char *name, long long value);
 
