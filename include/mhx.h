@@ -56,6 +56,8 @@ int mhx_synchronize(mhx_ctx *);
  *   s1_seg_per (8)    records per thread and tile of the segment group-by (4 or 8)
  *   s1_stream (1)     0: never the two-pass bucket-streaming variant (k_s1_stream); s1_stream_max (40000): largest
  *                     average lv1 bucket (records) it is chosen for
+ *   s1_stream_direct (1)  0: k_s1_stream always reads a bucket twice (second time to mark); 1: when the marks are those of
+ *                     the non-solid occurrences and m <= 2 they come from the table and the second read is skipped
  *   count_seg (1), count_seg_bits (0), count_seg_la (3)  the same for count (k_count_seg)
  *   dist_sparse_marks (0)  multi-GPU stage 1 emits MHX_ROUTE_S1_MARKS records instead of marking a bitmap of the
  *                     global read set (set by mhx_dist_setup; the torch.distributed path of megahit_amd/dist.py

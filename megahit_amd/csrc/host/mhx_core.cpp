@@ -6,6 +6,11 @@
 // implemented here; when MHX_REF_CORE names a reference `megahit_core` binary they are forwarded to
 // it unchanged, so the unmodified `megahit` orchestrator can run with this binary in place.
 #include <unistd.h>
+#include <fcntl.h>
+#include <signal.h>
+#include <sys/prctl.h>
+#include <sys/wait.h>
+#include <cerrno>
 
 #include <algorithm>
 
@@ -189,9 +194,22 @@ std::vector<uint64_t> shard_reads(const mhxio::BinFile &bin, int n) {
 
 // The outputs are on disk and closed: leave without tearing the HIP runtime down (freeing tens of GB of device memory
 // page by page costs more than the GPU stages of a small job).  MHX_CLEAN_EXIT=1 destroys the handle first.
+int g_done_fd = -1;  // write end of the pipe to the front process (main): set in the process that does the work
 [[noreturn]] void finish(mhx_ctx *c) {
   if (getenv("MHX_CLEAN_EXIT")) mhx_destroy(c);
   fflush(nullptr);
+  if (g_done_fd >= 0) {
+    // Everything the caller waits for exists and is closed.  Tell the front process, which exits with our status at once;
+    // this process then dies, and the release of tens of GB of GPU mappings (~0.1 s of kernel time at 10 M reads, as much
+    // as the GPU stages) is not on the caller's clock.  The standard streams are closed so that a caller reading our
+    // stderr through a pipe sees its end when the front process exits.
+    const unsigned char ok = 0;
+    if (write(g_done_fd, &ok, 1) != 1) _exit(1);
+    close(g_done_fd);
+    close(0);
+    close(1);
+    close(2);
+  }
   _exit(0);
 }
 
@@ -923,6 +941,38 @@ int main(int argc, char **argv) {
     argv += 2;
     argc -= 2;
   }
+  const std::string sub = argv[1];
+  const bool ours = sub == "count" || sub == "read2sdbg" || sub == "seq2sdbg" || (sub == "buildlib" && !getenv("MHX_BUILDLIB_REF")) ||
+                    (sub == "iterate" && !getenv("MHX_ITERATE_REF"));
+  if (ours && !getenv("MHX_NO_FORK") && !getenv("MHX_CLEAN_EXIT")) {
+    // the work runs in a child (forked before anything touches the HIP runtime); this front process only waits for the
+    // child's "outputs are complete" byte (finish()) or, failing that, for its exit status
+    int fds[2];
+    if (pipe(fds) == 0) {
+      fflush(nullptr);
+      const pid_t pid = fork();
+      if (pid == 0) {
+        close(fds[0]);
+        (void)fcntl(fds[1], F_SETFD, FD_CLOEXEC);
+        (void)prctl(PR_SET_PDEATHSIG, SIGKILL);  // no orphan if the front process is killed
+        g_done_fd = fds[1];
+      } else if (pid > 0) {
+        close(fds[1]);
+        unsigned char st = 0;
+        ssize_t got;
+        do got = read(fds[0], &st, 1);
+        while (got < 0 && errno == EINTR);
+        if (got == 1) _exit(st);
+        int ws = 0;
+        while (waitpid(pid, &ws, 0) < 0 && errno == EINTR) {
+        }
+        return WIFEXITED(ws) ? WEXITSTATUS(ws) : 128 + WTERMSIG(ws);
+      } else {
+        close(fds[0]);
+        close(fds[1]);
+      }
+    }
+  }
   if (g_num_gpus > 1) {
     const int have = mhx_device_count();
     if (!getenv("MHX_GPU_MAP") && have > 0 && g_num_gpus > have) {
@@ -930,7 +980,6 @@ int main(int argc, char **argv) {
       g_num_gpus = have;
     }
   }
-  const std::string sub = argv[1];
   if (sub == "count") return main_kmer_count(argc - 1, argv + 1);
   if (sub == "read2sdbg") return main_read2sdbg(argc - 1, argv + 1);
   if (sub == "seq2sdbg") return main_seq2sdbg(argc - 1, argv + 1);

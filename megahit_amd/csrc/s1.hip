@@ -428,6 +428,7 @@ struct S1SegArgs {
   uint64_t pos_stride;
   uint32_t *err;
   int la_chunks;      // look-ahead limit, in chunks of 256 records
+  int direct_marks;   // k_s1_stream: the non-solid marks come from the table (one stored position per key), no second read
 };
 
 constexpr unsigned long long kSegEmpty = ~0ull;  // never a key: head/tail bits 63 do not occur (max (4<<3)|4)
@@ -776,13 +777,16 @@ __global__ __launch_bounds__(256) void k_s1_seg(const uint32_t *__restrict__ ite
 // ---------------------------------------------------------------------------------------------------------------
 // Bucket-streaming variant of the segment group-by: sort only the top 16 bits of the (k-1)-mer — the reference's lv1
 // bucket, two LSD passes — and let one workgroup take one whole bucket (~20 K records at 10 M reads): it streams the
-// bucket twice (the second time out of L2 / Infinity Cache: a bucket is a few hundred KB), first inserting the keys
-// into an LDS table, then marking every record with its key's count.  Inside a bucket the prefix is constant, so the
+// bucket, inserting the keys into an LDS table, and then marks every record with its key's count — by streaming the bucket a
+// second time (PMC: that read comes from HBM again, the buckets of all workgroups do not fit the caches) or, when the
+// marks wanted are those of the NON-solid occurrences and m <= 2 (direct_marks: the usual case, most occurrences being
+// solid), straight from the table: a key that ends with count 1 < m has exactly one record, whose position the insert
+// left next to the key, so the second read never happens.  Inside a bucket the prefix is constant, so the
 // table key is the remaining 2(k-1)-16 (k-1)-mer bits + head/tail = 32 bits at k <= 22 (4-byte compare-and-swap), and
 // nothing of k_s1_seg's segment ownership / look-ahead is needed: "two-level bucketed sort" with the second level in LDS.
 // A bucket with more distinct keys than the table holds sets *err -> the host falls back to k_s1_seg (three passes).
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int kStreamThreads = 512;
+constexpr int kStreamThreads = 1024;  // one workgroup per CU: keys + counts + first positions = 96 KB of LDS
 constexpr int kStreamSlots = 8192;
 constexpr uint32_t kStreamEmpty = 0xFFFFFFFFu;  // never a key: head/tail bits 63 do not occur
 
@@ -795,6 +799,7 @@ __global__ __launch_bounds__(kStreamThreads) void k_s1_stream(const uint32_t *__
   static_assert((1 << LOGS) == NSLOT, "table size");
   __shared__ uint32_t keys[NSLOT];
   __shared__ uint32_t cnts[NSLOT];
+  __shared__ uint32_t fpos[NSLOT];  // position word of the record that created the slot (direct_marks)
   __shared__ uint32_t lhist[kSegHist];
   __shared__ uint32_t s_bad, s_agg_cur, s_mark_cur, s_bucket;
   const int tid = threadIdx.x, lane = tid & (kWave - 1);
@@ -836,10 +841,11 @@ __global__ __launch_bounds__(kStreamThreads) void k_s1_stream(const uint32_t *__
     for (uint64_t base = lo; base < hi; base += NT) {
       const uint64_t gi = base + tid;
       const bool ins = gi < hi;
-      uint32_t lk = 0;
+      uint32_t lk = 0, w2 = 0;
       if (ins) {
         const uint32_t *p = items + gi * 3;
         lk = local_key(p[0], p[1]);
+        w2 = p[2];
       }
       const uint32_t hf = lk * 0x9E3779B1u;
       const uint32_t hm = hf >> 25;
@@ -862,6 +868,7 @@ __global__ __launch_bounds__(kStreamThreads) void k_s1_stream(const uint32_t *__
           const uint32_t old = atomicCAS(&keys[h], kStreamEmpty, lk);
           if (old == kStreamEmpty || old == lk) {
             atomicAdd(&cnts[h], mult);
+            if (old == kStreamEmpty) fpos[h] = w2;  // only read back when the count stays 1: then this record is the key's only one
             break;
           }
           h = (h + 1) & (NSLOT - 1);
@@ -874,7 +881,7 @@ __global__ __launch_bounds__(kStreamThreads) void k_s1_stream(const uint32_t *__
     uint32_t my_agg = 0;
     if (!bad) {
       // B: marks, streaming the bucket again (cache-resident)
-      if (a.mark_mode != 2) {
+      if (a.mark_mode != 2 && !a.direct_marks) {
         for (uint64_t base = lo; base < hi; base += NT) {
           const uint64_t gi = base + tid;
           const bool in = gi < hi;
@@ -924,6 +931,7 @@ __global__ __launch_bounds__(kStreamThreads) void k_s1_stream(const uint32_t *__
         const uint32_t hb = cnt > MHX_MAX_MUL ? (uint32_t)MHX_MAX_MUL : cnt;  // :430-436
         if (hb < kSegHist) atomicAdd(&lhist[hb], 1u);
         else atomicAdd(&a.hist[hb], 1ull);
+        if (a.direct_marks && !solid) a.solid_bytes[fpos[sl] - 1] = 1;  // count 1 < m <= 2: the key's only record (mark_mode 1)
         if (AGG && solid) {
           const uint64_t smer = ((uint64_t)bi << 48) | ((uint64_t)(lk >> 6) << (48 - rem));  // the (k-1)-mer, MSB-first
           const uint64_t x = ((uint64_t)((lk >> 3) & 7u) << 62) | (smer >> 2) | ((uint64_t)(lk & 7u) << (62 - 2 * k));
@@ -1428,7 +1436,7 @@ int s1_process(mhx_ctx *c, uint32_t k, uint32_t m, int want_mercy, uint32_t *buf
     const uint32_t pfx_mask = plan.seg_bits >= 32 ? 0xFFFFFFFFu : ~(0xFFFFFFFFu >> plan.seg_bits);
     const uint32_t eq_mask1 = (kmer_bits > 32 ? ~(0xFFFFFFFFu >> (kmer_bits - 32)) : 0u) | 63u;
     const bool agg_on = agg && mode != 2;
-    const unsigned grid = (unsigned)std::min<uint64_t>(n_work, plan.stream ? 256 * 2 : (per == 4 ? 256 * 6 : 256 * 3));
+    const unsigned grid = (unsigned)std::min<uint64_t>(n_work, plan.stream ? 256 : (per == 4 ? 256 * 6 : 256 * 3));
     // per-workgroup output regions in the spare sort buffer (S*4 >= 12 bytes per record, outputs are 8-byte entries)
     const uint32_t region = (uint32_t)std::min<uint64_t>(n_items * (uint64_t)S * 4 / 8 / grid, 0xFFFFFFF0u);
     uint2 *raw = nullptr;
@@ -1451,8 +1459,10 @@ int s1_process(mhx_ctx *c, uint32_t k, uint32_t m, int want_mercy, uint32_t *buf
       seg_grid = grid;
       seg_mcap = mcap;
     }
+    // the stream kernel marks the non-solid occurrences from its table when each of them is its key's only record
+    const int direct = plan.stream && mode == 1 && m <= 2 && pos_stride == 0 && !mraw && solid_bytes && c->opt("s1_stream_direct", 1) ? 1 : 0;
     S1SegArgs a{(int)k, m, pfx_mask, eq_mask1, solid_bytes, mode, hist, ctr, raw, seg_cap, counts, mraw, mcap, mcounts, pos_stride, seg_err,
-                plan.stream ? (int)c->opt("s1_stream_probes", 1024) : la};
+                plan.stream ? (int)c->opt("s1_stream_probes", 1024) : la, direct};
     MHX_HIP(hipMemsetAsync(seg_err, 0, 4, st));
     const char *nm = mode == 2 ? "s1_sample" : "s1_groups";
     const double bytes = plan.stream ? (double)n_items * 12 / stride : (double)n_work * T * 12;

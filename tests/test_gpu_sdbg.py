@@ -127,9 +127,10 @@ def test_read2sdbg_s1_without_mercy_compact_records(engine, kind, k, m):
     check_sdbg(engine, engine.read2sdbg_s2(k, m), ob.s2(pkg, k, m, w1["is_solid"]))
 
 
-SEG_DEFAULTS = dict(s1_seg=1, s1_seg_bits=0, s1_seg_la=3, s1_seg_per=8, s1_stream=1, s1_stream_max=40000, s1_stream_probes=1024)
+SEG_DEFAULTS = dict(s1_seg=1, s1_seg_bits=0, s1_seg_la=3, s1_seg_per=8, s1_stream=1, s1_stream_max=40000, s1_stream_probes=1024, s1_stream_direct=1)
 SEG_VARIANTS = [dict(s1_seg=0),                      # classic: full sort + tile kernel
                 dict(s1_stream=0),                  # tile kernel (k_s1_seg) instead of bucket streaming (k_s1_stream)
+                dict(s1_stream_direct=0),           # bucket streaming with the second read of the bucket instead of marks from the table
                 dict(s1_stream_probes=0),           # every bucket 'overflows' its table: stream -> tile kernel fallback
                 dict(s1_stream=0, s1_seg_la=0, s1_seg_bits=8),  # tile kernel gives up -> classic
                 dict(s1_seg_bits=8, s1_seg_la=0),   # segments of ~1000 records with no look-ahead: tiles give up -> fallback
