@@ -837,7 +837,7 @@ __global__ __launch_bounds__(kStreamThreads) void k_s1_stream(const uint32_t *__
       __syncthreads();
       continue;
     }
-    // A: insert (wave-aggregated: one compare-and-swap + add per group of equal keys in a wavefront)
+    // A: insert
     for (uint64_t base = lo; base < hi; base += NT) {
       const uint64_t gi = base + tid;
       const bool ins = gi < hi;
@@ -848,19 +848,11 @@ __global__ __launch_bounds__(kStreamThreads) void k_s1_stream(const uint32_t *__
         w2 = p[2];
       }
       const uint32_t hf = lk * 0x9E3779B1u;
-      const uint32_t hm = hf >> 25;
-      uint64_t pm = __ballot(ins);
-#pragma unroll
-      for (int b = 0; b < 7; ++b) {
-        const bool bit = (hm >> b) & 1u;
-        const uint64_t mb = __ballot(bit);
-        pm &= bit ? mb : ~mb;
-      }
-      const int leader = ins ? __builtin_ctzll(pm) : lane;
-      const bool eq = ins && __shfl(lk, leader, kWave) == lk;
-      const uint64_t grp = __ballot(eq) & pm;
-      if (ins && (lane == leader || !eq)) {
-        const uint32_t mult = lane == leader ? (uint32_t)__builtin_popcountll(grp) : 1u;
+      // one compare-and-swap + add per record: inside a bucket the records are in read order, equal keys are rarely
+      // neighbours, so grouping the lanes of a wavefront by key (as k_s1_seg does on its sorted segments) saves few atomics
+      // and costs eight ballots per round; the LDS serialises same-address atomics by itself
+      if (ins) {
+        const uint32_t mult = 1u;
         uint32_t h = hf >> (32 - LOGS);
         int probes = 0;
         const int probe_limit = a.la_chunks;  // (stream mode: the host passes the probe limit here; tests set it to 0)
