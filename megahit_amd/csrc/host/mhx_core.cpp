@@ -102,6 +102,7 @@ mhx_ctx *open_gpu() {
   if (const char *e = getenv("MHX_DEVICE")) dev = atoi(e);
   mhx_ctx *c = mhx_create(dev);
   if (!c) fatal("%s", mhx_last_error());
+  if (getenv("MHX_PROFILE")) mhx_profile_enable(c, 1);  // per-kernel HIP-event times, printed by finish()
   return c;
 }
 #define CK(call)                                  \
@@ -196,6 +197,13 @@ std::vector<uint64_t> shard_reads(const mhxio::BinFile &bin, int n) {
 // page by page costs more than the GPU stages of a small job).  MHX_CLEAN_EXIT=1 destroys the handle first.
 int g_done_fd = -1;  // write end of the pipe to the front process (main): set in the process that does the work
 [[noreturn]] void finish(mhx_ctx *c) {
+  if (getenv("MHX_PROFILE")) {
+    std::vector<mhx_kernel_stat> ks(256);
+    const int n = mhx_profile_get(c, ks.data(), (int)ks.size());
+    ks.resize(n < 0 ? 0 : std::min<size_t>((size_t)n, ks.size()));
+    std::sort(ks.begin(), ks.end(), [](const mhx_kernel_stat &a, const mhx_kernel_stat &b) { return a.total_ms > b.total_ms; });
+    for (const mhx_kernel_stat &s : ks) info("profile %-24s %6u launches %12.3f ms", s.name, s.launches, s.total_ms);
+  }
   if (getenv("MHX_CLEAN_EXIT")) mhx_destroy(c);
   fflush(nullptr);
   if (g_done_fd >= 0) {

@@ -4,6 +4,7 @@
 // kmlib/kmrns.h:118-175), compiled from the sources where they lie, and dumps every array it built, so that
 // tests/test_gpu_sdbg_index.py can compare the device-resident hand-over of libmhx word for word.
 // The index structures are private members of the reference's classes: this dumper (and only it) opens them up.
+#include <chrono>
 #define private public
 #define protected public
 #include "sdbg/sdbg.h"
@@ -50,7 +51,9 @@ int main(int argc, char **argv) {
     return 1;
   }
   SDBG g;
+  const auto t_load0 = std::chrono::steady_clock::now();
   g.LoadFromFile(argv[1]);
+  fprintf(stderr, "ref_sdbg_dump: LoadFromFile %.3f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t_load0).count());
   g_out = fopen(argv[2], "wb");
   if (!g_out) return 1;
   const auto &ct = g.content_;
@@ -91,7 +94,9 @@ int main(int argc, char **argv) {
   section("fwd_bwd", fb.data(), 8, fb.size());
   if (argc >= 4) {  // the reference's SdBG-level tip trimming (assembly/sdbg_pruning.cpp:147-179)
     const int max_tip_len = atoi(argv[3]);
+    const auto t_tips0 = std::chrono::steady_clock::now();
     uint64_t n_tips = sdbg_pruning::RemoveTips(g, max_tip_len);
+    fprintf(stderr, "ref_sdbg_dump: RemoveTips %.3f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t_tips0).count());
     section("tips_removed", &n_tips, 8, 1);
     section("invalid_after_tips", g.invalid_.data_array_.data(), 8, g.invalid_.data_array_.size());
   }

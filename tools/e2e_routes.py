@@ -24,6 +24,9 @@ MHX = os.path.join(ROOT, "megahit_amd", "mhx_core")
 def run(args):
     best = None
     for _ in range(2):
+        # the driver reclaims a process's VRAM after its exit (tens of GB: seconds); a process that starts meanwhile waits in
+        # hipMalloc (measured: stage 1 of the mercy route 0.8 s on a quiet GPU, 1.8-3.4 s back to back) — let it finish
+        time.sleep(3.0)
         t0 = time.perf_counter()
         p = subprocess.run([MHX] + args, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True)
         dt = time.perf_counter() - t0
