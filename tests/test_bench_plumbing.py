@@ -30,12 +30,19 @@ def test_pmc_traffic_lookup_is_tied_to_the_kernel_sources(tmp_path):
 
 
 def test_committed_bench_line_has_the_contract_fields():
-    with open(os.path.join(ROOT, "profiles", "r01_bench_v5.json")) as f:
+    with open(os.path.join(ROOT, "profiles", "r02_bench.json")) as f:
         d = json.loads(f.read())
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
-                "dtype", "data", "config", "roofline", "cpu_baseline"):
+                "dtype", "data", "config", "roofline", "cpu_baseline", "parity_checked", "e2e"):
         assert key in d, key
     assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1 and d["roofline"]["peak"] == 8000.0
     assert abs(d["roofline"]["frac"] - d["roofline"]["achieved"] / d["roofline"]["peak"]) < 1e-3
     assert d["cpu_baseline"]["kind"] == "reference" and d["cpu_baseline"]["cores"] >= 1
     assert "workload" in d["config"] and d["vs_baseline"] is None
+    assert d["parity_checked"] is True and d["parity"]["digest"] == d["parity"]["reference_digest"]
+    # the counter measurement the line quotes belongs to the committed kernels
+    with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as f:
+        pmc = json.load(f)
+    from megahit_amd import buildid
+    assert pmc["build_id"] == buildid.build_id(), "profiles/r02_pmc_traffic.json was collected on other kernel sources: re-run tools/gpu_evidence.sh"
+    assert d["roofline"]["traffic"] == pmc["kernels"]["k_radix_onesweep<3, 8, 3>"]["hbm_bytes"]
