@@ -59,6 +59,7 @@ int mhx_synchronize(mhx_ctx *);
  *   s1_stream_direct (1)  0: k_s1_stream always reads a bucket twice (second time to mark); 1: when the marks are those of
  *                     the non-solid occurrences and m <= 2 they come from the table and the second read is skipped
  *   count_seg (1), count_seg_bits (0), count_seg_la (3)  the same for count (k_count_seg)
+ *   count_extract_fixed (1)  0: count's items always come from the wave-per-read kernel (no fused digit histograms)
  *   dist_sparse_marks (0)  multi-GPU stage 1 emits MHX_ROUTE_S1_MARKS records instead of marking a bitmap of the
  *                     global read set (set by mhx_dist_setup; the torch.distributed path of megahit_amd/dist.py
  *                     still reduces the bitmap)

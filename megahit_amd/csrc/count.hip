@@ -9,6 +9,7 @@
 //   emit        packed solid edges + per-bucket counts (PackEdge :32-52, EdgeWriter::Write)
 #include "dev_prims.h"
 #include "mhx_internal.h"
+#include "sort_digits.h"
 #include "tile_groups.h"
 
 namespace mhx {
@@ -67,6 +68,62 @@ __global__ __launch_bounds__(256) void k_count_extract(const uint32_t *__restric
         for (int i = 0; i < S / 2; ++i) reinterpret_cast<uint2 *>(dst)[i] = make_uint2(out[2 * i], out[2 * i + 1]);
       }
     }
+  }
+}
+
+// Reads of one length (the usual case): item g belongs to read g / per, position g % per, so every lane has work (a wave
+// per read leaves its last round of 64 nearly empty: 129 items at 150 bp), and the digit histograms of the coming sort
+// are taken while the record is in registers (no separate read of the 16-byte records).
+template <int KW, int S>
+__global__ __launch_bounds__(256) void k_count_extract_fixed(const uint32_t *__restrict__ seq, uint32_t L, uint32_t per, uint64_t n_items, int k,
+                                                             uint64_t pos_base, uint32_t *__restrict__ items, DigitSpecs specs,
+                                                             unsigned long long *__restrict__ ghist) {
+  __shared__ uint32_t h[kMaxFusedPasses][256];
+  for (int i = threadIdx.x; i < specs.n * 256; i += 256) (&h[0][0])[i] = 0;
+  __syncthreads();
+  const uint64_t n_blocks = (n_items + 255) / 256;
+  for (uint64_t blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
+    const uint64_t g = blk * 256 + threadIdx.x;
+    if (g >= n_items) continue;
+    const uint64_t r = g / per;
+    const uint32_t p = (uint32_t)(g - r * per);
+    const uint64_t st = r * L;
+    uint32_t e[KW], rc[KW];
+    load_chars<KW>(seq, st + p, k + 1, e);
+    rc_chars<KW>(e, k + 1, rc);
+    const int strand = cmp_words<KW>(rc, e) < 0;  // rev_edge.cmp(edge) < 0, kmer_counter.cpp:179
+    const unsigned prev = p > 0 ? base_at(seq, st + p - 1) : kSentinel;
+    const unsigned next = p + k + 1 < L ? base_at(seq, st + p + k + 1) : kSentinel;
+    const uint64_t full = ((pos_base + st + p) << 1) | (uint64_t)strand;
+    uint64_t info;
+    uint32_t out[S];
+    if (!strand) {
+#pragma unroll
+      for (int i = 0; i < KW; ++i) out[i] = e[i];
+      info = (full << 6) | (prev << 3) | next;
+    } else {
+#pragma unroll
+      for (int i = 0; i < KW; ++i) out[i] = rc[i];
+      info = (full << 6) | (comp_or_sentinel(next) << 3) | comp_or_sentinel(prev);
+    }
+    out[KW] = (uint32_t)(info >> 32);
+    out[KW + 1] = (uint32_t)info;
+    if constexpr (S > KW + 2) out[KW + 2] = 0;
+    for (int q = 0; q < specs.n; ++q) atomicAdd(&h[q][words_digit2<S>(out, specs.d[q])], 1u);
+    uint32_t *dst = items + g * S;
+    if constexpr (S % 4 == 0) {
+#pragma unroll
+      for (int i = 0; i < S / 4; ++i)
+        reinterpret_cast<uint4 *>(dst)[i] = make_uint4(out[4 * i], out[4 * i + 1], out[4 * i + 2], out[4 * i + 3]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < S / 2; ++i) reinterpret_cast<uint2 *>(dst)[i] = make_uint2(out[2 * i], out[2 * i + 1]);
+    }
+  }
+  __syncthreads();
+  for (int q = 0; q < specs.n; ++q) {
+    const uint32_t v = h[q][threadIdx.x];
+    if (v) atomicAdd(&ghist[q * 256 + threadIdx.x], (unsigned long long)v);
   }
 }
 
@@ -620,8 +677,28 @@ static void count_postprocess(mhx_ctx *c, const uint32_t *sorted, uint64_t n_ite
 static int count_kw(uint32_t k) { return (int)div_ceil((k + 1) * 2, 32); }
 int count_stride(uint32_t k) { return round_up2(count_kw(k) + 2); }
 
-// items of the local reads -> c->ws("items_a"); returns their number
-uint64_t count_extract(mhx_ctx *c, uint32_t k) {
+// the record sort of count: only the top seg_bits of the key when the segment group-by (k_count_seg) follows, else all of it
+static std::vector<SortPass> count_sort_passes(mhx_ctx *c, uint32_t k, uint32_t m, uint64_t n_items, int *seg_bits_out) {
+  const int KWv = count_kw(k), S = count_stride(k);
+  const int wpe = (int)div_ceil((k + 1) * 2 + 16, 32);
+  const int key_bits = (int)(k + 1) * 2;
+  // Segment group-by (k_count_seg): sort only the top seg_bits of the key (a segment then holds ~100 records), count the
+  // equal keys of every segment in LDS, sort the few solid edges afterwards.  16-byte records / 2-word edges (k <= 23).
+  int seg_bits = 0;
+  if (c->opt("count_seg", 1) && S == 4 && KWv == 2 && wpe == 2 && m < 4096 && n_items) {
+    const double n_eff = (double)n_items * (double)(c->n_parts > 1 ? c->n_parts : 1);
+    seg_bits = 8;
+    while (seg_bits < 32 && n_eff / 96.0 > (double)(1ull << seg_bits)) seg_bits += 8;
+    if (c->opt("count_seg_bits", 0)) seg_bits = (int)c->opt("count_seg_bits", 0);
+    seg_bits = std::max(1, std::min(seg_bits, 32));
+  }
+  if (seg_bits_out) *seg_bits_out = seg_bits;
+  return seg_bits ? make_passes(KWv, 64 - seg_bits, 64) : make_passes(KWv, KWv * 32 - key_bits, KWv * 32);
+}
+
+// items of the local reads -> c->ws("items_a"); returns their number.  m > 0: the caller will sort them for mhx_count with
+// this minimum count, so the digit histograms of that sort can be taken on the way (fixed-length reads)
+uint64_t count_extract(mhx_ctx *c, uint32_t k, uint32_t m) {
   SeqSet &s = c->seqs;
   if (k < 9 || k > MHX_MAX_K) throw Error("count: k out of range [9,255]");
   const int KWv = count_kw(k), S = count_stride(k);
@@ -642,18 +719,43 @@ uint64_t count_extract(mhx_ctx *c, uint32_t k) {
   }
   const size_t item_bytes = (size_t)S * 4;
   uint32_t *buf_a = c->ws("items_a", n_items * item_bytes + 64).as<uint32_t>();
+  c->pre_hist_buf = nullptr;
   if (n_items) {
     const unsigned grid = 256 * 8;
+    const bool fixed = s.fixed_len >= k + 1 && n_items == (uint64_t)ns * (s.fixed_len - k) && c->opt("count_extract_fixed", 1) != 0;
+    DigitSpecs specs;
+    specs.n = 0;
+    unsigned long long *pre_hist = nullptr;
+    if (fixed && m > 0) {
+      const std::vector<SortPass> passes = count_sort_passes(c, k, m, n_items, nullptr);
+      if ((int)passes.size() <= kMaxFusedPasses) {
+        c->pre_hist_sig = passes_signature(passes);
+        specs.n = (int)passes.size();
+        for (int p = 0; p < specs.n; ++p) specs.d[p] = spec_of_pass(passes[p], KWv);
+        pre_hist = c->ws("sort_pre_hist", (size_t)kMaxFusedPasses * 256 * 8).as<unsigned long long>();
+        MHX_HIP(hipMemsetAsync(pre_hist, 0, (size_t)specs.n * 256 * 8, st));
+        c->pre_hist_buf = buf_a;
+        c->pre_hist_n = n_items;
+        c->pre_hist_passes = specs.n;
+      }
+    }
+#define MHX_CX(SV)                                                                                                               \
+  do {                                                                                                                           \
+    if (fixed)                                                                                                                   \
+      MHX_LAUNCH(c, "count_extract", (double)n_items * item_bytes + (double)s.n_bases / 4,                                       \
+                 hipLaunchKernelGGL((k_count_extract_fixed<KW, SV>), dim3((unsigned)std::min<uint64_t>(div_ceil(n_items, 256), 256 * 16)), \
+                                    dim3(256), 0, st, s.words.as<uint32_t>(), s.fixed_len, s.fixed_len - k, n_items, (int)k, c->pos_base, \
+                                    buf_a, specs, pre_hist));                                                                     \
+    else                                                                                                                         \
+      MHX_LAUNCH(c, "count_extract", (double)n_items * item_bytes + (double)s.n_bases / 4,                                       \
+                 hipLaunchKernelGGL((k_count_extract<KW, SV>), dim3(grid), dim3(256), 0, st, s.words.as<uint32_t>(),              \
+                                    s.start.as<uint64_t>(), item_start, ns, (int)k, c->pos_base, buf_a));                         \
+  } while (0)
     MHX_DISPATCH_KW(KWv, {
-      if (S == KW + 2)
-        MHX_LAUNCH(c, "count_extract", (double)n_items * item_bytes + (double)s.n_bases / 4,
-                   hipLaunchKernelGGL((k_count_extract<KW, KW + 2>), dim3(grid), dim3(256), 0, st, s.words.as<uint32_t>(),
-                                      s.start.as<uint64_t>(), item_start, ns, (int)k, c->pos_base, buf_a));
-      else
-        MHX_LAUNCH(c, "count_extract", (double)n_items * item_bytes + (double)s.n_bases / 4,
-                   hipLaunchKernelGGL((k_count_extract<KW, KW + 3>), dim3(grid), dim3(256), 0, st, s.words.as<uint32_t>(),
-                                      s.start.as<uint64_t>(), item_start, ns, (int)k, c->pos_base, buf_a));
+      if (S == KW + 2) MHX_CX(KW + 2);
+      else MHX_CX(KW + 3);
     });
+#undef MHX_CX
   }
   return n_items;
 }
@@ -668,18 +770,9 @@ int count_process(mhx_ctx *c, uint32_t k, uint32_t m, uint32_t *buf_a, uint32_t 
   hipStream_t st = c->stream;
   const bool global = c->global_bases != 0;
   const int key_bits = (int)(k + 1) * 2;
-  // Segment group-by (k_count_seg): sort only the top seg_bits of the key (a segment then holds ~100 records), count the
-  // equal keys of every segment in LDS, sort the few solid edges afterwards.  16-byte records / 2-word edges (k <= 23).
   int seg_bits = 0;
-  if (c->opt("count_seg", 1) && S == 4 && KWv == 2 && wpe == 2 && m < 4096 && n_items) {
-    const double n_eff = (double)n_items * (double)(c->n_parts > 1 ? c->n_parts : 1);
-    seg_bits = 8;
-    while (seg_bits < 32 && n_eff / 96.0 > (double)(1ull << seg_bits)) seg_bits += 8;
-    if (c->opt("count_seg_bits", 0)) seg_bits = (int)c->opt("count_seg_bits", 0);
-    seg_bits = std::max(1, std::min(seg_bits, 32));
-  }
-  uint32_t *sorted = radix_sort(c, buf_a, buf_b, n_items, S, KWv,
-                                seg_bits ? make_passes(KWv, 64 - seg_bits, 64) : make_passes(KWv, KWv * 32 - key_bits, KWv * 32));
+  const std::vector<SortPass> sort_passes = count_sort_passes(c, k, m, n_items, &seg_bits);
+  uint32_t *sorted = radix_sort(c, buf_a, buf_b, n_items, S, KWv, sort_passes);
   uint32_t *spare = sorted == buf_a ? buf_b : buf_a;
 
   // results

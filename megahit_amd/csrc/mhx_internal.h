@@ -198,7 +198,7 @@ void bucket_histogram(mhx_ctx *c, int stage, uint32_t k, uint32_t m, uint64_t *h
 int s2_stride(uint32_t k);
 constexpr int MHX_BUF_IS_SOLID_LOCAL = 100;  // internal: this rank's slice of the global bitmap (multi-GPU)
 constexpr int MHX_BUF_MERCY_CAND_LOCAL = 101;  // internal: routed mercy candidates of the local reads, local positions
-uint64_t count_extract(mhx_ctx *c, uint32_t k);
+uint64_t count_extract(mhx_ctx *c, uint32_t k, uint32_t m = 0);
 int count_stride(uint32_t k);
 int count_process(mhx_ctx *c, uint32_t k, uint32_t m, uint32_t *buf_a, uint32_t *buf_b, uint64_t n_items, mhx_count_result *out);
 void count_apply_events(mhx_ctx *c, const unsigned long long *ev, uint64_t n);

@@ -55,7 +55,7 @@ static StageItems extract_all(mhx_ctx *c, int stage, uint32_t k, uint32_t m) {
     r.n = s1_extract(c, k, compact);
     r.S = s1_stride(k, compact);
   } else if (stage == MHX_STAGE_COUNT) {
-    r.n = count_extract(c, k);
+    r.n = count_extract(c, k, m);
     r.S = count_stride(k);
   } else if (stage == MHX_STAGE_SEQ2SDBG) {
     r.n = seq2sdbg_extract(c, k);

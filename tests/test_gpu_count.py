@@ -50,10 +50,10 @@ def test_count_matches_oracle(engine, kind, k, m):
     assert np.array_equal(engine.fetch(lib.BUF_LAST_0_IN, np.uint32), want["last_0_in"])
 
 
-COUNT_SEG_DEFAULTS = dict(count_seg=1, count_seg_bits=0, count_seg_la=3)
+COUNT_SEG_DEFAULTS = dict(count_seg=1, count_seg_bits=0, count_seg_la=3, count_extract_fixed=1)
 
 
-@pytest.mark.parametrize("opts", [dict(count_seg=0), dict(count_seg_bits=8, count_seg_la=0), dict(count_seg_bits=8), dict(count_seg_bits=16, count_seg_la=1),
+@pytest.mark.parametrize("opts", [dict(count_seg=0), dict(count_extract_fixed=0), dict(count_seg_bits=8, count_seg_la=0), dict(count_seg_bits=8), dict(count_seg_bits=16, count_seg_la=1),
                                   dict(count_seg_bits=32)], ids=lambda o: ",".join("%s=%d" % kv for kv in o.items()))
 @pytest.mark.parametrize("kind,k,m", [("fixed", 21, 2), ("var", 21, 2), ("lowcomplex", 21, 2), ("var", 23, 3), ("fixed", 17, 1)])
 def test_count_segment_groupby_variants(engine, kind, k, m, opts):
