@@ -92,6 +92,42 @@ def repetitive_reads(seed):
     return [reads[i] for i in order]
 
 
+def size_class_reads(seed):
+    """lv1 buckets of about 10^5 records (the replay's largest LDS class, 69 633..147 456 records) and of ~5 x 10^4: 1300
+    poly-A reads and 2600 (AC)n reads, whose (k-1)-mers fall into one and two buckets, with sequencing errors sprinkled in so
+    that the buckets also hold short runs and singletons, plus random reads"""
+    rng = np.random.default_rng(seed)
+    reads = []
+    for _ in range(1300):
+        r = np.zeros(100, dtype=np.uint8)
+        e = rng.random(100) < 0.002
+        r[e] = rng.integers(0, 4, size=int(e.sum()), dtype=np.uint8)
+        reads.append(r)
+    for i in range(2600):
+        r = np.tile(np.array([0, 1], dtype=np.uint8), 50)[i % 2:][:98].copy()
+        e = rng.random(r.size) < 0.002
+        r[e] = rng.integers(0, 4, size=int(e.sum()), dtype=np.uint8)
+        reads.append(r)
+    reads += [rng.integers(0, 4, size=int(rng.integers(40, 120)), dtype=np.uint8) for _ in range(800)]
+    order = rng.permutation(len(reads))
+    return [reads[i] for i in order]
+
+
+@pytest.mark.parametrize("k,m", [(21, 2), (27, 3)])
+def test_kmsort_replay_largest_lds_class(engine, k, m):
+    reads = size_class_reads(5)
+    pkg = ob.Package(reads, reverse=True)
+    w1 = ob.s1(pkg, k, m, tie_stable=False)
+    load(engine, pkg)
+    sizes = np.sort(engine.bucket_histogram(lib.STAGE_S1_MERCY, k, m))[::-1]
+    assert 69632 < sizes[0] <= 147456, sizes[:4]  # the class under test is really met
+    r1 = engine.read2sdbg_s1(k, m, want_mercy=2)
+    assert r1.n_items == w1["n_items"]
+    assert np.array_equal(engine.fetch(lib.BUF_MERCY_CAND, np.int64), w1["mercy"])
+    solid = engine.fetch(lib.BUF_IS_SOLID, np.uint64)
+    assert np.array_equal(solid, w1["is_solid"][: solid.size])
+
+
 @pytest.mark.parametrize("k,m,legacy", [(21, 2, 0), (21, 2, 1), (31, 3, 0), (31, 3, 1), (61, 2, 0)])
 def test_kmsort_replay_on_repetitive_reads(engine, k, m, legacy):
     """the wave-per-bucket replay (tags in LDS / in global memory for the poly-A bucket) and the one-thread-per-bucket
