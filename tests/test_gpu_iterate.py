@@ -73,3 +73,48 @@ def test_iterate_on_synthetic_contigs(tmp_path, k, step, seed):
                    check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     n = compare(os.path.join(d, "asm.contigs.fa"), os.path.join(d, "asm.bubble_seq.fa"), os.path.join(d, "reads.bin"), k, step, d)
     assert n > 0
+
+
+def write_overlapping_contigs(path_ctg, path_bub, genome, k, rng):
+    """pieces of the genome that overlap by k bases (as unitigs do), half of them reverse-complemented, written as the
+    assembler writes contigs; a few short 'bubble' sequences"""
+    lut = np.frombuffer(b"ACGT", dtype=np.uint8)
+    n, pos = 0, 0
+    with open(path_ctg, "wb") as f:
+        while pos + k + 2 < genome.size:
+            ln = int(rng.integers(k + 1, 4 * k))
+            piece = genome[pos:pos + ln]
+            if rng.random() < 0.5:
+                piece = (3 - piece[::-1]).astype(np.uint8)
+            flag = 0 if rng.random() < 0.9 else int(rng.integers(1, 3))  # some standalone / loop contigs: dropped by iterate
+            f.write(b">k%d_%d flag=%d multi=12.0000 len=%d\n" % (k, n, flag, piece.size))
+            f.write(lut[piece].tobytes() + b"\n")
+            n += 1
+            pos += ln - k if rng.random() < 0.85 else ln + int(rng.integers(0, 5))
+    with open(path_bub, "wb") as f:
+        for i in range(20):
+            a = int(rng.integers(0, genome.size - 3 * k))
+            piece = genome[a:a + int(rng.integers(k + 1, 2 * k))]
+            f.write(b">k%d_%d flag=0 multi=2.0000 len=%d\n" % (k, n + i, piece.size))
+            f.write(lut[piece].tobytes() + b"\n")
+    return n
+
+
+@pytest.mark.parametrize("k,step,seed", [(79, 20, 41), (119, 22, 42), (99, 28, 43), (31, 2, 44)])
+def test_iterate_wide_kmers(tmp_path, k, step, seed):
+    """keys of up to 8 words, new k-mers of up to 9: contigs cut from the genome, reads of 150..220 bases with errors"""
+    d = str(tmp_path)
+    rng = np.random.default_rng(seed)
+    genome = rng.integers(0, 4, size=30000, dtype=np.uint8)
+    reads = []
+    for _ in range(6000):
+        ln = int(rng.integers(150, 221))
+        a = int(rng.integers(0, genome.size - ln))
+        r = genome[a:a + ln].copy()
+        e = rng.random(ln) < 0.003
+        r[e] = rng.integers(0, 4, size=int(e.sum()), dtype=np.uint8)
+        reads.append(r if rng.random() < 0.5 else (3 - r[::-1]).astype(np.uint8))
+    synth.write_read_lib(os.path.join(d, "reads"), [reads])
+    write_overlapping_contigs(os.path.join(d, "c.fa"), os.path.join(d, "b.fa"), genome, k, rng)
+    n = compare(os.path.join(d, "c.fa"), os.path.join(d, "b.fa"), os.path.join(d, "reads.bin"), k, step, d)
+    assert n > 100
