@@ -123,6 +123,12 @@ def test_index_straight_from_stage2_buffers(engine, tmp_path):
 def _tip_cases():
     out = [e for e in _cases() if e["case"]["prog"] == "read2sdbg"][:6]
     out += [e for e in _cases() if e["case"]["prog"] == "seq2sdbg"][:4]
+    seen = {(e["case"]["prog"], e["case"]["k"]) for e in out}
+    for e in _cases():  # one graph per further k: multi-word tip labels, max_tip_len up to 238
+        key = (e["case"]["prog"], e["case"]["k"])
+        if key not in seen:
+            seen.add(key)
+            out.append(e)
     return out
 
 
