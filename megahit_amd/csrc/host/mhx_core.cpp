@@ -105,9 +105,23 @@ mhx_ctx *open_gpu() {
   if (getenv("MHX_PROFILE")) mhx_profile_enable(c, 1);  // per-kernel HIP-event times, printed by finish()
   return c;
 }
+// The chained-scan sort gives up (and says so) when a unit waits seconds for a predecessor — a wedged or heavily shared
+// GPU.  Its remedy is the classic histogram + scan + scatter passes (MHX_SORT=classic: slower, no inter-workgroup waiting).
+// The worker process tells the front process (main) to start the sub-program again that way instead of failing the caller.
+extern int g_done_fd;
+constexpr unsigned char kRetryClassicSort = 75;
+[[noreturn]] void fail_call(const char *msg) {
+  if (g_done_fd >= 0 && !getenv("MHX_SORT") && strstr(msg, "chained scan timed out")) {
+    mhxio::info("%s: running the sub-program again with MHX_SORT=classic", msg);
+    fflush(nullptr);
+    const unsigned char st = kRetryClassicSort;
+    if (write(g_done_fd, &st, 1) == 1) _exit(kRetryClassicSort);
+  }
+  fatal("%s", msg);
+}
 #define CK(call)                                  \
   do {                                            \
-    if ((call) != 0) fatal("%s", mhx_last_error()); \
+    if ((call) != 0) fail_call(mhx_last_error()); \
   } while (0)
 
 // ---- multi-GPU: `mhx_core --gpus N <sub-program> ...` or MHX_NUM_GPUS=N.  One host thread per GPU in this process (no
@@ -171,7 +185,7 @@ void run_ranks(const RankSet &rs, Body body) {
     });
   for (auto &t : th) t.join();
   for (int r = 0; r < rs.n; ++r)
-    if (!err[r].empty()) fatal("rank %d: %s", r, err[r].c_str());
+    if (!err[r].empty()) fail_call(("rank " + std::to_string(r) + ": " + err[r]).c_str());
   for (int r = 0; r < rs.n; ++r) {
     mhx_comm_destroy(comm[r]);
     mhx_destroy(ctx[r]);
@@ -196,6 +210,10 @@ std::vector<uint64_t> shard_reads(const mhxio::BinFile &bin, int n) {
 // The outputs are on disk and closed: leave without tearing the HIP runtime down (freeing tens of GB of device memory
 // page by page costs more than the GPU stages of a small job).  MHX_CLEAN_EXIT=1 destroys the handle first.
 int g_done_fd = -1;  // write end of the pipe to the front process (main): set in the process that does the work
+// test hook (tests/test_front_process.py): the first worker pretends the chained scan timed out
+void maybe_pretend_scan_timeout() {
+  if (getenv("MHX_TEST_SCAN_TIMEOUT_ONCE") && !getenv("MHX_SORT")) fail_call("radix sort: chained scan timed out waiting for a predecessor unit (test hook)");
+}
 [[noreturn]] void finish(mhx_ctx *c) {
   if (getenv("MHX_PROFILE")) {
     std::vector<mhx_kernel_stat> ks(256);
@@ -955,8 +973,9 @@ int main(int argc, char **argv) {
   if (ours && !getenv("MHX_NO_FORK") && !getenv("MHX_CLEAN_EXIT")) {
     // the work runs in a child (forked before anything touches the HIP runtime); this front process only waits for the
     // child's "outputs are complete" byte (finish()) or, failing that, for its exit status
-    int fds[2];
-    if (pipe(fds) == 0) {
+    for (int attempt = 0; attempt < 2; ++attempt) {
+      int fds[2];
+      if (pipe(fds) != 0) break;
       fflush(nullptr);
       const pid_t pid = fork();
       if (pid == 0) {
@@ -964,21 +983,28 @@ int main(int argc, char **argv) {
         (void)fcntl(fds[1], F_SETFD, FD_CLOEXEC);
         (void)prctl(PR_SET_PDEATHSIG, SIGKILL);  // no orphan if the front process is killed
         g_done_fd = fds[1];
-      } else if (pid > 0) {
-        close(fds[1]);
-        unsigned char st = 0;
-        ssize_t got;
-        do got = read(fds[0], &st, 1);
-        while (got < 0 && errno == EINTR);
-        if (got == 1) _exit(st);
-        int ws = 0;
-        while (waitpid(pid, &ws, 0) < 0 && errno == EINTR) {
-        }
-        return WIFEXITED(ws) ? WEXITSTATUS(ws) : 128 + WTERMSIG(ws);
-      } else {
+        break;  // the worker: on to the sub-program
+      }
+      if (pid < 0) {
         close(fds[0]);
         close(fds[1]);
+        break;  // no child: do the work here
       }
+      close(fds[1]);
+      unsigned char st = 0;
+      ssize_t got;
+      do got = read(fds[0], &st, 1);
+      while (got < 0 && errno == EINTR);
+      close(fds[0]);
+      if (got == 1 && st != kRetryClassicSort) _exit(st);
+      int ws = 0;
+      while (waitpid(pid, &ws, 0) < 0 && errno == EINTR) {
+      }
+      if (got == 1 && attempt == 0) {  // kRetryClassicSort: once more, without the chained scan
+        setenv("MHX_SORT", "classic", 1);
+        continue;
+      }
+      return WIFEXITED(ws) ? WEXITSTATUS(ws) : 128 + WTERMSIG(ws);
     }
   }
   if (g_num_gpus > 1) {
@@ -988,6 +1014,7 @@ int main(int argc, char **argv) {
       g_num_gpus = have;
     }
   }
+  if (ours) maybe_pretend_scan_timeout();
   if (sub == "count") return main_kmer_count(argc - 1, argv + 1);
   if (sub == "read2sdbg") return main_read2sdbg(argc - 1, argv + 1);
   if (sub == "seq2sdbg") return main_seq2sdbg(argc - 1, argv + 1);

@@ -67,3 +67,21 @@ def test_both_ways_of_running_write_the_same_files(tmp_path):
     assert a.returncode == 0 and b.returncode == 0
     assert canon.digest_file(os.path.join(d, "a.bin")) == canon.digest_file(os.path.join(d, "b.bin"))
     assert open(os.path.join(d, "a.lib_info")).read() == open(os.path.join(d, "b.lib_info")).read()
+
+
+def test_a_chained_scan_timeout_is_retried_with_the_classic_sort(tmp_path):
+    """the worker reports "chained scan timed out" (here: a test hook pretends it once) -> the front process starts the
+    sub-program again with MHX_SORT=classic instead of failing the caller; without a front process the error stays fatal"""
+    d = str(tmp_path)
+    lib = write_inputs(d)
+    p = run(["buildlib", lib, os.path.join(d, "out")], {"MHX_BUILDLIB_HOST": "1", "MHX_TEST_SCAN_TIMEOUT_ONCE": "1"})
+    assert p.returncode == 0, p.stderr
+    assert "running the sub-program again with MHX_SORT=classic" in p.stderr
+    ref = run(["buildlib", lib, os.path.join(d, "ref")], {"MHX_BUILDLIB_HOST": "1"})
+    assert ref.returncode == 0
+    assert canon.digest_file(os.path.join(d, "out.bin")) == canon.digest_file(os.path.join(d, "ref.bin"))
+    q = run(["buildlib", lib, os.path.join(d, "out2")], {"MHX_BUILDLIB_HOST": "1", "MHX_TEST_SCAN_TIMEOUT_ONCE": "1", "MHX_NO_FORK": "1"})
+    assert q.returncode == 1 and "chained scan timed out" in q.stderr
+    # a caller who chose the sort himself gets no retry loop (the hook only fires without MHX_SORT)
+    r = run(["buildlib", lib, os.path.join(d, "out3")], {"MHX_BUILDLIB_HOST": "1", "MHX_TEST_SCAN_TIMEOUT_ONCE": "1", "MHX_SORT": "classic"})
+    assert r.returncode == 0

@@ -86,3 +86,15 @@ def test_cli_automatic_memory_plan(ent, tmp_path, monkeypatch):
     p = subprocess.run([gu.MHX_CORE, c["prog"], "-k", str(c["k"]), "-m", str(c["m"]), "--read_lib_file", os.path.join(gu.GOLD, c["lib"]),
                         "--output_prefix", str(tmp_path / "again"), "--host_mem", "2e9", "--num_cpu_threads", "3"], stderr=subprocess.PIPE, text=True)
     assert p.returncode == 0 and "Memory plan:" in p.stderr, p.stderr[-800:]
+
+
+@pytest.mark.parametrize("ent", [e for e in gu.cases() if e["case"]["k"] == 21 and e["case"].get("lib") == "hc" and not e["case"].get("input")][:3], ids=gu.case_id)
+def test_cli_retries_with_the_classic_sort_after_a_scan_timeout(ent, tmp_path, monkeypatch):
+    """the front process restarts a sub-program whose chained-scan sort gave up (here: a test hook pretends it in the first
+    worker) with MHX_SORT=classic: exit 0 and the reference's outputs, from the histogram + scan + scatter passes"""
+    monkeypatch.setenv("MHX_TEST_SCAN_TIMEOUT_ONCE", "1")
+    got = gu.run_case(gu.MHX_CORE, ent, str(tmp_path))
+    for key, want in ent.items():
+        if key in ("case", "mercy_cand_kmsort"):
+            continue
+        assert got.get(key) == want, key
