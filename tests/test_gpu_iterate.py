@@ -118,3 +118,19 @@ def test_iterate_wide_kmers(tmp_path, k, step, seed):
     write_overlapping_contigs(os.path.join(d, "c.fa"), os.path.join(d, "b.fa"), genome, k, rng)
     n = compare(os.path.join(d, "c.fa"), os.path.join(d, "b.fa"), os.path.join(d, "reads.bin"), k, step, d)
     assert n > 100
+
+
+@pytest.mark.parametrize("k,step,seed", [(21, 8, 1), (22, 6, 5), (39, 20, 4)])
+def test_iterate_equals_the_python_oracle(tmp_path, k, step, seed):
+    """the same inputs as tests/test_oracle_iterate.py (where the restatement is pinned to the reference): contigs with
+    competing flanks, a contig of exactly k+1 bases, a palindromic flank, dropped loop / standalone contigs"""
+    import sys
+    sys.path.insert(0, os.path.join(gu.ROOT, "oracle"))
+    import iterate_oracle as io
+    import test_oracle_iterate as toi
+    d = str(tmp_path)
+    toi.make_case(d, k, seed)
+    hm, em = run_iterate(gu.MHX_CORE, os.path.join(d, "c.fa"), os.path.join(d, "b.fa"), os.path.join(d, "reads.bin"), k, step, os.path.join(d, "mhx"))
+    rows, wpe, _n_flanks, _aligned = io.iterate(os.path.join(d, "c.fa"), os.path.join(d, "b.fa"), os.path.join(d, "reads.bin"), k, step)
+    assert hm["words_per_edge"] == wpe and hm["kmer_size"] == k + step and hm["is_sorted"] == 0
+    assert em.shape == rows.shape and np.array_equal(em, rows)
