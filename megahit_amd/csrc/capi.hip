@@ -716,7 +716,7 @@ int mhx_sort_records(mhx_ctx *c, uint32_t *host_items, uint64_t n, uint32_t key_
       MHX_HIP(hipMemsetAsync(a, 0, n * S * 4, c->stream));
       MHX_HIP(hipMemcpy2DAsync(a, S * 4, host_items, w * 4, w * 4, n, hipMemcpyHostToDevice, c->stream));
     }
-    uint32_t *r = mhx::radix_sort(c, a, b, n, S, (int)key_words, mhx::make_passes((int)key_words, 0, (int)key_words * 32));
+    uint32_t *r = mhx::sort_whole_key(c, a, b, n, S, (int)key_words, mhx::make_passes((int)key_words, 0, (int)key_words * 32));
     if (S == w) MHX_HIP(hipMemcpyAsync(host_items, r, n * w * 4, hipMemcpyDeviceToHost, c->stream));
     else MHX_HIP(hipMemcpy2DAsync(host_items, w * 4, r, S * 4, w * 4, n, hipMemcpyDeviceToHost, c->stream));
     MHX_HIP(hipStreamSynchronize(c->stream));

@@ -772,7 +772,8 @@ int count_process(mhx_ctx *c, uint32_t k, uint32_t m, uint32_t *buf_a, uint32_t 
   const int key_bits = (int)(k + 1) * 2;
   int seg_bits = 0;
   const std::vector<SortPass> sort_passes = count_sort_passes(c, k, m, n_items, &seg_bits);
-  uint32_t *sorted = radix_sort(c, buf_a, buf_b, n_items, S, KWv, sort_passes);
+  // (no segment group-by: the whole zero-padded (k+1)-mer is the key; equal keys keep their input order)
+  uint32_t *sorted = seg_bits ? radix_sort(c, buf_a, buf_b, n_items, S, KWv, sort_passes) : sort_whole_key(c, buf_a, buf_b, n_items, S, KWv, sort_passes);
   uint32_t *spare = sorted == buf_a ? buf_b : buf_a;
 
   // results
@@ -842,7 +843,7 @@ int count_process(mhx_ctx *c, uint32_t k, uint32_t m, uint32_t *buf_a, uint32_t 
                                       reinterpret_cast<unsigned long long *>(ea)));
         // uint64 (lo word first in memory) -> (hi, lo) word pairs = the edge's word order; sort by the (k+1)-mer bits
         hipLaunchKernelGGL(k_swap_pairs, dim3((unsigned)div_ceil(n_edges, 256)), dim3(256), 0, st, ea, n_edges);
-        uint32_t *es = radix_sort(c, ea, eb, n_edges, 2, 2, make_passes(2, 64 - key_bits, 64));
+        uint32_t *es = sort_whole_key(c, ea, eb, n_edges, 2, 2, make_passes(2, 64 - key_bits, 64));  // distinct keys: the count bits never decide
         MHX_HIP(hipMemcpyAsync(edges, es, n_edges * 8, hipMemcpyDeviceToDevice, st));
         hipLaunchKernelGGL(k_edge_buckets, dim3((unsigned)div_ceil(n_edges, 256)), dim3(256), 0, st, edges, n_edges, bcount);
         MHX_HIP(hipGetLastError());
@@ -855,7 +856,7 @@ int count_process(mhx_ctx *c, uint32_t k, uint32_t m, uint32_t *buf_a, uint32_t 
       MHX_HIP(hipMemcpyAsync(hist, sv_hist, (MHX_MAX_MUL + 1) * 8, hipMemcpyDeviceToDevice, st));
       MHX_HIP(hipMemsetAsync(ev_n, 0, 8, st));
       uint32_t *other = sorted == buf_a ? buf_b : buf_a;
-      sorted = radix_sort(c, sorted, other, n_items, S, KWv, make_passes(KWv, KWv * 32 - key_bits, KWv * 32));
+      sorted = sort_whole_key(c, sorted, other, n_items, S, KWv, make_passes(KWv, KWv * 32 - key_bits, KWv * 32));
       spare = sorted == buf_a ? buf_b : buf_a;
       events = global ? reinterpret_cast<unsigned long long *>(spare) : nullptr;
     }

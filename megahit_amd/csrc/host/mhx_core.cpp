@@ -19,6 +19,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -117,7 +118,10 @@ constexpr unsigned char kRetryClassicSort = 75;
     const unsigned char st = kRetryClassicSort;
     if (write(g_done_fd, &st, 1) == 1) _exit(kRetryClassicSort);
   }
-  fatal("%s", msg);
+  // (not exit(): with rank threads still running, static destructors and the HIP runtime's atexit handlers can hang)
+  fprintf(stderr, "FATAL %s\n", msg);
+  fflush(nullptr);
+  _exit(1);
 }
 #define CK(call)                                  \
   do {                                            \
@@ -169,23 +173,33 @@ void run_ranks(const RankSet &rs, Body body) {
   }
   info("%d ranks on devices %s over %s", rs.n, [&] { std::string d; for (int v : rs.dev) d += std::to_string(v) + " "; return d; }().c_str(),
        rs.local ? "the in-process transport" : "RCCL");
-  std::vector<std::string> err(rs.n);
+  // A rank that fails must take the whole process down at once, from its own thread: the other ranks sit in a barrier of
+  // the in-process transport or in an RCCL collective that this rank will never enter, so joining them would hang.
+  // fail_rank -> fail_call: tells the front process (classic-sort retry or failure) and leaves with _exit, no teardown.
+  auto fail_rank = [](int r, const std::string &what) {
+    static std::mutex once;
+    std::lock_guard<std::mutex> lk(once);  // the first failing rank reports; a second one waits here until the process is gone
+    fail_call(("rank " + std::to_string(r) + ": " + (what.empty() ? "failed" : what)).c_str());
+  };
   std::vector<std::thread> th;
   for (int r = 0; r < rs.n; ++r)
     th.emplace_back([&, r] {
       try {
+        if (getenv("MHX_TEST_RANK_FAIL") && atoi(getenv("MHX_TEST_RANK_FAIL")) == r) throw std::string("test hook: this rank fails before its first collective");
         if (!rs.local) {
           comm[r] = mhx_comm_init_rank(ctx[r], id, r, rs.n);  // collective: returns when every rank has joined
           if (!comm[r]) throw std::string(mhx_last_error());
         }
         body(r, ctx[r], comm[r]);
       } catch (const std::string &e) {
-        err[r] = e.empty() ? "failed" : e;
+        fail_rank(r, e);
+      } catch (const std::exception &e) {  // std::bad_alloc from a fetch, std::system_error, ...
+        fail_rank(r, e.what());
+      } catch (...) {
+        fail_rank(r, "unknown exception");
       }
     });
   for (auto &t : th) t.join();
-  for (int r = 0; r < rs.n; ++r)
-    if (!err[r].empty()) fail_call(("rank " + std::to_string(r) + ": " + err[r]).c_str());
   for (int r = 0; r < rs.n; ++r) {
     mhx_comm_destroy(comm[r]);
     mhx_destroy(ctx[r]);
@@ -207,8 +221,7 @@ std::vector<uint64_t> shard_reads(const mhxio::BinFile &bin, int n) {
   return first;
 }
 
-// The outputs are on disk and closed: leave without tearing the HIP runtime down (freeing tens of GB of device memory
-// page by page costs more than the GPU stages of a small job).  MHX_CLEAN_EXIT=1 destroys the handle first.
+// The outputs are on disk and closed: release the device memory and leave without running the HIP runtime's own teardown.
 int g_done_fd = -1;  // write end of the pipe to the front process (main): set in the process that does the work
 // test hook (tests/test_front_process.py): the first worker pretends the chained scan timed out
 void maybe_pretend_scan_timeout() {
@@ -222,13 +235,16 @@ void maybe_pretend_scan_timeout() {
     std::sort(ks.begin(), ks.end(), [](const mhx_kernel_stat &a, const mhx_kernel_stat &b) { return a.total_ms > b.total_ms; });
     for (const mhx_kernel_stat &s : ks) info("profile %-24s %6u launches %12.3f ms", s.name, s.launches, s.total_ms);
   }
-  if (getenv("MHX_CLEAN_EXIT")) mhx_destroy(c);
+  // Default: give the device memory back HERE, synchronously (hipFree of every buffer), before the caller is told that we
+  // are done.  Leaving it to process exit is faster for this call (MHX_EARLY_EXIT=1: the front process returns while the
+  // driver still reclaims tens of GB in the background) but the next GPU process of a pipeline then starts on a device
+  // that is busy unmapping: its hipMalloc calls wait and hipMemGetInfo under-reports (the reference's orchestrator runs
+  // count -> seq2sdbg -> assemble -> iterate -> seq2sdbg back to back).
+  if (!getenv("MHX_EARLY_EXIT") || getenv("MHX_CLEAN_EXIT")) mhx_destroy(c);
   fflush(nullptr);
   if (g_done_fd >= 0) {
-    // Everything the caller waits for exists and is closed.  Tell the front process, which exits with our status at once;
-    // this process then dies, and the release of tens of GB of GPU mappings (~0.1 s of kernel time at 10 M reads, as much
-    // as the GPU stages) is not on the caller's clock.  The standard streams are closed so that a caller reading our
-    // stderr through a pipe sees its end when the front process exits.
+    // Everything the caller waits for exists and is closed: tell the front process.  The standard streams are closed so
+    // that a caller reading our stderr through a pipe sees its end when the front process exits.
     const unsigned char ok = 0;
     if (write(g_done_fd, &ok, 1) != 1) _exit(1);
     close(g_done_fd);
@@ -996,14 +1012,18 @@ int main(int argc, char **argv) {
       do got = read(fds[0], &st, 1);
       while (got < 0 && errno == EINTR);
       close(fds[0]);
-      if (got == 1 && st != kRetryClassicSort) _exit(st);
+      // MHX_EARLY_EXIT=1: return as soon as the outputs are complete, while the worker still gives its device memory back
+      // (a caller that starts the next GPU process right away then waits in hipMalloc and sees less free memory than
+      // there will be: the reference's orchestrator runs its sub-programs back to back).  Default: wait for the worker.
+      if (got == 1 && st != kRetryClassicSort && getenv("MHX_EARLY_EXIT")) _exit(st);
       int ws = 0;
       while (waitpid(pid, &ws, 0) < 0 && errno == EINTR) {
       }
-      if (got == 1 && attempt == 0) {  // kRetryClassicSort: once more, without the chained scan
+      if (got == 1 && st == kRetryClassicSort && attempt == 0) {  // once more, without the chained scan
         setenv("MHX_SORT", "classic", 1);
         continue;
       }
+      if (got == 1 && st != kRetryClassicSort) return st;  // "outputs complete" (0): the worker's own exit is teardown only
       return WIFEXITED(ws) ? WEXITSTATUS(ws) : 128 + WTERMSIG(ws);
     }
   }

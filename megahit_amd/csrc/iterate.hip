@@ -229,7 +229,7 @@ int iterate_edges(mhx_ctx *c, uint32_t k, uint32_t step, const uint32_t *ctg_wor
   }
   out->n_flanks = n_fl;
   uint32_t *fl = fa;
-  if (n_fl > 1) fl = radix_sort(c, fa, fb, n_fl, FS, KWv + 2, make_passes(KWv + 2, 0, (KWv + 2) * 32));
+  if (n_fl > 1) fl = sort_whole_key(c, fa, fb, n_fl, FS, KWv + 2, make_passes(KWv + 2, 0, (KWv + 2) * 32));
   // 2. reads
   const uint64_t n_reads = s.n_seqs;
   const uint32_t wpr = (uint32_t)div_ceil(s.max_len ? s.max_len : 1, 64);
@@ -261,7 +261,7 @@ int iterate_edges(mhx_ctx *c, uint32_t k, uint32_t step, const uint32_t *ctg_wor
                  hipLaunchKernelGGL((k_iter_emit<KW>), dim3((unsigned)div_ceil(n_reads, 256)), dim3(256), 0, st, s.words.as<uint32_t>(),
                                     s.start.as<uint64_t>(), n_reads, (int)k, (int)step, exist, wpr, off, ka, NS));
     });
-    uint32_t *ks = radix_sort(c, ka, kb, n_new, NS, NWv, make_passes(NWv, NWv * 32 - 2 * (int)(k + step + 1), NWv * 32));
+    uint32_t *ks = sort_whole_key(c, ka, kb, n_new, NS, NWv, make_passes(NWv, NWv * 32 - 2 * (int)(k + step + 1), NWv * 32));
     uint32_t *head = c->ws("it_head", (n_new + 1) * 4).as<uint32_t>();
     uint64_t *pos = c->ws("it_pos", (n_new + 2) * 8).as<uint64_t>();
     hipLaunchKernelGGL(k_iter_heads, dim3((unsigned)div_ceil(n_new, 256)), dim3(256), 0, st, ks, n_new, NS, NWv, head);

@@ -153,6 +153,9 @@ struct SortPass {
 // (least-significant pass first).  Returns the buffer holding the result.
 uint32_t *radix_sort(mhx_ctx *c, uint32_t *buf_a, uint32_t *buf_b, uint64_t n, int stride, int key_words,
                      const std::vector<SortPass> &passes);
+// prefix passes + segment finish in LDS when that saves passes (sort.hip); same result as radix_sort with `passes`
+uint32_t *sort_whole_key(mhx_ctx *c, uint32_t *buf_a, uint32_t *buf_b, uint64_t n, int stride, int key_words,
+                         const std::vector<SortPass> &passes);
 std::vector<SortPass> make_passes(int key_words, int lo_bit, int hi_bit);
 uint64_t passes_signature(const std::vector<SortPass> &ps);
 bool probe_lds_atomic_order(mhx_ctx *c);

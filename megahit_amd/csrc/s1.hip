@@ -166,6 +166,89 @@ __global__ __launch_bounds__(256) void k_s1_extract_fixed(const uint32_t *__rest
   }
 }
 
+__device__ __forceinline__ uint64_t rc64(uint64_t x, int n);
+// The same records for the usual shape — fixed-length reads, 12-byte compact records, k <= 29 — with a fraction of the
+// instructions (the generic kernel above is bound by instruction issue: ~240 VALU operations per record, among them a
+// 64-bit division by the items-per-read count, four separate base look-ups and word-array shuffles):
+//   * the k+3 bases prev|head|(k-1)-mer|tail|next of an item are ONE 64-bit window of the packed store (three words, two
+//     funnel shifts); head/tail/prev/next are bit fields of it, the reverse complement is a 64-bit bit-reverse;
+//   * read index and slot advance incrementally with the persistent loop (the per-iteration stride of the workgroup,
+//     divided by the items per read, comes from the host), the only division left is a 32-bit one.
+// Same output, bit for bit, as k_s1_extract_fixed<2, 3, true> (read_to_sdbg_s1.cpp:228-292, :344-363).
+__global__ __launch_bounds__(256) void k_s1_extract_fast(const uint32_t *__restrict__ seq, uint32_t L, uint32_t per, uint64_t n_items, int k,
+                                                         uint64_t pos_base, uint32_t rank_tag, uint32_t *__restrict__ items, DigitSpecs specs,
+                                                         unsigned long long *__restrict__ ghist, uint32_t step_q, uint32_t step_r) {
+  __shared__ uint32_t xpose[256 * 3];
+  __shared__ uint32_t h[kMaxFusedPasses][256];
+  for (int i = threadIdx.x; i < specs.n * 256; i += 256) (&h[0][0])[i] = 0;
+  __syncthreads();
+  const uint64_t n_blocks = (n_items + 255) / 256;
+  const int km1 = k - 1;
+  const uint64_t kmask = ~0ull << (64 - 2 * km1);
+  // (read, first slot) of this workgroup's current block of 256 items
+  uint64_t q0 = ((uint32_t)blockIdx.x * 256u) / per;
+  uint32_t rem0 = ((uint32_t)blockIdx.x * 256u) % per;
+  for (uint64_t blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
+    const uint64_t g = blk * 256 + threadIdx.x;
+    uint32_t out[3];
+    if (g < n_items) {
+      const uint32_t t = rem0 + threadIdx.x, dq = t / per, j = t - dq * per;
+      const uint64_t st = (q0 + dq) * L;
+      uint32_t q;
+      int forced = -1;
+      if (j < 2) { q = 0; forced = (int)j; }
+      else if (j >= L - k + 2) { q = L - k + 1; forced = (int)(j - (L - k + 2)); }
+      else q = j - 1;
+      const uint64_t a = st + q;
+      if (a >= 2) {
+        const uint64_t b = a - 2;  // window: bases [a-2, a+30)
+        const uint64_t w = b >> 4;
+        const unsigned sh = (unsigned)(b & 15) * 2;
+        const uint32_t x0 = seq[w], x1 = seq[w + 1], x2 = seq[w + 2];
+        const uint64_t win = ((uint64_t)funnel_l(x0, x1, sh) << 32) | funnel_l(x1, x2, sh);
+        const unsigned prev_b = (unsigned)(win >> 62), head_b = (unsigned)(win >> 60) & 3u;
+        const unsigned tail_b = (unsigned)(win >> (58 - 2 * km1)) & 3u, next_b = (unsigned)(win >> (56 - 2 * km1)) & 3u;
+        const uint64_t f = (win << 4) & kmask;
+        const uint64_t rc = rc64(f, km1);
+        const unsigned head = q >= 1 ? head_b : kSentinel, prev = q >= 2 ? prev_b : kSentinel;
+        const unsigned tail = q + k - 1 < L ? tail_b : kSentinel, next = q + k < L ? next_b : kSentinel;
+        (void)prev;
+        (void)next;  // compact records carry no prev/next
+        int strand;
+        if (forced >= 0) strand = forced;
+        else strand = f > rc ? 1 : (f < rc ? 0 : (head <= 3 - tail ? 0 : 1));
+        const uint64_t key = strand ? (rc | (comp_or_sentinel(tail) << 3) | comp_or_sentinel(head)) : (f | (head << 3) | tail);
+        out[0] = (uint32_t)(key >> 32);
+        out[1] = (uint32_t)key | rank_tag;
+        out[2] = (uint32_t)(pos_base + a);
+      } else {  // the first two bases of the store: no window in front of them
+        s1_make_item<2, 3, true>(seq, st, L, k, j, pos_base, rank_tag, out);
+      }
+      for (int p = 0; p < specs.n; ++p) atomicAdd(&h[p][words_digit2<3>(out, specs.d[p])], 1u);
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) xpose[threadIdx.x * 3 + i] = out[i];
+    __syncthreads();
+    const uint64_t w0 = blk * 768, n_words = n_items * 3;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const uint64_t w = w0 + (uint64_t)i * 256 + threadIdx.x;
+      if (w < n_words) items[w] = xpose[i * 256 + threadIdx.x];
+    }
+    __syncthreads();
+    q0 += step_q;
+    rem0 += step_r;
+    if (rem0 >= per) {
+      rem0 -= per;
+      ++q0;
+    }
+  }
+  for (int p = 0; p < specs.n; ++p) {
+    const uint32_t v = h[p][threadIdx.x];
+    if (v) atomicAdd(&ghist[p * 256 + threadIdx.x], (unsigned long long)v);
+  }
+}
+
 constexpr int kS1LocalHist = 1024;
 
 template <int S>
@@ -792,7 +875,7 @@ constexpr uint32_t kStreamEmpty = 0xFFFFFFFFu;  // never a key: head/tail bits 6
 
 __global__ void k_bucket_bounds(const uint32_t *__restrict__ items, uint64_t n, int stride, uint64_t *__restrict__ bstart);  // kmsort_emu.hip
 
-template <bool AGG>
+template <bool AGG, int UNR>
 __global__ __launch_bounds__(kStreamThreads) void k_s1_stream(const uint32_t *__restrict__ items, const uint64_t *__restrict__ bounds, S1SegArgs a,
                                                              uint32_t bucket_stride, uint32_t *__restrict__ ticket) {
   constexpr int NT = kStreamThreads, NSLOT = kStreamSlots, LOGS = 13;
@@ -837,29 +920,37 @@ __global__ __launch_bounds__(kStreamThreads) void k_s1_stream(const uint32_t *__
       __syncthreads();
       continue;
     }
-    // A: insert
-    for (uint64_t base = lo; base < hi; base += NT) {
-      const uint64_t gi = base + tid;
-      const bool ins = gi < hi;
-      uint32_t lk = 0, w2 = 0;
-      if (ins) {
-        const uint32_t *p = items + gi * 3;
-        lk = local_key(p[0], p[1]);
-        w2 = p[2];
+    // A: insert.  UNR records per thread and trip: their loads are issued together — with one 12-byte load in flight per
+    // wavefront the 16 wavefronts of a CU keep ~12 KB on the wire, 1.5 TB/s device-wide at ~2 us under load, which is
+    // what this kernel measured before (the LDS table was never the limit)
+    for (uint64_t base = lo; base < hi; base += (uint64_t)NT * UNR) {
+      uint32_t rw0[UNR], rw1[UNR], rw2[UNR];
+      bool rin[UNR];
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const uint64_t gi = base + (uint64_t)u * NT + tid;
+        rin[u] = gi < hi;
+        // unconditional loads (index clamped into the bucket, lo < hi): straight-line code, so that the compiler issues all
+        // UNR loads before the first wait — a load inside an `if` is followed by s_waitcnt vmcnt(0) at the end of its block
+        const uint32_t *p = items + (rin[u] ? gi : hi - 1) * 3;
+        rw0[u] = p[0];
+        rw1[u] = p[1];
+        rw2[u] = p[2];
       }
-      const uint32_t hf = lk * 0x9E3779B1u;
-      // one compare-and-swap + add per record: inside a bucket the records are in read order, equal keys are rarely
-      // neighbours, so grouping the lanes of a wavefront by key (as k_s1_seg does on its sorted segments) saves few atomics
-      // and costs eight ballots per round; the LDS serialises same-address atomics by itself
-      if (ins) {
-        const uint32_t mult = 1u;
-        uint32_t h = hf >> (32 - LOGS);
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        if (!rin[u]) continue;
+        const uint32_t lk = local_key(rw0[u], rw1[u]), w2 = rw2[u];
+        // one compare-and-swap + add per record: inside a bucket the records are in read order, equal keys are rarely
+        // neighbours, so grouping the lanes of a wavefront by key (as k_s1_seg does on its sorted segments) saves few atomics
+        // and costs eight ballots per round; the LDS serialises same-address atomics by itself
+        uint32_t h = (lk * 0x9E3779B1u) >> (32 - LOGS);
         int probes = 0;
         const int probe_limit = a.la_chunks;  // (stream mode: the host passes the probe limit here; tests set it to 0)
         for (; probes < probe_limit; ++probes) {
           const uint32_t old = atomicCAS(&keys[h], kStreamEmpty, lk);
           if (old == kStreamEmpty || old == lk) {
-            atomicAdd(&cnts[h], mult);
+            atomicAdd(&cnts[h], 1u);
             if (old == kStreamEmpty) fpos[h] = w2;  // only read back when the count stays 1: then this record is the key's only one
             break;
           }
@@ -1312,6 +1403,15 @@ uint64_t s1_extract(mhx_ctx *c, uint32_t k, bool compact) {
         c->pre_hist_passes = specs.n;
       }
     }
+    const bool fast = fixed && compact && KWv == 2 && S == 3 && k <= 29 && c->opt("s1_extract_fast", 1) != 0;
+    if (fast) {
+      const unsigned fgrid = (unsigned)std::min<uint64_t>(div_ceil(n_items, 256), 256 * 16);
+      const uint32_t per = s.fixed_len - k + 4;
+      const uint64_t stride_items = (uint64_t)fgrid * 256;
+      MHX_LAUNCH(c, "s1_extract", (double)n_items * item_bytes + (double)s.n_bases / 4,
+                 hipLaunchKernelGGL(k_s1_extract_fast, dim3(fgrid), dim3(256), 0, st, s.words.as<uint32_t>(), s.fixed_len, per, n_items, (int)k,
+                                    pos_base, rank_tag, buf_a, specs, pre_hist, (uint32_t)(stride_items / per), (uint32_t)(stride_items % per)));
+    } else {
 #define MHX_S1X(SV, CP)                                                                                                      \
   do {                                                                                                                       \
     if (fixed) {                                                                                                             \
@@ -1334,6 +1434,7 @@ uint64_t s1_extract(mhx_ctx *c, uint32_t k, bool compact) {
       }
     });
 #undef MHX_S1X
+    }
   }
   return n_items;
 }
@@ -1350,9 +1451,12 @@ int s1_process(mhx_ctx *c, uint32_t k, uint32_t m, int want_mercy, uint32_t *buf
   const int kmer_bits = (int)(k - 1) * 2;
   // want_mercy == 2: records with equal keys in exactly the order the reference's kmsort leaves them (H1)
   S1Plan plan = s1_plan(c, k, n_items, compact, want_mercy);
+  // (records that carry their source rank between the (k-1)-mer and head/tail must not be ordered by whole key words)
+  const bool tagged_keys = compact && s1_rank_tagged(c, k);
   uint32_t *sorted = want_mercy == 2
                          ? kmsort_exact(c, buf_a, buf_b, n_items, S, KWv)
-                         : radix_sort(c, buf_a, buf_b, n_items, S, KWv, plan.passes);
+                         : (plan.seg_bits || tagged_keys ? radix_sort(c, buf_a, buf_b, n_items, S, KWv, plan.passes)
+                                                         : sort_whole_key(c, buf_a, buf_b, n_items, S, KWv, plan.passes));
   c->pre_hist_buf = nullptr;
   uint32_t *spare = sorted == buf_a ? buf_b : buf_a;
 
@@ -1463,10 +1567,19 @@ int s1_process(mhx_ctx *c, uint32_t k, uint32_t m, int want_mercy, uint32_t *buf
       uint32_t *ticket = c->ws("s1_stream_ticket", 64).as<uint32_t>();
       MHX_HIP(hipMemsetAsync(ticket, 0, 4, st));
       hipLaunchKernelGGL(k_bucket_bounds, dim3(MHX_NUM_BUCKETS / 256 + 1), dim3(256), 0, st, sorted, n_items, 3, bounds);
-      if (agg_on)
-        MHX_LAUNCH(c, nm, bytes, hipLaunchKernelGGL((k_s1_stream<true>), dim3(grid), dim3(kStreamThreads), 0, st, sorted, bounds, a, stride, ticket));
-      else
-        MHX_LAUNCH(c, nm, bytes, hipLaunchKernelGGL((k_s1_stream<false>), dim3(grid), dim3(kStreamThreads), 0, st, sorted, bounds, a, stride, ticket));
+      const int unr = (int)c->opt("s1_stream_unroll", 4);
+#define MHX_STREAM(AGGV, UV) \
+  MHX_LAUNCH(c, nm, bytes, hipLaunchKernelGGL((k_s1_stream<AGGV, UV>), dim3(grid), dim3(kStreamThreads), 0, st, sorted, bounds, a, stride, ticket))
+      if (agg_on) {
+        if (unr >= 4) MHX_STREAM(true, 4);
+        else if (unr >= 2) MHX_STREAM(true, 2);
+        else MHX_STREAM(true, 1);
+      } else {
+        if (unr >= 4) MHX_STREAM(false, 4);
+        else if (unr >= 2) MHX_STREAM(false, 2);
+        else MHX_STREAM(false, 1);
+      }
+#undef MHX_STREAM
       return;
     }
 #define MHX_SEG(PERV, AGGV) \
@@ -1561,7 +1674,7 @@ int s1_process(mhx_ctx *c, uint32_t k, uint32_t m, int want_mercy, uint32_t *buf
         MHX_HIP(hipMemcpyAsync(hist, hist_save, (MHX_MAX_MUL + 1) * 8, hipMemcpyDeviceToDevice, st));
         MHX_HIP(hipMemsetAsync(ctr, 0, 64, st));
         uint32_t *other = sorted == buf_a ? buf_b : buf_a;
-        sorted = radix_sort(c, sorted, other, n_items, S, KWv, s1_sort_passes(k));
+        sorted = tagged_keys ? radix_sort(c, sorted, other, n_items, S, KWv, s1_sort_passes(k)) : sort_whole_key(c, sorted, other, n_items, S, KWv, s1_sort_passes(k));
         spare = sorted == buf_a ? buf_b : buf_a;
         mercy = reinterpret_cast<long long *>(spare);
       }

@@ -641,7 +641,7 @@ uint64_t s2_extract(mhx_ctx *c, uint32_t k, uint32_t m) {
 int s2_process(mhx_ctx *c, uint32_t k, uint32_t *buf_a, uint32_t *buf_b, uint64_t n_items, mhx_sdbg_result *out) {
   const int KWv = s2_kw(k), S = round_up2(KWv);
   const int char_bits = (int)k * 2;
-  uint32_t *sorted = radix_sort(c, buf_a, buf_b, n_items, S, KWv, make_passes_ranges(KWv, {{0, 4}, {KWv * 32 - char_bits, KWv * 32}}));
+  uint32_t *sorted = sort_whole_key(c, buf_a, buf_b, n_items, S, KWv, make_passes_ranges(KWv, {{0, 4}, {KWv * 32 - char_bits, KWv * 32}}));
   emit_sdbg(c, sorted, n_items, S, KWv, k, 0, out);
   return 0;
 }
@@ -679,7 +679,8 @@ uint64_t s2_agg_extract(mhx_ctx *c, uint32_t k) {
 }
 // sort by k-mer chars, "full" flag and W (the count bits [0,16) ride along), then emit
 int s2_agg_process(mhx_ctx *c, uint32_t k, uint32_t *buf_a, uint32_t *buf_b, uint64_t n_items, mhx_sdbg_result *out) {
-  uint32_t *sorted = radix_sort(c, buf_a, buf_b, n_items, 2, 2, make_passes_ranges(2, {{16, 20}, {64 - 2 * (int)k, 64}}));
+  // (the whole-key order also orders equal keys by their count bits: the emission sums them, any order does)
+  uint32_t *sorted = sort_whole_key(c, buf_a, buf_b, n_items, 2, 2, make_passes_ranges(2, {{16, 20}, {64 - 2 * (int)k, 64}}));
   emit_sdbg(c, sorted, n_items, 2, 2, k, 2, out);
   return 0;
 }

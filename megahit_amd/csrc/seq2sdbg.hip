@@ -123,7 +123,8 @@ uint64_t seq2sdbg_extract(mhx_ctx *c, uint32_t k) {
 int seq2sdbg_process(mhx_ctx *c, uint32_t k, uint32_t *buf_a, uint32_t *buf_b, uint64_t n_items, mhx_sdbg_result *out) {
   const int KWv = seq2sdbg_kw(k), S = seq2sdbg_stride(k);
   const int char_bits = (int)k * 2;
-  uint32_t *sorted = radix_sort(c, buf_a, buf_b, n_items, S, KWv, make_passes_ranges(KWv, {{0, 20}, {KWv * 32 - char_bits, KWv * 32}}));
+  // whole-key order = chars, then flag/W/multiplicity (the bits between them are zero padding)
+  uint32_t *sorted = sort_whole_key(c, buf_a, buf_b, n_items, S, KWv, make_passes_ranges(KWv, {{0, 20}, {KWv * 32 - char_bits, KWv * 32}}));
   emit_sdbg(c, sorted, n_items, S, KWv, k, 1, out);
   return 0;
 }

@@ -91,3 +91,74 @@ def write_fasta(path, reads):
     with open(path, "w") as f:
         for i, r in enumerate(reads):
             f.write(">r%d\n%s\n" % (i, lut[np.asarray(r)].tobytes().decode()))
+
+
+def write_fasta_interleaved(path, blocks):
+    """blocks: uint8 [n, L] arrays (r1,r2,r1,r2,...) -> one interleaved FASTA, vectorised (headers all '>r')."""
+    lut = np.frombuffer(b"ACGT", dtype=np.uint8)
+    with open(path, "wb") as f:
+        for reads in blocks:
+            n, L = reads.shape
+            rec = np.empty((n, L + 4), dtype=np.uint8)
+            rec[:, 0] = ord(">")
+            rec[:, 1] = ord("r")
+            rec[:, 2] = ord("\n")
+            rec[:, 3:3 + L] = lut[reads]
+            rec[:, 3 + L] = ord("\n")
+            rec.tofile(f)
+
+
+def plant_repeats(genome, seed, n_families, min_len=25, max_len=140, max_copies=4):
+    """Exact repeats planted in place: family f = a random sequence of min_len..max_len bases written at 2..max_copies
+    random positions.  A repeat of length >= k forks the de Bruijn graph of order k and is resolved once k exceeds it, so
+    an iterative k-list (21 ... 119) has work to do at every step (a uniform random genome assembles completely at k=21:
+    the reference's orchestrator then stops after k=29)."""
+    rng = np.random.default_rng(seed)
+    G = genome.size
+    lens = rng.integers(min_len, max_len + 1, size=n_families)
+    copies = rng.integers(2, max_copies + 1, size=n_families)
+    for L, c in zip(lens, copies):
+        unit = rng.integers(0, 4, size=int(L), dtype=np.uint8)
+        for pos in rng.integers(0, G - int(L), size=int(c)):
+            genome[pos:pos + int(L)] = unit
+    return genome
+
+
+def gen_shard_library(n_reads, genome_seed, read_seed0, read_len=150, frag=400, err=0.005, repeat_families=0):
+    """The single-genome workload family of SURVEY.md section 8d (configs 2-4): genome of 2.5 bp per read (~60x), PE blocks
+    of 1 M pairs with seeds read_seed0 + i.  -> (genome, list of uint8 [n_i, read_len] blocks)."""
+    G = int(n_reads * 2.5)
+    genome = np.random.default_rng(genome_seed).integers(0, 4, size=G, dtype=np.uint8)
+    if repeat_families:
+        plant_repeats(genome, genome_seed + 7919, repeat_families)
+    blocks = []
+    for i, lo in enumerate(range(0, n_reads // 2, 1000000)):
+        c = min(1000000, n_reads // 2 - lo)
+        blocks.append(gen_pe_reads(c, G, read_len=read_len, frag=frag, err=err, seed=read_seed0 + i, genome=genome))
+    return genome, blocks
+
+
+def gen_metagenome_library(n_reads, n_genomes, genome_len=2500000, seed=3, sigma=1.0, read_len=150, frag=400, err=0.005):
+    """SURVEY.md section 8d config 5 ("high diversity"): `n_genomes` i.i.d. genomes of `genome_len` bases with log-normal
+    abundances (sigma), PE fragments never spanning two genomes.  Blocks of 1 M pairs (seeds 1000*seed + 1 + i)."""
+    rng = np.random.default_rng(seed)
+    genome = rng.integers(0, 4, size=n_genomes * genome_len, dtype=np.uint8)
+    ab = rng.lognormal(0.0, sigma, size=n_genomes)
+    cdf = np.cumsum(ab / ab.sum())
+    blocks = []
+    for i, lo in enumerate(range(0, n_reads // 2, 1000000)):
+        c = min(1000000, n_reads // 2 - lo)
+        r = np.random.default_rng(1000 * seed + 1 + i)
+        g = np.minimum(np.searchsorted(cdf, r.random(c)), n_genomes - 1)
+        start = g * genome_len + r.integers(0, genome_len - frag, size=c)
+        idx = np.arange(read_len)
+        r1 = genome[start[:, None] + idx[None, :]]
+        r2 = 3 - genome[(start + frag - 1)[:, None] - idx[None, :]]
+        reads = np.empty((2 * c, read_len), dtype=np.uint8)
+        reads[0::2] = r1
+        reads[1::2] = r2
+        mask = r.random(reads.shape) < err
+        delta = r.integers(1, 4, size=int(mask.sum()), dtype=np.uint8)
+        reads[mask] = (reads[mask] + delta) & 3
+        blocks.append(reads)
+    return blocks

@@ -3,7 +3,7 @@
    1-pass            read2sdbg                      (--kmin-1pass without mercy)
    1-pass + mercy    read2sdbg --need_mercy         (reference-exact tie order)
    2-pass            count, then seq2sdbg --need_mercy   (the orchestrator's default, src/megahit:939-966)
-   python tools/e2e_routes.py > profiles/r02_e2e_routes.json"""
+   python tools/e2e_routes.py > profiles/r03_e2e_routes.json"""
 import json
 import os
 import re
@@ -23,10 +23,7 @@ MHX = os.path.join(ROOT, "megahit_amd", "mhx_core")
 
 def run(args):
     best = None
-    for _ in range(2):
-        # the driver reclaims a process's VRAM after its exit (tens of GB: seconds); a process that starts meanwhile waits in
-        # hipMalloc (measured: stage 1 of the mercy route 0.8 s on a quiet GPU, 1.8-3.4 s back to back) — let it finish
-        time.sleep(3.0)
+    for _ in range(2):  # back to back, no pauses: mhx_core gives its device memory back before it returns
         t0 = time.perf_counter()
         p = subprocess.run([MHX] + args, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True)
         dt = time.perf_counter() - t0

@@ -32,6 +32,41 @@ def gen_library(prefix, n_reads):
     synth.write_read_lib(prefix, blocks)
 
 
+META = {"reads": 40000000, "genomes": 160, "genome_len": 2500000, "seed": 3, "k": 27, "m": 1}
+
+
+def gen_meta_library(prefix, n_reads=META["reads"]):
+    """BASELINE configs[4] ("500 M x 150 bp high-diversity metagenome, meta-large preset: k=27, -m 1") at single-GPU-shard
+    size: 40 M reads, and 160 of the config's 2 000 genomes (2.5 Mbp each, log-normal abundances, sigma 1) so that the
+    shard keeps the config's ~15x coverage — what one GPU of eight sees of its own lv1 buckets after the exchange."""
+    blocks = synth.gen_metagenome_library(n_reads, META["genomes"] * n_reads // META["reads"] or 1, META["genome_len"], seed=META["seed"])
+    synth.write_read_lib(prefix, blocks)
+
+
+def meta_golden(args):
+    """tests/golden/fullsize_meta.json: the reference's read2sdbg -k 27 -m 1 (stage 1 skipped, main_sdbg_build.cpp:139-147)"""
+    n = int(args.reads) // 2 * 2 if args.reads != 1e7 else META["reads"]
+    ref = os.path.join(ROOT, "oracle", "_ref", "ref_core")
+    d = args.keep or tempfile.mkdtemp(prefix="mhx_meta_")
+    os.makedirs(d, exist_ok=True)
+    lib = os.path.join(d, "reads")
+    if not os.path.exists(lib + ".bin"):
+        gen_meta_library(lib, n)
+    k, m = META["k"], META["m"]
+    out = {"reads": n, "k": k, "m": m, "edges": n * (150 - k), "genomes": META["genomes"] * n // META["reads"] or 1, "generator": "tools/make_fullsize_golden.py --preset meta",
+           "reference_threads": args.threads, "lib_bin_md5": canon.digest_file(lib + ".bin"), "cases": {}}
+    dt, _ = run([ref, "read2sdbg", "-k", str(k), "-m", str(m), "--host_mem", "%g" % args.host_mem, "--num_cpu_threads", str(args.threads),
+                 "--read_lib_file", lib, "--output_prefix", os.path.join(d, "r2s")])
+    c = sdbg_summary(os.path.join(d, "r2s"))
+    c["wall_s"] = round(dt, 1)
+    out["cases"]["read2sdbg"] = c
+    print("read2sdbg -k %d -m %d" % (k, m), c, flush=True)
+    path = args.out if args.out.endswith("_meta.json") else os.path.join(ROOT, "tests", "golden", "fullsize_meta.json")
+    with open(path, "w") as f:
+        json.dump(out, f, indent=1)
+    print("wrote", path)
+
+
 def run(cmd):
     t0 = time.perf_counter()
     p = subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True)
@@ -56,7 +91,11 @@ def main():
     ap.add_argument("--threads", type=int, default=8)
     ap.add_argument("--keep", default=None, help="work directory to keep (default: a temp dir)")
     ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden", "fullsize.json"))
+    ap.add_argument("--preset", choices=["configs1", "meta"], default="configs1")
+    ap.add_argument("--host_mem", type=float, default=48e9)
     args = ap.parse_args()
+    if args.preset == "meta":
+        return meta_golden(args)
     n = int(args.reads) // 2 * 2
     k, m = 21, 2
     ref = os.path.join(ROOT, "oracle", "_ref", "ref_core")
