@@ -233,7 +233,16 @@ void maybe_pretend_scan_timeout() {
     const int n = mhx_profile_get(c, ks.data(), (int)ks.size());
     ks.resize(n < 0 ? 0 : std::min<size_t>((size_t)n, ks.size()));
     std::sort(ks.begin(), ks.end(), [](const mhx_kernel_stat &a, const mhx_kernel_stat &b) { return a.total_ms > b.total_ms; });
-    for (const mhx_kernel_stat &s : ks) info("profile %-24s %6u launches %12.3f ms", s.name, s.launches, s.total_ms);
+    for (const mhx_kernel_stat &s : ks) info("profile %-24s %6u launches %12.3f ms %14.0f algorithmic bytes", s.name, s.launches, s.total_ms, s.algo_bytes);
+    if (const char *path = getenv("MHX_PROFILE_JSON")) {  // the same, machine-readable (tools/config_bench.py)
+      if (FILE *f = fopen(path, "w")) {
+        fprintf(f, "{\"kernels\": {");
+        for (size_t i = 0; i < ks.size(); ++i)
+          fprintf(f, "%s\"%s\": {\"launches\": %u, \"ms\": %.4f, \"bytes\": %.0f}", i ? ", " : "", ks[i].name, ks[i].launches, ks[i].total_ms, ks[i].algo_bytes);
+        fprintf(f, "}}\n");
+        fclose(f);
+      }
+    }
   }
   // Default: give the device memory back HERE, synchronously (hipFree of every buffer), before the caller is told that we
   // are done.  Leaving it to process exit is faster for this call (MHX_EARLY_EXIT=1: the front process returns while the

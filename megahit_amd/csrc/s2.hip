@@ -686,8 +686,45 @@ int s2_agg_process(mhx_ctx *c, uint32_t k, uint32_t *buf_a, uint32_t *buf_b, uin
 }
 bool s2_use_aggregated(const mhx_ctx *c, uint32_t k, uint32_t m) { return c->agg_valid && c->agg_k == k && c->agg_m == m && m > 1; }
 
+// Single GPU, everything resident: the aggregated items are sorted where stage 1 left them (ws "s2_agg_items", the dummies
+// appended behind them) instead of being copied into "items_a" first — 0.94 GB read + written per step at 10 M reads.  The
+// sort consumes them: a second stage 2 without a new stage 1 takes the per-occurrence path (same records).
+static int s2_agg_in_place(mhx_ctx *c, uint32_t k, mhx_sdbg_result *out) {
+  SeqSet &s = c->seqs;
+  hipStream_t st = c->stream;
+  const uint64_t n_agg = c->agg_n;
+  auto it = c->results.find(MHX_BUF_IS_SOLID);
+  if (it == c->results.end() || it->second.used < div_ceil(s.n_bases, 64) * 8) throw Error("read2sdbg_s2: no is_solid bitmap");
+  const unsigned long long *solid = it->second.as<unsigned long long>();
+  const uint64_t n_words = div_ceil(s.n_bases, 64);
+  unsigned long long *cur = c->ws("s2d_cursor", 64).as<unsigned long long>();
+  MHX_HIP(hipMemsetAsync(cur, 0, 16, st));
+  uint64_t bound = 0;
+  if (n_words) {
+    MHX_LAUNCH(c, "s2_bound", (double)n_words * 8,
+               hipLaunchKernelGGL(k_s2d_bound, dim3((unsigned)div_ceil(n_words, 256)), dim3(256), 0, st, solid, n_words, cur + 1));
+    MHX_HIP(hipMemcpyAsync(&bound, cur + 1, 8, hipMemcpyDeviceToHost, st));
+    MHX_HIP(hipStreamSynchronize(st));
+  }
+  uint32_t *buf_a = grow_preserving(c, c->work["s2_agg_items"], (n_agg + bound) * 8 + 64, n_agg * 8).as<uint32_t>();
+  uint64_t n_dummy = 0;
+  if (bound) {
+    MHX_LAUNCH(c, "s2_extract", (double)bound * 8 + (double)n_words * 8,
+               hipLaunchKernelGGL(k_s2d_emit, dim3((unsigned)div_ceil(n_words, 256)), dim3(256), 0, st, s.words.as<uint32_t>(),
+                                  s.start.as<uint64_t>(), s.n_seqs, s.fixed_len, (int)k, solid, n_words, reinterpret_cast<uint2 *>(buf_a) + n_agg, cur));
+    MHX_HIP(hipMemcpyAsync(&n_dummy, cur, 8, hipMemcpyDeviceToHost, st));
+    MHX_HIP(hipStreamSynchronize(st));
+  }
+  const uint64_t n_items = n_agg + n_dummy;
+  uint32_t *buf_b = c->ws("items_b", n_items * 8 + 64).as<uint32_t>();
+  c->agg_valid = false;
+  return s2_agg_process(c, k, buf_a, buf_b, n_items, out);
+}
+
 int run_s2(mhx_ctx *c, uint32_t k, uint32_t m, mhx_sdbg_result *out) {
   if (c->global_bases) throw Error("read2sdbg_s2: a global layout is set; use the mhx_dist_* entry points");
+  if (!c->filter_on && !c->accumulate && c->n_parts <= 1 && s2_use_aggregated(c, k, m) && c->opt("s2_agg_in_place", 1))
+    return s2_agg_in_place(c, k, out);
   const StageItems it = extract_stage(c, MHX_STAGE_S2, k, m);
   uint32_t *buf_a = c->work["items_a"].as<uint32_t>();
   uint32_t *buf_b = c->ws("items_b", it.n * (size_t)it.S * 4 + 64).as<uint32_t>();

@@ -28,6 +28,12 @@ KLIST = [21, 29, 39, 59, 79, 99, 119]
 REPEAT_FAMILIES = 8000  # exact repeats of 25..140 bp planted in the genome (synth.plant_repeats): work for every k of the list
 
 
+def sdbg_summary(prefix):
+    _hdr, rows = canon.read_sdbg_info(prefix)
+    live = [r for r in rows if r[0] != canon.NULL_ID]
+    return {"digest": canon.digest_sdbg(prefix), "n_sdbg": sum(r[3] for r in live), "n_tips": sum(r[4] for r in live), "n_large": sum(r[5] for r in live)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reads", type=float, default=12.5e6)
@@ -58,6 +64,14 @@ def main():
     doc = {"reads": n, "klist": KLIST, "generator": "tools/make_klist_golden.py", "genome_seed": 2, "read_seed0": 2001, "repeat_families": REPEAT_FAMILIES,
            "reference_threads": args.threads, "cases": {}}
     shutil.rmtree(args.pack, ignore_errors=True)
+    # k = 21: count + seq2sdbg --need_mercy on the read library itself (regenerated on the GPU box: only digests travel)
+    k21 = os.path.join(out, "tmp", "k21", "21")
+    hdr, _rows = canon.read_edges_info(k21)
+    doc["lib_bin_md5"] = canon.digest_file(os.path.join(out, "tmp", "reads.lib.bin"))
+    doc["k21"] = {"count": {"digest": canon.digest_edges(k21), "n_edges": hdr["num_edges"], "counting_md5": canon.digest_file(k21 + ".counting"),
+                            "cand_md5": canon.digest_file(k21 + ".cand")},
+                  "seq2sdbg_need_mercy": sdbg_summary(k21)}
+    print("k=21", doc["k21"], flush=True)
     for k in KLIST[1:]:
         m = re.search(r"command \S+ (seq2sdbg .*? -k %d .*)" % k, log)
         assert m, "no seq2sdbg command for k=%d in the log" % k
@@ -88,20 +102,18 @@ def main():
                 i += 2
             elif a in ("--output_prefix", "--host_mem", "--num_cpu_threads", "--mem_flag"):
                 i += 2
-            else:
+            elif a in ("seq2sdbg", "--need_mercy"):
                 packed_args.append(a)
-                i += 1 if a in ("seq2sdbg", "--need_mercy") else 0
-                if a not in ("seq2sdbg", "--need_mercy"):
-                    packed_args.append(argv[i + 1])
-                    i += 2
+                i += 1
+            else:  # -k, --kmer_from
+                packed_args += [a, argv[i + 1]]
+                i += 2
         prefix = os.path.join(out, "tmp", "k%d" % k, str(k))
-        hdr, rows = canon.read_sdbg_info(prefix)
-        live = [r for r in rows if r[0] != canon.NULL_ID]
-        t = re.search(r"seq2sdbg .*? -k %d .*?\n(?:.*\n)*?.*Real: ([0-9.]+)" % k, log)
-        doc["cases"]["k%d" % k] = {"args": packed_args, "digest": canon.digest_sdbg(prefix), "n_sdbg": sum(r[3] for r in live),
-                                   "n_tips": sum(r[4] for r in live), "n_large": sum(r[5] for r in live),
-                                   "reference_real_s": float(t.group(1)) if t else None,
-                                   "packed_bytes": sum(os.path.getsize(os.path.join(d, f)) for f in os.listdir(d))}
+        t = re.search(r"Real: ([0-9.]+)", log[m.end():])  # the Real: line of this very run (utils.h:152)
+        c = sdbg_summary(prefix)
+        c.update(args=packed_args, reference_real_s=float(t.group(1)) if t else None,
+                 packed_bytes=sum(os.path.getsize(os.path.join(d, f)) for f in os.listdir(d)))
+        doc["cases"]["k%d" % k] = c
         print("k=%d" % k, doc["cases"]["k%d" % k], flush=True)
     with open(args.out, "w") as f:
         json.dump(doc, f, indent=1)
