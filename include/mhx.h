@@ -365,6 +365,9 @@ typedef struct {
   double total_ms;     /* HIP-event time on the engine's stream */
   double algo_bytes;   /* algorithmic bytes moved by those launches */
 } mhx_kernel_stat;
+/* host seconds this process spent in hipMalloc / hipFree for libmhx's device buffers, bytes and calls of hipMalloc
+   (process-wide; any pointer may be NULL).  A process started right behind another GPU process waits there. */
+void mhx_alloc_stats(double *malloc_s, double *free_s, uint64_t *bytes, uint64_t *calls);
 int mhx_profile_enable(mhx_ctx *, int on);
 int mhx_profile_reset(mhx_ctx *);
 /* returns number of distinct kernels; fills up to cap entries */

@@ -1,5 +1,7 @@
 // C-ABI entry points of libmhx.so (declared in include/mhx.h) and context plumbing.
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <thread>
 #include <cstdarg>
 #include <cstdlib>
@@ -18,19 +20,32 @@ void set_error(const char *fmt, ...) {
   va_end(ap);
 }
 
+// host time spent inside hipMalloc / hipFree by this process (mhx_alloc_stats): a process that starts while the driver
+// still reclaims the device memory of its predecessor waits HERE, not in its kernels
+static std::atomic<uint64_t> g_alloc_ns{0}, g_alloc_bytes{0}, g_alloc_calls{0}, g_free_ns{0};
+static uint64_t now_ns() { return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
 void DevBuf::reserve(size_t bytes) {
   if (bytes == 0) bytes = 16;
   if (cap >= bytes && p) return;
-  if (p && cap) (void)hipFree(p);
+  if (p && cap) {
+    const uint64_t t0 = now_ns();
+    (void)hipFree(p);
+    g_free_ns += now_ns() - t0;
+  }
   p = nullptr;
   cap = 0;
   // grow with a little headroom so that repeated calls with slightly different sizes do not re-allocate
   size_t want = bytes + bytes / 16 + 256;
+  const uint64_t t0 = now_ns();
   hipError_t e = hipMalloc(&p, want);
   if (e != hipSuccess) {
     want = bytes;
     e = hipMalloc(&p, want);
   }
+  g_alloc_ns += now_ns() - t0;
+  g_alloc_calls += 1;
+  if (e == hipSuccess) g_alloc_bytes += want;
   if (e != hipSuccess) {
     p = nullptr;
     char b[256];
@@ -40,7 +55,11 @@ void DevBuf::reserve(size_t bytes) {
   cap = want;
 }
 void DevBuf::release() {
-  if (p && cap) (void)hipFree(p);
+  if (p && cap) {
+    const uint64_t t0 = now_ns();
+    (void)hipFree(p);
+    g_free_ns += now_ns() - t0;
+  }
   p = nullptr;
   cap = used = 0;
 }
@@ -886,6 +905,13 @@ int mhx_adopt_is_solid_slice(mhx_ctx *c, const void *d_words, uint64_t n_words) 
     if (c->global_marks_inverted) mhx::invert_local_marks(c, b.as<unsigned long long>(), need);
     MHX_HIP(hipStreamSynchronize(c->stream));
   })
+}
+
+void mhx_alloc_stats(double *malloc_s, double *free_s, uint64_t *bytes, uint64_t *calls) {
+  if (malloc_s) *malloc_s = (double)mhx::g_alloc_ns.load() * 1e-9;
+  if (free_s) *free_s = (double)mhx::g_free_ns.load() * 1e-9;
+  if (bytes) *bytes = mhx::g_alloc_bytes.load();
+  if (calls) *calls = mhx::g_alloc_calls.load();
 }
 
 uint64_t mhx_device_free_bytes(mhx_ctx *c) {

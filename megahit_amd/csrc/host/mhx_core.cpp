@@ -250,6 +250,12 @@ void maybe_pretend_scan_timeout() {
   // that is busy unmapping: its hipMalloc calls wait and hipMemGetInfo under-reports (the reference's orchestrator runs
   // count -> seq2sdbg -> assemble -> iterate -> seq2sdbg back to back).
   if (!getenv("MHX_EARLY_EXIT") || getenv("MHX_CLEAN_EXIT")) mhx_destroy(c);
+  {
+    double ms = 0, fs = 0;
+    uint64_t bytes = 0, calls = 0;
+    mhx_alloc_stats(&ms, &fs, &bytes, &calls);
+    info("Device memory: %llu allocations, %.2f GB, %.4f s in hipMalloc, %.4f s in hipFree", (unsigned long long)calls, (double)bytes / 1e9, ms, fs);
+  }
   fflush(nullptr);
   if (g_done_fd >= 0) {
     // Everything the caller waits for exists and is closed: tell the front process.  The standard streams are closed so

@@ -175,63 +175,86 @@ __device__ __forceinline__ uint64_t rc64(uint64_t x, int n);
 //   * read index and slot advance incrementally with the persistent loop (the per-iteration stride of the workgroup,
 //     divided by the items per read, comes from the host), the only division left is a 32-bit one.
 // Same output, bit for bit, as k_s1_extract_fixed<2, 3, true> (read_to_sdbg_s1.cpp:228-292, :344-363).
+constexpr int kFastPasses = 4;
+template <int IT>  // items per thread and trip: their window loads are issued together (one in flight per thread = latency-bound)
 __global__ __launch_bounds__(256) void k_s1_extract_fast(const uint32_t *__restrict__ seq, uint32_t L, uint32_t per, uint64_t n_items, int k,
                                                          uint64_t pos_base, uint32_t rank_tag, uint32_t *__restrict__ items, DigitSpecs specs,
                                                          unsigned long long *__restrict__ ghist, uint32_t step_q, uint32_t step_r) {
-  __shared__ uint32_t xpose[256 * 3];
-  __shared__ uint32_t h[kMaxFusedPasses][256];
-  for (int i = threadIdx.x; i < specs.n * 256; i += 256) (&h[0][0])[i] = 0;
+  constexpr int B = 256 * IT;  // items per workgroup and trip
+  __shared__ uint32_t xpose[B * 3];
+  // digit histograms of the coming sort passes (at most kFastPasses of them here), one copy per wavefront: the lanes of
+  // different wavefronts never queue up behind each other at a hot digit
+  __shared__ uint32_t h[kFastPasses][4][256];
+  for (int i = threadIdx.x; i < kFastPasses * 4 * 256; i += 256) (&h[0][0][0])[i] = 0;
   __syncthreads();
-  const uint64_t n_blocks = (n_items + 255) / 256;
+  const int wv = threadIdx.x >> 6;
+  const uint64_t n_blocks = (n_items + B - 1) / B;
   const int km1 = k - 1;
   const uint64_t kmask = ~0ull << (64 - 2 * km1);
-  // (read, first slot) of this workgroup's current block of 256 items
-  uint64_t q0 = ((uint32_t)blockIdx.x * 256u) / per;
-  uint32_t rem0 = ((uint32_t)blockIdx.x * 256u) % per;
+  // (read, first slot) of this workgroup's current block of B items
+  uint64_t q0 = ((uint32_t)blockIdx.x * (uint32_t)B) / per;
+  uint32_t rem0 = ((uint32_t)blockIdx.x * (uint32_t)B) % per;
   for (uint64_t blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
-    const uint64_t g = blk * 256 + threadIdx.x;
-    uint32_t out[3];
-    if (g < n_items) {
-      const uint32_t t = rem0 + threadIdx.x, dq = t / per, j = t - dq * per;
+    uint32_t x0[IT], x1[IT], x2[IT], jj[IT], qq[IT];
+    uint64_t aa[IT], stt[IT];
+    bool ok[IT], win_ok[IT];
+#pragma unroll
+    for (int u = 0; u < IT; ++u) {
+      const uint64_t g = blk * B + (uint64_t)u * 256 + threadIdx.x;
+      ok[u] = g < n_items;
+      const uint32_t t = rem0 + (uint32_t)u * 256u + threadIdx.x, dq = t / per, j = t - dq * per;
       const uint64_t st = (q0 + dq) * L;
       uint32_t q;
-      int forced = -1;
-      if (j < 2) { q = 0; forced = (int)j; }
-      else if (j >= L - k + 2) { q = L - k + 1; forced = (int)(j - (L - k + 2)); }
+      if (j < 2) q = 0;
+      else if (j >= L - k + 2) q = L - k + 1;
       else q = j - 1;
       const uint64_t a = st + q;
-      if (a >= 2) {
-        const uint64_t b = a - 2;  // window: bases [a-2, a+30)
-        const uint64_t w = b >> 4;
-        const unsigned sh = (unsigned)(b & 15) * 2;
-        const uint32_t x0 = seq[w], x1 = seq[w + 1], x2 = seq[w + 2];
-        const uint64_t win = ((uint64_t)funnel_l(x0, x1, sh) << 32) | funnel_l(x1, x2, sh);
-        const unsigned prev_b = (unsigned)(win >> 62), head_b = (unsigned)(win >> 60) & 3u;
-        const unsigned tail_b = (unsigned)(win >> (58 - 2 * km1)) & 3u, next_b = (unsigned)(win >> (56 - 2 * km1)) & 3u;
-        const uint64_t f = (win << 4) & kmask;
-        const uint64_t rc = rc64(f, km1);
-        const unsigned head = q >= 1 ? head_b : kSentinel, prev = q >= 2 ? prev_b : kSentinel;
-        const unsigned tail = q + k - 1 < L ? tail_b : kSentinel, next = q + k < L ? next_b : kSentinel;
-        (void)prev;
-        (void)next;  // compact records carry no prev/next
-        int strand;
-        if (forced >= 0) strand = forced;
-        else strand = f > rc ? 1 : (f < rc ? 0 : (head <= 3 - tail ? 0 : 1));
-        const uint64_t key = strand ? (rc | (comp_or_sentinel(tail) << 3) | comp_or_sentinel(head)) : (f | (head << 3) | tail);
-        out[0] = (uint32_t)(key >> 32);
-        out[1] = (uint32_t)key | rank_tag;
-        out[2] = (uint32_t)(pos_base + a);
-      } else {  // the first two bases of the store: no window in front of them
-        s1_make_item<2, 3, true>(seq, st, L, k, j, pos_base, rank_tag, out);
-      }
-      for (int p = 0; p < specs.n; ++p) atomicAdd(&h[p][words_digit2<3>(out, specs.d[p])], 1u);
+      win_ok[u] = ok[u] && a >= 2;
+      const uint64_t b = win_ok[u] ? a - 2 : 0;  // window: bases [a-2, a+30); clamped to the store's start when there is none
+      const uint64_t w = b >> 4;
+      x0[u] = seq[w];
+      x1[u] = seq[w + 1];
+      x2[u] = seq[w + 2];
+      jj[u] = j;
+      qq[u] = q;
+      aa[u] = a;
+      stt[u] = st;
     }
 #pragma unroll
-    for (int i = 0; i < 3; ++i) xpose[threadIdx.x * 3 + i] = out[i];
-    __syncthreads();
-    const uint64_t w0 = blk * 768, n_words = n_items * 3;
+    for (int u = 0; u < IT; ++u) {
+      uint32_t out[3] = {0, 0, 0};
+      if (ok[u]) {
+        const uint32_t j = jj[u], q = qq[u];
+        int forced = -1;
+        if (j < 2) forced = (int)j;
+        else if (j >= L - k + 2) forced = (int)(j - (L - k + 2));
+        if (win_ok[u]) {
+          const unsigned sh = (unsigned)((aa[u] - 2) & 15) * 2;
+          const uint64_t win = ((uint64_t)funnel_l(x0[u], x1[u], sh) << 32) | funnel_l(x1[u], x2[u], sh);
+          const unsigned head_b = (unsigned)(win >> 60) & 3u, tail_b = (unsigned)(win >> (58 - 2 * km1)) & 3u;
+          const uint64_t f = (win << 4) & kmask;
+          const uint64_t rc = rc64(f, km1);
+          const unsigned head = q >= 1 ? head_b : kSentinel;
+          const unsigned tail = q + k - 1 < L ? tail_b : kSentinel;
+          int strand;
+          if (forced >= 0) strand = forced;
+          else strand = f > rc ? 1 : (f < rc ? 0 : (head <= 3 - tail ? 0 : 1));
+          const uint64_t key = strand ? (rc | (comp_or_sentinel(tail) << 3) | comp_or_sentinel(head)) : (f | (head << 3) | tail);
+          out[0] = (uint32_t)(key >> 32);
+          out[1] = (uint32_t)key | rank_tag;
+          out[2] = (uint32_t)(pos_base + aa[u]);
+        } else {  // the first two bases of the store: no window in front of them
+          s1_make_item<2, 3, true>(seq, stt[u], L, k, j, pos_base, rank_tag, out);
+        }
+        for (int p = 0; p < specs.n; ++p) atomicAdd(&h[p][wv][words_digit2<3>(out, specs.d[p])], 1u);
+      }
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
+      for (int i = 0; i < 3; ++i) xpose[(u * 256 + threadIdx.x) * 3 + i] = out[i];
+    }
+    __syncthreads();
+    const uint64_t w0 = blk * (uint64_t)(B * 3), n_words = n_items * 3;
+#pragma unroll
+    for (int i = 0; i < 3 * IT; ++i) {
       const uint64_t w = w0 + (uint64_t)i * 256 + threadIdx.x;
       if (w < n_words) items[w] = xpose[i * 256 + threadIdx.x];
     }
@@ -244,7 +267,7 @@ __global__ __launch_bounds__(256) void k_s1_extract_fast(const uint32_t *__restr
     }
   }
   for (int p = 0; p < specs.n; ++p) {
-    const uint32_t v = h[p][threadIdx.x];
+    const uint32_t v = h[p][0][threadIdx.x] + h[p][1][threadIdx.x] + h[p][2][threadIdx.x] + h[p][3][threadIdx.x];
     if (v) atomicAdd(&ghist[p * 256 + threadIdx.x], (unsigned long long)v);
   }
 }
@@ -911,10 +934,12 @@ __global__ __launch_bounds__(kStreamThreads) void k_s1_stream(const uint32_t *__
   unsigned long long st_solid = 0, st_both = 0;
 
   for (;;) {
+    MHX_TT_BEGIN
     if (tid == 0) s_bucket = atomicAdd(ticket, 1u);
     __syncthreads();
     const uint32_t bi = s_bucket * bucket_stride;
     if (bi >= MHX_NUM_BUCKETS) break;
+    MHX_TT(10)
     const uint64_t lo = bounds[bi], hi = bounds[bi + 1];
     if (lo == hi) {
       __syncthreads();
@@ -943,7 +968,8 @@ __global__ __launch_bounds__(kStreamThreads) void k_s1_stream(const uint32_t *__
         const uint32_t lk = local_key(rw0[u], rw1[u]), w2 = rw2[u];
         // one compare-and-swap + add per record: inside a bucket the records are in read order, equal keys are rarely
         // neighbours, so grouping the lanes of a wavefront by key (as k_s1_seg does on its sorted segments) saves few atomics
-        // and costs eight ballots per round; the LDS serialises same-address atomics by itself
+        // and costs eight ballots per round; the LDS serialises same-address atomics by itself.  (Issuing the UNR first
+        // probes back to back before looking at any result measured slower: 8.9 vs 7.1 ms.)
         uint32_t h = (lk * 0x9E3779B1u) >> (32 - LOGS);
         int probes = 0;
         const int probe_limit = a.la_chunks;  // (stream mode: the host passes the probe limit here; tests set it to 0)
@@ -960,6 +986,7 @@ __global__ __launch_bounds__(kStreamThreads) void k_s1_stream(const uint32_t *__
       }
     }
     __syncthreads();
+    MHX_TT(11)
     const bool bad = s_bad != 0;
     uint32_t my_agg = 0;
     if (!bad) {
@@ -1022,6 +1049,7 @@ __global__ __launch_bounds__(kStreamThreads) void k_s1_stream(const uint32_t *__
         }
       }
     }
+    MHX_TT(12)
     uint32_t agg_at = 0;
     bool agg_ok = true;
     if constexpr (AGG) {
@@ -1035,6 +1063,7 @@ __global__ __launch_bounds__(kStreamThreads) void k_s1_stream(const uint32_t *__
       agg_at = wbase + incl - my_agg;
     }
     __syncthreads();  // every count has been read: emit, then recycle the slots
+    MHX_TT(13)
     for (int sl = tid; sl < NSLOT; sl += NT) {
       const uint32_t lk = keys[sl];
       if (lk == kStreamEmpty) continue;
@@ -1062,6 +1091,7 @@ __global__ __launch_bounds__(kStreamThreads) void k_s1_stream(const uint32_t *__
       s_bad = 0;
     }
     __syncthreads();
+    MHX_TT(14)
   }
   if (a.mark_mode == 2) {
     st_solid = wave_sum(st_solid);
@@ -1403,14 +1433,23 @@ uint64_t s1_extract(mhx_ctx *c, uint32_t k, bool compact) {
         c->pre_hist_passes = specs.n;
       }
     }
-    const bool fast = fixed && compact && KWv == 2 && S == 3 && k <= 29 && c->opt("s1_extract_fast", 1) != 0;
+    const bool fast = fixed && compact && KWv == 2 && S == 3 && k <= 29 && specs.n <= kFastPasses && c->opt("s1_extract_fast", 1) != 0;
     if (fast) {
-      const unsigned fgrid = (unsigned)std::min<uint64_t>(div_ceil(n_items, 256), 256 * 16);
+      const int it = (int)c->opt("s1_extract_items", 4);
       const uint32_t per = s.fixed_len - k + 4;
-      const uint64_t stride_items = (uint64_t)fgrid * 256;
-      MHX_LAUNCH(c, "s1_extract", (double)n_items * item_bytes + (double)s.n_bases / 4,
-                 hipLaunchKernelGGL(k_s1_extract_fast, dim3(fgrid), dim3(256), 0, st, s.words.as<uint32_t>(), s.fixed_len, per, n_items, (int)k,
-                                    pos_base, rank_tag, buf_a, specs, pre_hist, (uint32_t)(stride_items / per), (uint32_t)(stride_items % per)));
+#define MHX_FAST(ITV)                                                                                                                  \
+  do {                                                                                                                                 \
+    const unsigned fgrid = (unsigned)std::min<uint64_t>(div_ceil(n_items, 256 * ITV), 256 * 8);                                        \
+    const uint64_t stride_items = (uint64_t)fgrid * 256 * ITV;                                                                         \
+    MHX_LAUNCH(c, "s1_extract", (double)n_items * item_bytes + (double)s.n_bases / 4,                                                  \
+               hipLaunchKernelGGL((k_s1_extract_fast<ITV>), dim3(fgrid), dim3(256), 0, st, s.words.as<uint32_t>(), s.fixed_len, per, n_items, \
+                                  (int)k, pos_base, rank_tag, buf_a, specs, pre_hist, (uint32_t)(stride_items / per), (uint32_t)(stride_items % per))); \
+  } while (0)
+      if (it >= 8) MHX_FAST(8);
+      else if (it >= 4) MHX_FAST(4);
+      else if (it >= 2) MHX_FAST(2);
+      else MHX_FAST(1);
+#undef MHX_FAST
     } else {
 #define MHX_S1X(SV, CP)                                                                                                      \
   do {                                                                                                                       \
@@ -1567,15 +1606,17 @@ int s1_process(mhx_ctx *c, uint32_t k, uint32_t m, int want_mercy, uint32_t *buf
       uint32_t *ticket = c->ws("s1_stream_ticket", 64).as<uint32_t>();
       MHX_HIP(hipMemsetAsync(ticket, 0, 4, st));
       hipLaunchKernelGGL(k_bucket_bounds, dim3(MHX_NUM_BUCKETS / 256 + 1), dim3(256), 0, st, sorted, n_items, 3, bounds);
-      const int unr = (int)c->opt("s1_stream_unroll", 4);
+      const int unr = (int)c->opt("s1_stream_unroll", 4);  // 8: measured no better than 4
 #define MHX_STREAM(AGGV, UV) \
   MHX_LAUNCH(c, nm, bytes, hipLaunchKernelGGL((k_s1_stream<AGGV, UV>), dim3(grid), dim3(kStreamThreads), 0, st, sorted, bounds, a, stride, ticket))
       if (agg_on) {
-        if (unr >= 4) MHX_STREAM(true, 4);
+        if (unr >= 8) MHX_STREAM(true, 8);
+        else if (unr >= 4) MHX_STREAM(true, 4);
         else if (unr >= 2) MHX_STREAM(true, 2);
         else MHX_STREAM(true, 1);
       } else {
-        if (unr >= 4) MHX_STREAM(false, 4);
+        if (unr >= 8) MHX_STREAM(false, 8);
+        else if (unr >= 4) MHX_STREAM(false, 4);
         else if (unr >= 2) MHX_STREAM(false, 2);
         else MHX_STREAM(false, 1);
       }

@@ -695,144 +695,81 @@ static uint32_t *radix_sort_impl(mhx_ctx *c, uint32_t *a, uint32_t *b, uint64_t 
 }
 
 // ---------------------------------------------------------------------------
-// Prefix sort + segment finish (kmlib::kmsort's job on wide keys without one pass per key byte, reference
+// Prefix sort + segment finish (kmlib::kmsort's job on wide keys without one pass per key byte; the reference's
 // src/sorting/kmsort_selector.cpp:39-63 treats every width alike: n_bytes = 4*NWords - 2 radix levels).
 // The LSD passes above cost 2 x record bytes of HBM traffic per 8 key bits: 33 passes over 40-byte records at k = 119.
 // But after passes over only the top `pbits` bits of key word 0, every maximal stretch of equal prefix — a SEGMENT —
-// already sits at its final place as a whole, and holds a handful of records when 2^pbits ~ n/4.  One more kernel
-// finishes the job in LDS: a workgroup stages a tile (+ look-ahead), every record counts, walking outwards from its own
-// place until the prefix changes, the records of its segment that precede it in (whole key, input order) — its rank —
-// and the tile is written back permuted.  Stable.  A segment belongs to the tile holding its first record; one that
-// outgrows the look-ahead raises *err and the host sorts all bits with LSD passes instead (same result).
+// already sits at its final place as a whole, and holds a handful of records when 2^pbits ~ n/10.  One more kernel
+// finishes the job: one thread per record walks outwards from its own place until the prefix changes and counts the
+// records of its segment that precede it in (whole key, input order) — its rank — then writes the record to
+// segment start + rank.  Stable.  The neighbours' key words come out of the caches (the threads of a wavefront read
+// adjacent records), no LDS tile, no barriers, ~24 registers: the latency of the walk hides behind dozens of resident
+// wavefronts.  (A first version staged tiles in LDS and ranked there: 2 workgroups per CU, one dependent LDS chain per
+// record — 9-15 ms for the 117 M 8-byte records that three LSD passes move in 2 ms.)
+// A walk longer than kSegWalkLimit raises *err and the host sorts every bit with LSD passes instead (same result).
 // ---------------------------------------------------------------------------
-template <int S>
-struct SegFin {
-  static constexpr int kPer = (32 / S) < 1 ? 1 : ((32 / S) > 16 ? 16 : (32 / S));  // ~32 KiB of records per tile
-  static constexpr int kT = 256 * kPer;
-  static constexpr int kLaPer = (kPer + 1) / 2;
-  static constexpr int kLA = 256 * kLaPer;  // look-ahead records
-  static constexpr int kRounds = kPer + kLaPer;
-};
+constexpr int kSegWalkLimit = 4096;
 
 template <int S>
 __global__ __launch_bounds__(256) void k_seg_finish(const uint32_t *__restrict__ in, uint32_t *__restrict__ out, uint64_t n, int kw,
-                                                    uint32_t pfx_mask, uint32_t *__restrict__ err, uint64_t n_tiles) {
-  using C = SegFin<S>;
-  constexpr int T = C::kT, LA = C::kLA, NR = C::kRounds;
-  __shared__ __attribute__((aligned(16))) uint32_t tile0[(T + LA + 4) * S];
-  uint32_t *const tile = tile0 + 4 * S;  // tile[-1]: the record before the tile
-  __shared__ uint16_t sdest[T + LA];
-  __shared__ int s_lo, s_hi;
-  const int tid = threadIdx.x;
-  for (uint64_t ti = blockIdx.x; ti < n_tiles; ti += gridDim.x) {
-    const uint64_t base = ti * (uint64_t)T;
-    const uint64_t rem = n - base;
-    const int t_n = rem < (uint64_t)T ? (int)rem : T;
-    const int staged = rem < (uint64_t)(T + LA) ? (int)rem : T + LA;
-    if (tid == 0) {
-      s_lo = staged;
-      s_hi = 0;
-    }
-    {  // stage: tile + look-ahead + predecessor
-      const uint32_t *src = in + base * S;
-      const int n_words = staged * S;
-      if constexpr ((T * S) % 4 == 0) {
-        const int n_vec = n_words / 4;
-        for (int v = tid; v < n_vec; v += 256) reinterpret_cast<uint4 *>(tile)[v] = reinterpret_cast<const uint4 *>(src)[v];
-        for (int w = n_vec * 4 + tid; w < n_words; w += 256) tile[w] = src[w];
-      } else {
-        for (int w = tid; w < n_words; w += 256) tile[w] = src[w];
-      }
-      if (tid < S && base != 0) tile[-S + tid] = src[-S + tid];
-    }
-    __syncthreads();
-    // ranks: one copy of the walking loops (not unrolled), destinations parked in LDS
-#pragma unroll 1
-    for (int j = 0; j < NR; ++j) {
-      const int i = j * 256 + tid;
-      if (i >= staged) break;
-      sdest[i] = 0xFFFFu;
-      Rec<S> me;
-      load_rec<S>(tile + (size_t)i * S, me);
-      const uint32_t r0 = me.w[0];
-      // -1: other segment, 0: key_x < mine, 1: equal, 2: greater
-      auto cmp = [&](int x) -> int {
-        const uint32_t *p = tile + x * S;
-        uint32_t v = p[0];
-        if ((v ^ r0) & pfx_mask) return -1;
-        if (v != r0) return v < r0 ? 0 : 2;
+                                                    uint32_t pfx_mask, uint32_t *__restrict__ err) {
+  const uint64_t stride = (uint64_t)gridDim.x * 256;
+  for (uint64_t gi = (uint64_t)blockIdx.x * 256 + threadIdx.x; gi < n; gi += stride) {
+    Rec<S> me;
+    load_rec<S>(in + gi * S, me);
+    const uint32_t r0 = me.w[0];
+    // -1: other segment, 0: key_x < mine, 1: equal, 2: greater
+    auto cmp = [&](uint64_t x) -> int {
+      const uint32_t *p = in + x * S;
+      uint32_t v = p[0];
+      if ((v ^ r0) & pfx_mask) return -1;
+      if (v != r0) return v < r0 ? 0 : 2;
 #pragma unroll
-        for (int w = 1; w < S; ++w) {
-          if (w >= kw) break;
-          v = p[w];
-          if (v != me.w[w]) return v < me.w[w] ? 0 : 2;
-        }
-        return 1;
-      };
-      int before = 0, x = i - 1;
-      const int stop = base != 0 ? -1 : 0;  // index -1 exists unless this is the first tile
-      bool foreign = false;                 // the segment started in an earlier tile
-      for (;; --x) {
-        if (x < stop) break;
-        const int c = cmp(x);
-        if (c < 0) break;
-        if (x < 0) {
-          foreign = true;
-          break;
-        }
-        before += c <= 1;
+      for (int w = 1; w < S; ++w) {
+        if (w >= kw) break;
+        v = p[w];
+        if (v != me.w[w]) return v < me.w[w] ? 0 : 2;
       }
-      const int seg_start = x + 1;
-      if (foreign || seg_start >= t_n) continue;  // not ours (e.g. a look-ahead record of a segment that starts behind the tile)
-      int y = i + 1;
-      for (; y < staged; ++y) {
-        const int c = cmp(y);
-        if (c < 0) break;
-        before += c == 0;
-      }
-      if (y == staged && base + (uint64_t)staged < n) {  // the segment may go on beyond the look-ahead: is the next record part of it?
-        if (((in[(base + staged) * S] ^ r0) & pfx_mask) == 0) atomicOr(err, 1u);
-      }
-      sdest[i] = (uint16_t)(seg_start + before);
-      atomicMin(&s_lo, i);
-      atomicMax(&s_hi, i + 1);
-    }
-    __syncthreads();
-    Rec<S> rec[NR];
-    int dest[NR];
-#pragma unroll
-    for (int j = 0; j < NR; ++j) {
-      const int i = j * 256 + tid;
-      dest[j] = -1;
-      if (i < staged && sdest[i] != 0xFFFFu) {
-        dest[j] = sdest[i];
-        load_rec<S>(tile + (size_t)i * S, rec[j]);
+      return 1;
+    };
+    uint32_t before = 0;
+    uint64_t x = gi;
+    bool over = false;
+    while (x > 0) {
+      const int c = cmp(x - 1);
+      if (c < 0) break;
+      before += c <= 1;
+      --x;
+      if (gi - x > (uint64_t)kSegWalkLimit) {
+        over = true;
+        break;
       }
     }
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < NR; ++j)
-      if (dest[j] >= 0) store_rec<S>(tile + (size_t)dest[j] * S, rec[j]);
-    __syncthreads();
-    {  // our stretch of the array, coalesced
-      const int lo = s_lo, hi = s_hi;
-      uint32_t *dst = out + base * S;
-      for (int w = lo * S + tid; w < hi * S; w += 256) dst[w] = tile[w];
+    uint64_t y = gi + 1;
+    while (!over && y < n) {
+      const int c = cmp(y);
+      if (c < 0) break;
+      before += c == 0;
+      ++y;
+      if (y - gi > (uint64_t)kSegWalkLimit) over = true;
     }
-    __syncthreads();
+    if (over) {
+      atomicOr(err, 1u);
+      continue;
+    }
+    store_rec<S>(out + (x + before) * S, me);
   }
 }
 
 template <int S>
 static bool seg_finish_impl(mhx_ctx *c, const uint32_t *in, uint32_t *out, uint64_t n, int key_words, int pbits) {
-  const uint64_t n_tiles = div_ceil(n, (uint64_t)SegFin<S>::kT);
   uint32_t *err = c->ws("seg_finish_err", 64).as<uint32_t>();
   MHX_HIP(hipMemsetAsync(err, 0, 4, c->stream));
   const uint32_t pfx_mask = pbits >= 32 ? 0xFFFFFFFFu : ~(0xFFFFFFFFu >> pbits);
   static const std::string nm = "seg_finish_" + std::to_string(S * 4) + "B";
   MHX_LAUNCH(c, nm.c_str(), 2.0 * (double)n * S * 4,
-             hipLaunchKernelGGL((k_seg_finish<S>), dim3((unsigned)std::min<uint64_t>(n_tiles, 256 * 3)), dim3(256), 0, c->stream, in, out, n,
-                                key_words, pfx_mask, err, n_tiles));
+             hipLaunchKernelGGL((k_seg_finish<S>), dim3((unsigned)std::min<uint64_t>(div_ceil(n, 256), 256 * 64)), dim3(256), 0, c->stream, in, out, n,
+                                key_words, pfx_mask, err));
   uint32_t e = 0;
   MHX_HIP(hipMemcpyAsync(&e, err, 4, hipMemcpyDeviceToHost, c->stream));
   MHX_HIP(hipStreamSynchronize(c->stream));
@@ -853,20 +790,38 @@ static bool seg_finish(mhx_ctx *c, const uint32_t *in, uint32_t *out, uint64_t n
 // The caller vouches that `passes` orders the records exactly as the whole key does (bits it leaves out are constant or
 // may order equal keys arbitrarily).
 uint32_t *sort_whole_key(mhx_ctx *c, uint32_t *a, uint32_t *b, uint64_t n, int stride, int key_words, const std::vector<SortPass> &passes) {
-  const int mode = (int)c->opt("sort_hybrid", 1);
+  const int mode = (int)c->opt("sort_hybrid", 1);  // 0: never, 1: when the cost model says so, 2: always (tests)
   const uint64_t min_n = (uint64_t)c->opt("sort_hybrid_min", 1 << 16);
   if (!mode || n < min_n || n >= (1ull << 40)) return radix_sort(c, a, b, n, stride, key_words, passes);
-  // smallest prefix width (whole bytes, <= 32 bits) that leaves ~avg records per segment
-  const double avg = (double)c->opt("sort_hybrid_avg", 4);
-  int pbits = 8;
-  while (pbits < 32 && (double)n / avg > (double)(1ull << pbits)) pbits += 8;
-  if (const long long f = c->opt("sort_hybrid_bits", 0)) pbits = (int)std::min<long long>(32, std::max<long long>(1, f));
-  const int n_partial = (pbits + 7) / 8;
-  if (n_partial + 1 >= (int)passes.size() && mode != 2) return radix_sort(c, a, b, n, stride, key_words, passes);  // nothing to gain
-  uint32_t *sorted = radix_sort(c, a, b, n, stride, key_words, make_passes(key_words, key_words * 32 - pbits, key_words * 32));
+  // Cost model, picoseconds per record on MI355X (measured at 0.8-1.2 x 10^8 records, round 3): an LSD pass moves the record
+  // twice, ~3 ps per 32-bit word (0.71 ms for 117 M 8-byte records, 1.8 ms for 82 M 40-byte ones); the finish kernel costs
+  // ~19 ps when nearly every segment is a single record and ~41 ps at ~7 records per segment, nearly independent of the
+  // record width (it moves each record once and compares a couple of key words per neighbour).  So: never for 8-byte
+  // records with 6 passes (stage 2 at k = 21), always for the wide keys of seq2sdbg at k >= 29 (3.4x at k = 119).
+  const double pass_ps = 3.0 * stride;
+  auto finish_ps = [&](int pbits) {
+    const double avg = pbits >= 40 ? 0.0 : (double)n / (double)(1ull << pbits);  // records per prefix value if the keys were uniform
+    return avg <= 1.0 ? 19.0 : (avg >= 8.0 ? 41.0 + 3.0 * (avg - 8.0) : 19.0 + (avg - 1.0) * 22.0 / 7.0);
+  };
+  int best_bits = 0;
+  double best = (double)passes.size() * pass_ps;
+  for (int pbits = 8; pbits <= 32; pbits += 8) {
+    const double t = (pbits / 8) * pass_ps + finish_ps(pbits) + (double)c->opt("sort_hybrid_margin_ps", 6);
+    if ((double)n / (double)(1ull << pbits) <= 64.0 && t < best) {  // (segments of hundreds of records: the walk is quadratic)
+      best = t;
+      best_bits = pbits;
+    }
+  }
+  if (mode == 2 && !best_bits) {  // forced: the width the model would like best
+    best_bits = 8;
+    while (best_bits < 32 && (double)n / 4.0 > (double)(1ull << best_bits)) best_bits += 8;
+  }
+  if (const long long f = c->opt("sort_hybrid_bits", 0)) best_bits = (int)std::min<long long>(32, std::max<long long>(1, f));
+  if (!best_bits) return radix_sort(c, a, b, n, stride, key_words, passes);
+  uint32_t *sorted = radix_sort(c, a, b, n, stride, key_words, make_passes(key_words, key_words * 32 - best_bits, key_words * 32));
   uint32_t *other = sorted == a ? b : a;
-  if (seg_finish(c, sorted, other, n, stride, key_words, pbits)) return other;
-  return radix_sort(c, sorted, other, n, stride, key_words, passes);  // a segment larger than the look-ahead: every bit by LSD passes
+  if (seg_finish(c, sorted, other, n, stride, key_words, best_bits)) return other;
+  return radix_sort(c, sorted, other, n, stride, key_words, passes);  // a segment beyond the walk limit: every bit by LSD passes
 }
 
 // One stable multisplit pass: digit = owner_lut[item.w[0] >> 16].  Items of owner p end up contiguous

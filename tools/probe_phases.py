@@ -32,3 +32,8 @@ tot = sum(buf[i] for i in range(10))
 print("s1_groups %.3f ms, s1_sample %.3f ms" % (st["s1_groups"]["ms"], st.get("s1_sample", {"ms": 0})["ms"]))
 for i, name in enumerate(PHASES):
     print("  %-12s %6.2f %%  (%d ticks)" % (name, 100.0 * buf[i] / max(tot, 1), buf[i]))
+# the bucket-streaming kernel (k_s1_stream): clocks of thread 0 of every workgroup, summed
+STREAM = ["ticket+bounds", "insert", "slot pass (count, marks, histogram)", "agg offsets + barrier", "emit + recycle"]
+tot = sum(buf[10 + i] for i in range(5))
+for i, name in enumerate(STREAM):
+    print("  stream %-38s %6.2f %%  (%d ticks)" % (name, 100.0 * buf[10 + i] / max(tot, 1), buf[10 + i]))
