@@ -856,7 +856,23 @@ int mhx_dist_route_records(mhx_ctx *c, int which, uint64_t stride_bases, mhx_dis
       n = c->n_marks;
       int hi_bit = 1;
       while (hi_bit < 64 && (c->global_bases >> hi_bit)) ++hi_bit;
-      p = const_cast<uint64_t *>(mhx::sort_u64(c, c->ws("s1_marks", 64).p, n, hi_bit));
+      // The marks only have to be grouped by the rank that holds the read, rank = position / stride.  mhx_dist_setup makes
+      // the stride a multiple of 2^j with global_bases <= 2^(j+8): the 8 position bits from j upwards then order the ranks,
+      // and ONE pass over them (a two-field digit when it straddles the 32-bit words of the little-endian uint64; no copy,
+      // no word swaps) replaces the full sort of the positions (5 passes + 3 copies of ~10^8 marks per rank and step).
+      const int j = hi_bit > 8 ? hi_bit - 8 : 0;
+      if (c->opt("dist_marks_one_pass", 1) && n && j > 0 && j + 8 <= 64 && stride_bases % (1ull << j) == 0) {
+        mhx::SortPass ps{0, 0, 0, 0};
+        // key words = the two memory words of the record: word 0 (low half) is the "high" key word of the record sort
+        if (j >= 32) ps = {j - 32, 8, 0, 0};
+        else if (j + 8 <= 32) ps = {32 + j, 8, 0, 0};
+        else ps = {32 + j, 32 - j, 0, j + 8 - 32};
+        uint32_t *src = c->ws("s1_marks", n * 8 + 64).as<uint32_t>();
+        uint32_t *tmp = c->ws("s1_marks_sorted", n * 8 + 64).as<uint32_t>();
+        p = mhx::radix_sort(c, src, tmp, n, 2, 2, std::vector<mhx::SortPass>{ps});
+      } else {
+        p = const_cast<uint64_t *>(mhx::sort_u64(c, c->ws("s1_marks", 64).p, n, hi_bit));
+      }
       shift = 0;
     } else throw mhx::Error("dist_route_records: unknown record kind");
     uint64_t *bounds = c->ws("route_bounds", (c->n_parts + 2) * 8).as<uint64_t>();

@@ -182,20 +182,21 @@ struct mhx_comm {
     grp->barrier();
   }
   // device buffers with the per-peer segments back to back (peers ascending); counts in items
+  // skip_self: this rank's own segment stays where it is (the receive buffer has no room for it: recv_counts[rank] is ignored)
   void all_to_all_v(const void *d_send, const std::vector<uint64_t> &send_counts, void *d_recv, const std::vector<uint64_t> &recv_counts,
-                    uint32_t item_bytes) {
+                    uint32_t item_bytes, bool skip_self = false) {
     hipStream_t st = ctx->stream;
     std::vector<uint64_t> so(n + 1, 0), ro(n + 1, 0);
     for (int p = 0; p < n; ++p) {
       so[p + 1] = so[p] + send_counts[p] * item_bytes;
-      ro[p + 1] = ro[p] + recv_counts[p] * item_bytes;
+      ro[p + 1] = ro[p] + (skip_self && p == rank ? 0 : recv_counts[p]) * item_bytes;
     }
     const char *s = static_cast<const char *>(d_send);
     char *r = static_cast<char *>(d_recv);
     if (nccl || n == 1) {
       // own segment: a device copy; every other segment: point-to-point messages of at most max_msg_bytes, all pairs of a
       // round in one group (direct xGMI sends, not a ring).  Sender and receiver derive the same chunking from the counts.
-      if (so[rank + 1] > so[rank])
+      if (!skip_self && so[rank + 1] > so[rank])
         MHX_HIP(hipMemcpyAsync(r + ro[rank], s + so[rank], so[rank + 1] - so[rank], hipMemcpyDeviceToDevice, st));
       const uint64_t chunk = std::max<uint64_t>(item_bytes, max_msg_bytes / item_bytes * item_bytes);
       uint64_t rounds = 0;
@@ -224,7 +225,7 @@ struct mhx_comm {
     for (int p = 0; p < n; ++p) {
       const uint64_t bytes = ro[p + 1] - ro[p];
       if (bytes) MHX_HIP(hipMemcpyAsync(r + ro[p], grp->send_ptr[p] + grp->send_off[p][rank], bytes, hipMemcpyDeviceToDevice, st));
-    }
+    }  // (skip_self: ro[rank + 1] == ro[rank], nothing is copied for this rank's own segment)
     MHX_HIP(hipStreamSynchronize(st));
     grp->barrier();  // nobody reuses a send buffer before every peer has read it
   }
@@ -265,6 +266,59 @@ static uint64_t exchange_stage(mhx_ctx *c, mhx_comm *cm, int stage, uint32_t k, 
   move_items(c, cm, it, counts, &n);
   return n;
 }
+__global__ void k_bucket_bounds(const uint32_t *__restrict__ items, uint64_t n, int stride, uint64_t *__restrict__ bstart);  // kmsort_emu.hip
+
+// Stage 1 without the owner multisplit (no mercy candidates, 12-byte records, the bucket-streaming plan): every rank runs
+// the SAME two LSD passes as a single GPU does — they order its records by lv1 bucket, so the records of each owner's
+// contiguous bucket range are contiguous already — sends those slices as they are, keeps its own slice in place, and
+// the owner's group-by kernel reads a bucket as one sub-range per sender (k_s1_stream's sources) instead of sorting the
+// received records again.  Replaces: owner histogram + owner scatter + a second histogram + two more passes over the
+// received records (round 2: 91 ms against 53 ms for a single rank).  Returns false (nothing exchanged yet, the extracted
+// items are in ws "items_a") when the plan does not apply on every rank.
+static bool dist_s1_presorted(mhx_ctx *c, mhx_comm *cm, uint32_t k, uint32_t m, const StageItems &it, mhx_s1_result *r1) {
+  const int n = cm->n, rank = cm->rank;
+  std::vector<uint64_t> v{it.n, it.S == 3 ? 0ull : 1ull};
+  cm->all_reduce(v, true);  // the largest local item count decides for everybody; any rank with other records vetoes
+  if (v[1] || !c->opt("dist_presort", 1) || !s1_presort_applies(c, k, v[0])) return false;
+  hipStream_t st = c->stream;
+  uint32_t *a = c->work["items_a"].as<uint32_t>();
+  uint32_t *b = c->ws("items_b", it.n * 12 + 64).as<uint32_t>();
+  uint32_t *sorted = it.n ? s1_presort(c, k, a, b, it.n) : a;
+  uint64_t *d_bounds = c->ws("dist_bounds", (MHX_NUM_BUCKETS + 2) * 8).as<uint64_t>();
+  std::vector<uint64_t> bounds(MHX_NUM_BUCKETS + 1, 0);
+  if (it.n) {
+    hipLaunchKernelGGL(k_bucket_bounds, dim3(MHX_NUM_BUCKETS / 256 + 1), dim3(256), 0, st, sorted, it.n, 3, d_bounds);
+    MHX_HIP(hipMemcpyAsync(bounds.data(), d_bounds, (MHX_NUM_BUCKETS + 1) * 8, hipMemcpyDeviceToHost, st));
+    MHX_HIP(hipStreamSynchronize(st));
+  }
+  std::vector<uint64_t> counts(n), rc;
+  for (int p = 0; p < n; ++p) counts[p] = bounds[c->part_begin[p + 1]] - bounds[c->part_begin[p]];
+  cm->all_to_all_counts(counts, rc);
+  uint64_t n_recv = 0, total = 0;
+  for (int p = 0; p < n; ++p) {
+    if (p != rank) n_recv += rc[p];
+    total += rc[p];
+  }
+  uint32_t *recv = c->ws("items_recv", n_recv * 12 + 64).as<uint32_t>();
+  cm->all_to_all_v(sorted, counts, recv, rc, 12, true);
+  S1Sources src;
+  src.n = n;
+  uint64_t at = 0;
+  for (int p = 0; p < n; ++p) {
+    if (p == rank) src.ptr.push_back(sorted + bounds[c->part_begin[rank]] * 3);
+    else {
+      src.ptr.push_back(recv + at * 3);
+      at += rc[p];
+    }
+    src.count.push_back(rc[p]);
+  }
+  // the group-by's output regions: the local ping-pong buffer that does not hold the sorted records, if it is large enough
+  uint32_t *other = sorted == a ? b : a;
+  src.spare = total <= it.n ? other : c->ws("s1_spare", total * 12 + 64).as<uint32_t>();
+  s1_process(c, k, m, 0, nullptr, nullptr, total, r1, &src);
+  return true;
+}
+
 static uint64_t route(mhx_ctx *c, mhx_comm *cm, int which) {
   mhx_dist_items it{};
   std::vector<uint64_t> counts(cm->n, 0);
@@ -398,6 +452,12 @@ int mhx_dist_setup(mhx_ctx *c, mhx_comm *cm, int balance_stage, uint32_t k, uint
     cm->all_reduce(nb, true);
     cm->stride_bases = (nb[0] + 63) / 64 * 64;
     if (!cm->stride_bases) cm->stride_bases = 64;
+    {  // a multiple of 2^j with n * stride <= 2^(j+8): 8 position bits then tell the ranks apart (capi.hip, MHX_ROUTE_S1_MARKS)
+      int j = 6;
+      auto up = [&](int jj) { return (cm->stride_bases + (1ull << jj) - 1) >> jj << jj; };
+      while ((uint64_t)n * up(j) > (1ull << (j + 8))) ++j;
+      cm->stride_bases = up(j);
+    }
     MHX_CK(mhx_set_global_layout(c, (uint64_t)cm->rank * cm->stride_bases, (uint64_t)n * cm->stride_bases));
     c->options["dist_sparse_marks"] = 1;
   })
@@ -411,8 +471,28 @@ int mhx_dist_read2sdbg(mhx_ctx *c, mhx_comm *cm, uint32_t k, uint32_t min_count,
     mhx_s1_result r1{};
     if (num_mercy) *num_mercy = 0;
     if (min_count > 1) {  // stage 1 is skipped when every edge is solid (main_sdbg_build.cpp:139-147)
-      const uint64_t n1 = mhx::exchange_stage(c, cm, need_mercy ? MHX_STAGE_S1_MERCY : MHX_STAGE_S1, k, min_count);
-      MHX_CK(mhx_dist_process_s1(c, k, min_count, need_mercy, n1, &r1));
+      bool done = false;
+      if (!need_mercy) {
+        if (c->work.find("owner_lut") == c->work.end()) throw mhx::Error("dist_read2sdbg: call mhx_dist_setup first");
+        const mhx::StageItems it = mhx::extract_stage(c, MHX_STAGE_S1, k, min_count);
+        done = mhx::dist_s1_presorted(c, cm, k, min_count, it, &r1);
+        if (!done) {  // the classic exchange of the items extracted above: owner multisplit, all-to-all, sort at the owner
+          c->pre_hist_buf = nullptr;
+          mhx_dist_items di{};
+          std::vector<uint64_t> counts(cm->n, 0);
+          uint32_t *send = c->ws("items_send", it.n * (size_t)it.S * 4 + 64).as<uint32_t>();
+          mhx::partition_by_owner(c, c->work["items_a"].as<uint32_t>(), send, it.n, it.S, c->work["owner_lut"].as<uint8_t>(), c->n_parts, counts.data());
+          di.d_items = send;
+          di.n_items = it.n;
+          di.item_bytes = (uint32_t)it.S * 4;
+          uint64_t n1 = 0;
+          mhx::move_items(c, cm, di, counts, &n1);
+          MHX_CK(mhx_dist_process_s1(c, k, min_count, 0, n1, &r1));
+        }
+      } else {
+        const uint64_t n1 = mhx::exchange_stage(c, cm, MHX_STAGE_S1_MERCY, k, min_count);
+        MHX_CK(mhx_dist_process_s1(c, k, min_count, need_mercy, n1, &r1));
+      }
       // the marks of the NON-solid (k+1)-mer occurrences of the owned buckets -> the ranks that hold those reads, which
       // derive is_solid = "a (k+1)-mer starts here and it is not marked" for their reads
       mhx::route(c, cm, MHX_ROUTE_S1_MARKS);

@@ -184,7 +184,17 @@ uint64_t s1_extract(mhx_ctx *c, uint32_t k, bool compact);
 bool s1_compact(const mhx_ctx *c, uint32_t k, int want_mercy);
 bool s1_rank_tagged(const mhx_ctx *c, uint32_t k);
 int s1_stride(uint32_t k, bool compact);
-int s1_process(mhx_ctx *c, uint32_t k, uint32_t m, int want_mercy, uint32_t *buf_a, uint32_t *buf_b, uint64_t n_items, mhx_s1_result *out);
+// stage-1 records pre-sorted by lv1 bucket, in n arrays (multi-GPU: one per sending rank; comm.hip)
+struct S1Sources {
+  int n = 0;
+  std::vector<const uint32_t *> ptr;
+  std::vector<uint64_t> count;
+  uint32_t *spare = nullptr;  // scratch of >= 12 bytes per record for the group-by's output regions
+};
+bool s1_presort_applies(const mhx_ctx *c, uint32_t k, uint64_t n_local_items);
+uint32_t *s1_presort(mhx_ctx *c, uint32_t k, uint32_t *buf_a, uint32_t *buf_b, uint64_t n_items);
+int s1_process(mhx_ctx *c, uint32_t k, uint32_t m, int want_mercy, uint32_t *buf_a, uint32_t *buf_b, uint64_t n_items, mhx_s1_result *out,
+               const S1Sources *pre = nullptr);
 uint64_t s2_extract(mhx_ctx *c, uint32_t k, uint32_t m);
 int s2_process(mhx_ctx *c, uint32_t k, uint32_t *buf_a, uint32_t *buf_b, uint64_t n_items, mhx_sdbg_result *out);
 bool s2_use_aggregated(const mhx_ctx *c, uint32_t k, uint32_t m);

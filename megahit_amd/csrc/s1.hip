@@ -899,13 +899,17 @@ constexpr uint32_t kStreamEmpty = 0xFFFFFFFFu;  // never a key: head/tail bits 6
 __global__ void k_bucket_bounds(const uint32_t *__restrict__ items, uint64_t n, int stride, uint64_t *__restrict__ bstart);  // kmsort_emu.hip
 
 template <bool AGG, int UNR>
-__global__ __launch_bounds__(kStreamThreads) void k_s1_stream(const uint32_t *__restrict__ items, const uint64_t *__restrict__ bounds, S1SegArgs a,
-                                                             uint32_t bucket_stride, uint32_t *__restrict__ ticket) {
+__global__ __launch_bounds__(kStreamThreads) void k_s1_stream(const uint32_t *__restrict__ items0, const uint64_t *__restrict__ bounds, S1SegArgs a,
+                                                             uint32_t bucket_stride, uint32_t *__restrict__ ticket,
+                                                             const uint32_t *const *__restrict__ srcs, int n_src) {
+  // Multi-GPU: the records of a bucket arrive as n_src sub-ranges, one per sending rank, each rank's records sorted by
+  // bucket in an array of its own (srcs[q], bounds[q * (65536 + 1) + bucket]); single GPU: one source, items0.
   constexpr int NT = kStreamThreads, NSLOT = kStreamSlots, LOGS = 13;
   static_assert((1 << LOGS) == NSLOT, "table size");
   __shared__ uint32_t keys[NSLOT];
   __shared__ uint32_t cnts[NSLOT];
   __shared__ uint32_t fpos[NSLOT];  // position word of the record that created the slot (direct_marks)
+  __shared__ uint8_t ftag[NSLOT];   // ... and its source rank, when the records carry one (positions past 2^32, multi-GPU)
   __shared__ uint32_t lhist[kSegHist];
   __shared__ uint32_t s_bad, s_agg_cur, s_mark_cur, s_bucket;
   const int tid = threadIdx.x, lane = tid & (kWave - 1);
@@ -940,14 +944,19 @@ __global__ __launch_bounds__(kStreamThreads) void k_s1_stream(const uint32_t *__
     const uint32_t bi = s_bucket * bucket_stride;
     if (bi >= MHX_NUM_BUCKETS) break;
     MHX_TT(10)
-    const uint64_t lo = bounds[bi], hi = bounds[bi + 1];
-    if (lo == hi) {
+    uint64_t total = 0;
+    for (int q = 0; q < n_src; ++q) total += bounds[(size_t)q * (MHX_NUM_BUCKETS + 1) + bi + 1] - bounds[(size_t)q * (MHX_NUM_BUCKETS + 1) + bi];
+    if (total == 0) {
       __syncthreads();
       continue;
     }
     // A: insert.  UNR records per thread and trip: their loads are issued together — with one 12-byte load in flight per
     // wavefront the 16 wavefronts of a CU keep ~12 KB on the wire, 1.5 TB/s device-wide at ~2 us under load, which is
     // what this kernel measured before (the LDS table was never the limit)
+    for (int q = 0; q < n_src; ++q) {
+    const uint64_t lo = bounds[(size_t)q * (MHX_NUM_BUCKETS + 1) + bi], hi = bounds[(size_t)q * (MHX_NUM_BUCKETS + 1) + bi + 1];
+    if (lo == hi) continue;
+    const uint32_t *__restrict__ items = n_src > 1 ? srcs[q] : items0;
     for (uint64_t base = lo; base < hi; base += (uint64_t)NT * UNR) {
       uint32_t rw0[UNR], rw1[UNR], rw2[UNR];
       bool rin[UNR];
@@ -966,6 +975,7 @@ __global__ __launch_bounds__(kStreamThreads) void k_s1_stream(const uint32_t *__
       for (int u = 0; u < UNR; ++u) {
         if (!rin[u]) continue;
         const uint32_t lk = local_key(rw0[u], rw1[u]), w2 = rw2[u];
+        const uint32_t tag = (rw1[u] >> 6) & 0xFFu;
         // one compare-and-swap + add per record: inside a bucket the records are in read order, equal keys are rarely
         // neighbours, so grouping the lanes of a wavefront by key (as k_s1_seg does on its sorted segments) saves few atomics
         // and costs eight ballots per round; the LDS serialises same-address atomics by itself.  (Issuing the UNR first
@@ -977,7 +987,10 @@ __global__ __launch_bounds__(kStreamThreads) void k_s1_stream(const uint32_t *__
           const uint32_t old = atomicCAS(&keys[h], kStreamEmpty, lk);
           if (old == kStreamEmpty || old == lk) {
             atomicAdd(&cnts[h], 1u);
-            if (old == kStreamEmpty) fpos[h] = w2;  // only read back when the count stays 1: then this record is the key's only one
+            if (old == kStreamEmpty) {  // only read back when the count stays 1: then this record is the key's only one
+              fpos[h] = w2;
+              if (a.pos_stride) ftag[h] = (uint8_t)tag;
+            }
             break;
           }
           h = (h + 1) & (NSLOT - 1);
@@ -985,6 +998,7 @@ __global__ __launch_bounds__(kStreamThreads) void k_s1_stream(const uint32_t *__
         if (probes == probe_limit) s_bad = 1;
       }
     }
+    }  // sources
     __syncthreads();
     MHX_TT(11)
     const bool bad = s_bad != 0;
@@ -992,6 +1006,9 @@ __global__ __launch_bounds__(kStreamThreads) void k_s1_stream(const uint32_t *__
     if (!bad) {
       // B: marks, streaming the bucket again (cache-resident)
       if (a.mark_mode != 2 && !a.direct_marks) {
+        for (int q = 0; q < n_src; ++q) {
+        const uint64_t lo = bounds[(size_t)q * (MHX_NUM_BUCKETS + 1) + bi], hi = bounds[(size_t)q * (MHX_NUM_BUCKETS + 1) + bi + 1];
+        const uint32_t *__restrict__ items = n_src > 1 ? srcs[q] : items0;
         for (uint64_t base = lo; base < hi; base += NT) {
           const uint64_t gi = base + tid;
           const bool in = gi < hi;
@@ -1026,6 +1043,7 @@ __global__ __launch_bounds__(kStreamThreads) void k_s1_stream(const uint32_t *__
             }
           }
         }
+        }  // sources
       }
       // C: per distinct key (every occupied slot)
       for (int sl = tid; sl < NSLOT; sl += NT) {
@@ -1041,7 +1059,15 @@ __global__ __launch_bounds__(kStreamThreads) void k_s1_stream(const uint32_t *__
         const uint32_t hb = cnt > MHX_MAX_MUL ? (uint32_t)MHX_MAX_MUL : cnt;  // :430-436
         if (hb < kSegHist) atomicAdd(&lhist[hb], 1u);
         else atomicAdd(&a.hist[hb], 1ull);
-        if (a.direct_marks && !solid) a.solid_bytes[fpos[sl] - 1] = 1;  // count 1 < m <= 2: the key's only record (mark_mode 1)
+        if (a.direct_marks && !solid) {  // count 1 < m <= 2: the key's only record (mark_mode 1)
+          if (!marks_out) a.solid_bytes[fpos[sl] - 1] = 1;
+          else {  // multi-GPU: the mark is the global position itself, appended to this workgroup's region
+            const uint64_t abs = fpos[sl] + (a.pos_stride ? (uint64_t)ftag[sl] * a.pos_stride : 0ull);
+            const uint32_t at = atomicAdd(&s_mark_cur, 1u);
+            if (at + s_agg_cur < a.marks_cap) marks_out[at] = abs - 1;
+            else atomicOr(a.err, 2u);
+          }
+        }
         if (AGG && solid) {
           const uint64_t smer = ((uint64_t)bi << 48) | ((uint64_t)(lk >> 6) << (48 - rem));  // the (k-1)-mer, MSB-first
           const uint64_t x = ((uint64_t)((lk >> 3) & 7u) << 62) | (smer >> 2) | ((uint64_t)(lk & 7u) << (62 - 2 * k));
@@ -1479,8 +1505,19 @@ uint64_t s1_extract(mhx_ctx *c, uint32_t k, bool compact) {
 }
 
 // sort + group reduction of n_items items held in buf_a (buf_b = ping-pong space of the same size)
+bool s1_presort_applies(const mhx_ctx *c, uint32_t k, uint64_t n_local_items) {
+  return s1_plan(c, k, n_local_items, s1_compact(c, k, 0), 0).stream;
+}
+// the two LSD passes that order this rank's stage-1 records by lv1 bucket (the first half of s1_process on the stream plan)
+uint32_t *s1_presort(mhx_ctx *c, uint32_t k, uint32_t *buf_a, uint32_t *buf_b, uint64_t n_items) {
+  // (the passes of the stream plan, whatever s1_plan would say for THIS rank's item count: the ranks decided together)
+  uint32_t *sorted = radix_sort(c, buf_a, buf_b, n_items, 3, s1_kw(k), make_passes(2, 48, 64));
+  c->pre_hist_buf = nullptr;
+  return sorted;
+}
+
 int s1_process(mhx_ctx *c, uint32_t k, uint32_t m, int want_mercy, uint32_t *buf_a, uint32_t *buf_b, uint64_t n_items,
-               mhx_s1_result *out) {
+               mhx_s1_result *out, const S1Sources *pre) {
   SeqSet &s = c->seqs;
   const bool compact = s1_compact(c, k, want_mercy);
   const int KWv = s1_kw(k), S = s1_stride(k, compact);
@@ -1489,15 +1526,20 @@ int s1_process(mhx_ctx *c, uint32_t k, uint32_t m, int want_mercy, uint32_t *buf
   const bool global = c->global_bases != 0;  // multi-GPU: positions index the global read set
   const int kmer_bits = (int)(k - 1) * 2;
   // want_mercy == 2: records with equal keys in exactly the order the reference's kmsort leaves them (H1)
+  // pre: the records come pre-sorted by lv1 bucket in several arrays (multi-GPU: one per sending rank, comm.hip); n_items
+  // is their total.  Only the bucket-streaming group-by reads them in place; if it gives up, they are gathered and the
+  // function continues as if they had arrived unsorted.
   S1Plan plan = s1_plan(c, k, n_items, compact, want_mercy);
+  if (pre && (!plan.stream || want_mercy || !compact)) throw Error("s1_process: pre-sorted sources need the bucket-streaming plan");
   // (records that carry their source rank between the (k-1)-mer and head/tail must not be ordered by whole key words)
   const bool tagged_keys = compact && s1_rank_tagged(c, k);
-  uint32_t *sorted = want_mercy == 2
+  uint32_t *sorted = pre ? nullptr
+                     : want_mercy == 2
                          ? kmsort_exact(c, buf_a, buf_b, n_items, S, KWv)
                          : (plan.seg_bits || tagged_keys ? radix_sort(c, buf_a, buf_b, n_items, S, KWv, plan.passes)
                                                          : sort_whole_key(c, buf_a, buf_b, n_items, S, KWv, plan.passes));
   c->pre_hist_buf = nullptr;
-  uint32_t *spare = sorted == buf_a ? buf_b : buf_a;
+  uint32_t *spare = pre ? pre->spare : (sorted == buf_a ? buf_b : buf_a);
 
   const uint64_t n_bits = global ? c->global_bases : s.n_bases;
   // MHX_S1_MARK: atomic (atomicOr into the bitmap) | solid | nonsolid (force the byte-map polarity) | unset = auto
@@ -1595,20 +1637,32 @@ int s1_process(mhx_ctx *c, uint32_t k, uint32_t m, int want_mercy, uint32_t *buf
       seg_mcap = mcap;
     }
     // the stream kernel marks the non-solid occurrences from its table when each of them is its key's only record
-    const int direct = plan.stream && mode == 1 && m <= 2 && pos_stride == 0 && !mraw && solid_bytes && c->opt("s1_stream_direct", 1) ? 1 : 0;
+    const int direct = plan.stream && mode == 1 && m <= 2 && (mraw || (pos_stride == 0 && solid_bytes)) && c->opt("s1_stream_direct", 1) ? 1 : 0;
     S1SegArgs a{(int)k, m, pfx_mask, eq_mask1, solid_bytes, mode, hist, ctr, raw, seg_cap, counts, mraw, mcap, mcounts, pos_stride, seg_err,
                 plan.stream ? (int)c->opt("s1_stream_probes", 1024) : la, direct};
     MHX_HIP(hipMemsetAsync(seg_err, 0, 4, st));
     const char *nm = mode == 2 ? "s1_sample" : "s1_groups";
     const double bytes = plan.stream ? (double)n_items * 12 / stride : (double)n_work * T * 12;
     if (plan.stream) {
-      uint64_t *bounds = c->ws("s1_bucket_bounds", (MHX_NUM_BUCKETS + 2) * 8).as<uint64_t>();
+      const int n_src = pre && sorted == nullptr ? pre->n : 1;
+      uint64_t *bounds = c->ws("s1_bucket_bounds", (size_t)n_src * (MHX_NUM_BUCKETS + 1) * 8 + 64).as<uint64_t>();
       uint32_t *ticket = c->ws("s1_stream_ticket", 64).as<uint32_t>();
       MHX_HIP(hipMemsetAsync(ticket, 0, 4, st));
-      hipLaunchKernelGGL(k_bucket_bounds, dim3(MHX_NUM_BUCKETS / 256 + 1), dim3(256), 0, st, sorted, n_items, 3, bounds);
+      const uint32_t *const *srcs = nullptr;
+      if (n_src > 1 || (pre && sorted == nullptr)) {
+        DevBuf &sp = c->ws("s1_src_ptrs", (size_t)n_src * 8 + 64);
+        MHX_HIP(hipMemcpyAsync(sp.p, pre->ptr.data(), (size_t)n_src * 8, hipMemcpyHostToDevice, st));
+        srcs = sp.as<const uint32_t *>();
+        for (int q = 0; q < n_src; ++q)
+          hipLaunchKernelGGL(k_bucket_bounds, dim3(MHX_NUM_BUCKETS / 256 + 1), dim3(256), 0, st, pre->ptr[q], pre->count[q], 3,
+                             bounds + (size_t)q * (MHX_NUM_BUCKETS + 1));
+      } else {
+        hipLaunchKernelGGL(k_bucket_bounds, dim3(MHX_NUM_BUCKETS / 256 + 1), dim3(256), 0, st, sorted, n_items, 3, bounds);
+      }
+      const uint32_t *items0 = pre && sorted == nullptr ? pre->ptr[0] : sorted;
       const int unr = (int)c->opt("s1_stream_unroll", 4);  // 8: measured no better than 4
 #define MHX_STREAM(AGGV, UV) \
-  MHX_LAUNCH(c, nm, bytes, hipLaunchKernelGGL((k_s1_stream<AGGV, UV>), dim3(grid), dim3(kStreamThreads), 0, st, sorted, bounds, a, stride, ticket))
+  MHX_LAUNCH(c, nm, bytes, hipLaunchKernelGGL((k_s1_stream<AGGV, UV>), dim3(grid), dim3(kStreamThreads), 0, st, items0, bounds, a, stride, ticket, srcs, n_src))
       if (agg_on) {
         if (unr >= 8) MHX_STREAM(true, 8);
         else if (unr >= 4) MHX_STREAM(true, 4);
@@ -1702,6 +1756,16 @@ int s1_process(mhx_ctx *c, uint32_t k, uint32_t m, int want_mercy, uint32_t *buf
       if (e && plan.stream) {  // a bucket with too many distinct keys for the LDS table: three passes + the tile kernel
         MHX_HIP(hipMemcpyAsync(hist, hist_save, (MHX_MAX_MUL + 1) * 8, hipMemcpyDeviceToDevice, st));
         MHX_HIP(hipMemsetAsync(ctr, 0, 64, st));
+        if (pre && sorted == nullptr) {  // gather the sources: from here on they are one unsorted array
+          buf_a = c->ws("s1_gather_a", n_items * item_bytes + 64).as<uint32_t>();
+          buf_b = c->ws("s1_gather_b", n_items * item_bytes + 64).as<uint32_t>();
+          uint64_t at = 0;
+          for (int q = 0; q < pre->n; ++q) {
+            if (pre->count[q]) MHX_HIP(hipMemcpyAsync(buf_a + at * S, pre->ptr[q], pre->count[q] * item_bytes, hipMemcpyDeviceToDevice, st));
+            at += pre->count[q];
+          }
+          sorted = buf_a;
+        }
         plan = s1_plan(c, k, n_items, compact, want_mercy, false);
         uint32_t *other = sorted == buf_a ? buf_b : buf_a;
         sorted = radix_sort(c, sorted, other, n_items, S, KWv, plan.passes);
@@ -1797,7 +1861,7 @@ int s1_process(mhx_ctx *c, uint32_t k, uint32_t m, int want_mercy, uint32_t *buf
   c->results[MHX_BUF_SORTED_ITEMS].release();
   c->results[MHX_BUF_SORTED_ITEMS].p = sorted;
   c->results[MHX_BUF_SORTED_ITEMS].cap = 0;
-  c->results[MHX_BUF_SORTED_ITEMS].used = n_items * item_bytes;
+  c->results[MHX_BUF_SORTED_ITEMS].used = sorted ? n_items * item_bytes : 0;  // (pre-sorted sources stay where they are)
   c->sorted_item_words = S;
   MHX_HIP(hipStreamSynchronize(st));
   if (out) {

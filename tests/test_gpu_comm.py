@@ -86,6 +86,10 @@ def check_sdbg(outs, want):
     (2, 21, 2, 0, None), (3, 21, 2, STAGE_S1, None), (2, 21, 1, 0, None), (3, 31, 2, STAGE_S1, None), (1, 27, 2, 0, None),
     (2, 21, 2, STAGE_S1, {"s1_seg": 0}),                      # classic stage 1: global byte map -> collected marks
     (3, 21, 2, 0, {"s1_seg_bits": 8, "s1_seg_la": 0}),       # tiles give up -> classic fallback inside the dist path
+    (3, 21, 2, STAGE_S1, {"dist_presort": 0}),               # owner multisplit + sort at the owner (the round-2 exchange)
+    (2, 21, 2, 0, {"s1_stream_probes": 0}),                  # pre-sorted sources, the table gives up -> gathered, tile kernel
+    (3, 21, 3, STAGE_S1, None),                              # m = 3: the marks need the second read over every source
+    (3, 21, 2, 0, {"s1_stream_direct": 0}),                  # marks from the second read instead of the table
 ])
 def test_read2sdbg_ranks_as_threads(world, k, m, balance, opts):
     def body(r, e, cm):
@@ -206,3 +210,18 @@ def test_cli_gpus_flag_reproduces_reference(ent, gpus, tmp_path, monkeypatch):
         if key in ("case", "mercy_cand_kmsort"):
             continue
         assert got.get(key) == want, key
+
+
+def test_cli_failing_rank_ends_the_process(tmp_path, monkeypatch):
+    """a rank that fails before its first collective must not leave the others waiting in a barrier:
+    the process ends at once with the rank's message"""
+    ent = [e for e in gu.cases() if e["case"]["prog"] == "read2sdbg"][0]
+    c = ent["case"]
+    monkeypatch.setenv("MHX_NUM_GPUS", "2")
+    monkeypatch.setenv("MHX_GPU_MAP", "0,0")
+    monkeypatch.setenv("MHX_TEST_RANK_FAIL", "1")
+    p = subprocess.run([gu.MHX_CORE, "read2sdbg", "-k", str(c["k"]), "-m", str(c["m"]), "--read_lib_file", os.path.join(gu.GOLD, c["lib"]),
+                        "--output_prefix", str(tmp_path / "out"), "--host_mem", "2e9", "--num_cpu_threads", "3"],
+                       stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, timeout=120)
+    assert p.returncode == 1
+    assert "rank 1" in p.stderr and "test hook" in p.stderr
