@@ -47,6 +47,9 @@ mhx_ctx *mhx_create(int device);
 void mhx_destroy(mhx_ctx *);
 /* release cached device workspaces (they are otherwise kept between calls) */
 int mhx_trim(mhx_ctx *);
+/* forget inputs, results, partition, filters and options, keep the device buffers: the next job starts as on a new
+   handle without re-allocating (what `mhx_core --serve` does between two sub-programs) */
+int mhx_reset(mhx_ctx *);
 int mhx_synchronize(mhx_ctx *);
 /* Tuning / diagnostic knobs of one handle (never needed for correct results).  A knob that was not set falls back to
  * the environment variable MHX_<NAME IN UPPER CASE>, then to its built-in default.  Known names:

@@ -541,6 +541,41 @@ int mhx_trim(mhx_ctx *c) {
   })
 }
 
+// Forget every input, result and mode of the handle but keep its device buffers (grow-only allocations, the pinned
+// staging buffers, the streams): the next job on this handle starts like on a new one without paying for allocations.
+int mhx_reset(mhx_ctx *c) {
+  MHX_TRY({
+    MHX_HIP(hipSetDevice(c->device));
+    MHX_HIP(hipStreamSynchronize(c->stream));
+    c->seqs.n_seqs = c->seqs.n_bases = c->seqs.n_words = 0;
+    c->seqs.fixed_len = c->seqs.max_len = 0;
+    c->seqs.mult.used = 0;
+    c->seqs.h_start.clear();
+    for (auto &kv : c->results) kv.second.used = 0;
+    auto it = c->results.find(MHX_BUF_SORTED_ITEMS);  // a view into a workspace, not an allocation
+    if (it != c->results.end()) c->results.erase(it);
+    c->sorted_item_words = 0;
+    c->my_part = 0;
+    c->n_parts = 1;
+    c->part_begin.clear();
+    c->pos_base = c->global_bases = 0;
+    c->agg_valid = false;
+    c->agg_n = 0;
+    c->n_route = 0;
+    c->pre_hist_buf = nullptr;
+    c->filter_on = c->accumulate = false;
+    c->filter_expected = c->filter_batch_bytes = 0;
+    c->global_marks_inverted = false;
+    c->s1_acc_bits = c->mercy_acc_n = 0;
+    c->s1_acc_k = c->s1_acc_m = c->count_acc_k = c->count_acc_m = 0;
+    c->n_marks = c->dist_local_solid = 0;
+    c->dist_s2_agg = false;
+    c->options.clear();
+    c->prof_collect();
+    c->stats.clear();
+  })
+}
+
 void mhx_destroy(mhx_ctx *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);

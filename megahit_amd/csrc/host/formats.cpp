@@ -17,6 +17,7 @@
 
 namespace mhxio {
 
+bool g_fatal_throws = false;
 void fatal(const char *fmt, ...) {
   va_list ap;
   va_start(ap, fmt);
@@ -24,6 +25,7 @@ void fatal(const char *fmt, ...) {
   vfprintf(stderr, fmt, ap);
   fprintf(stderr, "\n");
   va_end(ap);
+  if (g_fatal_throws) throw Fatal{};  // a resident server (mhx_core --serve) fails the request, not the process
   exit(1);
 }
 void info(const char *fmt, ...) {

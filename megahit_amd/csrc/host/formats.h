@@ -10,6 +10,8 @@
 
 namespace mhxio {
 
+struct Fatal {};                   // thrown by fatal() instead of exit(1) when g_fatal_throws is set (message already printed)
+extern bool g_fatal_throws;
 [[noreturn]] void fatal(const char *fmt, ...);
 void info(const char *fmt, ...);
 

@@ -7,8 +7,11 @@
 // it unchanged, so the unmodified `megahit` orchestrator can run with this binary in place.
 #include <unistd.h>
 #include <fcntl.h>
+#include <poll.h>
 #include <signal.h>
 #include <sys/prctl.h>
+#include <sys/socket.h>
+#include <sys/un.h>
 #include <sys/wait.h>
 #include <cerrno>
 
@@ -26,6 +29,8 @@
 
 #include "formats.h"
 #include "mhx.h"
+
+extern char **environ;
 
 using mhxio::fatal;
 using mhxio::info;
@@ -98,12 +103,29 @@ int num_threads_or_all(int n) {
   return hc ? (int)hc : 1;
 }
 
+// `mhx_core --serve <socket>`: this process stays, holds one handle and its device buffers, and runs the sub-programs that
+// clients (mhx_core started with MHX_SERVER=<socket>) send it, one after the other — see serve() below.
+bool g_serving = false;
+mhx_ctx *g_served_ctx = nullptr;
+// leave a sub-program early (usage errors): the process, or only the request when serving
+[[noreturn]] void quit(int status) {
+  if (g_serving) throw mhxio::Fatal{};
+  exit(status);
+}
+
 mhx_ctx *open_gpu() {
   int dev = 0;
   if (const char *e = getenv("MHX_DEVICE")) dev = atoi(e);
-  mhx_ctx *c = mhx_create(dev);
-  if (!c) fatal("%s", mhx_last_error());
-  if (getenv("MHX_PROFILE")) mhx_profile_enable(c, 1);  // per-kernel HIP-event times, printed by finish()
+  mhx_ctx *c = nullptr;
+  if (g_serving && g_served_ctx) {
+    c = g_served_ctx;
+    if (mhx_reset(c) != 0) fatal("%s", mhx_last_error());
+  } else {
+    c = mhx_create(dev);
+    if (!c) fatal("%s", mhx_last_error());
+    if (g_serving) g_served_ctx = c;
+  }
+  mhx_profile_enable(c, getenv("MHX_PROFILE") ? 1 : 0);  // per-kernel HIP-event times, printed by finish()
   return c;
 }
 // The chained-scan sort gives up (and says so) when a unit waits seconds for a predecessor — a wedged or heavily shared
@@ -112,6 +134,10 @@ mhx_ctx *open_gpu() {
 extern int g_done_fd;
 constexpr unsigned char kRetryClassicSort = 75;
 [[noreturn]] void fail_call(const char *msg) {
+  if (g_serving) {
+    fprintf(stderr, "FATAL %s\n", msg);
+    throw mhxio::Fatal{};
+  }
   if (g_done_fd >= 0 && !getenv("MHX_SORT") && strstr(msg, "chained scan timed out")) {
     mhxio::info("%s: running the sub-program again with MHX_SORT=classic", msg);
     fflush(nullptr);
@@ -227,7 +253,7 @@ int g_done_fd = -1;  // write end of the pipe to the front process (main): set i
 void maybe_pretend_scan_timeout() {
   if (getenv("MHX_TEST_SCAN_TIMEOUT_ONCE") && !getenv("MHX_SORT")) fail_call("radix sort: chained scan timed out waiting for a predecessor unit (test hook)");
 }
-[[noreturn]] void finish(mhx_ctx *c) {
+int finish(mhx_ctx *c) {
   if (getenv("MHX_PROFILE")) {
     std::vector<mhx_kernel_stat> ks(256);
     const int n = mhx_profile_get(c, ks.data(), (int)ks.size());
@@ -249,12 +275,17 @@ void maybe_pretend_scan_timeout() {
   // driver still reclaims tens of GB in the background) but the next GPU process of a pipeline then starts on a device
   // that is busy unmapping: its hipMalloc calls wait and hipMemGetInfo under-reports (the reference's orchestrator runs
   // count -> seq2sdbg -> assemble -> iterate -> seq2sdbg back to back).
-  if (!getenv("MHX_EARLY_EXIT") || getenv("MHX_CLEAN_EXIT")) mhx_destroy(c);
+  if (!g_serving && (!getenv("MHX_EARLY_EXIT") || getenv("MHX_CLEAN_EXIT"))) mhx_destroy(c);
   {
     double ms = 0, fs = 0;
     uint64_t bytes = 0, calls = 0;
     mhx_alloc_stats(&ms, &fs, &bytes, &calls);
-    info("Device memory: %llu allocations, %.2f GB, %.4f s in hipMalloc, %.4f s in hipFree", (unsigned long long)calls, (double)bytes / 1e9, ms, fs);
+    info("Device memory: %llu allocations, %.2f GB, %.4f s in hipMalloc, %.4f s in hipFree%s", (unsigned long long)calls, (double)bytes / 1e9, ms, fs,
+         g_serving ? " (server: totals since its start, buffers kept)" : "");
+  }
+  if (g_serving) {  // the handle and its buffers stay for the next request
+    fflush(nullptr);
+    return 0;
   }
   fflush(nullptr);
   if (g_done_fd >= 0) {
@@ -435,7 +466,7 @@ int main_kmer_count(int argc, char **argv) {
   } catch (std::string &e) {
     fprintf(stderr, "%s\nUsage: sdbg_builder count --input_file fastx_file -o out\nOptions:\n", e.c_str());
     o.usage();
-    exit(1);
+    quit(1);
   }
   const uint32_t k = (uint32_t)atoi(o.get("kmer_k").c_str()), m = (uint32_t)atoi(o.get("min_kmer_frequency").c_str());
   const int n_threads = num_threads_or_all(atoi(o.get("num_cpu_threads").c_str()));
@@ -524,7 +555,7 @@ int main_kmer_count(int argc, char **argv) {
   info("Total number of candidate reads: %lld (%lld)", (long long)n_cand, (long long)n_tips);
   info("Total number of solid edges: %llu", (unsigned long long)r.n_edges);
   info("Postprocess done. Time elapsed: %.4f", t.lap());
-  finish(c);
+  return finish(c);
 }
 
 int main_read2sdbg(int argc, char **argv) {
@@ -544,7 +575,7 @@ int main_read2sdbg(int argc, char **argv) {
   } catch (std::string &e) {
     fprintf(stderr, "%s\nUsage: sdbg_builder read2sdbg --read_lib_file fastx_file -o out\nOptions:\n", e.c_str());
     o.usage();
-    exit(1);
+    quit(1);
   }
   const uint32_t k = (uint32_t)atoi(o.get("kmer_k").c_str()), m = (uint32_t)atoi(o.get("min_kmer_frequency").c_str());
   const int n_threads = num_threads_or_all(atoi(o.get("num_cpu_threads").c_str()));
@@ -649,7 +680,7 @@ int main_read2sdbg(int argc, char **argv) {
   info("Stage 2 done (%llu items). Time elapsed: %.4f", (unsigned long long)acc.r.n_items, t.lap());
   acc.write(out, k, out_files(n_threads));
   info("Postprocess done. Time elapsed: %.4f", t.lap());
-  finish(c);
+  return finish(c);
 }
 
 int main_seq2sdbg(int argc, char **argv) {
@@ -676,7 +707,7 @@ int main_seq2sdbg(int argc, char **argv) {
             "%s\nUsage: sdbg_builder seq2sdbg -k kmer_size --contig contigs.fa [--addi_contig add.fa] [--input_prefix input] -o out\nOptions:\n",
             e.c_str());
     o.usage();
-    exit(1);
+    quit(1);
   }
   const uint32_t k = (uint32_t)atoi(o.get("kmer_size").c_str()), k_from = (uint32_t)atoi(o.get("kmer_from").c_str());
   const int n_threads = num_threads_or_all(atoi(o.get("num_cpu_threads").c_str()));
@@ -811,7 +842,7 @@ int main_seq2sdbg(int argc, char **argv) {
   info("GPU seq2sdbg done (%llu items). Time elapsed: %.4f", (unsigned long long)acc.r.n_items, t.lap());
   acc.write(out, k, out_files(n_threads));
   info("Postprocess done. Time elapsed: %.4f", t.lap());
-  finish(c);
+  return finish(c);
 }
 
 // ---------------------------------------------------------------------------
@@ -821,7 +852,7 @@ int main_seq2sdbg(int argc, char **argv) {
 int main_buildlib(int argc, char **argv) {
   if (argc < 3) {
     fprintf(stderr, "Usage %s <read_lib_file> <out_prefix>\n", argv[0]);
-    exit(1);
+    quit(1);
   }
   const std::string lib_file = argv[1], out = argv[2];
   Timer t;
@@ -920,7 +951,7 @@ int main_buildlib(int argc, char **argv) {
   for (const Lib &l : libs) fprintf(li, "%s\n%lld %lld %u %d\n", l.meta.c_str(), (long long)l.begin, (long long)l.end, l.max_len, l.paired ? 1 : 0);
   if (fclose(li) != 0) fatal("write error on %s.lib_info", out.c_str());
   info("buildlib done: %lld reads, %lld bases. Time elapsed: %.4f", (long long)total_reads, (long long)total_bases, t.lap());
-  if (c) finish(c);
+  if (c) return finish(c);
   return 0;
 }
 
@@ -951,7 +982,7 @@ int main_iterate(int argc, char **argv) {
   } catch (std::string &e) {
     fprintf(stderr, "%s\nUsage: %s [opt]\nopt with (*) are must\nopt:\n", e.c_str(), argv[0]);
     o.usage();
-    exit(1);
+    quit(1);
   }
   Timer t;
   mhx_ctx *c = open_gpu();
@@ -979,15 +1010,313 @@ int main_iterate(int argc, char **argv) {
   if (!edges.empty()) CK(mhx_fetch(c, MHX_BUF_EDGES, edges.data(), 0, edges.size() * 4));
   mhxio::write_edges_unsorted(o.get("output_prefix"), (uint32_t)(k + step), r.words_per_edge, edges.data(), r.n_edges);
   info("Total: %llu. Iterative edges: %llu. Time elapsed: %.4f", (unsigned long long)bin.n_reads, (unsigned long long)r.n_edges, t.lap());
-  finish(c);
+  return finish(c);
+}
+
+
+
+// route one sub-program (argv[0] = program name, argv[1] = sub-program); only the ones this binary implements
+int dispatch(int argc, char **argv) {
+  const std::string sub = argv[1];
+  maybe_pretend_scan_timeout();
+  if (sub == "count") return main_kmer_count(argc - 1, argv + 1);
+  if (sub == "read2sdbg") return main_read2sdbg(argc - 1, argv + 1);
+  if (sub == "seq2sdbg") return main_seq2sdbg(argc - 1, argv + 1);
+  if (sub == "buildlib") return main_buildlib(argc - 1, argv + 1);
+  if (sub == "iterate") return main_iterate(argc - 1, argv + 1);
+  fatal("sub-program '%s' is not served", sub.c_str());
+}
+
+// ---------------------------------------------------------------------------
+// Resident server.  Every GPU process pays for device initialisation, for hipMalloc of its working set and — in bursts,
+// whenever the driver has to scrub the memory earlier processes gave back before it can hand it out again — seconds of
+// waiting inside hipMalloc (profiles/r03_process_churn.json: 1-3 s every third or fourth process at 40 GB each), more
+// than the sub-programs' own work.  The reference's orchestrator starts ~4 GPU-path processes per k.
+//   mhx_core --serve <socket>          stays, holds ONE handle with its (grow-only) device buffers, runs the requests it
+//                                      receives one after the other, leaves after MHX_SERVE_IDLE_S (120) idle seconds
+//   MHX_SERVER=<socket> mhx_core ...   sends its command line, working directory, MHX_* environment and its stderr
+//                                      (descriptor passing) to the server and exits with the status it gets back;
+//                                      with MHX_SERVER_AUTOSTART=1 it starts the server when none listens; if no server
+//                                      can be reached it does the work itself, as without MHX_SERVER
+//   mhx_core --serve-stop <socket>     asks the server to leave now
+// Request: u32 argc, {u32 len, bytes}*, u32 n_env, {u32 len, bytes "NAME=value"}*, u32 len + cwd, then one byte carrying
+// the client's stderr as SCM_RIGHTS.  Reply: one status byte.
+namespace serve_io {
+bool write_all(int fd, const void *p, size_t n) {
+  const char *c = static_cast<const char *>(p);
+  while (n) {
+    const ssize_t w = write(fd, c, n);
+    if (w < 0 && errno == EINTR) continue;
+    if (w <= 0) return false;
+    c += w;
+    n -= (size_t)w;
+  }
+  return true;
+}
+bool read_all(int fd, void *p, size_t n) {
+  char *c = static_cast<char *>(p);
+  while (n) {
+    const ssize_t r = read(fd, c, n);
+    if (r < 0 && errno == EINTR) continue;
+    if (r <= 0) return false;
+    c += r;
+    n -= (size_t)r;
+  }
+  return true;
+}
+bool put_str(int fd, const std::string &v) {
+  const uint32_t n = (uint32_t)v.size();
+  return write_all(fd, &n, 4) && write_all(fd, v.data(), n);
+}
+bool get_str(int fd, std::string *v) {
+  uint32_t n = 0;
+  if (!read_all(fd, &n, 4) || n > (1u << 20)) return false;
+  v->resize(n);
+  return n == 0 || read_all(fd, &(*v)[0], n);
+}
+bool send_fd(int sock, int fd) {
+  char byte = 'F', ctrl[CMSG_SPACE(sizeof(int))];
+  memset(ctrl, 0, sizeof ctrl);
+  iovec iov{&byte, 1};
+  msghdr msg{};
+  msg.msg_iov = &iov;
+  msg.msg_iovlen = 1;
+  msg.msg_control = ctrl;
+  msg.msg_controllen = sizeof ctrl;
+  cmsghdr *cm = CMSG_FIRSTHDR(&msg);
+  cm->cmsg_level = SOL_SOCKET;
+  cm->cmsg_type = SCM_RIGHTS;
+  cm->cmsg_len = CMSG_LEN(sizeof(int));
+  memcpy(CMSG_DATA(cm), &fd, sizeof(int));
+  return sendmsg(sock, &msg, 0) == 1;
+}
+int recv_fd(int sock) {
+  char byte = 0, ctrl[CMSG_SPACE(sizeof(int))];
+  iovec iov{&byte, 1};
+  msghdr msg{};
+  msg.msg_iov = &iov;
+  msg.msg_iovlen = 1;
+  msg.msg_control = ctrl;
+  msg.msg_controllen = sizeof ctrl;
+  if (recvmsg(sock, &msg, 0) != 1) return -1;
+  for (cmsghdr *cm = CMSG_FIRSTHDR(&msg); cm; cm = CMSG_NXTHDR(&msg, cm))
+    if (cm->cmsg_level == SOL_SOCKET && cm->cmsg_type == SCM_RIGHTS) {
+      int fd = -1;
+      memcpy(&fd, CMSG_DATA(cm), sizeof(int));
+      return fd;
+    }
+  return -1;
+}
+int connect_to(const char *path) {
+  sockaddr_un a{};
+  a.sun_family = AF_UNIX;
+  if (strlen(path) >= sizeof a.sun_path) return -1;
+  strcpy(a.sun_path, path);
+  const int fd = socket(AF_UNIX, SOCK_STREAM, 0);
+  if (fd < 0) return -1;
+  if (connect(fd, reinterpret_cast<sockaddr *>(&a), sizeof a) != 0) {
+    close(fd);
+    return -1;
+  }
+  return fd;
+}
+}  // namespace serve_io
+
+int serve(const char *path) {
+  using namespace serve_io;
+  signal(SIGPIPE, SIG_IGN);
+  sockaddr_un a{};
+  a.sun_family = AF_UNIX;
+  if (strlen(path) >= sizeof a.sun_path) fatal("socket path too long: %s", path);
+  strcpy(a.sun_path, path);
+  const int ls = socket(AF_UNIX, SOCK_STREAM, 0);
+  if (ls < 0) fatal("socket: %s", strerror(errno));
+  if (connect_to(path) >= 0) fatal("a server already listens on %s", path);
+  unlink(path);
+  if (bind(ls, reinterpret_cast<sockaddr *>(&a), sizeof a) != 0 || listen(ls, 16) != 0) fatal("cannot listen on %s: %s", path, strerror(errno));
+  const int idle_s = getenv("MHX_SERVE_IDLE_S") ? std::max(1, atoi(getenv("MHX_SERVE_IDLE_S"))) : 120;
+  g_serving = true;
+  mhxio::g_fatal_throws = true;
+  info("serving on %s (leaves after %d idle seconds)", path, idle_s);
+  uint64_t served = 0;
+  for (;;) {
+    pollfd pf{ls, POLLIN, 0};
+    const int pr = poll(&pf, 1, idle_s * 1000);
+    if (pr < 0 && errno == EINTR) continue;
+    if (pr <= 0) break;  // idle
+    const int fd = accept(ls, nullptr, nullptr);
+    if (fd < 0) continue;
+    uint32_t argc = 0, n_env = 0;
+    std::vector<std::string> args, envs;
+    std::string cwd;
+    bool ok = read_all(fd, &argc, 4) && argc >= 1 && argc < 4096;
+    for (uint32_t i = 0; ok && i < argc; ++i) {
+      args.emplace_back();
+      ok = get_str(fd, &args.back());
+    }
+    ok = ok && read_all(fd, &n_env, 4) && n_env < 4096;
+    for (uint32_t i = 0; ok && i < n_env; ++i) {
+      envs.emplace_back();
+      ok = get_str(fd, &envs.back());
+    }
+    ok = ok && get_str(fd, &cwd);
+    const int err_fd = ok ? recv_fd(fd) : -1;
+    if (!ok || err_fd < 0) {
+      if (err_fd >= 0) close(err_fd);
+      close(fd);
+      continue;
+    }
+    if (args[0] == "--serve-stop") {
+      const unsigned char st = 0;
+      (void)write_all(fd, &st, 1);
+      close(err_fd);
+      close(fd);
+      break;
+    }
+    // the request's world: its stderr, its working directory, its MHX_* settings
+    fflush(nullptr);
+    const int saved_err = dup(2);
+    dup2(err_fd, 2);
+    close(err_fd);
+    char old_cwd[4096] = "";
+    if (!getcwd(old_cwd, sizeof old_cwd)) old_cwd[0] = 0;
+    std::vector<std::pair<std::string, std::string>> restore;  // (name, previous value or "\x01" for unset)
+    std::vector<std::string> drop;                             // MHX_* of the server that the client does not have
+    for (char **e = environ; *e; ++e)
+      if (!strncmp(*e, "MHX_", 4) && strncmp(*e, "MHX_SERVE", 9)) {
+        const std::string kv = *e, name = kv.substr(0, kv.find('='));
+        bool sent = false;
+        for (const std::string &x : envs) sent = sent || x.compare(0, name.size() + 1, name + "=") == 0;
+        if (!sent) drop.push_back(kv);
+      }
+    for (const std::string &kv : drop) {
+      const std::string name = kv.substr(0, kv.find('='));
+      restore.push_back({name, kv.substr(name.size() + 1)});
+      unsetenv(name.c_str());
+    }
+    for (const std::string &kv : envs) {
+      const size_t eq = kv.find('=');
+      if (eq == std::string::npos) continue;
+      const std::string name = kv.substr(0, eq);
+      const char *prev = getenv(name.c_str());
+      restore.push_back({name, prev ? std::string(prev) : std::string("\x01")});
+      setenv(name.c_str(), kv.c_str() + eq + 1, 1);
+    }
+    unsigned char status = 1;
+    if (chdir(cwd.c_str()) != 0) {
+      fprintf(stderr, "FATAL cannot enter %s\n", cwd.c_str());
+    } else {
+      std::vector<char *> argv;
+      static char prog[] = "mhx_core";
+      argv.push_back(prog);
+      for (std::string &x : args) argv.push_back(&x[0]);
+      argv.push_back(nullptr);
+      try {
+        status = (unsigned char)dispatch((int)argv.size() - 1, argv.data());
+      } catch (const mhxio::Fatal &) {
+        status = 1;
+      } catch (const std::string &e) {
+        fprintf(stderr, "%s\n", e.c_str());
+        status = 1;
+      } catch (const std::exception &e) {
+        fprintf(stderr, "FATAL %s\n", e.what());
+        status = 1;
+      }
+    }
+    fflush(nullptr);
+    dup2(saved_err, 2);
+    close(saved_err);
+    if (old_cwd[0] && chdir(old_cwd) != 0) {
+    }
+    for (auto it = restore.rbegin(); it != restore.rend(); ++it) {
+      if (it->second == "\x01") unsetenv(it->first.c_str());
+      else setenv(it->first.c_str(), it->second.c_str(), 1);
+    }
+    (void)write_all(fd, &status, 1);
+    close(fd);
+    ++served;
+  }
+  info("server on %s leaves after %llu requests", path, (unsigned long long)served);
+  if (g_served_ctx) mhx_destroy(g_served_ctx);
+  close(ls);
+  unlink(path);
+  fflush(nullptr);
+  _exit(0);
+}
+
+// the client side: -1 = not served (do the work here), else the exit status the server reported
+int try_server(int argc, char **argv) {
+  using namespace serve_io;
+  const char *path = getenv("MHX_SERVER");
+  if (!path || !*path) return -1;
+  int fd = connect_to(path);
+  if (fd < 0 && getenv("MHX_SERVER_AUTOSTART")) {
+    const pid_t pid = fork();
+    if (pid == 0) {  // detach: the server must survive this client and must not hold its pipes
+      setsid();
+      const int nul = open("/dev/null", O_RDWR);
+      const char *logp = getenv("MHX_SERVER_LOG");
+      const int lg = logp ? open(logp, O_WRONLY | O_CREAT | O_APPEND, 0644) : -1;
+      dup2(nul, 0);
+      dup2(nul, 1);
+      dup2(lg >= 0 ? lg : nul, 2);
+      for (int f = 3; f < 256; ++f) close(f);
+      if (fork() != 0) _exit(0);
+      char self[4096];
+      const ssize_t n = readlink("/proc/self/exe", self, sizeof self - 1);
+      if (n <= 0) _exit(1);
+      self[n] = 0;
+      execl(self, self, "--serve", path, (char *)nullptr);
+      _exit(1);
+    }
+    if (pid > 0) {
+      int ws = 0;
+      while (waitpid(pid, &ws, 0) < 0 && errno == EINTR) {
+      }
+      for (int i = 0; i < 200 && fd < 0; ++i) {  // up to 10 s for the socket to appear
+        usleep(50000);
+        fd = connect_to(path);
+      }
+    }
+  }
+  if (fd < 0) return -1;
+  bool ok = true;
+  const uint32_t n = (uint32_t)(argc - 1);
+  ok = write_all(fd, &n, 4);
+  for (int i = 1; ok && i < argc; ++i) ok = put_str(fd, argv[i]);
+  std::vector<std::string> envs;
+  for (char **e = environ; *e; ++e)
+    if (!strncmp(*e, "MHX_", 4) && strncmp(*e, "MHX_SERVE", 9)) envs.push_back(*e);
+  const uint32_t ne = (uint32_t)envs.size();
+  ok = ok && write_all(fd, &ne, 4);
+  for (const std::string &x : envs) ok = ok && put_str(fd, x);
+  char cwd[4096] = ".";
+  if (!getcwd(cwd, sizeof cwd)) strcpy(cwd, ".");
+  ok = ok && put_str(fd, cwd) && send_fd(fd, 2);
+  if (!ok) {  // nothing has run yet: do the work here
+    close(fd);
+    return -1;
+  }
+  unsigned char st = 1;
+  if (!read_all(fd, &st, 1)) st = 1;  // the server went away in the middle of the request
+  close(fd);
+  return st;
 }
 
 }  // namespace
 
 int main(int argc, char **argv) {
   if (argc < 2) {
-    fprintf(stderr, "Usage: %s <sub_program> [sub options]\n    sub-programs: buildlib count read2sdbg seq2sdbg iterate (GPU); others via MHX_REF_CORE\n", argv[0]);
+    fprintf(stderr, "Usage: %s <sub_program> [sub options]\n    sub-programs: buildlib count read2sdbg seq2sdbg iterate (GPU); others via MHX_REF_CORE\n"
+            "    %s --serve <socket> | --serve-stop <socket>   (resident server, see MHX_SERVER)\n", argv[0], argv[0]);
     return 1;
+  }
+  if (!strcmp(argv[1], "--serve") && argc >= 3) return serve(argv[2]);
+  if (!strcmp(argv[1], "--serve-stop") && argc >= 3) {
+    setenv("MHX_SERVER", argv[2], 1);
+    unsetenv("MHX_SERVER_AUTOSTART");
+    const int st = try_server(argc, argv);
+    return st < 0 ? 1 : st;
   }
   // `mhx_core --gpus N <sub-program> ...` (or MHX_NUM_GPUS): our only addition to the reference's command line; it sits
   // before the sub-program so that the sub-programs' own option sets stay the reference's
@@ -1001,6 +1330,10 @@ int main(int argc, char **argv) {
   const std::string sub = argv[1];
   const bool ours = sub == "count" || sub == "read2sdbg" || sub == "seq2sdbg" || (sub == "buildlib" && !getenv("MHX_BUILDLIB_REF")) ||
                     (sub == "iterate" && !getenv("MHX_ITERATE_REF"));
+  if (ours && g_num_gpus == 1) {
+    const int st = try_server(argc, argv);
+    if (st >= 0) return st;
+  }
   if (ours && !getenv("MHX_NO_FORK") && !getenv("MHX_CLEAN_EXIT")) {
     // the work runs in a child (forked before anything touches the HIP runtime); this front process only waits for the
     // child's "outputs are complete" byte (finish()) or, failing that, for its exit status
@@ -1049,13 +1382,8 @@ int main(int argc, char **argv) {
       g_num_gpus = have;
     }
   }
-  if (ours) maybe_pretend_scan_timeout();
-  if (sub == "count") return main_kmer_count(argc - 1, argv + 1);
-  if (sub == "read2sdbg") return main_read2sdbg(argc - 1, argv + 1);
-  if (sub == "seq2sdbg") return main_seq2sdbg(argc - 1, argv + 1);
+  if (ours) return dispatch(argc, argv);
   if (sub == "kmax") { printf("%d\n", MHX_MAX_K); return 0; }
-  if (sub == "buildlib" && !getenv("MHX_BUILDLIB_REF")) return main_buildlib(argc - 1, argv + 1);
-  if (sub == "iterate" && !getenv("MHX_ITERATE_REF")) return main_iterate(argc - 1, argv + 1);
   if (const char *ref = getenv("MHX_REF_CORE")) {
     execv(ref, argv);  // buildlib / assemble / iterate / local / ... : not on this path
     perror("execv MHX_REF_CORE");

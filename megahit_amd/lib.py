@@ -146,6 +146,7 @@ SYMBOLS = {
     "mhx_bucket_histogram": (C.c_int, [_P, C.c_int, C.c_uint32, C.c_uint32, _P]),
     "mhx_set_bucket_filter": (C.c_int, [_P, _P, C.c_uint64, C.c_uint64, C.c_int]),
     "mhx_alloc_stats": (None, [_P, _P, _P, _P]),
+    "mhx_reset": (C.c_int, [_P]),
     "mhx_profile_enable": (C.c_int, [_P, C.c_int]),
     "mhx_profile_reset": (C.c_int, [_P]),
     "mhx_profile_get": (C.c_int, [_P, C.POINTER(KernelStat), C.c_int]),

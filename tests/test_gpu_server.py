@@ -1,0 +1,67 @@
+"""GPU: the sub-programs through the resident server (`mhx_core --serve`, clients with MHX_SERVER): one process keeps the
+handle and its device buffers across count -> seq2sdbg -> read2sdbg -> ... and every request still reproduces the
+reference's digests (tests/golden/golden.json) — state of one request must not leak into the next."""
+import os
+import subprocess
+import time
+
+import pytest
+
+import golden_util as gu
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def server(tmp_path_factory):
+    d = tmp_path_factory.mktemp("srv")
+    sock = str(d / "mhx.sock")
+    log = open(str(d / "server.log"), "w")
+    p = subprocess.Popen([gu.MHX_CORE, "--serve", sock], stdout=subprocess.DEVNULL, stderr=log, env=dict(os.environ, MHX_SERVE_IDLE_S="60"))
+    for _ in range(500):
+        if os.path.exists(sock):
+            break
+        time.sleep(0.02)
+    assert os.path.exists(sock)
+    yield sock, p
+    subprocess.run([gu.MHX_CORE, "--serve-stop", sock], timeout=60)
+    try:
+        p.wait(timeout=30)
+    except subprocess.TimeoutExpired:
+        p.kill()
+    log.close()
+
+
+def _pick():
+    seen, out = set(), []
+    for e in gu.cases():
+        c = e["case"]
+        key = (c["prog"], c.get("k"), c.get("mercy"), c.get("input"))
+        if key in seen:
+            continue
+        seen.add(key)
+        out.append(e)
+    return out[:14]
+
+
+@pytest.mark.parametrize("ent", _pick(), ids=gu.case_id)
+def test_served_requests_reproduce_the_reference(ent, tmp_path, server, monkeypatch):
+    sock, proc = server
+    monkeypatch.setenv("MHX_SERVER", sock)
+    got = gu.run_case(gu.MHX_CORE, ent, str(tmp_path))
+    for key, want in ent.items():
+        if key in ("case", "mercy_cand_kmsort"):
+            continue
+        assert got.get(key) == want, key
+    assert proc.poll() is None, "the server died"
+
+
+def test_the_work_really_ran_in_the_server(tmp_path, server, monkeypatch):
+    sock, _proc = server
+    ent = [e for e in gu.cases() if e["case"]["prog"] == "count"][0]
+    c = ent["case"]
+    env = dict(os.environ, MHX_SERVER=sock)
+    p = subprocess.run([gu.MHX_CORE, "count", "-k", str(c["k"]), "-m", str(c["m"]), "--read_lib_file", os.path.join(gu.GOLD, c["lib"]),
+                        "--output_prefix", str(tmp_path / "o"), "--host_mem", "2e9", "--num_cpu_threads", "3"], stderr=subprocess.PIPE, text=True, env=env)
+    assert p.returncode == 0
+    assert "server: totals since its start" in p.stderr
