@@ -345,6 +345,11 @@ int mhx_dist_read2sdbg(mhx_ctx *, mhx_comm *, uint32_t k, uint32_t min_count, in
 /* count: edges / bucket counts / histogram of the owned buckets, first_0_out / last_0_in of the local reads */
 int mhx_dist_count(mhx_ctx *, mhx_comm *, uint32_t k, uint32_t min_count, mhx_count_result *out);
 /* seq2sdbg: the loaded sequences (+ multiplicities) may be spread over the ranks in any way */
+/* collective GenMercyEdges (seq_to_sdbg.cpp:171-357) for `seq2sdbg --need_mercy` on several GPUs: the (k+1)-mer edges are
+   sharded over the ranks (mhx_load_edges of a contiguous slice each; a rank may hold none), EVERY rank passes ALL candidate
+   reads; has_in / has_out are OR-ed over the ranks, each mercy edge is appended on exactly one rank.  *num_mercy = all. */
+int mhx_dist_gen_mercy_edges(mhx_ctx *, mhx_comm *, uint32_t k, const uint32_t *cand_packed, uint64_t cand_words, uint64_t n_cand,
+                             const uint64_t *cand_start, uint64_t *num_mercy);
 int mhx_dist_seq2sdbg(mhx_ctx *, mhx_comm *, uint32_t k, mhx_sdbg_result *out);
 
 /* ---- memory-bounded operation: the reference's lv1 passes (base_engine.cpp:54-141,213-281) ----

@@ -329,6 +329,89 @@ static uint64_t route(mhx_ctx *c, mhx_comm *cm, int which) {
   return n;
 }
 
+// ---- bucket-range passes on several GPUs (the reference's lv1 passes, base_engine.cpp:54-141,254-281, per rank) ----
+// When the items a rank would own (or extract) in one go do not fit its free memory, the stage runs P times; pass i
+// handles, of EVERY owner's bucket range, the i-th of P sub-ranges of about equal weight (global lv1 histogram), so that
+// all ranks stay busy in every pass.  Every rank extracts only the kept buckets of its reads (mhx_set_bucket_filter).
+struct DistPasses {
+  int n = 1;
+  std::vector<std::vector<uint8_t>> keep;   // [pass][bucket]
+  std::vector<uint64_t> expected;           // [pass]: local items in the kept buckets
+};
+static DistPasses plan_dist_passes(mhx_ctx *c, mhx_comm *cm, int stage, uint32_t k, uint32_t m, size_t item_bytes) {
+  DistPasses dp;
+  // bytes per item a pass needs on a rank: the extracted copy + the send copy / sorted copy + receive buffer + its sort twin
+  const double per_item = 4.0 * (double)item_bytes + 1.0;
+  uint64_t max_items = (uint64_t)c->opt("dist_max_items", 0);
+  if (const char *e = getenv("MHX_MAX_ITEMS")) max_items = strtoull(e, nullptr, 10);
+  if (!max_items && !getenv("MHX_FREE_BYTES")) {
+    // the usual case decided without a scan of the reads: an upper bound of the items of the whole job (stage 1 / count:
+    // one per base + 4 per read; stage 2 per occurrence, seq2sdbg: ~2 per base), twice the fair share per rank
+    const mhx::SeqSet &s = c->seqs;
+    const double per_base = (stage == MHX_STAGE_S2 || stage == MHX_STAGE_SEQ2SDBG) ? 2.2 : 1.0;
+    std::vector<uint64_t> v{(uint64_t)(per_base * (double)s.n_bases) + 4 * s.n_seqs, ~0ull - mhx_device_free_bytes(c)};
+    std::vector<uint64_t> mx = v;
+    cm->all_reduce(mx, true);
+    const double fit = (double)(~0ull - mx[1]) * 0.8 / per_item;
+    if (2.0 * (double)mx[0] <= fit) return dp;  // (the largest local bound stands in for every rank's share)
+  }
+  std::vector<uint64_t> hist(MHX_NUM_BUCKETS, 0);
+  const uint64_t saved = c->global_bases;
+  MHX_CK(mhx_bucket_histogram(c, stage, k, m, hist.data()));
+  c->global_bases = saved;
+  const std::vector<uint64_t> local = hist;
+  cm->all_reduce(hist, false);
+  if (!max_items) {
+    std::vector<uint64_t> fr{~0ull - mhx_device_free_bytes(c)};
+    cm->all_reduce(fr, true);  // the rank with the least free memory decides
+    double free_bytes = (double)(~0ull - fr[0]);
+    if (const char *e = getenv("MHX_FREE_BYTES")) free_bytes = atof(e);
+    max_items = (uint64_t)std::max(1.0, free_bytes * 0.8 / per_item);
+  }
+  uint64_t worst = 0, local_total = 0;
+  for (int p = 0; p < cm->n; ++p) {
+    uint64_t owned = 0;
+    for (uint32_t b = c->part_begin[p]; b < c->part_begin[p + 1]; ++b) owned += hist[b];
+    worst = std::max(worst, owned);
+  }
+  for (uint64_t v : local) local_total += v;
+  std::vector<uint64_t> w{std::max(worst, local_total)};
+  cm->all_reduce(w, true);
+  const uint64_t P = std::min<uint64_t>(4096, (w[0] + max_items - 1) / max_items);
+  if (P <= 1) return dp;
+  dp.n = (int)P;
+  dp.keep.assign(P, std::vector<uint8_t>(MHX_NUM_BUCKETS, 0));
+  dp.expected.assign(P, 0);
+  for (int p = 0; p < cm->n; ++p) {
+    long double owned = 0, acc = 0;
+    for (uint32_t b = c->part_begin[p]; b < c->part_begin[p + 1]; ++b) owned += hist[b];
+    uint64_t i = 0;
+    for (uint32_t b = c->part_begin[p]; b < c->part_begin[p + 1]; ++b) {
+      while (i + 1 < P && acc >= owned * (long double)(i + 1) / (long double)P) ++i;
+      dp.keep[i][b] = 1;
+      dp.expected[i] += local[b];
+      acc += hist[b];
+    }
+  }
+  return dp;
+}
+static void set_pass(mhx_ctx *c, const DistPasses &dp, int i, bool accumulate) {
+  if (dp.n <= 1) return;
+  MHX_CK(mhx_set_bucket_filter(c, dp.keep[i].data(), dp.expected[i], 0, accumulate && i > 0 ? 1 : 0));
+}
+static void clear_pass(mhx_ctx *c, const DistPasses &dp) {
+  if (dp.n > 1) MHX_CK(mhx_set_bucket_filter(c, nullptr, 0, 0, 0));
+}
+static void add_result(mhx_sdbg_result &a, const mhx_sdbg_result &b) {
+  a.n_items += b.n_items;
+  a.n_sdbg += b.n_sdbg;
+  a.n_tips += b.n_tips;
+  a.n_large += b.n_large;
+  a.sdbg_bytes += b.sdbg_bytes;
+  a.words_per_tip_label = b.words_per_tip_label;
+  a.item_words = b.item_words;
+}
+
 }  // namespace mhx
 
 extern "C" {
@@ -471,28 +554,39 @@ int mhx_dist_read2sdbg(mhx_ctx *c, mhx_comm *cm, uint32_t k, uint32_t min_count,
     mhx_s1_result r1{};
     if (num_mercy) *num_mercy = 0;
     if (min_count > 1) {  // stage 1 is skipped when every edge is solid (main_sdbg_build.cpp:139-147)
-      bool done = false;
-      if (!need_mercy) {
-        if (c->work.find("owner_lut") == c->work.end()) throw mhx::Error("dist_read2sdbg: call mhx_dist_setup first");
-        const mhx::StageItems it = mhx::extract_stage(c, MHX_STAGE_S1, k, min_count);
-        done = mhx::dist_s1_presorted(c, cm, k, min_count, it, &r1);
-        if (!done) {  // the classic exchange of the items extracted above: owner multisplit, all-to-all, sort at the owner
-          c->pre_hist_buf = nullptr;
-          mhx_dist_items di{};
-          std::vector<uint64_t> counts(cm->n, 0);
-          uint32_t *send = c->ws("items_send", it.n * (size_t)it.S * 4 + 64).as<uint32_t>();
-          mhx::partition_by_owner(c, c->work["items_a"].as<uint32_t>(), send, it.n, it.S, c->work["owner_lut"].as<uint8_t>(), c->n_parts, counts.data());
-          di.d_items = send;
-          di.n_items = it.n;
-          di.item_bytes = (uint32_t)it.S * 4;
-          uint64_t n1 = 0;
-          mhx::move_items(c, cm, di, counts, &n1);
-          MHX_CK(mhx_dist_process_s1(c, k, min_count, 0, n1, &r1));
+      if (c->work.find("owner_lut") == c->work.end()) throw mhx::Error("dist_read2sdbg: call mhx_dist_setup first");
+      const int st1 = need_mercy ? MHX_STAGE_S1_MERCY : MHX_STAGE_S1;
+      const mhx::DistPasses dp = mhx::plan_dist_passes(c, cm, st1, k, min_count, (size_t)mhx::s1_stride(k, mhx::s1_compact(c, k, need_mercy)) * 4);
+      uint64_t n_items_all = 0;
+      for (int pass = 0; pass < dp.n; ++pass) {
+        mhx::set_pass(c, dp, pass, true);
+        mhx_s1_result rp{};
+        bool done = false;
+        if (!need_mercy) {
+          const mhx::StageItems it = mhx::extract_stage(c, MHX_STAGE_S1, k, min_count);
+          done = mhx::dist_s1_presorted(c, cm, k, min_count, it, &rp);
+          if (!done) {  // the classic exchange of the items extracted above: owner multisplit, all-to-all, sort at the owner
+            c->pre_hist_buf = nullptr;
+            mhx_dist_items di{};
+            std::vector<uint64_t> counts(cm->n, 0);
+            uint32_t *send = c->ws("items_send", it.n * (size_t)it.S * 4 + 64).as<uint32_t>();
+            mhx::partition_by_owner(c, c->work["items_a"].as<uint32_t>(), send, it.n, it.S, c->work["owner_lut"].as<uint8_t>(), c->n_parts, counts.data());
+            di.d_items = send;
+            di.n_items = it.n;
+            di.item_bytes = (uint32_t)it.S * 4;
+            uint64_t n1 = 0;
+            mhx::move_items(c, cm, di, counts, &n1);
+            MHX_CK(mhx_dist_process_s1(c, k, min_count, 0, n1, &rp));
+          }
+        } else {
+          const uint64_t n1 = mhx::exchange_stage(c, cm, MHX_STAGE_S1_MERCY, k, min_count);
+          MHX_CK(mhx_dist_process_s1(c, k, min_count, need_mercy, n1, &rp));
         }
-      } else {
-        const uint64_t n1 = mhx::exchange_stage(c, cm, MHX_STAGE_S1_MERCY, k, min_count);
-        MHX_CK(mhx_dist_process_s1(c, k, min_count, need_mercy, n1, &r1));
+        n_items_all += rp.n_items;
+        r1 = rp;
       }
+      mhx::clear_pass(c, dp);
+      r1.n_items = n_items_all;
       // the marks of the NON-solid (k+1)-mer occurrences of the owned buckets -> the ranks that hold those reads, which
       // derive is_solid = "a (k+1)-mer starts here and it is not marked" for their reads
       mhx::route(c, cm, MHX_ROUTE_S1_MARKS);
@@ -504,9 +598,21 @@ int mhx_dist_read2sdbg(mhx_ctx *c, mhx_comm *cm, uint32_t k, uint32_t min_count,
         if (num_mercy) *num_mercy = nm;
       }
     }
-    const uint64_t n2 = mhx::exchange_stage(c, cm, MHX_STAGE_S2, k, min_count);
     mhx_sdbg_result r2{};
-    MHX_CK(mhx_dist_process_s2(c, k, n2, &r2));
+    {
+      const size_t ib2 = (min_count > 1 && k <= 22) ? 8 : (size_t)mhx::s2_stride(k) * 4;
+      const mhx::DistPasses dp = mhx::plan_dist_passes(c, cm, MHX_STAGE_S2, k, min_count, ib2);
+      for (int pass = 0; pass < dp.n; ++pass) {
+        mhx::set_pass(c, dp, pass, false);
+        const uint64_t n2 = mhx::exchange_stage(c, cm, MHX_STAGE_S2, k, min_count);
+        mhx_sdbg_result rp{};
+        MHX_CK(mhx_dist_process_s2(c, k, n2, &rp));
+        if (dp.n > 1) mhx::sdbg_accumulate(c, pass == 0);
+        mhx::add_result(r2, rp);
+      }
+      mhx::clear_pass(c, dp);
+      if (dp.n > 1) mhx::sdbg_publish_accumulated(c);
+    }
     if (out1) *out1 = r1;
     if (out2) *out2 = r2;
   })
@@ -516,11 +622,71 @@ int mhx_dist_count(mhx_ctx *c, mhx_comm *cm, uint32_t k, uint32_t min_count, mhx
   MHX_TRYC({
     MHX_HIP(hipSetDevice(c->device));
     if (!c->global_bases || !cm->stride_bases) throw mhx::Error("dist_count: call mhx_dist_setup first");
-    const uint64_t n = mhx::exchange_stage(c, cm, MHX_STAGE_COUNT, k, min_count);
+    const mhx::DistPasses dp = mhx::plan_dist_passes(c, cm, MHX_STAGE_COUNT, k, min_count, (size_t)mhx::count_stride(k) * 4);
     mhx_count_result r{};
-    MHX_CK(mhx_dist_process_count(c, k, min_count, n, &r));
-    mhx::route(c, cm, MHX_ROUTE_COUNT_EVENTS);
+    hipStream_t st = c->stream;
+    uint64_t acc_edge_bytes = 0;
+    for (int pass = 0; pass < dp.n; ++pass) {
+      mhx::set_pass(c, dp, pass, true);
+      const uint64_t n = mhx::exchange_stage(c, cm, MHX_STAGE_COUNT, k, min_count);
+      mhx_count_result rp{};
+      MHX_CK(mhx_dist_process_count(c, k, min_count, n, &rp));
+      mhx::route(c, cm, MHX_ROUTE_COUNT_EVENTS);
+      if (dp.n > 1) {  // the solid edges and their per-bucket numbers of every pass, kept on the device (a bucket belongs to one pass)
+        mhx::DevBuf &src = c->results[MHX_BUF_EDGES];
+        mhx::DevBuf &dst = mhx::grow_preserving(c, c->work["acc_edges"], acc_edge_bytes + src.used + 64, acc_edge_bytes);
+        if (src.used) MHX_HIP(hipMemcpyAsync(reinterpret_cast<char *>(dst.p) + acc_edge_bytes, src.p, src.used, hipMemcpyDeviceToDevice, st));
+        acc_edge_bytes += src.used;
+        unsigned long long *ab = c->ws("acc_edge_buckets", MHX_NUM_BUCKETS * 8).as<unsigned long long>();
+        if (pass == 0) MHX_HIP(hipMemsetAsync(ab, 0, MHX_NUM_BUCKETS * 8, st));
+        hipLaunchKernelGGL(mhx::k_add_u64, dim3(MHX_NUM_BUCKETS / 256), dim3(256), 0, st, ab, c->results[MHX_BUF_BUCKET_COUNT].as<unsigned long long>(),
+                           MHX_NUM_BUCKETS);
+        MHX_HIP(hipStreamSynchronize(st));
+      }
+      r.n_items += rp.n_items;
+      r.n_distinct += rp.n_distinct;
+      r.n_edges += rp.n_edges;
+      r.words_per_edge = rp.words_per_edge;
+    }
+    mhx::clear_pass(c, dp);
+    if (dp.n > 1) {
+      std::swap(c->results[MHX_BUF_EDGES].p, c->work["acc_edges"].p);
+      std::swap(c->results[MHX_BUF_EDGES].cap, c->work["acc_edges"].cap);
+      c->results[MHX_BUF_EDGES].used = acc_edge_bytes;
+      std::swap(c->results[MHX_BUF_BUCKET_COUNT].p, c->work["acc_edge_buckets"].p);
+      std::swap(c->results[MHX_BUF_BUCKET_COUNT].cap, c->work["acc_edge_buckets"].cap);
+      c->results[MHX_BUF_BUCKET_COUNT].used = MHX_NUM_BUCKETS * 8;
+    }
     if (out) *out = r;
+  })
+}
+
+int mhx_dist_gen_mercy_edges(mhx_ctx *c, mhx_comm *cm, uint32_t k, const uint32_t *cand_packed, uint64_t cand_words, uint64_t n_cand,
+                             const uint64_t *cand_start, uint64_t *num_mercy) {
+  MHX_TRYC({
+    MHX_HIP(hipSetDevice(c->device));
+    mhx::MercyShare share;
+    share.my_part = cm->rank;
+    share.n_parts = cm->n;
+    share.reduce_flags = [&](uint8_t *d_flags, uint64_t nf) {
+      // flags are has_in | has_out << 1 per base position; OR over the ranks = "any rank's count is non-zero": four positions
+      // per 64-bit word, 8 bits per flag bit, summed over <= 255 ranks
+      std::vector<uint8_t> h(nf);
+      MHX_HIP(hipMemcpyAsync(h.data(), d_flags, nf, hipMemcpyDeviceToHost, c->stream));
+      MHX_HIP(hipStreamSynchronize(c->stream));
+      std::vector<uint64_t> v((nf + 3) / 4, 0);
+      for (uint64_t i = 0; i < nf; ++i) v[i / 4] |= (uint64_t)((h[i] & 1u) | ((h[i] & 2u) << 7)) << (16 * (i % 4));
+      cm->all_reduce(v, false);
+      for (uint64_t i = 0; i < nf; ++i) {
+        const uint64_t x = v[i / 4] >> (16 * (i % 4));
+        h[i] = (uint8_t)(((x & 0xFFu) ? 1u : 0u) | (((x >> 8) & 0xFFu) ? 2u : 0u));
+      }
+      MHX_HIP(hipMemcpyAsync(d_flags, h.data(), nf, hipMemcpyHostToDevice, c->stream));
+      MHX_HIP(hipStreamSynchronize(c->stream));
+    };
+    uint64_t nm = 0;
+    mhx::run_gen_mercy(c, k, cand_packed, cand_words, n_cand, cand_start, &nm, &share);
+    if (num_mercy) *num_mercy = nm;
   })
 }
 
@@ -529,9 +695,18 @@ int mhx_dist_seq2sdbg(mhx_ctx *c, mhx_comm *cm, uint32_t k, mhx_sdbg_result *out
     MHX_HIP(hipSetDevice(c->device));
     if (c->part_begin.empty()) throw mhx::Error("dist_seq2sdbg: call mhx_dist_setup first");
     const uint64_t saved = c->global_bases;  // items carry no positions
-    const uint64_t n = mhx::exchange_stage(c, cm, MHX_STAGE_SEQ2SDBG, k, 0);
+    const mhx::DistPasses dp = mhx::plan_dist_passes(c, cm, MHX_STAGE_SEQ2SDBG, k, 0, (size_t)mhx::seq2sdbg_stride(k) * 4);
     mhx_sdbg_result r{};
-    MHX_CK(mhx_dist_process_seq2sdbg(c, k, n, &r));
+    for (int pass = 0; pass < dp.n; ++pass) {
+      mhx::set_pass(c, dp, pass, false);
+      const uint64_t n = mhx::exchange_stage(c, cm, MHX_STAGE_SEQ2SDBG, k, 0);
+      mhx_sdbg_result rp{};
+      MHX_CK(mhx_dist_process_seq2sdbg(c, k, n, &rp));
+      if (dp.n > 1) mhx::sdbg_accumulate(c, pass == 0);
+      mhx::add_result(r, rp);
+    }
+    mhx::clear_pass(c, dp);
+    if (dp.n > 1) mhx::sdbg_publish_accumulated(c);
     c->global_bases = saved;
     if (out) *out = r;
   })

@@ -716,8 +716,7 @@ int main_seq2sdbg(int argc, char **argv) {
   if (need_mercy && in.empty())  // GenMercyEdges reads <input_prefix>.cand and the sorted edges (seq_to_sdbg.cpp:171-189,435)
     fatal("--need_mercy needs --input_prefix (its .cand file and the sorted edges to search)");
   Timer t;
-  if (g_num_gpus > 1 && need_mercy) info("seq2sdbg --need_mercy searches the whole sorted edge list (seq_to_sdbg.cpp:171-357): running on one GPU");
-  if (g_num_gpus > 1 && !need_mercy) {
+  if (g_num_gpus > 1) {
     // edges are sharded contiguously over the ranks (their items carry no positions, so any split works); the contigs,
     // a small share of the input, are loaded by rank 0; sorting and emission are balanced by the bucket partition
     const RankSet rs = rank_set();
@@ -739,6 +738,16 @@ int main_seq2sdbg(int argc, char **argv) {
     }
     read_one(o.get("addi_contig"), 0, 0);
     read_one(o.get("local_contig"), 0, 0);
+    // --need_mercy: every rank gets all candidate reads; the search runs against the rank's slice of the sorted edges and
+    // the per-position answers are OR-ed over the ranks (mhx_dist_gen_mercy_edges)
+    mhxio::PackedSeqs cand;
+    if (need_mercy) {
+      std::vector<uint32_t> rec = mhxio::read_bin_file(in + ".cand");
+      std::vector<uint64_t> off = mhxio::index_bin_records(rec);
+      for (size_t i = 0; i < off.size(); ++i) cand.append_packed(&rec[off[i] + 1], rec[off[i]], false);
+      info("Adding mercy edges...");
+    }
+    std::vector<uint64_t> n_mercy(rs.n, 0);
     std::vector<SdbgAcc> part(rs.n);
     run_ranks(rs, [&](int r, mhx_ctx *c, mhx_comm *cm) {
       const uint64_t ne = es.n_edges(), lo = ne * r / rs.n, hi = ne * (r + 1) / rs.n;
@@ -746,6 +755,10 @@ int main_seq2sdbg(int argc, char **argv) {
       if (hi > lo) {
         CKT(mhx_load_edges(c, es.data + lo * es.words_per_edge, hi - lo, es.k, es.words_per_edge));
         loaded = true;
+      }
+      if (need_mercy) {
+        CKT(mhx_dist_gen_mercy_edges(c, cm, k, cand.words.data(), cand.words.size(), cand.n_seqs(), cand.start.data(), &n_mercy[r]));
+        loaded = loaded || mhx_num_sequences(c) > 0;
       }
       if (r == 0 && contigs.n_seqs()) {
         if (loaded)
@@ -769,6 +782,7 @@ int main_seq2sdbg(int argc, char **argv) {
       part[r].add(fetch_t<uint8_t>(c, MHX_BUF_SDBG_BYTES), fetch_t<uint64_t>(c, MHX_BUF_BUCKET_OFFSET), fetch_t<uint64_t>(c, MHX_BUF_BUCKET_COUNT),
                   fetch_t<uint64_t>(c, MHX_BUF_BUCKET_TIPS), fetch_t<uint64_t>(c, MHX_BUF_BUCKET_LARGE), fetch_t<uint64_t>(c, MHX_BUF_W_COUNT), r2);
     });
+    if (need_mercy) info("Number of reads: %llu, Number of mercy edges: %llu", (unsigned long long)cand.n_seqs(), (unsigned long long)n_mercy[0]);
     SdbgAcc acc;
     for (int q = 0; q < rs.n; ++q) acc.add(part[q]);
     info("GPU seq2sdbg done (%llu items). Time elapsed: %.4f", (unsigned long long)acc.r.n_items, t.lap());

@@ -230,13 +230,17 @@ static void grow_preserve(mhx_ctx *c, DevBuf &b, size_t new_bytes, size_t keep_b
   b = nb;
 }
 
+// Multi-GPU (share != nullptr): the sorted edges are sharded over the ranks, every rank holds ALL candidate reads.  A rank's
+// binary searches only see its shard, so has_in / has_out are OR-ed over the ranks (share->reduce_flags) before the per-read
+// state machine runs — identically on every rank — and the mercy edges it yields are dealt out round robin: rank r appends
+// edge i iff i % n_parts == my_part.  *n_mercy = the number of ALL mercy edges (the reference's "Number of mercy edges").
 int run_gen_mercy(mhx_ctx *c, uint32_t k, const uint32_t *cand_packed, uint64_t cand_words, uint64_t n_cand, const uint64_t *cand_start,
-                  uint64_t *n_mercy) {
+                  uint64_t *n_mercy, const MercyShare *share) {
   SeqSet &s = c->seqs;
   hipStream_t st = c->stream;
   if (n_mercy) *n_mercy = 0;
   if (s.n_seqs && s.fixed_len != k + 1) throw Error("gen_mercy_edges: the loaded sequences must be (k+1)-mer edges");
-  if (s.mult.used < s.n_seqs * 2) throw Error("gen_mercy_edges: multiplicities not loaded");
+  if (s.n_seqs && s.mult.used < s.n_seqs * 2) throw Error("gen_mercy_edges: multiplicities not loaded");
   if (n_cand == 0) return 0;
   const uint64_t cand_bases = cand_start[n_cand];
   uint32_t *cseq = c->ws("cand_words", (cand_words + 64) * 4).as<uint32_t>();
@@ -253,6 +257,7 @@ int run_gen_mercy(mhx_ctx *c, uint32_t k, const uint32_t *cand_packed, uint64_t 
                                     s.words.as<uint32_t>(), s.n_seqs, cseq, cstart, n_cand, (int)k, flags));
     });
   }
+  if (share && share->reduce_flags && cand_bases) share->reduce_flags(flags, cand_bases);
   uint32_t *cnt = c->ws("cand_cnt", (n_cand + 1) * 4).as<uint32_t>();
   uint64_t *pos = c->ws("cand_pos", (n_cand + 2) * 8).as<uint64_t>();
   const unsigned g = (unsigned)div_ceil(n_cand, 256);
@@ -262,10 +267,29 @@ int run_gen_mercy(mhx_ctx *c, uint32_t k, const uint32_t *cand_packed, uint64_t 
   uint64_t nm = 0;
   MHX_HIP(hipMemcpyAsync(&nm, pos + n_cand + 1, 8, hipMemcpyDeviceToHost, st));
   MHX_HIP(hipStreamSynchronize(st));
+  const uint64_t nm_all = nm;
   if (nm) {
     uint64_t *mercy_abs = c->ws("mercy_abs", nm * 8).as<uint64_t>();
     MHX_LAUNCH(c, "mercy_scan", (double)cand_bases + (double)nm * 8,
                hipLaunchKernelGGL(k_mercy_scan<true>, dim3(g), dim3(256), 0, st, flags, cstart, n_cand, (int)k, nullptr, pos, mercy_abs));
+    if (share && share->n_parts > 1) {  // this rank's share of the list (a few 10^5 entries: through the host)
+      std::vector<uint64_t> all(nm), mine;
+      MHX_HIP(hipMemcpyAsync(all.data(), mercy_abs, nm * 8, hipMemcpyDeviceToHost, st));
+      MHX_HIP(hipStreamSynchronize(st));
+      for (uint64_t i = (uint64_t)share->my_part; i < nm; i += (uint64_t)share->n_parts) mine.push_back(all[i]);
+      nm = mine.size();
+      if (nm) MHX_HIP(hipMemcpyAsync(mercy_abs, mine.data(), nm * 8, hipMemcpyHostToDevice, st));
+      MHX_HIP(hipStreamSynchronize(st));
+    }
+  }
+  if (nm) {
+    uint64_t *mercy_abs = c->ws("mercy_abs", nm * 8).as<uint64_t>();
+    if (!s.n_seqs) {  // a rank without edges of its own: an empty fixed-length (k+1)-mer set to append to
+      s.fixed_len = k + 1;
+      s.n_bases = s.n_words = 0;
+      s.words.reserve(64 * 4);
+      MHX_HIP(hipMemsetAsync(s.words.p, 0, 64 * 4, st));
+    }
     const uint64_t old_bases = s.n_bases, new_seqs = s.n_seqs + nm, new_bases = new_seqs * (k + 1);
     const uint64_t new_words = div_ceil(new_bases, 16);
     grow_preserve(c, s.words, (new_words + 64) * 4, (s.n_words + 1) * 4);
@@ -289,7 +313,7 @@ int run_gen_mercy(mhx_ctx *c, uint32_t k, const uint32_t *cand_packed, uint64_t 
     MHX_HIP(hipStreamSynchronize(st));
     upload_fixed_starts(c);
   }
-  if (n_mercy) *n_mercy = nm;
+  if (n_mercy) *n_mercy = nm_all;
   return 0;
 }
 

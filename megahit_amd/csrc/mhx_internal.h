@@ -5,6 +5,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <stdexcept>
 #include <string>
@@ -195,6 +196,9 @@ bool s1_presort_applies(const mhx_ctx *c, uint32_t k, uint64_t n_local_items);
 uint32_t *s1_presort(mhx_ctx *c, uint32_t k, uint32_t *buf_a, uint32_t *buf_b, uint64_t n_items);
 int s1_process(mhx_ctx *c, uint32_t k, uint32_t m, int want_mercy, uint32_t *buf_a, uint32_t *buf_b, uint64_t n_items, mhx_s1_result *out,
                const S1Sources *pre = nullptr);
+__global__ void k_add_u64(unsigned long long *__restrict__ a, const unsigned long long *__restrict__ b, int n);
+void sdbg_accumulate(mhx_ctx *c, bool first);
+void sdbg_publish_accumulated(mhx_ctx *c);
 uint64_t s2_extract(mhx_ctx *c, uint32_t k, uint32_t m);
 int s2_process(mhx_ctx *c, uint32_t k, uint32_t *buf_a, uint32_t *buf_b, uint64_t n_items, mhx_sdbg_result *out);
 bool s2_use_aggregated(const mhx_ctx *c, uint32_t k, uint32_t m);
@@ -238,8 +242,12 @@ int run_s1(mhx_ctx *c, uint32_t k, uint32_t m, int want_mercy, mhx_s1_result *ou
 int run_s1_mercy(mhx_ctx *c, uint32_t k, uint64_t *num_mercy);
 int run_s2(mhx_ctx *c, uint32_t k, uint32_t m, mhx_sdbg_result *out);
 int run_seq2sdbg(mhx_ctx *c, uint32_t k, mhx_sdbg_result *out);
+struct MercyShare {  // multi-GPU seq2sdbg --need_mercy (mercy.hip / comm.hip)
+  int my_part = 0, n_parts = 1;
+  std::function<void(uint8_t *d_flags, uint64_t n)> reduce_flags;  // bitwise OR of the per-position flags over the ranks
+};
 int run_gen_mercy(mhx_ctx *c, uint32_t k, const uint32_t *cand_packed, uint64_t cand_words, uint64_t n_cand,
-                  const uint64_t *cand_start, uint64_t *n_mercy);
+                  const uint64_t *cand_start, uint64_t *n_mercy, const MercyShare *share = nullptr);
 void upload_sequences(mhx_ctx *c, const uint32_t *packed, uint64_t n_words, uint64_t n_seqs, uint32_t fixed_len,
                       const uint64_t *start_pos);
 void upload_fixed_starts(mhx_ctx *c);

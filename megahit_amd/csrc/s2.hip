@@ -567,6 +567,68 @@ void emit_sdbg(mhx_ctx *c, const uint32_t *sorted, uint64_t n_items, int S, int 
   }
 }
 
+// ---- SdBG outputs of several bucket-range passes kept on the device (multi-GPU passes, comm.hip): every bucket is
+// produced by exactly one pass, the byte streams concatenate in pass order, the per-bucket tables add up.
+__global__ void k_sdbg_acc_tables(const unsigned long long *__restrict__ cnt, const unsigned long long *__restrict__ tips,
+                                  const unsigned long long *__restrict__ large, const unsigned long long *__restrict__ off,
+                                  unsigned long long prev_bytes, unsigned long long *__restrict__ a_cnt, unsigned long long *__restrict__ a_tips,
+                                  unsigned long long *__restrict__ a_large, unsigned long long *__restrict__ a_off) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= MHX_NUM_BUCKETS || !cnt[b]) return;
+  a_cnt[b] += cnt[b];
+  a_tips[b] += tips[b];
+  a_large[b] += large[b];
+  a_off[b] = off[b] + prev_bytes;
+}
+__global__ void k_add_u64(unsigned long long *__restrict__ a, const unsigned long long *__restrict__ b, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) a[i] += b[i];
+}
+void sdbg_accumulate(mhx_ctx *c, bool first) {
+  hipStream_t st = c->stream;
+  static const int tabs[4] = {MHX_BUF_BUCKET_COUNT, MHX_BUF_BUCKET_TIPS, MHX_BUF_BUCKET_LARGE, MHX_BUF_BUCKET_OFFSET};
+  static const char *names[4] = {"acc_bucket_count", "acc_bucket_tips", "acc_bucket_large", "acc_bucket_offset"};
+  unsigned long long *acc[4];
+  for (int i = 0; i < 4; ++i) {
+    acc[i] = c->ws(names[i], MHX_NUM_BUCKETS * 8).as<unsigned long long>();
+    if (first) MHX_HIP(hipMemsetAsync(acc[i], 0, MHX_NUM_BUCKETS * 8, st));
+  }
+  unsigned long long *acc_w = c->ws("acc_w_count", 80).as<unsigned long long>();
+  if (first) {
+    MHX_HIP(hipMemsetAsync(acc_w, 0, 80, st));
+    c->work["acc_sdbg_bytes"].used = 0;
+  }
+  DevBuf &src = c->results[MHX_BUF_SDBG_BYTES];
+  const uint64_t prev = c->work["acc_sdbg_bytes"].used;
+  DevBuf &dst = grow_preserving(c, c->work["acc_sdbg_bytes"], prev + src.used + 64, prev);
+  if (src.used) MHX_HIP(hipMemcpyAsync(reinterpret_cast<char *>(dst.p) + prev, src.p, src.used, hipMemcpyDeviceToDevice, st));
+  dst.used = prev + src.used;
+  hipLaunchKernelGGL(k_sdbg_acc_tables, dim3(MHX_NUM_BUCKETS / 256), dim3(256), 0, st, c->results[tabs[0]].as<unsigned long long>(),
+                     c->results[tabs[1]].as<unsigned long long>(), c->results[tabs[2]].as<unsigned long long>(),
+                     c->results[tabs[3]].as<unsigned long long>(), (unsigned long long)prev, acc[0], acc[1], acc[2], acc[3]);
+  hipLaunchKernelGGL(k_add_u64, dim3(1), dim3(64), 0, st, acc_w, c->results[MHX_BUF_W_COUNT].as<unsigned long long>(), 10);
+  MHX_HIP(hipGetLastError());
+  MHX_HIP(hipStreamSynchronize(st));
+}
+// the accumulated outputs become the handle's SdBG result buffers
+void sdbg_publish_accumulated(mhx_ctx *c) {
+  static const int tabs[4] = {MHX_BUF_BUCKET_COUNT, MHX_BUF_BUCKET_TIPS, MHX_BUF_BUCKET_LARGE, MHX_BUF_BUCKET_OFFSET};
+  static const char *names[4] = {"acc_bucket_count", "acc_bucket_tips", "acc_bucket_large", "acc_bucket_offset"};
+  MHX_HIP(hipStreamSynchronize(c->stream));
+  for (int i = 0; i < 4; ++i) {
+    std::swap(c->results[tabs[i]].p, c->work[names[i]].p);
+    std::swap(c->results[tabs[i]].cap, c->work[names[i]].cap);
+    c->results[tabs[i]].used = MHX_NUM_BUCKETS * 8;
+  }
+  std::swap(c->results[MHX_BUF_W_COUNT].p, c->work["acc_w_count"].p);
+  std::swap(c->results[MHX_BUF_W_COUNT].cap, c->work["acc_w_count"].cap);
+  c->results[MHX_BUF_W_COUNT].used = 80;
+  const uint64_t used = c->work["acc_sdbg_bytes"].used;
+  std::swap(c->results[MHX_BUF_SDBG_BYTES].p, c->work["acc_sdbg_bytes"].p);
+  std::swap(c->results[MHX_BUF_SDBG_BYTES].cap, c->work["acc_sdbg_bytes"].cap);
+  c->results[MHX_BUF_SDBG_BYTES].used = used;
+}
+
 // fewest 8-bit passes covering the given bit ranges (ascending, disjoint; at most two): the bits of the
 // ranges are concatenated into one virtual key, so a digit may consist of the top of one range and the
 // bottom of the next (two-field digit) instead of wasting a pass on a partial digit per range.

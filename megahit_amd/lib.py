@@ -142,6 +142,7 @@ SYMBOLS = {
     "mhx_dist_read2sdbg": (C.c_int, [_P, _P, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(S1Result), C.POINTER(SdbgResult), _P]),
     "mhx_dist_count": (C.c_int, [_P, _P, C.c_uint32, C.c_uint32, C.POINTER(CountResult)]),
     "mhx_dist_seq2sdbg": (C.c_int, [_P, _P, C.c_uint32, C.POINTER(SdbgResult)]),
+    "mhx_dist_gen_mercy_edges": (C.c_int, [_P, _P, C.c_uint32, _P, C.c_uint64, C.c_uint64, _P, C.POINTER(C.c_uint64)]),
     "mhx_device_free_bytes": (C.c_uint64, [_P]),
     "mhx_bucket_histogram": (C.c_int, [_P, C.c_int, C.c_uint32, C.c_uint32, _P]),
     "mhx_set_bucket_filter": (C.c_int, [_P, _P, C.c_uint64, C.c_uint64, C.c_int]),
@@ -479,3 +480,11 @@ class Comm:
         r = SdbgResult()
         self._chk(self.lib.mhx_dist_seq2sdbg(self.e.h, self.h, k, C.byref(r)))
         return r
+
+    def gen_mercy_edges(self, k, cand_packed, n_cand, cand_start):
+        """collective: every rank passes ALL candidate reads; returns the number of all mercy edges"""
+        cand_packed = np.ascontiguousarray(cand_packed, dtype=np.uint32)
+        cand_start = np.ascontiguousarray(cand_start, dtype=np.uint64)
+        n = C.c_uint64(0)
+        self._chk(self.lib.mhx_dist_gen_mercy_edges(self.e.h, self.h, k, _ptr(cand_packed), cand_packed.size, n_cand, _ptr(cand_start), C.byref(n)))
+        return n.value

@@ -90,6 +90,10 @@ def check_sdbg(outs, want):
     (2, 21, 2, 0, {"s1_stream_probes": 0}),                  # pre-sorted sources, the table gives up -> gathered, tile kernel
     (3, 21, 3, STAGE_S1, None),                              # m = 3: the marks need the second read over every source
     (3, 21, 2, 0, {"s1_stream_direct": 0}),                  # marks from the second read instead of the table
+    # bucket-range passes on several ranks (base_engine.cpp:54-141): every stage runs over several sub-ranges of every owner's buckets
+    (3, 21, 2, STAGE_S1, {"dist_max_items": 40000}),
+    (2, 21, 1, 0, {"dist_max_items": 60000}),                # m = 1: stage 2 per occurrence
+    (2, 27, 2, 0, {"dist_max_items": 40000}),                # 16-byte records: owner multisplit path, passes
 ])
 def test_read2sdbg_ranks_as_threads(world, k, m, balance, opts):
     def body(r, e, cm):
@@ -110,14 +114,14 @@ def test_read2sdbg_ranks_as_threads(world, k, m, balance, opts):
     check_sdbg(outs, want)
 
 
-@pytest.mark.parametrize("world,k,m,mercy", [(2, 21, 2, 1), (3, 27, 3, 1), (2, 21, 2, 2)])
-def test_read2sdbg_mercy_ranks_as_threads(world, k, m, mercy):
+@pytest.mark.parametrize("world,k,m,mercy,opts", [(2, 21, 2, 1, None), (3, 27, 3, 1, None), (2, 21, 2, 2, None), (2, 21, 2, 1, {"dist_max_items": 50000})])
+def test_read2sdbg_mercy_ranks_as_threads(world, k, m, mercy, opts):
     def body(r, e, cm):
         cm.setup(0, k, m)
         _r1, _r2, nm = cm.read2sdbg(k, m, need_mercy=mercy)
         return sdbg_of(e) + (nm,)
 
-    outs = run_ranks(world, load_reads, body)
+    outs = run_ranks(world, load_reads, body, opts)
     pkg = all_reads(world)
     s1 = ob.s1(pkg, k, m, tie_stable=mercy == 1)
     n_want, solid = ob.s2_add_mercy(pkg, k, s1["is_solid"], s1["mercy"])
@@ -141,15 +145,15 @@ def test_rank_tagged_records_with_sparse_marks(monkeypatch):
     check_sdbg(outs, ob.s2(pkg, k, m, s1["is_solid"]))
 
 
-@pytest.mark.parametrize("world,k,m", [(2, 21, 2), (3, 31, 3)])
-def test_count_ranks_as_threads(world, k, m):
+@pytest.mark.parametrize("world,k,m,opts", [(2, 21, 2, None), (3, 31, 3, None), (3, 21, 2, {"dist_max_items": 30000})])
+def test_count_ranks_as_threads(world, k, m, opts):
     def body(r, e, cm):
         cm.setup(STAGE_COUNT, k, m)
         cm.count(k, m)
         return (e.fetch(lib.BUF_EDGES, np.uint32), e.fetch(lib.BUF_BUCKET_COUNT, np.uint64), e.fetch(lib.BUF_MUL_HIST, np.int64),
                 e.fetch(lib.BUF_FIRST_0_OUT, np.uint32), e.fetch(lib.BUF_LAST_0_IN, np.uint32))
 
-    outs = run_ranks(world, load_reads, body)
+    outs = run_ranks(world, load_reads, body, opts)
     want = ob.count(all_reads(world), k, m)
     assert np.array_equal(np.concatenate([o[0] for o in outs]).reshape(-1, want["wpe"]), want["edges"])
     assert np.array_equal(sum(o[1] for o in outs), want["bucket_count"])
@@ -158,8 +162,8 @@ def test_count_ranks_as_threads(world, k, m):
     assert np.array_equal(np.concatenate([o[4] for o in outs]), want["last_0_in"])
 
 
-@pytest.mark.parametrize("world,k", [(2, 21), (3, 39)])
-def test_seq2sdbg_ranks_as_threads(world, k):
+@pytest.mark.parametrize("world,k,opts", [(2, 21, None), (3, 39, None), (3, 39, {"dist_max_items": 3000})])
+def test_seq2sdbg_ranks_as_threads(world, k, opts):
     def load(r, e):
         seqs, mult = _seqs_with_mult(50 + r)
         pkg = ob.Package(seqs, reverse=False)
@@ -171,7 +175,7 @@ def test_seq2sdbg_ranks_as_threads(world, k):
         cm.seq2sdbg(k)
         return sdbg_of(e)
 
-    outs = run_ranks(world, load, body)
+    outs = run_ranks(world, load, body, opts)
     seqs, mult = [], []
     for r in range(world):
         s, m_ = _seqs_with_mult(50 + r)
@@ -198,7 +202,9 @@ def test_rccl_transport_single_rank():
 
 
 @pytest.mark.parametrize("ent", [e for e in gu.cases() if e["case"]["prog"] in ("count", "read2sdbg")][:6] +
-                         [e for e in gu.cases() if e["case"]["prog"] == "seq2sdbg" and e["case"].get("input") == "count" and not e["case"].get("mercy")][:2],
+                         [e for e in gu.cases() if e["case"]["prog"] == "seq2sdbg" and e["case"].get("input") == "count" and not e["case"].get("mercy")][:2] +
+                         # seq2sdbg --need_mercy (the orchestrator's default k_min route): edges sharded, candidate reads everywhere
+                         [e for e in gu.cases() if e["case"]["prog"] == "seq2sdbg" and e["case"].get("input") == "count" and e["case"].get("mercy")][:3],
                          ids=gu.case_id)
 @pytest.mark.parametrize("gpus", [2, 3])
 def test_cli_gpus_flag_reproduces_reference(ent, gpus, tmp_path, monkeypatch):
