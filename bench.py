@@ -50,35 +50,44 @@ def make_reads(n_reads, rank, world):
     return np.concatenate(chunks)
 
 
+PMC_FILE = "profiles/r03_pmc_traffic.json"
+
+
 def pmc_traffic(kernel_name, path=None):
-    """HBM bytes per launch of `kernel_name` measured with rocprofv3 PMC passes on THIS workload and THIS tree
-    (profiles/r02_pmc_traffic.json, produced by tools/gpu_evidence.sh -> tools/pmc_to_json.py with the gfx950
+    """HBM bytes per launch of `kernel_name` measured with rocprofv3 PMC passes on THIS workload and THIS build
+    (profiles/r03_pmc_traffic.json, produced by tools/gpu_evidence.sh -> tools/pmc_to_json.py with the gfx950
     FETCH_SIZE x2 correction).  Counters cannot be collected from inside the timed run, so the committed measurement is
-    reported — but only when it was taken on the same kernel sources (megahit_amd/buildid.py): otherwise null."""
-    path = path or os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+    reported — but only when it was taken on the same kernel sources AND the same built library (megahit_amd/buildid.py:
+    sha256 of the sources, sha256 of libmhx.so): otherwise null."""
+    path = path or os.path.join(ROOT, PMC_FILE)
     try:
-        from megahit_amd.buildid import build_id
+        from megahit_amd.buildid import build_id, lib_id
         with open(path) as f:
             doc = json.load(f)
         if doc.get("build_id") != build_id():
-            return None, "profiles/r02_pmc_traffic.json was measured on other kernel sources (build_id %s, running %s)" % (doc.get("build_id"), build_id())
+            return None, "%s was measured on other kernel sources (build_id %s, running %s)" % (PMC_FILE, doc.get("build_id"), build_id())
+        if doc.get("lib_id") is not None and doc.get("lib_id") != lib_id():
+            return None, "%s was measured with another build of libmhx.so (lib_id %s, running %s)" % (PMC_FILE, doc.get("lib_id"), lib_id())
         kernels = doc["kernels"]
     except Exception:
         return None, None
     # profile name -> kernel symbol prefix
-    table = {"s1_groups": ("k_s1_seg<", "k_tile_groups<3"), "count_groups": ("k_count_seg<",), "s1_extract": ("k_s1_extract_fixed<", "k_s1_extract<"),
-             "count_extract": ("k_count_extract<",)}
+    table = {"s1_groups": ("k_s1_stream<", "k_s1_seg<", "k_tile_groups<3"), "count_groups": ("k_count_seg<",),
+             "s1_extract": ("k_s1_extract_fast<", "k_s1_extract_fixed<", "k_s1_extract<"), "s1_digit_hist": ("k_s1_extract_fast<4, false",),
+             "count_extract": ("k_count_extract<",), "radix_scatter_12B_gen": ("k_radix_onesweep<3, 8, 3, S1Gen",)}
     prefixes = list(table.get(kernel_name, ()))
     for stem, names in (("radix_scatter_", ("k_radix_onesweep", "k_radix_scatter")), ("radix_hist_all_", ("k_radix_hist_all",)),
                         ("radix_hist_", ("k_radix_hist",))):
-        if kernel_name.startswith(stem) and kernel_name.endswith("B") and kernel_name[len(stem):-1].isdigit():
-            prefixes = ["%s<%d," % (nm, int(kernel_name[len(stem):-1]) // 4) for nm in names] + \
-                       ["%s<%d>" % (nm, int(kernel_name[len(stem):-1]) // 4) for nm in names]
+        if not prefixes and kernel_name.startswith(stem) and kernel_name.endswith("B") and kernel_name[len(stem):-1].isdigit():
+            w = int(kernel_name[len(stem):-1]) // 4
+            # (the chained-scan kernel that LOADS its records: SrcArray; the generated first pass has a name of its own)
+            prefixes = ["%s<%d, 8, 3, SrcArray" % (names[0], w), "%s<%d, 8, 2, SrcArray" % (names[0], w)] + \
+                       ["%s<%d," % (nm, w) for nm in names] + ["%s<%d>" % (nm, w) for nm in names]
             break
     for prefix in prefixes:
         for k, v in kernels.items():
             if k.startswith(prefix):
-                return v["hbm_bytes"], "profiles/r02_pmc_traffic.json:" + k
+                return v["hbm_bytes"], PMC_FILE + ":" + k
     return None, None
 
 
@@ -144,7 +153,7 @@ def cpu_baseline(sample_reads, threads=None):
            "sample": "read2sdbg k=%d m=%d on %d synthetic %d bp reads (%.1f M edges), best wall %.1f s incl. file I/O"
                      % (K, MIN_COUNT, reads.shape[0], READ_LEN, E / 1e6, tried[best])}
     try:
-        with open(os.path.join(ROOT, "profiles", "r02_cpu_fullsize.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r03_cpu_fullsize.json" if os.path.exists(os.path.join(ROOT, "profiles", "r03_cpu_fullsize.json")) else "r02_cpu_fullsize.json")) as f:
             out["full_size"] = json.load(f)
     except Exception:
         pass
@@ -181,17 +190,11 @@ def end_to_end(n_reads):
     with tempfile.TemporaryDirectory(prefix="mhx_e2e_") as d:
         mfg.gen_library(os.path.join(d, "reads"), n_reads)
         common = ["-k", str(K), "-m", str(MIN_COUNT), "--host_mem", "64e9", "--num_cpu_threads", "8", "--read_lib_file", os.path.join(d, "reads")]
-        t_all = time.perf_counter()
-        r2s = [call(["read2sdbg"] + common + ["--output_prefix", os.path.join(d, "out")]) for _ in range(2)]
-        t_cnt, ph_cnt = call(["count"] + common + ["--output_prefix", os.path.join(d, "cnt")])
-        t_s2s, ph_s2s = call(["seq2sdbg", "-k", str(K), "--kmer_from", "0", "--host_mem", "64e9", "--num_cpu_threads", "8", "--input_prefix",
-                              os.path.join(d, "cnt"), "--need_mercy", "--output_prefix", os.path.join(d, "s2m")])
-        t_all = time.perf_counter() - t_all
-        digest = canon.digest_sdbg(os.path.join(d, "out"))
-        digest_route = canon.digest_sdbg(os.path.join(d, "s2m"))
-        # the same four sub-programs through the resident server (mhx_core --serve: one process keeps the handle and its
-        # device buffers): what a pipeline that exports MHX_SERVER pays per sub-program
+        # Through the resident server first, on a quiet device (mhx_core --serve: one process keeps the handle and its device
+        # buffers): what a pipeline that exports MHX_SERVER pays per sub-program.  "cold" = the server's first
+        # three requests (handle creation, every buffer allocated for the first time), "steady" = the same three again.
         served = None
+        outs = {}
         try:
             sock = os.path.join(d, "mhx.sock")
             srv = subprocess.Popen([mhx, "--serve", sock], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, env=dict(os.environ, MHX_SERVE_IDLE_S="60"))
@@ -200,17 +203,17 @@ def end_to_end(n_reads):
                     break
                 time.sleep(0.02)
             os.environ["MHX_SERVER"] = sock
-            call(["read2sdbg"] + common + ["--output_prefix", os.path.join(d, "w")])  # the first request creates the handle and grows the buffers
-            t0 = time.perf_counter()
-            s_r2s, ph_r2s = call(["read2sdbg"] + common + ["--output_prefix", os.path.join(d, "sv")])
-            s_cnt, ph_sc = call(["count"] + common + ["--output_prefix", os.path.join(d, "scnt")])
-            s_s2s, ph_ss = call(["seq2sdbg", "-k", str(K), "--kmer_from", "0", "--host_mem", "64e9", "--num_cpu_threads", "8", "--input_prefix",
-                                 os.path.join(d, "scnt"), "--need_mercy", "--output_prefix", os.path.join(d, "ss2m")])
-            t_served = time.perf_counter() - t0
-            served = {"read2sdbg_s": round(s_r2s, 3), "count_s": round(s_cnt, 3), "seq2sdbg_need_mercy_s": round(s_s2s, 3),
-                      "default_route_back_to_back_s": round(s_cnt + s_s2s, 3), "three_requests_back_to_back_s": round(t_served, 3),
-                      "phases_read2sdbg_s": ph_r2s, "phases_count_s": ph_sc, "phases_seq2sdbg_s": ph_ss,
-                      "digests_equal_process_runs": canon.digest_sdbg(os.path.join(d, "sv")) == digest and canon.digest_sdbg(os.path.join(d, "ss2m")) == digest_route}
+            served = {}
+            for label in ("cold", "steady"):
+                t0 = time.perf_counter()
+                s_r2s, ph_r2s = call(["read2sdbg"] + common + ["--output_prefix", os.path.join(d, "sv")])
+                s_cnt, ph_sc = call(["count"] + common + ["--output_prefix", os.path.join(d, "scnt")])
+                s_s2s, ph_ss = call(["seq2sdbg", "-k", str(K), "--kmer_from", "0", "--host_mem", "64e9", "--num_cpu_threads", "8", "--input_prefix",
+                                     os.path.join(d, "scnt"), "--need_mercy", "--output_prefix", os.path.join(d, "ss2m")])
+                served[label] = {"read2sdbg_s": round(s_r2s, 3), "count_s": round(s_cnt, 3), "seq2sdbg_need_mercy_s": round(s_s2s, 3),
+                                 "default_route_back_to_back_s": round(s_cnt + s_s2s, 3), "three_requests_back_to_back_s": round(time.perf_counter() - t0, 3),
+                                 "phases_read2sdbg_s": ph_r2s, "phases_count_s": ph_sc, "phases_seq2sdbg_s": ph_ss}
+            outs = {"sv": canon.digest_sdbg(os.path.join(d, "sv")), "ss2m": canon.digest_sdbg(os.path.join(d, "ss2m"))}
         except Exception as ex:
             served = {"error": str(ex)[-300:]}
         finally:
@@ -223,6 +226,16 @@ def end_to_end(n_reads):
                     srv.kill()
                 except Exception:
                     pass
+        t_all = time.perf_counter()
+        r2s = [call(["read2sdbg"] + common + ["--output_prefix", os.path.join(d, "out")]) for _ in range(2)]
+        t_cnt, ph_cnt = call(["count"] + common + ["--output_prefix", os.path.join(d, "cnt")])
+        t_s2s, ph_s2s = call(["seq2sdbg", "-k", str(K), "--kmer_from", "0", "--host_mem", "64e9", "--num_cpu_threads", "8", "--input_prefix",
+                              os.path.join(d, "cnt"), "--need_mercy", "--output_prefix", os.path.join(d, "s2m")])
+        t_all = time.perf_counter() - t_all
+        digest = canon.digest_sdbg(os.path.join(d, "out"))
+        digest_route = canon.digest_sdbg(os.path.join(d, "s2m"))
+        if served and "error" not in served:
+            served["digests_equal_process_runs"] = outs.get("sv") == digest and outs.get("ss2m") == digest_route
     dt, phases = r2s[1]
     out = {"wall_s": round(dt, 3), "wall_s_first_run": round(r2s[0][0], 3), "M_edges_per_s": round(n_reads * (READ_LEN - K) / dt / 1e6, 1),
            "phases_s": phases, "digest": digest,
@@ -441,6 +454,11 @@ def main():
                           "lv1 buckets over %d GPUs (C++ driver, RCCL ncclSend/ncclRecv all-to-all, marks routed to the read owners)" % world},
                "roofline": roof,
                "parity_checked": bool(parity["checked"]) if parity else None, "parity": parity}
+        try:
+            from megahit_amd.buildid import build_id, lib_id
+            out["build_id"], out["lib_id"] = build_id(), lib_id()
+        except Exception:
+            pass
         if use_dist:
             out["config"]["rank0_s1_items"] = int(res[0].n_items)
             out["config"]["rank0_s2_items"] = int(res[1].n_items)

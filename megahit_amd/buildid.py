@@ -8,6 +8,18 @@ import os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def lib_id():
+    """sha256 of the built library itself (what actually runs); None when it is not built"""
+    try:
+        h = hashlib.sha256()
+        with open(os.path.join(ROOT, "megahit_amd", "libmhx.so"), "rb") as fh:
+            for chunk in iter(lambda: fh.read(1 << 20), b""):
+                h.update(chunk)
+        return h.hexdigest()[:16]
+    except OSError:
+        return None
+
+
 def build_id():
     h = hashlib.sha256()
     src = os.path.join(ROOT, "megahit_amd", "csrc")

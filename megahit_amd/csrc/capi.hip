@@ -516,6 +516,10 @@ mhx_ctx *mhx_create(int device) {
     mhx_ctx *c = new mhx_ctx();
     c->device = device;
     MHX_HIP(hipStreamCreate(&c->stream));
+    {
+      hipDeviceProp_t prop;
+      if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->n_cus = prop.multiProcessorCount;
+    }
     // ranking inside the radix scatter: ballot match-any (default, order-independent by construction);
     // MHX_SORT_RANK=atomic opts into one returning LDS atomic per record, used only if the device passes
     // the lane-order probe (measured on MI355X: probe passes, gain < 2 %, so it is not the default)

@@ -136,6 +136,9 @@ struct mhx_comm {
   uint64_t max_msg_bytes = 1ull << 28;  // 256 MiB per message (one 16 GB message hung RCCL 2.26 on MI355X)
   // agreed layout
   uint64_t stride_bases = 0;
+  // stages that were found to need no bucket-range passes since the last mhx_dist_setup (key: stage, k, m): the check costs
+  // an all-reduce and a hipMemGetInfo per call; every rank sees the same calls, so the caches agree
+  std::vector<uint64_t> one_pass_ok;
 
   // ---- collectives on small host vectors ----
   void all_reduce(std::vector<uint64_t> &v, bool is_max) {
@@ -283,6 +286,13 @@ static bool dist_s1_presorted(mhx_ctx *c, mhx_comm *cm, uint32_t k, uint32_t m, 
   hipStream_t st = c->stream;
   uint32_t *a = c->work["items_a"].as<uint32_t>();
   uint32_t *b = c->ws("items_b", it.n * 12 + 64).as<uint32_t>();
+  if (c->gen_first_pass && c->pre_hist_sig != passes_signature(make_passes(2, 48, 64))) {
+    // deferred items, but this rank's own plan was not the two-pass one the ranks agreed on: materialise them the plain way
+    c->gen_first_pass = nullptr;
+    const StageItems again = extract_stage(c, MHX_STAGE_S1, k, m);
+    if (again.n != it.n) throw Error("dist_s1_presorted: item count changed");
+    a = c->work["items_a"].as<uint32_t>();
+  }
   uint32_t *sorted = it.n ? s1_presort(c, k, a, b, it.n) : a;
   uint64_t *d_bounds = c->ws("dist_bounds", (MHX_NUM_BUCKETS + 2) * 8).as<uint64_t>();
   std::vector<uint64_t> bounds(MHX_NUM_BUCKETS + 1, 0);
@@ -344,7 +354,9 @@ static DistPasses plan_dist_passes(mhx_ctx *c, mhx_comm *cm, int stage, uint32_t
   const double per_item = 4.0 * (double)item_bytes + 1.0;
   uint64_t max_items = (uint64_t)c->opt("dist_max_items", 0);
   if (const char *e = getenv("MHX_MAX_ITEMS")) max_items = strtoull(e, nullptr, 10);
+  const uint64_t plan_key = ((uint64_t)stage << 48) | ((uint64_t)k << 16) | (uint64_t)(m & 0xFFFFu);
   if (!max_items && !getenv("MHX_FREE_BYTES")) {
+    if (std::find(cm->one_pass_ok.begin(), cm->one_pass_ok.end(), plan_key) != cm->one_pass_ok.end()) return dp;
     // the usual case decided without a scan of the reads: an upper bound of the items of the whole job (stage 1 / count:
     // one per base + 4 per read; stage 2 per occurrence, seq2sdbg: ~2 per base), twice the fair share per rank
     const mhx::SeqSet &s = c->seqs;
@@ -353,7 +365,10 @@ static DistPasses plan_dist_passes(mhx_ctx *c, mhx_comm *cm, int stage, uint32_t
     std::vector<uint64_t> mx = v;
     cm->all_reduce(mx, true);
     const double fit = (double)(~0ull - mx[1]) * 0.8 / per_item;
-    if (2.0 * (double)mx[0] <= fit) return dp;  // (the largest local bound stands in for every rank's share)
+    if (2.0 * (double)mx[0] <= fit) {  // (the largest local bound stands in for every rank's share)
+      cm->one_pass_ok.push_back(plan_key);
+      return dp;
+    }
   }
   std::vector<uint64_t> hist(MHX_NUM_BUCKETS, 0);
   const uint64_t saved = c->global_bases;
@@ -543,6 +558,7 @@ int mhx_dist_setup(mhx_ctx *c, mhx_comm *cm, int balance_stage, uint32_t k, uint
     }
     MHX_CK(mhx_set_global_layout(c, (uint64_t)cm->rank * cm->stride_bases, (uint64_t)n * cm->stride_bases));
     c->options["dist_sparse_marks"] = 1;
+    cm->one_pass_ok.clear();
   })
 }
 
@@ -563,9 +579,17 @@ int mhx_dist_read2sdbg(mhx_ctx *c, mhx_comm *cm, uint32_t k, uint32_t min_count,
         mhx_s1_result rp{};
         bool done = false;
         if (!need_mercy) {
-          const mhx::StageItems it = mhx::extract_stage(c, MHX_STAGE_S1, k, min_count);
+          // (the pre-sort's first pass may make the records itself: then "items_a" holds nothing yet — s1.hip, S1Gen)
+          c->gen_first_pass = nullptr;
+          c->s1_defer_items = !c->filter_on && c->opt("dist_presort", 1);
+          mhx::StageItems it = mhx::extract_stage(c, MHX_STAGE_S1, k, min_count);
+          c->s1_defer_items = false;
           done = mhx::dist_s1_presorted(c, cm, k, min_count, it, &rp);
           if (!done) {  // the classic exchange of the items extracted above: owner multisplit, all-to-all, sort at the owner
+            if (c->gen_first_pass) {  // ... which were deferred to a sort that will not happen: make them now
+              c->gen_first_pass = nullptr;
+              it = mhx::extract_stage(c, MHX_STAGE_S1, k, min_count);
+            }
             c->pre_hist_buf = nullptr;
             mhx_dist_items di{};
             std::vector<uint64_t> counts(cm->n, 0);

@@ -85,6 +85,8 @@ __global__ void k_fastq_records(const char *__restrict__ t, uint64_t n, const ui
   // would then be taken as sequence...): anything but the plain shape goes to the sequential parser
   if (l0 == 0 || t[b0] != '@' || l2 == 0 || t[b2] != '+' || l1 != l3 || l1 == 0 || (l1 >> 31)) {
     atomicOr(bad, 1u);
+    seq_start[r] = 0;  // the kernels that follow are launched regardless of *bad: give them an empty, in-bounds record
+    seq_len[r] = 0;    // (the workspace is never zeroed: stale values here would be read as an address and a length)
     return;
   }
   const char c1 = t[b1];

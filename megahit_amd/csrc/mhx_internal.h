@@ -15,6 +15,7 @@
 
 namespace mhx {
 
+struct OnesweepLaunch;
 void set_error(const char *fmt, ...);
 
 struct Error : std::runtime_error {
@@ -68,6 +69,7 @@ struct SeqSet {
 
 struct mhx_ctx {
   int device = 0;
+  int n_cus = 0;  // compute units of the device (0: unknown)
   hipStream_t stream = nullptr;
   mhx::SeqSet seqs;
   std::map<int, mhx::DevBuf> results;      // keyed by enum mhx_buffer
@@ -91,6 +93,12 @@ struct mhx_ctx {
   uint64_t pre_hist_n = 0;
   int pre_hist_passes = 0;
   uint64_t pre_hist_sig = 0;  // passes_signature() of the plan the histograms were taken for
+  // first sort pass whose records are generated instead of loaded (sort_kernels.h OnesweepLaunch; set by s1.hip, consumed by
+  // the next radix_sort on exactly this buffer and item count): the buffer then holds NO items yet
+  std::function<void(const mhx::OnesweepLaunch &)> gen_first_pass;
+  const void *gen_buf = nullptr;
+  uint64_t gen_n = 0;
+  bool s1_defer_items = false;  // the caller of extract_stage(S1) will sort right away: s1_extract may defer the items to that sort
   // memory-bounded passes (passes.hip): only items of the kept lv1 buckets are materialised
   bool filter_on = false, accumulate = false;
   uint64_t filter_expected = 0, filter_batch_bytes = 0;
@@ -158,6 +166,7 @@ uint32_t *radix_sort(mhx_ctx *c, uint32_t *buf_a, uint32_t *buf_b, uint64_t n, i
 uint32_t *sort_whole_key(mhx_ctx *c, uint32_t *buf_a, uint32_t *buf_b, uint64_t n, int stride, int key_words,
                          const std::vector<SortPass> &passes);
 std::vector<SortPass> make_passes(int key_words, int lo_bit, int hi_bit);
+bool sort_takes_generated_first_pass(const mhx_ctx *c, uint64_t n, int stride, const std::vector<SortPass> &passes);
 uint64_t passes_signature(const std::vector<SortPass> &ps);
 bool probe_lds_atomic_order(mhx_ctx *c);
 // kmsort_emu.hip: sort with the reference's exact (unstable) tie order, one GPU thread per lv1 bucket

@@ -19,6 +19,7 @@
 
 #include "mhx_internal.h"
 #include "sort_digits.h"
+#include "sort_kernels.h"
 #include "tile_groups.h"
 
 namespace mhx {
@@ -175,13 +176,71 @@ __device__ __forceinline__ uint64_t rc64(uint64_t x, int n);
 //   * read index and slot advance incrementally with the persistent loop (the per-iteration stride of the workgroup,
 //     divided by the items per read, comes from the host), the only division left is a 32-bit one.
 // Same output, bit for bit, as k_s1_extract_fixed<2, 3, true> (read_to_sdbg_s1.cpp:228-292, :344-363).
+// one stage-1 record of a fixed-length read set from the 64-bit window around its (k-1)-mer: read r, slot j (see above)
+__device__ __forceinline__ void s1_fast_item(const uint32_t *__restrict__ seq, uint32_t L, int k, uint64_t r, uint32_t j, uint64_t pos_base,
+                                             uint32_t rank_tag, uint32_t (&out)[3]) {
+  const int km1 = k - 1;
+  const uint64_t st = r * L;
+  uint32_t q;
+  int forced = -1;
+  if (j < 2) { q = 0; forced = (int)j; }
+  else if (j >= L - k + 2) { q = L - k + 1; forced = (int)(j - (L - k + 2)); }
+  else q = j - 1;
+  const uint64_t a = st + q;
+  if (a < 2) {  // the first two bases of the store: no window in front of them
+    s1_make_item<2, 3, true>(seq, st, L, k, j, pos_base, rank_tag, out);
+    return;
+  }
+  const uint64_t b = a - 2, w = b >> 4;
+  const unsigned sh = (unsigned)(b & 15) * 2;
+  const uint32_t x0 = seq[w], x1 = seq[w + 1], x2 = seq[w + 2];
+  const uint64_t win = ((uint64_t)funnel_l(x0, x1, sh) << 32) | funnel_l(x1, x2, sh);
+  const unsigned head_b = (unsigned)(win >> 60) & 3u, tail_b = (unsigned)(win >> (58 - 2 * km1)) & 3u;
+  const uint64_t f = (win << 4) & (~0ull << (64 - 2 * km1));
+  const uint64_t rc = rc64(f, km1);
+  const unsigned head = q >= 1 ? head_b : kSentinel;
+  const unsigned tail = q + k - 1 < L ? tail_b : kSentinel;
+  int strand;
+  if (forced >= 0) strand = forced;
+  else strand = f > rc ? 1 : (f < rc ? 0 : (head <= 3 - tail ? 0 : 1));
+  const uint64_t key = strand ? (rc | (comp_or_sentinel(tail) << 3) | comp_or_sentinel(head)) : (f | (head << 3) | tail);
+  out[0] = (uint32_t)(key >> 32);
+  out[1] = (uint32_t)key | rank_tag;
+  out[2] = (uint32_t)(pos_base + a);
+}
+
+// The same records as a SOURCE of the first chained-scan pass (sort_kernels.h): no record array is written by the
+// extraction and read back by the sort — 16 GB each way at 10 M reads.  The digit histograms the chained scan needs
+// beforehand come from k_s1_extract_fast<IT, false>, the same arithmetic without the stores.
+struct S1Gen {
+  const uint32_t *seq;
+  uint32_t L, per;
+  int k;
+  uint64_t pos_base;
+  uint32_t rank_tag;
+  template <int NI>
+  __device__ __forceinline__ void get(uint64_t first, uint64_t n, Rec<3> (&rec)[NI]) const {
+    uint64_t r = first / per;  // one 64-bit division per tile and thread, then read and slot advance with the items
+    uint32_t j = (uint32_t)(first - r * per);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      if (first + (uint64_t)i * kWave < n) s1_fast_item(seq, L, k, r, j, pos_base, rank_tag, rec[i].w);
+      j += kWave;
+      while (j >= per) {
+        j -= per;
+        ++r;
+      }
+    }
+  }
+};
+
 constexpr int kFastPasses = 4;
-template <int IT>  // items per thread and trip: their window loads are issued together (one in flight per thread = latency-bound)
+template <int IT, bool WRITE>  // items per thread and trip; WRITE = false: only the digit histograms: their window loads are issued together (one in flight per thread = latency-bound)
 __global__ __launch_bounds__(256) void k_s1_extract_fast(const uint32_t *__restrict__ seq, uint32_t L, uint32_t per, uint64_t n_items, int k,
                                                          uint64_t pos_base, uint32_t rank_tag, uint32_t *__restrict__ items, DigitSpecs specs,
                                                          unsigned long long *__restrict__ ghist, uint32_t step_q, uint32_t step_r) {
   constexpr int B = 256 * IT;  // items per workgroup and trip
-  __shared__ uint32_t xpose[B * 3];
+  __shared__ uint32_t xpose[WRITE ? B * 3 : 1];
   // digit histograms of the coming sort passes (at most kFastPasses of them here), one copy per wavefront: the lanes of
   // different wavefronts never queue up behind each other at a hot digit
   __shared__ uint32_t h[kFastPasses][4][256];
@@ -189,76 +248,41 @@ __global__ __launch_bounds__(256) void k_s1_extract_fast(const uint32_t *__restr
   __syncthreads();
   const int wv = threadIdx.x >> 6;
   const uint64_t n_blocks = (n_items + B - 1) / B;
-  const int km1 = k - 1;
-  const uint64_t kmask = ~0ull << (64 - 2 * km1);
   // (read, first slot) of this workgroup's current block of B items
   uint64_t q0 = ((uint32_t)blockIdx.x * (uint32_t)B) / per;
   uint32_t rem0 = ((uint32_t)blockIdx.x * (uint32_t)B) % per;
   for (uint64_t blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
-    uint32_t x0[IT], x1[IT], x2[IT], jj[IT], qq[IT];
-    uint64_t aa[IT], stt[IT];
-    bool ok[IT], win_ok[IT];
+    uint32_t outs[IT][3];
+    bool ok[IT];
 #pragma unroll
     for (int u = 0; u < IT; ++u) {
       const uint64_t g = blk * B + (uint64_t)u * 256 + threadIdx.x;
       ok[u] = g < n_items;
       const uint32_t t = rem0 + (uint32_t)u * 256u + threadIdx.x, dq = t / per, j = t - dq * per;
-      const uint64_t st = (q0 + dq) * L;
-      uint32_t q;
-      if (j < 2) q = 0;
-      else if (j >= L - k + 2) q = L - k + 1;
-      else q = j - 1;
-      const uint64_t a = st + q;
-      win_ok[u] = ok[u] && a >= 2;
-      const uint64_t b = win_ok[u] ? a - 2 : 0;  // window: bases [a-2, a+30); clamped to the store's start when there is none
-      const uint64_t w = b >> 4;
-      x0[u] = seq[w];
-      x1[u] = seq[w + 1];
-      x2[u] = seq[w + 2];
-      jj[u] = j;
-      qq[u] = q;
-      aa[u] = a;
-      stt[u] = st;
+      // (a thread beyond the last item recomputes item 0: unconditional loads, nothing stored)
+      s1_fast_item(seq, L, k, ok[u] ? q0 + dq : 0, ok[u] ? j : 2, pos_base, rank_tag, outs[u]);
     }
 #pragma unroll
     for (int u = 0; u < IT; ++u) {
-      uint32_t out[3] = {0, 0, 0};
+      uint32_t(&out)[3] = outs[u];
       if (ok[u]) {
-        const uint32_t j = jj[u], q = qq[u];
-        int forced = -1;
-        if (j < 2) forced = (int)j;
-        else if (j >= L - k + 2) forced = (int)(j - (L - k + 2));
-        if (win_ok[u]) {
-          const unsigned sh = (unsigned)((aa[u] - 2) & 15) * 2;
-          const uint64_t win = ((uint64_t)funnel_l(x0[u], x1[u], sh) << 32) | funnel_l(x1[u], x2[u], sh);
-          const unsigned head_b = (unsigned)(win >> 60) & 3u, tail_b = (unsigned)(win >> (58 - 2 * km1)) & 3u;
-          const uint64_t f = (win << 4) & kmask;
-          const uint64_t rc = rc64(f, km1);
-          const unsigned head = q >= 1 ? head_b : kSentinel;
-          const unsigned tail = q + k - 1 < L ? tail_b : kSentinel;
-          int strand;
-          if (forced >= 0) strand = forced;
-          else strand = f > rc ? 1 : (f < rc ? 0 : (head <= 3 - tail ? 0 : 1));
-          const uint64_t key = strand ? (rc | (comp_or_sentinel(tail) << 3) | comp_or_sentinel(head)) : (f | (head << 3) | tail);
-          out[0] = (uint32_t)(key >> 32);
-          out[1] = (uint32_t)key | rank_tag;
-          out[2] = (uint32_t)(pos_base + aa[u]);
-        } else {  // the first two bases of the store: no window in front of them
-          s1_make_item<2, 3, true>(seq, stt[u], L, k, j, pos_base, rank_tag, out);
-        }
         for (int p = 0; p < specs.n; ++p) atomicAdd(&h[p][wv][words_digit2<3>(out, specs.d[p])], 1u);
       }
+      if constexpr (WRITE) {
 #pragma unroll
-      for (int i = 0; i < 3; ++i) xpose[(u * 256 + threadIdx.x) * 3 + i] = out[i];
+        for (int i = 0; i < 3; ++i) xpose[(u * 256 + threadIdx.x) * 3 + i] = out[i];
+      }
     }
-    __syncthreads();
-    const uint64_t w0 = blk * (uint64_t)(B * 3), n_words = n_items * 3;
+    if constexpr (WRITE) {
+      __syncthreads();
+      const uint64_t w0 = blk * (uint64_t)(B * 3), n_words = n_items * 3;
 #pragma unroll
-    for (int i = 0; i < 3 * IT; ++i) {
-      const uint64_t w = w0 + (uint64_t)i * 256 + threadIdx.x;
-      if (w < n_words) items[w] = xpose[i * 256 + threadIdx.x];
+      for (int i = 0; i < 3 * IT; ++i) {
+        const uint64_t w = w0 + (uint64_t)i * 256 + threadIdx.x;
+        if (w < n_words) items[w] = xpose[i * 256 + threadIdx.x];
+      }
+      __syncthreads();
     }
-    __syncthreads();
     q0 += step_q;
     rem0 += step_r;
     if (rem0 >= per) {
@@ -266,6 +290,7 @@ __global__ __launch_bounds__(256) void k_s1_extract_fast(const uint32_t *__restr
       ++q0;
     }
   }
+  __syncthreads();
   for (int p = 0; p < specs.n; ++p) {
     const uint32_t v = h[p][0][threadIdx.x] + h[p][1][threadIdx.x] + h[p][2][threadIdx.x] + h[p][3][threadIdx.x];
     if (v) atomicAdd(&ghist[p * 256 + threadIdx.x], (unsigned long long)v);
@@ -1463,19 +1488,33 @@ uint64_t s1_extract(mhx_ctx *c, uint32_t k, bool compact) {
     if (fast) {
       const int it = (int)c->opt("s1_extract_items", 4);
       const uint32_t per = s.fixed_len - k + 4;
-#define MHX_FAST(ITV)                                                                                                                  \
+      // Deferred items: the caller sorts right away (run_s1, the multi-GPU pre-sort), so only the digit histograms are taken
+      // here and the first sort pass makes the records itself (S1Gen): "items_a" stays empty until that pass has run.
+      const bool defer = c->s1_defer_items && pre_hist && c->opt("s1_fused_first_pass", 1) &&
+                         sort_takes_generated_first_pass(c, n_items, 3, s1_plan(c, k, n_items, compact, 0).passes);
+#define MHX_FAST(ITV, WR, NAME)                                                                                                        \
   do {                                                                                                                                 \
     const unsigned fgrid = (unsigned)std::min<uint64_t>(div_ceil(n_items, 256 * ITV), 256 * 8);                                        \
     const uint64_t stride_items = (uint64_t)fgrid * 256 * ITV;                                                                         \
-    MHX_LAUNCH(c, "s1_extract", (double)n_items * item_bytes + (double)s.n_bases / 4,                                                  \
-               hipLaunchKernelGGL((k_s1_extract_fast<ITV>), dim3(fgrid), dim3(256), 0, st, s.words.as<uint32_t>(), s.fixed_len, per, n_items, \
+    MHX_LAUNCH(c, NAME, (WR ? (double)n_items * item_bytes : 0.0) + (double)s.n_bases / 4,                                             \
+               hipLaunchKernelGGL((k_s1_extract_fast<ITV, WR>), dim3(fgrid), dim3(256), 0, st, s.words.as<uint32_t>(), s.fixed_len, per, n_items, \
                                   (int)k, pos_base, rank_tag, buf_a, specs, pre_hist, (uint32_t)(stride_items / per), (uint32_t)(stride_items % per))); \
   } while (0)
-      if (it >= 8) MHX_FAST(8);
-      else if (it >= 4) MHX_FAST(4);
-      else if (it >= 2) MHX_FAST(2);
-      else MHX_FAST(1);
+      if (defer) {
+        MHX_FAST(4, false, "s1_digit_hist");
+        const S1Gen g{s.words.as<uint32_t>(), s.fixed_len, per, (int)k, pos_base, rank_tag};
+        c->gen_first_pass = [g](const OnesweepLaunch &l) {
+          hipLaunchKernelGGL((k_radix_onesweep<3, 8, 3, S1Gen>), dim3(l.grid), dim3(kSortThreads), 0, l.stream, g, l.out, l.n, l.ds, l.nbits, l.bin_start,
+                             l.status, l.ticket, l.err, l.tag, l.xcd_units);
+        };
+        c->gen_buf = buf_a;
+        c->gen_n = n_items;
+      } else if (it >= 8) MHX_FAST(8, true, "s1_extract");
+      else if (it >= 4) MHX_FAST(4, true, "s1_extract");
+      else if (it >= 2) MHX_FAST(2, true, "s1_extract");
+      else MHX_FAST(1, true, "s1_extract");
 #undef MHX_FAST
+      c->s1_defer_items = false;
     } else {
 #define MHX_S1X(SV, CP)                                                                                                      \
   do {                                                                                                                       \
@@ -1501,6 +1540,7 @@ uint64_t s1_extract(mhx_ctx *c, uint32_t k, bool compact) {
 #undef MHX_S1X
     }
   }
+  c->s1_defer_items = false;
   return n_items;
 }
 
@@ -1903,7 +1943,10 @@ void s1_apply_marks(mhx_ctx *c, const unsigned long long *recv, uint64_t n) {
 
 int run_s1(mhx_ctx *c, uint32_t k, uint32_t m, int want_mercy, mhx_s1_result *out) {
   if (c->global_bases) throw Error("read2sdbg_s1: a global layout is set; use the mhx_dist_* entry points");
+  c->s1_defer_items = !want_mercy && !c->filter_on;  // s1_process sorts "items_a" first thing: its first pass may make the records
+  c->gen_first_pass = nullptr;
   const StageItems it = extract_stage(c, want_mercy ? MHX_STAGE_S1_MERCY : MHX_STAGE_S1, k, m);
+  c->s1_defer_items = false;
   uint32_t *buf_a = c->work["items_a"].as<uint32_t>();
   uint32_t *buf_b = c->ws("items_b", it.n * (size_t)it.S * 4 + 64).as<uint32_t>();
   return s1_process(c, k, m, want_mercy, buf_a, buf_b, it.n, out);

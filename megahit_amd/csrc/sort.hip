@@ -15,87 +15,9 @@
 
 #include "mhx_internal.h"
 #include "sort_digits.h"
+#include "sort_kernels.h"
 
 namespace mhx {
-
-constexpr int kSortThreads = 256;
-constexpr int kSortWaves = kSortThreads / kWave;
-
-// default records per thread per tile, chosen so the LDS stage stays <= 64 KiB
-template <int S>
-constexpr int default_items() {
-  return (S <= 4) ? 4 : (S <= 8 ? 8 : (S <= 12 ? 5 : (S <= 16 ? 4 : 3)));
-}
-template <int S, int ITEMS>
-struct SortCfg {
-  static constexpr int kItems = ITEMS;
-  static constexpr int kTile = kSortThreads * kItems;
-  static constexpr int kTilesPerChunk = (16384 / kTile) > 4 ? (16384 / kTile) : 4;  // ~16 K records per chunk
-  static constexpr int kChunk = kTile * kTilesPerChunk;
-};
-
-template <int S>
-struct Rec {
-  uint32_t w[S];
-};
-
-template <int S>
-__device__ __forceinline__ void load_rec(const uint32_t *__restrict__ p, Rec<S> &r) {
-  if constexpr (S % 4 == 0) {
-#pragma unroll
-    for (int i = 0; i < S / 4; ++i) {
-      uint4 v = reinterpret_cast<const uint4 *>(p)[i];
-      r.w[4 * i] = v.x; r.w[4 * i + 1] = v.y; r.w[4 * i + 2] = v.z; r.w[4 * i + 3] = v.w;
-    }
-  } else if constexpr (S % 2 == 0) {
-#pragma unroll
-    for (int i = 0; i < S / 2; ++i) {
-      uint2 v = reinterpret_cast<const uint2 *>(p)[i];
-      r.w[2 * i] = v.x; r.w[2 * i + 1] = v.y;
-    }
-  } else {  // odd strides (12-byte records): dword accesses, merged by the compiler where alignment allows
-#pragma unroll
-    for (int i = 0; i < S; ++i) r.w[i] = p[i];
-  }
-}
-template <int S>
-__device__ __forceinline__ void store_rec(uint32_t *__restrict__ p, const Rec<S> &r) {
-  if constexpr (S % 4 == 0) {
-#pragma unroll
-    for (int i = 0; i < S / 4; ++i)
-      reinterpret_cast<uint4 *>(p)[i] = make_uint4(r.w[4 * i], r.w[4 * i + 1], r.w[4 * i + 2], r.w[4 * i + 3]);
-  } else if constexpr (S % 2 == 0) {
-#pragma unroll
-    for (int i = 0; i < S / 2; ++i) reinterpret_cast<uint2 *>(p)[i] = make_uint2(r.w[2 * i], r.w[2 * i + 1]);
-  } else {
-#pragma unroll
-    for (int i = 0; i < S; ++i) p[i] = r.w[i];
-  }
-}
-
-// digit of a record held in registers: bits [bit, bit+nbits) of word wi (and wi-1 when straddling)
-template <int S>
-__device__ __forceinline__ unsigned rec_digit(const Rec<S> &r, int wi, unsigned bit, unsigned mask) {
-  uint32_t lo = 0, hi = 0;
-#pragma unroll
-  for (int i = 0; i < S; ++i) {
-    if (i == wi) lo = r.w[i];
-    if (i == wi - 1) hi = r.w[i];
-  }
-  uint64_t v = ((uint64_t)hi << 32) | lo;
-  return (unsigned)(v >> bit) & mask;
-}
-template <int S>
-__device__ __forceinline__ unsigned rec_digit2(const Rec<S> &r, const DigitSpec &ds) {
-  unsigned d = rec_digit<S>(r, ds.wi1, ds.bit1, ds.mask1);
-  if (ds.mask2) d |= rec_digit<S>(r, ds.wi2, ds.bit2, ds.mask2) << ds.sh2;
-  return d;
-}
-__device__ __forceinline__ unsigned mem_digit(const uint32_t *p, int wi, unsigned bit, unsigned mask) {
-  uint64_t v = p[wi];
-  if (bit + (32 - __builtin_clz(mask)) > 32 && wi > 0) v |= (uint64_t)p[wi - 1] << 32;
-  return (unsigned)(v >> bit) & mask;
-}
 
 template <int S, int NI>
 __global__ __launch_bounds__(kSortThreads) void k_radix_hist(const uint32_t *__restrict__ items, uint64_t n, DigitSpec ds,
@@ -321,164 +243,6 @@ __global__ __launch_bounds__(256) void k_bin_starts(const unsigned long long *__
   starts[blockIdx.x * 256 + threadIdx.x] = block_exclusive_sum<uint64_t, 256>((uint64_t)v, sm, nullptr);
 }
 
-constexpr unsigned long long kStValMask = (1ull << 56) - 1;
-
-template <int S, int NI, int UT>
-__global__ __launch_bounds__(kSortThreads) void k_radix_onesweep(const uint32_t *__restrict__ in, uint32_t *__restrict__ out, uint64_t n,
-                                                                 DigitSpec ds, int nbits, const unsigned long long *__restrict__ bin_start,
-                                                                 unsigned long long *__restrict__ status, uint32_t *__restrict__ ticket,
-                                                                 uint32_t *__restrict__ err, unsigned long long tag, int xcd_units) {
-  constexpr int kTile = kSortThreads * NI;
-  __shared__ __attribute__((aligned(16))) uint32_t stage[kTile * S];
-  __shared__ uint32_t wave_cnt[kSortWaves][256];
-  __shared__ long long g_off[256];
-  __shared__ uint64_t g_base[256];
-  __shared__ uint32_t sm_scan[kSortThreads / kWave + 1];
-  __shared__ uint32_t s_unit;
-
-  const int tid = threadIdx.x, w = tid / kWave, lane = tid & (kWave - 1);
-  const uint64_t lanemask_lt = (1ull << lane) - 1;
-  if (tid == 0) {
-    if (xcd_units) {
-      // Neighbouring units write neighbouring runs of every bin.  Block b is placed on XCD b % 8 and each XCD has an L2 of
-      // its own, so with one ticket counter the two halves of nearly every boundary cache line are dirtied in two
-      // different L2s and leave them as two partial-line writes (measured: 1.5x the algorithmic bytes written).  With one
-      // counter per b % 8 and runs of 16 consecutive units per counter, 15 of 16 boundaries stay inside one L2.
-      // A unit only ever waits for lower-numbered units = tickets of lower or equal index = lower block ids: blocks that
-      // were dispatched before it, on whichever XCD (the grid is a multiple of 128, so the map is a bijection).
-      const uint32_t cls = blockIdx.x & 7u, tk = atomicAdd(ticket + cls, 1u);
-      s_unit = ((tk >> 4) * 8 + cls) * 16 + (tk & 15u);
-    } else {
-      s_unit = atomicAdd(ticket, 1u);
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < kSortWaves; ++i) wave_cnt[i][tid] = 0;
-  __syncthreads();
-  const uint64_t unit = s_unit;
-  const uint64_t unit_base = unit * (uint64_t)(kTile * UT);
-
-  // 1. the unit's records -> registers (wave-blocked striped arrangement inside each tile, as in k_radix_scatter)
-  Rec<S> rec[UT][NI];
-#pragma unroll
-  for (int t = 0; t < UT; ++t)
-#pragma unroll
-    for (int j = 0; j < NI; ++j) {
-      const uint64_t gi = unit_base + (uint64_t)t * kTile + (uint64_t)(w * (kWave * NI) + j * kWave + lane);
-      if (gi < n) load_rec<S>(in + gi * S, rec[t][j]);
-    }
-  // 2. digit counts of the unit (per-wave LDS histograms), published before anything depends on other units
-#pragma unroll
-  for (int t = 0; t < UT; ++t)
-#pragma unroll
-    for (int j = 0; j < NI; ++j) {
-      const uint64_t gi = unit_base + (uint64_t)t * kTile + (uint64_t)(w * (kWave * NI) + j * kWave + lane);
-      if (gi < n) atomicAdd(&wave_cnt[w][rec_digit2<S>(rec[t][j], ds)], 1u);
-    }
-  __syncthreads();
-  unsigned long long unit_tot = 0;
-#pragma unroll
-  for (int i = 0; i < kSortWaves; ++i) unit_tot += wave_cnt[i][tid];
-  unsigned long long *const st = status + unit * 256 + tid;
-  const unsigned long long tagbits = tag << 58;
-  __hip_atomic_store(st, tagbits | ((unit == 0 ? 2ull : 1ull) << 56) | unit_tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __syncthreads();
-
-  // 4. tile by tile: rank, stage in LDS by digit, write the per-digit runs (same as k_radix_scatter)
-#pragma unroll
-  for (int t = 0; t < UT; ++t) {
-    const uint64_t tile_base = unit_base + (uint64_t)t * kTile;
-    if (tile_base >= n) break;
-    const uint64_t rem = n - tile_base;
-    const int tile_n = rem < (uint64_t)kTile ? (int)rem : kTile;
-#pragma unroll
-    for (int i = 0; i < kSortWaves; ++i) wave_cnt[i][tid] = 0;
-    __syncthreads();
-    uint32_t rank[NI];
-    unsigned dig[NI];
-#pragma unroll
-    for (int j = 0; j < NI; ++j) {
-      const int li = w * (kWave * NI) + j * kWave + lane;
-      const bool valid = li < tile_n;
-      const unsigned d = valid ? rec_digit2<S>(rec[t][j], ds) : 0u;
-      dig[j] = d;
-      uint64_t peers = __ballot(valid);
-      for (int b = 0; b < nbits; ++b) {
-        const bool bitset = (d >> b) & 1u;
-        const uint64_t m = __ballot(bitset);
-        peers &= bitset ? m : ~m;
-      }
-      const uint32_t before = wave_cnt[w][d];
-      rank[j] = before + __builtin_popcountll(peers & lanemask_lt);
-      __builtin_amdgcn_wave_barrier();
-      if (valid && (peers & lanemask_lt) == 0) wave_cnt[w][d] = before + __builtin_popcountll(peers);
-      __builtin_amdgcn_wave_barrier();
-    }
-    __syncthreads();
-    {
-      uint32_t c[kSortWaves], tot = 0;
-#pragma unroll
-      for (int i = 0; i < kSortWaves; ++i) {
-        c[i] = wave_cnt[i][tid];
-        tot += c[i];
-      }
-      const uint32_t start = block_exclusive_sum<uint32_t, kSortThreads>(tot, sm_scan, nullptr);
-      uint32_t run = start;
-#pragma unroll
-      for (int i = 0; i < kSortWaves; ++i) {
-        wave_cnt[i][tid] = run;
-        run += c[i];
-      }
-      if (t == 0) {
-        // 3. decoupled look-back (after the first tile's ranking, so that the predecessors had time to publish): sum the
-        //    counts of the predecessors until one of them knows its inclusive prefix
-        unsigned long long excl = 0;
-        if (unit > 0) {
-          for (uint64_t p = unit; p-- > 0;) {
-            unsigned long long v;
-            uint32_t polls = 0;  // per predecessor: a unit only ever waits for units that already run (ticket order)
-            for (;;) {
-              v = __hip_atomic_load(status + p * 256 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              if ((v >> 58) == tag && ((v >> 56) & 3ull)) break;
-              if (++polls > (1u << 27)) {  // seconds of polling one predecessor (a wedged GPU): terminate, the host raises on *err
-                atomicOr(err, 1u);
-                v = 2ull << 56;
-                break;
-              }
-              if (polls < 64) __builtin_amdgcn_s_sleep(1);
-              else __builtin_amdgcn_s_sleep(8);
-            }
-            excl += v & kStValMask;
-            if (((v >> 56) & 3ull) == 2ull) break;
-          }
-          __hip_atomic_store(st, tagbits | (2ull << 56) | (excl + unit_tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        g_base[tid] = bin_start[tid] + excl;
-      }
-      g_off[tid] = (long long)g_base[tid] - (long long)start;
-      g_base[tid] += tot;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < NI; ++j) {
-      const int li = w * (kWave * NI) + j * kWave + lane;
-      if (li < tile_n) store_rec<S>(stage + (size_t)(wave_cnt[w][dig[j]] + rank[j]) * S, rec[t][j]);
-    }
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < NI; ++j) {
-      const int li = j * kSortThreads + tid;
-      if (li < tile_n) {
-        Rec<S> r;
-        load_rec<S>(stage + (size_t)li * S, r);
-        const unsigned d = rec_digit2<S>(r, ds);
-        store_rec<S>(out + (uint64_t)(g_off[d] + li) * S, r);
-      }
-    }
-    __syncthreads();
-  }
-}
-
 // Does the LDS apply the lanes of ONE returning atomic instruction that hit the same address in lane order?
 // Each wave does ds_add_rtn on a few shared counters with adversarial lane->address patterns; a lane's
 // returned value must equal the number of lower lanes of its wave that used the same address.
@@ -554,7 +318,15 @@ DigitSpec spec_of_pass(const SortPass &ps, int key_words) {
 template <int S, int NI, int UT>
 static uint32_t *radix_sort_onesweep(mhx_ctx *c, uint32_t *a, uint32_t *b, uint64_t n, int key_words, const std::vector<SortPass> &passes) {
   const int P = (int)passes.size();
-  const int xcd_units = c->opt("sort_xcd_units", 1) != 0;
+  // a generated first pass (s1.hip): valid for exactly this buffer, item count and unit shape
+  std::function<void(const OnesweepLaunch &)> gen;
+  if (c->gen_first_pass && c->gen_buf == (const void *)a && c->gen_n == n && S == 3 && NI == 8 && UT == 3) gen = c->gen_first_pass;
+  c->gen_first_pass = nullptr;
+  // Per-XCD tickets (see k_radix_onesweep): a unit may wait for a unit whose block id is up to 127 higher, so the scheme needs
+  // the whole 8-XCD part with a couple of hundred workgroups resident at once (MI355X in SPX mode: 256 CUs x 3-4 workgroups).
+  // On a partition (CPX: 32 CUs, one XCD) or an unknown device the single ticket counter is used: its look-back only ever
+  // waits for lower tickets, which are running by construction.
+  const int xcd_units = c->opt("sort_xcd_units", 1) != 0 && c->n_cus >= 192;
   const uint64_t unit = (uint64_t)kSortThreads * NI * UT, n_units = xcd_units ? (div_ceil(n, unit) + 127) / 128 * 128 : div_ceil(n, unit);
   hipStream_t st = c->stream;
   unsigned long long *status = c->ws("sort_status", n_units * 256 * 8).as<unsigned long long>();
@@ -574,6 +346,7 @@ static uint32_t *radix_sort_onesweep(mhx_ctx *c, uint32_t *a, uint32_t *b, uint6
   const bool pre = c->pre_hist_buf == (const void *)a && c->pre_hist_n == n && c->pre_hist_passes == P && P <= kMaxFusedPasses &&
                    c->pre_hist_sig == passes_signature(passes);
   c->pre_hist_buf = nullptr;
+  if (gen && !pre) throw Error("radix sort: a generated first pass needs the digit histograms of the plan (pre-hist)");
   if (pre) MHX_HIP(hipMemcpyAsync(gh, c->work["sort_pre_hist"].p, (size_t)P * 256 * 8, hipMemcpyDeviceToDevice, st));
   for (int p0 = 0; p0 < P && !pre; p0 += kMaxFusedPasses) {  // one read of the input per 16 passes
     DigitSpecs specs;
@@ -584,10 +357,17 @@ static uint32_t *radix_sort_onesweep(mhx_ctx *c, uint32_t *a, uint32_t *b, uint6
   }
   hipLaunchKernelGGL(k_bin_starts, dim3(P), dim3(256), 0, st, gh, starts);
   for (int p = 0; p < P; ++p) {
-    MHX_LAUNCH(c, nm_scat.c_str(), 2 * bytes,
-               hipLaunchKernelGGL((k_radix_onesweep<S, NI, UT>), dim3((unsigned)n_units), dim3(kSortThreads), 0, st, a, b, n, all[p],
-                                  passes[p].bits + passes[p].bits2, starts + p * 256, status, tickets + p * 8, tickets + kErrSlot,
-                                  (unsigned long long)(p + 1), xcd_units));
+    if (p == 0 && gen) {  // the records of the first pass are made on the fly (no input array): the generator's owner launches
+      static const std::string nm_gen = nm_scat + "_gen";
+      MHX_LAUNCH(c, nm_gen.c_str(), bytes,
+                 gen(OnesweepLaunch{(unsigned)n_units, st, b, n, all[p], passes[p].bits + passes[p].bits2, starts + p * 256, status, tickets + p * 8,
+                                    tickets + kErrSlot, (unsigned long long)(p + 1), xcd_units}));
+    } else {
+      MHX_LAUNCH(c, nm_scat.c_str(), 2 * bytes,
+                 hipLaunchKernelGGL((k_radix_onesweep<S, NI, UT, SrcArray<S>>), dim3((unsigned)n_units), dim3(kSortThreads), 0, st, SrcArray<S>{a}, b, n,
+                                    all[p], passes[p].bits + passes[p].bits2, starts + p * 256, status, tickets + p * 8, tickets + kErrSlot,
+                                    (unsigned long long)(p + 1), xcd_units));
+    }
     std::swap(a, b);
   }
   uint32_t e = 0;
@@ -867,6 +647,17 @@ void partition_by_owner(mhx_ctx *c, const uint32_t *a, uint32_t *b, uint64_t n, 
     case 20: return partition_impl<20>(c, a, b, n, lut, n_parts, counts);
     default: throw Error("partition_by_owner: unsupported record stride");
   }
+}
+
+// true when radix_sort(stride 3, these passes) runs the chained-scan passes with the default 8x3 unit shape, i.e. when it
+// will take a generated first pass (mhx_ctx::gen_first_pass)
+bool sort_takes_generated_first_pass(const mhx_ctx *c, uint64_t n, int stride, const std::vector<SortPass> &passes) {
+  (void)c;
+  const char *e = getenv("MHX_SORT"), *sh = getenv("MHX_SORT_SHAPE"), *it = getenv("MHX_SORT_ITEMS");
+  if (e && !strcmp(e, "classic")) return false;
+  if ((sh && strcmp(sh, "8x3")) || (it && atoi(it) != default_items<3>())) return false;
+  return stride == 3 && n > 0 && passes.size() <= (size_t)kMaxChainedPasses && passes.size() <= (size_t)kMaxFusedPasses &&
+         div_ceil(n, (uint64_t)kSortThreads * 8) < (1ull << 31);
 }
 
 uint32_t *radix_sort(mhx_ctx *c, uint32_t *a, uint32_t *b, uint64_t n, int stride, int key_words,

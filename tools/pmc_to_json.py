@@ -13,7 +13,7 @@ import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from megahit_amd.buildid import build_id  # noqa: E402
+from megahit_amd.buildid import build_id, lib_id  # noqa: E402
 
 import pandas as pd
 
@@ -30,7 +30,7 @@ def per_kernel(d, counter):
 fetch = per_kernel(sys.argv[1], "FETCH_SIZE")
 write = per_kernel(sys.argv[2], "WRITE_SIZE")
 out = {"_doc": "HBM bytes per launch = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (see tools/pmc_to_json.py)",
-       "build_id": build_id(), "command": "python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-e2e", "kernels": {}}
+       "build_id": build_id(), "lib_id": lib_id(), "command": "python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-e2e", "kernels": {}}
 for k in sorted(set(fetch) | set(write)):
     fr = 2 * 1024 * fetch.get(k, (0, 0.0))[1]
     wr = 1024 * write.get(k, (0, 0.0))[1]
