@@ -360,7 +360,8 @@ static DistPasses plan_dist_passes(mhx_ctx *c, mhx_comm *cm, int stage, uint32_t
     // the usual case decided without a scan of the reads: an upper bound of the items of the whole job (stage 1 / count:
     // one per base + 4 per read; stage 2 per occurrence, seq2sdbg: ~2 per base), twice the fair share per rank
     const mhx::SeqSet &s = c->seqs;
-    const double per_base = (stage == MHX_STAGE_S2 || stage == MHX_STAGE_SEQ2SDBG) ? 2.2 : 1.0;
+    // (stage 2 after a stage 1 with k <= 22 sorts the aggregated items: one or two per DISTINCT solid (k+1)-mer)
+    const double per_base = stage == MHX_STAGE_S2 ? (m > 1 && k <= 22 ? 0.5 : 2.2) : (stage == MHX_STAGE_SEQ2SDBG ? 2.2 : 1.0);
     std::vector<uint64_t> v{(uint64_t)(per_base * (double)s.n_bases) + 4 * s.n_seqs, ~0ull - mhx_device_free_bytes(c)};
     std::vector<uint64_t> mx = v;
     cm->all_reduce(mx, true);
@@ -393,7 +394,10 @@ static DistPasses plan_dist_passes(mhx_ctx *c, mhx_comm *cm, int stage, uint32_t
   std::vector<uint64_t> w{std::max(worst, local_total)};
   cm->all_reduce(w, true);
   const uint64_t P = std::min<uint64_t>(4096, (w[0] + max_items - 1) / max_items);
-  if (P <= 1) return dp;
+  if (P <= 1) {
+    if (!c->opt("dist_max_items", 0) && !getenv("MHX_MAX_ITEMS") && !getenv("MHX_FREE_BYTES")) cm->one_pass_ok.push_back(plan_key);
+    return dp;
+  }
   dp.n = (int)P;
   dp.keep.assign(P, std::vector<uint8_t>(MHX_NUM_BUCKETS, 0));
   dp.expected.assign(P, 0);

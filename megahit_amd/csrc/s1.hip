@@ -359,6 +359,14 @@ struct S1Op {
   long long *mercy;
   unsigned long long *mercy_n;
   uint64_t pos_stride;  // compact records tagged with their source rank: global position = local + rank * pos_stride (else 0)
+  // mercy candidates go to a region of the workgroup's own, mercy[mercy_off[blockIdx.x] ...], counted in
+  // mercy_counts[blockIdx.x]: 5 x 10^7 candidates at 10 M reads meant ~2 x 10^7 wavefront-level atomics on ONE global word,
+  // ~10 ns each = the 190 ms of this kernel in round 2.  A region holds two entries per record of the workgroup's tiles
+  // (tile indices blockIdx.x, + gridDim.x, ...).  A workgroup also handles the tail of its last group beyond its tile, so
+  // in theory it can meet more candidates than its region holds: then it sets mercy_counts[gridDim.x] and the host runs the
+  // kernel again with the shared cursor.  nullptr: the shared cursor mercy_n.
+  uint32_t *mercy_counts;
+  const uint64_t *mercy_off;
 
   __device__ bool same_run(const uint32_t *cur, const uint32_t *prev) const { return ((cur[kw - 1] ^ prev[kw - 1]) & 63u) == 0; }
   __device__ bool item_phase_enabled() const { return false; }
@@ -509,12 +517,23 @@ struct S1Op {
       if (m0 | m1) {
         const int lane = lane_id(), leader = __builtin_ctzll(m0 | m1);
         const unsigned n0 = (unsigned)__builtin_popcountll(m0);
+        const unsigned n_all = n0 + (unsigned)__builtin_popcountll(m1);
         unsigned long long at = 0;
-        if (lane == leader) at = atomicAdd(mercy_n, (unsigned long long)(n0 + __builtin_popcountll(m1)));
-        at = __shfl(at, leader, kWave);
+        bool ok = true;
+        if (mercy_counts) {
+          uint32_t a32 = 0;
+          if (lane == leader) a32 = atomicAdd(mercy_counts + blockIdx.x, n_all);
+          a32 = __shfl(a32, leader, kWave);
+          at = mercy_off[blockIdx.x] + a32;
+          ok = at + n_all <= mercy_off[blockIdx.x + 1];
+          if (!ok && lane == leader) atomicOr(mercy_counts + gridDim.x, 1u);
+        } else {
+          if (lane == leader) at = atomicAdd(mercy_n, (unsigned long long)n_all);
+          at = __shfl(at, leader, kWave);
+        }
         const unsigned long long below = (1ull << lane) - 1;
-        if (c0 >= 0) mercy[at + __builtin_popcountll(m0 & below)] = c0;
-        if (c1 >= 0) mercy[at + n0 + __builtin_popcountll(m1 & below)] = c1;
+        if (ok && c0 >= 0) mercy[at + __builtin_popcountll(m0 & below)] = c0;
+        if (ok && c1 >= 0) mercy[at + n0 + __builtin_popcountll(m1 & below)] = c1;
       }
     }
   }
@@ -1173,6 +1192,20 @@ __global__ __launch_bounds__(256) void k_agg_compact(const uint2 *__restrict__ r
   for (uint32_t i = blockIdx.y * 256 + threadIdx.x; i < n; i += gridDim.y * 256) dense[off + i] = from_back ? src[cap - 1 - i] : src[i];
 }
 
+// regions of different sizes (start offsets in off[]) -> one dense array, region order kept
+__global__ __launch_bounds__(256) void k_regions_compact(const uint2 *__restrict__ raw, const uint64_t *__restrict__ off, const uint32_t *__restrict__ counts,
+                                                        uint2 *__restrict__ dense) {
+  __shared__ uint64_t sm[256 / kWave + 1];
+  const uint32_t r = blockIdx.x;
+  uint64_t part = 0;
+  for (uint32_t i = threadIdx.x; i < r; i += 256) part += counts[i];
+  uint64_t at;
+  block_exclusive_sum<uint64_t, 256>(part, sm, &at);
+  const uint32_t n = counts[r];
+  const uint2 *src = raw + off[r];
+  for (uint32_t i = blockIdx.y * 256 + threadIdx.x; i < n; i += gridDim.y * 256) dense[at + i] = src[i];
+}
+
 // multi-GPU, sparse marks, classic path: positions of the set bytes of the (global) byte map, appended in any order
 __global__ __launch_bounds__(256) void k_collect_marks(const uint8_t *__restrict__ bytes, uint64_t n_bytes, unsigned long long *__restrict__ out,
                                                       unsigned long long *__restrict__ cursor) {
@@ -1310,32 +1343,88 @@ void invert_local_marks(mhx_ctx *c, unsigned long long *words, uint64_t n_words)
 template <int S, bool COMPACT, bool AGG>
 static void s1_groups_launch(mhx_ctx *c, const uint32_t *sorted, uint64_t n_items, int KWv, int kmer_bits, uint32_t m,
                              uint8_t *is_solid, unsigned long long *solid_bits, int mark_atomic, unsigned long long *hist, unsigned long long *ctr, int want_mercy,
-                             long long *mercy, int k, uint2 *agg_items, uint64_t *agg_cursor, int mark_mode) {
+                             long long *&mercy, int k, uint2 *agg_items, uint64_t *agg_cursor, int mark_mode) {
   SeqSet &s = c->seqs;
   constexpr int T = S1Tile<S>::kT;
   const uint64_t n_tiles = div_ceil(n_items, T);
   const int full_words = kmer_bits / 32, rem = kmer_bits % 32;
   const uint32_t last_mask = rem ? 0xFFFFFFFFu << (32 - rem) : 0;
   const uint64_t pos_stride = COMPACT && s1_rank_tagged(c, (uint32_t)k) ? c->global_bases / (uint64_t)c->n_parts : 0;
-  S1Op<S, COMPACT, AGG> op{k, agg_items, KWv, m, s.start.as<uint64_t>(), s.n_seqs, s.fixed_len, is_solid, solid_bits, mark_atomic, mark_mode, hist, ctr, want_mercy, mercy, ctr + 1, pos_stride};
+  S1Op<S, COMPACT, AGG> op{k, agg_items, KWv, m, s.start.as<uint64_t>(), s.n_seqs, s.fixed_len, is_solid, solid_bits, mark_atomic, mark_mode, hist, ctr, want_mercy, mercy, ctr + 1, pos_stride,
+                           nullptr, nullptr};
   if (mark_mode == 2) {  // statistics on every 64th tile (no output): solid fraction -> marking polarity
     const uint32_t stride = 64;
     const uint64_t nt = div_ceil(n_tiles, stride);
     MHX_LAUNCH(c, "s1_sample", (double)nt * T * S * 4,
                hipLaunchKernelGGL((k_tile_groups<S, T, S1Op<S, COMPACT, false>, false>), dim3(tile_grid(nt)), dim3(kTileThreads), 0, c->stream, sorted,
                                   n_items, full_words, last_mask, S1Op<S, COMPACT, false>{k, nullptr, KWv, m, s.start.as<uint64_t>(), s.n_seqs,
-                                  s.fixed_len, is_solid, solid_bits, mark_atomic, 2, hist, ctr, 0, mercy, ctr + 1, pos_stride},
+                                  s.fixed_len, is_solid, solid_bits, mark_atomic, 2, hist, ctr, 0, mercy, ctr + 1, pos_stride, nullptr, nullptr},
                                   (uint64_t *)nullptr, (const uint64_t *)nullptr, n_tiles, nt, stride));
     return;
   }
-  if constexpr (AGG)
-    MHX_LAUNCH(c, "s1_groups", (double)n_items * S * 4,
-               hipLaunchKernelGGL((k_tile_groups<S, T, S1Op<S, COMPACT, true>, true>), dim3(tile_grid(n_tiles)), dim3(kTileThreads), 0, c->stream,
-                                  sorted, n_items, full_words, last_mask, op, agg_cursor, (const uint64_t *)nullptr, n_tiles, n_tiles));
-  else
-    MHX_LAUNCH(c, "s1_groups", (double)n_items * S * 4,
-               hipLaunchKernelGGL((k_tile_groups<S, T, S1Op<S, COMPACT, false>, false>), dim3(tile_grid(n_tiles)), dim3(kTileThreads), 0, c->stream,
-                                  sorted, n_items, full_words, last_mask, op, (uint64_t *)nullptr, (const uint64_t *)nullptr, n_tiles, n_tiles));
+  hipStream_t st = c->stream;
+  const unsigned grid = tile_grid(n_tiles);
+  // mercy candidates in per-workgroup regions of the spare sort buffer (2 entries of 8 bytes per 16-byte record): region b
+  // starts at twice the number of records in the tiles of the workgroups before b — 2 * n_items entries in all
+  const bool regions = !COMPACT && want_mercy && n_items && c->opt("s1_mercy_regions", 1);
+  uint32_t *counts = nullptr;
+  uint64_t *d_off = nullptr;
+  if (regions) {
+    counts = c->ws("s1_mercy_counts", (size_t)grid * 4 + 64).as<uint32_t>();
+    MHX_HIP(hipMemsetAsync(counts, 0, (size_t)grid * 4 + 4, st));
+    std::vector<uint64_t> off(grid + 1);
+    const uint64_t q = n_tiles / grid, r = n_tiles % grid, b_last = (n_tiles - 1) % grid, short_by = n_tiles * (uint64_t)T - n_items;
+    for (uint64_t b = 0; b <= grid; ++b) off[b] = 2 * ((uint64_t)T * (b * q + std::min<uint64_t>(b, r)) - (b > b_last ? short_by : 0));
+    d_off = c->ws("s1_mercy_off", (size_t)(grid + 1) * 8).as<uint64_t>();
+    MHX_HIP(hipMemcpyAsync(d_off, off.data(), (size_t)(grid + 1) * 8, hipMemcpyHostToDevice, st));
+    MHX_HIP(hipStreamSynchronize(st));  // `off` is a local
+    op.mercy_counts = counts;
+    op.mercy_off = d_off;
+  }
+  // state to go back to should a region overflow: the histogram and (AGG) the cursor of the aggregated items
+  unsigned long long *hist_save = nullptr;
+  uint64_t agg_before[3] = {0, 0, 0};
+  if (regions) {
+    hist_save = c->ws("s1_hist_save2", (MHX_MAX_MUL + 1) * 8).as<unsigned long long>();
+    MHX_HIP(hipMemcpyAsync(hist_save, hist, (MHX_MAX_MUL + 1) * 8, hipMemcpyDeviceToDevice, st));
+    if (AGG && agg_cursor) MHX_HIP(hipMemcpyAsync(agg_before, agg_cursor, 24, hipMemcpyDeviceToHost, st));
+    MHX_HIP(hipStreamSynchronize(st));
+  }
+  auto launch = [&]() {
+    if constexpr (AGG)
+      MHX_LAUNCH(c, "s1_groups", (double)n_items * S * 4,
+                 hipLaunchKernelGGL((k_tile_groups<S, T, S1Op<S, COMPACT, true>, true>), dim3(grid), dim3(kTileThreads), 0, st, sorted, n_items,
+                                    full_words, last_mask, op, agg_cursor, (const uint64_t *)nullptr, n_tiles, n_tiles));
+    else
+      MHX_LAUNCH(c, "s1_groups", (double)n_items * S * 4,
+                 hipLaunchKernelGGL((k_tile_groups<S, T, S1Op<S, COMPACT, false>, false>), dim3(grid), dim3(kTileThreads), 0, st, sorted, n_items,
+                                    full_words, last_mask, op, (uint64_t *)nullptr, (const uint64_t *)nullptr, n_tiles, n_tiles));
+  };
+  launch();
+  if (!regions) return;
+  std::vector<uint32_t> h_counts(grid + 1);
+  MHX_HIP(hipMemcpyAsync(h_counts.data(), counts, (size_t)(grid + 1) * 4, hipMemcpyDeviceToHost, st));
+  MHX_HIP(hipStreamSynchronize(st));
+  if (h_counts[grid] || c->opt("s1_mercy_regions", 1) == 2) {  // (2: tests force the way back)
+    MHX_HIP(hipMemcpyAsync(hist, hist_save, (MHX_MAX_MUL + 1) * 8, hipMemcpyDeviceToDevice, st));
+    MHX_HIP(hipMemsetAsync(ctr, 0, 16, st));
+    if (AGG && agg_cursor) MHX_HIP(hipMemcpyAsync(agg_cursor, agg_before, 24, hipMemcpyHostToDevice, st));
+    op.mercy_counts = nullptr;
+    launch();
+    MHX_HIP(hipStreamSynchronize(st));
+    return;
+  }
+  h_counts.resize(grid);
+  uint64_t total = 0;
+  for (unsigned i = 0; i < grid; ++i) total += h_counts[i];
+  long long *dense = c->ws("s1_mercy_dense", total * 8 + 64).as<long long>();
+  if (total)
+    MHX_LAUNCH(c, "mercy_compact", (double)total * 16,
+               hipLaunchKernelGGL(k_regions_compact, dim3(grid, 8), dim3(256), 0, st, reinterpret_cast<const uint2 *>(mercy), d_off, counts,
+                                  reinterpret_cast<uint2 *>(dense)));
+  MHX_HIP(hipMemcpyAsync(ctr + 1, &total, 8, hipMemcpyHostToDevice, st));
+  MHX_HIP(hipStreamSynchronize(st));  // `total` is a stack variable
+  mercy = dense;
 }
 
 // int64 <-> (hi,lo) word pairs so that the big-endian record sort orders them numerically

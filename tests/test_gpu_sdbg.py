@@ -344,3 +344,23 @@ def test_read2sdbg_fixed_length_reads(engine, k, m, mercy):
     assert np.array_equal(engine.fetch(lib.BUF_EDGES, np.uint32).reshape(-1, r.words_per_edge), want["edges"])
     assert np.array_equal(engine.fetch(lib.BUF_FIRST_0_OUT, np.uint32), want["first_0_out"])
     assert np.array_equal(engine.fetch(lib.BUF_LAST_0_IN, np.uint32), want["last_0_in"])
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2], ids=["shared-cursor", "regions", "regions-then-fallback"])
+@pytest.mark.parametrize("kind,k,m,exact", [("fixed", 21, 2, False), ("var", 27, 3, False), ("lowcomplex", 21, 2, True)])
+def test_mercy_candidates_from_per_workgroup_regions(engine, kind, k, m, exact, mode):
+    """stage 1 with mercy candidates: the candidates leave the tile kernel through per-workgroup regions (default), through
+    the shared cursor (0), or through the regions followed by the forced way back (2) — the same sorted list every time"""
+    reads = make_reads(kind, 11)
+    pkg = ob.Package(reads, reverse=True)
+    w1 = ob.s1(pkg, k, m, tie_stable=not exact)
+    load(engine, pkg)
+    engine.set_option("s1_mercy_regions", mode)
+    try:
+        engine.read2sdbg_s1(k, m, want_mercy=2 if exact else 1)
+    finally:
+        engine.set_option("s1_mercy_regions", 1)
+    assert np.array_equal(engine.fetch(lib.BUF_MERCY_CAND, np.int64), w1["mercy"])
+    assert np.array_equal(engine.fetch(lib.BUF_MUL_HIST, np.int64), w1["hist"])
+    solid = engine.fetch(lib.BUF_IS_SOLID, np.uint64)
+    assert np.array_equal(solid, w1["is_solid"][: solid.size])

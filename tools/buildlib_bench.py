@@ -44,6 +44,20 @@ def main():
                 best = dt if best is None else min(best, dt)
             out[tag + "_s"] = round(best, 3)
             out[tag + "_bin_md5"] = canon.digest_file(os.path.join(d, tag + ".bin"))
+        # where mhx_core's time goes: its own phase clocks and per-kernel HIP-event times (MHX_PROFILE)
+        import re
+        prof = os.path.join(d, "prof.json")
+        env = dict(os.environ, MHX_PROFILE="1", MHX_PROFILE_JSON=prof)
+        p = subprocess.run([os.path.join(ROOT, "megahit_amd", "mhx_core"), "buildlib", os.path.join(d, "lib"), os.path.join(d, "p")], check=True,
+                           stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, env=env)
+        with open(prof) as f:
+            ks = json.load(f)["kernels"]
+        out["kernel_ms_total"] = round(sum(v["ms"] for v in ks.values()), 3)
+        out["kernels"] = {k: {"ms": round(v["ms"], 3), "algo_bytes": v["bytes"], "GBs": round(v["bytes"] / v["ms"] / 1e6, 1) if v["ms"] else None}
+                          for k, v in sorted(ks.items(), key=lambda kv: -kv[1]["ms"])[:8]}
+        m = re.search(r"Device memory: .*", p.stderr)
+        out["device_memory"] = m.group(0) if m else None
+        out["host_share_s"] = round(out["mhx_core_s"] - out["kernel_ms_total"] / 1e3, 3)
         out["identical"] = out["reference_bin_md5"] == out["mhx_core_bin_md5"]
         out["speedup"] = round(out["reference_s"] / out["mhx_core_s"], 1)
     print(json.dumps(out, indent=1))

@@ -5,7 +5,7 @@ reference's own code on the host cores of the same box:
    N2  megahit_core iterate (oracle/_ref/ref_megahit_core)        vs  mhx_core iterate                     -> equal edge sets
 The contigs of N2 are cut from the genome the reads were drawn from (pieces of 100..500 bases, half of them reverse-
 complemented, consecutive pieces overlapping by k bases as unitigs do, one junction in ten a gap instead), written as the assembler writes them.
-   python tools/next_rows_bench.py [reads] > profiles/r02_next_rows.json"""
+   python tools/next_rows_bench.py [reads] > profiles/r03_next_rows.json"""
 import json
 import os
 import re
@@ -26,6 +26,14 @@ MHX = os.path.join(ROOT, "megahit_amd", "mhx_core")
 REF_DUMP = os.path.join(ROOT, "oracle", "_ref", "ref_sdbg_dump")
 REF_FULL = os.path.join(ROOT, "oracle", "_ref", "ref_megahit_core")
 K, M, STEP = 21, 2, 8
+
+
+def kernel_table(stats, top=8):
+    """per-kernel HIP-event ms and algorithmic bytes -> the heaviest kernels with their achieved algorithmic GB/s"""
+    rows = sorted(stats.items(), key=lambda kv: -kv[1]["ms"])[:top]
+    return {k: {"launches": v["launches"], "ms": round(v["ms"], 3), "algo_bytes": v["bytes"],
+                "GBs": round(v["bytes"] / v["ms"] / 1e6, 1) if v["ms"] else None, "frac_of_8TBs": round(v["bytes"] / v["ms"] / 1e6 / 8000.0, 4) if v["ms"] else None}
+            for k, v in rows}
 
 
 def run(cmd, env=None):
@@ -94,22 +102,28 @@ def main():
         t_files = time.perf_counter() - t0
         eng.sdbg_build_index(k)  # warm-up (allocations)
         eng.synchronize()
+        eng.profile(True)
+        eng.profile_reset()
         t0 = time.perf_counter()
         info = eng.sdbg_build_index(k)
         eng.synchronize()
         t_index = time.perf_counter() - t0
+        k_index = kernel_table(eng.profile_get())
         ti.check_index(eng, k, want)  # every array against the reference's (raises on a difference)
         info = eng.sdbg_build_index(k)
         eng.synchronize()
+        eng.profile_reset()
         t0 = time.perf_counter()
         n_tips = eng.sdbg_remove_tips(info, 2 * K)
         eng.synchronize()
         t_tips = time.perf_counter() - t0
+        k_tips = kernel_table(eng.profile_get())
+        eng.profile(False)
         tips_equal = n_tips == int(want["tips_removed"][0]) and np.array_equal(eng.fetch(lib.BUF_SDBG_INVALID, np.uint64), want["invalid_after_tips"])
         out["N1_sdbg_index"] = {"records": int(info.n_items), "reference_LoadFromFile_s": t_ref_load, "mhx_build_index_s": round(t_index, 4),
-                                "mhx_read_files_and_upload_s": round(t_files, 3), "all_arrays_equal": True}
+                                "mhx_read_files_and_upload_s": round(t_files, 3), "all_arrays_equal": True, "kernels": k_index}
         out["N4_remove_tips"] = {"max_tip_len": 2 * K, "tips_removed": n_tips, "reference_RemoveTips_s": t_ref_tips, "mhx_remove_tips_s": round(t_tips, 4),
-                                 "count_and_bitmap_equal": bool(tips_equal)}
+                                 "count_and_bitmap_equal": bool(tips_equal), "kernels": k_tips}
         del eng, want
         # ---- N2
         n_ctg = write_contigs(os.path.join(d, "c.fa"), os.path.join(d, "b.fa"), n_reads)
@@ -117,11 +131,15 @@ def main():
                   "-r", os.path.join(d, "reads.bin")]
         t_ref, _ = run([REF_FULL] + common + ["-o", os.path.join(d, "it_ref")])
         t_mhx, log = run([MHX] + common + ["-o", os.path.join(d, "it_mhx")])
-        t_mhx2, log = run([MHX] + common + ["-o", os.path.join(d, "it_mhx")])
+        prof = os.path.join(d, "it_prof.json")
+        t_mhx2, log = run([MHX] + common + ["-o", os.path.join(d, "it_mhx")], env={"MHX_PROFILE": "1", "MHX_PROFILE_JSON": prof})
+        with open(prof) as f:
+            k_iter = kernel_table(json.load(f)["kernels"])
         hr, er = sorted_edges(os.path.join(d, "it_ref"))
         hm, em = sorted_edges(os.path.join(d, "it_mhx"))
         out["N2_iterate"] = {"contigs": n_ctg, "step": STEP, "edges": int(er.shape[0]), "reference_wall_s_16_threads": round(t_ref, 3),
-                             "mhx_core_wall_s": round(min(t_mhx, t_mhx2), 3), "edge_sets_equal": bool(hm == hr and em.shape == er.shape and np.array_equal(em, er))}
+                             "mhx_core_wall_s": round(min(t_mhx, t_mhx2), 3), "edge_sets_equal": bool(hm == hr and em.shape == er.shape and np.array_equal(em, er)),
+                             "kernels": k_iter}
     print(json.dumps(out, indent=1))
 
 
