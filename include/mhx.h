@@ -326,6 +326,19 @@ typedef struct mhx_comm mhx_comm;
  * id == NULL gives a trivial communicator without RCCL.  Returns NULL on error. */
 int mhx_comm_unique_id(void *id /* MHX_COMM_ID_BYTES */);
 mhx_comm *mhx_comm_init_rank(mhx_ctx *, const void *id, int rank, int n_ranks);
+/* A communicator whose bytes the CALLER moves, through host memory — e.g. torch.distributed over gloo when the ranks are
+   processes without a shared RCCL world (several processes on one GPU; tests/test_gpu_multiprocess.py).  libmhx stages the
+   per-peer segments in host memory and calls back; the callbacks return 0 on success.
+     all_reduce_u64    in-place element-wise sum (is_max = 0) or max (is_max = 1) of n 64-bit values over all ranks; the max
+                       may be computed on the values read as SIGNED 64-bit (libmhx only mixes values of one sign per element)
+     all_to_all_bytes  send / recv: the segments for / from rank 0, 1, ... back to back, send_bytes[p] / recv_bytes[p] bytes
+                       (0 for the caller's own rank) */
+typedef struct mhx_host_transport {
+  int (*all_reduce_u64)(void *user, uint64_t *values, uint64_t n, int is_max);
+  int (*all_to_all_bytes)(void *user, const void *send, const uint64_t *send_bytes, void *recv, const uint64_t *recv_bytes);
+  void *user;
+} mhx_host_transport;
+mhx_comm *mhx_comm_init_hosted(mhx_ctx *, int rank, int n_ranks, const mhx_host_transport *t);
 /* in-process transport without RCCL: the n ranks are threads of this process and may share GPUs (tests); exchanges are
  * device-to-device copies between the ranks' buffers.  out receives n handles, out[r] bound to ctxs[r]. */
 int mhx_comm_local_group(int n_ranks, mhx_ctx *const *ctxs, mhx_comm **out);

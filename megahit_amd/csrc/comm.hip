@@ -133,6 +133,10 @@ struct mhx_comm {
   ncclComm_t nccl = nullptr;
   // local transport
   mhx::LocalGroup *grp = nullptr;
+  // hosted transport: the caller moves the bytes (host memory) with whatever it has — e.g. torch.distributed over gloo
+  mhx_host_transport hosted{};
+  bool is_hosted = false;
+  std::vector<char> h_send, h_recv;
   uint64_t max_msg_bytes = 1ull << 28;  // 256 MiB per message (one 16 GB message hung RCCL 2.26 on MI355X)
   // agreed layout
   uint64_t stride_bases = 0;
@@ -144,6 +148,10 @@ struct mhx_comm {
   void all_reduce(std::vector<uint64_t> &v, bool is_max) {
     if (n == 1) return;
     hipStream_t st = ctx->stream;
+    if (is_hosted) {
+      if (hosted.all_reduce_u64(hosted.user, v.data(), v.size(), is_max ? 1 : 0) != 0) throw mhx::Error("hosted transport: all_reduce failed");
+      return;
+    }
     if (nccl) {
       unsigned long long *d = ctx->ws("comm_small", v.size() * 8 + 64).as<unsigned long long>();
       MHX_HIP(hipMemcpyAsync(d, v.data(), v.size() * 8, hipMemcpyHostToDevice, st));
@@ -169,6 +177,13 @@ struct mhx_comm {
       return;
     }
     hipStream_t st = ctx->stream;
+    if (is_hosted) {  // the n x n count matrix as a sum of one-row matrices
+      std::vector<uint64_t> m((size_t)n * n, 0);
+      for (int p = 0; p < n; ++p) m[(size_t)rank * n + p] = send[p];
+      all_reduce(m, false);
+      for (int p = 0; p < n; ++p) recv[p] = m[(size_t)p * n + rank];
+      return;
+    }
     if (nccl) {
       unsigned long long *d = ctx->ws("comm_small", (size_t)(n + 1) * n * 8 + 64).as<unsigned long long>();
       MHX_HIP(hipMemcpyAsync(d, send.data(), (size_t)n * 8, hipMemcpyHostToDevice, st));
@@ -196,6 +211,37 @@ struct mhx_comm {
     }
     const char *s = static_cast<const char *>(d_send);
     char *r = static_cast<char *>(d_recv);
+    if (is_hosted && n > 1) {
+      // own segment: a device copy; everything else through host memory and the caller's byte mover
+      if (!skip_self && so[rank + 1] > so[rank])
+        MHX_HIP(hipMemcpyAsync(r + ro[rank], s + so[rank], so[rank + 1] - so[rank], hipMemcpyDeviceToDevice, st));
+      std::vector<uint64_t> sb(n), rb(n);
+      uint64_t s_tot = 0, r_tot = 0;
+      for (int p = 0; p < n; ++p) {
+        sb[p] = p == rank ? 0 : so[p + 1] - so[p];
+        rb[p] = p == rank ? 0 : ro[p + 1] - ro[p];
+        s_tot += sb[p];
+        r_tot += rb[p];
+      }
+      h_send.resize(s_tot);
+      h_recv.resize(r_tot);
+      uint64_t at = 0;
+      for (int p = 0; p < n; ++p)
+        if (sb[p]) {
+          MHX_HIP(hipMemcpyAsync(h_send.data() + at, s + so[p], sb[p], hipMemcpyDeviceToHost, st));
+          at += sb[p];
+        }
+      MHX_HIP(hipStreamSynchronize(st));
+      if (hosted.all_to_all_bytes(hosted.user, h_send.data(), sb.data(), h_recv.data(), rb.data()) != 0) throw mhx::Error("hosted transport: all_to_all failed");
+      at = 0;
+      for (int p = 0; p < n; ++p)
+        if (rb[p]) {
+          MHX_HIP(hipMemcpyAsync(r + ro[p], h_recv.data() + at, rb[p], hipMemcpyHostToDevice, st));
+          at += rb[p];
+        }
+      MHX_HIP(hipStreamSynchronize(st));
+      return;
+    }
     if (nccl || n == 1) {
       // own segment: a device copy; every other segment: point-to-point messages of at most max_msg_bytes, all pairs of a
       // round in one group (direct xGMI sends, not a ring).  Sender and receiver derive the same chunking from the counts.
@@ -234,7 +280,7 @@ struct mhx_comm {
   }
   void barrier() {
     if (n == 1) return;
-    if (nccl) {
+    if (nccl || is_hosted) {
       std::vector<uint64_t> one(1, 1);
       all_reduce(one, false);
     } else {
@@ -472,6 +518,23 @@ mhx_comm *mhx_comm_init_rank(mhx_ctx *c, const void *id, int rank, int n_ranks) 
       memcpy(&u, id, sizeof u);
       MHX_NCCL(mhx::rccl().CommInitRank(&cm->nccl, n_ranks, u, rank));
     }
+    return cm;
+  } catch (const std::exception &e) {
+    mhx::set_error("%s", e.what());
+    return nullptr;
+  }
+}
+
+mhx_comm *mhx_comm_init_hosted(mhx_ctx *c, int rank, int n_ranks, const mhx_host_transport *t) {
+  try {
+    if (!c || !t || !t->all_reduce_u64 || !t->all_to_all_bytes || n_ranks < 1 || n_ranks > 256 || rank < 0 || rank >= n_ranks)
+      throw mhx::Error("comm_init_hosted: bad arguments");
+    mhx_comm *cm = new mhx_comm;
+    cm->rank = rank;
+    cm->n = n_ranks;
+    cm->ctx = c;
+    cm->hosted = *t;
+    cm->is_hosted = true;
     return cm;
   } catch (const std::exception &e) {
     mhx::set_error("%s", e.what());

@@ -195,10 +195,31 @@ __global__ void k_tips_init(DevSdbg g, unsigned long long *__restrict__ ignored)
 }
 // Trim (sdbg_pruning.cpp:61-145), the two walking loops: backward from the sinks (dir 0), forward from the sources (dir 1).
 // A path is at most `len` edges, so it is walked twice instead of stored: once to decide, once to mark.
+// The nodes a walk starts from are the few that `ignored` does not cover (sources and sinks: ~1 % of the edges): they are
+// listed first (one popcount pass over the bitmap + a scan), and the walk kernel runs one thread per LISTED node instead of
+// one per node of the graph — 12 launches over 6 x 10^7 threads each were 48 ms, nearly all of it threads that returned at once.
+__global__ void k_tips_cand_count(const unsigned long long *__restrict__ ignored, uint64_t n, uint64_t n_words, uint32_t *__restrict__ cnt) {
+  const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= n_words) return;
+  unsigned long long free_bits = ~ignored[w];
+  if ((w + 1) * 64 > n) free_bits &= (n & 63) ? ((1ull << (n & 63)) - 1) : ~0ull;
+  cnt[w] = (uint32_t)__builtin_popcountll(free_bits);
+}
+__global__ void k_tips_cand_write(const unsigned long long *__restrict__ ignored, uint64_t n, uint64_t n_words, const uint64_t *__restrict__ off,
+                                  uint64_t *__restrict__ cand) {
+  const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= n_words) return;
+  unsigned long long free_bits = ~ignored[w];
+  if ((w + 1) * 64 > n) free_bits &= (n & 63) ? ((1ull << (n & 63)) - 1) : ~0ull;
+  uint64_t o = off[w];
+  for (; free_bits; free_bits &= free_bits - 1) cand[o++] = w * 64 + (uint64_t)__builtin_ctzll(free_bits);
+}
+
 __global__ void k_tips_walk(DevSdbg g, int len, int dir, unsigned long long *__restrict__ ignored, unsigned long long *__restrict__ to_remove,
-                            unsigned long long *__restrict__ n_tips) {
-  const uint64_t id = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (id >= g.n) return;
+                            unsigned long long *__restrict__ n_tips, const uint64_t *__restrict__ cand, uint64_t n_cand) {
+  const uint64_t ci = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (ci >= (cand ? n_cand : g.n)) return;
+  const uint64_t id = cand ? cand[ci] : ci;
   if (sd_bit(ignored, id)) return;
   if (dir == 0 ? !sd_outdeg_zero(g, id) : !sd_indeg_zero(g, id)) return;
   uint64_t other = kNull, cur = id;
@@ -279,9 +300,31 @@ int sdbg_remove_tips(mhx_ctx *c, const mhx_sdbg_index_info *info, int max_tip_le
   MHX_HIP(hipMemsetAsync(cnt, 0, 8, st));
   const unsigned grid = (unsigned)div_ceil(g.n, 256);
   MHX_LAUNCH(c, "tips_init", (double)g.n * 2, hipLaunchKernelGGL(k_tips_init, dim3(grid), dim3(256), 0, st, g, ignored));
+  const bool listed = c->opt("tips_candidate_list", 1) != 0;
+  uint32_t *wcnt = listed ? c->ws("tips_word_cnt", (nw + 1) * 4).as<uint32_t>() : nullptr;
+  uint64_t *woff = listed ? c->ws("tips_word_off", (nw + 2) * 8).as<uint64_t>() : nullptr;
+  auto walk = [&](int len, int dir) {
+    if (!listed) {
+      MHX_LAUNCH(c, "tips_walk", (double)g.n, hipLaunchKernelGGL(k_tips_walk, dim3(grid), dim3(256), 0, st, g, len, dir, ignored, to_remove, cnt,
+                                                                   (const uint64_t *)nullptr, (uint64_t)0));
+      return;
+    }
+    const unsigned gw = (unsigned)div_ceil(nw, 256);
+    uint64_t n_cand = 0;
+    MHX_LAUNCH(c, "tips_candidates", (double)nw * 16,
+               hipLaunchKernelGGL(k_tips_cand_count, dim3(gw), dim3(256), 0, st, ignored, g.n, nw, wcnt));
+    exclusive_scan_u32_u64(c, wcnt, woff, nw, woff + nw + 1);
+    MHX_HIP(hipMemcpyAsync(&n_cand, woff + nw + 1, 8, hipMemcpyDeviceToHost, st));
+    MHX_HIP(hipStreamSynchronize(st));
+    if (!n_cand) return;
+    uint64_t *cand = c->ws("tips_cand", n_cand * 8 + 64).as<uint64_t>();
+    hipLaunchKernelGGL(k_tips_cand_write, dim3(gw), dim3(256), 0, st, ignored, g.n, nw, woff, cand);
+    MHX_LAUNCH(c, "tips_walk", (double)n_cand * 64,
+               hipLaunchKernelGGL(k_tips_walk, dim3((unsigned)div_ceil(n_cand, 256)), dim3(256), 0, st, g, len, dir, ignored, to_remove, cnt, cand, n_cand));
+  };
   auto trim = [&](int len) {
-    MHX_LAUNCH(c, "tips_walk", (double)g.n, hipLaunchKernelGGL(k_tips_walk, dim3(grid), dim3(256), 0, st, g, len, 0, ignored, to_remove, cnt));
-    MHX_LAUNCH(c, "tips_walk", (double)g.n, hipLaunchKernelGGL(k_tips_walk, dim3(grid), dim3(256), 0, st, g, len, 1, ignored, to_remove, cnt));
+    walk(len, 0);
+    walk(len, 1);
     hipLaunchKernelGGL(k_tips_apply, dim3((unsigned)div_ceil(nw, 256)), dim3(256), 0, st, g.invalid, to_remove, nw);
   };
   for (int len = 2; len < max_tip_len; len *= 2) trim(len);  // sdbg_pruning.cpp:159-166

@@ -147,6 +147,7 @@ SYMBOLS = {
     "mhx_bucket_histogram": (C.c_int, [_P, C.c_int, C.c_uint32, C.c_uint32, _P]),
     "mhx_set_bucket_filter": (C.c_int, [_P, _P, C.c_uint64, C.c_uint64, C.c_int]),
     "mhx_alloc_stats": (None, [_P, _P, _P, _P]),
+    "mhx_comm_init_hosted": (_P, [_P, C.c_int, C.c_int, _P]),
     "mhx_reset": (C.c_int, [_P]),
     "mhx_profile_enable": (C.c_int, [_P, C.c_int]),
     "mhx_profile_reset": (C.c_int, [_P]),
@@ -278,7 +279,7 @@ class Engine:
         self._chk(self.lib.mhx_sort_records(self.h, _ptr(items), items.shape[0], key_words, items.shape[1] - key_words))
         return items
 
-    # ---- multi-GPU phases (see megahit_amd/dist.py)
+    # ---- multi-GPU phases, one call each (the C++ drivers of comm.hip compose them: lib.Comm)
     def set_partition(self, my_part, n_parts, bucket_begin):
         bb = np.ascontiguousarray(bucket_begin, dtype=np.uint32)
         self._chk(self.lib.mhx_set_partition(self.h, my_part, n_parts, _ptr(bb)))
@@ -331,7 +332,7 @@ class Engine:
         return r
 
     def as_tensor(self, ptr, nbytes, device):
-        """torch uint8 view of library-owned device memory (for the collectives in megahit_amd/dist.py)."""
+        """torch uint8 view of library-owned device memory (zero copy)."""
         from .dist import device_bytes
         return device_bytes(ptr, nbytes, device)
 
@@ -435,6 +436,21 @@ class Comm:
         if not h:
             raise MhxError(engine.lib.mhx_last_error().decode())
         return cls(engine, h)
+
+    @classmethod
+    def hosted(cls, engine, dist, rank, n_ranks):
+        """The caller's torch.distributed group (any backend that moves CPU tensors, e.g. gloo) moves the bytes through host
+        memory (megahit_amd/hosted.py): rank processes that cannot share an RCCL world, e.g. several on one GPU."""
+        from . import hosted as H
+        t, keep = H.make_transport(dist, rank, n_ranks)
+        engine.lib.mhx_comm_init_hosted.restype = C.c_void_p
+        engine.lib.mhx_comm_init_hosted.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(H.HostTransport)]
+        h = engine.lib.mhx_comm_init_hosted(engine.h, rank, n_ranks, C.byref(t))
+        if not h:
+            raise MhxError(engine.lib.mhx_last_error().decode())
+        cm = cls(engine, h)
+        cm._keep = (t, keep)  # the callbacks must outlive the communicator
+        return cm
 
     @classmethod
     def local_group(cls, engines):

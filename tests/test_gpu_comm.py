@@ -14,8 +14,8 @@ import pytest
 import golden_util as gu
 import oracle_binding as ob
 from megahit_amd import canon, lib
-from test_dist_cpu import _reads as reads_of
-from test_dist_cpu import _seqs_with_mult
+from dist_inputs import reads_of
+from dist_inputs import seqs_with_mult as _seqs_with_mult
 
 pytestmark = pytest.mark.gpu
 

@@ -88,7 +88,7 @@ def test_bucket_histogram_equals_oracle_items(engine, stage, k, m):
     import oracle_binding as ob
     from test_gpu_count import load, make_reads
     if stage == "seq2sdbg":
-        from test_dist_cpu import _seqs_with_mult
+        from dist_inputs import seqs_with_mult as _seqs_with_mult
         seqs, mult = _seqs_with_mult(9)
         pkg = ob.Package(seqs, reverse=False)
         engine.load_sequences(pkg.words(), pkg.n_seqs, 0, pkg.start())
