@@ -160,6 +160,25 @@ def cpu_baseline(sample_reads, threads=None):
     return out
 
 
+def cpu_full_size(n_reads, threads=8):
+    """--cpu-full: the reference's read2sdbg on the whole workload of this run (the library of tools/make_fullsize_golden.py),
+    timed here and now on this host, digest compared with the committed known answer"""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import make_fullsize_golden as mfg
+    from megahit_amd import canon
+    ref = os.path.join(ROOT, "oracle", "_ref", "ref_core")
+    with tempfile.TemporaryDirectory(prefix="mhx_cpufull_") as d:
+        mfg.gen_library(os.path.join(d, "reads"), n_reads)
+        cmd = [ref, "read2sdbg", "-k", str(K), "-m", str(MIN_COUNT), "--host_mem", "64e9", "--num_cpu_threads", str(threads),
+               "--read_lib_file", os.path.join(d, "reads"), "--output_prefix", os.path.join(d, "out")]
+        t0 = time.perf_counter()
+        subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        dt = time.perf_counter() - t0
+        digest = canon.digest_sdbg(os.path.join(d, "out"))
+    return {"wall_s": round(dt, 1), "threads": threads, "M_edges_per_s": round(n_reads * (READ_LEN - K) / dt / 1e6, 2), "digest": digest,
+            "host_cores": os.cpu_count()}
+
+
 def end_to_end(n_reads):
     """Files in -> files out through the drop-in CLI on the same 10 M-read library (.bin/.lib_info), every process started
     right behind the previous one — no pauses — as the reference's orchestrator starts its sub-programs (src/megahit:771-847):
@@ -299,6 +318,8 @@ def main():
     ap.add_argument("--cpu-sample-reads", type=float, default=1e6)
     ap.add_argument("--no-e2e", action="store_true", help="skip the files-in -> files-out run of the CLI after the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-full", action="store_true", help="also time the reference's CPU path on the FULL workload in this very run "
+                    "(~2 min of host time at 10 M reads; without it the full-size figure quoted is the one committed under profiles/)")
     ap.add_argument("--force-dist", action="store_true", help="run the multi-GPU code path (RCCL collectives) even with one rank")
     ap.add_argument("--engine", choices=["read2sdbg", "count", "seq2sdbg"], default="read2sdbg",
                     help="sub-program to time; read2sdbg is BASELINE.json's metric, the others are reported beside it (1 GPU)")
@@ -476,6 +497,8 @@ def main():
             if not args.no_cpu_baseline and args.engine == "read2sdbg":
                 try:
                     out["cpu_baseline"] = cpu_baseline(int(args.cpu_sample_reads) // 2 * 2)
+                    if args.cpu_full:
+                        out["cpu_baseline"]["full_size_this_run"] = cpu_full_size(n_reads)
                 except Exception as ex:  # the baseline is reporting only; never lose the GPU number
                     out["cpu_baseline"] = {"value": None, "error": str(ex)}
             if e2e_result is not None:

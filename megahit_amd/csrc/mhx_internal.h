@@ -98,6 +98,7 @@ struct mhx_ctx {
   std::function<void(const mhx::OnesweepLaunch &)> gen_first_pass;
   const void *gen_buf = nullptr;
   uint64_t gen_n = 0;
+  bool s2_filter_in_extract = false;  // passes.hip -> s2_extract: apply ws "filter_lut" while counting / writing the items
   bool s1_defer_items = false;  // the caller of extract_stage(S1) will sort right away: s1_extract may defer the items to that sort
   // memory-bounded passes (passes.hip): only items of the kept lv1 buckets are materialised
   bool filter_on = false, accumulate = false;

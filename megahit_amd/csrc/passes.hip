@@ -126,6 +126,22 @@ void bucket_histogram(mhx_ctx *c, int stage, uint32_t k, uint32_t m, uint64_t *h
 // items of `stage` -> ws("items_a"), restricted to the kept buckets when a filter is set
 StageItems extract_stage(mhx_ctx *c, int stage, uint32_t k, uint32_t m) {
   if (!c->filter_on) return extract_all(c, stage, k, m);
+  if (stage == MHX_STAGE_S2 && !s2_use_aggregated(c, k, m) && c->opt("s2_filter_in_extract", 1)) {
+    // stage 2 per occurrence: the extraction itself leaves out the items of the dropped buckets (s2.hip s2_kept_mask) — one
+    // scan of the reads per pass, no staging batches, no keep/drop split, nothing of the dropped buckets ever written
+    c->s2_filter_in_extract = true;
+    StageItems r;
+    try {
+      r = extract_all(c, stage, k, m);
+    } catch (...) {
+      c->s2_filter_in_extract = false;
+      throw;
+    }
+    c->s2_filter_in_extract = false;
+    if (r.n > c->filter_expected) throw Error("bucket filter: more items in the kept buckets than announced");
+    c->pre_hist_buf = nullptr;
+    return r;
+  }
   hipStream_t st = c->stream;
   const uint8_t *lut = c->work["filter_lut"].as<uint8_t>();
   uint64_t kept = 0;

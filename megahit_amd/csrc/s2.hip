@@ -40,10 +40,40 @@ __device__ __forceinline__ unsigned s2_items_at(const uint32_t *__restrict__ seq
   return (1u + left + right) * (pal ? 1u : 2u);
 }
 
+// lv1 bucket (top 8 chars) of `in` shifted left by c chars
+template <int KW>
+__device__ __forceinline__ uint32_t shifted_bucket(const uint32_t (&in)[KW], int c) {
+  uint64_t hi = (uint64_t)in[0] << 32;
+  if constexpr (KW > 1) hi |= in[1];
+  return (uint32_t)((hi << (2 * c)) >> 48);
+}
+// Bucket-range passes (mhx_set_bucket_filter): which of the items of an occurrence fall into kept buckets, as a bit mask in
+// the order s2_write_items emits them (left fwd, left rc, solid fwd, solid rc, right fwd, right rc; bits of absent items 0).
+// The filter is applied HERE, while the items are counted and written, instead of materialising every item of every read in
+// batches and splitting kept from dropped afterwards (the reference's OffsetFiller::IsHandling test, base_engine.h:106-108,
+// sits in the same place: Lv1FillOffsets).
+template <int KW>
+__device__ __forceinline__ unsigned s2_kept_mask(const uint32_t (&e)[KW], const uint32_t (&rc)[KW], unsigned mask, const uint8_t *__restrict__ drop) {
+  const bool pal = mask & 4u;
+  unsigned keep = 0;
+  auto k = [&](const uint32_t (&w)[KW], int c) -> unsigned { return drop[shifted_bucket<KW>(w, c)] ? 0u : 1u; };
+  if (mask & 1u) {
+    keep |= k(e, 0) << 0;
+    if (!pal) keep |= k(rc, 2) << 1;
+  }
+  keep |= k(e, 1) << 2;
+  if (!pal) keep |= k(rc, 1) << 3;
+  if (mask & 2u) {
+    keep |= k(e, 2) << 4;
+    if (!pal) keep |= k(rc, 0) << 5;
+  }
+  return keep;
+}
+
 template <int KW>
 __global__ __launch_bounds__(256) void k_s2_count(const uint32_t *__restrict__ seq, const uint64_t *__restrict__ start, uint64_t n_seqs,
                                                   int k, const unsigned long long *__restrict__ solid, int sure,
-                                                  uint32_t *__restrict__ cnt) {
+                                                  uint32_t *__restrict__ cnt, const uint8_t *__restrict__ drop) {
   const int lane = lane_id();
   const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / kWave;
   const uint64_t n_waves = (uint64_t)gridDim.x * blockDim.x / kWave;
@@ -56,6 +86,12 @@ __global__ __launch_bounds__(256) void k_s2_count(const uint32_t *__restrict__ s
         const uint32_t p = p0 + lane;
         unsigned mask, c = 0;
         if (p < L - k) c = s2_items_at<KW>(seq, solid, sure != 0, st, L, p, k, &mask);
+        if (drop && c) {  // only the items of the kept buckets
+          uint32_t e[KW], rc[KW];
+          load_chars<KW>(seq, st + p, k + 1, e);
+          rc_chars<KW>(e, k + 1, rc);
+          c = (unsigned)__builtin_popcount(s2_kept_mask<KW>(e, rc, mask, drop));
+        }
         total += wave_sum<uint32_t>(c);
       }
     }
@@ -104,28 +140,34 @@ __device__ __forceinline__ void s2_store(const uint32_t (&key)[KW], uint32_t low
 //   right-$ fwd: e[2..k] (k-1) W=e[1] rc: rc[0..k-1]           W=$
 template <int KW, int S>
 __device__ __forceinline__ void s2_write_items(const uint32_t (&e)[KW], const uint32_t (&rc)[KW], int k, unsigned mask,
-                                               uint32_t *__restrict__ dst) {
+                                               uint32_t *__restrict__ dst, unsigned keep = 0x3Fu) {
   const bool pal = mask & 4u;
   const uint32_t e0 = e[0] >> 30, e1 = (e[0] >> 28) & 3u, r0 = rc[0] >> 30, r1 = (rc[0] >> 28) & 3u;
   uint32_t t[KW];
   if (mask & 1u) {
-    shl_mask_chars<KW>(e, 0, k, t);
-    s2_store<KW, S>(t, 8u | kSentinel, dst); dst += S;
-    if (!pal) {
+    if (keep & 1u) {
+      shl_mask_chars<KW>(e, 0, k, t);
+      s2_store<KW, S>(t, 8u | kSentinel, dst); dst += S;
+    }
+    if (!pal && (keep & 2u)) {
       shl_mask_chars<KW>(rc, 2, k - 1, t);
       s2_store<KW, S>(t, r1, dst); dst += S;
     }
   }
-  shl_mask_chars<KW>(e, 1, k, t);
-  s2_store<KW, S>(t, 8u | e0, dst); dst += S;
-  if (!pal) {
+  if (keep & 4u) {
+    shl_mask_chars<KW>(e, 1, k, t);
+    s2_store<KW, S>(t, 8u | e0, dst); dst += S;
+  }
+  if (!pal && (keep & 8u)) {
     shl_mask_chars<KW>(rc, 1, k, t);
     s2_store<KW, S>(t, 8u | r0, dst); dst += S;
   }
   if (mask & 2u) {
-    shl_mask_chars<KW>(e, 2, k - 1, t);
-    s2_store<KW, S>(t, e1, dst); dst += S;
-    if (!pal) {
+    if (keep & 16u) {
+      shl_mask_chars<KW>(e, 2, k - 1, t);
+      s2_store<KW, S>(t, e1, dst); dst += S;
+    }
+    if (!pal && (keep & 32u)) {
       shl_mask_chars<KW>(rc, 0, k, t);
       s2_store<KW, S>(t, 8u | kSentinel, dst); dst += S;
     }
@@ -136,7 +178,7 @@ template <int KW, int S>
 __global__ __launch_bounds__(256) void k_s2_extract(const uint32_t *__restrict__ seq, const uint64_t *__restrict__ start,
                                                     const uint64_t *__restrict__ item_start, uint64_t n_seqs, int k,
                                                     const unsigned long long *__restrict__ solid, int sure,
-                                                    uint32_t *__restrict__ items) {
+                                                    uint32_t *__restrict__ items, const uint8_t *__restrict__ drop) {
   const int lane = lane_id();
   const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / kWave;
   const uint64_t n_waves = (uint64_t)gridDim.x * blockDim.x / kWave;
@@ -147,7 +189,7 @@ __global__ __launch_bounds__(256) void k_s2_extract(const uint32_t *__restrict__
     uint64_t carry = item_start[r];
     for (uint32_t p0 = 0; p0 < L - k; p0 += kWave) {
       const uint32_t p = p0 + lane;
-      unsigned mask = 0, c = 0;
+      unsigned mask = 0, c = 0, keep = 0x3Fu;
       uint32_t e[KW], rc[KW];
       if (p < L - k) {
         const uint64_t fo = st + p;
@@ -159,11 +201,15 @@ __global__ __launch_bounds__(256) void k_s2_extract(const uint32_t *__restrict__
           const bool right = p + k + 1 == L || !(sure || bit_at(solid, fo + 1)); // :411-412
           mask = (left ? 1u : 0u) | (right ? 2u : 0u) | (pal ? 4u : 0u);
           c = (1u + left + right) * (pal ? 1u : 2u);
+          if (drop) {
+            keep = s2_kept_mask<KW>(e, rc, mask, drop);
+            c = (unsigned)__builtin_popcount(keep);
+          }
         }
       }
       const uint32_t inc = wave_inclusive_sum<uint32_t>(c);
       const uint32_t tot = __shfl(inc, kWave - 1, kWave);
-      if (c) s2_write_items<KW, S>(e, rc, k, mask, items + (carry + inc - c) * S);
+      if (c) s2_write_items<KW, S>(e, rc, k, mask, items + (carry + inc - c) * S, keep);
       carry += tot;
     }
   }
@@ -673,11 +719,13 @@ uint64_t s2_extract(mhx_ctx *c, uint32_t k, uint32_t m) {
   uint64_t *item_start = c->ws("seq_item_start", (ns + 2) * 8).as<uint64_t>();
   uint64_t n_items = 0;
   const unsigned grid = 256 * 8;
+  // bucket-range passes: only the items of the kept buckets are counted and written (s2_kept_mask)
+  const uint8_t *drop = c->s2_filter_in_extract ? c->work["filter_lut"].as<uint8_t>() : nullptr;
   if (ns) {
     MHX_DISPATCH_KW(KWv, {
       MHX_LAUNCH(c, "s2_count", (double)s.n_bases * 3 / 8 + (double)ns * 20,
                  hipLaunchKernelGGL((k_s2_count<KW>), dim3(grid), dim3(256), 0, st, s.words.as<uint32_t>(), s.start.as<uint64_t>(), ns,
-                                    (int)k, solid, sure, cnt));
+                                    (int)k, solid, sure, cnt, drop));
     });
     exclusive_scan_u32_u64(c, cnt, item_start, ns, item_start + ns + 1);
     MHX_HIP(hipMemcpyAsync(&n_items, item_start + ns + 1, 8, hipMemcpyDeviceToHost, st));
@@ -690,11 +738,11 @@ uint64_t s2_extract(mhx_ctx *c, uint32_t k, uint32_t m) {
       if (S == KW)
         MHX_LAUNCH(c, "s2_extract", (double)n_items * item_bytes + (double)s.n_bases * 3 / 8,
                    hipLaunchKernelGGL((k_s2_extract<KW, KW>), dim3(grid), dim3(256), 0, st, s.words.as<uint32_t>(), s.start.as<uint64_t>(),
-                                      item_start, ns, (int)k, solid, sure, buf_a));
+                                      item_start, ns, (int)k, solid, sure, buf_a, drop));
       else
         MHX_LAUNCH(c, "s2_extract", (double)n_items * item_bytes + (double)s.n_bases * 3 / 8,
                    hipLaunchKernelGGL((k_s2_extract<KW, KW + 1>), dim3(grid), dim3(256), 0, st, s.words.as<uint32_t>(),
-                                      s.start.as<uint64_t>(), item_start, ns, (int)k, solid, sure, buf_a));
+                                      s.start.as<uint64_t>(), item_start, ns, (int)k, solid, sure, buf_a, drop));
     });
   }
   return n_items;

@@ -339,7 +339,8 @@ static uint32_t *radix_sort_onesweep(mhx_ctx *c, uint32_t *a, uint32_t *b, uint6
   MHX_HIP(hipMemsetAsync(tickets, 0, (kErrSlot + 8) * 4, st));
   const double bytes = (double)n * S * 4;
   static const std::string nm_hist = "radix_hist_all_" + std::to_string(S * 4) + "B", nm_scat = "radix_scatter_" + std::to_string(S * 4) + "B";
-  const unsigned hgrid = (unsigned)std::min<uint64_t>(div_ceil(n, kSortThreads), 4096);
+  // (>= 16 records per thread: every workgroup ends with 256 global atomics per pass, which is all a small input would do)
+  const unsigned hgrid = (unsigned)std::min<uint64_t>(div_ceil(n, (uint64_t)kSortThreads * 16), 4096);
   std::vector<DigitSpec> all(P);
   for (int p = 0; p < P; ++p) all[p] = spec_of_pass(passes[p], key_words);
   // extraction may have taken the digit histograms while it produced the records (s1.hip): then no read at all
