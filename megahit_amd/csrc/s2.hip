@@ -253,47 +253,63 @@ __device__ __forceinline__ void s2d_run_ends(const unsigned long long *__restric
   *r = w & ~((w >> 1) | (next << 63));
 }
 // upper bound of the number of dummy items (exact unless palindromes occur)
+// (grid-stride: one atomic on the shared total per workgroup, not per 256 words — 9 x 10^4 same-address atomics were the
+// whole millisecond this kernel took for a 190 MB bitmap)
 __global__ __launch_bounds__(256) void k_s2d_bound(const unsigned long long *__restrict__ solid, uint64_t n_words,
                                                    unsigned long long *__restrict__ total) {
   __shared__ uint64_t sm[256 / kWave + 1];
-  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   uint64_t c = 0;
-  if (i < n_words) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += (uint64_t)gridDim.x * blockDim.x) {
     unsigned long long l, r;
     s2d_run_ends(solid, i, n_words, &l, &r);
-    c = 2ull * (__builtin_popcountll(l) + __builtin_popcountll(r));
+    c += 2ull * (__builtin_popcountll(l) + __builtin_popcountll(r));
   }
   uint64_t tot;
   block_exclusive_sum<uint64_t, 256>(c, sm, &tot);
   if (threadIdx.x == 0 && tot) atomicAdd(total, (unsigned long long)tot);
 }
+constexpr int kS2dWords = 8;
 // emission in arbitrary order (the items are sorted next): per block one atomicAdd on the output cursor
 __global__ __launch_bounds__(256) void k_s2d_emit(const uint32_t *__restrict__ seq, const uint64_t *__restrict__ start, uint64_t n_seqs,
                                                   uint32_t fixed_len, int k, const unsigned long long *__restrict__ solid, uint64_t n_words,
                                                   uint2 *__restrict__ items, unsigned long long *__restrict__ cursor) {
   __shared__ uint64_t sm[256 / kWave + 1];
   __shared__ unsigned long long s_base;
-  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const uint64_t mask_k = ~0ull << (64 - 2 * k), mask_k1 = ~0ull << (64 - 2 * (k - 1));
-  unsigned long long l = 0, r = 0;
-  if (i < n_words) s2d_run_ends(solid, i, n_words, &l, &r);
-  // pass 1: number of items of this word (palindromes emit the forward item only)
+  // kS2dWords bitmap words per thread and cursor bump: 16 x fewer same-address atomics than one per 256 words
+  for (uint64_t blk = blockIdx.x; blk * (256ull * kS2dWords) < n_words; blk += gridDim.x) {
   uint32_t c = 0;
-  for (unsigned long long cand = l | r; cand; cand &= cand - 1) {
-    const int b = __builtin_ctzll(cand);
-    const uint64_t fo = i * 64 + b;
-    uint32_t w[2];
-    load_chars<2>(seq, fo, k + 1, w);
-    const uint64_t e = ((uint64_t)w[0] << 32) | w[1];
-    const unsigned ends = (unsigned)((l >> b) & 1ull) + (unsigned)((r >> b) & 1ull);
-    c += ends * (e == rc64_s2(e, k + 1) ? 1u : 2u);
+  unsigned long long ls[kS2dWords], rs[kS2dWords];
+#pragma unroll
+  for (int q = 0; q < kS2dWords; ++q) {
+    const uint64_t i = blk * (256ull * kS2dWords) + (uint64_t)q * 256 + threadIdx.x;
+    ls[q] = rs[q] = 0;
+    if (i < n_words) s2d_run_ends(solid, i, n_words, &ls[q], &rs[q]);
+  }
+  // pass 1: number of items of these words (palindromes emit the forward item only)
+#pragma unroll
+  for (int q = 0; q < kS2dWords; ++q) {
+    const uint64_t i = blk * (256ull * kS2dWords) + (uint64_t)q * 256 + threadIdx.x;
+    const unsigned long long l = ls[q], r = rs[q];
+    for (unsigned long long cand = l | r; cand; cand &= cand - 1) {
+      const int b = __builtin_ctzll(cand);
+      const uint64_t fo = i * 64 + b;
+      uint32_t w[2];
+      load_chars<2>(seq, fo, k + 1, w);
+      const uint64_t e = ((uint64_t)w[0] << 32) | w[1];
+      const unsigned ends = (unsigned)((l >> b) & 1ull) + (unsigned)((r >> b) & 1ull);
+      c += ends * (e == rc64_s2(e, k + 1) ? 1u : 2u);
+    }
   }
   uint64_t tot;
   const uint64_t excl = block_exclusive_sum<uint64_t, 256>((uint64_t)c, sm, &tot);
   if (threadIdx.x == 0) s_base = tot ? atomicAdd(cursor, (unsigned long long)tot) : 0ull;
   __syncthreads();
-  if (!c) return;
   uint2 *dst = items + s_base + excl;
+#pragma unroll
+  for (int q = 0; q < kS2dWords; ++q) {
+    const uint64_t i = blk * (256ull * kS2dWords) + (uint64_t)q * 256 + threadIdx.x;
+    const unsigned long long l = ls[q], r = rs[q];
   for (unsigned long long cand = l | r; cand; cand &= cand - 1) {
     const int b = __builtin_ctzll(cand);
     const uint64_t fo = i * 64 + b;
@@ -315,6 +331,9 @@ __global__ __launch_bounds__(256) void k_s2d_emit(const uint32_t *__restrict__ s
       if (!pal) put(er & mask_k, 1, kSentinel);                          //   rc : e'[0..k-1], W = $
     }
   }
+  }  // q
+  __syncthreads();
+  }  // blk
   (void)start;
   (void)n_seqs;
   (void)fixed_len;
@@ -770,7 +789,7 @@ uint64_t s2_agg_extract(mhx_ctx *c, uint32_t k) {
   uint64_t bound = 0;
   if (n_words) {
     MHX_LAUNCH(c, "s2_bound", (double)n_words * 8,
-               hipLaunchKernelGGL(k_s2d_bound, dim3((unsigned)div_ceil(n_words, 256)), dim3(256), 0, st, solid, n_words, cur + 1));
+               hipLaunchKernelGGL(k_s2d_bound, dim3((unsigned)std::min<uint64_t>(div_ceil(n_words, 256), 2048)), dim3(256), 0, st, solid, n_words, cur + 1));
     MHX_HIP(hipMemcpyAsync(&bound, cur + 1, 8, hipMemcpyDeviceToHost, st));
     MHX_HIP(hipStreamSynchronize(st));
   }
@@ -779,7 +798,7 @@ uint64_t s2_agg_extract(mhx_ctx *c, uint32_t k) {
   uint64_t n_dummy = 0;
   if (bound) {
     MHX_LAUNCH(c, "s2_extract", (double)bound * 8 + (double)n_words * 8,
-               hipLaunchKernelGGL(k_s2d_emit, dim3((unsigned)div_ceil(n_words, 256)), dim3(256), 0, st, s.words.as<uint32_t>(),
+               hipLaunchKernelGGL(k_s2d_emit, dim3((unsigned)std::min<uint64_t>(div_ceil(n_words, 256 * kS2dWords), 4096)), dim3(256), 0, st, s.words.as<uint32_t>(),
                                   s.start.as<uint64_t>(), ns, s.fixed_len, (int)k, solid, n_words, reinterpret_cast<uint2 *>(buf_a) + n_agg, cur));
     MHX_HIP(hipMemcpyAsync(&n_dummy, cur, 8, hipMemcpyDeviceToHost, st));
     MHX_HIP(hipStreamSynchronize(st));
@@ -812,7 +831,7 @@ static int s2_agg_in_place(mhx_ctx *c, uint32_t k, mhx_sdbg_result *out) {
   uint64_t bound = 0;
   if (n_words) {
     MHX_LAUNCH(c, "s2_bound", (double)n_words * 8,
-               hipLaunchKernelGGL(k_s2d_bound, dim3((unsigned)div_ceil(n_words, 256)), dim3(256), 0, st, solid, n_words, cur + 1));
+               hipLaunchKernelGGL(k_s2d_bound, dim3((unsigned)std::min<uint64_t>(div_ceil(n_words, 256), 2048)), dim3(256), 0, st, solid, n_words, cur + 1));
     MHX_HIP(hipMemcpyAsync(&bound, cur + 1, 8, hipMemcpyDeviceToHost, st));
     MHX_HIP(hipStreamSynchronize(st));
   }
@@ -820,7 +839,7 @@ static int s2_agg_in_place(mhx_ctx *c, uint32_t k, mhx_sdbg_result *out) {
   uint64_t n_dummy = 0;
   if (bound) {
     MHX_LAUNCH(c, "s2_extract", (double)bound * 8 + (double)n_words * 8,
-               hipLaunchKernelGGL(k_s2d_emit, dim3((unsigned)div_ceil(n_words, 256)), dim3(256), 0, st, s.words.as<uint32_t>(),
+               hipLaunchKernelGGL(k_s2d_emit, dim3((unsigned)std::min<uint64_t>(div_ceil(n_words, 256 * kS2dWords), 4096)), dim3(256), 0, st, s.words.as<uint32_t>(),
                                   s.start.as<uint64_t>(), s.n_seqs, s.fixed_len, (int)k, solid, n_words, reinterpret_cast<uint2 *>(buf_a) + n_agg, cur));
     MHX_HIP(hipMemcpyAsync(&n_dummy, cur, 8, hipMemcpyDeviceToHost, st));
     MHX_HIP(hipStreamSynchronize(st));

@@ -1,8 +1,8 @@
 """The reference's CPU path at FULL size (BASELINE configs[1]: 10 M reads, read2sdbg k=21 m=2) on this host, at several
-OpenMP thread counts -> JSON (profiles/r02_cpu_fullsize.json).  Run once per round on the GPU box's host by
+OpenMP thread counts -> JSON (profiles/r03_cpu_fullsize.json).  Run once per round on the GPU box's host by
 tools/gpu_evidence.sh; bench.py quotes it beside its bounded in-run sample.
 
-    python tools/cpu_fullsize.py [--threads 8,32] > profiles/r02_cpu_fullsize.json"""
+    python tools/cpu_fullsize.py [--threads 8,32] > profiles/r03_cpu_fullsize.json"""
 import argparse
 import json
 import os

@@ -1,8 +1,10 @@
 #!/bin/bash
 # One gpurun call: the bench lines, rocprofv3 kernel stats and the two PMC passes of the same command, the reference's
-# CPU path at full size on this host.   gpurun --timeout 2400 -- 'bash tools/gpu_evidence.sh r02 [skip_cpu]'
-# Results land in gpurun_out/TAG_*; copy what is to be judged into profiles/.
-TAG=${1:-r02}
+# CPU path at full size on this host, the other sub-programs, routes and rows.
+#     gpurun --timeout 3000 -- 'bash tools/gpu_evidence.sh r03 [skip_cpu]'
+# Results land in gpurun_out/TAG_*; what is to be judged is copied into profiles/ by the caller (the PMC file right here,
+# so that the bench line of this very call can quote it).
+TAG=${1:-r03}
 R=$(pwd)
 O=$R/gpurun_out
 mkdir -p $O
@@ -19,22 +21,23 @@ timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/${TAG}_pmc_fetc
 timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/${TAG}_pmc_write -- $BENCH > $O/${TAG}_pmc_write.log 2>&1
 cd $R
 python tools/pmc_to_json.py $O/${TAG}_pmc_fetch $O/${TAG}_pmc_write > $O/${TAG}_pmc_traffic.json 2> $O/${TAG}_pmc_to_json.err
-cp $O/${TAG}_pmc_traffic.json profiles/r02_pmc_traffic.json   # so that the bench line below carries the traffic of this very tree
+cp $O/${TAG}_pmc_traffic.json profiles/${TAG}_pmc_traffic.json   # so that the bench line below carries the traffic of this very build
 find $O/${TAG}_trace -name '*kernel_stats.csv' -exec cp {} $O/${TAG}_kernel_stats.csv \;
 find $O/${TAG}_trace $O/${TAG}_pmc_fetch $O/${TAG}_pmc_write -type f ! -name '*stats.csv' -delete 2>/dev/null
-[ -n "$CPU_PID" ] && wait $CPU_PID && cp $O/${TAG}_cpu_fullsize.json profiles/r02_cpu_fullsize.json
-timeout 900 python bench.py > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err
-cat $O/${TAG}_bench.json
-timeout 600 python bench.py --engine count --steps 3 --no-e2e > $O/${TAG}_bench_count.json 2>> $O/${TAG}_bench.err
-timeout 600 python bench.py --engine seq2sdbg --steps 3 --no-e2e > $O/${TAG}_bench_seq2sdbg.json 2>> $O/${TAG}_bench.err
-timeout 600 python bench.py --force-dist --steps 3 --no-cpu-baseline --no-e2e > $O/${TAG}_bench_force_dist.json 2>> $O/${TAG}_bench.err
-cat $O/${TAG}_bench_count.json $O/${TAG}_bench_seq2sdbg.json
-# the three routes to the first graph through the CLI (files in -> files out), stage 1 with the reference-exact tie order,
-# buildlib, and the copy-invariance check at 20 M / 40 M reads on one GPU
-timeout 600 python tools/e2e_routes.py > $O/${TAG}_e2e_routes.json 2> $O/${TAG}_e2e_routes.err
+timeout 300 python bench.py --engine count --steps 3 --no-e2e > $O/${TAG}_bench_count.json 2> $O/${TAG}_bench_count.err
+timeout 300 python bench.py --engine seq2sdbg --steps 3 --no-e2e > $O/${TAG}_bench_seq2sdbg.json 2> $O/${TAG}_bench_seq2sdbg.err
+timeout 300 python bench.py --force-dist --steps 5 --warmup 2 --no-cpu-baseline --no-e2e > $O/${TAG}_bench_force_dist.json 2> $O/${TAG}_bench_force_dist.err
+cut -c1-300 $O/${TAG}_bench_count.json $O/${TAG}_bench_seq2sdbg.json $O/${TAG}_bench_force_dist.json
 timeout 300 python tools/mercy_prof.py 10e6 > $O/${TAG}_mercy_stage1.json 2> $O/${TAG}_mercy_stage1.err
 timeout 300 python tools/buildlib_bench.py > $O/${TAG}_buildlib.json 2> $O/${TAG}_buildlib.err
-timeout 600 python tools/scale_check.py 10e6 2 > $O/${TAG}_scale_20M.json 2> $O/${TAG}_scale_20M.err
-timeout 900 python tools/scale_check.py 10e6 4 > $O/${TAG}_scale_40M.json 2> $O/${TAG}_scale_40M.err
-tail -c 600 $O/${TAG}_scale_40M.json
-ls -la $O | tail -20
+timeout 600 python tools/next_rows_bench.py > $O/${TAG}_next_rows.json 2> $O/${TAG}_next_rows.err
+timeout 600 python tools/config_bench.py klist > $O/${TAG}_bench_klist.json 2> $O/${TAG}_bench_klist.err
+tail -6 $O/${TAG}_bench_klist.err
+timeout 1200 python tools/config_bench.py meta > $O/${TAG}_bench_meta.json 2> $O/${TAG}_bench_meta.err
+tail -3 $O/${TAG}_bench_meta.err
+[ -n "$CPU_PID" ] && wait $CPU_PID && cp $O/${TAG}_cpu_fullsize.json profiles/${TAG}_cpu_fullsize.json
+# the headline line last, on a device that the runs above have left (its e2e part starts a resident server first)
+timeout 900 python bench.py > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err
+cat $O/${TAG}_bench.json | cut -c1-2500
+timeout 600 python tools/e2e_routes.py > $O/${TAG}_e2e_routes.json 2> $O/${TAG}_e2e_routes.err
+ls -la $O | grep ${TAG}_ | tail -30
