@@ -235,6 +235,81 @@ struct S1Gen {
 };
 
 constexpr int kFastPasses = 4;
+// The digit histograms of the coming sort passes without making the records (the pre-pass of the generating first pass):
+// every thread takes IT CONSECUTIVE items — one division per trip, the three window words are reloaded only when the
+// window moves into the next word (every 16 items), and of the key only its first word is formed (the passes of the
+// partial-sort plans take their digits from the top 32 key bits: `hi_only`; head / tail never reach them).
+template <int IT>
+__global__ __launch_bounds__(256) void k_s1_digit_hist(const uint32_t *__restrict__ seq, uint32_t L, uint32_t per, uint64_t n_items, int k,
+                                                       DigitSpecs specs, unsigned long long *__restrict__ ghist, uint32_t step_q, uint32_t step_r) {
+  constexpr int B = 256 * IT;
+  __shared__ uint32_t h[kFastPasses][4][256];
+  for (int i = threadIdx.x; i < kFastPasses * 4 * 256; i += 256) (&h[0][0][0])[i] = 0;
+  __syncthreads();
+  const int wv = threadIdx.x >> 6;
+  const int km1 = k - 1;
+  const uint64_t kmask = ~0ull << (64 - 2 * km1);
+  const uint64_t n_blocks = (n_items + B - 1) / B;
+  uint64_t q0 = ((uint32_t)blockIdx.x * (uint32_t)B) / per;
+  uint32_t rem0 = ((uint32_t)blockIdx.x * (uint32_t)B) % per;
+  for (uint64_t blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
+    const uint64_t g0 = blk * B + (uint64_t)threadIdx.x * IT;
+    const uint32_t t = rem0 + (uint32_t)threadIdx.x * IT, dq = t / per;
+    uint64_t r = q0 + dq;
+    uint32_t j = t - dq * per;
+    uint64_t wcur = ~0ull;
+    uint32_t x0 = 0, x1 = 0, x2 = 0;
+#pragma unroll
+    for (int u = 0; u < IT; ++u) {
+      if (g0 + u < n_items) {
+        uint32_t q;
+        int forced = -1;
+        if (j < 2) { q = 0; forced = (int)j; }
+        else if (j >= L - k + 2) { q = L - k + 1; forced = (int)(j - (L - k + 2)); }
+        else q = j - 1;
+        const uint64_t a = r * L + q;
+        uint32_t hi;
+        if (a >= 2) {
+          const uint64_t b = a - 2, w = b >> 4;
+          if (w != wcur) {
+            x0 = seq[w];
+            x1 = seq[w + 1];
+            x2 = seq[w + 2];
+            wcur = w;
+          }
+          const unsigned sh = (unsigned)(b & 15) * 2;
+          const uint64_t win = ((uint64_t)funnel_l(x0, x1, sh) << 32) | funnel_l(x1, x2, sh);
+          const uint64_t f = (win << 4) & kmask;
+          const uint64_t rc = rc64(f, km1);
+          const bool use_rc = forced >= 0 ? forced == 1 : f > rc;  // (f == rc: the same first word either way)
+          hi = (uint32_t)((use_rc ? rc : f) >> 32);
+        } else {
+          uint32_t out[3];
+          s1_make_item<2, 3, true>(seq, r * L, L, k, j, 0, 0u, out);
+          hi = out[0];
+        }
+        const uint32_t o2[2] = {hi, 0u};
+        for (int p = 0; p < specs.n; ++p) atomicAdd(&h[p][wv][words_digit2<2>(o2, specs.d[p])], 1u);
+      }
+      if (++j == per) {
+        j = 0;
+        ++r;
+      }
+    }
+    q0 += step_q;
+    rem0 += step_r;
+    if (rem0 >= per) {
+      rem0 -= per;
+      ++q0;
+    }
+  }
+  __syncthreads();
+  for (int p = 0; p < specs.n; ++p) {
+    const uint32_t v = h[p][0][threadIdx.x] + h[p][1][threadIdx.x] + h[p][2][threadIdx.x] + h[p][3][threadIdx.x];
+    if (v) atomicAdd(&ghist[p * 256 + threadIdx.x], (unsigned long long)v);
+  }
+}
+
 template <int IT, bool WRITE>  // items per thread and trip; WRITE = false: only the digit histograms: their window loads are issued together (one in flight per thread = latency-bound)
 __global__ __launch_bounds__(256) void k_s1_extract_fast(const uint32_t *__restrict__ seq, uint32_t L, uint32_t per, uint64_t n_items, int k,
                                                          uint64_t pos_base, uint32_t rank_tag, uint32_t *__restrict__ items, DigitSpecs specs,
@@ -1589,12 +1664,31 @@ uint64_t s1_extract(mhx_ctx *c, uint32_t k, bool compact) {
                hipLaunchKernelGGL((k_s1_extract_fast<ITV, WR>), dim3(fgrid), dim3(256), 0, st, s.words.as<uint32_t>(), s.fixed_len, per, n_items, \
                                   (int)k, pos_base, rank_tag, buf_a, specs, pre_hist, (uint32_t)(stride_items / per), (uint32_t)(stride_items % per))); \
   } while (0)
+      bool hi_only = true;  // every digit of the plan comes from the first key word?
+      for (int p = 0; p < specs.n; ++p) hi_only = hi_only && specs.d[p].wi1 == 0 && (!specs.d[p].mask2 || specs.d[p].wi2 == 0);
       if (defer) {
-        MHX_FAST(4, false, "s1_digit_hist");
+        if (hi_only && c->opt("s1_digit_hist_blocked", 1)) {
+          constexpr int ITH = 8;
+          const unsigned fgrid = (unsigned)std::min<uint64_t>(div_ceil(n_items, 256 * ITH), 256 * 8);
+          const uint64_t stride_items = (uint64_t)fgrid * 256 * ITH;
+          MHX_LAUNCH(c, "s1_digit_hist", (double)s.n_bases / 4,
+                     hipLaunchKernelGGL((k_s1_digit_hist<ITH>), dim3(fgrid), dim3(256), 0, st, s.words.as<uint32_t>(), s.fixed_len, per, n_items, (int)k,
+                                        specs, pre_hist, (uint32_t)(stride_items / per), (uint32_t)(stride_items % per)));
+        } else {
+          MHX_FAST(4, false, "s1_digit_hist");
+        }
         const S1Gen g{s.words.as<uint32_t>(), s.fixed_len, per, (int)k, pos_base, rank_tag};
-        c->gen_first_pass = [g](const OnesweepLaunch &l) {
-          hipLaunchKernelGGL((k_radix_onesweep<3, 8, 3, S1Gen>), dim3(l.grid), dim3(kSortThreads), 0, l.stream, g, l.out, l.n, l.ds, l.nbits, l.bin_start,
-                             l.status, l.ticket, l.err, l.tag, l.xcd_units);
+        // The consumers of this pass (the LDS group-bys behind the remaining passes; compact records, no mercy) count equal
+        // keys: they need the records grouped, not in input order — so the first pass may place the records of a digit in
+        // any order (the later passes are stable with respect to whatever order it leaves).
+        const bool any_order = c->opt("s1_gen_any_order", 1) != 0;
+        c->gen_first_pass = [g, any_order](const OnesweepLaunch &l) {
+          if (any_order)
+            hipLaunchKernelGGL((k_radix_onesweep<3, 8, 3, S1Gen, true>), dim3(l.grid), dim3(kSortThreads), 0, l.stream, g, l.out, l.n, l.ds, l.nbits,
+                               l.bin_start, l.status, l.ticket, l.err, l.tag, l.xcd_units);
+          else
+            hipLaunchKernelGGL((k_radix_onesweep<3, 8, 3, S1Gen, false>), dim3(l.grid), dim3(kSortThreads), 0, l.stream, g, l.out, l.n, l.ds, l.nbits,
+                               l.bin_start, l.status, l.ticket, l.err, l.tag, l.xcd_units);
         };
         c->gen_buf = buf_a;
         c->gen_n = n_items;

@@ -104,7 +104,10 @@ struct SrcArray {
 
 constexpr unsigned long long kStValMask = (1ull << 56) - 1;
 
-template <int S, int NI, int UT, class Src>
+// ANY_ORDER: the records of one digit may leave in any order (the pass is a partition, not a stable sort): a record's rank
+// inside its wavefront is then ONE returning LDS atomic instead of the 8-ballot match-any (~45 VALU operations) — for a
+// first pass whose consumer only needs the records grouped (s1.hip: the generating pass, which is instruction-bound).
+template <int S, int NI, int UT, class Src, bool ANY_ORDER = false>
 __global__ __launch_bounds__(kSortThreads) void k_radix_onesweep(Src src, uint32_t *__restrict__ out, uint64_t n,
                                                                  DigitSpec ds, int nbits, const unsigned long long *__restrict__ bin_start,
                                                                  unsigned long long *__restrict__ status, uint32_t *__restrict__ ticket,
@@ -178,17 +181,21 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_onesweep(Src src, uint32
       const bool valid = li < tile_n;
       const unsigned d = valid ? rec_digit2<S>(rec[t][j], ds) : 0u;
       dig[j] = d;
-      uint64_t peers = __ballot(valid);
-      for (int b = 0; b < nbits; ++b) {
-        const bool bitset = (d >> b) & 1u;
-        const uint64_t m = __ballot(bitset);
-        peers &= bitset ? m : ~m;
+      if constexpr (ANY_ORDER) {
+        rank[j] = valid ? atomicAdd(&wave_cnt[w][d], 1u) : 0u;
+      } else {
+        uint64_t peers = __ballot(valid);
+        for (int b = 0; b < nbits; ++b) {
+          const bool bitset = (d >> b) & 1u;
+          const uint64_t m = __ballot(bitset);
+          peers &= bitset ? m : ~m;
+        }
+        const uint32_t before = wave_cnt[w][d];
+        rank[j] = before + __builtin_popcountll(peers & lanemask_lt);
+        __builtin_amdgcn_wave_barrier();
+        if (valid && (peers & lanemask_lt) == 0) wave_cnt[w][d] = before + __builtin_popcountll(peers);
+        __builtin_amdgcn_wave_barrier();
       }
-      const uint32_t before = wave_cnt[w][d];
-      rank[j] = before + __builtin_popcountll(peers & lanemask_lt);
-      __builtin_amdgcn_wave_barrier();
-      if (valid && (peers & lanemask_lt) == 0) wave_cnt[w][d] = before + __builtin_popcountll(peers);
-      __builtin_amdgcn_wave_barrier();
     }
     __syncthreads();
     {
