@@ -1314,40 +1314,55 @@ __global__ void k_apply_marks(const unsigned long long *__restrict__ pos, uint64
   else atomicOr(bad, 1u);
 }
 
-// byte map -> AtomicBitVector layout (bit i = word i/64, bit i%64; kmbitvector.h:67-88) + popcount
+// byte map -> AtomicBitVector layout (bit i = word i/64, bit i%64; kmbitvector.h:67-88) + popcount.
+// A thread takes 16 bytes (one coalesced 16-byte load per lane: a wavefront reads 1 KB in one instruction), four
+// neighbouring lanes put their 16 bits together.  (One thread per 64 bytes made every load instruction touch 64 lines.)
+__device__ __forceinline__ uint32_t low_bits_of_16_bytes(const uint4 x) {
+  const uint32_t xs[4] = {x.x, x.y, x.z, x.w};
+  uint32_t m = 0;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const uint32_t b = xs[t] & 0x01010101u;  // bytes are 0/1: gather the low bit of each of the 4 bytes
+    m |= ((b | (b >> 7) | (b >> 14) | (b >> 21)) & 0xFu) << (4 * t);
+  }
+  return m;
+}
+// m16 of lanes 4j..4j+3 -> bits of word j (returned on lane 4j)
+__device__ __forceinline__ unsigned long long join_4_lanes(uint32_t m16) {
+  return (unsigned long long)m16 | ((unsigned long long)__shfl_down(m16, 1, kWave) << 16) | ((unsigned long long)__shfl_down(m16, 2, kWave) << 32) |
+         ((unsigned long long)__shfl_down(m16, 3, kWave) << 48);
+}
+// Persistent: a thread walks over chunks g, g + T, g + 2T, ... (T = all threads, a multiple of 4) and adds up its popcounts;
+// one block reduction and one atomic per workgroup at the end.
 __global__ __launch_bounds__(256) void k_pack_solid(const uint8_t *__restrict__ bytes, uint64_t n_bits, unsigned long long *__restrict__ words,
                                                     uint64_t n_words, unsigned long long *__restrict__ n_solid) {
   __shared__ uint64_t sm[256 / kWave + 1];
-  const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  unsigned long long v = 0;
-  if (w < n_words) {
-    const uint4 *p = reinterpret_cast<const uint4 *>(bytes + w * 64);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const uint4 x = p[q];
-      const uint32_t xs[4] = {x.x, x.y, x.z, x.w};
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        // bytes are 0/1: gather the low bit of each of the 4 bytes
-        const uint32_t b = xs[t] & 0x01010101u;
-        const uint32_t nib = (b | (b >> 7) | (b >> 14) | (b >> 21)) & 0xFu;
-        v |= (unsigned long long)nib << (q * 16 + t * 4);
-      }
+  const uint64_t T = (uint64_t)gridDim.x * blockDim.x, n_chunks = n_words * 4;  // the byte map is padded to whole words
+  uint32_t pop = 0;
+  for (uint64_t g0 = (uint64_t)blockIdx.x * blockDim.x; g0 < n_chunks; g0 += T) {  // workgroup-uniform trip count (shuffles inside)
+    const uint64_t g = g0 + threadIdx.x, p0 = g * 16;
+    uint32_t m16 = 0;
+    if (g < n_chunks && p0 < n_bits) {
+      m16 = low_bits_of_16_bytes(reinterpret_cast<const uint4 *>(bytes)[g]);
+      if (p0 + 16 > n_bits) m16 &= (1u << (n_bits - p0)) - 1u;
     }
-    if ((w + 1) * 64 > n_bits) v &= (n_bits & 63) ? ((1ull << (n_bits & 63)) - 1) : ~0ull;
-    words[w] = v;
+    const unsigned long long v = join_4_lanes(m16);
+    if ((threadIdx.x & 3) == 0 && g < n_chunks) words[g >> 2] = v;
+    pop += (uint32_t)__builtin_popcount(m16);
   }
   uint64_t tot;
-  block_exclusive_sum<uint64_t, 256>((uint64_t)__builtin_popcountll(v), sm, &tot);
+  block_exclusive_sum<uint64_t, 256>((uint64_t)pop, sm, &tot);
   if (threadIdx.x == 0 && tot) atomicAdd(n_solid, (unsigned long long)tot);
 }
 
 __global__ __launch_bounds__(256) void k_count_solid(const unsigned long long *__restrict__ words, uint64_t n_words,
                                                      unsigned long long *__restrict__ n_solid) {
   __shared__ uint64_t sm[256 / kWave + 1];
-  const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  uint64_t pop = 0;  // one atomic per workgroup of a bounded grid: 10^5 atomics on one word cost ~1 ms by themselves
+  for (uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < n_words; w += (uint64_t)gridDim.x * blockDim.x)
+    pop += (uint64_t)__builtin_popcountll(words[w]);
   uint64_t tot;
-  block_exclusive_sum<uint64_t, 256>(w < n_words ? (uint64_t)__builtin_popcountll(words[w]) : 0, sm, &tot);
+  block_exclusive_sum<uint64_t, 256>(pop, sm, &tot);
   if (threadIdx.x == 0 && tot) atomicAdd(n_solid, (unsigned long long)tot);
 }
 
@@ -1357,12 +1372,12 @@ __global__ __launch_bounds__(256) void k_pack_solid_inv(const uint8_t *__restric
                                                         uint64_t n_seqs, uint32_t fixed_len, int k, unsigned long long *__restrict__ words,
                                                         uint64_t n_words, unsigned long long *__restrict__ n_solid) {
   __shared__ uint64_t sm[256 / kWave + 1];
-  const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  unsigned long long v = 0;
-  if (w < n_words) {
+  uint64_t pop = 0;
+  for (uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < n_words; w += (uint64_t)gridDim.x * blockDim.x) {
+    unsigned long long v = 0;
     const uint64_t p0 = w * 64;
     uint64_t rid = p0 < n_bits ? seq_of_offset(start, n_seqs, fixed_len, p0) : 0;
-    uint64_t rs = start[rid], re = start[rid + 1];
+    uint64_t re = start[rid + 1];
     const uint4 *pb = reinterpret_cast<const uint4 *>(bytes + p0);
     for (int q = 0; q < 4; ++q) {
       const uint4 x = pb[q];
@@ -1370,21 +1385,50 @@ __global__ __launch_bounds__(256) void k_pack_solid_inv(const uint8_t *__restric
       for (int t = 0; t < 16; ++t) {
         const uint64_t p = p0 + q * 16 + t;
         if (p >= n_bits) break;
-        while (p >= re) {
-          ++rid;
-          rs = re;
-          re = start[rid + 1];
-        }
+        while (p >= re) re = start[++rid + 1];
         const bool valid = p + (uint64_t)k + 1 <= re;  // a (k+1)-mer of this read starts at p
         const bool marked = (xs[t >> 2] >> ((t & 3) * 8)) & 1u;
         if (valid && !marked) v |= 1ull << (q * 16 + t);
       }
     }
-    (void)rs;
     words[w] = v;
+    pop += (uint64_t)__builtin_popcountll(v);
   }
   uint64_t tot;
-  block_exclusive_sum<uint64_t, 256>((uint64_t)__builtin_popcountll(v), sm, &tot);
+  block_exclusive_sum<uint64_t, 256>(pop, sm, &tot);
+  if (threadIdx.x == 0 && tot) atomicAdd(n_solid, (unsigned long long)tot);
+}
+
+// The same for reads of one length L with L - k >= 16: the valid positions of 16 consecutive ones follow from the offset
+// of the first in its read (valid: offset <= L - k - 1), so a thread needs one 16-byte load, one remainder and a few masks
+// instead of a 64-step walk over the read boundaries.
+__global__ __launch_bounds__(256) void k_pack_solid_inv_fixed(const uint8_t *__restrict__ bytes, uint64_t n_bits, uint32_t L, int k,
+                                                              unsigned long long *__restrict__ words, uint64_t n_words,
+                                                              unsigned long long *__restrict__ n_solid) {
+  __shared__ uint64_t sm[256 / kWave + 1];
+  const uint64_t T = (uint64_t)gridDim.x * blockDim.x, n_chunks = n_words * 4;
+  const uint32_t step = (uint32_t)((T * 16) % L);  // the offset in the read advances by this much (mod L) per trip: one
+  uint32_t off = (uint32_t)((((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 16) % L);  // 64-bit remainder per thread, not per chunk
+  uint32_t pop = 0;
+  for (uint64_t g0 = (uint64_t)blockIdx.x * blockDim.x; g0 < n_chunks; g0 += T) {
+    const uint64_t g = g0 + threadIdx.x, p0 = g * 16;
+    uint32_t m16 = 0;
+    if (g < n_chunks && p0 < n_bits) {
+      const uint32_t marked = low_bits_of_16_bytes(reinterpret_cast<const uint4 *>(bytes)[g]);
+      const int t1 = min(max((int)L - k - (int)off, 0), 16);  // positions [0, t1): a (k+1)-mer of this read starts there
+      const int t2 = min((int)L - (int)off, 16);              // positions [t2, 16): the next read, offsets < 16 <= L - k
+      uint32_t valid = ((1u << t1) - 1u) | (0xFFFFu & ~((1u << t2) - 1u));
+      if (p0 + 16 > n_bits) valid &= (1u << (n_bits - p0)) - 1u;
+      m16 = valid & ~marked & 0xFFFFu;
+    }
+    const unsigned long long v = join_4_lanes(m16);
+    if ((threadIdx.x & 3) == 0 && g < n_chunks) words[g >> 2] = v;
+    pop += (uint32_t)__builtin_popcount(m16);
+    off += step;
+    if (off >= L) off -= L;
+  }
+  uint64_t tot;
+  block_exclusive_sum<uint64_t, 256>((uint64_t)pop, sm, &tot);
   if (threadIdx.x == 0 && tot) atomicAdd(n_solid, (unsigned long long)tot);
 }
 
@@ -2046,16 +2090,22 @@ int s1_process(mhx_ctx *c, uint32_t k, uint32_t m, int want_mercy, uint32_t *buf
   }
   if (n_words64 && mark_atomic)
     MHX_LAUNCH(c, "count_solid", (double)n_words64 * 8,
-               hipLaunchKernelGGL(k_count_solid, dim3((unsigned)div_ceil(n_words64, 256)), dim3(256), 0, st, is_solid, n_words64, ctr));
+               hipLaunchKernelGGL(k_count_solid, dim3((unsigned)std::min<uint64_t>(div_ceil(n_words64, 256), 4096)), dim3(256), 0, st, is_solid, n_words64, ctr));
   c->global_marks_inverted = global && !mark_atomic;
-  if (n_words64 && !mark_atomic && s1_mark_mode_used == 1 && !global)
-    MHX_LAUNCH(c, "pack_solid", (double)n_words64 * 72,
-               hipLaunchKernelGGL(k_pack_solid_inv, dim3((unsigned)div_ceil(n_words64, 256)), dim3(256), 0, st, solid_bytes, n_bits,
-                                  s.start.as<uint64_t>(), s.n_seqs, s.fixed_len, (int)k, is_solid, n_words64, ctr));
+  if (n_words64 && !mark_atomic && s1_mark_mode_used == 1 && !global) {
+    if (s.fixed_len >= k + 16 && c->opt("s1_pack_fixed", 1))
+      MHX_LAUNCH(c, "pack_solid", (double)n_words64 * 72,
+                 hipLaunchKernelGGL(k_pack_solid_inv_fixed, dim3((unsigned)std::min<uint64_t>(div_ceil(n_words64 * 4, 256), 4096)), dim3(256), 0, st, solid_bytes, n_bits,
+                                    s.fixed_len, (int)k, is_solid, n_words64, ctr));
+    else
+      MHX_LAUNCH(c, "pack_solid", (double)n_words64 * 72,
+                 hipLaunchKernelGGL(k_pack_solid_inv, dim3((unsigned)std::min<uint64_t>(div_ceil(n_words64, 256), 4096)), dim3(256), 0, st, solid_bytes, n_bits,
+                                    s.start.as<uint64_t>(), s.n_seqs, s.fixed_len, (int)k, is_solid, n_words64, ctr));
+  }
   if (n_words64 && !mark_atomic && (s1_mark_mode_used != 1 || global))  // global: the marks themselves (see above)
     MHX_LAUNCH(c, "pack_solid", (double)n_words64 * 72,
-               hipLaunchKernelGGL(k_pack_solid, dim3((unsigned)div_ceil(n_words64, 256)), dim3(256), 0, st, solid_bytes, n_bits, is_solid, n_words64,
-                                  ctr));
+               hipLaunchKernelGGL(k_pack_solid, dim3((unsigned)std::min<uint64_t>(div_ceil(n_words64 * 4, 256), 4096)), dim3(256), 0, st, solid_bytes, n_bits, is_solid,
+                                  n_words64, ctr));
   {
     unsigned long long h[2];
     MHX_HIP(hipMemcpyAsync(h, ctr, 16, hipMemcpyDeviceToHost, st));
@@ -2112,9 +2162,13 @@ void s1_apply_marks(mhx_ctx *c, const unsigned long long *recv, uint64_t n) {
                hipLaunchKernelGGL(k_apply_marks, dim3((unsigned)div_ceil(n, 256)), dim3(256), 0, st, recv, n, c->pos_base, s.n_bases, bytes, bad));
   DevBuf &b = c->result(MHX_BUF_IS_SOLID_LOCAL, (need + 1) * 8);
   b.used = need * 8;
-  if (need)
+  if (need && s.fixed_len >= c->s1_acc_k + 16 && c->opt("s1_pack_fixed", 1))
     MHX_LAUNCH(c, "pack_solid", (double)need * 72,
-               hipLaunchKernelGGL(k_pack_solid_inv, dim3((unsigned)div_ceil(need, 256)), dim3(256), 0, st, bytes, s.n_bases, s.start.as<uint64_t>(),
+               hipLaunchKernelGGL(k_pack_solid_inv_fixed, dim3((unsigned)std::min<uint64_t>(div_ceil(need * 4, 256), 4096)), dim3(256), 0, st, bytes, s.n_bases, s.fixed_len,
+                                  (int)c->s1_acc_k, b.as<unsigned long long>(), need, ctr));
+  else if (need)
+    MHX_LAUNCH(c, "pack_solid", (double)need * 72,
+               hipLaunchKernelGGL(k_pack_solid_inv, dim3((unsigned)std::min<uint64_t>(div_ceil(need, 256), 4096)), dim3(256), 0, st, bytes, s.n_bases, s.start.as<uint64_t>(),
                                   s.n_seqs, s.fixed_len, (int)c->s1_acc_k, b.as<unsigned long long>(), need, ctr));
   unsigned long long h[5] = {0, 0, 0, 0, 0};
   MHX_HIP(hipMemcpyAsync(h, ctr, 40, hipMemcpyDeviceToHost, st));

@@ -500,48 +500,57 @@ struct SdbgOp {
   }
 };
 
-// bstart[3][65536] (kNoStart = empty bucket) + totals -> per-bucket counts and byte offsets.
-// One workgroup; thread t owns buckets [256t, 256t+256).
-__global__ __launch_bounds__(256) void k_bucket_fix(const unsigned long long *__restrict__ bstart, const uint64_t *__restrict__ totals,
-                                                    int wpt, unsigned long long *__restrict__ b_items, unsigned long long *__restrict__ b_tips,
-                                                    unsigned long long *__restrict__ b_large, unsigned long long *__restrict__ b_off) {
-  __shared__ unsigned long long first[3][256];
-  const int t = threadIdx.x, lo = t * 256, hi = lo + 256;
-  unsigned long long f0 = kNoStart, f1 = kNoStart, f2 = kNoStart;
-  for (int bk = lo; bk < hi; ++bk)
-    if (bstart[bk] != kNoStart) {
-      f0 = bstart[bk];
-      f1 = bstart[MHX_NUM_BUCKETS + bk];
-      f2 = bstart[2 * MHX_NUM_BUCKETS + bk];
-      break;
-    }
-  first[0][t] = f0;
-  first[1][t] = f1;
-  first[2][t] = f2;
+// bstart[3][65536] (kNoStart = empty bucket) + totals -> per-bucket counts and byte offsets: a bucket ends where the next
+// non-empty one starts.  256 workgroups of 256 buckets each (coalesced reads; the single workgroup with 256 buckets per
+// thread of rounds 1-2 took 0.31 ms of every step).  k_bucket_first: first non-empty bucket of every workgroup's range.
+__global__ __launch_bounds__(256) void k_bucket_first(const unsigned long long *__restrict__ bstart, uint32_t *__restrict__ block_first) {
+  __shared__ uint32_t first;
+  if (threadIdx.x == 0) first = 0xFFFFFFFFu;
   __syncthreads();
-  unsigned long long n0 = totals[0], n1 = totals[1], n2 = totals[2];  // start of the next non-empty bucket
-  for (int u = t + 1; u < 256; ++u)
-    if (first[0][u] != kNoStart) {
-      n0 = first[0][u];
-      n1 = first[1][u];
-      n2 = first[2][u];
-      break;
-    }
-  for (int bk = hi - 1; bk >= lo; --bk) {
-    const unsigned long long s0 = bstart[bk];
-    if (s0 != kNoStart) {
-      const unsigned long long s1 = bstart[MHX_NUM_BUCKETS + bk], s2 = bstart[2 * MHX_NUM_BUCKETS + bk];
-      b_items[bk] = n0 - s0;
-      b_tips[bk] = n1 - s1;
-      b_large[bk] = n2 - s2;
-      b_off[bk] = 2ull * (s0 + s2) + 4ull * wpt * s1;
-      n0 = s0;
-      n1 = s1;
-      n2 = s2;
-    } else {
-      b_items[bk] = b_tips[bk] = b_large[bk] = 0;
-      b_off[bk] = 2ull * (n0 + n2) + 4ull * wpt * n1;
-    }
+  const uint32_t bk = blockIdx.x * 256 + threadIdx.x;
+  if (bstart[bk] != kNoStart) atomicMin(&first, bk);
+  __syncthreads();
+  if (threadIdx.x == 0) block_first[blockIdx.x] = first;
+}
+__global__ __launch_bounds__(256) void k_bucket_fix(const unsigned long long *__restrict__ bstart, const uint32_t *__restrict__ block_first,
+                                                    const uint64_t *__restrict__ totals, int wpt, unsigned long long *__restrict__ b_items,
+                                                    unsigned long long *__restrict__ b_tips, unsigned long long *__restrict__ b_large,
+                                                    unsigned long long *__restrict__ b_off) {
+  __shared__ unsigned long long s0s[256], s1s[256], s2s[256];
+  __shared__ unsigned long long wave_mask[256 / kWave];
+  __shared__ unsigned long long after[3];  // start of the first non-empty bucket behind this workgroup's range (or the totals)
+  const int t = threadIdx.x, lane = t & (kWave - 1), wv = t / kWave;
+  const uint32_t bk = blockIdx.x * 256 + t;
+  const unsigned long long s0 = bstart[bk], s1 = bstart[MHX_NUM_BUCKETS + bk], s2 = bstart[2 * MHX_NUM_BUCKETS + bk];
+  s0s[t] = s0;
+  s1s[t] = s1;
+  s2s[t] = s2;
+  const unsigned long long mask = __ballot(s0 != kNoStart);
+  if (lane == 0) wave_mask[wv] = mask;
+  if (t == 0) {
+    uint32_t nb = 0xFFFFFFFFu;
+    for (uint32_t j = blockIdx.x + 1; j < MHX_NUM_BUCKETS / 256 && nb == 0xFFFFFFFFu; ++j) nb = block_first[j];
+    after[0] = nb == 0xFFFFFFFFu ? totals[0] : bstart[nb];
+    after[1] = nb == 0xFFFFFFFFu ? totals[1] : bstart[MHX_NUM_BUCKETS + nb];
+    after[2] = nb == 0xFFFFFFFFu ? totals[2] : bstart[2 * MHX_NUM_BUCKETS + nb];
+  }
+  __syncthreads();
+  // next non-empty bucket behind mine: in my wavefront, in a later wavefront of the workgroup, or behind the workgroup
+  int nx = -1;
+  const unsigned long long later = lane == kWave - 1 ? 0ull : (mask >> (lane + 1));
+  if (later) nx = wv * kWave + lane + 1 + __builtin_ctzll(later);
+  else
+    for (int w = wv + 1; w < 256 / kWave && nx < 0; ++w)
+      if (wave_mask[w]) nx = w * kWave + __builtin_ctzll(wave_mask[w]);
+  const unsigned long long n0 = nx >= 0 ? s0s[nx] : after[0], n1 = nx >= 0 ? s1s[nx] : after[1], n2 = nx >= 0 ? s2s[nx] : after[2];
+  if (s0 != kNoStart) {
+    b_items[bk] = n0 - s0;
+    b_tips[bk] = n1 - s1;
+    b_large[bk] = n2 - s2;
+    b_off[bk] = 2ull * (s0 + s2) + 4ull * wpt * s1;
+  } else {
+    b_items[bk] = b_tips[bk] = b_large[bk] = 0;
+    b_off[bk] = 2ull * (n0 + n2) + 4ull * wpt * n1;
   }
 }
 
@@ -588,8 +597,11 @@ static void emit_sdbg_impl(mhx_ctx *c, const uint32_t *sorted, uint64_t n_items,
   MHX_LAUNCH(c, "sdbg_emit", bytes + (double)out_bytes,
              hipLaunchKernelGGL((k_tile_groups<S, T, SdbgOp<S>, true>), dim3(tile_grid(n_tiles)), dim3(kTileThreads), 0, st, sorted, n_items,
                                 full_words, last_mask, op, (uint64_t *)nullptr, (const uint64_t *)tb, n_tiles, n_tiles));
+  uint32_t *block_first = c->ws("bucket_block_first", MHX_NUM_BUCKETS / 256 * 4).as<uint32_t>();
+  hipLaunchKernelGGL(k_bucket_first, dim3(MHX_NUM_BUCKETS / 256), dim3(256), 0, st, bstart, block_first);
   MHX_LAUNCH(c, "bucket_stats", (double)MHX_NUM_BUCKETS * 56,
-             hipLaunchKernelGGL(k_bucket_fix, dim3(1), dim3(256), 0, st, bstart, d_tot, P.wpt, b_items, b_tips, b_large, b_off));
+             hipLaunchKernelGGL(k_bucket_fix, dim3(MHX_NUM_BUCKETS / 256), dim3(256), 0, st, bstart, block_first, d_tot, P.wpt, b_items, b_tips,
+                                b_large, b_off));
 }
 
 // sorted: n_items records of stride S with kw key words, sorted; fills the SdBG result buffers.

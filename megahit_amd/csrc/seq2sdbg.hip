@@ -39,7 +39,7 @@ __global__ __launch_bounds__(256) void k_seq_extract(const uint32_t *__restrict_
   }
   const uint64_t st = start[sid];
   const int64_t n = (int64_t)(start[sid + 1] - st);
-  const uint64_t t = idx - item_start[sid];
+  const uint64_t t = idx - (fixed_items ? sid * fixed_items : item_start[sid]);
   const int64_t o = (int64_t)(t >> 1);
   const int strand = (int)(t & 1);
   const int nc = k - (o + k > n ? 1 : 0);
@@ -86,17 +86,19 @@ uint64_t seq2sdbg_extract(mhx_ctx *c, uint32_t k) {
   const uint64_t ns = s.n_seqs;
   hipStream_t st = c->stream;
 
-  uint32_t *cnt = c->ws("seq_item_cnt", (ns + 1) * 4).as<uint32_t>();
-  uint64_t *item_start = c->ws("seq_item_start", (ns + 2) * 8).as<uint64_t>();
-  uint64_t n_items = 0;
-  if (ns) {
+  // sequences of one length >= k + 1 (an edge file, reads): item i of sequence s is number s * fixed_items + i — no counts, no scan
+  const uint32_t fixed_items = (s.fixed_len >= k + 1) ? 2 * (s.fixed_len - k + 2) : 0;
+  uint64_t *item_start = nullptr;
+  uint64_t n_items = (uint64_t)fixed_items * ns;
+  if (ns && !fixed_items) {
+    uint32_t *cnt = c->ws("seq_item_cnt", (ns + 1) * 4).as<uint32_t>();
+    item_start = c->ws("seq_item_start", (ns + 2) * 8).as<uint64_t>();
     MHX_LAUNCH(c, "item_counts", (double)ns * 12,
                hipLaunchKernelGGL(k_seq_item_counts2, dim3((unsigned)div_ceil(ns, 256)), dim3(256), 0, st, s.start.as<uint64_t>(), ns, k, cnt));
     exclusive_scan_u32_u64(c, cnt, item_start, ns, item_start + ns + 1);
     MHX_HIP(hipMemcpyAsync(&n_items, item_start + ns + 1, 8, hipMemcpyDeviceToHost, st));
     MHX_HIP(hipStreamSynchronize(st));
   }
-  const uint32_t fixed_items = (s.fixed_len >= k + 1) ? 2 * (s.fixed_len - k + 2) : 0;
   const size_t item_bytes = (size_t)S * 4;
   uint32_t *buf_a = c->ws("items_a", n_items * item_bytes + 64).as<uint32_t>();
   // one thread per item; a grid holds fewer than 2^32 threads, so large inputs take several launches

@@ -574,15 +574,16 @@ uint32_t *sort_whole_key(mhx_ctx *c, uint32_t *a, uint32_t *b, uint64_t n, int s
   const int mode = (int)c->opt("sort_hybrid", 1);  // 0: never, 1: when the cost model says so, 2: always (tests)
   const uint64_t min_n = (uint64_t)c->opt("sort_hybrid_min", 1 << 16);
   if (!mode || n < min_n || n >= (1ull << 40)) return radix_sort(c, a, b, n, stride, key_words, passes);
-  // Cost model, picoseconds per record on MI355X (measured at 0.8-1.2 x 10^8 records, round 3): an LSD pass moves the record
-  // twice, ~3 ps per 32-bit word (0.71 ms for 117 M 8-byte records, 1.8 ms for 82 M 40-byte ones); the finish kernel costs
-  // ~19 ps when nearly every segment is a single record and ~41 ps at ~7 records per segment, nearly independent of the
-  // record width (it moves each record once and compares a couple of key words per neighbour).  So: never for 8-byte
-  // records with 6 passes (stage 2 at k = 21), always for the wide keys of seq2sdbg at k >= 29 (3.4x at k = 119).
+  // Cost model, picoseconds per record on MI355X (measured at 0.8-1.2 x 10^8 records, round 3, profiles/r03_bench_klist.json):
+  // an LSD pass moves the record twice, ~3 ps per 32-bit word (0.71 ms for 117 M 8-byte records, 1.9 ms for 82 M 40-byte
+  // ones); the finish kernel moves it once and reads a couple of key words of every neighbour in its segment:
+  // ~(14 + 4.5 S) ps at one record per segment plus ~(2 + 0.8 S) ps per further record of the segment (S = words per record:
+  // 2.2 ms for 117 M 8-byte singletons, 3.8 ms for 117 M 16-byte ones, 7.9 ms for 111 M 24-byte records at ~7 per segment).
+  // So: never for 8-byte records with 6 passes (stage 2 at k = 21), 32 prefix bits for the wide keys of seq2sdbg at k >= 29.
   const double pass_ps = 3.0 * stride;
   auto finish_ps = [&](int pbits) {
     const double avg = pbits >= 40 ? 0.0 : (double)n / (double)(1ull << pbits);  // records per prefix value if the keys were uniform
-    return avg <= 1.0 ? 19.0 : (avg >= 8.0 ? 41.0 + 3.0 * (avg - 8.0) : 19.0 + (avg - 1.0) * 22.0 / 7.0);
+    return (14.0 + 4.5 * stride) + std::max(0.0, avg - 1.0) * (2.0 + 0.8 * stride);
   };
   int best_bits = 0;
   double best = (double)passes.size() * pass_ps;

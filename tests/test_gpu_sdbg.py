@@ -163,7 +163,7 @@ def test_read2sdbg_s1_without_mercy_compact_records(engine, kind, k, m):
     check_sdbg(engine, engine.read2sdbg_s2(k, m), ob.s2(pkg, k, m, w1["is_solid"]))
 
 
-SEG_DEFAULTS = dict(s1_seg=1, s1_seg_bits=0, s1_seg_la=3, s1_seg_per=8, s1_stream=1, s1_stream_max=40000, s1_stream_probes=1024, s1_stream_direct=1)
+SEG_DEFAULTS = dict(s1_seg=1, s1_seg_bits=0, s1_seg_la=3, s1_seg_per=8, s1_stream=1, s1_stream_max=40000, s1_stream_probes=1024, s1_stream_direct=1, s1_pack_fixed=1)
 SEG_VARIANTS = [dict(s1_seg=0),                      # classic: full sort + tile kernel
                 dict(s1_stream=0),                  # tile kernel (k_s1_seg) instead of bucket streaming (k_s1_stream)
                 dict(s1_stream_direct=0),           # bucket streaming with the second read of the bucket instead of marks from the table
@@ -174,7 +174,8 @@ SEG_VARIANTS = [dict(s1_seg=0),                      # classic: full sort + tile
                 dict(s1_seg_bits=16, s1_seg_la=1),
                 dict(s1_seg_bits=32),               # prefix = the whole first key word
                 dict(s1_seg_per=4),
-                dict(s1_seg_per=4, s1_seg_bits=8)]
+                dict(s1_seg_per=4, s1_seg_bits=8),
+                dict(s1_pack_fixed=0)]               # reads of one length: the general byte-map -> bitmap kernel
 
 
 @pytest.mark.parametrize("opts", SEG_VARIANTS, ids=lambda o: ",".join("%s=%d" % kv for kv in o.items()))
