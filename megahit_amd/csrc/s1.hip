@@ -177,15 +177,14 @@ __device__ __forceinline__ uint64_t rc64(uint64_t x, int n);
 //     divided by the items per read, comes from the host), the only division left is a 32-bit one.
 // Same output, bit for bit, as k_s1_extract_fixed<2, 3, true> (read_to_sdbg_s1.cpp:228-292, :344-363).
 // one stage-1 record of a fixed-length read set from the 64-bit window around its (k-1)-mer: read r, slot j (see above)
-__device__ __forceinline__ void s1_fast_item(const uint32_t *__restrict__ seq, uint32_t L, int k, uint64_t r, uint32_t j, uint64_t pos_base,
+__device__ __forceinline__ void s1_fast_item(const uint32_t *__restrict__ seq, uint32_t L, int k, uint64_t st, uint32_t j, uint64_t pos_base,
                                              uint32_t rank_tag, uint32_t (&out)[3]) {
+  // st = first base of the read (read index x L: the callers advance it with the slots instead of multiplying per item)
   const int km1 = k - 1;
-  const uint64_t st = r * L;
-  uint32_t q;
-  int forced = -1;
-  if (j < 2) { q = 0; forced = (int)j; }
-  else if (j >= L - k + 2) { q = L - k + 1; forced = (int)(j - (L - k + 2)); }
-  else q = j - 1;
+  // slot -> offset of the (k-1)-mer; slots 0, 1 and the last two are the forced-strand pairs at the read's ends
+  const uint32_t jf = L - k + 2;
+  const uint32_t q = min(j > 0 ? j - 1 : 0u, jf - 1);
+  const int forced = j < 2 ? (int)j : (j >= jf ? (int)(j - jf) : -1);
   const uint64_t a = st + q;
   if (a < 2) {  // the first two bases of the store: no window in front of them
     s1_make_item<2, 3, true>(seq, st, L, k, j, pos_base, rank_tag, out);
@@ -220,15 +219,16 @@ struct S1Gen {
   uint32_t rank_tag;
   template <int NI>
   __device__ __forceinline__ void get(uint64_t first, uint64_t n, Rec<3> (&rec)[NI]) const {
-    uint64_t r = first / per;  // one 64-bit division per tile and thread, then read and slot advance with the items
+    const uint64_t r = first / per;  // one 64-bit division per tile and thread, then read offset and slot advance with the items
     uint32_t j = (uint32_t)(first - r * per);
+    uint64_t st = r * L;
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
-      if (first + (uint64_t)i * kWave < n) s1_fast_item(seq, L, k, r, j, pos_base, rank_tag, rec[i].w);
+      if (first + (uint64_t)i * kWave < n) s1_fast_item(seq, L, k, st, j, pos_base, rank_tag, rec[i].w);
       j += kWave;
       while (j >= per) {
         j -= per;
-        ++r;
+        st += L;
       }
     }
   }
@@ -310,6 +310,86 @@ __global__ __launch_bounds__(256) void k_s1_digit_hist(const uint32_t *__restric
   }
 }
 
+// The same histograms with straight-line code per item (the usual plans: every digit is one bit field of the first key
+// word).  k_s1_digit_hist above spends ~100 VALU operations and a dozen branches per item (slot cases, the slow path of the
+// store's first bases inlined eight times, the generic two-field digit read from the argument block per pass); here the
+// slot -> offset / forced-strand mapping is arithmetic, the read's base offset advances with the slots, the digits are
+// shift + mask with both in scalar registers, and the three items whose window would start before the store (read 0,
+// slots 0..2) are counted by one thread up front.
+struct HiDigits {
+  unsigned sh[kFastPasses], mk[kFastPasses];
+  int n;
+};
+template <int IT, int NP>  // NP digit histograms
+__global__ __launch_bounds__(256) void k_s1_digit_hist_plain(const uint32_t *__restrict__ seq, uint32_t L, uint32_t per, uint64_t n_items, int k,
+                                                             HiDigits hd, unsigned long long *__restrict__ ghist, uint32_t step_q, uint32_t step_r) {
+  constexpr int B = 256 * IT;
+  __shared__ uint32_t h[kFastPasses][4][256];
+  for (int i = threadIdx.x; i < kFastPasses * 4 * 256; i += 256) (&h[0][0][0])[i] = 0;
+  __syncthreads();
+  const int wv = threadIdx.x >> 6;
+  const int km1 = k - 1;
+  const uint64_t kmask = ~0ull << (64 - 2 * km1);
+  const uint32_t qlast = L - k + 1, jf = L - k + 2;  // last offset of a (k-1)-mer; first slot of the forced pair at the read's end
+  auto count = [&](uint32_t hi) {
+#pragma unroll
+    for (int p = 0; p < NP; ++p) atomicAdd(&h[p][wv][(hi >> hd.sh[p]) & hd.mk[p]], 1u);
+  };
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+    for (uint32_t j = 0; j < 3 && j < n_items; ++j) {
+      uint32_t out[3];
+      s1_make_item<2, 3, true>(seq, 0, L, k, j, 0, 0u, out);
+      count(out[0]);
+    }
+  const uint64_t n_blocks = (n_items + B - 1) / B;
+  uint64_t q0 = ((uint32_t)blockIdx.x * (uint32_t)B) / per;
+  uint32_t rem0 = ((uint32_t)blockIdx.x * (uint32_t)B) % per;
+  for (uint64_t blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
+    const uint64_t g0 = blk * B + (uint64_t)threadIdx.x * IT;
+    const uint32_t t = rem0 + (uint32_t)threadIdx.x * IT, dq = t / per;
+    uint32_t j = t - dq * per;
+    uint64_t base = (q0 + dq) * L;  // first base of the read
+    uint64_t wcur = ~0ull;
+    uint32_t x0 = 0, x1 = 0, x2 = 0;
+#pragma unroll
+    for (int u = 0; u < IT; ++u) {
+      const uint32_t q = min(j > 0 ? j - 1 : 0u, qlast);
+      const bool forced = j < 2 || j >= jf;
+      const uint32_t fstrand = j < 2 ? j : j - jf;
+      const uint64_t a = base + q;
+      const uint64_t b = a >= 2 ? a - 2 : 0, w = b >> 4;
+      if (w != wcur) {
+        x0 = seq[w];
+        x1 = seq[w + 1];
+        x2 = seq[w + 2];
+        wcur = w;
+      }
+      const unsigned sh = (unsigned)(b & 15) * 2;
+      const uint64_t win = ((uint64_t)funnel_l(x0, x1, sh) << 32) | funnel_l(x1, x2, sh);
+      const uint64_t f = (win << 4) & kmask;
+      const uint64_t rc = rc64(f, km1);
+      const bool use_rc = forced ? fstrand == 1 : f > rc;  // (f == rc: the same first word either way)
+      if (g0 + u < n_items && a >= 2) count((uint32_t)((use_rc ? rc : f) >> 32));
+      if (++j == per) {
+        j = 0;
+        base += L;
+      }
+    }
+    q0 += step_q;
+    rem0 += step_r;
+    if (rem0 >= per) {
+      rem0 -= per;
+      ++q0;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    const uint32_t v = h[p][0][threadIdx.x] + h[p][1][threadIdx.x] + h[p][2][threadIdx.x] + h[p][3][threadIdx.x];
+    if (v) atomicAdd(&ghist[p * 256 + threadIdx.x], (unsigned long long)v);
+  }
+}
+
 template <int IT, bool WRITE>  // items per thread and trip; WRITE = false: only the digit histograms: their window loads are issued together (one in flight per thread = latency-bound)
 __global__ __launch_bounds__(256) void k_s1_extract_fast(const uint32_t *__restrict__ seq, uint32_t L, uint32_t per, uint64_t n_items, int k,
                                                          uint64_t pos_base, uint32_t rank_tag, uint32_t *__restrict__ items, DigitSpecs specs,
@@ -335,7 +415,7 @@ __global__ __launch_bounds__(256) void k_s1_extract_fast(const uint32_t *__restr
       ok[u] = g < n_items;
       const uint32_t t = rem0 + (uint32_t)u * 256u + threadIdx.x, dq = t / per, j = t - dq * per;
       // (a thread beyond the last item recomputes item 0: unconditional loads, nothing stored)
-      s1_fast_item(seq, L, k, ok[u] ? q0 + dq : 0, ok[u] ? j : 2, pos_base, rank_tag, outs[u]);
+      s1_fast_item(seq, L, k, ok[u] ? (q0 + dq) * L : 0, ok[u] ? j : 2, pos_base, rank_tag, outs[u]);
     }
 #pragma unroll
     for (int u = 0; u < IT; ++u) {
@@ -1715,9 +1795,27 @@ uint64_t s1_extract(mhx_ctx *c, uint32_t k, bool compact) {
           constexpr int ITH = 8;
           const unsigned fgrid = (unsigned)std::min<uint64_t>(div_ceil(n_items, 256 * ITH), 256 * 8);
           const uint64_t stride_items = (uint64_t)fgrid * 256 * ITH;
-          MHX_LAUNCH(c, "s1_digit_hist", (double)s.n_bases / 4,
-                     hipLaunchKernelGGL((k_s1_digit_hist<ITH>), dim3(fgrid), dim3(256), 0, st, s.words.as<uint32_t>(), s.fixed_len, per, n_items, (int)k,
-                                        specs, pre_hist, (uint32_t)(stride_items / per), (uint32_t)(stride_items % per)));
+          HiDigits hd;
+          hd.n = specs.n;
+          bool plain = c->opt("s1_digit_hist_plain", 1) != 0;  // every digit one bit field of the first key word?
+          for (int p = 0; p < specs.n; ++p) {
+            plain = plain && specs.d[p].mask2 == 0 && specs.d[p].wi1 == 0 && specs.d[p].bit1 < 32;
+            hd.sh[p] = specs.d[p].bit1;
+            hd.mk[p] = specs.d[p].mask1;
+          }
+#define MHX_PLAIN(NPV)                                                                                                                       \
+  MHX_LAUNCH(c, "s1_digit_hist", (double)s.n_bases / 4,                                                                                      \
+             hipLaunchKernelGGL((k_s1_digit_hist_plain<ITH, NPV>), dim3(fgrid), dim3(256), 0, st, s.words.as<uint32_t>(), s.fixed_len, per, \
+                                n_items, (int)k, hd, pre_hist, (uint32_t)(stride_items / per), (uint32_t)(stride_items % per)))
+          if (plain && specs.n == 1) MHX_PLAIN(1);
+          else if (plain && specs.n == 2) MHX_PLAIN(2);
+          else if (plain && specs.n == 3) MHX_PLAIN(3);
+          else if (plain && specs.n == 4) MHX_PLAIN(4);
+#undef MHX_PLAIN
+          else
+            MHX_LAUNCH(c, "s1_digit_hist", (double)s.n_bases / 4,
+                       hipLaunchKernelGGL((k_s1_digit_hist<ITH>), dim3(fgrid), dim3(256), 0, st, s.words.as<uint32_t>(), s.fixed_len, per, n_items,
+                                          (int)k, specs, pre_hist, (uint32_t)(stride_items / per), (uint32_t)(stride_items % per)));
         } else {
           MHX_FAST(4, false, "s1_digit_hist");
         }
