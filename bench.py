@@ -74,14 +74,16 @@ def pmc_traffic(kernel_name, path=None):
     # profile name -> kernel symbol prefix
     table = {"s1_groups": ("k_s1_stream<", "k_s1_seg<", "k_tile_groups<3"), "count_groups": ("k_count_seg<",),
              "s1_extract": ("k_s1_extract_fast<", "k_s1_extract_fixed<", "k_s1_extract<"), "s1_digit_hist": ("k_s1_extract_fast<4, false",),
-             "count_extract": ("k_count_extract<",), "radix_scatter_12B_gen": ("k_radix_onesweep<3, 8, 3, S1Gen",)}
+             "count_extract": ("k_count_extract<",),
+             "radix_scatter_12B_gen": ("k_radix_onesweep_u<3, 8, 3, S1Gen", "k_radix_onesweep<3, 8, 3, S1Gen")}
     prefixes = list(table.get(kernel_name, ()))
     for stem, names in (("radix_scatter_", ("k_radix_onesweep", "k_radix_scatter")), ("radix_hist_all_", ("k_radix_hist_all",)),
                         ("radix_hist_", ("k_radix_hist",))):
         if not prefixes and kernel_name.startswith(stem) and kernel_name.endswith("B") and kernel_name[len(stem):-1].isdigit():
             w = int(kernel_name[len(stem):-1]) // 4
             # (the chained-scan kernel that LOADS its records: SrcArray; the generated first pass has a name of its own)
-            prefixes = ["%s<%d, 8, 3, SrcArray" % (names[0], w), "%s<%d, 8, 2, SrcArray" % (names[0], w)] + \
+            prefixes = ["%s_u<%d, 8, 3, SrcArray" % (names[0], w), "%s_u<%d, 8, 2, SrcArray" % (names[0], w),
+                        "%s<%d, 8, 3, SrcArray" % (names[0], w), "%s<%d, 8, 2, SrcArray" % (names[0], w)] + \
                        ["%s<%d," % (nm, w) for nm in names] + ["%s<%d>" % (nm, w) for nm in names]
             break
     for prefix in prefixes:

@@ -1825,7 +1825,13 @@ uint64_t s1_extract(mhx_ctx *c, uint32_t k, bool compact) {
         // any order (the later passes are stable with respect to whatever order it leaves).
         const bool any_order = c->opt("s1_gen_any_order", 1) != 0;
         c->gen_first_pass = [g, any_order](const OnesweepLaunch &l) {
-          if (any_order)
+          if (l.unit_runs && l.wi == 0 && any_order)  // (the digits of this plan lie in the first key word)
+            hipLaunchKernelGGL((k_radix_onesweep_u<3, 8, 3, S1Gen, true, 0>), dim3(l.grid), dim3(kSortThreads), 0, l.stream, g, l.out, l.n, l.ds, l.nbits,
+                               l.bin_start, l.status, l.ticket, l.err, l.tag, l.xcd_units);
+          else if (l.unit_runs && l.wi == 0)
+            hipLaunchKernelGGL((k_radix_onesweep_u<3, 8, 3, S1Gen, false, 0>), dim3(l.grid), dim3(kSortThreads), 0, l.stream, g, l.out, l.n, l.ds, l.nbits,
+                               l.bin_start, l.status, l.ticket, l.err, l.tag, l.xcd_units);
+          else if (any_order)
             hipLaunchKernelGGL((k_radix_onesweep<3, 8, 3, S1Gen, true>), dim3(l.grid), dim3(kSortThreads), 0, l.stream, g, l.out, l.n, l.ds, l.nbits,
                                l.bin_start, l.status, l.ticket, l.err, l.tag, l.xcd_units);
           else

@@ -357,16 +357,33 @@ static uint32_t *radix_sort_onesweep(mhx_ctx *c, uint32_t *a, uint32_t *b, uint6
                hipLaunchKernelGGL((k_radix_hist_all<S>), dim3(hgrid), dim3(kSortThreads), 0, st, a, n, specs, gh + (size_t)p0 * 256));
   }
   hipLaunchKernelGGL(k_bin_starts, dim3(P), dim3(256), 0, st, gh, starts);
+  // unit-wide runs (k_radix_onesweep_u) for the default unit shape of every width; MHX_SORT_UNIT_RUNS=0: the tile-by-tile kernel
+  constexpr bool kHasUnitRuns = (S <= 3 && NI == 8 && UT == 3) || (S == 4 && NI == 8 && UT == 2) || (S > 4 && NI == 4 && UT == 2);
+  const bool unit_runs = kHasUnitRuns && c->opt("sort_unit_runs", 1) != 0;
   for (int p = 0; p < P; ++p) {
+    const int nb = passes[p].bits + passes[p].bits2;
+    const int wi = digit_word_of(all[p], nb, 1);
     if (p == 0 && gen) {  // the records of the first pass are made on the fly (no input array): the generator's owner launches
       static const std::string nm_gen = nm_scat + "_gen";
       MHX_LAUNCH(c, nm_gen.c_str(), bytes,
-                 gen(OnesweepLaunch{(unsigned)n_units, st, b, n, all[p], passes[p].bits + passes[p].bits2, starts + p * 256, status, tickets + p * 8,
-                                    tickets + kErrSlot, (unsigned long long)(p + 1), xcd_units}));
+                 gen(OnesweepLaunch{(unsigned)n_units, st, b, n, all[p], nb, starts + p * 256, status, tickets + p * 8,
+                                    tickets + kErrSlot, (unsigned long long)(p + 1), xcd_units, unit_runs ? 1 : 0, wi}));
+    } else if (unit_runs) {
+      if constexpr (kHasUnitRuns) {
+#define MHX_U(WIV)                                                                                                                              \
+  hipLaunchKernelGGL((k_radix_onesweep_u<S, NI, UT, SrcArray<S>, false, WIV>), dim3((unsigned)n_units), dim3(kSortThreads), 0, st, SrcArray<S>{a}, b, \
+                     n, all[p], nb, starts + p * 256, status, tickets + p * 8, tickets + kErrSlot, (unsigned long long)(p + 1), xcd_units)
+        MHX_LAUNCH(c, nm_scat.c_str(), 2 * bytes, {
+          if (wi == 0) MHX_U(0);
+          else if (wi == 1) MHX_U(1);
+          else MHX_U(-1);
+        });
+#undef MHX_U
+      }
     } else {
       MHX_LAUNCH(c, nm_scat.c_str(), 2 * bytes,
                  hipLaunchKernelGGL((k_radix_onesweep<S, NI, UT, SrcArray<S>>), dim3((unsigned)n_units), dim3(kSortThreads), 0, st, SrcArray<S>{a}, b, n,
-                                    all[p], passes[p].bits + passes[p].bits2, starts + p * 256, status, tickets + p * 8, tickets + kErrSlot,
+                                    all[p], nb, starts + p * 256, status, tickets + p * 8, tickets + kErrSlot,
                                     (unsigned long long)(p + 1), xcd_units));
     }
     std::swap(a, b);

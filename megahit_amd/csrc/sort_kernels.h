@@ -263,6 +263,191 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_onesweep(Src src, uint32
 }
 
 
+// digit of a record when the pass's digit is ONE bit field inside word WI (no second field, no straddle): a shift and an
+// and — the generic rec_digit picks the word with 2 S selects per call (~40 v_cndmask per record over the three uses)
+template <int S, int WI>
+__device__ __forceinline__ unsigned rec_digit_w(const Rec<S> &r, const DigitSpec &ds) {
+  if constexpr (WI >= 0) return (r.w[WI] >> ds.bit1) & ds.mask1;
+  else return rec_digit2<S>(r, ds);
+}
+// host side of the same: the word a pass's digit lies in, -1 when the generic form is needed
+inline int digit_word_of(const DigitSpec &ds, int nbits, int max_word) {
+  return (ds.mask2 == 0 && ds.wi1 >= 0 && ds.wi1 <= max_word && (int)ds.bit1 + nbits <= 32) ? ds.wi1 : -1;
+}
+
+// The chained-scan pass with UNIT-WIDE runs.  k_radix_onesweep above ranks, stages and writes its unit tile by tile: a
+// unit of UT tiles leaves UT separate runs per digit (8 records = 96 bytes each at 12-byte records), written tens of
+// microseconds apart — longer than a dirty line survives in the XCD's L2 under this kernel's own traffic, so the two
+// halves of most boundary lines reach the memory as two partial writes (PMC: 1.5 x the algorithmic bytes written).
+// Here all UT tiles are ranked first (the per-(tile, wave) counters of one digit laid out in input order: the same
+// stable order), every record gets its position p inside the unit's digit-sorted sequence, and the LDS stage is a WINDOW
+// sliding over that sequence: round r stages the records with p in [r T, (r+1) T) and writes them, so every digit's run
+// of the unit leaves once, in one piece (two pieces for the at most UT - 1 digits a window edge cuts).  Same LDS stage,
+// the counters UT times as large, no separate counting phase before the ranking (the ranking's counters ARE the counts
+// the look-back publishes), fewer barriers.
+// workgroups (= waves per SIMD) the register budget has to allow per CU
+template <int S, int NI, int UT>
+constexpr int onesweep_u_waves() {
+  return S * NI * UT <= 48 ? 4 : 3;  // <= 48 record registers: 4; the 72 of 12-byte records in 8x3 units: 3
+}
+template <int S, int NI, int UT, class Src, bool ANY_ORDER, int WI>
+__global__ __launch_bounds__(kSortThreads) void k_radix_onesweep_u(Src src, uint32_t *__restrict__ out, uint64_t n, DigitSpec ds, int nbits,
+                                                                   const unsigned long long *__restrict__ bin_start,
+                                                                   unsigned long long *__restrict__ status, uint32_t *__restrict__ ticket,
+                                                                   uint32_t *__restrict__ err, unsigned long long tag, int xcd_units) {
+  constexpr int kTile = kSortThreads * NI;
+  static_assert(kTile * (UT + 1) < 0xFFFF, "16-bit ranks and positions");
+  __shared__ __attribute__((aligned(16))) uint32_t stage[kTile * S];
+  __shared__ uint32_t cnt[UT][kSortWaves][256];  // counts of (tile, wave, digit), then their starts inside the unit
+  __shared__ long long g_off[256];               // global position minus position inside the unit, per digit
+  __shared__ uint32_t sm_scan[kSortThreads / kWave + 1];
+  __shared__ uint32_t s_unit;
+
+  const int tid = threadIdx.x, w = tid / kWave, lane = tid & (kWave - 1);
+  const uint64_t lanemask_lt = (1ull << lane) - 1;
+  if (tid == 0) {
+    if (xcd_units) {  // (see k_radix_onesweep)
+      const uint32_t cls = blockIdx.x & 7u, tk = atomicAdd(ticket + cls, 1u);
+      s_unit = ((tk >> 4) * 8 + cls) * 16 + (tk & 15u);
+    } else {
+      s_unit = atomicAdd(ticket, 1u);
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < UT; ++t)
+#pragma unroll
+    for (int i = 0; i < kSortWaves; ++i) cnt[t][i][tid] = 0;
+  __syncthreads();
+  const uint64_t unit = s_unit;
+  const uint64_t unit_base = unit * (uint64_t)(kTile * UT);
+
+  // 1. the unit's records -> registers (wave-blocked striped arrangement inside each tile)
+  Rec<S> rec[UT][NI];
+#pragma unroll
+  for (int t = 0; t < UT; ++t) src.template get<NI>(unit_base + (uint64_t)t * kTile + (uint64_t)(w * (kWave * NI) + lane), n, rec[t]);
+
+  // 2. rank every record among the records of its (tile, wave) with the same digit.  Ranks, later positions, are kept two
+  //    per register (16 bits each; 0xFFFF = no record): the unit's records already take 72 registers at 12 bytes
+  uint32_t pk[UT][(NI + 1) / 2];
+#pragma unroll
+  for (int t = 0; t < UT; ++t) {
+#pragma unroll
+    for (int h = 0; h < (NI + 1) / 2; ++h) pk[t][h] = 0xFFFFFFFFu;
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const uint64_t gi = unit_base + (uint64_t)t * kTile + (uint64_t)(w * (kWave * NI) + j * kWave + lane);
+      const bool valid = gi < n;
+      const unsigned d = valid ? rec_digit_w<S, WI>(rec[t][j], ds) : 0u;
+      uint32_t rk;
+      if constexpr (ANY_ORDER) {
+        rk = valid ? atomicAdd(&cnt[t][w][d], 1u) : 0xFFFFu;
+      } else {
+        uint64_t peers = __ballot(valid);
+        for (int b = 0; b < nbits; ++b) {
+          const bool bitset = (d >> b) & 1u;
+          const uint64_t m = __ballot(bitset);
+          peers &= bitset ? m : ~m;
+        }
+        const uint32_t before = cnt[t][w][d];
+        rk = valid ? before + __builtin_popcountll(peers & lanemask_lt) : 0xFFFFu;
+        __builtin_amdgcn_wave_barrier();
+        if (valid && (peers & lanemask_lt) == 0) cnt[t][w][d] = before + __builtin_popcountll(peers);
+        __builtin_amdgcn_wave_barrier();
+      }
+      pk[t][j >> 1] = (j & 1) ? ((pk[t][j >> 1] & 0xFFFFu) | (rk << 16)) : ((pk[t][j >> 1] & 0xFFFF0000u) | rk);
+      // finish this record's rank here: left alone the compiler keeps `before` and the peer mask of all 24 records alive
+      // until the positions are formed (~70 registers = one workgroup per CU less)
+      asm volatile("" : "+v"(pk[t][j >> 1]));
+    }
+  }
+  __syncthreads();
+
+  // 3. thread d: the unit's count of digit d -> status word; starts of the (tile, wave) cells inside the unit; look-back
+  {
+    uint32_t c[UT][kSortWaves], tot = 0;
+#pragma unroll
+    for (int t = 0; t < UT; ++t)
+#pragma unroll
+      for (int i = 0; i < kSortWaves; ++i) {
+        c[t][i] = cnt[t][i][tid];
+        tot += c[t][i];
+      }
+    unsigned long long *const st = status + unit * 256 + tid;
+    const unsigned long long tagbits = tag << 58;
+    __hip_atomic_store(st, tagbits | ((unit == 0 ? 2ull : 1ull) << 56) | (unsigned long long)tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t start = block_exclusive_sum<uint32_t, kSortThreads>(tot, sm_scan, nullptr);
+    uint32_t run = start;
+#pragma unroll
+    for (int t = 0; t < UT; ++t)
+#pragma unroll
+      for (int i = 0; i < kSortWaves; ++i) {
+        cnt[t][i][tid] = run;
+        run += c[t][i];
+      }
+    unsigned long long excl = 0;
+    if (unit > 0 && unit_base < n) {  // (a unit beyond the input — the grid is rounded up — publishes its zero counts and is done)
+      for (uint64_t p = unit; p-- > 0;) {
+        unsigned long long v;
+        uint32_t polls = 0;  // per predecessor: a unit only ever waits for units that already run (ticket order)
+        for (;;) {
+          v = __hip_atomic_load(status + p * 256 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if ((v >> 58) == tag && ((v >> 56) & 3ull)) break;
+          if (++polls > (1u << 27)) {  // seconds of polling one predecessor (a wedged GPU): terminate, the host raises on *err
+            atomicOr(err, 1u);
+            v = 2ull << 56;
+            break;
+          }
+          if (polls < 64) __builtin_amdgcn_s_sleep(1);
+          else __builtin_amdgcn_s_sleep(8);
+        }
+        excl += v & kStValMask;
+        if (((v >> 56) & 3ull) == 2ull) break;
+      }
+      __hip_atomic_store(st, tagbits | (2ull << 56) | (excl + (unsigned long long)tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    g_off[tid] = (long long)(bin_start[tid] + excl) - (long long)start;
+  }
+  __syncthreads();
+
+  // 4. positions inside the unit's digit-sorted sequence, then the window slides over it
+#pragma unroll
+  for (int t = 0; t < UT; ++t)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const uint32_t rk = (pk[t][j >> 1] >> ((j & 1) * 16)) & 0xFFFFu;
+      if (rk != 0xFFFFu) {
+        const uint32_t p = cnt[t][w][rec_digit_w<S, WI>(rec[t][j], ds)] + rk;
+        pk[t][j >> 1] = (j & 1) ? ((pk[t][j >> 1] & 0xFFFFu) | (p << 16)) : ((pk[t][j >> 1] & 0xFFFF0000u) | p);
+      }
+    }
+  const uint64_t rem = n > unit_base ? n - unit_base : 0;
+  const uint32_t unit_n = rem < (uint64_t)(kTile * UT) ? (uint32_t)rem : (uint32_t)(kTile * UT);
+#pragma unroll
+  for (int r = 0; r < UT; ++r) {
+    const uint32_t lo = (uint32_t)r * kTile;
+    if (lo >= unit_n) break;
+#pragma unroll
+    for (int t = 0; t < UT; ++t)
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const uint32_t rel = ((pk[t][j >> 1] >> ((j & 1) * 16)) & 0xFFFFu) - lo;  // (no record: 0xFFFF - lo, far outside)
+        if (rel < (uint32_t)kTile) store_rec<S>(stage + (size_t)rel * S, rec[t][j]);
+      }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const uint32_t li = (uint32_t)(j * kSortThreads + tid);
+      if (lo + li < unit_n) {
+        Rec<S> rr;
+        load_rec<S>(stage + (size_t)li * S, rr);
+        const unsigned d = rec_digit_w<S, WI>(rr, ds);
+        store_rec<S>(out + (uint64_t)(g_off[d] + (long long)(lo + li)) * S, rr);
+      }
+    }
+    __syncthreads();
+  }
+}
+
 // what a generated first pass needs to be launched (sort.hip fills it, the generator's owner launches its instantiation)
 struct OnesweepLaunch {
   unsigned grid;
@@ -276,6 +461,8 @@ struct OnesweepLaunch {
   uint32_t *ticket, *err;
   unsigned long long tag;
   int xcd_units;
+  int unit_runs;  // launch k_radix_onesweep_u (unit-wide runs) when the generator's owner has it for digit word `wi`
+  int wi;         // digit_word_of(ds, nbits, ...)
 };
 
 }  // namespace mhx

@@ -1,0 +1,71 @@
+"""A/B of tuning knobs on ONE box, in ONE process: the 10 M-read library of bench.py is generated and uploaded once, then
+every configuration (space-separated name=value lists, mhx_set_option knobs) runs warm-up + timed steps of read2sdbg with
+the library's own per-kernel clocks, and the SdBG its last step left in HBM is digested against the reference's
+(tests/golden/fullsize.json) — box-to-box variation is larger than most effects, and generating the reads costs more
+than the steps.
+
+    python tools/ab_options.py "sort_unit_runs=0" "sort_unit_runs=1" [--steps 6] [--engine read2sdbg|count]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("configs", nargs="+")
+    ap.add_argument("--steps", type=int, default=6)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--reads", type=float, default=10e6)
+    ap.add_argument("--engine", default="read2sdbg")
+    ap.add_argument("--rounds", type=int, default=1, help="repeat the whole list (drift of the box shows)")
+    args = ap.parse_args()
+    from megahit_amd import lib
+    n_reads = int(args.reads) // 16 * 16
+    t0 = time.time()
+    packed = bench.make_reads(n_reads, 0, 1)
+    print("generated %d reads in %.1f s" % (n_reads, time.time() - t0), file=sys.stderr, flush=True)
+    eng = lib.Engine(0)
+    eng.load_sequences(packed, n_reads, bench.READ_LEN, None)
+    E = n_reads * (bench.READ_LEN - bench.K)
+    out = []
+    for rnd in range(args.rounds):
+        for cfg in args.configs:
+            opts = dict((kv.split("=")[0], int(kv.split("=")[1])) for kv in cfg.split() if kv)
+            for name, v in opts.items():  # (a knob keeps its value until a later configuration sets it again: list it in every one)
+                eng.set_option(name, v)
+
+            def step():
+                if args.engine == "count":
+                    return eng.count(bench.K, bench.MIN_COUNT), None
+                r1 = eng.read2sdbg_s1(bench.K, bench.MIN_COUNT)
+                return r1, eng.read2sdbg_s2(bench.K, bench.MIN_COUNT)
+            for _ in range(args.warmup):
+                res = step()
+            eng.synchronize()
+            eng.profile(True)
+            eng.profile_reset()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                res = step()
+            eng.synchronize()
+            dt = time.perf_counter() - t0
+            stats = eng.profile_get()
+            eng.profile(False)
+            par = bench.output_parity(eng, args.engine, n_reads, 1, res)
+            line = {"config": cfg, "round": rnd, "ms_per_step": round(dt / args.steps * 1e3, 3), "M_edges_per_s": round(E * args.steps / dt / 1e6, 1),
+                    "parity_checked": bool(par["checked"]) if par else None,
+                    "kernel_ms_per_step": {k: round(v["ms"] / args.steps, 3) for k, v in sorted(stats.items(), key=lambda kv: -kv[1]["ms"]) if v["ms"] / args.steps >= 0.05}}
+            out.append(line)
+            print(json.dumps(line), flush=True)
+    eng.close()
+
+
+if __name__ == "__main__":
+    main()
