@@ -285,13 +285,9 @@ inline int digit_word_of(const DigitSpec &ds, int nbits, int max_word) {
 // of the unit leaves once, in one piece (two pieces for the at most UT - 1 digits a window edge cuts).  Same LDS stage,
 // the counters UT times as large, no separate counting phase before the ranking (the ranking's counters ARE the counts
 // the look-back publishes), fewer barriers.
-// workgroups (= waves per SIMD) the register budget has to allow per CU
-template <int S, int NI, int UT>
-constexpr int onesweep_u_waves() {
-  return S * NI * UT <= 48 ? 4 : 3;  // <= 48 record registers: 4; the 72 of 12-byte records in 8x3 units: 3
-}
-template <int S, int NI, int UT, class Src, bool ANY_ORDER, int WI>
-__global__ __launch_bounds__(kSortThreads) void k_radix_onesweep_u(Src src, uint32_t *__restrict__ out, uint64_t n, DigitSpec ds, int nbits,
+// WPE: waves per SIMD (= workgroups per CU) the register allocation has to leave room for; 1 = the compiler's own choice
+template <int S, int NI, int UT, class Src, bool ANY_ORDER, int WI, int WPE = 1>
+__global__ __launch_bounds__(kSortThreads) __attribute__((amdgpu_waves_per_eu(WPE, 8))) void k_radix_onesweep_u(Src src, uint32_t *__restrict__ out, uint64_t n, DigitSpec ds, int nbits,
                                                                    const unsigned long long *__restrict__ bin_start,
                                                                    unsigned long long *__restrict__ status, uint32_t *__restrict__ ticket,
                                                                    uint32_t *__restrict__ err, unsigned long long tag, int xcd_units) {

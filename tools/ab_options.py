@@ -38,6 +38,7 @@ def main():
     for rnd in range(args.rounds):
         for cfg in args.configs:
             opts = dict((kv.split("=")[0], int(kv.split("=")[1])) for kv in cfg.split() if kv)
+            s1_only = bool(opts.pop("stage1_only", 0))  # (pseudo-knob of this tool: time stage 1 alone, no digest)
             for name, v in opts.items():  # (a knob keeps its value until a later configuration sets it again: list it in every one)
                 eng.set_option(name, v)
 
@@ -45,7 +46,7 @@ def main():
                 if args.engine == "count":
                     return eng.count(bench.K, bench.MIN_COUNT), None
                 r1 = eng.read2sdbg_s1(bench.K, bench.MIN_COUNT)
-                return r1, eng.read2sdbg_s2(bench.K, bench.MIN_COUNT)
+                return r1, (None if s1_only else eng.read2sdbg_s2(bench.K, bench.MIN_COUNT))
             for _ in range(args.warmup):
                 res = step()
             eng.synchronize()
@@ -58,7 +59,7 @@ def main():
             dt = time.perf_counter() - t0
             stats = eng.profile_get()
             eng.profile(False)
-            par = bench.output_parity(eng, args.engine, n_reads, 1, res)
+            par = None if s1_only else bench.output_parity(eng, args.engine, n_reads, 1, res)
             line = {"config": cfg, "round": rnd, "ms_per_step": round(dt / args.steps * 1e3, 3), "M_edges_per_s": round(E * args.steps / dt / 1e6, 1),
                     "parity_checked": bool(par["checked"]) if par else None,
                     "kernel_ms_per_step": {k: round(v["ms"] / args.steps, 3) for k, v in sorted(stats.items(), key=lambda kv: -kv[1]["ms"]) if v["ms"] / args.steps >= 0.05}}
