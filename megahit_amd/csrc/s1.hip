@@ -735,7 +735,6 @@ struct S1SegArgs {
   int la_chunks;      // look-ahead limit, in chunks of 256 records
   int direct_marks;   // k_s1_stream: the non-solid marks come from the table (one stored position per key), no second read
   int used_list;      // k_s1_stream: the per-key phases walk a list of the occupied slots instead of the whole table
-  int debug_mode;     // k_s1_stream, TIMING EXPERIMENTS ONLY (wrong results): 1 = loads without inserts, 2 = inserts of cache-resident records
 };
 
 constexpr unsigned long long kSegEmpty = ~0ull;  // never a key: head/tail bits 63 do not occur (max (4<<3)|4)
@@ -1113,7 +1112,7 @@ __global__ __launch_bounds__(kStreamThreads) void k_s1_stream(const uint32_t *__
   __shared__ uint8_t ftag[NSLOT];   // ... and its source rank, when the records carry one (positions past 2^32, multi-GPU)
   // the occupied slots in the order they were claimed: a bucket fills about a third of the table (2 670 of 8 192 slots at
   // 10 M reads), and the two per-key phases below would otherwise visit all 8 192 slots of all 65 536 buckets — as many
-  // LDS reads as the bucket has records
+  // LDS reads as the bucket has records.  (Measured: 8.15 -> 8.10 ms only; this kernel's time is its insert phase.)
   __shared__ uint16_t used[NSLOT];
   __shared__ uint32_t lhist[kSegHist];
   __shared__ uint32_t s_bad, s_agg_cur, s_mark_cur, s_bucket, s_nused;
@@ -1174,7 +1173,7 @@ __global__ __launch_bounds__(kStreamThreads) void k_s1_stream(const uint32_t *__
         rin[u] = gi < hi;
         // unconditional loads (index clamped into the bucket, lo < hi): straight-line code, so that the compiler issues all
         // UNR loads before the first wait — a load inside an `if` is followed by s_waitcnt vmcnt(0) at the end of its block
-        const uint32_t *p = items + (a.debug_mode == 2 ? lo + ((gi - lo) & 1023u) < hi ? lo + ((gi - lo) & 1023u) : lo : (rin[u] ? gi : hi - 1)) * 3;
+        const uint32_t *p = items + (rin[u] ? gi : hi - 1) * 3;
         rw0[u] = p[0];
         rw1[u] = p[1];
         rw2[u] = p[2];
@@ -1182,10 +1181,6 @@ __global__ __launch_bounds__(kStreamThreads) void k_s1_stream(const uint32_t *__
 #pragma unroll
       for (int u = 0; u < UNR; ++u) {
         if (!rin[u]) continue;
-        if (a.debug_mode == 1) {  // (timing experiment: the loads alone)
-          if ((rw0[u] ^ rw1[u] ^ rw2[u]) == 0x9E3779B1u) s_bad = 1;
-          continue;
-        }
         const uint32_t lk = local_key(rw0[u], rw1[u]), w2 = rw2[u];
         const uint32_t tag = (rw1[u] >> 6) & 0xFFu;
         // one compare-and-swap + add per record: inside a bucket the records are in read order, equal keys are rarely
@@ -2027,8 +2022,7 @@ int s1_process(mhx_ctx *c, uint32_t k, uint32_t m, int want_mercy, uint32_t *buf
     // the stream kernel marks the non-solid occurrences from its table when each of them is its key's only record
     const int direct = plan.stream && mode == 1 && m <= 2 && (mraw || (pos_stride == 0 && solid_bytes)) && c->opt("s1_stream_direct", 1) ? 1 : 0;
     S1SegArgs a{(int)k, m, pfx_mask, eq_mask1, solid_bytes, mode, hist, ctr, raw, seg_cap, counts, mraw, mcap, mcounts, pos_stride, seg_err,
-                plan.stream ? (int)c->opt("s1_stream_probes", 1024) : la, direct, c->opt("s1_stream_used_list", 1) != 0 ? 1 : 0,
-                (int)c->opt("s1_stream_debug", 0)};
+                plan.stream ? (int)c->opt("s1_stream_probes", 1024) : la, direct, c->opt("s1_stream_used_list", 1) != 0 ? 1 : 0};
     MHX_HIP(hipMemsetAsync(seg_err, 0, 4, st));
     const char *nm = mode == 2 ? "s1_sample" : "s1_groups";
     const double bytes = plan.stream ? (double)n_items * 12 / stride : (double)n_work * T * 12;

@@ -359,8 +359,6 @@ static uint32_t *radix_sort_onesweep(mhx_ctx *c, uint32_t *a, uint32_t *b, uint6
   hipLaunchKernelGGL(k_bin_starts, dim3(P), dim3(256), 0, st, gh, starts);
   // unit-wide runs (k_radix_onesweep_u) for the default unit shape of every width; MHX_SORT_UNIT_RUNS=0: the tile-by-tile kernel
   constexpr bool kHasUnitRuns = (S <= 3 && NI == 8 && (UT == 3 || UT == 2)) || (S == 4 && NI == 8 && UT == 2) || (S > 4 && NI == 4 && UT == 2);
-  // 12-byte records in 8x3 units: 138 registers = 3 workgroups per CU; sort_unit_waves=4 asks the compiler for 128 (a few spills)
-  const bool waves4 = S == 3 && NI == 8 && UT == 3 && c->opt("sort_unit_waves", 3) == 4;
   const bool unit_runs = kHasUnitRuns && c->opt("sort_unit_runs", 1) != 0;
   for (int p = 0; p < P; ++p) {
     const int nb = passes[p].bits + passes[p].bits2;
@@ -376,11 +374,7 @@ static uint32_t *radix_sort_onesweep(mhx_ctx *c, uint32_t *a, uint32_t *b, uint6
   hipLaunchKernelGGL((k_radix_onesweep_u<S, NI, UT, SrcArray<S>, false, WIV>), dim3((unsigned)n_units), dim3(kSortThreads), 0, st, SrcArray<S>{a}, b, \
                      n, all[p], nb, starts + p * 256, status, tickets + p * 8, tickets + kErrSlot, (unsigned long long)(p + 1), xcd_units)
         MHX_LAUNCH(c, nm_scat.c_str(), 2 * bytes, {
-          if (wi == 0 && waves4) {
-            if constexpr (S == 3 && NI == 8 && UT == 3)
-              hipLaunchKernelGGL((k_radix_onesweep_u<S, NI, UT, SrcArray<S>, false, 0, 4>), dim3((unsigned)n_units), dim3(kSortThreads), 0, st, SrcArray<S>{a},
-                                 b, n, all[p], nb, starts + p * 256, status, tickets + p * 8, tickets + kErrSlot, (unsigned long long)(p + 1), xcd_units);
-          } else if (wi == 0) MHX_U(0);
+          if (wi == 0) MHX_U(0);
           else if (wi == 1) MHX_U(1);
           else MHX_U(-1);
         });

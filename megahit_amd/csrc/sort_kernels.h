@@ -284,10 +284,13 @@ inline int digit_word_of(const DigitSpec &ds, int nbits, int max_word) {
 // sliding over that sequence: round r stages the records with p in [r T, (r+1) T) and writes them, so every digit's run
 // of the unit leaves once, in one piece (two pieces for the at most UT - 1 digits a window edge cuts).  Same LDS stage,
 // the counters UT times as large, no separate counting phase before the ranking (the ranking's counters ARE the counts
-// the look-back publishes), fewer barriers.
-// WPE: waves per SIMD (= workgroups per CU) the register allocation has to leave room for; 1 = the compiler's own choice
-template <int S, int NI, int UT, class Src, bool ANY_ORDER, int WI, int WPE = 1>
-__global__ __launch_bounds__(kSortThreads) __attribute__((amdgpu_waves_per_eu(WPE, 8))) void k_radix_onesweep_u(Src src, uint32_t *__restrict__ out, uint64_t n, DigitSpec ds, int nbits,
+// the look-back publishes), fewer barriers.  Measured at 1.33 G 12-byte records (round 3, A/B inside one run, PMC passes):
+// bytes written per pass 24.7 -> 17.0 GB (1.55 -> 1.06 x algorithmic), 10.6 -> 8.9 ms per pass; the generating first pass
+// 19.6 -> 17.0 GB, 10.0 -> 9.3 ms; 8-byte records 0.73 -> 0.65 ms per pass; 16-byte records (count) 11.5 -> 10.9 ms.
+// (12-byte records, 8x3 units: 138 registers = 3 workgroups per CU.  Asking the compiler for 128 = 4 workgroups costs 13
+// spilled registers and measured slower: 10.7 instead of 9.2 ms per pass.)
+template <int S, int NI, int UT, class Src, bool ANY_ORDER, int WI>
+__global__ __launch_bounds__(kSortThreads) void k_radix_onesweep_u(Src src, uint32_t *__restrict__ out, uint64_t n, DigitSpec ds, int nbits,
                                                                    const unsigned long long *__restrict__ bin_start,
                                                                    unsigned long long *__restrict__ status, uint32_t *__restrict__ ticket,
                                                                    uint32_t *__restrict__ err, unsigned long long tag, int xcd_units) {
