@@ -93,6 +93,22 @@ def pmc_traffic(kernel_name, path=None):
     return None, None
 
 
+def tuned_defaults():
+    """name -> value of megahit_amd/mhx_tuning.conf (the tuned defaults libmhx reads at mhx_create), {} when absent"""
+    out = {}
+    if os.environ.get("MHX_NO_TUNING"):
+        return out
+    try:
+        with open(os.environ.get("MHX_TUNING_FILE") or os.path.join(ROOT, "megahit_amd", "mhx_tuning.conf")) as f:
+            for line in f:
+                parts = line.split("#")[0].replace("=", " ").split()
+                if len(parts) == 2:
+                    out[parts[0]] = int(parts[1])
+    except OSError:
+        pass
+    return out
+
+
 def copy_bandwidth(torch):
     """GB/s (read + write) of a plain device-to-device copy of 2 GiB in this run: what a streaming kernel reaches on
     this part, quoted beside the datasheet peak."""
@@ -482,6 +498,7 @@ def main():
             out["build_id"], out["lib_id"] = build_id(), lib_id()
         except Exception:
             pass
+        out["tuning"] = tuned_defaults()  # megahit_amd/mhx_tuning.conf: the knob defaults this run (and the CLI) used
         if use_dist:
             out["config"]["rank0_s1_items"] = int(res[0].n_items)
             out["config"]["rank0_s2_items"] = int(res[1].n_items)

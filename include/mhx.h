@@ -72,6 +72,17 @@ int mhx_synchronize(mhx_ctx *);
  *                     block-id class b % 8 (sort.hip); same output
  * Returns <0 for a NULL handle/name. */
 int mhx_set_option(mhx_ctx *, const char *name, long long value);
+/* The value a knob has for this handle: an explicit mhx_set_option, else the environment variable MHX_<NAME>, else the
+ * installation's tuned default — a `name = value` line of mhx_tuning.conf beside libmhx.so (MHX_TUNING_FILE names another
+ * file, MHX_NO_TUNING=1 ignores it; written by tools/ab_options.py --write-tuning from an A/B on the box; read once, at
+ * mhx_create) — else `dflt`.  Knobs only ever choose between code paths with identical results.  Round 3:
+ *   sort_unit_runs (1)     0: the chained-scan pass ranks, stages and writes its unit tile by tile (k_radix_onesweep) instead of
+ *                          unit-wide runs (k_radix_onesweep_u)
+ *   sort_rank_atomic (0)   1: the passes that load their records rank with one returning LDS atomic per record instead of the
+ *                          match-any ballots — only on a device that passes the lane-order probe (sort.hip)
+ *   s1_stream_used_list (1) 0: the bucket streaming walks its whole LDS table in the per-key phases instead of the list of
+ *                          occupied slots */
+long long mhx_get_option(mhx_ctx *, const char *name, long long dflt);
 
 /* ---- sequence store (replaces SeqPackage held by each engine:
  *      kmer_counter.h:76, read_to_sdbg.h:47-51, seq_to_sdbg.h:79) ---- */

@@ -5,6 +5,9 @@
 #include <thread>
 #include <cstdarg>
 #include <cstdlib>
+#include <dlfcn.h>
+#include <fstream>
+#include <sstream>
 
 #include "dev_prims.h"
 #include "mhx_internal.h"
@@ -506,6 +509,8 @@ int mhx_device_count(void) {
   return n;
 }
 
+static void load_tuning(mhx_ctx *c);
+
 mhx_ctx *mhx_create(int device) {
   try {
     int n = 0;
@@ -520,6 +525,7 @@ mhx_ctx *mhx_create(int device) {
       hipDeviceProp_t prop;
       if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->n_cus = prop.multiProcessorCount;
     }
+    load_tuning(c);
     // ranking inside the radix scatter: ballot match-any (default, order-independent by construction);
     // MHX_SORT_RANK=atomic opts into one returning LDS atomic per record, used only if the device passes
     // the lane-order probe (measured on MI355X: probe passes, gain < 2 %, so it is not the default)
@@ -612,8 +618,41 @@ long long mhx_ctx::opt(const char *name, long long dflt) const {
   std::string env = "MHX_";
   for (const char *p = name; *p; ++p) env += (char)toupper((unsigned char)*p);
   const char *e = getenv(env.c_str());
-  return e && *e ? atoll(e) : dflt;
+  if (e && *e) return atoll(e);
+  auto tu = tuned.find(name);
+  return tu != tuned.end() ? tu->second : dflt;
 }
+
+// mhx_tuning.conf beside libmhx.so: the knob settings measured best on this installation (tools/ab_options.py writes it from
+// an A/B on the box); `name = value` or `name value` per line, '#' starts a comment.  Every knob only chooses between
+// code paths that produce identical results.
+static void load_tuning(mhx_ctx *c) {
+  if (getenv("MHX_NO_TUNING")) return;
+  std::string path;
+  if (const char *f = getenv("MHX_TUNING_FILE")) path = f;
+  else {
+    Dl_info info;
+    if (!dladdr((const void *)&mhx_synchronize, &info) || !info.dli_fname) return;
+    path = info.dli_fname;
+    const size_t slash = path.rfind('/');
+    path = (slash == std::string::npos ? std::string(".") : path.substr(0, slash)) + "/mhx_tuning.conf";
+  }
+  std::ifstream in(path);
+  if (!in) return;
+  std::string line;
+  while (std::getline(in, line)) {
+    const size_t hash = line.find('#');
+    if (hash != std::string::npos) line.resize(hash);
+    for (char &ch : line)
+      if (ch == '=') ch = ' ';
+    std::istringstream ls(line);
+    std::string name;
+    long long v;
+    if (ls >> name >> v) c->tuned[name] = v;
+  }
+  if (getenv("MHX_VERBOSE")) fprintf(stderr, "[mhx] %zu tuned defaults from %s\n", c->tuned.size(), path.c_str());
+}
+long long mhx_get_option(mhx_ctx *c, const char *name, long long dflt) { return c && name ? c->opt(name, dflt) : dflt; }
 int mhx_set_option(mhx_ctx *c, const char *name, long long value) {
   if (!c || !name) return -1;
   c->options[name] = value;

@@ -82,6 +82,7 @@ struct mhx_ctx {
   // the LDS applies same-address lanes of one returning atomic in lane order (probed at mhx_create):
   // lets the radix scatter rank records with one ds_add_rtn instead of an 8-ballot match-any
   bool lds_atomic_ordered = false;
+  bool lds_probe_done = false;  // probe_lds_atomic_order has run on this handle (sort.hip runs it on first use of sort_rank_atomic)
   // stage-2 items aggregated by stage 1 (ws "s2_agg_items"): valid for one (k, m) until the reads or the
   // is_solid bitmap change
   bool agg_valid = false;
@@ -112,6 +113,9 @@ struct mhx_ctx {
   bool dist_s2_agg = false;  // the items of the current multi-GPU stage-2 exchange are aggregated ones
   // tuning knobs (mhx_set_option): explicit value, else environment MHX_<NAME>, else the default
   std::map<std::string, long long> options;
+  // tuned defaults of this installation: `name = value` lines of mhx_tuning.conf beside libmhx.so (MHX_TUNING_FILE names
+  // another file, MHX_NO_TUNING=1 ignores it), read at mhx_create; consulted after explicit options and the environment
+  std::map<std::string, long long> tuned;
   long long opt(const char *name, long long dflt) const;
   // pinned staging buffers of upload_pinned (capi.hip)
   void *pinned[2] = {nullptr, nullptr};

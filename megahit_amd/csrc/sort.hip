@@ -360,6 +360,19 @@ static uint32_t *radix_sort_onesweep(mhx_ctx *c, uint32_t *a, uint32_t *b, uint6
   // unit-wide runs (k_radix_onesweep_u) for the default unit shape of every width; MHX_SORT_UNIT_RUNS=0: the tile-by-tile kernel
   constexpr bool kHasUnitRuns = (S <= 3 && NI == 8 && (UT == 3 || UT == 2)) || (S == 4 && NI == 8 && UT == 2) || (S > 4 && NI == 4 && UT == 2);
   const bool unit_runs = kHasUnitRuns && c->opt("sort_unit_runs", 1) != 0;
+  // sort_rank_atomic: rank the records of a wavefront with ONE returning LDS atomic per record (the ANY_ORDER form of the
+  // kernel) instead of the match-any over the digit bits (8 ballots, ~80 VALU operations per record: half the instructions
+  // of a pass).  That is a STABLE ranking exactly when the LDS applies the same-address lanes of one atomic instruction in
+  // lane order — not an architectural promise, so the device is probed first (probe_lds_atomic_order: adversarial
+  // lane -> address patterns) and the ballots stay in use wherever the probe fails.
+  bool rank_atomic = false;
+  if (unit_runs && c->opt("sort_rank_atomic", 0) != 0) {
+    if (!c->lds_probe_done) {
+      c->lds_atomic_ordered = probe_lds_atomic_order(c) || c->lds_atomic_ordered;
+      c->lds_probe_done = true;
+    }
+    rank_atomic = c->lds_atomic_ordered;
+  }
   for (int p = 0; p < P; ++p) {
     const int nb = passes[p].bits + passes[p].bits2;
     const int wi = digit_word_of(all[p], nb, 1);
@@ -370,13 +383,15 @@ static uint32_t *radix_sort_onesweep(mhx_ctx *c, uint32_t *a, uint32_t *b, uint6
                                     tickets + kErrSlot, (unsigned long long)(p + 1), xcd_units, unit_runs ? 1 : 0, wi}));
     } else if (unit_runs) {
       if constexpr (kHasUnitRuns) {
-#define MHX_U(WIV)                                                                                                                              \
-  hipLaunchKernelGGL((k_radix_onesweep_u<S, NI, UT, SrcArray<S>, false, WIV>), dim3((unsigned)n_units), dim3(kSortThreads), 0, st, SrcArray<S>{a}, b, \
+#define MHX_U(ANYV, WIV)                                                                                                                       \
+  hipLaunchKernelGGL((k_radix_onesweep_u<S, NI, UT, SrcArray<S>, ANYV, WIV>), dim3((unsigned)n_units), dim3(kSortThreads), 0, st, SrcArray<S>{a}, b, \
                      n, all[p], nb, starts + p * 256, status, tickets + p * 8, tickets + kErrSlot, (unsigned long long)(p + 1), xcd_units)
         MHX_LAUNCH(c, nm_scat.c_str(), 2 * bytes, {
-          if (wi == 0) MHX_U(0);
-          else if (wi == 1) MHX_U(1);
-          else MHX_U(-1);
+          if (wi == 0 && rank_atomic) MHX_U(true, 0);
+          else if (wi == 1 && rank_atomic) MHX_U(true, 1);
+          else if (wi == 0) MHX_U(false, 0);
+          else if (wi == 1) MHX_U(false, 1);
+          else MHX_U(false, -1);
         });
 #undef MHX_U
       }

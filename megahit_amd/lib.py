@@ -95,6 +95,7 @@ SYMBOLS = {
     "mhx_trim": (C.c_int, [_P]),
     "mhx_synchronize": (C.c_int, [_P]),
     "mhx_set_option": (C.c_int, [_P, C.c_char_p, C.c_longlong]),
+    "mhx_get_option": (C.c_longlong, [_P, C.c_char_p, C.c_longlong]),
     "mhx_load_sequences": (C.c_int, [_P, _P, C.c_uint64, C.c_uint64, C.c_uint32, _P]),
     "mhx_load_bin_records": (C.c_int, [_P, _P, C.c_uint64, C.c_uint64, C.c_int]),
     "mhx_append_sequences": (C.c_int, [_P, _P, C.c_uint64, C.c_uint64, C.c_uint32, _P, _P]),
@@ -396,6 +397,10 @@ class Engine:
     def set_option(self, name, value):
         """Tuning / diagnostic knob of this handle (include/mhx.h: mhx_set_option)."""
         self._chk(self.lib.mhx_set_option(self.h, name.encode(), int(value)))
+
+    def get_option(self, name, default):
+        """Effective value of a knob for this handle (include/mhx.h: mhx_get_option): explicit option, environment, tuned default."""
+        return int(self.lib.mhx_get_option(self.h, name.encode(), int(default)))
 
     # ---- profiling
     def profile(self, on=True):

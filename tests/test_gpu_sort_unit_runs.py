@@ -14,12 +14,16 @@ from test_gpu_sdbg import check_sdbg
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=[1, 0], ids=["unit_runs", "tile_runs"])
+# unit-wide runs with the match-any ballots (the default), the tile-by-tile pass, unit-wide runs ranked with one LDS atomic
+# per record (include/mhx.h: sort_rank_atomic; stable where the device passes the lane-order probe, else the ballots run)
+@pytest.fixture(params=[(1, 0), (0, 0), (1, 1)], ids=["unit_runs", "tile_runs", "unit_runs_atomic"])
 def unit_runs(engine, request):
-    engine.set_option("sort_unit_runs", request.param)
+    engine.set_option("sort_unit_runs", request.param[0])
+    engine.set_option("sort_rank_atomic", request.param[1])
     engine.set_option("sort_hybrid", 0)  # every key bit by LSD passes
     yield request.param
     engine.set_option("sort_unit_runs", 1)
+    engine.set_option("sort_rank_atomic", 0)
     engine.set_option("sort_hybrid", 1)
 
 

@@ -25,6 +25,11 @@ def main():
     ap.add_argument("--reads", type=float, default=10e6)
     ap.add_argument("--engine", default="read2sdbg")
     ap.add_argument("--rounds", type=int, default=1, help="repeat the whole list (drift of the box shows)")
+    ap.add_argument("--write-tuning", default=None, metavar="FILE",
+                    help="write the knobs of the fastest configuration whose outputs matched the reference in every round to FILE "
+                         "(megahit_amd/mhx_tuning.conf: the tuned defaults libmhx reads at mhx_create); the first configuration "
+                         "is kept unless another one is faster by --min-gain-ms")
+    ap.add_argument("--min-gain-ms", type=float, default=0.15)
     args = ap.parse_args()
     from megahit_amd import lib
     n_reads = int(args.reads) // 16 * 16
@@ -66,6 +71,31 @@ def main():
             out.append(line)
             print(json.dumps(line), flush=True)
     eng.close()
+    if args.write_tuning:
+        best = {}
+        for line in out:
+            b = best.setdefault(line["config"], {"ms": 1e30, "ok": True})
+            b["ms"] = min(b["ms"], line["ms_per_step"])
+            b["ok"] = b["ok"] and line["parity_checked"] is True
+        base = args.configs[0]
+        pick = base if best[base]["ok"] else None
+        for cfg in args.configs[1:]:
+            if best[cfg]["ok"] and (pick is None or best[cfg]["ms"] < best[pick]["ms"] - (args.min_gain_ms if pick == base else 0.0)):
+                pick = cfg
+        if pick is None:
+            print("no configuration reproduced the reference: nothing written", file=sys.stderr)
+            return
+        knobs = [kv.split("=") for kv in pick.split() if kv and not kv.startswith("stage1_only")]
+        with open(args.write_tuning, "w") as f:
+            f.write("# tuned defaults of libmhx (read at mhx_create; explicit options and MHX_* environment variables win).\n"
+                    "# Written by tools/ab_options.py from an A/B on the box: %s, %d x %d steps each; every line chooses between\n"
+                    "# code paths with identical results (all configurations below matched the reference's digest).\n"
+                    % (args.engine, args.rounds, args.steps))
+            for cfg in args.configs:
+                f.write("#   %-60s %.3f ms/step%s\n" % (cfg, best[cfg]["ms"], "" if best[cfg]["ok"] else "  (REJECTED: outputs differ)"))
+            for name, v in knobs:
+                f.write("%s = %d\n" % (name, int(v)))
+        print("tuning: %s -> %s" % (pick, args.write_tuning), file=sys.stderr)
 
 
 if __name__ == "__main__":
