@@ -176,24 +176,11 @@ __device__ __forceinline__ uint64_t rc64(uint64_t x, int n);
 //   * read index and slot advance incrementally with the persistent loop (the per-iteration stride of the workgroup,
 //     divided by the items per read, comes from the host), the only division left is a 32-bit one.
 // Same output, bit for bit, as k_s1_extract_fixed<2, 3, true> (read_to_sdbg_s1.cpp:228-292, :344-363).
-// one stage-1 record of a fixed-length read set from the 64-bit window around its (k-1)-mer: read r, slot j (see above)
-__device__ __forceinline__ void s1_fast_item(const uint32_t *__restrict__ seq, uint32_t L, int k, uint64_t st, uint32_t j, uint64_t pos_base,
-                                             uint32_t rank_tag, uint32_t (&out)[3]) {
-  // st = first base of the read (read index x L: the callers advance it with the slots instead of multiplying per item)
+// the record of the (k-1)-mer at offset q of its read (absolute base a), from the 64 bits of the store that start two bases
+// in front of it: prev | head | (k-1)-mer | tail | next ...
+__device__ __forceinline__ void s1_item_from_window(uint64_t win, uint32_t q, int forced, uint32_t L, int k, uint64_t a, uint64_t pos_base,
+                                                    uint32_t rank_tag, uint32_t (&out)[3]) {
   const int km1 = k - 1;
-  // slot -> offset of the (k-1)-mer; slots 0, 1 and the last two are the forced-strand pairs at the read's ends
-  const uint32_t jf = L - k + 2;
-  const uint32_t q = min(j > 0 ? j - 1 : 0u, jf - 1);
-  const int forced = j < 2 ? (int)j : (j >= jf ? (int)(j - jf) : -1);
-  const uint64_t a = st + q;
-  if (a < 2) {  // the first two bases of the store: no window in front of them
-    s1_make_item<2, 3, true>(seq, st, L, k, j, pos_base, rank_tag, out);
-    return;
-  }
-  const uint64_t b = a - 2, w = b >> 4;
-  const unsigned sh = (unsigned)(b & 15) * 2;
-  const uint32_t x0 = seq[w], x1 = seq[w + 1], x2 = seq[w + 2];
-  const uint64_t win = ((uint64_t)funnel_l(x0, x1, sh) << 32) | funnel_l(x1, x2, sh);
   const unsigned head_b = (unsigned)(win >> 60) & 3u, tail_b = (unsigned)(win >> (58 - 2 * km1)) & 3u;
   const uint64_t f = (win << 4) & (~0ull << (64 - 2 * km1));
   const uint64_t rc = rc64(f, km1);
@@ -206,6 +193,26 @@ __device__ __forceinline__ void s1_fast_item(const uint32_t *__restrict__ seq, u
   out[0] = (uint32_t)(key >> 32);
   out[1] = (uint32_t)key | rank_tag;
   out[2] = (uint32_t)(pos_base + a);
+}
+
+// one stage-1 record of a fixed-length read set from the 64-bit window around its (k-1)-mer: read r, slot j (see above)
+__device__ __forceinline__ void s1_fast_item(const uint32_t *__restrict__ seq, uint32_t L, int k, uint64_t st, uint32_t j, uint64_t pos_base,
+                                             uint32_t rank_tag, uint32_t (&out)[3]) {
+  // st = first base of the read (read index x L: the callers advance it with the slots instead of multiplying per item)
+  // slot -> offset of the (k-1)-mer; slots 0, 1 and the last two are the forced-strand pairs at the read's ends
+  const uint32_t jf = L - k + 2;
+  const uint32_t q = min(j > 0 ? j - 1 : 0u, jf - 1);
+  const int forced = j < 2 ? (int)j : (j >= jf ? (int)(j - jf) : -1);
+  const uint64_t a = st + q;
+  // The window starts two bases in front of the (k-1)-mer.  For the first two bases of the store (read 0, offsets 0 and 1) it
+  // would start before the store: take the window at base 0 and shift it down instead — what moves in at the top stands for
+  // bases that no record uses (offset 0 has no head, and the compact record carries no prev).  Straight-line code: with the
+  // general item code behind a branch here, every window load of the generating sort pass was waited for on the spot.
+  const uint64_t b = a >= 2 ? a - 2 : 0, w = b >> 4;
+  const unsigned sh = (unsigned)(b & 15) * 2, down = a >= 2 ? 0u : (unsigned)(2 - a) * 2;
+  const uint32_t x0 = seq[w], x1 = seq[w + 1], x2 = seq[w + 2];
+  const uint64_t win = (((uint64_t)funnel_l(x0, x1, sh) << 32) | funnel_l(x1, x2, sh)) >> down;
+  s1_item_from_window(win, q, forced, L, k, a, pos_base, rank_tag, out);
 }
 
 // The same records as a SOURCE of the first chained-scan pass (sort_kernels.h): no record array is written by the
@@ -224,11 +231,126 @@ struct S1Gen {
     uint64_t st = r * L;
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
-      if (first + (uint64_t)i * kWave < n) s1_fast_item(seq, L, k, st, j, pos_base, rank_tag, rec[i].w);
+      // (an item beyond the last one is made from read 0, slot 2 and dropped: unconditional loads inside the store, so that
+      // the window loads of a tile are issued together)
+      const bool ok = first + (uint64_t)i * kWave < n;
+      uint32_t out[3];
+      s1_fast_item(seq, L, k, ok ? st : 0, ok ? j : 2u, pos_base, rank_tag, out);
+      if (ok) {
+        rec[i].w[0] = out[0];
+        rec[i].w[1] = out[1];
+        rec[i].w[2] = out[2];
+      }
       j += kWave;
       while (j >= per) {
         j -= per;
         st += L;
+      }
+    }
+  }
+  // (interface of k_radix_onesweep_u: the item a thread holds in slot j of a tile, and all records of a unit that are one thread's)
+  template <int NI>
+  __device__ __forceinline__ uint64_t index(uint64_t tile_base, int w, int lane, int j) const {
+    return tile_base + (uint64_t)(w * (kWave * NI) + j * kWave + lane);
+  }
+  template <int NI, int UT>
+  __device__ __forceinline__ void get_unit(uint64_t unit_base, int w, int lane, uint64_t n, Rec<3> (&rec)[UT][NI]) const {
+#pragma unroll
+    for (int t = 0; t < UT; ++t) get<NI>(unit_base + (uint64_t)t * (kSortThreads * NI) + (uint64_t)(w * (kWave * NI) + lane), n, rec[t]);
+  }
+};
+
+// The same generator with CONSECUTIVE items per thread (a pass whose records may leave in any order does not care which
+// thread holds which item of the unit): eight consecutive slots of a read share their window words — four words loaded
+// once for the run that starts at the thread's first item and four for the start of the next read, instead of three words
+// per item —, the slot and the read's base offset advance by increments, and there is one division per tile and thread as
+// before.  Needs at least NI slots per read (at most one read boundary inside a thread's items).
+struct S1GenBlocked {
+  const uint32_t *seq;
+  uint32_t L, per;
+  int k;
+  uint64_t pos_base;
+  uint32_t rank_tag;
+  uint32_t tile_q, tile_r;  // items of a tile (256 NI) divided by the slots per read: quotient and remainder
+  template <int NI>
+  __device__ __forceinline__ uint64_t index(uint64_t tile_base, int w, int lane, int j) const {
+    return tile_base + (uint64_t)((w * kWave + lane) * NI + j);
+  }
+  // all tiles of a unit at once: ONE division, the window words of all UT tiles requested before the first item is made
+  // (the striped generator waits for one window load per item: 24 round trips to the store per thread and unit)
+  template <int NI, int UT>
+  __device__ __forceinline__ void get_unit(uint64_t unit_base, int w, int lane, uint64_t n, Rec<3> (&rec)[UT][NI]) const {
+    constexpr uint32_t kTileItems = kSortThreads * NI;
+    const uint64_t g00 = unit_base + (uint64_t)((w * kWave + lane) * NI);
+    const uint32_t qlast = L - k + 1, jf = L - k + 2;
+    uint32_t jt[UT];   // slot of the thread's first item in tile t
+    uint64_t bt[UT];   // first base of that item's read
+    {
+      const uint64_t r = g00 / per;
+      jt[0] = (uint32_t)(g00 - r * per);
+      bt[0] = r * L;
+#pragma unroll
+      for (int t = 1; t < UT; ++t) {
+        uint32_t jn = jt[t - 1] + tile_r;
+        uint64_t bn = bt[t - 1] + (uint64_t)tile_q * L;
+        if (jn >= per) {
+          jn -= per;
+          bn += L;
+        }
+        jt[t] = jn;
+        bt[t] = bn;
+      }
+#pragma unroll
+      for (int t = 0; t < UT; ++t)
+        if (g00 + (uint64_t)t * kTileItems >= n) {  // nothing of this tile is this thread's: loads from the start of the store, nothing kept
+          jt[t] = 0;
+          bt[t] = 0;
+        }
+    }
+    uint64_t wcur[UT], wnext[UT];
+    uint32_t c[UT][4], nx[UT][4];
+#pragma unroll
+    for (int t = 0; t < UT; ++t) {
+      const uint32_t q0 = min(jt[t] > 0 ? jt[t] - 1 : 0u, qlast);
+      const uint64_t a0 = bt[t] + q0, b0 = a0 >= 2 ? a0 - 2 : 0;
+      wcur[t] = b0 >> 4;                    // first word of the windows of the run that starts at the thread's first item
+      wnext[t] = (bt[t] + L - 2) >> 4;      // ... of the run at the start of the next read (slot 0: offset 0, window 2 bases in front)
+#pragma unroll
+      for (int x = 0; x < 4; ++x) {
+        c[t][x] = seq[wcur[t] + x];
+        nx[t][x] = seq[wnext[t] + x];       // (the store is padded: also behind the last read)
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < UT; ++t) {
+      const uint64_t g0 = g00 + (uint64_t)t * kTileItems;
+      uint32_t j = jt[t];
+      uint64_t base = bt[t], wc = wcur[t];
+      uint32_t c0 = c[t][0], c1 = c[t][1], c2 = c[t][2], c3 = c[t][3];
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const uint32_t q = min(j > 0 ? j - 1 : 0u, qlast);
+        const int forced = j < 2 ? (int)j : (j >= jf ? (int)(j - jf) : -1);
+        const uint64_t a = base + q;
+        const uint64_t b = a >= 2 ? a - 2 : 0;  // (the first two bases of the store: s1_fast_item)
+        const unsigned down = a >= 2 ? 0u : (unsigned)(2 - a) * 2;
+        const bool second = (b >> 4) != wc;     // a run of NI <= 8 windows starts in at most two different words
+        const unsigned sh = (unsigned)(b & 15) * 2;
+        const uint32_t x0 = second ? c1 : c0, x1 = second ? c2 : c1, x2 = second ? c3 : c2;
+        const uint64_t win = (((uint64_t)funnel_l(x0, x1, sh) << 32) | funnel_l(x1, x2, sh)) >> down;
+        uint32_t out[3];
+        s1_item_from_window(win, q, forced, L, k, a, pos_base, rank_tag, out);
+        if (g0 + (uint64_t)i < n) {
+          rec[t][i].w[0] = out[0];
+          rec[t][i].w[1] = out[1];
+          rec[t][i].w[2] = out[2];
+        }
+        if (++j == per) {
+          j = 0;
+          base += L;
+          c0 = nx[t][0]; c1 = nx[t][1]; c2 = nx[t][2]; c3 = nx[t][3];
+          wc = wnext[t];
+        }
       }
     }
   }
@@ -320,7 +442,10 @@ struct HiDigits {
   unsigned sh[kFastPasses], mk[kFastPasses];
   int n;
 };
-template <int IT, int NP>  // NP digit histograms
+// PRE: the window words of a thread's IT consecutive items are requested up front — four words for the run that starts at its
+// first item, four for the start of the next read, as in S1GenBlocked — instead of being reloaded (and waited for) inside the
+// item loop whenever the window moves into the next word.
+template <int IT, int NP, bool PRE = false>  // NP digit histograms
 __global__ __launch_bounds__(256) void k_s1_digit_hist_plain(const uint32_t *__restrict__ seq, uint32_t L, uint32_t per, uint64_t n_items, int k,
                                                              HiDigits hd, unsigned long long *__restrict__ ghist, uint32_t step_q, uint32_t step_r) {
   constexpr int B = 256 * IT;
@@ -351,6 +476,21 @@ __global__ __launch_bounds__(256) void k_s1_digit_hist_plain(const uint32_t *__r
     uint64_t base = (q0 + dq) * L;  // first base of the read
     uint64_t wcur = ~0ull;
     uint32_t x0 = 0, x1 = 0, x2 = 0;
+    uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0, n0 = 0, n1 = 0, n2 = 0, n3 = 0;
+    uint64_t wnext = 0;
+    if constexpr (PRE) {
+      static_assert(IT <= 8, "a run of IT windows starts in at most two words");
+      if (g0 >= n_items) {  // (nothing of this block is this thread's: loads from the start of the store, nothing counted)
+        j = 0;
+        base = 0;
+      }
+      const uint32_t qs = min(j > 0 ? j - 1 : 0u, qlast);
+      const uint64_t as = base + qs, bs = as >= 2 ? as - 2 : 0;
+      wcur = bs >> 4;
+      wnext = (base + L - 2) >> 4;
+      c0 = seq[wcur]; c1 = seq[wcur + 1]; c2 = seq[wcur + 2]; c3 = seq[wcur + 3];
+      n0 = seq[wnext]; n1 = seq[wnext + 1]; n2 = seq[wnext + 2]; n3 = seq[wnext + 3];
+    }
 #pragma unroll
     for (int u = 0; u < IT; ++u) {
       const uint32_t q = min(j > 0 ? j - 1 : 0u, qlast);
@@ -358,7 +498,12 @@ __global__ __launch_bounds__(256) void k_s1_digit_hist_plain(const uint32_t *__r
       const uint32_t fstrand = j < 2 ? j : j - jf;
       const uint64_t a = base + q;
       const uint64_t b = a >= 2 ? a - 2 : 0, w = b >> 4;
-      if (w != wcur) {
+      if constexpr (PRE) {
+        const bool second = w != wcur;
+        x0 = second ? c1 : c0;
+        x1 = second ? c2 : c1;
+        x2 = second ? c3 : c2;
+      } else if (w != wcur) {
         x0 = seq[w];
         x1 = seq[w + 1];
         x2 = seq[w + 2];
@@ -373,6 +518,10 @@ __global__ __launch_bounds__(256) void k_s1_digit_hist_plain(const uint32_t *__r
       if (++j == per) {
         j = 0;
         base += L;
+        if constexpr (PRE) {
+          c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+          wcur = wnext;
+        }
       }
     }
     q0 += step_q;
@@ -735,6 +884,7 @@ struct S1SegArgs {
   int la_chunks;      // look-ahead limit, in chunks of 256 records
   int direct_marks;   // k_s1_stream: the non-solid marks come from the table (one stored position per key), no second read
   int used_list;      // k_s1_stream: the per-key phases walk a list of the occupied slots instead of the whole table
+  int read_first;     // k_s1_stream: look at the slot with a plain LDS read before trying to claim it
 };
 
 constexpr unsigned long long kSegEmpty = ~0ull;  // never a key: head/tail bits 63 do not occur (max (4<<3)|4)
@@ -1092,20 +1242,21 @@ __global__ __launch_bounds__(256) void k_s1_seg(const uint32_t *__restrict__ ite
 // nothing of k_s1_seg's segment ownership / look-ahead is needed: "two-level bucketed sort" with the second level in LDS.
 // A bucket with more distinct keys than the table holds sets *err -> the host falls back to k_s1_seg (three passes).
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int kStreamThreads = 1024;  // one workgroup per CU: keys + counts + first positions = 96 KB of LDS
-constexpr int kStreamSlots = 8192;
+constexpr int kStreamThreads = 1024;  // one workgroup per CU: 8192 slots of key + count + first position + list entry = 122 KB of LDS
 constexpr uint32_t kStreamEmpty = 0xFFFFFFFFu;  // never a key: head/tail bits 63 do not occur
 
 __global__ void k_bucket_bounds(const uint32_t *__restrict__ items, uint64_t n, int stride, uint64_t *__restrict__ bstart);  // kmsort_emu.hip
 
-template <bool AGG, int UNR>
-__global__ __launch_bounds__(kStreamThreads) void k_s1_stream(const uint32_t *__restrict__ items0, const uint64_t *__restrict__ bounds, S1SegArgs a,
+// NT / LOGS: 1024 threads and 8192 slots = one workgroup per CU (122 KB of LDS); 512 threads and 4096 slots (62 KB) = two per CU:
+// while one of them walks its table (LDS only, a quarter of a bucket's time) the other has loads in flight, at the price of
+// a table that gives up at half as many distinct keys per bucket (s1_stream_half)
+template <bool AGG, int UNR, int NT = kStreamThreads, int LOGS = 13>
+__global__ __launch_bounds__(NT) void k_s1_stream(const uint32_t *__restrict__ items0, const uint64_t *__restrict__ bounds, S1SegArgs a,
                                                              uint32_t bucket_stride, uint32_t *__restrict__ ticket,
                                                              const uint32_t *const *__restrict__ srcs, int n_src) {
   // Multi-GPU: the records of a bucket arrive as n_src sub-ranges, one per sending rank, each rank's records sorted by
   // bucket in an array of its own (srcs[q], bounds[q * (65536 + 1) + bucket]); single GPU: one source, items0.
-  constexpr int NT = kStreamThreads, NSLOT = kStreamSlots, LOGS = 13;
-  static_assert((1 << LOGS) == NSLOT, "table size");
+  constexpr int NSLOT = 1 << LOGS;
   __shared__ uint32_t keys[NSLOT];
   __shared__ uint32_t cnts[NSLOT];
   __shared__ uint32_t fpos[NSLOT];  // position word of the record that created the slot (direct_marks)
@@ -1191,7 +1342,15 @@ __global__ __launch_bounds__(kStreamThreads) void k_s1_stream(const uint32_t *__
         int probes = 0;
         const int probe_limit = a.la_chunks;  // (stream mode: the host passes the probe limit here; tests set it to 0)
         for (; probes < probe_limit; ++probes) {
-          const uint32_t old = atomicCAS(&keys[h], kStreamEmpty, lk);
+          // read_first: most records meet their key already in the table (one key per ~8 records at 60x): a plain LDS read
+          // finds that out without the read-modify-write of a compare-and-swap, which then only the claims of empty slots pay
+          uint32_t old;
+          if (a.read_first) {
+            old = __hip_atomic_load(&keys[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (old == kStreamEmpty) old = atomicCAS(&keys[h], kStreamEmpty, lk);
+          } else {
+            old = atomicCAS(&keys[h], kStreamEmpty, lk);
+          }
           if (old == kStreamEmpty || old == lk) {
             atomicAdd(&cnts[h], 1u);
             if (old == kStreamEmpty) {  // only read back when the count stays 1: then this record is the key's only one
@@ -1815,15 +1974,19 @@ uint64_t s1_extract(mhx_ctx *c, uint32_t k, bool compact) {
             hd.sh[p] = specs.d[p].bit1;
             hd.mk[p] = specs.d[p].mask1;
           }
-#define MHX_PLAIN(NPV)                                                                                                                       \
+#define MHX_PLAIN2(NPV, PREV)                                                                                                                \
   MHX_LAUNCH(c, "s1_digit_hist", (double)s.n_bases / 4,                                                                                      \
-             hipLaunchKernelGGL((k_s1_digit_hist_plain<ITH, NPV>), dim3(fgrid), dim3(256), 0, st, s.words.as<uint32_t>(), s.fixed_len, per, \
+             hipLaunchKernelGGL((k_s1_digit_hist_plain<ITH, NPV, PREV>), dim3(fgrid), dim3(256), 0, st, s.words.as<uint32_t>(), s.fixed_len, per, \
                                 n_items, (int)k, hd, pre_hist, (uint32_t)(stride_items / per), (uint32_t)(stride_items % per)))
-          if (plain && specs.n == 1) MHX_PLAIN(1);
+#define MHX_PLAIN(NPV) MHX_PLAIN2(NPV, false)
+          // s1_digit_hist_preload: window words requested up front (needs at least 8 slots per read)
+          if (plain && specs.n == 2 && per >= 8 && c->opt("s1_digit_hist_preload", 0) != 0) MHX_PLAIN2(2, true);
+          else if (plain && specs.n == 1) MHX_PLAIN(1);
           else if (plain && specs.n == 2) MHX_PLAIN(2);
           else if (plain && specs.n == 3) MHX_PLAIN(3);
           else if (plain && specs.n == 4) MHX_PLAIN(4);
 #undef MHX_PLAIN
+#undef MHX_PLAIN2
           else
             MHX_LAUNCH(c, "s1_digit_hist", (double)s.n_bases / 4,
                        hipLaunchKernelGGL((k_s1_digit_hist<ITH>), dim3(fgrid), dim3(256), 0, st, s.words.as<uint32_t>(), s.fixed_len, per, n_items,
@@ -1836,8 +1999,15 @@ uint64_t s1_extract(mhx_ctx *c, uint32_t k, bool compact) {
         // keys: they need the records grouped, not in input order — so the first pass may place the records of a digit in
         // any order (the later passes are stable with respect to whatever order it leaves).
         const bool any_order = c->opt("s1_gen_any_order", 1) != 0;
-        c->gen_first_pass = [g, any_order](const OnesweepLaunch &l) {
-          if (l.unit_runs && l.wi == 0 && any_order)  // (the digits of this plan lie in the first key word)
+        // s1_gen_blocked: consecutive items per thread (S1GenBlocked) — only where the order inside a digit is free
+        const bool blocked = any_order && per >= 8 && c->opt("s1_gen_blocked", 0) != 0;
+        const S1GenBlocked gb{s.words.as<uint32_t>(), s.fixed_len, per, (int)k, pos_base, rank_tag, (uint32_t)(kSortThreads * 8) / per,
+                              (uint32_t)(kSortThreads * 8) % per};
+        c->gen_first_pass = [g, gb, any_order, blocked](const OnesweepLaunch &l) {
+          if (l.unit_runs && l.wi == 0 && blocked)
+            hipLaunchKernelGGL((k_radix_onesweep_u<3, 8, 3, S1GenBlocked, true, 0>), dim3(l.grid), dim3(kSortThreads), 0, l.stream, gb, l.out, l.n, l.ds, l.nbits,
+                               l.bin_start, l.status, l.ticket, l.err, l.tag, l.xcd_units);
+          else if (l.unit_runs && l.wi == 0 && any_order)  // (the digits of this plan lie in the first key word)
             hipLaunchKernelGGL((k_radix_onesweep_u<3, 8, 3, S1Gen, true, 0>), dim3(l.grid), dim3(kSortThreads), 0, l.stream, g, l.out, l.n, l.ds, l.nbits,
                                l.bin_start, l.status, l.ticket, l.err, l.tag, l.xcd_units);
           else if (l.unit_runs && l.wi == 0)
@@ -1996,7 +2166,9 @@ int s1_process(mhx_ctx *c, uint32_t k, uint32_t m, int want_mercy, uint32_t *buf
     const uint32_t pfx_mask = plan.seg_bits >= 32 ? 0xFFFFFFFFu : ~(0xFFFFFFFFu >> plan.seg_bits);
     const uint32_t eq_mask1 = (kmer_bits > 32 ? ~(0xFFFFFFFFu >> (kmer_bits - 32)) : 0u) | 63u;
     const bool agg_on = agg && mode != 2;
-    const unsigned grid = (unsigned)std::min<uint64_t>(n_work, plan.stream ? 256 : (per == 4 ? 256 * 6 : 256 * 3));
+    // s1_stream_half: two 512-thread workgroups with 4096-slot tables per CU instead of one with 1024 threads and 8192 slots
+    const bool half = plan.stream && c->opt("s1_stream_half", 0) != 0;
+    const unsigned grid = (unsigned)std::min<uint64_t>(n_work, plan.stream ? (half ? 512 : 256) : (per == 4 ? 256 * 6 : 256 * 3));
     // per-workgroup output regions in the spare sort buffer (S*4 >= 12 bytes per record, outputs are 8-byte entries)
     const uint32_t region = (uint32_t)std::min<uint64_t>(n_items * (uint64_t)S * 4 / 8 / grid, 0xFFFFFFF0u);
     uint2 *raw = nullptr;
@@ -2022,7 +2194,8 @@ int s1_process(mhx_ctx *c, uint32_t k, uint32_t m, int want_mercy, uint32_t *buf
     // the stream kernel marks the non-solid occurrences from its table when each of them is its key's only record
     const int direct = plan.stream && mode == 1 && m <= 2 && (mraw || (pos_stride == 0 && solid_bytes)) && c->opt("s1_stream_direct", 1) ? 1 : 0;
     S1SegArgs a{(int)k, m, pfx_mask, eq_mask1, solid_bytes, mode, hist, ctr, raw, seg_cap, counts, mraw, mcap, mcounts, pos_stride, seg_err,
-                plan.stream ? (int)c->opt("s1_stream_probes", 1024) : la, direct, c->opt("s1_stream_used_list", 1) != 0 ? 1 : 0};
+                plan.stream ? (int)c->opt("s1_stream_probes", 1024) : la, direct, c->opt("s1_stream_used_list", 1) != 0 ? 1 : 0,
+                c->opt("s1_stream_read_first", 0) != 0 ? 1 : 0};
     MHX_HIP(hipMemsetAsync(seg_err, 0, 4, st));
     const char *nm = mode == 2 ? "s1_sample" : "s1_groups";
     const double bytes = plan.stream ? (double)n_items * 12 / stride : (double)n_work * T * 12;
@@ -2046,7 +2219,12 @@ int s1_process(mhx_ctx *c, uint32_t k, uint32_t m, int want_mercy, uint32_t *buf
       const int unr = (int)c->opt("s1_stream_unroll", 4);  // 8: measured no better than 4
 #define MHX_STREAM(AGGV, UV) \
   MHX_LAUNCH(c, nm, bytes, hipLaunchKernelGGL((k_s1_stream<AGGV, UV>), dim3(grid), dim3(kStreamThreads), 0, st, items0, bounds, a, stride, ticket, srcs, n_src))
-      if (agg_on) {
+      if (half) {
+        if (agg_on)
+          MHX_LAUNCH(c, nm, bytes, hipLaunchKernelGGL((k_s1_stream<true, 4, 512, 12>), dim3(grid), dim3(512), 0, st, items0, bounds, a, stride, ticket, srcs, n_src));
+        else
+          MHX_LAUNCH(c, nm, bytes, hipLaunchKernelGGL((k_s1_stream<false, 4, 512, 12>), dim3(grid), dim3(512), 0, st, items0, bounds, a, stride, ticket, srcs, n_src));
+      } else if (agg_on) {
         if (unr >= 8) MHX_STREAM(true, 8);
         else if (unr >= 4) MHX_STREAM(true, 4);
         else if (unr >= 2) MHX_STREAM(true, 2);

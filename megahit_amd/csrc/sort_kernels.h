@@ -99,6 +99,16 @@ struct SrcArray {
       if (gi < n) load_rec<S>(in + gi * S, rec[j]);
     }
   }
+  // (interface of k_radix_onesweep_u: the item a thread holds in slot j of a tile, and all records of a unit that are one thread's)
+  template <int NI>
+  __device__ __forceinline__ uint64_t index(uint64_t tile_base, int w, int lane, int j) const {
+    return tile_base + (uint64_t)(w * (kWave * NI) + j * kWave + lane);
+  }
+  template <int NI, int UT>
+  __device__ __forceinline__ void get_unit(uint64_t unit_base, int w, int lane, uint64_t n, Rec<S> (&rec)[UT][NI]) const {
+#pragma unroll
+    for (int t = 0; t < UT; ++t) get<NI>(unit_base + (uint64_t)t * (kSortThreads * NI) + (uint64_t)(w * (kWave * NI) + lane), n, rec[t]);
+  }
 };
 // ... or a generator (s1.hip: S1Gen makes the stage-1 records straight from the packed reads in the first pass)
 
@@ -320,10 +330,9 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_onesweep_u(Src src, uint
   const uint64_t unit = s_unit;
   const uint64_t unit_base = unit * (uint64_t)(kTile * UT);
 
-  // 1. the unit's records -> registers (wave-blocked striped arrangement inside each tile)
+  // 1. the unit's records -> registers (loaded: wave-blocked striped arrangement inside each tile; generated: the source's choice)
   Rec<S> rec[UT][NI];
-#pragma unroll
-  for (int t = 0; t < UT; ++t) src.template get<NI>(unit_base + (uint64_t)t * kTile + (uint64_t)(w * (kWave * NI) + lane), n, rec[t]);
+  src.template get_unit<NI, UT>(unit_base, w, lane, n, rec);
 
   // 2. rank every record among the records of its (tile, wave) with the same digit.  Ranks, later positions, are kept two
   //    per register (16 bits each; 0xFFFF = no record): the unit's records already take 72 registers at 12 bytes
@@ -334,7 +343,7 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_onesweep_u(Src src, uint
     for (int h = 0; h < (NI + 1) / 2; ++h) pk[t][h] = 0xFFFFFFFFu;
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
-      const uint64_t gi = unit_base + (uint64_t)t * kTile + (uint64_t)(w * (kWave * NI) + j * kWave + lane);
+      const uint64_t gi = src.template index<NI>(unit_base + (uint64_t)t * kTile, w, lane, j);  // (which item this is: the source's arrangement)
       const bool valid = gi < n;
       const unsigned d = valid ? rec_digit_w<S, WI>(rec[t][j], ds) : 0u;
       uint32_t rk;

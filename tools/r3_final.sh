@@ -16,5 +16,5 @@ find $O/${TAG}_trace $O/${TAG}_pmc_fetch $O/${TAG}_pmc_write -type f ! -name '*s
 grep -h '^{' $O/${TAG}_trace.log | tail -1 | cut -c1-300
 timeout 220 python bench.py > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err; echo "bench rc=$?"
 cut -c1-1500 $O/${TAG}_bench.json
-timeout 60 python bench.py --force-dist --steps 5 --warmup 2 --no-cpu-baseline --no-e2e > $O/${TAG}_bench_force_dist.json 2> $O/${TAG}_bench_force_dist.err; echo "dist rc=$?"
+timeout 45 python bench.py --force-dist --steps 5 --warmup 2 --no-cpu-baseline --no-e2e > $O/${TAG}_bench_force_dist.json 2> $O/${TAG}_bench_force_dist.err; echo "dist rc=$?"
 cut -c1-400 $O/${TAG}_bench_force_dist.json
