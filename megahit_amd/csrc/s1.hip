@@ -263,8 +263,8 @@ struct S1Gen {
 // The same generator with CONSECUTIVE items per thread (a pass whose records may leave in any order does not care which
 // thread holds which item of the unit): eight consecutive slots of a read share their window words — four words loaded
 // once for the run that starts at the thread's first item and four for the start of the next read, instead of three words
-// per item —, the slot and the read's base offset advance by increments, and there is one division per tile and thread as
-// before.  Needs at least NI slots per read (at most one read boundary inside a thread's items).
+// per item —, the slot and the read's base offset advance by increments, and there is one division per UNIT and thread.
+// Needs at least NI slots per read (at most one read boundary inside a thread's items of a tile).
 struct S1GenBlocked {
   const uint32_t *seq;
   uint32_t L, per;
