@@ -53,12 +53,25 @@ def make_reads(n_reads, rank, world):
 PMC_FILE = "profiles/r03_pmc_traffic.json"
 
 
+def lib_built_from_current_sources():
+    """libmhx.so is at least as new as every kernel source (make's own criterion).  A library REBUILT from the very sources a
+    counter measurement was taken on (same build_id) need not be byte-identical to the measured one; a library OLDER than the
+    sources is a stale build, and the measurement of the sources says nothing about it."""
+    import glob
+    try:
+        so = os.path.getmtime(os.path.join(ROOT, "megahit_amd", "libmhx.so"))
+        src = os.path.join(ROOT, "megahit_amd", "csrc")
+        return all(os.path.getmtime(f) <= so for f in glob.glob(os.path.join(src, "*.hip")) + glob.glob(os.path.join(src, "*.h")))
+    except OSError:
+        return False
+
+
 def pmc_traffic(kernel_name, path=None):
     """HBM bytes per launch of `kernel_name` measured with rocprofv3 PMC passes on THIS workload and THIS build
     (profiles/r03_pmc_traffic.json, produced by tools/gpu_evidence.sh -> tools/pmc_to_json.py with the gfx950
     FETCH_SIZE x2 correction).  Counters cannot be collected from inside the timed run, so the committed measurement is
-    reported — but only when it was taken on the same kernel sources AND the same built library (megahit_amd/buildid.py:
-    sha256 of the sources, sha256 of libmhx.so): otherwise null."""
+    reported — but only when it was taken on the same kernel sources (megahit_amd/buildid.py: sha256 of the sources) and the
+    library that runs is the measured one (sha256 of libmhx.so) or was built from those sources afterwards: otherwise null."""
     path = path or os.path.join(ROOT, PMC_FILE)
     try:
         from megahit_amd.buildid import build_id, lib_id
@@ -66,7 +79,7 @@ def pmc_traffic(kernel_name, path=None):
             doc = json.load(f)
         if doc.get("build_id") != build_id():
             return None, "%s was measured on other kernel sources (build_id %s, running %s)" % (PMC_FILE, doc.get("build_id"), build_id())
-        if doc.get("lib_id") is not None and doc.get("lib_id") != lib_id():
+        if doc.get("lib_id") is not None and doc.get("lib_id") != lib_id() and not lib_built_from_current_sources():
             return None, "%s was measured with another build of libmhx.so (lib_id %s, running %s)" % (PMC_FILE, doc.get("lib_id"), lib_id())
         kernels = doc["kernels"]
     except Exception:

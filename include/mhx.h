@@ -81,7 +81,14 @@ int mhx_set_option(mhx_ctx *, const char *name, long long value);
  *   sort_rank_atomic (0)   1: the passes that load their records rank with one returning LDS atomic per record instead of the
  *                          match-any ballots — only on a device that passes the lane-order probe (sort.hip)
  *   s1_stream_used_list (1) 0: the bucket streaming walks its whole LDS table in the per-key phases instead of the list of
- *                          occupied slots */
+ *                          occupied slots
+ *   s1_gen_blocked (0)     1: the generating first sort pass of stage 1 gives every thread consecutive items and requests the
+ *                          window words of a whole unit up front (S1GenBlocked) instead of one window load per item
+ *   s1_digit_hist_preload (0) 1: the same in the digit-histogram pre-pass
+ *   s1_stream_read_first (0) 1: the bucket streaming reads a slot before it tries to claim it
+ *   s1_stream_half (0)     1: two 512-thread workgroups with 4096-slot tables per CU in the bucket streaming instead of one
+ *                          with 1024 threads and 8192 slots (a table that overflows sends the stage to the tile kernel)
+ * (mhx_tuning.conf of this tree, from the A/B on an MI355X: sort_rank_atomic = 1, s1_gen_blocked = 1.) */
 long long mhx_get_option(mhx_ctx *, const char *name, long long dflt);
 
 /* ---- sequence store (replaces SeqPackage held by each engine:

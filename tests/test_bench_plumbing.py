@@ -7,7 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def test_pmc_traffic_lookup_is_tied_to_the_kernel_sources(tmp_path):
+def test_pmc_traffic_lookup_is_tied_to_the_kernel_sources(tmp_path, monkeypatch):
     """roofline.traffic comes from a committed PMC measurement only if that measurement was taken on the very kernel
     sources that are running (megahit_amd/buildid.py)"""
     import bench
@@ -16,7 +16,8 @@ def test_pmc_traffic_lookup_is_tied_to_the_kernel_sources(tmp_path):
            "kernels": {"k_radix_onesweep<3, 8, 3, SrcArray<3> >": {"hbm_bytes": 40000000000},
                        "k_radix_onesweep<3, 8, 3, S1Gen>": {"hbm_bytes": 25000000000},
                        "k_radix_onesweep<2, 8, 2, SrcArray<2> >": {"hbm_bytes": 2000000000},
-                       "k_s1_stream<true, 4>": {"hbm_bytes": 21000000000}}}
+                       "k_s1_stream<false, 4, 1024, 13>": {"hbm_bytes": 250000000},
+                       "k_s1_stream<true, 4, 1024, 13>": {"hbm_bytes": 21000000000}}}
     p = str(tmp_path / "pmc.json")
     with open(p, "w") as f:
         json.dump(doc, f)
@@ -25,9 +26,12 @@ def test_pmc_traffic_lookup_is_tied_to_the_kernel_sources(tmp_path):
     assert bench.pmc_traffic("radix_scatter_12B_gen", p)[0] == 25000000000
     assert bench.pmc_traffic("radix_scatter_8B", p)[0] == 2000000000
     assert bench.pmc_traffic("s1_groups", p)[0] == 21000000000
-    doc["lib_id"] = "1" * 16
+    doc["lib_id"] = "1" * 16  # another binary: accepted only if it was built from the current sources (not older than any of them)
     with open(p, "w") as f:
         json.dump(doc, f)
+    monkeypatch.setattr(bench, "lib_built_from_current_sources", lambda: True)
+    assert bench.pmc_traffic("radix_scatter_12B", p)[0] == 40000000000
+    monkeypatch.setattr(bench, "lib_built_from_current_sources", lambda: False)
     traffic, why = bench.pmc_traffic("radix_scatter_12B", p)
     assert traffic is None and "another build of libmhx.so" in why
     doc["build_id"] = "0" * 16
