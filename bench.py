@@ -87,7 +87,7 @@ def pmc_traffic(kernel_name, path=None):
     # profile name -> kernel symbol prefix
     # (k_s1_stream<false, ...> is the 1/64 sampling launch "s1_sample"; the group-by itself emits the aggregated items: <true, ...>)
     table = {"s1_groups": ("k_s1_stream<true", "k_s1_stream<", "k_s1_seg<", "k_tile_groups<3"), "count_groups": ("k_count_seg<",),
-             "s1_extract": ("k_s1_extract_fast<", "k_s1_extract_fixed<", "k_s1_extract<"), "s1_digit_hist": ("k_s1_extract_fast<4, false",),
+             "s1_extract": ("k_s1_extract_fast<", "k_s1_extract_fixed<", "k_s1_extract<"), "s1_digit_hist": ("k_s1_digit_hist", "k_s1_extract_fast<4, false"),
              "count_extract": ("k_count_extract<",),
              "radix_scatter_12B_gen": ("k_radix_onesweep_u<3, 8, 3, S1Gen", "k_radix_onesweep<3, 8, 3, S1Gen"),
              "s1_sample": ("k_s1_stream<false",)}
