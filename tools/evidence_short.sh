@@ -1,7 +1,7 @@
 #!/bin/bash
 # Trimmed evidence set for a short GPU budget (one gpurun call): rocprofv3 kernel stats, the two PMC passes of the same command,
 # the bench line (default flags: CPU baseline sample + end-to-end block) quoting the PMC traffic of this very build, the
-# multi-GPU code path with one rank.     gpurun --timeout 520 -- 'bash tools/r3_final.sh r03'
+# multi-GPU code path with one rank.     gpurun --timeout 520 -- 'bash tools/evidence_short.sh r03'
 TAG=${1:-r03}
 R=$(pwd); O=$R/gpurun_out; mkdir -p $O; export TMPDIR=/tmp
 cd /tmp

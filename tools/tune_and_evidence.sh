@@ -1,6 +1,6 @@
 #!/bin/bash
 # One gpurun call: tests of the knob-selected code paths, greedy tuning on the box -> megahit_amd/mhx_tuning.conf, then the
-# evidence set (tools/r3_final.sh) under the tuned defaults that will ship.
+# evidence set (tools/evidence_short.sh) under the tuned defaults that will ship.
 R=$(pwd); O=$R/gpurun_out; mkdir -p $O; export TMPDIR=/tmp
 timeout 150 python -m pytest tests/test_gpu_round3_knobs.py tests/test_gpu_tuning.py tests/test_gpu_sort_unit_runs.py tests/test_gpu_sdbg.py -m gpu -x -q > $O/e4_tests.log 2>&1; T=$?
 echo "tests rc=$T"; grep -E "passed|failed|error" $O/e4_tests.log | tail -3
@@ -14,4 +14,4 @@ for l in open("gpurun_out/e4_ab.jsonl"):
 P
 tail -1 $O/e4_ab.err
 [ -f $O/mhx_tuning.conf ] && cp $O/mhx_tuning.conf megahit_amd/mhx_tuning.conf && cat megahit_amd/mhx_tuning.conf
-bash tools/r3_final.sh r03
+bash tools/evidence_short.sh r03
