@@ -492,7 +492,14 @@ def main():
                 "copy_kernel_GBs": copy_gbs, "frac_of_copy_kernel": round(achieved / copy_gbs, 4) if copy_gbs else None,
                 "launches_per_step": ks["launches"] // max(1, args.steps), "avg_launch_ms": round(per_launch_ms, 4),
                 "algo_bytes_per_launch": per_launch_bytes,
-                "kernel_ms_per_step": {k2: round(v["ms"] / args.steps, 3) for k2, v in sorted(stats.items(), key=lambda kv: -kv[1]["ms"])}}
+                "kernel_ms_per_step": {k2: round(v["ms"] / args.steps, 3) for k2, v in sorted(stats.items(), key=lambda kv: -kv[1]["ms"])},
+                # the same figure for the three kernels with the largest time per step (they are within a few per cent of each
+                # other, and which of them leads changes from box to box): algorithmic GB/s of one launch and its fraction of the peak
+                "top_kernels": [{"kernel": k2, "ms_per_step": round(v["ms"] / args.steps, 3), "launches_per_step": v["launches"] // max(1, args.steps),
+                                 "achieved": round(v["bytes"] / v["ms"] / 1e6, 1) if v["ms"] > 0 else None,
+                                 "frac": round(v["bytes"] / v["ms"] / 1e6 / HBM_PEAK_GBS, 4) if v["ms"] > 0 else None,
+                                 "traffic": pmc_traffic(k2)[0] if n_reads == 10000000 and args.engine == "read2sdbg" and not use_dist else None}
+                                for k2, v in sorted(stats.items(), key=lambda kv: -kv[1]["ms"])[:3]]}
         metric = {"read2sdbg": "M (k+1)-mer edges sorted+counted/sec, sdbg_build k=21",
                   "count": "M (k+1)-mer edges sorted+counted/sec, count k=21 (beside the headline metric)",
                   "seq2sdbg": "M input (k+1)-mer edges/sec, seq2sdbg k=21 (beside the headline metric)"}[args.engine]
