@@ -94,7 +94,7 @@ def blocked_unit(seq, L, per, k, unit_base, n):
     return out
 
 
-@pytest.mark.parametrize("L,k,n_reads", [(100, 21, 150), (30, 21, 700), (60, 25, 90), (50, 29, 40), (36, 29, 600), (33, 29, 900), (150, 22, 20), (40, 14, 8)])
+@pytest.mark.parametrize("L,k,n_reads", [(100, 21, 150), (30, 21, 700), (60, 25, 90), (50, 29, 40), (36, 29, 600), (33, 29, 900), (150, 22, 20), (40, 15, 8)])
 def test_blocked_generator_makes_the_oracles_items(L, k, n_reads):
     rng = np.random.default_rng(L * 100 + k)
     reads = [rng.integers(0, 4, size=L, dtype=np.uint8) for _ in range(n_reads)]
