@@ -9,8 +9,8 @@ than the steps.
 
 --write-tuning FILE stores the winner as the installation's tuned defaults (libmhx reads mhx_tuning.conf beside libmhx.so
 at mhx_create; include/mhx.h: mhx_get_option).  Only configurations whose outputs matched the reference's digest qualify.
---greedy KNOBS: starting from the first configuration, each knob of the list is switched on in turn and kept when the step
-gets faster by --min-gain-ms.
+--greedy KNOBS: starting from the first configuration, each knob of the list is switched on in turn ("name", or "name=value" for
+another value than 1) and kept when the step gets faster by --min-gain-ms.
 """
 import argparse
 import json
@@ -89,16 +89,19 @@ def main():
     pick, report = None, []
     if args.greedy:
         cur = parse(args.configs[0])
-        for name in args.greedy.split():
+        trials = []  # (knob, value to try): "name" = switch it on, "name=8" = that value (its starting value belongs in the first configuration)
+        for item in args.greedy.split():
+            name, _, val = item.partition("=")
+            trials.append((name, int(val) if val else 1))
             cur.setdefault(name, 0)
         base = measure(cur, note="greedy: start")
         t_cur, ok = base["ms_per_step"], base["parity_checked"] is True
         report.append((fmt(cur), t_cur, ok))
         if ok:
-            for name in args.greedy.split():
+            for name, val in trials:
                 trial = dict(cur)
-                trial[name] = 1
-                ln = measure(trial, note="greedy: try %s" % name)
+                trial[name] = val
+                ln = measure(trial, note="greedy: try %s=%d" % (name, val))
                 good = ln["parity_checked"] is True and ln["ms_per_step"] < t_cur - args.min_gain_ms
                 report.append((fmt(trial), ln["ms_per_step"], ln["parity_checked"] is True))
                 if good:
