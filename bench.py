@@ -50,7 +50,14 @@ def make_reads(n_reads, rank, world):
     return np.concatenate(chunks)
 
 
-PMC_FILE = "profiles/r03_pmc_traffic.json"
+def _latest_pmc_file():
+    """the counter measurement of the latest round under profiles/ (rNN_pmc_traffic.json; tools/evidence_short.sh writes it)"""
+    import glob
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_traffic.json")))
+    return os.path.relpath(found[-1], ROOT) if found else "profiles/r03_pmc_traffic.json"
+
+
+PMC_FILE = _latest_pmc_file()
 
 
 def lib_built_from_current_sources():
