@@ -57,15 +57,22 @@ int mhx_synchronize(mhx_ctx *);
  *   s1_seg_bits (0)   force the prefix width of the partial stage-1 sort (0 = chosen from the item count)
  *   s1_seg_la (3)     look-ahead chunks of the segment group-by before a tile gives up (-> classic path)
  *   s1_seg_per (8)    records per thread and tile of the segment group-by (4 or 8)
- *   s1_stream (1)     0: never the two-pass bucket-streaming variant (k_s1_stream); s1_stream_max (40000): largest
- *                     average lv1 bucket (records) it is chosen for
+ *   s1_stream (1)     0: never the bucket-streaming group-by (k_s1_stream).  Its sort prefix follows the job's density
+ *                     (records per lv1 bucket where the group-by runs): s1_stream_max (40000) records per streamed
+ *                     bucket at most — 16 prefix bits in two passes up to that, 2^s sub-rounds per bucket up to
+ *                     2^s1_stream_sub_max (1) times that, 17..24 bits in three passes beyond; s1_stream_bits (0) /
+ *                     s1_stream_sub0 (-1) force the prefix width / the sub-rounds (tests); s1_stream_fill: slots a
+ *                     round may claim before the bucket is split (7/8 of the table); s1_stream_probes (1024)
+ *   s1_filter_in_gen (1)  0: a bucket filter (memory plan) is applied to stage 1 by extraction batches + a keep/drop
+ *                     split even where the generating first sort pass could leave the dropped buckets out itself
+ *   s1_pos_bits (0)   width of the position word of compact stage-1 records (0 = 32); the position bits above it ride
+ *                     as a tag in the key words (s1.hip s1_pos_tag).  Tests use narrow words to exercise the tags.
  *   s1_stream_direct (1)  0: k_s1_stream always reads a bucket twice (second time to mark); 1: when the marks are those of
  *                     the non-solid occurrences and m <= 2 they come from the table and the second read is skipped
  *   count_seg (1), count_seg_bits (0), count_seg_la (3)  the same for count (k_count_seg)
  *   count_extract_fixed (1)  0: count's items always come from the wave-per-read kernel (no fused digit histograms)
  *   dist_sparse_marks (0)  multi-GPU stage 1 emits MHX_ROUTE_S1_MARKS records instead of marking a bitmap of the
- *                     global read set (set by mhx_dist_setup; the torch.distributed path of megahit_amd/dist.py
- *                     still reduces the bitmap)
+ *                     global read set (set by mhx_dist_setup)
  *   kmsort_emu_legacy (0)  1: read2sdbg --need_mercy replays kmsort with one thread per lv1 bucket on whole records
  *                     (round 1) instead of one wave per bucket on tags + indices (kmsort_emu.hip); same output
  *   sort_xcd_units (1)  0: the chained-scan scatter hands its units out from one ticket counter instead of one per
@@ -78,8 +85,10 @@ int mhx_set_option(mhx_ctx *, const char *name, long long value);
  * mhx_create) — else `dflt`.  Knobs only ever choose between code paths with identical results.  Round 3:
  *   sort_unit_runs (1)     0: the chained-scan pass ranks, stages and writes its unit tile by tile (k_radix_onesweep) instead of
  *                          unit-wide runs (k_radix_onesweep_u)
- *   sort_rank_atomic (0)   1: the passes that load their records rank with one returning LDS atomic per record instead of the
- *                          match-any ballots — only on a device that passes the lane-order probe (sort.hip)
+ *   sort_rank_uniform (1)  0: every loading pass ranks with the match-any ballots.  1: a pass whose plan declares the bits
+ *                          sorted before it (the prefix plans of stage 1) ranks with one LDS atomic per record wherever all
+ *                          records of a wavefront instruction agree on those bits — an order that cannot matter there — and
+ *                          with the ballots elsewhere (sort_kernels.h RANK 2); correct on any hardware
  *   s1_stream_used_list (1) 0: the bucket streaming walks its whole LDS table in the per-key phases instead of the list of
  *                          occupied slots
  *   s1_gen_blocked (0)     1: the generating first sort pass of stage 1 gives every thread consecutive items and requests the
@@ -87,9 +96,14 @@ int mhx_set_option(mhx_ctx *, const char *name, long long value);
  *   s1_digit_hist_preload (0) 1: the same in the digit-histogram pre-pass
  *   s1_stream_read_first (0) 1: the bucket streaming reads a slot before it tries to claim it
  *   s1_stream_half (0)     1: two 512-thread workgroups with 4096-slot tables per CU in the bucket streaming instead of one
- *                          with 1024 threads and 8192 slots (a table that overflows sends the stage to the tile kernel)
- * (mhx_tuning.conf of this tree, from the A/B on an MI355X: sort_rank_atomic = 1, s1_gen_blocked = 1.) */
+ *                          with 1024 threads and 8192 slots (a bucket whose keys overflow a table is split inside the kernel)
+ *   s1_stream_prefetch (0) 1: the bucket streaming has the record loads of trip i + 1 in flight while it inserts trip i, and
+ *                          (s1_stream_next_bucket, 1) fetches the next bucket's ticket and bounds during the current bucket
+ * (mhx_tuning.conf of this tree: s1_gen_blocked = 1.) */
 long long mhx_get_option(mhx_ctx *, const char *name, long long dflt);
+/* What the last stage 1 of this handle ran as: "stream p16 sub0 2 passes (20345 records per lv1 bucket)" / "seg p24 3 passes" /
+ * "full sort 6 passes".  The string lives until the next stage 1 of the handle; "" before the first. */
+const char *mhx_last_s1_plan(const mhx_ctx *);
 
 /* ---- sequence store (replaces SeqPackage held by each engine:
  *      kmer_counter.h:76, read_to_sdbg.h:47-51, seq_to_sdbg.h:79) ---- */
@@ -275,7 +289,7 @@ int mhx_sort_records(mhx_ctx *, uint32_t *host_items, uint64_t n, uint32_t key_w
 /* ---- multi-GPU: one handle per GPU/process.  The 65536 lv1 buckets are split into
  * contiguous owner ranges; every rank extracts the items of ITS reads, partitions them by owner
  * (one stable multisplit pass), the caller moves them with an all-to-all on its own communication
- * backend (RCCL via torch.distributed in megahit_amd/dist.py), and every rank sorts + reduces the
+ * backend (or lets mhx_comm / mhx_dist_* below do it over RCCL), and every rank sorts + reduces the
  * buckets it owns — the reference's OffsetFiller::IsHandling bucket filter (base_engine.h:106-108)
  * turned into an exchange.  All three sub-programs are supported (BASELINE configs[2..4]). ---- */
 int mhx_set_partition(mhx_ctx *, int my_part, int n_parts, const uint32_t *bucket_begin /* n_parts+1 */);
@@ -395,6 +409,10 @@ int mhx_dist_seq2sdbg(mhx_ctx *, mhx_comm *, uint32_t k, mhx_sdbg_result *out);
  * all reads.  Works with the single-GPU calls and with mhx_dist_extract. */
 uint64_t mhx_device_free_bytes(mhx_ctx *);  /* free HBM on the handle's device right now (workspaces of this handle included in "used") */
 int mhx_bucket_histogram(mhx_ctx *, int stage /* enum mhx_stage */, uint32_t k, uint32_t min_count, uint64_t *hist /* 65536 */);
+/* Device bytes a bucket-range pass of `stage` over n_items kept items needs for its items (sort buffers, staging, status
+ * words), the stage's fixed state aside — for the sequences loaded now (stage 1 on fixed-length reads makes its records in
+ * the first sort pass and needs two 12-byte buffers; the general path three item buffers).  0 on error. */
+uint64_t mhx_stage_pass_bytes(mhx_ctx *, int stage, uint32_t k, uint32_t min_count, uint64_t n_items);
 int mhx_set_bucket_filter(mhx_ctx *, const uint8_t *keep, uint64_t expected_items, uint64_t batch_bytes, int accumulate);
 
 /* ---- measurement ---- */

@@ -82,11 +82,14 @@ def digest_edges(prefix):
     return h.hexdigest()
 
 
-def digest_sdbg(prefix):
+def digest_sdbg(prefix, bucket_lo=0, bucket_hi=None):
+    """md5 over the SdBG's buckets in ascending id order; with bucket_lo/bucket_hi only the buckets in [lo, hi)."""
     hdr, buckets = canonical_sdbg(prefix)
     h = hashlib.md5()
     h.update(("k%d w%d|" % (hdr["k"], hdr["words_per_tip_label"])).encode())
     for bid, ni, nt, nl, b in buckets:
+        if bid < bucket_lo or (bucket_hi is not None and bid >= bucket_hi):
+            continue
         h.update(np.array([bid, ni, nt, nl], dtype=np.uint64).tobytes())
         h.update(b)
     return h.hexdigest()

@@ -526,13 +526,6 @@ mhx_ctx *mhx_create(int device) {
       if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->n_cus = prop.multiProcessorCount;
     }
     load_tuning(c);
-    // ranking inside the radix scatter: ballot match-any (default, order-independent by construction);
-    // MHX_SORT_RANK=atomic opts into one returning LDS atomic per record, used only if the device passes
-    // the lane-order probe (measured on MI355X: probe passes, gain < 2 %, so it is not the default)
-    const char *rk = getenv("MHX_SORT_RANK");
-    if (rk && !strcmp(rk, "atomic")) c->lds_atomic_ordered = mhx::probe_lds_atomic_order(c);
-    if (getenv("MHX_VERBOSE")) fprintf(stderr, "[mhx] device %d: LDS atomic lane order %s -> %s ranking\n", device,
-                                       c->lds_atomic_ordered ? "verified" : "not used", c->lds_atomic_ordered ? "atomic" : "ballot");
     return c;
   } catch (const std::exception &e) {
     mhx::set_error("%s", e.what());
@@ -573,6 +566,13 @@ int mhx_reset(mhx_ctx *c) {
     c->agg_n = 0;
     c->n_route = 0;
     c->pre_hist_buf = nullptr;
+    // (whatever a failed request left half-way: a deferred first pass, a filter handed to an extraction)
+    c->gen_first_pass = nullptr;
+    c->gen_buf = nullptr;
+    c->gen_n = c->gen_slots = 0;
+    c->s1_defer_items = c->s2_filter_in_extract = c->s1_filter_in_gen = false;
+    c->s1_density = 0;
+    c->filter_kept = 0;
     c->filter_on = c->accumulate = false;
     c->filter_expected = c->filter_batch_bytes = 0;
     c->global_marks_inverted = false;
@@ -611,6 +611,8 @@ void mhx_destroy(mhx_ctx *c) {
 }
 
 int mhx_synchronize(mhx_ctx *c) { MHX_TRY(MHX_HIP(hipStreamSynchronize(c->stream))) }
+
+extern "C" const char *mhx_last_s1_plan(const mhx_ctx *c) { return c ? c->last_s1_plan.c_str() : ""; }
 
 long long mhx_ctx::opt(const char *name, long long dflt) const {
   auto it = options.find(name);
@@ -1013,6 +1015,32 @@ uint64_t mhx_device_free_bytes(mhx_ctx *c) {
   if (hipSetDevice(c->device) != hipSuccess || hipMemGetInfo(&free_b, &total_b) != hipSuccess) return 0;
   return (uint64_t)free_b;
 }
+uint64_t mhx_stage_pass_bytes(mhx_ctx *c, int stage, uint32_t k, uint32_t min_count, uint64_t n_items) {
+  // what a pass over n_items (kept) items of `stage` holds on the device besides the stage's fixed state
+  try {
+    (void)min_count;
+    if (stage == MHX_STAGE_S1 && c->seqs.n_seqs) {
+      const bool was = c->filter_on;  // (the question is about a filtered pass)
+      const uint64_t exp = c->filter_expected;
+      c->filter_on = true;
+      c->filter_expected = n_items;
+      const bool gen = mhx::s1_filter_in_gen_applies(c, k);
+      c->filter_on = was;
+      c->filter_expected = exp;
+      // the generating first pass: two 12-byte record buffers, nothing staged, nothing split; its status words walk ALL item slots
+      if (gen) return n_items * 24 + n_items / 2 + (c->seqs.n_bases + 4 * c->seqs.n_seqs) / 3;
+      return n_items * (3 * (uint64_t)mhx::s1_stride(k, mhx::s1_compact(c, k, 0)) * 4 + 1);
+    }
+    uint64_t ib = 16;
+    if (stage == MHX_STAGE_S1_MERCY) ib = (uint64_t)mhx::s1_stride(k, false) * 4;
+    else if (stage == MHX_STAGE_COUNT) ib = (uint64_t)mhx::count_stride(k) * 4;
+    else if (stage == MHX_STAGE_SEQ2SDBG) ib = (uint64_t)mhx::seq2sdbg_stride(k) * 4;
+    else if (stage == MHX_STAGE_S2) ib = (uint64_t)mhx::s2_stride(k) * 4;
+    return n_items * (3 * ib + 1);  // 2 sort buffers + the filtered copy (+ status words)
+  } catch (...) {
+    return 0;
+  }
+}
 int mhx_bucket_histogram(mhx_ctx *c, int stage, uint32_t k, uint32_t min_count, uint64_t *hist) {
   MHX_TRY({
     MHX_HIP(hipSetDevice(c->device));
@@ -1037,12 +1065,23 @@ int mhx_set_bucket_filter(mhx_ctx *c, const uint8_t *keep, uint64_t expected_ite
       return 0;
     }
     std::vector<uint8_t> lut(MHX_NUM_BUCKETS);
-    for (int b = 0; b < MHX_NUM_BUCKETS; ++b) lut[b] = keep[b] ? 0 : 1;  // owner 0 = keep, 1 = drop (partition_by_owner)
+    std::vector<uint32_t> bits(MHX_NUM_BUCKETS / 32, 0);  // the same as a bitmap (bit b of word b / 32): the generating pass of stage 1 reads it
+    uint32_t kept = 0;
+    for (int b = 0; b < MHX_NUM_BUCKETS; ++b) {
+      lut[b] = keep[b] ? 0 : 1;  // owner 0 = keep, 1 = drop (partition_by_owner)
+      if (keep[b]) {
+        bits[b >> 5] |= 1u << (b & 31);
+        ++kept;
+      }
+    }
     mhx::DevBuf &d = c->ws("filter_lut", MHX_NUM_BUCKETS);
+    mhx::DevBuf &db = c->ws("filter_bits", MHX_NUM_BUCKETS / 8);
     MHX_HIP(hipMemcpyAsync(d.p, lut.data(), MHX_NUM_BUCKETS, hipMemcpyHostToDevice, c->stream));
+    MHX_HIP(hipMemcpyAsync(db.p, bits.data(), MHX_NUM_BUCKETS / 8, hipMemcpyHostToDevice, c->stream));
     MHX_HIP(hipStreamSynchronize(c->stream));
     c->filter_on = true;
     c->filter_expected = expected_items;
+    c->filter_kept = kept;
   })
 }
 

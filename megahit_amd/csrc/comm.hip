@@ -315,13 +315,14 @@ static uint64_t exchange_stage(mhx_ctx *c, mhx_comm *cm, int stage, uint32_t k, 
   move_items(c, cm, it, counts, &n);
   return n;
 }
-__global__ void k_bucket_bounds(const uint32_t *__restrict__ items, uint64_t n, int stride, uint64_t *__restrict__ bstart);  // kmsort_emu.hip
+__global__ void k_bucket_bounds(const uint32_t *__restrict__ items, uint64_t n, int stride, uint64_t *__restrict__ bstart, int pbits);  // kmsort_emu.hip
 
 // Stage 1 without the owner multisplit (no mercy candidates, 12-byte records, the bucket-streaming plan): every rank runs
-// the SAME two LSD passes as a single GPU does — they order its records by lv1 bucket, so the records of each owner's
-// contiguous bucket range are contiguous already — sends those slices as they are, keeps its own slice in place, and
-// the owner's group-by kernel reads a bucket as one sub-range per sender (k_s1_stream's sources) instead of sorting the
-// received records again.  Replaces: owner histogram + owner scatter + a second histogram + two more passes over the
+// the SAME LSD passes as a single GPU does — two over the 16 bits of the lv1 bucket at 10 M reads per GPU, three over up to
+// 24 prefix bits when the job's buckets are larger (the plan follows the density the ranks agreed on, mhx_ctx::s1_density) —
+// they order its records by lv1 bucket, so the records of each owner's contiguous bucket range are contiguous already —
+// sends those slices as they are, keeps its own slice in place, and the owner's group-by kernel reads a bucket of the
+// plan's prefix as one sub-range per sender (k_s1_stream's sources) instead of sorting the received records again.  Replaces: owner histogram + owner scatter + a second histogram + two more passes over the
 // received records (round 2: 91 ms against 53 ms for a single rank).  Returns false (nothing exchanged yet, the extracted
 // items are in ws "items_a") when the plan does not apply on every rank.
 static bool dist_s1_presorted(mhx_ctx *c, mhx_comm *cm, uint32_t k, uint32_t m, const StageItems &it, mhx_s1_result *r1) {
@@ -332,18 +333,13 @@ static bool dist_s1_presorted(mhx_ctx *c, mhx_comm *cm, uint32_t k, uint32_t m, 
   hipStream_t st = c->stream;
   uint32_t *a = c->work["items_a"].as<uint32_t>();
   uint32_t *b = c->ws("items_b", it.n * 12 + 64).as<uint32_t>();
-  if (c->gen_first_pass && c->pre_hist_sig != passes_signature(make_passes(2, 48, 64))) {
-    // deferred items, but this rank's own plan was not the two-pass one the ranks agreed on: materialise them the plain way
-    c->gen_first_pass = nullptr;
-    const StageItems again = extract_stage(c, MHX_STAGE_S1, k, m);
-    if (again.n != it.n) throw Error("dist_s1_presorted: item count changed");
-    a = c->work["items_a"].as<uint32_t>();
-  }
-  uint32_t *sorted = it.n ? s1_presort(c, k, a, b, it.n) : a;
+  // (deferred items: the histograms taken at extraction belong to the plan of the agreed density, the one s1_presort makes)
+  int pbits = 16;
+  uint32_t *sorted = s1_presort(c, k, a, b, it.n, &pbits);
   uint64_t *d_bounds = c->ws("dist_bounds", (MHX_NUM_BUCKETS + 2) * 8).as<uint64_t>();
   std::vector<uint64_t> bounds(MHX_NUM_BUCKETS + 1, 0);
   if (it.n) {
-    hipLaunchKernelGGL(k_bucket_bounds, dim3(MHX_NUM_BUCKETS / 256 + 1), dim3(256), 0, st, sorted, it.n, 3, d_bounds);
+    hipLaunchKernelGGL(k_bucket_bounds, dim3(MHX_NUM_BUCKETS / 256 + 1), dim3(256), 0, st, sorted, it.n, 3, d_bounds, 16);
     MHX_HIP(hipMemcpyAsync(bounds.data(), d_bounds, (MHX_NUM_BUCKETS + 1) * 8, hipMemcpyDeviceToHost, st));
     MHX_HIP(hipStreamSynchronize(st));
   }
@@ -359,6 +355,7 @@ static bool dist_s1_presorted(mhx_ctx *c, mhx_comm *cm, uint32_t k, uint32_t m, 
   cm->all_to_all_v(sorted, counts, recv, rc, 12, true);
   S1Sources src;
   src.n = n;
+  src.pbits = pbits;
   uint64_t at = 0;
   for (int p = 0; p < n; ++p) {
     if (p == rank) src.ptr.push_back(sorted + bounds[c->part_begin[rank]] * 3);
@@ -641,14 +638,22 @@ int mhx_dist_read2sdbg(mhx_ctx *c, mhx_comm *cm, uint32_t k, uint32_t min_count,
       const int st1 = need_mercy ? MHX_STAGE_S1_MERCY : MHX_STAGE_S1;
       const mhx::DistPasses dp = mhx::plan_dist_passes(c, cm, st1, k, min_count, (size_t)mhx::s1_stride(k, mhx::s1_compact(c, k, need_mercy)) * 4);
       uint64_t n_items_all = 0;
+      {  // the records per lv1 bucket of the whole job, agreed on by the ranks: every rank makes the same stage-1 sort plan from it
+        const mhx::SeqSet &sq = c->seqs;
+        const uint64_t local = sq.fixed_len >= k + 1 ? sq.n_seqs * (uint64_t)(sq.fixed_len - k + 4) : sq.n_bases + 4 * sq.n_seqs;
+        std::vector<uint64_t> mx{local};
+        cm->all_reduce(mx, true);
+        c->s1_density = std::max(1.0, (double)mx[0] * (double)cm->n / (double)MHX_NUM_BUCKETS);
+      }
       for (int pass = 0; pass < dp.n; ++pass) {
         mhx::set_pass(c, dp, pass, true);
         mhx_s1_result rp{};
         bool done = false;
         if (!need_mercy) {
-          // (the pre-sort's first pass may make the records itself: then "items_a" holds nothing yet — s1.hip, S1Gen)
+          // (the pre-sort's first pass may make the records itself — and drop those of the buckets a pass leaves out: then
+          // "items_a" holds nothing yet — s1.hip, S1GenT)
           c->gen_first_pass = nullptr;
-          c->s1_defer_items = !c->filter_on && c->opt("dist_presort", 1);
+          c->s1_defer_items = c->opt("dist_presort", 1) != 0;
           mhx::StageItems it = mhx::extract_stage(c, MHX_STAGE_S1, k, min_count);
           c->s1_defer_items = false;
           done = mhx::dist_s1_presorted(c, cm, k, min_count, it, &rp);
@@ -677,6 +682,7 @@ int mhx_dist_read2sdbg(mhx_ctx *c, mhx_comm *cm, uint32_t k, uint32_t min_count,
         r1 = rp;
       }
       mhx::clear_pass(c, dp);
+      c->s1_density = 0;
       r1.n_items = n_items_all;
       // the marks of the NON-solid (k+1)-mer occurrences of the owned buckets -> the ranks that hold those reads, which
       // derive is_solid = "a (k+1)-mer starts here and it is not marked" for their reads

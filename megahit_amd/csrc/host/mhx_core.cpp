@@ -340,7 +340,10 @@ std::vector<BucketRange> plan_ranges(mhx_ctx *c, int stage, uint32_t k, uint32_t
     const double avail = free_bytes * 0.8 - fixed_bytes;
     if (avail <= 0) fatal("not enough free device memory for the fixed state of this stage (%.1f GB free, %.1f GB needed)", free_bytes / 1e9,
                           fixed_bytes / 1e9);
-    const double fit = avail / (3.0 * (double)item_bytes + 1.0);  // 2 sort buffers + filtered copy (+ status words)
+    // 2 sort buffers + filtered copy (+ status words); the library knows better where a stage has a leaner path
+    const uint64_t probe = 1ull << 30, lib_bytes = mhx_stage_pass_bytes(c, stage, k, m, probe);
+    const double per_item = lib_bytes ? (double)lib_bytes / (double)probe : 3.0 * (double)item_bytes + 1.0;
+    const double fit = avail / per_item;
     if (items_upper_bound <= fit) return {{0, MHX_NUM_BUCKETS, 0}};
     max_items = (uint64_t)fit;
   }

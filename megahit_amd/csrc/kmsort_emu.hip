@@ -845,13 +845,14 @@ static void emu_launch_classes(mhx_ctx *c, const uint32_t *grouped, uint32_t *ot
   if (ovf) throw Error("kmsort_exact: segment stack overflow");
 }
 
-__global__ void k_bucket_bounds(const uint32_t *__restrict__ items, uint64_t n, int stride, uint64_t *__restrict__ bstart) {
-  const uint32_t bk = blockIdx.x * blockDim.x + threadIdx.x;  // first record whose bucket >= bk, bk = 0..65536
-  if (bk > MHX_NUM_BUCKETS) return;
+// bstart[b] = first record whose top `pbits` key bits are >= b, b = 0 .. 2^pbits (records sorted on those bits; 16 = lv1 buckets)
+__global__ void k_bucket_bounds(const uint32_t *__restrict__ items, uint64_t n, int stride, uint64_t *__restrict__ bstart, int pbits) {
+  const uint32_t bk = blockIdx.x * blockDim.x + threadIdx.x;
+  if (bk > (1u << pbits)) return;
   uint64_t lo = 0, hi = n;
   while (lo < hi) {
     const uint64_t mid = (lo + hi) >> 1;
-    if ((items[mid * stride] >> 16) < bk) lo = mid + 1;
+    if ((items[mid * stride] >> (32 - pbits)) < bk) lo = mid + 1;
     else hi = mid;
   }
   bstart[bk] = lo;
@@ -867,7 +868,7 @@ uint32_t *kmsort_exact(mhx_ctx *c, uint32_t *buf_a, uint32_t *buf_b, uint64_t n,
   // 2. bucket boundaries
   uint64_t *bstart = c->ws("emu_bstart", (MHX_NUM_BUCKETS + 2) * 8).as<uint64_t>();
   MHX_LAUNCH(c, "bucket_bounds", (double)MHX_NUM_BUCKETS * 8 * 30,
-             hipLaunchKernelGGL(k_bucket_bounds, dim3((MHX_NUM_BUCKETS + 1 + 255) / 256), dim3(256), 0, st, grouped, n, S, bstart));
+             hipLaunchKernelGGL(k_bucket_bounds, dim3((MHX_NUM_BUCKETS + 1 + 255) / 256), dim3(256), 0, st, grouped, n, S, bstart, 16));
   // 3. replay kmsort: one wave per bucket on tags + indices, gathered into the spare buffer
   if (!c->opt("kmsort_emu_legacy", 0)) {
     uint32_t *other = grouped == buf_a ? buf_b : buf_a;

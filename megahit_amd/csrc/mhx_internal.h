@@ -79,10 +79,6 @@ struct mhx_ctx {
   int my_part = 0, n_parts = 1;
   std::vector<uint32_t> part_begin;
   uint64_t pos_base = 0, global_bases = 0;
-  // the LDS applies same-address lanes of one returning atomic in lane order (probed at mhx_create):
-  // lets the radix scatter rank records with one ds_add_rtn instead of an 8-ballot match-any
-  bool lds_atomic_ordered = false;
-  bool lds_probe_done = false;  // probe_lds_atomic_order has run on this handle (sort.hip runs it on first use of sort_rank_atomic)
   // stage-2 items aggregated by stage 1 (ws "s2_agg_items"): valid for one (k, m) until the reads or the
   // is_solid bitmap change
   bool agg_valid = false;
@@ -98,8 +94,15 @@ struct mhx_ctx {
   // the next radix_sort on exactly this buffer and item count): the buffer then holds NO items yet
   std::function<void(const mhx::OnesweepLaunch &)> gen_first_pass;
   const void *gen_buf = nullptr;
-  uint64_t gen_n = 0;
+  uint64_t gen_n = 0;      // records the generated pass leaves (= what the rest of the sort handles)
+  uint64_t gen_slots = 0;  // item slots it walks (> gen_n when it drops the items of filtered-out lv1 buckets)
   bool s2_filter_in_extract = false;  // passes.hip -> s2_extract: apply ws "filter_lut" while counting / writing the items
+  bool s1_filter_in_gen = false;      // passes.hip -> s1_extract: the generating first sort pass applies ws "filter_bits" (s1.hip S1GenT<true>)
+  uint32_t filter_kept = 0;           // lv1 buckets the filter keeps
+  // stage 1: records per lv1 bucket the ranks of a multi-GPU run agreed on (comm.hip; 0: each call derives it from its own
+  // item count, s1.hip s1_density) — every rank must make the same sort plan
+  double s1_density = 0;
+  std::string last_s1_plan;           // what the last stage 1 ran as (mhx_last_s1_plan; bench.py prints it)
   bool s1_defer_items = false;  // the caller of extract_stage(S1) will sort right away: s1_extract may defer the items to that sort
   // memory-bounded passes (passes.hip): only items of the kept lv1 buckets are materialised
   bool filter_on = false, accumulate = false;
@@ -162,6 +165,9 @@ struct SortPass {
   int bits;        // digit = bits [shift, shift+bits) ...
   int shift2 = 0;  // ... optionally continued by bits [shift2, shift2+bits2) as its upper part
   int bits2 = 0;   // bits + bits2 <= 8
+  // >= 0: the earlier passes of the plan sorted bits [prev_lo, shift), and the consumer does not look at the order of records
+  // that agree on every bit the plan sorts — lets the pass rank with LDS atomics where that cannot matter (sort_kernels.h RANK 2)
+  int prev_lo = -1;
 };
 // Sorts n items of `stride` uint32 words held in buf_a (ping-pong with buf_b) by the digit passes
 // (least-significant pass first).  Returns the buffer holding the result.
@@ -173,7 +179,6 @@ uint32_t *sort_whole_key(mhx_ctx *c, uint32_t *buf_a, uint32_t *buf_b, uint64_t 
 std::vector<SortPass> make_passes(int key_words, int lo_bit, int hi_bit);
 bool sort_takes_generated_first_pass(const mhx_ctx *c, uint64_t n, int stride, const std::vector<SortPass> &passes);
 uint64_t passes_signature(const std::vector<SortPass> &ps);
-bool probe_lds_atomic_order(mhx_ctx *c);
 // kmsort_emu.hip: sort with the reference's exact (unstable) tie order, one GPU thread per lv1 bucket
 uint32_t *kmsort_exact(mhx_ctx *c, uint32_t *buf_a, uint32_t *buf_b, uint64_t n, int S, int key_words);
 
@@ -205,9 +210,15 @@ struct S1Sources {
   std::vector<const uint32_t *> ptr;
   std::vector<uint64_t> count;
   uint32_t *spare = nullptr;  // scratch of >= 12 bytes per record for the group-by's output regions
+  int pbits = 16;             // key prefix bits the sources are sorted on (the stream plan's seg_bits)
 };
 bool s1_presort_applies(const mhx_ctx *c, uint32_t k, uint64_t n_local_items);
-uint32_t *s1_presort(mhx_ctx *c, uint32_t k, uint32_t *buf_a, uint32_t *buf_b, uint64_t n_items);
+uint32_t *s1_presort(mhx_ctx *c, uint32_t k, uint32_t *buf_a, uint32_t *buf_b, uint64_t n_items, int *pbits);
+bool s1_filter_in_gen_applies(const mhx_ctx *c, uint32_t k);
+bool s1_bucket_histogram_fast(mhx_ctx *c, uint32_t k, unsigned long long *hist);
+uint32_t s1_pos_bits(const mhx_ctx *c);
+uint64_t s1_pos_stride(const mhx_ctx *c, uint32_t k);
+std::string s1_plan_text(const mhx_ctx *c, uint32_t k, uint64_t n_items);
 int s1_process(mhx_ctx *c, uint32_t k, uint32_t m, int want_mercy, uint32_t *buf_a, uint32_t *buf_b, uint64_t n_items, mhx_s1_result *out,
                const S1Sources *pre = nullptr);
 __global__ void k_add_u64(unsigned long long *__restrict__ a, const unsigned long long *__restrict__ b, int n);

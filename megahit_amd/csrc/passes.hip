@@ -114,7 +114,9 @@ void bucket_histogram(mhx_ctx *c, int stage, uint32_t k, uint32_t m, uint64_t *h
   hipStream_t st = c->stream;
   unsigned long long *hist = c->ws("bucket_hist", MHX_NUM_BUCKETS * 8).as<unsigned long long>();
   MHX_HIP(hipMemsetAsync(hist, 0, MHX_NUM_BUCKETS * 8, st));
-  for_each_batch(c, stage, k, m, [&](const StageItems &b) {
+  // (stage 1 without mercy on reads of one length: straight from the packed reads, s1.hip)
+  const bool fast = stage == MHX_STAGE_S1 && s1_bucket_histogram_fast(c, k, hist);
+  if (!fast) for_each_batch(c, stage, k, m, [&](const StageItems &b) {
     if (b.n)
       hipLaunchKernelGGL(k_bucket_hist, dim3((unsigned)std::min<uint64_t>(div_ceil(b.n, 256), 8192)), dim3(256), 0, st,
                          c->work["items_a"].as<uint32_t>(), b.n, b.S, hist);
@@ -142,6 +144,21 @@ StageItems extract_stage(mhx_ctx *c, int stage, uint32_t k, uint32_t m) {
     c->pre_hist_buf = nullptr;
     return r;
   }
+  if (stage == MHX_STAGE_S1 && c->s1_defer_items && s1_filter_in_gen_applies(c, k)) {
+    // stage 1 on the fast shape: the first sort pass makes the records and leaves out those of the dropped buckets (s1.hip
+    // S1GenT<true>) — one scan of the reads per pass, nothing staged, nothing split; "items_a" is empty until that pass ran
+    c->s1_filter_in_gen = true;
+    StageItems r{0, 0, false, true};
+    try {
+      r.n = s1_extract(c, k, true);
+    } catch (...) {
+      c->s1_filter_in_gen = false;
+      throw;
+    }
+    r.S = s1_stride(k, true);
+    return r;
+  }
+  c->s1_defer_items = false;  // (batches: the items are materialised here)
   hipStream_t st = c->stream;
   const uint8_t *lut = c->work["filter_lut"].as<uint8_t>();
   uint64_t kept = 0;

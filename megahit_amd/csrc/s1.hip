@@ -35,9 +35,17 @@ __global__ void k_s1_item_counts(const uint64_t *__restrict__ start, uint64_t n_
 // COMPACT (no mercy requested): the aux part is one word, the absolute position of the (k-1)-mer; that is
 // all the group reduction needs to set is_solid, and it makes the record 12 instead of 16 bytes at k <= 29.
 // item of slot j (0 .. L-k+3) of the read at base offset st, length L (read_to_sdbg_s1.cpp:228-292, :344-363)
+// Positions in compact records: the record's third word holds the low `pos_bits` bits of the (k-1)-mer's global base
+// position, the bits above them (the "tag", < 256) ride in key bits that no comparison looks at, between the (k-1)-mer and
+// head/tail: bits [6, 14) of the last key word.  pos_bits = 32 unless a test asks for less (s1_pos_bits); read sets below
+// 2^pos_bits bases have tag 0 everywhere — the plain 32-bit position.  (Replaces the rank tags of round 2/3: the same bits,
+// but a function of the position alone, so one rank may hold more than 2^32 bases: 100 M reads on one GPU.)
+__device__ __forceinline__ uint32_t s1_pos_word(uint64_t p, uint32_t pos_bits) { return pos_bits >= 32 ? (uint32_t)p : (uint32_t)p & ((1u << pos_bits) - 1u); }
+__device__ __forceinline__ uint32_t s1_pos_tag(uint64_t p, uint32_t pos_bits) { return (uint32_t)(p >> pos_bits) << 6; }
+
 template <int KW, int S, bool COMPACT>
 __device__ __forceinline__ void s1_make_item(const uint32_t *__restrict__ seq, uint64_t st, uint32_t L, int k, uint32_t j, uint64_t pos_base,
-                                             uint32_t rank_tag, uint32_t (&out)[S]) {
+                                             uint32_t pos_bits, uint32_t (&out)[S]) {
   // slot -> ((k-1)-mer offset q, forced strand or -1)
   uint32_t q;
   int forced = -1;
@@ -73,10 +81,9 @@ __device__ __forceinline__ void s1_make_item(const uint32_t *__restrict__ seq, u
     info = (full << 6) | (comp_or_sentinel(next) << 3) | comp_or_sentinel(prev);
   }
   if constexpr (COMPACT) {
-    // multi-GPU beyond 2^32 global positions: the position stays rank-local (pos_base = 0) and the source rank rides in
-    // key bits that no comparison looks at (between the head/tail bits and the (k-1)-mer): rank_tag = rank << 6
-    out[KW - 1] |= rank_tag;
-    out[KW] = (uint32_t)(pos_base + st + q);
+    const uint64_t p = pos_base + st + q;
+    out[KW - 1] |= s1_pos_tag(p, pos_bits);
+    out[KW] = s1_pos_word(p, pos_bits);
     if constexpr (S > KW + 1) out[KW + 1] = 0;
   } else {
     out[KW] = (uint32_t)(info >> 32);
@@ -88,7 +95,7 @@ __device__ __forceinline__ void s1_make_item(const uint32_t *__restrict__ seq, u
 template <int KW, int S, bool COMPACT>
 __global__ __launch_bounds__(256) void k_s1_extract(const uint32_t *__restrict__ seq, const uint64_t *__restrict__ start,
                                                     const uint64_t *__restrict__ item_start, uint64_t n_seqs, int k,
-                                                    uint64_t pos_base, uint32_t rank_tag, uint32_t *__restrict__ items) {
+                                                    uint64_t pos_base, uint32_t pos_bits, uint32_t *__restrict__ items) {
   const int lane = lane_id();
   const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / kWave;
   const uint64_t n_waves = (uint64_t)gridDim.x * blockDim.x / kWave;
@@ -100,7 +107,7 @@ __global__ __launch_bounds__(256) void k_s1_extract(const uint32_t *__restrict__
     const uint32_t n_slots = L - k + 4;
     for (uint32_t j = lane; j < n_slots; j += kWave) {
       uint32_t out[S];
-      s1_make_item<KW, S, COMPACT>(seq, st, L, k, j, pos_base, rank_tag, out);
+      s1_make_item<KW, S, COMPACT>(seq, st, L, k, j, pos_base, pos_bits, out);
       uint32_t *dst = items + (ibase + j) * S;
       if constexpr (S % 2 == 1) {
 #pragma unroll
@@ -122,7 +129,7 @@ __global__ __launch_bounds__(256) void k_s1_extract(const uint32_t *__restrict__
 // through LDS so that each store instruction writes 256 contiguous bytes.
 template <int KW, int S, bool COMPACT>
 __global__ __launch_bounds__(256) void k_s1_extract_fixed(const uint32_t *__restrict__ seq, uint32_t L, uint32_t per, uint64_t n_items, int k,
-                                                          uint64_t pos_base, uint32_t rank_tag, uint32_t *__restrict__ items, DigitSpecs specs,
+                                                          uint64_t pos_base, uint32_t pos_bits, uint32_t *__restrict__ items, DigitSpecs specs,
                                                           unsigned long long *__restrict__ ghist) {
   __shared__ uint32_t xpose[S % 2 == 1 ? 256 * S : 1];
   __shared__ uint32_t h[kMaxFusedPasses][256];  // digit histograms of the coming sort passes (specs.n == 0: none)
@@ -134,7 +141,7 @@ __global__ __launch_bounds__(256) void k_s1_extract_fixed(const uint32_t *__rest
     uint32_t out[S];
     if (g < n_items) {
       const uint64_t r = g / per;
-      s1_make_item<KW, S, COMPACT>(seq, r * L, L, k, (uint32_t)(g - r * per), pos_base, rank_tag, out);
+      s1_make_item<KW, S, COMPACT>(seq, r * L, L, k, (uint32_t)(g - r * per), pos_base, pos_bits, out);
       for (int p = 0; p < specs.n; ++p) atomicAdd(&h[p][words_digit2<S>(out, specs.d[p])], 1u);
     }
     if constexpr (S % 2 == 1) {
@@ -179,7 +186,7 @@ __device__ __forceinline__ uint64_t rc64(uint64_t x, int n);
 // the record of the (k-1)-mer at offset q of its read (absolute base a), from the 64 bits of the store that start two bases
 // in front of it: prev | head | (k-1)-mer | tail | next ...
 __device__ __forceinline__ void s1_item_from_window(uint64_t win, uint32_t q, int forced, uint32_t L, int k, uint64_t a, uint64_t pos_base,
-                                                    uint32_t rank_tag, uint32_t (&out)[3]) {
+                                                    uint32_t pos_bits, uint32_t (&out)[3]) {
   const int km1 = k - 1;
   const unsigned head_b = (unsigned)(win >> 60) & 3u, tail_b = (unsigned)(win >> (58 - 2 * km1)) & 3u;
   const uint64_t f = (win << 4) & (~0ull << (64 - 2 * km1));
@@ -190,14 +197,15 @@ __device__ __forceinline__ void s1_item_from_window(uint64_t win, uint32_t q, in
   if (forced >= 0) strand = forced;
   else strand = f > rc ? 1 : (f < rc ? 0 : (head <= 3 - tail ? 0 : 1));
   const uint64_t key = strand ? (rc | (comp_or_sentinel(tail) << 3) | comp_or_sentinel(head)) : (f | (head << 3) | tail);
+  const uint64_t p = pos_base + a;
   out[0] = (uint32_t)(key >> 32);
-  out[1] = (uint32_t)key | rank_tag;
-  out[2] = (uint32_t)(pos_base + a);
+  out[1] = (uint32_t)key | s1_pos_tag(p, pos_bits);
+  out[2] = s1_pos_word(p, pos_bits);
 }
 
 // one stage-1 record of a fixed-length read set from the 64-bit window around its (k-1)-mer: read r, slot j (see above)
 __device__ __forceinline__ void s1_fast_item(const uint32_t *__restrict__ seq, uint32_t L, int k, uint64_t st, uint32_t j, uint64_t pos_base,
-                                             uint32_t rank_tag, uint32_t (&out)[3]) {
+                                             uint32_t pos_bits, uint32_t (&out)[3]) {
   // st = first base of the read (read index x L: the callers advance it with the slots instead of multiplying per item)
   // slot -> offset of the (k-1)-mer; slots 0, 1 and the last two are the forced-strand pairs at the read's ends
   const uint32_t jf = L - k + 2;
@@ -212,18 +220,32 @@ __device__ __forceinline__ void s1_fast_item(const uint32_t *__restrict__ seq, u
   const unsigned sh = (unsigned)(b & 15) * 2, down = a >= 2 ? 0u : (unsigned)(2 - a) * 2;
   const uint32_t x0 = seq[w], x1 = seq[w + 1], x2 = seq[w + 2];
   const uint64_t win = (((uint64_t)funnel_l(x0, x1, sh) << 32) | funnel_l(x1, x2, sh)) >> down;
-  s1_item_from_window(win, q, forced, L, k, a, pos_base, rank_tag, out);
+  s1_item_from_window(win, q, forced, L, k, a, pos_base, pos_bits, out);
 }
 
 // The same records as a SOURCE of the first chained-scan pass (sort_kernels.h): no record array is written by the
 // extraction and read back by the sort — 16 GB each way at 10 M reads.  The digit histograms the chained scan needs
 // beforehand come from k_s1_extract_fast<IT, false>, the same arithmetic without the stores.
-struct S1Gen {
+// lv1-bucket filter inside the generators (FILTER): `keep` is a bitmap over the 65 536 lv1 buckets (bit b of word b / 32); an
+// item of a dropped bucket becomes a record that is_record() rejects — head/tail bits 63, which no real record carries — and
+// the pass leaves it out (Src::kMayDrop, sort_kernels.h).  This is where the reference's OffsetFiller::IsHandling sits
+// (base_engine.h:106-108): a bucket-range pass of the memory plan scans the reads once and writes only what it keeps.
+__device__ __forceinline__ bool s1_bucket_kept(const uint32_t *__restrict__ keep, uint32_t w0) {
+  const uint32_t b = w0 >> 16;
+  return (keep[b >> 5] >> (b & 31u)) & 1u;
+}
+constexpr uint32_t kS1Dropped = 0xFFFFFFFFu;  // second key word of a dropped item
+
+template <bool FILTER>
+struct S1GenT {
   const uint32_t *seq;
   uint32_t L, per;
   int k;
   uint64_t pos_base;
-  uint32_t rank_tag;
+  uint32_t pos_bits;
+  const uint32_t *keep;
+  static constexpr bool kMayDrop = FILTER;
+  __device__ __forceinline__ bool is_record(const Rec<3> &r) const { return !FILTER || (r.w[1] & 63u) != 63u; }
   template <int NI>
   __device__ __forceinline__ void get(uint64_t first, uint64_t n, Rec<3> (&rec)[NI]) const {
     const uint64_t r = first / per;  // one 64-bit division per tile and thread, then read offset and slot advance with the items
@@ -235,7 +257,9 @@ struct S1Gen {
       // the window loads of a tile are issued together)
       const bool ok = first + (uint64_t)i * kWave < n;
       uint32_t out[3];
-      s1_fast_item(seq, L, k, ok ? st : 0, ok ? j : 2u, pos_base, rank_tag, out);
+      s1_fast_item(seq, L, k, ok ? st : 0, ok ? j : 2u, pos_base, pos_bits, out);
+      if constexpr (FILTER)
+        if (!s1_bucket_kept(keep, out[0])) out[1] = kS1Dropped;
       if (ok) {
         rec[i].w[0] = out[0];
         rec[i].w[1] = out[1];
@@ -259,19 +283,24 @@ struct S1Gen {
     for (int t = 0; t < UT; ++t) get<NI>(unit_base + (uint64_t)t * (kSortThreads * NI) + (uint64_t)(w * (kWave * NI) + lane), n, rec[t]);
   }
 };
+using S1Gen = S1GenT<false>;
 
 // The same generator with CONSECUTIVE items per thread (a pass whose records may leave in any order does not care which
 // thread holds which item of the unit): eight consecutive slots of a read share their window words — four words loaded
 // once for the run that starts at the thread's first item and four for the start of the next read, instead of three words
 // per item —, the slot and the read's base offset advance by increments, and there is one division per UNIT and thread.
 // Needs at least NI slots per read (at most one read boundary inside a thread's items of a tile).
-struct S1GenBlocked {
+template <bool FILTER>
+struct S1GenBlockedT {
   const uint32_t *seq;
   uint32_t L, per;
   int k;
   uint64_t pos_base;
-  uint32_t rank_tag;
+  uint32_t pos_bits;
   uint32_t tile_q, tile_r;  // items of a tile (256 NI) divided by the slots per read: quotient and remainder
+  const uint32_t *keep;
+  static constexpr bool kMayDrop = FILTER;
+  __device__ __forceinline__ bool is_record(const Rec<3> &r) const { return !FILTER || (r.w[1] & 63u) != 63u; }
   template <int NI>
   __device__ __forceinline__ uint64_t index(uint64_t tile_base, int w, int lane, int j) const {
     return tile_base + (uint64_t)((w * kWave + lane) * NI + j);
@@ -339,7 +368,9 @@ struct S1GenBlocked {
         const uint32_t x0 = second ? c1 : c0, x1 = second ? c2 : c1, x2 = second ? c3 : c2;
         const uint64_t win = (((uint64_t)funnel_l(x0, x1, sh) << 32) | funnel_l(x1, x2, sh)) >> down;
         uint32_t out[3];
-        s1_item_from_window(win, q, forced, L, k, a, pos_base, rank_tag, out);
+        s1_item_from_window(win, q, forced, L, k, a, pos_base, pos_bits, out);
+        if constexpr (FILTER)
+          if (!s1_bucket_kept(keep, out[0])) out[1] = kS1Dropped;
         if (g0 + (uint64_t)i < n) {
           rec[t][i].w[0] = out[0];
           rec[t][i].w[1] = out[1];
@@ -355,6 +386,7 @@ struct S1GenBlocked {
     }
   }
 };
+using S1GenBlocked = S1GenBlockedT<false>;
 
 constexpr int kFastPasses = 4;
 // The digit histograms of the coming sort passes without making the records (the pre-pass of the generating first pass):
@@ -407,7 +439,7 @@ __global__ __launch_bounds__(256) void k_s1_digit_hist(const uint32_t *__restric
           hi = (uint32_t)((use_rc ? rc : f) >> 32);
         } else {
           uint32_t out[3];
-          s1_make_item<2, 3, true>(seq, r * L, L, k, j, 0, 0u, out);
+          s1_make_item<2, 3, true>(seq, r * L, L, k, j, 0, 32u, out);
           hi = out[0];
         }
         const uint32_t o2[2] = {hi, 0u};
@@ -447,7 +479,9 @@ struct HiDigits {
 // item loop whenever the window moves into the next word.
 template <int IT, int NP, bool PRE = false>  // NP digit histograms
 __global__ __launch_bounds__(256) void k_s1_digit_hist_plain(const uint32_t *__restrict__ seq, uint32_t L, uint32_t per, uint64_t n_items, int k,
-                                                             HiDigits hd, unsigned long long *__restrict__ ghist, uint32_t step_q, uint32_t step_r) {
+                                                             HiDigits hd, unsigned long long *__restrict__ ghist, uint32_t step_q, uint32_t step_r,
+                                                             const uint32_t *__restrict__ keep) {
+  // keep != nullptr: only the items of the kept lv1 buckets are counted (the generating pass drops the others, S1GenT<true>)
   constexpr int B = 256 * IT;
   __shared__ uint32_t h[kFastPasses][4][256];
   for (int i = threadIdx.x; i < kFastPasses * 4 * 256; i += 256) (&h[0][0][0])[i] = 0;
@@ -457,13 +491,14 @@ __global__ __launch_bounds__(256) void k_s1_digit_hist_plain(const uint32_t *__r
   const uint64_t kmask = ~0ull << (64 - 2 * km1);
   const uint32_t qlast = L - k + 1, jf = L - k + 2;  // last offset of a (k-1)-mer; first slot of the forced pair at the read's end
   auto count = [&](uint32_t hi) {
+    if (keep && !s1_bucket_kept(keep, hi)) return;
 #pragma unroll
     for (int p = 0; p < NP; ++p) atomicAdd(&h[p][wv][(hi >> hd.sh[p]) & hd.mk[p]], 1u);
   };
   if (blockIdx.x == 0 && threadIdx.x == 0)
     for (uint32_t j = 0; j < 3 && j < n_items; ++j) {
       uint32_t out[3];
-      s1_make_item<2, 3, true>(seq, 0, L, k, j, 0, 0u, out);
+      s1_make_item<2, 3, true>(seq, 0, L, k, j, 0, 32u, out);
       count(out[0]);
     }
   const uint64_t n_blocks = (n_items + B - 1) / B;
@@ -478,12 +513,14 @@ __global__ __launch_bounds__(256) void k_s1_digit_hist_plain(const uint32_t *__r
     uint32_t x0 = 0, x1 = 0, x2 = 0;
     uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0, n0 = 0, n1 = 0, n2 = 0, n3 = 0;
     uint64_t wnext = 0;
+    // nothing of this block is this thread's (the last block): its window loads go to the start of the store, nothing is
+    // counted — every address a thread asks for lies inside the store and its 32 pad words
+    if (g0 >= n_items) {
+      j = 0;
+      base = 0;
+    }
     if constexpr (PRE) {
       static_assert(IT <= 8, "a run of IT windows starts in at most two words");
-      if (g0 >= n_items) {  // (nothing of this block is this thread's: loads from the start of the store, nothing counted)
-        j = 0;
-        base = 0;
-      }
       const uint32_t qs = min(j > 0 ? j - 1 : 0u, qlast);
       const uint64_t as = base + qs, bs = as >= 2 ? as - 2 : 0;
       wcur = bs >> 4;
@@ -539,9 +576,100 @@ __global__ __launch_bounds__(256) void k_s1_digit_hist_plain(const uint32_t *__r
   }
 }
 
+// The lv1-bucket histogram of stage 1 (the reference's Lv0CalcBucketSize, read_to_sdbg_s1.cpp:145-206) for the fast shape —
+// what a memory plan asks for before it splits a 100 M-read job into bucket ranges.  The same window arithmetic as the
+// digit-histogram pre-pass; the 65 536 counters do not fit the LDS as 32-bit words, so a launch counts one HALF of the
+// bucket space (128 KB, one 1024-thread workgroup per CU) and the host launches twice.  (The general path takes the
+// histogram from extracted items with one global atomic per item: seconds at 10^10 items.)
+template <int IT>
+__global__ __launch_bounds__(1024) void k_s1_bucket_hist_fast(const uint32_t *__restrict__ seq, uint32_t L, uint32_t per, uint64_t n_items, int k,
+                                                              unsigned long long *__restrict__ ghist, uint32_t step_q, uint32_t step_r, uint32_t half) {
+  constexpr int NT = 1024, B = NT * IT, NB = MHX_NUM_BUCKETS / 2;
+  __shared__ uint32_t h[NB];
+  for (int i = threadIdx.x; i < NB; i += NT) h[i] = 0;
+  __syncthreads();
+  const int km1 = k - 1;
+  const uint64_t kmask = ~0ull << (64 - 2 * km1);
+  const uint32_t qlast = L - k + 1, jf = L - k + 2;
+  auto count = [&](uint32_t hi) {
+    const uint32_t b = hi >> 16;
+    if ((b >> 15) == half) atomicAdd(&h[b & (NB - 1)], 1u);
+  };
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+    for (uint32_t j = 0; j < 3 && j < n_items; ++j) {  // (the items whose window would start before the store)
+      uint32_t out[3];
+      s1_make_item<2, 3, true>(seq, 0, L, k, j, 0, 32u, out);
+      count(out[0]);
+    }
+  const uint64_t n_blocks = (n_items + B - 1) / B;
+  uint64_t q0 = ((uint64_t)blockIdx.x * (uint64_t)B) / per;
+  uint32_t rem0 = (uint32_t)(((uint64_t)blockIdx.x * (uint64_t)B) % per);
+  for (uint64_t blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
+    const uint64_t g0 = blk * B + (uint64_t)threadIdx.x * IT;
+    const uint32_t t = rem0 + (uint32_t)threadIdx.x * IT, dq = t / per;
+    uint32_t j = t - dq * per;
+    uint64_t base = (q0 + dq) * L;
+    if (g0 >= n_items) {  // (nothing of this block is this thread's: loads from the start of the store, nothing counted)
+      j = 0;
+      base = 0;
+    }
+    uint64_t wcur = ~0ull;
+    uint32_t x0 = 0, x1 = 0, x2 = 0;
+#pragma unroll
+    for (int u = 0; u < IT; ++u) {
+      const uint32_t q = min(j > 0 ? j - 1 : 0u, qlast);
+      const bool forced = j < 2 || j >= jf;
+      const uint32_t fstrand = j < 2 ? j : j - jf;
+      const uint64_t a = base + q;
+      const uint64_t b = a >= 2 ? a - 2 : 0, w = b >> 4;
+      if (w != wcur) {
+        x0 = seq[w];
+        x1 = seq[w + 1];
+        x2 = seq[w + 2];
+        wcur = w;
+      }
+      const unsigned sh = (unsigned)(b & 15) * 2;
+      const uint64_t win = ((uint64_t)funnel_l(x0, x1, sh) << 32) | funnel_l(x1, x2, sh);
+      const uint64_t f = (win << 4) & kmask;
+      const uint64_t rc = rc64(f, km1);
+      const bool use_rc = forced ? fstrand == 1 : f > rc;  // (f == rc: the same first word either way)
+      if (g0 + u < n_items && a >= 2) count((uint32_t)((use_rc ? rc : f) >> 32));
+      if (++j == per) {
+        j = 0;
+        base += L;
+      }
+    }
+    q0 += step_q;
+    rem0 += step_r;
+    if (rem0 >= per) {
+      rem0 -= per;
+      ++q0;
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < NB; i += NT)
+    if (h[i]) atomicAdd(&ghist[half * NB + i], (unsigned long long)h[i]);
+}
+// -> true when it ran (fixed-length reads, 12-byte compact records); hist: device, 65 536 counters, zeroed by the caller
+bool s1_bucket_histogram_fast(mhx_ctx *c, uint32_t k, unsigned long long *hist) {
+  SeqSet &s = c->seqs;
+  if (!c->opt("s1_bucket_hist_fast", 1) || !s.n_seqs || s.fixed_len < k + 1 || !s1_compact(c, k, 0) || (2 * (k - 1) + 6 + 31) / 32 != 2 || k > 29) return false;  // (two key words)
+  constexpr int IT = 8;
+  const uint32_t per = s.fixed_len - k + 4;
+  const uint64_t n_items = s.n_seqs * (uint64_t)per;
+  const uint64_t cus = c->n_cus > 0 ? (uint64_t)c->n_cus : 256;
+  const unsigned grid = (unsigned)std::min<uint64_t>(div_ceil(n_items, 1024 * IT), cus);
+  const uint64_t stride_items = (uint64_t)grid * 1024 * IT;
+  for (uint32_t half = 0; half < 2; ++half)
+    MHX_LAUNCH(c, "s1_bucket_hist", (double)s.n_bases / 4,
+               hipLaunchKernelGGL((k_s1_bucket_hist_fast<IT>), dim3(grid), dim3(1024), 0, c->stream, s.words.as<uint32_t>(), s.fixed_len, per, n_items, (int)k,
+                                  hist, (uint32_t)(stride_items / per), (uint32_t)(stride_items % per), half));
+  return true;
+}
+
 template <int IT, bool WRITE>  // items per thread and trip; WRITE = false: only the digit histograms: their window loads are issued together (one in flight per thread = latency-bound)
 __global__ __launch_bounds__(256) void k_s1_extract_fast(const uint32_t *__restrict__ seq, uint32_t L, uint32_t per, uint64_t n_items, int k,
-                                                         uint64_t pos_base, uint32_t rank_tag, uint32_t *__restrict__ items, DigitSpecs specs,
+                                                         uint64_t pos_base, uint32_t pos_bits, uint32_t *__restrict__ items, DigitSpecs specs,
                                                          unsigned long long *__restrict__ ghist, uint32_t step_q, uint32_t step_r) {
   constexpr int B = 256 * IT;  // items per workgroup and trip
   __shared__ uint32_t xpose[WRITE ? B * 3 : 1];
@@ -564,7 +692,7 @@ __global__ __launch_bounds__(256) void k_s1_extract_fast(const uint32_t *__restr
       ok[u] = g < n_items;
       const uint32_t t = rem0 + (uint32_t)u * 256u + threadIdx.x, dq = t / per, j = t - dq * per;
       // (a thread beyond the last item recomputes item 0: unconditional loads, nothing stored)
-      s1_fast_item(seq, L, k, ok[u] ? (q0 + dq) * L : 0, ok[u] ? j : 2, pos_base, rank_tag, outs[u]);
+      s1_fast_item(seq, L, k, ok[u] ? (q0 + dq) * L : 0, ok[u] ? j : 2, pos_base, pos_bits, outs[u]);
     }
 #pragma unroll
     for (int u = 0; u < IT; ++u) {
@@ -1231,42 +1359,63 @@ __global__ __launch_bounds__(256) void k_s1_seg(const uint32_t *__restrict__ ite
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Bucket-streaming variant of the segment group-by: sort only the top 16 bits of the (k-1)-mer — the reference's lv1
-// bucket, two LSD passes — and let one workgroup take one whole bucket (~20 K records at 10 M reads): it streams the
-// bucket, inserting the keys into an LDS table, and then marks every record with its key's count — by streaming the bucket a
-// second time (PMC: that read comes from HBM again, the buckets of all workgroups do not fit the caches) or, when the
+// Bucket-streaming variant of the segment group-by ("two-level bucketed sort" with the second level in LDS): the records
+// are sorted on the top `pbits` bits of the (k-1)-mer only — 16 bits = the reference's lv1 bucket and two LSD passes at
+// 10 M reads per GPU, up to 24 bits and three passes for larger jobs, so that a streamed bucket stays at ~20-40 K records
+// whatever the job size (s1_plan) — and one workgroup takes one whole bucket: it streams the bucket, inserting the keys
+// into an LDS table, and then marks every record with its key's count — by streaming the bucket a second time or, when the
 // marks wanted are those of the NON-solid occurrences and m <= 2 (direct_marks: the usual case, most occurrences being
 // solid), straight from the table: a key that ends with count 1 < m has exactly one record, whose position the insert
-// left next to the key, so the second read never happens.  Inside a bucket the prefix is constant, so the
-// table key is the remaining 2(k-1)-16 (k-1)-mer bits + head/tail = 32 bits at k <= 22 (4-byte compare-and-swap), and
-// nothing of k_s1_seg's segment ownership / look-ahead is needed: "two-level bucketed sort" with the second level in LDS.
-// A bucket with more distinct keys than the table holds sets *err -> the host falls back to k_s1_seg (three passes).
+// left next to the key, so the second read never happens.  Inside a bucket the prefix is constant, so the table key is the
+// remaining 2(k-1)-pbits (k-1)-mer bits + head/tail <= 32 bits at k <= 22 (4-byte compare-and-swap), and nothing of
+// k_s1_seg's segment ownership / look-ahead is needed.
+//
+// SUB-ROUNDS: a bucket whose distinct keys do not fit the table is not the stage's problem but the bucket's: the workgroup
+// takes it in 2^s rounds, round j inserting only the records whose top s local-key bits equal j (the bucket is read once
+// per round, each round is a complete group-by of a disjoint key set: marks, histogram and aggregated items of a finished
+// round stand).  A round that overflows is split in two, recursively; with all local-key bits fixed a round holds one key,
+// so the recursion ends.  The host may also ask for 2^sub0 rounds for every bucket up front (a job whose buckets are known
+// to hold 2-4 x what the table takes: cheaper than a third sort pass, s1_plan).  Nothing here redoes the stage: *err is
+// left for what the host really has to handle (an output region that is too small).
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int kStreamThreads = 1024;  // one workgroup per CU: 8192 slots of key + count + first position + list entry = 122 KB of LDS
 constexpr uint32_t kStreamEmpty = 0xFFFFFFFFu;  // never a key: head/tail bits 63 do not occur
 
-__global__ void k_bucket_bounds(const uint32_t *__restrict__ items, uint64_t n, int stride, uint64_t *__restrict__ bstart);  // kmsort_emu.hip
+__global__ void k_bucket_bounds(const uint32_t *__restrict__ items, uint64_t n, int stride, uint64_t *__restrict__ bstart, int pbits);  // kmsort_emu.hip
+
+struct S1StreamGeom {
+  int pbits;          // prefix bits the records are sorted on: 2^pbits buckets, bounds[q * (2^pbits + 1) + b]
+  int sub0;           // every bucket starts with 2^sub0 sub-rounds
+  int prefetch;       // runtime switch of the PF instantiation's next-bucket pipelining (one source only)
+  uint32_t n_buckets; // 1 << pbits
+  uint32_t max_fill;  // a round gives up when it has claimed more slots than this (long probe chains are slow before they fail)
+};
 
 // NT / LOGS: 1024 threads and 8192 slots = one workgroup per CU (122 KB of LDS); 512 threads and 4096 slots (62 KB) = two per CU:
-// while one of them walks its table (LDS only, a quarter of a bucket's time) the other has loads in flight, at the price of
-// a table that gives up at half as many distinct keys per bucket (s1_stream_half)
-template <bool AGG, int UNR, int NT = kStreamThreads, int LOGS = 13>
+// while one of them walks its table the other has loads in flight, at the price of a table that holds half as many keys
+// (s1_stream_half; with sub-rounds an overflow costs that bucket one more read, not the stage).
+// PF: the record loads of trip i + 1 are issued BEFORE the inserts of trip i, and thread 0 fetches the ticket and the bounds of
+// the next bucket while the current one is worked on.  Phase clocks of wave 0 (round 3, 4 M reads): a trip of 4 records per
+// thread waits ~4 600 cycles for its loads and then spends ~4 200 cycles in its 4 compare-and-swap + add pairs (all 16
+// wavefronts of the CU hit the LDS atomics at the same time), one after the other; and a bucket started with three
+// latencies in a row (ticket -> bounds -> first records).
+template <bool AGG, int UNR, int NT = kStreamThreads, int LOGS = 13, bool PF = false>
 __global__ __launch_bounds__(NT) void k_s1_stream(const uint32_t *__restrict__ items0, const uint64_t *__restrict__ bounds, S1SegArgs a,
-                                                             uint32_t bucket_stride, uint32_t *__restrict__ ticket,
+                                                             S1StreamGeom geo, uint32_t bucket_stride, uint32_t *__restrict__ ticket,
                                                              const uint32_t *const *__restrict__ srcs, int n_src) {
   // Multi-GPU: the records of a bucket arrive as n_src sub-ranges, one per sending rank, each rank's records sorted by
-  // bucket in an array of its own (srcs[q], bounds[q * (65536 + 1) + bucket]); single GPU: one source, items0.
+  // bucket in an array of its own (srcs[q], bounds[q * (n_buckets + 1) + bucket]); single GPU: one source, items0.
   constexpr int NSLOT = 1 << LOGS;
   __shared__ uint32_t keys[NSLOT];
   __shared__ uint32_t cnts[NSLOT];
   __shared__ uint32_t fpos[NSLOT];  // position word of the record that created the slot (direct_marks)
-  __shared__ uint8_t ftag[NSLOT];   // ... and its source rank, when the records carry one (positions past 2^32, multi-GPU)
+  __shared__ uint8_t ftag[NSLOT];   // ... and the position bits above it (s1_pos_tag), when the read set has any
   // the occupied slots in the order they were claimed: a bucket fills about a third of the table (2 670 of 8 192 slots at
-  // 10 M reads), and the two per-key phases below would otherwise visit all 8 192 slots of all 65 536 buckets — as many
-  // LDS reads as the bucket has records.  (Measured: 8.15 -> 8.10 ms only; this kernel's time is its insert phase.)
+  // 10 M reads), and the per-key phases below would otherwise visit all 8 192 slots of all buckets
   __shared__ uint16_t used[NSLOT];
   __shared__ uint32_t lhist[kSegHist];
   __shared__ uint32_t s_bad, s_agg_cur, s_mark_cur, s_bucket, s_nused;
+  __shared__ uint64_t s_lo, s_hi;  // pipelined: bounds of the bucket in s_bucket, fetched while the bucket before it was worked on
   const int tid = threadIdx.x, lane = tid & (kWave - 1);
   const uint64_t lanemask_lt = (1ull << lane) - 1;
   uint2 *const agg_end = AGG ? a.agg_raw + (size_t)(blockIdx.x + 1) * a.agg_cap : nullptr;
@@ -1280,214 +1429,342 @@ __global__ __launch_bounds__(NT) void k_s1_stream(const uint32_t *__restrict__ i
     s_bad = 0;
     s_agg_cur = 0;
     s_mark_cur = 0;
+    s_nused = 0;
   }
-  __syncthreads();
   const uint32_t m = a.m;
   const int k = a.k;
-  // local key: the (k-1)-mer bits below the 16-bit bucket prefix, then head/tail (the rank tag bits in between dropped)
-  const int rem = 2 * (k - 1) - 16;  // 2..26 bits at k = 10..22
+  const int pbits = geo.pbits;
+  const size_t bstride = (size_t)geo.n_buckets + 1;
+  // local key: the (k-1)-mer bits below the prefix, then head/tail (the position tag bits in between dropped)
+  const int rem = 2 * (k - 1) - pbits;  // 0..26 bits
+  const int lk_bits = rem + 6;          // <= 32
   auto local_key = [&](uint32_t w0, uint32_t w1) -> uint32_t {
     const uint64_t key = ((uint64_t)w0 << 32) | w1;
-    return (uint32_t)((key << 16) >> (64 - rem)) << 6 | (w1 & 63u);
+    const uint32_t mer = rem ? (uint32_t)((key << pbits) >> (64 - rem)) : 0u;
+    return mer << 6 | (w1 & 63u);
+  };
+  // the (k+1)-mer head.S.tail of a table key of bucket bi, chars MSB-first in 64 bits
+  auto edge_of = [&](uint32_t bi, uint32_t lk) -> uint64_t {
+    const uint64_t smer = ((uint64_t)bi << (64 - pbits)) | (rem ? (uint64_t)(lk >> 6) << (64 - pbits - rem) : 0ull);
+    return ((uint64_t)((lk >> 3) & 7u) << 62) | (smer >> 2) | ((uint64_t)(lk & 7u) << (62 - 2 * k));
   };
   unsigned long long st_solid = 0, st_both = 0;
+  const bool pipelined = PF && geo.prefetch && n_src == 1;
+  auto bounds_of = [&](int q, uint32_t b, uint64_t &lo_, uint64_t &hi_) {
+    if (pipelined) {
+      lo_ = s_lo;
+      hi_ = s_hi;
+    } else {
+      lo_ = bounds[(size_t)q * bstride + b];
+      hi_ = bounds[(size_t)q * bstride + b + 1];
+    }
+  };
+  // (a workgroup stops taking buckets once the host has to step in anyway)
+  auto take_ticket = [&]() -> uint32_t {
+    return __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 0xFFFFFFFFu / (bucket_stride ? bucket_stride : 1u) : atomicAdd(ticket, 1u);
+  };
+  if (pipelined && tid == 0) {
+    const uint32_t t0 = take_ticket();
+    const uint64_t b0 = (uint64_t)t0 * bucket_stride;
+    s_bucket = t0;
+    if (b0 < geo.n_buckets) {
+      s_lo = bounds[b0];
+      s_hi = bounds[b0 + 1];
+    }
+  }
+  __syncthreads();
 
   for (;;) {
     MHX_TT_BEGIN
-    if (tid == 0) {
-      s_bucket = atomicAdd(ticket, 1u);
-      s_nused = 0;
-    }
+    if (tid == 0 && !pipelined) s_bucket = take_ticket();
     __syncthreads();
-    const uint32_t bi = s_bucket * bucket_stride;
-    if (bi >= MHX_NUM_BUCKETS) break;
+    const uint64_t bi64 = (uint64_t)s_bucket * bucket_stride;
+    if (bi64 >= geo.n_buckets) break;
+    const uint32_t bi = (uint32_t)bi64;
     MHX_TT(10)
+    // pipelined, thread 0: the next bucket's ticket now, its bounds behind the first inserts, both handed over when this bucket ends
+    uint32_t next_ticket = 0;
+    uint64_t next_lo = 0, next_hi = 0;
+    bool next_fetched = false;
+    if (pipelined && tid == 0) next_ticket = take_ticket();
+    auto fetch_next = [&]() {
+      if (pipelined && tid == 0 && !next_fetched) {
+        const uint64_t nb = (uint64_t)next_ticket * bucket_stride;
+        if (nb < geo.n_buckets) {
+          next_lo = bounds[nb];
+          next_hi = bounds[nb + 1];
+        }
+        next_fetched = true;
+      }
+    };
+    auto publish_next = [&]() {  // (behind a barrier that every reader of s_bucket / s_lo / s_hi has passed)
+      if (pipelined && tid == 0) {
+        s_bucket = next_ticket;
+        s_lo = next_lo;
+        s_hi = next_hi;
+      }
+    };
     uint64_t total = 0;
-    for (int q = 0; q < n_src; ++q) total += bounds[(size_t)q * (MHX_NUM_BUCKETS + 1) + bi + 1] - bounds[(size_t)q * (MHX_NUM_BUCKETS + 1) + bi];
+    for (int q = 0; q < n_src; ++q) {
+      uint64_t lo_, hi_;
+      bounds_of(q, bi, lo_, hi_);
+      total += hi_ - lo_;
+    }
     if (total == 0) {
+      __syncthreads();
+      fetch_next();
+      publish_next();
       __syncthreads();
       continue;
     }
-    // A: insert.  UNR records per thread and trip: their loads are issued together — with one 12-byte load in flight per
-    // wavefront the 16 wavefronts of a CU keep ~12 KB on the wire, 1.5 TB/s device-wide at ~2 us under load, which is
-    // what this kernel measured before (the LDS table was never the limit)
-    for (int q = 0; q < n_src; ++q) {
-    const uint64_t lo = bounds[(size_t)q * (MHX_NUM_BUCKETS + 1) + bi], hi = bounds[(size_t)q * (MHX_NUM_BUCKETS + 1) + bi + 1];
-    if (lo == hi) continue;
-    const uint32_t *__restrict__ items = n_src > 1 ? srcs[q] : items0;
-    for (uint64_t base = lo; base < hi; base += (uint64_t)NT * UNR) {
-      uint32_t rw0[UNR], rw1[UNR], rw2[UNR];
-      bool rin[UNR];
-#pragma unroll
-      for (int u = 0; u < UNR; ++u) {
-        const uint64_t gi = base + (uint64_t)u * NT + tid;
-        rin[u] = gi < hi;
-        // unconditional loads (index clamped into the bucket, lo < hi): straight-line code, so that the compiler issues all
-        // UNR loads before the first wait — a load inside an `if` is followed by s_waitcnt vmcnt(0) at the end of its block
-        const uint32_t *p = items + (rin[u] ? gi : hi - 1) * 3;
-        rw0[u] = p[0];
-        rw1[u] = p[1];
-        rw2[u] = p[2];
-      }
-#pragma unroll
-      for (int u = 0; u < UNR; ++u) {
-        if (!rin[u]) continue;
-        const uint32_t lk = local_key(rw0[u], rw1[u]), w2 = rw2[u];
-        const uint32_t tag = (rw1[u] >> 6) & 0xFFu;
-        // one compare-and-swap + add per record: inside a bucket the records are in read order, equal keys are rarely
-        // neighbours, so grouping the lanes of a wavefront by key (as k_s1_seg does on its sorted segments) saves few atomics
-        // and costs eight ballots per round; the LDS serialises same-address atomics by itself.  (Issuing the UNR first
-        // probes back to back before looking at any result measured slower: 8.9 vs 7.1 ms.)
-        uint32_t h = (lk * 0x9E3779B1u) >> (32 - LOGS);
-        int probes = 0;
-        const int probe_limit = a.la_chunks;  // (stream mode: the host passes the probe limit here; tests set it to 0)
-        for (; probes < probe_limit; ++probes) {
-          // read_first: most records meet their key already in the table (one key per ~8 records at 60x): a plain LDS read
-          // finds that out without the read-modify-write of a compare-and-swap, which then only the claims of empty slots pay
-          uint32_t old;
-          if (a.read_first) {
-            old = __hip_atomic_load(&keys[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (old == kStreamEmpty) old = atomicCAS(&keys[h], kStreamEmpty, lk);
-          } else {
-            old = atomicCAS(&keys[h], kStreamEmpty, lk);
-          }
-          if (old == kStreamEmpty || old == lk) {
-            atomicAdd(&cnts[h], 1u);
-            if (old == kStreamEmpty) {  // only read back when the count stays 1: then this record is the key's only one
-              fpos[h] = w2;
-              if (a.pos_stride) ftag[h] = (uint8_t)tag;
-              if (a.used_list) used[atomicAdd(&s_nused, 1u)] = (uint16_t)h;
-            }
-            break;
-          }
-          h = (h + 1) & (NSLOT - 1);
-        }
-        if (probes == probe_limit) s_bad = 1;
-      }
-    }
-    }  // sources
-    __syncthreads();
-    MHX_TT(11)
-    const bool bad = s_bad != 0;
-    const int n_walk = a.used_list ? (int)s_nused : NSLOT;  // (both per-key phases walk the same slots in the same order per thread)
-    uint32_t my_agg = 0;
-    if (!bad) {
-      // B: marks, streaming the bucket again (cache-resident)
-      if (a.mark_mode != 2 && !a.direct_marks) {
-        for (int q = 0; q < n_src; ++q) {
-        const uint64_t lo = bounds[(size_t)q * (MHX_NUM_BUCKETS + 1) + bi], hi = bounds[(size_t)q * (MHX_NUM_BUCKETS + 1) + bi + 1];
+    // the bucket in rounds: round (sub, rj) takes the records whose top `sub` local-key bits are rj
+    uint32_t sub = (uint32_t)min(geo.sub0, lk_bits), rj = 0;
+    const uint32_t sub_first = sub;
+    for (;;) {
+      const uint32_t sub_sh = (uint32_t)lk_bits - sub;  // (sub == 0: no test)
+      // A: insert.  UNR records per thread and trip: their loads are issued together — with one 12-byte load in flight per
+      // wavefront the 16 wavefronts of a CU keep ~12 KB on the wire, 1.5 TB/s device-wide at ~2 us under load
+      for (int q = 0; q < n_src; ++q) {
+        uint64_t lo, hi;
+        bounds_of(q, bi, lo, hi);
+        if (lo == hi) continue;
         const uint32_t *__restrict__ items = n_src > 1 ? srcs[q] : items0;
-        for (uint64_t base = lo; base < hi; base += NT) {
-          const uint64_t gi = base + tid;
-          const bool in = gi < hi;
-          uint32_t w1 = 0, w2 = 0, cnt = 0;
-          if (in) {
-            const uint32_t *p = items + gi * 3;
-            const uint32_t w0 = p[0];
-            w1 = p[1];
-            w2 = p[2];
-            const uint32_t lk = local_key(w0, w1);
-            uint32_t h = (lk * 0x9E3779B1u) >> (32 - LOGS);
-            while (keys[h] != lk) h = (h + 1) & (NSLOT - 1);
-            cnt = cnts[h];
+        // the records of the trip that starts at `from`: unconditional loads (index clamped into the bucket, lo < hi): straight-line
+        // code, so that the compiler issues all UNR loads before the first wait — a load inside an `if` is followed by
+        // s_waitcnt vmcnt(0) at the end of its block.  (`items` comes out of a select between a kernel argument and a pointer read
+        // from memory: the compiler would use FLAT loads, which count in lgkmcnt as well — every wait for an LDS atomic would
+        // then wait for the loads in flight too; hence the explicit global address space.)
+        typedef const __attribute__((address_space(1))) uint32_t *gptr;
+        const gptr gitems = (gptr)items;
+        auto load_trip = [&](uint64_t from, uint32_t (&w0)[UNR], uint32_t (&w1)[UNR], uint32_t (&w2)[UNR], bool (&in)[UNR]) {
+#pragma unroll
+          for (int u = 0; u < UNR; ++u) {
+            const uint64_t gi = from + (uint64_t)u * NT + tid;
+            in[u] = gi < hi;
+            const gptr p = gitems + (in[u] ? gi : hi - 1) * 3;
+            w0[u] = p[0];
+            w1[u] = p[1];
+            w2[u] = p[2];
           }
-          const bool both = (w1 & 0x24u) == 0;
-          const bool solid = both && cnt >= m;
-          const bool mk = in && (a.mark_mode == 1 ? (both && !solid) : solid);
-          const uint64_t abs = w2 + (uint64_t)((w1 >> 6) & 0xFFu) * a.pos_stride;
-          if (!marks_out) {
-            if (mk) a.solid_bytes[abs - 1] = 1;  // is_solid.set(pos - 1), :464 (or its complement)
+        };
+        uint32_t nw0[UNR], nw1[UNR], nw2[UNR];
+        bool nin[UNR];
+        if constexpr (PF) load_trip(lo, nw0, nw1, nw2, nin);
+        for (uint64_t base = lo; base < hi; base += (uint64_t)NT * UNR) {
+          uint32_t rw0[UNR], rw1[UNR], rw2[UNR];
+          bool rin[UNR];
+          if constexpr (PF) {
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+              rw0[u] = nw0[u];
+              rw1[u] = nw1[u];
+              rw2[u] = nw2[u];
+              rin[u] = nin[u];
+            }
+            // (behind the last trip this asks for the bucket's last record UNR times: in[] comes out all false, nothing is inserted)
+            load_trip(base + (uint64_t)NT * UNR, nw0, nw1, nw2, nin);
           } else {
-            const uint64_t mm = __ballot(mk);
-            if (mm) {
-              uint32_t mbase = 0;
-              if (lane == 0) mbase = atomicAdd(&s_mark_cur, (uint32_t)__builtin_popcountll(mm));
-              mbase = __shfl(mbase, 0, kWave);
-              if (mk) {
-                const uint32_t at = mbase + (uint32_t)__builtin_popcountll(mm & lanemask_lt);
-                if (at + s_agg_cur < a.marks_cap) marks_out[at] = abs - 1;
-                else atomicOr(a.err, 2u);
+            load_trip(base, rw0, rw1, rw2, rin);
+          }
+#pragma unroll
+          for (int u = 0; u < UNR; ++u) {
+            const uint32_t lk = local_key(rw0[u], rw1[u]), w2 = rw2[u];
+            const bool mine = rin[u] && (sub == 0 || (lk >> sub_sh) == rj);
+            // low-complexity reads: when every record of the wavefront instruction carries the same key (a poly-A stretch:
+            // tens of thousands of records of ONE key in a row) one lane inserts for all of them instead of 64 lanes queueing
+            // up at one LDS address
+            const uint64_t mm = __ballot(mine);
+            if (!mm) continue;
+            const int leader = __builtin_ctzll(mm);
+            const bool uniform = __ballot(mine && lk != __shfl(lk, leader, kWave)) == 0 && mm != (1ull << leader);
+            if (!mine || (uniform && lane != leader)) continue;
+            const uint32_t mult = uniform ? (uint32_t)__builtin_popcountll(mm) : 1u;
+            const uint32_t tag = (rw1[u] >> 6) & 0xFFu;
+            // one compare-and-swap + add per record: inside a bucket the records are in read order, equal keys are rarely
+            // neighbours, so grouping the lanes of a wavefront by key (as k_s1_seg does on its sorted segments) saves few atomics
+            // and costs eight ballots per round; the LDS serialises same-address atomics by itself.
+            uint32_t h = (lk * 0x9E3779B1u) >> (32 - LOGS);
+            int probes = 0;
+            const int probe_limit = a.la_chunks;  // (stream mode: the host passes the probe limit here; tests set it to 0)
+            for (; probes < probe_limit; ++probes) {
+              // read_first: most records meet their key already in the table (one key per ~8 records at 60x): a plain LDS read
+              // finds that out without the read-modify-write of a compare-and-swap, which then only the claims of empty slots pay
+              uint32_t old;
+              if (a.read_first) {
+                old = __hip_atomic_load(&keys[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (old == kStreamEmpty) old = atomicCAS(&keys[h], kStreamEmpty, lk);
+              } else {
+                old = atomicCAS(&keys[h], kStreamEmpty, lk);
+              }
+              if (old == kStreamEmpty || old == lk) {
+                atomicAdd(&cnts[h], mult);
+                if (old == kStreamEmpty) {  // only read back when the count stays 1: then this record is the key's only one
+                  fpos[h] = w2;
+                  if (a.pos_stride) ftag[h] = (uint8_t)tag;
+                  const uint32_t at = atomicAdd(&s_nused, 1u);
+                  if (at < (uint32_t)NSLOT) used[at] = (uint16_t)h;
+                  if (at >= geo.max_fill) s_bad = 1;
+                }
+                break;
+              }
+              h = (h + 1) & (NSLOT - 1);
+            }
+            if (probes == probe_limit) s_bad = 1;
+          }
+          if (pipelined && base == lo) fetch_next();  // (thread 0: two loads whose results are wanted at the end of the bucket)
+        }
+      }  // sources
+      __syncthreads();
+      MHX_TT(11)
+      fetch_next();
+      // (s_bad / s_nused are read here, between the barrier behind the inserts and the next one; thread 0 resets them behind that)
+      const bool bad = s_bad != 0;
+      const uint32_t n_claimed = s_nused;
+      const int n_walk = a.used_list ? (int)min(n_claimed, (uint32_t)NSLOT) : NSLOT;  // (the per-key phases walk the same slots in the same order per thread)
+      uint32_t my_agg = 0;
+      if (!bad) {
+        // B: marks, streaming the bucket again
+        if (a.mark_mode != 2 && !a.direct_marks) {
+          for (int q = 0; q < n_src; ++q) {
+            uint64_t lo, hi;
+            bounds_of(q, bi, lo, hi);
+            const uint32_t *__restrict__ items = n_src > 1 ? srcs[q] : items0;
+            for (uint64_t base = lo; base < hi; base += NT) {
+              const uint64_t gi = base + tid;
+              bool in = gi < hi;
+              uint32_t w1 = 0, w2 = 0, cnt = 0;
+              if (in) {
+                const uint32_t *p = items + gi * 3;
+                const uint32_t w0 = p[0];
+                w1 = p[1];
+                w2 = p[2];
+                const uint32_t lk = local_key(w0, w1);
+                in = sub == 0 || (lk >> sub_sh) == rj;  // (a key of another round is not in the table)
+                if (in) {
+                  uint32_t h = (lk * 0x9E3779B1u) >> (32 - LOGS);
+                  while (keys[h] != lk) h = (h + 1) & (NSLOT - 1);
+                  cnt = cnts[h];
+                }
+              }
+              const bool both = (w1 & 0x24u) == 0;
+              const bool solid = both && cnt >= m;
+              const bool mk = in && (a.mark_mode == 1 ? (both && !solid) : solid);
+              const uint64_t abs = w2 + (uint64_t)((w1 >> 6) & 0xFFu) * a.pos_stride;
+              if (!marks_out) {
+                if (mk) a.solid_bytes[abs - 1] = 1;  // is_solid.set(pos - 1), :464 (or its complement)
+              } else {
+                const uint64_t mm = __ballot(mk);
+                if (mm) {
+                  uint32_t mbase = 0;
+                  if (lane == 0) mbase = atomicAdd(&s_mark_cur, (uint32_t)__builtin_popcountll(mm));
+                  mbase = __shfl(mbase, 0, kWave);
+                  if (mk) {
+                    const uint32_t at = mbase + (uint32_t)__builtin_popcountll(mm & lanemask_lt);
+                    if (at + s_agg_cur < a.marks_cap) marks_out[at] = abs - 1;
+                    else atomicOr(a.err, 2u);
+                  }
+                }
               }
             }
+          }  // sources
+        }
+        // C: per distinct key (every occupied slot)
+        for (int it = tid; it < n_walk; it += NT) {
+          const int sl = a.used_list ? (int)used[it] : it;
+          const uint32_t lk = keys[sl];
+          if (lk == kStreamEmpty || (lk & 0x24u) != 0) continue;
+          const uint32_t cnt = cnts[sl];
+          const bool solid = cnt >= m;
+          if (a.mark_mode == 2) {
+            st_both += cnt;
+            if (solid) st_solid += cnt;
+            continue;
           }
-        }
-        }  // sources
-      }
-      // C: per distinct key (every occupied slot)
-      for (int it = tid; it < n_walk; it += NT) {
-        const int sl = a.used_list ? (int)used[it] : it;
-        const uint32_t lk = keys[sl];
-        if (lk == kStreamEmpty || (lk & 0x24u) != 0) continue;
-        const uint32_t cnt = cnts[sl];
-        const bool solid = cnt >= m;
-        if (a.mark_mode == 2) {
-          st_both += cnt;
-          if (solid) st_solid += cnt;
-          continue;
-        }
-        const uint32_t hb = cnt > MHX_MAX_MUL ? (uint32_t)MHX_MAX_MUL : cnt;  // :430-436
-        if (hb < kSegHist) atomicAdd(&lhist[hb], 1u);
-        else atomicAdd(&a.hist[hb], 1ull);
-        if (a.direct_marks && !solid) {  // count 1 < m <= 2: the key's only record (mark_mode 1)
-          if (!marks_out) a.solid_bytes[fpos[sl] - 1] = 1;
-          else {  // multi-GPU: the mark is the global position itself, appended to this workgroup's region
+          const uint32_t hb = cnt > MHX_MAX_MUL ? (uint32_t)MHX_MAX_MUL : cnt;  // :430-436
+          if (hb < kSegHist) atomicAdd(&lhist[hb], 1u);
+          else atomicAdd(&a.hist[hb], 1ull);
+          if (a.direct_marks && !solid) {  // count 1 < m <= 2: the key's only record (mark_mode 1)
             const uint64_t abs = fpos[sl] + (a.pos_stride ? (uint64_t)ftag[sl] * a.pos_stride : 0ull);
-            const uint32_t at = atomicAdd(&s_mark_cur, 1u);
-            if (at + s_agg_cur < a.marks_cap) marks_out[at] = abs - 1;
-            else atomicOr(a.err, 2u);
+            if (!marks_out) a.solid_bytes[abs - 1] = 1;
+            else {  // multi-GPU: the mark is the global position itself, appended to this workgroup's region
+              const uint32_t at = atomicAdd(&s_mark_cur, 1u);
+              if (at + s_agg_cur < a.marks_cap) marks_out[at] = abs - 1;
+              else atomicOr(a.err, 2u);
+            }
+          }
+          if (AGG && solid) {
+            const uint64_t x = edge_of(bi, lk);
+            my_agg += x == rc64(x, k + 1) ? 1u : 2u;
           }
         }
-        if (AGG && solid) {
-          const uint64_t smer = ((uint64_t)bi << 48) | ((uint64_t)(lk >> 6) << (48 - rem));  // the (k-1)-mer, MSB-first
-          const uint64_t x = ((uint64_t)((lk >> 3) & 7u) << 62) | (smer >> 2) | ((uint64_t)(lk & 7u) << (62 - 2 * k));
-          my_agg += x == rc64(x, k + 1) ? 1u : 2u;
-        }
       }
-    }
-    MHX_TT(12)
-    uint32_t agg_at = 0;
-    bool agg_ok = true;
-    if constexpr (AGG) {
-      const uint32_t incl = wave_inclusive_sum(my_agg);
-      const uint32_t tot = __shfl(incl, kWave - 1, kWave);
-      uint32_t wbase = 0;
-      if (lane == 0 && tot) wbase = atomicAdd(&s_agg_cur, tot);
-      wbase = __shfl(wbase, 0, kWave);
-      agg_ok = wbase + tot + (marks_out ? s_mark_cur : 0u) <= a.agg_cap;
-      if (!agg_ok && lane == 0) atomicOr(a.err, 1u);
-      agg_at = wbase + incl - my_agg;
-    }
-    __syncthreads();  // every count has been read: emit, then recycle the slots
-    MHX_TT(13)
-    for (int it = tid; it < n_walk; it += NT) {
-      const int sl = a.used_list ? (int)used[it] : it;
-      const uint32_t lk = keys[sl];
-      if (lk == kStreamEmpty) continue;
+      MHX_TT(12)
+      uint32_t agg_at = 0;
+      bool agg_ok = true;
       if constexpr (AGG) {
-        const uint32_t cnt = cnts[sl];
-        if (!bad && agg_ok && a.mark_mode != 2 && (lk & 0x24u) == 0 && cnt >= m) {
-          const uint64_t mask_k = ~0ull << (64 - 2 * k);
-          const uint64_t smer = ((uint64_t)bi << 48) | ((uint64_t)(lk >> 6) << (48 - rem));
-          const uint64_t x = ((uint64_t)((lk >> 3) & 7u) << 62) | (smer >> 2) | ((uint64_t)(lk & 7u) << (62 - 2 * k));
-          const uint64_t xr = rc64(x, k + 1);
-          const uint64_t mul = cnt > MHX_MAX_MUL ? (uint64_t)MHX_MAX_MUL : cnt;
-          const uint64_t f = ((x << 2) & mask_k) | (1ull << 19) | ((x >> 62) << 16) | mul;
-          agg_end[-1 - (long)agg_at++] = make_uint2((uint32_t)(f >> 32), (uint32_t)f);
-          if (x != xr) {
-            const uint64_t b = ((xr << 2) & mask_k) | (1ull << 19) | ((xr >> 62) << 16) | mul;
-            agg_end[-1 - (long)agg_at++] = make_uint2((uint32_t)(b >> 32), (uint32_t)b);
+        const uint32_t incl = wave_inclusive_sum(my_agg);
+        const uint32_t tot = __shfl(incl, kWave - 1, kWave);
+        uint32_t wbase = 0;
+        if (lane == 0 && tot) wbase = atomicAdd(&s_agg_cur, tot);
+        wbase = __shfl(wbase, 0, kWave);
+        agg_ok = wbase + tot + (marks_out ? s_mark_cur : 0u) <= a.agg_cap;
+        if (!agg_ok && lane == 0) atomicOr(a.err, 1u);
+        agg_at = wbase + incl - my_agg;
+      }
+      __syncthreads();  // every count has been read: emit, then recycle the slots
+      MHX_TT(13)
+      // (a round that gave up may have claimed more slots than the list holds: then the whole table is wiped)
+      const bool wipe_all = bad && n_claimed > (uint32_t)NSLOT;
+      const int n_recycle = wipe_all || !a.used_list ? NSLOT : n_walk;
+      for (int it = tid; it < n_recycle; it += NT) {
+        const int sl = (a.used_list && !wipe_all) ? (int)used[it] : it;
+        const uint32_t lk = keys[sl];
+        if (lk == kStreamEmpty) continue;
+        if constexpr (AGG) {
+          const uint32_t cnt = cnts[sl];
+          if (!bad && agg_ok && a.mark_mode != 2 && (lk & 0x24u) == 0 && cnt >= m) {
+            const uint64_t mask_k = ~0ull << (64 - 2 * k);
+            const uint64_t x = edge_of(bi, lk);
+            const uint64_t xr = rc64(x, k + 1);
+            const uint64_t mul = cnt > MHX_MAX_MUL ? (uint64_t)MHX_MAX_MUL : cnt;
+            const uint64_t f = ((x << 2) & mask_k) | (1ull << 19) | ((x >> 62) << 16) | mul;
+            agg_end[-1 - (long)agg_at++] = make_uint2((uint32_t)(f >> 32), (uint32_t)f);
+            if (x != xr) {
+              const uint64_t b = ((xr << 2) & mask_k) | (1ull << 19) | ((xr >> 62) << 16) | mul;
+              agg_end[-1 - (long)agg_at++] = make_uint2((uint32_t)(b >> 32), (uint32_t)b);
+            }
           }
         }
+        keys[sl] = kStreamEmpty;
+        cnts[sl] = 0;
       }
-      keys[sl] = kStreamEmpty;
-      cnts[sl] = 0;
+      // the next round of this bucket, or the next bucket (uniform: `bad` came out of shared memory behind a barrier)
+      bool bucket_done = false;
+      if (bad) {
+        if ((int)sub >= lk_bits) {  // one key per round and still no room: only a probe limit of 0 (tests) gets here
+          if (tid == 0) atomicOr(a.err, 1u);
+          bucket_done = true;
+        } else {
+          ++sub;
+          rj <<= 1;
+        }
+      } else {
+        ++rj;
+        while (sub > sub_first && (rj & 1u) == 0) {
+          --sub;
+          rj >>= 1;
+        }
+        bucket_done = sub == sub_first && rj == (1u << sub_first);
+      }
+      if (tid == 0) {
+        s_bad = 0;
+        s_nused = 0;
+      }
+      if (bucket_done) publish_next();
+      __syncthreads();
+      MHX_TT(14)
+      if (bucket_done) break;
     }
-    if (bad && tid == 0) {
-      atomicOr(a.err, 1u);
-      s_bad = 0;
-    }
-    __syncthreads();
-    MHX_TT(14)
   }
   if (a.mark_mode == 2) {
     st_solid = wave_sum(st_solid);
@@ -1719,7 +1996,7 @@ static void s1_groups_launch(mhx_ctx *c, const uint32_t *sorted, uint64_t n_item
   const uint64_t n_tiles = div_ceil(n_items, T);
   const int full_words = kmer_bits / 32, rem = kmer_bits % 32;
   const uint32_t last_mask = rem ? 0xFFFFFFFFu << (32 - rem) : 0;
-  const uint64_t pos_stride = COMPACT && s1_rank_tagged(c, (uint32_t)k) ? c->global_bases / (uint64_t)c->n_parts : 0;
+  const uint64_t pos_stride = COMPACT ? s1_pos_stride(c, (uint32_t)k) : 0;
   S1Op<S, COMPACT, AGG> op{k, agg_items, KWv, m, s.start.as<uint64_t>(), s.n_seqs, s.fixed_len, is_solid, solid_bits, mark_atomic, mark_mode, hist, ctr, want_mercy, mercy, ctr + 1, pos_stride,
                            nullptr, nullptr};
   if (mark_mode == 2) {  // statistics on every 64th tile (no output): solid fraction -> marking polarity
@@ -1847,28 +2124,78 @@ static std::vector<SortPass> s1_sort_passes(uint32_t k) {
   const int KWv = s1_kw(k), kmer_bits = (int)(k - 1) * 2;
   return make_passes_ranges(KWv, {{0, 6}, {KWv * 32 - kmer_bits, KWv * 32}});
 }
-// Stage-1 sort plan.  seg_bits > 0: only the top seg_bits of the (k-1)-mer are sorted and k_s1_seg groups the equal keys
-// of each segment (no-mercy 12-byte records); the width is chosen so that a segment holds ~100 records on average
-// (n_eff = items of the whole job: a rank of a multi-GPU run owns 1/n_parts of the key space).
+// Stage-1 sort plan.  seg_bits > 0: only the top seg_bits of the (k-1)-mer are sorted and an LDS group-by counts the equal
+// keys of each segment (no-mercy 12-byte records).
+//   stream: one workgroup streams one bucket of the seg_bits-bit prefix (k_s1_stream).  The width follows the DENSITY of the
+//   job — records per lv1 bucket where the group-by runs — so that a streamed bucket holds at most s1_stream_max records
+//   (a third of which are distinct keys at 60x coverage: what the 8192-slot table takes with room to spare) whatever the job
+//   size: 16 bits and two LSD passes up to s1_stream_max records per lv1 bucket (10 M reads per GPU), the same two passes
+//   with 2^sub0 sub-rounds per bucket up to 2^s1_stream_sub_max times that (a second read of the bucket is cheaper than a
+//   third pass over all records), beyond that 17..24 bits in three passes.  A bucket that overflows anyway splits itself
+//   (k_s1_stream): no job size and no single bucket sends the stage anywhere else.
+//   otherwise: k_s1_seg on tiles, the width chosen so that a segment holds ~100 records.
 struct S1Plan {
   std::vector<SortPass> passes;
   int seg_bits;
-  bool stream;  // seg_bits == 16 and one workgroup streams one lv1 bucket (k_s1_stream) instead of tiles (k_s1_seg)
+  bool stream;
+  int sub0 = 0;            // stream: sub-rounds every bucket starts with (log2)
+  double per_bucket = 0;   // the density the plan was made for
 };
+// records per lv1 bucket at the group-by: the items of the whole job over the buckets in play.  A rank of a multi-GPU run
+// owns 1/n_parts of the key space; under a bucket filter (memory plan) the announced item count of the kept buckets stands
+// for the call's own (the plan is made before the kept items are counted, and every later look must give the same plan);
+// comm.hip sets the figure the ranks agreed on (s1_density).
+static double s1_density(const mhx_ctx *c, uint64_t n_items) {
+  if (c->s1_density > 0) return c->s1_density;
+  const double n = c->filter_on ? (double)c->filter_expected : (double)n_items;
+  const double buckets = c->filter_on && c->filter_kept ? (double)c->filter_kept : (double)MHX_NUM_BUCKETS;
+  return n * (double)(c->n_parts > 1 ? c->n_parts : 1) / buckets;
+}
+// LSD passes over the top `pbits` key bits in digits of about equal width (<= 8 bits); every pass after the first declares
+// the bits sorted before it: the consumers of these plans count equal keys, the order of records equal in all sorted bits is
+// free (SortPass::prev_lo)
+static std::vector<SortPass> s1_prefix_passes(int pbits) {
+  const int np = (pbits + 7) / 8, lo = 64 - pbits;
+  std::vector<SortPass> p;
+  int at = lo;
+  for (int i = 0; i < np; ++i) {
+    const int w = pbits / np + (i < pbits % np ? 1 : 0);
+    SortPass sp{at, w, 0, 0};
+    sp.prev_lo = i ? lo : -1;
+    p.push_back(sp);
+    at += w;
+  }
+  return p;
+}
 static S1Plan s1_plan(const mhx_ctx *c, uint32_t k, uint64_t n_items, bool compact, int want_mercy, bool allow_stream = true) {
   const int force_bits = (int)c->opt("s1_seg_bits", 0);
   const int kmer_bits = (int)(k - 1) * 2;
   S1Plan p{s1_sort_passes(k), 0, false};
   if (!c->opt("s1_seg", 1) || !compact || want_mercy || s1_kw(k) != 2 || s1_stride(k, compact) != 3 || !n_items) return p;
-  const double n_eff = (double)n_items * (double)(c->n_parts > 1 ? c->n_parts : 1);
-  // two passes + bucket streaming while a bucket's distinct keys fit the LDS table (~1/8 of its records are distinct at
-  // 60x coverage; a fuller table sends the host to the tile kernel below)
-  if (allow_stream && c->opt("s1_stream", 1) && !force_bits && k >= 10 && k <= 22 && n_eff / 65536.0 <= (double)c->opt("s1_stream_max", 40000)) {
-    p.seg_bits = 16;
+  const double per_bucket = s1_density(c, n_items);
+  p.per_bucket = per_bucket;
+  if (allow_stream && c->opt("s1_stream", 1) && !force_bits && k >= 10 && k <= 22) {
+    const double cap = (double)std::max<long long>(1, c->opt("s1_stream_max", 40000));
+    const int sub_max = (int)std::min<long long>(std::max<long long>(c->opt("s1_stream_sub_max", 1), 0), 6);
+    int need = 0;  // the buckets have to be 2^need times finer than the lv1 buckets
+    while (need < 30 && per_bucket > cap * (double)(1ull << need)) ++need;
+    int pbits = 16, sub0 = 0;
+    if (need <= sub_max) sub0 = need;
+    else {
+      pbits = std::min(16 + need, 24);
+      sub0 = std::min(16 + need - pbits, 6);  // (past 24 bits: the rest as sub-rounds; the kernel splits further if it has to)
+    }
+    if (const long long f = c->opt("s1_stream_bits", 0)) pbits = (int)std::min<long long>(std::max<long long>(f, 9), 24);
+    const long long fs = c->opt("s1_stream_sub0", -1);
+    if (fs >= 0) sub0 = (int)std::min<long long>(fs, 6);
+    pbits = std::min(pbits, kmer_bits);
+    p.seg_bits = pbits;
     p.stream = true;
-    p.passes = make_passes(2, 48, 64);
+    p.sub0 = sub0;
+    p.passes = s1_prefix_passes(pbits);
     return p;
   }
+  const double n_eff = per_bucket * (double)MHX_NUM_BUCKETS;
   int bits = 8;
   while (bits < 32 && n_eff / 96.0 > (double)(1ull << bits)) bits += 8;
   if (force_bits) bits = force_bits;
@@ -1877,22 +2204,43 @@ static S1Plan s1_plan(const mhx_ctx *c, uint32_t k, uint64_t n_items, bool compa
   p.passes = make_passes(2, 64 - bits, 64);
   return p;
 }
-// compact 1-word aux when no mercy candidates are wanted and positions fit 32 bits
-// Multi-GPU with more than 2^32 global base positions: compact records keep a rank-local 32-bit position and carry the
-// source rank in the unused key bits between head/tail and the (k-1)-mer (needs 8 spare bits and the rank-stride layout
-// of megahit_amd/dist.py: rank r's reads start at r * stride, stride = global_bases / n_parts < 2^32).
-bool s1_rank_tagged(const mhx_ctx *c, uint32_t k) {
-  static const bool force = getenv("MHX_S1_FORCE_TAGGED") != nullptr;  // tests: take this path at small sizes too
-  if (!c->global_bases || (c->global_bases < (1ull << 32) && !force) || c->n_parts < 1 || c->n_parts > 256) return false;
-  if (c->global_bases % (uint64_t)c->n_parts) return false;
-  const uint64_t stride = c->global_bases / (uint64_t)c->n_parts;
-  const int spare = 32 * s1_kw(k) - (int)(k - 1) * 2 - 6;
-  return stride < (1ull << 32) && c->pos_base == stride * (uint64_t)c->my_part && c->seqs.n_bases <= stride && spare >= 8;
+// what a caller may print: "stream p16 s0 2 passes" / "seg 24" / "full sort"
+std::string s1_plan_text(const mhx_ctx *c, uint32_t k, uint64_t n_items) {
+  const S1Plan p = s1_plan(c, k, n_items, s1_compact(c, k, 0), 0);
+  char buf[128];
+  if (p.stream) snprintf(buf, sizeof buf, "stream p%d sub%d %zu passes (%.0f records per lv1 bucket)", p.seg_bits, p.sub0, p.passes.size(), p.per_bucket);
+  else if (p.seg_bits) snprintf(buf, sizeof buf, "seg p%d %zu passes", p.seg_bits, p.passes.size());
+  else snprintf(buf, sizeof buf, "full sort %zu passes", p.passes.size());
+  return buf;
 }
+// Compact records (12 bytes at k <= 29: key + one position word) whenever no mercy candidates are wanted and the positions
+// fit: below 2^pos_bits bases as they are, beyond that with the upper position bits as a tag inside the key words
+// (s1_pos_tag: 8 spare bits between the (k-1)-mer and head/tail, i.e. up to 2^(pos_bits + 8) bases: 7 G reads of 150 bp).
+uint32_t s1_pos_bits(const mhx_ctx *c) {
+  static const bool force = getenv("MHX_S1_FORCE_TAGGED") != nullptr;  // tests: tags at small sizes too
+  const long long f = c->opt("s1_pos_bits", 0);
+  if (f > 0) return (uint32_t)std::min<long long>(std::max<long long>(f, 4), 32);
+  if (force) {  // the narrowest position word that keeps the tags below 128
+    const uint64_t n_bits = c->global_bases ? c->global_bases : c->seqs.n_bases;
+    uint32_t b = 4;
+    while (b < 32 && (n_bits >> b) >= 128) ++b;
+    return b;
+  }
+  return 32;
+}
+bool s1_rank_tagged(const mhx_ctx *c, uint32_t k) {
+  const uint64_t n_bits = c->global_bases ? c->global_bases : c->seqs.n_bases;
+  const uint32_t pb = s1_pos_bits(c);
+  if ((n_bits >> pb) == 0) return false;  // every tag is 0
+  const int spare = 32 * s1_kw(k) - (int)(k - 1) * 2 - 6;
+  return spare >= 8 && (n_bits >> pb) < 256;
+}
+// global position = position word + tag * s1_pos_stride (0: no tags in this read set)
+uint64_t s1_pos_stride(const mhx_ctx *c, uint32_t k) { return s1_rank_tagged(c, k) ? 1ull << s1_pos_bits(c) : 0ull; }
 bool s1_compact(const mhx_ctx *c, uint32_t k, int want_mercy) {
   if (want_mercy) return false;
   const uint64_t n_bits = c->global_bases ? c->global_bases : c->seqs.n_bases;
-  return n_bits < (1ull << 32) || s1_rank_tagged(c, k);
+  return (n_bits >> s1_pos_bits(c)) == 0 || s1_rank_tagged(c, k);
 }
 int s1_stride(uint32_t k, bool compact) {
   const int kw = s1_kw(k);
@@ -1900,42 +2248,67 @@ int s1_stride(uint32_t k, bool compact) {
   return kw + 1 == 3 ? 3 : round_up2(kw + 1);  // 12-byte records are supported natively, other odd widths are padded
 }
 
-// items of the local reads -> c->ws("items_a"); returns their number
+// items of the local reads -> c->ws("items_a"); returns their number.
+// Three ways, fastest first: (1) deferred — only the digit histograms of the coming sort are taken here and the sort's first
+// pass makes the records itself (fixed-length reads, 12-byte records; under a bucket filter that pass drops the items of
+// the other buckets: c->s1_filter_in_gen); (2) the window-arithmetic extraction; (3) the general kernels.
+static bool s1_shape_is_fast(const mhx_ctx *c, uint32_t k, bool compact) {
+  const SeqSet &s = c->seqs;
+  return s.n_seqs && s.fixed_len >= k + 1 && compact && s1_kw(k) == 2 && s1_stride(k, compact) == 3 && k <= 29 && c->opt("s1_extract_fast", 1) != 0;
+}
+// can a bucket filter be applied inside the generating first pass (instead of extraction batches + a keep/drop split)?
+bool s1_filter_in_gen_applies(const mhx_ctx *c, uint32_t k) {
+  const bool compact = s1_compact(c, k, 0);
+  if (!c->filter_on || !c->opt("s1_filter_in_gen", 1) || !s1_shape_is_fast(c, k, compact) || !c->opt("s1_fused_first_pass", 1)) return false;
+  if (!c->opt("s1_digit_hist_blocked", 1) || !c->opt("s1_digit_hist_plain", 1) || !c->opt("s1_gen_any_order", 1) || !c->opt("sort_unit_runs", 1)) return false;
+  const uint64_t n_slots = (uint64_t)c->seqs.n_seqs * (c->seqs.fixed_len - k + 4);
+  const S1Plan plan = s1_plan(c, k, n_slots, compact, 0);
+  // (the plans whose digits are bit fields of the first key word: the prefix plans)
+  return plan.seg_bits > 0 && (int)plan.passes.size() <= kFastPasses && sort_takes_generated_first_pass(c, std::max<uint64_t>(c->filter_expected, 1), 3, plan.passes);
+}
+
 uint64_t s1_extract(mhx_ctx *c, uint32_t k, bool compact) {
   SeqSet &s = c->seqs;
   if (k < 9 || k > MHX_MAX_K) throw Error("read2sdbg: k out of range [9,255]");
   const int KWv = s1_kw(k), S = s1_stride(k, compact);
   const uint64_t ns = s.n_seqs;
   hipStream_t st = c->stream;
+  const bool filter_in_gen = c->s1_filter_in_gen;
+  c->s1_filter_in_gen = false;
   uint32_t *cnt = c->ws("seq_item_cnt", (ns + 1) * 4).as<uint32_t>();
   uint64_t *item_start = c->ws("seq_item_start", (ns + 2) * 8).as<uint64_t>();
   uint64_t n_items = 0;
-  if (ns) {
+  const bool shape_fast = s1_shape_is_fast(c, k, compact);
+  if (ns && shape_fast && s.fixed_len >= k + 1) {
+    n_items = ns * (uint64_t)(s.fixed_len - k + 4);  // (no per-read table for reads of one length)
+  } else if (ns) {
     MHX_LAUNCH(c, "item_counts", (double)ns * 12,
                hipLaunchKernelGGL(k_s1_item_counts, dim3((unsigned)div_ceil(ns, 256)), dim3(256), 0, st, s.start.as<uint64_t>(), ns, k, cnt));
     exclusive_scan_u32_u64(c, cnt, item_start, ns, item_start + ns + 1);
     MHX_HIP(hipMemcpyAsync(&n_items, item_start + ns + 1, 8, hipMemcpyDeviceToHost, st));
     MHX_HIP(hipStreamSynchronize(st));
   }
+  if (filter_in_gen && !(shape_fast && n_items)) throw Error("s1_extract: the bucket filter was left to a generating pass that does not apply");
   const size_t item_bytes = (size_t)S * 4;
-  uint32_t *buf_a = c->ws("items_a", n_items * item_bytes + 64).as<uint32_t>();
+  // (deferred + filtered: the buffer is sized once the kept items are counted)
+  uint32_t *buf_a = filter_in_gen ? nullptr : c->ws("items_a", n_items * item_bytes + 64).as<uint32_t>();
   if (n_items) {
     const unsigned grid = 256 * 8;
     const bool fixed = s.fixed_len >= k + 1 && n_items == (uint64_t)ns * (s.fixed_len - k + 4);
-    const bool tagged = compact && s1_rank_tagged(c, k);
-    const uint64_t pos_base = tagged ? 0 : c->pos_base;
-    const uint32_t rank_tag = tagged ? (uint32_t)c->my_part << 6 : 0u;
+    const uint64_t pos_base = c->pos_base;
+    const uint32_t pos_bits = s1_pos_bits(c);
     // the stage-1 sort's digit histograms come for free while the records are still in registers (fixed-length path)
     DigitSpecs specs;
     specs.n = 0;
     unsigned long long *pre_hist = nullptr;
     c->pre_hist_buf = nullptr;
+    std::vector<SortPass> plan_passes;
     if (fixed && S <= 4) {
-      const std::vector<SortPass> passes = s1_plan(c, k, n_items, compact, compact ? 0 : 1).passes;
-      if ((int)passes.size() <= kMaxFusedPasses) {
-        c->pre_hist_sig = passes_signature(passes);
-        specs.n = (int)passes.size();
-        for (int p = 0; p < specs.n; ++p) specs.d[p] = spec_of_pass(passes[p], KWv);
+      plan_passes = s1_plan(c, k, n_items, compact, compact ? 0 : 1).passes;
+      if ((int)plan_passes.size() <= kMaxFusedPasses) {
+        c->pre_hist_sig = passes_signature(plan_passes);
+        specs.n = (int)plan_passes.size();
+        for (int p = 0; p < specs.n; ++p) specs.d[p] = spec_of_pass(plan_passes[p], KWv);
         pre_hist = c->ws("sort_pre_hist", (size_t)kMaxFusedPasses * 256 * 8).as<unsigned long long>();
         MHX_HIP(hipMemsetAsync(pre_hist, 0, (size_t)specs.n * 256 * 8, st));
         c->pre_hist_buf = buf_a;
@@ -1943,41 +2316,43 @@ uint64_t s1_extract(mhx_ctx *c, uint32_t k, bool compact) {
         c->pre_hist_passes = specs.n;
       }
     }
-    const bool fast = fixed && compact && KWv == 2 && S == 3 && k <= 29 && specs.n <= kFastPasses && c->opt("s1_extract_fast", 1) != 0;
+    const bool fast = fixed && shape_fast && specs.n <= kFastPasses;
     if (fast) {
       const int it = (int)c->opt("s1_extract_items", 4);
       const uint32_t per = s.fixed_len - k + 4;
       // Deferred items: the caller sorts right away (run_s1, the multi-GPU pre-sort), so only the digit histograms are taken
       // here and the first sort pass makes the records itself (S1Gen): "items_a" stays empty until that pass has run.
-      const bool defer = c->s1_defer_items && pre_hist && c->opt("s1_fused_first_pass", 1) &&
-                         sort_takes_generated_first_pass(c, n_items, 3, s1_plan(c, k, n_items, compact, 0).passes);
+      const bool defer = filter_in_gen || (c->s1_defer_items && pre_hist && c->opt("s1_fused_first_pass", 1) &&
+                                           sort_takes_generated_first_pass(c, n_items, 3, plan_passes));
 #define MHX_FAST(ITV, WR, NAME)                                                                                                        \
   do {                                                                                                                                 \
     const unsigned fgrid = (unsigned)std::min<uint64_t>(div_ceil(n_items, 256 * ITV), 256 * 8);                                        \
     const uint64_t stride_items = (uint64_t)fgrid * 256 * ITV;                                                                         \
     MHX_LAUNCH(c, NAME, (WR ? (double)n_items * item_bytes : 0.0) + (double)s.n_bases / 4,                                             \
                hipLaunchKernelGGL((k_s1_extract_fast<ITV, WR>), dim3(fgrid), dim3(256), 0, st, s.words.as<uint32_t>(), s.fixed_len, per, n_items, \
-                                  (int)k, pos_base, rank_tag, buf_a, specs, pre_hist, (uint32_t)(stride_items / per), (uint32_t)(stride_items % per))); \
+                                  (int)k, pos_base, pos_bits, buf_a, specs, pre_hist, (uint32_t)(stride_items / per), (uint32_t)(stride_items % per))); \
   } while (0)
       bool hi_only = true;  // every digit of the plan comes from the first key word?
       for (int p = 0; p < specs.n; ++p) hi_only = hi_only && specs.d[p].wi1 == 0 && (!specs.d[p].mask2 || specs.d[p].wi2 == 0);
       if (defer) {
+        const uint32_t *keep = filter_in_gen ? c->work["filter_bits"].as<uint32_t>() : nullptr;
+        bool plain = hi_only && c->opt("s1_digit_hist_blocked", 1) && c->opt("s1_digit_hist_plain", 1) != 0;  // every digit one bit field of the first key word?
+        HiDigits hd;
+        hd.n = specs.n;
+        for (int p = 0; p < specs.n; ++p) {
+          plain = plain && specs.d[p].mask2 == 0 && specs.d[p].wi1 == 0 && specs.d[p].bit1 < 32;
+          hd.sh[p] = specs.d[p].bit1;
+          hd.mk[p] = specs.d[p].mask1;
+        }
+        if (filter_in_gen && !plain) throw Error("s1_extract: the bucket filter was left to a generating pass that does not apply");
         if (hi_only && c->opt("s1_digit_hist_blocked", 1)) {
           constexpr int ITH = 8;
           const unsigned fgrid = (unsigned)std::min<uint64_t>(div_ceil(n_items, 256 * ITH), 256 * 8);
           const uint64_t stride_items = (uint64_t)fgrid * 256 * ITH;
-          HiDigits hd;
-          hd.n = specs.n;
-          bool plain = c->opt("s1_digit_hist_plain", 1) != 0;  // every digit one bit field of the first key word?
-          for (int p = 0; p < specs.n; ++p) {
-            plain = plain && specs.d[p].mask2 == 0 && specs.d[p].wi1 == 0 && specs.d[p].bit1 < 32;
-            hd.sh[p] = specs.d[p].bit1;
-            hd.mk[p] = specs.d[p].mask1;
-          }
 #define MHX_PLAIN2(NPV, PREV)                                                                                                                \
   MHX_LAUNCH(c, "s1_digit_hist", (double)s.n_bases / 4,                                                                                      \
              hipLaunchKernelGGL((k_s1_digit_hist_plain<ITH, NPV, PREV>), dim3(fgrid), dim3(256), 0, st, s.words.as<uint32_t>(), s.fixed_len, per, \
-                                n_items, (int)k, hd, pre_hist, (uint32_t)(stride_items / per), (uint32_t)(stride_items % per)))
+                                n_items, (int)k, hd, pre_hist, (uint32_t)(stride_items / per), (uint32_t)(stride_items % per), keep))
 #define MHX_PLAIN(NPV) MHX_PLAIN2(NPV, false)
           // s1_digit_hist_preload: window words requested up front (needs at least 8 slots per read)
           if (plain && specs.n == 2 && per >= 8 && c->opt("s1_digit_hist_preload", 0) != 0) MHX_PLAIN2(2, true);
@@ -1994,34 +2369,53 @@ uint64_t s1_extract(mhx_ctx *c, uint32_t k, bool compact) {
         } else {
           MHX_FAST(4, false, "s1_digit_hist");
         }
-        const S1Gen g{s.words.as<uint32_t>(), s.fixed_len, per, (int)k, pos_base, rank_tag};
+        uint64_t n_records = n_items;  // what the generating pass will leave
+        if (filter_in_gen) {  // the kept items = the sum of any one digit histogram
+          std::vector<unsigned long long> h0(256);
+          MHX_HIP(hipMemcpyAsync(h0.data(), pre_hist, 256 * 8, hipMemcpyDeviceToHost, st));
+          MHX_HIP(hipStreamSynchronize(st));
+          n_records = 0;
+          for (unsigned long long v : h0) n_records += v;
+          if (n_records > c->filter_expected) throw Error("bucket filter: more items in the kept buckets than announced");
+          buf_a = c->ws("items_a", n_records * item_bytes + 64).as<uint32_t>();
+          c->pre_hist_buf = buf_a;
+          c->pre_hist_n = n_records;
+        }
         // The consumers of this pass (the LDS group-bys behind the remaining passes; compact records, no mercy) count equal
         // keys: they need the records grouped, not in input order — so the first pass may place the records of a digit in
         // any order (the later passes are stable with respect to whatever order it leaves).
         const bool any_order = c->opt("s1_gen_any_order", 1) != 0;
         // s1_gen_blocked: consecutive items per thread (S1GenBlocked) — only where the order inside a digit is free
         const bool blocked = any_order && per >= 8 && c->opt("s1_gen_blocked", 0) != 0;
-        const S1GenBlocked gb{s.words.as<uint32_t>(), s.fixed_len, per, (int)k, pos_base, rank_tag, (uint32_t)(kSortThreads * 8) / per,
-                              (uint32_t)(kSortThreads * 8) % per};
-        c->gen_first_pass = [g, gb, any_order, blocked](const OnesweepLaunch &l) {
-          if (l.unit_runs && l.wi == 0 && blocked)
-            hipLaunchKernelGGL((k_radix_onesweep_u<3, 8, 3, S1GenBlocked, true, 0>), dim3(l.grid), dim3(kSortThreads), 0, l.stream, gb, l.out, l.n, l.ds, l.nbits,
-                               l.bin_start, l.status, l.ticket, l.err, l.tag, l.xcd_units);
-          else if (l.unit_runs && l.wi == 0 && any_order)  // (the digits of this plan lie in the first key word)
-            hipLaunchKernelGGL((k_radix_onesweep_u<3, 8, 3, S1Gen, true, 0>), dim3(l.grid), dim3(kSortThreads), 0, l.stream, g, l.out, l.n, l.ds, l.nbits,
-                               l.bin_start, l.status, l.ticket, l.err, l.tag, l.xcd_units);
-          else if (l.unit_runs && l.wi == 0)
-            hipLaunchKernelGGL((k_radix_onesweep_u<3, 8, 3, S1Gen, false, 0>), dim3(l.grid), dim3(kSortThreads), 0, l.stream, g, l.out, l.n, l.ds, l.nbits,
-                               l.bin_start, l.status, l.ticket, l.err, l.tag, l.xcd_units);
-          else if (any_order)
-            hipLaunchKernelGGL((k_radix_onesweep<3, 8, 3, S1Gen, true>), dim3(l.grid), dim3(kSortThreads), 0, l.stream, g, l.out, l.n, l.ds, l.nbits,
-                               l.bin_start, l.status, l.ticket, l.err, l.tag, l.xcd_units);
-          else
-            hipLaunchKernelGGL((k_radix_onesweep<3, 8, 3, S1Gen, false>), dim3(l.grid), dim3(kSortThreads), 0, l.stream, g, l.out, l.n, l.ds, l.nbits,
-                               l.bin_start, l.status, l.ticket, l.err, l.tag, l.xcd_units);
+        const S1GenT<false> g{s.words.as<uint32_t>(), s.fixed_len, per, (int)k, pos_base, pos_bits, nullptr};
+        const S1GenT<true> gf{s.words.as<uint32_t>(), s.fixed_len, per, (int)k, pos_base, pos_bits, keep};
+        const S1GenBlockedT<false> gb{s.words.as<uint32_t>(), s.fixed_len, per, (int)k, pos_base, pos_bits, (uint32_t)(kSortThreads * 8) / per,
+                                      (uint32_t)(kSortThreads * 8) % per, nullptr};
+        const S1GenBlockedT<true> gbf{s.words.as<uint32_t>(), s.fixed_len, per, (int)k, pos_base, pos_bits, (uint32_t)(kSortThreads * 8) / per,
+                                      (uint32_t)(kSortThreads * 8) % per, keep};
+        c->gen_first_pass = [g, gf, gb, gbf, any_order, blocked, filter_in_gen](const OnesweepLaunch &l) {
+#define MHX_GEN(KERNEL, SRCT, RANKV, SRCV)                                                                                              \
+  hipLaunchKernelGGL((KERNEL<3, 8, 3, SRCT, RANKV>), dim3(l.grid), dim3(kSortThreads), 0, l.stream, SRCV, l.out, l.n, l.ds, l.nbits, l.bin_start, \
+                     l.status, l.ticket, l.err, l.tag, l.xcd_units)
+#define MHX_GEN_U(SRCT, RANKV, SRCV)                                                                                                    \
+  hipLaunchKernelGGL((k_radix_onesweep_u<3, 8, 3, SRCT, RANKV, 0>), dim3(l.grid), dim3(kSortThreads), 0, l.stream, SRCV, l.out, l.n, l.ds, l.nbits, \
+                     l.bin_start, l.status, l.ticket, l.err, l.tag, l.xcd_units)
+          if (filter_in_gen) {  // (s1_filter_in_gen_applies vouched for unit-wide runs, digits in the first key word, any order)
+            if (!(l.unit_runs && l.wi == 0 && any_order)) throw Error("s1: the filtering generator needs the unit-wide pass on a first-word digit");
+            if (blocked) MHX_GEN_U(S1GenBlockedT<true>, 1, gbf);
+            else MHX_GEN_U(S1GenT<true>, 1, gf);
+          } else if (l.unit_runs && l.wi == 0 && blocked) MHX_GEN_U(S1GenBlockedT<false>, 1, gb);
+          else if (l.unit_runs && l.wi == 0 && any_order) MHX_GEN_U(S1GenT<false>, 1, g);  // (the digits of this plan lie in the first key word)
+          else if (l.unit_runs && l.wi == 0) MHX_GEN_U(S1GenT<false>, 0, g);
+          else if (any_order) MHX_GEN(k_radix_onesweep, S1GenT<false>, true, g);
+          else MHX_GEN(k_radix_onesweep, S1GenT<false>, false, g);
+#undef MHX_GEN
+#undef MHX_GEN_U
         };
         c->gen_buf = buf_a;
-        c->gen_n = n_items;
+        c->gen_n = n_records;
+        c->gen_slots = n_items;
+        n_items = n_records;
       } else if (it >= 8) MHX_FAST(8, true, "s1_extract");
       else if (it >= 4) MHX_FAST(4, true, "s1_extract");
       else if (it >= 2) MHX_FAST(2, true, "s1_extract");
@@ -2029,17 +2423,22 @@ uint64_t s1_extract(mhx_ctx *c, uint32_t k, bool compact) {
 #undef MHX_FAST
       c->s1_defer_items = false;
     } else {
+      if (ns && shape_fast) {  // (the per-read table was skipped above: the general kernels want it)
+        MHX_LAUNCH(c, "item_counts", (double)ns * 12,
+                   hipLaunchKernelGGL(k_s1_item_counts, dim3((unsigned)div_ceil(ns, 256)), dim3(256), 0, st, s.start.as<uint64_t>(), ns, k, cnt));
+        exclusive_scan_u32_u64(c, cnt, item_start, ns, item_start + ns + 1);
+      }
 #define MHX_S1X(SV, CP)                                                                                                      \
   do {                                                                                                                       \
     if (fixed) {                                                                                                             \
       MHX_LAUNCH(c, "s1_extract", (double)n_items * item_bytes + (double)s.n_bases / 4,                                      \
                  hipLaunchKernelGGL((k_s1_extract_fixed<KW, SV, CP>), dim3((unsigned)std::min<uint64_t>(div_ceil(n_items, 256), 256 * 16)), \
                                     dim3(256), 0, st, s.words.as<uint32_t>(), s.fixed_len, s.fixed_len - k + 4, n_items, (int)k, \
-                                    pos_base, rank_tag, buf_a, specs, pre_hist));                                               \
+                                    pos_base, pos_bits, buf_a, specs, pre_hist));                                               \
     } else                                                                                                                   \
       MHX_LAUNCH(c, "s1_extract", (double)n_items * item_bytes + (double)s.n_bases / 4,                                      \
                  hipLaunchKernelGGL((k_s1_extract<KW, SV, CP>), dim3(grid), dim3(256), 0, st, s.words.as<uint32_t>(),        \
-                                    s.start.as<uint64_t>(), item_start, ns, (int)k, pos_base, rank_tag, buf_a));              \
+                                    s.start.as<uint64_t>(), item_start, ns, (int)k, pos_base, pos_bits, buf_a));              \
   } while (0)
     MHX_DISPATCH_KW(KWv, {
       if (compact) {
@@ -2061,114 +2460,161 @@ uint64_t s1_extract(mhx_ctx *c, uint32_t k, bool compact) {
 bool s1_presort_applies(const mhx_ctx *c, uint32_t k, uint64_t n_local_items) {
   return s1_plan(c, k, n_local_items, s1_compact(c, k, 0), 0).stream;
 }
-// the two LSD passes that order this rank's stage-1 records by lv1 bucket (the first half of s1_process on the stream plan)
-uint32_t *s1_presort(mhx_ctx *c, uint32_t k, uint32_t *buf_a, uint32_t *buf_b, uint64_t n_items) {
-  // (the passes of the stream plan, whatever s1_plan would say for THIS rank's item count: the ranks decided together)
-  uint32_t *sorted = radix_sort(c, buf_a, buf_b, n_items, 3, s1_kw(k), make_passes(2, 48, 64));
+// the LSD passes that order this rank's stage-1 records by the plan's prefix (the first half of s1_process on the stream
+// plan; the ranks agreed on the density the plan follows: mhx_ctx::s1_density)
+uint32_t *s1_presort(mhx_ctx *c, uint32_t k, uint32_t *buf_a, uint32_t *buf_b, uint64_t n_items, int *pbits) {
+  const S1Plan plan = s1_plan(c, k, std::max<uint64_t>(n_items, 1), true, 0);
+  if (!plan.stream) throw Error("s1_presort: the bucket-streaming plan does not apply");
+  *pbits = plan.seg_bits;
+  uint32_t *sorted = n_items ? radix_sort(c, buf_a, buf_b, n_items, 3, s1_kw(k), plan.passes) : buf_a;
   c->pre_hist_buf = nullptr;
   return sorted;
 }
 
-int s1_process(mhx_ctx *c, uint32_t k, uint32_t m, int want_mercy, uint32_t *buf_a, uint32_t *buf_b, uint64_t n_items,
-               mhx_s1_result *out, const S1Sources *pre) {
-  SeqSet &s = c->seqs;
-  const bool compact = s1_compact(c, k, want_mercy);
-  const int KWv = s1_kw(k), S = s1_stride(k, compact);
-  const size_t item_bytes = (size_t)S * 4;
-  hipStream_t st = c->stream;
-  const bool global = c->global_bases != 0;  // multi-GPU: positions index the global read set
-  const int kmer_bits = (int)(k - 1) * 2;
-  // want_mercy == 2: records with equal keys in exactly the order the reference's kmsort leaves them (H1)
-  // pre: the records come pre-sorted by lv1 bucket in several arrays (multi-GPU: one per sending rank, comm.hip); n_items
-  // is their total.  Only the bucket-streaming group-by reads them in place; if it gives up, they are gathered and the
-  // function continues as if they had arrived unsorted.
-  S1Plan plan = s1_plan(c, k, n_items, compact, want_mercy);
-  if (pre && (!plan.stream || want_mercy || !compact)) throw Error("s1_process: pre-sorted sources need the bucket-streaming plan");
-  // (records that carry their source rank between the (k-1)-mer and head/tail must not be ordered by whole key words)
-  const bool tagged_keys = compact && s1_rank_tagged(c, k);
-  uint32_t *sorted = pre ? nullptr
-                     : want_mercy == 2
-                         ? kmsort_exact(c, buf_a, buf_b, n_items, S, KWv)
-                         : (plan.seg_bits || tagged_keys ? radix_sort(c, buf_a, buf_b, n_items, S, KWv, plan.passes)
-                                                         : sort_whole_key(c, buf_a, buf_b, n_items, S, KWv, plan.passes));
-  c->pre_hist_buf = nullptr;
-  uint32_t *spare = pre ? pre->spare : (sorted == buf_a ? buf_b : buf_a);
-
-  const uint64_t n_bits = global ? c->global_bases : s.n_bases;
-  // MHX_S1_MARK: atomic (atomicOr into the bitmap) | solid | nonsolid (force the byte-map polarity) | unset = auto
-  const char *mark_env = getenv("MHX_S1_MARK");
-  const int mark_atomic = mark_env && !strcmp(mark_env, "atomic") ? 1 : 0;
-  // multi-GPU with sparse marks (comm.hip): the marks of the non-solid occurrences leave this function as a list of
-  // global positions (ws "s1_marks", c->n_marks) to be routed to the read owners; no bitmap / byte map of the GLOBAL read
-  // set exists unless the classic tile kernel has to run (then its byte map is converted to the list)
-  const bool sparse = global && !mark_atomic && c->opt("dist_sparse_marks", 0) != 0;
-  const uint64_t n_words64 = sparse ? 0 : div_ceil(n_bits, 64);
-  unsigned long long *is_solid = c->result(MHX_BUF_IS_SOLID, (n_words64 + 1) * 8).as<unsigned long long>();
-  c->results[MHX_BUF_IS_SOLID].used = n_words64 * 8;
-  unsigned long long *hist = c->result(MHX_BUF_MUL_HIST, (MHX_MAX_MUL + 1) * 8).as<unsigned long long>();
-  // accumulate (bucket-range passes after the first, passes.hip): marks, histogram, aggregated stage-2 items and
-  // mercy candidates of the earlier passes are kept and the published results are cumulative
-  const bool acc = c->accumulate && c->s1_acc_bits == n_bits && c->s1_acc_k == k && c->s1_acc_m == m;
+// ---- stage 1 behind the extraction, in steps (Read2SdbgS1::Lv2Postprocess and what it needs, read_to_sdbg_s1.cpp:368-555) ----
+//   sort_records   the plan's passes (or the reference-exact order for want_mercy == 2)
+//   open_outputs   is_solid / histogram / marks / aggregated stage-2 items, continued or fresh (bucket-range passes accumulate)
+//   polarity       mark the solid or the non-solid occurrences (a 1/64 sample decides on a single GPU)
+//   group_partial  the LDS group-bys on partially sorted records (bucket streaming, segments), with their ways back
+//   group_classic  full sort + k_tile_groups (mercy, wide keys, every give-up)
+//   publish        bitmap, counters, mercy candidates, result buffers
+namespace {
+struct S1Stage {
+  mhx_ctx *c;
+  uint32_t k, m;
+  int want_mercy;
+  uint32_t *buf_a, *buf_b;
+  uint64_t n_items;
+  const S1Sources *pre;
+  SeqSet &s;
+  hipStream_t st;
+  bool compact, global, tagged_keys;
+  int KWv, S, kmer_bits;
+  size_t item_bytes;
+  uint64_t pos_stride;
+  S1Plan plan;
+  uint32_t *sorted = nullptr, *spare = nullptr;
+  // outputs
+  uint64_t n_bits = 0, n_words64 = 0;
+  int mark_atomic = 0;
+  const char *mark_env = nullptr;
+  bool sparse = false, acc = false;
+  unsigned long long *is_solid = nullptr, *hist = nullptr, *ctr = nullptr;
   uint8_t *solid_bytes = nullptr;
-  const uint64_t marks_prev = sparse && acc ? c->n_marks : 0;  // marks of the earlier bucket-range passes stay in front
-  if (!sparse || !acc) c->n_marks = 0;
-  auto ensure_byte_map = [&]() {  // (sparse: only when the classic kernel runs; always zeroed, its marks are collected below)
+  uint64_t marks_prev = 0, seg_marks = 0;
+  bool classic_ran = false;
+  long long *mercy = nullptr;
+  bool agg = false;
+  uint2 *agg_items = nullptr;
+  uint64_t *agg_cursor = nullptr;
+  uint64_t agg_prev = 0, agg_bound = 0;
+  uint32_t seg_grid = 0, seg_cap = 0, seg_mcap = 0;
+  uint32_t *seg_err = nullptr;
+  int mark_mode = 0, mark_mode_used = 0;
+
+  S1Stage(mhx_ctx *c_, uint32_t k_, uint32_t m_, int wm, uint32_t *a, uint32_t *b, uint64_t n, const S1Sources *pre_)
+      : c(c_), k(k_), m(m_), want_mercy(wm), buf_a(a), buf_b(b), n_items(n), pre(pre_), s(c_->seqs), st(c_->stream) {
+    compact = s1_compact(c, k, want_mercy);
+    KWv = s1_kw(k);
+    S = s1_stride(k, compact);
+    item_bytes = (size_t)S * 4;
+    global = c->global_bases != 0;  // multi-GPU: positions index the global read set
+    kmer_bits = (int)(k - 1) * 2;
+    // (records that carry position bits between the (k-1)-mer and head/tail must not be ordered by whole key words)
+    tagged_keys = compact && s1_rank_tagged(c, k);
+    pos_stride = compact ? s1_pos_stride(c, k) : 0;
+    plan = s1_plan(c, k, n_items, compact, want_mercy);
+    // pre: the records come pre-sorted by the plan's prefix in several arrays (multi-GPU: one per sending rank, comm.hip);
+    // n_items is their total.  Only the bucket-streaming group-by reads them in place; if it gives up, they are gathered and
+    // the stage continues as if they had arrived unsorted.
+    if (pre && (!plan.stream || want_mercy || !compact)) throw Error("s1_process: pre-sorted sources need the bucket-streaming plan");
+    if (pre && pre->pbits != plan.seg_bits) throw Error("s1_process: the sources were sorted for another plan than the one this rank makes");
+  }
+
+  void sort_records() {
+    // want_mercy == 2: records with equal keys in exactly the order the reference's kmsort leaves them (H1)
+    sorted = pre ? nullptr
+             : want_mercy == 2
+                 ? kmsort_exact(c, buf_a, buf_b, n_items, S, KWv)
+                 : (plan.seg_bits || tagged_keys ? radix_sort(c, buf_a, buf_b, n_items, S, KWv, plan.passes)
+                                                 : sort_whole_key(c, buf_a, buf_b, n_items, S, KWv, plan.passes));
+    c->pre_hist_buf = nullptr;
+    set_spare(pre ? pre->spare : (sorted == buf_a ? buf_b : buf_a));
+  }
+  void set_spare(uint32_t *sp) {
+    spare = sp;
+    mercy = reinterpret_cast<long long *>(spare);  // mercy candidates (<= 2 per item, 8 B each): S*4 >= 16 bytes per item
+  }
+  void ensure_byte_map() {  // (sparse: only when the classic kernel runs; always zeroed, its marks are collected afterwards)
     if (solid_bytes) return;
     const uint64_t nw = div_ceil(n_bits, 64);
     solid_bytes = c->ws("solid_bytes", (nw + 1) * 64).as<uint8_t>();
     if (!acc || sparse) MHX_HIP(hipMemsetAsync(solid_bytes, 0, (nw + 1) * 64, st));
-  };
-  if (mark_atomic) {
-    if (!acc) MHX_HIP(hipMemsetAsync(is_solid, 0, (n_words64 + 1) * 8, st));
-  } else {
-    if (!sparse) ensure_byte_map();
-    MHX_HIP(hipMemsetAsync(is_solid + n_words64, 0, 8, st));
   }
-  bool classic_ran = false;
-  uint64_t seg_marks = 0;  // sparse: marks the segment kernel left in ws "s1_marks_seg"
-  if (!acc) MHX_HIP(hipMemsetAsync(hist, 0, (MHX_MAX_MUL + 1) * 8, st));
-  c->s1_acc_bits = n_bits;
-  c->s1_acc_k = k;
-  c->s1_acc_m = m;
-  unsigned long long *ctr = c->ws("s1_counters", 64).as<unsigned long long>();
-  MHX_HIP(hipMemsetAsync(ctr, 0, 64, st));
-
-  uint64_t n_solid = 0, n_mercy = 0;
-  int s1_mark_mode_used = 0;
-  // mercy candidates (<= 2 per item, 8 B each) go to the spare sort buffer: S*4 >= 16 bytes per item
-  long long *mercy = reinterpret_cast<long long *>(spare);
-  // aggregated stage-2 items (k <= 22, m >= 2): at most 2 per solid run, a solid run has >= m records
-  static const bool agg_off = getenv("MHX_S2_PER_OCCURRENCE") != nullptr;
-  const bool agg = !agg_off && k <= 22 && m >= 2 && KWv == 2;
-  const bool agg_continues = acc && c->agg_valid && c->agg_k == k && c->agg_m == m;
-  c->agg_valid = false;
-  uint2 *agg_items = nullptr;
-  uint64_t *agg_cursor = c->ws("s2_agg_cursor", 64).as<uint64_t>();
-  const uint64_t agg_prev = agg_continues ? c->agg_n : 0;  // items of the earlier passes stay in front
-  const uint64_t agg_bound = (n_items / m + 16) * 2;
-  auto agg_prepare_classic = [&]() {  // k_tile_groups appends to the dense array through a global cursor
+  void open_outputs() {
+    n_bits = global ? c->global_bases : s.n_bases;
+    // MHX_S1_MARK: atomic (atomicOr into the bitmap) | solid | nonsolid (force the byte-map polarity) | unset = auto
+    mark_env = getenv("MHX_S1_MARK");
+    mark_atomic = mark_env && !strcmp(mark_env, "atomic") ? 1 : 0;
+    // multi-GPU with sparse marks (comm.hip): the marks of the non-solid occurrences leave this stage as a list of
+    // global positions (ws "s1_marks", c->n_marks) to be routed to the read owners; no bitmap / byte map of the GLOBAL read
+    // set exists unless the classic tile kernel has to run (then its byte map is converted to the list)
+    sparse = global && !mark_atomic && c->opt("dist_sparse_marks", 0) != 0;
+    n_words64 = sparse ? 0 : div_ceil(n_bits, 64);
+    is_solid = c->result(MHX_BUF_IS_SOLID, (n_words64 + 1) * 8).as<unsigned long long>();
+    c->results[MHX_BUF_IS_SOLID].used = n_words64 * 8;
+    hist = c->result(MHX_BUF_MUL_HIST, (MHX_MAX_MUL + 1) * 8).as<unsigned long long>();
+    // accumulate (bucket-range passes after the first, passes.hip): marks, histogram, aggregated stage-2 items and
+    // mercy candidates of the earlier passes are kept and the published results are cumulative
+    acc = c->accumulate && c->s1_acc_bits == n_bits && c->s1_acc_k == k && c->s1_acc_m == m;
+    marks_prev = sparse && acc ? c->n_marks : 0;  // marks of the earlier bucket-range passes stay in front
+    if (!sparse || !acc) c->n_marks = 0;
+    if (mark_atomic) {
+      if (!acc) MHX_HIP(hipMemsetAsync(is_solid, 0, (n_words64 + 1) * 8, st));
+    } else {
+      if (!sparse) ensure_byte_map();
+      MHX_HIP(hipMemsetAsync(is_solid + n_words64, 0, 8, st));
+    }
+    if (!acc) MHX_HIP(hipMemsetAsync(hist, 0, (MHX_MAX_MUL + 1) * 8, st));
+    c->s1_acc_bits = n_bits;
+    c->s1_acc_k = k;
+    c->s1_acc_m = m;
+    ctr = c->ws("s1_counters", 64).as<unsigned long long>();
+    MHX_HIP(hipMemsetAsync(ctr, 0, 64, st));
+    // aggregated stage-2 items (k <= 22, m >= 2): at most 2 per solid run, a solid run has >= m records
+    static const bool agg_off = getenv("MHX_S2_PER_OCCURRENCE") != nullptr;
+    agg = !agg_off && k <= 22 && m >= 2 && KWv == 2;
+    const bool agg_continues = acc && c->agg_valid && c->agg_k == k && c->agg_m == m;
+    c->agg_valid = false;
+    agg_cursor = c->ws("s2_agg_cursor", 64).as<uint64_t>();
+    agg_prev = agg_continues ? c->agg_n : 0;  // items of the earlier passes stay in front
+    agg_bound = (n_items / m + 16) * 2;
+    seg_err = c->ws("s1_seg_err", 64).as<uint32_t>();
+  }
+  void agg_prepare_classic() {  // k_tile_groups appends to the dense array through a global cursor
     if (!agg) return;
     agg_items = grow_preserving(c, c->work["s2_agg_items"], (agg_prev + agg_bound) * 8, agg_prev * 8).as<uint2>();
     MHX_HIP(hipMemsetAsync(agg_cursor, 0, 24, st));
     if (agg_prev) MHX_HIP(hipMemcpyAsync(agg_cursor, &agg_prev, 8, hipMemcpyHostToDevice, st));
-  };
-  uint32_t seg_grid = 0, seg_cap = 0, seg_mcap = 0;
-  // segment group-by (k_s1_seg) on the partially sorted records
-  uint32_t *seg_err = c->ws("s1_seg_err", 64).as<uint32_t>();
-  auto seg_launch = [&](int mode) {
+  }
+
+  // the LDS group-bys on the partially sorted records: k_s1_stream (one bucket of the plan's prefix per workgroup at a time) or
+  // k_s1_seg (tiles).  mode = mark_mode (2: statistics on a 1/64 sample)
+  void launch_partial(int mode) {
     const int per = (int)c->opt("s1_seg_per", 8);
     const int la = (int)std::min<long long>(std::max<long long>(c->opt("s1_seg_la", 3), 0), 200);  // 16-bit tile counters
     const int T = 256 * (per == 4 ? 4 : 8);
     const uint64_t n_tiles = div_ceil(n_items, (uint64_t)T);
     const uint32_t stride = mode == 2 ? 64u : 1u;
-    const uint64_t n_work = plan.stream ? MHX_NUM_BUCKETS / stride : div_ceil(n_tiles, stride);
-    const uint64_t pos_stride = s1_rank_tagged(c, k) ? c->global_bases / (uint64_t)c->n_parts : 0;
+    const uint64_t n_buckets = plan.stream ? 1ull << plan.seg_bits : 0;
+    const uint64_t n_work = plan.stream ? div_ceil(n_buckets, stride) : div_ceil(n_tiles, stride);
     const uint32_t pfx_mask = plan.seg_bits >= 32 ? 0xFFFFFFFFu : ~(0xFFFFFFFFu >> plan.seg_bits);
     const uint32_t eq_mask1 = (kmer_bits > 32 ? ~(0xFFFFFFFFu >> (kmer_bits - 32)) : 0u) | 63u;
     const bool agg_on = agg && mode != 2;
     // s1_stream_half: two 512-thread workgroups with 4096-slot tables per CU instead of one with 1024 threads and 8192 slots
     const bool half = plan.stream && c->opt("s1_stream_half", 0) != 0;
-    const unsigned grid = (unsigned)std::min<uint64_t>(n_work, plan.stream ? (half ? 512 : 256) : (per == 4 ? 256 * 6 : 256 * 3));
+    const uint64_t cus = c->n_cus > 0 ? (uint64_t)c->n_cus : 256;
+    const unsigned grid = (unsigned)std::min<uint64_t>(n_work, plan.stream ? (half ? 2 * cus : cus) : (per == 4 ? 256 * 6 : 256 * 3));
     // per-workgroup output regions in the spare sort buffer (S*4 >= 12 bytes per record, outputs are 8-byte entries)
     const uint32_t region = (uint32_t)std::min<uint64_t>(n_items * (uint64_t)S * 4 / 8 / grid, 0xFFFFFFF0u);
     uint2 *raw = nullptr;
@@ -2192,49 +2638,56 @@ int s1_process(mhx_ctx *c, uint32_t k, uint32_t m, int want_mercy, uint32_t *buf
       seg_mcap = mcap;
     }
     // the stream kernel marks the non-solid occurrences from its table when each of them is its key's only record
-    const int direct = plan.stream && mode == 1 && m <= 2 && (mraw || (pos_stride == 0 && solid_bytes)) && c->opt("s1_stream_direct", 1) ? 1 : 0;
+    const int direct = plan.stream && mode == 1 && m <= 2 && (mraw || solid_bytes) && c->opt("s1_stream_direct", 1) ? 1 : 0;
     S1SegArgs a{(int)k, m, pfx_mask, eq_mask1, solid_bytes, mode, hist, ctr, raw, seg_cap, counts, mraw, mcap, mcounts, pos_stride, seg_err,
                 plan.stream ? (int)c->opt("s1_stream_probes", 1024) : la, direct, c->opt("s1_stream_used_list", 1) != 0 ? 1 : 0,
                 c->opt("s1_stream_read_first", 0) != 0 ? 1 : 0};
     MHX_HIP(hipMemsetAsync(seg_err, 0, 4, st));
     const char *nm = mode == 2 ? "s1_sample" : "s1_groups";
-    const double bytes = plan.stream ? (double)n_items * 12 / stride : (double)n_work * T * 12;
+    const double bytes = plan.stream ? (double)n_items * 12 / stride * (double)(1u << plan.sub0) : (double)n_work * T * 12;
     if (plan.stream) {
       const int n_src = pre && sorted == nullptr ? pre->n : 1;
-      uint64_t *bounds = c->ws("s1_bucket_bounds", (size_t)n_src * (MHX_NUM_BUCKETS + 1) * 8 + 64).as<uint64_t>();
+      uint64_t *bounds = c->ws("s1_bucket_bounds", (size_t)n_src * (n_buckets + 1) * 8 + 64).as<uint64_t>();
       uint32_t *ticket = c->ws("s1_stream_ticket", 64).as<uint32_t>();
       MHX_HIP(hipMemsetAsync(ticket, 0, 4, st));
+      const unsigned bgrid = (unsigned)((n_buckets + 1 + 255) / 256);
       const uint32_t *const *srcs = nullptr;
       if (n_src > 1 || (pre && sorted == nullptr)) {
         DevBuf &sp = c->ws("s1_src_ptrs", (size_t)n_src * 8 + 64);
         MHX_HIP(hipMemcpyAsync(sp.p, pre->ptr.data(), (size_t)n_src * 8, hipMemcpyHostToDevice, st));
         srcs = sp.as<const uint32_t *>();
         for (int q = 0; q < n_src; ++q)
-          hipLaunchKernelGGL(k_bucket_bounds, dim3(MHX_NUM_BUCKETS / 256 + 1), dim3(256), 0, st, pre->ptr[q], pre->count[q], 3,
-                             bounds + (size_t)q * (MHX_NUM_BUCKETS + 1));
+          hipLaunchKernelGGL(k_bucket_bounds, dim3(bgrid), dim3(256), 0, st, pre->ptr[q], pre->count[q], 3, bounds + (size_t)q * (n_buckets + 1),
+                             plan.seg_bits);
       } else {
-        hipLaunchKernelGGL(k_bucket_bounds, dim3(MHX_NUM_BUCKETS / 256 + 1), dim3(256), 0, st, sorted, n_items, 3, bounds);
+        MHX_LAUNCH(c, "bucket_bounds", (double)n_buckets * 8 * 30,
+                   hipLaunchKernelGGL(k_bucket_bounds, dim3(bgrid), dim3(256), 0, st, sorted, n_items, 3, bounds, plan.seg_bits));
       }
       const uint32_t *items0 = pre && sorted == nullptr ? pre->ptr[0] : sorted;
       const int unr = (int)c->opt("s1_stream_unroll", 4);  // 8: measured no better than 4
-#define MHX_STREAM(AGGV, UV) \
-  MHX_LAUNCH(c, nm, bytes, hipLaunchKernelGGL((k_s1_stream<AGGV, UV>), dim3(grid), dim3(kStreamThreads), 0, st, items0, bounds, a, stride, ticket, srcs, n_src))
+      const bool pf = c->opt("s1_stream_prefetch", 0) != 0;
+      const uint32_t nslot = half ? 4096u : 8192u;
+      const S1StreamGeom geo{plan.seg_bits, plan.sub0, pf && c->opt("s1_stream_next_bucket", 1) ? 1 : 0, (uint32_t)n_buckets,
+                             (uint32_t)std::min<long long>(std::max<long long>(c->opt("s1_stream_fill", nslot * 7 / 8), 1), nslot)};
+#define MHX_STREAM(AGGV, UV, NTV, LOGV, PFV)                                                                                               \
+  MHX_LAUNCH(c, nm, bytes, hipLaunchKernelGGL((k_s1_stream<AGGV, UV, NTV, LOGV, PFV>), dim3(grid), dim3(NTV), 0, st, items0, bounds, a, geo, \
+                                              stride, ticket, srcs, n_src))
+#define MHX_STREAM_PF(AGGV, UV, NTV, LOGV) \
+  do {                                     \
+    if (pf) MHX_STREAM(AGGV, UV, NTV, LOGV, true); \
+    else MHX_STREAM(AGGV, UV, NTV, LOGV, false);   \
+  } while (0)
       if (half) {
-        if (agg_on)
-          MHX_LAUNCH(c, nm, bytes, hipLaunchKernelGGL((k_s1_stream<true, 4, 512, 12>), dim3(grid), dim3(512), 0, st, items0, bounds, a, stride, ticket, srcs, n_src));
-        else
-          MHX_LAUNCH(c, nm, bytes, hipLaunchKernelGGL((k_s1_stream<false, 4, 512, 12>), dim3(grid), dim3(512), 0, st, items0, bounds, a, stride, ticket, srcs, n_src));
+        if (agg_on) MHX_STREAM_PF(true, 4, 512, 12);
+        else MHX_STREAM_PF(false, 4, 512, 12);
       } else if (agg_on) {
-        if (unr >= 8) MHX_STREAM(true, 8);
-        else if (unr >= 4) MHX_STREAM(true, 4);
-        else if (unr >= 2) MHX_STREAM(true, 2);
-        else MHX_STREAM(true, 1);
+        if (unr >= 8) MHX_STREAM_PF(true, 8, kStreamThreads, 13);
+        else MHX_STREAM_PF(true, 4, kStreamThreads, 13);
       } else {
-        if (unr >= 8) MHX_STREAM(false, 8);
-        else if (unr >= 4) MHX_STREAM(false, 4);
-        else if (unr >= 2) MHX_STREAM(false, 2);
-        else MHX_STREAM(false, 1);
+        if (unr >= 8) MHX_STREAM_PF(false, 8, kStreamThreads, 13);
+        else MHX_STREAM_PF(false, 4, kStreamThreads, 13);
       }
+#undef MHX_STREAM_PF
 #undef MHX_STREAM
       return;
     }
@@ -2248,195 +2701,228 @@ int s1_process(mhx_ctx *c, uint32_t k, uint32_t m, int want_mercy, uint32_t *buf
       else MHX_SEG(8, false);
     }
 #undef MHX_SEG
-  };
-  bool seg_failed = false;
-  if (n_items) {
-    // marking polarity from a 1/64 sample of the tiles: when most occurrences are solid it is cheaper to mark the
-    // non-solid ones (each mark is a 32-byte partial HBM write).  Single GPU only: ranks must agree on the meaning.
-    int mark_mode = 0;
-    const bool can_invert = !global && !mark_atomic && !c->filter_on && !c->accumulate;  // passes must agree on the meaning
-#define MHX_ARGS(WM) c, sorted, n_items, KWv, kmer_bits, m, solid_bytes, is_solid, mark_atomic, hist, ctr, WM, mercy, (int)k, agg_items, agg_cursor, mark_mode
-#define MHX_CASE(SV)                                                          \
-  case SV:                                                                    \
-    if (compact) s1_groups_launch<SV, true, false>(MHX_ARGS(0));              \
-    else s1_groups_launch<SV, false, false>(MHX_ARGS(want_mercy));            \
-    break;
-#define MHX_ALL_CASES                                                                                                            \
-  switch (S) {                                                                                                                   \
-    MHX_CASE(3) MHX_CASE(4) MHX_CASE(6) MHX_CASE(8) MHX_CASE(10) MHX_CASE(12) MHX_CASE(14) MHX_CASE(16) MHX_CASE(18) MHX_CASE(20) \
-    default: throw Error("read2sdbg_s1: unsupported record stride");                                                             \
   }
+
+  template <int SV, bool CP, bool AGGV>
+  void classic_case(int wm) {
+    s1_groups_launch<SV, CP, AGGV>(c, sorted, n_items, KWv, kmer_bits, m, solid_bytes, is_solid, mark_atomic, hist, ctr, wm, mercy, (int)k, agg_items,
+                                   agg_cursor, mark_mode);
+  }
+  void launch_classic_plain() {  // k_tile_groups without aggregated items
+#define MHX_CASE(SV)                                  \
+  case SV:                                            \
+    if (compact) classic_case<SV, true, false>(0);    \
+    else classic_case<SV, false, false>(want_mercy);  \
+    break;
+    switch (S) {
+      MHX_CASE(3) MHX_CASE(4) MHX_CASE(6) MHX_CASE(8) MHX_CASE(10) MHX_CASE(12) MHX_CASE(14) MHX_CASE(16) MHX_CASE(18) MHX_CASE(20)
+      default: throw Error("read2sdbg_s1: unsupported record stride");
+    }
+#undef MHX_CASE
+  }
+
+  // marking polarity from a 1/64 sample: when most occurrences are solid it is cheaper to mark the non-solid ones (each
+  // mark is a partial HBM write).  Single GPU only: ranks must agree on the meaning.
+  void polarity() {
+    const bool can_invert = !global && !mark_atomic && !c->filter_on && !c->accumulate;  // passes must agree on the meaning
     // multi-GPU: every rank marks the NON-solid occurrences of the buckets it owns (a fixed convention, so that the
-    // summed bitmaps mean the same on all ranks; typical inputs are mostly solid, see the polarity note above);
+    // summed bitmaps mean the same on all ranks; typical inputs are mostly solid);
     // mhx_adopt_is_solid_slice turns "valid position and not marked" into the local is_solid
     if (global && !mark_atomic) mark_mode = 1;
+    // bucket-range passes (memory plan): the same fixed convention, so that the passes' marks add up — and the bucket
+    // streaming takes them straight from its table (direct_marks)
+    else if ((c->filter_on || c->accumulate) && !mark_atomic && !mark_env) mark_mode = 1;
     else if (can_invert && mark_env && !strcmp(mark_env, "nonsolid")) mark_mode = 1;
     else if (can_invert && !mark_env && n_items > (1u << 16)) {
       mark_mode = 2;
-      if (plan.seg_bits) seg_launch(2);
-      else MHX_ALL_CASES
+      if (plan.seg_bits) launch_partial(2);
+      else launch_classic_plain();
       unsigned long long hs[3] = {0, 0, 0};
       MHX_HIP(hipMemcpyAsync(hs, ctr, 24, hipMemcpyDeviceToHost, st));
       MHX_HIP(hipStreamSynchronize(st));
       mark_mode = hs[2] > 0 && hs[0] * 2 > hs[2] ? 1 : 0;
       MHX_HIP(hipMemsetAsync(ctr, 0, 64, st));
     }
-    if (plan.seg_bits) {
-      // histogram / aggregate cursor as they are now, in case a tile gives up and the classic path has to redo the job
-      unsigned long long *hist_save = c->ws("s1_hist_save", (MHX_MAX_MUL + 1) * 8).as<unsigned long long>();
-      MHX_HIP(hipMemcpyAsync(hist_save, hist, (MHX_MAX_MUL + 1) * 8, hipMemcpyDeviceToDevice, st));
-    seg_again:
-      seg_launch(mark_mode);
-      uint32_t e = 0;
-      std::vector<uint32_t> h_counts(agg ? seg_grid : 0), h_mcounts(sparse ? seg_grid : 0);
-      MHX_HIP(hipMemcpyAsync(&e, seg_err, 4, hipMemcpyDeviceToHost, st));
-      if (agg) MHX_HIP(hipMemcpyAsync(h_counts.data(), c->work["s2_agg_counts"].p, (size_t)seg_grid * 4, hipMemcpyDeviceToHost, st));
-      if (sparse) MHX_HIP(hipMemcpyAsync(h_mcounts.data(), c->work["s1_mark_counts"].p, (size_t)seg_grid * 4, hipMemcpyDeviceToHost, st));
-      MHX_HIP(hipStreamSynchronize(st));
-      if (!e && sparse) {  // pack the workgroups' mark regions (they live in the spare sort buffer) behind the earlier passes' marks
-        for (uint32_t v : h_mcounts) seg_marks += v;
-        unsigned long long *dense = grow_preserving(c, c->work["s1_marks"], (marks_prev + seg_marks) * 8 + 64, marks_prev * 8).as<unsigned long long>();
-        if (seg_marks)
-          MHX_LAUNCH(c, "marks_compact", (double)seg_marks * 16,
-                     hipLaunchKernelGGL(k_agg_compact, dim3(seg_grid, 8), dim3(256), 0, st, reinterpret_cast<const uint2 *>(spare), seg_mcap,
-                                        c->work["s1_mark_counts"].as<uint32_t>(), reinterpret_cast<uint2 *>(dense + marks_prev), 0));
-        c->n_marks = marks_prev + seg_marks;
-      }
-      if (!e && agg) {  // pack the workgroups' regions behind the items of the earlier passes
-        uint64_t total = 0;
-        for (uint32_t v : h_counts) total += v;
-        uint2 *dense = grow_preserving(c, c->work["s2_agg_items"], (agg_prev + total) * 8 + 64, agg_prev * 8).as<uint2>();
-        if (total)
-          MHX_LAUNCH(c, "agg_compact", (double)total * 16,
-                     hipLaunchKernelGGL(k_agg_compact, dim3(seg_grid, 8), dim3(256), 0, st, reinterpret_cast<const uint2 *>(spare), seg_cap,
-                                        c->work["s2_agg_counts"].as<uint32_t>(), dense + agg_prev, 1));
-        const uint64_t agg_n = agg_prev + total;
-        MHX_HIP(hipMemcpyAsync(agg_cursor, &agg_n, 8, hipMemcpyHostToDevice, st));
-        MHX_HIP(hipStreamSynchronize(st));  // agg_n is a stack variable
-      }
-      if (e && plan.stream) {  // a bucket with too many distinct keys for the LDS table: three passes + the tile kernel
-        MHX_HIP(hipMemcpyAsync(hist, hist_save, (MHX_MAX_MUL + 1) * 8, hipMemcpyDeviceToDevice, st));
-        MHX_HIP(hipMemsetAsync(ctr, 0, 64, st));
-        if (pre && sorted == nullptr) {  // gather the sources: from here on they are one unsorted array
-          buf_a = c->ws("s1_gather_a", n_items * item_bytes + 64).as<uint32_t>();
-          buf_b = c->ws("s1_gather_b", n_items * item_bytes + 64).as<uint32_t>();
-          uint64_t at = 0;
-          for (int q = 0; q < pre->n; ++q) {
-            if (pre->count[q]) MHX_HIP(hipMemcpyAsync(buf_a + at * S, pre->ptr[q], pre->count[q] * item_bytes, hipMemcpyDeviceToDevice, st));
-            at += pre->count[q];
-          }
-          sorted = buf_a;
-        }
-        plan = s1_plan(c, k, n_items, compact, want_mercy, false);
-        uint32_t *other = sorted == buf_a ? buf_b : buf_a;
-        sorted = radix_sort(c, sorted, other, n_items, S, KWv, plan.passes);
-        spare = sorted == buf_a ? buf_b : buf_a;
-        mercy = reinterpret_cast<long long *>(spare);
-        seg_marks = 0;
-        goto seg_again;
-      }
-      if (e) {  // a segment beyond the look-ahead or a full table: full sort + the classic tile kernel (marks are idempotent)
-        seg_failed = true;
-        MHX_HIP(hipMemcpyAsync(hist, hist_save, (MHX_MAX_MUL + 1) * 8, hipMemcpyDeviceToDevice, st));
-        MHX_HIP(hipMemsetAsync(ctr, 0, 64, st));
-        uint32_t *other = sorted == buf_a ? buf_b : buf_a;
-        sorted = tagged_keys ? radix_sort(c, sorted, other, n_items, S, KWv, s1_sort_passes(k)) : sort_whole_key(c, sorted, other, n_items, S, KWv, s1_sort_passes(k));
-        spare = sorted == buf_a ? buf_b : buf_a;
-        mercy = reinterpret_cast<long long *>(spare);
-      }
-    }
-    if (!(plan.seg_bits && !seg_failed)) {
-      agg_prepare_classic();
-      ensure_byte_map();
-      classic_ran = true;
-    }
-    if (plan.seg_bits && !seg_failed) {
-    } else if (agg && S == 3) s1_groups_launch<3, true, true>(MHX_ARGS(0));
-    else if (agg && S == 4 && !compact) s1_groups_launch<4, false, true>(MHX_ARGS(want_mercy));
-    else MHX_ALL_CASES
-#undef MHX_ALL_CASES
-#undef MHX_CASE
-#undef MHX_ARGS
-    s1_mark_mode_used = mark_mode;
+  }
 
-  }
-  if (!n_items) agg_prepare_classic();  // no launch at all: the cursor still has to hold the earlier passes' count
-  if (agg && (S == 3 || (S == 4 && !compact))) {  // also with zero local items: every rank takes the same stage-2 path
-    c->agg_n = 0;
-    MHX_HIP(hipMemcpyAsync(&c->agg_n, agg_cursor, 8, hipMemcpyDeviceToHost, st));
-    c->agg_valid = true;
-    c->agg_k = k;
-    c->agg_m = m;
-  }
-  if (sparse && classic_ran) {  // the classic kernel marked a byte map of the global read set: turn it into the list
-    const uint64_t n_bytes = div_ceil(n_bits, 64) * 64;
-    unsigned long long *cur = c->ws("s1_mark_cursor", 64).as<unsigned long long>();
-    MHX_HIP(hipMemsetAsync(cur, 0, 8, st));
-    // upper bound of the marks: every record
-    unsigned long long *dense = grow_preserving(c, c->work["s1_marks"], (marks_prev + n_items) * 8 + 64, marks_prev * 8).as<unsigned long long>();
-    MHX_LAUNCH(c, "collect_marks", (double)n_bytes,
-               hipLaunchKernelGGL(k_collect_marks, dim3((unsigned)div_ceil(n_bytes, 256 * 16)), dim3(256), 0, st, solid_bytes, n_bytes,
-                                  dense + marks_prev, cur));
-    uint64_t got = 0;
-    MHX_HIP(hipMemcpyAsync(&got, cur, 8, hipMemcpyDeviceToHost, st));
+  // one run of the partial group-by: launch, read its error word and region counts back, pack the regions.  -> error word
+  uint32_t run_partial() {
+    launch_partial(mark_mode);
+    uint32_t e = 0;
+    std::vector<uint32_t> h_counts(agg ? seg_grid : 0), h_mcounts(sparse ? seg_grid : 0);
+    MHX_HIP(hipMemcpyAsync(&e, seg_err, 4, hipMemcpyDeviceToHost, st));
+    if (agg) MHX_HIP(hipMemcpyAsync(h_counts.data(), c->work["s2_agg_counts"].p, (size_t)seg_grid * 4, hipMemcpyDeviceToHost, st));
+    if (sparse) MHX_HIP(hipMemcpyAsync(h_mcounts.data(), c->work["s1_mark_counts"].p, (size_t)seg_grid * 4, hipMemcpyDeviceToHost, st));
     MHX_HIP(hipStreamSynchronize(st));
-    c->n_marks = marks_prev + got;
+    if (e) return e;
+    if (sparse) {  // pack the workgroups' mark regions (they live in the spare sort buffer) behind the earlier passes' marks
+      for (uint32_t v : h_mcounts) seg_marks += v;
+      unsigned long long *dense = grow_preserving(c, c->work["s1_marks"], (marks_prev + seg_marks) * 8 + 64, marks_prev * 8).as<unsigned long long>();
+      if (seg_marks)
+        MHX_LAUNCH(c, "marks_compact", (double)seg_marks * 16,
+                   hipLaunchKernelGGL(k_agg_compact, dim3(seg_grid, 8), dim3(256), 0, st, reinterpret_cast<const uint2 *>(spare), seg_mcap,
+                                      c->work["s1_mark_counts"].as<uint32_t>(), reinterpret_cast<uint2 *>(dense + marks_prev), 0));
+      c->n_marks = marks_prev + seg_marks;
+    }
+    if (agg) {  // pack the workgroups' regions behind the items of the earlier passes
+      uint64_t total = 0;
+      for (uint32_t v : h_counts) total += v;
+      uint2 *dense = grow_preserving(c, c->work["s2_agg_items"], (agg_prev + total) * 8 + 64, agg_prev * 8).as<uint2>();
+      if (total)
+        MHX_LAUNCH(c, "agg_compact", (double)total * 16,
+                   hipLaunchKernelGGL(k_agg_compact, dim3(seg_grid, 8), dim3(256), 0, st, reinterpret_cast<const uint2 *>(spare), seg_cap,
+                                      c->work["s2_agg_counts"].as<uint32_t>(), dense + agg_prev, 1));
+      const uint64_t agg_n = agg_prev + total;
+      MHX_HIP(hipMemcpyAsync(agg_cursor, &agg_n, 8, hipMemcpyHostToDevice, st));
+      MHX_HIP(hipStreamSynchronize(st));  // agg_n is a stack variable
+    }
+    return 0;
   }
-  if (n_words64 && mark_atomic)
-    MHX_LAUNCH(c, "count_solid", (double)n_words64 * 8,
-               hipLaunchKernelGGL(k_count_solid, dim3((unsigned)std::min<uint64_t>(div_ceil(n_words64, 256), 4096)), dim3(256), 0, st, is_solid, n_words64, ctr));
-  c->global_marks_inverted = global && !mark_atomic;
-  if (n_words64 && !mark_atomic && s1_mark_mode_used == 1 && !global) {
-    if (s.fixed_len >= k + 16 && c->opt("s1_pack_fixed", 1))
-      MHX_LAUNCH(c, "pack_solid", (double)n_words64 * 72,
-                 hipLaunchKernelGGL(k_pack_solid_inv_fixed, dim3((unsigned)std::min<uint64_t>(div_ceil(n_words64 * 4, 256), 4096)), dim3(256), 0, st, solid_bytes, n_bits,
-                                    s.fixed_len, (int)k, is_solid, n_words64, ctr));
-    else
-      MHX_LAUNCH(c, "pack_solid", (double)n_words64 * 72,
-                 hipLaunchKernelGGL(k_pack_solid_inv, dim3((unsigned)std::min<uint64_t>(div_ceil(n_words64, 256), 4096)), dim3(256), 0, st, solid_bytes, n_bits,
-                                    s.start.as<uint64_t>(), s.n_seqs, s.fixed_len, (int)k, is_solid, n_words64, ctr));
+  // the sources of a pre-sorted stage become one unsorted array (a way back only)
+  void gather_sources() {
+    buf_a = c->ws("s1_gather_a", n_items * item_bytes + 64).as<uint32_t>();
+    buf_b = c->ws("s1_gather_b", n_items * item_bytes + 64).as<uint32_t>();
+    uint64_t at = 0;
+    for (int q = 0; q < pre->n; ++q) {
+      if (pre->count[q]) MHX_HIP(hipMemcpyAsync(buf_a + at * S, pre->ptr[q], pre->count[q] * item_bytes, hipMemcpyDeviceToDevice, st));
+      at += pre->count[q];
+    }
+    sorted = buf_a;
   }
-  if (n_words64 && !mark_atomic && (s1_mark_mode_used != 1 || global))  // global: the marks themselves (see above)
-    MHX_LAUNCH(c, "pack_solid", (double)n_words64 * 72,
-               hipLaunchKernelGGL(k_pack_solid, dim3((unsigned)std::min<uint64_t>(div_ceil(n_words64 * 4, 256), 4096)), dim3(256), 0, st, solid_bytes, n_bits, is_solid,
-                                  n_words64, ctr));
-  {
-    unsigned long long h[2];
-    MHX_HIP(hipMemcpyAsync(h, ctr, 16, hipMemcpyDeviceToHost, st));
+  // -> true when the partial group-by did the job; false: the records are fully sorted now and the classic kernel has to run.
+  // The ways back (marks are idempotent, the histogram is restored): streaming -> segments when an output REGION of the
+  // streaming overflowed (a bucket whose keys overflow the table is split inside the kernel, it never comes here);
+  // segments -> full sort + classic when a segment outgrows the look-ahead or a tile's table.
+  bool group_partial() {
+    unsigned long long *hist_save = c->ws("s1_hist_save", (MHX_MAX_MUL + 1) * 8).as<unsigned long long>();
+    MHX_HIP(hipMemcpyAsync(hist_save, hist, (MHX_MAX_MUL + 1) * 8, hipMemcpyDeviceToDevice, st));
+    for (;;) {
+      const uint32_t e = run_partial();
+      if (!e) return true;
+      MHX_HIP(hipMemcpyAsync(hist, hist_save, (MHX_MAX_MUL + 1) * 8, hipMemcpyDeviceToDevice, st));
+      MHX_HIP(hipMemsetAsync(ctr, 0, 64, st));
+      seg_marks = 0;
+      uint32_t *other;
+      if (plan.stream) {
+        if (pre && sorted == nullptr) gather_sources();
+        plan = s1_plan(c, k, n_items, compact, want_mercy, false);
+        other = sorted == buf_a ? buf_b : buf_a;
+        sorted = radix_sort(c, sorted, other, n_items, S, KWv, plan.passes);
+        set_spare(sorted == buf_a ? buf_b : buf_a);
+        continue;
+      }
+      other = sorted == buf_a ? buf_b : buf_a;
+      sorted = tagged_keys ? radix_sort(c, sorted, other, n_items, S, KWv, s1_sort_passes(k)) : sort_whole_key(c, sorted, other, n_items, S, KWv, s1_sort_passes(k));
+      set_spare(sorted == buf_a ? buf_b : buf_a);
+      return false;
+    }
+  }
+  void group_classic() {
+    agg_prepare_classic();
+    ensure_byte_map();
+    classic_ran = true;
+    if (agg && S == 3) classic_case<3, true, true>(0);
+    else if (agg && S == 4 && !compact) classic_case<4, false, true>(want_mercy);
+    else launch_classic_plain();
+  }
+
+  void publish(mhx_s1_result *out) {
+    if (agg && (S == 3 || (S == 4 && !compact))) {  // also with zero local items: every rank takes the same stage-2 path
+      c->agg_n = 0;
+      MHX_HIP(hipMemcpyAsync(&c->agg_n, agg_cursor, 8, hipMemcpyDeviceToHost, st));
+      c->agg_valid = true;
+      c->agg_k = k;
+      c->agg_m = m;
+    }
+    if (sparse && classic_ran) {  // the classic kernel marked a byte map of the global read set: turn it into the list
+      const uint64_t n_bytes = div_ceil(n_bits, 64) * 64;
+      unsigned long long *cur = c->ws("s1_mark_cursor", 64).as<unsigned long long>();
+      MHX_HIP(hipMemsetAsync(cur, 0, 8, st));
+      // upper bound of the marks: every record
+      unsigned long long *dense = grow_preserving(c, c->work["s1_marks"], (marks_prev + n_items) * 8 + 64, marks_prev * 8).as<unsigned long long>();
+      MHX_LAUNCH(c, "collect_marks", (double)n_bytes,
+                 hipLaunchKernelGGL(k_collect_marks, dim3((unsigned)div_ceil(n_bytes, 256 * 16)), dim3(256), 0, st, solid_bytes, n_bytes,
+                                    dense + marks_prev, cur));
+      uint64_t got = 0;
+      MHX_HIP(hipMemcpyAsync(&got, cur, 8, hipMemcpyDeviceToHost, st));
+      MHX_HIP(hipStreamSynchronize(st));
+      c->n_marks = marks_prev + got;
+    }
+    if (n_words64 && mark_atomic)
+      MHX_LAUNCH(c, "count_solid", (double)n_words64 * 8,
+                 hipLaunchKernelGGL(k_count_solid, dim3((unsigned)std::min<uint64_t>(div_ceil(n_words64, 256), 4096)), dim3(256), 0, st, is_solid, n_words64, ctr));
+    c->global_marks_inverted = global && !mark_atomic;
+    if (n_words64 && !mark_atomic && mark_mode_used == 1 && !global) {
+      if (s.fixed_len >= k + 16 && c->opt("s1_pack_fixed", 1))
+        MHX_LAUNCH(c, "pack_solid", (double)n_words64 * 72,
+                   hipLaunchKernelGGL(k_pack_solid_inv_fixed, dim3((unsigned)std::min<uint64_t>(div_ceil(n_words64 * 4, 256), 4096)), dim3(256), 0, st, solid_bytes, n_bits,
+                                      s.fixed_len, (int)k, is_solid, n_words64, ctr));
+      else
+        MHX_LAUNCH(c, "pack_solid", (double)n_words64 * 72,
+                   hipLaunchKernelGGL(k_pack_solid_inv, dim3((unsigned)std::min<uint64_t>(div_ceil(n_words64, 256), 4096)), dim3(256), 0, st, solid_bytes, n_bits,
+                                      s.start.as<uint64_t>(), s.n_seqs, s.fixed_len, (int)k, is_solid, n_words64, ctr));
+    }
+    if (n_words64 && !mark_atomic && (mark_mode_used != 1 || global))  // global: the marks themselves (see polarity)
+      MHX_LAUNCH(c, "pack_solid", (double)n_words64 * 72,
+                 hipLaunchKernelGGL(k_pack_solid, dim3((unsigned)std::min<uint64_t>(div_ceil(n_words64 * 4, 256), 4096)), dim3(256), 0, st, solid_bytes, n_bits, is_solid,
+                                    n_words64, ctr));
+    uint64_t n_solid = 0, n_mercy = 0;
+    {
+      unsigned long long h[2];
+      MHX_HIP(hipMemcpyAsync(h, ctr, 16, hipMemcpyDeviceToHost, st));
+      MHX_HIP(hipStreamSynchronize(st));
+      n_solid = h[0];
+      n_mercy = h[1];
+      if (want_mercy && (c->accumulate || c->filter_on)) {  // keep the candidates of every pass; publish their sorted union
+        const uint64_t prev = acc ? c->mercy_acc_n : 0;
+        DevBuf &ma = grow_preserving(c, c->work["mercy_acc"], (prev + n_mercy) * 8 + 8, prev * 8);
+        if (n_mercy) MHX_HIP(hipMemcpyAsync(reinterpret_cast<char *>(ma.p) + prev * 8, mercy, n_mercy * 8, hipMemcpyDeviceToDevice, st));
+        c->mercy_acc_n = n_mercy = prev + n_mercy;
+        mercy = ma.as<long long>();
+      }
+      if (want_mercy && n_mercy) {
+        int hi_bit = 3;
+        while (hi_bit < 64 && ((n_bits << 2) >> hi_bit)) ++hi_bit;
+        const uint64_t *ms = sort_u64(c, mercy, n_mercy, hi_bit);
+        DevBuf &res = c->result(MHX_BUF_MERCY_CAND, n_mercy * 8);
+        MHX_HIP(hipMemcpyAsync(res.p, ms, n_mercy * 8, hipMemcpyDeviceToDevice, st));
+      }
+    }
+    if (!want_mercy || !n_mercy) {
+      c->result(MHX_BUF_MERCY_CAND, 8);
+      c->results[MHX_BUF_MERCY_CAND].used = 0;
+    }
+    c->results[MHX_BUF_SORTED_ITEMS].release();
+    c->results[MHX_BUF_SORTED_ITEMS].p = sorted;
+    c->results[MHX_BUF_SORTED_ITEMS].cap = 0;
+    c->results[MHX_BUF_SORTED_ITEMS].used = sorted ? n_items * item_bytes : 0;  // (pre-sorted sources stay where they are)
+    c->sorted_item_words = S;
     MHX_HIP(hipStreamSynchronize(st));
-    n_solid = h[0];
-    n_mercy = h[1];
-    if (want_mercy && (c->accumulate || c->filter_on)) {  // keep the candidates of every pass; publish their sorted union
-      const uint64_t prev = acc ? c->mercy_acc_n : 0;
-      DevBuf &ma = grow_preserving(c, c->work["mercy_acc"], (prev + n_mercy) * 8 + 8, prev * 8);
-      if (n_mercy) MHX_HIP(hipMemcpyAsync(reinterpret_cast<char *>(ma.p) + prev * 8, mercy, n_mercy * 8, hipMemcpyDeviceToDevice, st));
-      c->mercy_acc_n = n_mercy = prev + n_mercy;
-      mercy = ma.as<long long>();
-    }
-    if (want_mercy && n_mercy) {
-      int hi_bit = 3;
-      while (hi_bit < 64 && ((n_bits << 2) >> hi_bit)) ++hi_bit;
-      const uint64_t *ms = sort_u64(c, mercy, n_mercy, hi_bit);
-      DevBuf &res = c->result(MHX_BUF_MERCY_CAND, n_mercy * 8);
-      MHX_HIP(hipMemcpyAsync(res.p, ms, n_mercy * 8, hipMemcpyDeviceToDevice, st));
+    if (out) {
+      out->n_items = n_items;
+      out->n_solid = n_solid;
+      out->n_mercy_cand = want_mercy ? n_mercy : 0;
+      out->item_words = S;
     }
   }
-  if (!want_mercy || !n_mercy) {
-    c->result(MHX_BUF_MERCY_CAND, 8);
-    c->results[MHX_BUF_MERCY_CAND].used = 0;
+};
+}  // namespace
+
+int s1_process(mhx_ctx *c, uint32_t k, uint32_t m, int want_mercy, uint32_t *buf_a, uint32_t *buf_b, uint64_t n_items,
+               mhx_s1_result *out, const S1Sources *pre) {
+  S1Stage stage(c, k, m, want_mercy, buf_a, buf_b, n_items, pre);
+  c->last_s1_plan = s1_plan_text(c, k, n_items);
+  stage.sort_records();
+  stage.open_outputs();
+  if (n_items) {
+    stage.polarity();
+    const bool done = stage.plan.seg_bits && stage.group_partial();
+    if (!done) stage.group_classic();
+    stage.mark_mode_used = stage.mark_mode;
+  } else {
+    stage.agg_prepare_classic();  // no launch at all: the cursor still has to hold the earlier passes' count
   }
-  c->results[MHX_BUF_SORTED_ITEMS].release();
-  c->results[MHX_BUF_SORTED_ITEMS].p = sorted;
-  c->results[MHX_BUF_SORTED_ITEMS].cap = 0;
-  c->results[MHX_BUF_SORTED_ITEMS].used = sorted ? n_items * item_bytes : 0;  // (pre-sorted sources stay where they are)
-  c->sorted_item_words = S;
-  MHX_HIP(hipStreamSynchronize(st));
-  if (out) {
-    out->n_items = n_items;
-    out->n_solid = n_solid;
-    out->n_mercy_cand = want_mercy ? n_mercy : 0;
-    out->item_words = S;
-  }
+  stage.publish(out);
   return 0;
 }
 
@@ -2474,7 +2960,7 @@ void s1_apply_marks(mhx_ctx *c, const unsigned long long *recv, uint64_t n) {
 
 int run_s1(mhx_ctx *c, uint32_t k, uint32_t m, int want_mercy, mhx_s1_result *out) {
   if (c->global_bases) throw Error("read2sdbg_s1: a global layout is set; use the mhx_dist_* entry points");
-  c->s1_defer_items = !want_mercy && !c->filter_on;  // s1_process sorts "items_a" first thing: its first pass may make the records
+  c->s1_defer_items = !want_mercy;  // s1_process sorts "items_a" first thing: its first pass may make the records (and apply a bucket filter)
   c->gen_first_pass = nullptr;
   const StageItems it = extract_stage(c, want_mercy ? MHX_STAGE_S1_MERCY : MHX_STAGE_S1, k, m);
   c->s1_defer_items = false;

@@ -88,10 +88,8 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_hist_bytes(const uint8_t
   }
 }
 
-// RANK_ATOMIC: rank inside a wavefront with one returning LDS atomic per record instead of the 8-ballot
-// match-any.  Stable only if the LDS serialises same-address lanes of one instruction in lane order;
-// libmhx verifies that on the device at start-up (probe_lds_atomic_order) before selecting it.
-template <int S, int NI, bool RANK_ATOMIC>
+// Ranking inside a wavefront: match-any over the digit bits — stable by construction.
+template <int S, int NI>
 __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(const uint32_t *__restrict__ in, uint32_t *__restrict__ out, uint64_t n,
                                                                 DigitSpec ds, int nbits,
                                                                 const uint64_t *__restrict__ offs, uint64_t n_chunks,
@@ -144,9 +142,7 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(const uint32_t *
       const bool valid = li < tile_n;
       unsigned d = valid ? (lut ? (unsigned)lut[rec[j].w[0] >> 16] : rec_digit2<S>(rec[j], ds)) : 0u;
       dig[j] = d;
-      if constexpr (RANK_ATOMIC) {
-        rank[j] = valid ? atomicAdd(&wave_cnt[w][d], 1u) : 0u;
-      } else {
+      {
         // match-any over the digit bits
         uint64_t peers = __ballot(valid);
         for (int b = 0; b < (nbits < 0 ? -nbits : nbits); ++b) {
@@ -243,52 +239,6 @@ __global__ __launch_bounds__(256) void k_bin_starts(const unsigned long long *__
   starts[blockIdx.x * 256 + threadIdx.x] = block_exclusive_sum<uint64_t, 256>((uint64_t)v, sm, nullptr);
 }
 
-// Does the LDS apply the lanes of ONE returning atomic instruction that hit the same address in lane order?
-// Each wave does ds_add_rtn on a few shared counters with adversarial lane->address patterns; a lane's
-// returned value must equal the number of lower lanes of its wave that used the same address.
-__global__ __launch_bounds__(kSortThreads) void k_probe_lds_atomic(uint32_t *bad, uint32_t seed) {
-  __shared__ uint32_t cnt[kSortWaves][256];
-  const int tid = threadIdx.x, w = tid / kWave, lane = tid & (kWave - 1);
-  uint32_t x = seed * 2654435761u + blockIdx.x * 40503u + 12345u;
-  for (int it = 0; it < 64; ++it) {
-    for (int i = tid; i < kSortWaves * 256; i += kSortThreads) (&cnt[0][0])[i] = 0;
-    __syncthreads();
-    x = x * 1664525u + 1013904223u;
-    const uint32_t mode = (x >> 28) & 3u;
-    uint32_t lx = (x ^ (uint32_t)lane * 2246822519u) * 3266489917u;
-    lx ^= lx >> 15;
-    uint32_t d;
-    if (mode == 0) d = lx & 255u;           // random digits
-    else if (mode == 1) d = lx & 3u;        // 4 hot addresses
-    else if (mode == 2) d = 7u;             // all lanes one address
-    else d = (uint32_t)(lane & 1) * 128u + ((lx >> 8) & 1u);
-    const bool active = ((lx >> 20) & 7u) != 0;  // some lanes sit out
-    uint32_t got = 0;
-    if (active) got = atomicAdd(&cnt[w][d], 1u);
-    // expected: lower active lanes of this wave with the same d
-    uint32_t expect = 0;
-    for (int l = 0; l < kWave; ++l) {
-      const uint32_t od = __shfl(d, l, kWave);
-      const int oa = __shfl((int)active, l, kWave);
-      if (l < lane && oa && od == d) ++expect;
-    }
-    if (active && got != expect) atomicAdd(bad, 1u);
-    __syncthreads();
-  }
-}
-
-bool probe_lds_atomic_order(mhx_ctx *c) {
-  uint32_t *d_bad = c->ws("probe_bad", 64).as<uint32_t>();
-  MHX_HIP(hipMemsetAsync(d_bad, 0, 4, c->stream));
-  for (uint32_t seed = 1; seed <= 4; ++seed)
-    hipLaunchKernelGGL(k_probe_lds_atomic, dim3(1024), dim3(kSortThreads), 0, c->stream, d_bad, seed);
-  MHX_HIP(hipGetLastError());
-  uint32_t bad = 1;
-  MHX_HIP(hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, c->stream));
-  MHX_HIP(hipStreamSynchronize(c->stream));
-  return bad == 0;
-}
-
 std::vector<SortPass> make_passes(int key_words, int lo_bit, int hi_bit) {
   (void)key_words;
   std::vector<SortPass> p;
@@ -311,7 +261,31 @@ DigitSpec spec_of_pass(const SortPass &ps, int key_words) {
     ds.mask2 = (1u << ps.bits2) - 1;
     ds.sh2 = (unsigned)ps.bits;
   }
+  // bits [prev_lo, shift) sorted by the earlier passes (SortPass::prev_lo): usable when they lie in the digit's own word
+  if (ps.prev_lo >= 0 && ps.prev_lo < ps.shift && !ps.bits2 && ps.prev_lo / 32 == (ps.shift + ps.bits - 1) / 32) {
+    const unsigned hi = (unsigned)(ps.shift % 32), lo = (unsigned)(ps.prev_lo % 32);
+    ds.prev_mask = ((1u << hi) - 1u) & ~((1u << lo) - 1u);  // bits [lo, hi) of the word
+  }
   return ds;
+}
+
+// one decision per call about the shape of the sort (no function-local statics: a resident server answers requests with
+// different environments, and the decision has to agree with sort_takes_generated_first_pass)
+struct SortEnv {
+  bool classic;
+  std::string shape;  // "" = default
+  int items;          // 0 = default
+};
+static SortEnv sort_env() {
+  const char *e = getenv("MHX_SORT"), *sh = getenv("MHX_SORT_SHAPE"), *it = getenv("MHX_SORT_ITEMS");
+  return SortEnv{e && !strcmp(e, "classic"), sh ? sh : "", it ? atoi(it) : 0};
+}
+// a generated first pass that this call does not consume would leave the buffer without records: never sort that
+static void refuse_unconsumed_generator(mhx_ctx *c, const void *a, const char *who) {
+  if (c->gen_first_pass && c->gen_buf == a) {
+    c->gen_first_pass = nullptr;
+    throw Error(std::string(who) + ": the records of this buffer are to be made by a generated first pass, which this sort path cannot run");
+  }
 }
 
 // chained-scan sort (8/12/16-byte records, <= 8 passes); MHX_SORT=classic selects the histogram + scan + scatter passes
@@ -320,21 +294,29 @@ static uint32_t *radix_sort_onesweep(mhx_ctx *c, uint32_t *a, uint32_t *b, uint6
   const int P = (int)passes.size();
   // a generated first pass (s1.hip): valid for exactly this buffer, item count and unit shape
   std::function<void(const OnesweepLaunch &)> gen;
-  if (c->gen_first_pass && c->gen_buf == (const void *)a && c->gen_n == n && S == 3 && NI == 8 && UT == 3) gen = c->gen_first_pass;
+  // (gen_slots: item slots the generator walks — more than n when it drops the items of filtered-out lv1 buckets)
+  uint64_t gen_slots = n;
+  if (c->gen_first_pass && c->gen_buf == (const void *)a && c->gen_n == n && S == 3 && NI == 8 && UT == 3) {
+    gen = c->gen_first_pass;
+    gen_slots = std::max<uint64_t>(c->gen_slots, n);
+  }
+  if (!gen) refuse_unconsumed_generator(c, a, "radix sort (chained scan)");
   c->gen_first_pass = nullptr;
   // Per-XCD tickets (see k_radix_onesweep): a unit may wait for a unit whose block id is up to 127 higher, so the scheme needs
   // the whole 8-XCD part with a couple of hundred workgroups resident at once (MI355X in SPX mode: 256 CUs x 3-4 workgroups).
   // On a partition (CPX: 32 CUs, one XCD) or an unknown device the single ticket counter is used: its look-back only ever
   // waits for lower tickets, which are running by construction.
   const int xcd_units = c->opt("sort_xcd_units", 1) != 0 && c->n_cus >= 192;
-  const uint64_t unit = (uint64_t)kSortThreads * NI * UT, n_units = xcd_units ? (div_ceil(n, unit) + 127) / 128 * 128 : div_ceil(n, unit);
+  const uint64_t unit = (uint64_t)kSortThreads * NI * UT;
+  auto units_of = [&](uint64_t items) { return xcd_units ? (div_ceil(items, unit) + 127) / 128 * 128 : div_ceil(items, unit); };
+  const uint64_t n_units = units_of(n), n_units_gen = units_of(gen_slots);
   hipStream_t st = c->stream;
-  unsigned long long *status = c->ws("sort_status", n_units * 256 * 8).as<unsigned long long>();
+  unsigned long long *status = c->ws("sort_status", n_units_gen * 256 * 8).as<unsigned long long>();
   unsigned long long *gh = c->ws("sort_ghist", (size_t)2 * kMaxChainedPasses * 256 * 8).as<unsigned long long>();
   unsigned long long *starts = gh + kMaxChainedPasses * 256;
   constexpr int kErrSlot = kMaxChainedPasses * 8;
   uint32_t *tickets = c->ws("sort_tickets", (kErrSlot + 8) * 4).as<uint32_t>();  // 8 ticket counters per pass, then the error flag
-  MHX_HIP(hipMemsetAsync(status, 0, n_units * 256 * 8, st));
+  MHX_HIP(hipMemsetAsync(status, 0, n_units_gen * 256 * 8, st));
   MHX_HIP(hipMemsetAsync(gh, 0, (size_t)kMaxChainedPasses * 256 * 8, st));
   MHX_HIP(hipMemsetAsync(tickets, 0, (kErrSlot + 8) * 4, st));
   const double bytes = (double)n * S * 4;
@@ -360,38 +342,28 @@ static uint32_t *radix_sort_onesweep(mhx_ctx *c, uint32_t *a, uint32_t *b, uint6
   // unit-wide runs (k_radix_onesweep_u) for the default unit shape of every width; MHX_SORT_UNIT_RUNS=0: the tile-by-tile kernel
   constexpr bool kHasUnitRuns = (S <= 3 && NI == 8 && (UT == 3 || UT == 2)) || (S == 4 && NI == 8 && UT == 2) || (S > 4 && NI == 4 && UT == 2);
   const bool unit_runs = kHasUnitRuns && c->opt("sort_unit_runs", 1) != 0;
-  // sort_rank_atomic: rank the records of a wavefront with ONE returning LDS atomic per record (the ANY_ORDER form of the
-  // kernel) instead of the match-any over the digit bits (8 ballots, ~80 VALU operations per record: half the instructions
-  // of a pass).  That is a STABLE ranking exactly when the LDS applies the same-address lanes of one atomic instruction in
-  // lane order — not an architectural promise, so the device is probed first (probe_lds_atomic_order: adversarial
-  // lane -> address patterns) and the ballots stay in use wherever the probe fails.
-  bool rank_atomic = false;
-  if (unit_runs && c->opt("sort_rank_atomic", 0) != 0) {
-    if (!c->lds_probe_done) {
-      c->lds_atomic_ordered = probe_lds_atomic_order(c) || c->lds_atomic_ordered;
-      c->lds_probe_done = true;
-    }
-    rank_atomic = c->lds_atomic_ordered;
-  }
+  // sort_rank_uniform: passes whose plan declares the bits sorted before them (SortPass::prev_lo) rank with one LDS atomic per
+  // record wherever all records of a wavefront instruction agree on those bits, with the ballots elsewhere (RANK 2 of
+  // k_radix_onesweep_u: correct whatever order the LDS applies the lanes in).  Every other loading pass: the ballots.
+  const bool rank_uniform = unit_runs && c->opt("sort_rank_uniform", 1) != 0;
   for (int p = 0; p < P; ++p) {
     const int nb = passes[p].bits + passes[p].bits2;
     const int wi = digit_word_of(all[p], nb, 1);
     if (p == 0 && gen) {  // the records of the first pass are made on the fly (no input array): the generator's owner launches
       static const std::string nm_gen = nm_scat + "_gen";
       MHX_LAUNCH(c, nm_gen.c_str(), bytes,
-                 gen(OnesweepLaunch{(unsigned)n_units, st, b, n, all[p], nb, starts + p * 256, status, tickets + p * 8,
+                 gen(OnesweepLaunch{(unsigned)n_units_gen, st, b, gen_slots, all[p], nb, starts + p * 256, status, tickets + p * 8,
                                     tickets + kErrSlot, (unsigned long long)(p + 1), xcd_units, unit_runs ? 1 : 0, wi}));
     } else if (unit_runs) {
       if constexpr (kHasUnitRuns) {
-#define MHX_U(ANYV, WIV)                                                                                                                       \
-  hipLaunchKernelGGL((k_radix_onesweep_u<S, NI, UT, SrcArray<S>, ANYV, WIV>), dim3((unsigned)n_units), dim3(kSortThreads), 0, st, SrcArray<S>{a}, b, \
+#define MHX_U(RANKV, WIV)                                                                                                                      \
+  hipLaunchKernelGGL((k_radix_onesweep_u<S, NI, UT, SrcArray<S>, RANKV, WIV>), dim3((unsigned)n_units), dim3(kSortThreads), 0, st, SrcArray<S>{a}, b, \
                      n, all[p], nb, starts + p * 256, status, tickets + p * 8, tickets + kErrSlot, (unsigned long long)(p + 1), xcd_units)
         MHX_LAUNCH(c, nm_scat.c_str(), 2 * bytes, {
-          if (wi == 0 && rank_atomic) MHX_U(true, 0);
-          else if (wi == 1 && rank_atomic) MHX_U(true, 1);
-          else if (wi == 0) MHX_U(false, 0);
-          else if (wi == 1) MHX_U(false, 1);
-          else MHX_U(false, -1);
+          if (wi == 0 && rank_uniform && all[p].prev_mask) MHX_U(2, 0);
+          else if (wi == 0) MHX_U(0, 0);
+          else if (wi == 1) MHX_U(0, 1);
+          else MHX_U(0, -1);
         });
 #undef MHX_U
       }
@@ -414,18 +386,16 @@ template <int S, int NI>
 static uint32_t *radix_sort_impl2(mhx_ctx *c, uint32_t *a, uint32_t *b, uint64_t n, int key_words,
                                   const std::vector<SortPass> &passes) {
   if (n == 0) return a;
+  const SortEnv env = sort_env();
   if constexpr (S <= 8 && NI == default_items<S>()) {
-    static const bool classic = [] {
-      const char *e = getenv("MHX_SORT");
-      return e && !strcmp(e, "classic");
-    }();
+    const bool classic = env.classic;
     if (!classic && passes.size() <= (size_t)kMaxChainedPasses && div_ceil(n, (uint64_t)kSortThreads * 8) < (1ull << 31)) {
       if constexpr (S <= 4) {
         // unit shape: records per thread per tile x tiles per unit (MHX_SORT_SHAPE overrides).  Measured at 12 B, 1.33 G
         // records, ms per 6 passes on one box: 4x2 89, 4x4 66, 4x8 80, 8x1 88, 6x2 72, 12x1 75, 16x1 78, 8x2 59, 8x3 57, 8x4 70
         // (classic 3-kernel passes: 63 + 20 histogram): 2048-record tiles halve the number of scattered runs, units of
         // 4-6 K records amortise the look-back, more registers cost occupancy.
-        static const std::string shape = getenv("MHX_SORT_SHAPE") ? getenv("MHX_SORT_SHAPE") : (S <= 3 ? "8x3" : "8x2");
+        const std::string shape = !env.shape.empty() ? env.shape : (S <= 3 ? "8x3" : "8x2");
         if (shape == "8x2") return radix_sort_onesweep<S, 8, 2>(c, a, b, n, key_words, passes);
         if (shape == "4x4") return radix_sort_onesweep<S, 4, 4>(c, a, b, n, key_words, passes);
         if (shape == "16x1") return radix_sort_onesweep<S, 16, 1>(c, a, b, n, key_words, passes);
@@ -437,6 +407,7 @@ static uint32_t *radix_sort_impl2(mhx_ctx *c, uint32_t *a, uint32_t *b, uint64_t
       }
     }
   }
+  refuse_unconsumed_generator(c, a, "radix sort (classic passes)");
   const uint64_t n_chunks = div_ceil(n, SortCfg<S, NI>::kChunk);
   uint32_t *hist = c->ws("sort_hist", n_chunks * 256 * 4).as<uint32_t>();
   uint64_t *offs = c->ws("sort_offs", n_chunks * 256 * 8).as<uint64_t>();
@@ -475,14 +446,9 @@ static uint32_t *radix_sort_impl2(mhx_ctx *c, uint32_t *a, uint32_t *b, uint64_t
     exclusive_scan_u32_u64(c, hist, offs, n_chunks * 256, nullptr);
     uint8_t *dn = last ? nullptr : dnext;
     static const unsigned lds_pad = getenv("MHX_SORT_LDS_PAD") ? (unsigned)atoi(getenv("MHX_SORT_LDS_PAD")) : 0u;  // occupancy experiment
-    if (c->lds_atomic_ordered)
-      MHX_LAUNCH(c, nm_scat.c_str(), 2 * bytes + (dn ? (double)n : 0.0),
-                 hipLaunchKernelGGL((k_radix_scatter<S, NI, true>), dim3((unsigned)n_chunks), dim3(kSortThreads), lds_pad, c->stream, a, b, n, ds,
-                                    nbits, offs, n_chunks, (const uint8_t *)nullptr, ds_next, dn));
-    else
-      MHX_LAUNCH(c, nm_scat.c_str(), 2 * bytes + (dn ? (double)n : 0.0),
-                 hipLaunchKernelGGL((k_radix_scatter<S, NI, false>), dim3((unsigned)n_chunks), dim3(kSortThreads), lds_pad, c->stream, a, b, n, ds,
-                                    nbits, offs, n_chunks, (const uint8_t *)nullptr, ds_next, dn));
+    MHX_LAUNCH(c, nm_scat.c_str(), 2 * bytes + (dn ? (double)n : 0.0),
+               hipLaunchKernelGGL((k_radix_scatter<S, NI>), dim3((unsigned)n_chunks), dim3(kSortThreads), lds_pad, c->stream, a, b, n, ds,
+                                  nbits, offs, n_chunks, (const uint8_t *)nullptr, ds_next, dn));
     std::swap(a, b);
   }
   return a;
@@ -493,10 +459,8 @@ template <int S>
 static uint32_t *radix_sort_impl(mhx_ctx *c, uint32_t *a, uint32_t *b, uint64_t n, int key_words,
                                  const std::vector<SortPass> &passes) {
   if constexpr (S <= 4) {
-    static const int items = [] {
-      const char *e = getenv("MHX_SORT_ITEMS");
-      return e ? atoi(e) : default_items<S>();
-    }();
+    const SortEnv env = sort_env();
+    const int items = env.items ? env.items : default_items<S>();
     if (items == 2) return radix_sort_impl2<S, 2>(c, a, b, n, key_words, passes);
     if (items == 3) return radix_sort_impl2<S, 3>(c, a, b, n, key_words, passes);
     if (items == 6) return radix_sort_impl2<S, 6>(c, a, b, n, key_words, passes);
@@ -655,7 +619,7 @@ static void partition_impl(mhx_ctx *c, const uint32_t *a, uint32_t *b, uint64_t 
                                 n_chunks, lut));
   exclusive_scan_u32_u64(c, hist, offs, n_chunks * 256, offs + n_chunks * 256);
   MHX_LAUNCH(c, "owner_scatter", 2 * bytes,
-             hipLaunchKernelGGL((k_radix_scatter<S, default_items<S>(), false>), dim3((unsigned)n_chunks), dim3(kSortThreads), 0, c->stream, a, b, n, DigitSpec{0, 0u, 0xFFu, 0, 0u, 0u, 0u},
+             hipLaunchKernelGGL((k_radix_scatter<S, default_items<S>()>), dim3((unsigned)n_chunks), dim3(kSortThreads), 0, c->stream, a, b, n, DigitSpec{0, 0u, 0xFFu, 0, 0u, 0u, 0u},
                                 nbits, offs, n_chunks, lut, DigitSpec{0, 0u, 0xFFu, 0, 0u, 0u, 0u}, (uint8_t *)nullptr));
   std::vector<uint64_t> starts(n_parts + 1);
   for (int p = 0; p <= n_parts; ++p)
@@ -687,9 +651,9 @@ void partition_by_owner(mhx_ctx *c, const uint32_t *a, uint32_t *b, uint64_t n, 
 // will take a generated first pass (mhx_ctx::gen_first_pass)
 bool sort_takes_generated_first_pass(const mhx_ctx *c, uint64_t n, int stride, const std::vector<SortPass> &passes) {
   (void)c;
-  const char *e = getenv("MHX_SORT"), *sh = getenv("MHX_SORT_SHAPE"), *it = getenv("MHX_SORT_ITEMS");
-  if (e && !strcmp(e, "classic")) return false;
-  if ((sh && strcmp(sh, "8x3")) || (it && atoi(it) != default_items<3>())) return false;
+  const SortEnv env = sort_env();  // (the same per-call decision radix_sort_impl2 takes)
+  if (env.classic) return false;
+  if ((!env.shape.empty() && env.shape != "8x3") || (env.items && env.items != default_items<3>())) return false;
   return stride == 3 && n > 0 && passes.size() <= (size_t)kMaxChainedPasses && passes.size() <= (size_t)kMaxFusedPasses &&
          div_ceil(n, (uint64_t)kSortThreads * 8) < (1ull << 31);
 }

@@ -10,6 +10,7 @@ struct DigitSpec {
   unsigned bit1, mask1;
   int wi2;
   unsigned bit2, mask2, sh2;  // mask2 == 0: single field
+  unsigned prev_mask = 0;     // bits of word wi1 that the earlier passes of the plan have sorted (k_radix_onesweep_u RANK 2)
 };
 constexpr int kMaxFusedPasses = 16;  // digit histograms taken in one read of the input
 struct DigitSpecs {

@@ -90,6 +90,10 @@ __device__ __forceinline__ unsigned mem_digit(const uint32_t *p, int wi, unsigne
 template <int S>
 struct SrcArray {
   const uint32_t *in;
+  // kMayDrop: the source may decline item slots (a generator that filters by lv1 bucket): a unit then holds fewer records
+  // than item slots and the pass compacts them (k_radix_onesweep_u counts what is_record() accepts)
+  static constexpr bool kMayDrop = false;
+  __device__ __forceinline__ bool is_record(const Rec<S> &) const { return true; }
   // records first, first + 64, ... (NI of them, those below n) of one thread
   template <int NI>
   __device__ __forceinline__ void get(uint64_t first, uint64_t n, Rec<S> (&rec)[NI]) const {
@@ -299,7 +303,16 @@ inline int digit_word_of(const DigitSpec &ds, int nbits, int max_word) {
 // 19.6 -> 17.0 GB, 10.0 -> 9.3 ms; 8-byte records 0.73 -> 0.65 ms per pass; 16-byte records (count) 11.5 -> 10.9 ms.
 // (12-byte records, 8x3 units: 138 registers = 3 workgroups per CU.  Asking the compiler for 128 = 4 workgroups costs 13
 // spilled registers and measured slower: 10.7 instead of 9.2 ms per pass.)
-template <int S, int NI, int UT, class Src, bool ANY_ORDER, int WI>
+// RANK: how a record finds its rank among the records of its wavefront instruction with the same digit.
+//   0  match-any over the digit bits (8 ballots): stable by construction — every pass whose input order matters;
+//   1  ONE returning LDS atomic on the digit's counter: the lanes of a digit are ranked in whatever order the LDS applies
+//      them — for a pass whose records may leave in any order inside a digit (the generating first pass of stage 1);
+//   2  the atomic where it provably cannot matter, the ballots elsewhere: an LSD pass has to keep the order of two records
+//      only if they differ in the bits sorted so far (ds.prev_mask, bits of word WI) — when all records of the instruction
+//      agree on those, any order among them is a correct outcome for a consumer that does not look at the order of records
+//      equal in ALL sorted bits (the LDS group-by of stage 1).  Behind a pass over the neighbouring digit nearly every
+//      instruction qualifies (its 64 records are consecutive in the input).  No assumption about the LDS is involved.
+template <int S, int NI, int UT, class Src, int RANK, int WI>
 __global__ __launch_bounds__(kSortThreads) void k_radix_onesweep_u(Src src, uint32_t *__restrict__ out, uint64_t n, DigitSpec ds, int nbits,
                                                                    const unsigned long long *__restrict__ bin_start,
                                                                    unsigned long long *__restrict__ status, uint32_t *__restrict__ ticket,
@@ -344,10 +357,19 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_onesweep_u(Src src, uint
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
       const uint64_t gi = src.template index<NI>(unit_base + (uint64_t)t * kTile, w, lane, j);  // (which item this is: the source's arrangement)
-      const bool valid = gi < n;
+      bool valid = gi < n;
+      if constexpr (Src::kMayDrop) valid = valid && src.is_record(rec[t][j]);
       const unsigned d = valid ? rec_digit_w<S, WI>(rec[t][j], ds) : 0u;
       uint32_t rk;
-      if constexpr (ANY_ORDER) {
+      bool by_atomic = RANK == 1;
+      if constexpr (RANK == 2) {
+        static_assert(WI >= 0, "RANK 2 needs the digit and the bits sorted before it in one word");
+        const uint64_t vm = __ballot(valid);
+        const uint32_t pv = valid ? (rec[t][j].w[WI >= 0 ? WI : 0] & ds.prev_mask) : 0u;
+        const uint32_t p0 = __shfl(pv, vm ? __builtin_ctzll(vm) : 0, kWave);
+        by_atomic = __ballot(valid && pv != p0) == 0;
+      }
+      if (by_atomic) {
         rk = valid ? atomicAdd(&cnt[t][w][d], 1u) : 0xFFFFu;
       } else {
         uint64_t peers = __ballot(valid);
@@ -371,6 +393,7 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_onesweep_u(Src src, uint
   __syncthreads();
 
   // 3. thread d: the unit's count of digit d -> status word; starts of the (tile, wave) cells inside the unit; look-back
+  uint32_t unit_records = 0;  // records of the unit (all item slots below n, unless the source drops some)
   {
     uint32_t c[UT][kSortWaves], tot = 0;
 #pragma unroll
@@ -383,7 +406,7 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_onesweep_u(Src src, uint
     unsigned long long *const st = status + unit * 256 + tid;
     const unsigned long long tagbits = tag << 58;
     __hip_atomic_store(st, tagbits | ((unit == 0 ? 2ull : 1ull) << 56) | (unsigned long long)tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const uint32_t start = block_exclusive_sum<uint32_t, kSortThreads>(tot, sm_scan, nullptr);
+    const uint32_t start = block_exclusive_sum<uint32_t, kSortThreads>(tot, sm_scan, &unit_records);
     uint32_t run = start;
 #pragma unroll
     for (int t = 0; t < UT; ++t)
@@ -429,7 +452,7 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_onesweep_u(Src src, uint
       }
     }
   const uint64_t rem = n > unit_base ? n - unit_base : 0;
-  const uint32_t unit_n = rem < (uint64_t)(kTile * UT) ? (uint32_t)rem : (uint32_t)(kTile * UT);
+  const uint32_t unit_n = Src::kMayDrop ? unit_records : (rem < (uint64_t)(kTile * UT) ? (uint32_t)rem : (uint32_t)(kTile * UT));
 #pragma unroll
   for (int r = 0; r < UT; ++r) {
     const uint32_t lo = (uint32_t)r * kTile;

@@ -147,9 +147,11 @@ SYMBOLS = {
     "mhx_device_free_bytes": (C.c_uint64, [_P]),
     "mhx_bucket_histogram": (C.c_int, [_P, C.c_int, C.c_uint32, C.c_uint32, _P]),
     "mhx_set_bucket_filter": (C.c_int, [_P, _P, C.c_uint64, C.c_uint64, C.c_int]),
+    "mhx_stage_pass_bytes": (C.c_uint64, [_P, C.c_int, C.c_uint32, C.c_uint32, C.c_uint64]),
     "mhx_alloc_stats": (None, [_P, _P, _P, _P]),
     "mhx_comm_init_hosted": (_P, [_P, C.c_int, C.c_int, _P]),
     "mhx_reset": (C.c_int, [_P]),
+    "mhx_last_s1_plan": (C.c_char_p, [_P]),
     "mhx_profile_enable": (C.c_int, [_P, C.c_int]),
     "mhx_profile_reset": (C.c_int, [_P]),
     "mhx_profile_get": (C.c_int, [_P, C.POINTER(KernelStat), C.c_int]),
@@ -332,11 +334,6 @@ class Engine:
         self._chk(self.lib.mhx_dist_process_s2(self.h, k, n_items, C.byref(r)))
         return r
 
-    def as_tensor(self, ptr, nbytes, device):
-        """torch uint8 view of library-owned device memory (zero copy)."""
-        from .dist import device_bytes
-        return device_bytes(ptr, nbytes, device)
-
     def device_pointer(self, which):
         return self.lib.mhx_device_pointer(self.h, which)
 
@@ -397,6 +394,10 @@ class Engine:
     def set_option(self, name, value):
         """Tuning / diagnostic knob of this handle (include/mhx.h: mhx_set_option)."""
         self._chk(self.lib.mhx_set_option(self.h, name.encode(), int(value)))
+
+    def last_s1_plan(self):
+        """what the last stage 1 of this handle ran as (mhx_last_s1_plan)"""
+        return (self.lib.mhx_last_s1_plan(self.h) or b"").decode()
 
     def get_option(self, name, default):
         """Effective value of a knob for this handle (include/mhx.h: mhx_get_option): explicit option, environment, tuned default."""

@@ -5,7 +5,8 @@ read_to_sdbg_s2.cpp:521-614) — on fixed-length libraries, where the generating
   s1_digit_hist_preload  the same in the digit-histogram pre-pass
   s1_stream_half         two 512-thread workgroups with 4096-slot tables per CU in the bucket streaming
   s1_stream_read_first   a plain LDS read in front of the compare-and-swap
-  sort_rank_atomic       one LDS atomic per record instead of the match-any ballots (where the device passes the probe)"""
+  sort_rank_uniform      one LDS atomic per record where all records of a wavefront instruction agree on the bits sorted so far
+  s1_stream_prefetch     the bucket streaming requests the records of its next trip before it inserts those of the current one"""
 import numpy as np
 import pytest
 
@@ -16,7 +17,7 @@ from test_gpu_sdbg import check_sdbg
 
 pytestmark = pytest.mark.gpu
 
-KNOBS = ["s1_gen_blocked", "s1_digit_hist_preload", "s1_stream_half", "s1_stream_read_first", "sort_rank_atomic"]
+KNOBS = ["s1_gen_blocked", "s1_digit_hist_preload", "s1_stream_half", "s1_stream_read_first", "sort_rank_uniform", "s1_stream_prefetch"]
 SETTINGS = [{}] + [{k: 1} for k in KNOBS] + [{k: 1 for k in KNOBS}]
 
 
@@ -63,6 +64,6 @@ def test_read2sdbg_under_every_knob(engine, kind, k, m, setting):
 
 
 def engine_default(engine, name):
-    """what a fresh handle would use for `name`: the tuned default of the installation, else 0 (all round-3 knobs are off by default)"""
+    """what a fresh handle would use for `name`: the tuned default of the installation, else the built-in default"""
     from bench import tuned_defaults
-    return tuned_defaults().get(name, 0)
+    return tuned_defaults().get(name, 1 if name == "sort_rank_uniform" else 0)

@@ -14,16 +14,17 @@ from test_gpu_sdbg import check_sdbg
 pytestmark = pytest.mark.gpu
 
 
-# unit-wide runs with the match-any ballots (the default), the tile-by-tile pass, unit-wide runs ranked with one LDS atomic
-# per record (include/mhx.h: sort_rank_atomic; stable where the device passes the lane-order probe, else the ballots run)
-@pytest.fixture(params=[(1, 0), (0, 0), (1, 1)], ids=["unit_runs", "tile_runs", "unit_runs_atomic"])
+# unit-wide runs (the default: the prefix plans of stage 1 rank with an LDS atomic wherever all records of a wavefront
+# instruction agree on the bits sorted so far, include/mhx.h: sort_rank_uniform), the tile-by-tile pass, unit-wide runs with
+# the match-any ballots everywhere
+@pytest.fixture(params=[(1, 1), (0, 1), (1, 0)], ids=["unit_runs", "tile_runs", "unit_runs_ballots"])
 def unit_runs(engine, request):
     engine.set_option("sort_unit_runs", request.param[0])
-    engine.set_option("sort_rank_atomic", request.param[1])
+    engine.set_option("sort_rank_uniform", request.param[1])
     engine.set_option("sort_hybrid", 0)  # every key bit by LSD passes
     yield request.param
     engine.set_option("sort_unit_runs", 1)
-    engine.set_option("sort_rank_atomic", 0)
+    engine.set_option("sort_rank_uniform", 1)
     engine.set_option("sort_hybrid", 1)
 
 

@@ -67,6 +67,71 @@ def meta_golden(args):
     print("wrote", path)
 
 
+CONFIGS2 = {"reads": 100000000, "genome_seed": 2, "read_seed0": 2001, "k": 21, "m": 2}
+
+
+def gen_configs2_library(prefix, n_reads=CONFIGS2["reads"], procs=None):
+    """BASELINE configs[2] / the north-star size: 100 M x 150 bp PE reads of one 250 Mbp genome (seed 2; blocks 2001+i)."""
+    synth.write_pe_library(prefix, n_reads, CONFIGS2["genome_seed"], CONFIGS2["read_seed0"], procs=procs)
+
+
+def sdbg_octants(prefix):
+    """Digests of the eight contiguous eighths of the SdBG's lv1 buckets: what rank r of 8 owns (tools/config_bench.py owner8)."""
+    return [canon.digest_sdbg(prefix, r * 8192, (r + 1) * 8192) for r in range(8)]
+
+
+def configs2_golden(args):
+    """tests/golden/fullsize_100M.json: the reference's read2sdbg, count, seq2sdbg --need_mercy at the north-star size."""
+    n = int(args.reads) // 2 * 2 if args.reads != 1e7 else CONFIGS2["reads"]
+    k, m = CONFIGS2["k"], CONFIGS2["m"]
+    ref = os.path.join(ROOT, "oracle", "_ref", "ref_core")
+    d = args.keep or tempfile.mkdtemp(prefix="mhx_c2_")
+    os.makedirs(d, exist_ok=True)
+    lib = os.path.join(d, "reads")
+    if not os.path.exists(lib + ".bin"):
+        gen_configs2_library(lib, n)
+    path = args.out if args.out.endswith("_100M.json") else os.path.join(ROOT, "tests", "golden", "fullsize_100M.json")
+    out = {"reads": n, "k": k, "m": m, "edges": n * (150 - k), "generator": "tools/make_fullsize_golden.py --preset configs2",
+           "reference_threads": args.threads, "reference_host": "build container (%d cores)" % (os.cpu_count() or 0),
+           "lib_bin_md5": canon.digest_file(lib + ".bin"), "cases": {}}
+    if os.path.exists(path):
+        old = json.load(open(path))
+        if old.get("lib_bin_md5") == out["lib_bin_md5"]:
+            out["cases"] = old.get("cases", {})
+
+    def save():
+        with open(path, "w") as f:
+            json.dump(out, f, indent=1)
+
+    common = ["-k", str(k), "-m", str(m), "--host_mem", "%g" % args.host_mem, "--num_cpu_threads", str(args.threads), "--read_lib_file", lib]
+    if "read2sdbg" not in out["cases"]:
+        dt, _ = run([ref, "read2sdbg"] + common + ["--output_prefix", os.path.join(d, "r2s")])
+        c = sdbg_summary(os.path.join(d, "r2s"))
+        c.update(wall_s=round(dt, 1), counting_md5=canon.digest_file(os.path.join(d, "r2s.counting")), octants=sdbg_octants(os.path.join(d, "r2s")))
+        out["cases"]["read2sdbg"] = c
+        print("read2sdbg", c, flush=True)
+        save()
+    if "count" not in out["cases"]:
+        dt, _ = run([ref, "count"] + common + ["--output_prefix", os.path.join(d, "cnt")])
+        hdr, _rows = canon.read_edges_info(os.path.join(d, "cnt"))
+        c = {"digest": canon.digest_edges(os.path.join(d, "cnt")), "n_edges": hdr["num_edges"], "wall_s": round(dt, 1),
+             "counting_md5": canon.digest_file(os.path.join(d, "cnt.counting")),
+             "cand_md5": canon.digest_file(os.path.join(d, "cnt.cand"))}
+        out["cases"]["count"] = c
+        print("count", c, flush=True)
+        save()
+    if "seq2sdbg_need_mercy" not in out["cases"]:
+        s2s = ["-k", str(k), "--kmer_from", "0", "--host_mem", "%g" % args.host_mem, "--num_cpu_threads", str(args.threads),
+               "--input_prefix", os.path.join(d, "cnt")]
+        dt, _ = run([ref, "seq2sdbg"] + s2s + ["--need_mercy", "--output_prefix", os.path.join(d, "s2m")])
+        c = sdbg_summary(os.path.join(d, "s2m"))
+        c["wall_s"] = round(dt, 1)
+        out["cases"]["seq2sdbg_need_mercy"] = c
+        print("seq2sdbg_need_mercy", c, flush=True)
+        save()
+    print("wrote", path)
+
+
 def run(cmd):
     t0 = time.perf_counter()
     p = subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True)
@@ -91,11 +156,13 @@ def main():
     ap.add_argument("--threads", type=int, default=8)
     ap.add_argument("--keep", default=None, help="work directory to keep (default: a temp dir)")
     ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden", "fullsize.json"))
-    ap.add_argument("--preset", choices=["configs1", "meta"], default="configs1")
+    ap.add_argument("--preset", choices=["configs1", "meta", "configs2"], default="configs1")
     ap.add_argument("--host_mem", type=float, default=48e9)
     args = ap.parse_args()
     if args.preset == "meta":
         return meta_golden(args)
+    if args.preset == "configs2":
+        return configs2_golden(args)
     n = int(args.reads) // 2 * 2
     k, m = 21, 2
     ref = os.path.join(ROOT, "oracle", "_ref", "ref_core")
