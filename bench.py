@@ -39,15 +39,11 @@ def make_reads(n_reads, rank, world):
     from megahit_amd import synth
     total_reads = n_reads * world
     G = max(5000, int(total_reads * 2.5))
-    genome = np.random.default_rng(1).integers(0, 4, size=G, dtype=np.uint8)
-    chunks = []
-    step = 1000000
-    for i, lo in enumerate(range(0, n_reads // 2, step)):
-        n = min(step, n_reads // 2 - lo)
-        r = synth.gen_pe_reads(n, G, read_len=READ_LEN, frag=400, err=0.005, seed=1000 * (rank + 1) + 1 + i, genome=genome)
-        chunks.append(synth.pack_reads_concat(r[:, ::-1]))  # stored reversed, as the reference loads them
+    # blocks of 1 M pairs made by spawned worker processes (a few per rank), stored reversed, as the reference loads them;
     # every chunk is a whole number of words only if n*2*150 % 16 == 0: true for n multiple of 8
-    return np.concatenate(chunks)
+    jobs = synth.pe_jobs("reversed", n_reads, G, 1, 1000 * (rank + 1) + 1, read_len=READ_LEN)
+    procs = max(1, min(len(jobs), (os.cpu_count() or 1) // max(1, world)))
+    return np.concatenate(list(synth.map_pe_blocks(jobs, procs)))
 
 
 def _latest_pmc_file():
@@ -358,8 +354,8 @@ def main():
     ap.add_argument("--cpu-sample-reads", type=float, default=1e6)
     ap.add_argument("--no-e2e", action="store_true", help="skip the files-in -> files-out run of the CLI after the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-full", action="store_true", help="also time the reference's CPU path on the FULL workload in this very run "
-                    "(~2 min of host time at 10 M reads; without it the full-size figure quoted is the one committed under profiles/)")
+    ap.add_argument("--no-cpu-full", dest="cpu_full", action="store_false", help="do not time the reference's CPU path on the FULL workload "
+                    "in this very run (~2 min of host time at 10 M reads; the full-size figure quoted is then the one committed under profiles/)")
     ap.add_argument("--force-dist", action="store_true", help="run the multi-GPU code path (RCCL collectives) even with one rank")
     ap.add_argument("--engine", choices=["read2sdbg", "count", "seq2sdbg"], default="read2sdbg",
                     help="sub-program to time; read2sdbg is BASELINE.json's metric, the others are reported beside it (1 GPU)")
@@ -518,6 +514,7 @@ def main():
                "config": {"workload": workload + ", %d synthetic 150 bp PE reads per GPU "
                                       "(BASELINE configs[1]), inputs resident in HBM, outputs left in HBM" % n_reads,
                           "reads_per_gpu": n_reads, "edges_per_gpu": E, "k": K, "min_count": MIN_COUNT,
+                          "s1_plan": eng.last_s1_plan() if args.engine == "read2sdbg" else None,
                           "parallelism": "1 GPU" if not use_dist else
                           "lv1 buckets over %d GPUs (C++ driver, RCCL ncclSend/ncclRecv all-to-all, marks routed to the read owners)" % world},
                "roofline": roof,

@@ -369,6 +369,7 @@ static bool dist_s1_presorted(mhx_ctx *c, mhx_comm *cm, uint32_t k, uint32_t m, 
   uint32_t *other = sorted == a ? b : a;
   src.spare = total <= it.n ? other : c->ws("s1_spare", total * 12 + 64).as<uint32_t>();
   s1_process(c, k, m, 0, nullptr, nullptr, total, r1, &src);
+  c->last_s1_plan += " [pre-sorted exchange]";
   return true;
 }
 

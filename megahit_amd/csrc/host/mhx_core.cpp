@@ -596,6 +596,7 @@ int main_read2sdbg(int argc, char **argv) {
     std::vector<std::vector<int64_t>> hist(rs.n);
     std::vector<mhx_s1_result> r1(rs.n);
     std::vector<uint64_t> nm(rs.n, 0);
+    std::string plan_text;
     run_ranks(rs, [&](int r, mhx_ctx *c, mhx_comm *cm) {
       const uint64_t lo = first[r], hi = first[r + 1];
       const uint64_t w0 = lib.end_offset(lo), w1 = lib.end_offset(hi);
@@ -604,6 +605,7 @@ int main_read2sdbg(int argc, char **argv) {
       mhx_sdbg_result r2{};
       CKT(mhx_dist_read2sdbg(c, cm, k, m, mercy_mode, &r1[r], &r2, &nm[r]));
       if (m > 1) hist[r] = fetch_t<int64_t>(c, MHX_BUF_MUL_HIST);
+      if (r == 0) plan_text = mhx_last_s1_plan(c);
       part[r].add(fetch_t<uint8_t>(c, MHX_BUF_SDBG_BYTES), fetch_t<uint64_t>(c, MHX_BUF_BUCKET_OFFSET), fetch_t<uint64_t>(c, MHX_BUF_BUCKET_COUNT),
                   fetch_t<uint64_t>(c, MHX_BUF_BUCKET_TIPS), fetch_t<uint64_t>(c, MHX_BUF_BUCKET_LARGE), fetch_t<uint64_t>(c, MHX_BUF_W_COUNT), r2);
     });
@@ -621,6 +623,7 @@ int main_read2sdbg(int argc, char **argv) {
       info("Total number of solid edges: %lld", (long long)n_solid_edges);
       mhxio::write_counting(out, h.data());
       info("Stage 1 done (%llu items, %llu solid occurrences).", (unsigned long long)n1, (unsigned long long)ns);
+      info("Stage 1 plan: %s", plan_text.c_str());
       if (need_mercy) info("Number mercy: %llu", (unsigned long long)mercy_total);
     }
     SdbgAcc acc;
@@ -661,6 +664,7 @@ int main_read2sdbg(int argc, char **argv) {
     mhxio::write_counting(out, hist.data());
     info("Stage 1 done (%llu items, %llu solid occurrences). Time elapsed: %.4f", (unsigned long long)r1.n_items,
          (unsigned long long)r1.n_solid, t.lap());
+    info("Stage 1 plan: %s", mhx_last_s1_plan(c));
     if (need_mercy) {
       info("Adding mercy edges...");
       uint64_t nm = 0;

@@ -2217,7 +2217,7 @@ std::string s1_plan_text(const mhx_ctx *c, uint32_t k, uint64_t n_items) {
 // fit: below 2^pos_bits bases as they are, beyond that with the upper position bits as a tag inside the key words
 // (s1_pos_tag: 8 spare bits between the (k-1)-mer and head/tail, i.e. up to 2^(pos_bits + 8) bases: 7 G reads of 150 bp).
 uint32_t s1_pos_bits(const mhx_ctx *c) {
-  static const bool force = getenv("MHX_S1_FORCE_TAGGED") != nullptr;  // tests: tags at small sizes too
+  const bool force = getenv("MHX_S1_FORCE_TAGGED") != nullptr;  // tests: tags at small sizes too
   const long long f = c->opt("s1_pos_bits", 0);
   if (f > 0) return (uint32_t)std::min<long long>(std::max<long long>(f, 4), 32);
   if (force) {  // the narrowest position word that keeps the tags below 128

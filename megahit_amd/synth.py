@@ -164,15 +164,27 @@ def gen_metagenome_library(n_reads, n_genomes, genome_len=2500000, seed=3, sigma
     return blocks
 
 
-# ---- large libraries: blocks made by worker processes, written in order as they arrive (configs[2]: 100 M reads) ----
+# ---- large libraries: blocks made by worker processes, consumed in order as they arrive (configs[2]: 100 M reads) ----
+# Workers are SPAWNED (not forked): callers may have a HIP runtime with its threads alive in the parent.  Every worker makes the
+# genome once for itself (default_rng(seed) is deterministic: 1.4 s for 250 Mbp).
 
-_PE_GENOME = None
+_GENOMES = {}
 
 
-def _pe_block_records(job):
-    """Worker: one PE block -> the bytes of its `.bin` records (uint32 length + packed words per read)."""
-    c, G, read_len, frag, err, seed = job
-    reads = gen_pe_reads(c, G, read_len=read_len, frag=frag, err=err, seed=seed, genome=_PE_GENOME)
+def _genome(seed, G):
+    g = _GENOMES.get((seed, G))
+    if g is None:
+        _GENOMES.clear()
+        g = _GENOMES[(seed, G)] = np.random.default_rng(seed).integers(0, 4, size=G, dtype=np.uint8)
+    return g
+
+
+def _pe_block(job):
+    """Worker: one PE block -> `.bin` record bytes ("records") or the packed words of the REVERSED reads ("reversed")."""
+    form, c, G, genome_seed, read_len, frag, err, seed = job
+    reads = gen_pe_reads(c, G, read_len=read_len, frag=frag, err=err, seed=seed, genome=_genome(genome_seed, G))
+    if form == "reversed":
+        return pack_reads_concat(reads[:, ::-1])
     packed = pack_reads(reads)
     rec = np.empty((reads.shape[0], 1 + packed.shape[1]), dtype=np.uint32)
     rec[:, 0] = read_len
@@ -180,30 +192,38 @@ def _pe_block_records(job):
     return rec.tobytes()
 
 
+def map_pe_blocks(jobs, procs=None):
+    """-> iterator over _pe_block(job) in job order, computed by up to `procs` spawned workers (1: in this process)."""
+    import multiprocessing as mp
+    import os
+    import sys
+    procs = max(1, min(procs or (os.cpu_count() or 1), len(jobs), 64))
+    main = sys.modules.get("__main__")
+    if getattr(main, "__file__", None) is None and (not sys.argv or sys.argv[0] in ("", "-")):
+        procs = 1  # a program read from stdin: spawned workers cannot import their parent's __main__ (they hang)
+    if procs == 1:
+        for j in jobs:
+            yield _pe_block(j)
+        return
+    with mp.get_context("spawn").Pool(procs) as pool:
+        for out in pool.imap(_pe_block, jobs, chunksize=1):
+            yield out
+
+
+def pe_jobs(form, n_reads, G, genome_seed, read_seed0, read_len=150, frag=400, err=0.005):
+    return [(form, min(1000000, n_reads // 2 - lo), G, genome_seed, read_len, frag, err, read_seed0 + i)
+            for i, lo in enumerate(range(0, n_reads // 2, 1000000))]
+
+
 def write_pe_library(prefix, n_reads, genome_seed, read_seed0, procs=None, read_len=150, frag=400, err=0.005, description="synthetic"):
     """The single-genome family of SURVEY.md section 8d at any size, without holding the reads in memory: genome =
     default_rng(genome_seed) over 2.5 bp per read, PE blocks of 1 M pairs with seeds read_seed0 + i — byte for byte the
-    file write_read_lib(gen_shard_library(...)) writes.  The blocks are made by `procs` forked workers (the genome is
-    shared copy-on-write) and written in block order."""
-    import multiprocessing as mp
-    import os
-    global _PE_GENOME
+    file write_read_lib(gen_shard_library(...)) writes."""
     n_reads = n_reads // 2 * 2
     G = int(n_reads * 2.5)
-    _PE_GENOME = np.random.default_rng(genome_seed).integers(0, 4, size=G, dtype=np.uint8)
-    jobs = []
-    for i, lo in enumerate(range(0, n_reads // 2, 1000000)):
-        jobs.append((min(1000000, n_reads // 2 - lo), G, read_len, frag, err, read_seed0 + i))
-    procs = max(1, min(procs or (os.cpu_count() or 1), len(jobs), 64))
     with open(prefix + ".bin", "wb") as f:
-        if procs == 1:
-            for j in jobs:
-                f.write(_pe_block_records(j))
-        else:
-            with mp.get_context("fork").Pool(procs) as pool:
-                for blob in pool.imap(_pe_block_records, jobs, chunksize=1):
-                    f.write(blob)
-    _PE_GENOME = None
+        for blob in map_pe_blocks(pe_jobs("records", n_reads, G, genome_seed, read_seed0, read_len, frag, err), procs):
+            f.write(blob)
     with open(prefix + ".lib_info", "w") as f:
         f.write("%d %d\n%s\n0 %d %d %d\n" % (n_reads * read_len, n_reads, description, n_reads, read_len, 1))
     return n_reads, n_reads * read_len

@@ -94,6 +94,14 @@ def check_sdbg(outs, want):
     (3, 21, 2, STAGE_S1, {"dist_max_items": 40000}),
     (2, 21, 1, 0, {"dist_max_items": 60000}),                # m = 1: stage 2 per occurrence
     (2, 27, 2, 0, {"dist_max_items": 40000}),                # 16-byte records: owner multisplit path, passes
+    # round 4: the stream plan at any density (s1.hip s1_plan) on several ranks
+    (3, 21, 2, STAGE_S1, {"s1_stream_bits": 19}),            # three pre-sort passes, buckets of a 19-bit prefix read from three sources
+    (2, 21, 2, 0, {"s1_stream_sub0": 2, "s1_stream_prefetch": 1}),  # every bucket in four sub-rounds, prefetching kernel
+    (3, 21, 2, STAGE_S1, {"s1_stream_fill": 2}),             # every bucket overflows its table and splits itself, several sources
+    (3, 21, 2, 0, {"s1_stream_max": 2}),                     # the ranks derive a wider prefix from the density they agreed on
+    (2, 21, 2, 0, {"s1_pos_bits": 12}),                      # position tags in every record
+    (3, 21, 2, STAGE_S1, {"dist_max_items": 40000, "s1_filter_in_gen": 0}),  # bucket-range passes with extraction batches + split
+    (3, 21, 2, STAGE_S1, {"dist_max_items": 40000, "s1_stream_bits": 18, "s1_stream_fill": 3}),  # ... and everything at once
 ])
 def test_read2sdbg_ranks_as_threads(world, k, m, balance, opts):
     def body(r, e, cm):
@@ -130,7 +138,8 @@ def test_read2sdbg_mercy_ranks_as_threads(world, k, m, mercy, opts):
 
 
 def test_rank_tagged_records_with_sparse_marks(monkeypatch):
-    """compact records that carry the source rank in spare key bits (the layout past 2^32 global positions)"""
+    """compact records that carry the upper bits of their global position in spare key bits (what every record of a read set
+    past 2^32 bases does): MHX_S1_FORCE_TAGGED narrows the position word until the tags are in use"""
     monkeypatch.setenv("MHX_S1_FORCE_TAGGED", "1")
     world, k, m = 3, 21, 2
 

@@ -7,8 +7,19 @@ bandwidth, and the same run with the plain LSD plan (MHX_SORT_HYBRID=0) beside i
   meta    read2sdbg -k 27 -m 1 on the 40 M-read metagenome shard (tools/make_fullsize_golden.py --preset meta),
           digest checked against tests/golden/fullsize_meta.json; the memory plan decides the number of passes
 
+  configs2  the north-star size (BASELINE configs[2]): read2sdbg -k 21 -m 2 on 100 M synthetic reads (tools/make_fullsize_golden.py
+          --preset configs2), digests against tests/golden/fullsize_100M.json: (a) ONE GPU (memory plan: bucket-range passes,
+          positions past 2^32), (b) `--gpus 8` with all eight ranks mapped onto this device (the multi-GPU drivers with the
+          in-process transport; MHX_FREE_BYTES gives every rank an eighth of the HBM), wall and kernel seconds next to the
+          reference's wall time; [reads.bin directory] may be given to reuse a generated library
+  owner8  what ONE of eight GPUs does for configs[2]: stage 1 over one eighth of the lv1 buckets of the 100 M reads at a time
+          (mhx_set_bucket_filter, accumulating), per eighth the kernel time and ns per record on the streaming plan; then
+          stage 2 per eighth, each eighth's SdBG digest against the reference's (tests/golden/fullsize_100M.json octants)
+
     python tools/config_bench.py klist > profiles/r03_bench_klist.json
     python tools/config_bench.py meta  > profiles/r03_bench_meta.json
+    python tools/config_bench.py configs2 > profiles/r04_bench_configs2.json
+    python tools/config_bench.py owner8 > profiles/r04_bench_owner8.json
 """
 import json
 import os
@@ -25,6 +36,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 from megahit_amd import canon  # noqa: E402
 
 MHX = os.path.join(ROOT, "megahit_amd", "mhx_core")
+LAST_LOG = ""
 HBM_PEAK = 8000.0
 
 
@@ -35,6 +47,8 @@ def run(args, env, prof):
     t0 = time.perf_counter()
     p = subprocess.run([MHX] + args, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, env=e)
     wall = time.perf_counter() - t0
+    global LAST_LOG
+    LAST_LOG = p.stderr
     if p.returncode != 0:
         raise SystemExit(p.stderr[-3000:])
     phases = {m.group(1).strip()[:48]: float(m.group(2)) for m in re.finditer(r"INFO\s+(.*?)\.? Time elapsed: ([0-9.]+)", p.stderr)}
@@ -109,5 +123,112 @@ def meta():
     print(json.dumps(out, indent=1))
 
 
+def configs2_library(d):
+    """the 100 M-read library in directory d (generated unless d/reads.bin is there), md5 checked -> golden dict"""
+    import make_fullsize_golden as mfg
+    with open(os.path.join(ROOT, "tests", "golden", "fullsize_100M.json")) as f:
+        full = json.load(f)
+    if not os.path.exists(os.path.join(d, "reads.bin")):
+        t0 = time.perf_counter()
+        mfg.gen_configs2_library(os.path.join(d, "reads"), full["reads"])
+        sys.stderr.write("library generated in %.1f s\n" % (time.perf_counter() - t0))
+    assert canon.digest_file(os.path.join(d, "reads.bin")) == full["lib_bin_md5"], "the generator is not deterministic across boxes"
+    return full
+
+
+def configs2(keep=None, emit=True):
+    keep = keep or (sys.argv[2] if len(sys.argv) > 2 and emit else None)
+    with tempfile.TemporaryDirectory(prefix="mhx_c2_") as tmp:
+        d = keep or tmp
+        full = configs2_library(d)
+        n, k, m = full["reads"], full["k"], full["m"]
+        want = full["cases"]["read2sdbg"]
+        out = {"workload": "BASELINE configs[2] = the north-star size: read2sdbg -k %d -m %d on %d synthetic 150 bp PE reads (%.1f G edges)" % (k, m, n, full["edges"] / 1e9),
+               "reference": {"wall_s": want["wall_s"], "threads": full["reference_threads"], "host": full["reference_host"], "digest": want["digest"]}, "runs": {}}
+        common = ["read2sdbg", "-k", str(k), "-m", str(m), "--host_mem", "64e9", "--num_cpu_threads", "8", "--read_lib_file", os.path.join(d, "reads")]
+        for label, pre, env in (("one_gpu", [], {}),
+                                ("eight_ranks_on_one_device", ["--gpus", "8"], {"MHX_GPU_MAP": "0,0,0,0,0,0,0,0", "MHX_FREE_BYTES": "26e9"})):
+            o = os.path.join(tmp, "o_" + label)
+            wall, phases, kernels, passes = run(pre + common + ["--output_prefix", o], env, os.path.join(tmp, "prof.json"))
+            r = summarise(kernels)
+            ok = canon.digest_sdbg(o) == want["digest"] and canon.digest_file(o + ".counting") == want["counting_md5"]
+            r.update(wall_s=round(wall, 2), phases_s=phases, memory_plan_passes=passes, bit_identical_to_reference=ok,
+                     M_edges_per_s_wall=round(full["edges"] / wall / 1e6, 1), M_edges_per_s_kernel_time=round(full["edges"] / r["kernel_ms_total"] / 1e3, 1),
+                     speedup_over_reference_wall=round(want["wall_s"] / wall, 1))
+            out["runs"][label] = r
+            sys.stderr.write("%s %s\n" % (label, json.dumps({"wall_s": r["wall_s"], "kernel_ms": r["kernel_ms_total"], "ok": ok, "passes": passes})))
+            r["log_tail"] = [l for l in LAST_LOG.splitlines() if "plan" in l.lower() or "passes" in l][:12]
+            for fn in os.listdir(tmp):
+                if fn.startswith("o_"):
+                    os.remove(os.path.join(tmp, fn))
+    if emit:
+        print(json.dumps(out, indent=1))
+    return out
+
+
+def owner8(keep=None, emit=True):
+    import numpy as np
+    from megahit_amd import lib
+    keep = keep or (sys.argv[2] if len(sys.argv) > 2 and emit else None)
+    with tempfile.TemporaryDirectory(prefix="mhx_o8_") as tmp:
+        d = keep or tmp
+        full = configs2_library(d)
+        n, k, m = full["reads"], full["k"], full["m"]
+        e = lib.Engine(0)
+        recs = np.memmap(os.path.join(d, "reads.bin"), dtype=np.uint32, mode="r")
+        t0 = time.perf_counter()
+        e.load_bin_records(recs, n, reverse=True)
+        load_s = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        hist = np.asarray(e.bucket_histogram(lib.STAGE_S1, k, m), dtype=np.uint64)
+        hist_s = time.perf_counter() - t0
+        out = {"workload": "one GPU's share of BASELINE configs[2]: stage 1 of read2sdbg -k %d -m %d over one eighth of the lv1 buckets of %d reads at a time" % (k, m, n),
+               "load_s": round(load_s, 2), "bucket_histogram_s": round(hist_s, 3), "s1_items_all": int(hist.sum()), "eighths": []}
+        e.profile(True)
+        for o in range(8):
+            keepm = np.zeros(65536, dtype=np.uint8)
+            keepm[o * 8192:(o + 1) * 8192] = 1
+            n_keep = int(hist[o * 8192:(o + 1) * 8192].sum())
+            e.set_bucket_filter(keepm, n_keep, 0, accumulate=o > 0)
+            e.profile_reset()
+            t0 = time.perf_counter()
+            r1 = e.read2sdbg_s1(k, m)
+            e.synchronize()
+            dt = time.perf_counter() - t0
+            st = e.profile_get()
+            kms = sum(v["ms"] for v in st.values())
+            ent = {"eighth": o, "records": int(r1.n_items), "plan": e.last_s1_plan(), "wall_ms": round(dt * 1e3, 2), "kernel_ms": round(kms, 2),
+                   "ps_per_record_kernel_time": round(kms * 1e9 / max(1, r1.n_items), 2),
+                   "kernel_ms_top": {k2: round(v["ms"], 2) for k2, v in sorted(st.items(), key=lambda kv: -kv[1]["ms"])[:8]}}
+            assert r1.n_items == n_keep, (r1.n_items, n_keep)
+            out["eighths"].append(ent)
+            sys.stderr.write("s1 eighth %d: %s\n" % (o, json.dumps(ent)))
+        e.set_bucket_filter(None)
+        hist2 = np.asarray(e.bucket_histogram(lib.STAGE_S2, k, m), dtype=np.uint64)
+        ok_all = True
+        for o in range(8):
+            keepm = np.zeros(65536, dtype=np.uint8)
+            keepm[o * 8192:(o + 1) * 8192] = 1
+            e.set_bucket_filter(keepm, int(hist2[o * 8192:(o + 1) * 8192].sum()), 0)
+            e.profile_reset()
+            r2 = e.read2sdbg_s2(k, m)
+            st = e.profile_get()
+            dig = canon.digest_sdbg_buffers(k, e.fetch(lib.BUF_SDBG_BYTES, np.uint8), e.fetch(lib.BUF_BUCKET_COUNT, np.uint64), e.fetch(lib.BUF_BUCKET_TIPS, np.uint64),
+                                            e.fetch(lib.BUF_BUCKET_LARGE, np.uint64), e.fetch(lib.BUF_BUCKET_OFFSET, np.uint64))
+            ok = dig == full["cases"]["read2sdbg"]["octants"][o]
+            ok_all = ok_all and ok
+            out["eighths"][o].update(s2_items=int(r2.n_items), sdbg_records=int(r2.n_sdbg), s2_kernel_ms=round(sum(v["ms"] for v in st.values()), 2),
+                                     sdbg_digest_equals_reference=ok)
+            sys.stderr.write("s2 eighth %d: %d records, digest ok = %s\n" % (o, r2.n_sdbg, ok))
+        e.set_bucket_filter(None)
+        out["all_eighths_bit_identical_to_reference"] = ok_all
+        hl = 37.7e-3 / 1.33e9 * 1e12
+        out["headline_ps_per_record_round3"] = round(hl, 2)
+        e.close()
+    if emit:
+        print(json.dumps(out, indent=1))
+    return out
+
+
 if __name__ == "__main__":
-    {"klist": klist, "meta": meta}[sys.argv[1]]()
+    {"klist": klist, "meta": meta, "configs2": configs2, "owner8": owner8}[sys.argv[1]]()

@@ -22,14 +22,7 @@ from megahit_amd import canon, synth  # noqa: E402
 
 def gen_library(prefix, n_reads):
     """The bench.py / e2e_cli.py workload: one genome (seed 1, 2.5 bp per read), PE blocks of 1 M pairs (seed 1001+i)."""
-    import numpy as np
-    G = int(n_reads * 2.5)
-    genome = np.random.default_rng(1).integers(0, 4, size=G, dtype=np.uint8)
-    blocks = []
-    for i, lo in enumerate(range(0, n_reads // 2, 1000000)):
-        c = min(1000000, n_reads // 2 - lo)
-        blocks.append(synth.gen_pe_reads(c, G, read_len=150, frag=400, err=0.005, seed=1001 + i, genome=genome))
-    synth.write_read_lib(prefix, blocks)
+    synth.write_pe_library(prefix, n_reads, 1, 1001)  # (blocks made by worker processes, written in order)
 
 
 META = {"reads": 40000000, "genomes": 160, "genome_len": 2500000, "seed": 3, "k": 27, "m": 1}
