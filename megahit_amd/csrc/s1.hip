@@ -1011,8 +1011,6 @@ struct S1SegArgs {
   uint32_t *err;
   int la_chunks;      // look-ahead limit, in chunks of 256 records
   int direct_marks;   // k_s1_stream: the non-solid marks come from the table (one stored position per key), no second read
-  int used_list;      // k_s1_stream: the per-key phases walk a list of the occupied slots instead of the whole table
-  int read_first;     // k_s1_stream: look at the slot with a plain LDS read before trying to claim it
 };
 
 constexpr unsigned long long kSegEmpty = ~0ull;  // never a key: head/tail bits 63 do not occur (max (4<<3)|4)
@@ -1378,7 +1376,7 @@ __global__ __launch_bounds__(256) void k_s1_seg(const uint32_t *__restrict__ ite
 // to hold 2-4 x what the table takes: cheaper than a third sort pass, s1_plan).  Nothing here redoes the stage: *err is
 // left for what the host really has to handle (an output region that is too small).
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int kStreamThreads = 1024;  // one workgroup per CU: 8192 slots of key + count + first position + list entry = 122 KB of LDS
+constexpr int kStreamThreads = 1024;  // one workgroup per CU: 8192 slots of key + count + first position = 98 KB of LDS
 constexpr uint32_t kStreamEmpty = 0xFFFFFFFFu;  // never a key: head/tail bits 63 do not occur
 
 __global__ void k_bucket_bounds(const uint32_t *__restrict__ items, uint64_t n, int stride, uint64_t *__restrict__ bstart, int pbits);  // kmsort_emu.hip
@@ -1386,37 +1384,51 @@ __global__ void k_bucket_bounds(const uint32_t *__restrict__ items, uint64_t n, 
 struct S1StreamGeom {
   int pbits;          // prefix bits the records are sorted on: 2^pbits buckets, bounds[q * (2^pbits + 1) + b]
   int sub0;           // every bucket starts with 2^sub0 sub-rounds
-  int prefetch;       // runtime switch of the PF instantiation's next-bucket pipelining (one source only)
   uint32_t n_buckets; // 1 << pbits
-  uint32_t max_fill;  // a round gives up when it has claimed more slots than this (long probe chains are slow before they fail)
+  uint32_t max_fill;  // a round whose table ends up with more keys than this is redone in two halves
 };
 
-// NT / LOGS: 1024 threads and 8192 slots = one workgroup per CU (122 KB of LDS); 512 threads and 4096 slots (62 KB) = two per CU:
-// while one of them walks its table the other has loads in flight, at the price of a table that holds half as many keys
-// (s1_stream_half; with sub-rounds an overflow costs that bucket one more read, not the stage).
-// PF: the record loads of trip i + 1 are issued BEFORE the inserts of trip i, and thread 0 fetches the ticket and the bounds of
-// the next bucket while the current one is worked on.  Phase clocks of wave 0 (round 3, 4 M reads): a trip of 4 records per
-// thread waits ~4 600 cycles for its loads and then spends ~4 200 cycles in its 4 compare-and-swap + add pairs (all 16
-// wavefronts of the CU hit the LDS atomics at the same time), one after the other; and a bucket started with three
-// latencies in a row (ticket -> bounds -> first records).
-template <bool AGG, int UNR, int NT = kStreamThreads, int LOGS = 13, bool PF = false>
+constexpr int kStreamBatch = 4;     // buckets per ticket
+constexpr int kStreamSrcMax = kWave;  // bucket bounds of up to this many sources are staged in LDS (one lane of wave 0 per source)
+
+// NT / LOGS: 1024 threads and 8192 slots = one workgroup per CU (98 KB of LDS: key, count, first position; + 8 KB of tags
+// when the read set has positions past 2^32); 512 threads and 4096 slots = two per CU (s1_stream_half: tables at twice the
+// load — the insert phase alone measures 1.9 x slower per record, tools/micro/insert_probe.hip — kept for the tests, whose
+// buckets then overflow and split).
+//
+// What the kernel's time is made of, measured with tools/micro/{lds_probe,insert_probe}.hip on the device before this form
+// was written (round 4): an LDS operation of 64 random lanes costs the CU 6.5 cycles (add, read) to 11.8 (compare-and-swap
+// with return) — the 1.33 G records of the headline would need 0.6 ms of those; the insert phase took 4.5 ms because every
+// record ran its own probe loop (a loop iteration costs its instructions whether 64 lanes or 2 are still looking: ~3.5
+// iterations per record and wavefront) and because every new key paid a same-address atomic on a shared counter plus a
+// list entry.  Hence: the first probe of the UNR records of a trip is straight-line code for all lanes, the few lanes that
+// met another key retry TOGETHER in one loop per trip (whichever of their records is still pending), new keys are counted
+// per thread, and the per-key phase is ONE walk over the table (statistics, marks, aggregated items, wipe) instead of
+// three phases with a list of occupied slots.  Loads: the records of trip i + 1 — across the end of a round or of a bucket:
+// the first trip of what comes next — are requested before the inserts of trip i, and wave 0 fetches the next bucket's
+// ticket and bounds while the current bucket is worked on.
+template <bool AGG, int UNR, int NT, int LOGS, bool TAGS>
 __global__ __launch_bounds__(NT) void k_s1_stream(const uint32_t *__restrict__ items0, const uint64_t *__restrict__ bounds, S1SegArgs a,
-                                                             S1StreamGeom geo, uint32_t bucket_stride, uint32_t *__restrict__ ticket,
-                                                             const uint32_t *const *__restrict__ srcs, int n_src) {
+                                                  S1StreamGeom geo, uint32_t bucket_stride, uint32_t *__restrict__ ticket,
+                                                  const uint32_t *const *__restrict__ srcs, int n_src) {
   // Multi-GPU: the records of a bucket arrive as n_src sub-ranges, one per sending rank, each rank's records sorted by
   // bucket in an array of its own (srcs[q], bounds[q * (n_buckets + 1) + bucket]); single GPU: one source, items0.
   constexpr int NSLOT = 1 << LOGS;
+  constexpr int TRIP = NT * UNR;
+  static_assert(NSLOT % NT == 0 && UNR <= 8, "table walk / pending mask");
   __shared__ uint32_t keys[NSLOT];
   __shared__ uint32_t cnts[NSLOT];
-  __shared__ uint32_t fpos[NSLOT];  // position word of the record that created the slot (direct_marks)
-  __shared__ uint8_t ftag[NSLOT];   // ... and the position bits above it (s1_pos_tag), when the read set has any
-  // the occupied slots in the order they were claimed: a bucket fills about a third of the table (2 670 of 8 192 slots at
-  // 10 M reads), and the per-key phases below would otherwise visit all 8 192 slots of all buckets
-  __shared__ uint16_t used[NSLOT];
+  __shared__ uint32_t fpos[NSLOT];             // position word of the record that claimed the slot (direct_marks)
+  __shared__ uint8_t ftag[TAGS ? NSLOT : 4];   // ... and the position bits above it (s1_pos_tag), when the read set has any
   __shared__ uint32_t lhist[kSegHist];
-  __shared__ uint32_t s_bad, s_agg_cur, s_mark_cur, s_bucket, s_nused;
-  __shared__ uint64_t s_lo, s_hi;  // pipelined: bounds of the bucket in s_bucket, fetched while the bucket before it was worked on
+  __shared__ uint32_t s_bad[2], s_nclaimed[2];  // per round, double-buffered: the next round's are cleared while this round's are read
+  __shared__ uint32_t s_agg_cur, s_mark_cur;
+  // the bucket being worked on and the one after it: ticket and per-source bounds (wave 0 fills [par ^ 1] during bucket [par])
+  __shared__ uint32_t s_tk[2];
+  __shared__ uint64_t s_lo[2][kStreamSrcMax], s_hi[2][kStreamSrcMax];
+  __shared__ uint64_t s_src[kStreamSrcMax];  // the sources' arrays (multi-GPU)
   const int tid = threadIdx.x, lane = tid & (kWave - 1);
+  const bool wave0 = tid < kWave;
   const uint64_t lanemask_lt = (1ull << lane) - 1;
   uint2 *const agg_end = AGG ? a.agg_raw + (size_t)(blockIdx.x + 1) * a.agg_cap : nullptr;
   unsigned long long *const marks_out = a.marks_raw ? a.marks_raw + (size_t)blockIdx.x * a.marks_cap : nullptr;
@@ -1426,215 +1438,365 @@ __global__ __launch_bounds__(NT) void k_s1_stream(const uint32_t *__restrict__ i
   }
   for (int i = tid; i < kSegHist; i += NT) lhist[i] = 0;
   if (tid == 0) {
-    s_bad = 0;
+    s_bad[0] = s_bad[1] = 0;
+    s_nclaimed[0] = s_nclaimed[1] = 0;
     s_agg_cur = 0;
     s_mark_cur = 0;
-    s_nused = 0;
   }
   const uint32_t m = a.m;
   const int k = a.k;
   const int pbits = geo.pbits;
   const size_t bstride = (size_t)geo.n_buckets + 1;
+  const bool staged = n_src <= kStreamSrcMax;  // (more sources than lanes: the bounds are read from memory where they are needed)
   // local key: the (k-1)-mer bits below the prefix, then head/tail (the position tag bits in between dropped)
   const int rem = 2 * (k - 1) - pbits;  // 0..26 bits
   const int lk_bits = rem + 6;          // <= 32
+  const int mer_sh = 64 - 2 * (k - 1);
+  const uint32_t mer_mask = rem ? (1u << rem) - 1u : 0u;
   auto local_key = [&](uint32_t w0, uint32_t w1) -> uint32_t {
     const uint64_t key = ((uint64_t)w0 << 32) | w1;
-    const uint32_t mer = rem ? (uint32_t)((key << pbits) >> (64 - rem)) : 0u;
-    return mer << 6 | (w1 & 63u);
+    return ((uint32_t)(key >> mer_sh) & mer_mask) << 6 | (w1 & 63u);
   };
   // the (k+1)-mer head.S.tail of a table key of bucket bi, chars MSB-first in 64 bits
   auto edge_of = [&](uint32_t bi, uint32_t lk) -> uint64_t {
     const uint64_t smer = ((uint64_t)bi << (64 - pbits)) | (rem ? (uint64_t)(lk >> 6) << (64 - pbits - rem) : 0ull);
     return ((uint64_t)((lk >> 3) & 7u) << 62) | (smer >> 2) | ((uint64_t)(lk & 7u) << (62 - 2 * k));
   };
-  unsigned long long st_solid = 0, st_both = 0;
-  const bool pipelined = PF && geo.prefetch && n_src == 1;
-  auto bounds_of = [&](int q, uint32_t b, uint64_t &lo_, uint64_t &hi_) {
-    if (pipelined) {
-      lo_ = s_lo;
-      hi_ = s_hi;
-    } else {
-      lo_ = bounds[(size_t)q * bstride + b];
-      hi_ = bounds[(size_t)q * bstride + b + 1];
+  auto bucket_of = [&](int par) -> uint64_t { return (uint64_t)s_tk[par] * bucket_stride; };
+  // (explicit global address space for everything read from memory here: a select between an LDS and a global address would
+  //  become a FLAT load, and one FLAT load in flight makes every later wait for a global load a wait for ALL loads)
+  typedef const __attribute__((address_space(1))) uint64_t *gptr64;
+  const gptr64 gbounds = (gptr64)bounds;
+  auto lo_of = [&](int par, int q) -> uint64_t {
+    uint64_t v = s_lo[par][q & (kStreamSrcMax - 1)];
+    if (!staged) v = gbounds[(size_t)q * bstride + bucket_of(par)];
+    return v;
+  };
+  auto hi_of = [&](int par, int q) -> uint64_t {
+    uint64_t v = s_hi[par][q & (kStreamSrcMax - 1)];
+    if (!staged) v = gbounds[(size_t)q * bstride + bucket_of(par) + 1];
+    return v;
+  };
+  auto src_of = [&](int q) -> uint64_t {  // the array of source q
+    if (n_src <= 1) return (uint64_t)items0;
+    uint64_t v = s_src[q & (kStreamSrcMax - 1)];
+    if (!staged) v = ((gptr64)srcs)[q];
+    return v;
+  };
+  // wave 0 holds the workgroup's place in the bucket sequence.  Tickets come in batches of kStreamBatch consecutive buckets: the
+  // answer of the atomic is waited for on the spot (the compiler broadcasts it through a readfirstlane), which stalls wave 0 — an
+  // insert worker like the others — for a memory round trip, so it is made rare; neighbouring buckets are also neighbours in memory.
+  uint32_t w0_tk = 0, w0_left = 0;
+  auto next_ticket = [&]() -> uint32_t {
+    if (w0_left == 0) {
+      uint32_t r = lane == 0 ? atomicAdd(ticket, 1u) : 0u;
+      r = __shfl(r, 0, kWave);
+      const uint64_t first = (uint64_t)r * kStreamBatch;
+      w0_tk = first > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)first;
+      w0_left = kStreamBatch;
+    } else if (w0_tk != 0xFFFFFFFFu) {
+      ++w0_tk;
+    }
+    --w0_left;
+    return w0_tk;
+  };
+  // wave 0, lane q: the bounds of source q of bucket nb — requested, and used a bucket's inserts later (publish_desc); with them
+  // the host's error word: a workgroup stops taking buckets once the host has to step in anyway
+  uint64_t d_lo = 0, d_hi = 0;
+  uint32_t d_err = 0;
+  auto request_bounds = [&](uint64_t nb) {
+    d_lo = d_hi = 0;
+    d_err = ((const __attribute__((address_space(1))) uint32_t *)a.err)[0];
+    if (staged && nb < geo.n_buckets && lane < n_src) {
+      d_lo = gbounds[(size_t)lane * bstride + nb];
+      d_hi = gbounds[(size_t)lane * bstride + nb + 1];
     }
   };
-  // (a workgroup stops taking buckets once the host has to step in anyway)
-  auto take_ticket = [&]() -> uint32_t {
-    return __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 0xFFFFFFFFu / (bucket_stride ? bucket_stride : 1u) : atomicAdd(ticket, 1u);
-  };
-  if (pipelined && tid == 0) {
-    const uint32_t t0 = take_ticket();
-    const uint64_t b0 = (uint64_t)t0 * bucket_stride;
-    s_bucket = t0;
-    if (b0 < geo.n_buckets) {
-      s_lo = bounds[b0];
-      s_hi = bounds[b0 + 1];
+  auto publish_desc = [&](int par, uint32_t tk) {
+    if (lane == 0) s_tk[par] = d_err ? 0xFFFFFFFFu / (bucket_stride ? bucket_stride : 1u) : tk;
+    if (staged && lane < n_src) {
+      s_lo[par][lane] = d_lo;
+      s_hi[par][lane] = d_hi;
     }
+  };
+  if (wave0) {  // the first bucket of this workgroup
+    if (staged && n_src > 1 && lane < n_src) s_src[lane] = ((gptr64)srcs)[lane];
+    const uint32_t t0 = next_ticket();
+    request_bounds((uint64_t)t0 * bucket_stride);
+    publish_desc(0, t0);
   }
   __syncthreads();
 
+  // a trip = the next TRIP records of one source; the cursor walks the non-empty sources of a bucket in order (uniform values)
+  auto first_source = [&](int par, int from) -> int {
+    int q = from;
+    while (q < n_src && lo_of(par, q) == hi_of(par, q)) ++q;
+    return q;
+  };
+  typedef const __attribute__((address_space(1))) uint32_t *gptr;
+  struct TripRef {
+    gptr g;      // the trip's first record
+    uint32_t n;  // its records (1..TRIP)
+  };
+  auto uniform64 = [](uint64_t v) -> uint64_t {  // (a value all lanes agree on, moved to scalar registers: addresses become base + 32-bit offset)
+    return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+  };
+  // Explicit global address space: the pointer comes out of a select between a kernel argument and a pointer read from memory,
+  // and FLAT loads would count in lgkmcnt as well — every wait for an LDS atomic would then wait for the loads in flight too.
+  auto trip_ref = [&](int q, uint64_t base, uint64_t hi) -> TripRef {
+    const uint64_t src = src_of(q);
+    const uint64_t left = hi - base;
+    return TripRef{(gptr)uniform64(src + base * 12), (uint32_t)__builtin_amdgcn_readfirstlane((int)(left < (uint64_t)TRIP ? (uint32_t)left : (uint32_t)TRIP))};
+  };
+  // Unconditional loads, always (index clamped into the trip, which holds at least one record): straight-line code, so that all
+  // UNR loads are issued before the first wait — a load inside an `if` is waited for at the end of its block.  Where no trip
+  // follows, the caller passes a one-record stand-in and clears the mask.
+  auto load_trip = [&](const TripRef &t, uint32_t (&w0)[UNR], uint32_t (&w1)[UNR], uint32_t (&w2)[UNR], uint32_t &inm) {
+    inm = 0;
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const uint32_t idx = (uint32_t)(u * NT + tid);
+      const bool in = idx < t.n;
+      inm |= in ? 1u << u : 0u;
+      const gptr p = t.g + (in ? idx : t.n - 1) * 3u;
+      w0[u] = p[0];
+      w1[u] = p[1];
+      w2[u] = p[2];
+    }
+  };
+
+  unsigned long long st_solid = 0, st_both = 0;
+  const int probe_limit = a.la_chunks;  // (stream mode: the host passes the probe limit here; tests set it to 0)
+  // register set A: at the top of a round it holds the round's first trip, requested long before (by the round before it, or
+  // right here for the first bucket) — one writer on the hot path, so that no copies (= waits for the loads) are needed
+  uint32_t nw0[UNR], nw1[UNR], nw2[UNR], n_inm = 0;
+  int par = 0, rp = 0;
+  TripRef cur{(gptr)bounds, 1u};  // (always a readable address: the stand-in where no trip follows; at first the bounds themselves)
+  auto request_first = [&](int bpar) {  // the first trip of bucket [bpar] -> set A (bucket empty or none left: a stand-in, mask cleared)
+    bool follows = false;
+    if (bucket_of(bpar) < geo.n_buckets) {
+      const int q = first_source(bpar, 0);
+      if (q < n_src) {
+        cur = trip_ref(q, lo_of(bpar, q), hi_of(bpar, q));
+        follows = true;
+      }
+    }
+    load_trip(follows ? cur : TripRef{cur.g, 1u}, nw0, nw1, nw2, n_inm);
+    if (!follows) n_inm = 0;
+  };
+  request_first(0);
+
   for (;;) {
     MHX_TT_BEGIN
-    if (tid == 0 && !pipelined) s_bucket = take_ticket();
-    __syncthreads();
-    const uint64_t bi64 = (uint64_t)s_bucket * bucket_stride;
+    const uint64_t bi64 = bucket_of(par);
     if (bi64 >= geo.n_buckets) break;
     const uint32_t bi = (uint32_t)bi64;
-    MHX_TT(10)
-    // pipelined, thread 0: the next bucket's ticket now, its bounds behind the first inserts, both handed over when this bucket ends
-    uint32_t next_ticket = 0;
-    uint64_t next_lo = 0, next_hi = 0;
-    bool next_fetched = false;
-    if (pipelined && tid == 0) next_ticket = take_ticket();
-    auto fetch_next = [&]() {
-      if (pipelined && tid == 0 && !next_fetched) {
-        const uint64_t nb = (uint64_t)next_ticket * bucket_stride;
-        if (nb < geo.n_buckets) {
-          next_lo = bounds[nb];
-          next_hi = bounds[nb + 1];
-        }
-        next_fetched = true;
+    // wave 0: the next bucket — its ticket and the request for its bounds when this bucket's first round starts, handed over
+    // when that round's inserts end
+    uint32_t next_tk = 0;
+    int desc = 0;  // 1: bounds requested, 2: published
+    auto desc_step = [&](int upto) {
+      if (!wave0) return;
+      if (desc == 0) {
+        next_tk = next_ticket();
+        request_bounds((uint64_t)next_tk * bucket_stride);
+        desc = 1;
+      }
+      if (desc == 1 && upto == 2) {
+        publish_desc(par ^ 1, next_tk);
+        desc = 2;
       }
     };
-    auto publish_next = [&]() {  // (behind a barrier that every reader of s_bucket / s_lo / s_hi has passed)
-      if (pipelined && tid == 0) {
-        s_bucket = next_ticket;
-        s_lo = next_lo;
-        s_hi = next_hi;
-      }
-    };
-    uint64_t total = 0;
-    for (int q = 0; q < n_src; ++q) {
-      uint64_t lo_, hi_;
-      bounds_of(q, bi, lo_, hi_);
-      total += hi_ - lo_;
-    }
-    if (total == 0) {
+    int q0 = first_source(par, 0);
+    if (q0 == n_src) {  // an empty bucket
+      desc_step(2);
       __syncthreads();
-      fetch_next();
-      publish_next();
-      __syncthreads();
+      par ^= 1;
+      request_first(par);
       continue;
     }
+    MHX_TT(10)
     // the bucket in rounds: round (sub, rj) takes the records whose top `sub` local-key bits are rj
     uint32_t sub = (uint32_t)min(geo.sub0, lk_bits), rj = 0;
     const uint32_t sub_first = sub;
     for (;;) {
       const uint32_t sub_sh = (uint32_t)lk_bits - sub;  // (sub == 0: no test)
-      // A: insert.  UNR records per thread and trip: their loads are issued together — with one 12-byte load in flight per
-      // wavefront the 16 wavefronts of a CU keep ~12 KB on the wire, 1.5 TB/s device-wide at ~2 us under load
-      for (int q = 0; q < n_src; ++q) {
-        uint64_t lo, hi;
-        bounds_of(q, bi, lo, hi);
-        if (lo == hi) continue;
-        const uint32_t *__restrict__ items = n_src > 1 ? srcs[q] : items0;
-        // the records of the trip that starts at `from`: unconditional loads (index clamped into the bucket, lo < hi): straight-line
-        // code, so that the compiler issues all UNR loads before the first wait — a load inside an `if` is followed by
-        // s_waitcnt vmcnt(0) at the end of its block.  (`items` comes out of a select between a kernel argument and a pointer read
-        // from memory: the compiler would use FLAT loads, which count in lgkmcnt as well — every wait for an LDS atomic would
-        // then wait for the loads in flight too; hence the explicit global address space.)
-        typedef const __attribute__((address_space(1))) uint32_t *gptr;
-        const gptr gitems = (gptr)items;
-        auto load_trip = [&](uint64_t from, uint32_t (&w0)[UNR], uint32_t (&w1)[UNR], uint32_t (&w2)[UNR], bool (&in)[UNR]) {
+      uint32_t claims = 0;
+      // A: insert.  Two register sets take turns (A: nw*, B: mw*): while the trip in one is inserted, the loads of the trip after
+      // it fill the other — no copies between them (a copy of freshly loaded registers is a wait for the loads).
+      // the inserts of one trip
+      auto insert_trip = [&](const uint32_t (&rw0)[UNR], const uint32_t (&rw1)[UNR], const uint32_t (&rw2)[UNR], uint32_t inm) {
+        uint32_t lk[UNR];
+        uint32_t mine = 0;
 #pragma unroll
-          for (int u = 0; u < UNR; ++u) {
-            const uint64_t gi = from + (uint64_t)u * NT + tid;
-            in[u] = gi < hi;
-            const gptr p = gitems + (in[u] ? gi : hi - 1) * 3;
-            w0[u] = p[0];
-            w1[u] = p[1];
-            w2[u] = p[2];
-          }
-        };
-        uint32_t nw0[UNR], nw1[UNR], nw2[UNR];
-        bool nin[UNR];
-        if constexpr (PF) load_trip(lo, nw0, nw1, nw2, nin);
-        for (uint64_t base = lo; base < hi; base += (uint64_t)NT * UNR) {
-          uint32_t rw0[UNR], rw1[UNR], rw2[UNR];
-          bool rin[UNR];
-          if constexpr (PF) {
-#pragma unroll
-            for (int u = 0; u < UNR; ++u) {
-              rw0[u] = nw0[u];
-              rw1[u] = nw1[u];
-              rw2[u] = nw2[u];
-              rin[u] = nin[u];
-            }
-            // (behind the last trip this asks for the bucket's last record UNR times: in[] comes out all false, nothing is inserted)
-            load_trip(base + (uint64_t)NT * UNR, nw0, nw1, nw2, nin);
-          } else {
-            load_trip(base, rw0, rw1, rw2, rin);
-          }
-#pragma unroll
-          for (int u = 0; u < UNR; ++u) {
-            const uint32_t lk = local_key(rw0[u], rw1[u]), w2 = rw2[u];
-            const bool mine = rin[u] && (sub == 0 || (lk >> sub_sh) == rj);
-            // low-complexity reads: when every record of the wavefront instruction carries the same key (a poly-A stretch:
-            // tens of thousands of records of ONE key in a row) one lane inserts for all of them instead of 64 lanes queueing
-            // up at one LDS address
-            const uint64_t mm = __ballot(mine);
-            if (!mm) continue;
-            const int leader = __builtin_ctzll(mm);
-            const bool uniform = __ballot(mine && lk != __shfl(lk, leader, kWave)) == 0 && mm != (1ull << leader);
-            if (!mine || (uniform && lane != leader)) continue;
-            const uint32_t mult = uniform ? (uint32_t)__builtin_popcountll(mm) : 1u;
-            const uint32_t tag = (rw1[u] >> 6) & 0xFFu;
-            // one compare-and-swap + add per record: inside a bucket the records are in read order, equal keys are rarely
-            // neighbours, so grouping the lanes of a wavefront by key (as k_s1_seg does on its sorted segments) saves few atomics
-            // and costs eight ballots per round; the LDS serialises same-address atomics by itself.
-            uint32_t h = (lk * 0x9E3779B1u) >> (32 - LOGS);
-            int probes = 0;
-            const int probe_limit = a.la_chunks;  // (stream mode: the host passes the probe limit here; tests set it to 0)
-            for (; probes < probe_limit; ++probes) {
-              // read_first: most records meet their key already in the table (one key per ~8 records at 60x): a plain LDS read
-              // finds that out without the read-modify-write of a compare-and-swap, which then only the claims of empty slots pay
-              uint32_t old;
-              if (a.read_first) {
-                old = __hip_atomic_load(&keys[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (old == kStreamEmpty) old = atomicCAS(&keys[h], kStreamEmpty, lk);
-              } else {
-                old = atomicCAS(&keys[h], kStreamEmpty, lk);
-              }
-              if (old == kStreamEmpty || old == lk) {
-                atomicAdd(&cnts[h], mult);
-                if (old == kStreamEmpty) {  // only read back when the count stays 1: then this record is the key's only one
-                  fpos[h] = w2;
-                  if (a.pos_stride) ftag[h] = (uint8_t)tag;
-                  const uint32_t at = atomicAdd(&s_nused, 1u);
-                  if (at < (uint32_t)NSLOT) used[at] = (uint16_t)h;
-                  if (at >= geo.max_fill) s_bad = 1;
-                }
-                break;
-              }
-              h = (h + 1) & (NSLOT - 1);
-            }
-            if (probes == probe_limit) s_bad = 1;
-          }
-          if (pipelined && base == lo) fetch_next();  // (thread 0: two loads whose results are wanted at the end of the bucket)
+        for (int u = 0; u < UNR; ++u) {
+          lk[u] = local_key(rw0[u], rw1[u]);
+          const bool mn = ((inm >> u) & 1u) && (sub == 0 || (lk[u] >> sub_sh) == rj);
+          mine |= mn ? 1u << u : 0u;
         }
-      }  // sources
-      __syncthreads();
+        if (probe_limit <= 0) {
+          if (mine) s_bad[rp] = 1;
+          mine = 0;
+        }
+        // low-complexity reads: a whole trip of one wavefront carrying ONE key (a poly-A stretch: tens of thousands of records
+        // of one key in a row) is inserted by one lane instead of 64 lanes queueing up at one LDS address UNR times
+        bool one_key = mine == (1u << UNR) - 1u;
+#pragma unroll
+        for (int u = 1; u < UNR; ++u) one_key = one_key && lk[u] == lk[0];
+        one_key = __ballot(one_key && lk[0] == (uint32_t)__builtin_amdgcn_readfirstlane((int)lk[0])) == ~0ull;
+        uint32_t mult = 1;
+        if (one_key) {
+          mine = lane == 0 ? 1u : 0u;
+          mult = (uint32_t)(kWave * UNR);
+        }
+        // first probe of every record, straight-line; a lane that met another key there keeps the record pending
+        uint32_t h[UNR];
+        uint32_t pend = 0;
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+          h[u] = (lk[u] * 0x9E3779B1u) >> (32 - LOGS);
+          if ((mine >> u) & 1u) {
+            const uint32_t old = atomicCAS(&keys[h[u]], kStreamEmpty, lk[u]);
+            if (old == kStreamEmpty || old == lk[u]) {
+              atomicAdd(&cnts[h[u]], mult);
+              if (old == kStreamEmpty) {  // only read back when the count stays 1: then this record is the key's only one
+                fpos[h[u]] = rw2[u];
+                if (TAGS) ftag[h[u]] = (uint8_t)(rw1[u] >> 6);
+                ++claims;
+              }
+            } else {
+              pend |= 1u << u;
+              h[u] = (h[u] + 1) & (NSLOT - 1);
+            }
+          }
+        }
+        // the pending records of all lanes, one per lane and turn
+        int turns = 0;
+        while (__ballot(pend != 0)) {
+          if (pend) {
+            // (this lane's first pending record, picked with masks: written as `pu == u ? x[u] : ...` the compiler turns the
+            //  chain into an indexed load and moves the arrays to LDS — whose stores wait for the record loads)
+            const int pu = __builtin_ctz(pend);
+            uint32_t pk = lk[0], ph = h[0], pw = rw2[0], pt = rw1[0];
+#pragma unroll
+            for (int u = 1; u < UNR; ++u) {
+              const uint32_t sel = pu == u ? 0xFFFFFFFFu : 0u;
+              pk = (lk[u] & sel) | (pk & ~sel);
+              ph = (h[u] & sel) | (ph & ~sel);
+              pw = (rw2[u] & sel) | (pw & ~sel);
+              pt = (rw1[u] & sel) | (pt & ~sel);
+            }
+            const uint32_t old = atomicCAS(&keys[ph], kStreamEmpty, pk);
+            if (old == kStreamEmpty || old == pk) {
+              atomicAdd(&cnts[ph], mult);
+              if (old == kStreamEmpty) {
+                fpos[ph] = pw;
+                if (TAGS) ftag[ph] = (uint8_t)(pt >> 6);
+                ++claims;
+              }
+              pend &= pend - 1;
+            } else {
+              ph = (ph + 1) & (NSLOT - 1);
+#pragma unroll
+              for (int u = 0; u < UNR; ++u) {
+                const uint32_t sel = pu == u ? 0xFFFFFFFFu : 0u;
+                h[u] = (ph & sel) | (h[u] & ~sel);
+              }
+            }
+          }
+          if (++turns > probe_limit) {  // (uniform: every lane counts the same turns)
+            if (pend) s_bad[rp] = 1;
+            break;
+          }
+        }
+      };
+      {
+        int q = q0;
+        uint64_t base = lo_of(par, q), hi = hi_of(par, q);
+        // Set A was requested before the per-key walk of the round before this one, whose stores may still be on their way: loads
+        // and stores return out of order with respect to each other, so with both pending the compiler waits for ALL of them at the
+        // first use of a loaded register — including the loads requested just before.  Waiting here, before anything new is asked
+        // for, keeps the waits inside the trip loop at "all but the newest UNR loads".
+        __builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0) lgkmcnt(0)
+        desc_step(1);
+        // the trip after the current one (behind the last trip of the round: a one-record stand-in, mask cleared) -> the other set
+        bool more = true;
+        auto request_next = [&](uint32_t (&w0)[UNR], uint32_t (&w1)[UNR], uint32_t (&w2)[UNR], uint32_t &inm) {
+          base += TRIP;
+          if (base >= hi) {
+            q = first_source(par, q + 1);
+            if (q < n_src) {
+              base = lo_of(par, q);
+              hi = hi_of(par, q);
+            } else {
+              more = false;
+            }
+          }
+          if (more) cur = trip_ref(q, base, hi);
+          load_trip(more ? cur : TripRef{cur.g, 1u}, w0, w1, w2, inm);
+          if (!more) inm = 0;
+        };
+        uint32_t mw0[UNR], mw1[UNR], mw2[UNR], m_inm = 0;
+        for (;;) {
+          request_next(mw0, mw1, mw2, m_inm);
+          insert_trip(nw0, nw1, nw2, n_inm);
+          if (!more) break;
+          request_next(nw0, nw1, nw2, n_inm);
+          insert_trip(mw0, mw1, mw2, m_inm);
+          if (!more) break;
+        }
+      }
+      desc_step(2);
+      {
+        const uint32_t c = wave_sum(claims);
+        if (lane == 0 && c) atomicAdd(&s_nclaimed[rp], c);
+      }
+      __syncthreads();  // A: the table is complete
       MHX_TT(11)
-      fetch_next();
-      // (s_bad / s_nused are read here, between the barrier behind the inserts and the next one; thread 0 resets them behind that)
-      const bool bad = s_bad != 0;
-      const uint32_t n_claimed = s_nused;
-      const int n_walk = a.used_list ? (int)min(n_claimed, (uint32_t)NSLOT) : NSLOT;  // (the per-key phases walk the same slots in the same order per thread)
-      uint32_t my_agg = 0;
+      const bool bad = s_bad[rp] != 0 || s_nclaimed[rp] > geo.max_fill;
+      if (tid == 0) {
+        s_bad[rp ^ 1] = 0;
+        s_nclaimed[rp ^ 1] = 0;
+      }
+      // what comes next (uniform: `bad` came out of shared memory behind a barrier)
+      uint32_t nsub = sub, nrj = rj;
+      bool bucket_done = false, give_up = false;
+      if (bad) {
+        if ((int)sub >= lk_bits) {  // one key per round and still no room: only a probe limit of 0 (tests) gets here
+          give_up = true;
+          bucket_done = true;
+        } else {
+          nsub = sub + 1;
+          nrj = rj << 1;
+        }
+      } else {
+        nrj = rj + 1;
+        while (nsub > sub_first && (nrj & 1u) == 0) {
+          --nsub;
+          nrj >>= 1;
+        }
+        bucket_done = nsub == sub_first && nrj == (1u << sub_first);
+      }
+      if (give_up && tid == 0) atomicOr(a.err, 1u);
+      // ... and its first trip, requested before the per-key work of this round
+      if (!bucket_done) {
+        cur = trip_ref(q0, lo_of(par, q0), hi_of(par, q0));
+        load_trip(cur, nw0, nw1, nw2, n_inm);
+      } else {
+        request_first(par ^ 1);
+      }
       if (!bad) {
-        // B: marks, streaming the bucket again
+        // B: marks by a second read of the bucket (m > 2, or the marks of the solid occurrences are wanted)
         if (a.mark_mode != 2 && !a.direct_marks) {
           for (int q = 0; q < n_src; ++q) {
-            uint64_t lo, hi;
-            bounds_of(q, bi, lo, hi);
-            const uint32_t *__restrict__ items = n_src > 1 ? srcs[q] : items0;
+            const uint64_t lo = lo_of(par, q), hi = hi_of(par, q);
+            const gptr items = (gptr)src_of(q);
             for (uint64_t base = lo; base < hi; base += NT) {
               const uint64_t gi = base + tid;
               bool in = gi < hi;
               uint32_t w1 = 0, w2 = 0, cnt = 0;
               if (in) {
-                const uint32_t *p = items + gi * 3;
+                const gptr p = items + gi * 3;
                 const uint32_t w0 = p[0];
                 w1 = p[1];
                 w2 = p[2];
@@ -1666,105 +1828,96 @@ __global__ __launch_bounds__(NT) void k_s1_stream(const uint32_t *__restrict__ i
                 }
               }
             }
-          }  // sources
-        }
-        // C: per distinct key (every occupied slot)
-        for (int it = tid; it < n_walk; it += NT) {
-          const int sl = a.used_list ? (int)used[it] : it;
-          const uint32_t lk = keys[sl];
-          if (lk == kStreamEmpty || (lk & 0x24u) != 0) continue;
-          const uint32_t cnt = cnts[sl];
-          const bool solid = cnt >= m;
-          if (a.mark_mode == 2) {
-            st_both += cnt;
-            if (solid) st_solid += cnt;
-            continue;
           }
-          const uint32_t hb = cnt > MHX_MAX_MUL ? (uint32_t)MHX_MAX_MUL : cnt;  // :430-436
-          if (hb < kSegHist) atomicAdd(&lhist[hb], 1u);
-          else atomicAdd(&a.hist[hb], 1ull);
-          if (a.direct_marks && !solid) {  // count 1 < m <= 2: the key's only record (mark_mode 1)
-            const uint64_t abs = fpos[sl] + (a.pos_stride ? (uint64_t)ftag[sl] * a.pos_stride : 0ull);
-            if (!marks_out) a.solid_bytes[abs - 1] = 1;
-            else {  // multi-GPU: the mark is the global position itself, appended to this workgroup's region
-              const uint32_t at = atomicAdd(&s_mark_cur, 1u);
-              if (at + s_agg_cur < a.marks_cap) marks_out[at] = abs - 1;
-              else atomicOr(a.err, 2u);
-            }
-          }
-          if (AGG && solid) {
-            const uint64_t x = edge_of(bi, lk);
-            my_agg += x == rc64(x, k + 1) ? 1u : 2u;
-          }
+          __syncthreads();  // (the walk below wipes the table the loop above reads)
         }
       }
       MHX_TT(12)
-      uint32_t agg_at = 0;
-      bool agg_ok = true;
-      if constexpr (AGG) {
-        const uint32_t incl = wave_inclusive_sum(my_agg);
-        const uint32_t tot = __shfl(incl, kWave - 1, kWave);
-        uint32_t wbase = 0;
-        if (lane == 0 && tot) wbase = atomicAdd(&s_agg_cur, tot);
-        wbase = __shfl(wbase, 0, kWave);
-        agg_ok = wbase + tot + (marks_out ? s_mark_cur : 0u) <= a.agg_cap;
-        if (!agg_ok && lane == 0) atomicOr(a.err, 1u);
-        agg_at = wbase + incl - my_agg;
-      }
-      __syncthreads();  // every count has been read: emit, then recycle the slots
-      MHX_TT(13)
-      // (a round that gave up may have claimed more slots than the list holds: then the whole table is wiped)
-      const bool wipe_all = bad && n_claimed > (uint32_t)NSLOT;
-      const int n_recycle = wipe_all || !a.used_list ? NSLOT : n_walk;
-      for (int it = tid; it < n_recycle; it += NT) {
-        const int sl = (a.used_list && !wipe_all) ? (int)used[it] : it;
+      // C: one walk over the table — per distinct key: statistics, the mark of a key's only record, its aggregated stage-2
+      // items (their place in the workgroup's region from one LDS atomic per wavefront and step) — and the slot is free again
+#pragma unroll 1
+      for (int it = 0; it < NSLOT / NT; ++it) {
+        const int sl = it * NT + tid;
         const uint32_t lk = keys[sl];
-        if (lk == kStreamEmpty) continue;
-        if constexpr (AGG) {
-          const uint32_t cnt = cnts[sl];
-          if (!bad && agg_ok && a.mark_mode != 2 && (lk & 0x24u) == 0 && cnt >= m) {
-            const uint64_t mask_k = ~0ull << (64 - 2 * k);
-            const uint64_t x = edge_of(bi, lk);
-            const uint64_t xr = rc64(x, k + 1);
-            const uint64_t mul = cnt > MHX_MAX_MUL ? (uint64_t)MHX_MAX_MUL : cnt;
-            const uint64_t f = ((x << 2) & mask_k) | (1ull << 19) | ((x >> 62) << 16) | mul;
-            agg_end[-1 - (long)agg_at++] = make_uint2((uint32_t)(f >> 32), (uint32_t)f);
-            if (x != xr) {
-              const uint64_t b = ((xr << 2) & mask_k) | (1ull << 19) | ((xr >> 62) << 16) | mul;
-              agg_end[-1 - (long)agg_at++] = make_uint2((uint32_t)(b >> 32), (uint32_t)b);
+        uint32_t n_out = 0, cnt = 0;
+        uint64_t x = 0, xr = 0;
+        bool mark = false;
+        if (lk != kStreamEmpty) {
+          cnt = cnts[sl];
+          keys[sl] = kStreamEmpty;
+          cnts[sl] = 0;
+          if (!bad && (lk & 0x24u) == 0) {
+            const bool solid = cnt >= m;
+            if (a.mark_mode == 2) {
+              st_both += cnt;
+              if (solid) st_solid += cnt;
+            } else {
+              const uint32_t hb = cnt > MHX_MAX_MUL ? (uint32_t)MHX_MAX_MUL : cnt;  // :430-436
+              if (hb < kSegHist) atomicAdd(&lhist[hb], 1u);
+              else atomicAdd(&a.hist[hb], 1ull);
+              mark = a.direct_marks && !solid;  // count 1 < m <= 2: the key's only record (mark_mode 1)
+              if (AGG && solid) {
+                x = edge_of(bi, lk);
+                xr = rc64(x, k + 1);
+                n_out = x == xr ? 1u : 2u;
+              }
             }
           }
         }
-        keys[sl] = kStreamEmpty;
-        cnts[sl] = 0;
-      }
-      // the next round of this bucket, or the next bucket (uniform: `bad` came out of shared memory behind a barrier)
-      bool bucket_done = false;
-      if (bad) {
-        if ((int)sub >= lk_bits) {  // one key per round and still no room: only a probe limit of 0 (tests) gets here
-          if (tid == 0) atomicOr(a.err, 1u);
-          bucket_done = true;
-        } else {
-          ++sub;
-          rj <<= 1;
+        if (a.direct_marks) {  // (uniform)
+          const uint64_t abs = mark ? fpos[sl] + (TAGS ? (uint64_t)ftag[sl] * a.pos_stride : 0ull) : 0ull;
+          if (!marks_out) {
+            if (mark) a.solid_bytes[abs - 1] = 1;
+          } else {  // multi-GPU: the mark is the global position itself, appended to this workgroup's region
+            const uint64_t mm = __ballot(mark);
+            if (mm) {
+              uint32_t mbase = 0;
+              if (lane == 0) mbase = atomicAdd(&s_mark_cur, (uint32_t)__builtin_popcountll(mm));
+              mbase = __shfl(mbase, 0, kWave);
+              if (mark) {
+                const uint32_t at = mbase + (uint32_t)__builtin_popcountll(mm & lanemask_lt);
+                if (at + s_agg_cur < a.marks_cap) marks_out[at] = abs - 1;
+                else atomicOr(a.err, 2u);
+              }
+            }
+          }
         }
-      } else {
-        ++rj;
-        while (sub > sub_first && (rj & 1u) == 0) {
-          --sub;
-          rj >>= 1;
+        if constexpr (AGG) {
+          if (a.mark_mode != 2) {  // (uniform)
+            const uint32_t incl = wave_inclusive_sum(n_out);
+            const uint32_t tot = __shfl(incl, kWave - 1, kWave);
+            if (tot) {
+              uint32_t wbase = 0;
+              if (lane == 0) wbase = atomicAdd(&s_agg_cur, tot);
+              wbase = __shfl(wbase, 0, kWave);
+              if (wbase + tot + (marks_out ? s_mark_cur : 0u) <= a.agg_cap) {
+                if (n_out) {
+                  long at = (long)(wbase + incl - n_out);
+                  const uint64_t mask_k = ~0ull << (64 - 2 * k);
+                  const uint64_t mul = cnt > MHX_MAX_MUL ? (uint64_t)MHX_MAX_MUL : cnt;
+                  const uint64_t f = ((x << 2) & mask_k) | (1ull << 19) | ((x >> 62) << 16) | mul;
+                  agg_end[-1 - at++] = make_uint2((uint32_t)(f >> 32), (uint32_t)f);
+                  if (n_out == 2) {
+                    const uint64_t b = ((xr << 2) & mask_k) | (1ull << 19) | ((xr >> 62) << 16) | mul;
+                    agg_end[-1 - at] = make_uint2((uint32_t)(b >> 32), (uint32_t)b);
+                  }
+                }
+              } else if (lane == 0) {
+                atomicOr(a.err, 1u);
+              }
+            }
+          }
         }
-        bucket_done = sub == sub_first && rj == (1u << sub_first);
       }
-      if (tid == 0) {
-        s_bad = 0;
-        s_nused = 0;
-      }
-      if (bucket_done) publish_next();
-      __syncthreads();
+      MHX_TT(13)
+      __syncthreads();  // B: the table is empty
       MHX_TT(14)
+      rp ^= 1;
+      sub = nsub;
+      rj = nrj;
       if (bucket_done) break;
     }
+    par ^= 1;
   }
   if (a.mark_mode == 2) {
     st_solid = wave_sum(st_solid);
@@ -1774,6 +1927,7 @@ __global__ __launch_bounds__(NT) void k_s1_stream(const uint32_t *__restrict__ i
       atomicAdd(a.ctr + 2, st_both);
     }
   } else {
+    __syncthreads();
     for (int i = tid; i < kSegHist; i += NT)
       if (lhist[i]) atomicAdd(&a.hist[i], (unsigned long long)lhist[i]);
     if (AGG && tid == 0) a.agg_counts[blockIdx.x] = s_agg_cur < a.agg_cap ? s_agg_cur : a.agg_cap;
@@ -2239,6 +2393,7 @@ bool s1_rank_tagged(const mhx_ctx *c, uint32_t k) {
 uint64_t s1_pos_stride(const mhx_ctx *c, uint32_t k) { return s1_rank_tagged(c, k) ? 1ull << s1_pos_bits(c) : 0ull; }
 bool s1_compact(const mhx_ctx *c, uint32_t k, int want_mercy) {
   if (want_mercy) return false;
+  if (s1_kw(k) < 2) return false;  // k <= 14: a one-word key; the 16-byte records serve (8-byte compact records have no kernels)
   const uint64_t n_bits = c->global_bases ? c->global_bases : c->seqs.n_bases;
   return (n_bits >> s1_pos_bits(c)) == 0 || s1_rank_tagged(c, k);
 }
@@ -2640,8 +2795,7 @@ struct S1Stage {
     // the stream kernel marks the non-solid occurrences from its table when each of them is its key's only record
     const int direct = plan.stream && mode == 1 && m <= 2 && (mraw || solid_bytes) && c->opt("s1_stream_direct", 1) ? 1 : 0;
     S1SegArgs a{(int)k, m, pfx_mask, eq_mask1, solid_bytes, mode, hist, ctr, raw, seg_cap, counts, mraw, mcap, mcounts, pos_stride, seg_err,
-                plan.stream ? (int)c->opt("s1_stream_probes", 1024) : la, direct, c->opt("s1_stream_used_list", 1) != 0 ? 1 : 0,
-                c->opt("s1_stream_read_first", 0) != 0 ? 1 : 0};
+                plan.stream ? (int)c->opt("s1_stream_probes", 1024) : la, direct};
     MHX_HIP(hipMemsetAsync(seg_err, 0, 4, st));
     const char *nm = mode == 2 ? "s1_sample" : "s1_groups";
     const double bytes = plan.stream ? (double)n_items * 12 / stride * (double)(1u << plan.sub0) : (double)n_work * T * 12;
@@ -2664,30 +2818,26 @@ struct S1Stage {
                    hipLaunchKernelGGL(k_bucket_bounds, dim3(bgrid), dim3(256), 0, st, sorted, n_items, 3, bounds, plan.seg_bits));
       }
       const uint32_t *items0 = pre && sorted == nullptr ? pre->ptr[0] : sorted;
-      const int unr = (int)c->opt("s1_stream_unroll", 4);  // 8: measured no better than 4
-      const bool pf = c->opt("s1_stream_prefetch", 0) != 0;
       const uint32_t nslot = half ? 4096u : 8192u;
-      const S1StreamGeom geo{plan.seg_bits, plan.sub0, pf && c->opt("s1_stream_next_bucket", 1) ? 1 : 0, (uint32_t)n_buckets,
+      const S1StreamGeom geo{plan.seg_bits, plan.sub0, (uint32_t)n_buckets,
                              (uint32_t)std::min<long long>(std::max<long long>(c->opt("s1_stream_fill", nslot * 7 / 8), 1), nslot)};
-#define MHX_STREAM(AGGV, UV, NTV, LOGV, PFV)                                                                                               \
-  MHX_LAUNCH(c, nm, bytes, hipLaunchKernelGGL((k_s1_stream<AGGV, UV, NTV, LOGV, PFV>), dim3(grid), dim3(NTV), 0, st, items0, bounds, a, geo, \
+      const bool tags = pos_stride != 0;
+#define MHX_STREAM(AGGV, NTV, LOGV, TAGV)                                                                                                 \
+  MHX_LAUNCH(c, nm, bytes, hipLaunchKernelGGL((k_s1_stream<AGGV, 4, NTV, LOGV, TAGV>), dim3(grid), dim3(NTV), 0, st, items0, bounds, a, geo, \
                                               stride, ticket, srcs, n_src))
-#define MHX_STREAM_PF(AGGV, UV, NTV, LOGV) \
-  do {                                     \
-    if (pf) MHX_STREAM(AGGV, UV, NTV, LOGV, true); \
-    else MHX_STREAM(AGGV, UV, NTV, LOGV, false);   \
+#define MHX_STREAM_T(AGGV, NTV, LOGV)        \
+  do {                                       \
+    if (tags) MHX_STREAM(AGGV, NTV, LOGV, true); \
+    else MHX_STREAM(AGGV, NTV, LOGV, false);     \
   } while (0)
       if (half) {
-        if (agg_on) MHX_STREAM_PF(true, 4, 512, 12);
-        else MHX_STREAM_PF(false, 4, 512, 12);
-      } else if (agg_on) {
-        if (unr >= 8) MHX_STREAM_PF(true, 8, kStreamThreads, 13);
-        else MHX_STREAM_PF(true, 4, kStreamThreads, 13);
+        if (agg_on) MHX_STREAM_T(true, 512, 12);
+        else MHX_STREAM_T(false, 512, 12);
       } else {
-        if (unr >= 8) MHX_STREAM_PF(false, 8, kStreamThreads, 13);
-        else MHX_STREAM_PF(false, 4, kStreamThreads, 13);
+        if (agg_on) MHX_STREAM_T(true, kStreamThreads, 13);
+        else MHX_STREAM_T(false, kStreamThreads, 13);
       }
-#undef MHX_STREAM_PF
+#undef MHX_STREAM_T
 #undef MHX_STREAM
       return;
     }

@@ -76,7 +76,7 @@ def test_cli_automatic_memory_plan(ent, tmp_path, monkeypatch):
     import subprocess
     with open(os.path.join(gu.GOLD, ent["case"]["lib"] + ".lib_info")) as f:
         total_bases = int(f.read().split()[0])
-    monkeypatch.setenv("MHX_FREE_BYTES", str(40 * total_bases))  # room for ~0.6 items per base: two or three passes
+    monkeypatch.setenv("MHX_FREE_BYTES", str(25 * total_bases))  # room for ~0.7 12-byte items per base (two sort buffers): two or three passes
     got = gu.run_case(gu.MHX_CORE, ent, str(tmp_path))
     for key, want in ent.items():
         if key in ("case", "mercy_cand_kmsort"):

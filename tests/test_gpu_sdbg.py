@@ -147,7 +147,7 @@ def test_kmsort_replay_on_repetitive_reads(engine, k, m, legacy):
     assert np.array_equal(solid, w1["is_solid"][: solid.size])
 
 
-@pytest.mark.parametrize("kind,k,m", CASES)
+@pytest.mark.parametrize("kind,k,m", CASES + [("var", 11, 2), ("fixed", 13, 2), ("fixed", 14, 3)])
 def test_read2sdbg_s1_without_mercy_compact_records(engine, kind, k, m):
     """want_mercy=False takes the compact-record path (12-byte stage-1 items at k <= 29)."""
     reads = make_reads(kind, 6)

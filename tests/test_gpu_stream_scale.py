@@ -64,7 +64,7 @@ def check_read2sdbg(engine, pkg, k, m, plan_has=None):
 @pytest.mark.parametrize("prefetch", [0, 1])
 @pytest.mark.parametrize("bits,sub0", [(0, -1), (17, -1), (20, 0), (24, 0), (16, 1), (16, 3), (19, 2)])
 @pytest.mark.parametrize("kind,k,m", [("pe100", 21, 2), ("repeats100", 21, 2), ("tiny60", 21, 2), ("short30", 21, 2), ("var", 21, 2), ("pe100", 17, 3),
-                                      ("repeats100", 22, 2), ("pe100", 12, 2), ("lowcomplex", 10, 2)])
+                                      ("repeats100", 22, 2), ("pe100", 15, 2), ("lowcomplex", 16, 2)])
 def test_every_prefix_width_and_sub_round_count(engine, kind, k, m, bits, sub0, prefetch):
     pkg = ob.Package(library(kind, k * 10 + m), reverse=True)
     load(engine, pkg)
