@@ -1422,6 +1422,9 @@ __global__ __launch_bounds__(NT) void k_s1_stream(const uint32_t *__restrict__ i
   __shared__ uint8_t ftag[TAGS ? NSLOT : 4];   // ... and the position bits above it (s1_pos_tag), when the read set has any
   __shared__ uint32_t lhist[kSegHist];
   __shared__ uint32_t s_bad[2], s_nclaimed[2];  // per round, double-buffered: the next round's are cleared while this round's are read
+  constexpr int NLIST = NSLOT / 4;              // solid keys of a round waiting for their aggregated items (more: worked off in place)
+  __shared__ uint2 slist[AGG ? NLIST : 1];
+  __shared__ uint32_t s_list_n[2];
   __shared__ uint32_t s_agg_cur, s_mark_cur;
   // the bucket being worked on and the one after it: ticket and per-source bounds (wave 0 fills [par ^ 1] during bucket [par])
   __shared__ uint32_t s_tk[2];
@@ -1440,6 +1443,7 @@ __global__ __launch_bounds__(NT) void k_s1_stream(const uint32_t *__restrict__ i
   if (tid == 0) {
     s_bad[0] = s_bad[1] = 0;
     s_nclaimed[0] = s_nclaimed[1] = 0;
+    s_list_n[0] = s_list_n[1] = 0;
     s_agg_cur = 0;
     s_mark_cur = 0;
   }
@@ -1447,7 +1451,6 @@ __global__ __launch_bounds__(NT) void k_s1_stream(const uint32_t *__restrict__ i
   const int k = a.k;
   const int pbits = geo.pbits;
   const size_t bstride = (size_t)geo.n_buckets + 1;
-  const bool staged = n_src <= kStreamSrcMax;  // (more sources than lanes: the bounds are read from memory where they are needed)
   // local key: the (k-1)-mer bits below the prefix, then head/tail (the position tag bits in between dropped)
   const int rem = 2 * (k - 1) - pbits;  // 0..26 bits
   const int lk_bits = rem + 6;          // <= 32
@@ -1462,27 +1465,57 @@ __global__ __launch_bounds__(NT) void k_s1_stream(const uint32_t *__restrict__ i
     const uint64_t smer = ((uint64_t)bi << (64 - pbits)) | (rem ? (uint64_t)(lk >> 6) << (64 - pbits - rem) : 0ull);
     return ((uint64_t)((lk >> 3) & 7u) << 62) | (smer >> 2) | ((uint64_t)(lk & 7u) << (62 - 2 * k));
   };
+  // the aggregated stage-2 items of a solid key (one per strand; one for a palindrome) -> this workgroup's region, from its end.
+  // dense: called by whole wavefronts (the place comes from one LDS atomic per wavefront); otherwise by single lanes.
+  auto emit_items = [&](uint32_t bi, uint32_t lk, uint32_t cnt, bool dense, bool valid = true) {
+    uint64_t x = 0, xr = 0;
+    uint32_t n_out = 0;
+    if (valid) {
+      x = edge_of(bi, lk);
+      xr = rc64(x, k + 1);
+      n_out = x == xr ? 1u : 2u;
+    }
+    uint32_t at;
+    bool ok;
+    if (dense) {
+      const uint32_t incl = wave_inclusive_sum(n_out);
+      const uint32_t tot = __shfl(incl, kWave - 1, kWave);
+      if (!tot) return;
+      uint32_t wbase = 0;
+      if (lane == 0) wbase = atomicAdd(&s_agg_cur, tot);
+      wbase = __shfl(wbase, 0, kWave);
+      ok = wbase + tot + (marks_out ? s_mark_cur : 0u) <= a.agg_cap;
+      at = wbase + incl - n_out;
+    } else {
+      at = atomicAdd(&s_agg_cur, n_out);
+      ok = at + n_out + (marks_out ? s_mark_cur : 0u) <= a.agg_cap;
+    }
+    if (!ok) {
+      atomicOr(a.err, 1u);
+      return;
+    }
+    if (n_out) {
+      const uint64_t mask_k = ~0ull << (64 - 2 * k);
+      const uint64_t mul = cnt > MHX_MAX_MUL ? (uint64_t)MHX_MAX_MUL : cnt;
+      const uint64_t f = ((x << 2) & mask_k) | (1ull << 19) | ((x >> 62) << 16) | mul;
+      agg_end[-1 - (long)at] = make_uint2((uint32_t)(f >> 32), (uint32_t)f);
+      if (n_out == 2) {
+        const uint64_t b = ((xr << 2) & mask_k) | (1ull << 19) | ((xr >> 62) << 16) | mul;
+        agg_end[-2 - (long)at] = make_uint2((uint32_t)(b >> 32), (uint32_t)b);
+      }
+    }
+  };
+  auto hash_of = [&](uint32_t lk) -> uint32_t { return (lk * 0x9E3779B1u) >> (32 - LOGS); };
   auto bucket_of = [&](int par) -> uint64_t { return (uint64_t)s_tk[par] * bucket_stride; };
   // (explicit global address space for everything read from memory here: a select between an LDS and a global address would
   //  become a FLAT load, and one FLAT load in flight makes every later wait for a global load a wait for ALL loads)
   typedef const __attribute__((address_space(1))) uint64_t *gptr64;
   const gptr64 gbounds = (gptr64)bounds;
-  auto lo_of = [&](int par, int q) -> uint64_t {
-    uint64_t v = s_lo[par][q & (kStreamSrcMax - 1)];
-    if (!staged) v = gbounds[(size_t)q * bstride + bucket_of(par)];
-    return v;
-  };
-  auto hi_of = [&](int par, int q) -> uint64_t {
-    uint64_t v = s_hi[par][q & (kStreamSrcMax - 1)];
-    if (!staged) v = gbounds[(size_t)q * bstride + bucket_of(par) + 1];
-    return v;
-  };
-  auto src_of = [&](int q) -> uint64_t {  // the array of source q
-    if (n_src <= 1) return (uint64_t)items0;
-    uint64_t v = s_src[q & (kStreamSrcMax - 1)];
-    if (!staged) v = ((gptr64)srcs)[q];
-    return v;
-  };
+  // (bounds and arrays of the sources live in LDS — at most kStreamSrcMax senders, the host sees to that: a load from memory
+  //  inside the trip loop would be waited for together with the record loads in flight)
+  auto lo_of = [&](int par, int q) -> uint64_t { return s_lo[par][q]; };
+  auto hi_of = [&](int par, int q) -> uint64_t { return s_hi[par][q]; };
+  auto src_of = [&](int q) -> uint64_t { return n_src > 1 ? s_src[q] : (uint64_t)items0; };  // the array of source q
   // wave 0 holds the workgroup's place in the bucket sequence.  Tickets come in batches of kStreamBatch consecutive buckets: the
   // answer of the atomic is waited for on the spot (the compiler broadcasts it through a readfirstlane), which stalls wave 0 — an
   // insert worker like the others — for a memory round trip, so it is made rare; neighbouring buckets are also neighbours in memory.
@@ -1507,20 +1540,20 @@ __global__ __launch_bounds__(NT) void k_s1_stream(const uint32_t *__restrict__ i
   auto request_bounds = [&](uint64_t nb) {
     d_lo = d_hi = 0;
     d_err = ((const __attribute__((address_space(1))) uint32_t *)a.err)[0];
-    if (staged && nb < geo.n_buckets && lane < n_src) {
+    if (nb < geo.n_buckets && lane < n_src) {
       d_lo = gbounds[(size_t)lane * bstride + nb];
       d_hi = gbounds[(size_t)lane * bstride + nb + 1];
     }
   };
   auto publish_desc = [&](int par, uint32_t tk) {
     if (lane == 0) s_tk[par] = d_err ? 0xFFFFFFFFu / (bucket_stride ? bucket_stride : 1u) : tk;
-    if (staged && lane < n_src) {
+    if (lane < n_src) {
       s_lo[par][lane] = d_lo;
       s_hi[par][lane] = d_hi;
     }
   };
   if (wave0) {  // the first bucket of this workgroup
-    if (staged && n_src > 1 && lane < n_src) s_src[lane] = ((gptr64)srcs)[lane];
+    if (n_src > 1 && lane < n_src) s_src[lane] = ((gptr64)srcs)[lane];
     const uint32_t t0 = next_ticket();
     request_bounds((uint64_t)t0 * bucket_stride);
     publish_desc(0, t0);
@@ -1548,21 +1581,27 @@ __global__ __launch_bounds__(NT) void k_s1_stream(const uint32_t *__restrict__ i
     const uint64_t left = hi - base;
     return TripRef{(gptr)uniform64(src + base * 12), (uint32_t)__builtin_amdgcn_readfirstlane((int)(left < (uint64_t)TRIP ? (uint32_t)left : (uint32_t)TRIP))};
   };
-  // Unconditional loads, always (index clamped into the trip, which holds at least one record): straight-line code, so that all
-  // UNR loads are issued before the first wait — a load inside an `if` is waited for at the end of its block.  Where no trip
-  // follows, the caller passes a one-record stand-in and clears the mask.
+  // A thread's UNR records of a trip are CONSECUTIVE (UNR * 12 contiguous bytes, read as 16-byte loads — the records of a
+  // bucket may be inserted in any order, so which thread holds which record is free).  Measured on the device before this
+  // form was chosen (tools/micro/read_probe.hip, one 1024-thread workgroup per CU, the next trip requested before the
+  // current one is used, compute between the trips): records NT apart as 12-byte loads 2.2 TB/s, this form 3.3 TB/s, both
+  // 6.4 TB/s without compute.  Unconditional loads, always: straight-line code, so that all loads are issued before the
+  // first wait (a load inside an `if` is waited for at the end of its block); a thread beyond the trip's last record reads
+  // the window that starts at that record — up to 36 bytes past the trip's end: every record array here ends in 64 spare
+  // bytes (mhx_ctx::ws) — and its mask bits stay clear.  Where no trip follows, the caller passes a one-record stand-in.
+  static_assert(UNR == 4, "a thread's window of a trip: four 12-byte records = three 16-byte loads");
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4), aligned(4)));
+  typedef const __attribute__((address_space(1))) u32x4 *gptr4;
   auto load_trip = [&](const TripRef &t, uint32_t (&w0)[UNR], uint32_t (&w1)[UNR], uint32_t (&w2)[UNR], uint32_t &inm) {
-    inm = 0;
-#pragma unroll
-    for (int u = 0; u < UNR; ++u) {
-      const uint32_t idx = (uint32_t)(u * NT + tid);
-      const bool in = idx < t.n;
-      inm |= in ? 1u << u : 0u;
-      const gptr p = t.g + (in ? idx : t.n - 1) * 3u;
-      w0[u] = p[0];
-      w1[u] = p[1];
-      w2[u] = p[2];
-    }
+    const uint32_t first = (uint32_t)tid * UNR;  // (a constant of the thread)
+    const uint32_t left = t.n > first ? t.n - first : 0u;
+    inm = left >= UNR ? (1u << UNR) - 1u : (1u << left) - 1u;
+    const gptr4 p = (gptr4)(t.g + (first < t.n ? first : t.n - 1) * 3u);
+    const u32x4 a0 = p[0], a1 = p[1], a2 = p[2];
+    w0[0] = a0.x, w1[0] = a0.y, w2[0] = a0.z;
+    w0[1] = a0.w, w1[1] = a1.x, w2[1] = a1.y;
+    w0[2] = a1.z, w1[2] = a1.w, w2[2] = a2.x;
+    w0[3] = a2.y, w1[3] = a2.z, w2[3] = a2.w;
   };
 
   unsigned long long st_solid = 0, st_both = 0;
@@ -1649,63 +1688,64 @@ __global__ __launch_bounds__(NT) void k_s1_stream(const uint32_t *__restrict__ i
           mine = lane == 0 ? 1u : 0u;
           mult = (uint32_t)(kWave * UNR);
         }
-        // first probe of every record, straight-line; a lane that met another key there keeps the record pending
-        uint32_t h[UNR];
-        uint32_t pend = 0;
+        // First probe of every record, straight-line.  A lane that met another key there keeps the record pending — one per lane;
+        // a second one of the same trip (one lane in twenty) is seen to on the spot — and the pending records of all lanes are
+        // retried together afterwards: the retries cost their instructions per turn, however few lanes take part.
+        // (the slot found — the key's own, or a free one claimed: count it, and remember the record that claimed it)
+        auto settle = [&](uint32_t old, uint32_t key, uint32_t hh, uint32_t pos, uint32_t w1v) -> bool {
+          if (old != kStreamEmpty && old != key) return false;
+          atomicAdd(&cnts[hh], mult);
+          if (old == kStreamEmpty) {  // only read back when the count stays 1: then this record is the key's only one
+            fpos[hh] = pos;
+            if (TAGS) ftag[hh] = (uint8_t)(w1v >> 6);
+            ++claims;
+          }
+          return true;
+        };
+        auto probe = [&](uint32_t key, uint32_t hh, uint32_t pos, uint32_t w1v) -> bool {
+          return settle(atomicCAS(&keys[hh], kStreamEmpty, key), key, hh, pos, w1v);
+        };
+        // the UNR compare-and-swaps go out back to back: one LDS round trip per trip instead of UNR (with four wavefronts per SIMD
+        // the round trips, ~250 cycles each under load, are not hidden)
+        uint32_t h1[UNR], old1[UNR];
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
-          h[u] = (lk[u] * 0x9E3779B1u) >> (32 - LOGS);
+          h1[u] = hash_of(lk[u]);
+          old1[u] = kStreamEmpty;
+          if ((mine >> u) & 1u) old1[u] = atomicCAS(&keys[h1[u]], kStreamEmpty, lk[u]);
+        }
+        bool has = false;
+        uint32_t pk = 0, ph = 0, pw = 0, pt = 0;
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
           if ((mine >> u) & 1u) {
-            const uint32_t old = atomicCAS(&keys[h[u]], kStreamEmpty, lk[u]);
-            if (old == kStreamEmpty || old == lk[u]) {
-              atomicAdd(&cnts[h[u]], mult);
-              if (old == kStreamEmpty) {  // only read back when the count stays 1: then this record is the key's only one
-                fpos[h[u]] = rw2[u];
-                if (TAGS) ftag[h[u]] = (uint8_t)(rw1[u] >> 6);
-                ++claims;
+            uint32_t hh = h1[u];
+            if (!settle(old1[u], lk[u], hh, rw2[u], rw1[u])) {
+              hh = (hh + 1) & (NSLOT - 1);
+              if (!has) {
+                has = true;
+                pk = lk[u], ph = hh, pw = rw2[u], pt = rw1[u];
+              } else {
+                int n = 0;
+                while (!probe(lk[u], hh, rw2[u], rw1[u])) {
+                  hh = (hh + 1) & (NSLOT - 1);
+                  if (++n >= probe_limit) {
+                    s_bad[rp] = 1;
+                    break;
+                  }
+                }
               }
-            } else {
-              pend |= 1u << u;
-              h[u] = (h[u] + 1) & (NSLOT - 1);
             }
           }
         }
-        // the pending records of all lanes, one per lane and turn
         int turns = 0;
-        while (__ballot(pend != 0)) {
-          if (pend) {
-            // (this lane's first pending record, picked with masks: written as `pu == u ? x[u] : ...` the compiler turns the
-            //  chain into an indexed load and moves the arrays to LDS — whose stores wait for the record loads)
-            const int pu = __builtin_ctz(pend);
-            uint32_t pk = lk[0], ph = h[0], pw = rw2[0], pt = rw1[0];
-#pragma unroll
-            for (int u = 1; u < UNR; ++u) {
-              const uint32_t sel = pu == u ? 0xFFFFFFFFu : 0u;
-              pk = (lk[u] & sel) | (pk & ~sel);
-              ph = (h[u] & sel) | (ph & ~sel);
-              pw = (rw2[u] & sel) | (pw & ~sel);
-              pt = (rw1[u] & sel) | (pt & ~sel);
-            }
-            const uint32_t old = atomicCAS(&keys[ph], kStreamEmpty, pk);
-            if (old == kStreamEmpty || old == pk) {
-              atomicAdd(&cnts[ph], mult);
-              if (old == kStreamEmpty) {
-                fpos[ph] = pw;
-                if (TAGS) ftag[ph] = (uint8_t)(pt >> 6);
-                ++claims;
-              }
-              pend &= pend - 1;
-            } else {
-              ph = (ph + 1) & (NSLOT - 1);
-#pragma unroll
-              for (int u = 0; u < UNR; ++u) {
-                const uint32_t sel = pu == u ? 0xFFFFFFFFu : 0u;
-                h[u] = (ph & sel) | (h[u] & ~sel);
-              }
-            }
+        while (__ballot(has)) {
+          if (has) {
+            if (probe(pk, ph, pw, pt)) has = false;
+            else ph = (ph + 1) & (NSLOT - 1);
           }
           if (++turns > probe_limit) {  // (uniform: every lane counts the same turns)
-            if (pend) s_bad[rp] = 1;
+            if (has) s_bad[rp] = 1;
             break;
           }
         }
@@ -1757,6 +1797,7 @@ __global__ __launch_bounds__(NT) void k_s1_stream(const uint32_t *__restrict__ i
       if (tid == 0) {
         s_bad[rp ^ 1] = 0;
         s_nclaimed[rp ^ 1] = 0;
+        s_list_n[rp ^ 1] = 0;  // (read behind barrier B of the round before this one, by threads that have all passed barrier A since)
       }
       // what comes next (uniform: `bad` came out of shared memory behind a barrier)
       uint32_t nsub = sub, nrj = rj;
@@ -1803,7 +1844,7 @@ __global__ __launch_bounds__(NT) void k_s1_stream(const uint32_t *__restrict__ i
                 const uint32_t lk = local_key(w0, w1);
                 in = sub == 0 || (lk >> sub_sh) == rj;  // (a key of another round is not in the table)
                 if (in) {
-                  uint32_t h = (lk * 0x9E3779B1u) >> (32 - LOGS);
+                  uint32_t h = hash_of(lk);
                   while (keys[h] != lk) h = (h + 1) & (NSLOT - 1);
                   cnt = cnts[h];
                 }
@@ -1833,15 +1874,17 @@ __global__ __launch_bounds__(NT) void k_s1_stream(const uint32_t *__restrict__ i
         }
       }
       MHX_TT(12)
-      // C: one walk over the table — per distinct key: statistics, the mark of a key's only record, its aggregated stage-2
-      // items (their place in the workgroup's region from one LDS atomic per wavefront and step) — and the slot is free again
+      // C: one walk over the table — per distinct key: statistics and the mark of a key's only record; the slot is free again.
+      // The solid keys (a few per cent of the slots) are only LISTED here: what they need — the (k+1)-mer, its reverse
+      // complement, one or two aggregated stage-2 items — is ~100 instructions that every lane of a wavefront would sit
+      // through for the one or two lanes that hold a solid key (measured: the walk with that work inline took 29 % of the
+      // kernel).  The list is worked off densely behind barrier B, while other wavefronts already insert the next round.
 #pragma unroll 1
       for (int it = 0; it < NSLOT / NT; ++it) {
         const int sl = it * NT + tid;
         const uint32_t lk = keys[sl];
-        uint32_t n_out = 0, cnt = 0;
-        uint64_t x = 0, xr = 0;
-        bool mark = false;
+        uint32_t cnt = 0;
+        bool mark = false, want = false;
         if (lk != kStreamEmpty) {
           cnt = cnts[sl];
           keys[sl] = kStreamEmpty;
@@ -1856,11 +1899,7 @@ __global__ __launch_bounds__(NT) void k_s1_stream(const uint32_t *__restrict__ i
               if (hb < kSegHist) atomicAdd(&lhist[hb], 1u);
               else atomicAdd(&a.hist[hb], 1ull);
               mark = a.direct_marks && !solid;  // count 1 < m <= 2: the key's only record (mark_mode 1)
-              if (AGG && solid) {
-                x = edge_of(bi, lk);
-                xr = rc64(x, k + 1);
-                n_out = x == xr ? 1u : 2u;
-              }
+              want = AGG && solid;
             }
           }
         }
@@ -1883,28 +1922,15 @@ __global__ __launch_bounds__(NT) void k_s1_stream(const uint32_t *__restrict__ i
           }
         }
         if constexpr (AGG) {
-          if (a.mark_mode != 2) {  // (uniform)
-            const uint32_t incl = wave_inclusive_sum(n_out);
-            const uint32_t tot = __shfl(incl, kWave - 1, kWave);
-            if (tot) {
-              uint32_t wbase = 0;
-              if (lane == 0) wbase = atomicAdd(&s_agg_cur, tot);
-              wbase = __shfl(wbase, 0, kWave);
-              if (wbase + tot + (marks_out ? s_mark_cur : 0u) <= a.agg_cap) {
-                if (n_out) {
-                  long at = (long)(wbase + incl - n_out);
-                  const uint64_t mask_k = ~0ull << (64 - 2 * k);
-                  const uint64_t mul = cnt > MHX_MAX_MUL ? (uint64_t)MHX_MAX_MUL : cnt;
-                  const uint64_t f = ((x << 2) & mask_k) | (1ull << 19) | ((x >> 62) << 16) | mul;
-                  agg_end[-1 - at++] = make_uint2((uint32_t)(f >> 32), (uint32_t)f);
-                  if (n_out == 2) {
-                    const uint64_t b = ((xr << 2) & mask_k) | (1ull << 19) | ((xr >> 62) << 16) | mul;
-                    agg_end[-1 - at] = make_uint2((uint32_t)(b >> 32), (uint32_t)b);
-                  }
-                }
-              } else if (lane == 0) {
-                atomicOr(a.err, 1u);
-              }
+          const uint64_t wm = __ballot(want);
+          if (wm) {
+            uint32_t lbase = 0;
+            if (lane == 0) lbase = atomicAdd(&s_list_n[rp], (uint32_t)__builtin_popcountll(wm));
+            lbase = __shfl(lbase, 0, kWave);
+            if (want) {
+              const uint32_t at = lbase + (uint32_t)__builtin_popcountll(wm & lanemask_lt);
+              if (at < (uint32_t)NLIST) slist[at] = make_uint2(lk, cnt);
+              else emit_items(bi, lk, cnt, false);  // (more solid keys in one round than the list holds: in place)
             }
           }
         }
@@ -1912,6 +1938,14 @@ __global__ __launch_bounds__(NT) void k_s1_stream(const uint32_t *__restrict__ i
       MHX_TT(13)
       __syncthreads();  // B: the table is empty
       MHX_TT(14)
+      if constexpr (AGG) {  // the listed solid keys -> aggregated items
+        const uint32_t n_list = min(s_list_n[rp], (uint32_t)NLIST);
+        for (uint32_t base = 0; base < n_list; base += NT) {
+          const uint32_t i = base + tid;
+          const uint2 e = i < n_list ? slist[i] : make_uint2(0u, 0u);
+          emit_items(bi, e.x, e.y, true, i < n_list);
+        }
+      }
       rp ^= 1;
       sub = nsub;
       rj = nrj;
@@ -2613,7 +2647,8 @@ uint64_t s1_extract(mhx_ctx *c, uint32_t k, bool compact) {
 
 // sort + group reduction of n_items items held in buf_a (buf_b = ping-pong space of the same size)
 bool s1_presort_applies(const mhx_ctx *c, uint32_t k, uint64_t n_local_items) {
-  return s1_plan(c, k, n_local_items, s1_compact(c, k, 0), 0).stream;
+  // (k_s1_stream keeps the bounds and the arrays of up to kStreamSrcMax senders in LDS; more ranks take the classic exchange)
+  return c->n_parts <= kStreamSrcMax && s1_plan(c, k, n_local_items, s1_compact(c, k, 0), 0).stream;
 }
 // the LSD passes that order this rank's stage-1 records by the plan's prefix (the first half of s1_process on the stream
 // plan; the ranks agreed on the density the plan follows: mhx_ctx::s1_density)
@@ -2806,6 +2841,7 @@ struct S1Stage {
       MHX_HIP(hipMemsetAsync(ticket, 0, 4, st));
       const unsigned bgrid = (unsigned)((n_buckets + 1 + 255) / 256);
       const uint32_t *const *srcs = nullptr;
+      if (n_src > kStreamSrcMax) throw Error("s1: more pre-sorted sources than the bucket streaming takes");
       if (n_src > 1 || (pre && sorted == nullptr)) {
         DevBuf &sp = c->ws("s1_src_ptrs", (size_t)n_src * 8 + 64);
         MHX_HIP(hipMemcpyAsync(sp.p, pre->ptr.data(), (size_t)n_src * 8, hipMemcpyHostToDevice, st));
