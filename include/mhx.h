@@ -60,9 +60,10 @@ int mhx_synchronize(mhx_ctx *);
  *   s1_stream (1)     0: never the bucket-streaming group-by (k_s1_stream).  Its sort prefix follows the job's density
  *                     (records per lv1 bucket where the group-by runs): s1_stream_max (40000) records per streamed
  *                     bucket at most — 16 prefix bits in two passes up to that, 2^s sub-rounds per bucket up to
- *                     2^s1_stream_sub_max (1) times that, 17..24 bits in three passes beyond; s1_stream_bits (0) /
- *                     s1_stream_sub0 (-1) force the prefix width / the sub-rounds (tests); s1_stream_fill: slots a
- *                     round may claim before the bucket is split (7/8 of the table); s1_stream_probes (1024)
+ *                     2^s1_stream_sub_max (1) times that, 17..24 bits in three passes beyond (their
+ *                     width aims at s1_stream_max3 = s1_stream_max / 2 records per bucket: a third pass costs the same at any width); s1_stream_bits (0) /
+ *                     s1_stream_sub0 (-1) force the prefix width / the sub-rounds (tests); s1_stream_fill: keys a
+ *                     round's table may end up with before the round is redone in two halves (7/8 of the table); s1_stream_probes (1024)
  *   s1_filter_in_gen (1)  0: a bucket filter (memory plan) is applied to stage 1 by extraction batches + a keep/drop
  *                     split even where the generating first sort pass could leave the dropped buckets out itself
  *   s1_pos_bits (0)   width of the position word of compact stage-1 records (0 = 32); the position bits above it ride
@@ -89,16 +90,14 @@ int mhx_set_option(mhx_ctx *, const char *name, long long value);
  *                          sorted before it (the prefix plans of stage 1) ranks with one LDS atomic per record wherever all
  *                          records of a wavefront instruction agree on those bits — an order that cannot matter there — and
  *                          with the ballots elsewhere (sort_kernels.h RANK 2); correct on any hardware
- *   s1_stream_used_list (1) 0: the bucket streaming walks its whole LDS table in the per-key phases instead of the list of
- *                          occupied slots
  *   s1_gen_blocked (0)     1: the generating first sort pass of stage 1 gives every thread consecutive items and requests the
  *                          window words of a whole unit up front (S1GenBlocked) instead of one window load per item
  *   s1_digit_hist_preload (0) 1: the same in the digit-histogram pre-pass
- *   s1_stream_read_first (0) 1: the bucket streaming reads a slot before it tries to claim it
  *   s1_stream_half (0)     1: two 512-thread workgroups with 4096-slot tables per CU in the bucket streaming instead of one
  *                          with 1024 threads and 8192 slots (a bucket whose keys overflow a table is split inside the kernel)
- *   s1_stream_prefetch (0) 1: the bucket streaming has the record loads of trip i + 1 in flight while it inserts trip i, and
- *                          (s1_stream_next_bucket, 1) fetches the next bucket's ticket and bounds during the current bucket
+ * (Round 4: s1_stream_prefetch / s1_stream_next_bucket / s1_stream_used_list / s1_stream_read_first / s1_stream_unroll are gone:
+ *  the bucket streaming always has its next trip's loads in flight, fetches the next bucket's bounds during the current bucket and
+ *  walks its table once; setting them changes nothing.)
  * (mhx_tuning.conf of this tree: s1_gen_blocked = 1.) */
 long long mhx_get_option(mhx_ctx *, const char *name, long long dflt);
 /* What the last stage 1 of this handle ran as: "stream p16 sub0 2 passes (20345 records per lv1 bucket)" / "seg p24 3 passes" /

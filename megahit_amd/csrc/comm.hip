@@ -767,14 +767,26 @@ int mhx_dist_gen_mercy_edges(mhx_ctx *c, mhx_comm *cm, uint32_t k, const uint32_
     share.my_part = cm->rank;
     share.n_parts = cm->n;
     share.reduce_flags = [&](uint8_t *d_flags, uint64_t nf) {
-      // flags are has_in | has_out << 1 per base position; OR over the ranks = "any rank's count is non-zero": four positions
-      // per 64-bit word, 8 bits per flag bit, summed over <= 255 ranks
+      // flags are has_in | has_out << 1 per base position; OR over the ranks = the MAXIMUM of 0/1 fields — exact for any number
+      // of ranks (a sum of 8-bit fields wraps at 256 ranks): four positions per 64-bit word, 8 bits per flag bit; the maximum of
+      // the packed words is taken field by field below, from one reduction per field pair
       std::vector<uint8_t> h(nf);
       MHX_HIP(hipMemcpyAsync(h.data(), d_flags, nf, hipMemcpyDeviceToHost, c->stream));
       MHX_HIP(hipStreamSynchronize(c->stream));
       std::vector<uint64_t> v((nf + 3) / 4, 0);
       for (uint64_t i = 0; i < nf; ++i) v[i / 4] |= (uint64_t)((h[i] & 1u) | ((h[i] & 2u) << 7)) << (16 * (i % 4));
-      cm->all_reduce(v, false);
+      if (cm->n <= 255) {
+        cm->all_reduce(v, false);  // (no field can wrap: a sum is one reduction)
+      } else {  // every field on its own, as a maximum
+        std::vector<uint64_t> acc(v.size());
+        std::vector<uint64_t> one(v.size());
+        for (int f = 0; f < 8; ++f) {
+          for (size_t i = 0; i < v.size(); ++i) one[i] = (v[i] >> (8 * f)) & 0xFFull;
+          cm->all_reduce(one, true);
+          for (size_t i = 0; i < v.size(); ++i) acc[i] |= one[i] << (8 * f);
+        }
+        v.swap(acc);
+      }
       for (uint64_t i = 0; i < nf; ++i) {
         const uint64_t x = v[i / 4] >> (16 * (i % 4));
         h[i] = (uint8_t)(((x & 0xFFu) ? 1u : 0u) | (((x >> 8) & 0xFFu) ? 2u : 0u));

@@ -11,6 +11,7 @@
 #include <signal.h>
 #include <sys/prctl.h>
 #include <sys/socket.h>
+#include <sys/stat.h>
 #include <sys/un.h>
 #include <sys/wait.h>
 #include <cerrno>
@@ -133,8 +134,13 @@ mhx_ctx *open_gpu() {
 // The worker process tells the front process (main) to start the sub-program again that way instead of failing the caller.
 extern int g_done_fd;
 constexpr unsigned char kRetryClassicSort = 75;
+struct RetryClassic {};  // served request: run it once more with the classic sort passes
 [[noreturn]] void fail_call(const char *msg) {
   if (g_serving) {
+    if (!getenv("MHX_SORT") && strstr(msg, "chained scan timed out")) {
+      mhxio::info("%s: running the request again with MHX_SORT=classic", msg);
+      throw RetryClassic{};
+    }
     fprintf(stderr, "FATAL %s\n", msg);
     throw mhxio::Fatal{};
   }
@@ -1154,7 +1160,12 @@ int serve(const char *path) {
   if (ls < 0) fatal("socket: %s", strerror(errno));
   if (connect_to(path) >= 0) fatal("a server already listens on %s", path);
   unlink(path);
-  if (bind(ls, reinterpret_cast<sockaddr *>(&a), sizeof a) != 0 || listen(ls, 16) != 0) fatal("cannot listen on %s: %s", path, strerror(errno));
+  // the socket is this user's alone: a request carries argv, a working directory and environment settings, i.e. whoever may
+  // connect may write files as the server's user
+  const mode_t old_mask = umask(0177);
+  const bool bound = bind(ls, reinterpret_cast<sockaddr *>(&a), sizeof a) == 0;
+  umask(old_mask);
+  if (!bound || chmod(path, 0600) != 0 || listen(ls, 16) != 0) fatal("cannot listen on %s: %s", path, strerror(errno));
   const int idle_s = getenv("MHX_SERVE_IDLE_S") ? std::max(1, atoi(getenv("MHX_SERVE_IDLE_S"))) : 120;
   g_serving = true;
   mhxio::g_fatal_throws = true;
@@ -1167,6 +1178,16 @@ int serve(const char *path) {
     if (pr <= 0) break;  // idle
     const int fd = accept(ls, nullptr, nullptr);
     if (fd < 0) continue;
+    {  // same user only, and a client that stalls in the middle of its request does not hold the server for the others
+      ucred cr{};
+      socklen_t cl = sizeof cr;
+      if (getsockopt(fd, SOL_SOCKET, SO_PEERCRED, &cr, &cl) != 0 || cr.uid != geteuid()) {
+        close(fd);
+        continue;
+      }
+      timeval tv{10, 0};
+      setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof tv);
+    }
     uint32_t argc = 0, n_env = 0;
     std::vector<std::string> args, envs;
     std::string cwd;
@@ -1233,7 +1254,15 @@ int serve(const char *path) {
       for (std::string &x : args) argv.push_back(&x[0]);
       argv.push_back(nullptr);
       try {
-        status = (unsigned char)dispatch((int)argv.size() - 1, argv.data());
+        try {
+          status = (unsigned char)dispatch((int)argv.size() - 1, argv.data());
+        } catch (const RetryClassic &) {  // as the front process does for a worker (main): once more, without the chained scan
+          setenv("MHX_SORT", "classic", 1);
+          restore.emplace_back("MHX_SORT", "\x01");
+          status = (unsigned char)dispatch((int)argv.size() - 1, argv.data());
+        }
+      } catch (const RetryClassic &) {
+        status = 1;
       } catch (const mhxio::Fatal &) {
         status = 1;
       } catch (const std::string &e) {
@@ -1269,7 +1298,7 @@ int serve(const char *path) {
 int try_server(int argc, char **argv) {
   using namespace serve_io;
   const char *path = getenv("MHX_SERVER");
-  if (!path || !*path) return -1;
+  if (!path || !*path || !strcmp(path, "off") || !strcmp(path, "0")) return -1;
   int fd = connect_to(path);
   if (fd < 0 && getenv("MHX_SERVER_AUTOSTART")) {
     const pid_t pid = fork();
@@ -1347,6 +1376,22 @@ int main(int argc, char **argv) {
     argv[2] = argv[0];
     argv += 2;
     argc -= 2;
+  }
+  // Started under the reference's own name (a link megahit_core -> mhx_core, which is how an unmodified orchestrator finds
+  // us: INTEGRATION.md §1) the sub-programs of a pipeline run one behind the other, and each new process would pay for the
+  // device memory the one before it gave back (the driver scrubs returned memory: 1-4 s per process at 40-240 GB).  So under
+  // that name the resident server is the default: one per user and device, started on first use, gone after two idle minutes.
+  // MHX_SERVER=off (or any explicit MHX_SERVER) overrides; if no server can be reached the work is done here as ever.
+  {
+    const char *base = strrchr(argv[0], '/');
+    base = base ? base + 1 : argv[0];
+    if (!strcmp(base, "megahit_core") && !getenv("MHX_SERVER")) {
+      const char *dir = getenv("XDG_RUNTIME_DIR");
+      const char *dev = getenv("MHX_DEVICE");
+      const std::string path = std::string(dir && *dir ? dir : "/tmp") + "/mhx-core-" + std::to_string((unsigned)geteuid()) + "-dev" + (dev ? dev : "0") + ".sock";
+      setenv("MHX_SERVER", path.c_str(), 1);
+      setenv("MHX_SERVER_AUTOSTART", "1", 0);
+    }
   }
   const std::string sub = argv[1];
   const bool ours = sub == "count" || sub == "read2sdbg" || sub == "seq2sdbg" || (sub == "buildlib" && !getenv("MHX_BUILDLIB_REF")) ||

@@ -1605,7 +1605,9 @@ __global__ __launch_bounds__(NT) void k_s1_stream(const uint32_t *__restrict__ i
   };
 
   unsigned long long st_solid = 0, st_both = 0;
-  const int probe_limit = a.la_chunks;  // (stream mode: the host passes the probe limit here; tests set it to 0)
+  // (stream mode: the host passes the probe limit here; tests set it to 0.  Below 7/8 full a chain of 128 slots does not occur
+  //  in practice; where it does, the round is redone in two halves)
+  const int probe_limit = min(a.la_chunks, 128);
   // register set A: at the top of a round it holds the round's first trip, requested long before (by the round before it, or
   // right here for the first bucket) — one writer on the hot path, so that no copies (= waits for the loads) are needed
   uint32_t nw0[UNR], nw1[UNR], nw2[UNR], n_inm = 0;
@@ -1660,11 +1662,15 @@ __global__ __launch_bounds__(NT) void k_s1_stream(const uint32_t *__restrict__ i
     const uint32_t sub_first = sub;
     for (;;) {
       const uint32_t sub_sh = (uint32_t)lk_bits - sub;  // (sub == 0: no test)
-      uint32_t claims = 0;
+      uint32_t claims = 0, seen = 0;
       // A: insert.  Two register sets take turns (A: nw*, B: mw*): while the trip in one is inserted, the loads of the trip after
       // it fill the other — no copies between them (a copy of freshly loaded registers is a wait for the loads).
       // the inserts of one trip
       auto insert_trip = [&](const uint32_t (&rw0)[UNR], const uint32_t (&rw1)[UNR], const uint32_t (&rw2)[UNR], uint32_t inm) {
+        // a round that has outgrown its table is redone in two halves anyway: no further inserts (the probe chains of a table that
+        // fills up grow without bound long before an insert fails).  `seen` = the round's key count as read behind the trip before.
+        if (seen > geo.max_fill) return;
+        const uint32_t claims_before = claims;
         uint32_t lk[UNR];
         uint32_t mine = 0;
 #pragma unroll
@@ -1749,6 +1755,15 @@ __global__ __launch_bounds__(NT) void k_s1_stream(const uint32_t *__restrict__ i
             break;
           }
         }
+        // the keys this wavefront claimed in this trip (0..UNR per lane, counted with three ballots) -> the round's count, which is
+        // read back for the next trip's look at it
+        {
+          const uint32_t d = claims - claims_before;
+          const uint32_t c = (uint32_t)__builtin_popcountll(__ballot(d & 1u)) + 2u * (uint32_t)__builtin_popcountll(__ballot(d & 2u)) +
+                             4u * (uint32_t)__builtin_popcountll(__ballot(d & 4u));
+          if (lane == 0 && c) atomicAdd(&s_nclaimed[rp], c);
+          seen = __hip_atomic_load(&s_nclaimed[rp], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
       };
       {
         int q = q0;
@@ -1787,10 +1802,6 @@ __global__ __launch_bounds__(NT) void k_s1_stream(const uint32_t *__restrict__ i
         }
       }
       desc_step(2);
-      {
-        const uint32_t c = wave_sum(claims);
-        if (lane == 0 && c) atomicAdd(&s_nclaimed[rp], c);
-      }
       __syncthreads();  // A: the table is complete
       MHX_TT(11)
       const bool bad = s_bad[rp] != 0 || s_nclaimed[rp] > geo.max_fill;
@@ -2370,7 +2381,13 @@ static S1Plan s1_plan(const mhx_ctx *c, uint32_t k, uint64_t n_items, bool compa
     int pbits = 16, sub0 = 0;
     if (need <= sub_max) sub0 = need;
     else {
-      pbits = std::min(16 + need, 24);
+      // a third pass costs the same for 17 or 24 prefix bits: aim at buckets that fill a third of the table — the inserts of a
+      // table at two thirds take twice as long (tools/micro/insert_probe.hip), and the canonical (k-1)-mers make the low lv1
+      // buckets twice as full as the average — but not at so many buckets that their fixed cost (a walk over 8192 slots) shows
+      const double cap3 = (double)std::max<long long>(1, c->opt("s1_stream_max3", std::max<long long>(1, (long long)cap / 2)));
+      need = 0;
+      while (need < 30 && per_bucket > cap3 * (double)(1ull << need)) ++need;
+      pbits = std::min(16 + std::max(need, 1), 24);
       sub0 = std::min(16 + need - pbits, 6);  // (past 24 bits: the rest as sub-rounds; the kernel splits further if it has to)
     }
     if (const long long f = c->opt("s1_stream_bits", 0)) pbits = (int)std::min<long long>(std::max<long long>(f, 9), 24);

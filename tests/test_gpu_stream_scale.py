@@ -91,8 +91,8 @@ def test_overflowing_buckets_split_themselves(engine, kind, k, m, opts):
 @pytest.mark.parametrize("cap", [40000, 6, 3, 1])
 def test_the_plan_follows_the_density(engine, cap):
     """7.6 records per lv1 bucket in this library (498 000 items): with s1_stream_max = 6 the buckets are twice too large (one
-    level of sub-rounds, still two passes), with 3 four times (18 prefix bits, three passes), with 1 eight times (19 bits): the
-    plan is a pure function of the density and the knobs"""
+    level of sub-rounds, still two passes), with 3 four times and with 1 eight times (three passes; their width aims at half
+    the density: 19 prefix bits both): the plan is a pure function of the density and the knobs"""
     pkg = ob.Package(library("pe100", 5), reverse=True)
     load(engine, pkg)
     with knobs(engine, s1_stream_max=cap):
@@ -106,8 +106,11 @@ def test_the_plan_follows_the_density(engine, cap):
             assert plan.startswith("stream p16 sub0 2 passes"), plan
         elif need == 1:
             assert plan.startswith("stream p16 sub1 2 passes"), plan
-        else:
-            assert plan.startswith("stream p%d sub0 3 passes" % (16 + need)), plan
+        else:  # three passes whatever the width: the width aims at buckets half as full (s1_stream_max3 = s1_stream_max / 2)
+            cap3, need3 = max(1, cap // 2), 0
+            while per_bucket > cap3 * (1 << need3):
+                need3 += 1
+            assert plan.startswith("stream p%d sub0 3 passes" % (16 + max(need3, 1))), plan
 
 
 @pytest.mark.parametrize("opts", [dict(), dict(s1_stream_direct=0), dict(s1_stream=0), dict(s1_seg=0), dict(s1_stream_bits=20, s1_stream_prefetch=1), dict(s1_gen_blocked=0)],

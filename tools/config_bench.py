@@ -158,6 +158,7 @@ def configs2(keep=None, emit=True):
             out["runs"][label] = r
             sys.stderr.write("%s %s\n" % (label, json.dumps({"wall_s": r["wall_s"], "kernel_ms": r["kernel_ms_total"], "ok": ok, "passes": passes})))
             r["log_tail"] = [l for l in LAST_LOG.splitlines() if "plan" in l.lower() or "passes" in l][:12]
+            r["log"] = [l for l in LAST_LOG.splitlines() if l.startswith("INFO") or l.startswith("WARN")][-60:]
             for fn in os.listdir(tmp):
                 if fn.startswith("o_"):
                     os.remove(os.path.join(tmp, fn))
