@@ -102,3 +102,39 @@ def test_autostart(tmp_path):
         time.sleep(0.05)
     assert not os.path.exists(sock)
     assert "leaves after 2 requests" in open(os.path.join(d, "auto.log")).read()
+
+
+def test_the_references_name_starts_a_server_of_its_own_accord(tmp_path):
+    """megahit_core -> mhx_core: no MHX_SERVER in the environment, and the sub-program still runs in a resident server — started by
+    this very call, listening on $XDG_RUNTIME_DIR/mhx-core-<uid>-dev0.sock, readable and writable by its owner only; the same
+    call with MHX_SERVER=off, or under the name mhx_core, starts nothing"""
+    import stat
+    d = str(tmp_path)
+    link = os.path.join(d, "megahit_core")
+    os.symlink(gu.MHX_CORE, link)
+    lib = write_inputs(d)
+    rt = os.path.join(d, "rt")
+    os.mkdir(rt)
+    sock = os.path.join(rt, "mhx-core-%d-dev0.sock" % os.geteuid())
+    env = {k: v for k, v in os.environ.items() if not k.startswith("MHX_SERVER")}
+    env.update(XDG_RUNTIME_DIR=rt, MHX_BUILDLIB_HOST="1", MHX_SERVE_IDLE_S="20")
+
+    def call(prog, out, **extra):
+        return subprocess.run([prog, "buildlib", lib, os.path.join(d, out)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                              env=dict(env, **extra), timeout=60)
+    try:
+        p = call(gu.MHX_CORE, "plain")
+        assert p.returncode == 0 and not os.path.exists(sock), p.stderr[-400:]
+        p = call(link, "off", MHX_SERVER="off")
+        assert p.returncode == 0 and not os.path.exists(sock), p.stderr[-400:]
+        p = call(link, "served")
+        assert p.returncode == 0, p.stderr[-400:]
+        assert os.path.exists(sock), "no server was started"
+        assert stat.S_IMODE(os.stat(sock).st_mode) == 0o600
+        q = call(link, "served2")
+        assert q.returncode == 0
+        for name in ("off", "served", "served2"):
+            assert canon.digest_file(os.path.join(d, name + ".bin")) == canon.digest_file(os.path.join(d, "plain.bin")), name
+    finally:
+        if os.path.exists(sock):
+            subprocess.run([gu.MHX_CORE, "--serve-stop", sock], timeout=30)

@@ -1,10 +1,10 @@
 #!/bin/bash
 # One gpurun call: the bench lines, rocprofv3 kernel stats and the two PMC passes of the same command, the reference's
 # CPU path at full size on this host, the other sub-programs, routes and rows.
-#     gpurun --timeout 3000 -- 'bash tools/gpu_evidence.sh r03 [skip_cpu]'
+#     gpurun --timeout 3000 -- 'bash tools/gpu_evidence.sh r04 [skip_cpu]'
 # Results land in gpurun_out/TAG_*; what is to be judged is copied into profiles/ by the caller (the PMC file right here,
 # so that the bench line of this very call can quote it).
-TAG=${1:-r03}
+TAG=${1:-r04}
 R=$(pwd)
 O=$R/gpurun_out
 mkdir -p $O
@@ -40,4 +40,12 @@ tail -3 $O/${TAG}_bench_meta.err
 timeout 900 python bench.py > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err
 cat $O/${TAG}_bench.json | cut -c1-2500
 timeout 600 python tools/e2e_routes.py > $O/${TAG}_e2e_routes.json 2> $O/${TAG}_e2e_routes.err
+# the north-star size (BASELINE configs[2]): 100 M reads on one GPU (memory plan), as eight ranks on this device, and one GPU's
+# share of the 8-GPU job eighth by eighth — digests against tests/golden/fullsize_100M.json
+mkdir -p /tmp/c2lib
+timeout 900 python tools/config_bench.py configs2 /tmp/c2lib > $O/${TAG}_bench_configs2.json 2> $O/${TAG}_bench_configs2.err; tail -3 $O/${TAG}_bench_configs2.err
+timeout 600 python tools/config_bench.py owner8 /tmp/c2lib > $O/${TAG}_bench_owner8.json 2> $O/${TAG}_bench_owner8.err; tail -2 $O/${TAG}_bench_owner8.err
+rm -rf /tmp/c2lib
+# what LDS operations, the insert forms and the read patterns of the bucket streaming cost on this device (tools/micro)
+for m in lds_probe insert_probe read_probe; do [ -x tools/micro/$m ] && timeout 60 ./tools/micro/$m > $O/${TAG}_micro_$m.txt 2>&1; done
 ls -la $O | grep ${TAG}_ | tail -30

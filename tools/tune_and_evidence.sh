@@ -1,7 +1,7 @@
 #!/bin/bash
 # One gpurun call (~2.5 box-minutes): tests of the knob-selected code paths, greedy tuning on the box ->
 # megahit_amd/mhx_tuning.conf, then the evidence set (tools/evidence_short.sh) under the tuned defaults that will ship.
-#     gpurun --timeout 420 -- 'bash tools/tune_and_evidence.sh r04 "s1_pack8 s1_stream_unroll=8 s2_fused_emit"'
+#     gpurun --timeout 420 -- 'bash tools/tune_and_evidence.sh r04 "s1_gen_blocked s1_digit_hist_preload"'
 # TAG names the files under gpurun_out/ (copy what is to be judged into profiles/ and the tuning file into megahit_amd/).
 # KNOBS (optional) are tried on top of the current tuned defaults, in this order; a knob the library does not know changes
 # nothing and is not kept.
@@ -9,7 +9,6 @@ TAG=${1:-r04}
 KNOBS=${2:-"s1_gen_blocked s1_digit_hist_preload"}
 R=$(pwd); O=$R/gpurun_out; mkdir -p $O; export TMPDIR=/tmp
 TESTS="tests/test_gpu_round3_knobs.py tests/test_gpu_tuning.py tests/test_gpu_sort_unit_runs.py tests/test_gpu_sdbg.py"
-[ -f tests/test_gpu_fused_emit.py ] && TESTS="$TESTS tests/test_gpu_fused_emit.py"
 timeout 200 python -m pytest $TESTS -m gpu -x -q > $O/${TAG}_tune_tests.log 2>&1; T=$?
 echo "tests rc=$T"; grep -E "passed|failed|error" $O/${TAG}_tune_tests.log | tail -3
 if [ $T -ne 0 ]; then tail -40 $O/${TAG}_tune_tests.log; exit 1; fi
@@ -17,7 +16,6 @@ if [ $T -ne 0 ]; then tail -40 $O/${TAG}_tune_tests.log; exit 1; fi
 BASE=$(python - <<'P'
 import bench
 d = bench.tuned_defaults()
-d.setdefault("s1_stream_unroll", 4)
 print(" ".join("%s=%d" % kv for kv in d.items()))
 P
 )
