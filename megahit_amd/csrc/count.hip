@@ -693,7 +693,12 @@ static std::vector<SortPass> count_sort_passes(mhx_ctx *c, uint32_t k, uint32_t 
     seg_bits = std::max(1, std::min(seg_bits, 32));
   }
   if (seg_bits_out) *seg_bits_out = seg_bits;
-  return seg_bits ? make_passes(KWv, 64 - seg_bits, 64) : make_passes(KWv, KWv * 32 - key_bits, KWv * 32);
+  if (!seg_bits) return make_passes(KWv, KWv * 32 - key_bits, KWv * 32);
+  // (the segment group-by counts the equal keys of a segment whatever their order: every pass after the first may say which
+  //  bits were sorted before it, and ranks with LDS atomics where a wavefront's records agree on those — SortPass::prev_lo)
+  std::vector<SortPass> passes = make_passes(KWv, 64 - seg_bits, 64);
+  for (size_t i = 1; i < passes.size(); ++i) passes[i].prev_lo = 64 - seg_bits;
+  return passes;
 }
 
 // items of the local reads -> c->ws("items_a"); returns their number.  m > 0: the caller will sort them for mhx_count with

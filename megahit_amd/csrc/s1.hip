@@ -1456,9 +1456,12 @@ __global__ __launch_bounds__(NT) void k_s1_stream(const uint32_t *__restrict__ i
   const int lk_bits = rem + 6;          // <= 32
   const int mer_sh = 64 - 2 * (k - 1);
   const uint32_t mer_mask = rem ? (1u << rem) - 1u : 0u;
+  // (the low 32 bits of (w0:w1) >> mer_sh: one funnel shift while the (k-1)-mer reaches into the second word, k >= 18)
+  const bool mer_two_words = mer_sh < 32;
+  const uint32_t mer_sh1 = (uint32_t)(mer_two_words ? mer_sh : mer_sh - 32);
   auto local_key = [&](uint32_t w0, uint32_t w1) -> uint32_t {
-    const uint64_t key = ((uint64_t)w0 << 32) | w1;
-    return ((uint32_t)(key >> mer_sh) & mer_mask) << 6 | (w1 & 63u);
+    const uint32_t lo = mer_two_words ? __builtin_amdgcn_alignbit(w0, w1, mer_sh1) : w0 >> mer_sh1;
+    return (lo & mer_mask) << 6 | (w1 & 63u);
   };
   // the (k+1)-mer head.S.tail of a table key of bucket bi, chars MSB-first in 64 bits
   auto edge_of = [&](uint32_t bi, uint32_t lk) -> uint64_t {
@@ -1890,17 +1893,30 @@ __global__ __launch_bounds__(NT) void k_s1_stream(const uint32_t *__restrict__ i
       // complement, one or two aggregated stage-2 items — is ~100 instructions that every lane of a wavefront would sit
       // through for the one or two lanes that hold a solid key (measured: the walk with that work inline took 29 % of the
       // kernel).  The list is worked off densely behind barrier B, while other wavefronts already insert the next round.
-#pragma unroll 1
-      for (int it = 0; it < NSLOT / NT; ++it) {
-        const int sl = it * NT + tid;
-        const uint32_t lk = keys[sl];
-        uint32_t cnt = 0;
-        bool mark = false, want = false;
-        if (lk != kStreamEmpty) {
-          cnt = cnts[sl];
+      // (all of a thread's slots are read first and wiped, then looked at: one LDS round trip for the lot instead of three
+      //  dependent ones per slot; the places in the list of solid keys — and, on several GPUs, in the region of marks — come
+      //  from one wavefront scan and one LDS atomic per wavefront and walk instead of one per slot)
+      {
+        constexpr int W = NSLOT / NT;
+        uint32_t wk[W], wc[W], wp[W];
+#pragma unroll
+        for (int it = 0; it < W; ++it) {
+          const int sl = it * NT + tid;
+          wk[it] = keys[sl];
+          wc[it] = cnts[sl];
+          wp[it] = fpos[sl];
+        }
+#pragma unroll
+        for (int it = 0; it < W; ++it) {
+          const int sl = it * NT + tid;
           keys[sl] = kStreamEmpty;
           cnts[sl] = 0;
-          if (!bad && (lk & 0x24u) == 0) {
+        }
+        uint32_t want_bits = 0, mark_bits = 0;
+#pragma unroll
+        for (int it = 0; it < W; ++it) {
+          const uint32_t lk = wk[it], cnt = wc[it];
+          if (lk != kStreamEmpty && !bad && (lk & 0x24u) == 0) {
             const bool solid = cnt >= m;
             if (a.mark_mode == 2) {
               st_both += cnt;
@@ -1909,40 +1925,51 @@ __global__ __launch_bounds__(NT) void k_s1_stream(const uint32_t *__restrict__ i
               const uint32_t hb = cnt > MHX_MAX_MUL ? (uint32_t)MHX_MAX_MUL : cnt;  // :430-436
               if (hb < kSegHist) atomicAdd(&lhist[hb], 1u);
               else atomicAdd(&a.hist[hb], 1ull);
-              mark = a.direct_marks && !solid;  // count 1 < m <= 2: the key's only record (mark_mode 1)
-              want = AGG && solid;
+              if (a.direct_marks && !solid) mark_bits |= 1u << it;  // count 1 < m <= 2: the key's only record (mark_mode 1)
+              if (AGG && solid) want_bits |= 1u << it;
             }
           }
         }
         if (a.direct_marks) {  // (uniform)
-          const uint64_t abs = mark ? fpos[sl] + (TAGS ? (uint64_t)ftag[sl] * a.pos_stride : 0ull) : 0ull;
           if (!marks_out) {
-            if (mark) a.solid_bytes[abs - 1] = 1;
+#pragma unroll
+            for (int it = 0; it < W; ++it)
+              if ((mark_bits >> it) & 1u) a.solid_bytes[wp[it] + (TAGS ? (uint64_t)ftag[it * NT + tid] * a.pos_stride : 0ull) - 1] = 1;
           } else {  // multi-GPU: the mark is the global position itself, appended to this workgroup's region
-            const uint64_t mm = __ballot(mark);
-            if (mm) {
+            const uint32_t n_mk = (uint32_t)__builtin_popcount(mark_bits);
+            const uint32_t incl = wave_inclusive_sum(n_mk);
+            const uint32_t tot = __shfl(incl, kWave - 1, kWave);
+            if (tot) {
               uint32_t mbase = 0;
-              if (lane == 0) mbase = atomicAdd(&s_mark_cur, (uint32_t)__builtin_popcountll(mm));
+              if (lane == 0) mbase = atomicAdd(&s_mark_cur, tot);
               mbase = __shfl(mbase, 0, kWave);
-              if (mark) {
-                const uint32_t at = mbase + (uint32_t)__builtin_popcountll(mm & lanemask_lt);
-                if (at + s_agg_cur < a.marks_cap) marks_out[at] = abs - 1;
-                else atomicOr(a.err, 2u);
-              }
+              uint32_t at = mbase + incl - n_mk;
+#pragma unroll
+              for (int it = 0; it < W; ++it)
+                if ((mark_bits >> it) & 1u) {
+                  if (at + s_agg_cur < a.marks_cap) marks_out[at] = wp[it] + (TAGS ? (uint64_t)ftag[it * NT + tid] * a.pos_stride : 0ull) - 1;
+                  else atomicOr(a.err, 2u);
+                  ++at;
+                }
             }
           }
         }
         if constexpr (AGG) {
-          const uint64_t wm = __ballot(want);
-          if (wm) {
+          const uint32_t n_w = (uint32_t)__builtin_popcount(want_bits);
+          const uint32_t incl = wave_inclusive_sum(n_w);
+          const uint32_t tot = __shfl(incl, kWave - 1, kWave);
+          if (tot) {
             uint32_t lbase = 0;
-            if (lane == 0) lbase = atomicAdd(&s_list_n[rp], (uint32_t)__builtin_popcountll(wm));
+            if (lane == 0) lbase = atomicAdd(&s_list_n[rp], tot);
             lbase = __shfl(lbase, 0, kWave);
-            if (want) {
-              const uint32_t at = lbase + (uint32_t)__builtin_popcountll(wm & lanemask_lt);
-              if (at < (uint32_t)NLIST) slist[at] = make_uint2(lk, cnt);
-              else emit_items(bi, lk, cnt, false);  // (more solid keys in one round than the list holds: in place)
-            }
+            uint32_t at = lbase + incl - n_w;
+#pragma unroll
+            for (int it = 0; it < W; ++it)
+              if ((want_bits >> it) & 1u) {
+                if (at < (uint32_t)NLIST) slist[at] = make_uint2(wk[it], wc[it]);
+                else emit_items(bi, wk[it], wc[it], false);  // (more solid keys in one round than the list holds: in place)
+                ++at;
+              }
           }
         }
       }
