@@ -5,7 +5,7 @@ the library's own per-kernel clocks, and the SdBG its last step left in HBM is d
 than the steps.
 
     python tools/ab_options.py "sort_unit_runs=0" "sort_unit_runs=1" [--steps 6] [--engine read2sdbg|count] [--rounds 2]
-    python tools/ab_options.py "s1_stream_prefetch=0" --greedy "s1_gen_blocked s1_stream_half" --write-tuning megahit_amd/mhx_tuning.conf
+    python tools/ab_options.py "s1_gen_blocked=0" --greedy "s1_gen_blocked s1_digit_hist_preload" --write-tuning megahit_amd/mhx_tuning.conf
 
 --write-tuning FILE stores the winner as the installation's tuned defaults (libmhx reads mhx_tuning.conf beside libmhx.so
 at mhx_create; include/mhx.h: mhx_get_option).  Only configurations whose outputs matched the reference's digest qualify.
