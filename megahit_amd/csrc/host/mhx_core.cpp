@@ -1388,7 +1388,9 @@ int main(int argc, char **argv) {
     if (!strcmp(base, "megahit_core") && !getenv("MHX_SERVER")) {
       const char *dir = getenv("XDG_RUNTIME_DIR");
       const char *dev = getenv("MHX_DEVICE");
-      const std::string path = std::string(dir && *dir ? dir : "/tmp") + "/mhx-core-" + std::to_string((unsigned)geteuid()) + "-dev" + (dev ? dev : "0") + ".sock";
+      const std::string name = "/mhx-core-" + std::to_string((unsigned)geteuid()) + "-dev" + (dev ? dev : "0") + ".sock";
+      std::string path = std::string(dir && *dir ? dir : "/tmp") + name;
+      if (path.size() >= sizeof(sockaddr_un{}.sun_path)) path = "/tmp" + name;  // (a socket address holds ~107 characters)
       setenv("MHX_SERVER", path.c_str(), 1);
       setenv("MHX_SERVER_AUTOSTART", "1", 0);
     }
