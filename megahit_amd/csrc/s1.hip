@@ -1551,8 +1551,11 @@ __global__ __launch_bounds__(NT) void k_s1_stream(const uint32_t *__restrict__ i
   auto publish_desc = [&](int par, uint32_t tk) {
     if (lane == 0) s_tk[par] = d_err ? 0xFFFFFFFFu / (bucket_stride ? bucket_stride : 1u) : tk;
     if (lane < n_src) {
+      // (statistics on a sample — mark_mode 2 — look at no more than 8 trips of a bucket: one low-complexity bucket, poly-A at
+      //  lv1 bucket 0 for one, may hold millions of records, and a workgroup streams a bucket alone)
+      const uint64_t cap = (uint64_t)8 * NT * UNR;
       s_lo[par][lane] = d_lo;
-      s_hi[par][lane] = d_hi;
+      s_hi[par][lane] = a.mark_mode == 2 && d_hi - d_lo > cap ? d_lo + cap : d_hi;
     }
   };
   if (wave0) {  // the first bucket of this workgroup
