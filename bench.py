@@ -168,7 +168,7 @@ def cpu_baseline(sample_reads, threads=None):
         synth.write_read_lib(os.path.join(d, "reads"), [reads])
         if os.path.exists(ref):
             kind = "reference"
-            for t in (threads or sorted({min(8, cores), min(32, cores)})):
+            for t in (threads or sorted({min(8, cores), min(32, cores), min(64, cores), cores})):  # up to nproc, once
                 cmd = [ref, "read2sdbg", "-k", str(K), "-m", str(MIN_COUNT), "--host_mem", "32e9", "--num_cpu_threads", str(t),
                        "--read_lib_file", os.path.join(d, "reads"), "--output_prefix", os.path.join(d, "out")]
                 t0 = time.perf_counter()
@@ -189,7 +189,8 @@ def cpu_baseline(sample_reads, threads=None):
            "sample": "read2sdbg k=%d m=%d on %d synthetic %d bp reads (%.1f M edges), best wall %.1f s incl. file I/O"
                      % (K, MIN_COUNT, reads.shape[0], READ_LEN, E / 1e6, tried[best])}
     try:
-        with open(os.path.join(ROOT, "profiles", "r03_cpu_fullsize.json" if os.path.exists(os.path.join(ROOT, "profiles", "r03_cpu_fullsize.json")) else "r02_cpu_fullsize.json")) as f:
+        import glob
+        with open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_cpu_fullsize.json")))[-1]) as f:
             out["full_size"] = json.load(f)
     except Exception:
         pass
@@ -255,7 +256,7 @@ def end_to_end(n_reads):
         drop_in = os.path.join(ROOT, "megahit_amd", "megahit_core")
         if not os.path.exists(drop_in):
             os.symlink("mhx_core", drop_in)
-        sock = os.path.join(os.environ.get("XDG_RUNTIME_DIR") or "/tmp", "mhx-core-%d-dev%s.sock" % (os.geteuid(), os.environ.get("MHX_DEVICE", "0")))
+        sock = subprocess.run([mhx, "--default-socket"], stdout=subprocess.PIPE, text=True).stdout.strip()
         try:
             os.environ.pop("MHX_SERVER", None)
             mhx_plain, mhx = mhx, drop_in
@@ -383,8 +384,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+        if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+            # called the way `--gpus 1` is called, without a launcher: become the launcher — one rank per GPU over RCCL,
+            # rendezvous on the loopback address (the container's hostname may not resolve), this process's stdout (the
+            # one JSON line of rank 0) passed through
+            import socket
+            with socket.socket() as s:
+                s.bind(("127.0.0.1", 0))
+                port = s.getsockname()[1]
+            os.dup2(real_stdout, 1)
+            os.execv(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+                                      "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:])
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
 
     import numpy as np
@@ -394,18 +404,11 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (libmhx has no CPU fallback)")
     n_reads = int(args.reads) // 16 * 16
-    # The reference's CPU path on the WHOLE workload of this run, on 8 of this host's cores, started now and collected at the
-    # end: it takes about as long (85-150 s at 10 M reads) as everything else in this script together, so the driver's run
-    # carries a full-size CPU figure measured in the same run on the same box without taking twice as long.
-    cpu_full_proc = cpu_full_file = None
-    if rank == 0 and world == 1 and args.cpu_full and not args.no_cpu_baseline and args.engine == "read2sdbg" and \
-            os.path.exists(os.path.join(ROOT, "oracle", "_ref", "ref_core")):
-        try:
-            cpu_full_file = tempfile.NamedTemporaryFile(prefix="mhx_cpufull_", suffix=".json", delete=False)
-            cpu_full_proc = subprocess.Popen([sys.executable, os.path.join(ROOT, "tools", "cpu_fullsize.py"), "--threads", "8", "--reads", str(n_reads)],
-                                             stdout=cpu_full_file, stderr=subprocess.DEVNULL)
-        except Exception:
-            cpu_full_proc = None
+    # The reference's CPU path on the WHOLE workload of this run (8 of this host's cores, ~95 s at 10 M reads) runs at the very
+    # END, alone: started beside the read synthesis, the CLI runs and the GPU driver threads (round 4) it was timed under
+    # host contention, which flattered the GPU/CPU ratio.
+    cpu_full_wanted = rank == 0 and world == 1 and args.cpu_full and not args.no_cpu_baseline and args.engine == "read2sdbg" and \
+        os.path.exists(os.path.join(ROOT, "oracle", "_ref", "ref_core"))
     # Files in -> files out through the CLI, measured FIRST: mhx_core is a process of its own and is meant to find the GPU
     # as a caller finds it (measured after the timed steps, next to this process's ~100 GB of freshly released HBM, its
     # allocations alone took 0.2 s longer).  Reported in the JSON line at the end.
@@ -566,15 +569,14 @@ def main():
             if not args.no_cpu_baseline and args.engine == "read2sdbg":
                 try:
                     out["cpu_baseline"] = cpu_baseline(int(args.cpu_sample_reads) // 2 * 2)
-                    if cpu_full_proc is not None:
-                        t_wait = time.perf_counter()
-                        cpu_full_proc.wait(timeout=600)
-                        with open(cpu_full_file.name) as f:
-                            full_now = json.load(f)
-                        full_now["waited_for_it_at_the_end_s"] = round(time.perf_counter() - t_wait, 1)
-                        full_now["how"] = "tools/cpu_fullsize.py --threads 8, started when this script started, beside the GPU work"
+                    if cpu_full_wanted:
+                        eng.close()  # (nothing of this process competes with it: HBM released, no GPU work in flight)
+                        load_before = os.getloadavg()[0]
+                        proc = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "cpu_fullsize.py"), "--threads", "8", "--reads", str(n_reads)],
+                                              stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=900)
+                        full_now = json.loads(proc.stdout.decode())
+                        full_now["how"] = "tools/cpu_fullsize.py --threads 8, run alone after the GPU work of this script (host load average before it: %.1f)" % load_before
                         out["cpu_baseline"]["full_size_this_run"] = full_now
-                        os.unlink(cpu_full_file.name)
                 except Exception as ex:  # the baseline is reporting only; never lose the GPU number
                     out["cpu_baseline"] = {"value": None, "error": str(ex)}
             if e2e_result is not None:

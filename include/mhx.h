@@ -63,7 +63,7 @@ int mhx_synchronize(mhx_ctx *);
  *                     2^s1_stream_sub_max (1) times that, 17..24 bits in three passes beyond (their
  *                     width aims at s1_stream_max3 = s1_stream_max / 2 records per bucket: a third pass costs the same at any width); s1_stream_bits (0) /
  *                     s1_stream_sub0 (-1) force the prefix width / the sub-rounds (tests); s1_stream_fill: keys a
- *                     round's table may end up with before the round is redone in two halves (7/8 of the table); s1_stream_probes (1024)
+ *                     round's table may end up with before the round is redone in two halves (7/8 of the table); s1_stream_probes (1024; the kernel looks at no more than 128 slots per insert)
  *   s1_filter_in_gen (1)  0: a bucket filter (memory plan) is applied to stage 1 by extraction batches + a keep/drop
  *                     split even where the generating first sort pass could leave the dropped buckets out itself
  *   s1_pos_bits (0)   width of the position word of compact stage-1 records (0 = 32); the position bits above it ride

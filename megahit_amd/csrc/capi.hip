@@ -1020,13 +1020,19 @@ uint64_t mhx_stage_pass_bytes(mhx_ctx *c, int stage, uint32_t k, uint32_t min_co
   try {
     (void)min_count;
     if (stage == MHX_STAGE_S1 && c->seqs.n_seqs) {
-      const bool was = c->filter_on;  // (the question is about a filtered pass)
-      const uint64_t exp = c->filter_expected;
+      // (the question is about a filtered pass: asked with the filter fields set, restored whatever happens)
+      struct Restore {
+        mhx_ctx *c;
+        bool on;
+        uint64_t exp;
+        ~Restore() {
+          c->filter_on = on;
+          c->filter_expected = exp;
+        }
+      } restore{c, c->filter_on, c->filter_expected};
       c->filter_on = true;
       c->filter_expected = n_items;
       const bool gen = mhx::s1_filter_in_gen_applies(c, k);
-      c->filter_on = was;
-      c->filter_expected = exp;
       // the generating first pass: two 12-byte record buffers, nothing staged, nothing split; its status words walk ALL item slots
       if (gen) return n_items * 24 + n_items / 2 + (c->seqs.n_bases + 4 * c->seqs.n_seqs) / 3;
       return n_items * (3 * (uint64_t)mhx::s1_stride(k, mhx::s1_compact(c, k, 0)) * 4 + 1);

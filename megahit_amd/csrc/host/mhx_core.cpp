@@ -1330,6 +1330,15 @@ int try_server(int argc, char **argv) {
     }
   }
   if (fd < 0) return -1;
+  {  // the listener has to be this user's: a request hands over argv, the working directory, MHX_* settings and this process's
+     // stderr, and the answer decides whether the pipeline goes on — never to a socket somebody else bound under that name
+    ucred cr{};
+    socklen_t cl = sizeof cr;
+    if (getsockopt(fd, SOL_SOCKET, SO_PEERCRED, &cr, &cl) != 0 || cr.uid != geteuid()) {
+      close(fd);
+      return -1;
+    }
+  }
   bool ok = true;
   const uint32_t n = (uint32_t)(argc - 1);
   ok = write_all(fd, &n, 4);
@@ -1355,6 +1364,35 @@ int try_server(int argc, char **argv) {
 
 }  // namespace
 
+// where the default server of this user, device and set of visible devices listens ("" = nowhere safe: no server by default)
+static std::string default_server_socket() {
+  const char *dir = getenv("XDG_RUNTIME_DIR");
+  const char *dev = getenv("MHX_DEVICE");
+  // one server per user, device AND set of visible devices: "device 0" of a job that a scheduler gave another GPU
+  // (HIP_/ROCR_/CUDA_VISIBLE_DEVICES) is not the device 0 a server started by an earlier job holds
+  std::string vis;
+  for (const char *vn : {"HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "GPU_DEVICE_ORDINAL"})
+    if (const char *v = getenv(vn)) vis += std::string(vn) + "=" + v + ";";
+  char vtag[24] = "";
+  if (!vis.empty()) {
+    uint64_t h = 1469598103934665603ull;  // FNV-1a
+    for (unsigned char ch : vis) h = (h ^ ch) * 1099511628211ull;
+    snprintf(vtag, sizeof vtag, "-v%010llx", (unsigned long long)(h & 0xFFFFFFFFFFull));
+  }
+  const std::string name = "/mhx-core-" + std::to_string((unsigned)geteuid()) + "-dev" + (dev ? dev : "0") + vtag + ".sock";
+  std::string path = std::string(dir && *dir ? dir : "") + name;
+  if (!(dir && *dir) || path.size() >= sizeof(sockaddr_un{}.sun_path)) {
+    // no runtime directory (batch jobs), or an address too long for a socket (~107 characters): a directory of this
+    // user's own under /tmp, mode 0700, checked — in /tmp itself any local user could bind the name first
+    const std::string own = "/tmp/mhx-" + std::to_string((unsigned)geteuid());
+    struct stat sb{};
+    const bool made = mkdir(own.c_str(), 0700) == 0 || errno == EEXIST;
+    if (made && lstat(own.c_str(), &sb) == 0 && S_ISDIR(sb.st_mode) && sb.st_uid == geteuid() && (sb.st_mode & 077) == 0) path = own + name;
+    else path.clear();  // no safe place: every sub-program is a process of its own, as under mhx_core's own name
+  }
+  return !path.empty() && path.size() < sizeof(sockaddr_un{}.sun_path) ? path : std::string();
+}
+
 int main(int argc, char **argv) {
   if (argc < 2) {
     fprintf(stderr, "Usage: %s <sub_program> [sub options]\n    sub-programs: buildlib count read2sdbg seq2sdbg iterate (GPU); others via MHX_REF_CORE\n"
@@ -1362,6 +1400,10 @@ int main(int argc, char **argv) {
     return 1;
   }
   if (!strcmp(argv[1], "--serve") && argc >= 3) return serve(argv[2]);
+  if (!strcmp(argv[1], "--default-socket")) {  // (for scripts that want to stop or watch the default server: tests, bench.py)
+    printf("%s\n", default_server_socket().c_str());
+    return 0;
+  }
   if (!strcmp(argv[1], "--serve-stop") && argc >= 3) {
     setenv("MHX_SERVER", argv[2], 1);
     unsetenv("MHX_SERVER_AUTOSTART");
@@ -1386,13 +1428,11 @@ int main(int argc, char **argv) {
     const char *base = strrchr(argv[0], '/');
     base = base ? base + 1 : argv[0];
     if (!strcmp(base, "megahit_core") && !getenv("MHX_SERVER")) {
-      const char *dir = getenv("XDG_RUNTIME_DIR");
-      const char *dev = getenv("MHX_DEVICE");
-      const std::string name = "/mhx-core-" + std::to_string((unsigned)geteuid()) + "-dev" + (dev ? dev : "0") + ".sock";
-      std::string path = std::string(dir && *dir ? dir : "/tmp") + name;
-      if (path.size() >= sizeof(sockaddr_un{}.sun_path)) path = "/tmp" + name;  // (a socket address holds ~107 characters)
-      setenv("MHX_SERVER", path.c_str(), 1);
-      setenv("MHX_SERVER_AUTOSTART", "1", 0);
+      const std::string path = default_server_socket();
+      if (!path.empty()) {
+        setenv("MHX_SERVER", path.c_str(), 1);
+        setenv("MHX_SERVER_AUTOSTART", "1", 0);
+      }
     }
   }
   const std::string sub = argv[1];

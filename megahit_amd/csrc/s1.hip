@@ -2651,6 +2651,7 @@ uint64_t s1_extract(mhx_ctx *c, uint32_t k, bool compact) {
         c->gen_buf = buf_a;
         c->gen_n = n_records;
         c->gen_slots = n_items;
+        if (n_records == 0) c->gen_first_pass = nullptr;  // (a pass or rank that keeps no record: no sort will come and consume it)
         n_items = n_records;
       } else if (it >= 8) MHX_FAST(8, true, "s1_extract");
       else if (it >= 4) MHX_FAST(4, true, "s1_extract");
@@ -2819,7 +2820,7 @@ struct S1Stage {
     ctr = c->ws("s1_counters", 64).as<unsigned long long>();
     MHX_HIP(hipMemsetAsync(ctr, 0, 64, st));
     // aggregated stage-2 items (k <= 22, m >= 2): at most 2 per solid run, a solid run has >= m records
-    static const bool agg_off = getenv("MHX_S2_PER_OCCURRENCE") != nullptr;
+    const bool agg_off = getenv("MHX_S2_PER_OCCURRENCE") != nullptr;  // (read per call: a resident server answers requests with different environments)
     agg = !agg_off && k <= 22 && m >= 2 && KWv == 2;
     const bool agg_continues = acc && c->agg_valid && c->agg_k == k && c->agg_m == m;
     c->agg_valid = false;

@@ -385,7 +385,12 @@ static uint32_t *radix_sort_onesweep(mhx_ctx *c, uint32_t *a, uint32_t *b, uint6
 template <int S, int NI>
 static uint32_t *radix_sort_impl2(mhx_ctx *c, uint32_t *a, uint32_t *b, uint64_t n, int key_words,
                                   const std::vector<SortPass> &passes) {
-  if (n == 0) return a;
+  if (n == 0) {
+    // nothing to sort: a generated first pass armed for this buffer (a bucket-range pass or a rank that keeps no record)
+    // is spent with it — left armed it would meet the next sort of the same buffer
+    if (c->gen_first_pass && c->gen_buf == (const void *)a) c->gen_first_pass = nullptr;
+    return a;
+  }
   const SortEnv env = sort_env();
   if constexpr (S <= 8 && NI == default_items<S>()) {
     const bool classic = env.classic;
@@ -425,7 +430,12 @@ static uint32_t *radix_sort_impl2(mhx_ctx *c, uint32_t *a, uint32_t *b, uint64_t
   };
   // MHX_SORT_SIDE_DIGITS=1: scatter also writes the next pass's digit per record (1 B) so that the next histogram reads
   // bytes instead of records.  Measured on MI355X: histograms 52 -> 17 ms/step but scatter +33 ms/step: off by default.
-  static const bool use_side = getenv("MHX_SORT_SIDE_DIGITS") != nullptr;
+  // (experiments of rounds 1-2, compiled only into the timing build — libmhx.so reads none of them: make timing)
+#ifdef MHX_TILE_TIMING
+  const bool use_side = getenv("MHX_SORT_SIDE_DIGITS") != nullptr;
+#else
+  constexpr bool use_side = false;
+#endif
   uint8_t *dnext = use_side && passes.size() > 1 ? c->ws("sort_digits", n + 64).as<uint8_t>() : nullptr;
   static const std::string nm_histb = "radix_hist_bytes";
   for (size_t pi = 0; pi < passes.size(); ++pi) {
@@ -433,7 +443,11 @@ static uint32_t *radix_sort_impl2(mhx_ctx *c, uint32_t *a, uint32_t *b, uint64_t
     const DigitSpec ds = spec_of(ps);
     const bool last = pi + 1 == passes.size();
     const DigitSpec ds_next = last ? ds : spec_of(passes[pi + 1]);
-    static const bool dbg_identity = getenv("MHX_DEBUG_IDENTITY_SCATTER") != nullptr;  // WRONG RESULTS: timing experiment
+#ifdef MHX_TILE_TIMING
+    const bool dbg_identity = getenv("MHX_DEBUG_IDENTITY_SCATTER") != nullptr;  // WRONG RESULTS: timing experiment
+#else
+    constexpr bool dbg_identity = false;
+#endif
     const int nbits = dbg_identity ? -(ps.bits + ps.bits2) : ps.bits + ps.bits2;
     if (pi == 0 || !dnext)
       MHX_LAUNCH(c, nm_hist.c_str(), bytes,
@@ -445,7 +459,11 @@ static uint32_t *radix_sort_impl2(mhx_ctx *c, uint32_t *a, uint32_t *b, uint64_t
                                     c->stream, dnext, n, hist, n_chunks));
     exclusive_scan_u32_u64(c, hist, offs, n_chunks * 256, nullptr);
     uint8_t *dn = last ? nullptr : dnext;
-    static const unsigned lds_pad = getenv("MHX_SORT_LDS_PAD") ? (unsigned)atoi(getenv("MHX_SORT_LDS_PAD")) : 0u;  // occupancy experiment
+#ifdef MHX_TILE_TIMING
+    const unsigned lds_pad = getenv("MHX_SORT_LDS_PAD") ? (unsigned)atoi(getenv("MHX_SORT_LDS_PAD")) : 0u;  // occupancy experiment
+#else
+    constexpr unsigned lds_pad = 0u;
+#endif
     MHX_LAUNCH(c, nm_scat.c_str(), 2 * bytes + (dn ? (double)n : 0.0),
                hipLaunchKernelGGL((k_radix_scatter<S, NI>), dim3((unsigned)n_chunks), dim3(kSortThreads), lds_pad, c->stream, a, b, n, ds,
                                   nbits, offs, n_chunks, (const uint8_t *)nullptr, ds_next, dn));

@@ -78,7 +78,8 @@ def test_under_the_references_name_the_server_is_the_default(tmp_path, monkeypat
     monkeypatch.delenv("MHX_SERVER", raising=False)
     monkeypatch.setenv("XDG_RUNTIME_DIR", str(tmp_path))
     monkeypatch.setenv("MHX_SERVE_IDLE_S", "60")
-    sock = str(tmp_path / ("mhx-core-%d-dev0.sock" % os.geteuid()))
+    sock = subprocess.run([gu.MHX_CORE, "--default-socket"], stdout=subprocess.PIPE, text=True, check=True).stdout.strip()
+    assert os.path.dirname(sock) == str(tmp_path)
     ents = [e for e in gu.cases() if e["case"]["k"] == 21 and e["case"].get("lib") == "hc" and not e["case"].get("input")][:3]
     try:
         for i, ent in enumerate(ents + ents[:1]):

@@ -104,6 +104,12 @@ def test_autostart(tmp_path):
     assert "leaves after 2 requests" in open(os.path.join(d, "auto.log")).read()
 
 
+def default_socket(env):
+    """where megahit_core's default server listens under this environment (mhx_core --default-socket: one per user, device and
+    set of visible devices, in $XDG_RUNTIME_DIR or a 0700 directory of the user's own under /tmp)"""
+    return subprocess.run([gu.MHX_CORE, "--default-socket"], env=env, stdout=subprocess.PIPE, text=True, check=True).stdout.strip()
+
+
 def test_the_references_name_starts_a_server_of_its_own_accord(tmp_path):
     """megahit_core -> mhx_core: no MHX_SERVER in the environment, and the sub-program still runs in a resident server — started by
     this very call, listening on $XDG_RUNTIME_DIR/mhx-core-<uid>-dev0.sock, readable and writable by its owner only; the same
@@ -115,9 +121,10 @@ def test_the_references_name_starts_a_server_of_its_own_accord(tmp_path):
     lib = write_inputs(d)
     rt = os.path.join(d, "rt")
     os.mkdir(rt)
-    sock = os.path.join(rt, "mhx-core-%d-dev0.sock" % os.geteuid())
     env = {k: v for k, v in os.environ.items() if not k.startswith("MHX_SERVER")}
     env.update(XDG_RUNTIME_DIR=rt, MHX_BUILDLIB_HOST="1", MHX_SERVE_IDLE_S="20")
+    sock = default_socket(env)
+    assert os.path.dirname(sock) == rt and os.path.basename(sock).startswith("mhx-core-%d-dev0" % os.geteuid())
 
     def call(prog, out, **extra):
         return subprocess.run([prog, "buildlib", lib, os.path.join(d, out)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
@@ -138,3 +145,18 @@ def test_the_references_name_starts_a_server_of_its_own_accord(tmp_path):
     finally:
         if os.path.exists(sock):
             subprocess.run([gu.MHX_CORE, "--serve-stop", sock], timeout=30)
+
+
+def test_default_socket_without_a_runtime_directory_sits_in_a_directory_of_the_users_own():
+    """no $XDG_RUNTIME_DIR (batch jobs): /tmp/mhx-<uid>/ (0700, owned by the caller) instead of a name in /tmp itself, where any local
+    user could bind first; jobs with different visible devices get different servers"""
+    import stat
+    env = {k: v for k, v in os.environ.items() if k != "XDG_RUNTIME_DIR" and not k.endswith("VISIBLE_DEVICES")}
+    sock = default_socket(env)
+    own = "/tmp/mhx-%d" % os.geteuid()
+    assert os.path.dirname(sock) == own and os.path.basename(sock) == "mhx-core-%d-dev0.sock" % os.geteuid()
+    st = os.lstat(own)
+    assert stat.S_ISDIR(st.st_mode) and st.st_uid == os.geteuid() and stat.S_IMODE(st.st_mode) & 0o077 == 0
+    a = default_socket(dict(env, HIP_VISIBLE_DEVICES="3"))
+    b = default_socket(dict(env, HIP_VISIBLE_DEVICES="4"))
+    assert len({sock, a, b}) == 3 and default_socket(dict(env, HIP_VISIBLE_DEVICES="3")) == a
