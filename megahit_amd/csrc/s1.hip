@@ -388,6 +388,134 @@ struct S1GenBlockedT {
 };
 using S1GenBlocked = S1GenBlockedT<false>;
 
+// The blocked generator with the window arithmetic done ONCE per run of a thread's consecutive items (round 5; k <= 23).  A run
+// of up to 8 consecutive (k-1)-mers of one read, with the head base in front and the tail base behind each, spans
+// 8 + k + 1 <= 32 bases: one 64-bit window W of the store (two funnel shifts) holds them all, and the reverse complement
+// of a sub-window is a sub-window of the reverse complement — R = rc(W) is formed once (one 64-bit bit-reverse), and the item
+// at offset d inside the run is
+//     forward  (W << (2 d + 4)) & mask        reverse complement  (R << 2 (30 - (k-1) - d)) & mask
+// two shifts instead of two funnel shifts, three selects and a bit-reverse per item (S1GenBlockedT).  A thread's items cross at
+// most one read boundary (>= 8 slots per read): a second pair (W, R) for the start of the next read.  Three words per window
+// instead of four.  Same records, bit for bit.
+__device__ __forceinline__ void s1_item_from_parts(uint64_t f, uint64_t rc, unsigned head_b, unsigned tail_b, uint32_t q, int forced, uint32_t L, int k,
+                                                   uint64_t a, uint64_t pos_base, uint32_t pos_bits, uint32_t (&out)[3]) {
+  const unsigned head = q >= 1 ? head_b : kSentinel;
+  const unsigned tail = q + k - 1 < L ? tail_b : kSentinel;
+  int strand;
+  if (forced >= 0) strand = forced;
+  else strand = f > rc ? 1 : (f < rc ? 0 : (head <= 3 - tail ? 0 : 1));
+  const uint64_t key = strand ? (rc | (comp_or_sentinel(tail) << 3) | comp_or_sentinel(head)) : (f | (head << 3) | tail);
+  const uint64_t p = pos_base + a;
+  out[0] = (uint32_t)(key >> 32);
+  out[1] = (uint32_t)key | s1_pos_tag(p, pos_bits);
+  out[2] = s1_pos_word(p, pos_bits);
+}
+constexpr int kS1RollMaxK = 23;
+template <bool FILTER>
+struct S1GenRollT {
+  const uint32_t *seq;
+  uint32_t L, per;
+  int k;
+  uint64_t pos_base;
+  uint32_t pos_bits;
+  uint32_t tile_q, tile_r;  // items of a tile (256 NI) divided by the slots per read: quotient and remainder
+  const uint32_t *keep;
+  static constexpr bool kMayDrop = FILTER;
+  __device__ __forceinline__ bool is_record(const Rec<3> &r) const { return !FILTER || (r.w[1] & 63u) != 63u; }
+  template <int NI>
+  __device__ __forceinline__ uint64_t index(uint64_t tile_base, int w, int lane, int j) const {
+    return tile_base + (uint64_t)((w * kWave + lane) * NI + j);
+  }
+  template <int NI, int UT>
+  __device__ __forceinline__ void get_unit(uint64_t unit_base, int w, int lane, uint64_t n, Rec<3> (&rec)[UT][NI]) const {
+    static_assert(NI <= 8, "a run of NI items and their flanks inside one 32-base window");
+    constexpr uint32_t kTileItems = kSortThreads * NI;
+    const uint64_t g00 = unit_base + (uint64_t)((w * kWave + lane) * NI);
+    const uint32_t qlast = L - k + 1, jf = L - k + 2;
+    const int km1 = k - 1;
+    const uint64_t kmask = ~0ull << (64 - 2 * km1);
+    uint32_t jt[UT];   // slot of the thread's first item in tile t
+    uint64_t bt[UT];   // first base of that item's read
+    {
+      const uint64_t r = g00 / per;
+      jt[0] = (uint32_t)(g00 - r * per);
+      bt[0] = r * L;
+#pragma unroll
+      for (int t = 1; t < UT; ++t) {
+        uint32_t jn = jt[t - 1] + tile_r;
+        uint64_t bn = bt[t - 1] + (uint64_t)tile_q * L;
+        if (jn >= per) {
+          jn -= per;
+          bn += L;
+        }
+        jt[t] = jn;
+        bt[t] = bn;
+      }
+#pragma unroll
+      for (int t = 0; t < UT; ++t)
+        if (g00 + (uint64_t)t * kTileItems >= n) {  // nothing of this tile is this thread's: loads from the start of the store, nothing kept
+          jt[t] = 0;
+          bt[t] = 0;
+        }
+    }
+    uint32_t c[UT][3], nx[UT][3];
+    uint32_t q0t[UT];
+#pragma unroll
+    for (int t = 0; t < UT; ++t) {
+      q0t[t] = min(jt[t] > 0 ? jt[t] - 1 : 0u, qlast);
+      const uint64_t a0 = bt[t] + q0t[t], b0 = a0 >= 2 ? a0 - 2 : 0;
+      const uint64_t wcur = b0 >> 4, wnext = (bt[t] + L - 2) >> 4;
+#pragma unroll
+      for (int x = 0; x < 3; ++x) {
+        c[t][x] = seq[wcur + x];
+        nx[t][x] = seq[wnext + x];  // (the store is padded: also behind the last read)
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < UT; ++t) {
+      const uint64_t g0 = g00 + (uint64_t)t * kTileItems;
+      uint32_t j = jt[t];
+      uint64_t base = bt[t];
+      // the window of the run that starts at the thread's first item: from two bases in front of its (k-1)-mer (the store's first
+      // two bases: the window at base 0 shifted down, s1_fast_item) ...
+      const uint64_t a0 = base + q0t[t], b0 = a0 >= 2 ? a0 - 2 : 0;
+      const unsigned sh0 = (unsigned)(b0 & 15) * 2, down0 = a0 >= 2 ? 0u : (unsigned)(2 - a0) * 2;
+      uint64_t W = (((uint64_t)funnel_l(c[t][0], c[t][1], sh0) << 32) | funnel_l(c[t][1], c[t][2], sh0)) >> down0;
+      uint64_t R = rc64(W, 32);
+      uint32_t qrun = q0t[t];
+      // ... and of the run at the start of the next read (slot 0: offset 0)
+      const unsigned shn = (unsigned)((base + L - 2) & 15) * 2;
+      const uint64_t Wn = ((uint64_t)funnel_l(nx[t][0], nx[t][1], shn) << 32) | funnel_l(nx[t][1], nx[t][2], shn);
+      const uint64_t Rn = rc64(Wn, 32);
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const uint32_t q = min(j > 0 ? j - 1 : 0u, qlast);
+        const int forced = j < 2 ? (int)j : (j >= jf ? (int)(j - jf) : -1);
+        const unsigned d2 = (q - qrun) * 2;  // offset inside the run's window, in bits
+        const uint64_t f = (W << (d2 + 4)) & kmask;
+        const uint64_t rc = (R << ((unsigned)(2 * (30 - km1)) - d2)) & kmask;
+        const unsigned head_b = (unsigned)(W >> (60 - d2)) & 3u, tail_b = (unsigned)(W >> ((unsigned)(58 - 2 * km1) - d2)) & 3u;
+        uint32_t out[3];
+        s1_item_from_parts(f, rc, head_b, tail_b, q, forced, L, k, base + q, pos_base, pos_bits, out);
+        if constexpr (FILTER)
+          if (!s1_bucket_kept(keep, out[0])) out[1] = kS1Dropped;
+        if (g0 + (uint64_t)i < n) {
+          rec[t][i].w[0] = out[0];
+          rec[t][i].w[1] = out[1];
+          rec[t][i].w[2] = out[2];
+        }
+        if (++j == per) {
+          j = 0;
+          base += L;
+          W = Wn;
+          R = Rn;
+          qrun = 0;
+        }
+      }
+    }
+  }
+};
+
 constexpr int kFastPasses = 4;
 // The digit histograms of the coming sort passes without making the records (the pre-pass of the generating first pass):
 // every thread takes IT CONSECUTIVE items — one division per trip, the three window words are reloaded only when the
@@ -576,12 +704,95 @@ __global__ __launch_bounds__(256) void k_s1_digit_hist_plain(const uint32_t *__r
   }
 }
 
+// The same histograms with the window arithmetic of S1GenRollT: one window and one reverse complement per run of a thread's IT
+// consecutive items (and one pair for the start of the next read), two shifts per item (k <= 23, >= IT slots per read).
+template <int IT, int NP>
+__global__ __launch_bounds__(256) void k_s1_digit_hist_roll(const uint32_t *__restrict__ seq, uint32_t L, uint32_t per, uint64_t n_items, int k,
+                                                            HiDigits hd, unsigned long long *__restrict__ ghist, uint32_t step_q, uint32_t step_r,
+                                                            const uint32_t *__restrict__ keep) {
+  static_assert(IT <= 8, "a run of IT items and their flanks inside one 32-base window");
+  constexpr int B = 256 * IT;
+  __shared__ uint32_t h[kFastPasses][4][256];
+  for (int i = threadIdx.x; i < kFastPasses * 4 * 256; i += 256) (&h[0][0][0])[i] = 0;
+  __syncthreads();
+  const int wv = threadIdx.x >> 6;
+  const int km1 = k - 1;
+  const uint64_t kmask = ~0ull << (64 - 2 * km1);
+  const uint32_t qlast = L - k + 1, jf = L - k + 2;
+  const unsigned rsh = (unsigned)(2 * (30 - km1));
+  auto count = [&](uint32_t hi) {
+    if (keep && !s1_bucket_kept(keep, hi)) return;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) atomicAdd(&h[p][wv][(hi >> hd.sh[p]) & hd.mk[p]], 1u);
+  };
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+    for (uint32_t j = 0; j < 3 && j < n_items; ++j) {  // (the items whose window would start before the store)
+      uint32_t out[3];
+      s1_make_item<2, 3, true>(seq, 0, L, k, j, 0, 32u, out);
+      count(out[0]);
+    }
+  const uint64_t n_blocks = (n_items + B - 1) / B;
+  uint64_t q0 = ((uint32_t)blockIdx.x * (uint32_t)B) / per;
+  uint32_t rem0 = ((uint32_t)blockIdx.x * (uint32_t)B) % per;
+  for (uint64_t blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
+    const uint64_t g0 = blk * B + (uint64_t)threadIdx.x * IT;
+    const uint32_t t = rem0 + (uint32_t)threadIdx.x * IT, dq = t / per;
+    uint32_t j = t - dq * per;
+    uint64_t base = (q0 + dq) * L;  // first base of the read
+    if (g0 >= n_items) {            // (nothing of this block is this thread's: loads from the start of the store, nothing counted)
+      j = 0;
+      base = 0;
+    }
+    uint32_t qrun = min(j > 0 ? j - 1 : 0u, qlast);
+    const uint64_t a0 = base + qrun, b0 = a0 >= 2 ? a0 - 2 : 0;
+    const uint64_t wcur = b0 >> 4, wnext = (base + L - 2) >> 4;
+    const uint32_t c0 = seq[wcur], c1 = seq[wcur + 1], c2 = seq[wcur + 2];
+    const uint32_t n0 = seq[wnext], n1 = seq[wnext + 1], n2 = seq[wnext + 2];
+    const unsigned sh0 = (unsigned)(b0 & 15) * 2, down0 = a0 >= 2 ? 0u : (unsigned)(2 - a0) * 2;
+    uint64_t W = (((uint64_t)funnel_l(c0, c1, sh0) << 32) | funnel_l(c1, c2, sh0)) >> down0;
+    uint64_t R = rc64(W, 32);
+    const unsigned shn = (unsigned)((base + L - 2) & 15) * 2;
+    const uint64_t Wn = ((uint64_t)funnel_l(n0, n1, shn) << 32) | funnel_l(n1, n2, shn);
+    const uint64_t Rn = rc64(Wn, 32);
+#pragma unroll
+    for (int u = 0; u < IT; ++u) {
+      const uint32_t q = min(j > 0 ? j - 1 : 0u, qlast);
+      const bool forced = j < 2 || j >= jf;
+      const uint32_t fstrand = j < 2 ? j : j - jf;
+      const unsigned d2 = (q - qrun) * 2;
+      const uint64_t f = (W << (d2 + 4)) & kmask;
+      const uint64_t rc = (R << (rsh - d2)) & kmask;
+      const bool use_rc = forced ? fstrand == 1 : f > rc;  // (f == rc: the same first word either way)
+      if (g0 + u < n_items && base + q >= 2) count((uint32_t)((use_rc ? rc : f) >> 32));
+      if (++j == per) {
+        j = 0;
+        base += L;
+        W = Wn;
+        R = Rn;
+        qrun = 0;
+      }
+    }
+    q0 += step_q;
+    rem0 += step_r;
+    if (rem0 >= per) {
+      rem0 -= per;
+      ++q0;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    const uint32_t v = h[p][0][threadIdx.x] + h[p][1][threadIdx.x] + h[p][2][threadIdx.x] + h[p][3][threadIdx.x];
+    if (v) atomicAdd(&ghist[p * 256 + threadIdx.x], (unsigned long long)v);
+  }
+}
+
 // The lv1-bucket histogram of stage 1 (the reference's Lv0CalcBucketSize, read_to_sdbg_s1.cpp:145-206) for the fast shape —
 // what a memory plan asks for before it splits a 100 M-read job into bucket ranges.  The same window arithmetic as the
 // digit-histogram pre-pass; the 65 536 counters do not fit the LDS as 32-bit words, so a launch counts one HALF of the
 // bucket space (128 KB, one 1024-thread workgroup per CU) and the host launches twice.  (The general path takes the
 // histogram from extracted items with one global atomic per item: seconds at 10^10 items.)
-template <int IT>
+template <int IT, bool ROLL = false>  // ROLL: the window arithmetic of S1GenRollT (k <= 23, >= IT slots per read)
 __global__ __launch_bounds__(1024) void k_s1_bucket_hist_fast(const uint32_t *__restrict__ seq, uint32_t L, uint32_t per, uint64_t n_items, int k,
                                                               unsigned long long *__restrict__ ghist, uint32_t step_q, uint32_t step_r, uint32_t half) {
   constexpr int NT = 1024, B = NT * IT, NB = MHX_NUM_BUCKETS / 2;
@@ -613,6 +824,39 @@ __global__ __launch_bounds__(1024) void k_s1_bucket_hist_fast(const uint32_t *__
       j = 0;
       base = 0;
     }
+    if constexpr (ROLL) {
+      static_assert(IT <= 8, "a run of IT items and their flanks inside one 32-base window");
+      uint32_t qrun = min(j > 0 ? j - 1 : 0u, qlast);
+      const uint64_t a0 = base + qrun, b0 = a0 >= 2 ? a0 - 2 : 0;
+      const uint64_t wc0 = b0 >> 4, wnext = (base + L - 2) >> 4;
+      const uint32_t c0 = seq[wc0], c1 = seq[wc0 + 1], c2 = seq[wc0 + 2];
+      const uint32_t n0 = seq[wnext], n1 = seq[wnext + 1], n2 = seq[wnext + 2];
+      const unsigned sh0 = (unsigned)(b0 & 15) * 2, down0 = a0 >= 2 ? 0u : (unsigned)(2 - a0) * 2;
+      uint64_t W = (((uint64_t)funnel_l(c0, c1, sh0) << 32) | funnel_l(c1, c2, sh0)) >> down0;
+      uint64_t R = rc64(W, 32);
+      const unsigned shn = (unsigned)((base + L - 2) & 15) * 2;
+      const uint64_t Wn = ((uint64_t)funnel_l(n0, n1, shn) << 32) | funnel_l(n1, n2, shn);
+      const uint64_t Rn = rc64(Wn, 32);
+      const unsigned rsh = (unsigned)(2 * (30 - km1));
+#pragma unroll
+      for (int u = 0; u < IT; ++u) {
+        const uint32_t q = min(j > 0 ? j - 1 : 0u, qlast);
+        const bool forced = j < 2 || j >= jf;
+        const uint32_t fstrand = j < 2 ? j : j - jf;
+        const unsigned d2 = (q - qrun) * 2;
+        const uint64_t f = (W << (d2 + 4)) & kmask;
+        const uint64_t rc = (R << (rsh - d2)) & kmask;
+        const bool use_rc = forced ? fstrand == 1 : f > rc;
+        if (g0 + u < n_items && base + q >= 2) count((uint32_t)((use_rc ? rc : f) >> 32));
+        if (++j == per) {
+          j = 0;
+          base += L;
+          W = Wn;
+          R = Rn;
+          qrun = 0;
+        }
+      }
+    } else {
     uint64_t wcur = ~0ull;
     uint32_t x0 = 0, x1 = 0, x2 = 0;
 #pragma unroll
@@ -639,6 +883,7 @@ __global__ __launch_bounds__(1024) void k_s1_bucket_hist_fast(const uint32_t *__
         base += L;
       }
     }
+    }
     q0 += step_q;
     rem0 += step_r;
     if (rem0 >= per) {
@@ -660,10 +905,17 @@ bool s1_bucket_histogram_fast(mhx_ctx *c, uint32_t k, unsigned long long *hist) 
   const uint64_t cus = c->n_cus > 0 ? (uint64_t)c->n_cus : 256;
   const unsigned grid = (unsigned)std::min<uint64_t>(div_ceil(n_items, 1024 * IT), cus);
   const uint64_t stride_items = (uint64_t)grid * 1024 * IT;
-  for (uint32_t half = 0; half < 2; ++half)
-    MHX_LAUNCH(c, "s1_bucket_hist", (double)s.n_bases / 4,
-               hipLaunchKernelGGL((k_s1_bucket_hist_fast<IT>), dim3(grid), dim3(1024), 0, c->stream, s.words.as<uint32_t>(), s.fixed_len, per, n_items, (int)k,
-                                  hist, (uint32_t)(stride_items / per), (uint32_t)(stride_items % per), half));
+  const bool roll = per >= IT && (int)k <= kS1RollMaxK && c->opt("s1_digit_hist_roll", 1) != 0;
+  for (uint32_t half = 0; half < 2; ++half) {
+    if (roll)
+      MHX_LAUNCH(c, "s1_bucket_hist", (double)s.n_bases / 4,
+                 hipLaunchKernelGGL((k_s1_bucket_hist_fast<IT, true>), dim3(grid), dim3(1024), 0, c->stream, s.words.as<uint32_t>(), s.fixed_len, per, n_items,
+                                    (int)k, hist, (uint32_t)(stride_items / per), (uint32_t)(stride_items % per), half));
+    else
+      MHX_LAUNCH(c, "s1_bucket_hist", (double)s.n_bases / 4,
+                 hipLaunchKernelGGL((k_s1_bucket_hist_fast<IT>), dim3(grid), dim3(1024), 0, c->stream, s.words.as<uint32_t>(), s.fixed_len, per, n_items,
+                                    (int)k, hist, (uint32_t)(stride_items / per), (uint32_t)(stride_items % per), half));
+  }
   return true;
 }
 
@@ -2591,7 +2843,18 @@ uint64_t s1_extract(mhx_ctx *c, uint32_t k, bool compact) {
                                 n_items, (int)k, hd, pre_hist, (uint32_t)(stride_items / per), (uint32_t)(stride_items % per), keep))
 #define MHX_PLAIN(NPV) MHX_PLAIN2(NPV, false)
           // s1_digit_hist_preload: window words requested up front (needs at least 8 slots per read)
-          if (plain && specs.n == 2 && per >= 8 && c->opt("s1_digit_hist_preload", 0) != 0) MHX_PLAIN2(2, true);
+#define MHX_ROLL(NPV)                                                                                                                       \
+  MHX_LAUNCH(c, "s1_digit_hist", (double)s.n_bases / 4,                                                                                      \
+             hipLaunchKernelGGL((k_s1_digit_hist_roll<ITH, NPV>), dim3(fgrid), dim3(256), 0, st, s.words.as<uint32_t>(), s.fixed_len, per,  \
+                                n_items, (int)k, hd, pre_hist, (uint32_t)(stride_items / per), (uint32_t)(stride_items % per), keep))
+          // s1_digit_hist_roll: one window + one reverse complement per run of a thread's eight items (k <= 23, >= 8 slots per read)
+          const bool hroll = plain && per >= 8 && (int)k <= kS1RollMaxK && c->opt("s1_digit_hist_roll", 1) != 0;
+          if (hroll && specs.n == 1) MHX_ROLL(1);
+          else if (hroll && specs.n == 2) MHX_ROLL(2);
+          else if (hroll && specs.n == 3) MHX_ROLL(3);
+          else if (hroll && specs.n == 4) MHX_ROLL(4);
+#undef MHX_ROLL
+          else if (plain && specs.n == 2 && per >= 8 && c->opt("s1_digit_hist_preload", 0) != 0) MHX_PLAIN2(2, true);
           else if (plain && specs.n == 1) MHX_PLAIN(1);
           else if (plain && specs.n == 2) MHX_PLAIN(2);
           else if (plain && specs.n == 3) MHX_PLAIN(3);
@@ -2629,7 +2892,13 @@ uint64_t s1_extract(mhx_ctx *c, uint32_t k, bool compact) {
                                       (uint32_t)(kSortThreads * 8) % per, nullptr};
         const S1GenBlockedT<true> gbf{s.words.as<uint32_t>(), s.fixed_len, per, (int)k, pos_base, pos_bits, (uint32_t)(kSortThreads * 8) / per,
                                       (uint32_t)(kSortThreads * 8) % per, keep};
-        c->gen_first_pass = [g, gf, gb, gbf, any_order, blocked, filter_in_gen](const OnesweepLaunch &l) {
+        // s1_gen_roll: the blocked generator with one window + one reverse complement per run of a thread's items (k <= 23)
+        const bool roll = blocked && (int)k <= kS1RollMaxK && c->opt("s1_gen_roll", 1) != 0;
+        const S1GenRollT<false> gr{s.words.as<uint32_t>(), s.fixed_len, per, (int)k, pos_base, pos_bits, (uint32_t)(kSortThreads * 8) / per,
+                                   (uint32_t)(kSortThreads * 8) % per, nullptr};
+        const S1GenRollT<true> grf{s.words.as<uint32_t>(), s.fixed_len, per, (int)k, pos_base, pos_bits, (uint32_t)(kSortThreads * 8) / per,
+                                   (uint32_t)(kSortThreads * 8) % per, keep};
+        c->gen_first_pass = [g, gf, gb, gbf, gr, grf, roll, any_order, blocked, filter_in_gen](const OnesweepLaunch &l) {
 #define MHX_GEN(KERNEL, SRCT, RANKV, SRCV)                                                                                              \
   hipLaunchKernelGGL((KERNEL<3, 8, 3, SRCT, RANKV>), dim3(l.grid), dim3(kSortThreads), 0, l.stream, SRCV, l.out, l.n, l.ds, l.nbits, l.bin_start, \
                      l.status, l.ticket, l.err, l.tag, l.xcd_units)
@@ -2638,9 +2907,11 @@ uint64_t s1_extract(mhx_ctx *c, uint32_t k, bool compact) {
                      l.bin_start, l.status, l.ticket, l.err, l.tag, l.xcd_units)
           if (filter_in_gen) {  // (s1_filter_in_gen_applies vouched for unit-wide runs, digits in the first key word, any order)
             if (!(l.unit_runs && l.wi == 0 && any_order)) throw Error("s1: the filtering generator needs the unit-wide pass on a first-word digit");
-            if (blocked) MHX_GEN_U(S1GenBlockedT<true>, 1, gbf);
+            if (roll) MHX_GEN_U(S1GenRollT<true>, 1, grf);
+            else if (blocked) MHX_GEN_U(S1GenBlockedT<true>, 1, gbf);
             else MHX_GEN_U(S1GenT<true>, 1, gf);
-          } else if (l.unit_runs && l.wi == 0 && blocked) MHX_GEN_U(S1GenBlockedT<false>, 1, gb);
+          } else if (l.unit_runs && l.wi == 0 && roll) MHX_GEN_U(S1GenRollT<false>, 1, gr);
+          else if (l.unit_runs && l.wi == 0 && blocked) MHX_GEN_U(S1GenBlockedT<false>, 1, gb);
           else if (l.unit_runs && l.wi == 0 && any_order) MHX_GEN_U(S1GenT<false>, 1, g);  // (the digits of this plan lie in the first key word)
           else if (l.unit_runs && l.wi == 0) MHX_GEN_U(S1GenT<false>, 0, g);
           else if (any_order) MHX_GEN(k_radix_onesweep, S1GenT<false>, true, g);

@@ -500,6 +500,333 @@ struct SdbgOp {
   }
 };
 
+// ---------------------------------------------------------------------------------------------------------------
+// The same Lv2Postprocess + SdbgWriter for 8-byte records (S = 2: the aggregated stage-2 items of k <= 22, the per-occurrence
+// items of stage 2 up to k = 29, seq2sdbg at small k) without the generic tile machinery.  k_tile_groups builds run and
+// group lists of a tile in LDS behind a dozen barriers and serial prefix loops — ~50 us per 2048-record tile whatever the
+// operator does with them (sdbg_count + sdbg_emit: 4.3 ms for 0.94 GB of records, 0.05-0.08 of the HBM roofline).  Here
+// a record is one 64-bit value, "same group" and "same run" are one xor + and each, and every RUN HEAD does its run's work
+// alone: it walks its group in the staged window (tile + a halo either side; groups hold a handful of records), ORs the
+// (a, b) bits of what it meets, counts / sums its own run on the way, decides, and the three output counters become ballots.
+// A run belongs to the tile its head lies in; outputs are ordered by head position, as in k_tile_groups.
+// Groups or runs that reach beyond the window (low-complexity sequence: 10^5 identical '$' items of poly-A reads) take
+// the way through memory: the runs of a group are enumerated by galloping searches (records are sorted, so "same run as
+// record p" holds on a stretch around p) — O(runs x log length) loads instead of a walk —, and a long run's multiplicity
+// sum is formed by the whole wavefront, 64 records per step, until it reaches the cap.
+// ---------------------------------------------------------------------------------------------------------------
+struct SdbgFastP {
+  unsigned long long gmask, rmask;  // bits that tell groups apart / runs apart (rmask includes gmask), record = w0 << 32 | w1
+  int fsh, ash, bsh;                // "full" flag, k-th char, W char as shifts of the 64-bit record
+  int is_seq, wpt, k, ref_kw;
+  int halo;                         // records staged either side of the tile (<= kSdbgFastHalo; tests shrink it)
+};
+constexpr int kSdbgFastT = 2048, kSdbgFastPer = kSdbgFastT / 256, kSdbgFastHalo = 128;
+
+__device__ __forceinline__ unsigned long long sdbg_ld64(const uint2 *__restrict__ items, long long i) {
+  const uint2 r = items[i];
+  return ((unsigned long long)r.x << 32) | r.y;
+}
+__device__ __forceinline__ uint32_t sdbg_pair_bit(unsigned long long v, const SdbgFastP &P, int &a, int &b) {
+  a = ((v >> P.fsh) & 1ull) ? (int)((v >> P.ash) & 3ull) : 4;
+  b = (int)((v >> P.bsh) & 7ull);
+  return 1u << ((a == 4 ? 0 : a + 1) * 5 + b);
+}
+// last index + 1 of the stretch of records equal to `u` under `mask` that holds record p0
+__device__ __noinline__ long long sdbg_gallop_fwd(const uint2 *__restrict__ items, long long n, long long p0, unsigned long long u, unsigned long long mask) {
+  long long good = p0, bad, step = 1;
+  for (;;) {
+    const long long t = good + step;
+    if (t >= n) {
+      bad = n;
+      break;
+    }
+    if (((sdbg_ld64(items, t) ^ u) & mask) == 0) {
+      good = t;
+      step <<= 1;
+    } else {
+      bad = t;
+      break;
+    }
+  }
+  while (bad - good > 1) {
+    const long long mid = good + (bad - good) / 2;
+    if (((sdbg_ld64(items, mid) ^ u) & mask) == 0) good = mid;
+    else bad = mid;
+  }
+  return bad;
+}
+// first index of that stretch
+__device__ __noinline__ long long sdbg_gallop_bwd(const uint2 *__restrict__ items, long long p0, unsigned long long u, unsigned long long mask) {
+  long long good = p0, bad, step = 1;
+  for (;;) {
+    const long long t = good - step;
+    if (t < 0) {
+      bad = -1;
+      break;
+    }
+    if (((sdbg_ld64(items, t) ^ u) & mask) == 0) {
+      good = t;
+      step <<= 1;
+    } else {
+      bad = t;
+      break;
+    }
+  }
+  while (good - bad > 1) {
+    const long long mid = bad + (good - bad) / 2;
+    if (((sdbg_ld64(items, mid) ^ u) & mask) == 0) good = mid;
+    else bad = mid;
+  }
+  return good;
+}
+// the (a, b) pairs of the group of the run head at `head`, and where its run ends — from memory, run by run
+__device__ __noinline__ void sdbg_group_far(const uint2 *__restrict__ items, long long n, long long head, unsigned long long v, const SdbgFastP &P,
+                                            uint32_t &M, long long &run_end) {
+  int a, b;
+  M = sdbg_pair_bit(v, P, a, b);
+  long long p = head;
+  while (p > 0) {
+    const unsigned long long u = sdbg_ld64(items, p - 1);
+    if ((u ^ v) & P.gmask) break;
+    M |= sdbg_pair_bit(u, P, a, b);
+    p = sdbg_gallop_bwd(items, p - 1, u, P.rmask);
+  }
+  long long e = sdbg_gallop_fwd(items, n, head, v, P.rmask);
+  run_end = e;
+  while (e < n) {
+    const unsigned long long u = sdbg_ld64(items, e);
+    if ((u ^ v) & P.gmask) break;
+    M |= sdbg_pair_bit(u, P, a, b);
+    e = sdbg_gallop_fwd(items, n, e, u, P.rmask);
+  }
+}
+// SdbgOp::decide on plain values (read_to_sdbg_s2.cpp:568-589)
+__device__ __forceinline__ bool sdbg_decide(uint32_t M, int a, int b, int &w, int &last, int &is_dollar) {
+  const int a5 = a == 4 ? 0 : a + 1;
+  const uint32_t col = (1u << b) * 0x108420u;  // bits (a'+1)*5 + b for a' = 0..3
+  is_dollar = 0;
+  if (a == 4) {
+    if (M & col) return false;
+    is_dollar = 1;
+  }
+  if (b == 4) {
+    if ((M >> (a5 * 5)) & 0xFu) return false;
+  }
+  if (b == 4) w = 0;
+  else {
+    const uint32_t earlier = a == 4 ? 0u : (M & col & ((1u << (a5 * 5)) - 1u));
+    w = earlier ? b + 5 : b + 1;
+  }
+  if (a == 4) last = 0;
+  else if (b == 4) last = 1;
+  else last = (((M >> (a5 * 5)) & 0xFu) >> (b + 1)) == 0;
+  return true;
+}
+
+template <bool EMIT>
+__global__ __launch_bounds__(256) void k_sdbg_fast(const uint2 *__restrict__ items, long long n, SdbgFastP P, uint64_t *__restrict__ tile_tot,
+                                                   const uint64_t *__restrict__ tile_base, uint64_t n_tiles, uint16_t *__restrict__ out16,
+                                                   unsigned long long *__restrict__ w_count, unsigned long long *__restrict__ bstart) {
+  constexpr int T = kSdbgFastT, PER = kSdbgFastPer, H = kSdbgFastHalo, NW = 256 / kWave;
+  __shared__ unsigned long long win[T + 2 * H];  // win[H + i] = record base + i
+  // what a run head found out, per record of the tile: flags | W << 4 | multiplicity << 12 (0 = not a run head).  Kept in LDS,
+  // not in registers: the loops over a thread's records stay rolled and the kernel small (eight waves per SIMD instead of three
+  // — every phase here is a chain of dependent LDS reads)
+  __shared__ uint32_t res[T];
+  __shared__ uint32_t cell[3][PER * NW + 1];
+  __shared__ uint32_t wc[10];
+  constexpr uint32_t kKept = 1u, kTip = 2u, kLast = 8u, kHead = 0x100u, kBucketFirst = 0x200u, kPending = 0x400u, kFar = 0x800u;
+  const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = tid / kWave;
+  const uint64_t lanemask_lt = (1ull << lane) - 1;
+  const long long base = (long long)blockIdx.x * T;
+  // the staged window, as indices into win[]: [w_lo, w_hi); at_start / at_end: the window ends where the array ends
+  const int halo = P.halo;
+  const int w_lo = base >= halo ? H - halo : H - (int)base;
+  const long long rest = n - base;
+  const int w_hi = rest >= (long long)(T + halo) ? H + T + halo : H + (int)rest;
+  const bool at_start = base - (H - w_lo) == 0, at_end = base + (w_hi - H) == n;
+  for (int i = w_lo + tid; i < w_hi; i += 256) win[i] = sdbg_ld64(items, base - H + i);
+  if (EMIT && tid < 10) wc[tid] = 0;
+  __syncthreads();
+
+  // 1. every run head: the (a, b) pairs of its group, its own run's length / count sum, the decision
+  auto finish = [&](unsigned long long v, unsigned long long u, bool first, bool gh, uint32_t M, int a, int b, uint32_t mu, uint32_t fl) -> uint32_t {
+    if (P.is_seq == 1) mu = (uint32_t)MHX_MAX_MUL - (uint32_t)(v & 0xFFFFull);  // seq_to_sdbg.cpp:782-785
+    int w, last, tip;
+    if (sdbg_decide(M, a, b, w, last, tip)) fl |= kKept | (tip ? kTip : 0u) | (last ? kLast : 0u) | ((uint32_t)w << 4);
+    if (gh && (first || (u >> 48) != (v >> 48))) fl |= kBucketFirst;  // first group of its lv1 bucket
+    return fl | kHead | (mu << 12);
+  };
+  bool any_far = false;
+#pragma unroll 1
+  for (int j = 0; j < PER; ++j) {
+    const int idx = H + j * 256 + tid;
+    const long long g = base + j * 256 + tid;
+    uint32_t r = 0;
+    if (g < n) {
+      const unsigned long long v = win[idx];
+      const bool first = g == 0;
+      const unsigned long long u = first ? 0ull : win[idx - 1];
+      const bool rh = first || ((v ^ u) & P.rmask) != 0, gh = first || ((v ^ u) & P.gmask) != 0;
+      if (rh) {
+        int a, b, ax, bx;
+        uint32_t M = sdbg_pair_bit(v, P, a, b);
+        bool far = false;
+        if (!gh)
+          for (int p = idx - 1;; --p) {
+            if (p < w_lo) {
+              far = !at_start;
+              break;
+            }
+            const unsigned long long x = win[p];
+            if ((x ^ v) & P.gmask) break;
+            M |= sdbg_pair_bit(x, P, ax, bx);
+          }
+        uint32_t len = 1, sum = (uint32_t)(v & 0xFFFFull);
+        bool in_run = true;
+        if (!far)
+          for (int p = idx + 1;; ++p) {
+            if (p >= w_hi) {
+              far = !at_end;
+              break;
+            }
+            const unsigned long long x = win[p];
+            if ((x ^ v) & P.gmask) break;
+            in_run = in_run && ((x ^ v) & P.rmask) == 0;
+            if (in_run) {
+              ++len;
+              sum += (uint32_t)(x & 0xFFFFull);
+              if (sum > (uint32_t)MHX_MAX_MUL) sum = MHX_MAX_MUL;  // (a run in the window holds < 2^12 records: no overflow either way)
+            } else {
+              M |= sdbg_pair_bit(x, P, ax, bx);
+            }
+          }
+        if (far) {
+          r = kFar;
+          any_far = true;
+        } else {
+          r = finish(v, u, first, gh, M, a, b, P.is_seq == 2 ? sum : (len > (uint32_t)MHX_MAX_MUL ? (uint32_t)MHX_MAX_MUL : len), 0u);
+        }
+      }
+    }
+    res[j * 256 + tid] = r;
+  }
+  // 1b. run heads whose group or run reaches beyond the window (rare): the group's runs enumerated in memory; a long run of
+  //     aggregated items then has its counts summed by the whole wavefront, 64 records per step, until the cap is reached
+  if (__ballot(any_far)) {
+#pragma unroll 1
+    for (int j = 0; j < PER; ++j) {
+      const int idx = H + j * 256 + tid;
+      const long long g = base + j * 256 + tid;
+      uint32_t r = res[j * 256 + tid];
+      uint32_t todo = 0;  // records of a pending sum
+      if (r == kFar) {
+        const unsigned long long v = win[idx];
+        const bool first = g == 0;
+        const unsigned long long u = first ? 0ull : win[idx - 1];
+        const bool gh = first || ((v ^ u) & P.gmask) != 0;
+        int a, b;
+        uint32_t M = sdbg_pair_bit(v, P, a, b);
+        long long run_end;
+        sdbg_group_far(items, n, g, v, P, M, run_end);
+        const long long rl = run_end - g;
+        uint32_t mu = rl > (long long)MHX_MAX_MUL ? (uint32_t)MHX_MAX_MUL : (uint32_t)rl;
+        uint32_t fl = 0;
+        if (P.is_seq == 2) {
+          fl = kPending;
+          todo = rl > (long long)MHX_MAX_MUL ? (uint32_t)MHX_MAX_MUL : (uint32_t)rl;  // (every count is >= 1: the cap is reached within that many)
+          mu = 0;
+        }
+        r = finish(v, u, first, gh, M, a, b, mu, fl);
+      }
+      uint64_t pend = __ballot((r & kPending) != 0);
+      while (pend) {
+        const int src = __builtin_ctzll(pend);
+        pend &= pend - 1;
+        const long long head = base + j * 256 + (tid - lane) + src;
+        const uint32_t cnt = __shfl(todo, src, kWave);
+        uint32_t total = 0;
+        for (uint32_t off = 0; off < cnt && total < (uint32_t)MHX_MAX_MUL; off += kWave) {
+          const uint32_t x = off + lane < cnt ? items[head + off + lane].y & 0xFFFFu : 0u;
+          total += wave_sum(x);
+        }
+        if (lane == src) r = (r & 0xFFFu & ~kPending) | ((total > (uint32_t)MHX_MAX_MUL ? (uint32_t)MHX_MAX_MUL : total) << 12);
+      }
+      res[j * 256 + tid] = r;
+    }
+  }
+  // 2. the three counters of every record -> ballots; cells (round, wave) in record order -> exclusive prefixes
+#pragma unroll
+  for (int j = 0; j < PER; ++j) {
+    const uint32_t r = res[j * 256 + tid];
+    const bool kept = r & kKept;
+    const uint64_t bk = __ballot(kept), bt = __ballot(kept && (r & kTip)), bl = __ballot(kept && (r >> 12) > 254u);
+    if (lane == 0) {
+      cell[0][j * NW + wv] = (uint32_t)__builtin_popcountll(bk);
+      cell[1][j * NW + wv] = (uint32_t)__builtin_popcountll(bt);
+      cell[2][j * NW + wv] = (uint32_t)__builtin_popcountll(bl);
+    }
+  }
+  __syncthreads();
+  if (tid < kWave) {
+    static_assert(PER * NW <= kWave, "one wavefront scans the cells");
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const uint32_t x = lane < PER * NW ? cell[c][lane] : 0u;
+      const uint32_t incl = wave_inclusive_sum(x);
+      if (lane < PER * NW) cell[c][lane] = incl - x;
+      if (lane == PER * NW - 1) cell[c][PER * NW] = incl;
+    }
+  }
+  __syncthreads();
+  if constexpr (!EMIT) {
+    if (tid < 3) tile_tot[(uint64_t)tid * n_tiles + blockIdx.x] = cell[tid][PER * NW];
+  } else {
+    const uint64_t b0 = tile_base[blockIdx.x], b1 = tile_base[n_tiles + blockIdx.x], b2 = tile_base[2 * n_tiles + blockIdx.x];
+#pragma unroll 1
+    for (int j = 0; j < PER; ++j) {
+      const uint32_t r = res[j * 256 + tid];
+      const bool kept = r & kKept;
+      const uint32_t m = r >> 12;
+      const uint64_t bk = __ballot(kept), bt = __ballot(kept && (r & kTip)), bl = __ballot(kept && m > 254u);
+      if (!(r & kHead)) continue;
+      const uint64_t o0 = b0 + cell[0][j * NW + wv] + (uint32_t)__builtin_popcountll(bk & lanemask_lt);
+      const uint64_t o1 = b1 + cell[1][j * NW + wv] + (uint32_t)__builtin_popcountll(bt & lanemask_lt);
+      const uint64_t o2 = b2 + cell[2][j * NW + wv] + (uint32_t)__builtin_popcountll(bl & lanemask_lt);
+      const unsigned long long v = win[H + j * 256 + tid];
+      if (r & kBucketFirst) {
+        const uint32_t bkt = (uint32_t)(v >> 48);
+        bstart[bkt] = o0;
+        bstart[MHX_NUM_BUCKETS + bkt] = o1;
+        bstart[2 * MHX_NUM_BUCKETS + bkt] = o2;
+      }
+      if (!kept) continue;
+      const uint32_t w = (r >> 4) & 0xFu, last = (r & kLast) ? 1u : 0u, tip = (r & kTip) ? 1u : 0u;
+      uint64_t o16 = o0 + o2 + 2ull * P.wpt * o1;
+      // SdbgItem (sdbg_item.h:14-24): byte0 = w | last<<4 | tip<<5, byte1 = min(mul,255)
+      out16[o16++] = (uint16_t)(w | (last << 4) | (tip << 5) | ((m > 255 ? 255u : m) << 8));
+      if (m > 254) out16[o16++] = (uint16_t)m;
+      if (tip) {
+        for (int x = 0; x < P.wpt; ++x) {
+          uint32_t t = x == 0 ? (uint32_t)(v >> 32) : (uint32_t)v;
+          if (P.is_seq == 2 && x == P.wpt - 1) {  // (the reference's raw tip label: SdbgOp::unit_emit)
+            const int tip_chars = P.k - 1, in_word = tip_chars - 16 * x;
+            const uint32_t cm = in_word >= 16 ? 0xFFFFFFFFu : (in_word <= 0 ? 0u : 0xFFFFFFFFu << (32 - 2 * in_word));
+            t &= cm;
+            if (x == P.ref_kw - 1) t |= (uint32_t)((v >> P.bsh) & 7ull);
+          }
+          out16[o16++] = (uint16_t)(t & 0xFFFFu);
+          out16[o16++] = (uint16_t)(t >> 16);
+        }
+      }
+      atomicAdd(&wc[w], 1u);
+      if (last) atomicAdd(&wc[9], 1u);
+    }
+    __syncthreads();
+    if (tid < 10 && wc[tid]) atomicAdd(&w_count[tid], (unsigned long long)wc[tid]);
+  }
+}
+
 // bstart[3][65536] (kNoStart = empty bucket) + totals -> per-bucket counts and byte offsets: a bucket ends where the next
 // non-empty one starts.  256 workgroups of 256 buckets each (coalesced reads; the single workgroup with 256 buckets per
 // thread of rounds 1-2 took 0.31 ms of every step).  k_bucket_first: first non-empty bucket of every workgroup's range.
@@ -583,6 +910,44 @@ static void emit_sdbg_impl(mhx_ctx *c, const uint32_t *sorted, uint64_t n_items,
   const uint32_t last_mask = rem ? 0xFFFFFFFFu << (32 - rem) : 0;
   SdbgOp<S> op{P, nullptr, w_count, bstart};
   const double bytes = (double)n_items * S * 4;
+  if constexpr (S == 2) {
+    if (c->opt("sdbg_fast", 1) != 0 && P.kw >= 1 && P.kw <= 2 && P.aw <= 1) {  // 8-byte records: k_sdbg_fast (every run head on its own)
+      SdbgFastP F;
+      F.gmask = kmer_bits >= 64 ? ~0ull : (kmer_bits ? ~0ull << (64 - kmer_bits) : 0ull);
+      F.bsh = P.bshift + (P.kw - 1 == 0 ? 32 : 0);
+      F.fsh = P.fshift + (P.kw - 1 == 0 ? 32 : 0);
+      F.ash = P.ashift + (P.aw == 0 ? 32 : 0);
+      F.rmask = F.gmask | (0xFull << F.bsh) | (3ull << F.ash);
+      F.is_seq = P.is_seq;
+      F.wpt = P.wpt;
+      F.k = P.k;
+      F.ref_kw = P.ref_kw;
+      F.halo = (int)std::min<long long>(kSdbgFastHalo, std::max<long long>(1, c->opt("sdbg_fast_halo", kSdbgFastHalo)));
+      const uint64_t n_ft = div_ceil(n_items, (uint64_t)kSdbgFastT);
+      uint64_t *ftt = c->ws("tile_tot", (3 * n_ft + 4) * 8).as<uint64_t>();
+      uint64_t *ftb = c->ws("tile_base", (3 * n_ft + 4) * 8).as<uint64_t>();
+      const uint2 *recs = reinterpret_cast<const uint2 *>(sorted);
+      MHX_LAUNCH(c, "sdbg_count", bytes,
+                 hipLaunchKernelGGL((k_sdbg_fast<false>), dim3((unsigned)n_ft), dim3(256), 0, st, recs, (long long)n_items, F, ftt,
+                                    (const uint64_t *)nullptr, n_ft, (uint16_t *)nullptr, w_count, bstart));
+      for (int r = 0; r < 3; ++r) exclusive_scan_u64(c, ftt + r * n_ft, ftb + r * n_ft, n_ft, d_tot + r);
+      MHX_HIP(hipMemcpyAsync(tot, d_tot, 24, hipMemcpyDeviceToHost, st));
+      MHX_HIP(hipStreamSynchronize(st));
+      const uint64_t out_bytes = 2 * (tot[0] + tot[2]) + 4ull * P.wpt * tot[1];
+      uint16_t *out16 = c->result(MHX_BUF_SDBG_BYTES, out_bytes ? out_bytes : 2).as<uint16_t>();
+      c->results[MHX_BUF_SDBG_BYTES].used = out_bytes;
+      MHX_HIP(hipMemsetAsync(bstart, 0xFF, 3 * MHX_NUM_BUCKETS * 8, st));
+      MHX_LAUNCH(c, "sdbg_emit", bytes + (double)out_bytes,
+                 hipLaunchKernelGGL((k_sdbg_fast<true>), dim3((unsigned)n_ft), dim3(256), 0, st, recs, (long long)n_items, F, (uint64_t *)nullptr,
+                                    (const uint64_t *)ftb, n_ft, out16, w_count, bstart));
+      uint32_t *block_first = c->ws("bucket_block_first", MHX_NUM_BUCKETS / 256 * 4).as<uint32_t>();
+      hipLaunchKernelGGL(k_bucket_first, dim3(MHX_NUM_BUCKETS / 256), dim3(256), 0, st, bstart, block_first);
+      MHX_LAUNCH(c, "bucket_stats", (double)MHX_NUM_BUCKETS * 56,
+                 hipLaunchKernelGGL(k_bucket_fix, dim3(MHX_NUM_BUCKETS / 256), dim3(256), 0, st, bstart, block_first, d_tot, P.wpt, b_items, b_tips,
+                                    b_large, b_off));
+      return;
+    }
+  }
   MHX_LAUNCH(c, "sdbg_count", bytes,
              hipLaunchKernelGGL((k_tile_groups<S, T, SdbgOp<S>, false>), dim3(tile_grid(n_tiles)), dim3(kTileThreads), 0, st, sorted, n_items,
                                 full_words, last_mask, op, tt, (const uint64_t *)nullptr, n_tiles, n_tiles));
