@@ -1239,6 +1239,25 @@ struct S1Op {
 // three barriers per tile.  A tile whose last segment outgrows the look-ahead or whose keys overflow the table sets
 // *err and does nothing; the host then falls back to the full sort + k_tile_groups (same results).
 // ---------------------------------------------------------------------------------------------------------------
+// Giant buckets of the bucket streaming (round 5).  A workgroup streams a bucket alone, so ONE bucket of millions of records —
+// low-complexity sequence: 1 % poly-A reads put 13 M records of one key into lv1 bucket 0 — held the whole stage up for 15 ms.
+// Such a bucket (>= min_records) is cut into slices that many workgroups reduce in parallel (k_s1_giant_reduce: an LDS
+// table per slice -> "partial entries" = a key's first record + its count in the slice), the streaming kernel skips it
+// (flag[bucket]), and a second launch of the streaming kernel (GIANT) inserts the few partial entries with their counts
+// and does the per-key work as for any bucket.  A bucket whose slices do not reduce into their region (many distinct keys)
+// clears its flag and is streamed as before.  Everything is found and sized on the device: no host round trip.
+struct S1Giant {
+  uint8_t *flag;            // [n_buckets] 1: taken by the giant path
+  uint32_t *ctr;            // [0] giants found (may exceed gcap)  [2..3] partial entries allotted (64-bit)
+  uint32_t *bucket, *sl, *ns, *cap, *cur;  // per giant: bucket, slice length, slices, region capacity, entries written
+  unsigned long long *off;  // per giant: first entry of its region in `partial`
+  uint4 *partial;           // entries: the three words of a key's first record in the slice + its count there
+  uint32_t gcap;            // giants the list holds
+  uint32_t min_records;     // a bucket at least this large is a giant
+  unsigned long long pcap;  // entries `partial` holds
+};
+constexpr uint32_t kGiantSliceMin = 16384, kGiantEntriesPerSlice = 256;
+
 struct S1SegArgs {
   int k;
   uint32_t m;
@@ -1263,6 +1282,7 @@ struct S1SegArgs {
   uint32_t *err;
   int la_chunks;      // look-ahead limit, in chunks of 256 records
   int direct_marks;   // k_s1_stream: the non-solid marks come from the table (one stored position per key), no second read
+  S1Giant giant;      // k_s1_stream: buckets handed to the giant path (flag == nullptr: none)
 };
 
 constexpr unsigned long long kSegEmpty = ~0ull;  // never a key: head/tail bits 63 do not occur (max (4<<3)|4)
@@ -1640,6 +1660,150 @@ struct S1StreamGeom {
   uint32_t max_fill;  // a round whose table ends up with more keys than this is redone in two halves
 };
 
+// local key of a record inside a bucket of the pbits-bit prefix: the (k-1)-mer bits below the prefix, then head/tail
+__device__ __forceinline__ uint32_t s1_stream_local_key(uint32_t w0, uint32_t w1, int k, int pbits) {
+  const int rem = 2 * (k - 1) - pbits, mer_sh = 64 - 2 * (k - 1);
+  const uint64_t key = ((uint64_t)w0 << 32) | w1;
+  const uint32_t lo = (uint32_t)(key >> mer_sh);
+  return (rem ? (lo & ((1u << rem) - 1u)) << 6 : 0u) | (w1 & 63u);
+}
+// which buckets are giants: one thread per bucket; the list, the slices and the regions of partial entries are allotted here
+__global__ __launch_bounds__(256) void k_s1_giant_find(const uint64_t *__restrict__ bounds, int n_src, uint32_t n_buckets, S1Giant g) {
+  const uint32_t b = blockIdx.x * 256 + threadIdx.x;
+  if (b >= n_buckets) return;
+  const size_t bstride = (size_t)n_buckets + 1;
+  uint64_t total = 0;
+  for (int q = 0; q < n_src; ++q) total += bounds[q * bstride + b + 1] - bounds[q * bstride + b];
+  if (total < g.min_records) return;
+  uint64_t sl64 = (total + 255) / 256;
+  sl64 = (sl64 + 4095) / 4096 * 4096;
+  const uint32_t sl = (uint32_t)(sl64 < kGiantSliceMin ? kGiantSliceMin : (sl64 > (1u << 30) ? (1u << 30) : sl64));
+  uint64_t ns = 0;
+  for (int q = 0; q < n_src; ++q) ns += (bounds[q * bstride + b + 1] - bounds[q * bstride + b] + sl - 1) / sl;
+  const uint32_t gi = atomicAdd(&g.ctr[0], 1u);
+  if (gi >= g.gcap) return;
+  const unsigned long long cap = ns * kGiantEntriesPerSlice;
+  const unsigned long long off = atomicAdd(reinterpret_cast<unsigned long long *>(g.ctr + 2), cap);
+  const bool fits = off + cap <= g.pcap && cap < (1ull << 31);
+  g.bucket[gi] = b;
+  g.sl[gi] = sl;
+  g.ns[gi] = fits ? (uint32_t)ns : 0u;
+  g.cap[gi] = fits ? (uint32_t)cap : 0u;
+  g.off[gi] = off;
+  g.cur[gi] = 0;
+  if (fits) g.flag[b] = 1;
+}
+// the slices of the giants, each reduced by one workgroup: LDS table of the slice's keys (count, first record) -> partial entries
+__global__ __launch_bounds__(256) void k_s1_giant_reduce(const uint32_t *__restrict__ items0, const uint32_t *const *__restrict__ srcs,
+                                                         const uint64_t *__restrict__ bounds, int n_src, uint32_t n_buckets, int pbits, int k, S1Giant g) {
+  constexpr int NS = 4096, NT = 256, kFlushAt = NS / 2;
+  __shared__ uint32_t keys[NS], cnts[NS], fidx[NS];
+  __shared__ uint32_t s_claims, s_out, s_start, s_stop;
+  const int tid = threadIdx.x, lane = tid & (kWave - 1);
+  const size_t bstride = (size_t)n_buckets + 1;
+  const uint32_t n_g = min(g.ctr[0], g.gcap);
+  for (int i = tid; i < NS; i += NT) {
+    keys[i] = kStreamEmpty;
+    cnts[i] = 0;
+  }
+  if (tid == 0) s_claims = 0;
+  __syncthreads();
+  for (uint32_t gi = 0; gi < n_g; ++gi) {
+    const uint32_t ns = g.ns[gi];
+    if (!ns) continue;
+    const uint32_t b = g.bucket[gi], sl_len = g.sl[gi], cap = g.cap[gi];
+    uint4 *const region = g.partial + g.off[gi];
+    for (uint32_t sl = blockIdx.x; sl < ns; sl += gridDim.x) {
+      // the slice: `rem`-th slice of the first source that has that many
+      uint32_t rem = sl;
+      uint64_t lo = 0, hi = 0;
+      const uint32_t *src = items0;
+      for (int q = 0; q < n_src; ++q) {
+        const uint64_t l = bounds[q * bstride + b], h = bounds[q * bstride + b + 1];
+        const uint64_t nsq = (h - l + sl_len - 1) / sl_len;
+        if (rem < nsq) {
+          lo = l + (uint64_t)rem * sl_len;
+          hi = lo + sl_len < h ? lo + sl_len : h;
+          if (n_src > 1) src = srcs[q];
+          break;
+        }
+        rem -= (uint32_t)nsq;
+      }
+      // table -> this giant's region (any order; a region that does not hold them gives the bucket back to the streaming kernel)
+      auto flush = [&]() {
+        __syncthreads();
+        uint32_t mine = 0;
+        for (int i = tid; i < NS; i += NT) mine += keys[i] != kStreamEmpty;
+        if (tid == 0) s_out = 0;
+        __syncthreads();
+        const uint32_t incl = wave_inclusive_sum(mine);
+        uint32_t wbase = 0;
+        if (lane == kWave - 1 && incl) wbase = atomicAdd(&s_out, incl);
+        wbase = __shfl(wbase, kWave - 1, kWave);
+        __syncthreads();
+        if (tid == 0) {
+          const uint32_t tot = s_out;
+          const uint32_t start = tot ? atomicAdd(&g.cur[gi], tot) : 0u;
+          s_start = start;
+          s_stop = start + tot > cap;
+          if (s_stop) g.flag[b] = 0;
+          s_claims = 0;
+        }
+        __syncthreads();
+        uint32_t at = s_start + wbase + incl - mine;
+        const bool write = !s_stop;
+        for (int i = tid; i < NS; i += NT) {
+          const uint32_t key = keys[i];
+          if (key != kStreamEmpty) {
+            if (write) {
+              const uint32_t *r = src + (lo + fidx[i]) * 3;
+              region[at++] = make_uint4(r[0], r[1], r[2], cnts[i]);
+            }
+            keys[i] = kStreamEmpty;
+            cnts[i] = 0;
+          }
+        }
+        __syncthreads();
+      };
+      bool stop = false;
+      for (uint64_t base = lo; base < hi && !stop; base += NT) {
+        const uint64_t idx = base + tid;
+        const bool in = idx < hi;
+        uint32_t lk = 0;
+        if (in) {
+          const uint32_t *r = src + idx * 3;
+          lk = s1_stream_local_key(r[0], r[1], k, pbits);
+        }
+        // a wavefront whose records all carry one key (poly-A): one lane inserts for all
+        const uint32_t lk0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)lk);
+        const bool uniform = __ballot(in && lk == lk0) == ~0ull;
+        const uint32_t mult = uniform ? (uint32_t)kWave : 1u;
+        if (in && (!uniform || lane == 0)) {
+          uint32_t h = (lk * 0x9E3779B1u) >> (32 - 12);
+          for (;;) {
+            const uint32_t old = atomicCAS(&keys[h], kStreamEmpty, lk);
+            if (old == kStreamEmpty) {
+              fidx[h] = (uint32_t)(idx - lo);
+              atomicAdd(&s_claims, 1u);
+            }
+            if (old == kStreamEmpty || old == lk) {
+              atomicAdd(&cnts[h], mult);
+              break;
+            }
+            h = (h + 1) & (NS - 1);  // (the table is flushed at half full: a free slot exists)
+          }
+        }
+        __syncthreads();
+        if (s_claims >= (uint32_t)kFlushAt - NT) {  // (uniform; at most NT more keys before the next look)
+          flush();
+          stop = s_stop != 0;
+        }
+      }
+      if (!stop) flush();
+    }
+  }
+}
+
 constexpr int kStreamBatch = 4;     // buckets per ticket
 constexpr int kStreamSrcMax = kWave;  // bucket bounds of up to this many sources are staged in LDS (one lane of wave 0 per source)
 
@@ -1659,7 +1823,7 @@ constexpr int kStreamSrcMax = kWave;  // bucket bounds of up to this many source
 // three phases with a list of occupied slots.  Loads: the records of trip i + 1 — across the end of a round or of a bucket:
 // the first trip of what comes next — are requested before the inserts of trip i, and wave 0 fetches the next bucket's
 // ticket and bounds while the current bucket is worked on.
-template <bool AGG, int UNR, int NT, int LOGS, bool TAGS>
+template <bool AGG, int UNR, int NT, int LOGS, bool TAGS, bool GIANT = false>
 __global__ __launch_bounds__(NT) void k_s1_stream(const uint32_t *__restrict__ items0, const uint64_t *__restrict__ bounds, S1SegArgs a,
                                                   S1StreamGeom geo, uint32_t bucket_stride, uint32_t *__restrict__ ticket,
                                                   const uint32_t *const *__restrict__ srcs, int n_src) {
@@ -1680,6 +1844,7 @@ __global__ __launch_bounds__(NT) void k_s1_stream(const uint32_t *__restrict__ i
   __shared__ uint32_t s_agg_cur, s_mark_cur;
   // the bucket being worked on and the one after it: ticket and per-source bounds (wave 0 fills [par ^ 1] during bucket [par])
   __shared__ uint32_t s_tk[2];
+  __shared__ uint32_t s_bid[2];  // GIANT: the lv1 bucket (of the plan's prefix) the ticket's giant is
   __shared__ uint64_t s_lo[2][kStreamSrcMax], s_hi[2][kStreamSrcMax];
   __shared__ uint64_t s_src[kStreamSrcMax];  // the sources' arrays (multi-GPU)
   const int tid = threadIdx.x, lane = tid & (kWave - 1);
@@ -1696,9 +1861,12 @@ __global__ __launch_bounds__(NT) void k_s1_stream(const uint32_t *__restrict__ i
     s_bad[0] = s_bad[1] = 0;
     s_nclaimed[0] = s_nclaimed[1] = 0;
     s_list_n[0] = s_list_n[1] = 0;
-    s_agg_cur = 0;
-    s_mark_cur = 0;
+    // GIANT: the second launch over the same grid goes on where this workgroup's regions stand
+    s_agg_cur = GIANT && AGG ? a.agg_counts[blockIdx.x] : 0u;
+    s_mark_cur = GIANT && marks_out ? a.marks_counts[blockIdx.x] : 0u;
   }
+  // GIANT: the "buckets" of this launch are the entries of the giant list, their records the partial entries of k_s1_giant_reduce
+  const uint64_t n_lim = GIANT ? (uint64_t)min(a.giant.ctr[0], a.giant.gcap) : (uint64_t)geo.n_buckets;
   const uint32_t m = a.m;
   const int k = a.k;
   const int pbits = geo.pbits;
@@ -1791,17 +1959,28 @@ __global__ __launch_bounds__(NT) void k_s1_stream(const uint32_t *__restrict__ i
   // wave 0, lane q: the bounds of source q of bucket nb — requested, and used a bucket's inserts later (publish_desc); with them
   // the host's error word: a workgroup stops taking buckets once the host has to step in anyway
   uint64_t d_lo = 0, d_hi = 0;
-  uint32_t d_err = 0;
+  uint32_t d_err = 0, d_gf = 0, d_bid = 0;
   auto request_bounds = [&](uint64_t nb) {
     d_lo = d_hi = 0;
+    d_gf = 0;
     d_err = ((const __attribute__((address_space(1))) uint32_t *)a.err)[0];
-    if (nb < geo.n_buckets && lane < n_src) {
+    if constexpr (GIANT) {
+      if (nb < n_lim && lane == 0) {
+        d_bid = a.giant.bucket[nb];
+        const uint32_t got = min(a.giant.cur[nb], a.giant.cap[nb]);
+        d_lo = a.giant.off[nb];
+        d_hi = a.giant.ns[nb] && a.giant.flag[d_bid] ? d_lo + got : d_lo;  // (a giant that did not reduce was streamed by the first launch)
+      }
+    } else if (nb < geo.n_buckets && lane < n_src) {
       d_lo = gbounds[(size_t)lane * bstride + nb];
       d_hi = gbounds[(size_t)lane * bstride + nb + 1];
+      if (a.giant.flag && lane == 0) d_gf = ((const __attribute__((address_space(1))) uint8_t *)a.giant.flag)[nb];
     }
   };
   auto publish_desc = [&](int par, uint32_t tk) {
     if (lane == 0) s_tk[par] = d_err ? 0xFFFFFFFFu / (bucket_stride ? bucket_stride : 1u) : tk;
+    if (GIANT && lane == 0) s_bid[par] = d_bid;
+    if (!GIANT && a.giant.flag && __shfl(d_gf, 0, kWave)) d_hi = d_lo;  // a giant: left to k_s1_giant_reduce and the GIANT launch
     if (lane < n_src) {
       // (statistics on a sample — mark_mode 2 — look at no more than 8 trips of a bucket: one low-complexity bucket, poly-A at
       //  lv1 bucket 0 for one, may hold millions of records, and a workgroup streams a bucket alone)
@@ -1873,7 +2052,8 @@ __global__ __launch_bounds__(NT) void k_s1_stream(const uint32_t *__restrict__ i
   TripRef cur{(gptr)bounds, 1u};  // (always a readable address: the stand-in where no trip follows; at first the bounds themselves)
   auto request_first = [&](int bpar) {  // the first trip of bucket [bpar] -> set A (bucket empty or none left: a stand-in, mask cleared)
     bool follows = false;
-    if (bucket_of(bpar) < geo.n_buckets) {
+    if (GIANT) return;  // (the partial entries of a giant are read where they are inserted)
+    if (bucket_of(bpar) < n_lim) {
       const int q = first_source(bpar, 0);
       if (q < n_src) {
         cur = trip_ref(q, lo_of(bpar, q), hi_of(bpar, q));
@@ -1888,8 +2068,8 @@ __global__ __launch_bounds__(NT) void k_s1_stream(const uint32_t *__restrict__ i
   for (;;) {
     MHX_TT_BEGIN
     const uint64_t bi64 = bucket_of(par);
-    if (bi64 >= geo.n_buckets) break;
-    const uint32_t bi = (uint32_t)bi64;
+    if (bi64 >= n_lim) break;
+    const uint32_t bi = GIANT ? s_bid[par] : (uint32_t)bi64;
     // wave 0: the next bucket — its ticket and the request for its bounds when this bucket's first round starts, handed over
     // when that round's inserts end
     uint32_t next_tk = 0;
@@ -2023,7 +2203,41 @@ __global__ __launch_bounds__(NT) void k_s1_stream(const uint32_t *__restrict__ i
           seen = __hip_atomic_load(&s_nclaimed[rp], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
       };
-      {
+      if constexpr (GIANT) {
+        // the partial entries of the giant (first record of a key in a slice + its count there): few, inserted with their counts
+        desc_step(1);
+        const uint4 *const part = a.giant.partial;
+        const uint64_t lo = lo_of(par, 0), hi = hi_of(par, 0);
+        uint32_t my_claims = 0;
+        for (uint64_t e = lo + tid; e < hi; e += NT) {
+          const uint4 en = part[e];
+          const uint32_t lk = local_key(en.x, en.y);
+          if (sub != 0 && (lk >> sub_sh) != rj) continue;
+          if (probe_limit <= 0) {
+            s_bad[rp] = 1;
+            continue;
+          }
+          uint32_t hh = hash_of(lk);
+          for (int n = 0;; ++n) {
+            const uint32_t old = atomicCAS(&keys[hh], kStreamEmpty, lk);
+            if (old == kStreamEmpty || old == lk) {
+              atomicAdd(&cnts[hh], en.w);
+              if (old == kStreamEmpty) {
+                fpos[hh] = en.z;
+                if (TAGS) ftag[hh] = (uint8_t)(en.y >> 6);
+                ++my_claims;
+              }
+              break;
+            }
+            hh = (hh + 1) & (NSLOT - 1);
+            if (n >= probe_limit) {
+              s_bad[rp] = 1;
+              break;
+            }
+          }
+        }
+        if (my_claims) atomicAdd(&s_nclaimed[rp], my_claims);
+      } else {
         int q = q0;
         uint64_t base = lo_of(par, q), hi = hi_of(par, q);
         // Set A was requested before the per-key walk of the round before this one, whose stores may still be on their way: loads
@@ -2089,13 +2303,15 @@ __global__ __launch_bounds__(NT) void k_s1_stream(const uint32_t *__restrict__ i
       }
       if (give_up && tid == 0) atomicOr(a.err, 1u);
       // ... and its first trip, requested before the per-key work of this round
-      if (!bucket_done) {
-        cur = trip_ref(q0, lo_of(par, q0), hi_of(par, q0));
-        load_trip(cur, nw0, nw1, nw2, n_inm);
-      } else {
-        request_first(par ^ 1);
+      if constexpr (!GIANT) {
+        if (!bucket_done) {
+          cur = trip_ref(q0, lo_of(par, q0), hi_of(par, q0));
+          load_trip(cur, nw0, nw1, nw2, n_inm);
+        } else {
+          request_first(par ^ 1);
+        }
       }
-      if (!bad) {
+      if (!GIANT && !bad) {
         // B: marks by a second read of the bucket (m > 2, or the marks of the solid occurrences are wanted)
         if (a.mark_mode != 2 && !a.direct_marks) {
           for (int q = 0; q < n_src; ++q) {
@@ -3011,6 +3227,7 @@ struct S1Stage {
   unsigned long long *is_solid = nullptr, *hist = nullptr, *ctr = nullptr;
   uint8_t *solid_bytes = nullptr;
   uint64_t marks_prev = 0, seg_marks = 0;
+  const uint32_t *giant_ctr = nullptr;  // device counters of the giant path of the last launch_partial (nullptr: not taken)
   bool classic_ran = false;
   long long *mercy = nullptr;
   bool agg = false;
@@ -3177,6 +3394,35 @@ struct S1Stage {
       const S1StreamGeom geo{plan.seg_bits, plan.sub0, (uint32_t)n_buckets,
                              (uint32_t)std::min<long long>(std::max<long long>(c->opt("s1_stream_fill", nslot * 7 / 8), 1), nslot)};
       const bool tags = pos_stride != 0;
+      // giant buckets (S1Giant): found, cut into slices and reduced on the device before the streaming launch, finished by a second
+      // launch of the streaming kernel over the same grid (direct marks only: a key's first record stands for its slice)
+      const bool giant_on = direct && !half && mode == 1 && c->opt("s1_giant", 1) != 0;
+      uint32_t *ticket2 = nullptr;
+      if (giant_on) {
+        S1Giant &g = a.giant;
+        g.gcap = 4096;
+        g.min_records = (uint32_t)std::max<long long>(1, c->opt("s1_giant_min", 262144));
+        g.pcap = std::max<uint64_t>(2u << 20, n_items / 64);
+        g.flag = c->ws("s1_giant_flag", n_buckets + 64).as<uint8_t>();
+        uint32_t *lists = c->ws("s1_giant_lists", 64 + (size_t)g.gcap * (5 * 4 + 8)).as<uint32_t>();
+        g.ctr = lists;
+        ticket2 = lists + 8;
+        g.off = reinterpret_cast<unsigned long long *>(lists + 16);
+        g.bucket = lists + 16 + 2 * g.gcap;
+        g.sl = g.bucket + g.gcap;
+        g.ns = g.sl + g.gcap;
+        g.cap = g.ns + g.gcap;
+        g.cur = g.cap + g.gcap;
+        g.partial = c->ws("s1_giant_partial", g.pcap * 16 + 64).as<uint4>();
+        giant_ctr = lists;
+        MHX_HIP(hipMemsetAsync(g.flag, 0, n_buckets, st));
+        MHX_HIP(hipMemsetAsync(lists, 0, 64, st));
+        MHX_LAUNCH(c, "s1_giant_find", (double)n_src * n_buckets * 8,
+                   hipLaunchKernelGGL(k_s1_giant_find, dim3((unsigned)div_ceil(n_buckets, 256)), dim3(256), 0, st, bounds, n_src, (uint32_t)n_buckets, g));
+        MHX_LAUNCH(c, "s1_giant_reduce", 0.0,
+                   hipLaunchKernelGGL(k_s1_giant_reduce, dim3((unsigned)(3 * cus)), dim3(256), 0, st, items0, srcs, bounds, n_src, (uint32_t)n_buckets,
+                                      plan.seg_bits, (int)k, g));
+      }
 #define MHX_STREAM(AGGV, NTV, LOGV, TAGV)                                                                                                 \
   MHX_LAUNCH(c, nm, bytes, hipLaunchKernelGGL((k_s1_stream<AGGV, 4, NTV, LOGV, TAGV>), dim3(grid), dim3(NTV), 0, st, items0, bounds, a, geo, \
                                               stride, ticket, srcs, n_src))
@@ -3194,6 +3440,16 @@ struct S1Stage {
       }
 #undef MHX_STREAM_T
 #undef MHX_STREAM
+      if (giant_on) {  // the giants' partial entries -> the same per-key work, the same per-workgroup output regions
+#define MHX_GIANT(AGGV, TAGV)                                                                                                                  \
+  MHX_LAUNCH(c, "s1_giant_groups", 0.0, hipLaunchKernelGGL((k_s1_stream<AGGV, 4, kStreamThreads, 13, TAGV, true>), dim3(grid), dim3(kStreamThreads), 0, \
+                                                           st, items0, bounds, a, geo, 1u, ticket2, (const uint32_t *const *)nullptr, 1))
+        if (agg_on && tags) MHX_GIANT(true, true);
+        else if (agg_on) MHX_GIANT(true, false);
+        else if (tags) MHX_GIANT(false, true);
+        else MHX_GIANT(false, false);
+#undef MHX_GIANT
+      }
       return;
     }
 #define MHX_SEG(PERV, AGGV) \
@@ -3252,14 +3508,18 @@ struct S1Stage {
 
   // one run of the partial group-by: launch, read its error word and region counts back, pack the regions.  -> error word
   uint32_t run_partial() {
+    giant_ctr = nullptr;
     launch_partial(mark_mode);
     uint32_t e = 0;
     std::vector<uint32_t> h_counts(agg ? seg_grid : 0), h_mcounts(sparse ? seg_grid : 0);
+    uint32_t h_giant[4] = {0, 0, 0, 0};  // giants found, -, partial entries allotted (64 bits)
+    if (giant_ctr) MHX_HIP(hipMemcpyAsync(h_giant, giant_ctr, 16, hipMemcpyDeviceToHost, st));
     MHX_HIP(hipMemcpyAsync(&e, seg_err, 4, hipMemcpyDeviceToHost, st));
     if (agg) MHX_HIP(hipMemcpyAsync(h_counts.data(), c->work["s2_agg_counts"].p, (size_t)seg_grid * 4, hipMemcpyDeviceToHost, st));
     if (sparse) MHX_HIP(hipMemcpyAsync(h_mcounts.data(), c->work["s1_mark_counts"].p, (size_t)seg_grid * 4, hipMemcpyDeviceToHost, st));
     MHX_HIP(hipStreamSynchronize(st));
     if (e) return e;
+    if (h_giant[0]) c->last_s1_plan += " [" + std::to_string(h_giant[0]) + " giant buckets in slices]";
     if (sparse) {  // pack the workgroups' mark regions (they live in the spare sort buffer) behind the earlier passes' marks
       for (uint32_t v : h_mcounts) seg_marks += v;
       unsigned long long *dense = grow_preserving(c, c->work["s1_marks"], (marks_prev + seg_marks) * 8 + 64, marks_prev * 8).as<unsigned long long>();

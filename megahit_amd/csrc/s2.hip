@@ -746,8 +746,14 @@ __global__ __launch_bounds__(256) void k_sdbg_fast(const uint2 *__restrict__ ite
         const long long head = base + j * 256 + (tid - lane) + src;
         const uint32_t cnt = __shfl(todo, src, kWave);
         uint32_t total = 0;
-        for (uint32_t off = 0; off < cnt && total < (uint32_t)MHX_MAX_MUL; off += kWave) {
-          const uint32_t x = off + lane < cnt ? items[head + off + lane].y & 0xFFFFu : 0u;
+        constexpr uint32_t kStep = 8;  // loads in flight per lane and step (one load per step: a memory round trip per 64 records)
+        for (uint32_t off = 0; off < cnt && total < (uint32_t)MHX_MAX_MUL; off += kStep * kWave) {
+          uint32_t x = 0;
+#pragma unroll
+          for (uint32_t q = 0; q < kStep; ++q) {
+            const uint32_t i = off + q * kWave + lane;
+            x += i < cnt ? items[head + i].y & 0xFFFFu : 0u;
+          }
           total += wave_sum(x);
         }
         if (lane == src) r = (r & 0xFFFu & ~kPending) | ((total > (uint32_t)MHX_MAX_MUL ? (uint32_t)MHX_MAX_MUL : total) << 12);
