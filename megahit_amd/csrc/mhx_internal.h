@@ -102,6 +102,7 @@ struct mhx_ctx {
   // stage 1: records per lv1 bucket the ranks of a multi-GPU run agreed on (comm.hip; 0: each call derives it from its own
   // item count, s1.hip s1_density) — every rank must make the same sort plan
   double s1_density = 0;
+  bool s1_var_gen = false;            // the last s1_extract armed the variable-length generating pass (S1GenVarT)
   std::string last_s1_plan;           // what the last stage 1 ran as (mhx_last_s1_plan; bench.py prints it)
   bool s1_defer_items = false;  // the caller of extract_stage(S1) will sort right away: s1_extract may defer the items to that sort
   // memory-bounded passes (passes.hip): only items of the kept lv1 buckets are materialised

@@ -516,6 +516,153 @@ struct S1GenRollT {
   }
 };
 
+// Libraries whose reads are NOT of one length (trimmed reads: every real library) on the same generating pass (round 5).  The item
+// index space is padded, not the store: every read gets per = max_len - k + 4 item slots, slot j of read r is item (r, j), and the
+// slots a shorter read does not fill are declined (Src::kMayDrop — the mechanism of the bucket filter: the pass compacts what it
+// keeps).  The read's place in the store comes from start[] (three 8-byte loads per thread and tile: this read, the next, the
+// one after), its slot -> offset mapping from its own length.  Otherwise S1GenRollT: one window + one reverse complement per
+// run.  Costs the slots that are dropped ((max_len - mean_len) / per of them) — the host takes this form while at least half of
+// the slots are real.  Same records as k_s1_extract, bit for bit (read_to_sdbg_s1.cpp:228-292 serves any mix of lengths,
+// sequence_package.h:131-164).
+struct S1ReadGeo {
+  uint64_t base;   // first base of the read in the store
+  uint32_t L;      // its length
+  uint32_t qlast;  // last offset of a (k-1)-mer
+  uint32_t jf;     // first slot of the forced pair at the read's end
+  uint32_t cnt;    // item slots the read fills (0: shorter than k + 1)
+};
+__device__ __forceinline__ S1ReadGeo s1_read_geo(uint64_t base, uint64_t next_base, int k) {
+  S1ReadGeo g;
+  g.base = base;
+  g.L = (uint32_t)(next_base - base);
+  const bool any = g.L >= (uint32_t)k + 1;
+  g.qlast = any ? g.L - k + 1 : 0u;
+  g.jf = any ? g.L - k + 2 : 0xFFFFFFFFu;
+  g.cnt = any ? g.L - k + 4 : 0u;
+  return g;
+}
+// the 32-base window that starts two bases in front of base a (the store's first two bases: the window at base 0 shifted down)
+__device__ __forceinline__ void s1_window_addr(uint64_t a, uint64_t &word, unsigned &sh, unsigned &down) {
+  const uint64_t b = a >= 2 ? a - 2 : 0;
+  word = b >> 4;
+  sh = (unsigned)(b & 15) * 2;
+  down = a >= 2 ? 0u : (unsigned)(2 - a) * 2;
+}
+template <bool FILTER>
+struct S1GenVarT {
+  const uint32_t *seq;
+  const uint64_t *start;  // [n_seqs + 1]
+  uint64_t n_seqs;
+  uint32_t per;           // item slots per read: max_len - k + 4
+  int k;
+  uint64_t pos_base;
+  uint32_t pos_bits;
+  uint32_t tile_q, tile_r;  // items of a tile (256 NI) divided by the slots per read: quotient and remainder
+  const uint32_t *keep;
+  static constexpr bool kMayDrop = true;
+  __device__ __forceinline__ bool is_record(const Rec<3> &r) const { return (r.w[1] & 63u) != 63u; }
+  template <int NI>
+  __device__ __forceinline__ uint64_t index(uint64_t tile_base, int w, int lane, int j) const {
+    return tile_base + (uint64_t)((w * kWave + lane) * NI + j);
+  }
+  template <int NI, int UT>
+  __device__ __forceinline__ void get_unit(uint64_t unit_base, int w, int lane, uint64_t n, Rec<3> (&rec)[UT][NI]) const {
+    static_assert(NI <= 8, "a run of NI items and their flanks inside one 32-base window");
+    constexpr uint32_t kTileItems = kSortThreads * NI;
+    const uint64_t g00 = unit_base + (uint64_t)((w * kWave + lane) * NI);
+    const int km1 = k - 1;
+    const uint64_t kmask = ~0ull << (64 - 2 * km1);
+    uint32_t jt[UT];   // slot of the thread's first item in tile t
+    uint64_t rt[UT];   // its read
+    {
+      const uint64_t r = g00 / per;
+      jt[0] = (uint32_t)(g00 - r * per);
+      rt[0] = r;
+#pragma unroll
+      for (int t = 1; t < UT; ++t) {
+        uint32_t jn = jt[t - 1] + tile_r;
+        uint64_t rn = rt[t - 1] + tile_q;
+        if (jn >= per) {
+          jn -= per;
+          ++rn;
+        }
+        jt[t] = jn;
+        rt[t] = rn;
+      }
+#pragma unroll
+      for (int t = 0; t < UT; ++t)
+        if (g00 + (uint64_t)t * kTileItems >= n) {  // nothing of this tile is this thread's: loads from the start of the store, nothing kept
+          jt[t] = 0;
+          rt[t] = 0;
+        }
+    }
+    uint64_t s0[UT], s1[UT], s2[UT];
+#pragma unroll
+    for (int t = 0; t < UT; ++t) {
+      s0[t] = start[rt[t]];
+      s1[t] = start[rt[t] + 1];
+      s2[t] = start[rt[t] + 2 < n_seqs ? rt[t] + 2 : n_seqs];
+    }
+    uint32_t c[UT][3], nx[UT][3];
+#pragma unroll
+    for (int t = 0; t < UT; ++t) {
+      const S1ReadGeo cur = s1_read_geo(s0[t], s1[t], k);
+      const uint32_t q0 = min(jt[t] > 0 ? jt[t] - 1 : 0u, cur.qlast);
+      uint64_t wcur, wnext;
+      unsigned sh, down;
+      s1_window_addr(cur.base + q0, wcur, sh, down);
+      s1_window_addr(s1[t], wnext, sh, down);
+#pragma unroll
+      for (int x = 0; x < 3; ++x) {
+        c[t][x] = seq[wcur + x];
+        nx[t][x] = seq[wnext + x];  // (the store is padded: also behind the last read)
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < UT; ++t) {
+      const uint64_t g0 = g00 + (uint64_t)t * kTileItems;
+      uint32_t j = jt[t];
+      S1ReadGeo rd = s1_read_geo(s0[t], s1[t], k);
+      const S1ReadGeo rdn = s1_read_geo(s1[t], s2[t], k);
+      uint32_t qrun = min(j > 0 ? j - 1 : 0u, rd.qlast);
+      uint64_t wd;
+      unsigned sh0, down0, shn, downn;
+      s1_window_addr(rd.base + qrun, wd, sh0, down0);
+      uint64_t W = (((uint64_t)funnel_l(c[t][0], c[t][1], sh0) << 32) | funnel_l(c[t][1], c[t][2], sh0)) >> down0;
+      uint64_t R = rc64(W, 32);
+      s1_window_addr(rdn.base, wd, shn, downn);
+      const uint64_t Wn = (((uint64_t)funnel_l(nx[t][0], nx[t][1], shn) << 32) | funnel_l(nx[t][1], nx[t][2], shn)) >> downn;
+      const uint64_t Rn = rc64(Wn, 32);
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const uint32_t q = min(j > 0 ? j - 1 : 0u, rd.qlast);
+        const int forced = j < 2 ? (int)j : (j >= rd.jf ? (int)(j - rd.jf) : -1);
+        const unsigned d2 = (q - qrun) * 2;  // offset inside the run's window, in bits
+        const uint64_t f = (W << (d2 + 4)) & kmask;
+        const uint64_t rc = (R << ((unsigned)(2 * (30 - km1)) - d2)) & kmask;
+        const unsigned head_b = (unsigned)(W >> (60 - d2)) & 3u, tail_b = (unsigned)(W >> ((unsigned)(58 - 2 * km1) - d2)) & 3u;
+        uint32_t out[3];
+        s1_item_from_parts(f, rc, head_b, tail_b, q, forced, rd.L, k, rd.base + q, pos_base, pos_bits, out);
+        if (j >= rd.cnt) out[1] = kS1Dropped;  // a slot this read does not fill
+        if constexpr (FILTER)
+          if (!s1_bucket_kept(keep, out[0])) out[1] = kS1Dropped;
+        if (g0 + (uint64_t)i < n) {
+          rec[t][i].w[0] = out[0];
+          rec[t][i].w[1] = out[1];
+          rec[t][i].w[2] = out[2];
+        }
+        if (++j == per) {
+          j = 0;
+          rd = rdn;
+          W = Wn;
+          R = Rn;
+          qrun = 0;
+        }
+      }
+    }
+  }
+};
+
 constexpr int kFastPasses = 4;
 // The digit histograms of the coming sort passes without making the records (the pre-pass of the generating first pass):
 // every thread takes IT CONSECUTIVE items — one division per trip, the three window words are reloaded only when the
@@ -706,10 +853,10 @@ __global__ __launch_bounds__(256) void k_s1_digit_hist_plain(const uint32_t *__r
 
 // The same histograms with the window arithmetic of S1GenRollT: one window and one reverse complement per run of a thread's IT
 // consecutive items (and one pair for the start of the next read), two shifts per item (k <= 23, >= IT slots per read).
-template <int IT, int NP>
+template <int IT, int NP, bool VAR = false>  // VAR: reads of any length, `per` item slots each, start[] says where they lie (S1GenVarT)
 __global__ __launch_bounds__(256) void k_s1_digit_hist_roll(const uint32_t *__restrict__ seq, uint32_t L, uint32_t per, uint64_t n_items, int k,
                                                             HiDigits hd, unsigned long long *__restrict__ ghist, uint32_t step_q, uint32_t step_r,
-                                                            const uint32_t *__restrict__ keep) {
+                                                            const uint32_t *__restrict__ keep, const uint64_t *__restrict__ start, uint64_t n_seqs) {
   static_assert(IT <= 8, "a run of IT items and their flanks inside one 32-base window");
   constexpr int B = 256 * IT;
   __shared__ uint32_t h[kFastPasses][4][256];
@@ -718,19 +865,13 @@ __global__ __launch_bounds__(256) void k_s1_digit_hist_roll(const uint32_t *__re
   const int wv = threadIdx.x >> 6;
   const int km1 = k - 1;
   const uint64_t kmask = ~0ull << (64 - 2 * km1);
-  const uint32_t qlast = L - k + 1, jf = L - k + 2;
   const unsigned rsh = (unsigned)(2 * (30 - km1));
   auto count = [&](uint32_t hi) {
     if (keep && !s1_bucket_kept(keep, hi)) return;
 #pragma unroll
     for (int p = 0; p < NP; ++p) atomicAdd(&h[p][wv][(hi >> hd.sh[p]) & hd.mk[p]], 1u);
   };
-  if (blockIdx.x == 0 && threadIdx.x == 0)
-    for (uint32_t j = 0; j < 3 && j < n_items; ++j) {  // (the items whose window would start before the store)
-      uint32_t out[3];
-      s1_make_item<2, 3, true>(seq, 0, L, k, j, 0, 32u, out);
-      count(out[0]);
-    }
+  // (the first two bases of the store need no case of their own: the window at base 0 shifted down, s1_window_addr)
   const uint64_t n_blocks = (n_items + B - 1) / B;
   uint64_t q0 = ((uint32_t)blockIdx.x * (uint32_t)B) / per;
   uint32_t rem0 = ((uint32_t)blockIdx.x * (uint32_t)B) % per;
@@ -738,35 +879,44 @@ __global__ __launch_bounds__(256) void k_s1_digit_hist_roll(const uint32_t *__re
     const uint64_t g0 = blk * B + (uint64_t)threadIdx.x * IT;
     const uint32_t t = rem0 + (uint32_t)threadIdx.x * IT, dq = t / per;
     uint32_t j = t - dq * per;
-    uint64_t base = (q0 + dq) * L;  // first base of the read
-    if (g0 >= n_items) {            // (nothing of this block is this thread's: loads from the start of the store, nothing counted)
+    uint64_t r = q0 + dq;  // the read
+    if (g0 >= n_items) {   // (nothing of this block is this thread's: loads from the start of the store, nothing counted)
       j = 0;
-      base = 0;
+      r = 0;
     }
-    uint32_t qrun = min(j > 0 ? j - 1 : 0u, qlast);
-    const uint64_t a0 = base + qrun, b0 = a0 >= 2 ? a0 - 2 : 0;
-    const uint64_t wcur = b0 >> 4, wnext = (base + L - 2) >> 4;
+    S1ReadGeo rd, rdn;
+    if constexpr (VAR) {
+      const uint64_t s0 = start[r], s1 = start[r + 1], s2 = start[r + 2 < n_seqs ? r + 2 : n_seqs];
+      rd = s1_read_geo(s0, s1, k);
+      rdn = s1_read_geo(s1, s2, k);
+    } else {
+      rd = s1_read_geo(r * L, r * L + L, k);
+      rdn = s1_read_geo(r * L + L, r * L + 2 * (uint64_t)L, k);
+    }
+    uint32_t qrun = min(j > 0 ? j - 1 : 0u, rd.qlast);
+    uint64_t wcur, wnext;
+    unsigned sh0, down0, shn, downn;
+    s1_window_addr(rd.base + qrun, wcur, sh0, down0);
+    s1_window_addr(rdn.base, wnext, shn, downn);
     const uint32_t c0 = seq[wcur], c1 = seq[wcur + 1], c2 = seq[wcur + 2];
     const uint32_t n0 = seq[wnext], n1 = seq[wnext + 1], n2 = seq[wnext + 2];
-    const unsigned sh0 = (unsigned)(b0 & 15) * 2, down0 = a0 >= 2 ? 0u : (unsigned)(2 - a0) * 2;
     uint64_t W = (((uint64_t)funnel_l(c0, c1, sh0) << 32) | funnel_l(c1, c2, sh0)) >> down0;
     uint64_t R = rc64(W, 32);
-    const unsigned shn = (unsigned)((base + L - 2) & 15) * 2;
-    const uint64_t Wn = ((uint64_t)funnel_l(n0, n1, shn) << 32) | funnel_l(n1, n2, shn);
+    const uint64_t Wn = (((uint64_t)funnel_l(n0, n1, shn) << 32) | funnel_l(n1, n2, shn)) >> downn;
     const uint64_t Rn = rc64(Wn, 32);
 #pragma unroll
     for (int u = 0; u < IT; ++u) {
-      const uint32_t q = min(j > 0 ? j - 1 : 0u, qlast);
-      const bool forced = j < 2 || j >= jf;
-      const uint32_t fstrand = j < 2 ? j : j - jf;
+      const uint32_t q = min(j > 0 ? j - 1 : 0u, rd.qlast);
+      const bool forced = j < 2 || j >= rd.jf;
+      const uint32_t fstrand = j < 2 ? j : j - rd.jf;
       const unsigned d2 = (q - qrun) * 2;
       const uint64_t f = (W << (d2 + 4)) & kmask;
       const uint64_t rc = (R << (rsh - d2)) & kmask;
       const bool use_rc = forced ? fstrand == 1 : f > rc;  // (f == rc: the same first word either way)
-      if (g0 + u < n_items && base + q >= 2) count((uint32_t)((use_rc ? rc : f) >> 32));
+      if (g0 + u < n_items && j < rd.cnt) count((uint32_t)((use_rc ? rc : f) >> 32));
       if (++j == per) {
         j = 0;
-        base += L;
+        rd = rdn;
         W = Wn;
         R = Rn;
         qrun = 0;
@@ -895,9 +1045,94 @@ __global__ __launch_bounds__(1024) void k_s1_bucket_hist_fast(const uint32_t *__
   for (int i = threadIdx.x; i < NB; i += NT)
     if (h[i]) atomicAdd(&ghist[half * NB + i], (unsigned long long)h[i]);
 }
+// the same histogram for a library of reads of any length: `per` item slots per read, start[] says where the reads lie (S1GenVarT)
+template <int IT>
+__global__ __launch_bounds__(1024) void k_s1_bucket_hist_var(const uint32_t *__restrict__ seq, const uint64_t *__restrict__ start, uint64_t n_seqs,
+                                                             uint32_t per, uint64_t n_slots, int k, unsigned long long *__restrict__ ghist, uint32_t step_q,
+                                                             uint32_t step_r, uint32_t half) {
+  static_assert(IT <= 8, "a run of IT items and their flanks inside one 32-base window");
+  constexpr int NT = 1024, B = NT * IT, NB = MHX_NUM_BUCKETS / 2;
+  __shared__ uint32_t h[NB];
+  for (int i = threadIdx.x; i < NB; i += NT) h[i] = 0;
+  __syncthreads();
+  const int km1 = k - 1;
+  const uint64_t kmask = ~0ull << (64 - 2 * km1);
+  const unsigned rsh = (unsigned)(2 * (30 - km1));
+  const uint64_t n_blocks = (n_slots + B - 1) / B;
+  uint64_t q0 = ((uint64_t)blockIdx.x * (uint64_t)B) / per;
+  uint32_t rem0 = (uint32_t)(((uint64_t)blockIdx.x * (uint64_t)B) % per);
+  for (uint64_t blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
+    const uint64_t g0 = blk * B + (uint64_t)threadIdx.x * IT;
+    const uint32_t t = rem0 + (uint32_t)threadIdx.x * IT, dq = t / per;
+    uint32_t j = t - dq * per;
+    uint64_t r = q0 + dq;
+    if (g0 >= n_slots) {  // (nothing of this block is this thread's: loads from the start of the store, nothing counted)
+      j = 0;
+      r = 0;
+    }
+    const uint64_t s0 = start[r], s1 = start[r + 1], s2 = start[r + 2 < n_seqs ? r + 2 : n_seqs];
+    S1ReadGeo rd = s1_read_geo(s0, s1, k);
+    const S1ReadGeo rdn = s1_read_geo(s1, s2, k);
+    uint32_t qrun = min(j > 0 ? j - 1 : 0u, rd.qlast);
+    uint64_t wcur, wnext;
+    unsigned sh0, down0, shn, downn;
+    s1_window_addr(rd.base + qrun, wcur, sh0, down0);
+    s1_window_addr(rdn.base, wnext, shn, downn);
+    const uint32_t c0 = seq[wcur], c1 = seq[wcur + 1], c2 = seq[wcur + 2];
+    const uint32_t n0 = seq[wnext], n1 = seq[wnext + 1], n2 = seq[wnext + 2];
+    uint64_t W = (((uint64_t)funnel_l(c0, c1, sh0) << 32) | funnel_l(c1, c2, sh0)) >> down0;
+    uint64_t R = rc64(W, 32);
+    const uint64_t Wn = (((uint64_t)funnel_l(n0, n1, shn) << 32) | funnel_l(n1, n2, shn)) >> downn;
+    const uint64_t Rn = rc64(Wn, 32);
+#pragma unroll
+    for (int u = 0; u < IT; ++u) {
+      const uint32_t q = min(j > 0 ? j - 1 : 0u, rd.qlast);
+      const bool forced = j < 2 || j >= rd.jf;
+      const uint32_t fstrand = j < 2 ? j : j - rd.jf;
+      const unsigned d2 = (q - qrun) * 2;
+      const uint64_t f = (W << (d2 + 4)) & kmask;
+      const uint64_t rc = (R << (rsh - d2)) & kmask;
+      const bool use_rc = forced ? fstrand == 1 : f > rc;
+      if (g0 + u < n_slots && j < rd.cnt) {
+        const uint32_t b = (uint32_t)((use_rc ? rc : f) >> 48);
+        if ((b >> 15) == half) atomicAdd(&h[b & (NB - 1)], 1u);
+      }
+      if (++j == per) {
+        j = 0;
+        rd = rdn;
+        W = Wn;
+        R = Rn;
+        qrun = 0;
+      }
+    }
+    q0 += step_q;
+    rem0 += step_r;
+    if (rem0 >= per) {
+      rem0 -= per;
+      ++q0;
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < NB; i += NT)
+    if (h[i]) atomicAdd(&ghist[half * NB + i], (unsigned long long)h[i]);
+}
 // -> true when it ran (fixed-length reads, 12-byte compact records); hist: device, 65 536 counters, zeroed by the caller
+static bool s1_shape_is_var_fast(const mhx_ctx *c, uint32_t k, bool compact);
 bool s1_bucket_histogram_fast(mhx_ctx *c, uint32_t k, unsigned long long *hist) {
   SeqSet &s = c->seqs;
+  if (c->opt("s1_bucket_hist_fast", 1) && s1_shape_is_var_fast(c, k, s1_compact(c, k, 0))) {  // reads of any length: padded item slots
+    constexpr int ITV = 8;
+    const uint32_t per = s.max_len - k + 4;
+    const uint64_t n_slots = s.n_seqs * (uint64_t)per;
+    const uint64_t cus = c->n_cus > 0 ? (uint64_t)c->n_cus : 256;
+    const unsigned grid = (unsigned)std::min<uint64_t>(div_ceil(n_slots, 1024 * ITV), cus);
+    const uint64_t stride_items = (uint64_t)grid * 1024 * ITV;
+    for (uint32_t half = 0; half < 2; ++half)
+      MHX_LAUNCH(c, "s1_bucket_hist", (double)s.n_bases / 4 + (double)s.n_seqs * 8,
+                 hipLaunchKernelGGL((k_s1_bucket_hist_var<ITV>), dim3(grid), dim3(1024), 0, c->stream, s.words.as<uint32_t>(), s.start.as<uint64_t>(), s.n_seqs,
+                                    per, n_slots, (int)k, hist, (uint32_t)(stride_items / per), (uint32_t)(stride_items % per), half));
+    return true;
+  }
   if (!c->opt("s1_bucket_hist_fast", 1) || !s.n_seqs || s.fixed_len < k + 1 || !s1_compact(c, k, 0) || (2 * (k - 1) + 6 + 31) / 32 != 2 || k > 29) return false;  // (two key words)
   constexpr int IT = 8;
   const uint32_t per = s.fixed_len - k + 4;
@@ -2960,12 +3195,24 @@ static bool s1_shape_is_fast(const mhx_ctx *c, uint32_t k, bool compact) {
   const SeqSet &s = c->seqs;
   return s.n_seqs && s.fixed_len >= k + 1 && compact && s1_kw(k) == 2 && s1_stride(k, compact) == 3 && k <= 29 && c->opt("s1_extract_fast", 1) != 0;
 }
+// The same front for a library whose reads are NOT of one length (S1GenVarT): item slots padded to the longest read's count.  Taken
+// while at least half of the slots are real records (s1_var_min_fill per cent) — beyond that the extraction kernel + loaded passes
+// cost less than generating dropped slots.
+static bool s1_shape_is_var_fast(const mhx_ctx *c, uint32_t k, bool compact) {
+  const SeqSet &s = c->seqs;
+  if (!s.n_seqs || s.fixed_len || s.max_len < k + 1 || s.max_len - k + 4 < 8 || !compact || s1_kw(k) != 2 || s1_stride(k, compact) != 3 || (int)k > kS1RollMaxK) return false;
+  if (!c->opt("s1_extract_fast", 1) || !c->opt("s1_var_fast", 1)) return false;
+  const double fill = (double)s.n_bases / ((double)s.n_seqs * s.max_len);
+  return fill * 100.0 >= (double)c->opt("s1_var_min_fill", 50);
+}
 // can a bucket filter be applied inside the generating first pass (instead of extraction batches + a keep/drop split)?
 bool s1_filter_in_gen_applies(const mhx_ctx *c, uint32_t k) {
   const bool compact = s1_compact(c, k, 0);
-  if (!c->filter_on || !c->opt("s1_filter_in_gen", 1) || !s1_shape_is_fast(c, k, compact) || !c->opt("s1_fused_first_pass", 1)) return false;
+  const bool var = s1_shape_is_var_fast(c, k, compact);
+  if (!c->filter_on || !c->opt("s1_filter_in_gen", 1) || !(s1_shape_is_fast(c, k, compact) || var) || !c->opt("s1_fused_first_pass", 1)) return false;
   if (!c->opt("s1_digit_hist_blocked", 1) || !c->opt("s1_digit_hist_plain", 1) || !c->opt("s1_gen_any_order", 1) || !c->opt("sort_unit_runs", 1)) return false;
-  const uint64_t n_slots = (uint64_t)c->seqs.n_seqs * (c->seqs.fixed_len - k + 4);
+  if (var && !(c->opt("s1_gen_blocked", 0) && c->opt("s1_gen_roll", 1) && c->opt("s1_digit_hist_roll", 1))) return false;
+  const uint64_t n_slots = (uint64_t)c->seqs.n_seqs * ((var ? c->seqs.max_len : c->seqs.fixed_len) - k + 4);
   const S1Plan plan = s1_plan(c, k, n_slots, compact, 0);
   // (the plans whose digits are bit fields of the first key word: the prefix plans)
   return plan.seg_bits > 0 && (int)plan.passes.size() <= kFastPasses && sort_takes_generated_first_pass(c, std::max<uint64_t>(c->filter_expected, 1), 3, plan.passes);
@@ -2982,7 +3229,12 @@ uint64_t s1_extract(mhx_ctx *c, uint32_t k, bool compact) {
   uint32_t *cnt = c->ws("seq_item_cnt", (ns + 1) * 4).as<uint32_t>();
   uint64_t *item_start = c->ws("seq_item_start", (ns + 2) * 8).as<uint64_t>();
   uint64_t n_items = 0;
-  const bool shape_fast = s1_shape_is_fast(c, k, compact);
+  // reads of any length on the generating pass (S1GenVarT): only as deferred items — there is no extraction kernel of that form
+  const bool var_fast = s1_shape_is_var_fast(c, k, compact) && (filter_in_gen || c->s1_defer_items) && c->opt("s1_fused_first_pass", 1) &&
+                        c->opt("s1_gen_blocked", 0) && c->opt("s1_gen_roll", 1) && c->opt("s1_digit_hist_roll", 1) && c->opt("s1_digit_hist_blocked", 1) &&
+                        c->opt("s1_digit_hist_plain", 1) && c->opt("s1_gen_any_order", 1) && c->opt("sort_unit_runs", 1);
+  c->s1_var_gen = false;
+  const bool shape_fast = s1_shape_is_fast(c, k, compact) || var_fast;
   if (ns && shape_fast && s.fixed_len >= k + 1) {
     n_items = ns * (uint64_t)(s.fixed_len - k + 4);  // (no per-read table for reads of one length)
   } else if (ns) {
@@ -2999,6 +3251,9 @@ uint64_t s1_extract(mhx_ctx *c, uint32_t k, bool compact) {
   if (n_items) {
     const unsigned grid = 256 * 8;
     const bool fixed = s.fixed_len >= k + 1 && n_items == (uint64_t)ns * (s.fixed_len - k + 4);
+    // item slots the generating pass walks: the records of a fixed-length library, max_len - k + 4 per read otherwise
+    const uint32_t per_slots = var_fast ? s.max_len - k + 4 : (fixed ? s.fixed_len - k + 4 : 0u);
+    const uint64_t n_slots = var_fast ? ns * (uint64_t)per_slots : n_items;
     const uint64_t pos_base = c->pos_base;
     const uint32_t pos_bits = s1_pos_bits(c);
     // the stage-1 sort's digit histograms come for free while the records are still in registers (fixed-length path)
@@ -3007,7 +3262,7 @@ uint64_t s1_extract(mhx_ctx *c, uint32_t k, bool compact) {
     unsigned long long *pre_hist = nullptr;
     c->pre_hist_buf = nullptr;
     std::vector<SortPass> plan_passes;
-    if (fixed && S <= 4) {
+    if ((fixed || var_fast) && S <= 4) {
       plan_passes = s1_plan(c, k, n_items, compact, compact ? 0 : 1).passes;
       if ((int)plan_passes.size() <= kMaxFusedPasses) {
         c->pre_hist_sig = passes_signature(plan_passes);
@@ -3020,14 +3275,25 @@ uint64_t s1_extract(mhx_ctx *c, uint32_t k, bool compact) {
         c->pre_hist_passes = specs.n;
       }
     }
-    const bool fast = fixed && shape_fast && specs.n <= kFastPasses;
+    // (a variable-length library whose plan or sort cannot take the generated pass goes the general way below)
+    bool first_word_digits = true;
+    for (int p = 0; p < specs.n; ++p) first_word_digits = first_word_digits && specs.d[p].wi1 == 0 && specs.d[p].mask2 == 0 && specs.d[p].bit1 < 32;
+    const bool var_ok = var_fast && pre_hist && specs.n >= 1 && specs.n <= kFastPasses && first_word_digits &&
+                        (filter_in_gen || sort_takes_generated_first_pass(c, n_items, 3, plan_passes));
+    if (var_fast && !var_ok) {
+      if (filter_in_gen) throw Error("s1_extract: the bucket filter was left to a generating pass that does not apply");
+      specs.n = 0;
+      pre_hist = nullptr;
+      c->pre_hist_buf = nullptr;
+    }
+    const bool fast = (fixed || var_ok) && shape_fast && specs.n <= kFastPasses;
     if (fast) {
       const int it = (int)c->opt("s1_extract_items", 4);
-      const uint32_t per = s.fixed_len - k + 4;
+      const uint32_t per = per_slots;
       // Deferred items: the caller sorts right away (run_s1, the multi-GPU pre-sort), so only the digit histograms are taken
       // here and the first sort pass makes the records itself (S1Gen): "items_a" stays empty until that pass has run.
-      const bool defer = filter_in_gen || (c->s1_defer_items && pre_hist && c->opt("s1_fused_first_pass", 1) &&
-                                           sort_takes_generated_first_pass(c, n_items, 3, plan_passes));
+      const bool defer = filter_in_gen || var_ok || (c->s1_defer_items && pre_hist && c->opt("s1_fused_first_pass", 1) &&
+                                                      sort_takes_generated_first_pass(c, n_items, 3, plan_passes));
 #define MHX_FAST(ITV, WR, NAME)                                                                                                        \
   do {                                                                                                                                 \
     const unsigned fgrid = (unsigned)std::min<uint64_t>(div_ceil(n_items, 256 * ITV), 256 * 8);                                        \
@@ -3051,7 +3317,7 @@ uint64_t s1_extract(mhx_ctx *c, uint32_t k, bool compact) {
         if (filter_in_gen && !plain) throw Error("s1_extract: the bucket filter was left to a generating pass that does not apply");
         if (hi_only && c->opt("s1_digit_hist_blocked", 1)) {
           constexpr int ITH = 8;
-          const unsigned fgrid = (unsigned)std::min<uint64_t>(div_ceil(n_items, 256 * ITH), 256 * 8);
+          const unsigned fgrid = (unsigned)std::min<uint64_t>(div_ceil(n_slots, 256 * ITH), 256 * 8);
           const uint64_t stride_items = (uint64_t)fgrid * 256 * ITH;
 #define MHX_PLAIN2(NPV, PREV)                                                                                                                \
   MHX_LAUNCH(c, "s1_digit_hist", (double)s.n_bases / 4,                                                                                      \
@@ -3062,10 +3328,22 @@ uint64_t s1_extract(mhx_ctx *c, uint32_t k, bool compact) {
 #define MHX_ROLL(NPV)                                                                                                                       \
   MHX_LAUNCH(c, "s1_digit_hist", (double)s.n_bases / 4,                                                                                      \
              hipLaunchKernelGGL((k_s1_digit_hist_roll<ITH, NPV>), dim3(fgrid), dim3(256), 0, st, s.words.as<uint32_t>(), s.fixed_len, per,  \
-                                n_items, (int)k, hd, pre_hist, (uint32_t)(stride_items / per), (uint32_t)(stride_items % per), keep))
+                                n_items, (int)k, hd, pre_hist, (uint32_t)(stride_items / per), (uint32_t)(stride_items % per), keep,         \
+                                (const uint64_t *)nullptr, ns))
+#define MHX_ROLL_VAR(NPV)                                                                                                                   \
+  MHX_LAUNCH(c, "s1_digit_hist", (double)s.n_bases / 4 + (double)ns * 8,                                                                     \
+             hipLaunchKernelGGL((k_s1_digit_hist_roll<ITH, NPV, true>), dim3(fgrid), dim3(256), 0, st, s.words.as<uint32_t>(), 0u, per,     \
+                                n_slots, (int)k, hd, pre_hist, (uint32_t)(stride_items / per), (uint32_t)(stride_items % per), keep,         \
+                                s.start.as<uint64_t>(), ns))
           // s1_digit_hist_roll: one window + one reverse complement per run of a thread's eight items (k <= 23, >= 8 slots per read)
           const bool hroll = plain && per >= 8 && (int)k <= kS1RollMaxK && c->opt("s1_digit_hist_roll", 1) != 0;
-          if (hroll && specs.n == 1) MHX_ROLL(1);
+          if (var_ok && !(hroll && plain)) throw Error("s1_extract: the variable-length generating pass met a plan it cannot count");
+          if (var_ok && specs.n == 1) MHX_ROLL_VAR(1);
+          else if (var_ok && specs.n == 2) MHX_ROLL_VAR(2);
+          else if (var_ok && specs.n == 3) MHX_ROLL_VAR(3);
+          else if (var_ok && specs.n == 4) MHX_ROLL_VAR(4);
+#undef MHX_ROLL_VAR
+          else if (hroll && specs.n == 1) MHX_ROLL(1);
           else if (hroll && specs.n == 2) MHX_ROLL(2);
           else if (hroll && specs.n == 3) MHX_ROLL(3);
           else if (hroll && specs.n == 4) MHX_ROLL(4);
@@ -3082,6 +3360,7 @@ uint64_t s1_extract(mhx_ctx *c, uint32_t k, bool compact) {
                        hipLaunchKernelGGL((k_s1_digit_hist<ITH>), dim3(fgrid), dim3(256), 0, st, s.words.as<uint32_t>(), s.fixed_len, per, n_items,
                                           (int)k, specs, pre_hist, (uint32_t)(stride_items / per), (uint32_t)(stride_items % per)));
         } else {
+          if (var_ok) throw Error("s1_extract: the variable-length generating pass needs the blocked digit histogram");
           MHX_FAST(4, false, "s1_digit_hist");
         }
         uint64_t n_records = n_items;  // what the generating pass will leave
@@ -3110,18 +3389,28 @@ uint64_t s1_extract(mhx_ctx *c, uint32_t k, bool compact) {
                                       (uint32_t)(kSortThreads * 8) % per, keep};
         // s1_gen_roll: the blocked generator with one window + one reverse complement per run of a thread's items (k <= 23)
         const bool roll = blocked && (int)k <= kS1RollMaxK && c->opt("s1_gen_roll", 1) != 0;
+        if (var_ok && !roll) throw Error("s1_extract: the variable-length generating pass needs s1_gen_blocked and s1_gen_roll");
+        c->s1_var_gen = var_ok;
+        const S1GenVarT<false> gv{s.words.as<uint32_t>(), s.start.as<uint64_t>(), ns, per, (int)k, pos_base, pos_bits, (uint32_t)(kSortThreads * 8) / per,
+                                  (uint32_t)(kSortThreads * 8) % per, nullptr};
+        const S1GenVarT<true> gvf{s.words.as<uint32_t>(), s.start.as<uint64_t>(), ns, per, (int)k, pos_base, pos_bits, (uint32_t)(kSortThreads * 8) / per,
+                                  (uint32_t)(kSortThreads * 8) % per, keep};
         const S1GenRollT<false> gr{s.words.as<uint32_t>(), s.fixed_len, per, (int)k, pos_base, pos_bits, (uint32_t)(kSortThreads * 8) / per,
                                    (uint32_t)(kSortThreads * 8) % per, nullptr};
         const S1GenRollT<true> grf{s.words.as<uint32_t>(), s.fixed_len, per, (int)k, pos_base, pos_bits, (uint32_t)(kSortThreads * 8) / per,
                                    (uint32_t)(kSortThreads * 8) % per, keep};
-        c->gen_first_pass = [g, gf, gb, gbf, gr, grf, roll, any_order, blocked, filter_in_gen](const OnesweepLaunch &l) {
+        c->gen_first_pass = [g, gf, gb, gbf, gr, grf, gv, gvf, var_ok, roll, any_order, blocked, filter_in_gen](const OnesweepLaunch &l) {
 #define MHX_GEN(KERNEL, SRCT, RANKV, SRCV)                                                                                              \
   hipLaunchKernelGGL((KERNEL<3, 8, 3, SRCT, RANKV>), dim3(l.grid), dim3(kSortThreads), 0, l.stream, SRCV, l.out, l.n, l.ds, l.nbits, l.bin_start, \
                      l.status, l.ticket, l.err, l.tag, l.xcd_units)
 #define MHX_GEN_U(SRCT, RANKV, SRCV)                                                                                                    \
   hipLaunchKernelGGL((k_radix_onesweep_u<3, 8, 3, SRCT, RANKV, 0>), dim3(l.grid), dim3(kSortThreads), 0, l.stream, SRCV, l.out, l.n, l.ds, l.nbits, \
                      l.bin_start, l.status, l.ticket, l.err, l.tag, l.xcd_units)
-          if (filter_in_gen) {  // (s1_filter_in_gen_applies vouched for unit-wide runs, digits in the first key word, any order)
+          if (var_ok) {  // reads of any length: item slots padded to the longest read's, the slots a read does not fill declined
+            if (!(l.unit_runs && l.wi == 0 && any_order)) throw Error("s1: the variable-length generator needs the unit-wide pass on a first-word digit");
+            if (filter_in_gen) MHX_GEN_U(S1GenVarT<true>, 1, gvf);
+            else MHX_GEN_U(S1GenVarT<false>, 1, gv);
+          } else if (filter_in_gen) {  // (s1_filter_in_gen_applies vouched for unit-wide runs, digits in the first key word, any order)
             if (!(l.unit_runs && l.wi == 0 && any_order)) throw Error("s1: the filtering generator needs the unit-wide pass on a first-word digit");
             if (roll) MHX_GEN_U(S1GenRollT<true>, 1, grf);
             else if (blocked) MHX_GEN_U(S1GenBlockedT<true>, 1, gbf);
@@ -3137,7 +3426,7 @@ uint64_t s1_extract(mhx_ctx *c, uint32_t k, bool compact) {
         };
         c->gen_buf = buf_a;
         c->gen_n = n_records;
-        c->gen_slots = n_items;
+        c->gen_slots = n_slots;
         if (n_records == 0) c->gen_first_pass = nullptr;  // (a pass or rank that keeps no record: no sort will come and consume it)
         n_items = n_records;
       } else if (it >= 8) MHX_FAST(8, true, "s1_extract");
@@ -3677,6 +3966,8 @@ int s1_process(mhx_ctx *c, uint32_t k, uint32_t m, int want_mercy, uint32_t *buf
                mhx_s1_result *out, const S1Sources *pre) {
   S1Stage stage(c, k, m, want_mercy, buf_a, buf_b, n_items, pre);
   c->last_s1_plan = s1_plan_text(c, k, n_items);
+  if (c->s1_var_gen) c->last_s1_plan += " [reads of several lengths: " + std::to_string(c->seqs.max_len - k + 4) + " item slots per read on the generating pass]";
+  c->s1_var_gen = false;
   stage.sort_records();
   stage.open_outputs();
   if (n_items) {

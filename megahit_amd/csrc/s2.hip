@@ -520,7 +520,7 @@ struct SdbgFastP {
   int is_seq, wpt, k, ref_kw;
   int halo;                         // records staged either side of the tile (<= kSdbgFastHalo; tests shrink it)
 };
-constexpr int kSdbgFastT = 2048, kSdbgFastPer = kSdbgFastT / 256, kSdbgFastHalo = 128;
+constexpr int kSdbgFastHalo = 128;
 
 __device__ __forceinline__ unsigned long long sdbg_ld64(const uint2 *__restrict__ items, long long i) {
   const uint2 r = items[i];
@@ -623,11 +623,11 @@ __device__ __forceinline__ bool sdbg_decide(uint32_t M, int a, int b, int &w, in
   return true;
 }
 
-template <bool EMIT>
+template <bool EMIT, int T>  // T records per workgroup (256 threads)
 __global__ __launch_bounds__(256) void k_sdbg_fast(const uint2 *__restrict__ items, long long n, SdbgFastP P, uint64_t *__restrict__ tile_tot,
                                                    const uint64_t *__restrict__ tile_base, uint64_t n_tiles, uint16_t *__restrict__ out16,
                                                    unsigned long long *__restrict__ w_count, unsigned long long *__restrict__ bstart) {
-  constexpr int T = kSdbgFastT, PER = kSdbgFastPer, H = kSdbgFastHalo, NW = 256 / kWave;
+  constexpr int PER = T / 256, H = kSdbgFastHalo, NW = 256 / kWave;
   __shared__ unsigned long long win[T + 2 * H];  // win[H + i] = record base + i
   // what a run head found out, per record of the tile: flags | W << 4 | multiplicity << 12 (0 = not a run head).  Kept in LDS,
   // not in registers: the loops over a thread's records stay rolled and the kernel small (eight waves per SIMD instead of three
@@ -929,23 +929,36 @@ static void emit_sdbg_impl(mhx_ctx *c, const uint32_t *sorted, uint64_t n_items,
       F.k = P.k;
       F.ref_kw = P.ref_kw;
       F.halo = (int)std::min<long long>(kSdbgFastHalo, std::max<long long>(1, c->opt("sdbg_fast_halo", kSdbgFastHalo)));
-      const uint64_t n_ft = div_ceil(n_items, (uint64_t)kSdbgFastT);
+      const int ft = (int)c->opt("sdbg_fast_tile", 2048);  // records per workgroup: 1024 | 2048 | 4096
+      const uint64_t ftile = ft == 1024 ? 1024 : (ft == 4096 ? 4096 : 2048);
+      const uint64_t n_ft = div_ceil(n_items, ftile);
       uint64_t *ftt = c->ws("tile_tot", (3 * n_ft + 4) * 8).as<uint64_t>();
       uint64_t *ftb = c->ws("tile_base", (3 * n_ft + 4) * 8).as<uint64_t>();
       const uint2 *recs = reinterpret_cast<const uint2 *>(sorted);
-      MHX_LAUNCH(c, "sdbg_count", bytes,
-                 hipLaunchKernelGGL((k_sdbg_fast<false>), dim3((unsigned)n_ft), dim3(256), 0, st, recs, (long long)n_items, F, ftt,
-                                    (const uint64_t *)nullptr, n_ft, (uint16_t *)nullptr, w_count, bstart));
+      uint16_t *out16 = nullptr;
+      uint64_t out_bytes = 0;
+#define MHX_SDBG_FAST(EMITV, NAME, BYTES, TT, TB)                                                                                          \
+  do {                                                                                                                                     \
+    if (ftile == 1024)                                                                                                                     \
+      MHX_LAUNCH(c, NAME, BYTES, hipLaunchKernelGGL((k_sdbg_fast<EMITV, 1024>), dim3((unsigned)n_ft), dim3(256), 0, st, recs, (long long)n_items, F, TT, TB, \
+                                                    n_ft, out16, w_count, bstart));                                                        \
+    else if (ftile == 4096)                                                                                                                \
+      MHX_LAUNCH(c, NAME, BYTES, hipLaunchKernelGGL((k_sdbg_fast<EMITV, 4096>), dim3((unsigned)n_ft), dim3(256), 0, st, recs, (long long)n_items, F, TT, TB, \
+                                                    n_ft, out16, w_count, bstart));                                                        \
+    else                                                                                                                                   \
+      MHX_LAUNCH(c, NAME, BYTES, hipLaunchKernelGGL((k_sdbg_fast<EMITV, 2048>), dim3((unsigned)n_ft), dim3(256), 0, st, recs, (long long)n_items, F, TT, TB, \
+                                                    n_ft, out16, w_count, bstart));                                                        \
+  } while (0)
+      MHX_SDBG_FAST(false, "sdbg_count", bytes, ftt, (const uint64_t *)nullptr);
       for (int r = 0; r < 3; ++r) exclusive_scan_u64(c, ftt + r * n_ft, ftb + r * n_ft, n_ft, d_tot + r);
       MHX_HIP(hipMemcpyAsync(tot, d_tot, 24, hipMemcpyDeviceToHost, st));
       MHX_HIP(hipStreamSynchronize(st));
-      const uint64_t out_bytes = 2 * (tot[0] + tot[2]) + 4ull * P.wpt * tot[1];
-      uint16_t *out16 = c->result(MHX_BUF_SDBG_BYTES, out_bytes ? out_bytes : 2).as<uint16_t>();
+      out_bytes = 2 * (tot[0] + tot[2]) + 4ull * P.wpt * tot[1];
+      out16 = c->result(MHX_BUF_SDBG_BYTES, out_bytes ? out_bytes : 2).as<uint16_t>();
       c->results[MHX_BUF_SDBG_BYTES].used = out_bytes;
       MHX_HIP(hipMemsetAsync(bstart, 0xFF, 3 * MHX_NUM_BUCKETS * 8, st));
-      MHX_LAUNCH(c, "sdbg_emit", bytes + (double)out_bytes,
-                 hipLaunchKernelGGL((k_sdbg_fast<true>), dim3((unsigned)n_ft), dim3(256), 0, st, recs, (long long)n_items, F, (uint64_t *)nullptr,
-                                    (const uint64_t *)ftb, n_ft, out16, w_count, bstart));
+      MHX_SDBG_FAST(true, "sdbg_emit", bytes + (double)out_bytes, (uint64_t *)nullptr, (const uint64_t *)ftb);
+#undef MHX_SDBG_FAST
       uint32_t *block_first = c->ws("bucket_block_first", MHX_NUM_BUCKETS / 256 * 4).as<uint32_t>();
       hipLaunchKernelGGL(k_bucket_first, dim3(MHX_NUM_BUCKETS / 256), dim3(256), 0, st, bstart, block_first);
       MHX_LAUNCH(c, "bucket_stats", (double)MHX_NUM_BUCKETS * 56,

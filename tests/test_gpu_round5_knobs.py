@@ -62,3 +62,50 @@ def test_bucket_histogram_forms_agree(engine, roll):
         engine.set_option("s1_bucket_hist_fast", 1)
         engine.set_option("s1_digit_hist_roll", 1)
     assert np.array_equal(fast, slow)
+
+
+def var_library(kind, seed):
+    """libraries whose reads are not of one length: `trim` = reads of 100 bases, every one cut to U[60, 100]; `few` = 2 % of the reads
+    cut (N-trimmed reads of a real library); `edge` = reads of length 0, 1, k - 1, k, k + 1, k + 4 and long ones mixed, an empty read first"""
+    rng = np.random.default_rng(seed)
+    reads = fixed_library("repeats100" if kind == "few" else "pe100", seed)
+    if kind == "trim":
+        return [r[: int(rng.integers(60, 101))] for r in reads]
+    if kind == "few":
+        return [r[: int(rng.integers(30, 100))] if rng.random() < 0.02 else r for r in reads]
+    if kind == "edge":
+        out = [np.zeros(0, dtype=np.uint8)]
+        for i, r in enumerate(reads[:1500]):
+            out.append(r[: [0, 1, 20, 21, 22, 25, 100, 100, 100, 100][i % 10]])
+        return out
+    raise ValueError(kind)
+
+
+@pytest.mark.parametrize("var_fast", [1, 0])
+@pytest.mark.parametrize("kind,k,m", [("trim", 21, 2), ("few", 21, 2), ("edge", 21, 2), ("trim", 17, 3), ("few", 23, 2), ("trim", 24, 2), ("edge", 13, 2)])
+def test_reads_of_several_lengths_on_the_generating_pass(engine, kind, k, m, var_fast):
+    """S1GenVarT: item slots padded to the longest read's, the slots a read does not fill declined — against the oracle and against
+    the extraction kernel (s1_var_fast = 0); k = 24 is beyond the run form and takes the extraction kernel either way"""
+    reads = var_library(kind, seed=k + m)
+    pkg = ob.Package(reads, reverse=True)
+    load(engine, pkg)
+    want1 = ob.s1(pkg, k, m, tie_stable=True)
+    want2 = ob.s2(pkg, k, m, want1["is_solid"])
+    try:
+        engine.set_option("s1_gen_blocked", 1)
+        engine.set_option("s1_var_fast", var_fast)
+        engine.set_option("s1_var_min_fill", 10)  # (the edge library is mostly short reads: take the padded form anyway)
+        hist = engine.bucket_histogram(lib.STAGE_S1, k, m)
+        assert int(hist.sum()) == want1["n_items"]
+        r1 = engine.read2sdbg_s1(k, m)
+        assert ("item slots per read on the generating pass" in engine.last_s1_plan()) == bool(var_fast and 17 <= k <= 23), engine.last_s1_plan()  # (k = 13: a full-sort plan, whose digits leave the first key word)
+        solid = engine.fetch(lib.BUF_IS_SOLID, np.uint64)
+        assert r1.n_items == want1["n_items"]
+        assert np.array_equal(solid, want1["is_solid"][: solid.size])
+        assert np.array_equal(engine.fetch(lib.BUF_MUL_HIST, np.int64), want1["hist"])
+        check_sdbg(engine, engine.read2sdbg_s2(k, m), want2)
+    finally:
+        from test_gpu_round3_knobs import engine_default
+        engine.set_option("s1_gen_blocked", engine_default(engine, "s1_gen_blocked"))
+        engine.set_option("s1_var_fast", 1)
+        engine.set_option("s1_var_min_fill", 50)
