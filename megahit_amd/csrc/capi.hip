@@ -142,6 +142,8 @@ void upload_sequences(mhx_ctx *c, const uint32_t *packed, uint64_t n_words, uint
       if (L > mx) mx = (uint32_t)L;
     }
     s.max_len = mx;
+    // (a start array that describes reads of ONE length is a fixed-length library: the paths that need no per-read table)
+    if (n_seqs && start_pos[0] == 0 && s.n_bases == (uint64_t)mx * n_seqs) s.fixed_len = mx;
   } else {
     hipLaunchKernelGGL(k_fixed_starts, dim3((unsigned)div_ceil(n_seqs + 1, 256)), dim3(256), 0, st, s.start.as<uint64_t>(), n_seqs,
                        fixed_len);

@@ -922,8 +922,77 @@ void count_apply_events(mhx_ctx *c, const unsigned long long *ev, uint64_t n) {
   MHX_HIP(hipStreamSynchronize(st));
 }
 
+// count on the design of stage 1 (round 5; s1.hip: the first sort pass makes 12-byte records, two prefix passes, LDS group-by per
+// bucket with the has_in / has_out evidence in the table, first_0_out / last_0_in from a second look at the few buckets that
+// hold a solid key without an in- or out-edge).  -> false: that form gave up; nothing is published, the caller runs the
+// extraction + tile path.  Reference: KmerCounter::Lv2ExtractSubString + Lv2Postprocess (kmer_counter.cpp:208-381).
+static bool count_run_stream(mhx_ctx *c, uint32_t k, uint32_t m, mhx_count_result *out) {
+  SeqSet &s = c->seqs;
+  hipStream_t st = c->stream;
+  const uint64_t ns = s.n_seqs;
+  const int wpe = (int)div_ceil((k + 1) * 2 + 16, 32);
+  const int key_bits = (int)(k + 1) * 2;
+  c->count_acc_k = k;
+  c->count_acc_m = m;
+  uint32_t *first = c->result(MHX_BUF_FIRST_0_OUT, (ns ? ns : 1) * 4).as<uint32_t>();
+  uint32_t *last_out = c->result(MHX_BUF_LAST_0_IN, (ns ? ns : 1) * 4).as<uint32_t>();
+  uint32_t *last = c->ws("last_p1", (ns ? ns : 1) * 4).as<uint32_t>();
+  c->results[MHX_BUF_FIRST_0_OUT].used = ns * 4;
+  c->results[MHX_BUF_LAST_0_IN].used = ns * 4;
+  unsigned long long *hist = c->result(MHX_BUF_MUL_HIST, (MHX_MAX_MUL + 1) * 8).as<unsigned long long>();
+  unsigned long long *bcount = c->result(MHX_BUF_BUCKET_COUNT, MHX_NUM_BUCKETS * 8).as<unsigned long long>();
+  MHX_HIP(hipMemsetAsync(first, 0xFF, (ns ? ns : 1) * 4, st));
+  MHX_HIP(hipMemsetAsync(last, 0x00, (ns ? ns : 1) * 4, st));
+  MHX_HIP(hipMemsetAsync(hist, 0, (MHX_MAX_MUL + 1) * 8, st));
+  MHX_HIP(hipMemsetAsync(bcount, 0, MHX_NUM_BUCKETS * 8, st));
+  CountStreamOut o;
+  if (!count_stream_groups(c, k, m, first, last, hist, &o)) return false;
+  std::vector<uint32_t> h_counts(o.grid);
+  MHX_HIP(hipMemcpyAsync(h_counts.data(), o.counts, (size_t)o.grid * 4, hipMemcpyDeviceToHost, st));
+  MHX_HIP(hipStreamSynchronize(st));
+  uint64_t n_edges = 0;
+  for (uint32_t v : h_counts) n_edges += v;
+  uint32_t *ea = c->ws("cs_edges_a", (n_edges + 1) * 8).as<uint32_t>(), *eb = c->ws("cs_edges_b", (n_edges + 1) * 8).as<uint32_t>();
+  uint32_t *edges = c->result(MHX_BUF_EDGES, (n_edges ? n_edges : 1) * wpe * 4).as<uint32_t>();
+  c->results[MHX_BUF_EDGES].used = n_edges * wpe * 4;
+  if (n_edges) {
+    MHX_LAUNCH(c, "edges_compact", (double)n_edges * 16,
+               hipLaunchKernelGGL(k_edges_compact, dim3(o.grid, 4), dim3(256), 0, st, reinterpret_cast<const unsigned long long *>(o.spare), o.cap, o.counts,
+                                  reinterpret_cast<unsigned long long *>(ea)));
+    // uint64 (lo word first in memory) -> (hi, lo) word pairs = the edge's word order; sort by the (k+1)-mer bits
+    hipLaunchKernelGGL(k_swap_pairs, dim3((unsigned)div_ceil(n_edges, 256)), dim3(256), 0, st, ea, n_edges);
+    uint32_t *es = sort_whole_key(c, ea, eb, n_edges, 2, 2, make_passes(2, 64 - key_bits, 64));  // distinct keys: the count bits never decide
+    MHX_HIP(hipMemcpyAsync(edges, es, n_edges * 8, hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL(k_edge_buckets, dim3((unsigned)div_ceil(n_edges, 256)), dim3(256), 0, st, edges, n_edges, bcount);
+    MHX_HIP(hipGetLastError());
+  }
+  if (ns)
+    MHX_LAUNCH(c, "fix_last", (double)ns * 8, hipLaunchKernelGGL(k_fix_last, dim3((unsigned)div_ceil(ns, 256)), dim3(256), 0, st, last, last_out, ns));
+  mhx::DevBuf &si = c->results[MHX_BUF_SORTED_ITEMS];
+  si.release();
+  c->sorted_item_words = 3;
+  si.p = o.sorted;
+  si.cap = 0;  // cap 0 = not owned
+  si.used = o.n_items * 12;
+  c->last_s1_plan = "count: " + o.plan;
+  MHX_HIP(hipStreamSynchronize(st));
+  if (out) {
+    out->n_items = o.n_items;
+    out->n_distinct = o.n_distinct;
+    out->n_edges = n_edges;
+    out->words_per_edge = wpe;
+    out->item_words = 3;
+  }
+  return true;
+}
+
 int run_count(mhx_ctx *c, uint32_t k, uint32_t m, mhx_count_result *out) {
   if (c->global_bases) throw Error("count: the global layout is set; use the mhx_dist_* entry points (or mhx_set_global_layout(0, 0))");
+  if (count_stream_applies(c, k, m) && (int)div_ceil((k + 1) * 2 + 16, 32) == 2) {
+    c->gen_first_pass = nullptr;
+    if (count_run_stream(c, k, m, out)) return 0;
+    c->gen_first_pass = nullptr;  // (gave up: the extraction + tile path redoes the job from the reads)
+  }
   const StageItems it = extract_stage(c, MHX_STAGE_COUNT, k, m);
   uint32_t *buf_a = c->work["items_a"].as<uint32_t>();
   uint32_t *buf_b = c->ws("items_b", it.n * (size_t)it.S * 4 + 64).as<uint32_t>();

@@ -264,6 +264,18 @@ int sdbg_load_bytes(mhx_ctx *c, const uint8_t *bytes, uint64_t n_bytes, const ui
 
 // ---- engines ----
 int run_count(mhx_ctx *c, uint32_t k, uint32_t m, mhx_count_result *out);
+// count on the bucket streaming of stage 1 (s1.hip: CountGenT, k_s1_stream<COUNT>)
+struct CountStreamOut {
+  unsigned grid;      // workgroups = edge regions
+  uint32_t cap;       // 8-byte edges a region holds
+  uint32_t *counts;   // device: edges per region
+  uint32_t *spare;    // the sort buffer the regions live in
+  uint32_t *sorted;   // the records, ordered by the plan's prefix
+  uint64_t n_items, n_distinct;
+  std::string plan;
+};
+bool count_stream_applies(const mhx_ctx *c, uint32_t k, uint32_t m);
+bool count_stream_groups(mhx_ctx *c, uint32_t k, uint32_t m, uint32_t *first_0_out, uint32_t *last_0_in_p1, unsigned long long *hist, CountStreamOut *o);
 int run_s1(mhx_ctx *c, uint32_t k, uint32_t m, int want_mercy, mhx_s1_result *out);
 int run_s1_mercy(mhx_ctx *c, uint32_t k, uint64_t *num_mercy);
 int run_s2(mhx_ctx *c, uint32_t k, uint32_t m, mhx_sdbg_result *out);

@@ -663,6 +663,130 @@ struct S1GenVarT {
   }
 };
 
+// ---------------------------------------------------------------------------------------------------------------
+// `count` on the design of stage 1 (round 5): KmerCounter's lv2 items (kmer_counter.cpp:208-252) as 12-byte records made by the
+// first sort pass — word 0..1: the canonical (k+1)-mer in the top 2(k+1) bits, bits [7, 15) of word 1 the position tag, bit 6
+// the strand, bits [0, 6) prev / next as the reference packs them (complemented and swapped on the reverse strand); word 2 the
+// low 32 bits of the edge's global offset.  One 64-bit window W per run of a thread's eight consecutive items (prev | edge |
+// next = k + 3 bases from one base in front of the edge: k <= 22) and one reverse complement R = rc(W); item d of the run:
+// forward (W << (2 d + 2)) & mask, reverse complement (R << 2 (30 - k - d)) & mask.  Fixed-length reads, >= 8 items per read.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kCountStreamMaxK = 22;
+constexpr uint32_t kCountStrandBit = 64u;
+__device__ __forceinline__ uint32_t count_pos_tag(uint64_t p, uint32_t pos_bits) { return (uint32_t)(p >> pos_bits) << 7; }
+// the 32-base window that starts ONE base in front of base a (the store's first base: the window at base 0 shifted down)
+__device__ __forceinline__ void count_window_addr(uint64_t a, uint64_t &word, unsigned &sh, unsigned &down) {
+  const uint64_t b = a >= 1 ? a - 1 : 0;
+  word = b >> 4;
+  sh = (unsigned)(b & 15) * 2;
+  down = a >= 1 ? 0u : 2u;
+}
+__device__ __forceinline__ void count_item_from_parts(uint64_t f, uint64_t rc, unsigned prev_b, unsigned next_b, uint32_t p, uint32_t L, int k, uint64_t a,
+                                                      uint64_t pos_base, uint32_t pos_bits, uint32_t (&out)[3]) {
+  const unsigned prev = p > 0 ? prev_b : kSentinel;
+  const unsigned next = p + k + 1 < L ? next_b : kSentinel;
+  const bool strand = rc < f;  // rev_edge.cmp(edge) < 0, kmer_counter.cpp:179
+  const uint64_t key = strand ? (rc | kCountStrandBit | (comp_or_sentinel(next) << 3) | comp_or_sentinel(prev)) : (f | (prev << 3) | next);
+  const uint64_t g = pos_base + a;
+  out[0] = (uint32_t)(key >> 32);
+  out[1] = (uint32_t)key | count_pos_tag(g, pos_bits);
+  out[2] = s1_pos_word(g, pos_bits);
+}
+struct CountGenT {
+  const uint32_t *seq;
+  uint32_t L, per;  // per = L - k items per read
+  int k;
+  uint64_t pos_base;
+  uint32_t pos_bits;
+  uint32_t tile_q, tile_r;
+  static constexpr bool kMayDrop = false;
+  __device__ __forceinline__ bool is_record(const Rec<3> &) const { return true; }
+  template <int NI>
+  __device__ __forceinline__ uint64_t index(uint64_t tile_base, int w, int lane, int j) const {
+    return tile_base + (uint64_t)((w * kWave + lane) * NI + j);
+  }
+  template <int NI, int UT>
+  __device__ __forceinline__ void get_unit(uint64_t unit_base, int w, int lane, uint64_t n, Rec<3> (&rec)[UT][NI]) const {
+    static_assert(NI <= 8, "a run of NI edges and their flanks inside one 32-base window");
+    constexpr uint32_t kTileItems = kSortThreads * NI;
+    const uint64_t g00 = unit_base + (uint64_t)((w * kWave + lane) * NI);
+    const uint64_t emask = ~0ull << (64 - 2 * (k + 1));
+    const unsigned rsh = (unsigned)(2 * (30 - k));
+    uint32_t jt[UT];
+    uint64_t bt[UT];
+    {
+      const uint64_t r = g00 / per;
+      jt[0] = (uint32_t)(g00 - r * per);
+      bt[0] = r * L;
+#pragma unroll
+      for (int t = 1; t < UT; ++t) {
+        uint32_t jn = jt[t - 1] + tile_r;
+        uint64_t bn = bt[t - 1] + (uint64_t)tile_q * L;
+        if (jn >= per) {
+          jn -= per;
+          bn += L;
+        }
+        jt[t] = jn;
+        bt[t] = bn;
+      }
+#pragma unroll
+      for (int t = 0; t < UT; ++t)
+        if (g00 + (uint64_t)t * kTileItems >= n) {
+          jt[t] = 0;
+          bt[t] = 0;
+        }
+    }
+    uint32_t c[UT][3], nx[UT][3];
+#pragma unroll
+    for (int t = 0; t < UT; ++t) {
+      uint64_t wcur, wnext;
+      unsigned sh, down;
+      count_window_addr(bt[t] + jt[t], wcur, sh, down);
+      count_window_addr(bt[t] + L, wnext, sh, down);
+#pragma unroll
+      for (int x = 0; x < 3; ++x) {
+        c[t][x] = seq[wcur + x];
+        nx[t][x] = seq[wnext + x];  // (the store is padded: also behind the last read)
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < UT; ++t) {
+      const uint64_t g0 = g00 + (uint64_t)t * kTileItems;
+      uint32_t j = jt[t];
+      uint64_t base = bt[t];
+      uint64_t wd;
+      unsigned sh0, down0, shn, downn;
+      count_window_addr(base + j, wd, sh0, down0);
+      uint64_t W = (((uint64_t)funnel_l(c[t][0], c[t][1], sh0) << 32) | funnel_l(c[t][1], c[t][2], sh0)) >> down0;
+      uint64_t R = rc64(W, 32);
+      uint32_t prun = j;
+      count_window_addr(base + L, wd, shn, downn);
+      const uint64_t Wn = (((uint64_t)funnel_l(nx[t][0], nx[t][1], shn) << 32) | funnel_l(nx[t][1], nx[t][2], shn)) >> downn;
+      const uint64_t Rn = rc64(Wn, 32);
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const unsigned d2 = (j - prun) * 2;
+        const uint64_t f = (W << (d2 + 2)) & emask;
+        const uint64_t rc = (R << (rsh - d2)) & emask;
+        const unsigned prev_b = (unsigned)(W >> (62 - d2)) & 3u, next_b = (unsigned)(W >> ((unsigned)(58 - 2 * k) - d2)) & 3u;
+        uint32_t out[3];
+        count_item_from_parts(f, rc, prev_b, next_b, j, L, k, base + j, pos_base, pos_bits, out);
+        if (g0 + (uint64_t)i < n) {
+          rec[t][i].w[0] = out[0];
+          rec[t][i].w[1] = out[1];
+          rec[t][i].w[2] = out[2];
+        }
+        if (++j == per) {
+          j = 0;
+          base += L;
+          W = Wn;
+          R = Rn;
+          prun = 0;
+        }
+      }
+    }
+  }
+};
 constexpr int kFastPasses = 4;
 // The digit histograms of the coming sort passes without making the records (the pre-pass of the generating first pass):
 // every thread takes IT CONSECUTIVE items — one division per trip, the three window words are reloaded only when the
@@ -920,6 +1044,74 @@ __global__ __launch_bounds__(256) void k_s1_digit_hist_roll(const uint32_t *__re
         W = Wn;
         R = Rn;
         qrun = 0;
+      }
+    }
+    q0 += step_q;
+    rem0 += step_r;
+    if (rem0 >= per) {
+      rem0 -= per;
+      ++q0;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    const uint32_t v = h[p][0][threadIdx.x] + h[p][1][threadIdx.x] + h[p][2][threadIdx.x] + h[p][3][threadIdx.x];
+    if (v) atomicAdd(&ghist[p * 256 + threadIdx.x], (unsigned long long)v);
+  }
+}
+
+// the digit histograms of count's prefix passes (every digit one bit field of the first key word): CountGenT's arithmetic, no records
+template <int IT, int NP>
+__global__ __launch_bounds__(256) void k_count_digit_hist_roll(const uint32_t *__restrict__ seq, uint32_t L, uint32_t per, uint64_t n_items, int k,
+                                                               HiDigits hd, unsigned long long *__restrict__ ghist, uint32_t step_q, uint32_t step_r) {
+  static_assert(IT <= 8, "a run of IT edges and their flanks inside one 32-base window");
+  constexpr int B = 256 * IT;
+  __shared__ uint32_t h[kFastPasses][4][256];
+  for (int i = threadIdx.x; i < kFastPasses * 4 * 256; i += 256) (&h[0][0][0])[i] = 0;
+  __syncthreads();
+  const int wv = threadIdx.x >> 6;
+  const uint64_t emask = ~0ull << (64 - 2 * (k + 1));
+  const unsigned rsh = (unsigned)(2 * (30 - k));
+  const uint64_t n_blocks = (n_items + B - 1) / B;
+  uint64_t q0 = ((uint32_t)blockIdx.x * (uint32_t)B) / per;
+  uint32_t rem0 = ((uint32_t)blockIdx.x * (uint32_t)B) % per;
+  for (uint64_t blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
+    const uint64_t g0 = blk * B + (uint64_t)threadIdx.x * IT;
+    const uint32_t t = rem0 + (uint32_t)threadIdx.x * IT, dq = t / per;
+    uint32_t j = t - dq * per;
+    uint64_t base = (q0 + dq) * L;
+    if (g0 >= n_items) {  // (nothing of this block is this thread's: loads from the start of the store, nothing counted)
+      j = 0;
+      base = 0;
+    }
+    uint64_t wcur, wnext;
+    unsigned sh0, down0, shn, downn;
+    count_window_addr(base + j, wcur, sh0, down0);
+    count_window_addr(base + L, wnext, shn, downn);
+    const uint32_t c0 = seq[wcur], c1 = seq[wcur + 1], c2 = seq[wcur + 2];
+    const uint32_t n0 = seq[wnext], n1 = seq[wnext + 1], n2 = seq[wnext + 2];
+    uint64_t W = (((uint64_t)funnel_l(c0, c1, sh0) << 32) | funnel_l(c1, c2, sh0)) >> down0;
+    uint64_t R = rc64(W, 32);
+    const uint64_t Wn = (((uint64_t)funnel_l(n0, n1, shn) << 32) | funnel_l(n1, n2, shn)) >> downn;
+    const uint64_t Rn = rc64(Wn, 32);
+    uint32_t prun = j;
+#pragma unroll
+    for (int u = 0; u < IT; ++u) {
+      const unsigned d2 = (j - prun) * 2;
+      const uint64_t f = (W << (d2 + 2)) & emask;
+      const uint64_t rc = (R << (rsh - d2)) & emask;
+      const uint32_t hi = (uint32_t)((rc < f ? rc : f) >> 32);
+      if (g0 + u < n_items) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) atomicAdd(&h[p][wv][(hi >> hd.sh[p]) & hd.mk[p]], 1u);
+      }
+      if (++j == per) {
+        j = 0;
+        base += L;
+        W = Wn;
+        R = Rn;
+        prun = 0;
       }
     }
     q0 += step_q;
@@ -1518,6 +1710,11 @@ struct S1SegArgs {
   int la_chunks;      // look-ahead limit, in chunks of 256 records
   int direct_marks;   // k_s1_stream: the non-solid marks come from the table (one stored position per key), no second read
   S1Giant giant;      // k_s1_stream: buckets handed to the giant path (flag == nullptr: none)
+  // k_s1_stream<COUNT>: the reads (first_0_out / last_0_in are per read) and the two arrays (kmer_counter.cpp:307-368)
+  const uint64_t *c_start;
+  uint64_t c_n_seqs;
+  uint32_t c_fixed_len;
+  uint32_t *first_0_out, *last_0_in_p1;
 };
 
 constexpr unsigned long long kSegEmpty = ~0ull;  // never a key: head/tail bits 63 do not occur (max (4<<3)|4)
@@ -2058,7 +2255,12 @@ constexpr int kStreamSrcMax = kWave;  // bucket bounds of up to this many source
 // three phases with a list of occupied slots.  Loads: the records of trip i + 1 — across the end of a round or of a bucket:
 // the first trip of what comes next — are requested before the inserts of trip i, and wave 0 fetches the next bucket's
 // ticket and bounds while the current bucket is worked on.
-template <bool AGG, int UNR, int NT, int LOGS, bool TAGS, bool GIANT = false>
+// COUNT: the same bucket streaming for `count` (KmerCounter::Lv2Postprocess, kmer_counter.cpp:254-381) on the records of CountGenT:
+// the table key is the (k+1)-mer below the prefix, the slot's third word holds, per prev / next char, "seen once" and "seen twice"
+// bits (min count <= 2: has_in / has_out need no more), a solid key's packed edge goes to the workgroup's region (AGG's), and the
+// records of solid keys without an in- or out-edge — a few per bucket — are found by a second read of the bucket, which brings
+// first_0_out / last_0_in of their reads up to date.
+template <bool AGG, int UNR, int NT, int LOGS, bool TAGS, bool GIANT = false, bool COUNT = false>
 __global__ __launch_bounds__(NT) void k_s1_stream(const uint32_t *__restrict__ items0, const uint64_t *__restrict__ bounds, S1SegArgs a,
                                                   S1StreamGeom geo, uint32_t bucket_stride, uint32_t *__restrict__ ticket,
                                                   const uint32_t *const *__restrict__ srcs, int n_src) {
@@ -2077,6 +2279,7 @@ __global__ __launch_bounds__(NT) void k_s1_stream(const uint32_t *__restrict__ i
   __shared__ uint2 slist[AGG ? NLIST : 1];
   __shared__ uint32_t s_list_n[2];
   __shared__ uint32_t s_agg_cur, s_mark_cur;
+  __shared__ uint32_t s_flagged;  // COUNT: the round has a solid key without an in- or out-edge
   // the bucket being worked on and the one after it: ticket and per-source bounds (wave 0 fills [par ^ 1] during bucket [par])
   __shared__ uint32_t s_tk[2];
   __shared__ uint32_t s_bid[2];  // GIANT: the lv1 bucket (of the plan's prefix) the ticket's giant is
@@ -2090,6 +2293,7 @@ __global__ __launch_bounds__(NT) void k_s1_stream(const uint32_t *__restrict__ i
   for (int i = tid; i < NSLOT; i += NT) {
     keys[i] = kStreamEmpty;
     cnts[i] = 0;
+    if (COUNT) fpos[i] = 0;
   }
   for (int i = tid; i < kSegHist; i += NT) lhist[i] = 0;
   if (tid == 0) {
@@ -2107,16 +2311,19 @@ __global__ __launch_bounds__(NT) void k_s1_stream(const uint32_t *__restrict__ i
   const int pbits = geo.pbits;
   const size_t bstride = (size_t)geo.n_buckets + 1;
   // local key: the (k-1)-mer bits below the prefix, then head/tail (the position tag bits in between dropped)
-  const int rem = 2 * (k - 1) - pbits;  // 0..26 bits
-  const int lk_bits = rem + 6;          // <= 32
-  const int mer_sh = 64 - 2 * (k - 1);
-  const uint32_t mer_mask = rem ? (1u << rem) - 1u : 0u;
+  static_assert(!COUNT || (AGG && !GIANT), "count: edges leave through the regions of the aggregated items; no giant path");
+  const int key_chars = COUNT ? k + 1 : k - 1;
+  const int rem = 2 * key_chars - pbits;         // 0..26 bits (count: up to 32)
+  const int lk_bits = COUNT ? rem : rem + 6;     // <= 32
+  const int mer_sh = 64 - 2 * key_chars;
+  const uint32_t mer_mask = rem >= 32 ? 0xFFFFFFFFu : (rem ? (1u << rem) - 1u : 0u);
   // (the low 32 bits of (w0:w1) >> mer_sh: one funnel shift while the (k-1)-mer reaches into the second word, k >= 18)
   const bool mer_two_words = mer_sh < 32;
   const uint32_t mer_sh1 = (uint32_t)(mer_two_words ? mer_sh : mer_sh - 32);
   auto local_key = [&](uint32_t w0, uint32_t w1) -> uint32_t {
     const uint32_t lo = mer_two_words ? __builtin_amdgcn_alignbit(w0, w1, mer_sh1) : w0 >> mer_sh1;
-    return (lo & mer_mask) << 6 | (w1 & 63u);
+    if constexpr (COUNT) return lo & mer_mask;
+    else return (lo & mer_mask) << 6 | (w1 & 63u);
   };
   // the (k+1)-mer head.S.tail of a table key of bucket bi, chars MSB-first in 64 bits
   auto edge_of = [&](uint32_t bi, uint32_t lk) -> uint64_t {
@@ -2358,7 +2565,7 @@ __global__ __launch_bounds__(NT) void k_s1_stream(const uint32_t *__restrict__ i
         }
         // low-complexity reads: a whole trip of one wavefront carrying ONE key (a poly-A stretch: tens of thousands of records
         // of one key in a row) is inserted by one lane instead of 64 lanes queueing up at one LDS address UNR times
-        bool one_key = mine == (1u << UNR) - 1u;
+        bool one_key = !COUNT && mine == (1u << UNR) - 1u;  // (count: the records' prev / next chars differ even where their keys agree)
 #pragma unroll
         for (int u = 1; u < UNR; ++u) one_key = one_key && lk[u] == lk[0];
         one_key = __ballot(one_key && lk[0] == (uint32_t)__builtin_amdgcn_readfirstlane((int)lk[0])) == ~0ull;
@@ -2374,7 +2581,17 @@ __global__ __launch_bounds__(NT) void k_s1_stream(const uint32_t *__restrict__ i
         auto settle = [&](uint32_t old, uint32_t key, uint32_t hh, uint32_t pos, uint32_t w1v) -> bool {
           if (old != kStreamEmpty && old != key) return false;
           atomicAdd(&cnts[hh], mult);
-          if (old == kStreamEmpty) {  // only read back when the count stays 1: then this record is the key's only one
+          if constexpr (COUNT) {
+            if (old == kStreamEmpty) ++claims;
+            // prev char x: bit 2x = seen once, 2x + 1 = seen twice; next char x: bits 8 + 2x, 9 + 2x ('$' counts for nothing)
+            const unsigned pv = (w1v >> 3) & 7u, nx = w1v & 7u;
+            const uint32_t add = (pv < 4 ? 1u << (2 * pv) : 0u) | (nx < 4 ? 1u << (8 + 2 * nx) : 0u);
+            if (add) {
+              const uint32_t o = atomicOr(&fpos[hh], add);
+              const uint32_t again = ((o & add) << 1) & ~o;
+              if (again) atomicOr(&fpos[hh], again);
+            }
+          } else if (old == kStreamEmpty) {  // only read back when the count stays 1: then this record is the key's only one
             fpos[hh] = pos;
             if (TAGS) ftag[hh] = (uint8_t)(w1v >> 6);
             ++claims;
@@ -2546,7 +2763,7 @@ __global__ __launch_bounds__(NT) void k_s1_stream(const uint32_t *__restrict__ i
           request_first(par ^ 1);
         }
       }
-      if (!GIANT && !bad) {
+      if (!GIANT && !COUNT && !bad) {
         // B: marks by a second read of the bucket (m > 2, or the marks of the solid occurrences are wanted)
         if (a.mark_mode != 2 && !a.direct_marks) {
           for (int q = 0; q < n_src; ++q) {
@@ -2602,7 +2819,107 @@ __global__ __launch_bounds__(NT) void k_s1_stream(const uint32_t *__restrict__ i
       // (all of a thread's slots are read first and wiped, then looked at: one LDS round trip for the lot instead of three
       //  dependent ones per slot; the places in the list of solid keys — and, on several GPUs, in the region of marks — come
       //  from one wavefront scan and one LDS atomic per wavefront and walk instead of one per slot)
-      {
+      if constexpr (COUNT) {
+        // C (count): per distinct (k+1)-mer — multiplicity histogram, has_in / has_out from the seen-twice (m = 2) or seen-once
+        // (m = 1) bits, the packed edge of a solid key -> this workgroup's region; a solid key without an in- or out-edge
+        // leaves two flag bits in its slot for the second read below
+        constexpr int W = NSLOT / NT;
+        if (tid == 0) s_flagged = 0;
+        uint32_t wk[W], wc[W], wf[W];
+#pragma unroll
+        for (int it = 0; it < W; ++it) {
+          const int sl = it * NT + tid;
+          wk[it] = keys[sl];
+          wc[it] = cnts[sl];
+          wf[it] = fpos[sl];
+        }
+        __syncthreads();  // (s_flagged cleared before anybody sets it)
+        const uint32_t lvl = m >= 2 ? 0xAAu : 0x55u;  // which bit of a char's pair says "at least m"
+        uint32_t solid_bits = 0, n_dist = 0;
+        bool any_flag = false;
+#pragma unroll
+        for (int it = 0; it < W; ++it) {
+          const uint32_t lk = wk[it], cnt = wc[it];
+          uint32_t fb = 0;
+          if (lk != kStreamEmpty && !bad) {
+            ++n_dist;
+            const uint32_t hb = cnt > MHX_MAX_MUL ? (uint32_t)MHX_MAX_MUL : cnt;
+            if (hb < kSegHist) atomicAdd(&lhist[hb], 1u);
+            else atomicAdd(&a.hist[hb], 1ull);
+            if (cnt >= m) {
+              solid_bits |= 1u << it;
+              const bool has_in = (wf[it] & lvl) != 0, has_out = ((wf[it] >> 8) & lvl) != 0;
+              fb = (has_in ? 0u : 1u) | (has_out ? 0u : 2u);
+              any_flag = any_flag || fb != 0;
+            }
+            fpos[it * NT + tid] = fb << 30;
+          }
+        }
+        st_solid += n_dist;  // (count: distinct keys)
+        if (__ballot(any_flag) && lane == 0) s_flagged = 1;
+        {  // the solid keys' packed edges (PackEdge, kmer_counter.cpp:32-52: multiplicity in the low 16 bits) -> the region, from its front
+          const uint32_t n_e = (uint32_t)__builtin_popcount(solid_bits);
+          const uint32_t incl = wave_inclusive_sum(n_e);
+          const uint32_t tot = __shfl(incl, kWave - 1, kWave);
+          if (tot) {
+            uint32_t ebase = 0;
+            if (lane == 0) ebase = atomicAdd(&s_agg_cur, tot);
+            ebase = __shfl(ebase, 0, kWave);
+            if (ebase + tot > a.agg_cap) {
+              if (lane == 0) atomicOr(a.err, 1u);
+            } else {
+              unsigned long long *const eout = reinterpret_cast<unsigned long long *>(a.agg_raw + (size_t)blockIdx.x * a.agg_cap);
+              uint32_t at = ebase + incl - n_e;
+#pragma unroll
+              for (int it = 0; it < W; ++it)
+                if ((solid_bits >> it) & 1u) {
+                  const uint32_t cnt = wc[it];
+                  const unsigned long long edge = ((unsigned long long)bi << (64 - pbits)) | (rem ? (unsigned long long)wk[it] << mer_sh : 0ull);
+                  eout[at++] = edge | (cnt > MHX_MAX_MUL ? (unsigned long long)MHX_MAX_MUL : cnt);
+                }
+            }
+          }
+        }
+        __syncthreads();
+        if (s_flagged && !bad) {  // the records of the flagged keys: first_0_out / last_0_in of their reads (kmer_counter.cpp:307-368)
+          for (int q = 0; q < n_src; ++q) {
+            const uint64_t lo = lo_of(par, q), hi = hi_of(par, q);
+            const gptr items = (gptr)src_of(q);
+            for (uint64_t base = lo; base < hi; base += NT) {
+              const uint64_t gi = base + tid;
+              if (gi >= hi) continue;
+              const gptr p = items + gi * 3;
+              const uint32_t w0 = p[0], w1 = p[1], w2 = p[2];
+              const uint32_t lk = local_key(w0, w1);
+              if (sub != 0 && (lk >> sub_sh) != rj) continue;  // (a key of another round is not in the table)
+              uint32_t h = hash_of(lk);
+              while (keys[h] != lk) h = (h + 1) & (NSLOT - 1);
+              const uint32_t f = fpos[h] >> 30;
+              if (!f) continue;
+              const uint64_t abs = w2 + (TAGS ? (uint64_t)((w1 >> 7) & 0xFFu) * a.pos_stride : 0ull);
+              const bool fwd = (w1 & kCountStrandBit) == 0;
+              const uint64_t rid = seq_of_offset(a.c_start, a.c_n_seqs, a.c_fixed_len, abs);
+              const uint32_t off = (uint32_t)(abs - a.c_start[rid]);
+              if (f & 1u) {  // no in-edge: strand 0 -> last_0_in = max(off), strand 1 -> first_0_out = min(off + 1)
+                if (fwd) atomicMax(&a.last_0_in_p1[rid], off + 1);
+                else atomicMin(&a.first_0_out[rid], off + 1);
+              }
+              if (f & 2u) {  // no out-edge: the roles swap
+                if (fwd) atomicMin(&a.first_0_out[rid], off + 1);
+                else atomicMax(&a.last_0_in_p1[rid], off + 1);
+              }
+            }
+          }
+          __syncthreads();
+        }
+#pragma unroll
+        for (int it = 0; it < W; ++it) {
+          const int sl = it * NT + tid;
+          keys[sl] = kStreamEmpty;
+          cnts[sl] = 0;
+          fpos[sl] = 0;
+        }
+      } else {
         constexpr int W = NSLOT / NT;
         uint32_t wk[W], wc[W], wp[W];
 #pragma unroll
@@ -2682,7 +2999,7 @@ __global__ __launch_bounds__(NT) void k_s1_stream(const uint32_t *__restrict__ i
       MHX_TT(13)
       __syncthreads();  // B: the table is empty
       MHX_TT(14)
-      if constexpr (AGG) {  // the listed solid keys -> aggregated items
+      if constexpr (AGG && !COUNT) {  // the listed solid keys -> aggregated items
         const uint32_t n_list = min(s_list_n[rp], (uint32_t)NLIST);
         for (uint32_t base = 0; base < n_list; base += NT) {
           const uint32_t i = base + tid;
@@ -2696,6 +3013,11 @@ __global__ __launch_bounds__(NT) void k_s1_stream(const uint32_t *__restrict__ i
       if (bucket_done) break;
     }
     par ^= 1;
+  }
+  if constexpr (COUNT) {
+    st_solid = wave_sum(st_solid);
+    if (lane == 0 && st_solid) atomicAdd(a.ctr + 4, st_solid);
+    st_solid = 0;
   }
   if (a.mark_mode == 2) {
     st_solid = wave_sum(st_solid);
@@ -4012,6 +4334,136 @@ void s1_apply_marks(mhx_ctx *c, const unsigned long long *recv, uint64_t n) {
   if (h[4] & 0xFFFFFFFFull) throw Error("dist_apply_routed: a mark outside this rank's reads (ranks disagree on the global layout)");
   c->dist_local_solid = h[0];
   c->global_marks_inverted = false;
+}
+
+// ---- `count` on the bucket streaming (k_s1_stream<COUNT>): fixed-length reads on one GPU, k <= 22, min count <= 2 ----
+bool count_stream_applies(const mhx_ctx *c, uint32_t k, uint32_t m) {
+  const SeqSet &s = c->seqs;
+  if (!c->opt("count_stream", 1) || c->global_bases || c->filter_on || c->accumulate || c->n_parts > 1) return false;
+  // (a caller that asks for a particular form of the tile path gets the tile path)
+  if (!c->opt("count_seg", 1) || c->opt("count_seg_bits", 0) || !c->opt("count_extract_fixed", 1)) return false;
+  if (!s.n_seqs || s.fixed_len < k + 1 || s.fixed_len - k < 8 || k < 9 || (int)k > kCountStreamMaxK || m < 1 || m > 2) return false;
+  if (!c->opt("s1_fused_first_pass", 1) || !c->opt("sort_unit_runs", 1) || !c->opt("s1_gen_any_order", 1)) return false;
+  const uint64_t n_items = s.n_seqs * (uint64_t)(s.fixed_len - k);
+  const uint64_t n_bits = s.n_bases;
+  if ((n_bits >> s1_pos_bits(c)) >= 256) return false;  // (positions beyond the tags)
+  const S1Plan plan = s1_plan(c, k, n_items, true, 0);
+  if (!plan.stream || plan.passes.empty() || (int)plan.passes.size() > kFastPasses) return false;
+  for (const SortPass &ps : plan.passes)
+    if (ps.bits2 || ps.shift < 32) return false;  // (digits: bit fields of the first key word)
+  return sort_takes_generated_first_pass(c, n_items, 3, plan.passes);
+}
+// records made by the first sort pass, prefix passes, bucket streaming.  -> false: gave up (an output region too small): nothing
+// published, the caller runs the extraction + tile path; true: the solid edges lie in the per-workgroup regions of *spare
+bool count_stream_groups(mhx_ctx *c, uint32_t k, uint32_t m, uint32_t *first_0_out, uint32_t *last_0_in_p1, unsigned long long *hist,
+                         CountStreamOut *o) {
+  SeqSet &s = c->seqs;
+  hipStream_t st = c->stream;
+  const uint32_t per = s.fixed_len - k;
+  const uint64_t n_items = s.n_seqs * (uint64_t)per;
+  const S1Plan plan = s1_plan(c, k, n_items, true, 0);
+  const int KWv = 2;
+  uint32_t *buf_a = c->ws("items_a", n_items * 12 + 64).as<uint32_t>();
+  uint32_t *buf_b = c->ws("items_b", n_items * 12 + 64).as<uint32_t>();
+  // digit histograms of the plan's passes (the chained scan wants every pass's bin starts beforehand)
+  HiDigits hd;
+  hd.n = (int)plan.passes.size();
+  for (int p = 0; p < hd.n; ++p) {
+    const DigitSpec d = spec_of_pass(plan.passes[p], KWv);
+    hd.sh[p] = d.bit1;
+    hd.mk[p] = d.mask1;
+  }
+  unsigned long long *pre_hist = c->ws("sort_pre_hist", (size_t)kMaxFusedPasses * 256 * 8).as<unsigned long long>();
+  MHX_HIP(hipMemsetAsync(pre_hist, 0, (size_t)hd.n * 256 * 8, st));
+  {
+    constexpr int ITH = 8;
+    const unsigned fgrid = (unsigned)std::min<uint64_t>(div_ceil(n_items, 256 * ITH), 256 * 8);
+    const uint64_t stride_items = (uint64_t)fgrid * 256 * ITH;
+#define MHX_CH(NPV)                                                                                                                         \
+  MHX_LAUNCH(c, "count_digit_hist", (double)s.n_bases / 4,                                                                                  \
+             hipLaunchKernelGGL((k_count_digit_hist_roll<ITH, NPV>), dim3(fgrid), dim3(256), 0, st, s.words.as<uint32_t>(), s.fixed_len, per, \
+                                n_items, (int)k, hd, pre_hist, (uint32_t)(stride_items / per), (uint32_t)(stride_items % per)))
+    if (hd.n == 1) MHX_CH(1);
+    else if (hd.n == 2) MHX_CH(2);
+    else if (hd.n == 3) MHX_CH(3);
+    else MHX_CH(4);
+#undef MHX_CH
+  }
+  c->pre_hist_sig = passes_signature(plan.passes);
+  c->pre_hist_buf = buf_a;
+  c->pre_hist_n = n_items;
+  c->pre_hist_passes = hd.n;
+  const uint32_t pos_bits = s1_pos_bits(c);
+  const uint64_t pos_stride = (s.n_bases >> pos_bits) ? 1ull << pos_bits : 0ull;
+  const CountGenT g{s.words.as<uint32_t>(), s.fixed_len, per, (int)k, c->pos_base, pos_bits, (uint32_t)(kSortThreads * 8) / per, (uint32_t)(kSortThreads * 8) % per};
+  c->gen_first_pass = [g](const OnesweepLaunch &l) {
+    if (!(l.unit_runs && l.wi == 0)) throw Error("count: the generating pass needs the unit-wide pass on a first-word digit");
+    hipLaunchKernelGGL((k_radix_onesweep_u<3, 8, 3, CountGenT, 1, 0>), dim3(l.grid), dim3(kSortThreads), 0, l.stream, g, l.out, l.n, l.ds, l.nbits, l.bin_start,
+                       l.status, l.ticket, l.err, l.tag, l.xcd_units);
+  };
+  c->gen_buf = buf_a;
+  c->gen_n = n_items;
+  c->gen_slots = n_items;
+  uint32_t *sorted = radix_sort(c, buf_a, buf_b, n_items, 3, KWv, plan.passes);
+  c->pre_hist_buf = nullptr;
+  uint32_t *spare = sorted == buf_a ? buf_b : buf_a;
+  // bucket streaming
+  const uint64_t n_buckets = 1ull << plan.seg_bits;
+  const uint64_t cus = c->n_cus > 0 ? (uint64_t)c->n_cus : 256;
+  const unsigned grid = (unsigned)std::min<uint64_t>(n_buckets, cus);
+  const uint32_t region = (uint32_t)std::min<uint64_t>(n_items * 12 / 8 / grid, 0xFFFFFFF0u);
+  uint32_t *counts = c->ws("cs_edge_counts", (size_t)grid * 4).as<uint32_t>();
+  unsigned long long *ctr = c->ws("s1_counters", 64).as<unsigned long long>();
+  uint32_t *seg_err = c->ws("s1_seg_err", 64).as<uint32_t>();
+  MHX_HIP(hipMemsetAsync(ctr, 0, 64, st));
+  MHX_HIP(hipMemsetAsync(seg_err, 0, 4, st));
+  uint64_t *bounds = c->ws("s1_bucket_bounds", (n_buckets + 1) * 8 + 64).as<uint64_t>();
+  uint32_t *ticket = c->ws("s1_stream_ticket", 64).as<uint32_t>();
+  MHX_HIP(hipMemsetAsync(ticket, 0, 4, st));
+  MHX_LAUNCH(c, "bucket_bounds", (double)n_buckets * 8 * 30,
+             hipLaunchKernelGGL(k_bucket_bounds, dim3((unsigned)((n_buckets + 1 + 255) / 256)), dim3(256), 0, st, sorted, n_items, 3, bounds, plan.seg_bits));
+  S1SegArgs a{};
+  a.k = (int)k;
+  a.m = m;
+  a.mark_mode = 1;
+  a.hist = hist;
+  a.ctr = ctr;
+  a.agg_raw = reinterpret_cast<uint2 *>(spare);
+  a.agg_cap = region;
+  a.agg_counts = counts;
+  a.pos_stride = pos_stride;
+  a.err = seg_err;
+  a.la_chunks = (int)c->opt("s1_stream_probes", 1024);
+  a.c_start = s.start.as<uint64_t>();
+  a.c_n_seqs = s.n_seqs;
+  a.c_fixed_len = s.fixed_len;
+  a.first_0_out = first_0_out;
+  a.last_0_in_p1 = last_0_in_p1;
+  const S1StreamGeom geo{plan.seg_bits, plan.sub0, (uint32_t)n_buckets,
+                         (uint32_t)std::min<long long>(std::max<long long>(c->opt("s1_stream_fill", 8192 * 7 / 8), 1), 8192)};
+  const double bytes = (double)n_items * 12 * (double)(1u << plan.sub0);
+  if (pos_stride)
+    MHX_LAUNCH(c, "count_groups", bytes,
+               hipLaunchKernelGGL((k_s1_stream<true, 4, kStreamThreads, 13, true, false, true>), dim3(grid), dim3(kStreamThreads), 0, st, sorted, bounds, a, geo, 1u,
+                                  ticket, (const uint32_t *const *)nullptr, 1));
+  else
+    MHX_LAUNCH(c, "count_groups", bytes,
+               hipLaunchKernelGGL((k_s1_stream<true, 4, kStreamThreads, 13, false, false, true>), dim3(grid), dim3(kStreamThreads), 0, st, sorted, bounds, a, geo, 1u,
+                                  ticket, (const uint32_t *const *)nullptr, 1));
+  uint32_t e = 0;
+  unsigned long long h_ctr[8] = {0};
+  MHX_HIP(hipMemcpyAsync(&e, seg_err, 4, hipMemcpyDeviceToHost, st));
+  MHX_HIP(hipMemcpyAsync(h_ctr, ctr, 64, hipMemcpyDeviceToHost, st));
+  MHX_HIP(hipStreamSynchronize(st));
+  o->grid = grid;
+  o->cap = region;
+  o->counts = counts;
+  o->spare = spare;
+  o->sorted = sorted;
+  o->n_items = n_items;
+  o->n_distinct = h_ctr[4];
+  o->plan = s1_plan_text(c, k, n_items);
+  return e == 0;
 }
 
 int run_s1(mhx_ctx *c, uint32_t k, uint32_t m, int want_mercy, mhx_s1_result *out) {

@@ -227,3 +227,79 @@ def write_pe_library(prefix, n_reads, genome_seed, read_seed0, procs=None, read_
     with open(prefix + ".lib_info", "w") as f:
         f.write("%d %d\n%s\n0 %d %d %d\n" % (n_reads * read_len, n_reads, description, n_reads, read_len, 1))
     return n_reads, n_reads * read_len
+
+
+# ---- libraries whose reads are NOT of one length (trimmed reads: every real library after quality / N trimming) ----
+VARLEN_RULES = ("u100_150", "trim2pct")
+
+
+def trimmed_lengths(n, read_len, rule, seed):
+    """lengths of n reads of `read_len` bases after trimming: "u100_150" = every read cut to U[100, read_len];
+    "trim2pct" = 2 % of the reads cut to U[30, read_len), the others whole (N-trimmed reads of a real library)"""
+    rng = np.random.default_rng(seed)
+    if rule == "u100_150":
+        return rng.integers(min(100, read_len), read_len + 1, size=n).astype(np.uint32)
+    if rule == "trim2pct":
+        lens = np.full(n, read_len, dtype=np.uint32)
+        cut = rng.random(n) < 0.02
+        lens[cut] = rng.integers(min(30, read_len), read_len, size=int(cut.sum()))
+        return lens
+    raise ValueError(rule)
+
+
+def varlen_blocks(n_reads, rule, genome_seed=1, read_seed0=1001, read_len=150, frag=400, err=0.005):
+    """the library of write_pe_library / bench.py (same genome, same PE blocks of 1 M pairs) with every block's reads trimmed by `rule`
+    (length seed = the block's read seed + 500000): -> iterator over (bases uint8 [n, read_len], lens uint32 [n])"""
+    n_reads = n_reads // 2 * 2
+    G = max(5000, int(n_reads * 2.5))
+    genome = _genome(genome_seed, G)
+    for i, lo in enumerate(range(0, n_reads // 2, 1000000)):
+        c = min(1000000, n_reads // 2 - lo)
+        reads = gen_pe_reads(c, G, read_len=read_len, frag=frag, err=err, seed=read_seed0 + i, genome=genome)
+        yield reads, trimmed_lengths(reads.shape[0], read_len, rule, read_seed0 + i + 500000)
+
+
+def pack_var_reversed(reads, lens):
+    """reads uint8 [n, L], lens [n] -> (uint32 words of the gap-free concatenation of the REVERSED trimmed reads, as the reference's
+    SequencePackage holds a library it loaded; base count) — vectorised"""
+    n, L = reads.shape
+    rev = reads[:, ::-1]
+    keep = np.arange(L, dtype=np.uint32)[None, :] >= (L - lens)[:, None]  # the trimmed read = the first lens bases = the LAST lens of the reversal
+    flat = rev[keep]
+    n_bases = int(flat.size)
+    pad = (-flat.size) % 16
+    if pad:
+        flat = np.concatenate([flat, np.zeros(pad, dtype=np.uint8)])
+    out = np.zeros(flat.size // 16, dtype=np.uint32)
+    f = flat.reshape(-1, 16)
+    for j in range(16):
+        out |= f[:, j].astype(np.uint32) << np.uint32(30 - 2 * j)
+    return out, n_bases
+
+
+def write_var_read_lib(prefix, blocks, description="synthetic, trimmed", paired=True):
+    """blocks: iterable of (bases [n, L], lens [n]) -> `<prefix>.bin` / `.lib_info` in the reference's format (per read: uint32 length +
+    ceil(length / 16) words, bits past the length zero) — vectorised"""
+    total_bases = total_reads = max_len = 0
+    with open(prefix + ".bin", "wb") as f:
+        for reads, lens in blocks:
+            n, L = reads.shape
+            words = pack_reads(reads)  # [n, ceil(L / 16)]
+            nw = words.shape[1]
+            need = (lens + 15) // 16
+            # zero the bits past the read's end in its last word
+            last = np.maximum(need, 1) - 1
+            rem = (lens % 16).astype(np.uint32)
+            mask_last = np.where(rem == 0, np.uint32(0xFFFFFFFF), (np.uint32(0xFFFFFFFF) << (np.uint32(32) - 2 * rem)).astype(np.uint32))
+            words[np.arange(n), last] &= mask_last
+            rec = np.empty((n, 1 + nw), dtype=np.uint32)
+            rec[:, 0] = lens
+            rec[:, 1:] = words
+            keep = np.arange(1 + nw, dtype=np.uint32)[None, :] <= need[:, None]
+            rec[keep].tofile(f)
+            total_bases += int(lens.sum())
+            total_reads += n
+            max_len = max(max_len, int(lens.max()) if n else 0)
+    with open(prefix + ".lib_info", "w") as f:
+        f.write("%d %d\n%s\n0 %d %d %d\n" % (total_bases, total_reads, description, total_reads, max_len, int(paired)))
+    return total_reads, total_bases

@@ -1,0 +1,60 @@
+"""GPU: `count` on the design of stage 1 (CountGenT + k_s1_stream<COUNT>, s1.hip / count.hip: the first sort pass makes 12-byte
+records, prefix passes, LDS group-by per bucket, first_0_out / last_0_in from a second look at the buckets that need it) against the
+oracle's KmerCounter (reference src/sorting/kmer_counter.cpp:208-381): edges, per-bucket counts, multiplicity histogram,
+first_0_out / last_0_in — on fixed-length libraries incl. low-complexity reads, k up to 22, min count 1 and 2, with sub-rounds,
+overflowing tables, position tags and wider prefixes; and the tile path (count_stream = 0) beside it."""
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+from megahit_amd import lib
+from test_gpu_count import load
+from test_gpu_round3_knobs import fixed_library
+
+pytestmark = pytest.mark.gpu
+
+RESET = dict(count_stream=1, s1_stream_fill=7168, s1_pos_bits=0, s1_stream_bits=0, s1_stream_sub0=-1, s1_stream_probes=1024)
+
+
+def check_count(engine, pkg, k, m, opts, expect_stream):
+    want = ob.count(pkg, k, m)
+    load(engine, pkg)
+    try:
+        for n, v in opts.items():
+            engine.set_option(n, v)
+        engine.profile(True)
+        engine.profile_reset()
+        r = engine.count(k, m)
+        stats = engine.profile_get()
+        engine.profile(False)
+    finally:
+        engine.profile(False)
+        for n, v in RESET.items():
+            engine.set_option(n, v)
+    assert ("count_digit_hist" in stats) == expect_stream, sorted(stats)
+    assert r.n_items == want["n_items"] and r.words_per_edge == want["wpe"]
+    edges = engine.fetch(lib.BUF_EDGES, np.uint32).reshape(-1, r.words_per_edge)
+    assert edges.shape == want["edges"].shape
+    assert np.array_equal(edges, want["edges"])
+    assert np.array_equal(engine.fetch(lib.BUF_BUCKET_COUNT, np.uint64), want["bucket_count"])
+    assert np.array_equal(engine.fetch(lib.BUF_MUL_HIST, np.int64), want["hist"])
+    assert np.array_equal(engine.fetch(lib.BUF_FIRST_0_OUT, np.uint32), want["first_0_out"])
+    assert np.array_equal(engine.fetch(lib.BUF_LAST_0_IN, np.uint32), want["last_0_in"])
+
+
+@pytest.mark.parametrize("opts", [dict(), dict(count_stream=0), dict(s1_stream_fill=40), dict(s1_pos_bits=12), dict(s1_stream_bits=19), dict(s1_stream_sub0=2),
+                                  dict(s1_stream_probes=0)], ids=lambda o: ",".join("%s=%d" % kv for kv in o.items()) or "default")
+@pytest.mark.parametrize("kind,k,m", [("pe100", 21, 2), ("repeats100", 21, 2), ("tiny60", 21, 2), ("short30", 21, 2), ("pe100", 17, 1), ("repeats100", 22, 2),
+                                      ("pe100", 13, 2), ("repeats100", 21, 1)])
+def test_count_on_the_bucket_streaming(engine, kind, k, m, opts):
+    reads = fixed_library(kind, seed=k * 7 + m)
+    pkg = ob.Package(reads, reverse=True)
+    # (k = 13: a full-sort plan, not the stream plan — the tile path; a probe limit of 0 makes the stream form give up -> the tile path)
+    expect_stream = opts.get("count_stream", 1) == 1 and k >= 17
+    check_count(engine, pkg, k, m, opts, expect_stream)
+
+
+@pytest.mark.parametrize("k,m", [(23, 2), (21, 3)])
+def test_shapes_the_stream_form_does_not_take(engine, k, m):
+    reads = fixed_library("pe100", seed=3)
+    check_count(engine, ob.Package(reads, reverse=True), k, m, {}, False)

@@ -125,6 +125,33 @@ def configs2_golden(args):
     print("wrote", path)
 
 
+def varlen_golden(args):
+    """tests/golden/fullsize_varlen.json: the reference's read2sdbg -k 21 -m 2 on the configs[1] library with its reads TRIMMED
+    (synth.VARLEN_RULES: every read cut to U[100, 150]; 2 % of the reads cut) — libraries whose reads are not of one length"""
+    n = int(args.reads) // 2 * 2
+    k, m = 21, 2
+    ref = os.path.join(ROOT, "oracle", "_ref", "ref_core")
+    d = args.keep or tempfile.mkdtemp(prefix="mhx_var_")
+    os.makedirs(d, exist_ok=True)
+    path = args.out if args.out.endswith("_varlen.json") else os.path.join(ROOT, "tests", "golden", "fullsize_varlen.json")
+    out = {"reads": n, "k": k, "m": m, "generator": "tools/make_fullsize_golden.py --preset varlen", "reference_threads": args.threads, "rules": {}}
+    for rule in synth.VARLEN_RULES:
+        lib = os.path.join(d, "reads_" + rule)
+        if not os.path.exists(lib + ".bin"):
+            n_reads, n_bases = synth.write_var_read_lib(lib, synth.varlen_blocks(n, rule))
+        else:
+            n_bases = int(open(lib + ".lib_info").read().split()[0])
+        dt, _ = run([ref, "read2sdbg", "-k", str(k), "-m", str(m), "--host_mem", "%g" % args.host_mem, "--num_cpu_threads", str(args.threads),
+                     "--read_lib_file", lib, "--output_prefix", os.path.join(d, "r2s_" + rule)])
+        c = sdbg_summary(os.path.join(d, "r2s_" + rule))
+        c.update(wall_s=round(dt, 1), bases=n_bases, lib_bin_md5=canon.digest_file(lib + ".bin"))
+        out["rules"][rule] = c
+        print(rule, c, flush=True)
+        with open(path, "w") as f:
+            json.dump(out, f, indent=1)
+    print("wrote", path)
+
+
 def run(cmd):
     t0 = time.perf_counter()
     p = subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True)
@@ -149,13 +176,15 @@ def main():
     ap.add_argument("--threads", type=int, default=8)
     ap.add_argument("--keep", default=None, help="work directory to keep (default: a temp dir)")
     ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden", "fullsize.json"))
-    ap.add_argument("--preset", choices=["configs1", "meta", "configs2"], default="configs1")
+    ap.add_argument("--preset", choices=["configs1", "meta", "configs2", "varlen"], default="configs1")
     ap.add_argument("--host_mem", type=float, default=48e9)
     args = ap.parse_args()
     if args.preset == "meta":
         return meta_golden(args)
     if args.preset == "configs2":
         return configs2_golden(args)
+    if args.preset == "varlen":
+        return varlen_golden(args)
     n = int(args.reads) // 2 * 2
     k, m = 21, 2
     ref = os.path.join(ROOT, "oracle", "_ref", "ref_core")
