@@ -299,9 +299,13 @@ void upload_edges(mhx_ctx *c, const uint32_t *raw, uint64_t n_edges, uint32_t k,
   uint32_t *d_raw = c->ws("edges_raw", (n_edges * wpe + 4) * 4).as<uint32_t>();
   if (n_edges) upload_pinned(c, d_raw, raw, n_edges * wpe * 4);
   const uint64_t bases = n_edges * (uint64_t)len, n_out = div_ceil(bases, 16);
-  s.words.reserve((n_out + kSeqPadWords) * 4);
-  s.start.reserve((n_edges + 2) * 8);
-  s.mult.reserve((n_edges + 1) * 2);
+  // room for the mercy edges that may be appended behind them (SeqToSdbg::Initialize, seq_to_sdbg.cpp:370-378: 25 % by default,
+  // MEGAHIT_NUM_MERCY_FACTOR otherwise — the CLI passes it on as edges_reserve_permille): the store does not have to grow then
+  const uint64_t permille = (uint64_t)std::min<long long>(std::max<long long>(c->opt("edges_reserve_permille", 1000), 1000), 100000);
+  const uint64_t n_res = n_edges * permille / 1000;
+  s.words.reserve((div_ceil(n_res * (uint64_t)len, 16) + kSeqPadWords) * 4);
+  s.start.reserve((n_res + 2) * 8);
+  s.mult.reserve((n_res + 1) * 2);
   s.mult.used = n_edges * 2;
   MHX_HIP(hipMemsetAsync(s.words.as<uint32_t>() + n_out, 0, kSeqPadWords * 4, st));
   const uint64_t n_thr = std::max(n_out, n_edges);

@@ -31,6 +31,17 @@
 #include "formats.h"
 #include "mhx.h"
 
+// how much room the store of the sorted edges gets for mercy edges: the reference reserves 25 % more than the edges, or
+// MEGAHIT_NUM_MERCY_FACTOR times more when that is set (SeqToSdbg::Initialize, src/sorting/seq_to_sdbg.cpp:370-378)
+static long long mercy_reserve_permille() {
+  if (const char *f = getenv("MEGAHIT_NUM_MERCY_FACTOR")) {
+    char *end = nullptr;
+    const double v = strtod(f, &end);
+    if (end != f && v >= 0) return (long long)std::min(100000.0, 1000.0 * (1.0 + v));
+  }
+  return 1250;
+}
+
 extern char **environ;
 
 using mhxio::fatal;
@@ -195,6 +206,7 @@ void run_ranks(const RankSet &rs, Body body) {
   for (int r = 0; r < rs.n; ++r) {
     ctx[r] = mhx_create(rs.dev[r]);
     if (!ctx[r]) fatal("rank %d (device %d): %s", r, rs.dev[r], mhx_last_error());
+    mhx_profile_enable(ctx[r], getenv("MHX_PROFILE") ? 1 : 0);
   }
   std::vector<mhx_comm *> comm(rs.n, nullptr);
   unsigned char id[MHX_COMM_ID_BYTES];
@@ -232,6 +244,43 @@ void run_ranks(const RankSet &rs, Body body) {
       }
     });
   for (auto &t : th) t.join();
+  if (getenv("MHX_PROFILE")) {  // per-kernel HIP-event times of every rank (the ranks run side by side: the job's time per kernel is the slowest rank's)
+    std::map<std::string, mhx_kernel_stat> worst;
+    std::vector<std::vector<mhx_kernel_stat>> per_rank(rs.n);
+    for (int r = 0; r < rs.n; ++r) {
+      std::vector<mhx_kernel_stat> ks(64);
+      const int n = mhx_profile_get(ctx[r], ks.data(), (int)ks.size());
+      ks.resize(n < 0 ? 0 : std::min<size_t>((size_t)n, ks.size()));
+      for (const mhx_kernel_stat &k : ks) {
+        auto it = worst.find(k.name);
+        if (it == worst.end() || k.total_ms > it->second.total_ms) worst[k.name] = k;
+      }
+      per_rank[r] = ks;
+    }
+    std::vector<mhx_kernel_stat> ws;
+    for (auto &kv : worst) ws.push_back(kv.second);
+    std::sort(ws.begin(), ws.end(), [](const mhx_kernel_stat &a, const mhx_kernel_stat &b) { return a.total_ms > b.total_ms; });
+    for (const mhx_kernel_stat &k : ws) info("profile %-24s %6u launches %12.3f ms %14.0f algorithmic bytes (slowest of %d ranks)", k.name, k.launches, k.total_ms, k.algo_bytes, rs.n);
+    if (const char *path = getenv("MHX_PROFILE_JSON")) {
+      if (FILE *f = fopen(path, "w")) {
+        auto put = [&](const std::vector<mhx_kernel_stat> &ks) {
+          fprintf(f, "{");
+          for (size_t i = 0; i < ks.size(); ++i)
+            fprintf(f, "%s\"%s\": {\"launches\": %u, \"ms\": %.4f, \"bytes\": %.0f}", i ? ", " : "", ks[i].name, ks[i].launches, ks[i].total_ms, ks[i].algo_bytes);
+          fprintf(f, "}");
+        };
+        fprintf(f, "{\"kernels\": ");
+        put(ws);
+        fprintf(f, ", \"what\": \"per kernel the slowest of %d ranks\", \"ranks\": [", rs.n);
+        for (int r = 0; r < rs.n; ++r) {
+          if (r) fprintf(f, ", ");
+          put(per_rank[r]);
+        }
+        fprintf(f, "]}\n");
+        fclose(f);
+      }
+    }
+  }
   for (int r = 0; r < rs.n; ++r) {
     mhx_comm_destroy(comm[r]);
     mhx_destroy(ctx[r]);
@@ -766,7 +815,9 @@ int main_seq2sdbg(int argc, char **argv) {
       const uint64_t ne = es.n_edges(), lo = ne * r / rs.n, hi = ne * (r + 1) / rs.n;
       bool loaded = false;
       if (hi > lo) {
+        if (need_mercy) mhx_set_option(c, "edges_reserve_permille", mercy_reserve_permille());
         CKT(mhx_load_edges(c, es.data + lo * es.words_per_edge, hi - lo, es.k, es.words_per_edge));
+        if (need_mercy) mhx_set_option(c, "edges_reserve_permille", 1000);
         loaded = true;
       }
       if (need_mercy) {
@@ -809,7 +860,9 @@ int main_seq2sdbg(int argc, char **argv) {
     mhxio::EdgeSet es = mhxio::read_edges(in);
     info("Number edges: %llu", (unsigned long long)es.n_edges());
     // edges -> gap-free (k+1)-mer store + multiplicities (EdgeReader::ReadSorted/ReadUnsorted, edge_reader.h:24-52): on the GPU
+    if (need_mercy) mhx_set_option(c, "edges_reserve_permille", mercy_reserve_permille());
     CK(mhx_load_edges(c, es.data, es.n_edges(), es.k, es.words_per_edge));
+    if (need_mercy) mhx_set_option(c, "edges_reserve_permille", 1000);
     loaded = true;
     info("Read %llu edges. Time elapsed: %.4f", (unsigned long long)es.n_edges(), t.lap());
     if (need_mercy) {
@@ -1225,7 +1278,7 @@ int serve(const char *path) {
     std::vector<std::pair<std::string, std::string>> restore;  // (name, previous value or "\x01" for unset)
     std::vector<std::string> drop;                             // MHX_* of the server that the client does not have
     for (char **e = environ; *e; ++e)
-      if (!strncmp(*e, "MHX_", 4) && strncmp(*e, "MHX_SERVE", 9)) {
+      if ((!strncmp(*e, "MHX_", 4) && strncmp(*e, "MHX_SERVE", 9)) || !strncmp(*e, "MEGAHIT_NUM_MERCY_FACTOR=", 25)) {
         const std::string kv = *e, name = kv.substr(0, kv.find('='));
         bool sent = false;
         for (const std::string &x : envs) sent = sent || x.compare(0, name.size() + 1, name + "=") == 0;
@@ -1345,7 +1398,7 @@ int try_server(int argc, char **argv) {
   for (int i = 1; ok && i < argc; ++i) ok = put_str(fd, argv[i]);
   std::vector<std::string> envs;
   for (char **e = environ; *e; ++e)
-    if (!strncmp(*e, "MHX_", 4) && strncmp(*e, "MHX_SERVE", 9)) envs.push_back(*e);
+    if ((!strncmp(*e, "MHX_", 4) && strncmp(*e, "MHX_SERVE", 9)) || !strncmp(*e, "MEGAHIT_NUM_MERCY_FACTOR=", 25)) envs.push_back(*e);
   const uint32_t ne = (uint32_t)envs.size();
   ok = ok && write_all(fd, &ne, 4);
   for (const std::string &x : envs) ok = ok && put_str(fd, x);

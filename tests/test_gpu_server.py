@@ -105,3 +105,36 @@ def test_under_the_references_name_the_server_is_the_default(tmp_path, monkeypat
         assert p.returncode == 0 and "server: totals since its start" not in p.stderr, p.stderr[-600:]
     finally:
         subprocess.run([gu.MHX_CORE, "--serve-stop", sock], timeout=60)
+
+
+def test_settings_of_one_request_do_not_stick_to_the_server(tmp_path, server):
+    """the environment settings libmhx reads (MHX_S2_PER_OCCURRENCE, MHX_S1_MARK, the mhx_set_option knobs as MHX_<NAME>) are read per
+    call, not cached in function-local statics: the same sub-program asked for with and without a setting, in both orders, by
+    requests to one resident server, takes the path its own request names — seen from the stage-2 item count (per-occurrence items
+    against aggregated ones) and the stage-1 plan line — and writes the same files every time (ADVICE r3, VERDICT r4 weak #9)"""
+    import re
+    from megahit_amd import canon
+    sock, proc = server
+    ent = [e for e in gu.cases() if e["case"]["prog"] == "read2sdbg" and e["case"]["k"] == 21 and not e["case"].get("mercy")][0]
+    c = ent["case"]
+
+    def call(tag, **extra):
+        env = {k: v for k, v in os.environ.items() if k not in ("MHX_S2_PER_OCCURRENCE", "MHX_S1_MARK", "MHX_S1_STREAM", "MHX_SDBG_FAST")}
+        env.update(MHX_SERVER=sock, **extra)
+        out = str(tmp_path / tag)
+        p = subprocess.run([gu.MHX_CORE, "read2sdbg", "-k", str(c["k"]), "-m", str(c["m"]), "--read_lib_file", os.path.join(gu.GOLD, c["lib"]),
+                            "--output_prefix", out, "--host_mem", "2e9", "--num_cpu_threads", "3"], stderr=subprocess.PIPE, text=True, env=env)
+        assert p.returncode == 0, p.stderr[-600:]
+        items = int(re.search(r"Stage 2 done \((\d+) items\)", p.stderr).group(1))
+        plan = re.search(r"Stage 1 plan: (.*)", p.stderr).group(1)
+        return items, plan, canon.digest_sdbg(out)
+
+    a_items, a_plan, a_dig = call("a")
+    b_items, b_plan, b_dig = call("b", MHX_S2_PER_OCCURRENCE="1")
+    c_items, c_plan, c_dig = call("c")
+    d_items, d_plan, d_dig = call("d", MHX_S1_STREAM="0", MHX_SDBG_FAST="0")
+    e_items, e_plan, e_dig = call("e")
+    assert a_dig == b_dig == c_dig == d_dig == e_dig
+    assert b_items > a_items and c_items == a_items == e_items  # per occurrence only while asked for
+    assert "stream" in a_plan and "stream" not in d_plan and e_plan == a_plan == c_plan
+    assert proc.poll() is None, "the server died"
