@@ -626,7 +626,10 @@ __device__ __forceinline__ bool sdbg_decide(uint32_t M, int a, int b, int &w, in
 template <bool EMIT, int T>  // T records per workgroup (256 threads)
 __global__ __launch_bounds__(256) void k_sdbg_fast(const uint2 *__restrict__ items, long long n, SdbgFastP P, uint64_t *__restrict__ tile_tot,
                                                    const uint64_t *__restrict__ tile_base, uint64_t n_tiles, uint16_t *__restrict__ out16,
-                                                   unsigned long long *__restrict__ w_count, unsigned long long *__restrict__ bstart) {
+                                                   unsigned long long *__restrict__ w_count, unsigned long long *__restrict__ bstart,
+                                                   uint32_t *__restrict__ res_out) {
+  // res_out (counting launch): what every run head found out is kept, 4 bytes per record, and the emitting launch is
+  // k_sdbg_emit_res — no second walk over the groups
   constexpr int PER = T / 256, H = kSdbgFastHalo, NW = 256 / kWave;
   __shared__ unsigned long long win[T + 2 * H];  // win[H + i] = record base + i
   // what a run head found out, per record of the tile: flags | W << 4 | multiplicity << 12 (0 = not a run head).  Kept in LDS,
@@ -787,6 +790,13 @@ __global__ __launch_bounds__(256) void k_sdbg_fast(const uint2 *__restrict__ ite
   __syncthreads();
   if constexpr (!EMIT) {
     if (tid < 3) tile_tot[(uint64_t)tid * n_tiles + blockIdx.x] = cell[tid][PER * NW];
+    if (res_out) {
+#pragma unroll
+      for (int j = 0; j < PER; ++j) {
+        const long long g = base + j * 256 + tid;
+        if (g < n) res_out[g] = res[j * 256 + tid];
+      }
+    }
   } else {
     const uint64_t b0 = tile_base[blockIdx.x], b1 = tile_base[n_tiles + blockIdx.x], b2 = tile_base[2 * n_tiles + blockIdx.x];
 #pragma unroll 1
@@ -831,6 +841,93 @@ __global__ __launch_bounds__(256) void k_sdbg_fast(const uint2 *__restrict__ ite
     __syncthreads();
     if (tid < 10 && wc[tid]) atomicAdd(&w_count[tid], (unsigned long long)wc[tid]);
   }
+}
+
+// the emitting launch when the counting launch kept its findings (k_sdbg_fast<false>: res_out): prefix sums over the three
+// counters of the tile and the SdBG records — the sorted items themselves are read only for tips (their label) and for the
+// first group of an lv1 bucket
+template <int T>
+__global__ __launch_bounds__(256) void k_sdbg_emit_res(const uint2 *__restrict__ items, long long n, SdbgFastP P, const uint32_t *__restrict__ res_g,
+                                                       const uint64_t *__restrict__ tile_base, uint64_t n_tiles, uint16_t *__restrict__ out16,
+                                                       unsigned long long *__restrict__ w_count, unsigned long long *__restrict__ bstart) {
+  constexpr int PER = T / 256, NW = 256 / kWave;
+  constexpr uint32_t kKept = 1u, kTip = 2u, kLast = 8u, kHead = 0x100u, kBucketFirst = 0x200u;
+  __shared__ uint32_t cell[3][PER * NW + 1];
+  __shared__ uint32_t wc[10];
+  const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = tid / kWave;
+  const uint64_t lanemask_lt = (1ull << lane) - 1;
+  const long long base = (long long)blockIdx.x * T;
+  if (tid < 10) wc[tid] = 0;
+  uint32_t r[PER];
+#pragma unroll
+  for (int j = 0; j < PER; ++j) {
+    const long long g = base + j * 256 + tid;
+    r[j] = g < n ? res_g[g] : 0u;
+  }
+#pragma unroll
+  for (int j = 0; j < PER; ++j) {
+    const bool kept = r[j] & kKept;
+    const uint64_t bk = __ballot(kept), bt = __ballot(kept && (r[j] & kTip)), bl = __ballot(kept && (r[j] >> 12) > 254u);
+    if (lane == 0) {
+      cell[0][j * NW + wv] = (uint32_t)__builtin_popcountll(bk);
+      cell[1][j * NW + wv] = (uint32_t)__builtin_popcountll(bt);
+      cell[2][j * NW + wv] = (uint32_t)__builtin_popcountll(bl);
+    }
+  }
+  __syncthreads();
+  if (tid < kWave) {
+    static_assert(PER * NW <= kWave, "one wavefront scans the cells");
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const uint32_t x = lane < PER * NW ? cell[c][lane] : 0u;
+      const uint32_t incl = wave_inclusive_sum(x);
+      if (lane < PER * NW) cell[c][lane] = incl - x;
+    }
+  }
+  __syncthreads();
+  const uint64_t b0 = tile_base[blockIdx.x], b1 = tile_base[n_tiles + blockIdx.x], b2 = tile_base[2 * n_tiles + blockIdx.x];
+#pragma unroll
+  for (int j = 0; j < PER; ++j) {
+    const uint32_t rr = r[j];
+    const bool kept = rr & kKept;
+    const uint32_t m = rr >> 12;
+    const uint64_t bk = __ballot(kept), bt = __ballot(kept && (rr & kTip)), bl = __ballot(kept && m > 254u);
+    if (!(rr & kHead)) continue;
+    const uint64_t o0 = b0 + cell[0][j * NW + wv] + (uint32_t)__builtin_popcountll(bk & lanemask_lt);
+    const uint64_t o1 = b1 + cell[1][j * NW + wv] + (uint32_t)__builtin_popcountll(bt & lanemask_lt);
+    const uint64_t o2 = b2 + cell[2][j * NW + wv] + (uint32_t)__builtin_popcountll(bl & lanemask_lt);
+    const bool tip = kept && (rr & kTip);
+    unsigned long long v = 0;
+    if ((rr & kBucketFirst) || tip) v = sdbg_ld64(items, base + j * 256 + tid);
+    if (rr & kBucketFirst) {
+      const uint32_t bkt = (uint32_t)(v >> 48);
+      bstart[bkt] = o0;
+      bstart[MHX_NUM_BUCKETS + bkt] = o1;
+      bstart[2 * MHX_NUM_BUCKETS + bkt] = o2;
+    }
+    if (!kept) continue;
+    const uint32_t w = (rr >> 4) & 0xFu, last = (rr & kLast) ? 1u : 0u;
+    uint64_t o16 = o0 + o2 + 2ull * P.wpt * o1;
+    out16[o16++] = (uint16_t)(w | (last << 4) | ((tip ? 1u : 0u) << 5) | ((m > 255 ? 255u : m) << 8));  // SdbgItem, sdbg_item.h:14-24
+    if (m > 254) out16[o16++] = (uint16_t)m;
+    if (tip) {
+      for (int x = 0; x < P.wpt; ++x) {
+        uint32_t t = x == 0 ? (uint32_t)(v >> 32) : (uint32_t)v;
+        if (P.is_seq == 2 && x == P.wpt - 1) {  // (the reference's raw tip label: SdbgOp::unit_emit)
+          const int tip_chars = P.k - 1, in_word = tip_chars - 16 * x;
+          const uint32_t cm = in_word >= 16 ? 0xFFFFFFFFu : (in_word <= 0 ? 0u : 0xFFFFFFFFu << (32 - 2 * in_word));
+          t &= cm;
+          if (x == P.ref_kw - 1) t |= (uint32_t)((v >> P.bsh) & 7ull);
+        }
+        out16[o16++] = (uint16_t)(t & 0xFFFFu);
+        out16[o16++] = (uint16_t)(t >> 16);
+      }
+    }
+    atomicAdd(&wc[w], 1u);
+    if (last) atomicAdd(&wc[9], 1u);
+  }
+  __syncthreads();
+  if (tid < 10 && wc[tid]) atomicAdd(&w_count[tid], (unsigned long long)wc[tid]);
 }
 
 // bstart[3][65536] (kNoStart = empty bucket) + totals -> per-bucket counts and byte offsets: a bucket ends where the next
@@ -937,17 +1034,21 @@ static void emit_sdbg_impl(mhx_ctx *c, const uint32_t *sorted, uint64_t n_items,
       const uint2 *recs = reinterpret_cast<const uint2 *>(sorted);
       uint16_t *out16 = nullptr;
       uint64_t out_bytes = 0;
+      // sdbg_fast_keep: the counting launch keeps what its run heads found (4 bytes per record, up to sdbg_fast_keep_max_mb of them)
+      // and the emitting launch only scans and writes
+      const bool keep = c->opt("sdbg_fast_keep", 1) != 0 && n_items * 4 <= (uint64_t)c->opt("sdbg_fast_keep_max_mb", 4096) << 20;
+      uint32_t *res_g = keep ? c->ws("sdbg_res", n_items * 4 + 64).as<uint32_t>() : nullptr;
 #define MHX_SDBG_FAST(EMITV, NAME, BYTES, TT, TB)                                                                                          \
   do {                                                                                                                                     \
     if (ftile == 1024)                                                                                                                     \
       MHX_LAUNCH(c, NAME, BYTES, hipLaunchKernelGGL((k_sdbg_fast<EMITV, 1024>), dim3((unsigned)n_ft), dim3(256), 0, st, recs, (long long)n_items, F, TT, TB, \
-                                                    n_ft, out16, w_count, bstart));                                                        \
+                                                    n_ft, out16, w_count, bstart, res_g));                                                 \
     else if (ftile == 4096)                                                                                                                \
       MHX_LAUNCH(c, NAME, BYTES, hipLaunchKernelGGL((k_sdbg_fast<EMITV, 4096>), dim3((unsigned)n_ft), dim3(256), 0, st, recs, (long long)n_items, F, TT, TB, \
-                                                    n_ft, out16, w_count, bstart));                                                        \
+                                                    n_ft, out16, w_count, bstart, res_g));                                                 \
     else                                                                                                                                   \
       MHX_LAUNCH(c, NAME, BYTES, hipLaunchKernelGGL((k_sdbg_fast<EMITV, 2048>), dim3((unsigned)n_ft), dim3(256), 0, st, recs, (long long)n_items, F, TT, TB, \
-                                                    n_ft, out16, w_count, bstart));                                                        \
+                                                    n_ft, out16, w_count, bstart, res_g));                                                 \
   } while (0)
       MHX_SDBG_FAST(false, "sdbg_count", bytes, ftt, (const uint64_t *)nullptr);
       for (int r = 0; r < 3; ++r) exclusive_scan_u64(c, ftt + r * n_ft, ftb + r * n_ft, n_ft, d_tot + r);
@@ -957,7 +1058,21 @@ static void emit_sdbg_impl(mhx_ctx *c, const uint32_t *sorted, uint64_t n_items,
       out16 = c->result(MHX_BUF_SDBG_BYTES, out_bytes ? out_bytes : 2).as<uint16_t>();
       c->results[MHX_BUF_SDBG_BYTES].used = out_bytes;
       MHX_HIP(hipMemsetAsync(bstart, 0xFF, 3 * MHX_NUM_BUCKETS * 8, st));
-      MHX_SDBG_FAST(true, "sdbg_emit", bytes + (double)out_bytes, (uint64_t *)nullptr, (const uint64_t *)ftb);
+      if (keep) {
+        const double ebytes = (double)n_items * 4 + (double)out_bytes;
+        if (ftile == 1024)
+          MHX_LAUNCH(c, "sdbg_emit", ebytes, hipLaunchKernelGGL((k_sdbg_emit_res<1024>), dim3((unsigned)n_ft), dim3(256), 0, st, recs, (long long)n_items, F, res_g,
+                                                                (const uint64_t *)ftb, n_ft, out16, w_count, bstart));
+        else if (ftile == 4096)
+          MHX_LAUNCH(c, "sdbg_emit", ebytes, hipLaunchKernelGGL((k_sdbg_emit_res<4096>), dim3((unsigned)n_ft), dim3(256), 0, st, recs, (long long)n_items, F, res_g,
+                                                                (const uint64_t *)ftb, n_ft, out16, w_count, bstart));
+        else
+          MHX_LAUNCH(c, "sdbg_emit", ebytes, hipLaunchKernelGGL((k_sdbg_emit_res<2048>), dim3((unsigned)n_ft), dim3(256), 0, st, recs, (long long)n_items, F, res_g,
+                                                                (const uint64_t *)ftb, n_ft, out16, w_count, bstart));
+      } else {
+        res_g = nullptr;
+        MHX_SDBG_FAST(true, "sdbg_emit", bytes + (double)out_bytes, (uint64_t *)nullptr, (const uint64_t *)ftb);
+      }
 #undef MHX_SDBG_FAST
       uint32_t *block_first = c->ws("bucket_block_first", MHX_NUM_BUCKETS / 256 * 4).as<uint32_t>();
       hipLaunchKernelGGL(k_bucket_first, dim3(MHX_NUM_BUCKETS / 256), dim3(256), 0, st, bstart, block_first);

@@ -12,7 +12,8 @@ from test_gpu_sdbg import check_sdbg, edges_package, repetitive_reads
 
 pytestmark = pytest.mark.gpu
 
-VARIANTS = [dict(), dict(sdbg_fast=0), dict(sdbg_fast_halo=1), dict(sdbg_fast_halo=3), dict(sdbg_fast_halo=17)]
+VARIANTS = [dict(), dict(sdbg_fast=0), dict(sdbg_fast_halo=1), dict(sdbg_fast_halo=3), dict(sdbg_fast_halo=17), dict(sdbg_fast_keep=0), dict(sdbg_fast_keep=0, sdbg_fast_halo=2),
+            dict(sdbg_fast_tile=1024), dict(sdbg_fast_tile=4096, sdbg_fast_keep=0)]
 IDS = lambda o: ",".join("%s=%d" % kv for kv in o.items()) or "default"
 
 
@@ -24,6 +25,8 @@ def with_options(engine, opts, fn):
     finally:
         engine.set_option("sdbg_fast", 1)
         engine.set_option("sdbg_fast_halo", 128)
+        engine.set_option("sdbg_fast_keep", 1)
+        engine.set_option("sdbg_fast_tile", 2048)
 
 
 def many_dummies_reads(seed):
@@ -79,7 +82,7 @@ def test_seq2sdbg_items(engine, kind, k, m, opts):
     check_sdbg(engine, r, ob.seq2sdbg(epkg, mult, k), per_occurrence=True)
 
 
-@pytest.mark.parametrize("opts", [dict(), dict(sdbg_fast=0), dict(sdbg_fast_halo=2)], ids=IDS)
+@pytest.mark.parametrize("opts", [dict(), dict(sdbg_fast=0), dict(sdbg_fast_halo=2), dict(sdbg_fast_keep=0)], ids=IDS)
 def test_runs_beyond_tile_and_cap(engine, opts):
     """one run of 70 000 identical '$' items (its multiplicity sum reaches the 65535 cap inside the wavefront-wide sum), poly-A
     groups spanning tiles: the far path on real shapes, also with the default halo"""
