@@ -787,6 +787,120 @@ struct CountGenT {
     }
   }
 };
+// the same records from a library whose reads are not of one length: `per` = max_len - k item slots per read, the slots a shorter read
+// does not fill declined (S1GenVarT's scheme)
+struct CountGenVarT {
+  const uint32_t *seq;
+  const uint64_t *start;  // [n_seqs + 1]
+  uint64_t n_seqs;
+  uint32_t per;
+  int k;
+  uint64_t pos_base;
+  uint32_t pos_bits;
+  uint32_t tile_q, tile_r;
+  static constexpr bool kMayDrop = true;
+  __device__ __forceinline__ bool is_record(const Rec<3> &r) const { return (r.w[1] & 63u) != 63u; }
+  template <int NI>
+  __device__ __forceinline__ uint64_t index(uint64_t tile_base, int w, int lane, int j) const {
+    return tile_base + (uint64_t)((w * kWave + lane) * NI + j);
+  }
+  template <int NI, int UT>
+  __device__ __forceinline__ void get_unit(uint64_t unit_base, int w, int lane, uint64_t n, Rec<3> (&rec)[UT][NI]) const {
+    static_assert(NI <= 8, "a run of NI edges and their flanks inside one 32-base window");
+    constexpr uint32_t kTileItems = kSortThreads * NI;
+    const uint64_t g00 = unit_base + (uint64_t)((w * kWave + lane) * NI);
+    const uint64_t emask = ~0ull << (64 - 2 * (k + 1));
+    const unsigned rsh = (unsigned)(2 * (30 - k));
+    uint32_t jt[UT];
+    uint64_t rt[UT];
+    {
+      const uint64_t r = g00 / per;
+      jt[0] = (uint32_t)(g00 - r * per);
+      rt[0] = r;
+#pragma unroll
+      for (int t = 1; t < UT; ++t) {
+        uint32_t jn = jt[t - 1] + tile_r;
+        uint64_t rn = rt[t - 1] + tile_q;
+        if (jn >= per) {
+          jn -= per;
+          ++rn;
+        }
+        jt[t] = jn;
+        rt[t] = rn;
+      }
+#pragma unroll
+      for (int t = 0; t < UT; ++t)
+        if (g00 + (uint64_t)t * kTileItems >= n) {
+          jt[t] = 0;
+          rt[t] = 0;
+        }
+    }
+    uint64_t s0[UT], s1[UT], s2[UT];
+#pragma unroll
+    for (int t = 0; t < UT; ++t) {
+      s0[t] = start[rt[t]];
+      s1[t] = start[rt[t] + 1];
+      s2[t] = start[rt[t] + 2 < n_seqs ? rt[t] + 2 : n_seqs];
+    }
+    uint32_t c[UT][3], nx[UT][3];
+#pragma unroll
+    for (int t = 0; t < UT; ++t) {
+      const uint32_t L = (uint32_t)(s1[t] - s0[t]), cnt = L >= (uint32_t)k + 1 ? L - k : 0u;
+      const uint32_t j0 = min(jt[t], cnt ? cnt - 1 : 0u);  // (a run of declined slots only: any window of the read will do)
+      uint64_t wcur, wnext;
+      unsigned sh, down;
+      count_window_addr(s0[t] + j0, wcur, sh, down);
+      count_window_addr(s1[t], wnext, sh, down);
+#pragma unroll
+      for (int x = 0; x < 3; ++x) {
+        c[t][x] = seq[wcur + x];
+        nx[t][x] = seq[wnext + x];
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < UT; ++t) {
+      const uint64_t g0 = g00 + (uint64_t)t * kTileItems;
+      uint32_t j = jt[t];
+      uint64_t base = s0[t];
+      uint32_t L = (uint32_t)(s1[t] - s0[t]), cnt = L >= (uint32_t)k + 1 ? L - k : 0u;
+      const uint32_t Ln = (uint32_t)(s2[t] - s1[t]), cntn = Ln >= (uint32_t)k + 1 ? Ln - k : 0u;
+      uint64_t wd;
+      unsigned sh0, down0, shn, downn;
+      count_window_addr(base + min(j, cnt ? cnt - 1 : 0u), wd, sh0, down0);
+      uint64_t W = (((uint64_t)funnel_l(c[t][0], c[t][1], sh0) << 32) | funnel_l(c[t][1], c[t][2], sh0)) >> down0;
+      uint64_t R = rc64(W, 32);
+      uint32_t prun = j;
+      count_window_addr(s1[t], wd, shn, downn);
+      const uint64_t Wn = (((uint64_t)funnel_l(nx[t][0], nx[t][1], shn) << 32) | funnel_l(nx[t][1], nx[t][2], shn)) >> downn;
+      const uint64_t Rn = rc64(Wn, 32);
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const unsigned d2 = (j - prun) * 2;
+        const uint64_t f = (W << (d2 + 2)) & emask;
+        const uint64_t rc = (R << (rsh - d2)) & emask;
+        const unsigned prev_b = (unsigned)(W >> (62 - d2)) & 3u, next_b = (unsigned)(W >> ((unsigned)(58 - 2 * k) - d2)) & 3u;
+        uint32_t out[3];
+        count_item_from_parts(f, rc, prev_b, next_b, j, L, k, base + j, pos_base, pos_bits, out);
+        if (j >= cnt) out[1] = kS1Dropped;  // a slot this read does not fill
+        if (g0 + (uint64_t)i < n) {
+          rec[t][i].w[0] = out[0];
+          rec[t][i].w[1] = out[1];
+          rec[t][i].w[2] = out[2];
+        }
+        if (++j == per) {
+          j = 0;
+          base = s1[t];
+          L = Ln;
+          cnt = cntn;
+          W = Wn;
+          R = Rn;
+          prun = 0;
+        }
+      }
+    }
+  }
+};
+
 constexpr int kFastPasses = 4;
 // The digit histograms of the coming sort passes without making the records (the pre-pass of the generating first pass):
 // every thread takes IT CONSECUTIVE items — one division per trip, the three window words are reloaded only when the
@@ -1062,9 +1176,10 @@ __global__ __launch_bounds__(256) void k_s1_digit_hist_roll(const uint32_t *__re
 }
 
 // the digit histograms of count's prefix passes (every digit one bit field of the first key word): CountGenT's arithmetic, no records
-template <int IT, int NP>
+template <int IT, int NP, bool VAR = false>  // VAR: reads of any length, `per` = max_len - k item slots each (CountGenVarT)
 __global__ __launch_bounds__(256) void k_count_digit_hist_roll(const uint32_t *__restrict__ seq, uint32_t L, uint32_t per, uint64_t n_items, int k,
-                                                               HiDigits hd, unsigned long long *__restrict__ ghist, uint32_t step_q, uint32_t step_r) {
+                                                               HiDigits hd, unsigned long long *__restrict__ ghist, uint32_t step_q, uint32_t step_r,
+                                                               const uint64_t *__restrict__ start, uint64_t n_seqs) {
   static_assert(IT <= 8, "a run of IT edges and their flanks inside one 32-base window");
   constexpr int B = 256 * IT;
   __shared__ uint32_t h[kFastPasses][4][256];
@@ -1080,15 +1195,29 @@ __global__ __launch_bounds__(256) void k_count_digit_hist_roll(const uint32_t *_
     const uint64_t g0 = blk * B + (uint64_t)threadIdx.x * IT;
     const uint32_t t = rem0 + (uint32_t)threadIdx.x * IT, dq = t / per;
     uint32_t j = t - dq * per;
-    uint64_t base = (q0 + dq) * L;
+    uint64_t r = q0 + dq;
     if (g0 >= n_items) {  // (nothing of this block is this thread's: loads from the start of the store, nothing counted)
       j = 0;
-      base = 0;
+      r = 0;
+    }
+    uint64_t base, base_n;
+    uint32_t cnt, cntn;  // item slots this read / the next one fills
+    if constexpr (VAR) {
+      const uint64_t s0 = start[r], s1 = start[r + 1], s2 = start[r + 2 < n_seqs ? r + 2 : n_seqs];
+      const uint32_t L0 = (uint32_t)(s1 - s0), L1 = (uint32_t)(s2 - s1);
+      base = s0;
+      base_n = s1;
+      cnt = L0 >= (uint32_t)k + 1 ? L0 - k : 0u;
+      cntn = L1 >= (uint32_t)k + 1 ? L1 - k : 0u;
+    } else {
+      base = r * L;
+      base_n = base + L;
+      cnt = cntn = per;
     }
     uint64_t wcur, wnext;
     unsigned sh0, down0, shn, downn;
-    count_window_addr(base + j, wcur, sh0, down0);
-    count_window_addr(base + L, wnext, shn, downn);
+    count_window_addr(base + min(j, cnt ? cnt - 1 : 0u), wcur, sh0, down0);
+    count_window_addr(base_n, wnext, shn, downn);
     const uint32_t c0 = seq[wcur], c1 = seq[wcur + 1], c2 = seq[wcur + 2];
     const uint32_t n0 = seq[wnext], n1 = seq[wnext + 1], n2 = seq[wnext + 2];
     uint64_t W = (((uint64_t)funnel_l(c0, c1, sh0) << 32) | funnel_l(c1, c2, sh0)) >> down0;
@@ -1102,13 +1231,13 @@ __global__ __launch_bounds__(256) void k_count_digit_hist_roll(const uint32_t *_
       const uint64_t f = (W << (d2 + 2)) & emask;
       const uint64_t rc = (R << (rsh - d2)) & emask;
       const uint32_t hi = (uint32_t)((rc < f ? rc : f) >> 32);
-      if (g0 + u < n_items) {
+      if (g0 + u < n_items && j < cnt) {
 #pragma unroll
         for (int p = 0; p < NP; ++p) atomicAdd(&h[p][wv][(hi >> hd.sh[p]) & hd.mk[p]], 1u);
       }
       if (++j == per) {
         j = 0;
-        base += L;
+        cnt = cntn;
         W = Wn;
         R = Rn;
         prun = 0;
@@ -2565,12 +2694,26 @@ __global__ __launch_bounds__(NT) void k_s1_stream(const uint32_t *__restrict__ i
         }
         // low-complexity reads: a whole trip of one wavefront carrying ONE key (a poly-A stretch: tens of thousands of records
         // of one key in a row) is inserted by one lane instead of 64 lanes queueing up at one LDS address UNR times
-        bool one_key = !COUNT && mine == (1u << UNR) - 1u;  // (count: the records' prev / next chars differ even where their keys agree)
+        bool one_key = mine == (1u << UNR) - 1u;
 #pragma unroll
         for (int u = 1; u < UNR; ++u) one_key = one_key && lk[u] == lk[0];
         one_key = __ballot(one_key && lk[0] == (uint32_t)__builtin_amdgcn_readfirstlane((int)lk[0])) == ~0ull;
         uint32_t mult = 1;
+        uint32_t wave_add1 = 0, wave_add2 = 0;  // COUNT: the seen-once / seen-twice bits of all records of a one-key trip
         if (one_key) {
+          if constexpr (COUNT) {  // (the records' prev / next chars differ even where their keys agree: counted per char over the wavefront)
+#pragma unroll
+            for (unsigned x = 0; x < 4; ++x) {
+              uint32_t cp = 0, cn = 0;
+#pragma unroll
+              for (int u = 0; u < UNR; ++u) {
+                cp += (uint32_t)__builtin_popcountll(__ballot(((rw1[u] >> 3) & 7u) == x));
+                cn += (uint32_t)__builtin_popcountll(__ballot((rw1[u] & 7u) == x));
+              }
+              wave_add1 |= (cp ? 1u << (2 * x) : 0u) | (cn ? 1u << (8 + 2 * x) : 0u);
+              wave_add2 |= (cp >= 2 ? 2u << (2 * x) : 0u) | (cn >= 2 ? 2u << (8 + 2 * x) : 0u);
+            }
+          }
           mine = lane == 0 ? 1u : 0u;
           mult = (uint32_t)(kWave * UNR);
         }
@@ -2585,10 +2728,11 @@ __global__ __launch_bounds__(NT) void k_s1_stream(const uint32_t *__restrict__ i
             if (old == kStreamEmpty) ++claims;
             // prev char x: bit 2x = seen once, 2x + 1 = seen twice; next char x: bits 8 + 2x, 9 + 2x ('$' counts for nothing)
             const unsigned pv = (w1v >> 3) & 7u, nx = w1v & 7u;
-            const uint32_t add = (pv < 4 ? 1u << (2 * pv) : 0u) | (nx < 4 ? 1u << (8 + 2 * nx) : 0u);
-            if (add) {
-              const uint32_t o = atomicOr(&fpos[hh], add);
-              const uint32_t again = ((o & add) << 1) & ~o;
+            const uint32_t add1 = one_key ? wave_add1 : ((pv < 4 ? 1u << (2 * pv) : 0u) | (nx < 4 ? 1u << (8 + 2 * nx) : 0u));
+            const uint32_t add2 = one_key ? wave_add2 : 0u;
+            if (add1) {
+              const uint32_t o = atomicOr(&fpos[hh], add1 | add2);
+              const uint32_t again = ((o & add1) << 1) & ~(o | add2);  // a char seen before and now again: seen twice
               if (again) atomicOr(&fpos[hh], again);
             }
           } else if (old == kStreamEmpty) {  // only read back when the count stays 1: then this record is the key's only one
@@ -4342,9 +4486,16 @@ bool count_stream_applies(const mhx_ctx *c, uint32_t k, uint32_t m) {
   if (!c->opt("count_stream", 1) || c->global_bases || c->filter_on || c->accumulate || c->n_parts > 1) return false;
   // (a caller that asks for a particular form of the tile path gets the tile path)
   if (!c->opt("count_seg", 1) || c->opt("count_seg_bits", 0) || !c->opt("count_extract_fixed", 1)) return false;
-  if (!s.n_seqs || s.fixed_len < k + 1 || s.fixed_len - k < 8 || k < 9 || (int)k > kCountStreamMaxK || m < 1 || m > 2) return false;
+  if (!s.n_seqs || k < 9 || (int)k > kCountStreamMaxK || m < 1 || m > 2) return false;
+  const bool var = s.fixed_len == 0;  // reads of several lengths: item slots padded to the longest read's (CountGenVarT)
+  if (var) {
+    if (!c->opt("s1_var_fast", 1) || s.max_len < k + 1 || s.max_len - k < 8 || s.n_bases <= s.n_seqs * (uint64_t)k) return false;
+    if ((double)s.n_bases * 100.0 < (double)c->opt("s1_var_min_fill", 50) * (double)s.n_seqs * s.max_len) return false;
+  } else if (s.fixed_len < k + 1 || s.fixed_len - k < 8) {
+    return false;
+  }
   if (!c->opt("s1_fused_first_pass", 1) || !c->opt("sort_unit_runs", 1) || !c->opt("s1_gen_any_order", 1)) return false;
-  const uint64_t n_items = s.n_seqs * (uint64_t)(s.fixed_len - k);
+  const uint64_t n_items = var ? s.n_bases - s.n_seqs * (uint64_t)k : s.n_seqs * (uint64_t)(s.fixed_len - k);  // (var: the estimate the plan is made for)
   const uint64_t n_bits = s.n_bases;
   if ((n_bits >> s1_pos_bits(c)) >= 256) return false;  // (positions beyond the tags)
   const S1Plan plan = s1_plan(c, k, n_items, true, 0);
@@ -4359,12 +4510,12 @@ bool count_stream_groups(mhx_ctx *c, uint32_t k, uint32_t m, uint32_t *first_0_o
                          CountStreamOut *o) {
   SeqSet &s = c->seqs;
   hipStream_t st = c->stream;
-  const uint32_t per = s.fixed_len - k;
-  const uint64_t n_items = s.n_seqs * (uint64_t)per;
-  const S1Plan plan = s1_plan(c, k, n_items, true, 0);
+  const bool var = s.fixed_len == 0;
+  const uint32_t per = (var ? s.max_len : s.fixed_len) - k;  // item slots per read
+  const uint64_t n_slots = s.n_seqs * (uint64_t)per;
+  const uint64_t n_est = var ? s.n_bases - s.n_seqs * (uint64_t)k : n_slots;
+  const S1Plan plan = s1_plan(c, k, n_est, true, 0);
   const int KWv = 2;
-  uint32_t *buf_a = c->ws("items_a", n_items * 12 + 64).as<uint32_t>();
-  uint32_t *buf_b = c->ws("items_b", n_items * 12 + 64).as<uint32_t>();
   // digit histograms of the plan's passes (the chained scan wants every pass's bin starts beforehand)
   HiDigits hd;
   hd.n = (int)plan.passes.size();
@@ -4377,18 +4528,36 @@ bool count_stream_groups(mhx_ctx *c, uint32_t k, uint32_t m, uint32_t *first_0_o
   MHX_HIP(hipMemsetAsync(pre_hist, 0, (size_t)hd.n * 256 * 8, st));
   {
     constexpr int ITH = 8;
-    const unsigned fgrid = (unsigned)std::min<uint64_t>(div_ceil(n_items, 256 * ITH), 256 * 8);
+    const unsigned fgrid = (unsigned)std::min<uint64_t>(div_ceil(n_slots, 256 * ITH), 256 * 8);
     const uint64_t stride_items = (uint64_t)fgrid * 256 * ITH;
-#define MHX_CH(NPV)                                                                                                                         \
+#define MHX_CH(NPV, VARV)                                                                                                                   \
   MHX_LAUNCH(c, "count_digit_hist", (double)s.n_bases / 4,                                                                                  \
-             hipLaunchKernelGGL((k_count_digit_hist_roll<ITH, NPV>), dim3(fgrid), dim3(256), 0, st, s.words.as<uint32_t>(), s.fixed_len, per, \
-                                n_items, (int)k, hd, pre_hist, (uint32_t)(stride_items / per), (uint32_t)(stride_items % per)))
-    if (hd.n == 1) MHX_CH(1);
-    else if (hd.n == 2) MHX_CH(2);
-    else if (hd.n == 3) MHX_CH(3);
-    else MHX_CH(4);
+             hipLaunchKernelGGL((k_count_digit_hist_roll<ITH, NPV, VARV>), dim3(fgrid), dim3(256), 0, st, s.words.as<uint32_t>(), s.fixed_len, per, \
+                                n_slots, (int)k, hd, pre_hist, (uint32_t)(stride_items / per), (uint32_t)(stride_items % per),              \
+                                s.start.as<uint64_t>(), s.n_seqs))
+#define MHX_CH2(NPV)             \
+  do {                           \
+    if (var) MHX_CH(NPV, true);  \
+    else MHX_CH(NPV, false);     \
+  } while (0)
+    if (hd.n == 1) MHX_CH2(1);
+    else if (hd.n == 2) MHX_CH2(2);
+    else if (hd.n == 3) MHX_CH2(3);
+    else MHX_CH2(4);
+#undef MHX_CH2
 #undef MHX_CH
   }
+  uint64_t n_items = n_slots;  // the records
+  if (var) {  // = the sum of any one digit histogram
+    std::vector<unsigned long long> h0(256);
+    MHX_HIP(hipMemcpyAsync(h0.data(), pre_hist, 256 * 8, hipMemcpyDeviceToHost, st));
+    MHX_HIP(hipStreamSynchronize(st));
+    n_items = 0;
+    for (unsigned long long v : h0) n_items += v;
+    if (n_items == 0) return false;  // (no read holds an edge: the general path knows what to publish)
+  }
+  uint32_t *buf_a = c->ws("items_a", n_items * 12 + 64).as<uint32_t>();
+  uint32_t *buf_b = c->ws("items_b", n_items * 12 + 64).as<uint32_t>();
   c->pre_hist_sig = passes_signature(plan.passes);
   c->pre_hist_buf = buf_a;
   c->pre_hist_n = n_items;
@@ -4396,14 +4565,20 @@ bool count_stream_groups(mhx_ctx *c, uint32_t k, uint32_t m, uint32_t *first_0_o
   const uint32_t pos_bits = s1_pos_bits(c);
   const uint64_t pos_stride = (s.n_bases >> pos_bits) ? 1ull << pos_bits : 0ull;
   const CountGenT g{s.words.as<uint32_t>(), s.fixed_len, per, (int)k, c->pos_base, pos_bits, (uint32_t)(kSortThreads * 8) / per, (uint32_t)(kSortThreads * 8) % per};
-  c->gen_first_pass = [g](const OnesweepLaunch &l) {
+  const CountGenVarT gv{s.words.as<uint32_t>(), s.start.as<uint64_t>(), s.n_seqs, per, (int)k, c->pos_base, pos_bits, (uint32_t)(kSortThreads * 8) / per,
+                        (uint32_t)(kSortThreads * 8) % per};
+  c->gen_first_pass = [g, gv, var](const OnesweepLaunch &l) {
     if (!(l.unit_runs && l.wi == 0)) throw Error("count: the generating pass needs the unit-wide pass on a first-word digit");
-    hipLaunchKernelGGL((k_radix_onesweep_u<3, 8, 3, CountGenT, 1, 0>), dim3(l.grid), dim3(kSortThreads), 0, l.stream, g, l.out, l.n, l.ds, l.nbits, l.bin_start,
-                       l.status, l.ticket, l.err, l.tag, l.xcd_units);
+    if (var)
+      hipLaunchKernelGGL((k_radix_onesweep_u<3, 8, 3, CountGenVarT, 1, 0>), dim3(l.grid), dim3(kSortThreads), 0, l.stream, gv, l.out, l.n, l.ds, l.nbits,
+                         l.bin_start, l.status, l.ticket, l.err, l.tag, l.xcd_units);
+    else
+      hipLaunchKernelGGL((k_radix_onesweep_u<3, 8, 3, CountGenT, 1, 0>), dim3(l.grid), dim3(kSortThreads), 0, l.stream, g, l.out, l.n, l.ds, l.nbits, l.bin_start,
+                         l.status, l.ticket, l.err, l.tag, l.xcd_units);
   };
   c->gen_buf = buf_a;
   c->gen_n = n_items;
-  c->gen_slots = n_items;
+  c->gen_slots = n_slots;
   uint32_t *sorted = radix_sort(c, buf_a, buf_b, n_items, 3, KWv, plan.passes);
   c->pre_hist_buf = nullptr;
   uint32_t *spare = sorted == buf_a ? buf_b : buf_a;

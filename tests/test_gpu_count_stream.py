@@ -58,3 +58,20 @@ def test_count_on_the_bucket_streaming(engine, kind, k, m, opts):
 def test_shapes_the_stream_form_does_not_take(engine, k, m):
     reads = fixed_library("pe100", seed=3)
     check_count(engine, ob.Package(reads, reverse=True), k, m, {}, False)
+
+
+@pytest.mark.parametrize("opts", [dict(), dict(s1_var_fast=0), dict(s1_stream_fill=40), dict(s1_pos_bits=12)], ids=lambda o: ",".join("%s=%d" % kv for kv in o.items()) or "default")
+@pytest.mark.parametrize("kind,k,m", [("trim", 21, 2), ("few", 21, 2), ("edge", 21, 2), ("trim", 17, 1), ("few", 22, 2), ("lowcomplex", 21, 2), ("var", 21, 2)])
+def test_count_of_reads_of_several_lengths(engine, kind, k, m, opts):
+    """CountGenVarT: item slots padded to the longest read's — libraries with every read trimmed, with 2 % trimmed, with reads of
+    length 0, 1, k - 1, k, k + 1 and an empty first read, and the low-complexity / random-length libraries of the other count tests"""
+    from test_gpu_count import make_reads
+    from test_gpu_round5_knobs import var_library
+    reads = make_reads(kind, 11) if kind in ("lowcomplex", "var") else var_library(kind, seed=k + m)
+    pkg = ob.Package(reads, reverse=True)
+    engine.set_option("s1_var_min_fill", 10)
+    try:
+        check_count(engine, pkg, k, m, opts, expect_stream=opts.get("s1_var_fast", 1) == 1)
+    finally:
+        engine.set_option("s1_var_min_fill", 50)
+        engine.set_option("s1_var_fast", 1)
