@@ -403,6 +403,8 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (libmhx has no CPU fallback)")
+    if world > torch.cuda.device_count():
+        raise SystemExit("--gpus %d: this node shows %d GPUs (one rank per GPU: RCCL refuses two ranks on one device)" % (world, torch.cuda.device_count()))
     n_reads = int(args.reads) // 16 * 16
     # The reference's CPU path on the WHOLE workload of this run (8 of this host's cores, ~95 s at 10 M reads) runs at the very
     # END, alone: started beside the read synthesis, the CLI runs and the GPU driver threads (round 4) it was timed under

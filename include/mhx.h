@@ -98,6 +98,25 @@ int mhx_set_option(mhx_ctx *, const char *name, long long value);
  * (Round 4: s1_stream_prefetch / s1_stream_next_bucket / s1_stream_used_list / s1_stream_read_first / s1_stream_unroll are gone:
  *  the bucket streaming always has its next trip's loads in flight, fetches the next bucket's bounds during the current bucket and
  *  walks its table once; setting them changes nothing.)
+ * Round 5:
+ *   s1_gen_roll (1)        0: the blocked generating pass forms every item's window and reverse complement anew (S1GenBlockedT) instead
+ *                          of one 64-bit window + one reverse complement per run of a thread's eight items (S1GenRollT; k <= 23)
+ *   s1_digit_hist_roll (1) the same for the digit-histogram pre-pass and the lv1 histogram taken from the packed reads
+ *   s1_var_fast (1)        0: a library whose reads are not of one length never takes the generating pass (S1GenVarT / CountGenVarT:
+ *                          item slots padded to the longest read's, unfilled slots declined); s1_var_min_fill (50): per cent of the
+ *                          slots that have to be real records for that form to be taken
+ *   s1_giant (1)           0: a bucket of the bucket streaming is always streamed by one workgroup alone; 1: buckets of at least
+ *                          s1_giant_min (262144) records are cut into slices, reduced by many workgroups and finished from their
+ *                          partial entries (S1Giant, s1.hip) — low-complexity reads
+ *   count_stream (1)       0: `count` always extracts 16-byte items and reduces with the tile kernel (k_count_seg); 1: fixed- or
+ *                          variable-length reads on one GPU, k <= 22, min count <= 2 take 12-byte records made by the first sort
+ *                          pass and the bucket streaming (k_s1_stream<COUNT>)
+ *   sdbg_fast (1)          0: the SdBG records of 8-byte items come from the generic tile kernel (k_tile_groups<SdbgOp>); 1: every run
+ *                          head on its own (k_sdbg_fast); sdbg_fast_keep (1): the counting launch keeps its findings (4 bytes per item,
+ *                          up to sdbg_fast_keep_max_mb = 4096 MB) for the emitting launch; sdbg_fast_halo (128), sdbg_fast_tile (2048):
+ *                          records staged either side of a tile / per tile (tests, tuning)
+ *   edges_reserve_permille (1000)  room behind the edges mhx_load_edges uploads, for mercy edges (the CLI: 1250, or what
+ *                          MEGAHIT_NUM_MERCY_FACTOR says: seq_to_sdbg.cpp:370-378)
  * (mhx_tuning.conf of this tree: s1_gen_blocked = 1.) */
 long long mhx_get_option(mhx_ctx *, const char *name, long long dflt);
 /* What the last stage 1 of this handle ran as: "stream p16 sub0 2 passes (20345 records per lv1 bucket)" / "seg p24 3 passes" /
