@@ -102,6 +102,11 @@ def check_sdbg(outs, want):
     (2, 21, 2, 0, {"s1_pos_bits": 12}),                      # position tags in every record
     (3, 21, 2, STAGE_S1, {"dist_max_items": 40000, "s1_filter_in_gen": 0}),  # bucket-range passes with extraction batches + split
     (3, 21, 2, STAGE_S1, {"dist_max_items": 40000, "s1_stream_bits": 18, "s1_stream_fill": 3}),  # ... and everything at once
+    # round 5: giant buckets on several ranks — a bucket's records arrive as one sub-range per sender, the slices are cut per sender
+    (2, 21, 2, 0, {"s1_giant_min": 64}),
+    (3, 21, 2, STAGE_S1, {"s1_giant_min": 100, "s1_pos_bits": 12}),
+    (3, 21, 2, 0, {"s1_giant_min": 64, "s1_stream_fill": 40}),
+    (2, 21, 2, STAGE_S1, {"s1_giant_min": 64, "dist_max_items": 40000}),
 ])
 def test_read2sdbg_ranks_as_threads(world, k, m, balance, opts):
     def body(r, e, cm):
