@@ -112,7 +112,8 @@ int mhx_set_option(mhx_ctx *, const char *name, long long value);
  *                          variable-length reads on one GPU, k <= 22, min count <= 2 take 12-byte records made by the first sort
  *                          pass and the bucket streaming (k_s1_stream<COUNT>)
  *   sdbg_fast (1)          0: the SdBG records of 8-byte items come from the generic tile kernel (k_tile_groups<SdbgOp>); 1: every run
- *                          head on its own (k_sdbg_fast); sdbg_fast_keep (1): the counting launch keeps its findings (4 bytes per item,
+ *                          head on its own (k_sdbg_fast) for aggregated and seq2sdbg items (short runs), the tile kernel for items per
+ *                          occurrence (runs as long as the coverage); 2: the run-head form for every 8-byte item; sdbg_fast_keep (1): the counting launch keeps its findings (4 bytes per item,
  *                          up to sdbg_fast_keep_max_mb = 4096 MB) for the emitting launch; sdbg_fast_halo (128), sdbg_fast_tile (2048):
  *                          records staged either side of a tile / per tile (tests, tuning)
  *   edges_reserve_permille (1000)  room behind the edges mhx_load_edges uploads, for mercy edges (the CLI: 1250, or what

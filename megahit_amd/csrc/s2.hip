@@ -1014,7 +1014,12 @@ static void emit_sdbg_impl(mhx_ctx *c, const uint32_t *sorted, uint64_t n_items,
   SdbgOp<S> op{P, nullptr, w_count, bstart};
   const double bytes = (double)n_items * S * 4;
   if constexpr (S == 2) {
-    if (c->opt("sdbg_fast", 1) != 0 && P.kw >= 1 && P.kw <= 2 && P.aw <= 1) {  // 8-byte records: k_sdbg_fast (every run head on its own)
+    // 8-byte records: k_sdbg_fast (every run head on its own) where runs are short — the aggregated items of stage 1 and the items of
+    // seq2sdbg, one record per distinct (k+1)-mer and strand.  Items per OCCURRENCE (min count 1, k > 22: a run = the occurrences of
+    // one edge, ~coverage records) keep the tile kernel, whose work per record does not grow with the run: measured on the configs[4]
+    // shard (10 G items, runs of ~15) 79 + 126 ms against 408 + 416 ms for the run-head form.  sdbg_fast = 2 forces it (tests).
+    const long long fast_opt = c->opt("sdbg_fast", 1);
+    if ((fast_opt == 2 || (fast_opt == 1 && P.is_seq != 0)) && P.kw >= 1 && P.kw <= 2 && P.aw <= 1) {
       SdbgFastP F;
       F.gmask = kmer_bits >= 64 ? ~0ull : (kmer_bits ? ~0ull << (64 - kmer_bits) : 0ull);
       F.bsh = P.bshift + (P.kw - 1 == 0 ? 32 : 0);

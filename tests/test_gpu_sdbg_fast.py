@@ -64,6 +64,8 @@ def test_per_occurrence_items(engine, kind, k, m, opts):
         solid = ob.s1(pkg, k, m)["is_solid"]
         engine.read2sdbg_s1(k, m)
         engine.set_is_solid(solid)
+    opts = dict(opts)
+    opts.setdefault("sdbg_fast", 2)  # (items per occurrence take the tile kernel by default: 2 = the run-head form anyway)
     r = with_options(engine, opts, lambda: engine.read2sdbg_s2(k, m))
     check_sdbg(engine, r, ob.s2(pkg, k, m, solid), per_occurrence=True)
 
@@ -96,6 +98,8 @@ def test_runs_beyond_tile_and_cap(engine, opts):
     r = with_options(engine, opts, lambda: engine.read2sdbg_s2(k, m))
     check_sdbg(engine, r, want)
     assert int(want["bucket_large"].sum()) > 0
-    # the same reads per occurrence (m = 1: every occurrence an item — runs of 10^5 records)
+    # the same reads per occurrence (m = 1: every occurrence an item — runs of 10^5 records; the run-head form forced)
+    opts = dict(opts)
+    opts.setdefault("sdbg_fast", 2)
     r = with_options(engine, opts, lambda: engine.read2sdbg_s2(k, 1))
     check_sdbg(engine, r, ob.s2(pkg, k, 1, None), per_occurrence=True)
