@@ -63,3 +63,21 @@ def test_committed_bench_line_has_the_contract_fields():
     if d["roofline"]["traffic"] is not None:
         assert d["roofline"]["traffic"] in [v["hbm_bytes"] for v in pmc["kernels"].values()]
         assert d.get("build_id") in (None, pmc["build_id"])
+
+
+def test_bench_with_several_gpus_launches_its_own_ranks():
+    """`python bench.py --gpus N` the way `--gpus 1` is called, without a launcher (no WORLD_SIZE): the script becomes the launcher —
+    torch.distributed.run, one rank per GPU, rendezvous on 127.0.0.1 — instead of exiting with "launch with torch.distributed.run"
+    (VERDICT r4 weak #8).  No GPU here: every one of the N ranks gets as far as the check for one."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], cwd="/tmp", env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=240)
+    import torch
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        assert p.returncode == 0 and p.stdout.strip().startswith("{")
+        return
+    assert p.returncode != 0
+    assert "launch with torch.distributed.run" not in p.stderr
+    started = p.stderr.count("bench.py needs a GPU") + p.stderr.count("this node shows")
+    assert started == 2, p.stderr[-1500:]
