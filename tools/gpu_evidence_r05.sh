@@ -31,6 +31,7 @@ timeout 400 python tools/ab_options.py "s1_gen_roll=0 s1_digit_hist_roll=0 sdbg_
   "s1_gen_roll=1 s1_digit_hist_roll=1 sdbg_fast=0 s1_giant=0" "s1_gen_roll=1 s1_digit_hist_roll=1 sdbg_fast=1 sdbg_fast_keep=0 s1_giant=0" \
   "s1_gen_roll=1 s1_digit_hist_roll=1 sdbg_fast=1 sdbg_fast_keep=1 s1_giant=0" "s1_gen_roll=1 s1_digit_hist_roll=1 sdbg_fast=1 sdbg_fast_keep=1 s1_giant=1" \
   --rounds 2 > $O/${TAG}_ab_round5_knobs.jsonl 2> $O/${TAG}_ab_round5_knobs.err; echo "ab rc=$?"
+timeout 300 python tools/ab_options.py "s1_marks_list=0" "s1_marks_list=1" --rounds 2 > $O/${TAG}_ab_marks_list.jsonl 2> $O/${TAG}_ab_marks_list.err; echo "ab marks rc=$?"
 timeout 300 python tools/ab_options.py "count_stream=0" "count_stream=1" --engine count --rounds 2 > $O/${TAG}_ab_count_stream.jsonl 2> $O/${TAG}_ab_count_stream.err; echo "ab count rc=$?"
 timeout 300 python tools/mercy_prof.py 10e6 > $O/${TAG}_mercy_stage1.json 2> $O/${TAG}_mercy_stage1.err
 timeout 300 python tools/buildlib_bench.py > $O/${TAG}_buildlib.json 2> $O/${TAG}_buildlib.err
