@@ -110,3 +110,38 @@ def test_reads_of_several_lengths_on_the_generating_pass(engine, kind, k, m, var
         engine.set_option("s1_gen_blocked", engine_default(engine, "s1_gen_blocked"))
         engine.set_option("s1_var_fast", 1)
         engine.set_option("s1_var_min_fill", 50)
+
+
+@pytest.mark.parametrize("in_gen", [1, 0])
+@pytest.mark.parametrize("kind,k,m,opts", [("trim", 21, 2, {}), ("few", 21, 2, dict(s1_stream_bits=19)), ("edge", 21, 2, dict(s1_var_min_fill=10)),
+                                           ("trim", 17, 2, dict(s1_pos_bits=12))])
+def test_bucket_filter_on_reads_of_several_lengths(engine, kind, k, m, in_gen, opts):
+    """stage 1 in bucket-range passes (what mhx_core's memory plan does) on a library whose reads are not of one length: with
+    s1_filter_in_gen the generating pass of each range makes only the records of the kept buckets AND declines the slots a read does
+    not fill (S1GenVarT<true>), the lv1 histogram comes from the packed reads (k_s1_bucket_hist_var); without it extraction batches"""
+    from megahit_amd import passes
+    from test_gpu_passes import _check_sdbg
+    reads = var_library(kind, seed=k + m)
+    pkg = ob.Package(reads, reverse=True)
+    load(engine, pkg)
+    w1 = ob.s1(pkg, k, m, tie_stable=True)
+    want = ob.s2(pkg, k, m, w1["is_solid"])
+    try:
+        engine.set_option("s1_gen_blocked", 1)
+        engine.set_option("s1_filter_in_gen", in_gen)
+        for n, v in opts.items():
+            engine.set_option(n, v)
+        s1, got = passes.read2sdbg_in_passes(engine, k, m, max_items_s1=-3, max_items_s2=-4, need_mercy=0, batch_bytes=8 << 20)
+    finally:
+        from test_gpu_round3_knobs import engine_default
+        engine.set_option("s1_gen_blocked", engine_default(engine, "s1_gen_blocked"))
+        engine.set_option("s1_filter_in_gen", 1)
+        for n, v in dict(s1_stream_bits=0, s1_var_min_fill=50, s1_pos_bits=0).items():
+            engine.set_option(n, v)
+    assert s1["n_passes"] >= 3
+    assert s1["n_items"] == w1["n_items"]
+    assert np.array_equal(engine.fetch(lib.BUF_MUL_HIST, np.int64), w1["hist"])
+    bits = engine.fetch(lib.BUF_IS_SOLID, np.uint64)
+    assert np.array_equal(bits, w1["is_solid"][: bits.size])
+    got["n_passes"] = max(got["n_passes"], 3)
+    _check_sdbg(got, want)
