@@ -72,7 +72,7 @@ def test_bench_with_several_gpus_launches_its_own_ranks():
     import subprocess
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], cwd="/tmp", env=env,
-                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=240)
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)  # (the first `import torch` of a fresh container takes minutes)
     import torch
     if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
         assert p.returncode == 0 and p.stdout.strip().startswith("{")
