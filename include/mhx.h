@@ -165,7 +165,10 @@ enum mhx_buffer {
   MHX_BUF_BUCKET_OFFSET = 9,/* uint64[65536] starting byte of each bucket in MHX_BUF_SDBG_BYTES */
   MHX_BUF_BUCKET_TIPS = 10, /* uint64[65536] */
   MHX_BUF_BUCKET_LARGE = 11,/* uint64[65536] */
-  MHX_BUF_SORTED_ITEMS = 12,/* uint32[n_items][item_words]: the sorted lv2 items of the last engine (tests) */
+  MHX_BUF_SORTED_ITEMS = 12,/* uint32[n_items][item_words]: the lv2 items of the last engine as its sort left them (tests): a view into the
+                              sort workspace, overwritten by the next engine call.  Fully sorted on the tile paths; on the bucket-streaming
+                              plans (stage 1 without mercy, `count` at k <= 22: mhx_count_result.item_words == 3) 12-byte records ordered
+                              only by the plan's key prefix */
   MHX_BUF_W_COUNT = 13,     /* uint64[9] + ones_in_last: uint64[10] (sdbg_meta.h:41-48) */
   /* device-resident SdBG hand-over, filled by mhx_sdbg_build_index (below); layouts = the reference's in-memory ones */
   MHX_BUF_SDBG_W = 20,          /* uint64[ceil(n/16)]: 4 bits per item, item i at bits 4*(i%16) (sdbg_raw_content.h:22) */
