@@ -400,6 +400,8 @@ void mhx_comm_destroy(mhx_comm *);
 int mhx_comm_rank(const mhx_comm *);
 int mhx_comm_size(const mhx_comm *);
 int mhx_comm_barrier(mhx_comm *);
+/* payload bytes this rank has handed to OTHER ranks through the item / record exchanges since the last reset (what crosses xGMI) */
+uint64_t mhx_comm_bytes_sent(mhx_comm *, int reset);
 int mhx_comm_all_reduce_u64(mhx_comm *, uint64_t *values, uint64_t n, int is_max /* else sum */);
 /* agree on the bucket partition (balance_stage = 0: equal ranges; else an enum mhx_stage whose all-reduced lv1 bucket
  * histogram balances the ranges) and on the global read layout (rank r's bases at r * stride); sets dist_sparse_marks */

@@ -1043,6 +1043,22 @@ uint64_t mhx_stage_pass_bytes(mhx_ctx *c, int stage, uint32_t k, uint32_t min_co
       if (gen) return n_items * 24 + n_items / 2 + (c->seqs.n_bases + 4 * c->seqs.n_seqs) / 3;
       return n_items * (3 * (uint64_t)mhx::s1_stride(k, mhx::s1_compact(c, k, 0)) * 4 + 1);
     }
+    if (stage == MHX_STAGE_COUNT && c->seqs.n_seqs) {
+      struct Restore {
+        mhx_ctx *c;
+        bool on;
+        uint64_t exp;
+        ~Restore() {
+          c->filter_on = on;
+          c->filter_expected = exp;
+        }
+      } restore{c, c->filter_on, c->filter_expected};
+      c->filter_on = true;
+      c->filter_expected = n_items;
+      // count on the stage-1 design: two 12-byte record buffers (the solid edges and the events live in the spare one)
+      if (mhx::count_stream_applies(c, k, min_count) && (2 * (k + 1) + 16 + 31) / 32 == 2)
+        return n_items * 24 + n_items / 2 + c->seqs.n_bases / 3;
+    }
     uint64_t ib = 16;
     if (stage == MHX_STAGE_S1_MERCY) ib = (uint64_t)mhx::s1_stride(k, false) * 4;
     else if (stage == MHX_STAGE_COUNT) ib = (uint64_t)mhx::count_stride(k) * 4;

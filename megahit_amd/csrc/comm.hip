@@ -143,6 +143,9 @@ struct mhx_comm {
   // stages that were found to need no bucket-range passes since the last mhx_dist_setup (key: stage, k, m): the check costs
   // an all-reduce and a hipMemGetInfo per call; every rank sees the same calls, so the caches agree
   std::vector<uint64_t> one_pass_ok;
+  // payload bytes this rank handed to OTHER ranks in all_to_all_v since the last reset (mhx_comm_bytes_sent: the tests bound the
+  // bytes per foreign record with it, the bench prints it per step)
+  uint64_t bytes_sent = 0;
 
   // ---- collectives on small host vectors ----
   void all_reduce(std::vector<uint64_t> &v, bool is_max) {
@@ -211,6 +214,8 @@ struct mhx_comm {
     }
     const char *s = static_cast<const char *>(d_send);
     char *r = static_cast<char *>(d_recv);
+    for (int p = 0; p < n; ++p)
+      if (p != rank) bytes_sent += so[p + 1] - so[p];
     if (is_hosted && n > 1) {
       // own segment: a device copy; everything else through host memory and the caller's byte mover
       if (!skip_self && so[rank + 1] > so[rank])
@@ -370,6 +375,61 @@ static bool dist_s1_presorted(mhx_ctx *c, mhx_comm *cm, uint32_t k, uint32_t m, 
   src.spare = total <= it.n ? other : c->ws("s1_spare", total * 12 + 64).as<uint32_t>();
   s1_process(c, k, m, 0, nullptr, nullptr, total, r1, &src);
   c->last_s1_plan += " [pre-sorted exchange]";
+  return true;
+}
+
+// `count` the same way (round 6): every rank makes its 12-byte count records in the first pass of the single-GPU sort plan (CountGenT, also
+// under the bucket filter of a pass), orders them by the plan's prefix, sends each owner its contiguous slice, and the owner's bucket
+// streaming (k_s1_stream<COUNT>) reads a bucket as one sub-range per sender; the events that move first_0_out / last_0_in of reads held
+// by other ranks leave the kernel as a list and are routed like the tile path's (MHX_ROUTE_COUNT_EVENTS).  -> false: the ranks do not all
+// take this form (nothing exchanged), or an owner's streaming gave up (its state is as before the pass): the classic exchange runs.
+// Reference: KmerCounter over lv1 bucket ranges, kmer_counter.cpp:158-381 + base_engine.cpp:176-201.
+static bool dist_count_presorted(mhx_ctx *c, mhx_comm *cm, uint32_t k, uint32_t m, mhx_count_result *out) {
+  const int n = cm->n, rank = cm->rank;
+  std::vector<uint64_t> v{count_presort_applies(c, k, m) ? 0ull : 1ull};
+  cm->all_reduce(v, true);  // any rank that cannot vetoes
+  if (v[0]) return false;
+  hipStream_t st = c->stream;
+  uint64_t n_local = 0;
+  uint32_t *other = nullptr;
+  int pbits = 16;
+  uint32_t *sorted = count_presort(c, k, &n_local, &other, &pbits);
+  uint64_t *d_bounds = c->ws("dist_bounds", (MHX_NUM_BUCKETS + 2) * 8).as<uint64_t>();
+  std::vector<uint64_t> bounds(MHX_NUM_BUCKETS + 1, 0);
+  if (n_local) {
+    hipLaunchKernelGGL(k_bucket_bounds, dim3(MHX_NUM_BUCKETS / 256 + 1), dim3(256), 0, st, sorted, n_local, 3, d_bounds, 16);
+    MHX_HIP(hipMemcpyAsync(bounds.data(), d_bounds, (MHX_NUM_BUCKETS + 1) * 8, hipMemcpyDeviceToHost, st));
+    MHX_HIP(hipStreamSynchronize(st));
+  }
+  std::vector<uint64_t> counts(n), rc;
+  for (int p = 0; p < n; ++p) counts[p] = bounds[c->part_begin[p + 1]] - bounds[c->part_begin[p]];
+  cm->all_to_all_counts(counts, rc);
+  uint64_t n_recv = 0, total = 0;
+  for (int p = 0; p < n; ++p) {
+    if (p != rank) n_recv += rc[p];
+    total += rc[p];
+  }
+  uint32_t *recv = c->ws("items_recv", n_recv * 12 + 64).as<uint32_t>();
+  cm->all_to_all_v(sorted, counts, recv, rc, 12, true);
+  S1Sources src;
+  src.n = n;
+  src.pbits = pbits;
+  uint64_t at = 0;
+  for (int p = 0; p < n; ++p) {
+    if (p == rank) src.ptr.push_back(sorted + bounds[c->part_begin[rank]] * 3);
+    else {
+      src.ptr.push_back(recv + at * 3);
+      at += rc[p];
+    }
+    src.count.push_back(rc[p]);
+  }
+  // the edge regions: the local ping-pong buffer that does not hold the sorted records, if it is large enough
+  src.spare = total <= n_local ? other : c->ws("s1_spare", total * 12 + 64).as<uint32_t>();
+  mhx_count_result r{};
+  std::vector<uint64_t> fail{count_process_presorted(c, k, m, src, &r) == 0 ? 0ull : 1ull};
+  cm->all_reduce(fail, true);
+  if (fail[0]) return false;  // (every rank's first_0_out / last_0_in / histogram are as before this pass: count_run_stream restores them)
+  *out = r;
   return true;
 }
 
@@ -576,6 +636,12 @@ void mhx_comm_destroy(mhx_comm *cm) {
 int mhx_comm_rank(const mhx_comm *cm) { return cm ? cm->rank : -1; }
 int mhx_comm_size(const mhx_comm *cm) { return cm ? cm->n : -1; }
 int mhx_comm_barrier(mhx_comm *cm) { MHX_TRYC(cm->barrier()) }
+uint64_t mhx_comm_bytes_sent(mhx_comm *cm, int reset) {
+  if (!cm) return 0;
+  const uint64_t v = cm->bytes_sent;
+  if (reset) cm->bytes_sent = 0;
+  return v;
+}
 int mhx_comm_all_reduce_u64(mhx_comm *cm, uint64_t *values, uint64_t n, int is_max) {
   MHX_TRYC({
     std::vector<uint64_t> v(values, values + n);
@@ -724,11 +790,22 @@ int mhx_dist_count(mhx_ctx *c, mhx_comm *cm, uint32_t k, uint32_t min_count, mhx
     mhx_count_result r{};
     hipStream_t st = c->stream;
     uint64_t acc_edge_bytes = 0;
+    {  // the records per lv1 bucket of the whole job, agreed on by the ranks: every rank makes the same sort plan from it
+      const mhx::SeqSet &sq = c->seqs;
+      const uint64_t local = sq.fixed_len >= k + 1 ? sq.n_seqs * (uint64_t)(sq.fixed_len - k) : sq.n_bases;
+      std::vector<uint64_t> mx{local};
+      cm->all_reduce(mx, true);
+      c->s1_density = std::max(1.0, (double)mx[0] * (double)cm->n / (double)MHX_NUM_BUCKETS);
+    }
     for (int pass = 0; pass < dp.n; ++pass) {
       mhx::set_pass(c, dp, pass, true);
-      const uint64_t n = mhx::exchange_stage(c, cm, MHX_STAGE_COUNT, k, min_count);
       mhx_count_result rp{};
-      MHX_CK(mhx_dist_process_count(c, k, min_count, n, &rp));
+      if (!mhx::dist_count_presorted(c, cm, k, min_count, &rp)) {  // the classic exchange: 16-byte items, owner multisplit, tile path at the owner
+        c->gen_first_pass = nullptr;
+        c->pre_hist_buf = nullptr;
+        const uint64_t n = mhx::exchange_stage(c, cm, MHX_STAGE_COUNT, k, min_count);
+        MHX_CK(mhx_dist_process_count(c, k, min_count, n, &rp));
+      }
       mhx::route(c, cm, MHX_ROUTE_COUNT_EVENTS);
       if (dp.n > 1) {  // the solid edges and their per-bucket numbers of every pass, kept on the device (a bucket belongs to one pass)
         mhx::DevBuf &src = c->results[MHX_BUF_EDGES];
@@ -747,6 +824,7 @@ int mhx_dist_count(mhx_ctx *c, mhx_comm *cm, uint32_t k, uint32_t min_count, mhx
       r.words_per_edge = rp.words_per_edge;
     }
     mhx::clear_pass(c, dp);
+    c->s1_density = 0;
     if (dp.n > 1) {
       std::swap(c->results[MHX_BUF_EDGES].p, c->work["acc_edges"].p);
       std::swap(c->results[MHX_BUF_EDGES].cap, c->work["acc_edges"].cap);

@@ -939,14 +939,16 @@ void count_apply_events(mhx_ctx *c, const unsigned long long *ev, uint64_t n) {
 // bucket with the has_in / has_out evidence in the table, first_0_out / last_0_in from a second look at the few buckets that
 // hold a solid key without an in- or out-edge).  -> false: that form gave up; nothing is published, the caller runs the
 // extraction + tile path.  Reference: KmerCounter::Lv2ExtractSubString + Lv2Postprocess (kmer_counter.cpp:208-381).
-static bool count_run_stream(mhx_ctx *c, uint32_t k, uint32_t m, mhx_count_result *out) {
+static bool count_run_stream(mhx_ctx *c, uint32_t k, uint32_t m, mhx_count_result *out, const S1Sources *pre = nullptr) {
   SeqSet &s = c->seqs;
   hipStream_t st = c->stream;
   const uint64_t ns = s.n_seqs;
   const int wpe = (int)div_ceil((k + 1) * 2 + 16, 32);
   const int key_bits = (int)(k + 1) * 2;
-  c->count_acc_k = k;
-  c->count_acc_m = m;
+  // accumulate (bucket-range passes after the first): first_0_out, the raw last_0_in (+1) values and the histogram of the earlier
+  // passes are kept (count_process does the same on the tile path: the two may take turns pass by pass)
+  const bool acc = c->accumulate && c->results.count(MHX_BUF_FIRST_0_OUT) && c->results[MHX_BUF_FIRST_0_OUT].used == ns * 4 &&
+                   c->work.count("last_p1") && c->results.count(MHX_BUF_MUL_HIST) && c->count_acc_k == k && c->count_acc_m == m;
   uint32_t *first = c->result(MHX_BUF_FIRST_0_OUT, (ns ? ns : 1) * 4).as<uint32_t>();
   uint32_t *last_out = c->result(MHX_BUF_LAST_0_IN, (ns ? ns : 1) * 4).as<uint32_t>();
   uint32_t *last = c->ws("last_p1", (ns ? ns : 1) * 4).as<uint32_t>();
@@ -954,12 +956,30 @@ static bool count_run_stream(mhx_ctx *c, uint32_t k, uint32_t m, mhx_count_resul
   c->results[MHX_BUF_LAST_0_IN].used = ns * 4;
   unsigned long long *hist = c->result(MHX_BUF_MUL_HIST, (MHX_MAX_MUL + 1) * 8).as<unsigned long long>();
   unsigned long long *bcount = c->result(MHX_BUF_BUCKET_COUNT, MHX_NUM_BUCKETS * 8).as<unsigned long long>();
-  MHX_HIP(hipMemsetAsync(first, 0xFF, (ns ? ns : 1) * 4, st));
-  MHX_HIP(hipMemsetAsync(last, 0x00, (ns ? ns : 1) * 4, st));
-  MHX_HIP(hipMemsetAsync(hist, 0, (MHX_MAX_MUL + 1) * 8, st));
+  if (!acc) {
+    MHX_HIP(hipMemsetAsync(first, 0xFF, (ns ? ns : 1) * 4, st));
+    MHX_HIP(hipMemsetAsync(last, 0x00, (ns ? ns : 1) * 4, st));
+    MHX_HIP(hipMemsetAsync(hist, 0, (MHX_MAX_MUL + 1) * 8, st));
+  }
   MHX_HIP(hipMemsetAsync(bcount, 0, MHX_NUM_BUCKETS * 8, st));
+  // state as it is now: should the streaming form give up half-way (an edge region too small), the tile path redoes this pass on top
+  // of the earlier passes' results, not on top of what the finished buckets of this attempt left (atomics cannot be taken back)
+  uint32_t *sv_first = c->ws("cs_save_first", (ns ? ns : 1) * 4).as<uint32_t>(), *sv_last = c->ws("cs_save_last", (ns ? ns : 1) * 4).as<uint32_t>();
+  unsigned long long *sv_hist = c->ws("cs_save_hist", (MHX_MAX_MUL + 1) * 8).as<unsigned long long>();
+  if (acc) {
+    MHX_HIP(hipMemcpyAsync(sv_first, first, (ns ? ns : 1) * 4, hipMemcpyDeviceToDevice, st));
+    MHX_HIP(hipMemcpyAsync(sv_last, last, (ns ? ns : 1) * 4, hipMemcpyDeviceToDevice, st));
+    MHX_HIP(hipMemcpyAsync(sv_hist, hist, (MHX_MAX_MUL + 1) * 8, hipMemcpyDeviceToDevice, st));
+  }
   CountStreamOut o;
-  if (!count_stream_groups(c, k, m, first, last, hist, &o)) return false;
+  if (!count_stream_groups(c, k, m, first, last, hist, &o, pre)) {
+    if (acc) {
+      MHX_HIP(hipMemcpyAsync(first, sv_first, (ns ? ns : 1) * 4, hipMemcpyDeviceToDevice, st));
+      MHX_HIP(hipMemcpyAsync(last, sv_last, (ns ? ns : 1) * 4, hipMemcpyDeviceToDevice, st));
+      MHX_HIP(hipMemcpyAsync(hist, sv_hist, (MHX_MAX_MUL + 1) * 8, hipMemcpyDeviceToDevice, st));
+    }
+    return false;
+  }
   std::vector<uint32_t> h_counts(o.grid);
   MHX_HIP(hipMemcpyAsync(h_counts.data(), o.counts, (size_t)o.grid * 4, hipMemcpyDeviceToHost, st));
   MHX_HIP(hipStreamSynchronize(st));
@@ -980,14 +1000,21 @@ static bool count_run_stream(mhx_ctx *c, uint32_t k, uint32_t m, mhx_count_resul
                hipLaunchKernelGGL(k_edge_buckets, dim3((unsigned)div_ceil(n_edges, 256)), dim3(256), 0, st, edges, n_edges, bcount));
     MHX_HIP(hipGetLastError());
   }
-  if (ns)
+  if (pre) {  // several GPUs: the events -> sorted by position in ws("route_records"); first / last are finished by mhx_dist_apply_routed
+    int hi_bit = 2;
+    while (hi_bit < 64 && ((c->global_bases << 1) >> hi_bit)) ++hi_bit;
+    stash_route_records(c, o.events, o.n_events, hi_bit);
+  } else if (ns) {
     MHX_LAUNCH(c, "fix_last", (double)ns * 8, hipLaunchKernelGGL(k_fix_last, dim3((unsigned)div_ceil(ns, 256)), dim3(256), 0, st, last, last_out, ns));
+  }
   mhx::DevBuf &si = c->results[MHX_BUF_SORTED_ITEMS];
   si.release();
   c->sorted_item_words = 3;
   si.p = o.sorted;
   si.cap = 0;  // cap 0 = not owned
-  si.used = o.n_items * 12;
+  si.used = o.sorted ? o.n_items * 12 : 0;  // (pre-sorted sources stay where they are)
+  c->count_acc_k = k;
+  c->count_acc_m = m;
   c->last_s1_plan = "count: " + o.plan;
   MHX_HIP(hipStreamSynchronize(st));
   if (out) {
@@ -998,6 +1025,17 @@ static bool count_run_stream(mhx_ctx *c, uint32_t k, uint32_t m, mhx_count_resul
     out->item_words = 3;
   }
   return true;
+}
+
+// several GPUs: the records this rank owns, pre-sorted by the plan's prefix in one array per sending rank (comm.hip).  -> 0, or -1 when
+// the streaming form gave up (an output region too small): nothing published, the caller gathers the records for the tile path
+int count_process_presorted(mhx_ctx *c, uint32_t k, uint32_t m, const S1Sources &src, mhx_count_result *out) {
+  if (!c->global_bases) throw Error("count_process_presorted: call mhx_set_global_layout first");
+  if (count_run_stream(c, k, m, out, &src)) {
+    c->last_s1_plan += " [pre-sorted exchange]";
+    return 0;
+  }
+  return -1;
 }
 
 int run_count(mhx_ctx *c, uint32_t k, uint32_t m, mhx_count_result *out) {

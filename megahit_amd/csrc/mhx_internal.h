@@ -273,9 +273,16 @@ struct CountStreamOut {
   uint32_t *sorted;   // the records, ordered by the plan's prefix
   uint64_t n_items, n_distinct;
   std::string plan;
+  unsigned long long *events;  // several GPUs: position << 1 | kind, for the ranks that hold the reads (count.hip k_apply_count_events)
+  uint64_t n_events;
 };
 bool count_stream_applies(const mhx_ctx *c, uint32_t k, uint32_t m);
-bool count_stream_groups(mhx_ctx *c, uint32_t k, uint32_t m, uint32_t *first_0_out, uint32_t *last_0_in_p1, unsigned long long *hist, CountStreamOut *o);
+bool count_presort_applies(const mhx_ctx *c, uint32_t k, uint32_t m);
+uint32_t *count_presort(mhx_ctx *c, uint32_t k, uint64_t *n_items, uint32_t **other, int *pbits);
+int count_process_presorted(mhx_ctx *c, uint32_t k, uint32_t m, const S1Sources &src, mhx_count_result *out);  // count.hip; -1: gave up
+bool count_bucket_histogram_fast(mhx_ctx *c, uint32_t k, unsigned long long *hist);  // s1_front.hip
+bool count_stream_groups(mhx_ctx *c, uint32_t k, uint32_t m, uint32_t *first_0_out, uint32_t *last_0_in_p1, unsigned long long *hist, CountStreamOut *o,
+                         const S1Sources *pre = nullptr);
 int run_s1(mhx_ctx *c, uint32_t k, uint32_t m, int want_mercy, mhx_s1_result *out);
 int run_s1_mercy(mhx_ctx *c, uint32_t k, uint64_t *num_mercy);
 int run_s2(mhx_ctx *c, uint32_t k, uint32_t m, mhx_sdbg_result *out);

@@ -115,7 +115,8 @@ void bucket_histogram(mhx_ctx *c, int stage, uint32_t k, uint32_t m, uint64_t *h
   unsigned long long *hist = c->ws("bucket_hist", MHX_NUM_BUCKETS * 8).as<unsigned long long>();
   MHX_HIP(hipMemsetAsync(hist, 0, MHX_NUM_BUCKETS * 8, st));
   // (stage 1 without mercy on reads of one length: straight from the packed reads, s1.hip)
-  const bool fast = stage == MHX_STAGE_S1 && s1_bucket_histogram_fast(c, k, hist);
+  // (count on the stage-1 design, round 6: likewise — otherwise one global atomic per extracted item)
+  const bool fast = (stage == MHX_STAGE_S1 && s1_bucket_histogram_fast(c, k, hist)) || (stage == MHX_STAGE_COUNT && count_bucket_histogram_fast(c, k, hist));
   if (!fast) for_each_batch(c, stage, k, m, [&](const StageItems &b) {
     if (b.n)
       hipLaunchKernelGGL(k_bucket_hist, dim3((unsigned)std::min<uint64_t>(div_ceil(b.n, 256), 8192)), dim3(256), 0, st,

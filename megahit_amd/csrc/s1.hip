@@ -902,24 +902,25 @@ void s1_apply_marks(mhx_ctx *c, const unsigned long long *recv, uint64_t n) {
   c->global_marks_inverted = false;
 }
 
-// ---- `count` on the bucket streaming (k_s1_stream<COUNT>): fixed-length reads on one GPU, k <= 22, min count <= 2 ----
-bool count_stream_applies(const mhx_ctx *c, uint32_t k, uint32_t m) {
+// ---- `count` on the bucket streaming (k_s1_stream<COUNT>): k <= 22, min count <= 2; one GPU (also pass by pass under the bucket filter
+// of a memory plan) or, on several GPUs, at the bucket owners behind the pre-sorted exchange (comm.hip dist_count_presorted) ----
+static uint64_t count_plan_items(const mhx_ctx *c, uint32_t k) {  // the item count the plan is made for (var: an estimate)
   const SeqSet &s = c->seqs;
-  if (!c->opt("count_stream", 1) || c->global_bases || c->filter_on || c->accumulate || c->n_parts > 1) return false;
+  return s.fixed_len ? s.n_seqs * (uint64_t)(s.fixed_len - k) : s.n_bases - s.n_seqs * (uint64_t)k;
+}
+// what both forms need: the shape the generators serve, the plan's digits in the first key word, a 32-bit table key
+static bool count_stream_shape(const mhx_ctx *c, uint32_t k, uint32_t m, S1Plan *plan_out) {
+  const SeqSet &s = c->seqs;
+  if (!c->opt("count_stream", 1)) return false;
+  if (c->filter_on && !c->opt("s1_filter_in_gen", 1)) return false;
   // (a caller that asks for a particular form of the tile path gets the tile path)
   if (!c->opt("count_seg", 1) || c->opt("count_seg_bits", 0) || !c->opt("count_extract_fixed", 1)) return false;
   if (!s.n_seqs || k < 9 || (int)k > kCountStreamMaxK || m < 1 || m > 2) return false;
-  const bool var = s.fixed_len == 0;  // reads of several lengths: item slots padded to the longest read's (CountGenVarT)
-  if (var) {
-    if (!c->opt("s1_var_fast", 1) || s.max_len < k + 1 || s.max_len - k < 8 || s.n_bases <= s.n_seqs * (uint64_t)k) return false;
-    if ((double)s.n_bases * 100.0 < (double)c->opt("s1_var_min_fill", 50) * (double)s.n_seqs * s.max_len) return false;
-  } else if (s.fixed_len < k + 1 || s.fixed_len - k < 8) {
-    return false;
-  }
+  if (!count_shape_is_fast(c, k)) return false;  // (reads of several lengths: item slots padded to the longest read's, CountGenVarT)
   if (!c->opt("s1_fused_first_pass", 1) || !c->opt("sort_unit_runs", 1) || !c->opt("s1_gen_any_order", 1)) return false;
-  const uint64_t n_items = var ? s.n_bases - s.n_seqs * (uint64_t)k : s.n_seqs * (uint64_t)(s.fixed_len - k);  // (var: the estimate the plan is made for)
-  const uint64_t n_bits = s.n_bases;
+  const uint64_t n_bits = c->global_bases ? c->global_bases : s.n_bases;
   if ((n_bits >> s1_pos_bits(c)) >= 256) return false;  // (positions beyond the tags)
+  const uint64_t n_items = count_plan_items(c, k);
   const S1Plan plan = s1_plan(c, k, n_items, true, 0);
   if (!plan.stream || plan.passes.empty() || (int)plan.passes.size() > kFastPasses) return false;
   for (const SortPass &ps : plan.passes)
@@ -927,27 +928,70 @@ bool count_stream_applies(const mhx_ctx *c, uint32_t k, uint32_t m) {
   // the table key is the (k+1)-mer below the prefix in 32 bits, and the all-ones word stands for an empty slot (a forced narrow
   // prefix — s1_stream_bits — could ask for more)
   if (2 * ((int)k + 1) - plan.seg_bits > 31) return false;
-  return sort_takes_generated_first_pass(c, n_items, 3, plan.passes);
+  if (plan_out) *plan_out = plan;
+  return sort_takes_generated_first_pass(c, c->filter_on ? std::max<uint64_t>(c->filter_expected, 1) : n_items, 3, plan.passes);
+}
+bool count_stream_applies(const mhx_ctx *c, uint32_t k, uint32_t m) {
+  // (under a bucket filter — a pass of the memory plan — the generating pass keeps only the records of the kept lv1 buckets and the
+  //  plan follows the density of that bucket range, as in stage 1; first_0_out / last_0_in and the histogram accumulate over the passes)
+  if (c->global_bases || c->n_parts > 1) return false;
+  return count_stream_shape(c, k, m, nullptr);
+}
+// several GPUs: this rank's say (the ranks decide together, comm.hip); the plan follows the density they agreed on (mhx_ctx::s1_density)
+bool count_presort_applies(const mhx_ctx *c, uint32_t k, uint32_t m) {
+  if (!c->global_bases || c->n_parts > kStreamSrcMax || !c->opt("dist_presort", 1)) return false;
+  return count_stream_shape(c, k, m, nullptr);
+}
+// the front half on a rank of a multi-GPU run: this rank's records, made by the first sort pass and ordered by the plan's prefix
+// (n_items == 0: a rank or pass without an edge — nothing made, `sorted` is an empty buffer)
+uint32_t *count_presort(mhx_ctx *c, uint32_t k, uint64_t *n_items, uint32_t **other, int *pbits) {
+  const S1Plan plan = s1_plan(c, k, std::max<uint64_t>(count_plan_items(c, k), 1), true, 0);
+  if (!plan.stream) throw Error("count_presort: the bucket-streaming plan does not apply");
+  *pbits = plan.seg_bits;
+  uint32_t *buf_a = nullptr, *buf_b = nullptr;
+  *n_items = 0;
+  c->gen_first_pass = nullptr;
+  if (!count_stream_front(c, k, plan, &buf_a, &buf_b, n_items)) {
+    *n_items = 0;
+    c->gen_first_pass = nullptr;
+    c->pre_hist_buf = nullptr;
+    buf_a = c->ws("items_a", 64).as<uint32_t>();
+    *other = c->ws("items_b", 64).as<uint32_t>();
+    return buf_a;
+  }
+  uint32_t *sorted = radix_sort(c, buf_a, buf_b, *n_items, 3, 2, plan.passes);
+  c->pre_hist_buf = nullptr;
+  *other = sorted == buf_a ? buf_b : buf_a;
+  return sorted;
 }
 // records made by the first sort pass, prefix passes, bucket streaming.  -> false: gave up (an output region too small): nothing
-// published, the caller runs the extraction + tile path; true: the solid edges lie in the per-workgroup regions of *spare
+// published, the caller runs the extraction + tile path; true: the solid edges lie in the per-workgroup regions of *spare.
+// pre: the records lie pre-sorted by the plan's prefix in several arrays (several GPUs: one per sending rank); the events that move
+// first_0_out / last_0_in then leave as a list (o->events) for the ranks that hold the reads instead of being applied here.
 bool count_stream_groups(mhx_ctx *c, uint32_t k, uint32_t m, uint32_t *first_0_out, uint32_t *last_0_in_p1, unsigned long long *hist,
-                         CountStreamOut *o) {
+                         CountStreamOut *o, const S1Sources *pre) {
   SeqSet &s = c->seqs;
   hipStream_t st = c->stream;
-  const bool var = s.fixed_len == 0;
-  const uint32_t per = (var ? s.max_len : s.fixed_len) - k;  // item slots per read
-  const uint64_t n_slots = s.n_seqs * (uint64_t)per;
-  const uint64_t n_est = var ? s.n_bases - s.n_seqs * (uint64_t)k : n_slots;
-  const S1Plan plan = s1_plan(c, k, n_est, true, 0);
+  const bool global = c->global_bases != 0;
+  if (global != (pre != nullptr)) throw Error("count_stream_groups: pre-sorted sources belong to the multi-GPU layout and the other way round");
+  const S1Plan plan = s1_plan(c, k, std::max<uint64_t>(count_plan_items(c, k), 1), true, 0);
   const int KWv = 2;
-  uint32_t *buf_a = nullptr, *buf_b = nullptr;
+  uint32_t *sorted = nullptr, *spare = nullptr;
   uint64_t n_items = 0;
-  if (!count_stream_front(c, k, plan, &buf_a, &buf_b, &n_items)) return false;  // (no read holds an edge: the general path knows what to publish)
-  const uint64_t pos_stride = (s.n_bases >> s1_pos_bits(c)) ? 1ull << s1_pos_bits(c) : 0ull;
-  uint32_t *sorted = radix_sort(c, buf_a, buf_b, n_items, 3, KWv, plan.passes);
-  c->pre_hist_buf = nullptr;
-  uint32_t *spare = sorted == buf_a ? buf_b : buf_a;
+  if (pre) {
+    if (pre->pbits != plan.seg_bits) throw Error("count: the sources were sorted for another plan than the one this rank makes");
+    if (pre->n > kStreamSrcMax) throw Error("count: more pre-sorted sources than the bucket streaming takes");
+    for (uint64_t v : pre->count) n_items += v;
+    spare = pre->spare;
+  } else {
+    uint32_t *buf_a = nullptr, *buf_b = nullptr;
+    if (!count_stream_front(c, k, plan, &buf_a, &buf_b, &n_items)) return false;  // (no read holds an edge: the general path knows what to publish)
+    sorted = radix_sort(c, buf_a, buf_b, n_items, 3, KWv, plan.passes);
+    c->pre_hist_buf = nullptr;
+    spare = sorted == buf_a ? buf_b : buf_a;
+  }
+  const uint64_t n_bits = global ? c->global_bases : s.n_bases;
+  const uint64_t pos_stride = (n_bits >> s1_pos_bits(c)) ? 1ull << s1_pos_bits(c) : 0ull;
   // bucket streaming
   const uint64_t n_buckets = 1ull << plan.seg_bits;
   const uint64_t cus = c->n_cus > 0 ? (uint64_t)c->n_cus : 256;
@@ -961,11 +1005,22 @@ bool count_stream_groups(mhx_ctx *c, uint32_t k, uint32_t m, uint32_t *first_0_o
   uint32_t *seg_err = c->ws("s1_seg_err", 64).as<uint32_t>();
   MHX_HIP(hipMemsetAsync(ctr, 0, 64, st));
   MHX_HIP(hipMemsetAsync(seg_err, 0, 4, st));
-  uint64_t *bounds = c->ws("s1_bucket_bounds", (n_buckets + 1) * 8 + 64).as<uint64_t>();
+  const int n_src = pre ? pre->n : 1;
+  uint64_t *bounds = c->ws("s1_bucket_bounds", (size_t)n_src * (n_buckets + 1) * 8 + 64).as<uint64_t>();
   uint32_t *ticket = c->ws("s1_stream_ticket", 64).as<uint32_t>();
   MHX_HIP(hipMemsetAsync(ticket, 0, 4, st));
-  MHX_LAUNCH(c, "bucket_bounds", (double)n_buckets * 8 * 30,
-             hipLaunchKernelGGL(k_bucket_bounds, dim3((unsigned)((n_buckets + 1 + 255) / 256)), dim3(256), 0, st, sorted, n_items, 3, bounds, plan.seg_bits));
+  const unsigned bgrid = (unsigned)((n_buckets + 1 + 255) / 256);
+  const uint32_t *const *srcs = nullptr;
+  if (pre) {
+    DevBuf &sp = c->ws("s1_src_ptrs", (size_t)n_src * 8 + 64);
+    MHX_HIP(hipMemcpyAsync(sp.p, pre->ptr.data(), (size_t)n_src * 8, hipMemcpyHostToDevice, st));
+    srcs = sp.as<const uint32_t *>();
+    for (int q = 0; q < n_src; ++q)
+      hipLaunchKernelGGL(k_bucket_bounds, dim3(bgrid), dim3(256), 0, st, pre->ptr[q], pre->count[q], 3, bounds + (size_t)q * (n_buckets + 1), plan.seg_bits);
+  } else {
+    MHX_LAUNCH(c, "bucket_bounds", (double)n_buckets * 8 * 30,
+               hipLaunchKernelGGL(k_bucket_bounds, dim3(bgrid), dim3(256), 0, st, sorted, n_items, 3, bounds, plan.seg_bits));
+  }
   S1SegArgs a{};
   a.k = (int)k;
   a.m = m;
@@ -983,15 +1038,28 @@ bool count_stream_groups(mhx_ctx *c, uint32_t k, uint32_t m, uint32_t *first_0_o
   a.c_fixed_len = s.fixed_len;
   a.first_0_out = first_0_out;
   a.last_0_in_p1 = last_0_in_p1;
+  uint32_t ecap = 0;
+  uint32_t *ecounts = nullptr;
+  if (global) {
+    // events (8 bytes each; at most two per record of a solid key without an in- or out-edge: read ends, tips — a few per thousand
+    // records) in per-workgroup regions of a buffer of their own: the spare sort buffer holds the edge regions
+    const uint64_t total = std::max<uint64_t>(n_items / (uint64_t)std::max<long long>(c->opt("count_event_share", 4), 1), (uint64_t)grid * 4096);
+    ecap = (uint32_t)std::min<uint64_t>(total / grid, 0xFFFFFFF0u);
+    a.marks_raw = c->ws("cs_events", (size_t)grid * ecap * 8 + 64).as<unsigned long long>();
+    a.marks_cap = ecap;
+    a.marks_counts = ecounts = c->ws("cs_event_counts", (size_t)grid * 4).as<uint32_t>();
+  }
   const S1StreamGeom geo{plan.seg_bits, plan.sub0, (uint32_t)n_buckets,
                          (uint32_t)std::min<long long>(std::max<long long>(c->opt("s1_stream_fill", 8192 * 7 / 8), 1), 8192)};
   const double bytes = (double)n_items * 12 * (double)(1u << plan.sub0);
-  S1StreamLaunch sl{true, false, pos_stride != 0, false, true, grid, sorted, bounds, a, geo, 1u, ticket, nullptr, 1};
+  S1StreamLaunch sl{true, false, pos_stride != 0, false, true, grid, pre ? pre->ptr[0] : sorted, bounds, a, geo, 1u, ticket, srcs, n_src};
   s1_stream_launch(c, "count_groups", bytes, sl);
   uint32_t e = 0;
   unsigned long long h_ctr[8] = {0};
+  std::vector<uint32_t> h_ec(global ? grid : 0);
   MHX_HIP(hipMemcpyAsync(&e, seg_err, 4, hipMemcpyDeviceToHost, st));
   MHX_HIP(hipMemcpyAsync(h_ctr, ctr, 64, hipMemcpyDeviceToHost, st));
+  if (global) MHX_HIP(hipMemcpyAsync(h_ec.data(), ecounts, (size_t)grid * 4, hipMemcpyDeviceToHost, st));
   MHX_HIP(hipStreamSynchronize(st));
   o->grid = grid;
   o->cap = region;
@@ -1000,7 +1068,18 @@ bool count_stream_groups(mhx_ctx *c, uint32_t k, uint32_t m, uint32_t *first_0_o
   o->sorted = sorted;
   o->n_items = n_items;
   o->n_distinct = h_ctr[4];
-  o->plan = s1_plan_text(c, k, n_items);
+  o->plan = s1_plan_text(c, k, std::max<uint64_t>(count_plan_items(c, k), 1));
+  o->events = nullptr;
+  o->n_events = 0;
+  if (e == 0 && global) {  // the workgroups' event regions -> one list
+    for (uint32_t v : h_ec) o->n_events += v;
+    unsigned long long *dense = c->ws("cs_events_dense", o->n_events * 8 + 64).as<unsigned long long>();
+    if (o->n_events)
+      MHX_LAUNCH(c, "events_compact", (double)o->n_events * 16,
+                 hipLaunchKernelGGL(k_agg_compact, dim3(grid, 8), dim3(256), 0, st, reinterpret_cast<const uint2 *>(a.marks_raw), ecap, ecounts,
+                                    reinterpret_cast<uint2 *>(dense), 0));
+    o->events = dense;
+  }
   return e == 0;
 }
 

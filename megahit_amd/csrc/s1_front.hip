@@ -417,7 +417,7 @@ __global__ __launch_bounds__(256) void k_s1_digit_hist_roll(const uint32_t *__re
 template <int IT, int NP, bool VAR = false>  // VAR: reads of any length, `per` = max_len - k item slots each (CountGenVarT)
 __global__ __launch_bounds__(256) void k_count_digit_hist_roll(const uint32_t *__restrict__ seq, uint32_t L, uint32_t per, uint64_t n_items, int k,
                                                                HiDigits hd, unsigned long long *__restrict__ ghist, uint32_t step_q, uint32_t step_r,
-                                                               const uint64_t *__restrict__ start, uint64_t n_seqs) {
+                                                               const uint64_t *__restrict__ start, uint64_t n_seqs, const uint32_t *__restrict__ keep) {
   static_assert(IT <= 8, "a run of IT edges and their flanks inside one 32-base window");
   constexpr int B = 256 * IT;
   __shared__ uint32_t h[kFastPasses][4][256];
@@ -469,7 +469,7 @@ __global__ __launch_bounds__(256) void k_count_digit_hist_roll(const uint32_t *_
       const uint64_t f = (W << (d2 + 2)) & emask;
       const uint64_t rc = (R << (rsh - d2)) & emask;
       const uint32_t hi = (uint32_t)((rc < f ? rc : f) >> 32);
-      if (g0 + u < n_items && j < cnt) {
+      if (g0 + u < n_items && j < cnt && (!keep || s1_bucket_kept(keep, hi))) {  // (keep: a memory-plan pass counts what its generating pass will keep)
 #pragma unroll
         for (int p = 0; p < NP; ++p) atomicAdd(&h[p][wv][(hi >> hd.sh[p]) & hd.mk[p]], 1u);
       }
@@ -494,6 +494,84 @@ __global__ __launch_bounds__(256) void k_count_digit_hist_roll(const uint32_t *_
     const uint32_t v = h[p][0][threadIdx.x] + h[p][1][threadIdx.x] + h[p][2][threadIdx.x] + h[p][3][threadIdx.x];
     if (v) atomicAdd(&ghist[p * 256 + threadIdx.x], (unsigned long long)v);
   }
+}
+
+// The lv1-bucket histogram of `count` (KmerCounter::Lv0CalcBucketSize, kmer_counter.cpp:114-156) from the packed reads with CountGenT's
+// window arithmetic — what a memory plan asks for before it splits a job into bucket ranges; one half of the bucket space per launch,
+// as k_s1_bucket_hist_fast.  k <= kCountStreamMaxK, >= IT item slots per read.
+template <int IT, bool VAR>
+__global__ __launch_bounds__(1024) void k_count_bucket_hist(const uint32_t *__restrict__ seq, uint32_t L, uint32_t per, uint64_t n_items, int k,
+                                                            unsigned long long *__restrict__ ghist, uint32_t step_q, uint32_t step_r, uint32_t half,
+                                                            const uint64_t *__restrict__ start, uint64_t n_seqs) {
+  static_assert(IT <= 8, "a run of IT edges and their flanks inside one 32-base window");
+  constexpr int NT = 1024, B = NT * IT, NB = MHX_NUM_BUCKETS / 2;
+  __shared__ uint32_t h[NB];
+  for (int i = threadIdx.x; i < NB; i += NT) h[i] = 0;
+  __syncthreads();
+  const uint64_t emask = ~0ull << (64 - 2 * (k + 1));
+  const unsigned rsh = (unsigned)(2 * (30 - k));
+  const uint64_t n_blocks = (n_items + B - 1) / B;
+  uint64_t q0 = ((uint64_t)blockIdx.x * (uint64_t)B) / per;
+  uint32_t rem0 = (uint32_t)(((uint64_t)blockIdx.x * (uint64_t)B) % per);
+  for (uint64_t blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
+    const uint64_t g0 = blk * B + (uint64_t)threadIdx.x * IT;
+    const uint32_t t = rem0 + (uint32_t)threadIdx.x * IT, dq = t / per;
+    uint32_t j = t - dq * per;
+    uint64_t r = q0 + dq;
+    if (g0 >= n_items) {  // (nothing of this block is this thread's: loads from the start of the store, nothing counted)
+      j = 0;
+      r = 0;
+    }
+    uint64_t base, base_n;
+    uint32_t cnt, cntn;  // item slots this read / the next one fills
+    if constexpr (VAR) {
+      const uint64_t s0 = start[r], s1 = start[r + 1], s2 = start[r + 2 < n_seqs ? r + 2 : n_seqs];
+      const uint32_t L0 = (uint32_t)(s1 - s0), L1 = (uint32_t)(s2 - s1);
+      base = s0;
+      base_n = s1;
+      cnt = L0 >= (uint32_t)k + 1 ? L0 - k : 0u;
+      cntn = L1 >= (uint32_t)k + 1 ? L1 - k : 0u;
+    } else {
+      base = r * L;
+      base_n = base + L;
+      cnt = cntn = per;
+    }
+    uint64_t wcur, wnext;
+    unsigned sh0, down0, shn, downn;
+    count_window_addr(base + min(j, cnt ? cnt - 1 : 0u), wcur, sh0, down0);
+    count_window_addr(base_n, wnext, shn, downn);
+    const uint32_t c0 = seq[wcur], c1 = seq[wcur + 1], c2 = seq[wcur + 2];
+    const uint32_t n0 = seq[wnext], n1 = seq[wnext + 1], n2 = seq[wnext + 2];
+    uint64_t W = (((uint64_t)funnel_l(c0, c1, sh0) << 32) | funnel_l(c1, c2, sh0)) >> down0;
+    uint64_t R = rc64(W, 32);
+    const uint64_t Wn = (((uint64_t)funnel_l(n0, n1, shn) << 32) | funnel_l(n1, n2, shn)) >> downn;
+    const uint64_t Rn = rc64(Wn, 32);
+    uint32_t prun = j;
+#pragma unroll
+    for (int u = 0; u < IT; ++u) {
+      const unsigned d2 = (j - prun) * 2;
+      const uint64_t f = (W << (d2 + 2)) & emask;
+      const uint64_t rc = (R << (rsh - d2)) & emask;
+      const uint32_t b = (uint32_t)((rc < f ? rc : f) >> 48);
+      if (g0 + u < n_items && j < cnt && (b >> 15) == half) atomicAdd(&h[b & (NB - 1)], 1u);
+      if (++j == per) {
+        j = 0;
+        cnt = cntn;
+        W = Wn;
+        R = Rn;
+        prun = 0;
+      }
+    }
+    q0 += step_q;
+    rem0 += step_r;
+    if (rem0 >= per) {
+      rem0 -= per;
+      ++q0;
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < NB; i += NT)
+    if (h[i]) atomicAdd(&ghist[half * NB + i], (unsigned long long)h[i]);
 }
 
 // The lv1-bucket histogram of stage 1 (the reference's Lv0CalcBucketSize, read_to_sdbg_s1.cpp:145-206) for the fast shape —
@@ -708,6 +786,39 @@ bool s1_bucket_histogram_fast(mhx_ctx *c, uint32_t k, unsigned long long *hist) 
       MHX_LAUNCH(c, "s1_bucket_hist", (double)s.n_bases / 4,
                  hipLaunchKernelGGL((k_s1_bucket_hist_fast<IT>), dim3(grid), dim3(1024), 0, c->stream, s.words.as<uint32_t>(), s.fixed_len, per, n_items,
                                     (int)k, hist, (uint32_t)(stride_items / per), (uint32_t)(stride_items % per), half));
+  }
+  return true;
+}
+
+// the shapes CountGenT / CountGenVarT serve: >= 8 item slots per read, k <= kCountStreamMaxK; a library of several read lengths while at
+// least s1_var_min_fill per cent of the padded slots are edges
+bool count_shape_is_fast(const mhx_ctx *c, uint32_t k) {
+  const SeqSet &s = c->seqs;
+  if (!s.n_seqs || k < 9 || (int)k > kCountStreamMaxK) return false;
+  if (s.fixed_len) return s.fixed_len >= k + 1 && s.fixed_len - k >= 8;
+  if (!c->opt("s1_var_fast", 1) || s.max_len < k + 1 || s.max_len - k < 8 || s.n_bases <= s.n_seqs * (uint64_t)k) return false;
+  return (double)s.n_bases * 100.0 >= (double)c->opt("s1_var_min_fill", 50) * (double)s.n_seqs * s.max_len;
+}
+// -> true when it ran; hist: device, 65 536 counters, zeroed by the caller
+bool count_bucket_histogram_fast(mhx_ctx *c, uint32_t k, unsigned long long *hist) {
+  SeqSet &s = c->seqs;
+  if (!c->opt("s1_bucket_hist_fast", 1) || !c->opt("count_stream", 1) || !count_shape_is_fast(c, k)) return false;
+  constexpr int IT = 8;
+  const bool var = s.fixed_len == 0;
+  const uint32_t per = (var ? s.max_len : s.fixed_len) - k;
+  const uint64_t n_slots = s.n_seqs * (uint64_t)per;
+  const uint64_t cus = c->n_cus > 0 ? (uint64_t)c->n_cus : 256;
+  const unsigned grid = (unsigned)std::min<uint64_t>(div_ceil(n_slots, 1024 * IT), cus);
+  const uint64_t stride_items = (uint64_t)grid * 1024 * IT;
+  for (uint32_t half = 0; half < 2; ++half) {
+    if (var)
+      MHX_LAUNCH(c, "count_bucket_hist", (double)s.n_bases / 4 + (double)s.n_seqs * 8,
+                 hipLaunchKernelGGL((k_count_bucket_hist<IT, true>), dim3(grid), dim3(1024), 0, c->stream, s.words.as<uint32_t>(), 0u, per, n_slots, (int)k, hist,
+                                    (uint32_t)(stride_items / per), (uint32_t)(stride_items % per), half, s.start.as<uint64_t>(), s.n_seqs));
+    else
+      MHX_LAUNCH(c, "count_bucket_hist", (double)s.n_bases / 4,
+                 hipLaunchKernelGGL((k_count_bucket_hist<IT, false>), dim3(grid), dim3(1024), 0, c->stream, s.words.as<uint32_t>(), s.fixed_len, per, n_slots, (int)k,
+                                    hist, (uint32_t)(stride_items / per), (uint32_t)(stride_items % per), half, s.start.as<uint64_t>(), s.n_seqs));
   }
   return true;
 }
@@ -1065,6 +1176,9 @@ bool count_stream_front(mhx_ctx *c, uint32_t k, const S1Plan &plan, uint32_t **b
   const uint32_t per = (var ? s.max_len : s.fixed_len) - k;  // item slots per read
   const uint64_t n_slots = s.n_seqs * (uint64_t)per;
   const int KWv = 2;
+  // a pass of the memory plan: the lv1-bucket filter sits inside the histogram pre-pass and the generating pass (where the reference's
+  // OffsetFiller::IsHandling sits, base_engine.h:106-108) — one scan of the reads per pass, only the kept records ever written
+  const uint32_t *keep = c->filter_on ? c->work["filter_bits"].as<uint32_t>() : nullptr;
   // digit histograms of the plan's passes (the chained scan wants every pass's bin starts beforehand)
   HiDigits hd;
   hd.n = (int)plan.passes.size();
@@ -1083,7 +1197,7 @@ bool count_stream_front(mhx_ctx *c, uint32_t k, const S1Plan &plan, uint32_t **b
   MHX_LAUNCH(c, "count_digit_hist", (double)s.n_bases / 4,                                                                                  \
              hipLaunchKernelGGL((k_count_digit_hist_roll<ITH, NPV, VARV>), dim3(fgrid), dim3(256), 0, st, s.words.as<uint32_t>(), s.fixed_len, per, \
                                 n_slots, (int)k, hd, pre_hist, (uint32_t)(stride_items / per), (uint32_t)(stride_items % per),              \
-                                s.start.as<uint64_t>(), s.n_seqs))
+                                s.start.as<uint64_t>(), s.n_seqs, keep))
 #define MHX_CH2(NPV)             \
   do {                           \
     if (var) MHX_CH(NPV, true);  \
@@ -1097,13 +1211,14 @@ bool count_stream_front(mhx_ctx *c, uint32_t k, const S1Plan &plan, uint32_t **b
 #undef MHX_CH
   }
   uint64_t n_items = n_slots;  // the records
-  if (var) {  // = the sum of any one digit histogram
+  if (var || keep) {  // = the sum of any one digit histogram
     std::vector<unsigned long long> h0(256);
     MHX_HIP(hipMemcpyAsync(h0.data(), pre_hist, 256 * 8, hipMemcpyDeviceToHost, st));
     MHX_HIP(hipStreamSynchronize(st));
     n_items = 0;
     for (unsigned long long v : h0) n_items += v;
-    if (n_items == 0) return false;  // (no read holds an edge: the general path knows what to publish)
+    if (keep && n_items > c->filter_expected) throw Error("bucket filter: more items in the kept buckets than announced");
+    if (n_items == 0) return false;  // (no read holds an edge / no edge in the kept buckets: the general path knows what to publish)
   }
   uint32_t *buf_a = c->ws("items_a", n_items * 12 + 64).as<uint32_t>();
   uint32_t *buf_b = c->ws("items_b", n_items * 12 + 64).as<uint32_t>();
@@ -1115,17 +1230,22 @@ bool count_stream_front(mhx_ctx *c, uint32_t k, const S1Plan &plan, uint32_t **b
   c->pre_hist_n = n_items;
   c->pre_hist_passes = hd.n;
   const uint32_t pos_bits = s1_pos_bits(c);
-  const CountGenT g{s.words.as<uint32_t>(), s.fixed_len, per, (int)k, c->pos_base, pos_bits, (uint32_t)(kSortThreads * 8) / per, (uint32_t)(kSortThreads * 8) % per};
-  const CountGenVarT gv{s.words.as<uint32_t>(), s.start.as<uint64_t>(), s.n_seqs, per, (int)k, c->pos_base, pos_bits, (uint32_t)(kSortThreads * 8) / per,
-                        (uint32_t)(kSortThreads * 8) % per};
-  c->gen_first_pass = [g, gv, var](const OnesweepLaunch &l) {
+  const uint32_t tq = (uint32_t)(kSortThreads * 8) / per, tr = (uint32_t)(kSortThreads * 8) % per;
+  const CountGenT<false> g{s.words.as<uint32_t>(), s.fixed_len, per, (int)k, c->pos_base, pos_bits, tq, tr, nullptr};
+  const CountGenT<true> gf{s.words.as<uint32_t>(), s.fixed_len, per, (int)k, c->pos_base, pos_bits, tq, tr, keep};
+  const CountGenVarT<false> gv{s.words.as<uint32_t>(), s.start.as<uint64_t>(), s.n_seqs, per, (int)k, c->pos_base, pos_bits, tq, tr, nullptr};
+  const CountGenVarT<true> gvf{s.words.as<uint32_t>(), s.start.as<uint64_t>(), s.n_seqs, per, (int)k, c->pos_base, pos_bits, tq, tr, keep};
+  const bool filter = keep != nullptr;
+  c->gen_first_pass = [g, gf, gv, gvf, var, filter](const OnesweepLaunch &l) {
     if (!(l.unit_runs && l.wi == 0)) throw Error("count: the generating pass needs the unit-wide pass on a first-word digit");
-    if (var)
-      hipLaunchKernelGGL((k_radix_onesweep_u<3, 8, 3, CountGenVarT, 1, 0>), dim3(l.grid), dim3(kSortThreads), 0, l.stream, gv, l.out, l.n, l.ds, l.nbits,
-                         l.bin_start, l.status, l.ticket, l.err, l.tag, l.xcd_units);
-    else
-      hipLaunchKernelGGL((k_radix_onesweep_u<3, 8, 3, CountGenT, 1, 0>), dim3(l.grid), dim3(kSortThreads), 0, l.stream, g, l.out, l.n, l.ds, l.nbits, l.bin_start,
-                         l.status, l.ticket, l.err, l.tag, l.xcd_units);
+#define MHX_CGEN(SRCT, SRCV)                                                                                                                \
+  hipLaunchKernelGGL((k_radix_onesweep_u<3, 8, 3, SRCT, 1, 0>), dim3(l.grid), dim3(kSortThreads), 0, l.stream, SRCV, l.out, l.n, l.ds, l.nbits, \
+                     l.bin_start, l.status, l.ticket, l.err, l.tag, l.xcd_units)
+    if (var && filter) MHX_CGEN(CountGenVarT<true>, gvf);
+    else if (var) MHX_CGEN(CountGenVarT<false>, gv);
+    else if (filter) MHX_CGEN(CountGenT<true>, gf);
+    else MHX_CGEN(CountGenT<false>, g);
+#undef MHX_CGEN
   };
   c->gen_buf = buf_a;
   c->gen_n = n_items;

@@ -520,6 +520,9 @@ __device__ __forceinline__ void count_item_from_parts(uint64_t f, uint64_t rc, u
   out[1] = (uint32_t)key | count_pos_tag(g, pos_bits);
   out[2] = s1_pos_word(g, pos_bits);
 }
+// FILTER: the lv1-bucket filter of a memory-plan pass inside the generator, as in S1GenT (`keep`: a bitmap over the 65 536 lv1 buckets; a
+// dropped item becomes a record that is_record() rejects: prev / next bits 63, which PackEdge's fields never hold)
+template <bool FILTER>
 struct CountGenT {
   const uint32_t *seq;
   uint32_t L, per;  // per = L - k items per read
@@ -527,8 +530,9 @@ struct CountGenT {
   uint64_t pos_base;
   uint32_t pos_bits;
   uint32_t tile_q, tile_r;
-  static constexpr bool kMayDrop = false;
-  __device__ __forceinline__ bool is_record(const Rec<3> &) const { return true; }
+  const uint32_t *keep;
+  static constexpr bool kMayDrop = FILTER;
+  __device__ __forceinline__ bool is_record(const Rec<3> &r) const { return !FILTER || (r.w[1] & 63u) != 63u; }
   template <int NI>
   __device__ __forceinline__ uint64_t index(uint64_t tile_base, int w, int lane, int j) const {
     return tile_base + (uint64_t)((w * kWave + lane) * NI + j);
@@ -599,6 +603,8 @@ struct CountGenT {
         const unsigned prev_b = (unsigned)(W >> (62 - d2)) & 3u, next_b = (unsigned)(W >> ((unsigned)(58 - 2 * k) - d2)) & 3u;
         uint32_t out[3];
         count_item_from_parts(f, rc, prev_b, next_b, j, L, k, base + j, pos_base, pos_bits, out);
+        if constexpr (FILTER)
+          if (!s1_bucket_kept(keep, out[0])) out[1] = kS1Dropped;
         if (g0 + (uint64_t)i < n) {
           rec[t][i].w[0] = out[0];
           rec[t][i].w[1] = out[1];
@@ -617,6 +623,7 @@ struct CountGenT {
 };
 // the same records from a library whose reads are not of one length: `per` = max_len - k item slots per read, the slots a shorter read
 // does not fill declined (S1GenVarT's scheme)
+template <bool FILTER>
 struct CountGenVarT {
   const uint32_t *seq;
   const uint64_t *start;  // [n_seqs + 1]
@@ -626,6 +633,7 @@ struct CountGenVarT {
   uint64_t pos_base;
   uint32_t pos_bits;
   uint32_t tile_q, tile_r;
+  const uint32_t *keep;
   static constexpr bool kMayDrop = true;
   __device__ __forceinline__ bool is_record(const Rec<3> &r) const { return (r.w[1] & 63u) != 63u; }
   template <int NI>
@@ -710,6 +718,8 @@ struct CountGenVarT {
         uint32_t out[3];
         count_item_from_parts(f, rc, prev_b, next_b, j, L, k, base + j, pos_base, pos_bits, out);
         if (j >= cnt) out[1] = kS1Dropped;  // a slot this read does not fill
+        if constexpr (FILTER)
+          if (!s1_bucket_kept(keep, out[0])) out[1] = kS1Dropped;
         if (g0 + (uint64_t)i < n) {
           rec[t][i].w[0] = out[0];
           rec[t][i].w[1] = out[1];

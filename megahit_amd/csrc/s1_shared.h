@@ -152,6 +152,8 @@ void s1_classic_launch(mhx_ctx *c, int S, bool compact, bool agg, const uint32_t
                        uint2 *agg_items, uint64_t *agg_cursor, int mark_mode);
 // the front of `count` on this design (s1_front.hip): digit histograms of the plan's passes from the packed reads, the record buffers, and the
 // generating first pass armed for the next radix_sort on *buf_a.  -> false: no read holds an edge
+bool count_shape_is_fast(const mhx_ctx *c, uint32_t k);  // the shapes CountGenT / CountGenVarT serve
+bool count_bucket_histogram_fast(mhx_ctx *c, uint32_t k, unsigned long long *hist);  // lv1 histogram of count's items from the packed reads
 bool count_stream_front(mhx_ctx *c, uint32_t k, const S1Plan &plan, uint32_t **buf_a, uint32_t **buf_b, uint64_t *n_items);
 
 }  // namespace mhx

@@ -846,26 +846,52 @@ __global__ __launch_bounds__(NT) void k_s1_stream(const uint32_t *__restrict__ i
             const gptr items = (gptr)src_of(q);
             for (uint64_t base = lo; base < hi; base += NT) {
               const uint64_t gi = base + tid;
-              if (gi >= hi) continue;
-              const gptr p = items + gi * 3;
-              const uint32_t w0 = p[0], w1 = p[1], w2 = p[2];
-              const uint32_t lk = local_key(w0, w1);
-              if (sub != 0 && (lk >> sub_sh) != rj) continue;  // (a key of another round is not in the table)
-              uint32_t h = hash_of(lk);
-              while (keys[h] != lk) h = (h + 1) & (NSLOT - 1);
-              const uint32_t f = fpos[h] >> 30;
-              if (!f) continue;
+              uint32_t f = 0, w1 = 0, w2 = 0;
+              if (gi < hi) {
+                const gptr p = items + gi * 3;
+                const uint32_t w0 = p[0];
+                w1 = p[1];
+                w2 = p[2];
+                const uint32_t lk = local_key(w0, w1);
+                if (sub == 0 || (lk >> sub_sh) == rj) {  // (a key of another round is not in the table)
+                  uint32_t h = hash_of(lk);
+                  while (keys[h] != lk) h = (h + 1) & (NSLOT - 1);
+                  f = fpos[h] >> 30;
+                }
+              }
               const uint64_t abs = w2 + (TAGS ? (uint64_t)((w1 >> 7) & 0xFFu) * a.pos_stride : 0ull);
               const bool fwd = (w1 & kCountStrandBit) == 0;
-              const uint64_t rid = seq_of_offset(a.c_start, a.c_n_seqs, a.c_fixed_len, abs);
-              const uint32_t off = (uint32_t)(abs - a.c_start[rid]);
-              if (f & 1u) {  // no in-edge: strand 0 -> last_0_in = max(off), strand 1 -> first_0_out = min(off + 1)
-                if (fwd) atomicMax(&a.last_0_in_p1[rid], off + 1);
-                else atomicMin(&a.first_0_out[rid], off + 1);
-              }
-              if (f & 2u) {  // no out-edge: the roles swap
-                if (fwd) atomicMin(&a.first_0_out[rid], off + 1);
-                else atomicMax(&a.last_0_in_p1[rid], off + 1);
+              // no in-edge (f & 1): strand 0 -> last_0_in = max(off), strand 1 -> first_0_out = min(off + 1); no out-edge (f & 2): the
+              // roles swap.  As an event: position << 1 | (1: first_0_out, 0: last_0_in) — count.hip k_apply_count_events
+              if (!marks_out) {
+                if (f) {
+                  const uint64_t rid = seq_of_offset(a.c_start, a.c_n_seqs, a.c_fixed_len, abs);
+                  const uint32_t off = (uint32_t)(abs - a.c_start[rid]);
+                  if (f & 1u) {
+                    if (fwd) atomicMax(&a.last_0_in_p1[rid], off + 1);
+                    else atomicMin(&a.first_0_out[rid], off + 1);
+                  }
+                  if (f & 2u) {
+                    if (fwd) atomicMin(&a.first_0_out[rid], off + 1);
+                    else atomicMax(&a.last_0_in_p1[rid], off + 1);
+                  }
+                }
+              } else {  // several GPUs: the reads live on other ranks — the events go to this workgroup's region and are routed to the read owners
+                const uint32_t ne = (f & 1u) + (f >> 1);
+                const uint32_t incl = wave_inclusive_sum(ne);
+                const uint32_t tot = __shfl(incl, kWave - 1, kWave);
+                if (tot) {
+                  uint32_t ebase = 0;
+                  if (lane == 0) ebase = atomicAdd(&s_mark_cur, tot);
+                  ebase = __shfl(ebase, 0, kWave);
+                  uint32_t at = ebase + incl - ne;
+                  if (ebase + tot > a.marks_cap) {
+                    if (lane == 0) atomicOr(a.err, 2u);
+                  } else {
+                    if (f & 1u) marks_out[at++] = (abs << 1) | (fwd ? 0ull : 1ull);
+                    if (f & 2u) marks_out[at] = (abs << 1) | (fwd ? 1ull : 0ull);
+                  }
+                }
               }
             }
           }

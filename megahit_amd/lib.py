@@ -138,6 +138,7 @@ SYMBOLS = {
     "mhx_comm_rank": (C.c_int, [_P]),
     "mhx_comm_size": (C.c_int, [_P]),
     "mhx_comm_barrier": (C.c_int, [_P]),
+    "mhx_comm_bytes_sent": (C.c_uint64, [_P, C.c_int]),
     "mhx_comm_all_reduce_u64": (C.c_int, [_P, _P, C.c_uint64, C.c_int]),
     "mhx_dist_setup": (C.c_int, [_P, _P, C.c_int, C.c_uint32, C.c_uint32]),
     "mhx_dist_read2sdbg": (C.c_int, [_P, _P, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(S1Result), C.POINTER(SdbgResult), _P]),
@@ -479,6 +480,10 @@ class Comm:
 
     def barrier(self):
         self._chk(self.lib.mhx_comm_barrier(self.h))
+
+    def bytes_sent(self, reset=False):
+        """payload bytes this rank has handed to other ranks through the item / record exchanges since the last reset"""
+        return int(self.lib.mhx_comm_bytes_sent(self.h, int(reset)))
 
     def all_reduce(self, values, is_max=False):
         v = np.ascontiguousarray(values, dtype=np.uint64).copy()

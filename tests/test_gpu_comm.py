@@ -176,6 +176,65 @@ def test_count_ranks_as_threads(world, k, m, opts):
     assert np.array_equal(np.concatenate([o[4] for o in outs]), want["last_0_in"])
 
 
+def load_fixed_reads(r, e):
+    from megahit_amd import synth
+    genome = np.random.default_rng(98).integers(0, 4, size=4000, dtype=np.uint8)
+    reads = [x for x in synth.gen_pe_reads(500, 4000, read_len=100, frag=250, err=0.01, seed=300 + r, genome=genome)]
+    if r == 1:  # low-complexity reads on one rank: one key in thousands of records, events at every read end
+        reads[:40] = [np.zeros(100, dtype=np.uint8) for _ in range(40)]
+    pkg = ob.Package(reads, reverse=True)
+    e.load_sequences(pkg.words(), pkg.n_seqs, 0, pkg.start())
+    return reads
+
+
+@pytest.mark.parametrize("world,k,m,fixed,opts,presorted", [
+    (2, 21, 2, True, None, True), (3, 21, 1, True, None, True), (3, 22, 2, True, {"s1_pos_bits": 12}, True),
+    (2, 21, 2, False, {"s1_var_min_fill": 10}, True),                    # reads of several lengths: padded item slots on every rank
+    (3, 21, 2, True, {"dist_max_items": 30000}, True),                   # bucket-range passes: the filter inside every rank's generating pass
+    (3, 21, 2, True, {"s1_stream_bits": 19, "s1_stream_fill": 40}, True),  # three pre-sort passes, overflowing tables, three senders per bucket
+    (2, 21, 2, True, {"s1_stream_probes": 0}, False),                    # the owners' streaming gives up -> the classic exchange redoes the pass
+    (2, 21, 2, True, {"dist_presort": 0}, False), (2, 23, 2, True, None, False), (2, 21, 3, True, None, False),
+])
+def test_count_on_the_presorted_exchange(world, k, m, fixed, opts, presorted):
+    """round 6: `count` on several ranks on the stage-1 design — every rank's first sort pass makes its 12-byte records, the slices of the
+    owners' bucket ranges travel as they are (<= 12 bytes per foreign record), k_s1_stream<COUNT> reads a bucket from one sub-range per
+    sender, the first_0_out / last_0_in events are routed to the read owners; against the oracle's single KmerCounter run
+    (kmer_counter.cpp:158-381)"""
+    reads = [None] * world
+
+    def load(r, e):
+        if fixed:
+            reads[r] = load_fixed_reads(r, e)
+        else:
+            reads[r] = reads_of(100 + r, n_pairs=600)
+            pkg = ob.Package(reads[r], reverse=True)
+            e.load_sequences(pkg.words(), pkg.n_seqs, 0, pkg.start())
+
+    def body(r, e, cm):
+        cm.setup(STAGE_COUNT, k, m)
+        cm.count(k, m)
+        cm.bytes_sent(reset=True)
+        res = cm.count(k, m)  # buffers are reused: same answer the second time
+        return (e.fetch(lib.BUF_EDGES, np.uint32), e.fetch(lib.BUF_BUCKET_COUNT, np.uint64), e.fetch(lib.BUF_MUL_HIST, np.int64),
+                e.fetch(lib.BUF_FIRST_0_OUT, np.uint32), e.fetch(lib.BUF_LAST_0_IN, np.uint32), e.last_s1_plan(), cm.bytes_sent(), int(res.n_items))
+
+    outs = run_ranks(world, load, body, opts)
+    allr = []
+    for r in range(world):
+        allr += reads[r]
+    want = ob.count(ob.Package(allr, reverse=True), k, m)
+    assert np.array_equal(np.concatenate([o[0] for o in outs]).reshape(-1, want["wpe"]), want["edges"])
+    assert np.array_equal(sum(o[1] for o in outs), want["bucket_count"])
+    assert np.array_equal(sum(o[2] for o in outs), want["hist"])
+    assert np.array_equal(np.concatenate([o[3] for o in outs]), want["first_0_out"])
+    assert np.array_equal(np.concatenate([o[4] for o in outs]), want["last_0_in"])
+    assert sum(o[7] for o in outs) == want["n_items"]
+    for o in outs:
+        assert ("pre-sorted exchange" in o[5]) == presorted, o[5]
+    if presorted:  # what crossed the links: 12 bytes per record at most (+ the events, 8 bytes each, a few per thousand records)
+        assert sum(o[6] for o in outs) <= 12 * want["n_items"] + 16 * len(allr) * 4
+
+
 @pytest.mark.parametrize("world,k,opts", [(2, 21, None), (3, 39, None), (3, 39, {"dist_max_items": 3000})])
 def test_seq2sdbg_ranks_as_threads(world, k, opts):
     def load(r, e):
