@@ -793,6 +793,7 @@ int count_process(mhx_ctx *c, uint32_t k, uint32_t m, uint32_t *buf_a, uint32_t 
   uint32_t *sorted = seg_bits ? radix_sort(c, buf_a, buf_b, n_items, S, KWv, sort_passes) : sort_whole_key(c, buf_a, buf_b, n_items, S, KWv, sort_passes);
   uint32_t *spare = sorted == buf_a ? buf_b : buf_a;
 
+  c->last_s1_plan = seg_bits ? "count: tile path, segment group-by on " + std::to_string(seg_bits) + " prefix bits" : "count: tile path, full sort";
   // results
   // accumulate (bucket-range passes after the first): first_0_out, the raw last_0_in (+1) values and the histogram of
   // the earlier passes are kept; the published last_0_in is re-derived from the raw values after every pass

@@ -540,12 +540,14 @@ int main_kmer_count(int argc, char **argv) {
     std::vector<std::vector<uint64_t>> bc(rs.n);
     std::vector<std::vector<int64_t>> hist(rs.n);
     std::vector<mhx_count_result> res(rs.n);
+    std::string plan_text;
     run_ranks(rs, [&](int r, mhx_ctx *c, mhx_comm *cm) {
       const uint64_t lo = first[r], hi = first[r + 1];
       const uint64_t w0 = lib.end_offset(lo), w1 = lib.end_offset(hi);
       CKT(mhx_load_bin_records(c, lib.data + w0, w1 - w0, hi - lo, 1));
       CKT(mhx_dist_setup(c, cm, MHX_STAGE_COUNT, k, m));
       CKT(mhx_dist_count(c, cm, k, m, &res[r]));
+      if (r == 0) plan_text = mhx_last_s1_plan(c);
       edges[r] = fetch_t<uint32_t>(c, MHX_BUF_EDGES);
       bc[r] = fetch_t<uint64_t>(c, MHX_BUF_BUCKET_COUNT);
       hist[r] = fetch_t<int64_t>(c, MHX_BUF_MUL_HIST);
@@ -569,6 +571,7 @@ int main_kmer_count(int argc, char **argv) {
     }
     info("GPU count: %llu items, %llu distinct, %llu solid. Time elapsed: %.4f", (unsigned long long)r.n_items,
          (unsigned long long)r.n_distinct, (unsigned long long)r.n_edges, t.lap());
+    info("Count plan: %s", plan_text.c_str());
     mhxio::write_edges(out, k, r.words_per_edge, all_edges.data(), r.n_edges, bcount.data(), std::max(out_files(n_threads), std::min(rs.n, n_threads)));
     int64_t n_cand = 0, n_tips = 0;
     mhxio::write_cand(out, lib, first_out.data(), last_in.data(), &n_cand, &n_tips);
@@ -604,6 +607,7 @@ int main_kmer_count(int argc, char **argv) {
   clear_range(c, ranges);
   info("GPU count: %llu items, %llu distinct, %llu solid. Time elapsed: %.4f", (unsigned long long)r.n_items,
        (unsigned long long)r.n_distinct, (unsigned long long)r.n_edges, t.lap());
+  info("Count plan: %s", mhx_last_s1_plan(c));
   auto first = fetch<uint32_t>(c, MHX_BUF_FIRST_0_OUT), last = fetch<uint32_t>(c, MHX_BUF_LAST_0_IN);
   auto hist = fetch<int64_t>(c, MHX_BUF_MUL_HIST);
   mhxio::write_edges(out, k, r.words_per_edge, edges.data(), r.n_edges, bcount.data(), out_files(n_threads));

@@ -146,7 +146,10 @@ def configs2(keep=None, emit=True):
         n, k, m = full["reads"], full["k"], full["m"]
         want = full["cases"]["read2sdbg"]
         out = {"workload": "BASELINE configs[2] = the north-star size: read2sdbg -k %d -m %d on %d synthetic 150 bp PE reads (%.1f G edges)" % (k, m, n, full["edges"] / 1e9),
-               "reference": {"wall_s": want["wall_s"], "threads": full["reference_threads"], "host": full["reference_host"], "digest": want["digest"]}, "runs": {}}
+               "reference": {"wall_s": want["wall_s"], "threads": full["reference_threads"], "host": full["reference_host"], "digest": want["digest"],
+                             "same_host_as_the_gpu_runs": False,
+                             "note": "speedup_over_reference_wall divides by the reference's wall time on the BUILD container's 8 cores, not on the GPU box's host; the "
+                                     "same-host, same-run CPU figure exists at 10 M reads only (bench.py cpu_baseline.full_size_this_run)"}, "runs": {}}
         common = ["read2sdbg", "-k", str(k), "-m", str(m), "--host_mem", "64e9", "--num_cpu_threads", "8", "--read_lib_file", os.path.join(d, "reads")]
         for label, pre, env in (("one_gpu", [], {}),
                                 ("eight_ranks_on_one_device", ["--gpus", "8"], {"MHX_GPU_MAP": "0,0,0,0,0,0,0,0", "MHX_FREE_BYTES": "26e9"})):
@@ -161,6 +164,40 @@ def configs2(keep=None, emit=True):
             sys.stderr.write("%s %s\n" % (label, json.dumps({"wall_s": r["wall_s"], "kernel_ms": r["kernel_ms_total"], "ok": ok, "passes": passes})))
             r["log_tail"] = [l for l in LAST_LOG.splitlines() if "plan" in l.lower() or "passes" in l][:12]
             r["log"] = [l for l in LAST_LOG.splitlines() if l.startswith("INFO") or l.startswith("WARN")][-60:]
+            for fn in os.listdir(tmp):
+                if fn.startswith("o_"):
+                    os.remove(os.path.join(tmp, fn))
+        # The orchestrator's DEFAULT k_min route at this size (src/megahit:771-802,939-966; main_sdbg_build.cpp:35-86,158-224): `count`, then
+        # `seq2sdbg --need_mercy` over count's edges + .cand — on one GPU (memory plan: count's bucket-range passes on the stage-1 design)
+        # and as eight ranks on this device (pre-sorted exchange, events routed to the read owners); digests = the reference's own runs
+        wc, wm = full["cases"]["count"], full["cases"]["seq2sdbg_need_mercy"]
+        out["default_route"] = {"reference": {"count_wall_s": wc["wall_s"], "seq2sdbg_need_mercy_wall_s": wm["wall_s"], "threads": full["reference_threads"],
+                                               "host": full["reference_host"] + " — NOT the GPU box's host: a same-host figure exists only at 10 M reads (bench.py cpu_baseline)"},
+                                "runs": {}}
+        for label, pre, env in (("one_gpu", [], {}),
+                                ("eight_ranks_on_one_device", ["--gpus", "8"], {"MHX_GPU_MAP": "0,0,0,0,0,0,0,0", "MHX_FREE_BYTES": "26e9"})):
+            o = os.path.join(tmp, "o_" + label)
+            ent = {}
+            wall, phases, kernels, passes = run(pre + ["count", "-k", str(k), "-m", str(m), "--host_mem", "64e9", "--num_cpu_threads", "8", "--read_lib_file",
+                                                       os.path.join(d, "reads"), "--output_prefix", o], env, os.path.join(tmp, "prof.json"))
+            r = summarise(kernels)
+            hdr, _rows = canon.read_edges_info(o)
+            ok = (hdr["num_edges"] == wc["n_edges"] and canon.digest_edges(o) == wc["digest"] and canon.digest_file(o + ".counting") == wc["counting_md5"] and
+                  canon.digest_file(o + ".cand") == wc["cand_md5"])
+            r.update(wall_s=round(wall, 2), phases_s=phases, memory_plan_passes=passes, bit_identical_to_reference=ok,
+                     M_edges_per_s_kernel_time=round(full["edges"] / r["kernel_ms_total"] / 1e3, 1), speedup_over_reference_wall=round(wc["wall_s"] / wall, 1),
+                     log_tail=[l for l in LAST_LOG.splitlines() if "plan" in l.lower() or "passes" in l][:12])
+            ent["count"] = r
+            sys.stderr.write("default route %s count %s\n" % (label, json.dumps({"wall_s": r["wall_s"], "kernel_ms": r["kernel_ms_total"], "ok": ok, "passes": passes})))
+            wall, phases, kernels, passes = run(pre + ["seq2sdbg", "-k", str(k), "--kmer_from", "0", "--host_mem", "64e9", "--num_cpu_threads", "8", "--input_prefix", o,
+                                                       "--need_mercy", "--output_prefix", o + "_s"], env, os.path.join(tmp, "prof.json"))
+            r = summarise(kernels)
+            ok = canon.digest_sdbg(o + "_s") == wm["digest"]
+            r.update(wall_s=round(wall, 2), phases_s=phases, memory_plan_passes=passes, bit_identical_to_reference=ok,
+                     speedup_over_reference_wall=round(wm["wall_s"] / wall, 1))
+            ent["seq2sdbg_need_mercy"] = r
+            sys.stderr.write("default route %s seq2sdbg --need_mercy %s\n" % (label, json.dumps({"wall_s": r["wall_s"], "kernel_ms": r["kernel_ms_total"], "ok": ok})))
+            out["default_route"]["runs"][label] = ent
             for fn in os.listdir(tmp):
                 if fn.startswith("o_"):
                     os.remove(os.path.join(tmp, fn))
