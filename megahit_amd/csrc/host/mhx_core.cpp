@@ -5,6 +5,7 @@
 // Sub-programs outside the SdBG-construction path (buildlib, assemble, iterate, local, ...) are not
 // implemented here; when MHX_REF_CORE names a reference `megahit_core` binary they are forwarded to
 // it unchanged, so the unmodified `megahit` orchestrator can run with this binary in place.
+#include <cmath>
 #include <unistd.h>
 #include <fcntl.h>
 #include <poll.h>
@@ -399,8 +400,37 @@ std::vector<BucketRange> plan_ranges(mhx_ctx *c, int stage, uint32_t k, uint32_t
     const uint64_t probe = 1ull << 30, lib_bytes = mhx_stage_pass_bytes(c, stage, k, m, probe);
     const double per_item = lib_bytes ? (double)lib_bytes / (double)probe : 3.0 * (double)item_bytes + 1.0;
     const double fit = avail / per_item;
-    if (items_upper_bound <= fit) return {{0, MHX_NUM_BUCKETS, 0}};
-    max_items = (uint64_t)fit;
+    // Plan by TIME as well as by space (round 6).  On this driver hipMalloc costs per BYTE mapped, not per call (tools/micro/alloc_probe:
+    // 200 GB in one call 3.4 s, in 40 calls 4.4 s; between 3 and 30 ms per GB from box to box and process to process), while one more
+    // bucket-range pass costs one more scan of the reads by the histogram pre-pass and the generating pass (~6.5 ps per base: 0.1 s at
+    // 100 M reads) where the stage has that lean form (lib_bytes: the library says so).  The rate this very process has seen so far —
+    // the read store it has just allocated — decides: P passes minimise P * t_scan + bytes(P) * rate.  MHX_PLAN_BY_TIME=0 switches it off.
+    double time_cap = 0;
+    if (lib_bytes && (stage == MHX_STAGE_S1 || stage == MHX_STAGE_COUNT) && !(getenv("MHX_PLAN_BY_TIME") && atoi(getenv("MHX_PLAN_BY_TIME")) == 0)) {
+      double malloc_s = 0;
+      uint64_t abytes = 0;
+      mhx_alloc_stats(&malloc_s, nullptr, &abytes, nullptr);
+      // (seconds per byte.  The first few GB of a process come fast whatever the box — at 100 M reads the 4.6 GB of the read store
+      //  took 0.1 s, the 239 GB behind them 6.1 s — so what has been seen so far is only a lower bound: a working set of more than
+      //  64 GB is planned with at least 10 ms per GB, the middle of what the boxes of this pool show.  A resident server keeps its
+      //  buffers between requests: nothing to plan for there.)
+      double rate = abytes >= (1ull << 30) ? malloc_s / (double)abytes : 0.0;
+      if (per_item * items_upper_bound > 64e9 && !g_serving) rate = std::max(rate, 10e-12);
+      if (g_serving) rate = 0;
+      if (const char *e = getenv("MHX_ALLOC_S_PER_GB")) rate = atof(e) * 1e-9;  // tests
+      const double t_scan = 6.5e-12 * (double)mhx_num_bases(c);
+      if (rate > 0 && t_scan > 0) {
+        const double p_opt = std::sqrt(per_item * items_upper_bound * rate / t_scan);
+        const int p = (int)std::min(16.0, std::floor(p_opt + 0.5));
+        if (p >= 2) {
+          time_cap = items_upper_bound / p * 1.02;
+          info("Memory plan by time: hipMalloc ran at %.1f ms per GB so far; %d passes of ~%.1f GB each instead of one working set of %.1f GB", rate * 1e12,
+               p, per_item * items_upper_bound / p / 1e9, per_item * items_upper_bound / 1e9);
+        }
+      }
+    }
+    if (items_upper_bound <= fit && time_cap == 0) return {{0, MHX_NUM_BUCKETS, 0}};
+    max_items = (uint64_t)(time_cap > 0 ? std::min(fit, time_cap) : fit);
   }
   if (!max_items) return {{0, MHX_NUM_BUCKETS, 0}};
   std::vector<uint64_t> hist(MHX_NUM_BUCKETS);

@@ -311,7 +311,9 @@ S1Plan s1_plan(const mhx_ctx *c, uint32_t k, uint64_t n_items, bool compact, int
   if (!c->opt("s1_seg", 1) || !compact || want_mercy || s1_kw(k) != 2 || s1_stride(k, compact) != 3 || !n_items) return p;
   const double per_bucket = s1_density(c, n_items);
   p.per_bucket = per_bucket;
-  if (allow_stream && c->opt("s1_stream", 1) && !force_bits && k >= 10 && k <= 22) {
+  // (k <= 22: the local key — the (k-1)-mer below a 16-bit prefix + head/tail — fits 32 bits; up to k = 29, the widest (k-1)-mer the
+  //  12-byte record holds, the table keys are 64 bits wide: s1_stream_wide, round 6)
+  if (allow_stream && c->opt("s1_stream", 1) && !force_bits && k >= 10 && (k <= 22 || (k <= 29 && c->opt("s1_stream_wide", 1)))) {
     const double cap = (double)std::max<long long>(1, c->opt("s1_stream_max", 40000));
     const int sub_max = (int)std::min<long long>(std::max<long long>(c->opt("s1_stream_sub_max", 1), 0), 6);
     int need = 0;  // the buckets have to be 2^need times finer than the lv1 buckets
@@ -552,7 +554,7 @@ struct S1Stage {
     const uint32_t eq_mask1 = (kmer_bits > 32 ? ~(0xFFFFFFFFu >> (kmer_bits - 32)) : 0u) | 63u;
     const bool agg_on = agg && mode != 2;
     // s1_stream_half: two 512-thread workgroups with 4096-slot tables per CU instead of one with 1024 threads and 8192 slots
-    const bool half = plan.stream && c->opt("s1_stream_half", 0) != 0;
+    const bool half = plan.stream && c->opt("s1_stream_half", 0) != 0 && kmer_bits - plan.seg_bits + 6 <= 32;
     const uint64_t cus = c->n_cus > 0 ? (uint64_t)c->n_cus : 256;
     const unsigned grid = (unsigned)std::min<uint64_t>(n_work, plan.stream ? (half ? 2 * cus : cus) : (per == 4 ? 256 * 6 : 256 * 3));
     // per-workgroup output regions in the spare sort buffer (S*4 >= 12 bytes per record, outputs are 8-byte entries)
@@ -615,6 +617,7 @@ struct S1Stage {
       const S1StreamGeom geo{plan.seg_bits, plan.sub0, (uint32_t)n_buckets,
                              (uint32_t)std::min<long long>(std::max<long long>(c->opt("s1_stream_fill", nslot * 7 / 8), 1), nslot)};
       const bool tags = pos_stride != 0;
+      const bool key64 = kmer_bits - plan.seg_bits + 6 > 32;  // the local key: the (k-1)-mer below the prefix + head/tail
       // giant buckets (S1Giant): found, cut into slices and reduced on the device before the streaming launch, finished by a second
       // launch of the streaming kernel over the same grid (direct marks only: a key's first record stands for its slice)
       const bool giant_on = direct && !half && mode == 1 && c->opt("s1_giant", 1) != 0;
@@ -638,12 +641,14 @@ struct S1Stage {
         giant_ctr = lists;
         MHX_HIP(hipMemsetAsync(g.flag, 0, n_buckets, st));
         MHX_HIP(hipMemsetAsync(lists, 0, 64, st));
-        s1_giant_launch(c, items0, srcs, bounds, n_src, n_buckets, plan.seg_bits, (int)k, g);
+        s1_giant_launch(c, items0, srcs, bounds, n_src, n_buckets, plan.seg_bits, (int)k, g, key64);
       }
       S1StreamLaunch sl{agg_on, half, tags, false, false, grid, items0, bounds, a, geo, stride, ticket, srcs, n_src};
+      sl.key64 = key64;
       s1_stream_launch(c, nm, bytes, sl);
       if (giant_on) {  // the giants' partial entries -> the same per-key work, the same per-workgroup output regions
         S1StreamLaunch gl{agg_on, false, tags, true, false, grid, items0, bounds, a, geo, 1u, ticket2, nullptr, 1};
+        gl.key64 = key64;
         s1_stream_launch(c, "s1_giant_groups", 0.0, gl);
       }
       return;
@@ -915,7 +920,8 @@ static bool count_stream_shape(const mhx_ctx *c, uint32_t k, uint32_t m, S1Plan 
   if (c->filter_on && !c->opt("s1_filter_in_gen", 1)) return false;
   // (a caller that asks for a particular form of the tile path gets the tile path)
   if (!c->opt("count_seg", 1) || c->opt("count_seg_bits", 0) || !c->opt("count_extract_fixed", 1)) return false;
-  if (!s.n_seqs || k < 9 || (int)k > kCountStreamMaxK || m < 1 || m > 2) return false;
+  // (min count 1, 2: seen-once / seen-twice bits per prev / next char in the table slot; 3..15: 4-bit counters that stop at m)
+  if (!s.n_seqs || k < 9 || (int)k > kCountStreamMaxK || m < 1 || m > 15) return false;
   if (!count_shape_is_fast(c, k)) return false;  // (reads of several lengths: item slots padded to the longest read's, CountGenVarT)
   if (!c->opt("s1_fused_first_pass", 1) || !c->opt("sort_unit_runs", 1) || !c->opt("s1_gen_any_order", 1)) return false;
   const uint64_t n_bits = c->global_bases ? c->global_bases : s.n_bases;

@@ -27,12 +27,30 @@ namespace mhx {
 // left for what the host really has to handle (an output region that is too small).
 // ---------------------------------------------------------------------------------------------------------------
 
-// local key of a record inside a bucket of the pbits-bit prefix: the (k-1)-mer bits below the prefix, then head/tail
-__device__ __forceinline__ uint32_t s1_stream_local_key(uint32_t w0, uint32_t w1, int k, int pbits) {
+// local key of a record inside a bucket of the pbits-bit prefix: the (k-1)-mer bits below the prefix, then head/tail.  32 bits hold it
+// up to k = 22 at a 16-bit prefix; wider (k-1)-mers (k <= 29: the 12-byte record's two key words) take the 64-bit form (K64, round 6)
+template <bool K64>
+struct StreamKey {
+  typedef uint32_t T;
+  static constexpr T kEmpty = kStreamEmpty;  // never a key: head/tail bits 63 do not occur
+};
+template <>
+struct StreamKey<true> {
+  typedef unsigned long long T;
+  static constexpr T kEmpty = ~0ull;
+};
+template <bool K64>
+__device__ __forceinline__ typename StreamKey<K64>::T s1_stream_local_key(uint32_t w0, uint32_t w1, int k, int pbits) {
   const int rem = 2 * (k - 1) - pbits, mer_sh = 64 - 2 * (k - 1);
   const uint64_t key = ((uint64_t)w0 << 32) | w1;
-  const uint32_t lo = (uint32_t)(key >> mer_sh);
-  return (rem ? (lo & ((1u << rem) - 1u)) << 6 : 0u) | (w1 & 63u);
+  typedef typename StreamKey<K64>::T T;
+  const T lo = (T)(key >> mer_sh);
+  return (rem ? (lo & (((T)1 << rem) - 1)) << 6 : (T)0) | (T)(w1 & 63u);
+}
+template <bool K64>
+__device__ __forceinline__ uint32_t stream_hash(typename StreamKey<K64>::T lk, int logs) {
+  if constexpr (K64) return (((uint32_t)lk * 0x9E3779B1u) ^ ((uint32_t)(lk >> 32) * 0x85EBCA6Bu)) >> (32 - logs);
+  else return (lk * 0x9E3779B1u) >> (32 - logs);
 }
 // which buckets are giants: one thread per bucket; the list, the slices and the regions of partial entries are allotted here
 __global__ __launch_bounds__(256) void k_s1_giant_find(const uint64_t *__restrict__ bounds, int n_src, uint32_t n_buckets, S1Giant g) {
@@ -61,16 +79,20 @@ __global__ __launch_bounds__(256) void k_s1_giant_find(const uint64_t *__restric
   if (fits) g.flag[b] = 1;
 }
 // the slices of the giants, each reduced by one workgroup: LDS table of the slice's keys (count, first record) -> partial entries
+template <bool K64>
 __global__ __launch_bounds__(256) void k_s1_giant_reduce(const uint32_t *__restrict__ items0, const uint32_t *const *__restrict__ srcs,
                                                          const uint64_t *__restrict__ bounds, int n_src, uint32_t n_buckets, int pbits, int k, S1Giant g) {
   constexpr int NS = 4096, NT = 256, kFlushAt = NS / 2;
-  __shared__ uint32_t keys[NS], cnts[NS], fidx[NS];
+  typedef typename StreamKey<K64>::T KeyT;
+  constexpr KeyT kEmpty = StreamKey<K64>::kEmpty;
+  __shared__ KeyT keys[NS];
+  __shared__ uint32_t cnts[NS], fidx[NS];
   __shared__ uint32_t s_claims, s_out, s_start, s_stop;
   const int tid = threadIdx.x, lane = tid & (kWave - 1);
   const size_t bstride = (size_t)n_buckets + 1;
   const uint32_t n_g = min(g.ctr[0], g.gcap);
   for (int i = tid; i < NS; i += NT) {
-    keys[i] = kStreamEmpty;
+    keys[i] = kEmpty;
     cnts[i] = 0;
   }
   if (tid == 0) s_claims = 0;
@@ -107,7 +129,7 @@ __global__ __launch_bounds__(256) void k_s1_giant_reduce(const uint32_t *__restr
       auto flush = [&]() {
         __syncthreads();
         uint32_t mine = 0;
-        for (int i = tid; i < NS; i += NT) mine += keys[i] != kStreamEmpty;
+        for (int i = tid; i < NS; i += NT) mine += keys[i] != kEmpty;
         if (tid == 0) s_out = 0;
         __syncthreads();
         const uint32_t incl = wave_inclusive_sum(mine);
@@ -127,13 +149,13 @@ __global__ __launch_bounds__(256) void k_s1_giant_reduce(const uint32_t *__restr
         uint32_t at = s_start + wbase + incl - mine;
         const bool write = !s_stop;
         for (int i = tid; i < NS; i += NT) {
-          const uint32_t key = keys[i];
-          if (key != kStreamEmpty) {
+          const KeyT key = keys[i];
+          if (key != kEmpty) {
             if (write) {
               const uint32_t *r = src + (lo + fidx[i]) * 3;
               region[at++] = make_uint4(r[0], r[1], r[2], cnts[i]);
             }
-            keys[i] = kStreamEmpty;
+            keys[i] = kEmpty;
             cnts[i] = 0;
           }
         }
@@ -143,24 +165,25 @@ __global__ __launch_bounds__(256) void k_s1_giant_reduce(const uint32_t *__restr
       for (uint64_t base = lo; base < hi && !stop; base += NT) {
         const uint64_t idx = base + tid;
         const bool in = idx < hi;
-        uint32_t lk = 0;
+        KeyT lk = 0;
         if (in) {
           const uint32_t *r = src + idx * 3;
-          lk = s1_stream_local_key(r[0], r[1], k, pbits);
+          lk = s1_stream_local_key<K64>(r[0], r[1], k, pbits);
         }
         // a wavefront whose records all carry one key (poly-A): one lane inserts for all
-        const uint32_t lk0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)lk);
+        KeyT lk0 = (KeyT)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)lk);
+        if constexpr (K64) lk0 |= (KeyT)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((unsigned long long)lk >> 32)) << 32;
         const bool uniform = __ballot(in && lk == lk0) == ~0ull;
         const uint32_t mult = uniform ? (uint32_t)kWave : 1u;
         if (in && (!uniform || lane == 0)) {
-          uint32_t h = (lk * 0x9E3779B1u) >> (32 - 12);
+          uint32_t h = stream_hash<K64>(lk, 12);
           for (;;) {
-            const uint32_t old = atomicCAS(&keys[h], kStreamEmpty, lk);
-            if (old == kStreamEmpty) {
+            const KeyT old = atomicCAS(&keys[h], kEmpty, lk);
+            if (old == kEmpty) {
               fidx[h] = (uint32_t)(idx - lo);
               atomicAdd(&s_claims, 1u);
             }
-            if (old == kStreamEmpty || old == lk) {
+            if (old == kEmpty || old == lk) {
               atomicAdd(&cnts[h], mult);
               break;
             }
@@ -204,7 +227,7 @@ __global__ __launch_bounds__(256) void k_s1_giant_reduce(const uint32_t *__restr
 // bits (min count <= 2: has_in / has_out need no more), a solid key's packed edge goes to the workgroup's region (AGG's), and the
 // records of solid keys without an in- or out-edge — a few per bucket — are found by a second read of the bucket, which brings
 // first_0_out / last_0_in of their reads up to date.
-template <bool AGG, int UNR, int NT, int LOGS, bool TAGS, bool GIANT = false, bool COUNT = false>
+template <bool AGG, int UNR, int NT, int LOGS, bool TAGS, bool GIANT = false, bool COUNT = false, bool K64 = false>
 __global__ __launch_bounds__(NT) void k_s1_stream(const uint32_t *__restrict__ items0, const uint64_t *__restrict__ bounds, S1SegArgs a,
                                                   S1StreamGeom geo, uint32_t bucket_stride, uint32_t *__restrict__ ticket,
                                                   const uint32_t *const *__restrict__ srcs, int n_src) {
@@ -213,14 +236,17 @@ __global__ __launch_bounds__(NT) void k_s1_stream(const uint32_t *__restrict__ i
   constexpr int NSLOT = 1 << LOGS;
   constexpr int TRIP = NT * UNR;
   static_assert(NSLOT % NT == 0 && UNR <= 8, "table walk / pending mask");
-  __shared__ uint32_t keys[NSLOT];
+  typedef typename StreamKey<K64>::T KeyT;       // K64: local keys wider than 32 bits (k > 22 at a 16-bit prefix): 64-bit compare-and-swap
+  constexpr KeyT kEmpty = StreamKey<K64>::kEmpty;
+  static_assert(!K64 || !AGG || COUNT, "aggregated stage-2 items exist up to k = 22: their keys fit 32 bits");
+  __shared__ KeyT keys[NSLOT];
   __shared__ uint32_t cnts[NSLOT];
   __shared__ uint32_t fpos[NSLOT];             // position word of the record that claimed the slot (direct_marks)
   __shared__ uint8_t ftag[TAGS ? NSLOT : 4];   // ... and the position bits above it (s1_pos_tag), when the read set has any
   __shared__ uint32_t lhist[kSegHist];
   __shared__ uint32_t s_bad[2], s_nclaimed[2];  // per round, double-buffered: the next round's are cleared while this round's are read
   constexpr int NLIST = NSLOT / 4;              // solid keys of a round waiting for their aggregated items (more: worked off in place)
-  __shared__ uint2 slist[AGG ? NLIST : 1];
+  __shared__ uint2 slist[AGG && !COUNT ? NLIST : 1];
   __shared__ uint32_t s_list_n[2];
   __shared__ uint32_t s_agg_cur, s_mark_cur;
   __shared__ uint32_t s_flagged;  // COUNT: the round has a solid key without an in- or out-edge
@@ -235,7 +261,7 @@ __global__ __launch_bounds__(NT) void k_s1_stream(const uint32_t *__restrict__ i
   uint2 *const agg_end = AGG ? a.agg_raw + (size_t)(blockIdx.x + 1) * a.agg_cap : nullptr;
   unsigned long long *const marks_out = a.marks_raw ? a.marks_raw + (size_t)blockIdx.x * a.marks_cap : nullptr;
   for (int i = tid; i < NSLOT; i += NT) {
-    keys[i] = kStreamEmpty;
+    keys[i] = kEmpty;
     cnts[i] = 0;
     if (COUNT) fpos[i] = 0;
   }
@@ -251,6 +277,7 @@ __global__ __launch_bounds__(NT) void k_s1_stream(const uint32_t *__restrict__ i
   // GIANT: the "buckets" of this launch are the entries of the giant list, their records the partial entries of k_s1_giant_reduce
   const uint64_t n_lim = GIANT ? (uint64_t)min(a.giant.ctr[0], a.giant.gcap) : (uint64_t)geo.n_buckets;
   const uint32_t m = a.m;
+  const bool count_wide = COUNT && m > 2;  // count with min count 3..15: per-char counters instead of the seen-once / seen-twice bits
   const int k = a.k;
   const int pbits = geo.pbits;
   const size_t bstride = (size_t)geo.n_buckets + 1;
@@ -261,13 +288,26 @@ __global__ __launch_bounds__(NT) void k_s1_stream(const uint32_t *__restrict__ i
   const int lk_bits = COUNT ? rem : rem + 6;     // <= 32
   const int mer_sh = 64 - 2 * key_chars;
   const uint32_t mer_mask = rem >= 32 ? 0xFFFFFFFFu : (rem ? (1u << rem) - 1u : 0u);
+  const unsigned long long mer_mask64 = rem >= 64 ? ~0ull : (rem ? (1ull << rem) - 1ull : 0ull);
   // (the low 32 bits of (w0:w1) >> mer_sh: one funnel shift while the (k-1)-mer reaches into the second word, k >= 18)
   const bool mer_two_words = mer_sh < 32;
   const uint32_t mer_sh1 = (uint32_t)(mer_two_words ? mer_sh : mer_sh - 32);
-  auto local_key = [&](uint32_t w0, uint32_t w1) -> uint32_t {
-    const uint32_t lo = mer_two_words ? __builtin_amdgcn_alignbit(w0, w1, mer_sh1) : w0 >> mer_sh1;
-    if constexpr (COUNT) return lo & mer_mask;
-    else return (lo & mer_mask) << 6 | (w1 & 63u);
+  auto local_key = [&](uint32_t w0, uint32_t w1) -> KeyT {
+    if constexpr (K64) {
+      const unsigned long long lo = ((((unsigned long long)w0 << 32) | w1) >> mer_sh) & mer_mask64;
+      if constexpr (COUNT) return lo;
+      else return lo << 6 | (w1 & 63u);
+    } else {
+      const uint32_t lo = mer_two_words ? __builtin_amdgcn_alignbit(w0, w1, mer_sh1) : w0 >> mer_sh1;
+      if constexpr (COUNT) return lo & mer_mask;
+      else return (lo & mer_mask) << 6 | (w1 & 63u);
+    }
+  };
+  // (a value the lanes of a wavefront agree on: the first lane's)
+  auto first_lane_key = [](KeyT v) -> KeyT {
+    KeyT r = (KeyT)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+    if constexpr (K64) r |= (KeyT)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((unsigned long long)v >> 32)) << 32;
+    return r;
   };
   // the (k+1)-mer head.S.tail of a table key of bucket bi, chars MSB-first in 64 bits
   auto edge_of = [&](uint32_t bi, uint32_t lk) -> uint64_t {
@@ -314,7 +354,7 @@ __global__ __launch_bounds__(NT) void k_s1_stream(const uint32_t *__restrict__ i
       }
     }
   };
-  auto hash_of = [&](uint32_t lk) -> uint32_t { return (lk * 0x9E3779B1u) >> (32 - LOGS); };
+  auto hash_of = [&](KeyT lk) -> uint32_t { return stream_hash<K64>(lk, LOGS); };
   auto bucket_of = [&](int par) -> uint64_t { return (uint64_t)s_tk[par] * bucket_stride; };
   // (explicit global address space for everything read from memory here: a select between an LDS and a global address would
   //  become a FLAT load, and one FLAT load in flight makes every later wait for a global load a wait for ALL loads)
@@ -482,7 +522,8 @@ __global__ __launch_bounds__(NT) void k_s1_stream(const uint32_t *__restrict__ i
     }
     MHX_TT(10)
     // the bucket in rounds: round (sub, rj) takes the records whose top `sub` local-key bits are rj
-    uint32_t sub = (uint32_t)min(geo.sub0, lk_bits), rj = 0;
+    uint32_t sub = (uint32_t)min(geo.sub0, lk_bits);
+    KeyT rj = 0;  // (as wide as the local key: a round that keeps overflowing splits until every key bit is fixed)
     const uint32_t sub_first = sub;
     for (;;) {
       const uint32_t sub_sh = (uint32_t)lk_bits - sub;  // (sub == 0: no test)
@@ -495,12 +536,12 @@ __global__ __launch_bounds__(NT) void k_s1_stream(const uint32_t *__restrict__ i
         // fills up grow without bound long before an insert fails).  `seen` = the round's key count as read behind the trip before.
         if (seen > geo.max_fill) return;
         const uint32_t claims_before = claims;
-        uint32_t lk[UNR];
+        KeyT lk[UNR];
         uint32_t mine = 0;
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
           lk[u] = local_key(rw0[u], rw1[u]);
-          const bool mn = ((inm >> u) & 1u) && (sub == 0 || (lk[u] >> sub_sh) == rj);
+          const bool mn = ((inm >> u) & 1u) && (sub == 0 || (KeyT)(lk[u] >> sub_sh) == (KeyT)rj);
           mine |= mn ? 1u << u : 0u;
         }
         if (probe_limit <= 0) {
@@ -512,9 +553,10 @@ __global__ __launch_bounds__(NT) void k_s1_stream(const uint32_t *__restrict__ i
         bool one_key = mine == (1u << UNR) - 1u;
 #pragma unroll
         for (int u = 1; u < UNR; ++u) one_key = one_key && lk[u] == lk[0];
-        one_key = __ballot(one_key && lk[0] == (uint32_t)__builtin_amdgcn_readfirstlane((int)lk[0])) == ~0ull;
+        one_key = __ballot(one_key && lk[0] == first_lane_key(lk[0])) == ~0ull;
         uint32_t mult = 1;
         uint32_t wave_add1 = 0, wave_add2 = 0;  // COUNT: the seen-once / seen-twice bits of all records of a one-key trip
+        uint32_t wave_cp = 0, wave_cn = 0;      // COUNT, min count > 2: per char the trip's occurrences, capped at 255, one byte each
         if (one_key) {
           if constexpr (COUNT) {  // (the records' prev / next chars differ even where their keys agree: counted per char over the wavefront)
 #pragma unroll
@@ -527,6 +569,8 @@ __global__ __launch_bounds__(NT) void k_s1_stream(const uint32_t *__restrict__ i
               }
               wave_add1 |= (cp ? 1u << (2 * x) : 0u) | (cn ? 1u << (8 + 2 * x) : 0u);
               wave_add2 |= (cp >= 2 ? 2u << (2 * x) : 0u) | (cn >= 2 ? 2u << (8 + 2 * x) : 0u);
+              wave_cp |= min(cp, 255u) << (8 * x);
+              wave_cn |= min(cn, 255u) << (8 * x);
             }
           }
           mine = lane == 0 ? 1u : 0u;
@@ -536,13 +580,42 @@ __global__ __launch_bounds__(NT) void k_s1_stream(const uint32_t *__restrict__ i
         // a second one of the same trip (one lane in twenty) is seen to on the spot — and the pending records of all lanes are
         // retried together afterwards: the retries cost their instructions per turn, however few lanes take part.
         // (the slot found — the key's own, or a free one claimed: count it, and remember the record that claimed it)
-        auto settle = [&](uint32_t old, uint32_t key, uint32_t hh, uint32_t pos, uint32_t w1v) -> bool {
-          if (old != kStreamEmpty && old != key) return false;
+        auto settle = [&](KeyT old, KeyT key, uint32_t hh, uint32_t pos, uint32_t w1v) -> bool {
+          if (old != kEmpty && old != key) return false;
           atomicAdd(&cnts[hh], mult);
           if constexpr (COUNT) {
-            if (old == kStreamEmpty) ++claims;
-            // prev char x: bit 2x = seen once, 2x + 1 = seen twice; next char x: bits 8 + 2x, 9 + 2x ('$' counts for nothing)
+            if (old == kEmpty) ++claims;
             const unsigned pv = (w1v >> 3) & 7u, nx = w1v & 7u;
+            if (count_wide) {
+              // min count 3..15: per char a 4-bit counter that stops at m (prev char x: bits [4x, 4x + 4), next char x: [16 + 4x, 20 + 4x)),
+              // moved by compare-and-swap so that a field never runs over into its neighbour
+              uint32_t inc[2] = {0, 0};  // what this record (or, one key per wavefront: the whole trip) adds to its prev / next char
+              if (one_key) {
+                inc[0] = wave_cp;
+                inc[1] = wave_cn;
+              } else {
+                inc[0] = pv < 4 ? 1u << (8 * pv) : 0u;
+                inc[1] = nx < 4 ? 1u << (8 * nx) : 0u;
+              }
+              if (inc[0] | inc[1]) {
+                uint32_t cur = __hip_atomic_load(&fpos[hh], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                for (;;) {
+                  uint32_t nv = cur;
+#pragma unroll
+                  for (unsigned x = 0; x < 4; ++x) {
+                    const uint32_t ap = (inc[0] >> (8 * x)) & 0xFFu, an = (inc[1] >> (8 * x)) & 0xFFu;
+                    const uint32_t fp = (cur >> (4 * x)) & 15u, fn = (cur >> (16 + 4 * x)) & 15u;
+                    nv += (min(fp + ap, m) - fp) << (4 * x);
+                    nv += (min(fn + an, m) - fn) << (16 + 4 * x);
+                  }
+                  if (nv == cur) break;
+                  const uint32_t got = atomicCAS(&fpos[hh], cur, nv);
+                  if (got == cur) break;
+                  cur = got;
+                }
+              }
+            } else {
+            // prev char x: bit 2x = seen once, 2x + 1 = seen twice; next char x: bits 8 + 2x, 9 + 2x ('$' counts for nothing)
             const uint32_t add1 = one_key ? wave_add1 : ((pv < 4 ? 1u << (2 * pv) : 0u) | (nx < 4 ? 1u << (8 + 2 * nx) : 0u));
             const uint32_t add2 = one_key ? wave_add2 : 0u;
             if (add1) {
@@ -550,27 +623,30 @@ __global__ __launch_bounds__(NT) void k_s1_stream(const uint32_t *__restrict__ i
               const uint32_t again = ((o & add1) << 1) & ~(o | add2);  // a char seen before and now again: seen twice
               if (again) atomicOr(&fpos[hh], again);
             }
-          } else if (old == kStreamEmpty) {  // only read back when the count stays 1: then this record is the key's only one
+            }
+          } else if (old == kEmpty) {  // only read back when the count stays 1: then this record is the key's only one
             fpos[hh] = pos;
             if (TAGS) ftag[hh] = (uint8_t)(w1v >> 6);
             ++claims;
           }
           return true;
         };
-        auto probe = [&](uint32_t key, uint32_t hh, uint32_t pos, uint32_t w1v) -> bool {
-          return settle(atomicCAS(&keys[hh], kStreamEmpty, key), key, hh, pos, w1v);
+        auto probe = [&](KeyT key, uint32_t hh, uint32_t pos, uint32_t w1v) -> bool {
+          return settle(atomicCAS(&keys[hh], kEmpty, key), key, hh, pos, w1v);
         };
         // the UNR compare-and-swaps go out back to back: one LDS round trip per trip instead of UNR (with four wavefronts per SIMD
         // the round trips, ~250 cycles each under load, are not hidden)
-        uint32_t h1[UNR], old1[UNR];
+        uint32_t h1[UNR];
+        KeyT old1[UNR];
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
           h1[u] = hash_of(lk[u]);
-          old1[u] = kStreamEmpty;
-          if ((mine >> u) & 1u) old1[u] = atomicCAS(&keys[h1[u]], kStreamEmpty, lk[u]);
+          old1[u] = kEmpty;
+          if ((mine >> u) & 1u) old1[u] = atomicCAS(&keys[h1[u]], kEmpty, lk[u]);
         }
         bool has = false;
-        uint32_t pk = 0, ph = 0, pw = 0, pt = 0;
+        KeyT pk = 0;
+        uint32_t ph = 0, pw = 0, pt = 0;
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
           if ((mine >> u) & 1u) {
@@ -622,18 +698,18 @@ __global__ __launch_bounds__(NT) void k_s1_stream(const uint32_t *__restrict__ i
         uint32_t my_claims = 0;
         for (uint64_t e = lo + tid; e < hi; e += NT) {
           const uint4 en = part[e];
-          const uint32_t lk = local_key(en.x, en.y);
-          if (sub != 0 && (lk >> sub_sh) != rj) continue;
+          const KeyT lk = local_key(en.x, en.y);
+          if (sub != 0 && (KeyT)(lk >> sub_sh) != (KeyT)rj) continue;
           if (probe_limit <= 0) {
             s_bad[rp] = 1;
             continue;
           }
           uint32_t hh = hash_of(lk);
           for (int n = 0;; ++n) {
-            const uint32_t old = atomicCAS(&keys[hh], kStreamEmpty, lk);
-            if (old == kStreamEmpty || old == lk) {
+            const KeyT old = atomicCAS(&keys[hh], kEmpty, lk);
+            if (old == kEmpty || old == lk) {
               atomicAdd(&cnts[hh], en.w);
-              if (old == kStreamEmpty) {
+              if (old == kEmpty) {
                 fpos[hh] = en.z;
                 if (TAGS) ftag[hh] = (uint8_t)(en.y >> 6);
                 ++my_claims;
@@ -694,7 +770,8 @@ __global__ __launch_bounds__(NT) void k_s1_stream(const uint32_t *__restrict__ i
         s_list_n[rp ^ 1] = 0;  // (read behind barrier B of the round before this one, by threads that have all passed barrier A since)
       }
       // what comes next (uniform: `bad` came out of shared memory behind a barrier)
-      uint32_t nsub = sub, nrj = rj;
+      uint32_t nsub = sub;
+      KeyT nrj = rj;
       bool bucket_done = false, give_up = false;
       if (bad) {
         if ((int)sub >= lk_bits) {  // one key per round and still no room: only a probe limit of 0 (tests) gets here
@@ -710,7 +787,7 @@ __global__ __launch_bounds__(NT) void k_s1_stream(const uint32_t *__restrict__ i
           --nsub;
           nrj >>= 1;
         }
-        bucket_done = nsub == sub_first && nrj == (1u << sub_first);
+        bucket_done = nsub == sub_first && nrj == ((KeyT)1 << sub_first);
       }
       if (give_up && tid == 0) atomicOr(a.err, 1u);
       // ... and its first trip, requested before the per-key work of this round
@@ -737,8 +814,8 @@ __global__ __launch_bounds__(NT) void k_s1_stream(const uint32_t *__restrict__ i
                 const uint32_t w0 = p[0];
                 w1 = p[1];
                 w2 = p[2];
-                const uint32_t lk = local_key(w0, w1);
-                in = sub == 0 || (lk >> sub_sh) == rj;  // (a key of another round is not in the table)
+                const KeyT lk = local_key(w0, w1);
+                in = sub == 0 || (KeyT)(lk >> sub_sh) == (KeyT)rj;  // (a key of another round is not in the table)
                 if (in) {
                   uint32_t h = hash_of(lk);
                   while (keys[h] != lk) h = (h + 1) & (NSLOT - 1);
@@ -784,7 +861,8 @@ __global__ __launch_bounds__(NT) void k_s1_stream(const uint32_t *__restrict__ i
         // leaves two flag bits in its slot for the second read below
         constexpr int W = NSLOT / NT;
         if (tid == 0) s_flagged = 0;
-        uint32_t wk[W], wc[W], wf[W];
+        KeyT wk[W];
+        uint32_t wc[W], wf[W];
 #pragma unroll
         for (int it = 0; it < W; ++it) {
           const int sl = it * NT + tid;
@@ -793,21 +871,33 @@ __global__ __launch_bounds__(NT) void k_s1_stream(const uint32_t *__restrict__ i
           wf[it] = fpos[sl];
         }
         __syncthreads();  // (s_flagged cleared before anybody sets it)
-        const uint32_t lvl = m >= 2 ? 0xAAu : 0x55u;  // which bit of a char's pair says "at least m"
+        const uint32_t lvl = m >= 2 ? 0xAAu : 0x55u;  // which bit of a char's pair says "at least m" (min count <= 2)
         uint32_t solid_bits = 0, n_dist = 0;
         bool any_flag = false;
 #pragma unroll
         for (int it = 0; it < W; ++it) {
-          const uint32_t lk = wk[it], cnt = wc[it];
+          const KeyT lk = wk[it];
+          const uint32_t cnt = wc[it];
           uint32_t fb = 0;
-          if (lk != kStreamEmpty && !bad) {
+          if (lk != kEmpty && !bad) {
             ++n_dist;
             const uint32_t hb = cnt > MHX_MAX_MUL ? (uint32_t)MHX_MAX_MUL : cnt;
             if (hb < kSegHist) atomicAdd(&lhist[hb], 1u);
             else atomicAdd(&a.hist[hb], 1ull);
             if (cnt >= m) {
               solid_bits |= 1u << it;
-              const bool has_in = (wf[it] & lvl) != 0, has_out = ((wf[it] >> 8) & lvl) != 0;
+              bool has_in, has_out;
+              if (count_wide) {  // some char's counter reached m
+                has_in = has_out = false;
+#pragma unroll
+                for (unsigned x = 0; x < 4; ++x) {
+                  has_in = has_in || ((wf[it] >> (4 * x)) & 15u) >= m;
+                  has_out = has_out || ((wf[it] >> (16 + 4 * x)) & 15u) >= m;
+                }
+              } else {
+                has_in = (wf[it] & lvl) != 0;
+                has_out = ((wf[it] >> 8) & lvl) != 0;
+              }
               fb = (has_in ? 0u : 1u) | (has_out ? 0u : 2u);
               any_flag = any_flag || fb != 0;
             }
@@ -852,8 +942,8 @@ __global__ __launch_bounds__(NT) void k_s1_stream(const uint32_t *__restrict__ i
                 const uint32_t w0 = p[0];
                 w1 = p[1];
                 w2 = p[2];
-                const uint32_t lk = local_key(w0, w1);
-                if (sub == 0 || (lk >> sub_sh) == rj) {  // (a key of another round is not in the table)
+                const KeyT lk = local_key(w0, w1);
+                if (sub == 0 || (KeyT)(lk >> sub_sh) == (KeyT)rj) {  // (a key of another round is not in the table)
                   uint32_t h = hash_of(lk);
                   while (keys[h] != lk) h = (h + 1) & (NSLOT - 1);
                   f = fpos[h] >> 30;
@@ -900,13 +990,14 @@ __global__ __launch_bounds__(NT) void k_s1_stream(const uint32_t *__restrict__ i
 #pragma unroll
         for (int it = 0; it < W; ++it) {
           const int sl = it * NT + tid;
-          keys[sl] = kStreamEmpty;
+          keys[sl] = kEmpty;
           cnts[sl] = 0;
           fpos[sl] = 0;
         }
       } else {
         constexpr int W = NSLOT / NT;
-        uint32_t wk[W], wc[W], wp[W];
+        KeyT wk[W];
+        uint32_t wc[W], wp[W];
 #pragma unroll
         for (int it = 0; it < W; ++it) {
           const int sl = it * NT + tid;
@@ -917,14 +1008,15 @@ __global__ __launch_bounds__(NT) void k_s1_stream(const uint32_t *__restrict__ i
 #pragma unroll
         for (int it = 0; it < W; ++it) {
           const int sl = it * NT + tid;
-          keys[sl] = kStreamEmpty;
+          keys[sl] = kEmpty;
           cnts[sl] = 0;
         }
         uint32_t want_bits = 0, mark_bits = 0;
 #pragma unroll
         for (int it = 0; it < W; ++it) {
-          const uint32_t lk = wk[it], cnt = wc[it];
-          if (lk != kStreamEmpty && !bad && (lk & 0x24u) == 0) {
+          const KeyT lk = wk[it];
+          const uint32_t cnt = wc[it];
+          if (lk != kEmpty && !bad && (lk & 0x24u) == 0) {
             const bool solid = cnt >= m;
             if (a.mark_mode == 2) {
               st_both += cnt;
@@ -974,8 +1066,8 @@ __global__ __launch_bounds__(NT) void k_s1_stream(const uint32_t *__restrict__ i
 #pragma unroll
             for (int it = 0; it < W; ++it)
               if ((want_bits >> it) & 1u) {
-                if (at < (uint32_t)NLIST) slist[at] = make_uint2(wk[it], wc[it]);
-                else emit_items(bi, wk[it], wc[it], false);  // (more solid keys in one round than the list holds: in place)
+                if (at < (uint32_t)NLIST) slist[at] = make_uint2((uint32_t)wk[it], wc[it]);
+                else emit_items(bi, (uint32_t)wk[it], wc[it], false);  // (more solid keys in one round than the list holds: in place)
                 ++at;
               }
           }
@@ -1023,26 +1115,37 @@ __global__ __launch_bounds__(NT) void k_s1_stream(const uint32_t *__restrict__ i
 
 // ---- launchers (the only way into this unit's kernels) ----
 void s1_giant_launch(mhx_ctx *c, const uint32_t *items0, const uint32_t *const *srcs, const uint64_t *bounds, int n_src, uint64_t n_buckets, int pbits, int k,
-                     const S1Giant &g) {
+                     const S1Giant &g, bool key64) {
   hipStream_t st = c->stream;
   const uint64_t cus = c->n_cus > 0 ? (uint64_t)c->n_cus : 256;
   MHX_LAUNCH(c, "s1_giant_find", (double)n_src * n_buckets * 8,
              hipLaunchKernelGGL(k_s1_giant_find, dim3((unsigned)div_ceil(n_buckets, 256)), dim3(256), 0, st, bounds, n_src, (uint32_t)n_buckets, g));
-  MHX_LAUNCH(c, "s1_giant_reduce", 0.0,
-             hipLaunchKernelGGL(k_s1_giant_reduce, dim3((unsigned)(3 * cus)), dim3(256), 0, st, items0, srcs, bounds, n_src, (uint32_t)n_buckets, pbits, k, g));
+  if (key64)
+    MHX_LAUNCH(c, "s1_giant_reduce", 0.0,
+               hipLaunchKernelGGL(k_s1_giant_reduce<true>, dim3((unsigned)(3 * cus)), dim3(256), 0, st, items0, srcs, bounds, n_src, (uint32_t)n_buckets, pbits, k, g));
+  else
+    MHX_LAUNCH(c, "s1_giant_reduce", 0.0,
+               hipLaunchKernelGGL(k_s1_giant_reduce<false>, dim3((unsigned)(3 * cus)), dim3(256), 0, st, items0, srcs, bounds, n_src, (uint32_t)n_buckets, pbits, k, g));
 }
 
 void s1_stream_launch(mhx_ctx *c, const char *name, double bytes, const S1StreamLaunch &l) {
   hipStream_t st = c->stream;
-#define MHX_STREAM(AGGV, NTV, LOGV, TAGV, GIANTV, COUNTV)                                                                                        \
-  MHX_LAUNCH(c, name, bytes, hipLaunchKernelGGL((k_s1_stream<AGGV, 4, NTV, LOGV, TAGV, GIANTV, COUNTV>), dim3(l.grid), dim3(NTV), 0, st, l.items0, \
+#define MHX_STREAM_K(AGGV, NTV, LOGV, TAGV, GIANTV, COUNTV, K64V)                                                                                     \
+  MHX_LAUNCH(c, name, bytes, hipLaunchKernelGGL((k_s1_stream<AGGV, 4, NTV, LOGV, TAGV, GIANTV, COUNTV, K64V>), dim3(l.grid), dim3(NTV), 0, st, l.items0, \
                                                 l.bounds, l.a, l.geo, l.stride, l.ticket, l.srcs, l.n_src))
+#define MHX_STREAM(AGGV, NTV, LOGV, TAGV, GIANTV, COUNTV) MHX_STREAM_K(AGGV, NTV, LOGV, TAGV, GIANTV, COUNTV, false)
 #define MHX_STREAM_T(AGGV, NTV, LOGV, GIANTV, COUNTV)             \
   do {                                                            \
     if (l.tags) MHX_STREAM(AGGV, NTV, LOGV, true, GIANTV, COUNTV); \
     else MHX_STREAM(AGGV, NTV, LOGV, false, GIANTV, COUNTV);       \
   } while (0)
-  if (l.count) {
+  if (l.key64) {  // local keys of more than 32 bits (stage 1 at k = 23..29: no aggregated items there)
+    if (l.count || l.agg || l.half) throw Error("s1_stream_launch: 64-bit local keys serve stage 1 without aggregated items on full tables");
+    if (l.giant && l.tags) MHX_STREAM_K(false, kStreamThreads, 13, true, true, false, true);
+    else if (l.giant) MHX_STREAM_K(false, kStreamThreads, 13, false, true, false, true);
+    else if (l.tags) MHX_STREAM_K(false, kStreamThreads, 13, true, false, false, true);
+    else MHX_STREAM_K(false, kStreamThreads, 13, false, false, false, true);
+  } else if (l.count) {
     if (!l.agg || l.half || l.giant) throw Error("s1_stream_launch: count runs on full tables with edge regions, without the giant path");
     MHX_STREAM_T(true, kStreamThreads, 13, false, true);
   } else if (l.giant) {
@@ -1058,6 +1161,7 @@ void s1_stream_launch(mhx_ctx *c, const char *name, double bytes, const S1Stream
   }
 #undef MHX_STREAM_T
 #undef MHX_STREAM
+#undef MHX_STREAM_K
 }
 
 #ifdef MHX_TILE_TIMING

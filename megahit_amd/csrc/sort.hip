@@ -311,12 +311,20 @@ static uint32_t *radix_sort_onesweep(mhx_ctx *c, uint32_t *a, uint32_t *b, uint6
   auto units_of = [&](uint64_t items) { return xcd_units ? (div_ceil(items, unit) + 127) / 128 * 128 : div_ceil(items, unit); };
   const uint64_t n_units = units_of(n), n_units_gen = units_of(gen_slots);
   hipStream_t st = c->stream;
-  unsigned long long *status = c->ws("sort_status", n_units_gen * 256 * 8).as<unsigned long long>();
+  // sort_loaded_ut2 (12-byte records): the passes that LOAD their records take units of two tiles instead of three — 100 registers
+  // instead of 140, four workgroups per CU instead of three (the SQ counters of round 6 show the waves of these passes parked at
+  // waits and barriers for two thirds of their cycles: latency, not issue) — at the price of shorter unit-wide runs
+  constexpr bool kCanUt2 = S == 3 && NI == 8 && UT == 3;
+  const bool loaded_ut2 = kCanUt2 && c->opt("sort_loaded_ut2", 0) != 0;
+  const uint64_t unit2 = (uint64_t)kSortThreads * NI * 2;
+  const uint64_t n_units2 = xcd_units ? (div_ceil(n, unit2) + 127) / 128 * 128 : div_ceil(n, unit2);
+  const uint64_t n_status = std::max(n_units_gen, loaded_ut2 ? n_units2 : 0);
+  unsigned long long *status = c->ws("sort_status", n_status * 256 * 8).as<unsigned long long>();
   unsigned long long *gh = c->ws("sort_ghist", (size_t)2 * kMaxChainedPasses * 256 * 8).as<unsigned long long>();
   unsigned long long *starts = gh + kMaxChainedPasses * 256;
   constexpr int kErrSlot = kMaxChainedPasses * 8;
   uint32_t *tickets = c->ws("sort_tickets", (kErrSlot + 8) * 4).as<uint32_t>();  // 8 ticket counters per pass, then the error flag
-  MHX_HIP(hipMemsetAsync(status, 0, n_units_gen * 256 * 8, st));
+  MHX_HIP(hipMemsetAsync(status, 0, n_status * 256 * 8, st));
   MHX_HIP(hipMemsetAsync(gh, 0, (size_t)kMaxChainedPasses * 256 * 8, st));
   MHX_HIP(hipMemsetAsync(tickets, 0, (kErrSlot + 8) * 4, st));
   const double bytes = (double)n * S * 4;
@@ -359,6 +367,20 @@ static uint32_t *radix_sort_onesweep(mhx_ctx *c, uint32_t *a, uint32_t *b, uint6
 #define MHX_U(RANKV, WIV)                                                                                                                      \
   hipLaunchKernelGGL((k_radix_onesweep_u<S, NI, UT, SrcArray<S>, RANKV, WIV>), dim3((unsigned)n_units), dim3(kSortThreads), 0, st, SrcArray<S>{a}, b, \
                      n, all[p], nb, starts + p * 256, status, tickets + p * 8, tickets + kErrSlot, (unsigned long long)(p + 1), xcd_units)
+#define MHX_U2(RANKV, WIV)                                                                                                                     \
+  hipLaunchKernelGGL((k_radix_onesweep_u<S, NI, 2, SrcArray<S>, RANKV, WIV>), dim3((unsigned)n_units2), dim3(kSortThreads), 0, st, SrcArray<S>{a}, b, \
+                     n, all[p], nb, starts + p * 256, status, tickets + p * 8, tickets + kErrSlot, (unsigned long long)(p + 1), xcd_units)
+        if constexpr (kCanUt2) {
+          if (loaded_ut2 && wi == 0) {
+            MHX_LAUNCH(c, nm_scat.c_str(), 2 * bytes, {
+              if (rank_uniform && all[p].prev_mask) MHX_U2(2, 0);
+              else MHX_U2(0, 0);
+            });
+            std::swap(a, b);
+            continue;
+          }
+        }
+#undef MHX_U2
         MHX_LAUNCH(c, nm_scat.c_str(), 2 * bytes, {
           if (wi == 0 && rank_uniform && all[p].prev_mask) MHX_U(2, 0);
           else if (wi == 0) MHX_U(0, 0);

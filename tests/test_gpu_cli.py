@@ -76,7 +76,9 @@ def test_cli_automatic_memory_plan(ent, tmp_path, monkeypatch):
     import subprocess
     with open(os.path.join(gu.GOLD, ent["case"]["lib"] + ".lib_info")) as f:
         total_bases = int(f.read().split()[0])
-    monkeypatch.setenv("MHX_FREE_BYTES", str(25 * total_bases))  # room for ~0.7 12-byte items per base (two sort buffers): two or three passes
+    # room for ~0.7 (read2sdbg) / ~0.45 (count: 0.79 items per base on these libraries) 12-byte items per base in two sort buffers: two or three
+    # passes.  (Round 6: count runs on the 12-byte records of the stage-1 design also in passes — 24.5 bytes per kept item instead of 49.)
+    monkeypatch.setenv("MHX_FREE_BYTES", str((14 if ent["case"]["prog"] == "count" else 25) * total_bases))
     got = gu.run_case(gu.MHX_CORE, ent, str(tmp_path))
     for key, want in ent.items():
         if key in ("case", "mercy_cand_kmsort"):
@@ -98,3 +100,25 @@ def test_cli_retries_with_the_classic_sort_after_a_scan_timeout(ent, tmp_path, m
         if key in ("case", "mercy_cand_kmsort"):
             continue
         assert got.get(key) == want, key
+
+
+@pytest.mark.parametrize("prog", ["count", "read2sdbg"])
+def test_memory_plan_by_time(prog, tmp_path):
+    """round 6: where hipMalloc is slow (it costs per byte mapped on this driver) the memory plan takes several bucket-range passes of a
+    small working set instead of one large one — forced here with MHX_ALLOC_S_PER_GB; the outputs stay the reference's
+    (base_engine.cpp:54-141 plans its lv1 passes by space only)"""
+    import subprocess
+    ent = [e for e in gu.cases() if e["case"]["prog"] == prog and e["case"]["k"] == 21 and not e["case"].get("mercy")][0]
+    c = ent["case"]
+    out = str(tmp_path / "out")
+    env = dict(os.environ, MHX_ALLOC_S_PER_GB="1e6")
+    p = subprocess.run([gu.MHX_CORE, prog, "-k", str(c["k"]), "-m", str(c["m"]), "--read_lib_file", os.path.join(gu.GOLD, c["lib"]), "--output_prefix", out,
+                        "--host_mem", "2e9", "--num_cpu_threads", "3"], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, env=env, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    if "Memory plan by time" in p.stderr:  # (the lean form of the stage applies to this library: the plan fired)
+        assert "Memory plan:" in p.stderr and "passes over lv1 bucket ranges" in p.stderr, p.stderr[-1500:]
+    from megahit_amd import canon
+    if prog == "count":
+        assert canon.digest_edges(out) == ent["edges"] and canon.digest_file(out + ".cand") == ent["cand"] and canon.digest_file(out + ".counting") == ent["counting"]
+    else:
+        assert canon.digest_sdbg(out) == ent["sdbg"]

@@ -193,7 +193,8 @@ def load_fixed_reads(r, e):
     (3, 21, 2, True, {"dist_max_items": 30000}, True),                   # bucket-range passes: the filter inside every rank's generating pass
     (3, 21, 2, True, {"s1_stream_bits": 19, "s1_stream_fill": 40}, True),  # three pre-sort passes, overflowing tables, three senders per bucket
     (2, 21, 2, True, {"s1_stream_probes": 0}, False),                    # the owners' streaming gives up -> the classic exchange redoes the pass
-    (2, 21, 2, True, {"dist_presort": 0}, False), (2, 23, 2, True, None, False), (2, 21, 3, True, None, False),
+    (2, 21, 2, True, {"dist_presort": 0}, False), (2, 23, 2, True, None, False), (2, 21, 16, True, None, False),
+    (3, 21, 3, True, None, True), (2, 22, 4, True, {"s1_stream_fill": 40}, True),   # min count 3..15: per-char counters at the owners
 ])
 def test_count_on_the_presorted_exchange(world, k, m, fixed, opts, presorted):
     """round 6: `count` on several ranks on the stage-1 design — every rank's first sort pass makes its 12-byte records, the slices of the

@@ -60,7 +60,7 @@ def check(got, want):
 
 @pytest.mark.parametrize("opts", [dict(), dict(s1_stream_fill=40), dict(s1_pos_bits=12), dict(s1_stream_bits=19), dict(s1_stream_sub0=2)],
                          ids=lambda o: ",".join("%s=%d" % kv for kv in o.items()) or "default")
-@pytest.mark.parametrize("kind,k,m,n_passes", [("pe100", 21, 2, 3), ("repeats100", 21, 2, 4), ("short30", 21, 2, 2), ("pe100", 17, 1, 3), ("repeats100", 22, 2, 5)])
+@pytest.mark.parametrize("kind,k,m,n_passes", [("pe100", 21, 2, 3), ("repeats100", 21, 2, 4), ("short30", 21, 2, 2), ("pe100", 17, 1, 3), ("repeats100", 22, 2, 5), ("repeats100", 21, 3, 3)])
 def test_count_passes_on_the_streaming_design(engine, kind, k, m, n_passes, opts):
     pkg = ob.Package(fixed_library(kind, seed=k * 5 + m), reverse=True)
     want = ob.count(pkg, k, m)

@@ -45,7 +45,9 @@ def check_count(engine, pkg, k, m, opts, expect_stream):
 @pytest.mark.parametrize("opts", [dict(), dict(count_stream=0), dict(s1_stream_fill=40), dict(s1_pos_bits=12), dict(s1_stream_bits=19), dict(s1_stream_sub0=2),
                                   dict(s1_stream_probes=0)], ids=lambda o: ",".join("%s=%d" % kv for kv in o.items()) or "default")
 @pytest.mark.parametrize("kind,k,m", [("pe100", 21, 2), ("repeats100", 21, 2), ("tiny60", 21, 2), ("short30", 21, 2), ("pe100", 17, 1), ("repeats100", 22, 2),
-                                      ("pe100", 13, 2), ("repeats100", 21, 1)])
+                                      ("pe100", 13, 2), ("repeats100", 21, 1),
+                                      # round 6: min count 3..15 — per-char 4-bit counters that stop at m instead of the seen-once / seen-twice bits
+                                      ("pe100", 21, 3), ("repeats100", 21, 3), ("repeats100", 22, 5), ("pe100", 19, 15), ("short30", 21, 4)])
 def test_count_on_the_bucket_streaming(engine, kind, k, m, opts):
     reads = fixed_library(kind, seed=k * 7 + m)
     pkg = ob.Package(reads, reverse=True)
@@ -54,7 +56,7 @@ def test_count_on_the_bucket_streaming(engine, kind, k, m, opts):
     check_count(engine, pkg, k, m, opts, expect_stream)
 
 
-@pytest.mark.parametrize("k,m", [(23, 2), (21, 3)])
+@pytest.mark.parametrize("k,m", [(23, 2), (21, 16)])
 def test_shapes_the_stream_form_does_not_take(engine, k, m):
     reads = fixed_library("pe100", seed=3)
     check_count(engine, ob.Package(reads, reverse=True), k, m, {}, False)
