@@ -75,6 +75,7 @@ __device__ __forceinline__ bool key_differs(const uint32_t *a, const uint32_t *b
 //   void unit_emit(const TileCtx<S>&, uint32_t u, uint64_t o0, uint64_t o1, uint64_t o2)
 //   void item_final(const TileCtx<S>&, uint32_t rel, uint32_t run)   (if kItemFinal; after the group phase)
 constexpr int kLookAhead = 64;  // records staged beyond the tile so that short tails never touch HBM again
+constexpr int kTailWalk = 1024;  // a tail longer than this is searched (64-ary, the records are sorted), not walked
 
 // Debug build only (make timing -> libmhx_timing.so, tools/probe_phases.py): shader-clock ticks per phase of the
 // tile kernel, summed over workgroups.
@@ -231,11 +232,53 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_groups(const uint32_t *__
   __syncthreads();
   MHX_TT(2)
   // 3. tail of the last group, beyond the tile: wavefront 0, 64 records per step; the first step reads the
-  //    look-ahead records already in LDS
+  //    look-ahead records already in LDS.  A tail that is still going after kTailWalk records (low-complexity input: 10^7 records of
+  //    one key in a row) is not walked any further — 64 records per memory round trip took seconds per group — but SEARCHED: the
+  //    records are sorted, so "same group as the head" and "same run as record q" each hold on a stretch whose end a 64-ary search
+  //    finds in four round trips (round 6)
   if (n_groups > 0 && base + t_n < n && tid < kWave) {
     const uint32_t *gkey = tile + (size_t)(rpos[gpos[n_groups - 1]] & 0x7FFFFFFFu) * S;
     uint32_t nr = n_runs_tile, e = (uint32_t)t_n;
+    // first position in [lo, hi) where pred turns true (pred: false ... false true ... true); hi if it never does
+    auto wave_first = [&](uint64_t lo, uint64_t hi, auto pred) -> uint64_t {
+      while (lo < hi) {
+        const uint64_t span = hi - lo, step = (span + kWave - 1) / kWave;
+        const uint64_t p = lo + (uint64_t)lane * step;
+        const uint64_t m = __ballot(p < hi && pred(p));
+        if (!m) {  // every probe false: the answer lies behind the last one
+          if (step == 1) return hi;  // (every position probed: the narrowed hi — where pred holds — or the end of the range)
+          lo += (span - 1) / step * step + 1;
+          continue;
+        }
+        const int f = __builtin_ctzll(m);
+        if (f == 0) return lo;
+        hi = lo + (uint64_t)f * step;            // pred(hi) is true ...
+        lo = hi - step + 1;                      // ... pred(lo - 1) is false
+      }
+      return hi;
+    };
     for (;;) {
+      if (e - (uint32_t)t_n >= (uint32_t)kTailWalk) {
+        // the group's end, then the run heads between here and there, one search each
+        const uint64_t g_end = wave_first(base + e, n, [&](uint64_t p) { return key_differs<S>(items + p * S, gkey, full_words, last_mask); });
+        uint64_t q = base + e;  // the first record the walk has not looked at (record q - 1 belongs to the group)
+        auto head_at = [&](uint64_t p) {
+          if (lane == 0 && nr < (uint32_t)(T + kMaxTailRuns)) {
+            rpos[nr] = (uint32_t)(p - base);
+            rgid[nr] = (uint16_t)(n_groups - 1);
+          }
+          ++nr;
+        };
+        if (q < g_end && !op.same_run(items + q * S, items + (q - 1) * S)) head_at(q);
+        while (q < g_end) {
+          const uint32_t *rq = items + q * S;
+          const uint64_t r_end = wave_first(q + 1, g_end, [&](uint64_t p) { return !op.same_run(items + p * S, rq); });
+          if (r_end < g_end) head_at(r_end);
+          q = r_end;
+        }
+        e = (uint32_t)(g_end - base);
+        break;
+      }
       const uint32_t rel = e + lane;
       const uint64_t p = base + rel;
       bool in_group = false, rh = false;
@@ -297,8 +340,8 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_groups(const uint32_t *__
         const uint32_t i = (uint32_t)(j * kTileThreads + tid);
         if (i < (uint32_t)t_n && i >= first_head) op.item_phase(ctx, i, (uint32_t)own_run(j));
       }
-      if (tid < kWave)
-        for (uint32_t rel = (uint32_t)t_n + tid; rel < tail_end; rel += kWave) op.item_phase(ctx, rel, tail_run(rel));
+      // (the tail: the whole workgroup — one wavefront with one load in flight per lane took seconds for a tail of 10^7 records)
+      for (uint32_t rel = (uint32_t)t_n + tid; rel < tail_end; rel += kTileThreads) op.item_phase(ctx, rel, tail_run(rel));
     }
     __syncthreads();
   }
@@ -385,8 +428,7 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_groups(const uint32_t *__
         const uint32_t i = (uint32_t)(j * kTileThreads + tid);
         if (i < (uint32_t)t_n && i >= first_head) op.item_final(ctx, i, (uint32_t)own_run(j));
       }
-      if (tid < kWave)
-        for (uint32_t rel = (uint32_t)t_n + tid; rel < tail_end; rel += kWave) op.item_final(ctx, rel, tail_run(rel));
+      for (uint32_t rel = (uint32_t)t_n + tid; rel < tail_end; rel += kTileThreads) op.item_final(ctx, rel, tail_run(rel));
     }
   }
   __syncthreads();
