@@ -1058,8 +1058,41 @@ bool count_stream_groups(mhx_ctx *c, uint32_t k, uint32_t m, uint32_t *first_0_o
   const S1StreamGeom geo{plan.seg_bits, plan.sub0, (uint32_t)n_buckets,
                          (uint32_t)std::min<long long>(std::max<long long>(c->opt("s1_stream_fill", 8192 * 7 / 8), 1), 8192)};
   const double bytes = (double)n_items * 12 * (double)(1u << plan.sub0);
-  S1StreamLaunch sl{true, false, pos_stride != 0, false, true, grid, pre ? pre->ptr[0] : sorted, bounds, a, geo, 1u, ticket, srcs, n_src};
+  const uint32_t *items0 = pre ? pre->ptr[0] : sorted;
+  // giant buckets (round 6; S1Giant as in stage 1): a bucket of >= s1_giant_min records — 5 % poly-G reads put 6.6 x 10^7 records of
+  // one key into one — is cut into slices that many workgroups reduce into partial entries (a key's count and per-char counters in
+  // the slice); the streaming launch skips it, a second launch over the same grid inserts the partial entries and does the per-key
+  // work; a solid key without an in- or out-edge in such a bucket sends that launch's workgroup over the bucket's records once
+  const bool giant_on = c->opt("s1_giant", 1) != 0 && c->opt("count_giant", 1) != 0;
+  uint32_t *ticket2 = nullptr;
+  const uint32_t *giant_ctr = nullptr;
+  if (giant_on) {
+    S1Giant &g = a.giant;
+    g.gcap = 4096;
+    g.min_records = (uint32_t)std::max<long long>(1, c->opt("s1_giant_min", 262144));
+    g.pcap = std::max<uint64_t>(2u << 20, n_items / 64);
+    g.flag = c->ws("s1_giant_flag", n_buckets + 64).as<uint8_t>();
+    uint32_t *lists = c->ws("s1_giant_lists", 64 + (size_t)g.gcap * (5 * 4 + 8)).as<uint32_t>();
+    g.ctr = lists;
+    ticket2 = lists + 8;
+    g.off = reinterpret_cast<unsigned long long *>(lists + 16);
+    g.bucket = lists + 16 + 2 * g.gcap;
+    g.sl = g.bucket + g.gcap;
+    g.ns = g.sl + g.gcap;
+    g.cap = g.ns + g.gcap;
+    g.cur = g.cap + g.gcap;
+    g.partial = c->ws("s1_giant_partial", g.pcap * 16 + 64).as<uint4>();
+    giant_ctr = lists;
+    MHX_HIP(hipMemsetAsync(g.flag, 0, n_buckets, st));
+    MHX_HIP(hipMemsetAsync(lists, 0, 64, st));
+    s1_giant_launch(c, items0, srcs, bounds, n_src, n_buckets, plan.seg_bits, (int)k, g, false, true);
+  }
+  S1StreamLaunch sl{true, false, pos_stride != 0, false, true, grid, items0, bounds, a, geo, 1u, ticket, srcs, n_src};
   s1_stream_launch(c, "count_groups", bytes, sl);
+  if (giant_on) {
+    S1StreamLaunch gl{true, false, pos_stride != 0, true, true, grid, items0, bounds, a, geo, 1u, ticket2, srcs, n_src};
+    s1_stream_launch(c, "count_giant_groups", 0.0, gl);
+  }
   uint32_t e = 0;
   unsigned long long h_ctr[8] = {0};
   std::vector<uint32_t> h_ec(global ? grid : 0);
@@ -1075,6 +1108,11 @@ bool count_stream_groups(mhx_ctx *c, uint32_t k, uint32_t m, uint32_t *first_0_o
   o->n_items = n_items;
   o->n_distinct = h_ctr[4];
   o->plan = s1_plan_text(c, k, std::max<uint64_t>(count_plan_items(c, k), 1));
+  if (giant_ctr) {
+    uint32_t h_giant[4] = {0, 0, 0, 0};
+    MHX_HIP(hipMemcpy(h_giant, giant_ctr, 16, hipMemcpyDeviceToHost));
+    if (h_giant[0]) o->plan += " [" + std::to_string(h_giant[0]) + " giant buckets in slices]";
+  }
   o->events = nullptr;
   o->n_events = 0;
   if (e == 0 && global) {  // the workgroups' event regions -> one list

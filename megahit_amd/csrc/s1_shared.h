@@ -143,7 +143,7 @@ struct S1StreamLaunch {  // one launch of k_s1_stream (s1_stream.hip)
 };
 void s1_stream_launch(mhx_ctx *c, const char *name, double bytes, const S1StreamLaunch &l);
 void s1_giant_launch(mhx_ctx *c, const uint32_t *items0, const uint32_t *const *srcs, const uint64_t *bounds, int n_src, uint64_t n_buckets, int pbits, int k,
-                     const S1Giant &g, bool key64 = false);
+                     const S1Giant &g, bool key64 = false, bool count = false);
 // k_s1_seg (s1_tile.hip): per = 4 | 8 records per thread
 void s1_seg_launch(mhx_ctx *c, const char *name, double bytes, int per, bool agg, unsigned grid, const uint32_t *sorted, uint64_t n_items, const S1SegArgs &a,
                    uint64_t n_work, uint32_t stride);

@@ -79,7 +79,10 @@ __global__ __launch_bounds__(256) void k_s1_giant_find(const uint64_t *__restric
   if (fits) g.flag[b] = 1;
 }
 // the slices of the giants, each reduced by one workgroup: LDS table of the slice's keys (count, first record) -> partial entries
-template <bool K64>
+// COUNT (round 6): the slices of a giant bucket of `count`'s records.  A key's partial entry then carries, instead of its first record's
+// position, what KmerCounter::Lv2Postprocess needs of the key's prev / next chars (kmer_counter.cpp:283-305): per char a 4-bit counter
+// that stops at 15 (prev char x: bits [4x, 4x + 4), next char x: [16 + 4x, 20 + 4x)) — enough for any min count the streaming form takes.
+template <bool K64, bool COUNT>
 __global__ __launch_bounds__(256) void k_s1_giant_reduce(const uint32_t *__restrict__ items0, const uint32_t *const *__restrict__ srcs,
                                                          const uint64_t *__restrict__ bounds, int n_src, uint32_t n_buckets, int pbits, int k, S1Giant g) {
   constexpr int NS = 4096, NT = 256, kFlushAt = NS / 2;
@@ -87,6 +90,7 @@ __global__ __launch_bounds__(256) void k_s1_giant_reduce(const uint32_t *__restr
   constexpr KeyT kEmpty = StreamKey<K64>::kEmpty;
   __shared__ KeyT keys[NS];
   __shared__ uint32_t cnts[NS], fidx[NS];
+  __shared__ uint32_t cinfo[COUNT ? NS : 1];
   __shared__ uint32_t s_claims, s_out, s_start, s_stop;
   const int tid = threadIdx.x, lane = tid & (kWave - 1);
   const size_t bstride = (size_t)n_buckets + 1;
@@ -94,9 +98,30 @@ __global__ __launch_bounds__(256) void k_s1_giant_reduce(const uint32_t *__restr
   for (int i = tid; i < NS; i += NT) {
     keys[i] = kEmpty;
     cnts[i] = 0;
+    if (COUNT) cinfo[i] = 0;
   }
   if (tid == 0) s_claims = 0;
   __syncthreads();
+  // count: the (k+1)-mer below the prefix is the key (no head / tail field)
+  const int c_rem = 2 * (k + 1) - pbits, c_sh = 64 - 2 * (k + 1);
+  const unsigned long long c_mask = c_rem >= 64 ? ~0ull : (c_rem > 0 ? (1ull << c_rem) - 1ull : 0ull);
+  // saturating add of per-char counts (one byte per char in `pv` / `nx`) to a slot's eight 4-bit counters
+  auto add_chars = [&](uint32_t h, uint32_t pv, uint32_t nx) {
+    uint32_t cur = __hip_atomic_load(&cinfo[COUNT ? h : 0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    for (;;) {
+      uint32_t nv = cur;
+#pragma unroll
+      for (unsigned x = 0; x < 4; ++x) {
+        const uint32_t fp = (cur >> (4 * x)) & 15u, fn = (cur >> (16 + 4 * x)) & 15u;
+        nv += (min(fp + ((pv >> (8 * x)) & 0xFFu), 15u) - fp) << (4 * x);
+        nv += (min(fn + ((nx >> (8 * x)) & 0xFFu), 15u) - fn) << (16 + 4 * x);
+      }
+      if (nv == cur) break;
+      const uint32_t got = atomicCAS(&cinfo[COUNT ? h : 0], cur, nv);
+      if (got == cur) break;
+      cur = got;
+    }
+  };
   for (uint32_t gi = 0; gi < n_g; ++gi) {
     const uint32_t ns = g.ns[gi];
     if (!ns) continue;
@@ -153,10 +178,11 @@ __global__ __launch_bounds__(256) void k_s1_giant_reduce(const uint32_t *__restr
           if (key != kEmpty) {
             if (write) {
               const uint32_t *r = src + (lo + fidx[i]) * 3;
-              region[at++] = make_uint4(r[0], r[1], r[2], cnts[i]);
+              region[at++] = make_uint4(r[0], r[1], COUNT ? cinfo[i] : r[2], cnts[i]);
             }
             keys[i] = kEmpty;
             cnts[i] = 0;
+            if (COUNT) cinfo[i] = 0;
           }
         }
         __syncthreads();
@@ -166,15 +192,32 @@ __global__ __launch_bounds__(256) void k_s1_giant_reduce(const uint32_t *__restr
         const uint64_t idx = base + tid;
         const bool in = idx < hi;
         KeyT lk = 0;
+        uint32_t w1v = 0;
         if (in) {
           const uint32_t *r = src + idx * 3;
-          lk = s1_stream_local_key<K64>(r[0], r[1], k, pbits);
+          w1v = r[1];
+          if constexpr (COUNT) lk = (KeyT)(((((unsigned long long)r[0] << 32) | w1v) >> c_sh) & c_mask);
+          else lk = s1_stream_local_key<K64>(r[0], w1v, k, pbits);
         }
         // a wavefront whose records all carry one key (poly-A): one lane inserts for all
         KeyT lk0 = (KeyT)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)lk);
         if constexpr (K64) lk0 |= (KeyT)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((unsigned long long)lk >> 32)) << 32;
         const bool uniform = __ballot(in && lk == lk0) == ~0ull;
         const uint32_t mult = uniform ? (uint32_t)kWave : 1u;
+        uint32_t c_pv = 0, c_nx = 0;  // count: what this insert adds per prev / next char (one byte each)
+        if constexpr (COUNT) {
+          const unsigned pv = (w1v >> 3) & 7u, nx = w1v & 7u;
+          if (uniform) {
+#pragma unroll
+            for (unsigned x = 0; x < 4; ++x) {
+              c_pv |= min((uint32_t)__builtin_popcountll(__ballot(pv == x)), 255u) << (8 * x);
+              c_nx |= min((uint32_t)__builtin_popcountll(__ballot(nx == x)), 255u) << (8 * x);
+            }
+          } else {
+            c_pv = pv < 4 ? 1u << (8 * pv) : 0u;
+            c_nx = nx < 4 ? 1u << (8 * nx) : 0u;
+          }
+        }
         if (in && (!uniform || lane == 0)) {
           uint32_t h = stream_hash<K64>(lk, 12);
           for (;;) {
@@ -185,6 +228,9 @@ __global__ __launch_bounds__(256) void k_s1_giant_reduce(const uint32_t *__restr
             }
             if (old == kEmpty || old == lk) {
               atomicAdd(&cnts[h], mult);
+              if constexpr (COUNT) {
+                if (c_pv | c_nx) add_chars(h, c_pv, c_nx);
+              }
               break;
             }
             h = (h + 1) & (NS - 1);  // (the table is flushed at half full: a free slot exists)
@@ -278,11 +324,43 @@ __global__ __launch_bounds__(NT) void k_s1_stream(const uint32_t *__restrict__ i
   const uint64_t n_lim = GIANT ? (uint64_t)min(a.giant.ctr[0], a.giant.gcap) : (uint64_t)geo.n_buckets;
   const uint32_t m = a.m;
   const bool count_wide = COUNT && m > 2;  // count with min count 3..15: per-char counters instead of the seen-once / seen-twice bits
+  // count: per-char occurrences (one byte per prev char in pv8, per next char in nx8) -> the slot's char word, in either form
+  auto count_add_chars = [&](uint32_t *slot, uint32_t pv8, uint32_t nx8) {
+    if (count_wide) {
+      uint32_t cur = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      for (;;) {
+        uint32_t nv = cur;
+#pragma unroll
+        for (unsigned x = 0; x < 4; ++x) {
+          const uint32_t fp = (cur >> (4 * x)) & 15u, fn = (cur >> (16 + 4 * x)) & 15u;
+          nv += (min(fp + ((pv8 >> (8 * x)) & 0xFFu), m) - fp) << (4 * x);
+          nv += (min(fn + ((nx8 >> (8 * x)) & 0xFFu), m) - fn) << (16 + 4 * x);
+        }
+        if (nv == cur) break;
+        const uint32_t got = atomicCAS(slot, cur, nv);
+        if (got == cur) break;
+        cur = got;
+      }
+    } else {  // prev char x: bit 2x = seen once, 2x + 1 = seen twice; next char x: bits 8 + 2x, 9 + 2x
+      uint32_t add1 = 0, add2 = 0;
+#pragma unroll
+      for (unsigned x = 0; x < 4; ++x) {
+        const uint32_t cp = (pv8 >> (8 * x)) & 0xFFu, cn = (nx8 >> (8 * x)) & 0xFFu;
+        add1 |= (cp ? 1u << (2 * x) : 0u) | (cn ? 1u << (8 + 2 * x) : 0u);
+        add2 |= (cp >= 2 ? 2u << (2 * x) : 0u) | (cn >= 2 ? 2u << (8 + 2 * x) : 0u);
+      }
+      if (add1) {
+        const uint32_t o = atomicOr(slot, add1 | add2);
+        const uint32_t again = ((o & add1) << 1) & ~(o | add2);  // a char seen before and now again: seen twice
+        if (again) atomicOr(slot, again);
+      }
+    }
+  };
   const int k = a.k;
   const int pbits = geo.pbits;
   const size_t bstride = (size_t)geo.n_buckets + 1;
   // local key: the (k-1)-mer bits below the prefix, then head/tail (the position tag bits in between dropped)
-  static_assert(!COUNT || (AGG && !GIANT), "count: edges leave through the regions of the aggregated items; no giant path");
+  static_assert(!COUNT || AGG, "count: edges leave through the regions of the aggregated items");
   const int key_chars = COUNT ? k + 1 : k - 1;
   const int rem = 2 * key_chars - pbits;         // 0..26 bits (count: up to 32)
   const int lk_bits = COUNT ? rem : rem + 6;     // <= 32
@@ -709,7 +787,16 @@ __global__ __launch_bounds__(NT) void k_s1_stream(const uint32_t *__restrict__ i
             const KeyT old = atomicCAS(&keys[hh], kEmpty, lk);
             if (old == kEmpty || old == lk) {
               atomicAdd(&cnts[hh], en.w);
-              if (old == kEmpty) {
+              if constexpr (COUNT) {  // the slice's per-char counters (4 bits each, k_s1_giant_reduce) -> the slot's char word
+                if (old == kEmpty) ++my_claims;
+                uint32_t pv8 = 0, nx8 = 0;
+#pragma unroll
+                for (unsigned x = 0; x < 4; ++x) {
+                  pv8 |= ((en.z >> (4 * x)) & 15u) << (8 * x);
+                  nx8 |= ((en.z >> (16 + 4 * x)) & 15u) << (8 * x);
+                }
+                if (pv8 | nx8) count_add_chars(&fpos[hh], pv8, nx8);
+              } else if (old == kEmpty) {
                 fpos[hh] = en.z;
                 if (TAGS) ftag[hh] = (uint8_t)(en.y >> 6);
                 ++my_claims;
@@ -932,7 +1019,8 @@ __global__ __launch_bounds__(NT) void k_s1_stream(const uint32_t *__restrict__ i
         __syncthreads();
         if (s_flagged && !bad) {  // the records of the flagged keys: first_0_out / last_0_in of their reads (kmer_counter.cpp:307-368)
           for (int q = 0; q < n_src; ++q) {
-            const uint64_t lo = lo_of(par, q), hi = hi_of(par, q);
+            // (GIANT: the table was filled from the slices' partial entries; the records themselves lie where the bucket's bounds say)
+            const uint64_t lo = GIANT ? gbounds[(size_t)q * bstride + bi] : lo_of(par, q), hi = GIANT ? gbounds[(size_t)q * bstride + bi + 1] : hi_of(par, q);
             const gptr items = (gptr)src_of(q);
             for (uint64_t base = lo; base < hi; base += NT) {
               const uint64_t gi = base + tid;
@@ -1115,17 +1203,20 @@ __global__ __launch_bounds__(NT) void k_s1_stream(const uint32_t *__restrict__ i
 
 // ---- launchers (the only way into this unit's kernels) ----
 void s1_giant_launch(mhx_ctx *c, const uint32_t *items0, const uint32_t *const *srcs, const uint64_t *bounds, int n_src, uint64_t n_buckets, int pbits, int k,
-                     const S1Giant &g, bool key64) {
+                     const S1Giant &g, bool key64, bool count) {
   hipStream_t st = c->stream;
   const uint64_t cus = c->n_cus > 0 ? (uint64_t)c->n_cus : 256;
   MHX_LAUNCH(c, "s1_giant_find", (double)n_src * n_buckets * 8,
              hipLaunchKernelGGL(k_s1_giant_find, dim3((unsigned)div_ceil(n_buckets, 256)), dim3(256), 0, st, bounds, n_src, (uint32_t)n_buckets, g));
-  if (key64)
-    MHX_LAUNCH(c, "s1_giant_reduce", 0.0,
-               hipLaunchKernelGGL(k_s1_giant_reduce<true>, dim3((unsigned)(3 * cus)), dim3(256), 0, st, items0, srcs, bounds, n_src, (uint32_t)n_buckets, pbits, k, g));
-  else
-    MHX_LAUNCH(c, "s1_giant_reduce", 0.0,
-               hipLaunchKernelGGL(k_s1_giant_reduce<false>, dim3((unsigned)(3 * cus)), dim3(256), 0, st, items0, srcs, bounds, n_src, (uint32_t)n_buckets, pbits, k, g));
+#define MHX_GR(K64V, COUNTV)                                                                                                                          \
+  MHX_LAUNCH(c, "s1_giant_reduce", 0.0,                                                                                                                 \
+             hipLaunchKernelGGL((k_s1_giant_reduce<K64V, COUNTV>), dim3((unsigned)(3 * cus)), dim3(256), 0, st, items0, srcs, bounds, n_src, (uint32_t)n_buckets, \
+                                pbits, k, g))
+  if (key64 && count) MHX_GR(true, true);
+  else if (key64) MHX_GR(true, false);
+  else if (count) MHX_GR(false, true);
+  else MHX_GR(false, false);
+#undef MHX_GR
 }
 
 void s1_stream_launch(mhx_ctx *c, const char *name, double bytes, const S1StreamLaunch &l) {
@@ -1146,8 +1237,9 @@ void s1_stream_launch(mhx_ctx *c, const char *name, double bytes, const S1Stream
     else if (l.tags) MHX_STREAM_K(false, kStreamThreads, 13, true, false, false, true);
     else MHX_STREAM_K(false, kStreamThreads, 13, false, false, false, true);
   } else if (l.count) {
-    if (!l.agg || l.half || l.giant) throw Error("s1_stream_launch: count runs on full tables with edge regions, without the giant path");
-    MHX_STREAM_T(true, kStreamThreads, 13, false, true);
+    if (!l.agg || l.half) throw Error("s1_stream_launch: count runs on full tables with edge regions");
+    if (l.giant) MHX_STREAM_T(true, kStreamThreads, 13, true, true);
+    else MHX_STREAM_T(true, kStreamThreads, 13, false, true);
   } else if (l.giant) {
     if (l.half) throw Error("s1_stream_launch: the giant path runs on full tables");
     if (l.agg) MHX_STREAM_T(true, kStreamThreads, 13, true, false);

@@ -195,6 +195,7 @@ def load_fixed_reads(r, e):
     (2, 21, 2, True, {"s1_stream_probes": 0}, False),                    # the owners' streaming gives up -> the classic exchange redoes the pass
     (2, 21, 2, True, {"dist_presort": 0}, False), (2, 23, 2, True, None, False), (2, 21, 16, True, None, False),
     (3, 21, 3, True, None, True), (2, 22, 4, True, {"s1_stream_fill": 40}, True),   # min count 3..15: per-char counters at the owners
+    (3, 21, 2, True, {"s1_giant_min": 64}, True), (2, 21, 3, True, {"s1_giant_min": 100, "s1_pos_bits": 12}, True),  # giant buckets: slices cut per sender
 ])
 def test_count_on_the_presorted_exchange(world, k, m, fixed, opts, presorted):
     """round 6: `count` on several ranks on the stage-1 design — every rank's first sort pass makes its 12-byte records, the slices of the
