@@ -1083,6 +1083,16 @@ bool count_stream_groups(mhx_ctx *c, uint32_t k, uint32_t m, uint32_t *first_0_o
     g.cur = g.cap + g.gcap;
     g.partial = c->ws("s1_giant_partial", g.pcap * 16 + 64).as<uint4>();
     giant_ctr = lists;
+    // the listed keys of every giant (k_count_giant_look) and, on several GPUs, that kernel's events
+    g.fl_cap = kGiantFlagged;
+    g.fl_cnt = c->ws("cs_giant_fl_cnt", (size_t)g.gcap * 4 + 64).as<uint32_t>();
+    g.fl_key = c->ws("cs_giant_fl_key", (size_t)g.gcap * g.fl_cap * 8 + 64).as<unsigned long long>();
+    MHX_HIP(hipMemsetAsync(g.fl_cnt, 0, (size_t)g.gcap * 4 + 64, st));
+    if (global) {
+      g.ev_cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(n_items / 8, 1u << 20), 0xFFFFFFF0u);
+      g.ev = c->ws("cs_giant_events", (size_t)g.ev_cap * 8 + 64).as<unsigned long long>();
+      g.ev_cur = g.fl_cnt + g.gcap;  // (one of the spare words behind the counters, zeroed with them)
+    }
     MHX_HIP(hipMemsetAsync(g.flag, 0, n_buckets, st));
     MHX_HIP(hipMemsetAsync(lists, 0, 64, st));
     s1_giant_launch(c, items0, srcs, bounds, n_src, n_buckets, plan.seg_bits, (int)k, g, false, true);
@@ -1092,6 +1102,7 @@ bool count_stream_groups(mhx_ctx *c, uint32_t k, uint32_t m, uint32_t *first_0_o
   if (giant_on) {
     S1StreamLaunch gl{true, false, pos_stride != 0, true, true, grid, items0, bounds, a, geo, 1u, ticket2, srcs, n_src};
     s1_stream_launch(c, "count_giant_groups", 0.0, gl);
+    count_giant_look_launch(c, items0, srcs, bounds, n_src, n_buckets, plan.seg_bits, a);
   }
   uint32_t e = 0;
   unsigned long long h_ctr[8] = {0};
@@ -1115,13 +1126,20 @@ bool count_stream_groups(mhx_ctx *c, uint32_t k, uint32_t m, uint32_t *first_0_o
   }
   o->events = nullptr;
   o->n_events = 0;
-  if (e == 0 && global) {  // the workgroups' event regions -> one list
+  if (e == 0 && global) {  // the workgroups' event regions (+ the events of the look at the giants) -> one list
     for (uint32_t v : h_ec) o->n_events += v;
-    unsigned long long *dense = c->ws("cs_events_dense", o->n_events * 8 + 64).as<unsigned long long>();
+    uint32_t n_look = 0;
+    if (giant_on) {
+      MHX_HIP(hipMemcpy(&n_look, a.giant.ev_cur, 4, hipMemcpyDeviceToHost));
+      n_look = std::min(n_look, a.giant.ev_cap);
+    }
+    unsigned long long *dense = c->ws("cs_events_dense", (o->n_events + n_look) * 8 + 64).as<unsigned long long>();
     if (o->n_events)
       MHX_LAUNCH(c, "events_compact", (double)o->n_events * 16,
                  hipLaunchKernelGGL(k_agg_compact, dim3(grid, 8), dim3(256), 0, st, reinterpret_cast<const uint2 *>(a.marks_raw), ecap, ecounts,
                                     reinterpret_cast<uint2 *>(dense), 0));
+    if (n_look) MHX_HIP(hipMemcpyAsync(dense + o->n_events, a.giant.ev, (size_t)n_look * 8, hipMemcpyDeviceToDevice, st));
+    o->n_events += n_look;
     o->events = dense;
   }
   return e == 0;

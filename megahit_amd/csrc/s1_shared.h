@@ -57,7 +57,17 @@ struct S1Giant {
   uint32_t gcap;            // giants the list holds
   uint32_t min_records;     // a bucket at least this large is a giant
   unsigned long long pcap;  // entries `partial` holds
+  // count: the solid keys of a giant that have no in- or out-edge (local key << 2 | flags), listed by the launch on the partial entries;
+  // k_count_giant_look then sends MANY workgroups over the giant's records for first_0_out / last_0_in (one workgroup took 43 ms for the
+  // 6.6 x 10^7 records of a poly-G bucket).  A list that overflows: the listing workgroup looks at the bucket itself, as for any bucket.
+  uint32_t *fl_cnt;            // per giant: keys listed (may exceed fl_cap)
+  unsigned long long *fl_key;  // [gcap][fl_cap]
+  uint32_t fl_cap;
+  unsigned long long *ev;      // several GPUs: the events of k_count_giant_look (one list, a cursor in ev_cur), else nullptr
+  uint32_t *ev_cur;
+  uint32_t ev_cap;
 };
+constexpr uint32_t kGiantFlagged = 1024;
 constexpr uint32_t kGiantSliceMin = 16384, kGiantEntriesPerSlice = 256;
 
 struct S1SegArgs {
@@ -144,6 +154,9 @@ struct S1StreamLaunch {  // one launch of k_s1_stream (s1_stream.hip)
 void s1_stream_launch(mhx_ctx *c, const char *name, double bytes, const S1StreamLaunch &l);
 void s1_giant_launch(mhx_ctx *c, const uint32_t *items0, const uint32_t *const *srcs, const uint64_t *bounds, int n_src, uint64_t n_buckets, int pbits, int k,
                      const S1Giant &g, bool key64 = false, bool count = false);
+// count: first_0_out / last_0_in of the reads that hold a listed key of a giant bucket (s1_stream.hip k_count_giant_look)
+void count_giant_look_launch(mhx_ctx *c, const uint32_t *items0, const uint32_t *const *srcs, const uint64_t *bounds, int n_src, uint64_t n_buckets, int pbits,
+                             const S1SegArgs &a);
 // k_s1_seg (s1_tile.hip): per = 4 | 8 records per thread
 void s1_seg_launch(mhx_ctx *c, const char *name, double bytes, int per, bool agg, unsigned grid, const uint32_t *sorted, uint64_t n_items, const S1SegArgs &a,
                    uint64_t n_work, uint32_t stride);

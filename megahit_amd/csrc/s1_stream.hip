@@ -987,6 +987,12 @@ __global__ __launch_bounds__(NT) void k_s1_stream(const uint32_t *__restrict__ i
               }
               fb = (has_in ? 0u : 1u) | (has_out ? 0u : 2u);
               any_flag = any_flag || fb != 0;
+              if constexpr (GIANT) {  // listed for k_count_giant_look (a list that runs over: this workgroup looks itself, below)
+                if (fb && a.giant.fl_cnt) {
+                  const uint32_t at = atomicAdd(&a.giant.fl_cnt[(uint32_t)bi64], 1u);
+                  if (at < a.giant.fl_cap) a.giant.fl_key[(size_t)bi64 * a.giant.fl_cap + at] = ((unsigned long long)lk << 2) | fb;
+                }
+              }
             }
             fpos[it * NT + tid] = fb << 30;
           }
@@ -1017,6 +1023,13 @@ __global__ __launch_bounds__(NT) void k_s1_stream(const uint32_t *__restrict__ i
           }
         }
         __syncthreads();
+        if constexpr (GIANT) {  // the listed keys are k_count_giant_look's; only a list that ran over leaves the look to this workgroup
+          if (a.giant.fl_cnt) {
+            if (tid == 0 && s_flagged)
+              s_flagged = __hip_atomic_load(&a.giant.fl_cnt[(uint32_t)bi64], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > a.giant.fl_cap ? 1u : 0u;
+            __syncthreads();
+          }
+        }
         if (s_flagged && !bad) {  // the records of the flagged keys: first_0_out / last_0_in of their reads (kmer_counter.cpp:307-368)
           for (int q = 0; q < n_src; ++q) {
             // (GIANT: the table was filled from the slices' partial entries; the records themselves lie where the bucket's bounds say)
@@ -1201,7 +1214,114 @@ __global__ __launch_bounds__(NT) void k_s1_stream(const uint32_t *__restrict__ i
 }
 
 
+// count, giant buckets: the records of the listed keys (solid, without an in- or out-edge) move first_0_out / last_0_in of their reads
+// (kmer_counter.cpp:307-368) — the slices of the giant again, many workgroups, the giant's list as an LDS table
+__global__ __launch_bounds__(256) void k_count_giant_look(const uint32_t *__restrict__ items0, const uint32_t *const *__restrict__ srcs,
+                                                          const uint64_t *__restrict__ bounds, int n_src, uint32_t n_buckets, int pbits, S1SegArgs a) {
+  constexpr int NS = 4096, NT = 256;
+  static_assert(NS >= 2 * (int)kGiantFlagged, "the list at half load");
+  __shared__ unsigned long long tk[NS];
+  const S1Giant &g = a.giant;
+  const int tid = threadIdx.x, lane = tid & (kWave - 1);
+  const size_t bstride = (size_t)n_buckets + 1;
+  const uint32_t n_g = min(g.ctr[0], g.gcap);
+  const int k = a.k;
+  const int c_rem = 2 * (k + 1) - pbits, c_sh = 64 - 2 * (k + 1);
+  const unsigned long long c_mask = c_rem >= 64 ? ~0ull : (c_rem > 0 ? (1ull << c_rem) - 1ull : 0ull);
+  const bool tags = a.pos_stride != 0;
+  for (uint32_t gi = 0; gi < n_g; ++gi) {
+    const uint32_t ns = g.ns[gi], nf = g.fl_cnt[gi];
+    const uint32_t b = g.bucket[gi];
+    if (!ns || !nf || nf > g.fl_cap || !g.flag[b]) continue;  // (nothing listed; a list that ran over or a bucket given back: looked at by the streaming kernel)
+    if (blockIdx.x >= ns) continue;
+    __syncthreads();
+    for (int i = tid; i < NS; i += NT) tk[i] = ~0ull;
+    __syncthreads();
+    for (uint32_t i = tid; i < nf; i += NT) {
+      const unsigned long long e = g.fl_key[(size_t)gi * g.fl_cap + i];
+      uint32_t h = stream_hash<true>(e >> 2, 12);
+      while (atomicCAS(&tk[h], ~0ull, e) != ~0ull) h = (h + 1) & (NS - 1);
+    }
+    __syncthreads();
+    const uint32_t sl_len = g.sl[gi];
+    for (uint32_t sl = blockIdx.x; sl < ns; sl += gridDim.x) {
+      uint32_t rem = sl;
+      uint64_t lo = 0, hi = 0;
+      const uint32_t *src = items0;
+      for (int q = 0; q < n_src; ++q) {
+        const uint64_t l = bounds[q * bstride + b], h = bounds[q * bstride + b + 1];
+        const uint64_t nsq = (h - l + sl_len - 1) / sl_len;
+        if (rem < nsq) {
+          lo = l + (uint64_t)rem * sl_len;
+          hi = lo + sl_len < h ? lo + sl_len : h;
+          if (n_src > 1) src = srcs[q];
+          break;
+        }
+        rem -= (uint32_t)nsq;
+      }
+      for (uint64_t base = lo; base < hi; base += NT) {
+        const uint64_t idx = base + tid;
+        uint32_t f = 0, w1 = 0, w2 = 0;
+        if (idx < hi) {
+          const uint32_t *r = src + idx * 3;
+          w1 = r[1];
+          w2 = r[2];
+          const unsigned long long lk = ((((unsigned long long)r[0] << 32) | w1) >> c_sh) & c_mask;
+          uint32_t h = stream_hash<true>(lk, 12);
+          for (;;) {
+            const unsigned long long e = tk[h];
+            if (e == ~0ull) break;
+            if ((e >> 2) == lk) {
+              f = (uint32_t)e & 3u;
+              break;
+            }
+            h = (h + 1) & (NS - 1);
+          }
+        }
+        const uint64_t abs = w2 + (tags ? (uint64_t)((w1 >> 7) & 0xFFu) * a.pos_stride : 0ull);
+        const bool fwd = (w1 & kCountStrandBit) == 0;
+        if (!g.ev) {
+          if (f) {
+            const uint64_t rid = seq_of_offset(a.c_start, a.c_n_seqs, a.c_fixed_len, abs);
+            const uint32_t off = (uint32_t)(abs - a.c_start[rid]);
+            if (f & 1u) {
+              if (fwd) atomicMax(&a.last_0_in_p1[rid], off + 1);
+              else atomicMin(&a.first_0_out[rid], off + 1);
+            }
+            if (f & 2u) {
+              if (fwd) atomicMin(&a.first_0_out[rid], off + 1);
+              else atomicMax(&a.last_0_in_p1[rid], off + 1);
+            }
+          }
+        } else {  // several GPUs: events for the ranks that hold the reads (k_s1_stream<COUNT> writes the same)
+          const uint32_t ne = (f & 1u) + (f >> 1);
+          const uint32_t incl = wave_inclusive_sum(ne);
+          const uint32_t tot = __shfl(incl, kWave - 1, kWave);
+          if (tot) {
+            uint32_t ebase = 0;
+            if (lane == 0) ebase = atomicAdd(g.ev_cur, tot);
+            ebase = __shfl(ebase, 0, kWave);
+            uint32_t at = ebase + incl - ne;
+            if ((uint64_t)ebase + tot > g.ev_cap) {
+              if (lane == 0) atomicOr(a.err, 2u);
+            } else {
+              if (f & 1u) g.ev[at++] = (abs << 1) | (fwd ? 0ull : 1ull);
+              if (f & 2u) g.ev[at] = (abs << 1) | (fwd ? 1ull : 0ull);
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
 // ---- launchers (the only way into this unit's kernels) ----
+void count_giant_look_launch(mhx_ctx *c, const uint32_t *items0, const uint32_t *const *srcs, const uint64_t *bounds, int n_src, uint64_t n_buckets, int pbits,
+                             const S1SegArgs &a) {
+  const uint64_t cus = c->n_cus > 0 ? (uint64_t)c->n_cus : 256;
+  MHX_LAUNCH(c, "count_giant_look", 0.0,
+             hipLaunchKernelGGL(k_count_giant_look, dim3((unsigned)(3 * cus)), dim3(256), 0, c->stream, items0, srcs, bounds, n_src, (uint32_t)n_buckets, pbits, a));
+}
 void s1_giant_launch(mhx_ctx *c, const uint32_t *items0, const uint32_t *const *srcs, const uint64_t *bounds, int n_src, uint64_t n_buckets, int pbits, int k,
                      const S1Giant &g, bool key64, bool count) {
   hipStream_t st = c->stream;
