@@ -1056,7 +1056,7 @@ uint64_t mhx_stage_pass_bytes(mhx_ctx *c, int stage, uint32_t k, uint32_t min_co
       c->filter_on = true;
       c->filter_expected = n_items;
       // count on the stage-1 design: two 12-byte record buffers (the solid edges and the events live in the spare one)
-      if (mhx::count_stream_applies(c, k, min_count) && (2 * (k + 1) + 16 + 31) / 32 == 2)
+      if (mhx::count_stream_applies(c, k, min_count) && (2 * (k + 1) + 16 + 31) / 32 <= 3)
         return n_items * 24 + n_items / 2 + c->seqs.n_bases / 3;
     }
     uint64_t ib = 16;

@@ -622,11 +622,11 @@ __global__ __launch_bounds__(256) void k_edges_compact(const unsigned long long 
 // sorted 8-byte edges (hi word first in memory after the sort) -> bucket counts
 // edges per lv1 bucket.  The edges are sorted, so the lanes of a wavefront hold a few runs of equal buckets: the first lane of a run
 // adds the run's length (one atomic per lane on ~450 equal addresses in a row took 2.6 ms for 29.7 M edges: rocprofv3, round 5)
-__global__ __launch_bounds__(256) void k_edge_buckets(const uint32_t *__restrict__ edges, uint64_t n, unsigned long long *__restrict__ bcount) {
+__global__ __launch_bounds__(256) void k_edge_buckets(const uint32_t *__restrict__ edges, uint64_t n, unsigned long long *__restrict__ bcount, int wpe = 2) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int lane = threadIdx.x & (kWave - 1);
   const bool valid = i < n;
-  const uint32_t b = valid ? edges[2 * i] >> 16 : 0xFFFFFFFFu;
+  const uint32_t b = valid ? edges[(uint64_t)wpe * i] >> 16 : 0xFFFFFFFFu;
   const uint32_t pb = __shfl_up(b, 1, kWave);
   const bool head = valid && (lane == 0 || pb != b);
   const uint64_t heads = __ballot(head), valids = __ballot(valid);
@@ -634,6 +634,27 @@ __global__ __launch_bounds__(256) void k_edge_buckets(const uint32_t *__restrict
     const uint64_t later = lane == kWave - 1 ? 0ull : (heads >> (lane + 1)) << (lane + 1);  // run heads behind this lane
     const int end = later ? __builtin_ctzll(later) : (valids == ~0ull ? kWave : __builtin_ctzll(~valids));
     atomicAdd(&bcount[b], (unsigned long long)(end - lane));
+  }
+}
+// the same for the 16-byte entries of k >= 24 ((k+1)-mer words, multiplicity, 0), and their three-word form (kmer_counter.cpp:32-52)
+__global__ __launch_bounds__(256) void k_edges_compact16(const uint4 *__restrict__ raw, uint32_t cap, const uint32_t *__restrict__ counts, uint4 *__restrict__ dense) {
+  __shared__ uint64_t sm[256 / kWave + 1];
+  const uint32_t r = blockIdx.x;
+  uint64_t part = 0;
+  for (uint32_t i = threadIdx.x; i < r; i += 256) part += counts[i];
+  uint64_t off;
+  block_exclusive_sum<uint64_t, 256>(part, sm, &off);
+  const uint32_t nn = counts[r];
+  const uint4 *src = raw + (size_t)r * cap;
+  for (uint32_t i = blockIdx.y * 256 + threadIdx.x; i < nn; i += gridDim.y * 256) dense[off + i] = src[i];
+}
+__global__ void k_edges_pack3(const uint4 *__restrict__ sorted, uint64_t n, uint32_t *__restrict__ edges) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    const uint4 e = sorted[i];
+    edges[3 * i] = e.x;
+    edges[3 * i + 1] = e.y;
+    edges[3 * i + 2] = e.z;
   }
 }
 __global__ void k_swap_pairs(uint32_t *__restrict__ v, uint64_t n) {
@@ -986,10 +1007,20 @@ static bool count_run_stream(mhx_ctx *c, uint32_t k, uint32_t m, mhx_count_resul
   MHX_HIP(hipStreamSynchronize(st));
   uint64_t n_edges = 0;
   for (uint32_t v : h_counts) n_edges += v;
-  uint32_t *ea = c->ws("cs_edges_a", (n_edges + 1) * 8).as<uint32_t>(), *eb = c->ws("cs_edges_b", (n_edges + 1) * 8).as<uint32_t>();
+  const size_t eb_bytes = wpe == 3 ? 16 : 8;  // a region entry
+  uint32_t *ea = c->ws("cs_edges_a", (n_edges + 1) * eb_bytes).as<uint32_t>(), *eb = c->ws("cs_edges_b", (n_edges + 1) * eb_bytes).as<uint32_t>();
   uint32_t *edges = c->result(MHX_BUF_EDGES, (n_edges ? n_edges : 1) * wpe * 4).as<uint32_t>();
   c->results[MHX_BUF_EDGES].used = n_edges * wpe * 4;
-  if (n_edges) {
+  if (n_edges && wpe == 3) {  // k >= 24: 16-byte entries with the words in edge order -> sorted by the (k+1)-mer -> three-word edges
+    MHX_LAUNCH(c, "edges_compact", (double)n_edges * 32,
+               hipLaunchKernelGGL(k_edges_compact16, dim3(o.grid, 4), dim3(256), 0, st, reinterpret_cast<const uint4 *>(o.spare), o.cap / 2, o.counts,
+                                  reinterpret_cast<uint4 *>(ea)));
+    uint32_t *es = sort_whole_key(c, ea, eb, n_edges, 4, 2, make_passes(2, 64 - key_bits, 64));  // distinct keys
+    hipLaunchKernelGGL(k_edges_pack3, dim3((unsigned)div_ceil(n_edges, 256)), dim3(256), 0, st, reinterpret_cast<const uint4 *>(es), n_edges, edges);
+    MHX_LAUNCH(c, "edge_buckets", (double)n_edges * 12,
+               hipLaunchKernelGGL(k_edge_buckets, dim3((unsigned)div_ceil(n_edges, 256)), dim3(256), 0, st, edges, n_edges, bcount, 3));
+    MHX_HIP(hipGetLastError());
+  } else if (n_edges) {
     MHX_LAUNCH(c, "edges_compact", (double)n_edges * 16,
                hipLaunchKernelGGL(k_edges_compact, dim3(o.grid, 4), dim3(256), 0, st, reinterpret_cast<const unsigned long long *>(o.spare), o.cap, o.counts,
                                   reinterpret_cast<unsigned long long *>(ea)));
@@ -998,7 +1029,7 @@ static bool count_run_stream(mhx_ctx *c, uint32_t k, uint32_t m, mhx_count_resul
     uint32_t *es = sort_whole_key(c, ea, eb, n_edges, 2, 2, make_passes(2, 64 - key_bits, 64));  // distinct keys: the count bits never decide
     MHX_HIP(hipMemcpyAsync(edges, es, n_edges * 8, hipMemcpyDeviceToDevice, st));
     MHX_LAUNCH(c, "edge_buckets", (double)n_edges * 8,
-               hipLaunchKernelGGL(k_edge_buckets, dim3((unsigned)div_ceil(n_edges, 256)), dim3(256), 0, st, edges, n_edges, bcount));
+               hipLaunchKernelGGL(k_edge_buckets, dim3((unsigned)div_ceil(n_edges, 256)), dim3(256), 0, st, edges, n_edges, bcount, 2));
     MHX_HIP(hipGetLastError());
   }
   if (pre) {  // several GPUs: the events -> sorted by position in ws("route_records"); first / last are finished by mhx_dist_apply_routed
@@ -1041,7 +1072,7 @@ int count_process_presorted(mhx_ctx *c, uint32_t k, uint32_t m, const S1Sources 
 
 int run_count(mhx_ctx *c, uint32_t k, uint32_t m, mhx_count_result *out) {
   if (c->global_bases) throw Error("count: the global layout is set; use the mhx_dist_* entry points (or mhx_set_global_layout(0, 0))");
-  if (count_stream_applies(c, k, m) && (int)div_ceil((k + 1) * 2 + 16, 32) == 2) {
+  if (count_stream_applies(c, k, m) && (int)div_ceil((k + 1) * 2 + 16, 32) <= 3) {
     c->gen_first_pass = nullptr;
     if (count_run_stream(c, k, m, out)) return 0;
     c->gen_first_pass = nullptr;  // (gave up: the extraction + tile path redoes the job from the reads)

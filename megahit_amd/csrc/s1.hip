@@ -921,7 +921,7 @@ static bool count_stream_shape(const mhx_ctx *c, uint32_t k, uint32_t m, S1Plan 
   // (a caller that asks for a particular form of the tile path gets the tile path)
   if (!c->opt("count_seg", 1) || c->opt("count_seg_bits", 0) || !c->opt("count_extract_fixed", 1)) return false;
   // (min count 1, 2: seen-once / seen-twice bits per prev / next char in the table slot; 3..15: 4-bit counters that stop at m)
-  if (!s.n_seqs || k < 9 || (int)k > kCountStreamMaxK || m < 1 || m > 15) return false;
+  if (!s.n_seqs || k < 9 || m < 1 || m > 15) return false;  // (k: count_shape_is_fast — up to 22 with a shared window per run, up to 27 with one per item)
   if (!count_shape_is_fast(c, k)) return false;  // (reads of several lengths: item slots padded to the longest read's, CountGenVarT)
   if (!c->opt("s1_fused_first_pass", 1) || !c->opt("sort_unit_runs", 1) || !c->opt("s1_gen_any_order", 1)) return false;
   const uint64_t n_bits = c->global_bases ? c->global_bases : s.n_bases;
@@ -931,9 +931,9 @@ static bool count_stream_shape(const mhx_ctx *c, uint32_t k, uint32_t m, S1Plan 
   if (!plan.stream || plan.passes.empty() || (int)plan.passes.size() > kFastPasses) return false;
   for (const SortPass &ps : plan.passes)
     if (ps.bits2 || ps.shift < 32) return false;  // (digits: bit fields of the first key word)
-  // the table key is the (k+1)-mer below the prefix in 32 bits, and the all-ones word stands for an empty slot (a forced narrow
-  // prefix — s1_stream_bits — could ask for more)
-  if (2 * ((int)k + 1) - plan.seg_bits > 31) return false;
+  // the table key is the (k+1)-mer below the prefix: 32 bits (the all-ones word stands for an empty slot) up to k = 22 at a 16-bit
+  // prefix, the 64-bit form beyond (k = 23..27, or a forced narrow prefix — s1_stream_bits), which carries no position tags
+  if (2 * ((int)k + 1) - plan.seg_bits > 31 && (n_bits >> s1_pos_bits(c)) != 0) return false;
   if (plan_out) *plan_out = plan;
   return sort_takes_generated_first_pass(c, c->filter_on ? std::max<uint64_t>(c->filter_expected, 1) : n_items, 3, plan.passes);
 }
@@ -1005,7 +1005,7 @@ bool count_stream_groups(mhx_ctx *c, uint32_t k, uint32_t m, uint32_t *first_0_o
   // workgroups, so that a region holds at least ~6000 edges — with one workgroup, every record's (a region that overflows is
   // found only after the whole pass ran, and the tile path then repeats the work)
   const unsigned grid = (unsigned)std::min<uint64_t>(std::min<uint64_t>(n_buckets, cus), std::max<uint64_t>(n_items / 4096, 1));
-  const uint32_t region = (uint32_t)std::min<uint64_t>(n_items * 12 / 8 / grid, 0xFFFFFFF0u);
+  const uint32_t region = (uint32_t)std::min<uint64_t>(n_items * 12 / 8 / grid, 0xFFFFFFF0u) & ~1u;  // (even: 16-byte entries at k >= 24)
   uint32_t *counts = c->ws("cs_edge_counts", (size_t)grid * 4).as<uint32_t>();
   unsigned long long *ctr = c->ws("s1_counters", 64).as<unsigned long long>();
   uint32_t *seg_err = c->ws("s1_seg_err", 64).as<uint32_t>();
@@ -1044,6 +1044,7 @@ bool count_stream_groups(mhx_ctx *c, uint32_t k, uint32_t m, uint32_t *first_0_o
   a.c_fixed_len = s.fixed_len;
   a.first_0_out = first_0_out;
   a.last_0_in_p1 = last_0_in_p1;
+  a.c_wpe = (int)div_ceil((k + 1) * 2 + 16, 32);
   uint32_t ecap = 0;
   uint32_t *ecounts = nullptr;
   if (global) {
@@ -1059,6 +1060,7 @@ bool count_stream_groups(mhx_ctx *c, uint32_t k, uint32_t m, uint32_t *first_0_o
                          (uint32_t)std::min<long long>(std::max<long long>(c->opt("s1_stream_fill", 8192 * 7 / 8), 1), 8192)};
   const double bytes = (double)n_items * 12 * (double)(1u << plan.sub0);
   const uint32_t *items0 = pre ? pre->ptr[0] : sorted;
+  const bool key64 = 2 * ((int)k + 1) - plan.seg_bits > 31;  // the (k+1)-mer below the prefix: wider than a 32-bit table key
   // giant buckets (round 6; S1Giant as in stage 1): a bucket of >= s1_giant_min records — 5 % poly-G reads put 6.6 x 10^7 records of
   // one key into one — is cut into slices that many workgroups reduce into partial entries (a key's count and per-char counters in
   // the slice); the streaming launch skips it, a second launch over the same grid inserts the partial entries and does the per-key
@@ -1095,12 +1097,14 @@ bool count_stream_groups(mhx_ctx *c, uint32_t k, uint32_t m, uint32_t *first_0_o
     }
     MHX_HIP(hipMemsetAsync(g.flag, 0, n_buckets, st));
     MHX_HIP(hipMemsetAsync(lists, 0, 64, st));
-    s1_giant_launch(c, items0, srcs, bounds, n_src, n_buckets, plan.seg_bits, (int)k, g, false, true);
+    s1_giant_launch(c, items0, srcs, bounds, n_src, n_buckets, plan.seg_bits, (int)k, g, key64, true);
   }
   S1StreamLaunch sl{true, false, pos_stride != 0, false, true, grid, items0, bounds, a, geo, 1u, ticket, srcs, n_src};
+  sl.key64 = key64;
   s1_stream_launch(c, "count_groups", bytes, sl);
   if (giant_on) {
     S1StreamLaunch gl{true, false, pos_stride != 0, true, true, grid, items0, bounds, a, geo, 1u, ticket2, srcs, n_src};
+    gl.key64 = key64;
     s1_stream_launch(c, "count_giant_groups", 0.0, gl);
     count_giant_look_launch(c, items0, srcs, bounds, n_src, n_buckets, plan.seg_bits, a);
   }

@@ -414,7 +414,7 @@ __global__ __launch_bounds__(256) void k_s1_digit_hist_roll(const uint32_t *__re
 }
 
 // the digit histograms of count's prefix passes (every digit one bit field of the first key word): CountGenT's arithmetic, no records
-template <int IT, int NP, bool VAR = false>  // VAR: reads of any length, `per` = max_len - k item slots each (CountGenVarT)
+template <int IT, int NP, bool VAR = false, bool WIDE = false>  // VAR: reads of any length, `per` = max_len - k item slots each (CountGenVarT); WIDE: k = 23..27, a window per item (CountGenWideT)
 __global__ __launch_bounds__(256) void k_count_digit_hist_roll(const uint32_t *__restrict__ seq, uint32_t L, uint32_t per, uint64_t n_items, int k,
                                                                HiDigits hd, unsigned long long *__restrict__ ghist, uint32_t step_q, uint32_t step_r,
                                                                const uint64_t *__restrict__ start, uint64_t n_seqs, const uint32_t *__restrict__ keep) {
@@ -463,11 +463,29 @@ __global__ __launch_bounds__(256) void k_count_digit_hist_roll(const uint32_t *_
     const uint64_t Wn = (((uint64_t)funnel_l(n0, n1, shn) << 32) | funnel_l(n1, n2, shn)) >> downn;
     const uint64_t Rn = rc64(Wn, 32);
     uint32_t prun = j;
+    static_assert(!(VAR && WIDE), "the per-item windows serve fixed-length libraries");
+    uint64_t wbase = base, wword = ~0ull;  // WIDE: the read the item is in, the word its window was last loaded from
+    uint32_t x0 = 0, x1 = 0, x2 = 0;
 #pragma unroll
     for (int u = 0; u < IT; ++u) {
-      const unsigned d2 = (j - prun) * 2;
-      const uint64_t f = (W << (d2 + 2)) & emask;
-      const uint64_t rc = (R << (rsh - d2)) & emask;
+      uint64_t f, rc;
+      if constexpr (WIDE) {
+        const uint64_t a = wbase + j, b = a >= 1 ? a - 1 : 0, w = b >> 4;
+        if (w != wword) {
+          x0 = seq[w];
+          x1 = seq[w + 1];
+          x2 = seq[w + 2];
+          wword = w;
+        }
+        const unsigned sh = (unsigned)(b & 15) * 2;
+        const uint64_t win = (((uint64_t)funnel_l(x0, x1, sh) << 32) | funnel_l(x1, x2, sh)) >> (a >= 1 ? 0u : 2u);
+        f = (win << 2) & emask;
+        rc = rc64(f, k + 1);
+      } else {
+        const unsigned d2 = (j - prun) * 2;
+        f = (W << (d2 + 2)) & emask;
+        rc = (R << (rsh - d2)) & emask;
+      }
       const uint32_t hi = (uint32_t)((rc < f ? rc : f) >> 32);
       if (g0 + u < n_items && j < cnt && (!keep || s1_bucket_kept(keep, hi))) {  // (keep: a memory-plan pass counts what its generating pass will keep)
 #pragma unroll
@@ -479,6 +497,7 @@ __global__ __launch_bounds__(256) void k_count_digit_hist_roll(const uint32_t *_
         W = Wn;
         R = Rn;
         prun = 0;
+        wbase = base_n;
       }
     }
     q0 += step_q;
@@ -499,7 +518,7 @@ __global__ __launch_bounds__(256) void k_count_digit_hist_roll(const uint32_t *_
 // The lv1-bucket histogram of `count` (KmerCounter::Lv0CalcBucketSize, kmer_counter.cpp:114-156) from the packed reads with CountGenT's
 // window arithmetic — what a memory plan asks for before it splits a job into bucket ranges; one half of the bucket space per launch,
 // as k_s1_bucket_hist_fast.  k <= kCountStreamMaxK, >= IT item slots per read.
-template <int IT, bool VAR>
+template <int IT, bool VAR, bool WIDE = false>
 __global__ __launch_bounds__(1024) void k_count_bucket_hist(const uint32_t *__restrict__ seq, uint32_t L, uint32_t per, uint64_t n_items, int k,
                                                             unsigned long long *__restrict__ ghist, uint32_t step_q, uint32_t step_r, uint32_t half,
                                                             const uint64_t *__restrict__ start, uint64_t n_seqs) {
@@ -547,11 +566,29 @@ __global__ __launch_bounds__(1024) void k_count_bucket_hist(const uint32_t *__re
     const uint64_t Wn = (((uint64_t)funnel_l(n0, n1, shn) << 32) | funnel_l(n1, n2, shn)) >> downn;
     const uint64_t Rn = rc64(Wn, 32);
     uint32_t prun = j;
+    static_assert(!(VAR && WIDE), "the per-item windows serve fixed-length libraries");
+    uint64_t wbase = base, wword = ~0ull;
+    uint32_t x0 = 0, x1 = 0, x2 = 0;
 #pragma unroll
     for (int u = 0; u < IT; ++u) {
-      const unsigned d2 = (j - prun) * 2;
-      const uint64_t f = (W << (d2 + 2)) & emask;
-      const uint64_t rc = (R << (rsh - d2)) & emask;
+      uint64_t f, rc;
+      if constexpr (WIDE) {
+        const uint64_t a = wbase + j, bb = a >= 1 ? a - 1 : 0, w = bb >> 4;
+        if (w != wword) {
+          x0 = seq[w];
+          x1 = seq[w + 1];
+          x2 = seq[w + 2];
+          wword = w;
+        }
+        const unsigned sh = (unsigned)(bb & 15) * 2;
+        const uint64_t win = (((uint64_t)funnel_l(x0, x1, sh) << 32) | funnel_l(x1, x2, sh)) >> (a >= 1 ? 0u : 2u);
+        f = (win << 2) & emask;
+        rc = rc64(f, k + 1);
+      } else {
+        const unsigned d2 = (j - prun) * 2;
+        f = (W << (d2 + 2)) & emask;
+        rc = (R << (rsh - d2)) & emask;
+      }
       const uint32_t b = (uint32_t)((rc < f ? rc : f) >> 48);
       if (g0 + u < n_items && j < cnt && (b >> 15) == half) atomicAdd(&h[b & (NB - 1)], 1u);
       if (++j == per) {
@@ -560,6 +597,7 @@ __global__ __launch_bounds__(1024) void k_count_bucket_hist(const uint32_t *__re
         W = Wn;
         R = Rn;
         prun = 0;
+        wbase = base_n;
       }
     }
     q0 += step_q;
@@ -794,7 +832,10 @@ bool s1_bucket_histogram_fast(mhx_ctx *c, uint32_t k, unsigned long long *hist) 
 // least s1_var_min_fill per cent of the padded slots are edges
 bool count_shape_is_fast(const mhx_ctx *c, uint32_t k) {
   const SeqSet &s = c->seqs;
-  if (!s.n_seqs || k < 9 || (int)k > kCountStreamMaxK) return false;
+  if (!s.n_seqs || k < 9) return false;
+  if ((int)k > kCountStreamMaxK)  // k = 23..27: a window per item (CountGenWideT), reads of one length, no position tags
+    return (int)k <= kCountStreamWideMaxK && c->opt("count_stream_wide", 1) && s.fixed_len >= k + 1 && s.fixed_len - k >= 8 && (s.n_bases >> s1_pos_bits(c)) == 0 &&
+           (c->global_bases >> s1_pos_bits(c)) == 0;
   if (s.fixed_len) return s.fixed_len >= k + 1 && s.fixed_len - k >= 8;
   if (!c->opt("s1_var_fast", 1) || s.max_len < k + 1 || s.max_len - k < 8 || s.n_bases <= s.n_seqs * (uint64_t)k) return false;
   return (double)s.n_bases * 100.0 >= (double)c->opt("s1_var_min_fill", 50) * (double)s.n_seqs * s.max_len;
@@ -811,7 +852,11 @@ bool count_bucket_histogram_fast(mhx_ctx *c, uint32_t k, unsigned long long *his
   const unsigned grid = (unsigned)std::min<uint64_t>(div_ceil(n_slots, 1024 * IT), cus);
   const uint64_t stride_items = (uint64_t)grid * 1024 * IT;
   for (uint32_t half = 0; half < 2; ++half) {
-    if (var)
+    if ((int)k > kCountStreamMaxK)
+      MHX_LAUNCH(c, "count_bucket_hist", (double)s.n_bases / 4,
+                 hipLaunchKernelGGL((k_count_bucket_hist<IT, false, true>), dim3(grid), dim3(1024), 0, c->stream, s.words.as<uint32_t>(), s.fixed_len, per, n_slots, (int)k,
+                                    hist, (uint32_t)(stride_items / per), (uint32_t)(stride_items % per), half, s.start.as<uint64_t>(), s.n_seqs));
+    else if (var)
       MHX_LAUNCH(c, "count_bucket_hist", (double)s.n_bases / 4 + (double)s.n_seqs * 8,
                  hipLaunchKernelGGL((k_count_bucket_hist<IT, true>), dim3(grid), dim3(1024), 0, c->stream, s.words.as<uint32_t>(), 0u, per, n_slots, (int)k, hist,
                                     (uint32_t)(stride_items / per), (uint32_t)(stride_items % per), half, s.start.as<uint64_t>(), s.n_seqs));
@@ -1179,6 +1224,8 @@ bool count_stream_front(mhx_ctx *c, uint32_t k, const S1Plan &plan, uint32_t **b
   // a pass of the memory plan: the lv1-bucket filter sits inside the histogram pre-pass and the generating pass (where the reference's
   // OffsetFiller::IsHandling sits, base_engine.h:106-108) — one scan of the reads per pass, only the kept records ever written
   const uint32_t *keep = c->filter_on ? c->work["filter_bits"].as<uint32_t>() : nullptr;
+  const bool wide = (int)k > kCountStreamMaxK;  // k = 23..27: a window per item
+  if (wide && var) throw Error("count: the wide generator serves reads of one length");
   // digit histograms of the plan's passes (the chained scan wants every pass's bin starts beforehand)
   HiDigits hd;
   hd.n = (int)plan.passes.size();
@@ -1198,9 +1245,15 @@ bool count_stream_front(mhx_ctx *c, uint32_t k, const S1Plan &plan, uint32_t **b
              hipLaunchKernelGGL((k_count_digit_hist_roll<ITH, NPV, VARV>), dim3(fgrid), dim3(256), 0, st, s.words.as<uint32_t>(), s.fixed_len, per, \
                                 n_slots, (int)k, hd, pre_hist, (uint32_t)(stride_items / per), (uint32_t)(stride_items % per),              \
                                 s.start.as<uint64_t>(), s.n_seqs, keep))
+#define MHX_CHW(NPV)                                                                                                                        \
+  MHX_LAUNCH(c, "count_digit_hist", (double)s.n_bases / 4,                                                                                  \
+             hipLaunchKernelGGL((k_count_digit_hist_roll<ITH, NPV, false, true>), dim3(fgrid), dim3(256), 0, st, s.words.as<uint32_t>(), s.fixed_len, per, \
+                                n_slots, (int)k, hd, pre_hist, (uint32_t)(stride_items / per), (uint32_t)(stride_items % per),              \
+                                s.start.as<uint64_t>(), s.n_seqs, keep))
 #define MHX_CH2(NPV)             \
   do {                           \
-    if (var) MHX_CH(NPV, true);  \
+    if (wide) MHX_CHW(NPV);      \
+    else if (var) MHX_CH(NPV, true);  \
     else MHX_CH(NPV, false);     \
   } while (0)
     if (hd.n == 1) MHX_CH2(1);
@@ -1208,6 +1261,7 @@ bool count_stream_front(mhx_ctx *c, uint32_t k, const S1Plan &plan, uint32_t **b
     else if (hd.n == 3) MHX_CH2(3);
     else MHX_CH2(4);
 #undef MHX_CH2
+#undef MHX_CHW
 #undef MHX_CH
   }
   uint64_t n_items = n_slots;  // the records
@@ -1236,12 +1290,16 @@ bool count_stream_front(mhx_ctx *c, uint32_t k, const S1Plan &plan, uint32_t **b
   const CountGenVarT<false> gv{s.words.as<uint32_t>(), s.start.as<uint64_t>(), s.n_seqs, per, (int)k, c->pos_base, pos_bits, tq, tr, nullptr};
   const CountGenVarT<true> gvf{s.words.as<uint32_t>(), s.start.as<uint64_t>(), s.n_seqs, per, (int)k, c->pos_base, pos_bits, tq, tr, keep};
   const bool filter = keep != nullptr;
-  c->gen_first_pass = [g, gf, gv, gvf, var, filter](const OnesweepLaunch &l) {
+  const CountGenWideT<false> gw{s.words.as<uint32_t>(), s.fixed_len, per, (int)k, c->pos_base, pos_bits, tq, tr, nullptr};
+  const CountGenWideT<true> gwf{s.words.as<uint32_t>(), s.fixed_len, per, (int)k, c->pos_base, pos_bits, tq, tr, keep};
+  c->gen_first_pass = [g, gf, gv, gvf, gw, gwf, var, filter, wide](const OnesweepLaunch &l) {
     if (!(l.unit_runs && l.wi == 0)) throw Error("count: the generating pass needs the unit-wide pass on a first-word digit");
 #define MHX_CGEN(SRCT, SRCV)                                                                                                                \
   hipLaunchKernelGGL((k_radix_onesweep_u<3, 8, 3, SRCT, 1, 0>), dim3(l.grid), dim3(kSortThreads), 0, l.stream, SRCV, l.out, l.n, l.ds, l.nbits, \
                      l.bin_start, l.status, l.ticket, l.err, l.tag, l.xcd_units)
-    if (var && filter) MHX_CGEN(CountGenVarT<true>, gvf);
+    if (wide && filter) MHX_CGEN(CountGenWideT<true>, gwf);
+    else if (wide) MHX_CGEN(CountGenWideT<false>, gw);
+    else if (var && filter) MHX_CGEN(CountGenVarT<true>, gvf);
     else if (var) MHX_CGEN(CountGenVarT<false>, gv);
     else if (filter) MHX_CGEN(CountGenT<true>, gf);
     else MHX_CGEN(CountGenT<false>, g);

@@ -621,6 +621,106 @@ struct CountGenT {
     }
   }
 };
+// The same records for k = 23..27 (round 6): prev | edge | next no longer fit a window SHARED by a run of eight items (8 + k + 2 > 32
+// bases), so every item takes its own 64-bit window — k + 3 <= 30 bases — out of the four words its thread's run of eight touches
+// (S1GenBlockedT's scheme).  The (k+1)-mer, the strand bit and prev / next fill the two key words (2 (k + 1) + 7 <= 63 bits): no room
+// for a position tag — read sets below 2^32 bases.  Fixed-length reads, >= 8 items per read.
+constexpr int kCountStreamWideMaxK = 27;
+template <bool FILTER>
+struct CountGenWideT {
+  const uint32_t *seq;
+  uint32_t L, per;  // per = L - k items per read
+  int k;
+  uint64_t pos_base;
+  uint32_t pos_bits;
+  uint32_t tile_q, tile_r;
+  const uint32_t *keep;
+  static constexpr bool kMayDrop = FILTER;
+  __device__ __forceinline__ bool is_record(const Rec<3> &r) const { return !FILTER || (r.w[1] & 63u) != 63u; }
+  template <int NI>
+  __device__ __forceinline__ uint64_t index(uint64_t tile_base, int w, int lane, int j) const {
+    return tile_base + (uint64_t)((w * kWave + lane) * NI + j);
+  }
+  template <int NI, int UT>
+  __device__ __forceinline__ void get_unit(uint64_t unit_base, int w, int lane, uint64_t n, Rec<3> (&rec)[UT][NI]) const {
+    static_assert(NI <= 8, "a run of NI windows starts in at most two different words");
+    constexpr uint32_t kTileItems = kSortThreads * NI;
+    const uint64_t g00 = unit_base + (uint64_t)((w * kWave + lane) * NI);
+    const uint64_t emask = ~0ull << (64 - 2 * (k + 1));
+    uint32_t jt[UT];
+    uint64_t bt[UT];
+    {
+      const uint64_t r = g00 / per;
+      jt[0] = (uint32_t)(g00 - r * per);
+      bt[0] = r * L;
+#pragma unroll
+      for (int t = 1; t < UT; ++t) {
+        uint32_t jn = jt[t - 1] + tile_r;
+        uint64_t bn = bt[t - 1] + (uint64_t)tile_q * L;
+        if (jn >= per) {
+          jn -= per;
+          bn += L;
+        }
+        jt[t] = jn;
+        bt[t] = bn;
+      }
+#pragma unroll
+      for (int t = 0; t < UT; ++t)
+        if (g00 + (uint64_t)t * kTileItems >= n) {
+          jt[t] = 0;
+          bt[t] = 0;
+        }
+    }
+    uint64_t wcur[UT], wnext[UT];
+    uint32_t c[UT][4], nx[UT][4];
+#pragma unroll
+    for (int t = 0; t < UT; ++t) {
+      const uint64_t a0 = bt[t] + jt[t];
+      wcur[t] = (a0 >= 1 ? a0 - 1 : 0) >> 4;
+      wnext[t] = (bt[t] + L - 1) >> 4;
+#pragma unroll
+      for (int x = 0; x < 4; ++x) {
+        c[t][x] = seq[wcur[t] + x];
+        nx[t][x] = seq[wnext[t] + x];  // (the store is padded: also behind the last read)
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < UT; ++t) {
+      const uint64_t g0 = g00 + (uint64_t)t * kTileItems;
+      uint32_t j = jt[t];
+      uint64_t base = bt[t], wc = wcur[t];
+      uint32_t c0 = c[t][0], c1 = c[t][1], c2 = c[t][2], c3 = c[t][3];
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const uint64_t a = base + j;
+        const uint64_t b = a >= 1 ? a - 1 : 0;  // (the store's first base: the window at base 0 shifted down, count_window_addr)
+        const unsigned down = a >= 1 ? 0u : 2u;
+        const bool second = (b >> 4) != wc;
+        const unsigned sh = (unsigned)(b & 15) * 2;
+        const uint32_t x0 = second ? c1 : c0, x1 = second ? c2 : c1, x2 = second ? c3 : c2;
+        const uint64_t win = (((uint64_t)funnel_l(x0, x1, sh) << 32) | funnel_l(x1, x2, sh)) >> down;
+        const uint64_t f = (win << 2) & emask;
+        const uint64_t rc = rc64(f, k + 1);
+        const unsigned prev_b = (unsigned)(win >> 62) & 3u, next_b = (unsigned)(win >> (58 - 2 * k)) & 3u;
+        uint32_t out[3];
+        count_item_from_parts(f, rc, prev_b, next_b, j, L, k, a, pos_base, pos_bits, out);
+        if constexpr (FILTER)
+          if (!s1_bucket_kept(keep, out[0])) out[1] = kS1Dropped;
+        if (g0 + (uint64_t)i < n) {
+          rec[t][i].w[0] = out[0];
+          rec[t][i].w[1] = out[1];
+          rec[t][i].w[2] = out[2];
+        }
+        if (++j == per) {
+          j = 0;
+          base += L;
+          c0 = nx[t][0]; c1 = nx[t][1]; c2 = nx[t][2]; c3 = nx[t][3];
+          wc = wnext[t];
+        }
+      }
+    }
+  }
+};
 // the same records from a library whose reads are not of one length: `per` = max_len - k item slots per read, the slots a shorter read
 // does not fill declined (S1GenVarT's scheme)
 template <bool FILTER>

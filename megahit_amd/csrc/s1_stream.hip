@@ -1007,7 +1007,8 @@ __global__ __launch_bounds__(NT) void k_s1_stream(const uint32_t *__restrict__ i
             uint32_t ebase = 0;
             if (lane == 0) ebase = atomicAdd(&s_agg_cur, tot);
             ebase = __shfl(ebase, 0, kWave);
-            if (ebase + tot > a.agg_cap) {
+            const bool wide_edges = a.c_wpe == 3;  // k >= 24: the (k+1)-mer and the 16-bit multiplicity no longer share 64 bits
+            if (ebase + tot > (wide_edges ? a.agg_cap / 2 : a.agg_cap)) {
               if (lane == 0) atomicOr(a.err, 1u);
             } else {
               unsigned long long *const eout = reinterpret_cast<unsigned long long *>(a.agg_raw + (size_t)blockIdx.x * a.agg_cap);
@@ -1017,7 +1018,9 @@ __global__ __launch_bounds__(NT) void k_s1_stream(const uint32_t *__restrict__ i
                 if ((solid_bits >> it) & 1u) {
                   const uint32_t cnt = wc[it];
                   const unsigned long long edge = ((unsigned long long)bi << (64 - pbits)) | (rem ? (unsigned long long)wk[it] << mer_sh : 0ull);
-                  eout[at++] = edge | (cnt > MHX_MAX_MUL ? (unsigned long long)MHX_MAX_MUL : cnt);
+                  const uint32_t mul = cnt > MHX_MAX_MUL ? (uint32_t)MHX_MAX_MUL : cnt;
+                  if (wide_edges) reinterpret_cast<uint4 *>(eout)[at++] = make_uint4((uint32_t)(edge >> 32), (uint32_t)edge, mul, 0u);  // (words in edge order)
+                  else eout[at++] = edge | mul;
                 }
             }
           }
@@ -1350,8 +1353,12 @@ void s1_stream_launch(mhx_ctx *c, const char *name, double bytes, const S1Stream
     if (l.tags) MHX_STREAM(AGGV, NTV, LOGV, true, GIANTV, COUNTV); \
     else MHX_STREAM(AGGV, NTV, LOGV, false, GIANTV, COUNTV);       \
   } while (0)
-  if (l.key64) {  // local keys of more than 32 bits (stage 1 at k = 23..29: no aggregated items there)
-    if (l.count || l.agg || l.half) throw Error("s1_stream_launch: 64-bit local keys serve stage 1 without aggregated items on full tables");
+  if (l.key64 && l.count) {  // count at k = 23..27 (or under a forced narrow prefix): no position tags in those records
+    if (!l.agg || l.half || l.tags) throw Error("s1_stream_launch: count with 64-bit local keys runs on full tables, edge regions, no position tags");
+    if (l.giant) MHX_STREAM_K(true, kStreamThreads, 13, false, true, true, true);
+    else MHX_STREAM_K(true, kStreamThreads, 13, false, false, true, true);
+  } else if (l.key64) {  // local keys of more than 32 bits (stage 1 at k = 23..29: no aggregated items there)
+    if (l.agg || l.half) throw Error("s1_stream_launch: 64-bit local keys serve stage 1 without aggregated items on full tables");
     if (l.giant && l.tags) MHX_STREAM_K(false, kStreamThreads, 13, true, true, false, true);
     else if (l.giant) MHX_STREAM_K(false, kStreamThreads, 13, false, true, false, true);
     else if (l.tags) MHX_STREAM_K(false, kStreamThreads, 13, true, false, false, true);

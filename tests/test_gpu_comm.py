@@ -193,7 +193,8 @@ def load_fixed_reads(r, e):
     (3, 21, 2, True, {"dist_max_items": 30000}, True),                   # bucket-range passes: the filter inside every rank's generating pass
     (3, 21, 2, True, {"s1_stream_bits": 19, "s1_stream_fill": 40}, True),  # three pre-sort passes, overflowing tables, three senders per bucket
     (2, 21, 2, True, {"s1_stream_probes": 0}, False),                    # the owners' streaming gives up -> the classic exchange redoes the pass
-    (2, 21, 2, True, {"dist_presort": 0}, False), (2, 23, 2, True, None, False), (2, 21, 16, True, None, False),
+    (2, 21, 2, True, {"dist_presort": 0}, False), (2, 28, 2, True, None, False), (2, 21, 16, True, None, False),
+    (2, 23, 2, True, None, True), (3, 27, 2, True, {"s1_giant_min": 64}, True),     # k = 23..27: a window per item, 64-bit table keys, three-word edges
     (3, 21, 3, True, None, True), (2, 22, 4, True, {"s1_stream_fill": 40}, True),   # min count 3..15: per-char counters at the owners
     (3, 21, 2, True, {"s1_giant_min": 64}, True), (2, 21, 3, True, {"s1_giant_min": 100, "s1_pos_bits": 12}, True),  # giant buckets: slices cut per sender
 ])

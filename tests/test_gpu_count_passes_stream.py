@@ -60,8 +60,10 @@ def check(got, want):
 
 @pytest.mark.parametrize("opts", [dict(), dict(s1_stream_fill=40), dict(s1_pos_bits=12), dict(s1_stream_bits=19), dict(s1_stream_sub0=2)],
                          ids=lambda o: ",".join("%s=%d" % kv for kv in o.items()) or "default")
-@pytest.mark.parametrize("kind,k,m,n_passes", [("pe100", 21, 2, 3), ("repeats100", 21, 2, 4), ("short30", 21, 2, 2), ("pe100", 17, 1, 3), ("repeats100", 22, 2, 5), ("repeats100", 21, 3, 3)])
+@pytest.mark.parametrize("kind,k,m,n_passes", [("pe100", 21, 2, 3), ("repeats100", 21, 2, 4), ("short30", 21, 2, 2), ("pe100", 17, 1, 3), ("repeats100", 22, 2, 5), ("repeats100", 21, 3, 3), ("pe100", 27, 2, 3), ("repeats100", 24, 3, 2)])
 def test_count_passes_on_the_streaming_design(engine, kind, k, m, n_passes, opts):
+    if k > 22 and "s1_pos_bits" in opts:
+        pytest.skip("k = 23..27: the two key words have no room for a position tag (the tile path serves tagged read sets there)")
     pkg = ob.Package(fixed_library(kind, seed=k * 5 + m), reverse=True)
     want = ob.count(pkg, k, m)
     got, stats_h, per_pass, ranges = run_passes(engine, pkg, k, m, n_passes, opts)
@@ -102,8 +104,8 @@ def test_a_pass_that_gives_up_continues_on_the_tile_path(engine):
 
 def test_shapes_outside_the_streaming_design_still_take_the_tile_path_in_passes(engine):
     pkg = ob.Package(fixed_library("pe100", seed=5), reverse=True)
-    want = ob.count(pkg, 23, 3)
-    got, stats_h, per_pass, _ = run_passes(engine, pkg, 23, 3, 3, {})
+    want = ob.count(pkg, 29, 3)
+    got, stats_h, per_pass, _ = run_passes(engine, pkg, 29, 3, 3, {})
     assert "count_bucket_hist" not in stats_h
     assert all("count_digit_hist" not in st for st, _ in per_pass)
     check(got, want)

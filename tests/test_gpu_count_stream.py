@@ -13,7 +13,7 @@ from test_gpu_round3_knobs import fixed_library
 
 pytestmark = pytest.mark.gpu
 
-RESET = dict(count_stream=1, s1_stream_fill=7168, s1_pos_bits=0, s1_stream_bits=0, s1_stream_sub0=-1, s1_stream_probes=1024, s1_giant_min=262144, count_giant=1)
+RESET = dict(count_stream=1, s1_stream_fill=7168, s1_pos_bits=0, s1_stream_bits=0, s1_stream_sub0=-1, s1_stream_probes=1024, s1_giant_min=262144, count_giant=1, count_stream_wide=1)
 
 
 def check_count(engine, pkg, k, m, opts, expect_stream):
@@ -56,7 +56,21 @@ def test_count_on_the_bucket_streaming(engine, kind, k, m, opts):
     check_count(engine, pkg, k, m, opts, expect_stream)
 
 
-@pytest.mark.parametrize("k,m", [(23, 2), (21, 16)])
+@pytest.mark.parametrize("opts", [dict(), dict(s1_stream_fill=40), dict(s1_stream_bits=19), dict(s1_stream_sub0=2), dict(s1_giant_min=64), dict(count_stream_wide=0)],
+                         ids=lambda o: ",".join("%s=%d" % kv for kv in o.items()) or "default")
+@pytest.mark.parametrize("kind,k,m", [("pe100", 23, 2), ("repeats100", 24, 2), ("pe100", 25, 3), ("repeats100", 27, 2), ("pe100", 27, 1), ("pe100", 26, 2)])
+def test_count_at_k_23_to_27_on_the_bucket_streaming(engine, kind, k, m, opts):
+    """round 6: a window per item (CountGenWideT), 64-bit table keys, three-word edges from k = 24 (16-byte region entries); reads of one
+    length, no position tags"""
+    reads = fixed_library(kind, seed=k * 7 + m)
+    pkg = ob.Package(reads, reverse=True)
+    try:
+        check_count(engine, pkg, k, m, opts, expect_stream=opts.get("count_stream_wide", 1) == 1)
+    finally:
+        engine.set_option("count_stream_wide", 1)
+
+
+@pytest.mark.parametrize("k,m", [(28, 2), (21, 16)])
 def test_shapes_the_stream_form_does_not_take(engine, k, m):
     reads = fixed_library("pe100", seed=3)
     check_count(engine, ob.Package(reads, reverse=True), k, m, {}, False)

@@ -47,7 +47,7 @@ def main():
         return f
 
     cases = [("count k=21 m=2", step_count(21, 2), COUNT_BUFS, {"count_stream": 0}), ("count k=21 m=3", step_count(21, 3), COUNT_BUFS, {"count_stream": 0}),
-             ("count k=27 m=2", step_count(27, 2), COUNT_BUFS, None), ("count k=27 m=3", step_count(27, 3), COUNT_BUFS, None),
+             ("count k=27 m=2", step_count(27, 2), COUNT_BUFS, {"count_stream": 0}), ("count k=27 m=3", step_count(27, 3), COUNT_BUFS, {"count_stream": 0}),
              ("read2sdbg k=27 m=2", step_r2s(27, 2), SDBG_BUFS + ((lib.BUF_IS_SOLID, np.uint64), (lib.BUF_MUL_HIST, np.int64)), {"s1_stream_wide": 0}),
              ("read2sdbg k=27 m=1", step_r2s(27, 1), SDBG_BUFS, None)]
     if only:
