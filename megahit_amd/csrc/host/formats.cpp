@@ -63,19 +63,42 @@ void PackedSeqs::append_string(const char *s, uint32_t len, bool rev) {
     append_string("A", 1, false);
     return;
   }
-  uint64_t pos = start.back();
-  words.resize((pos + len + 15) / 16, 0);
-  for (uint32_t i = 0; i < len; ++i) {
-    char ch = s[rev ? len - 1 - i : i];
-    uint32_t c;  // "ACGTNacgtn" -> 0123201232 (sequence_package.h:80-82)
-    switch (ch) {
-      case 'C': case 'c': c = 1; break;
-      case 'G': case 'g': case 'N': case 'n': c = 2; break;
-      case 'T': case 't': c = 3; break;
-      default: c = 0;
+  // "ACGTNacgtn" -> 0123201232, anything else 0 (sequence_package.h:80-82); a table look-up per base and one store per 16 bases (the
+  // per-base read-modify-write of round 1 took 0.3 s for the 70 M contig bases of a k-list step: most of seq2sdbg's wall time)
+  static const struct Lut {
+    uint8_t c[256];
+    Lut() {
+      memset(c, 0, sizeof c);
+      c[(unsigned char)'C'] = c[(unsigned char)'c'] = 1;
+      c[(unsigned char)'G'] = c[(unsigned char)'g'] = c[(unsigned char)'N'] = c[(unsigned char)'n'] = 2;
+      c[(unsigned char)'T'] = c[(unsigned char)'t'] = 3;
     }
-    words[(pos + i) >> 4] |= c << (30 - 2 * ((pos + i) & 15));
+  } lut;
+  uint64_t pos = start.back();
+  if (words.capacity() < (pos + len + 15) / 16) words.reserve(std::max<size_t>((pos + len + 15) / 16, words.capacity() * 2));
+  words.resize((pos + len + 15) / 16, 0);
+  uint32_t *w = words.data();
+  const unsigned char *u = reinterpret_cast<const unsigned char *>(s);
+  uint32_t i = 0;
+  uint64_t p = pos;
+  auto code = [&](uint32_t j) -> uint32_t { return lut.c[u[rev ? len - 1 - j : j]]; };
+  for (; i < len && (p & 15); ++i, ++p) w[p >> 4] |= code(i) << (30 - 2 * (p & 15));
+  if (rev) {
+    for (; i + 16 <= len; i += 16, p += 16) {
+      const unsigned char *q = u + (len - 1 - i);  // bases i .. i + 15 are q[0], q[-1], ..., q[-15]
+      uint32_t x = 0;
+      for (int j = 0; j < 16; ++j) x = (x << 2) | lut.c[q[-j]];
+      w[p >> 4] = x;
+    }
+  } else {
+    for (; i + 16 <= len; i += 16, p += 16) {
+      const unsigned char *q = u + i;
+      uint32_t x = 0;
+      for (int j = 0; j < 16; ++j) x = (x << 2) | lut.c[q[j]];
+      w[p >> 4] = x;
+    }
   }
+  for (; i < len; ++i, ++p) w[p >> 4] |= code(i) << (30 - 2 * (p & 15));
   start.push_back(pos + len);
 }
 
@@ -521,8 +544,98 @@ void write_edges_unsorted(const std::string &prefix, uint32_t k, uint32_t wpe, c
   if (!meta) fatal("write error on %s.edges.info", prefix.c_str());
 }
 
+// a plain (not gzip'ed) contig file, mapped: header lines and sequence lines found with memchr, one-line sequences packed straight out
+// of the mapping (contig_reader.h:52-119 semantics, as the stream parser below)
+static int64_t read_contigs_mapped(const TextFile &tf, PackedSeqs *pkg, std::vector<uint16_t> *mult, unsigned min_len, unsigned k_from, unsigned k_to,
+                                   bool reverse, unsigned discard_flags) {
+  const bool extend_loop = k_from < k_to;
+  const char *p = tf.data, *end = tf.data + tf.size;
+  int64_t n_read = 0;
+  std::string seq;
+  auto line_end = [&](const char *q) -> const char * {
+    const char *e = static_cast<const char *>(memchr(q, '\n', (size_t)(end - q)));
+    return e ? e : end;
+  };
+  // skip to the first header
+  while (p < end && *p != '>') p = std::min(end, line_end(p) + 1);
+  while (p < end) {
+    const char *he = line_end(p);  // header: [p + 1, he)
+    const char *hs = p + 1, *hz = he;
+    while (hz > hs && (hz[-1] == '\r')) --hz;
+    const char *sp = hs;
+    while (sp < hz && *sp != ' ' && *sp != '\t') ++sp;
+    while (sp < hz && (*sp == ' ' || *sp == '\t')) ++sp;
+    const char *comment = sp;
+    const size_t clen = (size_t)(hz - sp);
+    // sequence lines up to the next header
+    const char *q = std::min(end, he + 1);
+    const char *s0 = nullptr;
+    size_t slen = 0;
+    bool multi = false;
+    while (q < end && *q != '>') {
+      const char *le = line_end(q);
+      size_t n = (size_t)(le - q);
+      while (n && q[n - 1] == '\r') --n;
+      if (n) {
+        if (!s0) {
+          s0 = q;
+          slen = n;
+        } else {
+          if (!multi) {
+            seq.assign(s0, slen);
+            multi = true;
+          }
+          seq.append(q, n);
+        }
+      }
+      q = std::min(end, le + 1);
+    }
+    if (multi) {
+      s0 = seq.data();
+      slen = seq.size();
+    }
+    p = q;
+    if (slen < min_len) continue;
+    const unsigned flag = clen > 5 ? (unsigned)(comment[5] - '0') : 0;  // "flag=x multi=..." (contig_reader.h:66)
+    if (discard_flags & flag) continue;                                // contig_reader.h:67-70
+    if (extend_loop && (flag & 2u)) {                                  // contig_flag::kLoop
+      if (slen < k_to + 1u) continue;
+      if (!multi) seq.assign(s0, slen);
+      for (unsigned i = k_from; i < k_to; ++i) seq.push_back(seq[i]);
+      s0 = seq.data();
+      slen = seq.size();
+    }
+    pkg->append_string(s0, (uint32_t)slen, reverse);
+    double m = 0;
+    if (clen > 13) {
+      char buf[48];
+      const size_t n = std::min(clen - 13, sizeof buf - 1);
+      memcpy(buf, comment + 13, n);
+      buf[n] = 0;
+      m = atof(buf);
+    }
+    mult->push_back((uint16_t)(m + .5));  // GetMultiplicity<mul_t>, contig_reader.h:111-119
+    ++n_read;
+  }
+  return n_read;
+}
+
 int64_t read_contigs(const std::string &fasta, PackedSeqs *pkg, std::vector<uint16_t> *mult, unsigned min_len, unsigned k_from,
                      unsigned k_to, bool reverse, unsigned discard_flags) {
+  if (!getenv("MHX_CONTIG_STREAM_PARSER")) {
+    TextFile tf = open_text_file(fasta);
+    if (tf.map) {  // (a gzip'ed file comes inflated into tf.owned: parsed the same way)
+      const int64_t n = read_contigs_mapped(tf, pkg, mult, min_len, k_from, k_to, reverse, discard_flags);
+      tf.close();
+      return n;
+    }
+    if (!tf.owned.empty() || tf.size == 0) {
+      const int64_t n = read_contigs_mapped(tf, pkg, mult, min_len, k_from, k_to, reverse, discard_flags);
+      tf.close();
+      return n;
+    }
+    tf.close();
+  }
   gzFile f = gzopen(fasta.c_str(), "r");
   if (!f) fatal("Cannot open %s", fasta.c_str());
   const bool extend_loop = k_from < k_to;

@@ -911,26 +911,43 @@ int main_seq2sdbg(int argc, char **argv) {
       info("Done. Time elapsed: %.4f", t.lap());
     }
   }
-  // contigs (reversed; loop contigs extended k_from -> k), bubble, addi, local: seq_to_sdbg.cpp:449-503
-  mhxio::PackedSeqs contigs;
-  std::vector<uint16_t> cmult;
-  auto read_one = [&](const std::string &f, unsigned kf, unsigned kt) {
-    if (f.empty()) return;
-    int64_t n = mhxio::read_contigs(f, &contigs, &cmult, k + 1, kf, kt, true);
-    info("Read %lld contigs from %s.", (long long)n, f.c_str());
+  // contigs (reversed; loop contigs extended k_from -> k), bubble, addi, local: seq_to_sdbg.cpp:449-503.  Every file is parsed and packed
+  // by a thread of its own (round 6: the sequential parse was most of this sub-program's wall time) and appended on the device in the
+  // reference's order
+  struct CtgFile {
+    std::string path;
+    unsigned kf, kt;
+    mhxio::PackedSeqs seqs;
+    std::vector<uint16_t> mult;
+    int64_t n = 0;
+  };
+  std::vector<CtgFile> files;
+  auto want = [&](const std::string &f, unsigned kf, unsigned kt) {
+    if (!f.empty()) files.push_back(CtgFile{f, kf, kt, {}, {}, 0});
   };
   if (!o.get("contig").empty()) {
-    read_one(o.get("contig"), k_from, k);
-    read_one(o.get("bubble"), 0, 0);
+    want(o.get("contig"), k_from, k);
+    want(o.get("bubble"), 0, 0);
   }
-  read_one(o.get("addi_contig"), 0, 0);
-  read_one(o.get("local_contig"), 0, 0);
-  if (contigs.n_seqs()) {
+  want(o.get("addi_contig"), 0, 0);
+  want(o.get("local_contig"), 0, 0);
+  {
+    std::vector<std::thread> th;
+    for (const CtgFile &cf : files)  // (a missing file is reported from this thread, as every other failure of the sub-program)
+      if (access(cf.path.c_str(), R_OK) != 0) fatal("Cannot open %s", cf.path.c_str());
+    for (size_t i = 1; i < files.size(); ++i)
+      th.emplace_back([&files, i, k]() { files[i].n = mhxio::read_contigs(files[i].path, &files[i].seqs, &files[i].mult, k + 1, files[i].kf, files[i].kt, true); });
+    if (!files.empty()) files[0].n = mhxio::read_contigs(files[0].path, &files[0].seqs, &files[0].mult, k + 1, files[0].kf, files[0].kt, true);
+    for (std::thread &t_ : th) t_.join();
+  }
+  for (CtgFile &cf : files) {
+    info("Read %lld contigs from %s.", (long long)cf.n, cf.path.c_str());
+    if (!cf.seqs.n_seqs()) continue;
     if (loaded)
-      CK(mhx_append_sequences(c, contigs.words.data(), contigs.words.size(), contigs.n_seqs(), 0, contigs.start.data(), cmult.data()));
+      CK(mhx_append_sequences(c, cf.seqs.words.data(), cf.seqs.words.size(), cf.seqs.n_seqs(), 0, cf.seqs.start.data(), cf.mult.data()));
     else {
-      CK(mhx_load_sequences(c, contigs.words.data(), contigs.words.size(), contigs.n_seqs(), 0, contigs.start.data()));
-      CK(mhx_load_multiplicity(c, cmult.data(), cmult.size()));
+      CK(mhx_load_sequences(c, cf.seqs.words.data(), cf.seqs.words.size(), cf.seqs.n_seqs(), 0, cf.seqs.start.data()));
+      CK(mhx_load_multiplicity(c, cf.mult.data(), cf.mult.size()));
     }
     loaded = true;
   }

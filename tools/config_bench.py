@@ -89,7 +89,7 @@ def klist():
                 gpu_s = next((v for n, v in phases.items() if n.startswith("GPU seq2sdbg done")), None)
                 items = int(re.search(r"\((\d+) items\)", next(n for n in phases if n.startswith("GPU seq2sdbg done"))).group(1))
                 r = summarise(kernels)
-                r.update(wall_s=round(wall, 3), gpu_stage_s=gpu_s, items=items, item_bytes=4 * ((2 * k + 20 + 31) // 32 + 1) // 2 * 2,
+                r.update(wall_s=round(wall, 3), phases_s=phases, gpu_stage_s=gpu_s, items=items, item_bytes=4 * ((2 * k + 20 + 31) // 32 + 1) // 2 * 2,
                          M_items_per_s=round(items / r["kernel_ms_total"] / 1e3, 1),
                          bit_identical_to_reference=canon.digest_sdbg(o) == tk.KL["cases"]["k%d" % k]["digest"])
                 ent[label] = r
