@@ -93,8 +93,7 @@ int mhx_set_option(mhx_ctx *, const char *name, long long value);
  *   s1_gen_blocked (0)     1: the generating first sort pass of stage 1 gives every thread consecutive items and requests the
  *                          window words of a whole unit up front (S1GenBlocked) instead of one window load per item
  *   s1_digit_hist_preload (0) 1: the same in the digit-histogram pre-pass
- *   s1_stream_half (0)     1: two 512-thread workgroups with 4096-slot tables per CU in the bucket streaming instead of one
- *                          with 1024 threads and 8192 slots (a bucket whose keys overflow a table is split inside the kernel)
+ * (Round 6: s1_stream_half and s1_marks_list are gone with their code: slower on every box for two rounds.)
  * (Round 4: s1_stream_prefetch / s1_stream_next_bucket / s1_stream_used_list / s1_stream_read_first / s1_stream_unroll are gone:
  *  the bucket streaming always has its next trip's loads in flight, fetches the next bucket's bounds during the current bucket and
  *  walks its table once; setting them changes nothing.)

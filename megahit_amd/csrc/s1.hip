@@ -54,17 +54,6 @@ __global__ __launch_bounds__(256) void k_collect_marks(const uint8_t *__restrict
   for (uint32_t mm = mask; mm; mm &= mm - 1) out[s_base + at++] = p0 + (uint64_t)__builtin_ctz(mm);
 }
 // routed marks (global positions of non-solid occurrences in the local reads) -> local byte map
-// the marks the bucket streaming left in its workgroups' regions (positions, 8 bytes each) -> the byte map (one GPU, s1_marks_list = 1:
-// an experiment of round 5, see launch_partial)
-__global__ __launch_bounds__(256) void k_apply_mark_regions(const unsigned long long *__restrict__ raw, uint32_t cap, const uint32_t *__restrict__ counts,
-                                                            uint8_t *__restrict__ bytes, uint64_t n_bytes) {
-  const uint32_t n = counts[blockIdx.x];
-  const unsigned long long *src = raw + (size_t)blockIdx.x * cap;
-  for (uint32_t i = blockIdx.y * 256 + threadIdx.x; i < n; i += gridDim.y * 256) {
-    const unsigned long long p = src[i];
-    if (p < n_bytes) bytes[p] = 1;
-  }
-}
 __global__ void k_apply_marks(const unsigned long long *__restrict__ pos, uint64_t n, uint64_t pos_base, uint64_t n_local, uint8_t *__restrict__ bytes,
                               uint32_t *__restrict__ bad) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -553,8 +542,9 @@ struct S1Stage {
     const uint32_t pfx_mask = plan.seg_bits >= 32 ? 0xFFFFFFFFu : ~(0xFFFFFFFFu >> plan.seg_bits);
     const uint32_t eq_mask1 = (kmer_bits > 32 ? ~(0xFFFFFFFFu >> (kmer_bits - 32)) : 0u) | 63u;
     const bool agg_on = agg && mode != 2;
-    // s1_stream_half: two 512-thread workgroups with 4096-slot tables per CU instead of one with 1024 threads and 8192 slots
-    const bool half = plan.stream && c->opt("s1_stream_half", 0) != 0 && kmer_bits - plan.seg_bits + 6 <= 32;
+    // (round 6: s1_stream_half — two 512-thread workgroups with 4096-slot tables per CU — and s1_marks_list — the marks as a list applied by a
+    //  kernel of their own — lost on every box for two rounds and are gone with their code: profiles/r03_ab_*, r05_ab_marks_list.jsonl)
+    const bool half = false;
     const uint64_t cus = c->n_cus > 0 ? (uint64_t)c->n_cus : 256;
     const unsigned grid = (unsigned)std::min<uint64_t>(n_work, plan.stream ? (half ? 2 * cus : cus) : (per == 4 ? 256 * 6 : 256 * 3));
     // per-workgroup output regions in the spare sort buffer (S*4 >= 12 bytes per record, outputs are 8-byte entries)
@@ -572,13 +562,7 @@ struct S1Stage {
     unsigned long long *mraw = nullptr;
     uint32_t *mcounts = nullptr;
     uint32_t mcap = 0;
-    // s1_marks_list (one GPU; off by default): the marks taken from the table leave the streaming kernel the same way and are applied
-    // to the byte map by a kernel of their own (k_apply_mark_regions) instead of being stored byte by byte from inside the inserts.
-    // Measured (profiles/r05_ab_marks_list.jsonl): k_s1_stream 7.89 -> 5.90 ms, but the 1.3 x 10^8 random byte stores then cost 2.94 ms
-    // on their own (8.3 GB of partial lines; the multi-GPU path pays 1.2 ms because its list went through an 8-bit pass over the top
-    // position bits first, which a single GPU would have to add): 35.0 -> 36.0 ms per step.  Kept as a knob, not as the default.
-    list_local = !sparse && mode == 1 && plan.stream && m <= 2 && solid_bytes != nullptr && c->opt("s1_stream_direct", 1) != 0 &&
-                 c->opt("s1_stream_half", 0) == 0 && c->opt("s1_marks_list", 0) != 0;
+    list_local = false;
     if ((sparse || list_local) && mode != 2) {
       mraw = reinterpret_cast<unsigned long long *>(spare);
       mcap = region;
@@ -700,10 +684,6 @@ struct S1Stage {
     MHX_HIP(hipStreamSynchronize(st));
     if (e) return e;
     if (h_giant[0]) c->last_s1_plan += " [" + std::to_string(h_giant[0]) + " giant buckets in slices]";
-    if (list_local)
-      MHX_LAUNCH(c, "apply_marks", (double)n_items * 0.1 * 9,
-                 hipLaunchKernelGGL(k_apply_mark_regions, dim3(seg_grid, 16), dim3(256), 0, st, reinterpret_cast<const unsigned long long *>(spare), seg_mcap,
-                                    c->work["s1_mark_counts"].as<uint32_t>(), solid_bytes, (uint64_t)((n_words64 + 1) * 64)));
     if (sparse) {  // pack the workgroups' mark regions (they live in the spare sort buffer) behind the earlier passes' marks
       for (uint32_t v : h_mcounts) seg_marks += v;
       unsigned long long *dense = grow_preserving(c, c->work["s1_marks"], (marks_prev + seg_marks) * 8 + 64, marks_prev * 8).as<unsigned long long>();

@@ -1372,8 +1372,7 @@ void s1_stream_launch(mhx_ctx *c, const char *name, double bytes, const S1Stream
     if (l.agg) MHX_STREAM_T(true, kStreamThreads, 13, true, false);
     else MHX_STREAM_T(false, kStreamThreads, 13, true, false);
   } else if (l.half) {
-    if (l.agg) MHX_STREAM_T(true, 512, 12, false, false);
-    else MHX_STREAM_T(false, 512, 12, false, false);
+    throw Error("s1_stream_launch: the half-size tables were retired in round 6");
   } else {
     if (l.agg) MHX_STREAM_T(true, kStreamThreads, 13, false, false);
     else MHX_STREAM_T(false, kStreamThreads, 13, false, false);

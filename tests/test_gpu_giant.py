@@ -18,7 +18,7 @@ from test_gpu_sdbg import check_sdbg
 
 pytestmark = pytest.mark.gpu
 
-RESET = dict(s1_marks_list=0, s1_giant=1, s1_giant_min=262144, s1_stream_fill=7168, s1_pos_bits=0, s1_stream_bits=0, s1_stream_sub0=-1, s1_stream_direct=1)
+RESET = dict(s1_giant=1, s1_giant_min=262144, s1_stream_fill=7168, s1_pos_bits=0, s1_stream_bits=0, s1_stream_sub0=-1, s1_stream_direct=1)
 
 
 def run(engine, reads, k, m, opts, expect_giants=None, expect_found=None):
@@ -52,7 +52,7 @@ def run(engine, reads, k, m, opts, expect_giants=None, expect_found=None):
 
 
 @pytest.mark.parametrize("opts", [dict(s1_giant_min=64), dict(s1_giant_min=1000), dict(s1_giant_min=64, s1_stream_fill=40), dict(s1_giant_min=64, s1_pos_bits=12),
-                                  dict(s1_giant_min=64, s1_stream_bits=19), dict(s1_giant_min=300, s1_stream_sub0=2), dict(s1_giant=0, s1_giant_min=64), dict(s1_giant_min=64, s1_marks_list=1)],
+                                  dict(s1_giant_min=64, s1_stream_bits=19), dict(s1_giant_min=300, s1_stream_sub0=2), dict(s1_giant=0, s1_giant_min=64)],
                          ids=lambda o: ",".join("%s=%d" % kv for kv in o.items()))
 @pytest.mark.parametrize("kind,k", [("pe100", 21), ("repeats100", 21), ("lowcomplex", 21), ("var", 21), ("repeats100", 22), ("pe100", 17), ("lowcomplex", 16)])
 def test_small_threshold(engine, kind, k, opts, monkeypatch):

@@ -3,7 +3,6 @@ of them on) reproduce the oracle — Read2SdbgS1 / S2 of the reference (src/sort
 read_to_sdbg_s2.cpp:521-614) — on fixed-length libraries, where the generating first sort pass runs:
   s1_gen_blocked         consecutive items per thread in the generating pass, window words of a whole unit requested up front
   s1_digit_hist_preload  the same in the digit-histogram pre-pass
-  s1_stream_half         two 512-thread workgroups with 4096-slot tables per CU in the bucket streaming
   s1_stream_read_first   a plain LDS read in front of the compare-and-swap
   sort_rank_uniform      one LDS atomic per record where all records of a wavefront instruction agree on the bits sorted so far
   s1_stream_prefetch     the bucket streaming requests the records of its next trip before it inserts those of the current one"""
@@ -17,7 +16,7 @@ from test_gpu_sdbg import check_sdbg
 
 pytestmark = pytest.mark.gpu
 
-KNOBS = ["s1_gen_blocked", "s1_digit_hist_preload", "s1_stream_half", "s1_stream_read_first", "sort_rank_uniform", "s1_stream_prefetch"]
+KNOBS = ["s1_gen_blocked", "s1_digit_hist_preload", "s1_stream_read_first", "sort_rank_uniform", "s1_stream_prefetch"]
 SETTINGS = [{}] + [{k: 1} for k in KNOBS] + [{k: 1 for k in KNOBS}]
 
 

@@ -15,7 +15,7 @@ from test_gpu_sdbg import check_sdbg
 pytestmark = pytest.mark.gpu
 
 SETTINGS = [dict(s1_gen_roll=1, s1_digit_hist_roll=1), dict(s1_gen_roll=0, s1_digit_hist_roll=1), dict(s1_gen_roll=1, s1_digit_hist_roll=0),
-            dict(s1_gen_roll=0, s1_digit_hist_roll=0), dict(s1_marks_list=1)]  # s1_marks_list = 1: the marks leave k_s1_stream as a list (regions) and are applied by a kernel of their own
+            dict(s1_gen_roll=0, s1_digit_hist_roll=0)]
 
 
 @pytest.mark.parametrize("setting", SETTINGS, ids=lambda s_: ",".join("%s=%d" % kv for kv in s_.items()))
@@ -45,7 +45,6 @@ def test_stage1_front_forms(engine, kind, k, m, setting):
         engine.set_option("s1_gen_blocked", engine_default(engine, "s1_gen_blocked"))
         engine.set_option("s1_gen_roll", 1)
         engine.set_option("s1_digit_hist_roll", 1)
-        engine.set_option("s1_marks_list", 0)
 
 
 @pytest.mark.parametrize("roll", [0, 1])

@@ -24,7 +24,7 @@ from test_gpu_sdbg import check_sdbg
 pytestmark = pytest.mark.gpu
 
 DEFAULTS = dict(s1_stream_bits=0, s1_stream_sub0=-1, s1_stream_prefetch=0, s1_stream_fill=7168, s1_stream_probes=1024, s1_stream_max=40000,
-                s1_stream_sub_max=1, s1_stream_half=0, s1_stream_direct=1, s1_pos_bits=0, s1_stream=1, s1_seg=1, s1_filter_in_gen=1,
+                s1_stream_sub_max=1, s1_stream_direct=1, s1_pos_bits=0, s1_stream=1, s1_seg=1, s1_filter_in_gen=1,
                 s1_stream_unroll=4, s1_gen_blocked=1)
 
 
@@ -73,7 +73,7 @@ def test_every_prefix_width_and_sub_round_count(engine, kind, k, m, bits, sub0, 
         check_read2sdbg(engine, pkg, k, m, plan_has=["stream p%d " % eff, "%d passes" % ((eff + 7) // 8)])
 
 
-@pytest.mark.parametrize("opts", [dict(s1_stream_fill=1), dict(s1_stream_fill=3, s1_stream_prefetch=1), dict(s1_stream_fill=16, s1_stream_half=1),
+@pytest.mark.parametrize("opts", [dict(s1_stream_fill=1), dict(s1_stream_fill=3, s1_stream_prefetch=1), dict(s1_stream_fill=16),
                                   dict(s1_stream_fill=5, s1_stream_direct=0), dict(s1_stream_fill=2, s1_stream_sub0=2, s1_stream_bits=18),
                                   dict(s1_stream_probes=0)],
                          ids=lambda o: ",".join("%s=%d" % kv for kv in sorted(o.items())))

@@ -92,7 +92,7 @@ def test_nothing_is_written_when_no_configuration_reproduces_the_reference(tmp_p
 
 def test_the_committed_tuning_file_parses_and_names_known_knobs():
     import bench
-    known = {"sort_unit_runs", "sort_rank_uniform", "s1_gen_blocked", "s1_digit_hist_preload", "s1_stream_read_first", "s1_stream_half", "s1_stream_used_list",
+    known = {"sort_unit_runs", "sort_rank_uniform", "s1_gen_blocked", "s1_digit_hist_preload", "s1_stream_read_first", "s1_stream_used_list",
              "s1_stream_unroll", "s1_stream_prefetch", "s1_stream_next_bucket"}
     got = bench.tuned_defaults()
     assert set(got) <= known, set(got) - known
