@@ -710,12 +710,53 @@ uint64_t mhx_buffer_bytes(const mhx_ctx *c, int which) {
   auto it = c->results.find(which);
   return it == c->results.end() ? 0 : it->second.used;
 }
+// device -> pageable host memory through the two pinned staging buffers of upload_pinned: the copy of chunk i + 1 off the device runs while
+// four threads move chunk i from its staging buffer to the destination (whose pages they touch for the first time on the way).  A plain
+// hipMemcpy into a fresh std::vector ran at ~1 GB/s: 2.4 GB of solid edges at 100 M reads were 3 s of `count`'s 4.7 s (round 6).
+static void download_pinned(mhx_ctx *c, void *h_dst, const void *d_src, size_t bytes) {
+  hipStream_t st = c->stream;
+  constexpr size_t kChunk = 32u << 20;
+  constexpr int kThreads = 4;
+  if (!c->pinned[0]) {
+    for (int i = 0; i < 2; ++i) {
+      MHX_HIP(hipHostMalloc(&c->pinned[i], kChunk, hipHostMallocDefault));
+      MHX_HIP(hipEventCreateWithFlags(&c->pinned_free[i], hipEventDisableTiming));
+    }
+  }
+  const char *src = static_cast<const char *>(d_src);
+  char *dst = static_cast<char *>(h_dst);
+  const size_t n_chunks = (bytes + kChunk - 1) / kChunk;
+  auto issue = [&](size_t i) {
+    const size_t off = i * kChunk, len = std::min(kChunk, bytes - off);
+    MHX_HIP(hipMemcpyAsync(c->pinned[i & 1], src + off, len, hipMemcpyDeviceToHost, st));
+    MHX_HIP(hipEventRecord(c->pinned_free[i & 1], st));
+  };
+  issue(0);
+  for (size_t i = 0; i < n_chunks; ++i) {
+    MHX_HIP(hipEventSynchronize(c->pinned_free[i & 1]));
+    if (i + 1 < n_chunks) issue(i + 1);
+    const size_t off = i * kChunk, len = std::min(kChunk, bytes - off);
+    const char *stage = static_cast<const char *>(c->pinned[i & 1]);
+    std::thread th[kThreads - 1];
+    const size_t part = (len / kThreads + 63) & ~(size_t)63;
+    for (int t = 1; t < kThreads; ++t) {
+      const size_t lo = std::min(len, part * t), hi = std::min(len, part * (t + 1));
+      th[t - 1] = std::thread([=] { if (hi > lo) memcpy(dst + off + lo, stage + lo, hi - lo); });
+    }
+    memcpy(dst + off, stage, std::min(len, part));
+    for (auto &t : th) t.join();
+  }
+  MHX_HIP(hipStreamSynchronize(st));
+}
 int mhx_fetch(mhx_ctx *c, int which, void *dst, uint64_t offset, uint64_t bytes) {
   MHX_TRY({
     auto it = c->results.find(which);
     if (it == c->results.end() || !it->second.p) throw mhx::Error("fetch: buffer not present");
     if (offset + bytes > it->second.used) throw mhx::Error("fetch: range exceeds buffer");
-    if (bytes) {
+    if (bytes >= (16u << 20) && c->opt("fetch_pinned", 1)) {
+      MHX_HIP(hipStreamSynchronize(c->stream));
+      download_pinned(c, dst, (const char *)it->second.p + offset, bytes);
+    } else if (bytes) {
       MHX_HIP(hipMemcpyAsync(dst, (const char *)it->second.p + offset, bytes, hipMemcpyDeviceToHost, c->stream));
       MHX_HIP(hipStreamSynchronize(c->stream));
     }

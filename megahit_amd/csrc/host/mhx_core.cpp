@@ -412,10 +412,11 @@ std::vector<BucketRange> plan_ranges(mhx_ctx *c, int stage, uint32_t k, uint32_t
       mhx_alloc_stats(&malloc_s, nullptr, &abytes, nullptr);
       // (seconds per byte.  The first few GB of a process come fast whatever the box — at 100 M reads the 4.6 GB of the read store
       //  took 0.1 s, the 239 GB behind them 6.1 s — so what has been seen so far is only a lower bound: a working set of more than
-      //  64 GB is planned with at least 10 ms per GB, the middle of what the boxes of this pool show.  A resident server keeps its
-      //  buffers between requests: nothing to plan for there.)
+      //  64 GB is planned with at least 5 ms per GB — the boxes of this pool showed 0.03 (one box), 2-4, 17 and 25 ms per GB for the
+      //  same 239 GB: a plan for 5 costs a fast box 0.25 s of extra read scans and saves a slow one 2-3 s.  A resident server keeps
+      //  its buffers between requests: nothing to plan for there.)
       double rate = abytes >= (1ull << 30) ? malloc_s / (double)abytes : 0.0;
-      if (per_item * items_upper_bound > 64e9 && !g_serving) rate = std::max(rate, 10e-12);
+      if (per_item * items_upper_bound > 64e9 && !g_serving) rate = std::max(rate, 5e-12);
       if (g_serving) rate = 0;
       if (const char *e = getenv("MHX_ALLOC_S_PER_GB")) rate = atof(e) * 1e-9;  // tests
       const double t_scan = 6.5e-12 * (double)mhx_num_bases(c);
@@ -625,9 +626,14 @@ int main_kmer_count(int argc, char **argv) {
     set_range(c, ranges, i, true);
     mhx_count_result pr;
     CK(mhx_count(c, k, m, &pr));
-    auto e = fetch<uint32_t>(c, MHX_BUF_EDGES);
+    {  // this pass's solid edges straight behind the earlier passes' (no second host copy)
+      const uint64_t eb = mhx_buffer_bytes(c, MHX_BUF_EDGES);
+      const size_t at = edges.size();
+      if (i == 0 && ranges.size() > 1) edges.reserve((size_t)(eb / 4) * ranges.size() * 5 / 4);
+      edges.resize(at + eb / 4);
+      if (eb) CK(mhx_fetch(c, MHX_BUF_EDGES, edges.data() + at, 0, eb));
+    }
     auto bc = fetch<uint64_t>(c, MHX_BUF_BUCKET_COUNT);
-    edges.insert(edges.end(), e.begin(), e.end());
     for (int b = 0; b < MHX_NUM_BUCKETS; ++b) bcount[b] += bc[b];
     r.n_items += pr.n_items;
     r.n_distinct += pr.n_distinct;
