@@ -115,7 +115,8 @@ def meta():
                                                  os.path.join(d, "reads"), "--output_prefix", o], {"MHX_SORT_HYBRID": hyb}, os.path.join(d, "prof.json"))
             r = summarise(kernels)
             r.update(wall_s=round(wall, 3), phases_s=phases, memory_plan_passes=passes, M_edges_per_s_kernel_time=round(full["edges"] / r["kernel_ms_total"] / 1e3, 1),
-                     bit_identical_to_reference=canon.digest_sdbg(o) == full["cases"]["read2sdbg"]["digest"])
+                     bit_identical_to_reference=canon.digest_sdbg(o) == full["cases"]["read2sdbg"]["digest"],
+                     host_side=[l for l in LAST_LOG.splitlines() if "Device " in l or "Memory plan" in l])
             out["runs"][label] = r
             sys.stderr.write("%s %s\n" % (label, json.dumps({"ms": r["kernel_ms_total"], "ok": r["bit_identical_to_reference"], "passes": passes})))
             for fn in os.listdir(d):
@@ -162,7 +163,7 @@ def configs2(keep=None, emit=True):
                      speedup_over_reference_wall=round(want["wall_s"] / wall, 1))
             out["runs"][label] = r
             sys.stderr.write("%s %s\n" % (label, json.dumps({"wall_s": r["wall_s"], "kernel_ms": r["kernel_ms_total"], "ok": ok, "passes": passes})))
-            r["log_tail"] = [l for l in LAST_LOG.splitlines() if "plan" in l.lower() or "passes" in l][:12]
+            r["log_tail"] = [l for l in LAST_LOG.splitlines() if "plan" in l.lower() or "passes" in l or "Device " in l][:14]
             r["log"] = [l for l in LAST_LOG.splitlines() if l.startswith("INFO") or l.startswith("WARN")][-60:]
             for fn in os.listdir(tmp):
                 if fn.startswith("o_"):
@@ -186,7 +187,7 @@ def configs2(keep=None, emit=True):
                   canon.digest_file(o + ".cand") == wc["cand_md5"])
             r.update(wall_s=round(wall, 2), phases_s=phases, memory_plan_passes=passes, bit_identical_to_reference=ok,
                      M_edges_per_s_kernel_time=round(full["edges"] / r["kernel_ms_total"] / 1e3, 1), speedup_over_reference_wall=round(wc["wall_s"] / wall, 1),
-                     log_tail=[l for l in LAST_LOG.splitlines() if "plan" in l.lower() or "passes" in l][:12])
+                     log_tail=[l for l in LAST_LOG.splitlines() if "plan" in l.lower() or "passes" in l or "Device " in l][:14])
             ent["count"] = r
             sys.stderr.write("default route %s count %s\n" % (label, json.dumps({"wall_s": r["wall_s"], "kernel_ms": r["kernel_ms_total"], "ok": ok, "passes": passes})))
             wall, phases, kernels, passes = run(pre + ["seq2sdbg", "-k", str(k), "--kmer_from", "0", "--host_mem", "64e9", "--num_cpu_threads", "8", "--input_prefix", o,
