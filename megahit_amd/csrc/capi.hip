@@ -125,7 +125,7 @@ void upload_sequences(mhx_ctx *c, const uint32_t *packed, uint64_t n_words, uint
                       const uint64_t *start_pos) {
   SeqSet &s = c->seqs;
   hipStream_t st = c->stream;
-  c->agg_valid = false;
+  c->agg_valid = false; c->solid_plain_k = 0;
   s.n_seqs = n_seqs;
   s.fixed_len = start_pos ? 0 : fixed_len;
   s.n_words = n_words;
@@ -191,7 +191,7 @@ void append_sequences(mhx_ctx *c, const uint32_t *packed, uint64_t n_words, uint
                       const uint16_t *mult) {
   SeqSet &s = c->seqs;
   hipStream_t st = c->stream;
-  c->agg_valid = false;
+  c->agg_valid = false; c->solid_plain_k = 0;
   if (n_new == 0) return;
   const uint64_t add_bases = start_pos ? start_pos[n_new] : n_new * (uint64_t)fixed_len;
   if (add_bases > n_words * 16) throw Error("append_sequences: start_pos/n_seqs exceed the packed buffer");
@@ -293,7 +293,7 @@ __global__ void k_unpack_edges(const uint32_t *__restrict__ raw, uint64_t n_edge
 void upload_edges(mhx_ctx *c, const uint32_t *raw, uint64_t n_edges, uint32_t k, uint32_t wpe) {
   hipStream_t st = c->stream;
   SeqSet &s = c->seqs;
-  c->agg_valid = false;
+  c->agg_valid = false; c->solid_plain_k = 0;
   const uint32_t len = k + 1;
   if (wpe != (len * 2 + 16 + 31) / 32) throw Error("load_edges: words_per_edge does not match k");
   uint32_t *d_raw = c->ws("edges_raw", (n_edges * wpe + 4) * 4).as<uint32_t>();
@@ -424,7 +424,7 @@ static bool upload_bin_records_fixed(mhx_ctx *c, const uint32_t *records, uint64
 }
 
 void upload_bin_records(mhx_ctx *c, const uint32_t *records, uint64_t n_words, uint64_t n_seqs, int reverse) {
-  c->agg_valid = false;
+  c->agg_valid = false; c->solid_plain_k = 0;
   if (upload_bin_records_fixed(c, records, n_words, n_seqs, reverse)) return;
   // lengths (host): an empty read becomes a 1-base 'A' (sequence_package.h:275-281)
   std::vector<uint64_t> rec_off(n_seqs + 1), start(n_seqs + 1);
@@ -568,7 +568,7 @@ int mhx_reset(mhx_ctx *c) {
     c->n_parts = 1;
     c->part_begin.clear();
     c->pos_base = c->global_bases = 0;
-    c->agg_valid = false;
+    c->agg_valid = false; c->solid_plain_k = 0;
     c->agg_n = 0;
     c->n_route = 0;
     c->pre_hist_buf = nullptr;
@@ -785,7 +785,7 @@ int mhx_set_is_solid(mhx_ctx *c, const uint64_t *bits, uint64_t n_words) {
   MHX_TRY({
     uint64_t need = mhx::div_ceil(c->seqs.n_bases, 64);
     if (n_words < need) throw mhx::Error("set_is_solid: bitmap too short");
-    c->agg_valid = false;
+    c->agg_valid = false; c->solid_plain_k = 0;
     mhx::DevBuf &b = c->result(MHX_BUF_IS_SOLID, (need + 1) * 8);
     b.used = need * 8;
     if (need) MHX_HIP(hipMemcpyAsync(b.p, bits, need * 8, hipMemcpyHostToDevice, c->stream));
@@ -1100,6 +1100,9 @@ uint64_t mhx_stage_pass_bytes(mhx_ctx *c, int stage, uint32_t k, uint32_t min_co
       if (mhx::count_stream_applies(c, k, min_count) && (2 * (k + 1) + 16 + 31) / 32 <= 3)
         return n_items * 24 + n_items / 2 + c->seqs.n_bases / 3;
     }
+    // stage 2 from a count of the (k+1)-mers (s2.hip s2_agg_from_count): two 12-byte record buffers per edge occurrence — about one per
+    // base, where the caller's item estimate (per-occurrence items) is ~2.2 per base — and the few aggregated items behind them
+    if (stage == MHX_STAGE_S2 && c->seqs.n_seqs && mhx::s2_agg_from_count_applies(c, k, min_count)) return n_items * 13;
     uint64_t ib = 16;
     if (stage == MHX_STAGE_S1_MERCY) ib = (uint64_t)mhx::s1_stride(k, false) * 4;
     else if (stage == MHX_STAGE_COUNT) ib = (uint64_t)mhx::count_stride(k) * 4;

@@ -78,7 +78,7 @@ void mercy_adopt_routed(mhx_ctx *c, const long long *recv, uint64_t n) {
 
 int run_s1_mercy(mhx_ctx *c, uint32_t k, uint64_t *num_mercy) {
   SeqSet &s = c->seqs;
-  c->agg_valid = false;  // mercy turns non-solid occurrences solid: stage 2 must look at every occurrence again
+  c->agg_valid = false; c->solid_plain_k = 0;  // mercy turns non-solid occurrences solid: stage 2 must look at every occurrence again
   hipStream_t st = c->stream;
   // multi-GPU: the local slice of the bitmap and the candidates routed to this rank
   auto itc = c->results.find(c->global_bases ? MHX_BUF_MERCY_CAND_LOCAL : MHX_BUF_MERCY_CAND);

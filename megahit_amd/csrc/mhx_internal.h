@@ -84,6 +84,10 @@ struct mhx_ctx {
   bool agg_valid = false;
   uint32_t agg_k = 0, agg_m = 0;
   uint64_t agg_n = 0;
+  // the is_solid bitmap is exactly what stage 1 found for this (k, m) — no mercy edges added, not set by the caller: stage 2 may then take its
+  // solid items from a count of the (k+1)-mers instead of from every occurrence (s2.hip s2_agg_from_count; 0: not so)
+  uint32_t solid_plain_k = 0, solid_plain_m = 0;
+  bool count_edges_only = false;  // count_stream_groups: only the solid edges are wanted (no first_0_out / last_0_in: positions do not matter)
   uint64_t n_route = 0;      // multi-GPU: records in ws("route_records") (count events)
   // digit histograms of the next sort, taken by the extraction kernel (ws "sort_pre_hist"): valid for exactly this buffer
   const void *pre_hist_buf = nullptr;
@@ -197,7 +201,7 @@ struct DigitSpec;
 DigitSpec spec_of_pass(const SortPass &ps, int key_words);
 std::vector<SortPass> make_passes_ranges(int key_words, const std::vector<std::pair<int, int>> &ranges);
 // s2.hip: SdBG records from sorted lv2 items (shared by read2sdbg S2 and seq2sdbg)
-void emit_sdbg(mhx_ctx *c, const uint32_t *sorted, uint64_t n_items, int S, int kw, uint32_t k, int is_seq, mhx_sdbg_result *out);
+void emit_sdbg(mhx_ctx *c, const uint32_t *sorted, uint64_t n_items, int S, int kw, uint32_t k, int is_seq, mhx_sdbg_result *out, int compact_bits = 0);
 
 void partition_by_owner(mhx_ctx *c, const uint32_t *a, uint32_t *b, uint64_t n, int stride, const uint8_t *lut, int n_parts,
                         uint64_t *counts);
@@ -265,6 +269,8 @@ int sdbg_load_bytes(mhx_ctx *c, const uint8_t *bytes, uint64_t n_bytes, const ui
 // ---- engines ----
 int run_count(mhx_ctx *c, uint32_t k, uint32_t m, mhx_count_result *out);
 // count on the bucket streaming of stage 1 (s1.hip: CountGenT, k_s1_stream<COUNT>)
+int s2_agg_compact_bits(uint32_t k);
+bool s2_agg_from_count_applies(mhx_ctx *c, uint32_t k, uint32_t m);  // s2.hip: stage 2's solid items from a count of the (k+1)-mers  // count bits of a compact aggregated stage-2 item (k = 23..28), 0: none
 struct CountStreamOut {
   unsigned grid;      // workgroups = edge regions
   uint32_t cap;       // 8-byte edges a region holds

@@ -819,6 +819,8 @@ struct S1Stage {
       c->result(MHX_BUF_MERCY_CAND, 8);
       c->results[MHX_BUF_MERCY_CAND].used = 0;
     }
+    c->solid_plain_k = global ? 0 : k;  // (the bitmap is stage 1's own for this (k, m) until mercy edges or the caller change it)
+    c->solid_plain_m = m;
     c->results[MHX_BUF_SORTED_ITEMS].release();
     c->results[MHX_BUF_SORTED_ITEMS].p = sorted;
     c->results[MHX_BUF_SORTED_ITEMS].cap = 0;
@@ -904,7 +906,7 @@ static bool count_stream_shape(const mhx_ctx *c, uint32_t k, uint32_t m, S1Plan 
   if (!s.n_seqs || k < 9 || m < 1 || m > 15) return false;  // (k: count_shape_is_fast — up to 22 with a shared window per run, up to 27 with one per item)
   if (!count_shape_is_fast(c, k)) return false;  // (reads of several lengths: item slots padded to the longest read's, CountGenVarT)
   if (!c->opt("s1_fused_first_pass", 1) || !c->opt("sort_unit_runs", 1) || !c->opt("s1_gen_any_order", 1)) return false;
-  const uint64_t n_bits = c->global_bases ? c->global_bases : s.n_bases;
+  const uint64_t n_bits = c->count_edges_only ? 0 : (c->global_bases ? c->global_bases : s.n_bases);  // (edges only: nobody reads the positions)
   if ((n_bits >> s1_pos_bits(c)) >= 256) return false;  // (positions beyond the tags)
   const uint64_t n_items = count_plan_items(c, k);
   const S1Plan plan = s1_plan(c, k, n_items, true, 0);
@@ -976,7 +978,7 @@ bool count_stream_groups(mhx_ctx *c, uint32_t k, uint32_t m, uint32_t *first_0_o
     c->pre_hist_buf = nullptr;
     spare = sorted == buf_a ? buf_b : buf_a;
   }
-  const uint64_t n_bits = global ? c->global_bases : s.n_bases;
+  const uint64_t n_bits = c->count_edges_only ? 0 : (global ? c->global_bases : s.n_bases);
   const uint64_t pos_stride = (n_bits >> s1_pos_bits(c)) ? 1ull << s1_pos_bits(c) : 0ull;
   // bucket streaming
   const uint64_t n_buckets = 1ull << plan.seg_bits;
@@ -1024,7 +1026,8 @@ bool count_stream_groups(mhx_ctx *c, uint32_t k, uint32_t m, uint32_t *first_0_o
   a.c_fixed_len = s.fixed_len;
   a.first_0_out = first_0_out;
   a.last_0_in_p1 = last_0_in_p1;
-  a.c_wpe = (int)div_ceil((k + 1) * 2 + 16, 32);
+  a.c_wpe = c->count_edges_only ? 3 : (int)div_ceil((k + 1) * 2 + 16, 32);  // (edges only: always the 16-byte entries, s2.hip reads them)
+  a.c_edges_only = c->count_edges_only ? 1 : 0;
   uint32_t ecap = 0;
   uint32_t *ecounts = nullptr;
   if (global) {

@@ -834,8 +834,8 @@ bool count_shape_is_fast(const mhx_ctx *c, uint32_t k) {
   const SeqSet &s = c->seqs;
   if (!s.n_seqs || k < 9) return false;
   if ((int)k > kCountStreamMaxK)  // k = 23..27: a window per item (CountGenWideT), reads of one length, no position tags
-    return (int)k <= kCountStreamWideMaxK && c->opt("count_stream_wide", 1) && s.fixed_len >= k + 1 && s.fixed_len - k >= 8 && (s.n_bases >> s1_pos_bits(c)) == 0 &&
-           (c->global_bases >> s1_pos_bits(c)) == 0;
+    return (int)k <= kCountStreamWideMaxK && c->opt("count_stream_wide", 1) && s.fixed_len >= k + 1 && s.fixed_len - k >= 8 &&
+           (c->count_edges_only || ((s.n_bases >> s1_pos_bits(c)) == 0 && (c->global_bases >> s1_pos_bits(c)) == 0));
   if (s.fixed_len) return s.fixed_len >= k + 1 && s.fixed_len - k >= 8;
   if (!c->opt("s1_var_fast", 1) || s.max_len < k + 1 || s.max_len - k < 8 || s.n_bases <= s.n_seqs * (uint64_t)k) return false;
   return (double)s.n_bases * 100.0 >= (double)c->opt("s1_var_min_fill", 50) * (double)s.n_seqs * s.max_len;

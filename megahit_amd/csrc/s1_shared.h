@@ -100,6 +100,7 @@ struct S1SegArgs {
   uint64_t c_n_seqs;
   uint32_t c_fixed_len;
   uint32_t *first_0_out, *last_0_in_p1;
+  int c_edges_only;  // count: no first_0_out / last_0_in wanted (stage 2's aggregated items from a count of the (k+1)-mers): no second look
   int c_wpe;  // words per packed edge (kmer_counter.cpp:32-52): 2 up to k = 23 — (k+1)-mer and multiplicity in 64 bits —, 3 beyond: 16-byte region entries
 };
 

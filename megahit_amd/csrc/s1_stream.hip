@@ -988,7 +988,7 @@ __global__ __launch_bounds__(NT) void k_s1_stream(const uint32_t *__restrict__ i
               fb = (has_in ? 0u : 1u) | (has_out ? 0u : 2u);
               any_flag = any_flag || fb != 0;
               if constexpr (GIANT) {  // listed for k_count_giant_look (a list that runs over: this workgroup looks itself, below)
-                if (fb && a.giant.fl_cnt) {
+                if (fb && a.giant.fl_cnt && !a.c_edges_only) {
                   const uint32_t at = atomicAdd(&a.giant.fl_cnt[(uint32_t)bi64], 1u);
                   if (at < a.giant.fl_cap) a.giant.fl_key[(size_t)bi64 * a.giant.fl_cap + at] = ((unsigned long long)lk << 2) | fb;
                 }
@@ -998,7 +998,7 @@ __global__ __launch_bounds__(NT) void k_s1_stream(const uint32_t *__restrict__ i
           }
         }
         st_solid += n_dist;  // (count: distinct keys)
-        if (__ballot(any_flag) && lane == 0) s_flagged = 1;
+        if (__ballot(any_flag) && lane == 0 && !a.c_edges_only) s_flagged = 1;
         {  // the solid keys' packed edges (PackEdge, kmer_counter.cpp:32-52: multiplicity in the low 16 bits) -> the region, from its front
           const uint32_t n_e = (uint32_t)__builtin_popcount(solid_bits);
           const uint32_t incl = wave_inclusive_sum(n_e);

@@ -272,7 +272,9 @@ constexpr int kS2dWords = 8;
 // emission in arbitrary order (the items are sorted next): per block one atomicAdd on the output cursor
 __global__ __launch_bounds__(256) void k_s2d_emit(const uint32_t *__restrict__ seq, const uint64_t *__restrict__ start, uint64_t n_seqs,
                                                   uint32_t fixed_len, int k, const unsigned long long *__restrict__ solid, uint64_t n_words,
-                                                  uint2 *__restrict__ items, unsigned long long *__restrict__ cursor) {
+                                                  uint2 *__restrict__ items, unsigned long long *__restrict__ cursor, int fsh = 19, int bsh = 16, int csh = 0) {
+  // (fsh / bsh / csh: where the "full" flag, the W char and the count sit below the chars: 19 / 16 / 0 in the seq2sdbg layout of the
+  //  aggregated items of k <= 22, cb + 3 / cb / 0 with the cb = 60 - 2k count bits of k = 23..28)
   __shared__ uint64_t sm[256 / kWave + 1];
   __shared__ unsigned long long s_base;
   const uint64_t mask_k = ~0ull << (64 - 2 * k), mask_k1 = ~0ull << (64 - 2 * (k - 1));
@@ -319,7 +321,7 @@ __global__ __launch_bounds__(256) void k_s2d_emit(const uint32_t *__restrict__ s
     const uint64_t er = rc64_s2(e, k + 1);
     const bool pal = e == er;
     auto put = [&](uint64_t key, uint64_t full, uint64_t wc) {
-      const uint64_t v = key | (full << 19) | (wc << 16) | 1ull;
+      const uint64_t v = key | (full << fsh) | (wc << bsh) | (1ull << csh);
       *dst++ = make_uint2((uint32_t)(v >> 32), (uint32_t)v);
     };
     if ((l >> b) & 1ull) {                                               // left-$ (read_to_sdbg_s2.cpp:387-396, :457-512)
@@ -349,6 +351,8 @@ struct SdbgParams {
   int wpt;             // words per tip label
   int is_seq;          // 0: S2 (multiplicity = run length); 1: seq2sdbg (65535 - key field); 2: aggregated S2 (sum of counts)
   int ref_kw;          // key words of the reference's stage-2 item, ceil((2k+4)/32) (tip-label reconstruction)
+  int cshift;          // is_seq 2: the count field of an aggregated item, bits [cshift, cshift + popcount(cmask)) of the last key word: the low 16
+  uint32_t cmask;      //           bits up to k = 22, the low 60 - 2k bits at k = 23..28 (s2_agg_compact_bits); flag | W sit right above it
 };
 
 template <int S>
@@ -435,7 +439,7 @@ struct SdbgOp {
     if (P.is_seq == 2) {  // pre-aggregated stage-2 items: multiplicity = sum of the items' counts
       const uint32_t e = i + c.run_len(r);
       uint64_t sum = 0;
-      for (uint32_t j = i; j < e && sum < MHX_MAX_MUL; ++j) sum += c.acc.word(j, P.kw - 1) & 0xFFFFu;
+      for (uint32_t j = i; j < e && sum < MHX_MAX_MUL; ++j) sum += (c.acc.word(j, P.kw - 1) >> P.cshift) & P.cmask;
       return sum > MHX_MAX_MUL ? (uint32_t)MHX_MAX_MUL : (uint32_t)sum;
     }
     if (P.is_seq) return MHX_MAX_MUL - (c.acc.word(i, P.kw - 1) & 0xFFFFu);  // seq_to_sdbg.cpp:782-785
@@ -518,6 +522,8 @@ struct SdbgFastP {
   unsigned long long gmask, rmask;  // bits that tell groups apart / runs apart (rmask includes gmask), record = w0 << 32 | w1
   int fsh, ash, bsh;                // "full" flag, k-th char, W char as shifts of the 64-bit record
   int is_seq, wpt, k, ref_kw;
+  int csh;                          // is_seq 2: count field of an aggregated item: (record >> csh) & cmk
+  uint32_t cmk;
   int halo;                         // records staged either side of the tile (<= kSdbgFastHalo; tests shrink it)
 };
 constexpr int kSdbgFastHalo = 128;
@@ -685,7 +691,7 @@ __global__ __launch_bounds__(256) void k_sdbg_fast(const uint2 *__restrict__ ite
             if ((x ^ v) & P.gmask) break;
             M |= sdbg_pair_bit(x, P, ax, bx);
           }
-        uint32_t len = 1, sum = (uint32_t)(v & 0xFFFFull);
+        uint32_t len = 1, sum = (uint32_t)(v >> P.csh) & P.cmk;
         bool in_run = true;
         if (!far)
           for (int p = idx + 1;; ++p) {
@@ -698,7 +704,7 @@ __global__ __launch_bounds__(256) void k_sdbg_fast(const uint2 *__restrict__ ite
             in_run = in_run && ((x ^ v) & P.rmask) == 0;
             if (in_run) {
               ++len;
-              sum += (uint32_t)(x & 0xFFFFull);
+              sum += (uint32_t)(x >> P.csh) & P.cmk;
               if (sum > (uint32_t)MHX_MAX_MUL) sum = MHX_MAX_MUL;  // (a run in the window holds < 2^12 records: no overflow either way)
             } else {
               M |= sdbg_pair_bit(x, P, ax, bx);
@@ -755,7 +761,7 @@ __global__ __launch_bounds__(256) void k_sdbg_fast(const uint2 *__restrict__ ite
 #pragma unroll
           for (uint32_t q = 0; q < kStep; ++q) {
             const uint32_t i = off + q * kWave + lane;
-            x += i < cnt ? items[head + i].y & 0xFFFFu : 0u;
+            x += i < cnt ? (items[head + i].y >> P.csh) & P.cmk : 0u;
           }
           total += wave_sum(x);
         }
@@ -1027,6 +1033,8 @@ static void emit_sdbg_impl(mhx_ctx *c, const uint32_t *sorted, uint64_t n_items,
       F.ash = P.ashift + (P.aw == 0 ? 32 : 0);
       F.rmask = F.gmask | (0xFull << F.bsh) | (3ull << F.ash);
       F.is_seq = P.is_seq;
+      F.csh = P.cshift;
+      F.cmk = P.cmask;
       F.wpt = P.wpt;
       F.k = P.k;
       F.ref_kw = P.ref_kw;
@@ -1109,15 +1117,19 @@ static void emit_sdbg_impl(mhx_ctx *c, const uint32_t *sorted, uint64_t n_items,
 }
 
 // sorted: n_items records of stride S with kw key words, sorted; fills the SdBG result buffers.
-void emit_sdbg(mhx_ctx *c, const uint32_t *sorted, uint64_t n_items, int S, int kw, uint32_t k, int is_seq, mhx_sdbg_result *out) {
+void emit_sdbg(mhx_ctx *c, const uint32_t *sorted, uint64_t n_items, int S, int kw, uint32_t k, int is_seq, mhx_sdbg_result *out, int compact_bits) {
   hipStream_t st = c->stream;
   SdbgParams P;
   P.stride = S;
   P.kw = kw;
   P.k = (int)k;
   P.ref_kw = (int)div_ceil(k * 2 + 4, 32);
-  P.bshift = is_seq ? 16 : 0;
+  // compact_bits > 0 (aggregated items of k = 23..28): the seq2sdbg layout with a count field of that many bits instead of 16 — chars,
+  // flag | W, count from the top down, so that the whole-key order is still chars, flag, W
+  P.bshift = is_seq ? (compact_bits ? compact_bits : 16) : 0;
   P.fshift = P.bshift + 3;
+  P.cshift = 0;
+  P.cmask = compact_bits ? (1u << compact_bits) - 1u : 0xFFFFu;
   P.aw = (int)(k - 1) / 16;
   P.ashift = (15 - (int)((k - 1) % 16)) * 2;
   P.wpt = (int)div_ceil(k, 16);
@@ -1329,6 +1341,173 @@ int s2_agg_process(mhx_ctx *c, uint32_t k, uint32_t *buf_a, uint32_t *buf_b, uin
   emit_sdbg(c, sorted, n_items, 2, 2, k, 2, out);
   return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Stage 2's solid items from a COUNT of the (k+1)-mers (round 6).  Without mercy edges the solid occurrences are exactly the
+// occurrences of the (k+1)-mers that occur at least m times, and per distinct one of them the per-occurrence stage 2 makes two runs of
+// equal items (read_to_sdbg_s2.cpp:398-409, counted again at :579) — so `count` on the bucket streaming (k_s1_stream<COUNT>, edges only:
+// no positions, no first_0_out / last_0_in) gives every solid item with its multiplicity, and only the '$' items at the ends of the
+// solid runs come from the reads.  Serves min count 1 (main_sdbg_build.cpp:139-147: stage 1 skipped, EVERY occurrence is an item: the
+// meta presets — 10^10 items at 40 M reads, k = 27) for k <= 27, and min count >= 2 at k = 23..27, where stage 1 has no aggregated items
+// of its own (they need 2k + 20 <= 64 bits).  k >= 23: the same 8-byte layout — chars, flag | W, count — with a count field of the 60 - 2k
+// bits that are left (an edge with a larger multiplicity becomes several items: the emission sums them).
+// ---------------------------------------------------------------------------------------------------------------
+int s2_agg_compact_bits(uint32_t k) { return k >= 23 && k <= 28 ? std::min(16, 60 - 2 * (int)k) : 0; }
+
+__global__ __launch_bounds__(256) void k_edges_to_agg(const uint4 *__restrict__ raw, uint32_t cap, const uint32_t *__restrict__ counts, int k, int fsh, int bsh, int csh,
+                                                      uint32_t cmax, uint2 *__restrict__ items, unsigned long long *__restrict__ cursor, unsigned long long items_cap,
+                                                      uint32_t *__restrict__ err) {
+  __shared__ uint64_t sm[256 / kWave + 1];
+  __shared__ unsigned long long s_base;
+  const uint32_t n = counts[blockIdx.x];  // region blockIdx.x of the count's workgroups: n entries of ((k+1)-mer words, multiplicity, 0)
+  const uint4 *src = raw + (size_t)blockIdx.x * cap;
+  const uint64_t mask_k = ~0ull << (64 - 2 * k);
+  for (uint32_t base = blockIdx.y * 256; base < n; base += gridDim.y * 256) {
+    const uint32_t i = base + threadIdx.x;
+    uint64_t e = 0, er = 0;
+    uint32_t mul = 0, pieces = 0, strands = 0;
+    if (i < n) {
+      const uint4 en = src[i];
+      e = ((uint64_t)en.x << 32) | en.y;
+      er = rc64_s2(e, k + 1);
+      mul = en.z;
+      pieces = (mul + cmax - 1) / cmax;
+      strands = e == er ? 1u : 2u;  // (a palindrome makes the forward items only, read_to_sdbg_s2.cpp:385-423)
+    }
+    uint64_t tot;
+    const uint64_t excl = block_exclusive_sum<uint64_t, 256>((uint64_t)pieces * strands, sm, &tot);
+    if (threadIdx.x == 0) s_base = tot ? atomicAdd(cursor, (unsigned long long)tot) : 0ull;
+    __syncthreads();
+    if (s_base + tot > items_cap) {
+      if (threadIdx.x == 0) atomicOr(err, 1u);
+    } else {
+      uint2 *dst = items + s_base + excl;
+      uint32_t left = mul;
+      for (uint32_t p = 0; p < pieces; ++p) {
+        const uint64_t cnt = left > cmax ? cmax : left;
+        left -= (uint32_t)cnt;
+        const uint64_t f = ((e << 2) & mask_k) | (1ull << fsh) | ((e >> 62) << bsh) | (cnt << csh);  // chars e[1..k], W = e[0]
+        *dst++ = make_uint2((uint32_t)(f >> 32), (uint32_t)f);
+        if (strands == 2) {
+          const uint64_t b = ((er << 2) & mask_k) | (1ull << fsh) | ((er >> 62) << bsh) | (cnt << csh);
+          *dst++ = make_uint2((uint32_t)(b >> 32), (uint32_t)b);
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+// every position where a (k+1)-mer starts: the "solid" bitmap of min count 1 (read_to_sdbg_s2.cpp:295,381)
+__global__ __launch_bounds__(256) void k_valid_starts(unsigned long long *__restrict__ words, uint64_t n_words, const uint64_t *__restrict__ start, uint64_t n_seqs,
+                                                      uint32_t fixed_len, int k) {
+  const uint64_t w = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (w >= n_words) return;
+  unsigned long long v = 0;
+  uint64_t r = seq_of_offset(start, n_seqs, fixed_len, w * 64);
+  for (int t = 0; t < 64; ++t) {
+    const uint64_t p = w * 64 + t;
+    while (r + 1 < n_seqs && start[r + 1] <= p) ++r;
+    if (p >= start[n_seqs]) break;
+    if (p + (uint64_t)k + 1 <= start[r + 1]) v |= 1ull << t;
+  }
+  words[w] = v;
+}
+
+bool s2_agg_from_count_applies(mhx_ctx *c, uint32_t k, uint32_t m) {
+  if (!c->opt("s2_agg_from_count", 1) || c->filter_on || c->accumulate || c->n_parts > 1 || c->global_bases) return false;
+  if (m < 1 || k < 10 || k > 27) return false;
+  if (m > 1 && (k <= 22 || c->solid_plain_k != k || c->solid_plain_m != m)) return false;  // (k <= 22: stage 1 made the aggregated items itself)
+  const bool was = c->count_edges_only;
+  c->count_edges_only = true;
+  const bool ok = count_stream_applies(c, k, m);
+  c->count_edges_only = was;
+  return ok;
+}
+// -> false: the count gave up (nothing published: the per-occurrence path runs)
+static bool s2_agg_from_count(mhx_ctx *c, uint32_t k, uint32_t m, mhx_sdbg_result *out) {
+  SeqSet &s = c->seqs;
+  hipStream_t st = c->stream;
+  const uint64_t ns = s.n_seqs;
+  const int cb = s2_agg_compact_bits(k);
+  const int cbits = cb ? cb : 16;
+  const int fsh = cbits + 3, bsh = cbits, csh = 0;  // chars | flag | W | count, as the aggregated items of k <= 22 with their 16 count bits
+  const uint32_t cmax = cb ? (1u << cb) - 1u : (uint32_t)MHX_MAX_MUL;
+  // 1. the solid (k+1)-mers and their multiplicities: the workgroups' edge regions of the count (scratch first/last/histogram: nobody reads them)
+  uint32_t *first = c->ws("s2c_first", (ns ? ns : 1) * 4).as<uint32_t>(), *last = c->ws("s2c_last", (ns ? ns : 1) * 4).as<uint32_t>();
+  unsigned long long *hist = c->ws("s2c_hist", (MHX_MAX_MUL + 1) * 8).as<unsigned long long>();
+  MHX_HIP(hipMemsetAsync(hist, 0, (MHX_MAX_MUL + 1) * 8, st));
+  CountStreamOut o;
+  c->count_edges_only = true;
+  c->gen_first_pass = nullptr;
+  bool ok = false;
+  try {
+    ok = count_stream_groups(c, k, m, first, last, hist, &o, nullptr);
+  } catch (...) {
+    c->count_edges_only = false;
+    c->gen_first_pass = nullptr;
+    throw;
+  }
+  c->count_edges_only = false;
+  c->gen_first_pass = nullptr;
+  if (!ok) return false;
+  std::vector<uint32_t> h_counts(o.grid);
+  MHX_HIP(hipMemcpyAsync(h_counts.data(), o.counts, (size_t)o.grid * 4, hipMemcpyDeviceToHost, st));
+  MHX_HIP(hipStreamSynchronize(st));
+  uint64_t n_edges = 0;
+  for (uint32_t v : h_counts) n_edges += v;
+  // 2. the bitmap the '$' items come from: stage 1's (min count > 1) or every (k+1)-mer start (min count 1)
+  const uint64_t n_words = div_ceil(s.n_bases, 64);
+  const unsigned long long *solid = nullptr;
+  if (m > 1) {
+    auto it = c->results.find(MHX_BUF_IS_SOLID);
+    if (it == c->results.end() || it->second.used < n_words * 8) throw Error("read2sdbg_s2: no is_solid bitmap");
+    solid = it->second.as<unsigned long long>();
+  } else {
+    unsigned long long *v = c->ws("s2c_valid", (n_words + 1) * 8).as<unsigned long long>();
+    if (n_words)
+      MHX_LAUNCH(c, "s2_valid_starts", (double)n_words * 8,
+                 hipLaunchKernelGGL(k_valid_starts, dim3((unsigned)div_ceil(n_words, 256)), dim3(256), 0, st, v, n_words, s.start.as<uint64_t>(), ns, s.fixed_len, (int)k));
+    solid = v;
+  }
+  unsigned long long *cur = c->ws("s2d_cursor", 64).as<unsigned long long>();
+  MHX_HIP(hipMemsetAsync(cur, 0, 32, st));
+  uint64_t bound = 0;
+  if (n_words) {
+    MHX_LAUNCH(c, "s2_bound", (double)n_words * 8,
+               hipLaunchKernelGGL(k_s2d_bound, dim3((unsigned)std::min<uint64_t>(div_ceil(n_words, 256), 2048)), dim3(256), 0, st, solid, n_words, cur + 1));
+    MHX_HIP(hipMemcpyAsync(&bound, cur + 1, 8, hipMemcpyDeviceToHost, st));
+    MHX_HIP(hipStreamSynchronize(st));
+  }
+  // 3. items: per edge and strand ceil(multiplicity / cmax) of them, then the dummies.  (The edge regions live in the count's spare sort
+  //    buffer "items_a" / "items_b": the items get buffers of their own.)
+  const uint64_t items_cap = 2 * (n_edges + o.n_items / cmax + 1);
+  uint32_t *buf_a = c->ws("s2c_items_a", (items_cap + bound) * 8 + 64).as<uint32_t>();
+  uint32_t *err = reinterpret_cast<uint32_t *>(cur + 3);
+  if (n_edges)
+    MHX_LAUNCH(c, "s2_edges_to_items", (double)n_edges * 16,
+               hipLaunchKernelGGL(k_edges_to_agg, dim3(o.grid, 8), dim3(256), 0, st, reinterpret_cast<const uint4 *>(o.spare), o.cap / 2, o.counts, (int)k, fsh, bsh, csh,
+                                  cmax, reinterpret_cast<uint2 *>(buf_a), cur + 2, (unsigned long long)items_cap, err));
+  unsigned long long h_cur[4] = {0, 0, 0, 0};
+  MHX_HIP(hipMemcpyAsync(h_cur, cur, 32, hipMemcpyDeviceToHost, st));
+  MHX_HIP(hipStreamSynchronize(st));
+  if (h_cur[3] & 0xFFFFFFFFull) throw Error("read2sdbg_s2: more aggregated items than their bound");
+  const uint64_t n_agg = h_cur[2];
+  uint64_t n_dummy = 0;
+  if (bound) {
+    MHX_LAUNCH(c, "s2_extract", (double)bound * 8 + (double)n_words * 8,
+               hipLaunchKernelGGL(k_s2d_emit, dim3((unsigned)std::min<uint64_t>(div_ceil(n_words, 256 * kS2dWords), 4096)), dim3(256), 0, st, s.words.as<uint32_t>(),
+                                  s.start.as<uint64_t>(), ns, s.fixed_len, (int)k, solid, n_words, reinterpret_cast<uint2 *>(buf_a) + n_agg, cur, fsh, bsh, csh));
+    MHX_HIP(hipMemcpyAsync(&n_dummy, cur, 8, hipMemcpyDeviceToHost, st));
+    MHX_HIP(hipStreamSynchronize(st));
+  }
+  const uint64_t n_items = n_agg + n_dummy;
+  uint32_t *buf_b = c->ws("s2c_items_b", n_items * 8 + 64).as<uint32_t>();
+  // 4. sort by chars, flag and W (the count bits ride along), emit
+  uint32_t *sorted = sort_whole_key(c, buf_a, buf_b, n_items, 2, 2, make_passes_ranges(2, {{cbits, cbits + 4}, {64 - 2 * (int)k, 64}}));
+  emit_sdbg(c, sorted, n_items, 2, 2, k, 2, out, cb);
+  c->last_s1_plan = "stage 2 from a count of the (k+1)-mers: " + o.plan;
+  return true;
+}
 bool s2_use_aggregated(const mhx_ctx *c, uint32_t k, uint32_t m) { return c->agg_valid && c->agg_k == k && c->agg_m == m && m > 1; }
 
 // Single GPU, everything resident: the aggregated items are sorted where stage 1 left them (ws "s2_agg_items", the dummies
@@ -1370,6 +1549,7 @@ int run_s2(mhx_ctx *c, uint32_t k, uint32_t m, mhx_sdbg_result *out) {
   if (c->global_bases) throw Error("read2sdbg_s2: a global layout is set; use the mhx_dist_* entry points");
   if (!c->filter_on && !c->accumulate && c->n_parts <= 1 && s2_use_aggregated(c, k, m) && c->opt("s2_agg_in_place", 1))
     return s2_agg_in_place(c, k, out);
+  if (s2_agg_from_count_applies(c, k, m) && s2_agg_from_count(c, k, m, out)) return 0;
   const StageItems it = extract_stage(c, MHX_STAGE_S2, k, m);
   uint32_t *buf_a = c->work["items_a"].as<uint32_t>();
   uint32_t *buf_b = c->ws("items_b", it.n * (size_t)it.S * 4 + 64).as<uint32_t>();
