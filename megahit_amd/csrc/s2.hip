@@ -1437,6 +1437,28 @@ static bool s2_agg_from_count(mhx_ctx *c, uint32_t k, uint32_t m, mhx_sdbg_resul
   unsigned long long *hist = c->ws("s2c_hist", (MHX_MAX_MUL + 1) * 8).as<unsigned long long>();
   MHX_HIP(hipMemsetAsync(hist, 0, (MHX_MAX_MUL + 1) * 8, st));
   CountStreamOut o;
+  // Min count 1 is the choice of the meta presets: high-diversity data, where a bucket's records are mostly DISTINCT keys (a quarter of them
+  // at the configs[4] shard against a twentieth at 60 x coverage).  Sub-rounds — a second read of every bucket instead of a third sort pass —
+  // then still overflow the table and split again (count_groups 198 ms at 40 M reads), a third pass over a finer prefix does not
+  // (36 ms + 27 for the pass): the plan is made with s1_stream_sub_max = 0 and 12 000 records per bucket unless the caller set those knobs.
+  struct KnobGuard {
+    mhx_ctx *c;
+    std::vector<std::string> set;
+    void put(const char *name, long long v) {
+      std::string env = std::string("MHX_") + name;
+      for (char &ch : env) ch = (char)toupper((unsigned char)ch);
+      if (c->options.count(name) || getenv(env.c_str())) return;
+      c->options[name] = v;
+      set.push_back(name);
+    }
+    ~KnobGuard() {
+      for (const std::string &n : set) c->options.erase(n);
+    }
+  } knobs{c, {}};
+  if (m == 1) {
+    knobs.put("s1_stream_sub_max", 0);
+    knobs.put("s1_stream_max3", 12000);
+  }
   c->count_edges_only = true;
   c->gen_first_pass = nullptr;
   bool ok = false;

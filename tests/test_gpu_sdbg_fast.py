@@ -27,6 +27,7 @@ def with_options(engine, opts, fn):
         engine.set_option("sdbg_fast_halo", 128)
         engine.set_option("sdbg_fast_keep", 1)
         engine.set_option("sdbg_fast_tile", 2048)
+        engine.set_option("s2_agg_from_count", 1)
 
 
 def many_dummies_reads(seed):
@@ -66,6 +67,7 @@ def test_per_occurrence_items(engine, kind, k, m, opts):
         engine.set_is_solid(solid)
     opts = dict(opts)
     opts.setdefault("sdbg_fast", 2)  # (items per occurrence take the tile kernel by default: 2 = the run-head form anyway)
+    opts.setdefault("s2_agg_from_count", 0)  # (round 6: min count 1 would take its solid items from a count of the (k+1)-mers)
     r = with_options(engine, opts, lambda: engine.read2sdbg_s2(k, m))
     check_sdbg(engine, r, ob.s2(pkg, k, m, solid), per_occurrence=True)
 

@@ -1,8 +1,9 @@
 """GPU probe (round 6): no input may take minutes — what low-complexity reads cost on EVERY path a sub-program can take.
 The 10 M-read library of bench.py, clean and with 1 % poly-A, 1 % (AC)n, 5 % poly-G reads planted, through
     count      k = 21 / 27, min count 2 / 3     (streaming design where it applies; the tile path beside it: count_stream = 0)
-    read2sdbg  k = 27, min count 2              (bucket streaming with 64-bit table keys; k_s1_seg beside it: s1_stream_wide = 0)
-    read2sdbg  k = 27, min count 1              (stage 1 skipped, stage 2 per occurrence)
+    read2sdbg  k = 27, min count 2              (bucket streaming with 64-bit table keys + stage 2 from a count of the (k+1)-mers; beside it
+                                                 k_s1_seg + stage 2 per occurrence: s1_stream_wide = 0, s2_agg_from_count = 0)
+    read2sdbg  k = 27, min count 1              (stage 1 skipped, stage 2 from a count; beside it stage 2 per occurrence)
 each timed (warm-up + steps, per-kernel clocks); where two paths exist their outputs are compared (digest of every result buffer).
 
     python tools/lowcomplexity_paths_probe.py [reads] > profiles/r06_lowcomplexity_paths.json"""
@@ -48,8 +49,8 @@ def main():
 
     cases = [("count k=21 m=2", step_count(21, 2), COUNT_BUFS, {"count_stream": 0}), ("count k=21 m=3", step_count(21, 3), COUNT_BUFS, {"count_stream": 0}),
              ("count k=27 m=2", step_count(27, 2), COUNT_BUFS, {"count_stream": 0}), ("count k=27 m=3", step_count(27, 3), COUNT_BUFS, {"count_stream": 0}),
-             ("read2sdbg k=27 m=2", step_r2s(27, 2), SDBG_BUFS + ((lib.BUF_IS_SOLID, np.uint64), (lib.BUF_MUL_HIST, np.int64)), {"s1_stream_wide": 0}),
-             ("read2sdbg k=27 m=1", step_r2s(27, 1), SDBG_BUFS, None)]
+             ("read2sdbg k=27 m=2", step_r2s(27, 2), SDBG_BUFS + ((lib.BUF_IS_SOLID, np.uint64), (lib.BUF_MUL_HIST, np.int64)), {"s1_stream_wide": 0, "s2_agg_from_count": 0}),
+             ("read2sdbg k=27 m=1", step_r2s(27, 1), SDBG_BUFS, {"s2_agg_from_count": 0})]
     if only:
         cases = [c for c in cases if any(o in c[0] for o in only)]
 
