@@ -117,6 +117,24 @@ int mhx_set_option(mhx_ctx *, const char *name, long long value);
  *                          records staged either side of a tile / per tile (tests, tuning)
  *   edges_reserve_permille (1000)  room behind the edges mhx_load_edges uploads, for mercy edges (the CLI: 1250, or what
  *                          MEGAHIT_NUM_MERCY_FACTOR says: seq_to_sdbg.cpp:370-378)
+ * Round 6:
+ *   count_stream (1)       now also: pass by pass under a bucket filter (memory plan; the filter sits inside the histogram pre-pass and the
+ *                          generating sort pass), on several GPUs (pre-sorted exchange, the first_0_out / last_0_in events routed to the
+ *                          read owners), min count 1..15 (3..15: per-char 4-bit counters that stop at m instead of seen-once / seen-twice
+ *                          bits); count_stream_wide (1): k = 23..27 on the same design — a window per item (CountGenWideT), 64-bit table
+ *                          keys, three-word edges from k = 24 —, reads of one length, read sets below 2^32 bases (no room for position tags)
+ *   count_giant (1)        0: `count` streams a giant bucket (>= s1_giant_min records) with one workgroup; 1: slices + partial entries with
+ *                          per-char counters + k_count_giant_look for the keys without an in- or out-edge
+ *   count_event_share (4)  several GPUs: the event regions of k_s1_stream<COUNT> hold items / count_event_share events in all
+ *   s1_stream_wide (1)     0: stage 1 at k = 23..29 takes the segment group-by (k_s1_seg); 1: the bucket streaming with 64-bit table keys
+ *   s2_agg_from_count (1)  0: stage 2 always makes its solid items per occurrence where stage 1 left no aggregated ones; 1: min count 1
+ *                          (k <= 27) and min count >= 2 at k = 23..27 take them from a count of the (k+1)-mers (s2.hip s2_agg_from_count)
+ *   sort_loaded_ut2 (0)    1: the 12-byte passes that load their records take units of two tiles (four workgroups per CU instead of three);
+ *                          measured slower (profiles/r06_ab_loaded_ut2.jsonl): the passes are bound per scattered run, not by occupancy
+ *   fetch_pinned (1)       0: mhx_fetch is one hipMemcpy into the caller's (pageable) memory; 1: results of >= 16 MB leave through two
+ *                          pinned staging buffers, the copy off the device overlapped with the copy into the destination
+ * The CLI's memory plan (host/mhx_core.cpp plan_ranges): MHX_PLAN_BY_TIME=0 plans by space only; MHX_ALLOC_S_PER_GB=<seconds> sets the
+ * hipMalloc rate the time plan assumes (tests).
  * (mhx_tuning.conf of this tree: s1_gen_blocked = 1.) */
 long long mhx_get_option(mhx_ctx *, const char *name, long long dflt);
 /* What the last stage 1 of this handle ran as: "stream p16 sub0 2 passes (20345 records per lv1 bucket)" / "seg p24 3 passes" /
