@@ -746,6 +746,42 @@ struct S1Stage {
       return false;
     }
   }
+  // stage 1 on super-k-mer records (s1_skm.hip): the group-by per minimizer bin, its aggregated items packed as run_partial packs them.
+  // -> false: an output region overflowed (nothing published; the caller takes the prefix plan from scratch)
+  bool run_skm(const SkmFront &f) {
+    mark_mode = 1;  // the marks of the non-solid occurrences, from the table
+    ensure_byte_map();
+    const uint64_t cus = c->n_cus > 0 ? (uint64_t)c->n_cus : 256;
+    const unsigned grid = (unsigned)std::min<uint64_t>(cus, f.n_bins);
+    uint2 *raw = nullptr;
+    uint32_t *counts = nullptr;
+    if (agg) {
+      seg_grid = grid;
+      seg_cap = (uint32_t)std::min<uint64_t>(f.spare_bytes / 8 / grid, 0xFFFFFFF0u);
+      raw = reinterpret_cast<uint2 *>(spare);
+      counts = c->ws("s2_agg_counts", (size_t)grid * 4).as<uint32_t>();
+    }
+    MHX_HIP(hipMemsetAsync(seg_err, 0, 4, st));
+    s1_skm_groups_launch(c, agg, grid, f, k, m, solid_bytes, hist, raw, seg_cap, counts, seg_err);
+    uint32_t e = 0;
+    std::vector<uint32_t> h_counts(agg ? seg_grid : 0);
+    MHX_HIP(hipMemcpyAsync(&e, seg_err, 4, hipMemcpyDeviceToHost, st));
+    if (agg) MHX_HIP(hipMemcpyAsync(h_counts.data(), counts, (size_t)seg_grid * 4, hipMemcpyDeviceToHost, st));
+    MHX_HIP(hipStreamSynchronize(st));
+    if (e) return false;
+    if (agg) {
+      uint64_t total = 0;
+      for (uint32_t v : h_counts) total += v;
+      uint2 *dense = grow_preserving(c, c->work["s2_agg_items"], (agg_prev + total) * 8 + 64, agg_prev * 8).as<uint2>();
+      if (total)
+        MHX_LAUNCH(c, "agg_compact", (double)total * 16,
+                   hipLaunchKernelGGL(k_agg_compact, dim3(seg_grid, 8), dim3(256), 0, st, reinterpret_cast<const uint2 *>(spare), seg_cap, counts, dense + agg_prev, 1));
+      const uint64_t agg_n = agg_prev + total;
+      MHX_HIP(hipMemcpyAsync(agg_cursor, &agg_n, 8, hipMemcpyHostToDevice, st));
+      MHX_HIP(hipStreamSynchronize(st));  // agg_n is a stack variable
+    }
+    return true;
+  }
   void group_classic() {
     agg_prepare_classic();
     ensure_byte_map();
@@ -1132,15 +1168,50 @@ bool count_stream_groups(mhx_ctx *c, uint32_t k, uint32_t m, uint32_t *first_0_o
   return e == 0;
 }
 
+// stage 1 on super-k-mer records.  -> false: the shape is served but this input is not (more records than windows / 2, a bin of
+// low-complexity reads, an output region that overflowed): nothing published, the prefix plan runs from scratch
+static bool s1_skm_try(mhx_ctx *c, uint32_t k, uint32_t m, mhx_s1_result *out, std::string *why) {
+  SkmFront f{};
+  if (!s1_skm_front(c, k, &f)) {
+    *why = f.n_records ? "a bin of " + std::to_string(f.max_bin) + " records" : "more records than the array holds";
+    return false;
+  }
+  const SeqSet &s = c->seqs;
+  const uint64_t n_items = s.n_seqs * (uint64_t)(s.fixed_len - k + 4);  // what the reference sorts (read_to_sdbg_s1.cpp:344-363)
+  S1Stage stage(c, k, m, 0, nullptr, nullptr, n_items, nullptr);
+  stage.sorted = nullptr;
+  stage.set_spare(f.spare);
+  stage.open_outputs();
+  if (!stage.run_skm(f)) {
+    *why = "an output region overflowed";
+    return false;
+  }
+  stage.mark_mode_used = 1;
+  char txt[256];
+  snprintf(txt, sizeof txt, "super-k-mers m%u, %u bins (%llu records for %llu windows: %.2f per record; largest bin %u)", k + 1 - 9, f.n_bins,
+           (unsigned long long)f.n_records, (unsigned long long)f.n_windows, f.n_records ? (double)f.n_windows / (double)f.n_records : 0.0, f.max_bin);
+  c->last_s1_plan = txt;
+  stage.publish(out);
+  return true;
+}
+
 int run_s1(mhx_ctx *c, uint32_t k, uint32_t m, int want_mercy, mhx_s1_result *out) {
   if (c->global_bases) throw Error("read2sdbg_s1: a global layout is set; use the mhx_dist_* entry points");
+  std::string skm_why;
+  if (s1_skm_applies(c, k, m, want_mercy)) {
+    c->gen_first_pass = nullptr;
+    c->pre_hist_buf = nullptr;
+    if (s1_skm_try(c, k, m, out, &skm_why)) return 0;
+  }
   c->s1_defer_items = !want_mercy;  // s1_process sorts "items_a" first thing: its first pass may make the records (and apply a bucket filter)
   c->gen_first_pass = nullptr;
   const StageItems it = extract_stage(c, want_mercy ? MHX_STAGE_S1_MERCY : MHX_STAGE_S1, k, m);
   c->s1_defer_items = false;
   uint32_t *buf_a = c->work["items_a"].as<uint32_t>();
   uint32_t *buf_b = c->ws("items_b", it.n * (size_t)it.S * 4 + 64).as<uint32_t>();
-  return s1_process(c, k, m, want_mercy, buf_a, buf_b, it.n, out);
+  const int rc = s1_process(c, k, m, want_mercy, buf_a, buf_b, it.n, out);
+  if (!skm_why.empty()) c->last_s1_plan += " [super-k-mer records given up: " + skm_why + "]";
+  return rc;
 }
 
 }  // namespace mhx

@@ -1,0 +1,107 @@
+"""GPU: read2sdbg stage 1 on super-k-mer records (round 6, megahit_amd/csrc/s1_skm.hip): the windows of a read that share a minimizer
+leave as one 16-byte record, two sort passes order the records by minimizer bin, one workgroup groups a bin in an LDS table with 64-bit
+keys.  Against the oracle's Read2SdbgS1 / Read2SdbgS2 (reference src/sorting/read_to_sdbg_s1.cpp:208-464, read_to_sdbg_s2.cpp:521-614):
+is_solid, the multiplicity histogram, the item count the reference sorts, and the SdBG stage 2 builds from the aggregated items — every k
+the path serves, min count 1 and 2, tables that overflow and split by a second hash, probe limits, libraries whose reads are shorter than
+two blocks, low-complexity reads (the path hands the job to the prefix plan and says so), and the shapes it declines."""
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+from megahit_amd import lib, synth
+from test_gpu_count import load, make_reads
+from test_gpu_round3_knobs import fixed_library
+from test_gpu_sdbg import check_sdbg
+
+pytestmark = pytest.mark.gpu
+
+RESET = dict(s1_skm=1, s1_stream_fill=7168, s1_stream_probes=1024, s1_skm_max_bin=65536, s1_skm_min_windows=1 << 22)
+
+
+def run(engine, reads, k, m, opts, want_plan="super-k-mers", want_kernels=("s1_skm_make", "s1_skm_groups"), absent=("s1_groups",), why=None):
+    pkg = ob.Package(reads, reverse=True)
+    want1 = ob.s1(pkg, k, m, tie_stable=True)
+    want2 = ob.s2(pkg, k, m, want1["is_solid"])
+    load(engine, pkg)
+    try:
+        for n, v in opts.items():
+            engine.set_option(n, v)
+        engine.profile(True)
+        engine.profile_reset()
+        r1 = engine.read2sdbg_s1(k, m)
+        stats = engine.profile_get()
+        engine.profile(False)
+        plan = engine.last_s1_plan()
+        assert plan.startswith(want_plan), plan
+        if why:
+            assert why in plan, plan
+        for kn in want_kernels:
+            assert kn in stats, sorted(stats)
+        for kn in absent:
+            assert kn not in stats, sorted(stats)
+        solid = engine.fetch(lib.BUF_IS_SOLID, np.uint64)
+        assert r1.n_items == want1["n_items"]
+        assert np.array_equal(solid, want1["is_solid"][: solid.size])
+        assert np.array_equal(engine.fetch(lib.BUF_MUL_HIST, np.int64), want1["hist"])
+        assert r1.n_solid == int(sum(bin(int(x)).count("1") for x in want1["is_solid"]))
+        check_sdbg(engine, engine.read2sdbg_s2(k, m), want2)
+    finally:
+        engine.profile(False)
+        for n, v in RESET.items():
+            engine.set_option(n, v)
+
+
+@pytest.mark.parametrize("opts", [dict(), dict(s1_stream_fill=40), dict(s1_stream_fill=3), dict(s1_stream_probes=2)],
+                         ids=lambda o: ",".join("%s=%d" % kv for kv in o.items()) or "default")
+@pytest.mark.parametrize("kind,k,m", [("pe100", 21, 2), ("repeats100", 21, 2), ("short30", 21, 2), ("tiny60", 21, 2), ("pe100", 19, 2), ("repeats100", 22, 2),
+                                      ("pe100", 20, 1), ("repeats100", 21, 1)])
+def test_stage1_on_super_kmer_records(engine, kind, k, m, opts):
+    run(engine, fixed_library(kind, seed=k * 7 + m), k, m, dict(opts, s1_skm=2, s1_skm_max_bin=1 << 30))
+
+
+def test_a_larger_library_takes_the_path_by_itself(engine):
+    """above s1_skm_min_windows the path is the default: 60 000 reads of 100 bases at k = 21"""
+    reads = [x for x in synth.gen_pe_reads(20000, 60000, read_len=100, frag=250, err=0.01, seed=3)]
+    run(engine, reads, 21, 2, dict(s1_skm_min_windows=1 << 20))
+
+
+def test_low_complexity_reads_go_to_the_prefix_plan(engine):
+    """reads of one base put every window into one bin: the records are made and ordered, the bin is found too large for one workgroup, and
+    the prefix plan (with its giant path) does the stage — the plan line says why"""
+    reads = fixed_library("pe100", seed=11) + [np.zeros(100, dtype=np.uint8) for _ in range(3000)]
+    run(engine, reads, 21, 2, dict(s1_skm=2, s1_skm_max_bin=1024), want_plan="stream", want_kernels=("s1_skm_make", "s1_groups"), absent=("s1_skm_groups",),
+        why="super-k-mer records given up: a bin of")
+
+
+def test_the_same_reads_with_the_limit_lifted(engine):
+    """... and with the limit lifted one workgroup streams the poly-A bin: slow, but the same answer"""
+    reads = fixed_library("pe100", seed=11) + [np.zeros(100, dtype=np.uint8) for _ in range(3000)]
+    run(engine, reads, 21, 2, dict(s1_skm=2, s1_skm_max_bin=1 << 30))
+
+
+@pytest.mark.parametrize("k,m,how", [(17, 2, "k"), (23, 2, "k"), (21, 3, "m"), (21, 2, "var"), (21, 2, "off")])
+def test_shapes_the_path_declines(engine, k, m, how):
+    reads = make_reads("var", 3) if how == "var" else fixed_library("pe100", seed=k)
+    opts = dict(s1_skm=0 if how == "off" else 2)
+    if how == "var":
+        opts["s1_var_min_fill"] = 10
+    try:
+        run(engine, reads, k, m, opts, want_plan="", want_kernels=(), absent=("s1_skm_make", "s1_skm_groups"))
+    finally:
+        engine.set_option("s1_var_min_fill", 50)
+
+
+def test_mercy_takes_the_sorted_records(engine):
+    reads = fixed_library("pe100", seed=2)
+    pkg = ob.Package(reads, reverse=True)
+    w1 = ob.s1(pkg, 21, 2, tie_stable=True)
+    load(engine, pkg)
+    try:
+        engine.set_option("s1_skm", 2)
+        r1 = engine.read2sdbg_s1(21, 2, want_mercy=True)
+        assert not engine.last_s1_plan().startswith("super-k-mers")
+        assert r1.n_items == w1["n_items"]
+        solid = engine.fetch(lib.BUF_IS_SOLID, np.uint64)
+        assert np.array_equal(solid, w1["is_solid"][: solid.size])
+    finally:
+        engine.set_option("s1_skm", 1)
