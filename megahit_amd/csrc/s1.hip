@@ -1176,9 +1176,7 @@ static bool s1_skm_try(mhx_ctx *c, uint32_t k, uint32_t m, mhx_s1_result *out, s
     *why = f.n_records ? "a bin of " + std::to_string(f.max_bin) + " records" : "more records than the array holds";
     return false;
   }
-  const SeqSet &s = c->seqs;
-  const uint64_t n_items = s.n_seqs * (uint64_t)(s.fixed_len - k + 4);  // what the reference sorts (read_to_sdbg_s1.cpp:344-363)
-  S1Stage stage(c, k, m, 0, nullptr, nullptr, n_items, nullptr);
+  S1Stage stage(c, k, m, 0, nullptr, nullptr, f.n_items, nullptr);  // (n_items: what the reference sorts, read_to_sdbg_s1.cpp:344-363)
   stage.sorted = nullptr;
   stage.set_spare(f.spare);
   stage.open_outputs();
@@ -1188,8 +1186,9 @@ static bool s1_skm_try(mhx_ctx *c, uint32_t k, uint32_t m, mhx_s1_result *out, s
   }
   stage.mark_mode_used = 1;
   char txt[256];
-  snprintf(txt, sizeof txt, "super-k-mers m%u, %u bins (%llu records for %llu windows: %.2f per record; largest bin %u)", k + 1 - 9, f.n_bins,
-           (unsigned long long)f.n_records, (unsigned long long)f.n_windows, f.n_records ? (double)f.n_windows / (double)f.n_records : 0.0, f.max_bin);
+  snprintf(txt, sizeof txt, "super-k-mers m%u, 2^%d bins (%llu records for %llu windows: %.2f per record; largest bin %u)%s", k + 1 - 9, f.bin_bits,
+           (unsigned long long)f.n_records, (unsigned long long)f.n_windows, f.n_records ? (double)f.n_windows / (double)f.n_records : 0.0, f.max_bin,
+           c->seqs.fixed_len ? "" : " [reads of several lengths]");
   c->last_s1_plan = txt;
   stage.publish(out);
   return true;

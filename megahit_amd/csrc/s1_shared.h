@@ -178,8 +178,10 @@ struct SkmFront {
   uint32_t *spare;       // the other sort buffer (the workgroups' output regions)
   uint64_t spare_bytes;
   uint64_t n_records, n_windows;
+  uint64_t n_items;        // what the reference sorts: L - k + 4 items per read that holds an edge
   const uint64_t *bounds;  // [n_bins + 1]
   uint32_t n_bins, max_bin;
+  int bin_bits;
 };
 bool s1_skm_applies(const mhx_ctx *c, uint32_t k, uint32_t m, int want_mercy);
 bool s1_skm_front(mhx_ctx *c, uint32_t k, SkmFront *f);

@@ -26,35 +26,43 @@ namespace mhx {
 constexpr int kSkmC = 8;                     // windows per aligned block = the longest run a record holds
 constexpr int kSkmW = 10;                    // m-mers per window: m = k + 1 - 9
 constexpr int kSkmNM = kSkmC + kSkmW - 1;    // m-mers a block looks at
-constexpr int kSkmBinBits = 16;
+constexpr int kSkmMinBinBits = 16, kSkmMaxBinBits = 20;  // two sort passes, or three
 
 __device__ __forceinline__ uint32_t skm_mix(uint32_t c) {  // (a bijection of 32 bits: the order of the m-mers)
   uint32_t h = c * 0x9E3779B1u;
   h ^= h >> 15;
   return h * 0x85EBCA6Bu;
 }
-__device__ __forceinline__ uint32_t skm_bin_of(uint32_t minh) {  // (the minimum of ten hashes is small: mixed once more before its top bits are taken)
+__device__ __forceinline__ uint32_t skm_bin_of(uint32_t minh) {  // (the minimum of ten hashes is small: mixed once more; the bin = its top bits)
   uint32_t h = minh ^ (minh >> 16);
   h *= 0x7FEB352Du;
   h ^= h >> 15;
-  return (h * 0x846CA68Bu) >> (32 - kSkmBinBits);
+  return h * 0x846CA68Bu;
 }
 
-// record: w0 = bin << 8 | (windows - 1) << 24 (bits 0..7 zero: the first sort pass may rank with LDS atomics, sort_kernels.h RANK 2),
-// w1:w2 = the bases of the run, MSB first (k + windows of them), w3 = position of the run's first base in the store
-template <int NT, int J>
-__global__ __launch_bounds__(NT) void k_skm_make(const uint32_t *__restrict__ seq, uint32_t L, uint32_t nwin, uint32_t bpr, uint64_t n_blocks, int k,
-                                                 uint4 *__restrict__ out, unsigned long long cap, unsigned long long *__restrict__ cursor,
-                                                 uint32_t *__restrict__ err) {
+// record (16 bytes): w0 = position bits 32.. << 28 | bin << 8 (bits 0..7 zero: the sort passes may rank with LDS atomics, sort_kernels.h
+// RANK 2), w1:w2 = the bases of the run, MSB first (k + windows of them: at most 30 at k <= 22) with windows - 1 in the three lowest bits,
+// w3 = position of the run's first base in the store, low 32 bits.
+// VAR: reads of several lengths — every read gets bpr = ceil((max_len - k) / 8) blocks, its place in the store comes from start[]
+// (as the padded item slots of S1GenVarT); a block beyond the read's last window makes nothing.
+template <int NT, int J, bool VAR>
+__global__ __launch_bounds__(NT) void k_skm_make(const uint32_t *__restrict__ seq, const uint64_t *__restrict__ start, uint32_t L, uint32_t bpr, uint64_t n_blocks,
+                                                 int k, int bin_bits, uint4 *__restrict__ out, unsigned long long cap, unsigned long long *__restrict__ cursor,
+                                                 uint32_t *__restrict__ err, unsigned long long *__restrict__ digit_hist) {
   __shared__ uint32_t sm_scan[NT / kWave + 1];
   __shared__ unsigned long long s_base;
+  __shared__ uint32_t dh[3][256];  // the digit histograms of the sort passes, taken while the records are made
   const int tid = threadIdx.x;
+  for (int i = tid; i < 768; i += NT) dh[i >> 8][i & 255] = 0;
+  __syncthreads();
   const int M = k + 1 - (kSkmW - 1);
   const uint32_t mmask = (1u << (2 * M)) - 1u;
   const int K1 = k + 1;
+  const unsigned bin_sh = 32u - (unsigned)bin_bits;
+  unsigned long long items = 0;  // VAR: what the reference sorts, L - k + 4 items per read that holds an edge (read_to_sdbg_s1.cpp:344-363)
   for (uint64_t it = blockIdx.x; it * (uint64_t)(NT * J) < n_blocks; it += gridDim.x) {
-    uint64_t Wv[J];
-    uint32_t binp[J][4], smask[J], pos0[J], nv[J];
+    uint64_t Wv[J], pos0[J];
+    uint32_t binp[J][8], smask[J], nv[J];
 #pragma unroll
     for (int j = 0; j < J; ++j) {
       const uint64_t b = it * (uint64_t)(NT * J) + (uint64_t)j * NT + tid;
@@ -63,47 +71,57 @@ __global__ __launch_bounds__(NT) void k_skm_make(const uint32_t *__restrict__ se
       Wv[j] = 0;
       pos0[j] = 0;
 #pragma unroll
-      for (int x = 0; x < 4; ++x) binp[j][x] = 0;
+      for (int x = 0; x < 8; ++x) binp[j][x] = 0;
       if (b < n_blocks) {
         const uint64_t r = b / bpr;
         const uint32_t q0 = (uint32_t)(b - r * bpr) * kSkmC;
-        const uint64_t a = r * L + q0;
-        const uint64_t wi = a >> 4;
-        const unsigned sh = (unsigned)(a & 15) * 2;
-        const uint32_t c0 = seq[wi], c1 = seq[wi + 1], c2 = seq[wi + 2];
-        const uint64_t W = ((uint64_t)funnel_l(c0, c1, sh) << 32) | funnel_l(c1, c2, sh);
-        const uint64_t R = rc64(W, 32);
-        uint32_t h[kSkmNM];
-#pragma unroll
-        for (int i = 0; i < kSkmNM; ++i) {
-          const uint32_t f = (uint32_t)(W >> (64 - 2 * (i + M))) & mmask;
-          const uint32_t rv = (uint32_t)(R >> (2 * i)) & mmask;
-          h[i] = skm_mix(min(f, rv));
+        uint64_t base;
+        uint32_t nwin;
+        if constexpr (VAR) {
+          base = start[r];
+          const uint64_t len_r = start[r + 1] - base;
+          nwin = len_r >= (uint64_t)K1 ? (uint32_t)(len_r - k) : 0u;
+          if (q0 == 0 && nwin) items += nwin + 4;
+        } else {
+          base = r * L;
+          nwin = L - k;
         }
-        // window j: the minimum of h[j .. j + 9] = min(suffix minimum inside h[0..9], prefix minimum inside h[10..16])
-        uint32_t sfx[kSkmW];
-        sfx[kSkmW - 1] = h[kSkmW - 1];
+        if (q0 < nwin) {
+          const uint64_t a = base + q0;
+          const uint64_t wi = a >> 4;
+          const unsigned sh = (unsigned)(a & 15) * 2;
+          const uint32_t c0 = seq[wi], c1 = seq[wi + 1], c2 = seq[wi + 2];
+          const uint64_t W = ((uint64_t)funnel_l(c0, c1, sh) << 32) | funnel_l(c1, c2, sh);
+          const uint64_t R = rc64(W, 32);
+          uint32_t h[kSkmNM];
 #pragma unroll
-        for (int i = kSkmW - 2; i >= 0; --i) sfx[i] = min(h[i], sfx[i + 1]);
-        uint32_t pfx = 0xFFFFFFFFu;
-        uint32_t bins[kSkmC];
-        bins[0] = skm_bin_of(sfx[0]);
+          for (int i = 0; i < kSkmNM; ++i) {
+            const uint32_t f = (uint32_t)(W >> (64 - 2 * (i + M))) & mmask;
+            const uint32_t rv = (uint32_t)(R >> (2 * i)) & mmask;
+            h[i] = skm_mix(min(f, rv));
+          }
+          // window j: the minimum of h[j .. j + 9] = min(suffix minimum inside h[0..9], prefix minimum inside h[10..16])
+          uint32_t sfx[kSkmW];
+          sfx[kSkmW - 1] = h[kSkmW - 1];
 #pragma unroll
-        for (int w = 1; w < kSkmC; ++w) {
-          pfx = min(pfx, h[kSkmW - 1 + w]);
-          bins[w] = skm_bin_of(min(sfx[w], pfx));
+          for (int i = kSkmW - 2; i >= 0; --i) sfx[i] = min(h[i], sfx[i + 1]);
+          uint32_t pfx = 0xFFFFFFFFu;
+          binp[j][0] = skm_bin_of(sfx[0]) >> bin_sh;
+#pragma unroll
+          for (int w = 1; w < kSkmC; ++w) {
+            pfx = min(pfx, h[kSkmW - 1 + w]);
+            binp[j][w] = skm_bin_of(min(sfx[w], pfx)) >> bin_sh;
+          }
+          const uint32_t n_here = min((uint32_t)kSkmC, nwin - q0);
+          uint32_t sm = 1u;
+#pragma unroll
+          for (int w = 1; w < kSkmC; ++w)
+            if ((uint32_t)w < n_here && binp[j][w] != binp[j][w - 1]) sm |= 1u << w;
+          smask[j] = sm;
+          nv[j] = n_here;
+          Wv[j] = W;
+          pos0[j] = a;
         }
-        const uint32_t n_here = min((uint32_t)kSkmC, nwin - q0);
-        uint32_t sm = 1u;
-#pragma unroll
-        for (int w = 1; w < kSkmC; ++w)
-          if ((uint32_t)w < n_here && bins[w] != bins[w - 1]) sm |= 1u << w;
-        smask[j] = sm;
-        nv[j] = n_here;
-        Wv[j] = W;
-        pos0[j] = (uint32_t)a;
-#pragma unroll
-        for (int x = 0; x < 4; ++x) binp[j][x] = bins[2 * x] | (bins[2 * x + 1] << 16);
       }
     }
     uint32_t cnt = 0;
@@ -114,27 +132,42 @@ __global__ __launch_bounds__(NT) void k_skm_make(const uint32_t *__restrict__ se
     if (tid == 0) s_base = total ? atomicAdd(cursor, (unsigned long long)total) : 0ull;
     __syncthreads();
     const unsigned long long base = s_base;
-    if (base + total > cap) {  // (uniform) the array is sized for one record per two windows: the host takes the prefix plan
+    if (base + total > cap) {  // (uniform) more records than the array was sized for: the host takes the prefix plan
       if (tid == 0) atomicOr(err, 1u);
       return;
     }
     unsigned long long at = base + excl;
 #pragma unroll
     for (int j = 0; j < J; ++j) {
-      uint32_t sm = smask[j];
-      while (sm) {
-        const int s = __builtin_ctz(sm);
-        sm &= sm - 1;
-        const int e = sm ? __builtin_ctz(sm) : (int)nv[j];
-        const int len = e - s;
-        const int nb = K1 + len - 1;
-        const uint64_t bases = (Wv[j] << (2 * s)) & (~0ull << (64 - 2 * nb));
-        const uint32_t pw = s < 2 ? binp[j][0] : (s < 4 ? binp[j][1] : (s < 6 ? binp[j][2] : binp[j][3]));
-        const uint32_t bin = (pw >> ((s & 1) * 16)) & 0xFFFFu;
-        out[at++] = make_uint4((bin << 8) | ((uint32_t)(len - 1) << 24), (uint32_t)(bases >> 32), (uint32_t)bases, pos0[j] + (uint32_t)s);
+      // (straight-line over the eight windows: no register array is indexed by a variable)
+      uint32_t run_bin = binp[j][0];
+      int run_s = 0;
+#pragma unroll
+      for (int w = 1; w <= kSkmC; ++w) {
+        const bool head = w < kSkmC && ((smask[j] >> w) & 1u);
+        if ((head || (uint32_t)w == nv[j]) && nv[j]) {  // a run ends in front of window w
+          const int len = w - run_s;
+          const uint64_t p = pos0[j] + (uint64_t)run_s;
+          const uint64_t bases = ((Wv[j] << (2 * run_s)) & (~0ull << (64 - 2 * (K1 + len - 1)))) | (uint64_t)(len - 1);
+          out[at++] = make_uint4((run_bin << 8) | ((uint32_t)(p >> 32) << 28), (uint32_t)(bases >> 32), (uint32_t)bases, (uint32_t)p);
+          atomicAdd(&dh[0][run_bin & 255u], 1u);
+          atomicAdd(&dh[1][(run_bin >> 8) & 255u], 1u);
+          atomicAdd(&dh[2][run_bin >> 16], 1u);
+        }
+        if (head) {
+          run_bin = binp[j][w < kSkmC ? w : 0];
+          run_s = w;
+        }
       }
     }
   }
+  if constexpr (VAR) {
+    items = wave_sum(items);
+    if ((tid & (kWave - 1)) == 0 && items) atomicAdd(cursor + 3, items);
+  }
+  __syncthreads();
+  for (int i = tid; i < 768; i += NT)
+    if (dh[i >> 8][i & 255]) atomicAdd(&digit_hist[i], (unsigned long long)dh[i >> 8][i & 255]);
 }
 
 // bounds[b] = the first record whose bin is >= b (b = 0 .. n_bins); a thread per bin, a binary search each
@@ -146,7 +179,7 @@ __global__ __launch_bounds__(256) void k_skm_bounds(const uint4 *__restrict__ re
     uint64_t lo = 0, hi = n;
     while (lo < hi) {
       const uint64_t mid = (lo + hi) >> 1;
-      const uint32_t bin = (reinterpret_cast<const uint32_t *>(recs + mid)[0] >> 8) & 0xFFFFu;
+      const uint32_t bin = (reinterpret_cast<const uint32_t *>(recs + mid)[0] >> 8) & 0xFFFFFu;
       if (bin < v) lo = mid + 1;
       else hi = mid;
     }
@@ -177,22 +210,23 @@ struct SkmArgs {
 
 constexpr int kSkmThreads = 1024, kSkmLogSlots = 13, kSkmBatch = 4;
 
-template <bool AGG>
+// TAGS: read sets of 2^32 bases and more — the position bits above 32 ride in the record's first word and next to the key in the table
+template <bool AGG, bool TAGS>
 __global__ __launch_bounds__(kSkmThreads) void k_s1_skm(const uint4 *__restrict__ recs, const uint64_t *__restrict__ bounds, SkmArgs a,
                                                         uint32_t *__restrict__ ticket) {
-  constexpr int NT = kSkmThreads, NSLOT = 1 << kSkmLogSlots, NW = NT / kWave, W = NSLOT / NT;
+  constexpr int NT = kSkmThreads, NSLOT = 1 << kSkmLogSlots, W = NSLOT / NT;
   constexpr unsigned long long kEmpty = ~0ull;  // never a key: head / tail bits 63 do not occur
   constexpr int NLIST = 1024;
   __shared__ unsigned long long keys[NSLOT];
   __shared__ uint32_t cnts[NSLOT];
   __shared__ uint32_t fpos[NSLOT];
+  __shared__ uint8_t ftag[TAGS ? NSLOT : 4];
   __shared__ uint32_t lhist[kSegHist];
   __shared__ unsigned long long slist_k[AGG ? NLIST : 1];
   __shared__ uint32_t slist_c[AGG ? NLIST : 1];
-  __shared__ uint32_t heads[NW][16];  // per wavefront: bit g set = window g of the trip is the first of its record
   __shared__ uint32_t s_bad, s_nclaimed, s_list_n, s_agg_cur, s_tk;
   __shared__ uint64_t s_lo[kSkmBatch + 1];
-  const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = tid / kWave;
+  const int tid = threadIdx.x, lane = tid & (kWave - 1);
   const int k = a.k, K1 = k + 1;
   const uint32_t m = a.m;
   const uint64_t kmask = ~0ull << (64 - 2 * (k - 1));
@@ -273,60 +307,92 @@ __global__ __launch_bounds__(kSkmThreads) void k_s1_skm(const uint4 *__restrict_
           const bool in = base + tid < hi;
           if (base + NT + tid < hi) nxt = recs[base + NT + tid];
           if (seen > a.max_fill) continue;  // (uniform per wavefront; the round is redone in halves anyway)
-          const uint32_t len = in ? ((r.x >> 24) & 7u) + 1u : 0u;
-          const uint32_t incl = wave_inclusive_sum(len);
-          const uint32_t T = __shfl(incl, kWave - 1, kWave);
-          const uint32_t start = incl - len;
-          if (lane < 16) heads[wv][lane] = 0;
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-          __builtin_amdgcn_wave_barrier();
-          if (len) atomicOr(&heads[wv][start >> 5], 1u << (start & 31u));
-          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-          __builtin_amdgcn_wave_barrier();
-          uint32_t cbase = 0, claims = 0;
-          for (uint32_t g0 = 0; g0 < T; g0 += kWave) {
-            const uint32_t g = g0 + lane;
-            const volatile uint32_t *hw = &heads[wv][(g0 >> 5)];
-            const uint64_t word = (uint64_t)hw[0] | ((uint64_t)hw[1] << 32);
-            const uint64_t le = lane == kWave - 1 ? ~0ull : ((2ull << lane) - 1ull);
-            const bool valid = g < T;
-            const uint32_t o = valid ? cbase + (uint32_t)__builtin_popcountll(word & le) - 1u : 0u;
-            cbase += (uint32_t)__builtin_popcountll(word);
-            const uint32_t bh = __shfl(r.y, (int)o, kWave), bl = __shfl(r.z, (int)o, kWave), ps = __shfl(r.w, (int)o, kWave);
-            const uint32_t so = __shfl(start, (int)o, kWave);
-            const uint32_t j = g - so;
-            const uint64_t win = (((uint64_t)bh << 32) | bl) << (2 * j);  // the (k+1)-mer head.S.tail, MSB first
-            const uint64_t f = (win << 2) & kmask;
-            const uint64_t rc = rc64(f, k - 1);
-            const unsigned head = (unsigned)(win >> 62), tail = (unsigned)(win >> (62 - 2 * k)) & 3u;
-            const int strand = f > rc ? 1 : (f < rc ? 0 : (head <= 3 - tail ? 0 : 1));
-            const unsigned long long key = strand ? (rc | ((uint64_t)(3u - tail) << 3) | (3u - head)) : (f | ((uint64_t)head << 3) | tail);
-            const uint32_t klo = (uint32_t)key, khi = (uint32_t)(key >> 32);
-            const uint32_t h2 = (klo * 0xC2B2AE35u) ^ (khi * 0x27D4EB2Fu);
-            bool pend = valid && (sub == 0 || (skm_mix(h2) >> (32 - sub)) == rj);
-            uint32_t hh = ((klo * 0x9E3779B1u) ^ (khi * 0x85EBCA6Bu)) >> (32 - kSkmLogSlots);
-            if (a.probe_limit <= 0 && pend) {
-              s_bad = 1;
-              pend = false;
+          const uint32_t len = in ? (r.z & 7u) + 1u : 0u;
+          const uint8_t tag = TAGS ? (uint8_t)(r.x >> 28) : (uint8_t)0;
+          // Every lane expands its own record, four windows at a time: the keys are independent of each other, so their compare-and-swaps
+          // go out back to back and ONE LDS round trip serves four windows.  (Dealing the windows of a wavefront's records evenly to the
+          // lanes — a bitmap of run heads, six shuffles per window — kept all lanes busy but cost three dependent LDS round trips and
+          // 120 vector instructions per window and wavefront: measured 9.0 ms against this form's; the SQ counters had the waves waiting
+          // 52 % of their cycles.)  The reverse complement of the record's 32 base slots is formed once: a window's is a sub-window of it.
+          const uint64_t rec_b = ((uint64_t)r.y << 32) | r.z;
+          const uint64_t rec_r = rc64(rec_b, 32);
+          uint32_t claims = 0;
+          // (the slot found — the key's own, or a free one claimed: count it, and remember the record that claimed it)
+          auto settle = [&](unsigned long long old, unsigned long long key, uint32_t hh, uint32_t pos) -> bool {
+            if (old != kEmpty && old != key) return false;
+            atomicAdd(&cnts[hh], 1u);
+            if (old == kEmpty) {  // only read back when the count stays 1: then this window is the key's only one
+              fpos[hh] = pos;
+              if constexpr (TAGS) ftag[hh] = tag + (pos < r.w ? 1 : 0);  // (a run across a multiple of 2^32)
+              ++claims;
             }
-            int turns = 0;
-            while (__ballot(pend)) {
-              if (pend) {
-                const unsigned long long old = atomicCAS(&keys[hh], kEmpty, key);
-                if (old == kEmpty) {
-                  fpos[hh] = ps + j;
-                  atomicAdd(&cnts[hh], 1u);
-                  ++claims;
-                  pend = false;
-                } else if (old == key) {
-                  atomicAdd(&cnts[hh], 1u);
-                  pend = false;
-                } else {
-                  hh = (hh + 1) & (NSLOT - 1);
+            return true;
+          };
+#pragma unroll
+          for (int half = 0; half < 2; ++half) {
+            if (half == 1 && __ballot(len > 4u) == 0) break;  // (uniform)
+            unsigned long long key[4], old1[4];
+            uint32_t h1[4], mine = 0;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const int j = half * 4 + u;
+              const uint64_t win = rec_b << (2 * j);  // the (k+1)-mer head.S.tail, MSB first
+              const uint64_t f = (win << 2) & kmask;
+              const uint64_t rc = (rec_r << (2 * (32 - k - j))) & kmask;
+              const unsigned head = (unsigned)(win >> 62), tail = (unsigned)(win >> (62 - 2 * k)) & 3u;
+              const bool rev = f > rc || (f == rc && head > 3u - tail);  // read_to_sdbg_s1.cpp:228-292
+              const uint64_t kf = f | ((uint64_t)head << 3) | tail, kr = rc | ((uint64_t)(3u - tail) << 3) | (3u - head);
+              key[u] = rev ? kr : kf;
+              const uint32_t klo = (uint32_t)key[u], khi = (uint32_t)(key[u] >> 32);
+              bool mn = (uint32_t)j < len;
+              if (sub) mn = mn && (skm_mix((klo * 0xC2B2AE35u) ^ (khi * 0x27D4EB2Fu)) >> (32 - sub)) == rj;  // (uniform branch)
+              mine |= mn ? 1u << u : 0u;
+              h1[u] = ((klo * 0x9E3779B1u) ^ (khi * 0x85EBCA6Bu)) >> (32 - kSkmLogSlots);
+            }
+            if (a.probe_limit <= 0) {
+              if (mine) s_bad = 1;
+              mine = 0;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              old1[u] = kEmpty;
+              if ((mine >> u) & 1u) old1[u] = atomicCAS(&keys[h1[u]], kEmpty, key[u]);
+            }
+            // a lane that met another key keeps the window pending — one per lane; a second one of the same four is seen to on the spot —
+            // and the pending windows of all lanes are retried together
+            bool has = false;
+            unsigned long long pk = 0;
+            uint32_t ph = 0, pp = 0;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              if ((mine >> u) & 1u) {
+                const uint32_t pos = r.w + (uint32_t)(half * 4 + u);
+                if (!settle(old1[u], key[u], h1[u], pos)) {
+                  uint32_t hh = (h1[u] + 1) & (NSLOT - 1);
+                  if (!has) {
+                    has = true;
+                    pk = key[u], ph = hh, pp = pos;
+                  } else {
+                    int n = 0;
+                    while (!settle(atomicCAS(&keys[hh], kEmpty, key[u]), key[u], hh, pos)) {
+                      hh = (hh + 1) & (NSLOT - 1);
+                      if (++n >= a.probe_limit) {
+                        s_bad = 1;
+                        break;
+                      }
+                    }
+                  }
                 }
               }
-              if (++turns > a.probe_limit) {
-                if (pend) s_bad = 1;
+            }
+            int turns = 0;
+            while (__ballot(has)) {
+              if (has) {
+                if (settle(atomicCAS(&keys[ph], kEmpty, pk), pk, ph, pp)) has = false;
+                else ph = (ph + 1) & (NSLOT - 1);
+              }
+              if (++turns > a.probe_limit) {  // (uniform: every lane counts the same turns)
+                if (has) s_bad = 1;
                 break;
               }
             }
@@ -362,12 +428,14 @@ __global__ __launch_bounds__(kSkmThreads) void k_s1_skm(const uint4 *__restrict_
         // C: one walk over the table — per distinct key: histogram, the mark of a non-solid key's only record, the solid keys listed
         unsigned long long wk[W];
         uint32_t wc[W], wp[W];
+        uint8_t wt[W];
 #pragma unroll
         for (int it = 0; it < W; ++it) {
           const int sl = it * NT + tid;
           wk[it] = keys[sl];
           wc[it] = cnts[sl];
           wp[it] = fpos[sl];
+          wt[it] = TAGS ? ftag[sl] : (uint8_t)0;
         }
 #pragma unroll
         for (int it = 0; it < W; ++it) {
@@ -383,7 +451,7 @@ __global__ __launch_bounds__(kSkmThreads) void k_s1_skm(const uint4 *__restrict_
             const uint32_t hb = cnt > MHX_MAX_MUL ? (uint32_t)MHX_MAX_MUL : cnt;  // :430-436
             if (hb < kSegHist) atomicAdd(&lhist[hb], 1u);
             else atomicAdd(&a.hist[hb], 1ull);
-            if (cnt < m) a.solid_bytes[wp[it]] = 1;  // count 1 < m <= 2: the key's only record is a non-solid occurrence
+            if (cnt < m) a.solid_bytes[((uint64_t)wt[it] << 32) | wp[it]] = 1;  // count 1 < m <= 2: the key's only window is a non-solid occurrence
             else if (AGG) want_bits |= 1u << it;
           }
         }
@@ -443,10 +511,12 @@ bool s1_skm_applies(const mhx_ctx *c, uint32_t k, uint32_t m, int want_mercy) {
   const long long knob = c->opt("s1_skm", 1);
   if (!knob || want_mercy || c->global_bases || c->n_parts > 1 || c->filter_on || c->accumulate || c->pos_base) return false;
   if (k < 19 || k > 22 || m < 1 || m > 2) return false;
-  if (!s.n_seqs || s.fixed_len < k + 1 || s.n_bases >= (1ull << 32)) return false;
+  if (!s.n_seqs || s.max_len < k + 1 || (s.n_bases >> 36)) return false;
+  // (reads of several lengths: every read takes the blocks of the longest — while at least s1_var_min_fill per cent of them hold windows)
+  if (!s.fixed_len && (double)s.n_bases * 100.0 < (double)c->opt("s1_var_min_fill", 50) * (double)s.n_seqs * s.max_len) return false;
   const char *e = getenv("MHX_S1_MARK");
   if (e && strcmp(e, "nonsolid")) return false;  // (a caller that asks for another polarity of the marks, or atomics into the bitmap)
-  const uint64_t n_win = s.n_seqs * (uint64_t)(s.fixed_len - k);
+  const uint64_t n_win = s.n_bases > s.n_seqs * (uint64_t)k ? s.n_bases - s.n_seqs * (uint64_t)k : 0;
   return knob >= 2 || n_win >= (uint64_t)c->opt("s1_skm_min_windows", 1 << 22);
 }
 
@@ -455,31 +525,52 @@ bool s1_skm_applies(const mhx_ctx *c, uint32_t k, uint32_t m, int want_mercy) {
 bool s1_skm_front(mhx_ctx *c, uint32_t k, SkmFront *f) {
   SeqSet &s = c->seqs;
   hipStream_t st = c->stream;
-  const uint32_t L = s.fixed_len, nwin = L - k, bpr = (nwin + kSkmC - 1) / kSkmC;
-  const uint64_t n_blocks = s.n_seqs * (uint64_t)bpr, n_win = s.n_seqs * (uint64_t)nwin;
-  const uint64_t cap = std::max<uint64_t>(n_win / 2, 1u << 16);
+  const bool var = s.fixed_len == 0;
+  const uint32_t L = var ? s.max_len : s.fixed_len, bpr = (L - k + kSkmC - 1) / kSkmC;
+  const uint64_t n_blocks = s.n_seqs * (uint64_t)bpr;
+  const uint64_t n_win = var ? (s.n_bases > s.n_seqs * (uint64_t)k ? s.n_bases - s.n_seqs * (uint64_t)k : 0) : s.n_seqs * (uint64_t)(L - k);  // (var: an estimate)
+  // the array: 0.284 records per window of random sequence at m = k - 8 (fewer in repeats); s1_skm_cap_pct per cent of the windows
+  const uint64_t cap = std::max<uint64_t>(n_win * (uint64_t)std::max<long long>(c->opt("s1_skm_cap_pct", 36), 1) / 100, 1u << 16);
+  // bins: ~5000 records each (20 000 windows: what the table of one workgroup takes in one round) — 2^16 up to 14 M reads of 150 bases,
+  // up to 2^20 and a third sort pass beyond
+  int bin_bits = kSkmMinBinBits;
+  while (bin_bits < kSkmMaxBinBits && (double)n_win * 0.29 / (double)(1ull << bin_bits) > 8192.0) ++bin_bits;
+  if (const long long fb = c->opt("s1_skm_bin_bits", 0)) bin_bits = (int)std::min<long long>(kSkmMaxBinBits, std::max<long long>(8, fb));
   uint4 *buf_a = c->ws("items_a", cap * 16 + 64).as<uint4>();
   uint4 *buf_b = c->ws("items_b", cap * 16 + 64).as<uint4>();
   unsigned long long *cursor = c->ws("skm_cursor", 64).as<unsigned long long>();
   uint32_t *err = reinterpret_cast<uint32_t *>(cursor + 1);
   uint32_t *max_bin = err + 1;
   MHX_HIP(hipMemsetAsync(cursor, 0, 64, st));
+  // (bits 0..7 of the first word are zero in every record: all passes may rank with LDS atomics)
+  std::vector<SortPass> passes;
+  for (int lo = 0; lo < bin_bits; lo += 8) passes.push_back(SortPass{8 + lo, std::min(8, bin_bits - lo), 0, 0, 0});
+  unsigned long long *pre_hist = c->ws("sort_pre_hist", (size_t)kMaxFusedPasses * 256 * 8).as<unsigned long long>();
+  MHX_HIP(hipMemsetAsync(pre_hist, 0, (size_t)3 * 256 * 8, st));
   constexpr int NT = 512, J = 2;
   const uint64_t cus = c->n_cus > 0 ? (uint64_t)c->n_cus : 256;
   const unsigned grid = (unsigned)std::min<uint64_t>(div_ceil(n_blocks, (uint64_t)NT * J), cus * 8);
-  MHX_LAUNCH(c, "s1_skm_make", (double)s.n_bases / 4 + (double)n_win * 16 / 3.5,
-             hipLaunchKernelGGL((k_skm_make<NT, J>), dim3(grid), dim3(NT), 0, st, s.words.as<uint32_t>(), L, nwin, bpr, n_blocks, (int)k, buf_a,
-                                (unsigned long long)cap, cursor, err));
-  unsigned long long h[2] = {0, 0};
-  MHX_HIP(hipMemcpyAsync(h, cursor, 16, hipMemcpyDeviceToHost, st));
+  MHX_LAUNCH(c, "s1_skm_make", (double)s.n_bases / 4 + (double)n_win * 16 / 3.5, {
+    if (var)
+      hipLaunchKernelGGL((k_skm_make<NT, J, true>), dim3(grid), dim3(NT), 0, st, s.words.as<uint32_t>(), s.start.as<uint64_t>(), L, bpr, n_blocks, (int)k, bin_bits, buf_a,
+                         (unsigned long long)cap, cursor, err, pre_hist);
+    else
+      hipLaunchKernelGGL((k_skm_make<NT, J, false>), dim3(grid), dim3(NT), 0, st, s.words.as<uint32_t>(), s.start.as<uint64_t>(), L, bpr, n_blocks, (int)k, bin_bits, buf_a,
+                         (unsigned long long)cap, cursor, err, pre_hist);
+  });
+  unsigned long long h[4] = {0, 0, 0, 0};
+  MHX_HIP(hipMemcpyAsync(h, cursor, 32, hipMemcpyDeviceToHost, st));
   MHX_HIP(hipStreamSynchronize(st));
+  f->n_records = 0;
   if ((uint32_t)h[1] != 0 || h[0] > cap) return false;
   const uint64_t n = h[0];
-  std::vector<SortPass> passes(2);
-  passes[0] = SortPass{8, 8, 0, 0, 0};
-  passes[1] = SortPass{16, 8, 0, 0, 0};
+  c->pre_hist_buf = buf_a;  // (radix_sort: no histogram read of its own)
+  c->pre_hist_n = n;
+  c->pre_hist_passes = (int)passes.size();
+  c->pre_hist_sig = passes_signature(passes);
   uint32_t *sorted = radix_sort(c, reinterpret_cast<uint32_t *>(buf_a), reinterpret_cast<uint32_t *>(buf_b), n, 4, 1, passes);
-  const uint32_t n_bins = 1u << kSkmBinBits;
+  c->pre_hist_buf = nullptr;
+  const uint32_t n_bins = 1u << bin_bits;
   uint64_t *bounds = c->ws("s1_bucket_bounds", ((size_t)n_bins + 1) * 8 + 64).as<uint64_t>();
   MHX_LAUNCH(c, "s1_skm_bounds", (double)n_bins * 8 * 30,
              hipLaunchKernelGGL(k_skm_bounds, dim3((n_bins + 1 + 255) / 256), dim3(256), 0, st, reinterpret_cast<const uint4 *>(sorted), n, n_bins, bounds, max_bin));
@@ -491,8 +582,10 @@ bool s1_skm_front(mhx_ctx *c, uint32_t k, SkmFront *f) {
   f->spare_bytes = cap * 16;
   f->n_records = n;
   f->n_windows = n_win;
+  f->n_items = var ? h[3] : s.n_seqs * (uint64_t)(L - k + 4);
   f->bounds = bounds;
   f->n_bins = n_bins;
+  f->bin_bits = bin_bits;
   f->max_bin = h_max;
   // a bin of many times the mean is low-complexity sequence (one minimizer for millions of windows): the prefix plan has the giant path
   const uint64_t limit = std::max<uint64_t>((uint64_t)c->opt("s1_skm_max_bin", 1 << 16), 16 * (n / n_bins + 1));
@@ -508,10 +601,15 @@ void s1_skm_groups_launch(mhx_ctx *c, bool agg, unsigned grid, const SkmFront &f
   SkmArgs a{(int)k, m, solid_bytes, hist, agg_raw, agg_cap, agg_counts, err,
             (uint32_t)std::min<long long>(std::max<long long>(c->opt("s1_stream_fill", nslot * 7 / 8), 1), nslot), (int)std::min<long long>(c->opt("s1_stream_probes", 1024), 1024),
             f.n_bins};
+  const bool tags = (c->seqs.n_bases >> 32) != 0 || c->opt("s1_skm_tags", 0) != 0;
+#define MHX_SKM(AGGV, TAGV) hipLaunchKernelGGL((k_s1_skm<AGGV, TAGV>), dim3(grid), dim3(kSkmThreads), 0, st, f.sorted, f.bounds, a, ticket)
   MHX_LAUNCH(c, "s1_skm_groups", (double)f.n_records * 16, {
-    if (agg) hipLaunchKernelGGL((k_s1_skm<true>), dim3(grid), dim3(kSkmThreads), 0, st, f.sorted, f.bounds, a, ticket);
-    else hipLaunchKernelGGL((k_s1_skm<false>), dim3(grid), dim3(kSkmThreads), 0, st, f.sorted, f.bounds, a, ticket);
+    if (agg && tags) MHX_SKM(true, true);
+    else if (agg) MHX_SKM(true, false);
+    else if (tags) MHX_SKM(false, true);
+    else MHX_SKM(false, false);
   });
+#undef MHX_SKM
 }
 
 }  // namespace mhx

@@ -15,7 +15,8 @@ from test_gpu_sdbg import check_sdbg
 
 pytestmark = pytest.mark.gpu
 
-RESET = dict(s1_skm=1, s1_stream_fill=7168, s1_stream_probes=1024, s1_skm_max_bin=65536, s1_skm_min_windows=1 << 22)
+RESET = dict(s1_skm=1, s1_stream_fill=7168, s1_stream_probes=1024, s1_skm_max_bin=65536, s1_skm_min_windows=1 << 22, s1_skm_bin_bits=0, s1_skm_tags=0, s1_skm_cap_pct=36,
+             s1_var_min_fill=50)
 
 
 def run(engine, reads, k, m, opts, want_plan="super-k-mers", want_kernels=("s1_skm_make", "s1_skm_groups"), absent=("s1_groups",), why=None):
@@ -79,16 +80,33 @@ def test_the_same_reads_with_the_limit_lifted(engine):
     run(engine, reads, 21, 2, dict(s1_skm=2, s1_skm_max_bin=1 << 30))
 
 
-@pytest.mark.parametrize("k,m,how", [(17, 2, "k"), (23, 2, "k"), (21, 3, "m"), (21, 2, "var"), (21, 2, "off")])
+@pytest.mark.parametrize("opts", [dict(s1_skm_bin_bits=20), dict(s1_skm_bin_bits=18, s1_stream_fill=40), dict(s1_skm_bin_bits=11), dict(s1_skm_tags=1)],
+                         ids=lambda o: ",".join("%s=%d" % kv for kv in o.items()))
+@pytest.mark.parametrize("kind,k,m", [("pe100", 21, 2), ("repeats100", 22, 2), ("short30", 19, 1)])
+def test_three_sort_passes_and_position_tags(engine, kind, k, m, opts):
+    """2^17..2^20 bins take a third sort pass (jobs beyond 14 M reads); s1_skm_tags: the kernel of read sets beyond 2^32 bases (tag 0 here;
+    tests/test_gpu_fullsize_100M.py has 1.5 x 10^10 bases)"""
+    run(engine, fixed_library(kind, seed=k + m), k, m, dict(opts, s1_skm=2, s1_skm_max_bin=1 << 30))
+
+
+@pytest.mark.parametrize("kind,k,m", [("var", 21, 2), ("var", 19, 1), ("lowcomplex", 22, 2), ("fixed", 21, 2)])
+def test_reads_of_several_lengths(engine, kind, k, m):
+    """every read takes the blocks of the longest; its place in the store comes from start[] (reads shorter than k + 1 make nothing)"""
+    run(engine, make_reads(kind, 11), k, m, dict(s1_skm=2, s1_skm_max_bin=1 << 30, s1_var_min_fill=5))
+
+
+def test_the_record_array_is_too_small(engine):
+    """s1_skm_cap_pct: the array holds that many records per 100 windows (0.284 per window in random sequence); one that overflows hands
+    the job to the prefix plan"""
+    run(engine, fixed_library("pe100", seed=8) * 12, 21, 2, dict(s1_skm=2, s1_skm_cap_pct=3), want_plan="stream", want_kernels=("s1_skm_make", "s1_groups"),
+        absent=("s1_skm_groups",), why="more records than the array holds")
+
+
+@pytest.mark.parametrize("k,m,how", [(17, 2, "k"), (23, 2, "k"), (21, 3, "m"), (21, 2, "sparse"), (21, 2, "off")])
 def test_shapes_the_path_declines(engine, k, m, how):
-    reads = make_reads("var", 3) if how == "var" else fixed_library("pe100", seed=k)
-    opts = dict(s1_skm=0 if how == "off" else 2)
-    if how == "var":
-        opts["s1_var_min_fill"] = 10
-    try:
-        run(engine, reads, k, m, opts, want_plan="", want_kernels=(), absent=("s1_skm_make", "s1_skm_groups"))
-    finally:
-        engine.set_option("s1_var_min_fill", 50)
+    """k outside 19..22, min count beyond 2, a library whose padded blocks would be mostly empty, the knob"""
+    reads = make_reads("var", 3) + [np.zeros(2000, dtype=np.uint8)] if how == "sparse" else fixed_library("pe100", seed=k)
+    run(engine, reads, k, m, dict(s1_skm=0 if how == "off" else 2), want_plan="", want_kernels=(), absent=("s1_skm_make", "s1_skm_groups"))
 
 
 def test_mercy_takes_the_sorted_records(engine):
