@@ -234,6 +234,13 @@ typedef struct {
  * (a group's first item = first in read order); 2 = candidates with the reference's exact tie order
  * (kmlib::kmsort's unstable permutation replayed per lv1 bucket; slower) — see DESIGN.md "H1". */
 int mhx_read2sdbg_s1(mhx_ctx *, uint32_t k, uint32_t min_count, int want_mercy, mhx_s1_result *out);
+/* 1 when stage 1 of the loaded reads would run on super-k-mer records (csrc/s1_skm.hip: one GPU, no mercy, 19 <= k <= 22, min count <= 2,
+ * no bucket filter) — a form that cuts a job too large for one working set into passes over ranges of its own bins BY ITSELF
+ * (the lv1 bucket ranges of base_engine.cpp:54-141 would break its records apart).  A caller that plans bucket-range passes asks first:
+ * on 1 it sets option s1_skm = 3 and calls mhx_read2sdbg_s1 once, without a filter — with 3 the call fails (instead of quietly taking the
+ * prefix plan on the whole job) when the input turns out not to be served, low-complexity reads for one, and the caller plans as before
+ * with s1_skm = 0.  host/mhx_core.cpp read2sdbg does exactly that. */
+int mhx_s1_self_planned(mhx_ctx *, uint32_t k, uint32_t min_count, int want_mercy);
 
 /* mercy block of Read2SdbgS2::Initialize (read_to_sdbg_s2.cpp:122-266): consumes MERCY_CAND,
  * sets extra IS_SOLID bits on the device copy; *num_mercy receives "Number mercy". */

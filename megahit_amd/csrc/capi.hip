@@ -775,6 +775,14 @@ int mhx_read2sdbg_s1(mhx_ctx *c, uint32_t k, uint32_t min_count, int want_mercy,
     mhx::run_s1(c, k, min_count, want_mercy, out);
   })
 }
+int mhx_s1_self_planned(mhx_ctx *c, uint32_t k, uint32_t min_count, int want_mercy) {
+  if (!c) return 0;
+  try {
+    return mhx::s1_skm_applies(c, k, min_count, want_mercy) ? 1 : 0;
+  } catch (...) {
+    return 0;
+  }
+}
 int mhx_read2sdbg_add_mercy(mhx_ctx *c, uint32_t k, uint64_t *num_mercy) {
   MHX_TRY({
     MHX_HIP(hipSetDevice(c->device));

@@ -759,17 +759,30 @@ int main_read2sdbg(int argc, char **argv) {
     const int mercy_mode = !need_mercy ? 0 : (getenv("MHX_STABLE_TIES") ? 1 : 2);
     const size_t s1_item_bytes = 16 + (k > 30 ? (size_t)((2 * (k - 1) + 6 + 31) / 32 - 2 + 1) / 2 * 8 : 0);
     // fixed: 1 B/base mark map + bitmap + the aggregated stage-2 items kept for stage 2 (k <= 22: <= 8 B per base, typically 1)
-    const auto ranges = plan_ranges(c, mercy_mode ? MHX_STAGE_S1_MERCY : MHX_STAGE_S1, k, m, s1_item_bytes,
-                                    (double)mhx_num_bases(c) + 4.0 * (double)mhx_num_sequences(c),
-                                    (double)mhx_num_bases(c) * (1.0 + 0.125 + (k <= 22 ? 1.0 : 0.0)));
-    uint64_t n1 = 0;
-    for (size_t i = 0; i < ranges.size(); ++i) {
-      set_range(c, ranges, i, true);
-      CK(mhx_read2sdbg_s1(c, k, m, mercy_mode, &r1));
-      n1 += r1.n_items;
+    // Stage 1 on super-k-mer records plans its own passes (include/mhx.h: mhx_s1_self_planned): asked first, unless the environment
+    // dictates a plan (MHX_MAX_ITEMS / MHX_FREE_BYTES: tests of the lv1 bucket plan).  If the input turns out not to be served —
+    // low-complexity reads — the call fails and the lv1 bucket plan takes over.
+    bool s1_done = false;
+    if (!getenv("MHX_MAX_ITEMS") && !getenv("MHX_FREE_BYTES") && mhx_s1_self_planned(c, k, m, mercy_mode) == 1) {
+      const long long before = mhx_get_option(c, "s1_skm", 1);
+      mhx_set_option(c, "s1_skm", 3);
+      s1_done = mhx_read2sdbg_s1(c, k, m, mercy_mode, &r1) == 0;
+      if (!s1_done) info("Stage 1 on super-k-mer records: %s; planning lv1 bucket ranges instead", mhx_last_error());
+      mhx_set_option(c, "s1_skm", s1_done ? before : 0);
     }
-    clear_range(c, ranges);
-    r1.n_items = n1;
+    if (!s1_done) {
+      const auto ranges = plan_ranges(c, mercy_mode ? MHX_STAGE_S1_MERCY : MHX_STAGE_S1, k, m, s1_item_bytes,
+                                      (double)mhx_num_bases(c) + 4.0 * (double)mhx_num_sequences(c),
+                                      (double)mhx_num_bases(c) * (1.0 + 0.125 + (k <= 22 ? 1.0 : 0.0)));
+      uint64_t n1 = 0;
+      for (size_t i = 0; i < ranges.size(); ++i) {
+        set_range(c, ranges, i, true);
+        CK(mhx_read2sdbg_s1(c, k, m, mercy_mode, &r1));
+        n1 += r1.n_items;
+      }
+      clear_range(c, ranges);
+      r1.n_items = n1;
+    }
     auto hist = fetch<int64_t>(c, MHX_BUF_MUL_HIST);
     int64_t n_solid_edges = 0;
     for (uint32_t i = m; i <= 65535; ++i) n_solid_edges += hist[i];

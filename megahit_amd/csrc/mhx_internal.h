@@ -283,6 +283,7 @@ struct CountStreamOut {
   uint64_t n_events;
 };
 bool count_stream_applies(const mhx_ctx *c, uint32_t k, uint32_t m);
+bool s1_skm_applies(const mhx_ctx *c, uint32_t k, uint32_t m, int want_mercy);  // s1_skm.hip: stage 1 on super-k-mer records serves this shape
 bool count_presort_applies(const mhx_ctx *c, uint32_t k, uint32_t m);
 uint32_t *count_presort(mhx_ctx *c, uint32_t k, uint64_t *n_items, uint32_t **other, int *pbits);
 int count_process_presorted(mhx_ctx *c, uint32_t k, uint32_t m, const S1Sources &src, mhx_count_result *out);  // count.hip; -1: gave up

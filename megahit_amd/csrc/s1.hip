@@ -779,6 +779,7 @@ struct S1Stage {
       const uint64_t agg_n = agg_prev + total;
       MHX_HIP(hipMemcpyAsync(agg_cursor, &agg_n, 8, hipMemcpyHostToDevice, st));
       MHX_HIP(hipStreamSynchronize(st));  // agg_n is a stack variable
+      agg_prev = agg_n;  // (the next pass over a range of bins appends)
     }
     return true;
   }
@@ -1171,25 +1172,36 @@ bool count_stream_groups(mhx_ctx *c, uint32_t k, uint32_t m, uint32_t *first_0_o
 // stage 1 on super-k-mer records.  -> false: the shape is served but this input is not (more records than windows / 2, a bin of
 // low-complexity reads, an output region that overflowed): nothing published, the prefix plan runs from scratch
 static bool s1_skm_try(mhx_ctx *c, uint32_t k, uint32_t m, mhx_s1_result *out, std::string *why) {
+  // (a job whose record arrays would take more than s1_skm_pass_gb runs in passes over ranges of bins: marks, histogram and aggregated
+  //  items add up; every pass scans the reads once more)
+  const int n_passes = s1_skm_passes(c, k);
   SkmFront f{};
-  if (!s1_skm_front(c, k, &f)) {
-    *why = f.n_records ? "a bin of " + std::to_string(f.max_bin) + " records" : "more records than the array holds";
-    return false;
-  }
-  S1Stage stage(c, k, m, 0, nullptr, nullptr, f.n_items, nullptr);  // (n_items: what the reference sorts, read_to_sdbg_s1.cpp:344-363)
+  S1Stage stage(c, k, m, 0, nullptr, nullptr, 0, nullptr);
   stage.sorted = nullptr;
-  stage.set_spare(f.spare);
-  stage.open_outputs();
-  if (!stage.run_skm(f)) {
-    *why = "an output region overflowed";
-    return false;
+  uint64_t n_records = 0;
+  uint32_t max_bin = 0;
+  for (int p = 0; p < n_passes; ++p) {
+    if (!s1_skm_front(c, k, &f, p, n_passes)) {
+      *why = f.n_records ? "a bin of " + std::to_string(f.max_bin) + " records" : "more records than the array holds";
+      return false;
+    }
+    stage.set_spare(f.spare);
+    if (p == 0) stage.open_outputs();
+    if (!stage.run_skm(f)) {
+      *why = "an output region overflowed";
+      return false;
+    }
+    n_records += f.n_records;
+    max_bin = std::max(max_bin, f.max_bin);
   }
+  stage.n_items = f.n_items;  // what the reference sorts (read_to_sdbg_s1.cpp:344-363)
   stage.mark_mode_used = 1;
-  char txt[256];
+  char txt[320];
   snprintf(txt, sizeof txt, "super-k-mers m%u, 2^%d bins (%llu records for %llu windows: %.2f per record; largest bin %u)%s", k + 1 - 9, f.bin_bits,
-           (unsigned long long)f.n_records, (unsigned long long)f.n_windows, f.n_records ? (double)f.n_windows / (double)f.n_records : 0.0, f.max_bin,
+           (unsigned long long)n_records, (unsigned long long)f.n_windows, n_records ? (double)f.n_windows / (double)n_records : 0.0, max_bin,
            c->seqs.fixed_len ? "" : " [reads of several lengths]");
   c->last_s1_plan = txt;
+  if (n_passes > 1) c->last_s1_plan += " [" + std::to_string(n_passes) + " passes over ranges of bins]";
   stage.publish(out);
   return true;
 }
@@ -1201,6 +1213,9 @@ int run_s1(mhx_ctx *c, uint32_t k, uint32_t m, int want_mercy, mhx_s1_result *ou
     c->gen_first_pass = nullptr;
     c->pre_hist_buf = nullptr;
     if (s1_skm_try(c, k, m, out, &skm_why)) return 0;
+    // s1_skm = 3: a caller that left the memory plan to this path (mhx_s1_self_planned) hears that it did not serve — the prefix plan
+    // of a whole job that was never cut into lv1 bucket ranges may not fit
+    if (c->opt("s1_skm", 1) == 3) throw Error("read2sdbg_s1: super-k-mer records given up (" + skm_why + ")");
   }
   c->s1_defer_items = !want_mercy;  // s1_process sorts "items_a" first thing: its first pass may make the records (and apply a bucket filter)
   c->gen_first_pass = nullptr;

@@ -47,8 +47,8 @@ __device__ __forceinline__ uint32_t skm_bin_of(uint32_t minh) {  // (the minimum
 // (as the padded item slots of S1GenVarT); a block beyond the read's last window makes nothing.
 template <int NT, int J, bool VAR>
 __global__ __launch_bounds__(NT) void k_skm_make(const uint32_t *__restrict__ seq, const uint64_t *__restrict__ start, uint32_t L, uint32_t bpr, uint64_t n_blocks,
-                                                 int k, int bin_bits, uint4 *__restrict__ out, unsigned long long cap, unsigned long long *__restrict__ cursor,
-                                                 uint32_t *__restrict__ err, unsigned long long *__restrict__ digit_hist) {
+                                                 int k, int bin_bits, uint32_t bin_lo, uint32_t bin_hi, int count_items, uint4 *__restrict__ out, unsigned long long cap,
+                                                 unsigned long long *__restrict__ cursor, uint32_t *__restrict__ err, unsigned long long *__restrict__ digit_hist) {
   __shared__ uint32_t sm_scan[NT / kWave + 1];
   __shared__ unsigned long long s_base;
   __shared__ uint32_t dh[3][256];  // the digit histograms of the sort passes, taken while the records are made
@@ -62,12 +62,12 @@ __global__ __launch_bounds__(NT) void k_skm_make(const uint32_t *__restrict__ se
   unsigned long long items = 0;  // VAR: what the reference sorts, L - k + 4 items per read that holds an edge (read_to_sdbg_s1.cpp:344-363)
   for (uint64_t it = blockIdx.x; it * (uint64_t)(NT * J) < n_blocks; it += gridDim.x) {
     uint64_t Wv[J], pos0[J];
-    uint32_t binp[J][8], smask[J], nv[J];
+    uint32_t binp[J][8], smask[J], kmask8[J];  // per block: the windows' bins, which windows start a run, which are this pass's
 #pragma unroll
     for (int j = 0; j < J; ++j) {
       const uint64_t b = it * (uint64_t)(NT * J) + (uint64_t)j * NT + tid;
       smask[j] = 0;
-      nv[j] = 0;
+      kmask8[j] = 0;
       Wv[j] = 0;
       pos0[j] = 0;
 #pragma unroll
@@ -81,7 +81,7 @@ __global__ __launch_bounds__(NT) void k_skm_make(const uint32_t *__restrict__ se
           base = start[r];
           const uint64_t len_r = start[r + 1] - base;
           nwin = len_r >= (uint64_t)K1 ? (uint32_t)(len_r - k) : 0u;
-          if (q0 == 0 && nwin) items += nwin + 4;
+          if (q0 == 0 && nwin && count_items) items += nwin + 4;
         } else {
           base = r * L;
           nwin = L - k;
@@ -112,13 +112,17 @@ __global__ __launch_bounds__(NT) void k_skm_make(const uint32_t *__restrict__ se
             pfx = min(pfx, h[kSkmW - 1 + w]);
             binp[j][w] = skm_bin_of(min(sfx[w], pfx)) >> bin_sh;
           }
+          // a pass of the memory plan keeps the bins [bin_lo, bin_hi): the windows of a run share their bin, so runs stay whole
           const uint32_t n_here = min((uint32_t)kSkmC, nwin - q0);
-          uint32_t sm = 1u;
+          uint32_t km = 0, sm = 0;
 #pragma unroll
-          for (int w = 1; w < kSkmC; ++w)
-            if ((uint32_t)w < n_here && binp[j][w] != binp[j][w - 1]) sm |= 1u << w;
+          for (int w = 0; w < kSkmC; ++w)
+            if ((uint32_t)w < n_here && binp[j][w] >= bin_lo && binp[j][w] < bin_hi) km |= 1u << w;
+#pragma unroll
+          for (int w = 0; w < kSkmC; ++w)
+            if (((km >> w) & 1u) && (w == 0 || !((km >> (w - 1)) & 1u) || binp[j][w] != binp[j][w > 0 ? w - 1 : 0])) sm |= 1u << w;
           smask[j] = sm;
-          nv[j] = n_here;
+          kmask8[j] = km;
           Wv[j] = W;
           pos0[j] = a;
         }
@@ -140,12 +144,13 @@ __global__ __launch_bounds__(NT) void k_skm_make(const uint32_t *__restrict__ se
 #pragma unroll
     for (int j = 0; j < J; ++j) {
       // (straight-line over the eight windows: no register array is indexed by a variable)
-      uint32_t run_bin = binp[j][0];
+      uint32_t run_bin = 0;
       int run_s = 0;
+      bool open = false;
 #pragma unroll
-      for (int w = 1; w <= kSkmC; ++w) {
-        const bool head = w < kSkmC && ((smask[j] >> w) & 1u);
-        if ((head || (uint32_t)w == nv[j]) && nv[j]) {  // a run ends in front of window w
+      for (int w = 0; w <= kSkmC; ++w) {
+        const bool kept = w < kSkmC && ((kmask8[j] >> w) & 1u), head = w < kSkmC && ((smask[j] >> w) & 1u);
+        if (open && (!kept || head)) {  // a run ends in front of window w
           const int len = w - run_s;
           const uint64_t p = pos0[j] + (uint64_t)run_s;
           const uint64_t bases = ((Wv[j] << (2 * run_s)) & (~0ull << (64 - 2 * (K1 + len - 1)))) | (uint64_t)(len - 1);
@@ -153,8 +158,10 @@ __global__ __launch_bounds__(NT) void k_skm_make(const uint32_t *__restrict__ se
           atomicAdd(&dh[0][run_bin & 255u], 1u);
           atomicAdd(&dh[1][(run_bin >> 8) & 255u], 1u);
           atomicAdd(&dh[2][run_bin >> 16], 1u);
+          open = false;
         }
         if (head) {
+          open = true;
           run_bin = binp[j][w < kSkmC ? w : 0];
           run_s = w;
         }
@@ -205,7 +212,7 @@ struct SkmArgs {
   uint32_t *err;
   uint32_t max_fill;
   int probe_limit;
-  uint32_t n_bins;
+  uint32_t bin_lo, bin_hi;  // the bins of this pass
 };
 
 constexpr int kSkmThreads = 1024, kSkmLogSlots = 13, kSkmBatch = 4;
@@ -288,9 +295,9 @@ __global__ __launch_bounds__(kSkmThreads) void k_s1_skm(const uint4 *__restrict_
   for (;;) {
     if (tid == 0) s_tk = atomicAdd(ticket, 1u);
     __syncthreads();
-    const uint64_t bin0 = (uint64_t)s_tk * kSkmBatch;
-    if (bin0 >= a.n_bins) break;
-    if (tid <= kSkmBatch) s_lo[tid] = bounds[min(bin0 + tid, (uint64_t)a.n_bins)];
+    const uint64_t bin0 = (uint64_t)a.bin_lo + (uint64_t)s_tk * kSkmBatch;
+    if (bin0 >= a.bin_hi) break;
+    if (tid <= kSkmBatch) s_lo[tid] = bounds[min(bin0 + tid, (uint64_t)a.bin_hi)];
     __syncthreads();
     for (int bb = 0; bb < kSkmBatch; ++bb) {
       const uint64_t lo = s_lo[bb], hi = s_lo[bb + 1];
@@ -522,7 +529,18 @@ bool s1_skm_applies(const mhx_ctx *c, uint32_t k, uint32_t m, int want_mercy) {
 
 // make the records, order them by bin, find the bins.  -> false: gave up (more records than the array was sized for, or a bin that one
 // workgroup should not stream alone: low-complexity reads) — nothing published
-bool s1_skm_front(mhx_ctx *c, uint32_t k, SkmFront *f) {
+int s1_skm_passes(const mhx_ctx *c, uint32_t k) {
+  // the two record arrays of a pass together take s1_skm_pass_gb (hipMalloc costs per byte on this driver — seconds per 100 GB — while one
+  // more pass costs one more scan of the reads by k_skm_make: 28 ms at 100 M reads); s1_skm_passes forces a count (tests)
+  const SeqSet &s = c->seqs;
+  if (const long long f = c->opt("s1_skm_passes", 0)) return (int)std::min<long long>(64, std::max<long long>(1, f));
+  const uint64_t n_win = s.n_bases > s.n_seqs * (uint64_t)k ? s.n_bases - s.n_seqs * (uint64_t)k : 0;
+  const double need = (double)n_win * (double)std::max<long long>(c->opt("s1_skm_cap_pct", 36), 1) / 100.0 * 32.0;
+  const double budget = (double)std::max<long long>(c->opt("s1_skm_pass_gb", 48), 1) * 1e9;
+  return (int)std::min(64.0, std::max(1.0, std::ceil(need / budget)));
+}
+
+bool s1_skm_front(mhx_ctx *c, uint32_t k, SkmFront *f, int pass, int n_passes) {
   SeqSet &s = c->seqs;
   hipStream_t st = c->stream;
   const bool var = s.fixed_len == 0;
@@ -530,7 +548,9 @@ bool s1_skm_front(mhx_ctx *c, uint32_t k, SkmFront *f) {
   const uint64_t n_blocks = s.n_seqs * (uint64_t)bpr;
   const uint64_t n_win = var ? (s.n_bases > s.n_seqs * (uint64_t)k ? s.n_bases - s.n_seqs * (uint64_t)k : 0) : s.n_seqs * (uint64_t)(L - k);  // (var: an estimate)
   // the array: 0.284 records per window of random sequence at m = k - 8 (fewer in repeats); s1_skm_cap_pct per cent of the windows
-  const uint64_t cap = std::max<uint64_t>(n_win * (uint64_t)std::max<long long>(c->opt("s1_skm_cap_pct", 36), 1) / 100, 1u << 16);
+  // (a pass of several: its share of the bins, which the hash fills evenly, and 15 % on top)
+  const uint64_t cap_all = n_win * (uint64_t)std::max<long long>(c->opt("s1_skm_cap_pct", 36), 1) / 100;
+  const uint64_t cap = std::max<uint64_t>(n_passes > 1 ? cap_all / n_passes + cap_all / n_passes * 15 / 100 : cap_all, 1u << 16);
   // bins: ~5000 records each (20 000 windows: what the table of one workgroup takes in one round) — 2^16 up to 14 M reads of 150 bases,
   // up to 2^20 and a third sort pass beyond
   int bin_bits = kSkmMinBinBits;
@@ -550,13 +570,15 @@ bool s1_skm_front(mhx_ctx *c, uint32_t k, SkmFront *f) {
   constexpr int NT = 512, J = 2;
   const uint64_t cus = c->n_cus > 0 ? (uint64_t)c->n_cus : 256;
   const unsigned grid = (unsigned)std::min<uint64_t>(div_ceil(n_blocks, (uint64_t)NT * J), cus * 8);
+  const uint32_t n_bins = 1u << bin_bits;
+  const uint32_t bin_lo = (uint32_t)((uint64_t)n_bins * pass / n_passes), bin_hi = (uint32_t)((uint64_t)n_bins * (pass + 1) / n_passes);
   MHX_LAUNCH(c, "s1_skm_make", (double)s.n_bases / 4 + (double)n_win * 16 / 3.5, {
     if (var)
-      hipLaunchKernelGGL((k_skm_make<NT, J, true>), dim3(grid), dim3(NT), 0, st, s.words.as<uint32_t>(), s.start.as<uint64_t>(), L, bpr, n_blocks, (int)k, bin_bits, buf_a,
-                         (unsigned long long)cap, cursor, err, pre_hist);
+      hipLaunchKernelGGL((k_skm_make<NT, J, true>), dim3(grid), dim3(NT), 0, st, s.words.as<uint32_t>(), s.start.as<uint64_t>(), L, bpr, n_blocks, (int)k, bin_bits, bin_lo, bin_hi,
+                         pass == 0 ? 1 : 0, buf_a, (unsigned long long)cap, cursor, err, pre_hist);
     else
-      hipLaunchKernelGGL((k_skm_make<NT, J, false>), dim3(grid), dim3(NT), 0, st, s.words.as<uint32_t>(), s.start.as<uint64_t>(), L, bpr, n_blocks, (int)k, bin_bits, buf_a,
-                         (unsigned long long)cap, cursor, err, pre_hist);
+      hipLaunchKernelGGL((k_skm_make<NT, J, false>), dim3(grid), dim3(NT), 0, st, s.words.as<uint32_t>(), s.start.as<uint64_t>(), L, bpr, n_blocks, (int)k, bin_bits, bin_lo, bin_hi,
+                         pass == 0 ? 1 : 0, buf_a, (unsigned long long)cap, cursor, err, pre_hist);
   });
   unsigned long long h[4] = {0, 0, 0, 0};
   MHX_HIP(hipMemcpyAsync(h, cursor, 32, hipMemcpyDeviceToHost, st));
@@ -570,7 +592,6 @@ bool s1_skm_front(mhx_ctx *c, uint32_t k, SkmFront *f) {
   c->pre_hist_sig = passes_signature(passes);
   uint32_t *sorted = radix_sort(c, reinterpret_cast<uint32_t *>(buf_a), reinterpret_cast<uint32_t *>(buf_b), n, 4, 1, passes);
   c->pre_hist_buf = nullptr;
-  const uint32_t n_bins = 1u << bin_bits;
   uint64_t *bounds = c->ws("s1_bucket_bounds", ((size_t)n_bins + 1) * 8 + 64).as<uint64_t>();
   MHX_LAUNCH(c, "s1_skm_bounds", (double)n_bins * 8 * 30,
              hipLaunchKernelGGL(k_skm_bounds, dim3((n_bins + 1 + 255) / 256), dim3(256), 0, st, reinterpret_cast<const uint4 *>(sorted), n, n_bins, bounds, max_bin));
@@ -582,13 +603,15 @@ bool s1_skm_front(mhx_ctx *c, uint32_t k, SkmFront *f) {
   f->spare_bytes = cap * 16;
   f->n_records = n;
   f->n_windows = n_win;
-  f->n_items = var ? h[3] : s.n_seqs * (uint64_t)(L - k + 4);
+  if (pass == 0) f->n_items = var ? h[3] : s.n_seqs * (uint64_t)(L - k + 4);
   f->bounds = bounds;
   f->n_bins = n_bins;
+  f->bin_lo = bin_lo;
+  f->bin_hi = bin_hi;
   f->bin_bits = bin_bits;
   f->max_bin = h_max;
   // a bin of many times the mean is low-complexity sequence (one minimizer for millions of windows): the prefix plan has the giant path
-  const uint64_t limit = std::max<uint64_t>((uint64_t)c->opt("s1_skm_max_bin", 1 << 16), 16 * (n / n_bins + 1));
+  const uint64_t limit = std::max<uint64_t>((uint64_t)c->opt("s1_skm_max_bin", 1 << 16), 16 * (n / (bin_hi - bin_lo) + 1));
   return h_max <= limit;
 }
 
@@ -600,7 +623,7 @@ void s1_skm_groups_launch(mhx_ctx *c, bool agg, unsigned grid, const SkmFront &f
   const uint32_t nslot = 1u << kSkmLogSlots;
   SkmArgs a{(int)k, m, solid_bytes, hist, agg_raw, agg_cap, agg_counts, err,
             (uint32_t)std::min<long long>(std::max<long long>(c->opt("s1_stream_fill", nslot * 7 / 8), 1), nslot), (int)std::min<long long>(c->opt("s1_stream_probes", 1024), 1024),
-            f.n_bins};
+            f.bin_lo, f.bin_hi};
   const bool tags = (c->seqs.n_bases >> 32) != 0 || c->opt("s1_skm_tags", 0) != 0;
 #define MHX_SKM(AGGV, TAGV) hipLaunchKernelGGL((k_s1_skm<AGGV, TAGV>), dim3(grid), dim3(kSkmThreads), 0, st, f.sorted, f.bounds, a, ticket)
   MHX_LAUNCH(c, "s1_skm_groups", (double)f.n_records * 16, {

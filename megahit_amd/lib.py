@@ -153,6 +153,7 @@ SYMBOLS = {
     "mhx_comm_init_hosted": (_P, [_P, C.c_int, C.c_int, _P]),
     "mhx_reset": (C.c_int, [_P]),
     "mhx_last_s1_plan": (C.c_char_p, [_P]),
+    "mhx_s1_self_planned": (C.c_int, [_P, C.c_uint32, C.c_uint32, C.c_int]),
     "mhx_profile_enable": (C.c_int, [_P, C.c_int]),
     "mhx_profile_reset": (C.c_int, [_P]),
     "mhx_profile_get": (C.c_int, [_P, C.POINTER(KernelStat), C.c_int]),
@@ -395,6 +396,10 @@ class Engine:
     def set_option(self, name, value):
         """Tuning / diagnostic knob of this handle (include/mhx.h: mhx_set_option)."""
         self._chk(self.lib.mhx_set_option(self.h, name.encode(), int(value)))
+
+    def s1_self_planned(self, k, min_count, want_mercy=False):
+        """stage 1 would run on super-k-mer records and cut the job into passes by itself (mhx_s1_self_planned)"""
+        return bool(self.lib.mhx_s1_self_planned(self.h, k, min_count, int(want_mercy)))
 
     def last_s1_plan(self):
         """what the last stage 1 of this handle ran as (mhx_last_s1_plan)"""

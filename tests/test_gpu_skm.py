@@ -16,7 +16,7 @@ from test_gpu_sdbg import check_sdbg
 pytestmark = pytest.mark.gpu
 
 RESET = dict(s1_skm=1, s1_stream_fill=7168, s1_stream_probes=1024, s1_skm_max_bin=65536, s1_skm_min_windows=1 << 22, s1_skm_bin_bits=0, s1_skm_tags=0, s1_skm_cap_pct=36,
-             s1_var_min_fill=50)
+             s1_var_min_fill=50, s1_skm_passes=0)
 
 
 def run(engine, reads, k, m, opts, want_plan="super-k-mers", want_kernels=("s1_skm_make", "s1_skm_groups"), absent=("s1_groups",), why=None):
@@ -93,6 +93,38 @@ def test_three_sort_passes_and_position_tags(engine, kind, k, m, opts):
 def test_reads_of_several_lengths(engine, kind, k, m):
     """every read takes the blocks of the longest; its place in the store comes from start[] (reads shorter than k + 1 make nothing)"""
     run(engine, make_reads(kind, 11), k, m, dict(s1_skm=2, s1_skm_max_bin=1 << 30, s1_var_min_fill=5))
+
+
+@pytest.mark.parametrize("kind,k,m,n_passes", [("pe100", 21, 2, 3), ("repeats100", 22, 2, 5), ("var", 21, 2, 2), ("short30", 20, 1, 4)])
+def test_passes_over_ranges_of_bins(engine, kind, k, m, n_passes):
+    """a job whose record arrays would not fit runs in passes over ranges of the minimizer bins (s1_skm_pass_gb; here forced): every pass
+    makes the records of its bins from the reads again; marks, histogram and aggregated items add up"""
+    reads = make_reads(kind, 5) if kind == "var" else fixed_library(kind, seed=k)
+    pkg = ob.Package(reads, reverse=True)
+    load(engine, pkg)
+    engine.set_option("s1_skm", 2)
+    engine.set_option("s1_var_min_fill", 5)
+    try:
+        assert engine.s1_self_planned(k, m) and not engine.s1_self_planned(k, m, want_mercy=True) and not engine.s1_self_planned(k, 3)
+    finally:
+        engine.set_option("s1_skm", 1)
+        engine.set_option("s1_var_min_fill", 50)
+    run(engine, reads, k, m, dict(s1_skm=2, s1_skm_max_bin=1 << 30, s1_skm_passes=n_passes, s1_var_min_fill=5), why="%d passes over ranges of bins" % n_passes)
+
+
+def test_a_caller_that_left_the_plan_to_the_path_hears_when_it_gives_up(engine):
+    """s1_skm = 3 (what host/mhx_core.cpp sets after mhx_s1_self_planned said 1): no quiet change to the prefix plan on the whole job"""
+    reads = fixed_library("pe100", seed=11) + [np.zeros(100, dtype=np.uint8) for _ in range(3000)]
+    load(engine, ob.Package(reads, reverse=True))
+    try:
+        engine.set_option("s1_skm", 3)
+        engine.set_option("s1_skm_max_bin", 1024)
+        with pytest.raises(lib.MhxError, match="super-k-mer records given up"):
+            engine.read2sdbg_s1(21, 2)
+    finally:
+        for n, v in RESET.items():
+            engine.set_option(n, v)
+    run(engine, reads, 21, 2, dict(s1_skm=0), want_plan="stream", want_kernels=("s1_groups",), absent=("s1_skm_make",))
 
 
 def test_the_record_array_is_too_small(engine):
