@@ -772,7 +772,9 @@ struct S1Stage {
     if (agg) {
       uint64_t total = 0;
       for (uint32_t v : h_counts) total += v;
-      uint2 *dense = grow_preserving(c, c->work["s2_agg_items"], (agg_prev + total) * 8 + 64, agg_prev * 8).as<uint2>();
+      // (a pass of several: the array is sized for all of them after the first — the bins fill evenly — instead of growing pass by pass)
+      const uint64_t expect = f.bin_hi > f.bin_lo ? (uint64_t)((double)(agg_prev + total) * (double)f.n_bins / (double)f.bin_hi * 1.05) : agg_prev + total;
+      uint2 *dense = grow_preserving(c, c->work["s2_agg_items"], std::max(agg_prev + total, expect) * 8 + 64, agg_prev * 8).as<uint2>();
       if (total)
         MHX_LAUNCH(c, "agg_compact", (double)total * 16,
                    hipLaunchKernelGGL(k_agg_compact, dim3(seg_grid, 8), dim3(256), 0, st, reinterpret_cast<const uint2 *>(spare), seg_cap, counts, dense + agg_prev, 1));

@@ -56,7 +56,12 @@ def test_configs2_on_one_gpu_and_as_eight_ranks(lib100):
     import config_bench as cb
     out = cb.configs2(keep=lib100, emit=False)
     evidence("bench_configs2.json", out)
-    one, eight = out["runs"]["one_gpu"], out["runs"]["eight_ranks_on_one_device"]
+    skm, one, eight = out["runs"]["one_gpu"], out["runs"]["one_gpu_prefix_plan"], out["runs"]["eight_ranks_on_one_device"]
+    # stage 1 on super-k-mer records (round 6): 1.5 x 10^10 bases — position tags —, 2^20 bins — a third sort pass —, passes over ranges of bins
+    assert skm["bit_identical_to_reference"], skm
+    assert any("Stage 1 plan: super-k-mers" in l and "passes over ranges of bins" in l for l in skm["log_tail"]), skm["log_tail"]
+    assert skm["speedup_over_reference_wall"] >= 10, skm["wall_s"]
+    # ... and with MHX_S1_SKM=0 the lv1 bucket ranges of the memory plan, every range on the bucket-streaming plan
     assert one["bit_identical_to_reference"], one
     assert one["memory_plan_passes"] >= 2, "the memory plan did not fire"
     assert any("Stage 1 plan: stream" in l for l in one["log_tail"]), one["log_tail"]

@@ -152,7 +152,9 @@ def configs2(keep=None, emit=True):
                              "note": "speedup_over_reference_wall divides by the reference's wall time on the BUILD container's 8 cores, not on the GPU box's host; the "
                                      "same-host, same-run CPU figure exists at 10 M reads only (bench.py cpu_baseline.full_size_this_run)"}, "runs": {}}
         common = ["read2sdbg", "-k", str(k), "-m", str(m), "--host_mem", "64e9", "--num_cpu_threads", "8", "--read_lib_file", os.path.join(d, "reads")]
-        for label, pre, env in (("one_gpu", [], {}),
+        # one_gpu: stage 1 on super-k-mer records, which cuts the job into passes over ranges of its own bins (round 6);
+        # one_gpu_prefix_plan: the same with MHX_S1_SKM=0 — the lv1 bucket ranges of the memory plan on the bucket-streaming plan
+        for label, pre, env in (("one_gpu", [], {}), ("one_gpu_prefix_plan", [], {"MHX_S1_SKM": "0"}),
                                 ("eight_ranks_on_one_device", ["--gpus", "8"], {"MHX_GPU_MAP": "0,0,0,0,0,0,0,0", "MHX_FREE_BYTES": "26e9"})):
             o = os.path.join(tmp, "o_" + label)
             wall, phases, kernels, passes = run(pre + common + ["--output_prefix", o], env, os.path.join(tmp, "prof.json"))
