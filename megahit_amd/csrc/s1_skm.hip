@@ -215,10 +215,10 @@ struct SkmArgs {
   uint32_t bin_lo, bin_hi;  // the bins of this pass
 };
 
-constexpr int kSkmThreads = 1024, kSkmLogSlots = 13, kSkmBatch = 4;
+constexpr int kSkmThreads = 1024, kSkmLogSlots = 13, kSkmBatch = 8;
 
 // TAGS: read sets of 2^32 bases and more — the position bits above 32 ride in the record's first word and next to the key in the table
-template <bool AGG, bool TAGS>
+template <bool AGG, bool TAGS, bool DEAL>
 __global__ __launch_bounds__(kSkmThreads) void k_s1_skm(const uint4 *__restrict__ recs, const uint64_t *__restrict__ bounds, SkmArgs a,
                                                         uint32_t *__restrict__ ticket) {
   constexpr int NT = kSkmThreads, NSLOT = 1 << kSkmLogSlots, W = NSLOT / NT;
@@ -231,9 +231,12 @@ __global__ __launch_bounds__(kSkmThreads) void k_s1_skm(const uint4 *__restrict_
   __shared__ uint32_t lhist[kSegHist];
   __shared__ unsigned long long slist_k[AGG ? NLIST : 1];
   __shared__ uint32_t slist_c[AGG ? NLIST : 1];
-  __shared__ uint32_t s_bad, s_nclaimed, s_list_n, s_agg_cur, s_tk;
+  __shared__ unsigned long long heads[DEAL ? kSkmThreads / kWave : 1][8];  // DEAL, per wavefront: bit g set = window g of the trip is the first of its record
+  __shared__ uint32_t s_bad2[2], s_nclaimed2[2], s_list_n2[2];  // per round, double-buffered: the next round's are cleared while this round's are read
+  __shared__ uint32_t s_agg_cur, s_tk;
   __shared__ uint64_t s_lo[kSkmBatch + 1];
-  const int tid = threadIdx.x, lane = tid & (kWave - 1);
+  const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = DEAL ? tid / kWave : 0;
+  const uint32_t le_lo = lane >= 31 ? 0xFFFFFFFFu : (2u << lane) - 1u, le_hi = lane < 32 ? 0u : (lane == 63 ? 0xFFFFFFFFu : (2u << (lane - 32)) - 1u);  // lanes <= this one
   const int k = a.k, K1 = k + 1;
   const uint32_t m = a.m;
   const uint64_t kmask = ~0ull << (64 - 2 * (k - 1));
@@ -244,11 +247,12 @@ __global__ __launch_bounds__(kSkmThreads) void k_s1_skm(const uint4 *__restrict_
   }
   for (int i = tid; i < kSegHist; i += NT) lhist[i] = 0;
   if (tid == 0) {
-    s_bad = 0;
-    s_nclaimed = 0;
-    s_list_n = 0;
+    s_bad2[0] = s_bad2[1] = 0;
+    s_nclaimed2[0] = s_nclaimed2[1] = 0;
+    s_list_n2[0] = s_list_n2[1] = 0;
     s_agg_cur = 0;
   }
+  int rp = 0;  // the round's parity
   __syncthreads();
 
   // the aggregated stage-2 items of a solid key (one per strand; one for a palindrome) -> this workgroup's region, from its end
@@ -292,6 +296,9 @@ __global__ __launch_bounds__(kSkmThreads) void k_s1_skm(const uint4 *__restrict_
     }
   };
 
+  uint4 pre = make_uint4(0u, 0u, 0u, 0u);  // a first trip requested ahead (of the bin that starts at pre_at)
+  uint64_t pre_at = 0;
+  bool pre_ok = false;
   for (;;) {
     if (tid == 0) s_tk = atomicAdd(ticket, 1u);
     __syncthreads();
@@ -307,8 +314,9 @@ __global__ __launch_bounds__(kSkmThreads) void k_s1_skm(const uint4 *__restrict_
       uint32_t sub = 0, rj = 0;
       for (;;) {
         uint32_t seen = 0;
-        // A: insert
-        uint4 nxt = lo + tid < hi ? recs[lo + tid] : make_uint4(0u, 0u, 0u, 0u);
+        // A: insert (the round's first trip was requested before the walk of the round before it)
+        uint4 nxt = pre_ok && pre_at == lo ? pre : (lo + tid < hi ? recs[lo + tid] : make_uint4(0u, 0u, 0u, 0u));
+        pre_ok = false;
         for (uint64_t base = lo; base < hi; base += NT) {
           const uint4 r = nxt;
           const bool in = base + tid < hi;
@@ -316,103 +324,212 @@ __global__ __launch_bounds__(kSkmThreads) void k_s1_skm(const uint4 *__restrict_
           if (seen > a.max_fill) continue;  // (uniform per wavefront; the round is redone in halves anyway)
           const uint32_t len = in ? (r.z & 7u) + 1u : 0u;
           const uint8_t tag = TAGS ? (uint8_t)(r.x >> 28) : (uint8_t)0;
-          // Every lane expands its own record, four windows at a time: the keys are independent of each other, so their compare-and-swaps
-          // go out back to back and ONE LDS round trip serves four windows.  (Dealing the windows of a wavefront's records evenly to the
-          // lanes — a bitmap of run heads, six shuffles per window — kept all lanes busy but cost three dependent LDS round trips and
-          // 120 vector instructions per window and wavefront: measured 9.0 ms against this form's; the SQ counters had the waves waiting
-          // 52 % of their cycles.)  The reverse complement of the record's 32 base slots is formed once: a window's is a sub-window of it.
-          const uint64_t rec_b = ((uint64_t)r.y << 32) | r.z;
-          const uint64_t rec_r = rc64(rec_b, 32);
           uint32_t claims = 0;
-          // (the slot found — the key's own, or a free one claimed: count it, and remember the record that claimed it)
-          auto settle = [&](unsigned long long old, unsigned long long key, uint32_t hh, uint32_t pos) -> bool {
+          // (the slot found — the key's own, or a free one claimed: count it, and remember the window that claimed it)
+          auto settle = [&](unsigned long long old, unsigned long long key, uint32_t hh, uint32_t pos, uint8_t tg) -> bool {
             if (old != kEmpty && old != key) return false;
             atomicAdd(&cnts[hh], 1u);
             if (old == kEmpty) {  // only read back when the count stays 1: then this window is the key's only one
               fpos[hh] = pos;
-              if constexpr (TAGS) ftag[hh] = tag + (pos < r.w ? 1 : 0);  // (a run across a multiple of 2^32)
+              if constexpr (TAGS) ftag[hh] = tg;
               ++claims;
             }
             return true;
           };
+          const uint64_t rec_b = ((uint64_t)r.y << 32) | r.z;
+          const uint64_t rec_r = rc64(rec_b, 32);  // (of the record's 32 base slots, once: a window's reverse complement is a sub-window of it)
+          if constexpr (DEAL) {
+            // The windows of the wavefront's 64 records (~225) are DEALT to the lanes, 64 at a time: window g belongs to the record whose
+            // run of windows starts at or before g — a bitmap of run heads per wavefront, one population count per window — and comes
+            // over with six shuffles.  All lanes work on every step (own-record expansion: 44 % of the lane steps, below); four steps
+            // share one round of compare-and-swaps and one retry loop.
+            const uint32_t incl = wave_inclusive_sum(len);
+            const uint32_t T = (uint32_t)__builtin_amdgcn_readlane((int)incl, kWave - 1);
+            const uint32_t start = incl - len;
+            // (the LDS executes a wavefront's operations in order: clear, set, read — no barrier between them)
+            if (lane < 8) heads[wv][lane] = 0ull;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (len) atomicOr(&heads[wv][start >> 6], 1ull << (start & 63u));
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const unsigned long long hv = __hip_atomic_load(&heads[wv][lane & 7], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const uint32_t hv_lo = (uint32_t)hv, hv_hi = (uint32_t)(hv >> 32);
+            const uint32_t bh = r.y, bl = r.z, qh = (uint32_t)(rec_r >> 32), ql = (uint32_t)rec_r;
+            const uint32_t pd = r.w - start;  // position of window g of the trip = pd + g
+            uint32_t cbase_m1 = 0xFFFFFFFFu;  // heads in front of this step's windows, minus one
 #pragma unroll
-          for (int half = 0; half < 2; ++half) {
-            if (half == 1 && __ballot(len > 4u) == 0) break;  // (uniform)
-            unsigned long long key[4], old1[4];
-            uint32_t h1[4], mine = 0;
+            for (int grp = 0; grp < 2; ++grp) {
+              if ((uint32_t)(grp * 4 * kWave) >= T) break;  // (uniform)
+              unsigned long long key[4], old1[4];
+              uint32_t h1[4], pos[4], mine = 0;
+              uint8_t tg[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-              const int j = half * 4 + u;
-              const uint64_t win = rec_b << (2 * j);  // the (k+1)-mer head.S.tail, MSB first
-              const uint64_t f = (win << 2) & kmask;
-              const uint64_t rc = (rec_r << (2 * (32 - k - j))) & kmask;
-              const unsigned head = (unsigned)(win >> 62), tail = (unsigned)(win >> (62 - 2 * k)) & 3u;
-              const bool rev = f > rc || (f == rc && head > 3u - tail);  // read_to_sdbg_s1.cpp:228-292
-              const uint64_t kf = f | ((uint64_t)head << 3) | tail, kr = rc | ((uint64_t)(3u - tail) << 3) | (3u - head);
-              key[u] = rev ? kr : kf;
-              const uint32_t klo = (uint32_t)key[u], khi = (uint32_t)(key[u] >> 32);
-              bool mn = (uint32_t)j < len;
-              if (sub) mn = mn && (skm_mix((klo * 0xC2B2AE35u) ^ (khi * 0x27D4EB2Fu)) >> (32 - sub)) == rj;  // (uniform branch)
-              mine |= mn ? 1u << u : 0u;
-              h1[u] = ((klo * 0x9E3779B1u) ^ (khi * 0x85EBCA6Bu)) >> (32 - kSkmLogSlots);
-            }
-            if (a.probe_limit <= 0) {
-              if (mine) s_bad = 1;
-              mine = 0;
-            }
+              for (int u = 0; u < 4; ++u) {
+                const int c = grp * 4 + u;
+                const uint32_t g = (uint32_t)(c * kWave) + (uint32_t)lane;
+                const uint32_t w_lo = (uint32_t)__builtin_amdgcn_readlane((int)hv_lo, c), w_hi = (uint32_t)__builtin_amdgcn_readlane((int)hv_hi, c);
+                const uint32_t o = cbase_m1 + (uint32_t)__builtin_popcount(w_lo & le_lo) + (uint32_t)__builtin_popcount(w_hi & le_hi);
+                cbase_m1 += (uint32_t)__builtin_popcount(w_lo) + (uint32_t)__builtin_popcount(w_hi);
+                const uint32_t xbh = __shfl(bh, (int)o, kWave), xbl = __shfl(bl, (int)o, kWave);
+                const uint32_t xqh = __shfl(qh, (int)o, kWave), xql = __shfl(ql, (int)o, kWave);
+                const uint32_t so = __shfl(start, (int)o, kWave), pdo = __shfl(pd, (int)o, kWave);
+                const uint32_t j = g - so;
+                const uint64_t win = (((uint64_t)xbh << 32) | xbl) << (2 * j);  // the (k+1)-mer head.S.tail, MSB first
+                const uint64_t f = (win << 2) & kmask;
+                const uint64_t rc = ((((uint64_t)xqh << 32) | xql) << (2 * (32 - k - j))) & kmask;
+                const unsigned head = (unsigned)(win >> 62), tail = ((uint32_t)win >> (62 - 2 * k)) & 3u;  // (k <= 22: the tail sits in the low word)
+                const bool rev = f > rc || (f == rc && head > 3u - tail);  // read_to_sdbg_s1.cpp:228-292
+                const uint64_t kf = f | ((uint64_t)head << 3) | tail, kr = rc | ((uint64_t)(3u - tail) << 3) | (3u - head);
+                key[u] = rev ? kr : kf;
+                const uint32_t klo = (uint32_t)key[u], khi = (uint32_t)(key[u] >> 32);
+                bool mn = g < T;
+                if (sub) mn = mn && (skm_mix((klo * 0xC2B2AE35u) ^ (khi * 0x27D4EB2Fu)) >> (32 - sub)) == rj;  // (uniform branch)
+                mine |= mn ? 1u << u : 0u;
+                h1[u] = ((klo * 0x9E3779B1u) ^ (khi * 0x85EBCA6Bu)) >> (32 - kSkmLogSlots);
+                pos[u] = pdo + g;
+                if constexpr (TAGS) {
+                  const uint32_t p0 = pdo + so;  // the record's own position word: a run across a multiple of 2^32 carries into the tag
+                  tg[u] = (uint8_t)(__shfl((uint32_t)tag, (int)o, kWave) + (pos[u] < p0 ? 1u : 0u));
+                } else {
+                  tg[u] = 0;
+                }
+              }
+              if (a.probe_limit <= 0) {
+                if (mine) s_bad2[rp] = 1;
+                mine = 0;
+              }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-              old1[u] = kEmpty;
-              if ((mine >> u) & 1u) old1[u] = atomicCAS(&keys[h1[u]], kEmpty, key[u]);
-            }
-            // a lane that met another key keeps the window pending — one per lane; a second one of the same four is seen to on the spot —
-            // and the pending windows of all lanes are retried together
-            bool has = false;
-            unsigned long long pk = 0;
-            uint32_t ph = 0, pp = 0;
+              for (int u = 0; u < 4; ++u) {
+                old1[u] = kEmpty;
+                if ((mine >> u) & 1u) old1[u] = atomicCAS(&keys[h1[u]], kEmpty, key[u]);
+              }
+              bool has = false;
+              unsigned long long pk = 0;
+              uint32_t ph = 0, pp = 0;
+              uint8_t pt = 0;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-              if ((mine >> u) & 1u) {
-                const uint32_t pos = r.w + (uint32_t)(half * 4 + u);
-                if (!settle(old1[u], key[u], h1[u], pos)) {
-                  uint32_t hh = (h1[u] + 1) & (NSLOT - 1);
-                  if (!has) {
-                    has = true;
-                    pk = key[u], ph = hh, pp = pos;
-                  } else {
-                    int n = 0;
-                    while (!settle(atomicCAS(&keys[hh], kEmpty, key[u]), key[u], hh, pos)) {
-                      hh = (hh + 1) & (NSLOT - 1);
-                      if (++n >= a.probe_limit) {
-                        s_bad = 1;
-                        break;
+              for (int u = 0; u < 4; ++u) {
+                if ((mine >> u) & 1u) {
+                  if (!settle(old1[u], key[u], h1[u], pos[u], tg[u])) {
+                    uint32_t hh = (h1[u] + 1) & (NSLOT - 1);
+                    if (!has) {
+                      has = true;
+                      pk = key[u], ph = hh, pp = pos[u], pt = tg[u];
+                    } else {
+                      int n = 0;
+                      while (!settle(atomicCAS(&keys[hh], kEmpty, key[u]), key[u], hh, pos[u], tg[u])) {
+                        hh = (hh + 1) & (NSLOT - 1);
+                        if (++n >= a.probe_limit) {
+                          s_bad2[rp] = 1;
+                          break;
+                        }
                       }
                     }
                   }
                 }
               }
-            }
-            int turns = 0;
-            while (__ballot(has)) {
-              if (has) {
-                if (settle(atomicCAS(&keys[ph], kEmpty, pk), pk, ph, pp)) has = false;
-                else ph = (ph + 1) & (NSLOT - 1);
+              int turns = 0;
+              while (__ballot(has)) {
+                if (has) {
+                  if (settle(atomicCAS(&keys[ph], kEmpty, pk), pk, ph, pp, pt)) has = false;
+                  else ph = (ph + 1) & (NSLOT - 1);
+                }
+                if (++turns > a.probe_limit) {  // (uniform: every lane counts the same turns)
+                  if (has) s_bad2[rp] = 1;
+                  break;
+                }
               }
-              if (++turns > a.probe_limit) {  // (uniform: every lane counts the same turns)
-                if (has) s_bad = 1;
-                break;
+            }
+          } else {
+            // Every lane expands its own record, four windows at a time: the keys are independent of each other, so their compare-and-swaps
+            // go out back to back and one LDS round trip serves four windows; lanes whose record is shorter idle.
+  #pragma unroll
+            for (int half = 0; half < 2; ++half) {
+              if (half == 1 && __ballot(len > 4u) == 0) break;  // (uniform)
+              unsigned long long key[4], old1[4];
+              uint32_t h1[4], mine = 0;
+  #pragma unroll
+              for (int u = 0; u < 4; ++u) {
+                const int j = half * 4 + u;
+                const uint64_t win = rec_b << (2 * j);  // the (k+1)-mer head.S.tail, MSB first
+                const uint64_t f = (win << 2) & kmask;
+                const uint64_t rc = (rec_r << (2 * (32 - k - j))) & kmask;
+                const unsigned head = (unsigned)(win >> 62), tail = (unsigned)(win >> (62 - 2 * k)) & 3u;
+                const bool rev = f > rc || (f == rc && head > 3u - tail);  // read_to_sdbg_s1.cpp:228-292
+                const uint64_t kf = f | ((uint64_t)head << 3) | tail, kr = rc | ((uint64_t)(3u - tail) << 3) | (3u - head);
+                key[u] = rev ? kr : kf;
+                const uint32_t klo = (uint32_t)key[u], khi = (uint32_t)(key[u] >> 32);
+                bool mn = (uint32_t)j < len;
+                if (sub) mn = mn && (skm_mix((klo * 0xC2B2AE35u) ^ (khi * 0x27D4EB2Fu)) >> (32 - sub)) == rj;  // (uniform branch)
+                mine |= mn ? 1u << u : 0u;
+                h1[u] = ((klo * 0x9E3779B1u) ^ (khi * 0x85EBCA6Bu)) >> (32 - kSkmLogSlots);
+              }
+              if (a.probe_limit <= 0) {
+                if (mine) s_bad2[rp] = 1;
+                mine = 0;
+              }
+  #pragma unroll
+              for (int u = 0; u < 4; ++u) {
+                old1[u] = kEmpty;
+                if ((mine >> u) & 1u) old1[u] = atomicCAS(&keys[h1[u]], kEmpty, key[u]);
+              }
+              // a lane that met another key keeps the window pending — one per lane; a second one of the same four is seen to on the spot —
+              // and the pending windows of all lanes are retried together
+              bool has = false;
+              unsigned long long pk = 0;
+              uint32_t ph = 0, pp = 0;
+              uint8_t pt = 0;
+  #pragma unroll
+              for (int u = 0; u < 4; ++u) {
+                if ((mine >> u) & 1u) {
+                  const uint32_t pos = r.w + (uint32_t)(half * 4 + u);
+                  const uint8_t ptag = TAGS ? (uint8_t)(tag + (pos < r.w ? 1 : 0)) : (uint8_t)0;  // (a run across a multiple of 2^32)
+                  if (!settle(old1[u], key[u], h1[u], pos, ptag)) {
+                    uint32_t hh = (h1[u] + 1) & (NSLOT - 1);
+                    if (!has) {
+                      has = true;
+                      pk = key[u], ph = hh, pp = pos, pt = ptag;
+                    } else {
+                      int n = 0;
+                      while (!settle(atomicCAS(&keys[hh], kEmpty, key[u]), key[u], hh, pos, ptag)) {
+                        hh = (hh + 1) & (NSLOT - 1);
+                        if (++n >= a.probe_limit) {
+                          s_bad2[rp] = 1;
+                          break;
+                        }
+                      }
+                    }
+                  }
+                }
+              }
+              int turns = 0;
+              while (__ballot(has)) {
+                if (has) {
+                  if (settle(atomicCAS(&keys[ph], kEmpty, pk), pk, ph, pp, pt)) has = false;
+                  else ph = (ph + 1) & (NSLOT - 1);
+                }
+                if (++turns > a.probe_limit) {  // (uniform: every lane counts the same turns)
+                  if (has) s_bad2[rp] = 1;
+                  break;
+                }
               }
             }
           }
           {
             const uint32_t c = wave_sum(claims);
-            if (lane == 0 && c) atomicAdd(&s_nclaimed, c);
-            seen = __hip_atomic_load(&s_nclaimed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (lane == 0 && c) atomicAdd(&s_nclaimed2[rp], c);
+            seen = __hip_atomic_load(&s_nclaimed2[rp], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             seen = (uint32_t)__builtin_amdgcn_readfirstlane((int)seen);
           }
         }
         __syncthreads();  // the table is complete
-        const bool bad = s_bad != 0 || s_nclaimed > a.max_fill;
+        const bool bad = s_bad2[rp] != 0 || s_nclaimed2[rp] > a.max_fill;
+        if (tid == 0) {  // (the other parity: last read behind the first barrier of the round before this one)
+          s_bad2[rp ^ 1] = 0;
+          s_nclaimed2[rp ^ 1] = 0;
+          s_list_n2[rp ^ 1] = 0;
+        }
         uint32_t nsub = sub, nrj = rj;
         bool done = false, give_up = false;
         if (bad) {
@@ -432,6 +549,23 @@ __global__ __launch_bounds__(kSkmThreads) void k_s1_skm(const uint4 *__restrict_
           done = nsub == 0 && nrj == 1u;
         }
         if (give_up && tid == 0) atomicOr(a.err, 1u);
+        {  // the first trip of what comes next — this bin again, or the next bin of the batch that holds records — is requested here
+          uint64_t nlo = lo, nhi = hi;
+          if (done) {
+            nlo = nhi = 0;
+            for (int nb = bb + 1; nb < kSkmBatch; ++nb)
+              if (s_lo[nb] != s_lo[nb + 1]) {
+                nlo = s_lo[nb];
+                nhi = s_lo[nb + 1];
+                break;
+              }
+          }
+          if (nlo != nhi) {
+            pre = nlo + tid < nhi ? recs[nlo + tid] : make_uint4(0u, 0u, 0u, 0u);
+            pre_at = nlo;
+            pre_ok = true;
+          }
+        }
         // C: one walk over the table — per distinct key: histogram, the mark of a non-solid key's only record, the solid keys listed
         unsigned long long wk[W];
         uint32_t wc[W], wp[W];
@@ -468,7 +602,7 @@ __global__ __launch_bounds__(kSkmThreads) void k_s1_skm(const uint4 *__restrict_
           const uint32_t tot = __shfl(incl, kWave - 1, kWave);
           if (tot) {
             uint32_t lbase = 0;
-            if (lane == 0) lbase = atomicAdd(&s_list_n, tot);
+            if (lane == 0) lbase = atomicAdd(&s_list_n2[rp], tot);
             lbase = __shfl(lbase, 0, kWave);
             uint32_t at = lbase + incl - n_w;
 #pragma unroll
@@ -486,20 +620,16 @@ __global__ __launch_bounds__(kSkmThreads) void k_s1_skm(const uint4 *__restrict_
         }
         __syncthreads();  // the table is empty, the list complete
         if constexpr (AGG) {
-          const uint32_t n_list = min(s_list_n, (uint32_t)NLIST);
+          const uint32_t n_list = min(s_list_n2[rp], (uint32_t)NLIST);
           for (uint32_t base = 0; base < n_list; base += NT) {
             const uint32_t i = base + tid;
             const bool v = i < n_list;
             emit_items(v ? slist_k[i] : 0ull, v ? slist_c[i] : 0u, true, v);
           }
         }
-        __syncthreads();
-        if (tid == 0) {
-          s_bad = 0;
-          s_nclaimed = 0;
-          s_list_n = 0;
-        }
-        __syncthreads();
+        // (no barrier here: the next round's inserts touch the table and the other parity's counters only; its walk, which writes the
+        //  list again, comes behind that round's first barrier — by then every thread has left this loop)
+        rp ^= 1;
         sub = nsub;
         rj = nrj;
         if (done) break;
@@ -625,7 +755,12 @@ void s1_skm_groups_launch(mhx_ctx *c, bool agg, unsigned grid, const SkmFront &f
             (uint32_t)std::min<long long>(std::max<long long>(c->opt("s1_stream_fill", nslot * 7 / 8), 1), nslot), (int)std::min<long long>(c->opt("s1_stream_probes", 1024), 1024),
             f.bin_lo, f.bin_hi};
   const bool tags = (c->seqs.n_bases >> 32) != 0 || c->opt("s1_skm_tags", 0) != 0;
-#define MHX_SKM(AGGV, TAGV) hipLaunchKernelGGL((k_s1_skm<AGGV, TAGV>), dim3(grid), dim3(kSkmThreads), 0, st, f.sorted, f.bounds, a, ticket)
+  const bool deal = c->opt("s1_skm_deal", 1) != 0;
+#define MHX_SKM(AGGV, TAGV)                                                                                                                     \
+  do {                                                                                                                                          \
+    if (deal) hipLaunchKernelGGL((k_s1_skm<AGGV, TAGV, true>), dim3(grid), dim3(kSkmThreads), 0, st, f.sorted, f.bounds, a, ticket);            \
+    else hipLaunchKernelGGL((k_s1_skm<AGGV, TAGV, false>), dim3(grid), dim3(kSkmThreads), 0, st, f.sorted, f.bounds, a, ticket);                \
+  } while (0)
   MHX_LAUNCH(c, "s1_skm_groups", (double)f.n_records * 16, {
     if (agg && tags) MHX_SKM(true, true);
     else if (agg) MHX_SKM(true, false);

@@ -16,7 +16,7 @@ from test_gpu_sdbg import check_sdbg
 pytestmark = pytest.mark.gpu
 
 RESET = dict(s1_skm=1, s1_stream_fill=7168, s1_stream_probes=1024, s1_skm_max_bin=65536, s1_skm_min_windows=1 << 22, s1_skm_bin_bits=0, s1_skm_tags=0, s1_skm_cap_pct=36,
-             s1_var_min_fill=50, s1_skm_passes=0)
+             s1_var_min_fill=50, s1_skm_passes=0, s1_skm_deal=1)
 
 
 def run(engine, reads, k, m, opts, want_plan="super-k-mers", want_kernels=("s1_skm_make", "s1_skm_groups"), absent=("s1_groups",), why=None):
@@ -52,7 +52,7 @@ def run(engine, reads, k, m, opts, want_plan="super-k-mers", want_kernels=("s1_s
             engine.set_option(n, v)
 
 
-@pytest.mark.parametrize("opts", [dict(), dict(s1_stream_fill=40), dict(s1_stream_fill=3), dict(s1_stream_probes=2)],
+@pytest.mark.parametrize("opts", [dict(), dict(s1_stream_fill=40), dict(s1_stream_fill=3), dict(s1_stream_probes=2), dict(s1_skm_deal=0), dict(s1_skm_deal=0, s1_stream_fill=40)],
                          ids=lambda o: ",".join("%s=%d" % kv for kv in o.items()) or "default")
 @pytest.mark.parametrize("kind,k,m", [("pe100", 21, 2), ("repeats100", 21, 2), ("short30", 21, 2), ("tiny60", 21, 2), ("pe100", 19, 2), ("repeats100", 22, 2),
                                       ("pe100", 20, 1), ("repeats100", 21, 1)])
@@ -80,7 +80,7 @@ def test_the_same_reads_with_the_limit_lifted(engine):
     run(engine, reads, 21, 2, dict(s1_skm=2, s1_skm_max_bin=1 << 30))
 
 
-@pytest.mark.parametrize("opts", [dict(s1_skm_bin_bits=20), dict(s1_skm_bin_bits=18, s1_stream_fill=40), dict(s1_skm_bin_bits=11), dict(s1_skm_tags=1)],
+@pytest.mark.parametrize("opts", [dict(s1_skm_bin_bits=20), dict(s1_skm_bin_bits=18, s1_stream_fill=40), dict(s1_skm_bin_bits=11), dict(s1_skm_tags=1), dict(s1_skm_tags=1, s1_skm_deal=0)],
                          ids=lambda o: ",".join("%s=%d" % kv for kv in o.items()))
 @pytest.mark.parametrize("kind,k,m", [("pe100", 21, 2), ("repeats100", 22, 2), ("short30", 19, 1)])
 def test_three_sort_passes_and_position_tags(engine, kind, k, m, opts):
