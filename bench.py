@@ -93,7 +93,7 @@ def pmc_traffic(kernel_name, path=None):
              "s1_extract": ("k_s1_extract_fast<", "k_s1_extract_fixed<", "k_s1_extract<"), "s1_digit_hist": ("k_s1_digit_hist", "k_s1_extract_fast<4, false"),
              "count_extract": ("k_count_extract<",),
              "radix_scatter_12B_gen": ("k_radix_onesweep_u<3, 8, 3, S1Gen", "k_radix_onesweep<3, 8, 3, S1Gen"),
-             "s1_sample": ("k_s1_stream<false",)}
+             "s1_sample": ("k_s1_stream<false",), "s1_skm_groups": ("k_s1_skm<",), "s1_skm_make": ("k_skm_make<",), "s1_skm_bounds": ("k_skm_bounds",)}
     prefixes = list(table.get(kernel_name, ()))
     for stem, names in (("radix_scatter_", ("k_radix_onesweep", "k_radix_scatter")), ("radix_hist_all_", ("k_radix_hist_all",)),
                         ("radix_hist_", ("k_radix_hist",))):
@@ -109,6 +109,24 @@ def pmc_traffic(kernel_name, path=None):
             if k.startswith(prefix):
                 return v["hbm_bytes"], PMC_FILE + ":" + k
     return None, None
+
+
+def pmc_traffic_per_step(path=None):
+    """HBM bytes of ALL kernels of one step, from the same counter file (its command runs 3 + 1 steps): sum of launches x bytes per launch / 4;
+    None unless the file was measured on the running build"""
+    path = path or os.path.join(ROOT, PMC_FILE)
+    try:
+        from megahit_amd.buildid import build_id
+        with open(path) as f:
+            doc = json.load(f)
+        if doc.get("build_id") != build_id():
+            return None
+        steps = 4 if "--steps 3 --warmup 1" in doc.get("command", "") else None
+        if not steps:
+            return None
+        return int(sum(v["hbm_bytes"] * v["launches"] for k, v in doc["kernels"].items() if not k.startswith("at::")) / steps)
+    except Exception:
+        return None
 
 
 def tuned_defaults():
@@ -527,6 +545,13 @@ def main():
                 "copy_kernel_GBs": copy_gbs, "frac_of_copy_kernel": round(achieved / copy_gbs, 4) if copy_gbs else None,
                 "launches_per_step": ks["launches"] // max(1, args.steps), "avg_launch_ms": round(per_launch_ms, 4),
                 "algo_bytes_per_launch": per_launch_bytes,
+                # every kernel of a step together (counter file of the running build, else null): what the step moves through HBM
+                "traffic_per_step_all_kernels": pmc_traffic_per_step() if n_reads == 10000000 and args.engine == "read2sdbg" and not use_dist else None,
+                # the contract's "bound" knows hbm | mfma; the group-by over super-k-mer records is neither: it reads 16 bytes per 3.5 windows and
+                # spends its time on LDS compare-and-swaps and the vector instructions that form the keys (profiles/rNN_pmc_sq.json)
+                "note": ("dominant kernel is the LDS group-by of stage 1 on super-k-mer records: bound by LDS atomics and vector issue, not by HBM — its "
+                         "fraction of the HBM peak says how few bytes it needs, not how well it runs; the HBM-bound kernels of the step are the sort passes "
+                         "(top_kernels)") if name == "s1_skm_groups" else None,
                 "kernel_ms_per_step": {k2: round(v["ms"] / args.steps, 3) for k2, v in sorted(stats.items(), key=lambda kv: -kv[1]["ms"])},
                 # the same figure for the three kernels with the largest time per step (they are within a few per cent of each
                 # other, and which of them leads changes from box to box): algorithmic GB/s of one launch and its fraction of the peak

@@ -133,11 +133,22 @@ int mhx_set_option(mhx_ctx *, const char *name, long long value);
  *                          measured slower (profiles/r06_ab_loaded_ut2.jsonl): the passes are bound per scattered run, not by occupancy
  *   fetch_pinned (1)       0: mhx_fetch is one hipMemcpy into the caller's (pageable) memory; 1: results of >= 16 MB leave through two
  *                          pinned staging buffers, the copy off the device overlapped with the copy into the destination
+ *   s1_skm (1)             stage 1 on super-k-mer records (csrc/s1_skm.hip): 0 never; 1 where the shape is served (one GPU, no mercy, no bucket
+ *                          filter, 19 <= k <= 22, min count <= 2, fewer than 2^36 bases, reads of one length or at least s1_var_min_fill per cent
+ *                          of the padded blocks filled) and the job has s1_skm_min_windows (2^22) windows; 2 whatever the size (tests);
+ *                          3 as 1, but a job the path gives up on FAILS instead of taking the prefix plan (mhx_s1_self_planned).
+ *                          s1_skm_cap_pct (36): records the arrays hold per 100 windows (0.284 per window in random sequence);
+ *                          s1_skm_max_bin (65536): a bin of more records hands the job to the prefix plan (low-complexity reads);
+ *                          s1_skm_pass_gb (48): both record arrays of a pass together — larger jobs run in passes over ranges of bins,
+ *                          s1_skm_passes (0) forces their number; s1_skm_bin_bits (0 = by density: 16..20) the bins; s1_skm_tags (0) 1: the
+ *                          kernel of read sets beyond 2^32 bases on any read set (tests); s1_skm_deal (1) 0: every lane expands its own
+ *                          record instead of the wavefront's windows being dealt to the lanes (measured 7 % slower)
  * The CLI's memory plan (host/mhx_core.cpp plan_ranges): MHX_PLAN_BY_TIME=0 plans by space only; MHX_ALLOC_S_PER_GB=<seconds> sets the
  * hipMalloc rate the time plan assumes (tests).
  * (mhx_tuning.conf of this tree: s1_gen_blocked = 1.) */
 long long mhx_get_option(mhx_ctx *, const char *name, long long dflt);
-/* What the last stage 1 of this handle ran as: "stream p16 sub0 2 passes (20345 records per lv1 bucket)" / "seg p24 3 passes" /
+/* What the last stage 1 of this handle ran as: "super-k-mers m13, 2^16 bins (366 M records for 1.29 G windows: 3.52 per record; …)" /
+ * "stream p16 sub0 2 passes (20345 records per lv1 bucket)" / "seg p24 3 passes" /
  * "full sort 6 passes".  The string lives until the next stage 1 of the handle; "" before the first. */
 const char *mhx_last_s1_plan(const mhx_ctx *);
 

@@ -1283,7 +1283,9 @@ bool count_stream_front(mhx_ctx *c, uint32_t k, const S1Plan &plan, uint32_t **b
   c->pre_hist_buf = buf_a;
   c->pre_hist_n = n_items;
   c->pre_hist_passes = hd.n;
-  const uint32_t pos_bits = s1_pos_bits(c);
+  // (edges only — stage 2's aggregated items from a count — nobody reads the positions: no tag bits either, which at k >= 23 would sit
+  //  on bits of the (k+1)-mer; count_stream_shape declines tagged read sets there in every other case)
+  const uint32_t pos_bits = c->count_edges_only ? 63u : s1_pos_bits(c);
   const uint32_t tq = (uint32_t)(kSortThreads * 8) / per, tr = (uint32_t)(kSortThreads * 8) % per;
   const CountGenT<false> g{s.words.as<uint32_t>(), s.fixed_len, per, (int)k, c->pos_base, pos_bits, tq, tr, nullptr};
   const CountGenT<true> gf{s.words.as<uint32_t>(), s.fixed_len, per, (int)k, c->pos_base, pos_bits, tq, tr, keep};

@@ -207,8 +207,14 @@ def test_read2sdbg_min_count_1(engine, kind, k):
     reads = make_reads(kind, 9)
     pkg = ob.Package(reads, reverse=True)
     load(engine, pkg)
-    r = engine.read2sdbg_s2(k, 1)  # for_sure_solid: S1 is skipped (main_sdbg_build.cpp:142-146)
-    check_sdbg(engine, r, ob.s2(pkg, k, 1, None), per_occurrence=True)
+    want = ob.s2(pkg, k, 1, None)
+    try:
+        for from_count in (0, 1):  # (round 6: the solid items from a count of the (k+1)-mers, k <= 27 — fewer items than occurrences)
+            engine.set_option("s2_agg_from_count", from_count)
+            r = engine.read2sdbg_s2(k, 1)  # for_sure_solid: S1 is skipped (main_sdbg_build.cpp:142-146)
+            check_sdbg(engine, r, want, per_occurrence=not from_count)
+    finally:
+        engine.set_option("s2_agg_from_count", 1)
 
 
 def edges_package(edges, k):
