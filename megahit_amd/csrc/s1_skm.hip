@@ -30,14 +30,15 @@ constexpr int kSkmMinBinBits = 16, kSkmMaxBinBits = 20;  // two sort passes, or 
 
 __device__ __forceinline__ uint32_t skm_mix(uint32_t c) {  // (a bijection of 32 bits: the order of the m-mers)
   uint32_t h = c * 0x9E3779B1u;
+  return h ^ (h >> 15);
+}
+__device__ __forceinline__ uint32_t skm_mix2(uint32_t c) {  // (the second hash of a table key: which half of a bin that overflowed it belongs to)
+  uint32_t h = c * 0x9E3779B1u;
   h ^= h >> 15;
   return h * 0x85EBCA6Bu;
 }
 __device__ __forceinline__ uint32_t skm_bin_of(uint32_t minh) {  // (the minimum of ten hashes is small: mixed once more; the bin = its top bits)
-  uint32_t h = minh ^ (minh >> 16);
-  h *= 0x7FEB352Du;
-  h ^= h >> 15;
-  return h * 0x846CA68Bu;
+  return (minh ^ (minh >> 16)) * 0x7FEB352Du;
 }
 
 // record (16 bytes): w0 = position bits 32.. << 28 | bin << 8 (bits 0..7 zero: the sort passes may rank with LDS atomics, sort_kernels.h
@@ -52,9 +53,11 @@ __global__ __launch_bounds__(NT) void k_skm_make(const uint32_t *__restrict__ se
   __shared__ uint32_t sm_scan[NT / kWave + 1];
   __shared__ unsigned long long s_base;
   __shared__ uint32_t dh[3][256];  // the digit histograms of the sort passes, taken while the records are made
+  __shared__ uint32_t lbin[J * kSkmC][NT];  // a thread's bins, read back by window number when its records leave (no register array indexed by a variable)
   const int tid = threadIdx.x;
   for (int i = tid; i < 768; i += NT) dh[i >> 8][i & 255] = 0;
   __syncthreads();
+  const bool third_digit = bin_bits > 16;
   const int M = k + 1 - (kSkmW - 1);
   const uint32_t mmask = (1u << (2 * M)) - 1u;
   const int K1 = k + 1;
@@ -62,16 +65,14 @@ __global__ __launch_bounds__(NT) void k_skm_make(const uint32_t *__restrict__ se
   unsigned long long items = 0;  // VAR: what the reference sorts, L - k + 4 items per read that holds an edge (read_to_sdbg_s1.cpp:344-363)
   for (uint64_t it = blockIdx.x; it * (uint64_t)(NT * J) < n_blocks; it += gridDim.x) {
     uint64_t Wv[J], pos0[J];
-    uint32_t binp[J][8], smask[J], kmask8[J];  // per block: the windows' bins, which windows start a run, which are this pass's
+    uint32_t smask[J], emask[J];  // per block: the windows that start a run of this pass's bins, and those that end one
 #pragma unroll
     for (int j = 0; j < J; ++j) {
       const uint64_t b = it * (uint64_t)(NT * J) + (uint64_t)j * NT + tid;
       smask[j] = 0;
-      kmask8[j] = 0;
+      emask[j] = 0;
       Wv[j] = 0;
       pos0[j] = 0;
-#pragma unroll
-      for (int x = 0; x < 8; ++x) binp[j][x] = 0;
       if (b < n_blocks) {
         const uint64_t r = b / bpr;
         const uint32_t q0 = (uint32_t)(b - r * bpr) * kSkmC;
@@ -106,23 +107,26 @@ __global__ __launch_bounds__(NT) void k_skm_make(const uint32_t *__restrict__ se
 #pragma unroll
           for (int i = kSkmW - 2; i >= 0; --i) sfx[i] = min(h[i], sfx[i + 1]);
           uint32_t pfx = 0xFFFFFFFFu;
-          binp[j][0] = skm_bin_of(sfx[0]) >> bin_sh;
+          uint32_t bins[kSkmC];
+          bins[0] = skm_bin_of(sfx[0]) >> bin_sh;
 #pragma unroll
           for (int w = 1; w < kSkmC; ++w) {
             pfx = min(pfx, h[kSkmW - 1 + w]);
-            binp[j][w] = skm_bin_of(min(sfx[w], pfx)) >> bin_sh;
+            bins[w] = skm_bin_of(min(sfx[w], pfx)) >> bin_sh;
           }
+#pragma unroll
+          for (int w = 0; w < kSkmC; ++w) lbin[j * kSkmC + w][tid] = bins[w];
           // a pass of the memory plan keeps the bins [bin_lo, bin_hi): the windows of a run share their bin, so runs stay whole
           const uint32_t n_here = min((uint32_t)kSkmC, nwin - q0);
           uint32_t km = 0, sm = 0;
 #pragma unroll
           for (int w = 0; w < kSkmC; ++w)
-            if ((uint32_t)w < n_here && binp[j][w] >= bin_lo && binp[j][w] < bin_hi) km |= 1u << w;
+            if ((uint32_t)w < n_here && bins[w] >= bin_lo && bins[w] < bin_hi) km |= 1u << w;
 #pragma unroll
           for (int w = 0; w < kSkmC; ++w)
-            if (((km >> w) & 1u) && (w == 0 || !((km >> (w - 1)) & 1u) || binp[j][w] != binp[j][w > 0 ? w - 1 : 0])) sm |= 1u << w;
+            if (((km >> w) & 1u) && (w == 0 || !((km >> (w - 1)) & 1u) || bins[w] != bins[w > 0 ? w - 1 : 0])) sm |= 1u << w;
           smask[j] = sm;
-          kmask8[j] = km;
+          emask[j] = km & ((sm >> 1) | ~(km >> 1));  // window w ends a run: the next one starts one, or is not this pass's (bit 8 of km is clear)
           Wv[j] = W;
           pos0[j] = a;
         }
@@ -143,28 +147,19 @@ __global__ __launch_bounds__(NT) void k_skm_make(const uint32_t *__restrict__ se
     unsigned long long at = base + excl;
 #pragma unroll
     for (int j = 0; j < J; ++j) {
-      // (straight-line over the eight windows: no register array is indexed by a variable)
-      uint32_t run_bin = 0;
-      int run_s = 0;
-      bool open = false;
-#pragma unroll
-      for (int w = 0; w <= kSkmC; ++w) {
-        const bool kept = w < kSkmC && ((kmask8[j] >> w) & 1u), head = w < kSkmC && ((smask[j] >> w) & 1u);
-        if (open && (!kept || head)) {  // a run ends in front of window w
-          const int len = w - run_s;
-          const uint64_t p = pos0[j] + (uint64_t)run_s;
-          const uint64_t bases = ((Wv[j] << (2 * run_s)) & (~0ull << (64 - 2 * (K1 + len - 1)))) | (uint64_t)(len - 1);
-          out[at++] = make_uint4((run_bin << 8) | ((uint32_t)(p >> 32) << 28), (uint32_t)(bases >> 32), (uint32_t)bases, (uint32_t)p);
-          atomicAdd(&dh[0][run_bin & 255u], 1u);
-          atomicAdd(&dh[1][(run_bin >> 8) & 255u], 1u);
-          atomicAdd(&dh[2][run_bin >> 16], 1u);
-          open = false;
-        }
-        if (head) {
-          open = true;
-          run_bin = binp[j][w < kSkmC ? w : 0];
-          run_s = w;
-        }
+      uint32_t sm = smask[j], em = emask[j];
+      while (sm) {  // (runs are disjoint and in order: the i-th start goes with the i-th end)
+        const int rs = __builtin_ctz(sm), re = __builtin_ctz(em);
+        sm &= sm - 1;
+        em &= em - 1;
+        const int len = re - rs + 1;
+        const uint32_t run_bin = lbin[j * kSkmC + rs][tid];
+        const uint64_t p = pos0[j] + (uint64_t)rs;
+        const uint64_t bases = ((Wv[j] << (2 * rs)) & (~0ull << (64 - 2 * (K1 + len - 1)))) | (uint64_t)(len - 1);
+        out[at++] = make_uint4((run_bin << 8) | ((uint32_t)(p >> 32) << 28), (uint32_t)(bases >> 32), (uint32_t)bases, (uint32_t)p);
+        atomicAdd(&dh[0][run_bin & 255u], 1u);
+        atomicAdd(&dh[1][(run_bin >> 8) & 255u], 1u);
+        if (third_digit) atomicAdd(&dh[2][run_bin >> 16], 1u);
       }
     }
   }
@@ -177,6 +172,11 @@ __global__ __launch_bounds__(NT) void k_skm_make(const uint32_t *__restrict__ se
     if (dh[i >> 8][i & 255]) atomicAdd(&digit_hist[i], (unsigned long long)dh[i >> 8][i & 255]);
 }
 
+// (Natural super-k-mers — runs cut at eight windows from their OWN start, the windows' minimizer hashes exchanged between the threads of a
+//  workgroup through LDS — were built and measured in round 6: 0.23 instead of 0.28 records per window, the two sort passes 5.7 -> 4.8 ms,
+//  but the make kernel 3.1 -> 7.9 ms (three barriers, a walk back and a walk forward through LDS per block, 1024-thread workgroups) and the
+//  group-by 7.7 -> 8.4 (282 windows per wavefront trip instead of 225: a second, nearly empty round of four chunks).  Not kept:
+//  profiles/r06-interim_ab_skm_natural.jsonl.)
 // bounds[b] = the first record whose bin is >= b (b = 0 .. n_bins); a thread per bin, a binary search each
 __global__ __launch_bounds__(256) void k_skm_bounds(const uint4 *__restrict__ recs, uint64_t n, uint32_t n_bins, uint64_t *__restrict__ bounds,
                                                     uint32_t *__restrict__ max_bin) {
@@ -384,7 +384,7 @@ __global__ __launch_bounds__(kSkmThreads) void k_s1_skm(const uint4 *__restrict_
                 key[u] = rev ? kr : kf;
                 const uint32_t klo = (uint32_t)key[u], khi = (uint32_t)(key[u] >> 32);
                 bool mn = g < T;
-                if (sub) mn = mn && (skm_mix((klo * 0xC2B2AE35u) ^ (khi * 0x27D4EB2Fu)) >> (32 - sub)) == rj;  // (uniform branch)
+                if (sub) mn = mn && (skm_mix2((klo * 0xC2B2AE35u) ^ (khi * 0x27D4EB2Fu)) >> (32 - sub)) == rj;  // (uniform branch)
                 mine |= mn ? 1u << u : 0u;
                 h1[u] = ((klo * 0x9E3779B1u) ^ (khi * 0x85EBCA6Bu)) >> (32 - kSkmLogSlots);
                 pos[u] = pdo + g;
@@ -461,7 +461,7 @@ __global__ __launch_bounds__(kSkmThreads) void k_s1_skm(const uint4 *__restrict_
                 key[u] = rev ? kr : kf;
                 const uint32_t klo = (uint32_t)key[u], khi = (uint32_t)(key[u] >> 32);
                 bool mn = (uint32_t)j < len;
-                if (sub) mn = mn && (skm_mix((klo * 0xC2B2AE35u) ^ (khi * 0x27D4EB2Fu)) >> (32 - sub)) == rj;  // (uniform branch)
+                if (sub) mn = mn && (skm_mix2((klo * 0xC2B2AE35u) ^ (khi * 0x27D4EB2Fu)) >> (32 - sub)) == rj;  // (uniform branch)
                 mine |= mn ? 1u << u : 0u;
                 h1[u] = ((klo * 0x9E3779B1u) ^ (khi * 0x85EBCA6Bu)) >> (32 - kSkmLogSlots);
               }
