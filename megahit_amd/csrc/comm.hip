@@ -378,6 +378,81 @@ static bool dist_s1_presorted(mhx_ctx *c, mhx_comm *cm, uint32_t k, uint32_t m, 
   return true;
 }
 
+// Stage 1 on super-k-mer records over several GPUs (round 6, s1_skm.hip): every rank makes the 16-byte records of ITS reads — the windows of a
+// read that share a minimizer are one record: 4.6 bytes per window, where the pre-sorted exchange above moves a 12-byte record per window —
+// orders them by minimizer bin (the passes of a single GPU), sends each owner of a contiguous range of BINS its slice as it is, and the
+// owner's group-by (k_s1_skm) reads a bin as one sub-range per sender.  Marks leave the owners as lists of global positions for the read
+// owners, aggregated stage-2 items stay for stage 2's exchange, as before.  The ranks agree on the number of bins (from the size of the
+// whole job), on taking this form at all (any rank may veto: shape, a memory plan, more than kSkmSrcMax ranks) and on giving it up (a
+// record array or an output region that overflowed, a bin of low-complexity reads): -> false, nothing of the pass published, the
+// pre-sorted exchange of the prefix plan runs.
+static bool dist_s1_skm(mhx_ctx *c, mhx_comm *cm, uint32_t k, uint32_t m, mhx_s1_result *r1, std::string *why) {
+  const int n = cm->n, rank = cm->rank;
+  const SeqSet &sq = c->seqs;
+  const uint64_t n_win_local = sq.n_bases > sq.n_seqs * (uint64_t)k ? sq.n_bases - sq.n_seqs * (uint64_t)k : 0;
+  std::vector<uint64_t> v{s1_skm_dist_applies(c, k, m) ? 0ull : 1ull, n_win_local};
+  cm->all_reduce(v, true);  // any rank that cannot vetoes; the largest shard sizes the bins
+  const long long knob = c->opt("s1_skm", 1);
+  if (v[0] || (knob < 2 && v[1] * (uint64_t)n < (uint64_t)c->opt("s1_skm_min_windows", 1 << 22))) return false;
+  int bin_bits = 16;
+  while (bin_bits < 20 && (double)v[1] * (double)n * 0.29 / (double)(1ull << bin_bits) > 8192.0) ++bin_bits;
+  if (const long long fb = c->opt("s1_skm_bin_bits", 0)) bin_bits = (int)std::min<long long>(20, std::max<long long>(8, fb));
+  hipStream_t st = c->stream;
+  SkmFront f{};
+  c->gen_first_pass = nullptr;
+  c->pre_hist_buf = nullptr;
+  std::vector<uint64_t> fail{s1_skm_front(c, k, &f, 0, 1, bin_bits) ? 0ull : 1ull};
+  cm->all_reduce(fail, true);
+  if (fail[0]) {
+    *why = f.n_records ? "a rank's bin of low-complexity reads" : "a rank's record array overflowed";
+    return false;
+  }
+  // the owners' bin ranges and this rank's slice for each
+  const uint32_t n_bins = f.n_bins;
+  std::vector<uint64_t> cut(n + 1, 0), at_cut(n + 1, 0);
+  for (int p = 0; p <= n; ++p) cut[p] = (uint64_t)n_bins * p / n;
+  for (int p = 0; p <= n; ++p) MHX_HIP(hipMemcpyAsync(&at_cut[p], f.src_bounds[0] + cut[p], 8, hipMemcpyDeviceToHost, st));
+  MHX_HIP(hipStreamSynchronize(st));
+  std::vector<uint64_t> counts(n), rc;
+  for (int p = 0; p < n; ++p) counts[p] = at_cut[p + 1] - at_cut[p];
+  cm->all_to_all_counts(counts, rc);
+  uint64_t n_recv = 0, total = 0;
+  for (int p = 0; p < n; ++p) {
+    if (p != rank) n_recv += rc[p];
+    total += rc[p];
+  }
+  uint4 *recv = c->ws("items_recv", n_recv * 16 + 64).as<uint4>();
+  cm->all_to_all_v(f.src[0], counts, recv, rc, 16, true);
+  // the sources of this owner's group-by: its own slice where it lies, the others in the receive buffer; where the bins start in each
+  SkmFront o = f;
+  o.n_src = n;
+  uint64_t *sb = c->ws("skm_src_bounds", (size_t)n * ((size_t)n_bins + 1) * 8 + 64).as<uint64_t>();
+  uint64_t at = 0;
+  for (int p = 0; p < n; ++p) {
+    const uint4 *ptr;
+    if (p == rank) ptr = f.src[0] + at_cut[rank];
+    else {
+      ptr = recv + at;
+      at += rc[p];
+    }
+    o.src[p] = ptr;
+    o.src_bounds[p] = sb + (size_t)p * ((size_t)n_bins + 1);
+    s1_skm_bounds_of(c, ptr, rc[p], n_bins, sb + (size_t)p * ((size_t)n_bins + 1));
+  }
+  o.bin_lo = (uint32_t)cut[rank];
+  o.bin_hi = (uint32_t)cut[rank + 1];
+  o.n_records = total;
+  mhx_s1_result rp{};
+  std::vector<uint64_t> fail2{s1_skm_owner(c, k, m, o, &rp) ? 0ull : 1ull};
+  cm->all_reduce(fail2, true);
+  if (fail2[0]) {
+    *why = "an owner's output region overflowed";
+    return false;
+  }
+  *r1 = rp;
+  return true;
+}
+
 // `count` the same way (round 6): every rank makes its 12-byte count records in the first pass of the single-GPU sort plan (CountGenT, also
 // under the bucket filter of a pass), orders them by the plan's prefix, sends each owner its contiguous slice, and the owner's bucket
 // streaming (k_s1_stream<COUNT>) reads a bucket as one sub-range per sender; the events that move first_0_out / last_0_in of reads held
@@ -716,7 +791,9 @@ int mhx_dist_read2sdbg(mhx_ctx *c, mhx_comm *cm, uint32_t k, uint32_t min_count,
         mhx::set_pass(c, dp, pass, true);
         mhx_s1_result rp{};
         bool done = false;
-        if (!need_mercy) {
+        std::string skm_why;
+        if (!need_mercy && dp.n == 1) done = mhx::dist_s1_skm(c, cm, k, min_count, &rp, &skm_why);  // super-k-mer records, exchanged by bin
+        if (!need_mercy && !done) {
           // (the pre-sort's first pass may make the records itself — and drop those of the buckets a pass leaves out: then
           // "items_a" holds nothing yet — s1.hip, S1GenT)
           c->gen_first_pass = nullptr;
@@ -741,10 +818,11 @@ int mhx_dist_read2sdbg(mhx_ctx *c, mhx_comm *cm, uint32_t k, uint32_t min_count,
             mhx::move_items(c, cm, di, counts, &n1);
             MHX_CK(mhx_dist_process_s1(c, k, min_count, 0, n1, &rp));
           }
-        } else {
+        } else if (need_mercy) {
           const uint64_t n1 = mhx::exchange_stage(c, cm, MHX_STAGE_S1_MERCY, k, min_count);
           MHX_CK(mhx_dist_process_s1(c, k, min_count, need_mercy, n1, &rp));
         }
+        if (!skm_why.empty()) c->last_s1_plan += " [super-k-mer records given up: " + skm_why + "]";
         n_items_all += rp.n_items;
         r1 = rp;
       }

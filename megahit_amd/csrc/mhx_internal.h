@@ -217,6 +217,32 @@ struct S1Sources {
   uint32_t *spare = nullptr;  // scratch of >= 12 bytes per record for the group-by's output regions
   int pbits = 16;             // key prefix bits the sources are sorted on (the stream plan's seg_bits)
 };
+// ---- stage 1 on super-k-mer records (s1_skm.hip) ----
+constexpr int kSkmBatch = 8;   // bins per ticket of the group-by
+constexpr int kSkmSrcMax = 8;  // sources of the group-by: one array on a single GPU, one per sending rank on several
+struct SkmFront {
+  int n_src;
+  const uint4 *src[kSkmSrcMax];            // the records, ordered by minimizer bin
+  const uint64_t *src_bounds[kSkmSrcMax];  // [n_bins + 1] each: where the bins start in the source
+  uint32_t *spare;       // the other sort buffer (the workgroups' output regions)
+  uint64_t spare_bytes;
+  uint64_t n_records, n_windows;
+  uint64_t n_items;        // what the reference sorts: L - k + 4 items per read that holds an edge
+  uint32_t n_bins, max_bin;
+  uint32_t bin_lo, bin_hi;  // the bins of this pass / of this owner
+  int bin_bits;
+};
+bool s1_skm_applies(const mhx_ctx *c, uint32_t k, uint32_t m, int want_mercy);
+bool s1_skm_dist_applies(const mhx_ctx *c, uint32_t k, uint32_t m);
+int s1_skm_passes(const mhx_ctx *c, uint32_t k);
+bool s1_skm_front(mhx_ctx *c, uint32_t k, SkmFront *f, int pass, int n_passes, int bin_bits_agreed = 0);
+void s1_skm_bounds_of(mhx_ctx *c, const uint4 *recs, uint64_t n, uint32_t n_bins, uint64_t *bounds);
+void s1_skm_groups_launch(mhx_ctx *c, bool agg, unsigned grid, const SkmFront &f, uint32_t k, uint32_t m, uint8_t *solid_bytes, unsigned long long *hist,
+                          uint2 *agg_raw, uint32_t agg_cap, uint32_t *agg_counts, uint32_t *err, unsigned long long *marks_raw, uint32_t marks_cap,
+                          uint32_t *marks_counts);
+// the owner's half on several GPUs (s1.hip): group-by over the received sources, marks as a list, aggregated items.  -> false: a region overflowed
+bool s1_skm_owner(mhx_ctx *c, uint32_t k, uint32_t m, const SkmFront &f, mhx_s1_result *out);
+
 bool s1_presort_applies(const mhx_ctx *c, uint32_t k, uint64_t n_local_items);
 uint32_t *s1_presort(mhx_ctx *c, uint32_t k, uint32_t *buf_a, uint32_t *buf_b, uint64_t n_items, int *pbits);
 bool s1_filter_in_gen_applies(const mhx_ctx *c, uint32_t k);
@@ -283,7 +309,6 @@ struct CountStreamOut {
   uint64_t n_events;
 };
 bool count_stream_applies(const mhx_ctx *c, uint32_t k, uint32_t m);
-bool s1_skm_applies(const mhx_ctx *c, uint32_t k, uint32_t m, int want_mercy);  // s1_skm.hip: stage 1 on super-k-mer records serves this shape
 bool count_presort_applies(const mhx_ctx *c, uint32_t k, uint32_t m);
 uint32_t *count_presort(mhx_ctx *c, uint32_t k, uint64_t *n_items, uint32_t **other, int *pbits);
 int count_process_presorted(mhx_ctx *c, uint32_t k, uint32_t m, const S1Sources &src, mhx_count_result *out);  // count.hip; -1: gave up

@@ -750,30 +750,49 @@ struct S1Stage {
   // -> false: an output region overflowed (nothing published; the caller takes the prefix plan from scratch)
   bool run_skm(const SkmFront &f) {
     mark_mode = 1;  // the marks of the non-solid occurrences, from the table
-    ensure_byte_map();
+    if (!sparse) ensure_byte_map();
     const uint64_t cus = c->n_cus > 0 ? (uint64_t)c->n_cus : 256;
-    const unsigned grid = (unsigned)std::min<uint64_t>(cus, f.n_bins);
+    // (a workgroup takes tickets of kSkmBatch bins: no more workgroups than tickets, so that a small job's regions are not cut thinner than its work)
+    const unsigned grid = (unsigned)std::min<uint64_t>(cus, std::max<uint64_t>(1, div_ceil((uint64_t)(f.bin_hi - f.bin_lo), (uint64_t)kSkmBatch)));
+    // per-workgroup output regions in the spare sort buffer: aggregated items in its first half, (several GPUs) marks in its second
+    const uint64_t region8 = f.spare_bytes / 8 / 2 / std::max(1u, grid);
     uint2 *raw = nullptr;
-    uint32_t *counts = nullptr;
+    uint32_t *counts = nullptr, *mcounts = nullptr;
+    unsigned long long *mraw = nullptr;
+    seg_grid = grid;
     if (agg) {
-      seg_grid = grid;
-      seg_cap = (uint32_t)std::min<uint64_t>(f.spare_bytes / 8 / grid, 0xFFFFFFF0u);
+      seg_cap = (uint32_t)std::min<uint64_t>(region8, 0xFFFFFFF0u);
       raw = reinterpret_cast<uint2 *>(spare);
       counts = c->ws("s2_agg_counts", (size_t)grid * 4).as<uint32_t>();
     }
+    if (sparse) {
+      seg_mcap = (uint32_t)std::min<uint64_t>(region8, 0xFFFFFFF0u);
+      mraw = reinterpret_cast<unsigned long long *>(spare) + f.spare_bytes / 8 / 2;
+      mcounts = c->ws("s1_mark_counts", (size_t)grid * 4).as<uint32_t>();
+    }
     MHX_HIP(hipMemsetAsync(seg_err, 0, 4, st));
-    s1_skm_groups_launch(c, agg, grid, f, k, m, solid_bytes, hist, raw, seg_cap, counts, seg_err);
+    s1_skm_groups_launch(c, agg, grid, f, k, m, solid_bytes, hist, raw, seg_cap, counts, seg_err, mraw, seg_mcap, mcounts);
     uint32_t e = 0;
-    std::vector<uint32_t> h_counts(agg ? seg_grid : 0);
+    std::vector<uint32_t> h_counts(agg ? seg_grid : 0), h_mcounts(sparse ? seg_grid : 0);
     MHX_HIP(hipMemcpyAsync(&e, seg_err, 4, hipMemcpyDeviceToHost, st));
     if (agg) MHX_HIP(hipMemcpyAsync(h_counts.data(), counts, (size_t)seg_grid * 4, hipMemcpyDeviceToHost, st));
+    if (sparse) MHX_HIP(hipMemcpyAsync(h_mcounts.data(), mcounts, (size_t)seg_grid * 4, hipMemcpyDeviceToHost, st));
     MHX_HIP(hipStreamSynchronize(st));
     if (e) return false;
+    if (sparse) {  // pack the workgroups' mark regions behind the earlier passes' marks (run_partial's way)
+      for (uint32_t v : h_mcounts) seg_marks += v;
+      unsigned long long *dense = grow_preserving(c, c->work["s1_marks"], (marks_prev + seg_marks) * 8 + 64, marks_prev * 8).as<unsigned long long>();
+      if (seg_marks)
+        MHX_LAUNCH(c, "marks_compact", (double)seg_marks * 16,
+                   hipLaunchKernelGGL(k_agg_compact, dim3(seg_grid, 8), dim3(256), 0, st, reinterpret_cast<const uint2 *>(mraw), seg_mcap, mcounts,
+                                      reinterpret_cast<uint2 *>(dense + marks_prev), 0));
+      c->n_marks = marks_prev + seg_marks;
+    }
     if (agg) {
       uint64_t total = 0;
       for (uint32_t v : h_counts) total += v;
       // (a pass of several: the array is sized for all of them after the first — the bins fill evenly — instead of growing pass by pass)
-      const uint64_t expect = f.bin_hi > f.bin_lo ? (uint64_t)((double)(agg_prev + total) * (double)f.n_bins / (double)f.bin_hi * 1.05) : agg_prev + total;
+      const uint64_t expect = !sparse && f.bin_hi > f.bin_lo ? (uint64_t)((double)(agg_prev + total) * (double)f.n_bins / (double)f.bin_hi * 1.05) : agg_prev + total;
       uint2 *dense = grow_preserving(c, c->work["s2_agg_items"], std::max(agg_prev + total, expect) * 8 + 64, agg_prev * 8).as<uint2>();
       if (total)
         MHX_LAUNCH(c, "agg_compact", (double)total * 16,
@@ -1204,6 +1223,24 @@ static bool s1_skm_try(mhx_ctx *c, uint32_t k, uint32_t m, mhx_s1_result *out, s
            c->seqs.fixed_len ? "" : " [reads of several lengths]");
   c->last_s1_plan = txt;
   if (n_passes > 1) c->last_s1_plan += " [" + std::to_string(n_passes) + " passes over ranges of bins]";
+  stage.publish(out);
+  return true;
+}
+
+// several GPUs: the owner's half of stage 1 on super-k-mer records — the sources are the record slices the ranks sent for this rank's bins
+// (comm.hip dist_s1_skm); marks leave as a list of global positions for the read owners, aggregated items stay for stage 2's exchange
+bool s1_skm_owner(mhx_ctx *c, uint32_t k, uint32_t m, const SkmFront &f, mhx_s1_result *out) {
+  S1Stage stage(c, k, m, 0, nullptr, nullptr, f.n_items, nullptr);
+  stage.sorted = nullptr;
+  stage.set_spare(f.spare);
+  stage.open_outputs();
+  if (!stage.sparse) throw Error("s1_skm_owner: the marks of a global layout leave as a list (dist_sparse_marks)");
+  if (!stage.run_skm(f)) return false;
+  stage.mark_mode_used = 1;
+  char txt[320];
+  snprintf(txt, sizeof txt, "super-k-mers m%u, 2^%d bins (%llu records at this owner, bins %u..%u) [records exchanged by bin]", k + 1 - 9, f.bin_bits,
+           (unsigned long long)f.n_records, f.bin_lo, f.bin_hi);
+  c->last_s1_plan = txt;
   stage.publish(out);
   return true;
 }

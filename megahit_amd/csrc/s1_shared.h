@@ -172,22 +172,4 @@ bool count_shape_is_fast(const mhx_ctx *c, uint32_t k);  // the shapes CountGenT
 bool count_bucket_histogram_fast(mhx_ctx *c, uint32_t k, unsigned long long *hist);  // lv1 histogram of count's items from the packed reads
 bool count_stream_front(mhx_ctx *c, uint32_t k, const S1Plan &plan, uint32_t **buf_a, uint32_t **buf_b, uint64_t *n_items);
 
-// ---- stage 1 on super-k-mer records (s1_skm.hip) ----
-struct SkmFront {
-  const uint4 *sorted;   // the records, ordered by minimizer bin
-  uint32_t *spare;       // the other sort buffer (the workgroups' output regions)
-  uint64_t spare_bytes;
-  uint64_t n_records, n_windows;
-  uint64_t n_items;        // what the reference sorts: L - k + 4 items per read that holds an edge
-  const uint64_t *bounds;  // [n_bins + 1]
-  uint32_t n_bins, max_bin;
-  uint32_t bin_lo, bin_hi;  // the bins of this pass
-  int bin_bits;
-};
-bool s1_skm_applies(const mhx_ctx *c, uint32_t k, uint32_t m, int want_mercy);
-int s1_skm_passes(const mhx_ctx *c, uint32_t k);
-bool s1_skm_front(mhx_ctx *c, uint32_t k, SkmFront *f, int pass, int n_passes);
-void s1_skm_groups_launch(mhx_ctx *c, bool agg, unsigned grid, const SkmFront &f, uint32_t k, uint32_t m, uint8_t *solid_bytes, unsigned long long *hist,
-                          uint2 *agg_raw, uint32_t agg_cap, uint32_t *agg_counts, uint32_t *err);
-
 }  // namespace mhx

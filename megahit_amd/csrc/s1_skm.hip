@@ -48,7 +48,8 @@ __device__ __forceinline__ uint32_t skm_bin_of(uint32_t minh) {  // (the minimum
 // (as the padded item slots of S1GenVarT); a block beyond the read's last window makes nothing.
 template <int NT, int J, bool VAR>
 __global__ __launch_bounds__(NT) void k_skm_make(const uint32_t *__restrict__ seq, const uint64_t *__restrict__ start, uint32_t L, uint32_t bpr, uint64_t n_blocks,
-                                                 int k, int bin_bits, uint32_t bin_lo, uint32_t bin_hi, int count_items, uint4 *__restrict__ out, unsigned long long cap,
+                                                 int k, int bin_bits, uint32_t bin_lo, uint32_t bin_hi, int count_items, uint64_t pos_base, uint4 *__restrict__ out,
+                                                 unsigned long long cap,
                                                  unsigned long long *__restrict__ cursor, uint32_t *__restrict__ err, unsigned long long *__restrict__ digit_hist) {
   __shared__ uint32_t sm_scan[NT / kWave + 1];
   __shared__ unsigned long long s_base;
@@ -128,7 +129,7 @@ __global__ __launch_bounds__(NT) void k_skm_make(const uint32_t *__restrict__ se
           smask[j] = sm;
           emask[j] = km & ((sm >> 1) | ~(km >> 1));  // window w ends a run: the next one starts one, or is not this pass's (bit 8 of km is clear)
           Wv[j] = W;
-          pos0[j] = a;
+          pos0[j] = pos_base + a;  // (several GPUs: this rank's reads start at pos_base of the global read set)
         }
       }
     }
@@ -213,14 +214,24 @@ struct SkmArgs {
   uint32_t max_fill;
   int probe_limit;
   uint32_t bin_lo, bin_hi;  // the bins of this pass
+  // several GPUs: the reads live on other ranks — a mark is the global position itself, appended to the workgroup's region
+  // marks_raw[blockIdx.x * marks_cap ...] (count in marks_counts[blockIdx.x]); the host packs the regions and routes them (comm.hip)
+  unsigned long long *marks_raw;
+  uint32_t marks_cap;
+  uint32_t *marks_counts;
+};
+// the records of a bin arrive as one sub-range per source: one array on a single GPU; on several, one per sending rank (each ordered by bin)
+struct SkmSrcs {
+  const uint4 *ptr[kSkmSrcMax];
+  const uint64_t *bounds[kSkmSrcMax];  // [n_bins + 1] each
+  int n;
 };
 
-constexpr int kSkmThreads = 1024, kSkmLogSlots = 13, kSkmBatch = 8;
+constexpr int kSkmThreads = 1024, kSkmLogSlots = 13;
 
 // TAGS: read sets of 2^32 bases and more — the position bits above 32 ride in the record's first word and next to the key in the table
 template <bool AGG, bool TAGS, bool DEAL>
-__global__ __launch_bounds__(kSkmThreads) void k_s1_skm(const uint4 *__restrict__ recs, const uint64_t *__restrict__ bounds, SkmArgs a,
-                                                        uint32_t *__restrict__ ticket) {
+__global__ __launch_bounds__(kSkmThreads) void k_s1_skm(SkmSrcs srcs, SkmArgs a, uint32_t *__restrict__ ticket) {
   constexpr int NT = kSkmThreads, NSLOT = 1 << kSkmLogSlots, W = NSLOT / NT;
   constexpr unsigned long long kEmpty = ~0ull;  // never a key: head / tail bits 63 do not occur
   constexpr int NLIST = 1024;
@@ -233,8 +244,8 @@ __global__ __launch_bounds__(kSkmThreads) void k_s1_skm(const uint4 *__restrict_
   __shared__ uint32_t slist_c[AGG ? NLIST : 1];
   __shared__ unsigned long long heads[DEAL ? kSkmThreads / kWave : 1][8];  // DEAL, per wavefront: bit g set = window g of the trip is the first of its record
   __shared__ uint32_t s_bad2[2], s_nclaimed2[2], s_list_n2[2];  // per round, double-buffered: the next round's are cleared while this round's are read
-  __shared__ uint32_t s_agg_cur, s_tk;
-  __shared__ uint64_t s_lo[kSkmBatch + 1];
+  __shared__ uint32_t s_agg_cur, s_mark_cur, s_tk;
+  __shared__ uint64_t s_lo[kSkmSrcMax][kSkmBatch + 1];
   const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = DEAL ? tid / kWave : 0;
   const uint32_t le_lo = lane >= 31 ? 0xFFFFFFFFu : (2u << lane) - 1u, le_hi = lane < 32 ? 0u : (lane == 63 ? 0xFFFFFFFFu : (2u << (lane - 32)) - 1u);  // lanes <= this one
   const int k = a.k, K1 = k + 1;
@@ -251,7 +262,10 @@ __global__ __launch_bounds__(kSkmThreads) void k_s1_skm(const uint4 *__restrict_
     s_nclaimed2[0] = s_nclaimed2[1] = 0;
     s_list_n2[0] = s_list_n2[1] = 0;
     s_agg_cur = 0;
+    s_mark_cur = 0;
   }
+  const int n_src = srcs.n;
+  unsigned long long *const marks_out = a.marks_raw ? a.marks_raw + (size_t)blockIdx.x * a.marks_cap : nullptr;
   int rp = 0;  // the round's parity
   __syncthreads();
 
@@ -304,19 +318,28 @@ __global__ __launch_bounds__(kSkmThreads) void k_s1_skm(const uint4 *__restrict_
     __syncthreads();
     const uint64_t bin0 = (uint64_t)a.bin_lo + (uint64_t)s_tk * kSkmBatch;
     if (bin0 >= a.bin_hi) break;
-    if (tid <= kSkmBatch) s_lo[tid] = bounds[min(bin0 + tid, (uint64_t)a.bin_hi)];
+    if (tid < n_src * (kSkmBatch + 1)) {
+      const int q = tid / (kSkmBatch + 1), x = tid - q * (kSkmBatch + 1);
+      s_lo[q][x] = srcs.bounds[q][min(bin0 + x, (uint64_t)a.bin_hi)];
+    }
     __syncthreads();
     for (int bb = 0; bb < kSkmBatch; ++bb) {
-      const uint64_t lo = s_lo[bb], hi = s_lo[bb + 1];
-      if (lo == hi) continue;
+      bool any = false;
+      for (int q = 0; q < n_src; ++q) any = any || s_lo[q][bb] != s_lo[q][bb + 1];
+      if (!any) continue;
+      const uint64_t lo0 = s_lo[0][bb], hi0 = s_lo[0][bb + 1];
       // the bin in rounds: round (sub, rj) takes the keys whose top `sub` bits of a second hash are rj (a round that overflows the
       // table is redone in two halves)
       uint32_t sub = 0, rj = 0;
       for (;;) {
         uint32_t seen = 0;
-        // A: insert (the round's first trip was requested before the walk of the round before it)
-        uint4 nxt = pre_ok && pre_at == lo ? pre : (lo + tid < hi ? recs[lo + tid] : make_uint4(0u, 0u, 0u, 0u));
-        pre_ok = false;
+        // A: insert, source by source (the round's first trip was requested before the walk of the round before it)
+        for (int q = 0; q < n_src; ++q) {
+        const uint64_t lo = s_lo[q][bb], hi = s_lo[q][bb + 1];
+        if (lo == hi) continue;
+        const uint4 *__restrict__ recs = srcs.ptr[q];
+        uint4 nxt = q == 0 && pre_ok && pre_at == lo ? pre : (lo + tid < hi ? recs[lo + tid] : make_uint4(0u, 0u, 0u, 0u));
+        if (q == 0) pre_ok = false;
         for (uint64_t base = lo; base < hi; base += NT) {
           const uint4 r = nxt;
           const bool in = base + tid < hi;
@@ -523,6 +546,7 @@ __global__ __launch_bounds__(kSkmThreads) void k_s1_skm(const uint4 *__restrict_
             seen = (uint32_t)__builtin_amdgcn_readfirstlane((int)seen);
           }
         }
+        }  // (sources)
         __syncthreads();  // the table is complete
         const bool bad = s_bad2[rp] != 0 || s_nclaimed2[rp] > a.max_fill;
         if (tid == 0) {  // (the other parity: last read behind the first barrier of the round before this one)
@@ -549,19 +573,19 @@ __global__ __launch_bounds__(kSkmThreads) void k_s1_skm(const uint4 *__restrict_
           done = nsub == 0 && nrj == 1u;
         }
         if (give_up && tid == 0) atomicOr(a.err, 1u);
-        {  // the first trip of what comes next — this bin again, or the next bin of the batch that holds records — is requested here
-          uint64_t nlo = lo, nhi = hi;
+        {  // the first trip of what comes next — this bin again, or the next bin of the batch that holds records — is requested here (first source)
+          uint64_t nlo = lo0, nhi = hi0;
           if (done) {
             nlo = nhi = 0;
             for (int nb = bb + 1; nb < kSkmBatch; ++nb)
-              if (s_lo[nb] != s_lo[nb + 1]) {
-                nlo = s_lo[nb];
-                nhi = s_lo[nb + 1];
+              if (s_lo[0][nb] != s_lo[0][nb + 1]) {
+                nlo = s_lo[0][nb];
+                nhi = s_lo[0][nb + 1];
                 break;
               }
           }
           if (nlo != nhi) {
-            pre = nlo + tid < nhi ? recs[nlo + tid] : make_uint4(0u, 0u, 0u, 0u);
+            pre = nlo + tid < nhi ? srcs.ptr[0][nlo + tid] : make_uint4(0u, 0u, 0u, 0u);
             pre_at = nlo;
             pre_ok = true;
           }
@@ -584,7 +608,7 @@ __global__ __launch_bounds__(kSkmThreads) void k_s1_skm(const uint4 *__restrict_
           keys[sl] = kEmpty;
           cnts[sl] = 0;
         }
-        uint32_t want_bits = 0;
+        uint32_t want_bits = 0, mark_bits = 0;
 #pragma unroll
         for (int it = 0; it < W; ++it) {
           if (wk[it] != kEmpty && !bad) {
@@ -592,8 +616,30 @@ __global__ __launch_bounds__(kSkmThreads) void k_s1_skm(const uint4 *__restrict_
             const uint32_t hb = cnt > MHX_MAX_MUL ? (uint32_t)MHX_MAX_MUL : cnt;  // :430-436
             if (hb < kSegHist) atomicAdd(&lhist[hb], 1u);
             else atomicAdd(&a.hist[hb], 1ull);
-            if (cnt < m) a.solid_bytes[((uint64_t)wt[it] << 32) | wp[it]] = 1;  // count 1 < m <= 2: the key's only window is a non-solid occurrence
+            if (cnt < m) mark_bits |= 1u << it;  // count 1 < m <= 2: the key's only window is a non-solid occurrence
             else if (AGG) want_bits |= 1u << it;
+          }
+        }
+        if (!marks_out) {  // (uniform)
+#pragma unroll
+          for (int it = 0; it < W; ++it)
+            if ((mark_bits >> it) & 1u) a.solid_bytes[((uint64_t)wt[it] << 32) | wp[it]] = 1;
+        } else {  // several GPUs: the mark is the global position itself, appended to this workgroup's region
+          const uint32_t n_mk = (uint32_t)__builtin_popcount(mark_bits);
+          const uint32_t incl = wave_inclusive_sum(n_mk);
+          const uint32_t tot = __shfl(incl, kWave - 1, kWave);
+          if (tot) {
+            uint32_t mbase = 0;
+            if (lane == 0) mbase = atomicAdd(&s_mark_cur, tot);
+            mbase = __shfl(mbase, 0, kWave);
+            uint32_t at = mbase + incl - n_mk;
+#pragma unroll
+            for (int it = 0; it < W; ++it)
+              if ((mark_bits >> it) & 1u) {
+                if (at < a.marks_cap) marks_out[at] = ((unsigned long long)wt[it] << 32) | wp[it];
+                else atomicOr(a.err, 2u);
+                ++at;
+              }
           }
         }
         if constexpr (AGG) {
@@ -640,6 +686,7 @@ __global__ __launch_bounds__(kSkmThreads) void k_s1_skm(const uint4 *__restrict_
   for (int i = tid; i < kSegHist; i += NT)
     if (lhist[i]) atomicAdd(&a.hist[i], (unsigned long long)lhist[i]);
   if (AGG && tid == 0) a.agg_counts[blockIdx.x] = s_agg_cur < a.agg_cap ? s_agg_cur : a.agg_cap;
+  if (marks_out && tid == 0) a.marks_counts[blockIdx.x] = s_mark_cur < a.marks_cap ? s_mark_cur : a.marks_cap;
 }
 
 // ---- host ----
@@ -657,6 +704,17 @@ bool s1_skm_applies(const mhx_ctx *c, uint32_t k, uint32_t m, int want_mercy) {
   return knob >= 2 || n_win >= (uint64_t)c->opt("s1_skm_min_windows", 1 << 22);
 }
 
+// several GPUs (comm.hip dist_s1_skm): this rank's say — the same shape with a global layout; at most kSkmSrcMax ranks (one source per sender)
+bool s1_skm_dist_applies(const mhx_ctx *c, uint32_t k, uint32_t m) {
+  const SeqSet &s = c->seqs;
+  if (!c->opt("s1_skm", 1) || !c->opt("dist_skm", 1) || !c->global_bases || c->n_parts > kSkmSrcMax || c->filter_on || c->accumulate) return false;
+  if (k < 19 || k > 22 || m < 1 || m > 2 || (c->global_bases >> 36)) return false;
+  if (!s.n_seqs || s.max_len < k + 1) return false;
+  if (!s.fixed_len && (double)s.n_bases * 100.0 < (double)c->opt("s1_var_min_fill", 50) * (double)s.n_seqs * s.max_len) return false;
+  if (getenv("MHX_S1_MARK") || !c->opt("dist_sparse_marks", 1)) return false;
+  return s1_skm_passes(c, k) == 1;
+}
+
 // make the records, order them by bin, find the bins.  -> false: gave up (more records than the array was sized for, or a bin that one
 // workgroup should not stream alone: low-complexity reads) — nothing published
 int s1_skm_passes(const mhx_ctx *c, uint32_t k) {
@@ -670,7 +728,7 @@ int s1_skm_passes(const mhx_ctx *c, uint32_t k) {
   return (int)std::min(64.0, std::max(1.0, std::ceil(need / budget)));
 }
 
-bool s1_skm_front(mhx_ctx *c, uint32_t k, SkmFront *f, int pass, int n_passes) {
+bool s1_skm_front(mhx_ctx *c, uint32_t k, SkmFront *f, int pass, int n_passes, int bin_bits_agreed) {
   SeqSet &s = c->seqs;
   hipStream_t st = c->stream;
   const bool var = s.fixed_len == 0;
@@ -686,6 +744,7 @@ bool s1_skm_front(mhx_ctx *c, uint32_t k, SkmFront *f, int pass, int n_passes) {
   int bin_bits = kSkmMinBinBits;
   while (bin_bits < kSkmMaxBinBits && (double)n_win * 0.29 / (double)(1ull << bin_bits) > 8192.0) ++bin_bits;
   if (const long long fb = c->opt("s1_skm_bin_bits", 0)) bin_bits = (int)std::min<long long>(kSkmMaxBinBits, std::max<long long>(8, fb));
+  if (bin_bits_agreed > 0) bin_bits = bin_bits_agreed;  // (several GPUs: the ranks made it from the size of the whole job)
   uint4 *buf_a = c->ws("items_a", cap * 16 + 64).as<uint4>();
   uint4 *buf_b = c->ws("items_b", cap * 16 + 64).as<uint4>();
   unsigned long long *cursor = c->ws("skm_cursor", 64).as<unsigned long long>();
@@ -705,10 +764,10 @@ bool s1_skm_front(mhx_ctx *c, uint32_t k, SkmFront *f, int pass, int n_passes) {
   MHX_LAUNCH(c, "s1_skm_make", (double)s.n_bases / 4 + (double)n_win * 16 / 3.5, {
     if (var)
       hipLaunchKernelGGL((k_skm_make<NT, J, true>), dim3(grid), dim3(NT), 0, st, s.words.as<uint32_t>(), s.start.as<uint64_t>(), L, bpr, n_blocks, (int)k, bin_bits, bin_lo, bin_hi,
-                         pass == 0 ? 1 : 0, buf_a, (unsigned long long)cap, cursor, err, pre_hist);
+                         pass == 0 ? 1 : 0, c->pos_base, buf_a, (unsigned long long)cap, cursor, err, pre_hist);
     else
       hipLaunchKernelGGL((k_skm_make<NT, J, false>), dim3(grid), dim3(NT), 0, st, s.words.as<uint32_t>(), s.start.as<uint64_t>(), L, bpr, n_blocks, (int)k, bin_bits, bin_lo, bin_hi,
-                         pass == 0 ? 1 : 0, buf_a, (unsigned long long)cap, cursor, err, pre_hist);
+                         pass == 0 ? 1 : 0, c->pos_base, buf_a, (unsigned long long)cap, cursor, err, pre_hist);
   });
   unsigned long long h[4] = {0, 0, 0, 0};
   MHX_HIP(hipMemcpyAsync(h, cursor, 32, hipMemcpyDeviceToHost, st));
@@ -728,13 +787,14 @@ bool s1_skm_front(mhx_ctx *c, uint32_t k, SkmFront *f, int pass, int n_passes) {
   uint32_t h_max = 0;
   MHX_HIP(hipMemcpyAsync(&h_max, max_bin, 4, hipMemcpyDeviceToHost, st));
   MHX_HIP(hipStreamSynchronize(st));
-  f->sorted = reinterpret_cast<const uint4 *>(sorted);
+  f->n_src = 1;
+  f->src[0] = reinterpret_cast<const uint4 *>(sorted);
+  f->src_bounds[0] = bounds;
   f->spare = sorted == reinterpret_cast<uint32_t *>(buf_a) ? reinterpret_cast<uint32_t *>(buf_b) : reinterpret_cast<uint32_t *>(buf_a);
   f->spare_bytes = cap * 16;
   f->n_records = n;
   f->n_windows = n_win;
   if (pass == 0) f->n_items = var ? h[3] : s.n_seqs * (uint64_t)(L - k + 4);
-  f->bounds = bounds;
   f->n_bins = n_bins;
   f->bin_lo = bin_lo;
   f->bin_hi = bin_hi;
@@ -746,20 +806,28 @@ bool s1_skm_front(mhx_ctx *c, uint32_t k, SkmFront *f, int pass, int n_passes) {
 }
 
 void s1_skm_groups_launch(mhx_ctx *c, bool agg, unsigned grid, const SkmFront &f, uint32_t k, uint32_t m, uint8_t *solid_bytes, unsigned long long *hist,
-                          uint2 *agg_raw, uint32_t agg_cap, uint32_t *agg_counts, uint32_t *err) {
+                          uint2 *agg_raw, uint32_t agg_cap, uint32_t *agg_counts, uint32_t *err, unsigned long long *marks_raw, uint32_t marks_cap,
+                          uint32_t *marks_counts) {
   hipStream_t st = c->stream;
   uint32_t *ticket = c->ws("s1_stream_ticket", 64).as<uint32_t>();
   MHX_HIP(hipMemsetAsync(ticket, 0, 4, st));
   const uint32_t nslot = 1u << kSkmLogSlots;
   SkmArgs a{(int)k, m, solid_bytes, hist, agg_raw, agg_cap, agg_counts, err,
             (uint32_t)std::min<long long>(std::max<long long>(c->opt("s1_stream_fill", nslot * 7 / 8), 1), nslot), (int)std::min<long long>(c->opt("s1_stream_probes", 1024), 1024),
-            f.bin_lo, f.bin_hi};
-  const bool tags = (c->seqs.n_bases >> 32) != 0 || c->opt("s1_skm_tags", 0) != 0;
+            f.bin_lo, f.bin_hi, marks_raw, marks_cap, marks_counts};
+  SkmSrcs srcs{};
+  srcs.n = f.n_src;
+  for (int q = 0; q < f.n_src; ++q) {
+    srcs.ptr[q] = f.src[q];
+    srcs.bounds[q] = f.src_bounds[q];
+  }
+  const uint64_t n_bits = c->global_bases ? c->global_bases : c->seqs.n_bases;
+  const bool tags = (n_bits >> 32) != 0 || c->opt("s1_skm_tags", 0) != 0;
   const bool deal = c->opt("s1_skm_deal", 1) != 0;
-#define MHX_SKM(AGGV, TAGV)                                                                                                                     \
-  do {                                                                                                                                          \
-    if (deal) hipLaunchKernelGGL((k_s1_skm<AGGV, TAGV, true>), dim3(grid), dim3(kSkmThreads), 0, st, f.sorted, f.bounds, a, ticket);            \
-    else hipLaunchKernelGGL((k_s1_skm<AGGV, TAGV, false>), dim3(grid), dim3(kSkmThreads), 0, st, f.sorted, f.bounds, a, ticket);                \
+#define MHX_SKM(AGGV, TAGV)                                                                                                  \
+  do {                                                                                                                       \
+    if (deal) hipLaunchKernelGGL((k_s1_skm<AGGV, TAGV, true>), dim3(grid), dim3(kSkmThreads), 0, st, srcs, a, ticket);        \
+    else hipLaunchKernelGGL((k_s1_skm<AGGV, TAGV, false>), dim3(grid), dim3(kSkmThreads), 0, st, srcs, a, ticket);            \
   } while (0)
   MHX_LAUNCH(c, "s1_skm_groups", (double)f.n_records * 16, {
     if (agg && tags) MHX_SKM(true, true);
@@ -768,6 +836,12 @@ void s1_skm_groups_launch(mhx_ctx *c, bool agg, unsigned grid, const SkmFront &f
     else MHX_SKM(false, false);
   });
 #undef MHX_SKM
+}
+
+// several GPUs: where the bins start in an array of records ordered by bin (a source of the owner's group-by)
+void s1_skm_bounds_of(mhx_ctx *c, const uint4 *recs, uint64_t n, uint32_t n_bins, uint64_t *bounds) {
+  uint32_t *scratch = c->ws("skm_cursor", 64).as<uint32_t>() + 8;
+  hipLaunchKernelGGL(k_skm_bounds, dim3((n_bins + 1 + 255) / 256), dim3(256), 0, c->stream, recs, n, n_bins, bounds, scratch);
 }
 
 }  // namespace mhx

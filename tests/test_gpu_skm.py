@@ -155,3 +155,52 @@ def test_mercy_takes_the_sorted_records(engine):
         assert np.array_equal(solid, w1["is_solid"][: solid.size])
     finally:
         engine.set_option("s1_skm", 1)
+
+
+@pytest.mark.parametrize("world,k,opts", [(2, 21, {}), (3, 22, {"s1_stream_fill": 40}), (3, 21, {"s1_skm_bin_bits": 18}), (2, 19, {"s1_skm_deal": 0}),
+                                          (2, 21, {"s1_skm_tags": 1}), (3, 20, {"s1_stream_fill": 3, "s1_skm_bin_bits": 9})])
+def test_several_ranks_exchange_records_by_bin(world, k, opts):
+    """comm.hip dist_s1_skm: every rank makes the records of its reads (global positions), orders them by bin, sends each owner of a
+    range of bins its slice; the owner's group-by reads a bin as one sub-range per sender; marks back to the read owners as lists, the
+    aggregated items on to stage 2's exchange.  Ranks as threads on one device; against the oracle on the union of the reads."""
+    from test_gpu_comm import run_ranks, load_reads, all_reads, sdbg_of, check_sdbg as check_ranks
+
+    def body(r, e, cm):
+        cm.setup(0, k, 2)
+        cm.read2sdbg(k, 2)
+        r1, r2, _ = cm.read2sdbg(k, 2)  # buffers are reused: same answer the second time
+        return sdbg_of(e) + (e.fetch(lib.BUF_MUL_HIST, np.int64), int(r1.n_solid), e.last_s1_plan(), int(r1.n_items), cm.bytes_sent())
+
+    outs = run_ranks(world, load_reads, body, dict(opts, s1_skm=2, s1_skm_max_bin=1 << 30, s1_var_min_fill=5))
+    pkg = all_reads(world)
+    s1 = ob.s1(pkg, k, 2)
+    for o in outs:
+        assert o[6].startswith("super-k-mers") and "exchanged by bin" in o[6], o[6]
+    assert np.array_equal(sum(o[4] for o in outs), s1["hist"])
+    assert sum(o[5] for o in outs) == int(sum(bin(int(x)).count("1") for x in s1["is_solid"]))
+    assert sum(o[7] for o in outs) == s1["n_items"]
+    check_ranks(outs, ob.s2(pkg, k, 2, s1["is_solid"]))
+
+
+def test_several_ranks_give_the_path_up_together(engine):
+    """one rank holds low-complexity reads: its largest bin is over the limit, all ranks hear of it and take the pre-sorted exchange of
+    the prefix plan"""
+    from test_gpu_comm import run_ranks, load_fixed_reads, sdbg_of, check_sdbg as check_ranks
+    world, k = 2, 21
+    reads = [None] * world
+
+    def load_r(r, e):
+        reads[r] = load_fixed_reads(r, e)
+
+    def body(r, e, cm):
+        cm.setup(0, k, 2)
+        cm.read2sdbg(k, 2)
+        return sdbg_of(e) + (e.fetch(lib.BUF_MUL_HIST, np.int64), e.last_s1_plan())
+
+    outs = run_ranks(world, load_r, body, dict(s1_skm=2, s1_skm_max_bin=256))
+    pkg = ob.Package(reads[0] + reads[1], reverse=True)
+    s1 = ob.s1(pkg, k, 2)
+    for o in outs:
+        assert o[5].startswith("stream") and "pre-sorted exchange" in o[5], o[5]
+    assert np.array_equal(sum(o[4] for o in outs), s1["hist"])
+    check_ranks(outs, ob.s2(pkg, k, 2, s1["is_solid"]))
