@@ -143,6 +143,8 @@ int mhx_set_option(mhx_ctx *, const char *name, long long value);
  *                          s1_skm_passes (0) forces their number; s1_skm_bin_bits (0 = by density: 16..20) the bins; s1_skm_tags (0) 1: the
  *                          kernel of read sets beyond 2^32 bases on any read set (tests); s1_skm_deal (1) 0: every lane expands its own
  *                          record instead of the wavefront's windows being dealt to the lanes (measured 7 % slower)
+ *   dist_skm (1)           several GPUs: 0: stage 1 never exchanges super-k-mer records by bin (comm.hip dist_s1_skm; the pre-sorted exchange
+ *                          of 12-byte records runs); 1: where every rank serves the shape (as s1_skm, at most 8 ranks, no memory plan)
  * The CLI's memory plan (host/mhx_core.cpp plan_ranges): MHX_PLAN_BY_TIME=0 plans by space only; MHX_ALLOC_S_PER_GB=<seconds> sets the
  * hipMalloc rate the time plan assumes (tests).
  * (mhx_tuning.conf of this tree: s1_gen_blocked = 1.) */

@@ -42,6 +42,7 @@ def _worker(rank, world, port, mode, k, m, opts, q):
         r1, r2, _nm = cm.read2sdbg(k, m)
         out["hist"] = e.fetch(lib.BUF_MUL_HIST, np.int64) if m > 1 else None
         out["n_solid"] = int(r1.n_solid)
+        out["plan"] = e.last_s1_plan()
     elif mode == "count":
         cm.setup(3, k, m)
         cm.count(k, m)
@@ -79,12 +80,17 @@ def run_world(world, mode, k, m, opts=None):
     return outs
 
 
-@pytest.mark.parametrize("world,k,m,opts", [(2, 21, 2, None), (3, 21, 2, {"dist_max_items": 40000}), (2, 27, 1, None), (2, 21, 2, {"dist_presort": 0})])
+@pytest.mark.parametrize("world,k,m,opts", [(2, 21, 2, None), (3, 21, 2, {"dist_max_items": 40000}), (2, 27, 1, None), (2, 21, 2, {"dist_presort": 0}),
+                                            # round 6: super-k-mer records exchanged by bin (comm.hip dist_s1_skm), rank processes over the hosted transport
+                                            (2, 21, 2, {"s1_skm": 2, "s1_skm_max_bin": 1 << 30, "s1_var_min_fill": 5}),
+                                            (3, 22, 2, {"s1_skm": 2, "s1_skm_max_bin": 1 << 30, "s1_var_min_fill": 5, "s1_stream_fill": 40})])
 def test_read2sdbg_rank_processes(world, k, m, opts):
     import oracle_binding as ob
     from dist_inputs import reads_of
     outs = run_world(world, "read2sdbg", k, m, opts)
     pkg = ob.Package(sum((reads_of(100 + r, n_pairs=600) for r in range(world)), []), reverse=True)
+    if opts and opts.get("s1_skm") == 2:
+        assert all(o["plan"].startswith("super-k-mers") and "exchanged by bin" in o["plan"] for o in outs), [o["plan"] for o in outs]
     if m > 1:
         s1 = ob.s1(pkg, k, m)
         want = ob.s2(pkg, k, m, s1["is_solid"])

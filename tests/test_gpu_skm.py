@@ -179,6 +179,9 @@ def test_several_ranks_exchange_records_by_bin(world, k, opts):
     assert np.array_equal(sum(o[4] for o in outs), s1["hist"])
     assert sum(o[5] for o in outs) == int(sum(bin(int(x)).count("1") for x in s1["is_solid"]))
     assert sum(o[7] for o in outs) == s1["n_items"]
+    # what crossed between the ranks in the two runs — the records of stage 1, the marks back, the items of stage 2 — stays under 8 bytes
+    # per stage-1 item of the job (the pre-sorted exchange of the prefix plan moves 12-byte records alone: 12 (N - 1) / N per item)
+    assert sum(o[8] for o in outs) <= 2 * 8 * s1["n_items"], (sum(o[8] for o in outs), s1["n_items"])
     check_ranks(outs, ob.s2(pkg, k, 2, s1["is_solid"]))
 
 
