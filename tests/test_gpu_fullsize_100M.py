@@ -94,7 +94,7 @@ def test_one_gpus_share_of_the_eight_gpu_job(lib100):
         assert ent["plan"].startswith("stream"), ent["plan"]
 
 
-def test_two_ranks_of_ten_million_reads_take_the_presorted_exchange(tmp_path):
+def test_two_ranks_of_ten_million_reads_each(tmp_path):
     """the N = 2 step of the driver's weak-scaling bench: 2.66 G stage-1 items over two owners = 40 588 records per lv1 bucket,
     past the 40 000 the round-3 plan stopped at; now two passes with two sub-rounds per bucket"""
     import make_fullsize_golden as mfg
@@ -102,12 +102,18 @@ def test_two_ranks_of_ten_million_reads_take_the_presorted_exchange(tmp_path):
     mfg.gen_library(os.path.join(d, "reads"), 20000000)
     common = ["read2sdbg", "-k", "21", "-m", "2", "--host_mem", "64e9", "--num_cpu_threads", "8", "--read_lib_file", os.path.join(d, "reads")]
     logs = {}
-    for label, pre, env in (("one", [], {}), ("two", ["--gpus", "2"], {"MHX_GPU_MAP": "0,0"})):
+    # two: super-k-mer records exchanged by bin (round 6: 2^17 bins for the 2.58 G windows of the job, a third sort pass);
+    # two_prefix (MHX_DIST_SKM=0): the pre-sorted exchange of 12-byte records on the prefix plan, as before
+    for label, pre, env in (("one", [], {}), ("two", ["--gpus", "2"], {"MHX_GPU_MAP": "0,0"}),
+                            ("two_prefix", ["--gpus", "2"], {"MHX_GPU_MAP": "0,0", "MHX_DIST_SKM": "0"})):
         p = subprocess.run([gu.MHX_CORE] + pre + common + ["--output_prefix", os.path.join(d, label)], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE,
                            text=True, env=dict(os.environ, **env))
         assert p.returncode == 0, p.stderr[-2000:]
         logs[label] = p.stderr
     m = re.search(r"Stage 1 plan: (.*)", logs["two"])
-    assert m and m.group(1).startswith("stream p16 sub1 2 passes") and "pre-sorted exchange" in m.group(1), logs["two"][-1500:]
-    assert canon.digest_sdbg(os.path.join(d, "one")) == canon.digest_sdbg(os.path.join(d, "two"))
-    assert canon.digest_file(os.path.join(d, "one.counting")) == canon.digest_file(os.path.join(d, "two.counting"))
+    assert m and m.group(1).startswith("super-k-mers") and "exchanged by bin" in m.group(1), logs["two"][-1500:]
+    m = re.search(r"Stage 1 plan: (.*)", logs["two_prefix"])
+    assert m and m.group(1).startswith("stream p16 sub1 2 passes") and "pre-sorted exchange" in m.group(1), logs["two_prefix"][-1500:]
+    for label in ("two", "two_prefix"):
+        assert canon.digest_sdbg(os.path.join(d, "one")) == canon.digest_sdbg(os.path.join(d, label))
+        assert canon.digest_file(os.path.join(d, "one.counting")) == canon.digest_file(os.path.join(d, label + ".counting"))
