@@ -142,7 +142,8 @@ int mhx_set_option(mhx_ctx *, const char *name, long long value);
  *                          s1_skm_pass_gb (48): both record arrays of a pass together — larger jobs run in passes over ranges of bins,
  *                          s1_skm_passes (0) forces their number; s1_skm_bin_bits (0 = by density: 16..20) the bins; s1_skm_tags (0) 1: the
  *                          kernel of read sets beyond 2^32 bases on any read set (tests); s1_skm_deal (1) 0: every lane expands its own
- *                          record instead of the wavefront's windows being dealt to the lanes (measured 7 % slower)
+ *                          record instead of the wavefront's windows being dealt to the lanes (measured 7 % slower); s1_skm_hp (1) 0: the
+ *                          windows of one base (poly-A, poly-G) stay in the records instead of being counted beside them (one GPU)
  *   dist_skm (1)           several GPUs: 0: stage 1 never exchanges super-k-mer records by bin (comm.hip dist_s1_skm; the pre-sorted exchange
  *                          of 12-byte records runs); 1: where every rank serves the shape (as s1_skm, at most 8 ranks, no memory plan)
  * The CLI's memory plan (host/mhx_core.cpp plan_ranges): MHX_PLAN_BY_TIME=0 plans by space only; MHX_ALLOC_S_PER_GB=<seconds> sets the

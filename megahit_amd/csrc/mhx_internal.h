@@ -231,6 +231,7 @@ struct SkmFront {
   uint32_t n_bins, max_bin;
   uint32_t bin_lo, bin_hi;  // the bins of this pass / of this owner
   int bin_bits;
+  unsigned long long *hp;   // one GPU: the homopolymer windows counted beside the records ([0..1] counts, [2..3] a position each), else nullptr
 };
 bool s1_skm_applies(const mhx_ctx *c, uint32_t k, uint32_t m, int want_mercy);
 bool s1_skm_dist_applies(const mhx_ctx *c, uint32_t k, uint32_t m);
@@ -240,6 +241,8 @@ void s1_skm_bounds_of(mhx_ctx *c, const uint4 *recs, uint64_t n, uint32_t n_bins
 void s1_skm_groups_launch(mhx_ctx *c, bool agg, unsigned grid, const SkmFront &f, uint32_t k, uint32_t m, uint8_t *solid_bytes, unsigned long long *hist,
                           uint2 *agg_raw, uint32_t agg_cap, uint32_t *agg_counts, uint32_t *err, unsigned long long *marks_raw, uint32_t marks_cap,
                           uint32_t *marks_counts);
+void s1_skm_hp_publish(mhx_ctx *c, const SkmFront &f, uint32_t k, uint32_t m, uint8_t *solid_bytes, unsigned long long *hist, uint2 *agg_items,
+                       uint64_t *agg_cursor, bool agg);
 // the owner's half on several GPUs (s1.hip): group-by over the received sources, marks as a list, aggregated items.  -> false: a region overflowed
 bool s1_skm_owner(mhx_ctx *c, uint32_t k, uint32_t m, const SkmFront &f, mhx_s1_result *out);
 

@@ -804,6 +804,13 @@ struct S1Stage {
     }
     return true;
   }
+  // the keys of the homopolymer windows, which k_skm_make counted beside the records: behind the last pass
+  void publish_skm_hp(const SkmFront &f) {
+    if (!f.hp) return;
+    uint2 *dense = nullptr;
+    if (agg) dense = grow_preserving(c, c->work["s2_agg_items"], (agg_prev + 4) * 8 + 64, agg_prev * 8).as<uint2>();  // (room for two keys' items)
+    s1_skm_hp_publish(c, f, k, m, solid_bytes, hist, dense, agg_cursor, agg);
+  }
   void group_classic() {
     agg_prepare_classic();
     ensure_byte_map();
@@ -1215,6 +1222,7 @@ static bool s1_skm_try(mhx_ctx *c, uint32_t k, uint32_t m, mhx_s1_result *out, s
     n_records += f.n_records;
     max_bin = std::max(max_bin, f.max_bin);
   }
+  stage.publish_skm_hp(f);
   stage.n_items = f.n_items;  // what the reference sorts (read_to_sdbg_s1.cpp:344-363)
   stage.mark_mode_used = 1;
   char txt[320];

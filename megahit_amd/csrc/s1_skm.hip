@@ -48,8 +48,8 @@ __device__ __forceinline__ uint32_t skm_bin_of(uint32_t minh) {  // (the minimum
 // (as the padded item slots of S1GenVarT); a block beyond the read's last window makes nothing.
 template <int NT, int J, bool VAR>
 __global__ __launch_bounds__(NT) void k_skm_make(const uint32_t *__restrict__ seq, const uint64_t *__restrict__ start, uint32_t L, uint32_t bpr, uint64_t n_blocks,
-                                                 int k, int bin_bits, uint32_t bin_lo, uint32_t bin_hi, int count_items, uint64_t pos_base, uint4 *__restrict__ out,
-                                                 unsigned long long cap,
+                                                 int k, int bin_bits, uint32_t bin_lo, uint32_t bin_hi, int count_items, uint64_t pos_base,
+                                                 unsigned long long *__restrict__ hp, uint4 *__restrict__ out, unsigned long long cap,
                                                  unsigned long long *__restrict__ cursor, uint32_t *__restrict__ err, unsigned long long *__restrict__ digit_hist) {
   __shared__ uint32_t sm_scan[NT / kWave + 1];
   __shared__ unsigned long long s_base;
@@ -64,6 +64,12 @@ __global__ __launch_bounds__(NT) void k_skm_make(const uint32_t *__restrict__ se
   const int K1 = k + 1;
   const unsigned bin_sh = 32u - (unsigned)bin_bits;
   unsigned long long items = 0;  // VAR: what the reference sorts, L - k + 4 items per read that holds an edge (read_to_sdbg_s1.cpp:344-363)
+  // HOMOPOLYMER windows — (k+1)-mers of one base: poly-A tails, the poly-G of a two-colour instrument's dark cycles — share ONE key by the
+  // million and would all sit behind one minimizer in one bin.  They never enter a record: a window of one base is counted here (hp != null,
+  // first pass only: hp[0] / hp[1] = windows of A or T / of C or G, hp[2] / hp[3] = the smallest position of one, should it be the only one)
+  // and published as the one or two keys they are by k_skm_hp_publish.
+  uint32_t hp_n[2] = {0, 0};
+  unsigned long long hp_p[2] = {~0ull, ~0ull};
   for (uint64_t it = blockIdx.x; it * (uint64_t)(NT * J) < n_blocks; it += gridDim.x) {
     uint64_t Wv[J], pos0[J];
     uint32_t smask[J], emask[J];  // per block: the windows that start a run of this pass's bins, and those that end one
@@ -119,10 +125,26 @@ __global__ __launch_bounds__(NT) void k_skm_make(const uint32_t *__restrict__ se
           for (int w = 0; w < kSkmC; ++w) lbin[j * kSkmC + w][tid] = bins[w];
           // a pass of the memory plan keeps the bins [bin_lo, bin_hi): the windows of a run share their bin, so runs stay whole
           const uint32_t n_here = min((uint32_t)kSkmC, nwin - q0);
-          uint32_t km = 0, sm = 0;
+          uint32_t km = 0, sm = 0, hm = 0;
+          if (hp) {  // (uniform) windows of one base: adjacent bases equal all along the window
+            const uint64_t dx = W ^ (W << 2);  // base i differs from base i + 1: bits 63 - 2i, 62 - 2i
+#pragma unroll
+            for (int w = 0; w < kSkmC; ++w)
+              if ((uint32_t)w < n_here && ((dx << (2 * w)) >> (64 - 2 * (K1 - 1))) == 0) hm |= 1u << w;
+            if (hm && count_items) {
+#pragma unroll
+              for (int w = 0; w < kSkmC; ++w)
+                if ((hm >> w) & 1u) {
+                  const unsigned b = (unsigned)(W >> (62 - 2 * w)) & 3u;
+                  const unsigned cls = b == 0 || b == 3 ? 0u : 1u;
+                  ++hp_n[cls];
+                  hp_p[cls] = min(hp_p[cls], pos_base + a + (uint64_t)w);
+                }
+            }
+          }
 #pragma unroll
           for (int w = 0; w < kSkmC; ++w)
-            if ((uint32_t)w < n_here && bins[w] >= bin_lo && bins[w] < bin_hi) km |= 1u << w;
+            if ((uint32_t)w < n_here && !((hm >> w) & 1u) && bins[w] >= bin_lo && bins[w] < bin_hi) km |= 1u << w;
 #pragma unroll
           for (int w = 0; w < kSkmC; ++w)
             if (((km >> w) & 1u) && (w == 0 || !((km >> (w - 1)) & 1u) || bins[w] != bins[w > 0 ? w - 1 : 0])) sm |= 1u << w;
@@ -168,9 +190,52 @@ __global__ __launch_bounds__(NT) void k_skm_make(const uint32_t *__restrict__ se
     items = wave_sum(items);
     if ((tid & (kWave - 1)) == 0 && items) atomicAdd(cursor + 3, items);
   }
+  if (hp && count_items) {
+#pragma unroll
+    for (int x = 0; x < 2; ++x) {
+      const uint32_t n_w = wave_sum(hp_n[x]);
+      if (n_w) {  // (uniform per wavefront)
+        unsigned long long pmin = hp_p[x];
+#pragma unroll
+        for (int d = kWave / 2; d > 0; d >>= 1) pmin = min(pmin, (unsigned long long)__shfl_xor((long long)pmin, d, kWave));
+        if ((tid & (kWave - 1)) == 0) {
+          atomicAdd(hp + x, (unsigned long long)n_w);
+          atomicMin(hp + 2 + x, pmin);
+        }
+      }
+    }
+  }
   __syncthreads();
   for (int i = tid; i < 768; i += NT)
     if (dh[i >> 8][i & 255]) atomicAdd(&digit_hist[i], (unsigned long long)dh[i >> 8][i & 255]);
+}
+
+// the one or two keys the homopolymer windows are (A...A with T...T, C...C with G...G): histogram, the mark of a key seen once, the
+// aggregated stage-2 items of a solid one, behind the items of the group-by — as the walk over the table does for every other key
+__global__ void k_skm_hp_publish(const unsigned long long *__restrict__ hp, int k, uint32_t m, uint8_t *__restrict__ solid_bytes,
+                                 unsigned long long *__restrict__ hist, uint2 *__restrict__ agg_items, uint64_t *__restrict__ agg_cursor, int agg) {
+  if (threadIdx.x || blockIdx.x) return;
+  for (int x = 0; x < 2; ++x) {
+    const unsigned long long cnt = hp[x];
+    if (!cnt) continue;
+    const unsigned long long hb = cnt > MHX_MAX_MUL ? (unsigned long long)MHX_MAX_MUL : cnt;
+    hist[hb] += 1;  // :430-436
+    if (cnt < m) {
+      solid_bytes[hp[2 + x]] = 1;  // its only window is a non-solid occurrence
+    } else if (agg) {
+      const uint64_t e0 = x == 0 ? 0ull : 0x5555555555555555ull;  // A...A / C...C, MSB first; the other strand: T...T / G...G
+      const uint64_t keep = ~0ull << (64 - 2 * (k + 1));
+      const uint64_t xs[2] = {e0 & keep, ~e0 & keep};
+      const uint64_t mask_k = ~0ull << (64 - 2 * k);
+      uint64_t at = *agg_cursor;
+      for (int y = 0; y < 2; ++y) {
+        const uint64_t v = xs[y];
+        const uint64_t f = ((v << 2) & mask_k) | (1ull << 19) | ((v >> 62) << 16) | hb;
+        agg_items[at++] = make_uint2((uint32_t)(f >> 32), (uint32_t)f);
+      }
+      *agg_cursor = at;
+    }
+  }
 }
 
 // (Natural super-k-mers — runs cut at eight windows from their OWN start, the windows' minimizer hashes exchanged between the threads of a
@@ -761,20 +826,54 @@ bool s1_skm_front(mhx_ctx *c, uint32_t k, SkmFront *f, int pass, int n_passes, i
   const unsigned grid = (unsigned)std::min<uint64_t>(div_ceil(n_blocks, (uint64_t)NT * J), cus * 8);
   const uint32_t n_bins = 1u << bin_bits;
   const uint32_t bin_lo = (uint32_t)((uint64_t)n_bins * pass / n_passes), bin_hi = (uint32_t)((uint64_t)n_bins * (pass + 1) / n_passes);
+  // homopolymer windows are counted beside the records on one GPU (several GPUs: they stay in the records; a job with many gives the path up)
+  unsigned long long *hp = nullptr;
+  if (!c->global_bases && c->opt("s1_skm_hp", 1)) {
+    hp = c->ws("skm_hp", 64).as<unsigned long long>();
+    if (pass == 0) {
+      const unsigned long long init[4] = {0ull, 0ull, ~0ull, ~0ull};
+      MHX_HIP(hipMemcpyAsync(hp, init, 32, hipMemcpyHostToDevice, st));
+      MHX_HIP(hipStreamSynchronize(st));  // (init is a stack variable)
+    }
+  }
   MHX_LAUNCH(c, "s1_skm_make", (double)s.n_bases / 4 + (double)n_win * 16 / 3.5, {
     if (var)
       hipLaunchKernelGGL((k_skm_make<NT, J, true>), dim3(grid), dim3(NT), 0, st, s.words.as<uint32_t>(), s.start.as<uint64_t>(), L, bpr, n_blocks, (int)k, bin_bits, bin_lo, bin_hi,
-                         pass == 0 ? 1 : 0, c->pos_base, buf_a, (unsigned long long)cap, cursor, err, pre_hist);
+                         pass == 0 ? 1 : 0, c->pos_base, hp, buf_a, (unsigned long long)cap, cursor, err, pre_hist);
     else
       hipLaunchKernelGGL((k_skm_make<NT, J, false>), dim3(grid), dim3(NT), 0, st, s.words.as<uint32_t>(), s.start.as<uint64_t>(), L, bpr, n_blocks, (int)k, bin_bits, bin_lo, bin_hi,
-                         pass == 0 ? 1 : 0, c->pos_base, buf_a, (unsigned long long)cap, cursor, err, pre_hist);
+                         pass == 0 ? 1 : 0, c->pos_base, hp, buf_a, (unsigned long long)cap, cursor, err, pre_hist);
   });
   unsigned long long h[4] = {0, 0, 0, 0};
+  std::vector<unsigned long long> h_dh(passes.size() * 256);
   MHX_HIP(hipMemcpyAsync(h, cursor, 32, hipMemcpyDeviceToHost, st));
+  MHX_HIP(hipMemcpyAsync(h_dh.data(), pre_hist, h_dh.size() * 8, hipMemcpyDeviceToHost, st));
   MHX_HIP(hipStreamSynchronize(st));
   f->n_records = 0;
+  f->hp = hp;
   if ((uint32_t)h[1] != 0 || h[0] > cap) return false;
   const uint64_t n = h[0];
+  {  // a bin far over the limit shows in the digit histograms already — one value of EVERY digit stands out by its records: no need to
+     // order the records to find it (low-complexity reads: 1 % of (AC)n reads put 1.7 M records behind one minimizer)
+    const uint64_t n_bins_pass = std::max<uint64_t>(1, ((1ull << bin_bits) + n_passes - 1) / n_passes);
+    const uint64_t limit = std::max<uint64_t>((uint64_t)c->opt("s1_skm_max_bin", 1 << 16), 16 * (n / n_bins_pass + 1));
+    bool all = n > 0;
+    uint64_t smallest_excess = ~0ull;
+    for (size_t p = 0; p < passes.size() && all; ++p) {
+      const uint64_t vals = 1ull << passes[p].bits;
+      uint64_t mx = 0;
+      for (uint64_t d = 0; d < vals; ++d) mx = std::max<uint64_t>(mx, h_dh[p * 256 + d]);
+      const uint64_t mean = n / std::max<uint64_t>(1, (p + 1 == passes.size() && n_passes > 1) ? std::max<uint64_t>(1, vals / n_passes) : vals);
+      const uint64_t excess = mx > mean ? mx - mean : 0;
+      smallest_excess = std::min(smallest_excess, excess);
+      all = excess >= limit + limit / 2;  // (1.5 x: the values of a digit differ by a few per cent of their mean — 256 bins each — far below the limit)
+    }
+    if (all) {
+      f->n_records = n;
+      f->max_bin = (uint32_t)std::min<uint64_t>(smallest_excess, 0xFFFFFFFFu);
+      return false;
+    }
+  }
   c->pre_hist_buf = buf_a;  // (radix_sort: no histogram read of its own)
   c->pre_hist_n = n;
   c->pre_hist_passes = (int)passes.size();
@@ -836,6 +935,14 @@ void s1_skm_groups_launch(mhx_ctx *c, bool agg, unsigned grid, const SkmFront &f
     else MHX_SKM(false, false);
   });
 #undef MHX_SKM
+}
+
+// the homopolymer keys counted by k_skm_make -> histogram, mark or aggregated items (after the last pass of the group-by)
+void s1_skm_hp_publish(mhx_ctx *c, const SkmFront &f, uint32_t k, uint32_t m, uint8_t *solid_bytes, unsigned long long *hist, uint2 *agg_items,
+                       uint64_t *agg_cursor, bool agg) {
+  if (!f.hp) return;
+  MHX_LAUNCH(c, "s1_skm_hp", 64.0, hipLaunchKernelGGL(k_skm_hp_publish, dim3(1), dim3(64), 0, c->stream, f.hp, (int)k, m, solid_bytes, hist, agg_items, agg_cursor,
+                                                       agg ? 1 : 0));
 }
 
 // several GPUs: where the bins start in an array of records ordered by bin (a source of the owner's group-by)

@@ -16,7 +16,7 @@ from test_gpu_sdbg import check_sdbg
 pytestmark = pytest.mark.gpu
 
 RESET = dict(s1_skm=1, s1_stream_fill=7168, s1_stream_probes=1024, s1_skm_max_bin=65536, s1_skm_min_windows=1 << 22, s1_skm_bin_bits=0, s1_skm_tags=0, s1_skm_cap_pct=36,
-             s1_var_min_fill=50, s1_skm_passes=0, s1_skm_deal=1)
+             s1_var_min_fill=50, s1_skm_passes=0, s1_skm_deal=1, s1_skm_hp=1)
 
 
 def run(engine, reads, k, m, opts, want_plan="super-k-mers", want_kernels=("s1_skm_make", "s1_skm_groups"), absent=("s1_groups",), why=None):
@@ -66,18 +66,54 @@ def test_a_larger_library_takes_the_path_by_itself(engine):
     run(engine, reads, 21, 2, dict(s1_skm_min_windows=1 << 20))
 
 
+def repeat_reads(n, unit, length=100):
+    return [np.tile(np.array(unit, dtype=np.uint8), length // len(unit) + 1)[:length] for _ in range(n)]
+
+
 def test_low_complexity_reads_go_to_the_prefix_plan(engine):
-    """reads of one base put every window into one bin: the records are made and ordered, the bin is found too large for one workgroup, and
-    the prefix plan (with its giant path) does the stage — the plan line says why"""
-    reads = fixed_library("pe100", seed=11) + [np.zeros(100, dtype=np.uint8) for _ in range(3000)]
+    """(AC)n reads put every window behind one minimizer: the bin is found too large for one workgroup — in the digit histograms of the
+    make kernel already when it is far over the limit, else behind the sort — and the prefix plan (with its giant path) does the stage;
+    the plan line says why"""
+    reads = fixed_library("pe100", seed=11) + repeat_reads(3000, [0, 1])
     run(engine, reads, 21, 2, dict(s1_skm=2, s1_skm_max_bin=1024), want_plan="stream", want_kernels=("s1_skm_make", "s1_groups"), absent=("s1_skm_groups",),
         why="super-k-mer records given up: a bin of")
+    run(engine, reads, 21, 2, dict(s1_skm=2, s1_skm_max_bin=25000), want_plan="stream", want_kernels=("s1_skm_make", "radix_scatter_16B", "s1_groups"),
+        absent=("s1_skm_groups",), why="super-k-mer records given up: a bin of")  # (less than 1.5 x the limit: found behind the sort)
 
 
 def test_the_same_reads_with_the_limit_lifted(engine):
-    """... and with the limit lifted one workgroup streams the poly-A bin: slow, but the same answer"""
-    reads = fixed_library("pe100", seed=11) + [np.zeros(100, dtype=np.uint8) for _ in range(3000)]
+    """... and with the limit lifted one workgroup streams the (AC)n bin: slow, but the same answer"""
+    reads = fixed_library("pe100", seed=11) + repeat_reads(3000, [0, 1])
     run(engine, reads, 21, 2, dict(s1_skm=2, s1_skm_max_bin=1 << 30))
+
+
+@pytest.mark.parametrize("case", ["polyA+polyG", "one window", "m1", "var", "passes", "two windows"])
+def test_homopolymer_windows_are_counted_beside_the_records(engine, case):
+    """(k+1)-mers of one base — poly-A tails, the poly-G of dark cycles — are ONE key by the million: they never enter a record
+    (k_skm_make counts them, k_skm_hp_publish makes the one or two keys they are), so such reads do not cost the path its bins.  A key seen
+    once gets its mark, a solid one its aggregated items; with s1_skm_hp = 0 the same library is given up"""
+    k, m, opts = 21, 2, dict(s1_skm=2, s1_skm_max_bin=1024)
+    reads = fixed_library("pe100", seed=13)
+    if case in ("polyA+polyG", "m1", "passes"):
+        reads = reads + repeat_reads(3000, [0]) + repeat_reads(700, [2]) + repeat_reads(200, [3]) + repeat_reads(90, [1])
+    if case == "m1":
+        m = 1
+    if case == "passes":
+        opts["s1_skm_passes"] = 3
+    if case in ("one window", "two windows"):  # exactly k + 1 (k + 2) bases of C inside a read: one (two) windows of one key in the whole job
+        rng = np.random.default_rng(4)
+        r = rng.integers(0, 4, size=100, dtype=np.uint8)
+        n_c = k + 1 if case == "one window" else k + 2
+        r[30:30 + n_c] = 1
+        r[29], r[30 + n_c] = 0, 3
+        reads = reads + [r]
+    if case == "var":
+        reads = make_reads("var", 21) + repeat_reads(500, [3], length=77) + repeat_reads(300, [1], length=33)
+        opts["s1_var_min_fill"] = 5
+    run(engine, reads, k, m, opts)
+    if case == "polyA+polyG":
+        run(engine, reads, k, m, dict(opts, s1_skm_hp=0), want_plan="stream", want_kernels=("s1_skm_make", "s1_groups"), absent=("s1_skm_groups",),
+            why="super-k-mer records given up: a bin of")
 
 
 @pytest.mark.parametrize("opts", [dict(s1_skm_bin_bits=20), dict(s1_skm_bin_bits=18, s1_stream_fill=40), dict(s1_skm_bin_bits=11), dict(s1_skm_tags=1), dict(s1_skm_tags=1, s1_skm_deal=0)],
@@ -114,7 +150,7 @@ def test_passes_over_ranges_of_bins(engine, kind, k, m, n_passes):
 
 def test_a_caller_that_left_the_plan_to_the_path_hears_when_it_gives_up(engine):
     """s1_skm = 3 (what host/mhx_core.cpp sets after mhx_s1_self_planned said 1): no quiet change to the prefix plan on the whole job"""
-    reads = fixed_library("pe100", seed=11) + [np.zeros(100, dtype=np.uint8) for _ in range(3000)]
+    reads = fixed_library("pe100", seed=11) + repeat_reads(3000, [0, 1])
     load(engine, ob.Package(reads, reverse=True))
     try:
         engine.set_option("s1_skm", 3)
