@@ -994,7 +994,19 @@ static bool count_run_stream(mhx_ctx *c, uint32_t k, uint32_t m, mhx_count_resul
     MHX_HIP(hipMemcpyAsync(sv_hist, hist, (MHX_MAX_MUL + 1) * 8, hipMemcpyDeviceToDevice, st));
   }
   CountStreamOut o;
-  if (!count_stream_groups(c, k, m, first, last, hist, &o, pre)) {
+  // super-k-mer records first where they serve (one GPU, no memory plan, k <= 21: s1_skm.hip); a job they give up on — low-complexity reads —
+  // goes on below from clean arrays
+  bool skm_done = false;
+  if (!pre && !acc && count_skm_applies(c, k, m)) {
+    bool touched = false;
+    skm_done = count_skm_groups(c, k, m, first, last, hist, &o, &touched);
+    if (!skm_done && touched) {
+      MHX_HIP(hipMemsetAsync(first, 0xFF, (ns ? ns : 1) * 4, st));
+      MHX_HIP(hipMemsetAsync(last, 0x00, (ns ? ns : 1) * 4, st));
+      MHX_HIP(hipMemsetAsync(hist, 0, (MHX_MAX_MUL + 1) * 8, st));
+    }
+  }
+  if (!skm_done && !count_stream_groups(c, k, m, first, last, hist, &o, pre)) {
     if (acc) {
       MHX_HIP(hipMemcpyAsync(first, sv_first, (ns ? ns : 1) * 4, hipMemcpyDeviceToDevice, st));
       MHX_HIP(hipMemcpyAsync(last, sv_last, (ns ? ns : 1) * 4, hipMemcpyDeviceToDevice, st));

@@ -236,7 +236,7 @@ struct SkmFront {
 bool s1_skm_applies(const mhx_ctx *c, uint32_t k, uint32_t m, int want_mercy);
 bool s1_skm_dist_applies(const mhx_ctx *c, uint32_t k, uint32_t m);
 int s1_skm_passes(const mhx_ctx *c, uint32_t k);
-bool s1_skm_front(mhx_ctx *c, uint32_t k, SkmFront *f, int pass, int n_passes, int bin_bits_agreed = 0);
+bool s1_skm_front(mhx_ctx *c, uint32_t k, SkmFront *f, int pass, int n_passes, int bin_bits_agreed = 0, bool for_count = false);
 void s1_skm_bounds_of(mhx_ctx *c, const uint4 *recs, uint64_t n, uint32_t n_bins, uint64_t *bounds);
 void s1_skm_groups_launch(mhx_ctx *c, bool agg, unsigned grid, const SkmFront &f, uint32_t k, uint32_t m, uint8_t *solid_bytes, unsigned long long *hist,
                           uint2 *agg_raw, uint32_t agg_cap, uint32_t *agg_counts, uint32_t *err, unsigned long long *marks_raw, uint32_t marks_cap,
@@ -312,6 +312,9 @@ struct CountStreamOut {
   uint64_t n_events;
 };
 bool count_stream_applies(const mhx_ctx *c, uint32_t k, uint32_t m);
+// `count` on super-k-mer records (s1_skm.hip): one GPU, 19 <= k <= 21, min count <= 2.  *touched: the caller's arrays may hold partial results
+bool count_skm_applies(const mhx_ctx *c, uint32_t k, uint32_t m);
+bool count_skm_groups(mhx_ctx *c, uint32_t k, uint32_t m, uint32_t *first_0_out, uint32_t *last_0_in_p1, unsigned long long *hist, CountStreamOut *o, bool *touched);
 bool count_presort_applies(const mhx_ctx *c, uint32_t k, uint32_t m);
 uint32_t *count_presort(mhx_ctx *c, uint32_t k, uint64_t *n_items, uint32_t **other, int *pbits);
 int count_process_presorted(mhx_ctx *c, uint32_t k, uint32_t m, const S1Sources &src, mhx_count_result *out);  // count.hip; -1: gave up

@@ -46,7 +46,11 @@ __device__ __forceinline__ uint32_t skm_bin_of(uint32_t minh) {  // (the minimum
 // w3 = position of the run's first base in the store, low 32 bits.
 // VAR: reads of several lengths — every read gets bpr = ceil((max_len - k) / 8) blocks, its place in the store comes from start[]
 // (as the padded item slots of S1GenVarT); a block beyond the read's last window makes nothing.
-template <int NT, int J, bool VAR>
+// COUNT: the records of `count` (KmerCounter, kmer_counter.cpp:158-381) — a window's key is the canonical (k+1)-mer and the table wants the base
+// in front of it and the base behind it: the record carries one more base either side of its run (k + windows + 2 <= 31 bases at k <= 21),
+// two flags for a run that starts at the first / ends at the last window of its read ('$' there), and its length in the first word:
+// w0 = position bits 32.. << 28 | bin << 8 | (windows - 1) << 5 | no_prev << 4 | no_next << 3.
+template <int NT, int J, bool VAR, bool COUNT = false>
 __global__ __launch_bounds__(NT) void k_skm_make(const uint32_t *__restrict__ seq, const uint64_t *__restrict__ start, uint32_t L, uint32_t bpr, uint64_t n_blocks,
                                                  int k, int bin_bits, uint32_t bin_lo, uint32_t bin_hi, int count_items, uint64_t pos_base,
                                                  unsigned long long *__restrict__ hp, uint4 *__restrict__ out, unsigned long long cap,
@@ -73,11 +77,13 @@ __global__ __launch_bounds__(NT) void k_skm_make(const uint32_t *__restrict__ se
   for (uint64_t it = blockIdx.x; it * (uint64_t)(NT * J) < n_blocks; it += gridDim.x) {
     uint64_t Wv[J], pos0[J];
     uint32_t smask[J], emask[J];  // per block: the windows that start a run of this pass's bins, and those that end one
+    uint32_t bflag[J];            // COUNT: bit 0 the block's first window is its read's first, bit 1 its last window is the read's last, bits 2.. its windows
 #pragma unroll
     for (int j = 0; j < J; ++j) {
       const uint64_t b = it * (uint64_t)(NT * J) + (uint64_t)j * NT + tid;
       smask[j] = 0;
       emask[j] = 0;
+      bflag[j] = 0;
       Wv[j] = 0;
       pos0[j] = 0;
       if (b < n_blocks) {
@@ -89,7 +95,7 @@ __global__ __launch_bounds__(NT) void k_skm_make(const uint32_t *__restrict__ se
           base = start[r];
           const uint64_t len_r = start[r + 1] - base;
           nwin = len_r >= (uint64_t)K1 ? (uint32_t)(len_r - k) : 0u;
-          if (q0 == 0 && nwin && count_items) items += nwin + 4;
+          if (q0 == 0 && nwin && count_items) items += nwin + (COUNT ? 0 : 4);  // (count: one item per window, kmer_counter.cpp:158-206)
         } else {
           base = r * L;
           nwin = L - k;
@@ -150,7 +156,13 @@ __global__ __launch_bounds__(NT) void k_skm_make(const uint32_t *__restrict__ se
             if (((km >> w) & 1u) && (w == 0 || !((km >> (w - 1)) & 1u) || bins[w] != bins[w > 0 ? w - 1 : 0])) sm |= 1u << w;
           smask[j] = sm;
           emask[j] = km & ((sm >> 1) | ~(km >> 1));  // window w ends a run: the next one starts one, or is not this pass's (bit 8 of km is clear)
-          Wv[j] = W;
+          if constexpr (COUNT) {  // the window that starts one base earlier: the base in front of the block's first window, then 31 bases
+            const uint64_t pb = a > 0 ? (uint64_t)((seq[(a - 1) >> 4] >> (30 - 2 * (unsigned)((a - 1) & 15))) & 3u) : 0ull;
+            Wv[j] = (W >> 2) | (pb << 62);
+            bflag[j] = (q0 == 0 ? 1u : 0u) | (q0 + n_here == nwin ? 2u : 0u) | (n_here << 2);
+          } else {
+            Wv[j] = W;
+          }
           pos0[j] = pos_base + a;  // (several GPUs: this rank's reads start at pos_base of the global read set)
         }
       }
@@ -178,8 +190,15 @@ __global__ __launch_bounds__(NT) void k_skm_make(const uint32_t *__restrict__ se
         const int len = re - rs + 1;
         const uint32_t run_bin = lbin[j * kSkmC + rs][tid];
         const uint64_t p = pos0[j] + (uint64_t)rs;
+        if constexpr (COUNT) {
+          const uint64_t bases = (Wv[j] << (2 * rs)) & (~0ull << (64 - 2 * (K1 + len + 1)));
+          const uint32_t n_blk = bflag[j] >> 2;
+          const uint32_t fl = ((bflag[j] & 1u) && rs == 0 ? 16u : 0u) | ((bflag[j] & 2u) && (uint32_t)(re + 1) == n_blk ? 8u : 0u);
+          out[at++] = make_uint4((run_bin << 8) | ((uint32_t)(p >> 32) << 28) | ((uint32_t)(len - 1) << 5) | fl, (uint32_t)(bases >> 32), (uint32_t)bases, (uint32_t)p);
+        } else {
         const uint64_t bases = ((Wv[j] << (2 * rs)) & (~0ull << (64 - 2 * (K1 + len - 1)))) | (uint64_t)(len - 1);
         out[at++] = make_uint4((run_bin << 8) | ((uint32_t)(p >> 32) << 28), (uint32_t)(bases >> 32), (uint32_t)bases, (uint32_t)p);
+        }
         atomicAdd(&dh[0][run_bin & 255u], 1u);
         atomicAdd(&dh[1][(run_bin >> 8) & 255u], 1u);
         if (third_digit) atomicAdd(&dh[2][run_bin >> 16], 1u);
@@ -754,6 +773,383 @@ __global__ __launch_bounds__(kSkmThreads) void k_s1_skm(SkmSrcs srcs, SkmArgs a,
   if (marks_out && tid == 0) a.marks_counts[blockIdx.x] = s_mark_cur < a.marks_cap ? s_mark_cur : a.marks_cap;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// `count` on super-k-mer records (KmerCounter::Lv2Postprocess, kmer_counter.cpp:254-381, on the records k_skm_make<.., COUNT> makes): the
+// table key is the canonical (k+1)-mer (the smaller of the window and its reverse complement, :179), the slot's third word holds, per base
+// in front and base behind — in the key's orientation — "seen once" and "seen twice" bits (min count <= 2: has_in / has_out need no more);
+// the walk over the table takes the histogram, sends a solid key's packed edge (PackEdge, :32-52) to the workgroup's region and leaves two
+// flag bits in the slot of a solid key without an in- or out-edge; a bin that has such a key is expanded once more, and the windows of the
+// flagged keys move first_0_out / last_0_in of their reads (:307-368).  One GPU; the windows are dealt to the lanes as in k_s1_skm.
+struct CountSkmArgs {
+  int k;
+  uint32_t m;
+  unsigned long long *hist, *ctr;  // ctr[4]: distinct keys
+  unsigned long long *edges_raw;   // per-workgroup regions of packed edges, filled from the front
+  uint32_t edges_cap;
+  uint32_t *edges_counts;
+  uint32_t *err;
+  uint32_t max_fill;
+  int probe_limit;
+  uint32_t bin_lo, bin_hi;
+  const uint64_t *c_start;
+  uint64_t c_n_seqs;
+  uint32_t c_fixed_len;
+  uint32_t *first_0_out, *last_0_in_p1;
+};
+
+template <bool TAGS, int G>
+__global__ __launch_bounds__(kSkmThreads) void k_count_skm(SkmSrcs srcs, CountSkmArgs a, uint32_t *__restrict__ ticket) {
+  constexpr int NT = kSkmThreads, NSLOT = 1 << kSkmLogSlots, W = NSLOT / NT;
+  constexpr unsigned long long kEmpty = ~0ull;  // never a key: the bits below the (k+1)-mer are zero
+  __shared__ unsigned long long keys[NSLOT];
+  __shared__ uint32_t cnts[NSLOT];
+  __shared__ uint32_t chw[NSLOT];  // base in front x: bit 2x seen once, 2x + 1 seen twice; base behind x: bits 8 + 2x, 9 + 2x; after the walk: flags << 30
+  __shared__ uint32_t lhist[kSegHist];
+  __shared__ unsigned long long heads[kSkmThreads / kWave][8];
+  __shared__ uint32_t s_bad, s_nclaimed, s_edge_cur, s_flagged, s_tk;
+  __shared__ uint64_t s_lo[kSkmSrcMax][kSkmBatch + 1];
+  const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = tid / kWave;
+  const uint32_t le_lo = lane >= 31 ? 0xFFFFFFFFu : (2u << lane) - 1u, le_hi = lane < 32 ? 0u : (lane == 63 ? 0xFFFFFFFFu : (2u << (lane - 32)) - 1u);
+  const int k = a.k, K1 = k + 1;
+  const uint32_t m = a.m;
+  const uint64_t kmask = ~0ull << (64 - 2 * K1);
+  const int n_src = srcs.n;
+  unsigned long long *const eout = a.edges_raw + (size_t)blockIdx.x * a.edges_cap;
+  for (int i = tid; i < NSLOT; i += NT) {
+    keys[i] = kEmpty;
+    cnts[i] = 0;
+    chw[i] = 0;
+  }
+  for (int i = tid; i < kSegHist; i += NT) lhist[i] = 0;
+  if (tid == 0) {
+    s_bad = 0;
+    s_nclaimed = 0;
+    s_edge_cur = 0;
+    s_flagged = 0;
+  }
+  __syncthreads();
+  unsigned long long n_dist_all = 0;
+
+  // One window of the trip, dealt to this lane: window g of the wavefront's records belongs to the record whose run starts at or before g
+  // (bitmap of run heads, hv) and comes over with seven shuffles.
+  struct Win {
+    bool valid, fwd;
+    unsigned long long key;
+    unsigned pv, nx;   // base in front / behind in the key's orientation (4: none)
+    uint32_t pos;      // low word of the window's position
+    uint8_t tag;
+  };
+  struct Trip {
+    uint32_t T, start, pd, hv_lo, hv_hi, bh, bl, qh, ql, meta;
+    uint8_t tag;
+  };
+  auto open_trip = [&](const uint4 &r, bool in) -> Trip {
+    Trip t;
+    const uint32_t len = in ? ((r.x >> 5) & 7u) + 1u : 0u;
+    const uint32_t incl = wave_inclusive_sum(len);
+    t.T = (uint32_t)__builtin_amdgcn_readlane((int)incl, kWave - 1);
+    t.start = incl - len;
+    if (lane < 8) heads[wv][lane] = 0ull;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (len) atomicOr(&heads[wv][t.start >> 6], 1ull << (t.start & 63u));
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const unsigned long long hv = __hip_atomic_load(&heads[wv][lane & 7], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    t.hv_lo = (uint32_t)hv;
+    t.hv_hi = (uint32_t)(hv >> 32);
+    const uint64_t rec_b = ((uint64_t)r.y << 32) | r.z;
+    const uint64_t rec_r = rc64(rec_b, 32);
+    t.bh = r.y, t.bl = r.z, t.qh = (uint32_t)(rec_r >> 32), t.ql = (uint32_t)rec_r;
+    t.pd = r.w - t.start;
+    t.meta = (r.x & 0xFFu) | (len << 8);  // flags, and the run's length for its last window
+    t.tag = TAGS ? (uint8_t)(r.x >> 28) : (uint8_t)0;
+    return t;
+  };
+  auto deal = [&](const Trip &t, int c, uint32_t &cbase_m1) -> Win {
+    Win w;
+    const uint32_t g = (uint32_t)(c * kWave) + (uint32_t)lane;
+    const uint32_t w_lo = (uint32_t)__builtin_amdgcn_readlane((int)t.hv_lo, c), w_hi = (uint32_t)__builtin_amdgcn_readlane((int)t.hv_hi, c);
+    const uint32_t o = cbase_m1 + (uint32_t)__builtin_popcount(w_lo & le_lo) + (uint32_t)__builtin_popcount(w_hi & le_hi);
+    cbase_m1 += (uint32_t)__builtin_popcount(w_lo) + (uint32_t)__builtin_popcount(w_hi);
+    const uint32_t xbh = __shfl(t.bh, (int)o, kWave), xbl = __shfl(t.bl, (int)o, kWave);
+    const uint32_t xqh = __shfl(t.qh, (int)o, kWave), xql = __shfl(t.ql, (int)o, kWave);
+    const uint32_t so = __shfl(t.start, (int)o, kWave), pdo = __shfl(t.pd, (int)o, kWave), mo = __shfl(t.meta, (int)o, kWave);
+    const uint32_t j = g - so;
+    const uint64_t B = ((uint64_t)xbh << 32) | xbl, R = ((uint64_t)xqh << 32) | xql;
+    const uint64_t x = (B << (2 * (1 + j))) & kmask;                 // the window: slots 1 + j .. j + k + 1 of the record
+    const uint64_t rcx = (R << (2 * (32 - 1 - K1 - j))) & kmask;     // its reverse complement: a sub-window of the record's
+    const unsigned pb = (unsigned)(B >> (62 - 2 * j)) & 3u, nb = (unsigned)(B >> (60 - 2 * K1 - 2 * j)) & 3u;
+    const unsigned prev = j == 0 && (mo & 16u) ? kSentinel : pb, next = j + 1 == (mo >> 8) && (mo & 8u) ? kSentinel : nb;
+    const bool strand = rcx < x;  // rev_edge.cmp(edge) < 0, kmer_counter.cpp:179
+    w.fwd = !strand;
+    w.key = strand ? rcx : x;
+    w.pv = strand ? comp_or_sentinel(next) : prev;
+    w.nx = strand ? comp_or_sentinel(prev) : next;
+    w.pos = pdo + g;
+    if constexpr (TAGS) w.tag = (uint8_t)(__shfl((uint32_t)t.tag, (int)o, kWave) + (w.pos < pdo + so ? 1u : 0u));
+    else w.tag = 0;
+    w.valid = g < t.T;
+    return w;
+  };
+  auto slot_of = [&](unsigned long long key) -> uint32_t {
+    const uint32_t klo = (uint32_t)key, khi = (uint32_t)(key >> 32);
+    return ((klo * 0x9E3779B1u) ^ (khi * 0x85EBCA6Bu)) >> (32 - kSkmLogSlots);
+  };
+  auto in_round = [&](unsigned long long key, uint32_t sub, uint32_t rj) -> bool {
+    if (!sub) return true;
+    const uint32_t klo = (uint32_t)key, khi = (uint32_t)(key >> 32);
+    return (skm_mix2((klo * 0xC2B2AE35u) ^ (khi * 0x27D4EB2Fu)) >> (32 - sub)) == rj;
+  };
+
+  for (;;) {
+    if (tid == 0) s_tk = atomicAdd(ticket, 1u);
+    __syncthreads();
+    const uint64_t bin0 = (uint64_t)a.bin_lo + (uint64_t)s_tk * kSkmBatch;
+    if (bin0 >= a.bin_hi) break;
+    if (tid < n_src * (kSkmBatch + 1)) {
+      const int q = tid / (kSkmBatch + 1), x = tid - q * (kSkmBatch + 1);
+      s_lo[q][x] = srcs.bounds[q][min(bin0 + x, (uint64_t)a.bin_hi)];
+    }
+    __syncthreads();
+    for (int bb = 0; bb < kSkmBatch; ++bb) {
+      bool any = false;
+      for (int q = 0; q < n_src; ++q) any = any || s_lo[q][bb] != s_lo[q][bb + 1];
+      if (!any) continue;
+      uint32_t sub = 0, rj = 0;
+      for (;;) {
+        uint32_t seen = 0;
+        // A: insert
+        for (int q = 0; q < n_src; ++q) {
+          const uint64_t lo = s_lo[q][bb], hi = s_lo[q][bb + 1];
+          const uint4 *__restrict__ recs = srcs.ptr[q];
+          for (uint64_t base = lo; base < hi; base += NT) {
+            const bool in = base + tid < hi;
+            const uint4 r = in ? recs[base + tid] : make_uint4(0u, 0u, 0u, 0u);
+            if (seen > a.max_fill) continue;
+            const Trip t = open_trip(r, in);
+            uint32_t claims = 0;
+            // (the slot found — the key's own, or a free one claimed: count the window and the bases either side of it)
+            auto settle = [&](unsigned long long old, unsigned long long key, uint32_t hh, unsigned pv, unsigned nx) -> bool {
+              if (old != kEmpty && old != key) return false;
+              atomicAdd(&cnts[hh], 1u);
+              if (old == kEmpty) ++claims;
+              const uint32_t add1 = (pv < 4 ? 1u << (2 * pv) : 0u) | (nx < 4 ? 1u << (8 + 2 * nx) : 0u);  // ('$' counts for nothing)
+              if (add1) {
+                const uint32_t o = atomicOr(&chw[hh], add1);
+                const uint32_t again = ((o & add1) << 1) & ~o;  // a base seen before and now again: seen twice
+                if (again) atomicOr(&chw[hh], again);
+              }
+              return true;
+            };
+            uint32_t cbase_m1 = 0xFFFFFFFFu;
+#pragma unroll
+            for (int grp = 0; grp < 8 / G; ++grp) {  // G chunks of 64 windows share one round of compare-and-swaps and one retry loop
+              if ((uint32_t)(grp * G * kWave) >= t.T) break;  // (uniform)
+              Win w[G];
+              unsigned long long old1[G];
+              uint32_t h1[G], mine = 0;
+#pragma unroll
+              for (int u = 0; u < G; ++u) {
+                w[u] = deal(t, grp * G + u, cbase_m1);
+                const bool mn = w[u].valid && in_round(w[u].key, sub, rj);
+                mine |= mn ? 1u << u : 0u;
+                h1[u] = slot_of(w[u].key);
+              }
+              if (a.probe_limit <= 0) {
+                if (mine) s_bad = 1;
+                mine = 0;
+              }
+#pragma unroll
+              for (int u = 0; u < G; ++u) {
+                old1[u] = kEmpty;
+                if ((mine >> u) & 1u) old1[u] = atomicCAS(&keys[h1[u]], kEmpty, w[u].key);
+              }
+              bool has = false;
+              unsigned long long pk = 0;
+              uint32_t ph = 0;
+              unsigned ppv = 0, pnx = 0;
+#pragma unroll
+              for (int u = 0; u < G; ++u) {
+                if ((mine >> u) & 1u) {
+                  if (!settle(old1[u], w[u].key, h1[u], w[u].pv, w[u].nx)) {
+                    uint32_t hh = (h1[u] + 1) & (NSLOT - 1);
+                    if (!has) {
+                      has = true;
+                      pk = w[u].key, ph = hh, ppv = w[u].pv, pnx = w[u].nx;
+                    } else {
+                      int n = 0;
+                      while (!settle(atomicCAS(&keys[hh], kEmpty, w[u].key), w[u].key, hh, w[u].pv, w[u].nx)) {
+                        hh = (hh + 1) & (NSLOT - 1);
+                        if (++n >= a.probe_limit) {
+                          s_bad = 1;
+                          break;
+                        }
+                      }
+                    }
+                  }
+                }
+              }
+              int turns = 0;
+              while (__ballot(has)) {
+                if (has) {
+                  if (settle(atomicCAS(&keys[ph], kEmpty, pk), pk, ph, ppv, pnx)) has = false;
+                  else ph = (ph + 1) & (NSLOT - 1);
+                }
+                if (++turns > a.probe_limit) {  // (uniform: every lane counts the same turns)
+                  if (has) s_bad = 1;
+                  break;
+                }
+              }
+            }
+            {
+              const uint32_t c = wave_sum(claims);
+              if (lane == 0 && c) atomicAdd(&s_nclaimed, c);
+              seen = __hip_atomic_load(&s_nclaimed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              seen = (uint32_t)__builtin_amdgcn_readfirstlane((int)seen);
+            }
+          }
+        }
+        __syncthreads();  // the table is complete
+        const bool bad = s_bad != 0 || s_nclaimed > a.max_fill;
+        uint32_t nsub = sub, nrj = rj;
+        bool done = false, give_up = false;
+        if (bad) {
+          if (sub >= 31) {
+            give_up = true;
+            done = true;
+          } else {
+            nsub = sub + 1;
+            nrj = rj << 1;
+          }
+        } else {
+          nrj = rj + 1;
+          while (nsub > 0 && (nrj & 1u) == 0) {
+            --nsub;
+            nrj >>= 1;
+          }
+          done = nsub == 0 && nrj == 1u;
+        }
+        if (give_up && tid == 0) atomicOr(a.err, 1u);
+        // C: one walk over the table — per distinct (k+1)-mer: histogram, has_in / has_out from the seen-twice (m = 2) or seen-once (m = 1)
+        // bits, the packed edge of a solid key -> this workgroup's region; a solid key without an in- or out-edge keeps two flag bits
+        unsigned long long wk[W];
+        uint32_t wc[W], wf[W];
+#pragma unroll
+        for (int it = 0; it < W; ++it) {
+          const int sl = it * NT + tid;
+          wk[it] = keys[sl];
+          wc[it] = cnts[sl];
+          wf[it] = chw[sl];
+        }
+        const uint32_t lvl = m >= 2 ? 0xAAu : 0x55u;
+        uint32_t solid_bits = 0, n_dist = 0;
+        bool any_flag = false;
+#pragma unroll
+        for (int it = 0; it < W; ++it) {
+          uint32_t fb = 0;
+          if (wk[it] != kEmpty && !bad) {
+            ++n_dist;
+            const uint32_t cnt = wc[it];
+            const uint32_t hb = cnt > MHX_MAX_MUL ? (uint32_t)MHX_MAX_MUL : cnt;
+            if (hb < kSegHist) atomicAdd(&lhist[hb], 1u);
+            else atomicAdd(&a.hist[hb], 1ull);
+            if (cnt >= m) {
+              solid_bits |= 1u << it;
+              const bool has_in = (wf[it] & lvl) != 0, has_out = ((wf[it] >> 8) & lvl) != 0;
+              fb = (has_in ? 0u : 1u) | (has_out ? 0u : 2u);
+              any_flag = any_flag || fb != 0;
+            }
+          }
+          chw[it * NT + tid] = fb << 30;
+        }
+        n_dist_all += n_dist;
+        if (__ballot(any_flag) && lane == 0) s_flagged = 1;
+        {  // the solid keys' packed edges (PackEdge, kmer_counter.cpp:32-52: multiplicity in the low 16 bits) -> the region, from its front
+          const uint32_t n_e = (uint32_t)__builtin_popcount(solid_bits);
+          const uint32_t incl = wave_inclusive_sum(n_e);
+          const uint32_t tot = __shfl(incl, kWave - 1, kWave);
+          if (tot) {
+            uint32_t ebase = 0;
+            if (lane == 0) ebase = atomicAdd(&s_edge_cur, tot);
+            ebase = __shfl(ebase, 0, kWave);
+            if (ebase + tot > a.edges_cap) {
+              if (lane == 0) atomicOr(a.err, 1u);
+            } else {
+              uint32_t at = ebase + incl - n_e;
+#pragma unroll
+              for (int it = 0; it < W; ++it)
+                if ((solid_bits >> it) & 1u) {
+                  const uint32_t mul = wc[it] > MHX_MAX_MUL ? (uint32_t)MHX_MAX_MUL : wc[it];
+                  eout[at++] = wk[it] | mul;
+                }
+            }
+          }
+        }
+        __syncthreads();  // the flags are in the slots
+        if (s_flagged && !bad) {  // the windows of the flagged keys: first_0_out / last_0_in of their reads (kmer_counter.cpp:307-368)
+          for (int q = 0; q < n_src; ++q) {
+            const uint64_t lo = s_lo[q][bb], hi = s_lo[q][bb + 1];
+            const uint4 *__restrict__ recs = srcs.ptr[q];
+            for (uint64_t base = lo; base < hi; base += NT) {
+              const bool in = base + tid < hi;
+              const uint4 r = in ? recs[base + tid] : make_uint4(0u, 0u, 0u, 0u);
+              const Trip t = open_trip(r, in);
+              uint32_t cbase_m1 = 0xFFFFFFFFu;
+              for (uint32_t c = 0; c * kWave < t.T; ++c) {
+                const Win w = deal(t, (int)c, cbase_m1);
+                uint32_t f = 0;
+                if (w.valid && in_round(w.key, sub, rj)) {  // (a key of another round is not in the table)
+                  uint32_t h = slot_of(w.key);
+                  while (keys[h] != w.key) h = (h + 1) & (NSLOT - 1);
+                  f = chw[h] >> 30;
+                }
+                if (f) {
+                  // no in-edge (f & 1): strand 0 -> last_0_in = max(off), strand 1 -> first_0_out = min(off + 1); no out-edge (f & 2): the roles swap
+                  const uint64_t abs = ((uint64_t)w.tag << 32) | w.pos;
+                  const uint64_t rid = seq_of_offset(a.c_start, a.c_n_seqs, a.c_fixed_len, abs);
+                  const uint32_t off = (uint32_t)(abs - (a.c_fixed_len ? rid * a.c_fixed_len : a.c_start[rid]));
+                  if (f & 1u) {
+                    if (w.fwd) atomicMax(&a.last_0_in_p1[rid], off + 1);
+                    else atomicMin(&a.first_0_out[rid], off + 1);
+                  }
+                  if (f & 2u) {
+                    if (w.fwd) atomicMin(&a.first_0_out[rid], off + 1);
+                    else atomicMax(&a.last_0_in_p1[rid], off + 1);
+                  }
+                }
+              }
+            }
+          }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < W; ++it) {
+          const int sl = it * NT + tid;
+          keys[sl] = kEmpty;
+          cnts[sl] = 0;
+          chw[sl] = 0;
+        }
+        if (tid == 0) {
+          s_bad = 0;
+          s_nclaimed = 0;
+          s_flagged = 0;
+        }
+        __syncthreads();
+        sub = nsub;
+        rj = nrj;
+        if (done) break;
+      }
+    }
+  }
+  n_dist_all = wave_sum(n_dist_all);
+  if (lane == 0 && n_dist_all) atomicAdd(a.ctr + 4, n_dist_all);
+  __syncthreads();
+  for (int i = tid; i < kSegHist; i += NT)
+    if (lhist[i]) atomicAdd(&a.hist[i], (unsigned long long)lhist[i]);
+  if (tid == 0) a.edges_counts[blockIdx.x] = s_edge_cur < a.edges_cap ? s_edge_cur : a.edges_cap;
+}
+
 // ---- host ----
 bool s1_skm_applies(const mhx_ctx *c, uint32_t k, uint32_t m, int want_mercy) {
   const SeqSet &s = c->seqs;
@@ -793,7 +1189,7 @@ int s1_skm_passes(const mhx_ctx *c, uint32_t k) {
   return (int)std::min(64.0, std::max(1.0, std::ceil(need / budget)));
 }
 
-bool s1_skm_front(mhx_ctx *c, uint32_t k, SkmFront *f, int pass, int n_passes, int bin_bits_agreed) {
+bool s1_skm_front(mhx_ctx *c, uint32_t k, SkmFront *f, int pass, int n_passes, int bin_bits_agreed, bool for_count) {
   SeqSet &s = c->seqs;
   hipStream_t st = c->stream;
   const bool var = s.fixed_len == 0;
@@ -828,7 +1224,7 @@ bool s1_skm_front(mhx_ctx *c, uint32_t k, SkmFront *f, int pass, int n_passes, i
   const uint32_t bin_lo = (uint32_t)((uint64_t)n_bins * pass / n_passes), bin_hi = (uint32_t)((uint64_t)n_bins * (pass + 1) / n_passes);
   // homopolymer windows are counted beside the records on one GPU (several GPUs: they stay in the records; a job with many gives the path up)
   unsigned long long *hp = nullptr;
-  if (!c->global_bases && c->opt("s1_skm_hp", 1)) {
+  if (!c->global_bases && !for_count && c->opt("s1_skm_hp", 1)) {
     hp = c->ws("skm_hp", 64).as<unsigned long long>();
     if (pass == 0) {
       const unsigned long long init[4] = {0ull, 0ull, ~0ull, ~0ull};
@@ -836,14 +1232,16 @@ bool s1_skm_front(mhx_ctx *c, uint32_t k, SkmFront *f, int pass, int n_passes, i
       MHX_HIP(hipStreamSynchronize(st));  // (init is a stack variable)
     }
   }
-  MHX_LAUNCH(c, "s1_skm_make", (double)s.n_bases / 4 + (double)n_win * 16 / 3.5, {
-    if (var)
-      hipLaunchKernelGGL((k_skm_make<NT, J, true>), dim3(grid), dim3(NT), 0, st, s.words.as<uint32_t>(), s.start.as<uint64_t>(), L, bpr, n_blocks, (int)k, bin_bits, bin_lo, bin_hi,
-                         pass == 0 ? 1 : 0, c->pos_base, hp, buf_a, (unsigned long long)cap, cursor, err, pre_hist);
-    else
-      hipLaunchKernelGGL((k_skm_make<NT, J, false>), dim3(grid), dim3(NT), 0, st, s.words.as<uint32_t>(), s.start.as<uint64_t>(), L, bpr, n_blocks, (int)k, bin_bits, bin_lo, bin_hi,
-                         pass == 0 ? 1 : 0, c->pos_base, hp, buf_a, (unsigned long long)cap, cursor, err, pre_hist);
+#define MHX_MAKE(VARV, COUNTV)                                                                                                                                   \
+  hipLaunchKernelGGL((k_skm_make<NT, J, VARV, COUNTV>), dim3(grid), dim3(NT), 0, st, s.words.as<uint32_t>(), s.start.as<uint64_t>(), L, bpr, n_blocks, (int)k, \
+                     bin_bits, bin_lo, bin_hi, pass == 0 ? 1 : 0, c->pos_base, hp, buf_a, (unsigned long long)cap, cursor, err, pre_hist)
+  MHX_LAUNCH(c, for_count ? "count_skm_make" : "s1_skm_make", (double)s.n_bases / 4 + (double)n_win * 16 / 3.5, {
+    if (var && for_count) MHX_MAKE(true, true);
+    else if (var) MHX_MAKE(true, false);
+    else if (for_count) MHX_MAKE(false, true);
+    else MHX_MAKE(false, false);
   });
+#undef MHX_MAKE
   unsigned long long h[4] = {0, 0, 0, 0};
   std::vector<unsigned long long> h_dh(passes.size() * 256);
   MHX_HIP(hipMemcpyAsync(h, cursor, 32, hipMemcpyDeviceToHost, st));
@@ -893,7 +1291,7 @@ bool s1_skm_front(mhx_ctx *c, uint32_t k, SkmFront *f, int pass, int n_passes, i
   f->spare_bytes = cap * 16;
   f->n_records = n;
   f->n_windows = n_win;
-  if (pass == 0) f->n_items = var ? h[3] : s.n_seqs * (uint64_t)(L - k + 4);
+  if (pass == 0) f->n_items = var ? h[3] : s.n_seqs * (uint64_t)(L - k + (for_count ? 0 : 4));
   f->n_bins = n_bins;
   f->bin_lo = bin_lo;
   f->bin_hi = bin_hi;
@@ -935,6 +1333,77 @@ void s1_skm_groups_launch(mhx_ctx *c, bool agg, unsigned grid, const SkmFront &f
     else MHX_SKM(false, false);
   });
 #undef MHX_SKM
+}
+
+// ---- `count` on super-k-mer records: one GPU, 19 <= k <= 21 (k + 10 bases and two flags in a record), min count <= 2, one pass ----
+bool count_skm_applies(const mhx_ctx *c, uint32_t k, uint32_t m) {
+  const SeqSet &s = c->seqs;
+  const long long knob = c->opt("count_skm", 1);
+  if (!knob || !c->opt("s1_skm", 1) || c->global_bases || c->n_parts > 1 || c->filter_on || c->accumulate || c->pos_base || c->count_edges_only) return false;
+  if (k < 19 || k > 21 || m < 1 || m > 2) return false;
+  if (!s.n_seqs || s.max_len < k + 1 || (s.n_bases >> 36)) return false;
+  if (!s.fixed_len && (double)s.n_bases * 100.0 < (double)c->opt("s1_var_min_fill", 50) * (double)s.n_seqs * s.max_len) return false;
+  if (s1_skm_passes(c, k) != 1) return false;
+  const uint64_t n_win = s.n_bases > s.n_seqs * (uint64_t)k ? s.n_bases - s.n_seqs * (uint64_t)k : 0;
+  return knob >= 2 || c->opt("s1_skm", 1) >= 2 || n_win >= (uint64_t)c->opt("s1_skm_min_windows", 1 << 22);
+}
+// -> false: gave up (record array, a bin of low-complexity reads, an edge region): the caller's arrays may hold partial results of this attempt
+bool count_skm_groups(mhx_ctx *c, uint32_t k, uint32_t m, uint32_t *first_0_out, uint32_t *last_0_in_p1, unsigned long long *hist, CountStreamOut *o, bool *touched) {
+  SeqSet &s = c->seqs;
+  hipStream_t st = c->stream;
+  *touched = false;
+  SkmFront f{};
+  c->gen_first_pass = nullptr;
+  c->pre_hist_buf = nullptr;
+  if (!s1_skm_front(c, k, &f, 0, 1, 0, true)) return false;
+  const uint64_t cus = c->n_cus > 0 ? (uint64_t)c->n_cus : 256;
+  const unsigned grid = (unsigned)std::min<uint64_t>(cus, std::max<uint64_t>(1, div_ceil((uint64_t)(f.bin_hi - f.bin_lo), (uint64_t)kSkmBatch)));
+  const uint32_t region = (uint32_t)std::min<uint64_t>(f.spare_bytes / 8 / grid, 0xFFFFFFF0u);
+  uint32_t *counts = c->ws("cs_edge_counts", (size_t)grid * 4).as<uint32_t>();
+  unsigned long long *ctr = c->ws("s1_counters", 64).as<unsigned long long>();
+  uint32_t *seg_err = c->ws("s1_seg_err", 64).as<uint32_t>();
+  uint32_t *ticket = c->ws("s1_stream_ticket", 64).as<uint32_t>();
+  MHX_HIP(hipMemsetAsync(ctr, 0, 64, st));
+  MHX_HIP(hipMemsetAsync(seg_err, 0, 4, st));
+  MHX_HIP(hipMemsetAsync(ticket, 0, 4, st));
+  const uint32_t nslot = 1u << kSkmLogSlots;
+  CountSkmArgs a{(int)k, m, hist, ctr, reinterpret_cast<unsigned long long *>(f.spare), region, counts, seg_err,
+                 (uint32_t)std::min<long long>(std::max<long long>(c->opt("s1_stream_fill", nslot * 7 / 8), 1), nslot), (int)std::min<long long>(c->opt("s1_stream_probes", 1024), 1024),
+                 f.bin_lo, f.bin_hi, s.start.as<uint64_t>(), s.n_seqs, s.fixed_len, first_0_out, last_0_in_p1};
+  SkmSrcs srcs{};
+  srcs.n = 1;
+  srcs.ptr[0] = f.src[0];
+  srcs.bounds[0] = f.src_bounds[0];
+  const bool tags = (s.n_bases >> 32) != 0 || c->opt("s1_skm_tags", 0) != 0;
+  *touched = true;
+  const bool g2 = c->opt("count_skm_group", 2) == 2;  // (four chunks per round of compare-and-swaps spill registers here: measured 13.6 against 13.1 ms)
+  MHX_LAUNCH(c, "count_skm_groups", (double)f.n_records * 16, {
+    if (tags && g2) hipLaunchKernelGGL((k_count_skm<true, 2>), dim3(grid), dim3(kSkmThreads), 0, st, srcs, a, ticket);
+    else if (tags) hipLaunchKernelGGL((k_count_skm<true, 4>), dim3(grid), dim3(kSkmThreads), 0, st, srcs, a, ticket);
+    else if (g2) hipLaunchKernelGGL((k_count_skm<false, 2>), dim3(grid), dim3(kSkmThreads), 0, st, srcs, a, ticket);
+    else hipLaunchKernelGGL((k_count_skm<false, 4>), dim3(grid), dim3(kSkmThreads), 0, st, srcs, a, ticket);
+  });
+  uint32_t e = 0;
+  unsigned long long h_ctr[8] = {0};
+  MHX_HIP(hipMemcpyAsync(&e, seg_err, 4, hipMemcpyDeviceToHost, st));
+  MHX_HIP(hipMemcpyAsync(h_ctr, ctr, 64, hipMemcpyDeviceToHost, st));
+  MHX_HIP(hipStreamSynchronize(st));
+  if (e) return false;
+  o->grid = grid;
+  o->cap = region;
+  o->counts = counts;
+  o->spare = f.spare;
+  o->sorted = nullptr;
+  o->n_items = f.n_items;
+  o->n_distinct = h_ctr[4];
+  o->events = nullptr;
+  o->n_events = 0;
+  char txt[256];
+  snprintf(txt, sizeof txt, "super-k-mers m%u, 2^%d bins (%llu records for %llu windows: %.2f per record; largest bin %u)%s", k + 1 - 9, f.bin_bits,
+           (unsigned long long)f.n_records, (unsigned long long)f.n_windows, f.n_records ? (double)f.n_windows / (double)f.n_records : 0.0, f.max_bin,
+           s.fixed_len ? "" : " [reads of several lengths]");
+  o->plan = txt;
+  return true;
 }
 
 // the homopolymer keys counted by k_skm_make -> histogram, mark or aggregated items (after the last pass of the group-by)

@@ -243,3 +243,67 @@ def test_several_ranks_give_the_path_up_together(engine):
         assert o[5].startswith("stream") and "pre-sorted exchange" in o[5], o[5]
     assert np.array_equal(sum(o[4] for o in outs), s1["hist"])
     check_ranks(outs, ob.s2(pkg, k, 2, s1["is_solid"]))
+
+
+# ---- `count` on super-k-mer records (k_skm_make<.., COUNT>, k_count_skm): against the oracle's KmerCounter (kmer_counter.cpp:158-414) ----
+def run_count(engine, reads, k, m, opts, want_plan="count: super-k-mers", want_kernels=("count_skm_make", "count_skm_groups"), absent=("count_groups",)):
+    pkg = ob.Package(reads, reverse=True)
+    want = ob.count(pkg, k, m)
+    load(engine, pkg)
+    try:
+        for n, v in opts.items():
+            engine.set_option(n, v)
+        engine.profile(True)
+        engine.profile_reset()
+        r = engine.count(k, m)
+        stats = engine.profile_get()
+        engine.profile(False)
+        plan = engine.last_s1_plan()
+        assert plan.startswith(want_plan), plan
+        for kn in want_kernels:
+            assert kn in stats, sorted(stats)
+        for kn in absent:
+            assert kn not in stats, sorted(stats)
+        assert r.n_items == want["n_items"] and r.words_per_edge == want["wpe"]
+        edges = engine.fetch(lib.BUF_EDGES, np.uint32).reshape(-1, r.words_per_edge)
+        assert edges.shape == want["edges"].shape and np.array_equal(edges, want["edges"])
+        assert np.array_equal(engine.fetch(lib.BUF_BUCKET_COUNT, np.uint64), want["bucket_count"])
+        assert np.array_equal(engine.fetch(lib.BUF_MUL_HIST, np.int64), want["hist"])
+        assert np.array_equal(engine.fetch(lib.BUF_FIRST_0_OUT, np.uint32), want["first_0_out"])
+        assert np.array_equal(engine.fetch(lib.BUF_LAST_0_IN, np.uint32), want["last_0_in"])
+    finally:
+        engine.profile(False)
+        for n, v in dict(RESET, count_skm=1, count_skm_group=2).items():
+            engine.set_option(n, v)
+
+
+@pytest.mark.parametrize("opts", [dict(), dict(s1_stream_fill=40), dict(s1_stream_fill=3), dict(s1_stream_probes=2), dict(s1_skm_bin_bits=18), dict(s1_skm_bin_bits=10),
+                                  dict(s1_skm_tags=1), dict(count_skm_group=4)], ids=lambda o: ",".join("%s=%d" % kv for kv in o.items()) or "default")
+@pytest.mark.parametrize("kind,k,m", [("pe100", 21, 2), ("repeats100", 21, 2), ("short30", 21, 2), ("tiny60", 20, 2), ("pe100", 19, 1), ("repeats100", 21, 1)])
+def test_count_on_super_kmer_records(engine, kind, k, m, opts):
+    run_count(engine, fixed_library(kind, seed=k * 11 + m), k, m, dict(opts, s1_skm=2, s1_skm_max_bin=1 << 30))
+
+
+@pytest.mark.parametrize("kind,k,m", [("var", 21, 2), ("var", 19, 1), ("lowcomplex", 21, 2), ("fixed", 20, 2)])
+def test_count_of_reads_of_several_lengths(engine, kind, k, m):
+    run_count(engine, make_reads(kind, 17), k, m, dict(s1_skm=2, s1_skm_max_bin=1 << 30, s1_var_min_fill=5, s1_skm_cap_pct=300))
+
+
+@pytest.mark.parametrize("how", ["k22", "m3", "off", "repeats", "polyA"])
+def test_count_shapes_outside_the_path(engine, how):
+    """k = 22 (no room for the two flanking bases), min count 3, the knob, and low-complexity reads — poly-A too: `count` keeps the one-base
+    windows in its records (their in / out characters matter) — take the prefix plan"""
+    k, m, opts = 21, 2, dict(s1_skm=2)
+    reads = fixed_library("pe100", seed=5)
+    if how == "k22":
+        k = 22
+    if how == "m3":
+        m = 3
+    if how == "off":
+        opts["count_skm"] = 0
+    if how == "repeats":
+        reads, opts = reads + repeat_reads(3000, [0, 1]), dict(opts, s1_skm_max_bin=1024)
+    if how == "polyA":
+        reads, opts = reads + repeat_reads(3000, [0]), dict(opts, s1_skm_max_bin=1024)
+    low = how in ("repeats", "polyA")
+    run_count(engine, reads, k, m, opts, want_plan="count: stream", want_kernels=("count_groups",) + (("count_skm_make",) if low else ()), absent=("count_skm_groups",))
