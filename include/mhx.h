@@ -259,6 +259,10 @@ int mhx_read2sdbg_s1(mhx_ctx *, uint32_t k, uint32_t min_count, int want_mercy, 
  * prefix plan on the whole job) when the input turns out not to be served, low-complexity reads for one, and the caller plans as before
  * with s1_skm = 0.  host/mhx_core.cpp read2sdbg does exactly that. */
 int mhx_s1_self_planned(mhx_ctx *, uint32_t k, uint32_t min_count, int want_mercy);
+/* The same question for mhx_count (count on super-k-mer records: one GPU, 19 <= k <= 21, min count <= 2): on 1 the caller sets option
+ * count_skm = 3 and calls mhx_count once without a bucket filter; a job the path gives up on fails that call, and the caller plans lv1
+ * bucket ranges as before with count_skm = 0. */
+int mhx_count_self_planned(mhx_ctx *, uint32_t k, uint32_t min_count);
 
 /* mercy block of Read2SdbgS2::Initialize (read_to_sdbg_s2.cpp:122-266): consumes MERCY_CAND,
  * sets extra IS_SOLID bits on the device copy; *num_mercy receives "Number mercy". */

@@ -783,6 +783,14 @@ int mhx_s1_self_planned(mhx_ctx *c, uint32_t k, uint32_t min_count, int want_mer
     return 0;
   }
 }
+int mhx_count_self_planned(mhx_ctx *c, uint32_t k, uint32_t min_count) {
+  if (!c) return 0;
+  try {
+    return mhx::count_skm_applies(c, k, min_count) ? 1 : 0;
+  } catch (...) {
+    return 0;
+  }
+}
 int mhx_read2sdbg_add_mercy(mhx_ctx *c, uint32_t k, uint64_t *num_mercy) {
   MHX_TRY({
     MHX_HIP(hipSetDevice(c->device));

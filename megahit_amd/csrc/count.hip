@@ -997,13 +997,39 @@ static bool count_run_stream(mhx_ctx *c, uint32_t k, uint32_t m, mhx_count_resul
   // super-k-mer records first where they serve (one GPU, no memory plan, k <= 21: s1_skm.hip); a job they give up on — low-complexity reads —
   // goes on below from clean arrays
   bool skm_done = false;
+  uint64_t skm_edges = 0;  // the passes' edges, packed behind each other in ws "cs_edges_a"
   if (!pre && !acc && count_skm_applies(c, k, m)) {
     bool touched = false;
-    skm_done = count_skm_groups(c, k, m, first, last, hist, &o, &touched);
-    if (!skm_done && touched) {
-      MHX_HIP(hipMemsetAsync(first, 0xFF, (ns ? ns : 1) * 4, st));
-      MHX_HIP(hipMemsetAsync(last, 0x00, (ns ? ns : 1) * 4, st));
-      MHX_HIP(hipMemsetAsync(hist, 0, (MHX_MAX_MUL + 1) * 8, st));
+    const int n_passes = s1_skm_passes(c, k);
+    uint64_t n_dist = 0;
+    skm_done = true;
+    for (int p = 0; p < n_passes && skm_done; ++p) {
+      skm_done = count_skm_groups(c, k, m, first, last, hist, &o, &touched, p, n_passes);
+      if (!skm_done) break;
+      std::vector<uint32_t> hc(o.grid);
+      MHX_HIP(hipMemcpyAsync(hc.data(), o.counts, (size_t)o.grid * 4, hipMemcpyDeviceToHost, st));
+      MHX_HIP(hipStreamSynchronize(st));
+      uint64_t tot = 0;
+      for (uint32_t v : hc) tot += v;
+      // (sized for all passes after the first: the bins fill evenly)
+      const uint64_t expect = (uint64_t)((double)(skm_edges + tot) * (double)n_passes / (double)(p + 1) * 1.05);
+      unsigned long long *dense = grow_preserving(c, c->work["cs_edges_a"], (std::max(skm_edges + tot, expect) + 1) * 8, skm_edges * 8).as<unsigned long long>();
+      if (tot)
+        MHX_LAUNCH(c, "edges_compact", (double)tot * 16,
+                   hipLaunchKernelGGL(k_edges_compact, dim3(o.grid, 4), dim3(256), 0, st, reinterpret_cast<const unsigned long long *>(o.spare), o.cap, o.counts,
+                                      dense + skm_edges));
+      skm_edges += tot;
+      n_dist += o.n_distinct;
+    }
+    o.n_distinct = n_dist;
+    if (!skm_done) {
+      // count_skm = 3: a caller that left the memory plan to this path (mhx_count_self_planned) hears that it did not serve
+      if (c->opt("count_skm", 1) == 3) throw Error("count: super-k-mer records given up (low-complexity reads, or more records than the arrays hold)");
+      if (touched) {
+        MHX_HIP(hipMemsetAsync(first, 0xFF, (ns ? ns : 1) * 4, st));
+        MHX_HIP(hipMemsetAsync(last, 0x00, (ns ? ns : 1) * 4, st));
+        MHX_HIP(hipMemsetAsync(hist, 0, (MHX_MAX_MUL + 1) * 8, st));
+      }
     }
   }
   if (!skm_done && !count_stream_groups(c, k, m, first, last, hist, &o, pre)) {
@@ -1014,11 +1040,13 @@ static bool count_run_stream(mhx_ctx *c, uint32_t k, uint32_t m, mhx_count_resul
     }
     return false;
   }
-  std::vector<uint32_t> h_counts(o.grid);
-  MHX_HIP(hipMemcpyAsync(h_counts.data(), o.counts, (size_t)o.grid * 4, hipMemcpyDeviceToHost, st));
-  MHX_HIP(hipStreamSynchronize(st));
-  uint64_t n_edges = 0;
-  for (uint32_t v : h_counts) n_edges += v;
+  uint64_t n_edges = skm_edges;
+  if (!skm_done) {
+    std::vector<uint32_t> h_counts(o.grid);
+    MHX_HIP(hipMemcpyAsync(h_counts.data(), o.counts, (size_t)o.grid * 4, hipMemcpyDeviceToHost, st));
+    MHX_HIP(hipStreamSynchronize(st));
+    for (uint32_t v : h_counts) n_edges += v;
+  }
   const size_t eb_bytes = wpe == 3 ? 16 : 8;  // a region entry
   uint32_t *ea = c->ws("cs_edges_a", (n_edges + 1) * eb_bytes).as<uint32_t>(), *eb = c->ws("cs_edges_b", (n_edges + 1) * eb_bytes).as<uint32_t>();
   uint32_t *edges = c->result(MHX_BUF_EDGES, (n_edges ? n_edges : 1) * wpe * 4).as<uint32_t>();
@@ -1033,9 +1061,10 @@ static bool count_run_stream(mhx_ctx *c, uint32_t k, uint32_t m, mhx_count_resul
                hipLaunchKernelGGL(k_edge_buckets, dim3((unsigned)div_ceil(n_edges, 256)), dim3(256), 0, st, edges, n_edges, bcount, 3));
     MHX_HIP(hipGetLastError());
   } else if (n_edges) {
-    MHX_LAUNCH(c, "edges_compact", (double)n_edges * 16,
-               hipLaunchKernelGGL(k_edges_compact, dim3(o.grid, 4), dim3(256), 0, st, reinterpret_cast<const unsigned long long *>(o.spare), o.cap, o.counts,
-                                  reinterpret_cast<unsigned long long *>(ea)));
+    if (!skm_done)  // (the passes over super-k-mer records packed theirs already)
+      MHX_LAUNCH(c, "edges_compact", (double)n_edges * 16,
+                 hipLaunchKernelGGL(k_edges_compact, dim3(o.grid, 4), dim3(256), 0, st, reinterpret_cast<const unsigned long long *>(o.spare), o.cap, o.counts,
+                                    reinterpret_cast<unsigned long long *>(ea)));
     // uint64 (lo word first in memory) -> (hi, lo) word pairs = the edge's word order; sort by the (k+1)-mer bits
     hipLaunchKernelGGL(k_swap_pairs, dim3((unsigned)div_ceil(n_edges, 256)), dim3(256), 0, st, ea, n_edges);
     uint32_t *es = sort_whole_key(c, ea, eb, n_edges, 2, 2, make_passes(2, 64 - key_bits, 64));  // distinct keys: the count bits never decide

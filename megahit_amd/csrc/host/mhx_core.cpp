@@ -635,14 +635,37 @@ int main_kmer_count(int argc, char **argv) {
   mhxio::BinFile lib = load_read_lib(c, o.get("read_lib_file"));
   info("%llu reads; Preparing data... Done. Time elapsed: %.4f", (unsigned long long)mhx_num_sequences(c), t.lap());
   const size_t count_item_bytes = (size_t)(((2 * (k + 1) + 31) / 32 + 2 + 1) / 2 * 2) * 4;
-  const auto ranges = plan_ranges(c, MHX_STAGE_COUNT, k, m, count_item_bytes, (double)mhx_num_bases(c), 12.0 * (double)mhx_num_sequences(c));
+  // count on super-k-mer records plans its own passes (include/mhx.h: mhx_count_self_planned): asked first, unless the environment dictates
+  // a plan; a job it gives up on fails the call and the lv1 bucket plan takes over
+  std::vector<BucketRange> ranges;
+  bool self_planned = false;
+  const long long skm_before = mhx_get_option(c, "count_skm", 1);
+  if (!getenv("MHX_MAX_ITEMS") && !getenv("MHX_FREE_BYTES") && mhx_count_self_planned(c, k, m) == 1) {
+    self_planned = true;
+    mhx_set_option(c, "count_skm", 3);
+    ranges = {{0, MHX_NUM_BUCKETS, 0}};
+  } else {
+    ranges = plan_ranges(c, MHX_STAGE_COUNT, k, m, count_item_bytes, (double)mhx_num_bases(c), 12.0 * (double)mhx_num_sequences(c));
+  }
   mhx_count_result r{};
   std::vector<uint32_t> edges;
   std::vector<uint64_t> bcount(MHX_NUM_BUCKETS, 0);
   for (size_t i = 0; i < ranges.size(); ++i) {
     set_range(c, ranges, i, true);
     mhx_count_result pr;
-    CK(mhx_count(c, k, m, &pr));
+    if (self_planned) {
+      const bool ok = mhx_count(c, k, m, &pr) == 0;
+      mhx_set_option(c, "count_skm", ok ? skm_before : 0);
+      self_planned = false;
+      if (!ok) {  // (nothing taken yet: plan the lv1 bucket ranges and start over)
+        info("count on super-k-mer records: %s; planning lv1 bucket ranges instead", mhx_last_error());
+        ranges = plan_ranges(c, MHX_STAGE_COUNT, k, m, count_item_bytes, (double)mhx_num_bases(c), 12.0 * (double)mhx_num_sequences(c));
+        i = (size_t)-1;
+        continue;
+      }
+    } else {
+      CK(mhx_count(c, k, m, &pr));
+    }
     {  // this pass's solid edges straight behind the earlier passes' (no second host copy)
       const uint64_t eb = mhx_buffer_bytes(c, MHX_BUF_EDGES);
       const size_t at = edges.size();

@@ -314,7 +314,8 @@ struct CountStreamOut {
 bool count_stream_applies(const mhx_ctx *c, uint32_t k, uint32_t m);
 // `count` on super-k-mer records (s1_skm.hip): one GPU, 19 <= k <= 21, min count <= 2.  *touched: the caller's arrays may hold partial results
 bool count_skm_applies(const mhx_ctx *c, uint32_t k, uint32_t m);
-bool count_skm_groups(mhx_ctx *c, uint32_t k, uint32_t m, uint32_t *first_0_out, uint32_t *last_0_in_p1, unsigned long long *hist, CountStreamOut *o, bool *touched);
+bool count_skm_groups(mhx_ctx *c, uint32_t k, uint32_t m, uint32_t *first_0_out, uint32_t *last_0_in_p1, unsigned long long *hist, CountStreamOut *o, bool *touched,
+                      int pass, int n_passes);
 bool count_presort_applies(const mhx_ctx *c, uint32_t k, uint32_t m);
 uint32_t *count_presort(mhx_ctx *c, uint32_t k, uint64_t *n_items, uint32_t **other, int *pbits);
 int count_process_presorted(mhx_ctx *c, uint32_t k, uint32_t m, const S1Sources &src, mhx_count_result *out);  // count.hip; -1: gave up

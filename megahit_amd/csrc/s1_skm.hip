@@ -1343,19 +1343,20 @@ bool count_skm_applies(const mhx_ctx *c, uint32_t k, uint32_t m) {
   if (k < 19 || k > 21 || m < 1 || m > 2) return false;
   if (!s.n_seqs || s.max_len < k + 1 || (s.n_bases >> 36)) return false;
   if (!s.fixed_len && (double)s.n_bases * 100.0 < (double)c->opt("s1_var_min_fill", 50) * (double)s.n_seqs * s.max_len) return false;
-  if (s1_skm_passes(c, k) != 1) return false;
   const uint64_t n_win = s.n_bases > s.n_seqs * (uint64_t)k ? s.n_bases - s.n_seqs * (uint64_t)k : 0;
   return knob >= 2 || c->opt("s1_skm", 1) >= 2 || n_win >= (uint64_t)c->opt("s1_skm_min_windows", 1 << 22);
 }
 // -> false: gave up (record array, a bin of low-complexity reads, an edge region): the caller's arrays may hold partial results of this attempt
-bool count_skm_groups(mhx_ctx *c, uint32_t k, uint32_t m, uint32_t *first_0_out, uint32_t *last_0_in_p1, unsigned long long *hist, CountStreamOut *o, bool *touched) {
+// (pass of n_passes: a job whose record arrays would take more than s1_skm_pass_gb runs in passes over ranges of bins, as stage 1 does; the
+//  caller packs every pass's edge regions behind the earlier passes' edges and orders them once at the end)
+bool count_skm_groups(mhx_ctx *c, uint32_t k, uint32_t m, uint32_t *first_0_out, uint32_t *last_0_in_p1, unsigned long long *hist, CountStreamOut *o, bool *touched,
+                      int pass, int n_passes) {
   SeqSet &s = c->seqs;
   hipStream_t st = c->stream;
-  *touched = false;
   SkmFront f{};
   c->gen_first_pass = nullptr;
   c->pre_hist_buf = nullptr;
-  if (!s1_skm_front(c, k, &f, 0, 1, 0, true)) return false;
+  if (!s1_skm_front(c, k, &f, pass, n_passes, 0, true)) return false;
   const uint64_t cus = c->n_cus > 0 ? (uint64_t)c->n_cus : 256;
   const unsigned grid = (unsigned)std::min<uint64_t>(cus, std::max<uint64_t>(1, div_ceil((uint64_t)(f.bin_hi - f.bin_lo), (uint64_t)kSkmBatch)));
   const uint32_t region = (uint32_t)std::min<uint64_t>(f.spare_bytes / 8 / grid, 0xFFFFFFF0u);
@@ -1394,7 +1395,7 @@ bool count_skm_groups(mhx_ctx *c, uint32_t k, uint32_t m, uint32_t *first_0_out,
   o->counts = counts;
   o->spare = f.spare;
   o->sorted = nullptr;
-  o->n_items = f.n_items;
+  if (pass == 0) o->n_items = f.n_items;
   o->n_distinct = h_ctr[4];
   o->events = nullptr;
   o->n_events = 0;
@@ -1403,6 +1404,7 @@ bool count_skm_groups(mhx_ctx *c, uint32_t k, uint32_t m, uint32_t *first_0_out,
            (unsigned long long)f.n_records, (unsigned long long)f.n_windows, f.n_records ? (double)f.n_windows / (double)f.n_records : 0.0, f.max_bin,
            s.fixed_len ? "" : " [reads of several lengths]");
   o->plan = txt;
+  if (n_passes > 1) o->plan += " [" + std::to_string(n_passes) + " passes over ranges of bins]";
   return true;
 }
 

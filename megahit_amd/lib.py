@@ -154,6 +154,7 @@ SYMBOLS = {
     "mhx_reset": (C.c_int, [_P]),
     "mhx_last_s1_plan": (C.c_char_p, [_P]),
     "mhx_s1_self_planned": (C.c_int, [_P, C.c_uint32, C.c_uint32, C.c_int]),
+    "mhx_count_self_planned": (C.c_int, [_P, C.c_uint32, C.c_uint32]),
     "mhx_profile_enable": (C.c_int, [_P, C.c_int]),
     "mhx_profile_reset": (C.c_int, [_P]),
     "mhx_profile_get": (C.c_int, [_P, C.POINTER(KernelStat), C.c_int]),
@@ -400,6 +401,10 @@ class Engine:
     def s1_self_planned(self, k, min_count, want_mercy=False):
         """stage 1 would run on super-k-mer records and cut the job into passes by itself (mhx_s1_self_planned)"""
         return bool(self.lib.mhx_s1_self_planned(self.h, k, min_count, int(want_mercy)))
+
+    def count_self_planned(self, k, min_count):
+        """count would run on super-k-mer records and cut the job into passes by itself (mhx_count_self_planned)"""
+        return bool(self.lib.mhx_count_self_planned(self.h, k, min_count))
 
     def last_s1_plan(self):
         """what the last stage 1 of this handle ran as (mhx_last_s1_plan)"""

@@ -73,15 +73,19 @@ def test_configs2_on_one_gpu_and_as_eight_ranks(lib100):
     # round 6: the orchestrator's default k_min route at this size — `count` + `seq2sdbg --need_mercy` (main_sdbg_build.cpp:35-86,158-224;
     # KmerCounter through lv1 bucket ranges, base_engine.cpp:176-201) — against the reference's own answers, on one GPU and as eight ranks
     dr = out["default_route"]["runs"]
-    for label in ("one_gpu", "eight_ranks_on_one_device"):
+    for label in ("one_gpu", "one_gpu_prefix_plan", "eight_ranks_on_one_device"):
         assert dr[label]["count"]["bit_identical_to_reference"], dr[label]["count"]
         assert dr[label]["seq2sdbg_need_mercy"]["bit_identical_to_reference"], dr[label]["seq2sdbg_need_mercy"]
-    assert dr["one_gpu"]["count"]["memory_plan_passes"] >= 2, "count's memory plan did not fire"
-    assert any("count: stream" in l for l in dr["one_gpu"]["count"]["log_tail"]), dr["one_gpu"]["count"]["log_tail"]  # every pass on the stage-1 design
+    # count on super-k-mer records, in passes over ranges of its own bins ...
+    assert any("count: super-k-mers" in l and "passes over ranges of bins" in l for l in dr["one_gpu"]["count"]["log_tail"]), dr["one_gpu"]["count"]["log_tail"]
+    # ... and with MHX_COUNT_SKM=0 on the lv1 bucket ranges of the memory plan
+    assert dr["one_gpu_prefix_plan"]["count"]["memory_plan_passes"] >= 2, "count's memory plan did not fire"
+    assert any("count: stream" in l for l in dr["one_gpu_prefix_plan"]["count"]["log_tail"]), dr["one_gpu_prefix_plan"]["count"]["log_tail"]  # every pass on the stage-1 design
     assert any("pre-sorted exchange" in l for l in dr["eight_ranks_on_one_device"]["count"]["log_tail"]), dr["eight_ranks_on_one_device"]["count"]["log_tail"]
     # `count` at 100 M within 1.5 x the kernel time of read2sdbg's stage 1 (the judge's bar for this round)
     s1_ms = sum(v for n, v in one["kernel_ms"].items() if n in ("radix_scatter_12B_gen", "radix_scatter_12B", "s1_groups", "s1_digit_hist", "s1_bucket_hist"))
-    assert dr["one_gpu"]["count"]["kernel_ms_total"] <= 1.5 * s1_ms, (dr["one_gpu"]["count"]["kernel_ms_total"], s1_ms)
+    assert dr["one_gpu_prefix_plan"]["count"]["kernel_ms_total"] <= 1.5 * s1_ms, (dr["one_gpu_prefix_plan"]["count"]["kernel_ms_total"], s1_ms)
+    assert dr["one_gpu"]["count"]["kernel_ms_total"] <= dr["one_gpu_prefix_plan"]["count"]["kernel_ms_total"], dr["one_gpu"]["count"]["kernel_ms"]
 
 
 @skip

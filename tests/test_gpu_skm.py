@@ -307,3 +307,35 @@ def test_count_shapes_outside_the_path(engine, how):
         reads, opts = reads + repeat_reads(3000, [0]), dict(opts, s1_skm_max_bin=1024)
     low = how in ("repeats", "polyA")
     run_count(engine, reads, k, m, opts, want_plan="count: stream", want_kernels=("count_groups",) + (("count_skm_make",) if low else ()), absent=("count_skm_groups",))
+
+
+@pytest.mark.parametrize("kind,k,m,n_passes", [("pe100", 21, 2, 3), ("repeats100", 20, 2, 5), ("var", 21, 2, 2), ("short30", 19, 1, 4)])
+def test_count_in_passes_over_ranges_of_bins(engine, kind, k, m, n_passes):
+    """a job beyond s1_skm_pass_gb of records: every pass makes the records of its bins again, the passes' edges are packed behind each
+    other and ordered once; mhx_count_self_planned tells a caller that plans lv1 ranges to leave this one alone"""
+    reads = make_reads(kind, 5) if kind == "var" else fixed_library(kind, seed=k)
+    load(engine, ob.Package(reads, reverse=True))
+    engine.set_option("s1_skm", 2)
+    engine.set_option("s1_var_min_fill", 5)
+    try:
+        assert engine.count_self_planned(k, m) and not engine.count_self_planned(22, m) and not engine.count_self_planned(k, 3)
+    finally:
+        engine.set_option("s1_skm", 1)
+        engine.set_option("s1_var_min_fill", 50)
+    run_count(engine, reads, k, m, dict(s1_skm=2, s1_skm_max_bin=1 << 30, s1_skm_passes=n_passes, s1_var_min_fill=5, s1_skm_cap_pct=300))
+    assert "%d passes over ranges of bins" % n_passes in engine.last_s1_plan()
+
+
+def test_count_fails_for_a_caller_that_left_the_plan_to_it(engine):
+    reads = fixed_library("pe100", seed=11) + repeat_reads(3000, [0, 1])
+    load(engine, ob.Package(reads, reverse=True))
+    try:
+        engine.set_option("s1_skm", 2)
+        engine.set_option("count_skm", 3)
+        engine.set_option("s1_skm_max_bin", 1024)
+        with pytest.raises(lib.MhxError, match="super-k-mer records given up"):
+            engine.count(21, 2)
+    finally:
+        for n, v in dict(RESET, count_skm=1).items():
+            engine.set_option(n, v)
+    run_count(engine, reads, 21, 2, dict(count_skm=0), want_plan="count: stream", want_kernels=("count_groups",), absent=("count_skm_make",))

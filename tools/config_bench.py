@@ -177,7 +177,9 @@ def configs2(keep=None, emit=True):
         out["default_route"] = {"reference": {"count_wall_s": wc["wall_s"], "seq2sdbg_need_mercy_wall_s": wm["wall_s"], "threads": full["reference_threads"],
                                                "host": full["reference_host"] + " — NOT the GPU box's host: a same-host figure exists only at 10 M reads (bench.py cpu_baseline)"},
                                 "runs": {}}
-        for label, pre, env in (("one_gpu", [], {}),
+        # one_gpu: count on super-k-mer records in passes over ranges of its own bins (round 6); one_gpu_prefix_plan: MHX_COUNT_SKM=0 — the lv1
+        # bucket ranges of the memory plan, every pass on the bucket streaming
+        for label, pre, env in (("one_gpu", [], {}), ("one_gpu_prefix_plan", [], {"MHX_COUNT_SKM": "0"}),
                                 ("eight_ranks_on_one_device", ["--gpus", "8"], {"MHX_GPU_MAP": "0,0,0,0,0,0,0,0", "MHX_FREE_BYTES": "26e9"})):
             o = os.path.join(tmp, "o_" + label)
             ent = {}
