@@ -1001,7 +1001,8 @@ static bool count_run_stream(mhx_ctx *c, uint32_t k, uint32_t m, mhx_count_resul
   if (!pre && !acc && count_skm_applies(c, k, m)) {
     bool touched = false;
     const int n_passes = s1_skm_passes(c, k);
-    uint64_t n_dist = 0;
+    uint64_t n_dist = 0, skm_records = 0;
+    uint32_t skm_max_bin = 0;
     skm_done = true;
     for (int p = 0; p < n_passes && skm_done; ++p) {
       skm_done = count_skm_groups(c, k, m, first, last, hist, &o, &touched, p, n_passes);
@@ -1020,8 +1021,18 @@ static bool count_run_stream(mhx_ctx *c, uint32_t k, uint32_t m, mhx_count_resul
                                       dense + skm_edges));
       skm_edges += tot;
       n_dist += o.n_distinct;
+      skm_records += o.skm_records;
+      skm_max_bin = std::max(skm_max_bin, o.skm_max_bin);
     }
     o.n_distinct = n_dist;
+    if (skm_done) {
+      char txt[320];
+      snprintf(txt, sizeof txt, "super-k-mers m%u, 2^%d bins (%llu records for %llu windows: %.2f per record; largest bin %u)%s", k + 1 - 9, o.skm_bin_bits,
+               (unsigned long long)skm_records, (unsigned long long)o.skm_windows, skm_records ? (double)o.skm_windows / (double)skm_records : 0.0, skm_max_bin,
+               s.fixed_len ? "" : " [reads of several lengths]");
+      o.plan = txt;
+      if (n_passes > 1) o.plan += " [" + std::to_string(n_passes) + " passes over ranges of bins]";
+    }
     if (!skm_done) {
       // count_skm = 3: a caller that left the memory plan to this path (mhx_count_self_planned) hears that it did not serve
       if (c->opt("count_skm", 1) == 3) throw Error("count: super-k-mer records given up (low-complexity reads, or more records than the arrays hold)");

@@ -310,6 +310,10 @@ struct CountStreamOut {
   std::string plan;
   unsigned long long *events;  // several GPUs: position << 1 | kind, for the ranks that hold the reads (count.hip k_apply_count_events)
   uint64_t n_events;
+  // count on super-k-mer records: what a pass made (the caller sums the passes for the plan line)
+  uint64_t skm_records = 0, skm_windows = 0;
+  uint32_t skm_max_bin = 0;
+  int skm_bin_bits = 0;
 };
 bool count_stream_applies(const mhx_ctx *c, uint32_t k, uint32_t m);
 // `count` on super-k-mer records (s1_skm.hip): one GPU, 19 <= k <= 21, min count <= 2.  *touched: the caller's arrays may hold partial results

@@ -1399,12 +1399,10 @@ bool count_skm_groups(mhx_ctx *c, uint32_t k, uint32_t m, uint32_t *first_0_out,
   o->n_distinct = h_ctr[4];
   o->events = nullptr;
   o->n_events = 0;
-  char txt[256];
-  snprintf(txt, sizeof txt, "super-k-mers m%u, 2^%d bins (%llu records for %llu windows: %.2f per record; largest bin %u)%s", k + 1 - 9, f.bin_bits,
-           (unsigned long long)f.n_records, (unsigned long long)f.n_windows, f.n_records ? (double)f.n_windows / (double)f.n_records : 0.0, f.max_bin,
-           s.fixed_len ? "" : " [reads of several lengths]");
-  o->plan = txt;
-  if (n_passes > 1) o->plan += " [" + std::to_string(n_passes) + " passes over ranges of bins]";
+  o->skm_records = f.n_records;
+  o->skm_windows = f.n_windows;
+  o->skm_max_bin = f.max_bin;
+  o->skm_bin_bits = f.bin_bits;
   return true;
 }
 
