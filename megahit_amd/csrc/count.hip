@@ -1024,6 +1024,15 @@ static bool count_run_stream(mhx_ctx *c, uint32_t k, uint32_t m, mhx_count_resul
       skm_records += o.skm_records;
       skm_max_bin = std::max(skm_max_bin, o.skm_max_bin);
     }
+    if (skm_done && o.skm_hp) {  // the one or two keys of the homopolymer windows, behind the passes' edges
+      unsigned long long *dense = grow_preserving(c, c->work["cs_edges_a"], (skm_edges + 3) * 8, skm_edges * 8).as<unsigned long long>();
+      uint64_t ne = 0, nk = 0;
+      bool flagged = false;
+      count_skm_hp_publish(c, o.skm_hp, k, m, hist, dense + skm_edges, &ne, &nk, &flagged);
+      skm_edges += ne;
+      n_dist += nk;
+      if (flagged) skm_done = false;  // (a solid homopolymer key without an in- or out-edge: its windows would move first_0_out / last_0_in)
+    }
     o.n_distinct = n_dist;
     if (skm_done) {
       char txt[320];
@@ -1036,6 +1045,7 @@ static bool count_run_stream(mhx_ctx *c, uint32_t k, uint32_t m, mhx_count_resul
     if (!skm_done) {
       // count_skm = 3: a caller that left the memory plan to this path (mhx_count_self_planned) hears that it did not serve
       if (c->opt("count_skm", 1) == 3) throw Error("count: super-k-mer records given up (low-complexity reads, or more records than the arrays hold)");
+      skm_edges = 0;
       if (touched) {
         MHX_HIP(hipMemsetAsync(first, 0xFF, (ns ? ns : 1) * 4, st));
         MHX_HIP(hipMemsetAsync(last, 0x00, (ns ? ns : 1) * 4, st));

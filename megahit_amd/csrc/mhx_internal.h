@@ -311,6 +311,7 @@ struct CountStreamOut {
   unsigned long long *events;  // several GPUs: position << 1 | kind, for the ranks that hold the reads (count.hip k_apply_count_events)
   uint64_t n_events;
   // count on super-k-mer records: what a pass made (the caller sums the passes for the plan line)
+  const unsigned long long *skm_hp = nullptr;  // the homopolymer windows k_skm_make counted beside the records (nullptr: none)
   uint64_t skm_records = 0, skm_windows = 0;
   uint32_t skm_max_bin = 0;
   int skm_bin_bits = 0;
@@ -320,6 +321,8 @@ bool count_stream_applies(const mhx_ctx *c, uint32_t k, uint32_t m);
 bool count_skm_applies(const mhx_ctx *c, uint32_t k, uint32_t m);
 bool count_skm_groups(mhx_ctx *c, uint32_t k, uint32_t m, uint32_t *first_0_out, uint32_t *last_0_in_p1, unsigned long long *hist, CountStreamOut *o, bool *touched,
                       int pass, int n_passes);
+void count_skm_hp_publish(mhx_ctx *c, const unsigned long long *hp, uint32_t k, uint32_t m, unsigned long long *hist, unsigned long long *edges_at,
+                          uint64_t *n_edges, uint64_t *n_keys, bool *flagged);
 bool count_presort_applies(const mhx_ctx *c, uint32_t k, uint32_t m);
 uint32_t *count_presort(mhx_ctx *c, uint32_t k, uint64_t *n_items, uint32_t **other, int *pbits);
 int count_process_presorted(mhx_ctx *c, uint32_t k, uint32_t m, const S1Sources &src, mhx_count_result *out);  // count.hip; -1: gave up

@@ -1,22 +1,26 @@
-// read2sdbg stage 1 on super-k-mer records (round 6): the no-mercy reduction of Read2SdbgS1 (reference src/sorting/read_to_sdbg_s1.cpp:208-366
-// makes one sort item per (k-1)-mer window of every read, :368-464 counts the groups of equal items) needs the (k+1)-mers GROUPED, not
-// sorted: is_solid, the multiplicity histogram and the aggregated stage-2 items are functions of the multiset of canonical (k+1)-mers.
+// read2sdbg stage 1 — and `count` — on super-k-mer records (round 6).  The no-mercy reduction of Read2SdbgS1 (reference
+// src/sorting/read_to_sdbg_s1.cpp:208-366 makes one sort item per (k-1)-mer window of every read, :368-464 counts the groups of equal items)
+// needs the (k+1)-mers GROUPED, not sorted: is_solid, the multiplicity histogram and the aggregated stage-2 items are functions of the
+// multiset of canonical (k+1)-mers; the same holds for KmerCounter (src/sorting/kmer_counter.cpp:158-381), whose edges are ordered afterwards.
 // So the grouping key need not be a prefix of the k-mer.  Here it is the MINIMIZER of the (k+1)-mer — the smallest hash of a canonical
 // m-mer inside it — which consecutive windows of a read share: a run of windows with one minimizer (a "super-k-mer") leaves the read as
 // ONE 16-byte record (its bases, where it starts, how many windows it holds) instead of one 12-byte record per window.
 //   k_skm_make    one thread per aligned block of 8 windows: 17 canonical m-mer hashes from one 64-bit window of the store and its
 //                 reverse complement, the 8 window minima by a suffix / prefix scan, a record per run of equal bins (3.5 windows per
-//                 record at k = 21) -> the record array through one cursor (one atomic per workgroup and trip)
-//   radix_sort    two passes over the 16-bit bin (the chained-scan passes of sort.hip on 16-byte records)
+//                 record at k = 21) -> the record array through one cursor (one atomic per workgroup and trip); the digit histograms of the
+//                 sort passes on the way; windows of ONE base (poly-A, poly-G) counted beside the records; COUNT: a base more either side
+//   radix_sort    two passes over the 16-bit bin (the chained-scan passes of sort.hip on 16-byte records; a third beyond 2^16 bins)
 //   k_skm_bounds  where each bin starts
-//   k_s1_skm      one workgroup per bin at a time: the windows of its records are dealt to the lanes one by one (a wavefront's 64
-//                 records hold ~225 windows: every lane takes the g-th, finds its record through a bitmap of run heads and two shuffles),
-//                 canonical key (read_to_sdbg_s1.cpp:228-292: the strand of the (k-1)-mer, then head / tail), LDS table with 64-bit
-//                 keys, one walk over the table for the histogram (:430-436), the marks of the non-solid occurrences (:464, inverted:
-//                 a key of count 1 < m has one record, whose position sits next to the key) and the aggregated stage-2 items.
-// 5.9 GB of records at 10 M reads instead of 16: the two sort passes and the read of the group-by move 2.7 x fewer bytes.
-// Shapes: one GPU, no bucket filter, reads of one length, min count <= 2, 19 <= k <= 22, positions below 2^32; everything else — and
-// any bin that outgrows what one workgroup should stream (low-complexity reads) — takes the prefix plan (s1_stream.hip).
+//   k_s1_skm      one workgroup per bin at a time: the windows of a wavefront's 64 records (~225) are dealt to the lanes 64 at a time (a bitmap
+//                 of run heads, six shuffles per window), canonical key (read_to_sdbg_s1.cpp:228-292: the strand of the (k-1)-mer, then
+//                 head / tail), LDS table with 64-bit keys, one walk over the table for the histogram (:430-436), the marks of the
+//                 non-solid occurrences (:464, inverted: a key of count 1 < m has one record, whose position sits next to the key) and the
+//                 aggregated stage-2 items; several sources per bin (several GPUs: one per sending rank) and the marks as a list there
+//   k_count_skm   the same for `count`: in / out characters in the slot, packed edges out, the windows of flagged keys in a second expansion
+// 6.0 GB of records at 10 M reads instead of 16: the two sort passes and the read of the group-by move 2.7 x fewer bytes.
+// Shapes: no mercy, no lv1 bucket filter (the path cuts large jobs into passes over ranges of its OWN bins), reads of one length or of
+// several, min count <= 2, 19 <= k <= 22 (count: 21), positions below 2^36; everything else — and any input with a bin that outgrows what
+// one workgroup should stream (repeats other than homopolymers) — takes the prefix plan (s1_stream.hip).  DESIGN.md 4o.
 #include <cstring>
 
 #include "s1_shared.h"
@@ -59,7 +63,9 @@ __global__ __launch_bounds__(NT) void k_skm_make(const uint32_t *__restrict__ se
   __shared__ unsigned long long s_base;
   __shared__ uint32_t dh[3][256];  // the digit histograms of the sort passes, taken while the records are made
   __shared__ uint32_t lbin[J * kSkmC][NT];  // a thread's bins, read back by window number when its records leave (no register array indexed by a variable)
+  __shared__ uint32_t hpl[2][12];  // COUNT: the homopolymer windows of this workgroup per class: [0] windows, [1 + x] base x in front, [5 + x] base x behind
   const int tid = threadIdx.x;
+  if (tid < 24) hpl[tid / 12][tid % 12] = 0;
   for (int i = tid; i < 768; i += NT) dh[i >> 8][i & 255] = 0;
   __syncthreads();
   const bool third_digit = bin_bits > 16;
@@ -143,8 +149,20 @@ __global__ __launch_bounds__(NT) void k_skm_make(const uint32_t *__restrict__ se
                 if ((hm >> w) & 1u) {
                   const unsigned b = (unsigned)(W >> (62 - 2 * w)) & 3u;
                   const unsigned cls = b == 0 || b == 3 ? 0u : 1u;
-                  ++hp_n[cls];
-                  hp_p[cls] = min(hp_p[cls], pos_base + a + (uint64_t)w);
+                  if constexpr (COUNT) {
+                    // count: the key is A...A (C...C); a window of T (G) is its reverse complement (strand 1: the bases either side swap and complement)
+                    const bool strand = b >= 2;
+                    const unsigned prev_raw = q0 + w == 0 ? kSentinel
+                                              : (w == 0 ? (unsigned)((seq[(a - 1) >> 4] >> (30 - 2 * (unsigned)((a - 1) & 15))) & 3u) : (unsigned)(W >> (64 - 2 * w)) & 3u);
+                    const unsigned next_raw = q0 + w + 1 == nwin ? kSentinel : (unsigned)(W >> (62 - 2 * (w + K1))) & 3u;
+                    const unsigned pv = strand ? comp_or_sentinel(next_raw) : prev_raw, nx = strand ? comp_or_sentinel(prev_raw) : next_raw;
+                    atomicAdd(&hpl[cls][0], 1u);
+                    if (pv < 4) atomicAdd(&hpl[cls][1 + pv], 1u);
+                    if (nx < 4) atomicAdd(&hpl[cls][5 + nx], 1u);
+                  } else {
+                    ++hp_n[cls];
+                    hp_p[cls] = min(hp_p[cls], pos_base + a + (uint64_t)w);
+                  }
                 }
             }
           }
@@ -209,7 +227,11 @@ __global__ __launch_bounds__(NT) void k_skm_make(const uint32_t *__restrict__ se
     items = wave_sum(items);
     if ((tid & (kWave - 1)) == 0 && items) atomicAdd(cursor + 3, items);
   }
-  if (hp && count_items) {
+  if constexpr (COUNT) {
+    __syncthreads();
+    if (hp && count_items && tid < 24 && hpl[tid / 12][tid % 12]) atomicAdd(hp + 8 + (tid / 12) * 16 + (tid % 12), (unsigned long long)hpl[tid / 12][tid % 12]);
+  }
+  if (!COUNT && hp && count_items) {
 #pragma unroll
     for (int x = 0; x < 2; ++x) {
       const uint32_t n_w = wave_sum(hp_n[x]);
@@ -773,6 +795,36 @@ __global__ __launch_bounds__(kSkmThreads) void k_s1_skm(SkmSrcs srcs, SkmArgs a,
   if (marks_out && tid == 0) a.marks_counts[blockIdx.x] = s_mark_cur < a.marks_cap ? s_mark_cur : a.marks_cap;
 }
 
+// count: the one or two keys the homopolymer windows are -> histogram, the packed edge of a solid one behind the passes' edges.  A solid one
+// WITHOUT an in- or out-edge would have to move first_0_out / last_0_in of every read that holds such a window: res[2] says so and the
+// caller takes the prefix plan (poly-A / poly-G stretches are preceded and followed by their own base: not seen in practice)
+__global__ void k_count_hp_publish(const unsigned long long *__restrict__ hp, int k, uint32_t m, unsigned long long *__restrict__ hist,
+                                   unsigned long long *__restrict__ edges_at, unsigned long long *__restrict__ res) {
+  if (threadIdx.x || blockIdx.x) return;
+  unsigned long long n_edges = 0, n_keys = 0, flagged = 0;
+  for (int x = 0; x < 2; ++x) {
+    const unsigned long long *t = hp + 8 + x * 16;
+    const unsigned long long cnt = t[0];
+    if (!cnt) continue;
+    ++n_keys;
+    const unsigned long long hb = cnt > MHX_MAX_MUL ? (unsigned long long)MHX_MAX_MUL : cnt;
+    hist[hb] += 1;
+    if (cnt >= m) {
+      bool has_in = false, has_out = false;
+      for (int c = 0; c < 4; ++c) {
+        has_in = has_in || t[1 + c] >= m;
+        has_out = has_out || t[5 + c] >= m;
+      }
+      if (!has_in || !has_out) flagged = 1;
+      const uint64_t key = (x == 0 ? 0ull : 0x5555555555555555ull) & (~0ull << (64 - 2 * (k + 1)));
+      edges_at[n_edges++] = key | hb;  // PackEdge, kmer_counter.cpp:32-52
+    }
+  }
+  res[0] = n_edges;
+  res[1] = n_keys;
+  res[2] = flagged;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // `count` on super-k-mer records (KmerCounter::Lv2Postprocess, kmer_counter.cpp:254-381, on the records k_skm_make<.., COUNT> makes): the
 // table key is the canonical (k+1)-mer (the smaller of the window and its reverse complement, :179), the slot's third word holds, per base
@@ -1224,11 +1276,12 @@ bool s1_skm_front(mhx_ctx *c, uint32_t k, SkmFront *f, int pass, int n_passes, i
   const uint32_t bin_lo = (uint32_t)((uint64_t)n_bins * pass / n_passes), bin_hi = (uint32_t)((uint64_t)n_bins * (pass + 1) / n_passes);
   // homopolymer windows are counted beside the records on one GPU (several GPUs: they stay in the records; a job with many gives the path up)
   unsigned long long *hp = nullptr;
-  if (!c->global_bases && !for_count && c->opt("s1_skm_hp", 1)) {
-    hp = c->ws("skm_hp", 64).as<unsigned long long>();
+  if (!c->global_bases && c->opt("s1_skm_hp", 1)) {
+    hp = c->ws("skm_hp", 512).as<unsigned long long>();  // [0..3] stage 1: windows per class, a position each; [8 + 16 class + ..] count: windows, bases in front, bases behind
     if (pass == 0) {
-      const unsigned long long init[4] = {0ull, 0ull, ~0ull, ~0ull};
-      MHX_HIP(hipMemcpyAsync(hp, init, 32, hipMemcpyHostToDevice, st));
+      unsigned long long init[48] = {0};
+      init[2] = init[3] = ~0ull;
+      MHX_HIP(hipMemcpyAsync(hp, init, sizeof init, hipMemcpyHostToDevice, st));
       MHX_HIP(hipStreamSynchronize(st));  // (init is a stack variable)
     }
   }
@@ -1399,11 +1452,25 @@ bool count_skm_groups(mhx_ctx *c, uint32_t k, uint32_t m, uint32_t *first_0_out,
   o->n_distinct = h_ctr[4];
   o->events = nullptr;
   o->n_events = 0;
+  o->skm_hp = f.hp;
   o->skm_records = f.n_records;
   o->skm_windows = f.n_windows;
   o->skm_max_bin = f.max_bin;
   o->skm_bin_bits = f.bin_bits;
   return true;
+}
+
+// count: the homopolymer keys -> histogram, edges behind `edges_at`.  -> edges appended, keys, and whether a solid one lacks an in- or out-edge
+void count_skm_hp_publish(mhx_ctx *c, const unsigned long long *hp, uint32_t k, uint32_t m, unsigned long long *hist, unsigned long long *edges_at,
+                          uint64_t *n_edges, uint64_t *n_keys, bool *flagged) {
+  unsigned long long *res = c->ws("skm_hp_res", 64).as<unsigned long long>();
+  hipLaunchKernelGGL(k_count_hp_publish, dim3(1), dim3(64), 0, c->stream, hp, (int)k, m, hist, edges_at, res);
+  unsigned long long h[3] = {0, 0, 0};
+  MHX_HIP(hipMemcpyAsync(h, res, 24, hipMemcpyDeviceToHost, c->stream));
+  MHX_HIP(hipStreamSynchronize(c->stream));
+  *n_edges = h[0];
+  *n_keys = h[1];
+  *flagged = h[2] != 0;
 }
 
 // the homopolymer keys counted by k_skm_make -> histogram, mark or aggregated items (after the last pass of the group-by)

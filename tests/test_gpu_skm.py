@@ -289,10 +289,44 @@ def test_count_of_reads_of_several_lengths(engine, kind, k, m):
     run_count(engine, make_reads(kind, 17), k, m, dict(s1_skm=2, s1_skm_max_bin=1 << 30, s1_var_min_fill=5, s1_skm_cap_pct=300))
 
 
-@pytest.mark.parametrize("how", ["k22", "m3", "off", "repeats", "polyA"])
+@pytest.mark.parametrize("case", ["polyA+polyG", "one window", "m1", "var", "passes", "two windows", "read ends"])
+def test_count_homopolymer_windows_beside_the_records(engine, case):
+    """count: the windows of one base are tallied per class with the bases in front of and behind them (k_skm_make<.., COUNT>), and
+    k_count_hp_publish makes the one or two keys they are: histogram entry, packed edge of a solid one (its in- and out-edges are its own
+    base).  With s1_skm_hp = 0 the same library gives the path up"""
+    k, m, opts = 21, 2, dict(s1_skm=2, s1_skm_max_bin=1024)
+    reads = fixed_library("pe100", seed=17)
+    if case in ("polyA+polyG", "m1", "passes"):
+        reads = reads + repeat_reads(3000, [0]) + repeat_reads(700, [2]) + repeat_reads(200, [3]) + repeat_reads(90, [1])
+    if case == "m1":
+        m = 1
+    if case == "passes":
+        opts["s1_skm_passes"] = 3
+    if case in ("one window", "two windows"):
+        rng = np.random.default_rng(4)
+        r = rng.integers(0, 4, size=100, dtype=np.uint8)
+        n_c = k + 1 if case == "one window" else k + 2
+        r[30:30 + n_c] = 1
+        r[29], r[30 + n_c] = 0, 3
+        reads = reads + [r]
+    if case == "read ends":  # reads that ARE one base from end to end, and one that ends in k + 3 of them: '$' in front of / behind some windows
+        rng = np.random.default_rng(6)
+        r = rng.integers(0, 4, size=100, dtype=np.uint8)
+        r[100 - (k + 3):] = 2
+        r[100 - (k + 4)] = 0
+        reads = reads + repeat_reads(40, [2]) + [r]
+    if case == "var":
+        reads = make_reads("var", 21) + repeat_reads(500, [3], length=77) + repeat_reads(300, [1], length=33)
+        opts["s1_var_min_fill"] = 5
+        opts["s1_skm_cap_pct"] = 300
+    run_count(engine, reads, k, m, opts)
+    if case == "polyA+polyG":
+        run_count(engine, reads, k, m, dict(opts, s1_skm_hp=0), want_plan="count: stream", want_kernels=("count_skm_make", "count_groups"), absent=("count_skm_groups",))
+
+
+@pytest.mark.parametrize("how", ["k22", "m3", "off", "repeats"])
 def test_count_shapes_outside_the_path(engine, how):
-    """k = 22 (no room for the two flanking bases), min count 3, the knob, and low-complexity reads — poly-A too: `count` keeps the one-base
-    windows in its records (their in / out characters matter) — take the prefix plan"""
+    """k = 22 (no room for the two flanking bases), min count 3, the knob, and reads of a two-base repeat take the prefix plan"""
     k, m, opts = 21, 2, dict(s1_skm=2)
     reads = fixed_library("pe100", seed=5)
     if how == "k22":
@@ -303,9 +337,7 @@ def test_count_shapes_outside_the_path(engine, how):
         opts["count_skm"] = 0
     if how == "repeats":
         reads, opts = reads + repeat_reads(3000, [0, 1]), dict(opts, s1_skm_max_bin=1024)
-    if how == "polyA":
-        reads, opts = reads + repeat_reads(3000, [0]), dict(opts, s1_skm_max_bin=1024)
-    low = how in ("repeats", "polyA")
+    low = how == "repeats"
     run_count(engine, reads, k, m, opts, want_plan="count: stream", want_kernels=("count_groups",) + (("count_skm_make",) if low else ()), absent=("count_skm_groups",))
 
 
