@@ -145,8 +145,8 @@ int mhx_set_option(mhx_ctx *, const char *name, long long value);
  *                          record instead of the wavefront's windows being dealt to the lanes (measured 7 % slower); s1_skm_hp (1) 0: the
  *                          windows of one base (poly-A, poly-G) stay in the records instead of being counted beside them (one GPU)
  *   count_skm (1)          `count` on super-k-mer records (k_skm_make<.., COUNT>, k_count_skm: a record carries one more base either side of its run,
- *                          the table the in / out characters): one GPU, 19 <= k <= 21, min count <= 2, no memory plan (a job of more than
- *                          s1_skm_pass_gb of records takes the prefix plan and its lv1 passes), no homopolymer side path; 0: never;
+ *                          the table the in / out characters): one GPU, 19 <= k <= 21, min count <= 2; jobs of more than s1_skm_pass_gb of
+ *                          records in passes over ranges of bins (mhx_count_self_planned); 0: never; 3: fail instead of falling back;
  *                          count_skm_group (2): chunks of 64 windows per round of compare-and-swaps (4 spills registers: measured slower)
  *   dist_skm (1)           several GPUs: 0: stage 1 never exchanges super-k-mer records by bin (comm.hip dist_s1_skm; the pre-sorted exchange
  *                          of 12-byte records runs); 1: where every rank serves the shape (as s1_skm, at most 8 ranks, no memory plan)
