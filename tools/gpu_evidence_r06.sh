@@ -40,7 +40,7 @@ timeout 600 python tools/varlen_bench.py > $O/${TAG}_varlen.json 2> $O/${TAG}_va
 timeout 300 python tools/ab_options.py "s1_skm=0" "s1_skm=1" "s1_skm=1 s1_skm_deal=0" --rounds 2 > $O/${TAG}_ab_skm.jsonl 2> $O/${TAG}_ab_skm.err; echo "ab skm rc=$?"
 MHX_S1_SKM=0 timeout 600 python tools/lowcomplexity_probe.py > $O/${TAG}_lowcomplexity_prefix.json 2> $O/${TAG}_lowcomplexity_prefix.err; echo "lowcomplexity prefix rc=$?"
 timeout 300 python tools/ab_options.py "s1_skm=0 sort_loaded_ut2=0" "s1_skm=0 sort_loaded_ut2=1" --rounds 2 > $O/${TAG}_ab_loaded_ut2.jsonl 2> $O/${TAG}_ab_loaded_ut2.err; echo "ab ut2 rc=$?"
-timeout 300 python tools/ab_options.py "count_skm=0 count_stream=0" "count_skm=0" "count_skm=1" --engine count --rounds 2 > $O/${TAG}_ab_count_stream.jsonl 2> $O/${TAG}_ab_count_stream.err; echo "ab count rc=$?"
+timeout 300 python tools/ab_options.py "count_skm=0 count_stream=0" "count_skm=0 count_stream=1" "count_skm=1 count_stream=1" --engine count --rounds 2 > $O/${TAG}_ab_count_stream.jsonl 2> $O/${TAG}_ab_count_stream.err; echo "ab count rc=$?"
 timeout 120 python tools/probe_sort_widths.py 5e8 > $O/${TAG}_sort_widths.json 2> $O/${TAG}_sort_widths.err; echo "sort widths rc=$?"
 timeout 300 tools/micro/alloc_probe 200 > $O/${TAG}_alloc_probe.jsonl 2>&1; echo "alloc probe rc=$?"
 timeout 300 python tools/mercy_prof.py 10e6 > $O/${TAG}_mercy_stage1.json 2> $O/${TAG}_mercy_stage1.err
