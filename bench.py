@@ -93,7 +93,8 @@ def pmc_traffic(kernel_name, path=None):
              "s1_extract": ("k_s1_extract_fast<", "k_s1_extract_fixed<", "k_s1_extract<"), "s1_digit_hist": ("k_s1_digit_hist", "k_s1_extract_fast<4, false"),
              "count_extract": ("k_count_extract<",),
              "radix_scatter_12B_gen": ("k_radix_onesweep_u<3, 8, 3, S1Gen", "k_radix_onesweep<3, 8, 3, S1Gen"),
-             "s1_sample": ("k_s1_stream<false",), "s1_skm_groups": ("k_s1_skm<",), "s1_skm_make": ("k_skm_make<",), "s1_skm_bounds": ("k_skm_bounds",)}
+             "s1_sample": ("k_s1_stream<false",), "s1_skm_groups": ("k_s1_skm<",), "s1_skm_make": ("k_skm_make<",), "s1_skm_bounds": ("k_skm_bounds",),
+             "count_skm_groups": ("k_count_skm<",), "count_skm_make": ("k_skm_make<",)}
     prefixes = list(table.get(kernel_name, ()))
     for stem, names in (("radix_scatter_", ("k_radix_onesweep", "k_radix_scatter")), ("radix_hist_all_", ("k_radix_hist_all",)),
                         ("radix_hist_", ("k_radix_hist",))):
@@ -551,7 +552,7 @@ def main():
                 # spends its time on LDS compare-and-swaps and the vector instructions that form the keys (profiles/rNN_pmc_sq.json)
                 "note": ("dominant kernel is the LDS group-by of stage 1 on super-k-mer records: bound by LDS atomics and vector issue, not by HBM — its "
                          "fraction of the HBM peak says how few bytes it needs, not how well it runs; the HBM-bound kernels of the step are the sort passes "
-                         "(top_kernels)") if name == "s1_skm_groups" else None,
+                         "(top_kernels)") if name in ("s1_skm_groups", "count_skm_groups") else None,
                 "kernel_ms_per_step": {k2: round(v["ms"] / args.steps, 3) for k2, v in sorted(stats.items(), key=lambda kv: -kv[1]["ms"])},
                 # the same figure for the three kernels with the largest time per step (they are within a few per cent of each
                 # other, and which of them leads changes from box to box): algorithmic GB/s of one launch and its fraction of the peak
