@@ -122,3 +122,39 @@ def test_memory_plan_by_time(prog, tmp_path):
         assert canon.digest_edges(out) == ent["edges"] and canon.digest_file(out + ".cand") == ent["cand"] and canon.digest_file(out + ".counting") == ent["counting"]
     else:
         assert canon.digest_sdbg(out) == ent["sdbg"]
+
+
+SKM_CASES = [e for e in gu.cases() if e["case"]["prog"] in ("count", "read2sdbg") and e["case"]["k"] == 21 and e["case"]["m"] == 2 and not e["case"].get("mercy")]
+
+
+@pytest.mark.parametrize("mode", ["in path", "given up"])
+@pytest.mark.parametrize("ent", SKM_CASES, ids=gu.case_id)
+def test_cli_leaves_the_plan_to_the_super_kmer_path(ent, mode, tmp_path, monkeypatch):
+    """round 6: `mhx_core read2sdbg` / `count` ask mhx_s1_self_planned / mhx_count_self_planned before they plan lv1 bucket ranges, run the
+    stage once without a filter with s1_skm / count_skm = 3, and — "given up": every bin of more than a few records counts as giant —
+    plan lv1 ranges after the call failed.  Same files as the reference's either way (the golden libraries: r3 fixed length, hc with
+    low-complexity reads, rag with reads of every length)."""
+    import subprocess
+    from megahit_amd import canon
+    c = ent["case"]
+    for name, v in (("MHX_S1_SKM", "2"), ("MHX_S1_VAR_MIN_FILL", "5"), ("MHX_S1_SKM_CAP_PCT", "400"), ("MHX_S1_SKM_MAX_BIN", str(1 << 30) if mode == "in path" else "1")):
+        monkeypatch.setenv(name, v)
+    out = str(tmp_path / "out")
+    args = [c["prog"], "-k", str(c["k"]), "-m", str(c["m"]), "--read_lib_file", os.path.join(gu.GOLD, c["lib"]), "--output_prefix", out, "--host_mem", "2e9",
+            "--num_cpu_threads", "3"]
+    p = subprocess.run([gu.MHX_CORE] + args, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True)
+    assert p.returncode == 0, p.stderr[-2000:]
+    if mode == "in path":
+        assert "super-k-mers" in p.stderr and "planning lv1 bucket ranges instead" not in p.stderr, p.stderr[-1500:]
+    else:
+        assert "planning lv1 bucket ranges instead" in p.stderr, p.stderr[-1500:]
+    got = {}
+    if c["prog"] == "count":
+        got = {"edges": canon.digest_edges(out), "cand": canon.digest_file(out + ".cand"), "counting": canon.digest_file(out + ".counting"),
+               "n_edges": int(canon.canonical_edges(out)[1].shape[0])}
+    else:
+        got = {"sdbg": canon.digest_sdbg(out), "n_sdbg": int(sum(b[1] for b in canon.canonical_sdbg(out)[1])), "counting": canon.digest_file(out + ".counting")}
+    for key, want in ent.items():
+        if key in ("case", "mercy_cand_kmsort"):
+            continue
+        assert got.get(key) == want, key
