@@ -374,3 +374,13 @@ def test_count_fails_for_a_caller_that_left_the_plan_to_it(engine):
         for n, v in dict(RESET, count_skm=1).items():
             engine.set_option(n, v)
     run_count(engine, reads, 21, 2, dict(count_skm=0), want_plan="count: stream", want_kernels=("count_groups",), absent=("count_skm_make",))
+
+
+@pytest.mark.parametrize("what", ["stage 1", "count"])
+def test_a_library_of_homopolymer_reads_only(engine, what):
+    """every window is counted beside the records: not one record is made, ordered or grouped"""
+    reads = repeat_reads(300, [0]) + repeat_reads(120, [3]) + repeat_reads(50, [2], length=64)
+    if what == "stage 1":
+        run(engine, reads, 21, 2, dict(s1_skm=2, s1_var_min_fill=5))
+    else:
+        run_count(engine, reads, 21, 2, dict(s1_skm=2, s1_var_min_fill=5))
