@@ -117,6 +117,12 @@ int mhx_set_option(mhx_ctx *, const char *name, long long value);
  *                          records staged either side of a tile / per tile (tests, tuning)
  *   edges_reserve_permille (1000)  room behind the edges mhx_load_edges uploads, for mercy edges (the CLI: 1250, or what
  *                          MEGAHIT_NUM_MERCY_FACTOR says: seq_to_sdbg.cpp:370-378)
+ * Older knobs kept for A/Bs and tests (every one only chooses between code paths with identical results):
+ *   s1_bucket_hist_fast (1)   0: the lv1 histogram of a memory plan extracts items instead of scanning the packed reads
+ *   s1_digit_hist_blocked (1), s1_digit_hist_plain (1)   0: the digit-histogram pre-pass of the generating sort pass in its round-3 forms
+ *   s1_gen_any_order (1)      0: the generating first sort pass ranks with ballots (a stable order) instead of LDS atomics
+ *   s1_pack_fixed (1)         0: the byte map of the marks becomes the bitmap through the general kernel also for reads of one length
+ *   sort_hybrid_margin_ps (6) picoseconds per record the prefix-passes + segment-finish plan has to win by in sort_whole_key's cost model
  * Round 6:
  *   count_stream (1)       now also: pass by pass under a bucket filter (memory plan; the filter sits inside the histogram pre-pass and the
  *                          generating sort pass), on several GPUs (pre-sorted exchange, the first_0_out / last_0_in events routed to the
